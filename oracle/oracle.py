@@ -1,0 +1,162 @@
+"""ctypes loader for the CPU oracle (oracle/trex_oracle.c).
+
+TEST INFRASTRUCTURE ONLY: importable from tests/, __graft_entry__.smoke() and the
+cpu_baseline leg of bench.py.  The product package (trex_amd/) never imports this.
+"""
+import ctypes as C
+import os
+import subprocess
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+RUN_DTYPE = np.dtype([("x0", "<u2"), ("x1", "<u2"), ("y", "<u2"), ("pad", "<u2")])
+BLOB_DTYPE = np.dtype([
+    ("run_begin", "<u4"), ("n_runs", "<u4"), ("pix_begin", "<u4"), ("n_pixels", "<u4"),
+    ("x0", "<u2"), ("y0", "<u2"), ("x1", "<u2"), ("y1", "<u2"),
+    ("bid", "<u4"), ("px_min_max", "<u4"),
+    ("m10", "<u8"), ("m01", "<u8"), ("m20", "<u8"), ("m11", "<u8"), ("m02", "<u8"),
+    ("sp", "<u8"), ("spx", "<u8"), ("spy", "<u8"),
+])
+assert BLOB_DTYPE.itemsize == 96 and RUN_DTYPE.itemsize == 8
+
+
+class Params(C.Structure):
+    _fields_ = [
+        ("width", C.c_int32), ("height", C.c_int32),
+        ("threshold", C.c_int32), ("threshold_maximum", C.c_int32),
+        ("enable_difference", C.c_int32), ("absolute_difference", C.c_int32),
+        ("image_invert", C.c_int32), ("inclusive", C.c_int32),
+        ("zero_is_background", C.c_int32), ("connectivity", C.c_int32),
+        ("dilation_size", C.c_int32), ("use_closing", C.c_int32), ("closing_size", C.c_int32),
+        ("n_ranges", C.c_int32),
+        ("cm_per_pixel", C.c_double),
+        ("ranges", C.c_double * 16),
+    ]
+
+
+def make_params(width, height, threshold=15, threshold_maximum=255, enable_difference=1,
+                absolute_difference=1, image_invert=0, inclusive=0, zero_is_background=1,
+                connectivity=8, dilation_size=0, use_closing=0, closing_size=3,
+                cm_per_pixel=1.0, size_ranges=()):
+    """Defaults = the reference's defaults (SURVEY.md section 5 settings table)."""
+    p = Params()
+    p.width, p.height = width, height
+    p.threshold, p.threshold_maximum = threshold, threshold_maximum
+    p.enable_difference, p.absolute_difference = enable_difference, absolute_difference
+    p.image_invert, p.inclusive = image_invert, inclusive
+    p.zero_is_background, p.connectivity = zero_is_background, connectivity
+    p.dilation_size, p.use_closing, p.closing_size = dilation_size, use_closing, closing_size
+    p.cm_per_pixel = cm_per_pixel
+    p.n_ranges = len(size_ranges)
+    for i, (a, b) in enumerate(size_ranges):
+        p.ranges[2 * i], p.ranges[2 * i + 1] = a, b
+    return p
+
+
+def build(force=False):
+    so = os.path.join(_HERE, "liboracle.so")
+    src = [os.path.join(_HERE, f) for f in ("trex_oracle.c", "trex_oracle.h")]
+    if force or not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in src if os.path.exists(s)):
+        subprocess.check_call(["make", "-C", _HERE, "-s", "-B"])
+    return so
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        so = os.path.join(_HERE, "liboracle.so")
+        if not os.path.exists(so):
+            build()
+        L = C.CDLL(so)
+        u8p = C.POINTER(C.c_uint8)
+        L.oracle_segment.restype = C.c_void_p
+        L.oracle_segment.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(Params)]
+        L.oracle_frame_counts.argtypes = [C.c_void_p] + [C.POINTER(C.c_int32)] * 3
+        L.oracle_frame_copy.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.oracle_frame_free.argtypes = [C.c_void_p]
+        L.oracle_generate_binary.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(Params)]
+        L.oracle_segment_batch.restype = C.c_int64
+        L.oracle_segment_batch.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.POINTER(Params), C.c_int32]
+        L.oracle_line_without_grid.restype = C.c_int32
+        L.oracle_line_without_grid.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32,
+                                               C.c_int32, C.c_int32, C.c_void_p, C.c_void_p,
+                                               C.POINTER(C.c_int32)]
+        L.oracle_threshold_blob.restype = C.c_void_p
+        L.oracle_threshold_blob.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32,
+                                            C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32]
+        L.oracle_bid.restype = C.c_uint32
+        L.oracle_bid.argtypes = [C.c_uint32] * 4
+        del u8p
+        _LIB = L
+    return _LIB
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def _take_frame(h):
+    L = lib()
+    nb, nr, npx = C.c_int32(), C.c_int32(), C.c_int32()
+    L.oracle_frame_counts(h, C.byref(nb), C.byref(nr), C.byref(npx))
+    blobs = np.zeros(nb.value, BLOB_DTYPE)
+    runs = np.zeros(nr.value, RUN_DTYPE)
+    pixels = np.zeros(npx.value, np.uint8)
+    L.oracle_frame_copy(h, _ptr(blobs), _ptr(runs), _ptr(pixels))
+    L.oracle_frame_free(h)
+    return blobs, runs, pixels
+
+
+def segment(frame, bg, params):
+    """One gray frame through the detect stage -> (blobs, runs, pixels) numpy arrays."""
+    frame = np.ascontiguousarray(frame, np.uint8)
+    bg = np.ascontiguousarray(bg, np.uint8)
+    assert frame.shape == (params.height, params.width) == bg.shape
+    h = lib().oracle_segment(_ptr(frame), _ptr(bg), C.byref(params))
+    return _take_frame(h)
+
+
+def generate_binary(frame, bg, params):
+    frame = np.ascontiguousarray(frame, np.uint8)
+    bg = np.ascontiguousarray(bg, np.uint8)
+    out = np.empty_like(frame)
+    lib().oracle_generate_binary(_ptr(frame), _ptr(bg), _ptr(out), C.byref(params))
+    return out
+
+
+def segment_batch(frames, bg, params, threads):
+    frames = np.ascontiguousarray(frames, np.uint8)
+    bg = np.ascontiguousarray(bg, np.uint8)
+    return lib().oracle_segment_batch(_ptr(frames), frames.shape[0], _ptr(bg), C.byref(params), threads)
+
+
+def line_without_grid(runs, pixels, bg, method, threshold):
+    """method: 0 absolute, 1 sign, 2 none.  bg: 2-D uint8 image or None."""
+    runs = np.ascontiguousarray(runs, RUN_DTYPE)
+    pixels = np.ascontiguousarray(pixels, np.uint8)
+    out_runs = np.zeros(max(len(pixels), 1), RUN_DTYPE)
+    out_px = np.zeros(max(len(pixels), 1), np.uint8)
+    n_px = C.c_int32()
+    if bg is not None:
+        bg = np.ascontiguousarray(bg, np.uint8)
+        bgp, stride = _ptr(bg), bg.shape[1]
+    else:
+        bgp, stride = None, 0
+    n = lib().oracle_line_without_grid(_ptr(runs), len(runs), _ptr(pixels), bgp, stride, method, threshold,
+                                       _ptr(out_runs), _ptr(out_px), C.byref(n_px))
+    return out_runs[:n].copy(), out_px[:n_px.value].copy()
+
+
+def threshold_blob(runs, pixels, bg, method, threshold, connectivity=8):
+    runs = np.ascontiguousarray(runs, RUN_DTYPE)
+    pixels = np.ascontiguousarray(pixels, np.uint8)
+    bg = np.ascontiguousarray(bg, np.uint8)
+    h = lib().oracle_threshold_blob(_ptr(runs), len(runs), _ptr(pixels), _ptr(bg), bg.shape[1],
+                                    bg.shape[1], bg.shape[0], method, threshold, connectivity)
+    return _take_frame(h)
+
+
+def bid(x0, x1, y, n):
+    return int(lib().oracle_bid(x0, x1, y, n))
