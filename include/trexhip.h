@@ -1,0 +1,148 @@
+/*
+ * trexhip.h -- C ABI of libtrexhip: the MI355X (gfx950) implementation of TRex's per-frame
+ * detection + identity hot path.  extern "C", plain pointers and sizes only.
+ *
+ * Each entry point names the reference interface (file:line under /root/reference) whose work
+ * it replaces; INTEGRATION.md shows the binding a TRex maintainer adds on the C++ side.
+ *
+ * Conventions
+ *   - every function returns 0 on success or a negative TREXHIP_E_* code; the message is kept
+ *     per thread and read with trexhip_last_error().  No exception crosses this ABI.
+ *   - one ctx per (host thread, device); calls on one ctx are not re-entrant.
+ *   - "_device" variants take device pointers (HBM-resident data) and only enqueue work on the
+ *     ctx stream; the plain variants take host pointers and include the PCIe copies.
+ *   - all result pointers handed out stay owned by the ctx and are valid until the next call
+ *     of the same function on that ctx.
+ */
+#ifndef TREXHIP_H
+#define TREXHIP_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TREXHIP_ABI_VERSION 1
+
+enum {
+    TREXHIP_OK = 0,
+    TREXHIP_E_INVALID = -1,    /* bad argument / not initialised (e.g. no background yet)   */
+    TREXHIP_E_DEVICE = -2,     /* HIP runtime error                                         */
+    TREXHIP_E_CAPACITY = -3,   /* a frame exceeded max_runs / pooled output capacity         */
+    TREXHIP_E_UNSUPPORTED = -4,
+    TREXHIP_E_NOMEM = -5
+};
+
+/* per-frame status bits in trexhip_frame_info.flags */
+#define TREXHIP_FRAME_OVERFLOW_RUNS   1u
+#define TREXHIP_FRAME_OVERFLOW_OUTPUT 2u
+
+/* Settings the hot path reads (names = TRex setting names). */
+typedef struct trexhip_params {
+    int32_t device;              /* HIP device ordinal                                         */
+    int32_t width, height;       /* frame size in pixels, < 65535 (pv.cpp:601-602)             */
+    int32_t max_batch;           /* frames per segment call                                    */
+    int32_t max_runs;            /* capacity: raw horizontal lines per frame                   */
+    int32_t max_blobs;           /* capacity: kept blobs per frame (pool = max_batch * this)   */
+    int32_t max_pixels;          /* capacity: kept foreground pixels per frame (pooled)        */
+    /* RawProcessing::generate_binary (BackgroundSubtraction.cpp:209) */
+    int32_t threshold;           /* detect_threshold            grabber/misc/default_config.cpp:98  */
+    int32_t threshold_maximum;   /* threshold_maximum           :99 (<255 => inRange[thr,max])      */
+    int32_t enable_difference;   /* enable_difference           :126                                */
+    int32_t absolute_difference; /* detect_threshold_is_absolute core/default_config.cpp:1168       */
+    int32_t image_invert;        /* image_invert                :1159                               */
+    int32_t inclusive;           /* 0: diff > thr (cv::threshold, default) ; 1: diff >= thr          */
+    int32_t zero_is_background;  /* 1 (default): a masked pixel of grey value 0 is background        */
+    /* CPULabeling::run (BackgroundSubtraction.cpp:216) */
+    int32_t connectivity;        /* 8 (default) or 4                                                 */
+    int32_t dilation_size;       /* core/default_config.cpp:1163                                     */
+    int32_t use_closing;         /* :1164                                                            */
+    int32_t closing_size;        /* :1165                                                            */
+    /* size filter (BackgroundSubtraction.cpp:259, core/SizeFilters.cpp:37-53) */
+    int32_t n_ranges;            /* detect_size_filter, 0 = accept all                               */
+    double  cm_per_pixel;
+    double  ranges[16];          /* [start,end) pairs in cm^2                                        */
+} trexhip_params;
+
+/* HorizontalLine{y,x0,x1}, x1 inclusive (pv.cpp:509); 8 bytes */
+typedef struct trexhip_run { uint16_t x0, x1, y, pad; } trexhip_run;
+
+/* One blob = one blob::Pair (lines + pixels) plus the reductions the tracker asks of it
+ * (pv::Blob::calculate_moments, Individual::weighted_centroid -- Individual.cpp:2414-2440).
+ * Sums are exact integers so host-side float results do not depend on summation order. */
+typedef struct trexhip_blob {
+    uint32_t run_begin, n_runs;     /* index into the frame's run array (sorted by (y,x0))   */
+    uint32_t pix_begin, n_pixels;   /* index into the frame's pixel array (gathered in run order) */
+    uint16_t x0, y0, x1, y1;        /* inclusive bounding box                                */
+    uint32_t bid;                   /* pv::bid of the blob (13/13/6-bit hash of first line)  */
+    uint32_t px_min_max;            /* min | max << 8 of the grey values                     */
+    uint64_t m10, m01;              /* sum x, sum y                                          */
+    uint64_t m20, m11, m02;         /* sum x^2, sum x*y, sum y^2                             */
+    uint64_t sp, spx, spy;          /* sum p, sum p*x, sum p*y                               */
+} trexhip_blob;
+
+typedef struct trexhip_frame_info {
+    uint32_t n_blobs, n_runs, n_pixels;   /* kept (after size filter)                        */
+    uint32_t blob_begin, run_begin, pix_begin; /* offsets of this frame in the pooled arrays */
+    uint32_t n_raw_runs, n_raw_blobs;     /* before filtering                                */
+    uint32_t flags;                       /* TREXHIP_FRAME_*                                 */
+    uint32_t reserved[3];
+} trexhip_frame_info;
+
+/* Host view of one segmented batch (pooled arrays, pinned host memory owned by the ctx). */
+typedef struct trexhip_batch_result {
+    int32_t n_frames;
+    uint32_t total_blobs, total_runs, total_pixels;
+    const trexhip_frame_info* frames;   /* [n_frames]                                        */
+    const trexhip_blob* blobs;          /* [total_blobs]; run_begin/pix_begin are FRAME-relative */
+    const trexhip_run* runs;            /* [total_runs]                                      */
+    const uint8_t* pixels;              /* [total_pixels]                                    */
+} trexhip_batch_result;
+
+/* Device view of the same tables (for downstream device stages and torch interop). */
+typedef struct trexhip_device_view {
+    const trexhip_frame_info* frames;
+    const trexhip_blob* blobs;
+    const trexhip_run* runs;
+    const uint8_t* pixels;
+    const uint32_t* totals;             /* [3] total blobs, runs, pixels                     */
+    const uint32_t* blob_frame;         /* [pool] frame index of each pooled blob            */
+} trexhip_device_view;
+
+typedef struct trexhip_ctx trexhip_ctx;
+
+int trexhip_abi_version(void);
+const char* trexhip_last_error(void);
+void trexhip_default_params(trexhip_params* p, int32_t width, int32_t height);
+
+/* BackgroundSubtraction::BackgroundSubtraction / Detection::init (python/Detection.cpp:16-58) */
+int trexhip_create(const trexhip_params* p, trexhip_ctx** out);
+/* BackgroundSubtraction::deinit (BackgroundSubtraction.cpp:118-120) */
+void trexhip_destroy(trexhip_ctx* ctx);
+/* use an external hipStream_t (e.g. torch's current stream); NULL = the ctx's own stream */
+int trexhip_set_stream(trexhip_ctx* ctx, void* hip_stream);
+
+/* BackgroundSubtraction::set_background -> Data::set (BackgroundSubtraction.cpp:86-101) */
+int trexhip_set_background(trexhip_ctx* ctx, const uint8_t* gray, int32_t stride);
+int trexhip_set_background_device(trexhip_ctx* ctx, const uint8_t* d_gray);
+
+/* BackgroundSubtraction::apply(std::vector<TileImage>&&) hot loop (BackgroundSubtraction.cpp:146-316):
+ * generate_binary + CPULabeling::run + size filter for n gray frames. */
+int trexhip_segment_device(trexhip_ctx* ctx, const uint8_t* d_frames, int32_t n);
+int trexhip_segment(trexhip_ctx* ctx, const uint8_t* const* frames, int32_t stride, int32_t n);
+/* wait for the last segment call and copy its tables to pinned host memory */
+int trexhip_fetch(trexhip_ctx* ctx, trexhip_batch_result* out);
+int trexhip_device_view_get(trexhip_ctx* ctx, trexhip_device_view* out);
+int trexhip_synchronize(trexhip_ctx* ctx);
+
+/* live HIP-event timing of the dominant kernels on the ctx stream (bench.py roofline):
+ * stage ids TREXHIP_STAGE_* ; returns accumulated milliseconds and launch count since reset */
+enum { TREXHIP_STAGE_ROWS = 0, TREXHIP_STAGE_SEGMENT_ALL = 1, TREXHIP_STAGE_COUNT = 8 };
+int trexhip_profile_enable(trexhip_ctx* ctx, int32_t on);
+int trexhip_profile_read(trexhip_ctx* ctx, int32_t stage, double* total_ms, int64_t* launches);
+int trexhip_profile_reset(trexhip_ctx* ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,72 @@
+"""CPU-side checks of the drop-in boundary: libtrexhip.so loads and exports every symbol
+include/trexhip.h declares; struct layouts agree between the C header and the ctypes mirror."""
+import ctypes as C
+import os
+import re
+import subprocess
+import numpy as np
+import pytest
+from trex_amd import capi
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def header_symbols():
+    text = open(os.path.join(ROOT, "include", "trexhip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(trexhip_[a-z_0-9]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    assert os.path.exists(capi.LIB_PATH), "build first: python -c 'import __graft_entry__ as g; g.build()'"
+    lib = C.CDLL(capi.LIB_PATH)
+    declared = header_symbols()
+    assert declared, "no declarations parsed"
+    for s in declared:
+        assert hasattr(lib, s), f"libtrexhip.so does not export {s}"
+    assert sorted(capi.SYMBOLS) == declared, "capi.SYMBOLS out of date with include/trexhip.h"
+    assert lib.trexhip_abi_version() == 1
+
+
+def test_struct_layouts_match_header(tmp_path):
+    src = tmp_path / "sz.c"
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "trexhip.h"\nint main(){printf("%zu %zu %zu %zu %zu %zu %zu\\n",'
+                   'sizeof(trexhip_params),sizeof(trexhip_run),sizeof(trexhip_blob),sizeof(trexhip_frame_info),'
+                   'sizeof(trexhip_batch_result),offsetof(trexhip_params,cm_per_pixel),offsetof(trexhip_blob,m10));return 0;}\n')
+    exe = tmp_path / "sz"
+    subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
+    got = [int(x) for x in subprocess.check_output([str(exe)]).split()]
+    assert got == [C.sizeof(capi.Params), capi.RUN_DTYPE.itemsize, capi.BLOB_DTYPE.itemsize, capi.INFO_DTYPE.itemsize,
+                   C.sizeof(capi.BatchResult), capi.Params.cm_per_pixel.offset, capi.BLOB_DTYPE.fields["m10"][1]]
+
+
+def test_oracle_and_product_share_table_layouts():
+    from oracle import oracle
+    assert oracle.BLOB_DTYPE == capi.BLOB_DTYPE and oracle.RUN_DTYPE == capi.RUN_DTYPE
+
+
+def test_default_params_are_the_reference_defaults():
+    p = capi.default_params(640, 480)
+    # detect_threshold 15, threshold_maximum 255, detect_threshold_is_absolute true,
+    # enable_difference true, image_invert false, dilation_size 0, use_closing false, closing_size 3
+    assert (p.threshold, p.threshold_maximum, p.absolute_difference, p.enable_difference) == (15, 255, 1, 1)
+    assert (p.image_invert, p.dilation_size, p.use_closing, p.closing_size, p.n_ranges) == (0, 0, 0, 3, 0)
+
+
+def test_product_does_not_reference_the_oracle():
+    bad = []
+    for d, _, files in os.walk(os.path.join(ROOT, "trex_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp", ".hpp")):
+                t = open(os.path.join(d, f), errors="ignore").read()
+                if re.search(r"\boracle\b", t) and "never imports" not in t:
+                    bad.append(os.path.join(d, f))
+    assert not bad, f"product sources mention the oracle: {bad}"
+
+
+def test_no_gpu_means_loud_failure():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(capi.TrexHipError):
+        capi.Segmenter(capi.default_params(64, 64))

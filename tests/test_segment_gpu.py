@@ -1,0 +1,184 @@
+"""Parity of the HIP detect stage (through the C ABI) against the CPU oracle: bit-exact blob
+tables, runs and pixels.  Mirrors the shape of the reference's own tests (TestLines.Threshold
+test_matching.cpp:1556-1602: overlapping shapes = 1 blob; test_segmenter.cpp:95-126 moving
+square) plus adversarial images."""
+import numpy as np
+import pytest
+import torch
+from oracle import oracle
+from trex_amd import capi, synth
+
+pytestmark = pytest.mark.gpu
+
+
+def run_gpu(frames, bg, device_resident=True, **kw):
+    frames = np.ascontiguousarray(frames, np.uint8)
+    n, H, W = frames.shape
+    p = capi.default_params(W, H, max_batch=max(n, 1), **kw)
+    seg = capi.Segmenter(p)
+    seg.set_background(bg)
+    if device_resident:
+        d = torch.from_numpy(frames).cuda()
+        seg.segment_device(d.data_ptr(), n)
+        res = seg.fetch()
+        del d
+    else:
+        seg.segment_host([f for f in frames])
+        res = seg.fetch()
+    seg.close()
+    return res
+
+
+def oracle_params(W, H, **kw):
+    kw = dict(kw)
+    kw.pop("max_runs", None); kw.pop("max_blobs", None); kw.pop("max_pixels", None)
+    return oracle.make_params(W, H, **kw)
+
+
+def assert_frame_equal(res, frame, bg, **kw):
+    H, W = frame.shape
+    ob, orr, opx = oracle.segment(frame, bg, oracle_params(W, H, **kw))
+    assert res.info["flags"] == 0
+    assert len(res.blobs) == len(ob), (len(res.blobs), len(ob))
+    assert res.runs.tobytes() == orr.tobytes()
+    assert res.pixels.tobytes() == opx.tobytes()
+    for name in ob.dtype.names:
+        assert np.array_equal(res.blobs[name], ob[name]), name
+    assert res.blobs.tobytes() == ob.tobytes()
+
+
+@pytest.mark.parametrize("shape", [(64, 48), (1280, 720), (1024, 33), (2304, 100), (4096, 16), (16, 16)])
+def test_random_scenes_bit_exact(shape):
+    W, H = shape
+    rng = np.random.default_rng(W * 7 + H)
+    frames = []
+    for i in range(3):
+        fr, bg = synth.random_scene(rng, W, H, density=0.1)
+        frames.append(fr)
+    res = run_gpu(np.stack(frames), bg)
+    for r, fr in zip(res, frames):
+        assert_frame_equal(r, fr, bg)
+
+
+@pytest.mark.parametrize("W", [17, 100, 1001, 1030, 2050])
+def test_unaligned_widths(W):
+    rng = np.random.default_rng(W)
+    fr, bg = synth.random_scene(rng, W, 40, density=0.15)
+    fr[:, W - 1] = 5       # foreground in the last column
+    fr[7, :] = 3           # a run spanning the full row
+    res = run_gpu(fr[None], bg)
+    assert_frame_equal(res[0], fr, bg)
+
+
+def test_reference_style_cases():
+    # moving 8x8 white square on black, 64x48 (test_segmenter.cpp:95-126)
+    bg = np.zeros((48, 64), np.uint8)
+    frames = []
+    for t in range(12):
+        f = bg.copy(); f[20:28, 3 * t:3 * t + 8] = 255; frames.append(f)
+    res = run_gpu(np.stack(frames), bg)
+    for t, r in enumerate(res):
+        assert len(r.blobs) == 1 and r.blobs["n_pixels"][0] == 64
+        assert (r.blobs["x0"][0], r.blobs["y0"][0]) == (3 * t, 20)
+        assert_frame_equal(r, frames[t], bg)
+    # overlapping circle + rectangle = one blob (test_matching.cpp:1556-1602)
+    H = W = 320
+    yy, xx = np.mgrid[0:H, 0:W]
+    bg = np.full((H, W), 255, np.uint8)
+    fr = bg.copy()
+    fr[(yy - 100) ** 2 + (xx - 100) ** 2 <= 50 ** 2] = 0 + 1
+    fr[90:200, 120:260] = 2
+    res = run_gpu(fr[None], bg)
+    assert len(res[0].blobs) == 1
+    assert_frame_equal(res[0], fr, bg)
+
+
+def test_adversarial_patterns():
+    H, W = 96, 2048
+    bg = np.full((H, W), 200, np.uint8)
+    yy, xx = np.mgrid[0:H, 0:W]
+    frames = []
+    f = bg.copy(); f[(yy + xx) % 2 == 0] = 10; frames.append(f)                 # checkerboard
+    f = bg.copy(); f[yy == xx % H] = 20; frames.append(f)                         # diagonals
+    f = bg.copy(); f[0, :] = 5; f[:, W - 1] = 5; f[H - 1, 2:] = 5; f[2:, 2] = 5; f[2, 2:W - 2] = 5; frames.append(f)
+    f = bg.copy(); f[:] = 3; frames.append(f)                                     # everything foreground
+    frames.append(bg.copy())                                                      # empty
+    f = bg.copy(); f[:, 1023] = 9; f[:, 1024] = 9; f[5, 1000:1100] = 9; frames.append(f)   # chunk boundary
+    f = bg.copy(); f[xx % 3 == 0] = 9; frames.append(f)                           # many 1-px runs per row
+    for conn in (8, 4):
+        res = run_gpu(np.stack(frames), bg, connectivity=conn)
+        for r, fr in zip(res, frames):
+            assert_frame_equal(r, fr, bg, connectivity=conn)
+    assert len(res[4].blobs) == 0 and res[4].info["n_raw_runs"] == 0
+
+
+@pytest.mark.parametrize("kw", [
+    dict(threshold=15, inclusive=1), dict(threshold=0, inclusive=1), dict(threshold=40, absolute_difference=0),
+    dict(threshold=20, threshold_maximum=60), dict(threshold=15, zero_is_background=0, inclusive=1),
+    dict(threshold=30, image_invert=1), dict(threshold=100, enable_difference=0),
+    dict(threshold=15, size_ranges=[(3, 9), (20, 1000)], cm_per_pixel=0.5),
+])
+def test_setting_variants(kw):
+    rng = np.random.default_rng(11)
+    W, H = 512, 64
+    bg = rng.integers(60, 200, (H, W)).astype(np.uint8)
+    fr = np.clip(bg.astype(int) + rng.integers(-70, 70, (H, W)), 0, 255).astype(np.uint8)
+    fr[rng.random((H, W)) < 0.02] = 0
+    res = run_gpu(fr[None], bg, **kw)
+    assert_frame_equal(res[0], fr, bg, **kw)
+
+
+def test_synthetic_configs_and_host_path():
+    fr, bg = synth.batch("C2", 3)
+    res = run_gpu(fr, bg, device_resident=False)
+    for r, f in zip(res, fr):
+        assert_frame_equal(r, f, bg)
+        assert len(r.blobs) == 32
+    fr, bg = synth.batch("C3", 2)
+    res = run_gpu(fr, bg)
+    for r, f in zip(res, fr):
+        assert_frame_equal(r, f, bg)
+        assert len(r.blobs) == 100
+
+
+def test_full_size_properties_c5():
+    # 4096x4096 / 256 individuals: size-independent properties + oracle on one frame
+    fr, bg = synth.batch("C5", 2)
+    res = run_gpu(fr, bg)
+    for r, f in zip(res, fr):
+        d = np.abs(f.astype(np.int16) - bg.astype(np.int16)) > 15
+        assert int(r.blobs["n_pixels"].sum()) == int(d.sum())
+        keys = r.runs["y"].astype(np.int64) << 16 | r.runs["x0"]
+        for b in r.blobs:                       # runs of a blob sorted by (y,x0)  (pv.cpp:505-508)
+            k = keys[b["run_begin"]:b["run_begin"] + b["n_runs"]]
+            assert np.all(np.diff(k) > 0)
+        assert len(r.blobs) == 256
+    assert_frame_equal(res[0], fr[0], bg)
+    # idempotence: segmenting the grey-under-mask image against a zero background gives the same lines
+    out = oracle.generate_binary(fr[0], bg, oracle.make_params(4096, 4096))
+    res2 = run_gpu(out[None], np.zeros_like(bg), threshold=0)
+    assert res2[0].runs.tobytes() == res[0].runs.tobytes()
+
+
+def test_capacity_overflow_is_reported():
+    H, W = 64, 256
+    bg = np.full((H, W), 200, np.uint8)
+    fr = bg.copy(); fr[:, ::2] = 5             # 128 runs per row = 8192 runs
+    res = run_gpu(np.stack([fr, bg]), bg, max_runs=1000)
+    assert res[0].info["flags"] & 1 and len(res[0].blobs) == 0
+    assert res[1].info["flags"] == 0 and len(res[1].blobs) == 0
+    res = run_gpu(fr[None], bg, max_runs=10000, max_blobs=100)
+    assert res[0].info["flags"] & 2
+
+
+def test_errors():
+    p = capi.default_params(64, 64)
+    seg = capi.Segmenter(p)
+    with pytest.raises(capi.TrexHipError):      # background not set (BackgroundSubtraction.cpp:58-73 waits; we refuse)
+        seg.segment_host([np.zeros((64, 64), np.uint8)])
+    seg.set_background(np.zeros((64, 64), np.uint8))
+    with pytest.raises(capi.TrexHipError):      # more frames than max_batch
+        seg.segment_host([np.zeros((64, 64), np.uint8)] * 17)
+    seg.close()
+    with pytest.raises(capi.TrexHipError):
+        capi.Segmenter(capi.default_params(70000, 64))

@@ -1,0 +1,224 @@
+"""ctypes binding of libtrexhip.so (include/trexhip.h) for the Python-side callers in this repo
+(tests, bench.py).  The C ABI is the product boundary; this module is only plumbing.
+
+There is NO CPU fallback: if the HIP library is missing or a call fails, this raises.
+"""
+import ctypes as C
+import os
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libtrexhip.so")
+_LIB = None
+
+RUN_DTYPE = np.dtype([("x0", "<u2"), ("x1", "<u2"), ("y", "<u2"), ("pad", "<u2")])
+BLOB_DTYPE = np.dtype([
+    ("run_begin", "<u4"), ("n_runs", "<u4"), ("pix_begin", "<u4"), ("n_pixels", "<u4"),
+    ("x0", "<u2"), ("y0", "<u2"), ("x1", "<u2"), ("y1", "<u2"),
+    ("bid", "<u4"), ("px_min_max", "<u4"),
+    ("m10", "<u8"), ("m01", "<u8"), ("m20", "<u8"), ("m11", "<u8"), ("m02", "<u8"),
+    ("sp", "<u8"), ("spx", "<u8"), ("spy", "<u8"),
+])
+INFO_DTYPE = np.dtype([
+    ("n_blobs", "<u4"), ("n_runs", "<u4"), ("n_pixels", "<u4"),
+    ("blob_begin", "<u4"), ("run_begin", "<u4"), ("pix_begin", "<u4"),
+    ("n_raw_runs", "<u4"), ("n_raw_blobs", "<u4"), ("flags", "<u4"), ("reserved", "<u4", (3,)),
+])
+assert BLOB_DTYPE.itemsize == 96 and RUN_DTYPE.itemsize == 8 and INFO_DTYPE.itemsize == 48
+
+STAGE_ROWS, STAGE_SEGMENT_ALL = 0, 1
+
+
+class Params(C.Structure):
+    _fields_ = [
+        ("device", C.c_int32), ("width", C.c_int32), ("height", C.c_int32),
+        ("max_batch", C.c_int32), ("max_runs", C.c_int32), ("max_blobs", C.c_int32), ("max_pixels", C.c_int32),
+        ("threshold", C.c_int32), ("threshold_maximum", C.c_int32),
+        ("enable_difference", C.c_int32), ("absolute_difference", C.c_int32),
+        ("image_invert", C.c_int32), ("inclusive", C.c_int32), ("zero_is_background", C.c_int32),
+        ("connectivity", C.c_int32), ("dilation_size", C.c_int32), ("use_closing", C.c_int32),
+        ("closing_size", C.c_int32), ("n_ranges", C.c_int32),
+        ("cm_per_pixel", C.c_double), ("ranges", C.c_double * 16),
+    ]
+
+
+class BatchResult(C.Structure):
+    _fields_ = [
+        ("n_frames", C.c_int32), ("total_blobs", C.c_uint32), ("total_runs", C.c_uint32), ("total_pixels", C.c_uint32),
+        ("frames", C.c_void_p), ("blobs", C.c_void_p), ("runs", C.c_void_p), ("pixels", C.c_void_p),
+    ]
+
+
+class DeviceView(C.Structure):
+    _fields_ = [("frames", C.c_void_p), ("blobs", C.c_void_p), ("runs", C.c_void_p), ("pixels", C.c_void_p),
+                ("totals", C.c_void_p), ("blob_frame", C.c_void_p)]
+
+
+class TrexHipError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"libtrexhip error {code}: {msg}")
+        self.code = code
+
+
+# every symbol include/trexhip.h declares (tests check the library exports all of them)
+SYMBOLS = [
+    "trexhip_abi_version", "trexhip_last_error", "trexhip_default_params", "trexhip_create", "trexhip_destroy",
+    "trexhip_set_stream", "trexhip_set_background", "trexhip_set_background_device", "trexhip_segment_device",
+    "trexhip_segment", "trexhip_fetch", "trexhip_device_view_get", "trexhip_synchronize",
+    "trexhip_profile_enable", "trexhip_profile_read", "trexhip_profile_reset",
+]
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(LIB_PATH):
+            raise TrexHipError(-1, f"{LIB_PATH} is missing: run __graft_entry__.build() (make -C trex_amd/csrc)")
+        L = C.CDLL(LIB_PATH)
+        L.trexhip_last_error.restype = C.c_char_p
+        L.trexhip_default_params.argtypes = [C.POINTER(Params), C.c_int32, C.c_int32]
+        L.trexhip_default_params.restype = None
+        L.trexhip_create.argtypes = [C.POINTER(Params), C.POINTER(C.c_void_p)]
+        L.trexhip_destroy.argtypes = [C.c_void_p]
+        L.trexhip_destroy.restype = None
+        L.trexhip_set_stream.argtypes = [C.c_void_p, C.c_void_p]
+        L.trexhip_set_background.argtypes = [C.c_void_p, C.c_void_p, C.c_int32]
+        L.trexhip_set_background_device.argtypes = [C.c_void_p, C.c_void_p]
+        L.trexhip_segment_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int32]
+        L.trexhip_segment.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.c_int32, C.c_int32]
+        L.trexhip_fetch.argtypes = [C.c_void_p, C.POINTER(BatchResult)]
+        L.trexhip_device_view_get.argtypes = [C.c_void_p, C.POINTER(DeviceView)]
+        L.trexhip_synchronize.argtypes = [C.c_void_p]
+        L.trexhip_profile_enable.argtypes = [C.c_void_p, C.c_int32]
+        L.trexhip_profile_read.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
+        L.trexhip_profile_reset.argtypes = [C.c_void_p]
+        _LIB = L
+    return _LIB
+
+
+def _check(rc):
+    if rc != 0:
+        raise TrexHipError(rc, lib().trexhip_last_error().decode())
+
+
+def default_params(width, height, **kw):
+    p = Params()
+    lib().trexhip_default_params(C.byref(p), width, height)
+    ranges = kw.pop("size_ranges", None)
+    for k, v in kw.items():
+        if not hasattr(p, k):
+            raise KeyError(k)
+        setattr(p, k, v)
+    if ranges is not None:
+        p.n_ranges = len(ranges)
+        for i, (a, b) in enumerate(ranges):
+            p.ranges[2 * i], p.ranges[2 * i + 1] = a, b
+    return p
+
+
+def _from_addr(addr, count, dtype):
+    if count == 0 or not addr:
+        return np.zeros(0, dtype)
+    buf = (C.c_uint8 * (count * dtype.itemsize)).from_address(addr)
+    return np.frombuffer(buf, dtype=dtype, count=count)
+
+
+class FrameResult:
+    """Blobs of one frame: structured arrays with frame-relative run/pixel offsets."""
+    __slots__ = ("info", "blobs", "runs", "pixels")
+
+    def __init__(self, info, blobs, runs, pixels):
+        self.info, self.blobs, self.runs, self.pixels = info, blobs, runs, pixels
+
+
+class Segmenter:
+    """Host-side handle mirroring TRex's BackgroundSubtraction (set_background / apply / fps / deinit)."""
+
+    def __init__(self, params):
+        self.params = params
+        self._h = C.c_void_p()
+        _check(lib().trexhip_create(C.byref(params), C.byref(self._h)))
+
+    def close(self):
+        if self._h:
+            lib().trexhip_destroy(self._h)
+            self._h = C.c_void_p()
+
+    deinit = close
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def handle(self):
+        return self._h
+
+    def set_stream(self, hip_stream_ptr):
+        _check(lib().trexhip_set_stream(self._h, C.c_void_p(hip_stream_ptr)))
+
+    def set_background(self, bg):
+        """bg: numpy uint8 [H,W] (host) or a torch CUDA uint8 tensor (device)."""
+        if isinstance(bg, np.ndarray):
+            bg = np.ascontiguousarray(bg, np.uint8)
+            assert bg.shape == (self.params.height, self.params.width)
+            _check(lib().trexhip_set_background(self._h, bg.ctypes.data_as(C.c_void_p), bg.shape[1]))
+        else:
+            assert bg.is_cuda and bg.is_contiguous() and bg.numel() == self.params.height * self.params.width
+            _check(lib().trexhip_set_background_device(self._h, C.c_void_p(bg.data_ptr())))
+
+    def segment_device(self, d_ptr, n):
+        """Enqueue the detect stage for n HBM-resident gray frames at device address d_ptr."""
+        _check(lib().trexhip_segment_device(self._h, C.c_void_p(d_ptr), n))
+
+    def segment_host(self, frames):
+        frames = [np.ascontiguousarray(f, np.uint8) for f in frames]
+        ptrs = (C.c_void_p * len(frames))(*[f.ctypes.data for f in frames])
+        stride = frames[0].shape[1] if frames else self.params.width
+        _check(lib().trexhip_segment(self._h, ptrs, stride, len(frames)))
+
+    def synchronize(self):
+        _check(lib().trexhip_synchronize(self._h))
+
+    def fetch(self, copy=True):
+        r = BatchResult()
+        rc = lib().trexhip_fetch(self._h, C.byref(r))
+        if rc != 0 and rc != -3:
+            _check(rc)
+        info = _from_addr(r.frames, r.n_frames, INFO_DTYPE)
+        blobs = _from_addr(r.blobs, r.total_blobs, BLOB_DTYPE)
+        runs = _from_addr(r.runs, r.total_runs, RUN_DTYPE)
+        pixels = _from_addr(r.pixels, r.total_pixels, np.dtype(np.uint8))
+        out = []
+        for i in range(r.n_frames):
+            fi = info[i]
+            if fi["flags"]:
+                out.append(FrameResult(fi.copy(), np.zeros(0, BLOB_DTYPE), np.zeros(0, RUN_DTYPE), np.zeros(0, np.uint8)))
+                continue
+            b = blobs[fi["blob_begin"]:fi["blob_begin"] + fi["n_blobs"]]
+            ru = runs[fi["run_begin"]:fi["run_begin"] + fi["n_runs"]]
+            px = pixels[fi["pix_begin"]:fi["pix_begin"] + fi["n_pixels"]]
+            if copy:
+                b, ru, px = b.copy(), ru.copy(), px.copy()
+            out.append(FrameResult(fi.copy(), b, ru, px))
+        if rc == -3:
+            self.last_capacity_error = lib().trexhip_last_error().decode()
+        return out
+
+    def device_view(self):
+        v = DeviceView()
+        _check(lib().trexhip_device_view_get(self._h, C.byref(v)))
+        return v
+
+    def profile_enable(self, on=True):
+        _check(lib().trexhip_profile_enable(self._h, 1 if on else 0))
+
+    def profile_read(self, stage):
+        ms, n = C.c_double(), C.c_int64()
+        _check(lib().trexhip_profile_read(self._h, stage, C.byref(ms), C.byref(n)))
+        return ms.value, n.value
+
+    def profile_reset(self):
+        _check(lib().trexhip_profile_reset(self._h))

@@ -1,0 +1,324 @@
+// capi.hip -- C ABI of libtrexhip (include/trexhip.h): context, memory, background, segment, fetch.
+#include "internal.h"
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <vector>
+
+namespace trexhip {
+
+static thread_local std::string g_error;
+void set_error(const std::string& msg) { g_error = msg; }
+
+static void stage_fold(Stage& s, bool all) {
+    // fold finished intervals into the totals; `all` waits for the outstanding ones too
+    size_t keep = 0;
+    for (size_t i = 0; i < s.pending.size(); ++i) {
+        EvPair p = s.pending[i];
+        hipError_t q = all ? hipEventSynchronize(p.b) : hipEventQuery(p.b);
+        float ms = 0.f;
+        if (q == hipSuccess && hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) {
+            s.total_ms += ms; s.launches++;
+            s.freelist.push_back(p);
+        } else if (q == hipErrorNotReady) {
+            s.pending[keep++] = p;
+        } else {
+            (void)hipGetLastError();
+            s.freelist.push_back(p);
+        }
+    }
+    s.pending.resize(keep);
+}
+void stage_begin(trexhip_ctx* ctx, int stage) {
+    if (!ctx->profiling) return;
+    Stage& s = ctx->stages[stage];
+    if (s.pending.size() > 1024) stage_fold(s, false);
+    EvPair p;
+    if (!s.freelist.empty()) { p = s.freelist.back(); s.freelist.pop_back(); }
+    else { hipEventCreate(&p.a); hipEventCreate(&p.b); }
+    hipEventRecord(p.a, ctx->stream);
+    s.cur = p;
+}
+void stage_end(trexhip_ctx* ctx, int stage) {
+    if (!ctx->profiling) return;
+    Stage& s = ctx->stages[stage];
+    if (!s.cur.a) return;
+    hipEventRecord(s.cur.b, ctx->stream);
+    s.pending.push_back(s.cur);
+    s.cur = EvPair();
+}
+void stage_read(trexhip_ctx* ctx, int stage) { stage_fold(ctx->stages[stage], true); }
+void stage_free(trexhip_ctx* ctx) {
+    for (auto& s : ctx->stages) {
+        stage_fold(s, true);
+        for (auto& p : s.freelist) { hipEventDestroy(p.a); hipEventDestroy(p.b); }
+        s.freelist.clear();
+    }
+}
+
+template <typename T>
+static int dmalloc(T** p, size_t count) {
+    if (count == 0) count = 1;
+    TH_CHECK_HIP(hipMalloc(reinterpret_cast<void**>(p), count * sizeof(T)));
+    return TREXHIP_OK;
+}
+template <typename T>
+static int hmalloc(T** p, size_t count) {
+    if (count == 0) count = 1;
+    TH_CHECK_HIP(hipHostMalloc(reinterpret_cast<void**>(p), count * sizeof(T), hipHostMallocDefault));
+    return TREXHIP_OK;
+}
+
+static int fill_cfg(trexhip_ctx* ctx) {
+    const trexhip_params& p = ctx->p;
+    SegCfg& c = ctx->cfg;
+    c.W = p.width; c.H = p.height; c.B = p.max_batch; c.R = p.max_runs;
+    const int thr = p.threshold < 0 ? -p.threshold : p.threshold;   // abs(threshold), as the reference does
+    if (p.threshold_maximum < 255) { c.tmin = thr; c.tmax = p.threshold_maximum; }   // cv::inRange
+    else { c.tmin = p.inclusive ? thr : thr + 1; c.tmax = 255; }                      // cv::threshold is strict
+    c.enable_diff = p.enable_difference; c.absdiff = p.absolute_difference;
+    c.invert = p.image_invert; c.zero_bg = p.zero_is_background;
+    c.slack = p.connectivity == 4 ? 0 : 1;
+    c.n_ranges = p.n_ranges;
+    c.sqcm = (float)(p.cm_per_pixel * p.cm_per_pixel);
+    for (int i = 0; i < 16; ++i) c.ranges[i] = p.ranges[i];
+    c.pool_blobs = (uint32_t)p.max_batch * (uint32_t)p.max_blobs;
+    c.pool_runs = (uint32_t)p.max_batch * (uint32_t)p.max_runs;
+    c.pool_pixels = (uint32_t)p.max_batch * (uint32_t)p.max_pixels;
+    return TREXHIP_OK;
+}
+
+}  // namespace trexhip
+
+using namespace trexhip;
+
+extern "C" {
+
+int trexhip_abi_version(void) { return TREXHIP_ABI_VERSION; }
+const char* trexhip_last_error(void) { return g_error.c_str(); }
+
+void trexhip_default_params(trexhip_params* p, int32_t width, int32_t height) {
+    if (!p) return;
+    std::memset(p, 0, sizeof(*p));
+    p->device = 0;
+    p->width = width; p->height = height;
+    p->max_batch = 16;
+    p->max_runs = 65536;
+    p->max_blobs = 2048;
+    p->max_pixels = 1 << 20;
+    p->threshold = 15; p->threshold_maximum = 255;
+    p->enable_difference = 1; p->absolute_difference = 1;
+    p->image_invert = 0; p->inclusive = 0; p->zero_is_background = 1;
+    p->connectivity = 8;
+    p->dilation_size = 0; p->use_closing = 0; p->closing_size = 3;
+    p->n_ranges = 0; p->cm_per_pixel = 1.0;
+}
+
+int trexhip_create(const trexhip_params* p, trexhip_ctx** out) {
+    if (!p || !out) { set_error("trexhip_create: null argument"); return TREXHIP_E_INVALID; }
+    *out = nullptr;
+    if (p->width <= 0 || p->height <= 0 || p->width >= 65535 || p->height >= 65535) {
+        set_error("trexhip_create: frame size must be in 1..65534 (pv.cpp:601-602)"); return TREXHIP_E_INVALID;
+    }
+    if (p->max_batch <= 0 || p->max_runs <= 0 || p->max_blobs <= 0 || p->max_pixels <= 0) {
+        set_error("trexhip_create: capacities must be positive"); return TREXHIP_E_INVALID;
+    }
+    if (p->connectivity != 8 && p->connectivity != 4) { set_error("trexhip_create: connectivity must be 4 or 8"); return TREXHIP_E_INVALID; }
+    if (p->n_ranges < 0 || p->n_ranges > 8) { set_error("trexhip_create: n_ranges must be 0..8"); return TREXHIP_E_INVALID; }
+    if (p->dilation_size != 0 || p->use_closing) {
+        set_error("trexhip_create: dilation_size / use_closing are not implemented on the device yet"); return TREXHIP_E_UNSUPPORTED;
+    }
+    int ndev = 0;
+    TH_CHECK_HIP(hipGetDeviceCount(&ndev));
+    if (p->device < 0 || p->device >= ndev) { set_error("trexhip_create: no such HIP device"); return TREXHIP_E_DEVICE; }
+    TH_CHECK_HIP(hipSetDevice(p->device));
+    trexhip_ctx* ctx = new (std::nothrow) trexhip_ctx();
+    if (!ctx) { set_error("out of host memory"); return TREXHIP_E_NOMEM; }
+    ctx->p = *p;
+    fill_cfg(ctx);
+    const size_t B = p->max_batch, H = p->height, W = p->width, R = p->max_runs, NB = p->max_blobs, P = p->max_pixels;
+    int rc = TREXHIP_OK;
+#define TRY(x) do { if (rc == TREXHIP_OK) rc = (x); } while (0)
+    if (hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking) != hipSuccess) { set_error("hipStreamCreate failed"); delete ctx; return TREXHIP_E_DEVICE; }
+    ctx->stream = ctx->own_stream;
+    TRY(dmalloc(&ctx->d_bg, H * W + 16));
+    TRY(dmalloc(&ctx->d_ctr, B + 4));
+    TRY(dmalloc(&ctx->d_row_cnt, B * H));
+    TRY(dmalloc(&ctx->d_row_off, B * H));
+    TRY(dmalloc(&ctx->d_row_base, B * (H + 1)));
+    TRY(dmalloc(&ctx->d_tmp_runs, B * R));
+    TRY(dmalloc(&ctx->d_raster, B * R));
+    TRY(dmalloc(&ctx->d_parent, B * R));
+    TRY(dmalloc(&ctx->d_root_ord, B * R));
+    TRY(dmalloc(&ctx->d_cnt_runs, B * R));
+    TRY(dmalloc(&ctx->d_cnt_px, B * R));
+    TRY(dmalloc(&ctx->d_cur_run, B * R));
+    TRY(dmalloc(&ctx->d_pix_begin, B * R));
+    TRY(dmalloc(&ctx->d_blob_map, B * R));
+    TRY(dmalloc(&ctx->d_info, B));
+    TRY(dmalloc(&ctx->d_blobs, B * NB));
+    TRY(dmalloc(&ctx->d_blob_frame, B * NB));
+    TRY(dmalloc(&ctx->d_runs, B * R));
+    TRY(dmalloc(&ctx->d_pixels, B * P));
+    TRY(hmalloc(&ctx->h_info, B));
+    TRY(hmalloc(&ctx->h_totals, 4));
+    TRY(hmalloc(&ctx->h_blobs, B * NB));
+    TRY(hmalloc(&ctx->h_runs, B * R));
+    TRY(hmalloc(&ctx->h_pixels, B * P));
+#undef TRY
+    if (rc != TREXHIP_OK) { trexhip_destroy(ctx); return rc; }
+    *out = ctx;
+    return TREXHIP_OK;
+}
+
+void trexhip_destroy(trexhip_ctx* ctx) {
+    if (!ctx) return;
+    hipSetDevice(ctx->p.device);
+    if (ctx->stream) hipStreamSynchronize(ctx->stream);
+    void* dev[] = {ctx->d_bg, ctx->d_staging, ctx->d_ctr, ctx->d_row_cnt, ctx->d_row_off, ctx->d_row_base, ctx->d_tmp_runs,
+                   ctx->d_raster, ctx->d_parent, ctx->d_root_ord, ctx->d_cnt_runs, ctx->d_cnt_px, ctx->d_cur_run,
+                   ctx->d_pix_begin, ctx->d_blob_map, ctx->d_info, ctx->d_blobs, ctx->d_blob_frame, ctx->d_runs, ctx->d_pixels};
+    for (void* p : dev) if (p) hipFree(p);
+    void* host[] = {ctx->h_info, ctx->h_totals, ctx->h_blobs, ctx->h_runs, ctx->h_pixels, ctx->h_staging};
+    for (void* p : host) if (p) hipHostFree(p);
+    stage_free(ctx);
+    if (ctx->own_stream) hipStreamDestroy(ctx->own_stream);
+    delete ctx;
+}
+
+int trexhip_set_stream(trexhip_ctx* ctx, void* hip_stream) {
+    if (!ctx) { set_error("null ctx"); return TREXHIP_E_INVALID; }
+    TH_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+    ctx->stream = hip_stream ? reinterpret_cast<hipStream_t>(hip_stream) : ctx->own_stream;
+    return TREXHIP_OK;
+}
+
+int trexhip_set_background(trexhip_ctx* ctx, const uint8_t* gray, int32_t stride) {
+    if (!ctx || !gray) { set_error("trexhip_set_background: null argument"); return TREXHIP_E_INVALID; }
+    if (stride < ctx->p.width) { set_error("trexhip_set_background: stride < width"); return TREXHIP_E_INVALID; }
+    TH_CHECK_HIP(hipSetDevice(ctx->p.device));
+    TH_CHECK_HIP(hipMemcpy2DAsync(ctx->d_bg, ctx->p.width, gray, stride, ctx->p.width, ctx->p.height,
+                                  hipMemcpyHostToDevice, ctx->stream));
+    TH_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+    ctx->has_bg = true;
+    return TREXHIP_OK;
+}
+
+int trexhip_set_background_device(trexhip_ctx* ctx, const uint8_t* d_gray) {
+    if (!ctx || !d_gray) { set_error("trexhip_set_background_device: null argument"); return TREXHIP_E_INVALID; }
+    TH_CHECK_HIP(hipSetDevice(ctx->p.device));
+    TH_CHECK_HIP(hipMemcpyAsync(ctx->d_bg, d_gray, (size_t)ctx->p.width * ctx->p.height, hipMemcpyDeviceToDevice, ctx->stream));
+    TH_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+    ctx->has_bg = true;
+    return TREXHIP_OK;
+}
+
+static int check_segment_args(trexhip_ctx* ctx, const void* frames, int32_t n) {
+    if (!ctx || !frames) { set_error("trexhip_segment: null argument"); return TREXHIP_E_INVALID; }
+    if (!ctx->has_bg) { set_error("trexhip_segment: background image not set"); return TREXHIP_E_INVALID; }
+    if (n < 0 || n > ctx->p.max_batch) { set_error("trexhip_segment: n outside 0..max_batch"); return TREXHIP_E_INVALID; }
+    return TREXHIP_OK;
+}
+
+int trexhip_segment_device(trexhip_ctx* ctx, const uint8_t* d_frames, int32_t n) {
+    int rc = check_segment_args(ctx, d_frames, n);
+    if (rc) return rc;
+    TH_CHECK_HIP(hipSetDevice(ctx->p.device));
+    if (n == 0) { ctx->last_n = 0; ctx->fetched = false; return TREXHIP_OK; }
+    return launch_segment(ctx, d_frames, n);
+}
+
+int trexhip_segment(trexhip_ctx* ctx, const uint8_t* const* frames, int32_t stride, int32_t n) {
+    int rc = check_segment_args(ctx, frames, n);
+    if (rc) return rc;
+    if (stride < ctx->p.width) { set_error("trexhip_segment: stride < width"); return TREXHIP_E_INVALID; }
+    TH_CHECK_HIP(hipSetDevice(ctx->p.device));
+    if (n == 0) { ctx->last_n = 0; ctx->fetched = false; return TREXHIP_OK; }
+    const size_t W = ctx->p.width, H = ctx->p.height;
+    if (!ctx->d_staging) {
+        rc = dmalloc(&ctx->d_staging, (size_t)ctx->p.max_batch * W * H + 16);
+        if (rc) return rc;
+        rc = hmalloc(&ctx->h_staging, (size_t)ctx->p.max_batch * W * H);
+        if (rc) return rc;
+    }
+    // the previous batch may still be reading the staging buffers
+    TH_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+    for (int i = 0; i < n; ++i) {
+        if (!frames[i]) { set_error("trexhip_segment: null frame pointer"); return TREXHIP_E_INVALID; }
+        uint8_t* dst = ctx->h_staging + (size_t)i * W * H;
+        if ((size_t)stride == W) std::memcpy(dst, frames[i], W * H);
+        else for (size_t y = 0; y < H; ++y) std::memcpy(dst + y * W, frames[i] + y * (size_t)stride, W);
+    }
+    TH_CHECK_HIP(hipMemcpyAsync(ctx->d_staging, ctx->h_staging, (size_t)n * W * H, hipMemcpyHostToDevice, ctx->stream));
+    return launch_segment(ctx, ctx->d_staging, n);
+}
+
+int trexhip_synchronize(trexhip_ctx* ctx) {
+    if (!ctx) { set_error("null ctx"); return TREXHIP_E_INVALID; }
+    TH_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+    return TREXHIP_OK;
+}
+
+int trexhip_fetch(trexhip_ctx* ctx, trexhip_batch_result* out) {
+    if (!ctx || !out) { set_error("trexhip_fetch: null argument"); return TREXHIP_E_INVALID; }
+    TH_CHECK_HIP(hipSetDevice(ctx->p.device));
+    std::memset(out, 0, sizeof(*out));
+    const int n = ctx->last_n;
+    out->n_frames = n;
+    out->frames = ctx->h_info; out->blobs = ctx->h_blobs; out->runs = ctx->h_runs; out->pixels = ctx->h_pixels;
+    if (n == 0) return TREXHIP_OK;
+    hipStream_t s = ctx->stream;
+    TH_CHECK_HIP(hipMemcpyAsync(ctx->h_info, ctx->d_info, sizeof(trexhip_frame_info) * n, hipMemcpyDeviceToHost, s));
+    TH_CHECK_HIP(hipMemcpyAsync(ctx->h_totals, ctx->d_ctr + ctx->p.max_batch, sizeof(uint32_t) * 4, hipMemcpyDeviceToHost, s));
+    TH_CHECK_HIP(hipStreamSynchronize(s));
+    // frames that overflowed the pool reserved nothing valid; clamp the copies to the pools
+    const uint32_t tb = ctx->h_totals[0] < ctx->cfg.pool_blobs ? ctx->h_totals[0] : ctx->cfg.pool_blobs;
+    const uint32_t tr = ctx->h_totals[1] < ctx->cfg.pool_runs ? ctx->h_totals[1] : ctx->cfg.pool_runs;
+    const uint32_t tp = ctx->h_totals[2] < ctx->cfg.pool_pixels ? ctx->h_totals[2] : ctx->cfg.pool_pixels;
+    if (tb) TH_CHECK_HIP(hipMemcpyAsync(ctx->h_blobs, ctx->d_blobs, sizeof(trexhip_blob) * tb, hipMemcpyDeviceToHost, s));
+    if (tr) TH_CHECK_HIP(hipMemcpyAsync(ctx->h_runs, ctx->d_runs, sizeof(trexhip_run) * tr, hipMemcpyDeviceToHost, s));
+    if (tp) TH_CHECK_HIP(hipMemcpyAsync(ctx->h_pixels, ctx->d_pixels, tp, hipMemcpyDeviceToHost, s));
+    TH_CHECK_HIP(hipStreamSynchronize(s));
+    out->total_blobs = tb; out->total_runs = tr; out->total_pixels = tp;
+    ctx->fetched = true;
+    int rc = TREXHIP_OK;
+    for (int i = 0; i < n; ++i)
+        if (ctx->h_info[i].flags) {
+            char buf[160];
+            std::snprintf(buf, sizeof(buf), "frame %d of the batch exceeded capacity (flags=%u, raw runs=%u): raise max_runs/max_blobs/max_pixels",
+                          i, ctx->h_info[i].flags, ctx->h_info[i].n_raw_runs);
+            set_error(buf);
+            rc = TREXHIP_E_CAPACITY;
+        }
+    return rc;
+}
+
+int trexhip_device_view_get(trexhip_ctx* ctx, trexhip_device_view* out) {
+    if (!ctx || !out) { set_error("trexhip_device_view_get: null argument"); return TREXHIP_E_INVALID; }
+    out->frames = ctx->d_info; out->blobs = ctx->d_blobs; out->runs = ctx->d_runs; out->pixels = ctx->d_pixels;
+    out->totals = ctx->d_ctr + ctx->p.max_batch; out->blob_frame = ctx->d_blob_frame;
+    return TREXHIP_OK;
+}
+
+int trexhip_profile_enable(trexhip_ctx* ctx, int32_t on) {
+    if (!ctx) { set_error("null ctx"); return TREXHIP_E_INVALID; }
+    ctx->profiling = on != 0;
+    return TREXHIP_OK;
+}
+
+int trexhip_profile_read(trexhip_ctx* ctx, int32_t stage, double* total_ms, int64_t* launches) {
+    if (!ctx || stage < 0 || stage >= TREXHIP_STAGE_COUNT) { set_error("trexhip_profile_read: bad argument"); return TREXHIP_E_INVALID; }
+    stage_read(ctx, stage);
+    Stage& s = ctx->stages[stage];
+    if (total_ms) *total_ms = s.total_ms;
+    if (launches) *launches = s.launches;
+    return TREXHIP_OK;
+}
+
+int trexhip_profile_reset(trexhip_ctx* ctx) {
+    if (!ctx) { set_error("null ctx"); return TREXHIP_E_INVALID; }
+    for (int i = 0; i < TREXHIP_STAGE_COUNT; ++i) { stage_read(ctx, i); ctx->stages[i].total_ms = 0.0; ctx->stages[i].launches = 0; }
+    return TREXHIP_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,96 @@
+// internal.h -- shared declarations of libtrexhip (not part of the ABI)
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+#include <vector>
+#include "../../include/trexhip.h"
+
+namespace trexhip {
+
+void set_error(const std::string& msg);
+
+#define TH_CHECK_HIP(expr)                                                                    \
+    do {                                                                                      \
+        hipError_t _e = (expr);                                                               \
+        if (_e != hipSuccess) {                                                               \
+            ::trexhip::set_error(std::string(#expr) + ": " + hipGetErrorString(_e));          \
+            return TREXHIP_E_DEVICE;                                                          \
+        }                                                                                     \
+    } while (0)
+
+// wave-uniform constants handed to every segment kernel by value
+struct SegCfg {
+    int W, H, B;          // frame size, frames in this launch
+    int R;                // raw run capacity per frame
+    int tmin;             // smallest difference value that passes the threshold
+    int tmax;             // largest passing value (255 unless threshold_maximum < 255)
+    int enable_diff, absdiff, invert, zero_bg;
+    int slack;            // 1 for 8-connectivity, 0 for 4
+    int n_ranges;
+    float sqcm;
+    double ranges[16];
+    uint32_t pool_blobs, pool_runs, pool_pixels;
+};
+
+// live kernel timing: event pairs are recorded on the ctx stream and only read (folded) on
+// trexhip_profile_read, so enabling profiling never adds a host sync to the timed region
+struct EvPair { hipEvent_t a = nullptr, b = nullptr; };
+struct Stage {
+    std::vector<EvPair> pending, freelist;
+    EvPair cur;
+    double total_ms = 0.0;
+    int64_t launches = 0;
+};
+
+}  // namespace trexhip
+
+struct trexhip_ctx {
+    trexhip_params p;
+    trexhip::SegCfg cfg;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;
+    bool has_bg = false;
+    int last_n = 0;
+    bool fetched = true;
+
+    // device memory (layout: DESIGN.md "Data layout in HBM")
+    uint8_t* d_bg = nullptr;
+    uint8_t* d_staging = nullptr;       // frames uploaded by the host-pointer API
+    const uint8_t* d_frames = nullptr;  // frames of the last segment call
+    uint32_t* d_ctr = nullptr;          // [B] per-frame tmp allocation counters + [4] pooled totals
+    uint32_t* d_row_cnt = nullptr;      // [B*H]
+    uint32_t* d_row_off = nullptr;      // [B*H]   offset of the row's runs in tmp order
+    uint32_t* d_row_base = nullptr;     // [B*(H+1)] exclusive scan of row_cnt = raster index
+    uint32_t* d_tmp_runs = nullptr;     // [B*R]   x0 | x1 << 16, allocation order
+    trexhip_run* d_raster = nullptr;    // [B*R]   runs in raster order
+    uint32_t* d_parent = nullptr;       // [B*R]   union-find parent -> root label
+    uint32_t* d_root_ord = nullptr;     // [B*R]   ordinal of the raw blob rooted at run r
+    uint32_t* d_cnt_runs = nullptr;     // [B*R]   per raw blob
+    uint32_t* d_cnt_px = nullptr;       // [B*R]
+    uint32_t* d_cur_run = nullptr;      // [B*R]   frame-relative run cursor per raw blob
+    uint32_t* d_pix_begin = nullptr;    // [B*R]   frame-relative pixel begin per raw blob
+    int32_t* d_blob_map = nullptr;      // [B*R]   raw blob ordinal -> kept index or -1
+    trexhip_frame_info* d_info = nullptr;  // [B]
+    trexhip_blob* d_blobs = nullptr;       // [B*NB] pooled
+    uint32_t* d_blob_frame = nullptr;      // [B*NB]
+    trexhip_run* d_runs = nullptr;         // [B*R] pooled, grouped by blob
+    uint8_t* d_pixels = nullptr;           // [B*P] pooled
+
+    // pinned host mirrors for trexhip_fetch
+    trexhip_frame_info* h_info = nullptr;
+    uint32_t* h_totals = nullptr;
+    trexhip_blob* h_blobs = nullptr;
+    trexhip_run* h_runs = nullptr;
+    uint8_t* h_pixels = nullptr;
+    uint8_t* h_staging = nullptr;       // pinned upload buffer
+
+    bool profiling = false;
+    trexhip::Stage stages[TREXHIP_STAGE_COUNT];
+};
+
+namespace trexhip {
+int launch_segment(trexhip_ctx* ctx, const uint8_t* d_frames, int n);
+void stage_begin(trexhip_ctx* ctx, int stage);
+void stage_end(trexhip_ctx* ctx, int stage);
+}

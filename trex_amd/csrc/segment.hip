@@ -1,0 +1,627 @@
+// segment.hip -- detect stage on gfx950: background subtraction + threshold + horizontal-line
+// extraction + connected components + size filter + blob gather.
+//
+// Replaces the body of BackgroundSubtraction::apply (reference:
+// Application/src/tracker/python/BackgroundSubtraction.cpp:146-316), i.e.
+// RawProcessing::generate_binary (:209) and CPULabeling::run (:216) plus the size filter (:245-291).
+//
+// Design (DESIGN.md "Kernels"): ONE streaming pass over the pixels (k_rows), everything after it
+// works on horizontal lines ("runs"), which are ~1000x fewer than pixels:
+//
+//   k_rows      1 wave = 1 image row; 16 B/lane coalesced loads of frame and background,
+//               v_sad_u8 reject of 4-pixel groups, per-lane 16-bit masks, run starts/ends by
+//               bit tricks + wave prefix sum, one atomic per row to reserve output space
+//   k_rowscan   per frame exclusive scan of runs-per-row  -> raster index of every row
+//   k_link      per row: copy runs to raster order, union with the touching runs of the row above
+//   k_flatten   per row: parent -> root label
+//   k_blobs     per frame: number blobs in raster order, count, size-filter, reserve pooled
+//               output, stable scatter of the runs into per-blob sorted lists
+//   k_gather    1 wave = 1 kept blob: gather grey values, bounding box, integer moments, bid
+#include "internal.h"
+
+namespace trexhip {
+
+static constexpr int WAVE = 64;
+
+__device__ __forceinline__ uint32_t lane_id() { return threadIdx.x & 63; }
+
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v) {
+    const uint32_t lane = lane_id();
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        uint32_t t = __shfl_up(v, d);
+        if (lane >= (uint32_t)d) v += t;
+    }
+    return v;
+}
+
+// exclusive scan over a 256-thread block; lds must hold >= 8 uint32
+__device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t* lds, uint32_t& total) {
+    const uint32_t lane = lane_id(), wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    uint32_t incl = wave_incl_scan(v);
+    __syncthreads();                       // lds reuse
+    if (lane == 63) lds[wave] = incl;
+    __syncthreads();
+    uint32_t off = 0, tot = 0;
+    for (uint32_t w = 0; w < nw; ++w) {
+        uint32_t s = lds[w];
+        if (w < wave) off += s;
+        tot += s;
+    }
+    total = tot;
+    return off + incl - v;
+}
+
+__device__ __forceinline__ uint32_t ld_relaxed(const uint32_t* p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_rows
+// ---------------------------------------------------------------------------------------------
+
+// exact per-pixel decision for one 32-bit word (4 pixels); a is already inverted when image_invert
+__device__ __forceinline__ uint32_t exact4(uint32_t a, uint32_t b, const SegCfg& c) {
+    uint32_t m = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int px = (a >> (8 * i)) & 0xff;
+        const int bg = (b >> (8 * i)) & 0xff;
+        int d;
+        if (!c.enable_diff) d = px;
+        else if (c.absdiff) d = abs(bg - px);
+        else d = max(bg - px, 0);
+        bool pass = d >= c.tmin && d <= c.tmax;
+        if (c.zero_bg) pass = pass && px != 0;
+        m |= (uint32_t)pass << i;
+    }
+    return m;
+}
+
+// 16 pixels of one lane -> 16-bit foreground mask.  A 4-pixel word is only evaluated exactly when
+// the sum of its absolute differences (one v_sad_u8) could reach the threshold.
+__device__ __forceinline__ uint32_t mask16(uint4 a, uint4 b, const SegCfg& c) {
+    if (c.invert) { a.x = ~a.x; a.y = ~a.y; a.z = ~a.z; a.w = ~a.w; }
+    if (!c.enable_diff) { b.x = b.y = b.z = b.w = 0; }
+    const uint32_t s0 = __builtin_amdgcn_sad_u8(a.x, b.x, 0u);
+    const uint32_t s1 = __builtin_amdgcn_sad_u8(a.y, b.y, 0u);
+    const uint32_t s2 = __builtin_amdgcn_sad_u8(a.z, b.z, 0u);
+    const uint32_t s3 = __builtin_amdgcn_sad_u8(a.w, b.w, 0u);
+    const uint32_t t = (uint32_t)c.tmin;
+    uint32_t m = 0;
+    if (max(max(s0, s1), max(s2, s3)) >= t) {
+        if (s0 >= t) m |= exact4(a.x, b.x, c);
+        if (s1 >= t) m |= exact4(a.y, b.y, c) << 4;
+        if (s2 >= t) m |= exact4(a.z, b.z, c) << 8;
+        if (s3 >= t) m |= exact4(a.w, b.w, c) << 12;
+    }
+    return m;
+}
+
+template <bool ALIGNED>
+__device__ __forceinline__ uint4 load16(const uint8_t* p, int x, int W) {
+    if (ALIGNED) {
+        return *reinterpret_cast<const uint4*>(p + x);
+    } else {
+        uint32_t w[4] = {0, 0, 0, 0};
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+            if (x + i < W) w[i >> 2] |= (uint32_t)p[x + i] << (8 * (i & 3));
+        return make_uint4(w[0], w[1], w[2], w[3]);
+    }
+}
+
+template <int NCH, bool ALIGNED>
+__global__ __launch_bounds__(256) void k_rows(const uint8_t* __restrict__ frames,
+                                              const uint8_t* __restrict__ bg, const SegCfg c,
+                                              uint32_t* __restrict__ frame_ctr,
+                                              uint32_t* __restrict__ row_cnt,
+                                              uint32_t* __restrict__ row_off,
+                                              uint32_t* __restrict__ tmp_runs) {
+    const int lane = lane_id();
+    const int wave = threadIdx.x >> 6;
+    // frame index fastest: blocks that run together read the same background rows (L2 / MALL hits)
+    const int f = blockIdx.x % c.B;
+    const int y = (blockIdx.x / c.B) * 4 + wave;
+    if (y >= c.H) return;
+    const int W = c.W;
+    const uint8_t* fp = frames + ((size_t)f * c.H + y) * W;
+    const uint8_t* bp = bg + (size_t)y * W;
+
+    uint4 a[NCH], b[NCH];
+#pragma unroll
+    for (int ch = 0; ch < NCH; ++ch) {
+        const int x = ch * 1024 + lane * 16;
+        if (x < W) {
+            a[ch] = load16<ALIGNED>(fp, x, W);
+            b[ch] = load16<ALIGNED>(bp, x, W);
+        } else {
+            a[ch] = make_uint4(0, 0, 0, 0);
+            b[ch] = make_uint4(0, 0, 0, 0);
+        }
+    }
+    uint32_t m[NCH];
+    bool any = false;
+#pragma unroll
+    for (int ch = 0; ch < NCH; ++ch) {
+        const int x = ch * 1024 + lane * 16;
+        uint32_t mm = 0;
+        if (x < W) {
+            mm = mask16(a[ch], b[ch], c);
+            if (!ALIGNED && x + 16 > W) mm &= (1u << (W - x)) - 1u;
+        }
+        m[ch] = mm;
+        any |= mm != 0;
+    }
+    const size_t ri = (size_t)f * c.H + y;
+    if (!__any(any)) {                       // most rows: no foreground at all
+        if (lane == 0) { row_cnt[ri] = 0; row_off[ri] = 0; }
+        return;
+    }
+
+    // run starts / ends per chunk.  bit j of en = "a run ended at pixel j-1".
+    uint32_t st[NCH], en[NCH], pre[NCH];     // pre = exclusive prefix (starts | ends << 16) incl. earlier chunks
+    uint32_t carry = 0, tot = 0;             // carry: last pixel of previous chunk set; tot: packed row totals
+#pragma unroll
+    for (int ch = 0; ch < NCH; ++ch) {
+        const uint32_t mm = m[ch];
+        if (__ballot(mm != 0) == 0 && carry == 0) { st[ch] = 0; en[ch] = 0; pre[ch] = tot; continue; }
+        uint32_t up = __shfl_up(mm >> 15, 1);
+        if (lane == 0) up = carry;
+        const uint32_t prevmask = ((mm << 1) | (up & 1u)) & 0xffffu;
+        const uint32_t s = mm & ~prevmask;
+        const uint32_t e = ~mm & prevmask;
+        const uint32_t v = __popc(s) | (__popc(e) << 16);
+        const uint32_t incl = wave_incl_scan(v);
+        st[ch] = s; en[ch] = e; pre[ch] = tot + incl - v;
+        tot += __shfl(incl, 63);
+        carry = __shfl(mm >> 15, 63) & 1u;
+    }
+    const uint32_t n_starts = tot & 0xffffu;     // runs in this row (== ends + carry)
+    uint32_t base = 0;
+    if (lane == 0) base = atomicAdd(&frame_ctr[f], n_starts);
+    base = __shfl(base, 0);
+    if (lane == 0) { row_cnt[ri] = n_starts; row_off[ri] = base; }
+    uint16_t* out = reinterpret_cast<uint16_t*>(tmp_runs + (size_t)f * c.R);
+    const uint32_t R = (uint32_t)c.R;
+#pragma unroll
+    for (int ch = 0; ch < NCH; ++ch) {
+        const int xb = ch * 1024 + lane * 16;
+        uint32_t s = st[ch], e = en[ch];
+        uint32_t ks = base + (pre[ch] & 0xffffu), ke = base + (pre[ch] >> 16);
+        while (s) {
+            const int j = __ffs(s) - 1; s &= s - 1;
+            if (ks < R) out[2 * ks] = (uint16_t)(xb + j);
+            ++ks;
+        }
+        while (e) {
+            const int j = __ffs(e) - 1; e &= e - 1;
+            if (ke < R) out[2 * ke + 1] = (uint16_t)(xb + j - 1);
+            ++ke;
+        }
+    }
+    if (carry && lane == 0) {                // run open at the end of the row closes at W-1
+        const uint32_t ke = base + (tot >> 16);
+        if (ke < R) out[2 * ke + 1] = (uint16_t)(W - 1);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_rowscan: exclusive scan of runs-per-row, parent init
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_rowscan(const SegCfg c, const uint32_t* __restrict__ row_cnt,
+                                                 uint32_t* __restrict__ row_base,
+                                                 uint32_t* __restrict__ parent,
+                                                 trexhip_frame_info* __restrict__ info) {
+    __shared__ uint32_t lds[8];
+    const int f = blockIdx.x;
+    const uint32_t* cnt = row_cnt + (size_t)f * c.H;
+    uint32_t* rb = row_base + (size_t)f * (c.H + 1);
+    uint32_t running = 0;
+    for (int y0 = 0; y0 < c.H; y0 += 256) {
+        const int y = y0 + threadIdx.x;
+        const uint32_t v = y < c.H ? cnt[y] : 0;
+        uint32_t total;
+        const uint32_t ex = block_excl_scan(v, lds, total);
+        if (y < c.H) rb[y] = running + ex;
+        running += total;
+    }
+    const uint32_t n = running;
+    const bool overflow = n > (uint32_t)c.R;
+    if (threadIdx.x == 0) {
+        rb[c.H] = n;
+        trexhip_frame_info fi = {};
+        fi.n_raw_runs = n;
+        fi.flags = overflow ? TREXHIP_FRAME_OVERFLOW_RUNS : 0u;
+        info[f] = fi;
+    }
+    if (!overflow) {
+        uint32_t* p = parent + (size_t)f * c.R;
+        for (uint32_t r = threadIdx.x; r < n; r += 256) p[r] = r;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// union-find on run indices (root = smallest raster index of the component)
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t uf_find(const uint32_t* parent, uint32_t a) {
+    uint32_t p = ld_relaxed(parent + a);
+    while (p != a) { a = p; p = ld_relaxed(parent + a); }
+    return a;
+}
+__device__ __forceinline__ void uf_union(uint32_t* parent, uint32_t a, uint32_t b) {
+    for (;;) {
+        a = uf_find(parent, a);
+        b = uf_find(parent, b);
+        if (a == b) return;
+        if (a > b) { const uint32_t t = a; a = b; b = t; }
+        const uint32_t old = atomicMin(parent + b, a);   // hook the larger root under the smaller
+        if (old == b) return;
+        b = old;                                         // b was hooked meanwhile: merge its parent too
+    }
+}
+
+// one thread = one image row: copy its runs to raster order, link with the row above
+__global__ __launch_bounds__(256) void k_link(const SegCfg c, const uint32_t* __restrict__ row_cnt,
+                                              const uint32_t* __restrict__ row_off,
+                                              const uint32_t* __restrict__ row_base,
+                                              const uint32_t* __restrict__ tmp_runs,
+                                              trexhip_run* __restrict__ raster, uint32_t* __restrict__ parent,
+                                              const trexhip_frame_info* __restrict__ info) {
+    const int gid = blockIdx.x * 256 + threadIdx.x;
+    if (gid >= c.B * c.H) return;
+    const int f = gid / c.H, y = gid - f * c.H;
+    if (info[f].flags) return;
+    const size_t ri = (size_t)f * c.H + y;
+    const uint32_t cnt = row_cnt[ri];
+    if (!cnt) return;
+    const uint32_t* tmp = tmp_runs + (size_t)f * c.R;
+    const uint32_t off = row_off[ri];
+    const uint32_t base = row_base[(size_t)f * (c.H + 1) + y];
+    trexhip_run* rr = raster + (size_t)f * c.R;
+    for (uint32_t i = 0; i < cnt; ++i) {
+        const uint32_t t = tmp[off + i];
+        trexhip_run r; r.x0 = (uint16_t)(t & 0xffffu); r.x1 = (uint16_t)(t >> 16); r.y = (uint16_t)y; r.pad = 0;
+        rr[base + i] = r;
+    }
+    if (y == 0) return;
+    const uint32_t pcnt = row_cnt[ri - 1];
+    if (!pcnt) return;
+    const uint32_t poff = row_off[ri - 1];
+    const uint32_t pbase = row_base[(size_t)f * (c.H + 1) + y - 1];
+    uint32_t* par = parent + (size_t)f * c.R;
+    uint32_t i = 0, j = 0;
+    uint32_t cur = tmp[off], prv = tmp[poff];
+    const int slack = c.slack;
+    for (;;) {
+        const int c0 = cur & 0xffffu, c1 = cur >> 16, p0 = prv & 0xffffu, p1 = prv >> 16;
+        if (p1 + slack >= c0 && c1 + slack >= p0) uf_union(par, pbase + j, base + i);
+        if (p1 < c1) { if (++j >= pcnt) break; prv = tmp[poff + j]; }
+        else         { if (++i >= cnt) break;  cur = tmp[off + i]; }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_flatten(const SegCfg c, const uint32_t* __restrict__ row_cnt,
+                                                 const uint32_t* __restrict__ row_base,
+                                                 uint32_t* __restrict__ parent,
+                                                 const trexhip_frame_info* __restrict__ info) {
+    const int gid = blockIdx.x * 256 + threadIdx.x;
+    if (gid >= c.B * c.H) return;
+    const int f = gid / c.H, y = gid - f * c.H;
+    if (info[f].flags) return;
+    const uint32_t cnt = row_cnt[(size_t)f * c.H + y];
+    if (!cnt) return;
+    const uint32_t base = row_base[(size_t)f * (c.H + 1) + y];
+    uint32_t* par = parent + (size_t)f * c.R;
+    for (uint32_t i = 0; i < cnt; ++i) {
+        const uint32_t root = uf_find(par, base + i);
+        __hip_atomic_store(par + base + i, root, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_blobs: one block per frame
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ bool size_ok(uint32_t npx, const SegCfg& c) {
+    if (c.n_ranges <= 0) return true;                       // SizeFilters.cpp:38
+    const double v = (double)((float)npx * c.sqcm);         // BackgroundSubtraction.cpp:139,259
+    for (int i = 0; i < c.n_ranges; ++i)
+        if (v >= c.ranges[2 * i] && v < c.ranges[2 * i + 1]) return true;
+    return false;
+}
+
+static constexpr int CURSOR_LDS = 8192;   // kept-blob run cursors held in LDS (else global)
+
+__global__ __launch_bounds__(256) void k_blobs(const SegCfg c, const trexhip_run* __restrict__ raster,
+                                               const uint32_t* __restrict__ parent,
+                                               uint32_t* __restrict__ root_ord, uint32_t* __restrict__ cnt_runs,
+                                               uint32_t* __restrict__ cnt_px, uint32_t* __restrict__ cur_run,
+                                               uint32_t* __restrict__ pix_begin, int32_t* __restrict__ blob_map, uint32_t* __restrict__ totals,
+                                               trexhip_frame_info* __restrict__ info,
+                                               trexhip_blob* __restrict__ blobs, uint32_t* __restrict__ blob_frame,
+                                               trexhip_run* __restrict__ out_runs) {
+    __shared__ uint32_t lds[8];
+    __shared__ uint32_t s_alloc[4];
+    __shared__ uint32_t s_cursor[CURSOR_LDS];
+    const int f = blockIdx.x;
+    const int tid = threadIdx.x;
+    trexhip_frame_info fi = info[f];
+    if (fi.flags) return;
+    const uint32_t n = fi.n_raw_runs;
+    const size_t fo = (size_t)f * c.R;
+    const trexhip_run* rr = raster + fo;
+    const uint32_t* lab = parent + fo;
+    uint32_t* ord = root_ord + fo;
+    uint32_t* cr = cnt_runs + fo;
+    uint32_t* cp = cnt_px + fo;
+    uint32_t* cur = cur_run + fo;
+    uint32_t* pbg = pix_begin + fo;
+    int32_t* bmap = blob_map + fo;
+
+    // A: ordinal of every raw blob = rank of its root run in raster order
+    uint32_t nraw = 0;
+    for (uint32_t b0 = 0; b0 < n; b0 += 256) {
+        const uint32_t r = b0 + tid;
+        const uint32_t flag = (r < n && lab[r] == r) ? 1u : 0u;
+        uint32_t total;
+        const uint32_t ex = block_excl_scan(flag, lds, total);
+        if (flag) ord[r] = nraw + ex;
+        nraw += total;
+    }
+    // counters live in L2 (atomics): zero them with L1-bypassing stores and drain before the barrier
+    for (uint32_t o = tid; o < nraw; o += 256) {
+        __hip_atomic_store(cr + o, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(cp + o, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    // B: runs / pixels per raw blob
+    for (uint32_t r = tid; r < n; r += 256) {
+        const uint32_t o = ord[lab[r]];
+        const trexhip_run q = rr[r];
+        atomicAdd(cr + o, 1u);
+        atomicAdd(cp + o, (uint32_t)(q.x1 - q.x0 + 1));
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    // C: size filter (BackgroundSubtraction.cpp:259) + "< UINT16_MAX lines" (:306); offsets of kept blobs
+    uint32_t kept = 0, kruns = 0, kpx = 0;
+    for (uint32_t b0 = 0; b0 < nraw; b0 += 256) {
+        const uint32_t o = b0 + tid;
+        uint32_t nr = 0, np = 0, keep = 0;
+        if (o < nraw) {
+            nr = ld_relaxed(cr + o); np = ld_relaxed(cp + o);
+            keep = (size_ok(np, c) && nr < 65535u) ? 1u : 0u;
+        }
+        uint32_t t0, t1, t2;
+        const uint32_t e0 = block_excl_scan(keep, lds, t0);
+        const uint32_t e1 = block_excl_scan(keep ? nr : 0u, lds, t1);
+        const uint32_t e2 = block_excl_scan(keep ? np : 0u, lds, t2);
+        if (o < nraw) {
+            bmap[o] = keep ? (int32_t)(kept + e0) : -1;
+            if (keep) { cur[o] = kruns + e1; pbg[o] = kpx + e2; }
+        }
+        kept += t0; kruns += t1; kpx += t2;
+    }
+    // reserve pooled output (blobs, runs, pixels) for this frame
+    if (tid == 0) {
+        const uint32_t bb = atomicAdd(totals + 0, kept);
+        const uint32_t rb = atomicAdd(totals + 1, kruns);
+        const uint32_t pb = atomicAdd(totals + 2, kpx);
+        const bool over = bb + kept > c.pool_blobs || rb + kruns > c.pool_runs || pb + kpx > c.pool_pixels;
+        s_alloc[0] = bb; s_alloc[1] = rb; s_alloc[2] = pb; s_alloc[3] = over ? 1u : 0u;
+    }
+    __syncthreads();
+    const uint32_t bb = s_alloc[0], rb = s_alloc[1], pb = s_alloc[2];
+    fi.n_raw_blobs = nraw;
+    if (s_alloc[3]) {
+        if (tid == 0) { fi.flags |= TREXHIP_FRAME_OVERFLOW_OUTPUT; info[f] = fi; }
+        return;
+    }
+    // blob records (counts / offsets; k_gather fills the rest)
+    for (uint32_t o = tid; o < nraw; o += 256) {
+        const int32_t k = bmap[o];
+        if (k < 0) continue;
+        trexhip_blob B = {};
+        B.run_begin = cur[o];
+        B.n_runs = ld_relaxed(cr + o);
+        B.pix_begin = pbg[o];
+        blobs[bb + k] = B;
+        blob_frame[bb + k] = (uint32_t)f;
+    }
+    const bool lds_cursor = kept <= (uint32_t)CURSOR_LDS;
+    if (lds_cursor)
+        for (uint32_t o = tid; o < nraw; o += 256) {
+            const int32_t k = bmap[o];
+            if (k >= 0) s_cursor[k] = cur[o];
+        }
+    __threadfence_block();
+    __syncthreads();
+    // D: stable scatter -- one wave walks the runs in raster order, 64 at a time; lanes of the same
+    // blob are grouped by ballot so every run gets (cursor of its blob) + (rank inside the group)
+    if (tid < 64) {
+        const uint32_t lane = tid;
+        trexhip_run* outr = out_runs + rb;
+        for (uint32_t b0 = 0; b0 < n; b0 += 64) {
+            const uint32_t r = b0 + lane;
+            int32_t k = -1; uint32_t o = 0;
+            trexhip_run q = {};
+            if (r < n) { o = ord[lab[r]]; k = bmap[o]; q = rr[r]; }
+            const bool active = k >= 0;
+            uint64_t remaining = __ballot(active);
+            uint32_t rank = 0, gsize = 0, leader = lane;
+            while (remaining) {
+                const int l = __ffsll((unsigned long long)remaining) - 1;
+                const int32_t lk = __shfl(k, l);
+                const uint64_t grp = __ballot(active && k == lk);
+                if (active && k == lk) {
+                    rank = __popcll(grp & ((1ull << lane) - 1ull));
+                    gsize = __popcll(grp);
+                    leader = (uint32_t)l;
+                }
+                remaining &= ~grp;
+            }
+            uint32_t pos = 0;
+            if (active && leader == lane) {
+                if (lds_cursor) { pos = s_cursor[k]; s_cursor[k] = pos + gsize; }
+                else            { pos = cur[o];      cur[o] = pos + gsize; }
+            }
+            pos = __shfl(pos, leader);
+            if (active) outr[pos + rank] = q;
+        }
+    }
+    if (tid == 0) {
+        fi.n_blobs = kept; fi.n_runs = kruns; fi.n_pixels = kpx;
+        fi.blob_begin = bb; fi.run_begin = rb; fi.pix_begin = pb;
+        info[f] = fi;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_gather: one wave per kept blob
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint64_t wave_sum64(uint64_t v) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        uint32_t lo = __shfl_xor((uint32_t)v, d), hi = __shfl_xor((uint32_t)(v >> 32), d);
+        v += ((uint64_t)hi << 32) | lo;
+    }
+    return v;
+}
+__device__ __forceinline__ uint32_t wave_min32(uint32_t v) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v = min(v, (uint32_t)__shfl_xor(v, d));
+    return v;
+}
+__device__ __forceinline__ uint32_t wave_max32(uint32_t v) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v = max(v, (uint32_t)__shfl_xor(v, d));
+    return v;
+}
+
+__device__ __forceinline__ uint32_t make_bid(uint32_t x0, uint32_t x1, uint32_t y, uint32_t n) {
+    // pv::bid (commons): 13/13/6 bit hash of the first line; verified on the reference's golden CSVs
+    uint32_t x = x0 + (x1 - x0 + 1) / 2;
+    x = min(x, 8191u); y = min(y, 8191u);
+    n = n < 1u ? 1u : min(n, 63u);
+    return (x << 19) | (y << 6) | n;
+}
+
+__global__ __launch_bounds__(256) void k_gather(const SegCfg c, const uint8_t* __restrict__ frames,
+                                                const uint32_t* __restrict__ totals,
+                                                const trexhip_frame_info* __restrict__ info,
+                                                const uint32_t* __restrict__ blob_frame,
+                                                trexhip_blob* __restrict__ blobs,
+                                                const trexhip_run* __restrict__ runs,
+                                                uint8_t* __restrict__ pixels) {
+    const uint32_t lane = lane_id();
+    const uint32_t nwaves = gridDim.x * 4;
+    const uint32_t total = min(totals[0], c.pool_blobs);
+    for (uint32_t bi = blockIdx.x * 4 + (threadIdx.x >> 6); bi < total; bi += nwaves) {
+        const uint32_t f = blob_frame[bi];
+        const trexhip_frame_info fi = info[f];
+        if (fi.flags) continue;
+        trexhip_blob B = blobs[bi];
+        const trexhip_run* rr = runs + fi.run_begin + B.run_begin;
+        uint8_t* px = pixels + fi.pix_begin + B.pix_begin;
+        const uint8_t* img = frames + (size_t)f * c.H * c.W;
+        uint64_t m10 = 0, m01 = 0, m20 = 0, m11 = 0, m02 = 0, sp = 0, spx = 0, spy = 0;
+        uint32_t x0 = 0xffff, x1 = 0, y0 = 0xffff, y1 = 0, pmin = 255, pmax = 0, po = 0;
+        for (uint32_t b0 = 0; b0 < B.n_runs; b0 += 64) {
+            const uint32_t i = b0 + lane;
+            trexhip_run q = {};
+            uint32_t len = 0;
+            if (i < B.n_runs) { q = rr[i]; len = (uint32_t)(q.x1 - q.x0 + 1); }
+            const uint32_t incl = wave_incl_scan(len);
+            uint32_t off = po + incl - len;
+            po += __shfl(incl, 63);
+            if (len) {
+                x0 = min(x0, (uint32_t)q.x0); x1 = max(x1, (uint32_t)q.x1);
+                y0 = min(y0, (uint32_t)q.y);  y1 = max(y1, (uint32_t)q.y);
+                const uint8_t* src = img + (size_t)q.y * c.W;
+                const uint64_t y = q.y;
+                uint64_t rp = 0;                                       // sum of grey values of this run
+                for (uint32_t x = q.x0; x <= q.x1; ++x) {
+                    uint32_t p = src[x];
+                    if (c.invert) p = 255u - p;
+                    px[off++] = (uint8_t)p;
+                    m10 += x; m20 += (uint64_t)x * x;
+                    rp += p; spx += (uint64_t)p * x;
+                    pmin = min(pmin, p); pmax = max(pmax, p);
+                }
+                const uint64_t L = len;
+                const uint64_t sx = (uint64_t)(q.x0 + q.x1) * L / 2;   // sum of x over the run
+                m01 += y * L; m02 += y * y * L; m11 += y * sx;
+                sp += rp; spy += rp * y;
+            }
+        }
+        m10 = wave_sum64(m10); m01 = wave_sum64(m01); m20 = wave_sum64(m20); m11 = wave_sum64(m11);
+        m02 = wave_sum64(m02); sp = wave_sum64(sp); spx = wave_sum64(spx); spy = wave_sum64(spy);
+        x0 = wave_min32(x0); y0 = wave_min32(y0); x1 = wave_max32(x1); y1 = wave_max32(y1);
+        pmin = wave_min32(pmin); pmax = wave_max32(pmax);
+        if (lane == 0) {
+            const trexhip_run first = rr[0];
+            B.n_pixels = po;
+            B.x0 = (uint16_t)x0; B.y0 = (uint16_t)y0; B.x1 = (uint16_t)x1; B.y1 = (uint16_t)y1;
+            B.bid = make_bid(first.x0, first.x1, first.y, B.n_runs);
+            B.px_min_max = pmin | (pmax << 8);
+            B.m10 = m10; B.m01 = m01; B.m20 = m20; B.m11 = m11; B.m02 = m02;
+            B.sp = sp; B.spx = spx; B.spy = spy;
+            blobs[bi] = B;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// host side launch
+// ---------------------------------------------------------------------------------------------
+template <bool ALIGNED>
+static void launch_rows(int nch, dim3 grid, hipStream_t s, const uint8_t* frames, const uint8_t* bg,
+                        const SegCfg& c, uint32_t* ctr, uint32_t* row_cnt, uint32_t* row_off, uint32_t* tmp) {
+    switch (nch) {
+        case 1: hipLaunchKernelGGL((k_rows<1, ALIGNED>), grid, dim3(256), 0, s, frames, bg, c, ctr, row_cnt, row_off, tmp); break;
+        case 2: hipLaunchKernelGGL((k_rows<2, ALIGNED>), grid, dim3(256), 0, s, frames, bg, c, ctr, row_cnt, row_off, tmp); break;
+        case 3: hipLaunchKernelGGL((k_rows<3, ALIGNED>), grid, dim3(256), 0, s, frames, bg, c, ctr, row_cnt, row_off, tmp); break;
+        case 4: hipLaunchKernelGGL((k_rows<4, ALIGNED>), grid, dim3(256), 0, s, frames, bg, c, ctr, row_cnt, row_off, tmp); break;
+        case 5: case 6:
+                hipLaunchKernelGGL((k_rows<6, ALIGNED>), grid, dim3(256), 0, s, frames, bg, c, ctr, row_cnt, row_off, tmp); break;
+        default: hipLaunchKernelGGL((k_rows<8, ALIGNED>), grid, dim3(256), 0, s, frames, bg, c, ctr, row_cnt, row_off, tmp); break;
+    }
+}
+
+int launch_segment(trexhip_ctx* ctx, const uint8_t* d_frames, int n) {
+    SegCfg c = ctx->cfg;
+    c.B = n;
+    hipStream_t s = ctx->stream;
+    const int H = c.H, W = c.W;
+    const int nch = (W + 1023) / 1024;
+    if (nch > 8) { set_error("frame width > 8192 is not supported yet"); return TREXHIP_E_UNSUPPORTED; }
+    stage_begin(ctx, TREXHIP_STAGE_SEGMENT_ALL);
+    TH_CHECK_HIP(hipMemsetAsync(ctx->d_ctr, 0, sizeof(uint32_t) * (ctx->p.max_batch + 4), s));
+    const dim3 grid_rows((unsigned)(((H + 3) / 4) * n));
+    const bool aligned = (W % 16 == 0) && ((reinterpret_cast<uintptr_t>(d_frames) & 15) == 0) &&
+                         ((reinterpret_cast<uintptr_t>(ctx->d_bg) & 15) == 0);
+    stage_begin(ctx, TREXHIP_STAGE_ROWS);
+    if (aligned) launch_rows<true>(nch, grid_rows, s, d_frames, ctx->d_bg, c, ctx->d_ctr, ctx->d_row_cnt, ctx->d_row_off, ctx->d_tmp_runs);
+    else         launch_rows<false>(nch, grid_rows, s, d_frames, ctx->d_bg, c, ctx->d_ctr, ctx->d_row_cnt, ctx->d_row_off, ctx->d_tmp_runs);
+    stage_end(ctx, TREXHIP_STAGE_ROWS);
+    hipLaunchKernelGGL(k_rowscan, dim3(n), dim3(256), 0, s, c, ctx->d_row_cnt, ctx->d_row_base, ctx->d_parent, ctx->d_info);
+    const dim3 grid_r((unsigned)((n * H + 255) / 256));
+    hipLaunchKernelGGL(k_link, grid_r, dim3(256), 0, s, c, ctx->d_row_cnt, ctx->d_row_off, ctx->d_row_base,
+                       ctx->d_tmp_runs, ctx->d_raster, ctx->d_parent, ctx->d_info);
+    hipLaunchKernelGGL(k_flatten, grid_r, dim3(256), 0, s, c, ctx->d_row_cnt, ctx->d_row_base, ctx->d_parent, ctx->d_info);
+    uint32_t* totals = ctx->d_ctr + ctx->p.max_batch;
+    hipLaunchKernelGGL(k_blobs, dim3(n), dim3(256), 0, s, c, ctx->d_raster, ctx->d_parent, ctx->d_root_ord,
+                       ctx->d_cnt_runs, ctx->d_cnt_px, ctx->d_cur_run, ctx->d_pix_begin, ctx->d_blob_map, totals, ctx->d_info,
+                       ctx->d_blobs, ctx->d_blob_frame, ctx->d_runs);
+    hipLaunchKernelGGL(k_gather, dim3(1024), dim3(256), 0, s, c, d_frames, totals, ctx->d_info, ctx->d_blob_frame,
+                       ctx->d_blobs, ctx->d_runs, ctx->d_pixels);
+    stage_end(ctx, TREXHIP_STAGE_SEGMENT_ALL);
+    TH_CHECK_HIP(hipGetLastError());
+    ctx->d_frames = d_frames;
+    ctx->last_n = n;
+    ctx->fetched = false;
+    return TREXHIP_OK;
+}
+
+}  // namespace trexhip
