@@ -14,6 +14,7 @@ pytestmark = pytest.mark.gpu
 def run_gpu(frames, bg, device_resident=True, **kw):
     frames = np.ascontiguousarray(frames, np.uint8)
     n, H, W = frames.shape
+    kw.setdefault("max_blobs", 32768)
     p = capi.default_params(W, H, max_batch=max(n, 1), **kw)
     seg = capi.Segmenter(p)
     seg.set_background(bg)
@@ -106,7 +107,7 @@ def test_adversarial_patterns():
     f = bg.copy(); f[:, 1023] = 9; f[:, 1024] = 9; f[5, 1000:1100] = 9; frames.append(f)   # chunk boundary
     f = bg.copy(); f[xx % 3 == 0] = 9; frames.append(f)                           # many 1-px runs per row
     for conn in (8, 4):
-        res = run_gpu(np.stack(frames), bg, connectivity=conn)
+        res = run_gpu(np.stack(frames), bg, connectivity=conn, max_runs=200000)
         for r, fr in zip(res, frames):
             assert_frame_equal(r, fr, bg, connectivity=conn)
     assert len(res[4].blobs) == 0 and res[4].info["n_raw_runs"] == 0

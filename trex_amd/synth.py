@@ -97,3 +97,53 @@ def random_scene(rng, width, height, density=0.02, max_len=12):
     for y, x, l, v in zip(ys, xs, ls, vs):
         fr[y, x:min(width, x + l)] = v
     return fr, bg
+
+
+def batch_torch(name, n_frames, device, t0=0):
+    """Same integer recipe as batch(), evaluated with torch on `device` (used by bench.py to fill HBM
+    with many distinct frames quickly).  Bit-identical to batch() -- tests/test_synth.py."""
+    import torch
+    w, h, nb, cid = CONFIGS[name]
+    bg_np = background(w, h)
+    bg = torch.from_numpy(bg_np).to(device)
+    bg32 = bg.to(torch.int32)
+    out = torch.empty((n_frames, h, w), dtype=torch.uint8, device=device)
+    g = int(math.ceil(math.sqrt(nb)))
+    pitch_x, pitch_y = w / g, h / g
+    idx = torch.arange(w * h, dtype=torch.int64, device=device).reshape(h, w)
+    for t in range(n_frames):
+        tt = t0 + t
+        img = bg32.clone()
+        s = (0x7E3 + 977 * cid + tt) & 0xFFFFFFFF
+        for i in range(nb):
+            s = _lcg(s); jx = ((s >> 4) & 0xFFFF) / 65535.0 - 0.5
+            s = _lcg(s); jy = ((s >> 4) & 0xFFFF) / 65535.0 - 0.5
+            s = _lcg(s); theta = 2.0 * math.pi * ((s >> 8) & 255) / 256.0
+            cx = (i % g + 0.5) * pitch_x + jx * pitch_x * 0.5
+            cy = (i // g + 0.5) * pitch_y + jy * pitch_y * 0.5
+            a, b = 18.0, 5.0
+            r = int(a) + 2
+            x0, x1 = max(0, int(cx) - r), min(w - 1, int(cx) + r)
+            y0, y1 = max(0, int(cy) - r), min(h - 1, int(cy) + r)
+            if x1 < x0 or y1 < y0:
+                continue
+            # the inside test is evaluated in float64 on the host (tiny window) so both generators agree bit for bit
+            xs = np.arange(x0, x1 + 1, dtype=np.float64)[None, :] - cx
+            ys = np.arange(y0, y1 + 1, dtype=np.float64)[:, None] - cy
+            ct, st = math.cos(theta), math.sin(theta)
+            u = xs * ct + ys * st
+            v = -xs * st + ys * ct
+            inside = (u / a) ** 2 + (v / b) ** 2 <= 1.0
+            xi = np.arange(x0, x1 + 1, dtype=np.int32)[None, :]
+            yi = np.arange(y0, y1 + 1, dtype=np.int32)[:, None]
+            val = bg_np[y0:y1 + 1, x0:x1 + 1].astype(np.int32) - 60 - ((xi ^ yi) & 7)
+            sub = img[y0:y1 + 1, x0:x1 + 1]
+            ins = torch.from_numpy(inside).to(device)
+            sub[ins] = torch.from_numpy(val).to(device)[ins]
+        st_ = (idx * 2654435761 + ((0x9E37 + tt * 7919 + cid) & 0xFFFFFFFF)) & 0xFFFFFFFF
+        st_ = (st_ * 1664525 + 1013904223) & 0xFFFFFFFF
+        mag = ((st_ >> 16) & 3).to(torch.int32)
+        sign = torch.where(((st_ >> 20) & 1) == 1, 1, -1).to(torch.int32)
+        img = img + sign * mag
+        out[t] = img.clamp_(0, 255).to(torch.uint8)
+    return out, bg
