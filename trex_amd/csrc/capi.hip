@@ -2,6 +2,7 @@
 #include "internal.h"
 #include <cstdio>
 #include <cstring>
+#include <cstdlib>
 #include <new>
 #include <vector>
 
@@ -73,6 +74,7 @@ static int fill_cfg(trexhip_ctx* ctx) {
     const trexhip_params& p = ctx->p;
     SegCfg& c = ctx->cfg;
     c.W = p.width; c.H = p.height; c.B = p.max_batch; c.R = p.max_runs;
+    c.T = p.height * TREXHIP_ROW_SLOT + p.max_runs;
     const int thr = p.threshold < 0 ? -p.threshold : p.threshold;   // abs(threshold), as the reference does
     if (p.threshold_maximum < 255) { c.tmin = thr; c.tmax = p.threshold_maximum; }   // cv::inRange
     else { c.tmin = p.inclusive ? thr : thr + 1; c.tmax = 255; }                      // cv::threshold is strict
@@ -136,17 +138,19 @@ int trexhip_create(const trexhip_params* p, trexhip_ctx** out) {
     if (!ctx) { set_error("out of host memory"); return TREXHIP_E_NOMEM; }
     ctx->p = *p;
     fill_cfg(ctx);
+    if (const char* e = std::getenv("TREXHIP_ROWS_ORDER")) ctx->tune_rows_order = std::atoi(e);
+    if (const char* e = std::getenv("TREXHIP_ROWS_BLOCKS")) ctx->tune_rows_blocks = std::atoi(e) > 0 ? std::atoi(e) : 2048;
     const size_t B = p->max_batch, H = p->height, W = p->width, R = p->max_runs, NB = p->max_blobs, P = p->max_pixels;
     int rc = TREXHIP_OK;
 #define TRY(x) do { if (rc == TREXHIP_OK) rc = (x); } while (0)
     if (hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking) != hipSuccess) { set_error("hipStreamCreate failed"); delete ctx; return TREXHIP_E_DEVICE; }
     ctx->stream = ctx->own_stream;
     TRY(dmalloc(&ctx->d_bg, H * W + 16));
-    TRY(dmalloc(&ctx->d_ctr, B + 4));
+    TRY(dmalloc(&ctx->d_ctr, B * TREXHIP_CTR_STRIDE + 4));
     TRY(dmalloc(&ctx->d_row_cnt, B * H));
     TRY(dmalloc(&ctx->d_row_off, B * H));
     TRY(dmalloc(&ctx->d_row_base, B * (H + 1)));
-    TRY(dmalloc(&ctx->d_tmp_runs, B * R));
+    TRY(dmalloc(&ctx->d_tmp_runs, B * (H * TREXHIP_ROW_SLOT + R)));
     TRY(dmalloc(&ctx->d_raster, B * R));
     TRY(dmalloc(&ctx->d_parent, B * R));
     TRY(dmalloc(&ctx->d_root_ord, B * R));
@@ -269,7 +273,7 @@ int trexhip_fetch(trexhip_ctx* ctx, trexhip_batch_result* out) {
     if (n == 0) return TREXHIP_OK;
     hipStream_t s = ctx->stream;
     TH_CHECK_HIP(hipMemcpyAsync(ctx->h_info, ctx->d_info, sizeof(trexhip_frame_info) * n, hipMemcpyDeviceToHost, s));
-    TH_CHECK_HIP(hipMemcpyAsync(ctx->h_totals, ctx->d_ctr + ctx->p.max_batch, sizeof(uint32_t) * 4, hipMemcpyDeviceToHost, s));
+    TH_CHECK_HIP(hipMemcpyAsync(ctx->h_totals, ctx->d_ctr + (size_t)ctx->p.max_batch * TREXHIP_CTR_STRIDE, sizeof(uint32_t) * 4, hipMemcpyDeviceToHost, s));
     TH_CHECK_HIP(hipStreamSynchronize(s));
     // frames that overflowed the pool reserved nothing valid; clamp the copies to the pools
     const uint32_t tb = ctx->h_totals[0] < ctx->cfg.pool_blobs ? ctx->h_totals[0] : ctx->cfg.pool_blobs;
@@ -296,7 +300,7 @@ int trexhip_fetch(trexhip_ctx* ctx, trexhip_batch_result* out) {
 int trexhip_device_view_get(trexhip_ctx* ctx, trexhip_device_view* out) {
     if (!ctx || !out) { set_error("trexhip_device_view_get: null argument"); return TREXHIP_E_INVALID; }
     out->frames = ctx->d_info; out->blobs = ctx->d_blobs; out->runs = ctx->d_runs; out->pixels = ctx->d_pixels;
-    out->totals = ctx->d_ctr + ctx->p.max_batch; out->blob_frame = ctx->d_blob_frame;
+    out->totals = ctx->d_ctr + (size_t)ctx->p.max_batch * TREXHIP_CTR_STRIDE; out->blob_frame = ctx->d_blob_frame;
     return TREXHIP_OK;
 }
 

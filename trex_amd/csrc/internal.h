@@ -6,6 +6,9 @@
 #include <vector>
 #include "../../include/trexhip.h"
 
+#define TREXHIP_ROW_SLOT 16
+#define TREXHIP_CTR_STRIDE 32
+
 namespace trexhip {
 
 void set_error(const std::string& msg);
@@ -23,6 +26,7 @@ void set_error(const std::string& msg);
 struct SegCfg {
     int W, H, B;          // frame size, frames in this launch
     int R;                // raw run capacity per frame
+    int T;                // entries per frame in the tmp run array = H*ROW_SLOT + R
     int tmin;             // smallest difference value that passes the threshold
     int tmax;             // largest passing value (255 unless threshold_maximum < 255)
     int enable_diff, absdiff, invert, zero_bg;
@@ -58,11 +62,11 @@ struct trexhip_ctx {
     uint8_t* d_bg = nullptr;
     uint8_t* d_staging = nullptr;       // frames uploaded by the host-pointer API
     const uint8_t* d_frames = nullptr;  // frames of the last segment call
-    uint32_t* d_ctr = nullptr;          // [B] per-frame tmp allocation counters + [4] pooled totals
+    uint32_t* d_ctr = nullptr;          // [B*CTR_STRIDE] per-frame overflow counters (128 B apart) + [4] pooled totals
     uint32_t* d_row_cnt = nullptr;      // [B*H]
     uint32_t* d_row_off = nullptr;      // [B*H]   offset of the row's runs in tmp order
     uint32_t* d_row_base = nullptr;     // [B*(H+1)] exclusive scan of row_cnt = raster index
-    uint32_t* d_tmp_runs = nullptr;     // [B*R]   x0 | x1 << 16, allocation order
+    uint32_t* d_tmp_runs = nullptr;     // [B*T]   x0 | x1 << 16; T = H*ROW_SLOT (row slots) + R (overflow area)
     trexhip_run* d_raster = nullptr;    // [B*R]   runs in raster order
     uint32_t* d_parent = nullptr;       // [B*R]   union-find parent -> root label
     uint32_t* d_root_ord = nullptr;     // [B*R]   ordinal of the raw blob rooted at run r
@@ -86,6 +90,9 @@ struct trexhip_ctx {
     uint8_t* h_staging = nullptr;       // pinned upload buffer
 
     bool profiling = false;
+    // tuning knobs (env TREXHIP_ROWS_ORDER / TREXHIP_ROWS_BLOCKS override the defaults)
+    int tune_rows_order = 1;
+    int tune_rows_blocks = 2048;
     trexhip::Stage stages[TREXHIP_STAGE_COUNT];
 };
 

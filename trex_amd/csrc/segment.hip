@@ -22,6 +22,8 @@
 namespace trexhip {
 
 static constexpr int WAVE = 64;
+static constexpr int ROW_SLOT = TREXHIP_ROW_SLOT;   // runs per row kept in the row's own slot
+static constexpr int CTR_STRIDE = TREXHIP_CTR_STRIDE;   // per-frame counters live 128 B apart
 
 __device__ __forceinline__ uint32_t lane_id() { return threadIdx.x & 63; }
 
@@ -111,105 +113,125 @@ __device__ __forceinline__ uint4 load16(const uint8_t* p, int x, int W) {
     }
 }
 
+// One wave = one image row at a time; waves walk the (frame,row) tasks with a grid stride and
+// prefetch the next row's 16-byte loads before they process the current one.
+//   order 0: frame index fastest (concurrent waves share background rows)
+//   order 1: row index fastest   (each frame is streamed front to back)
 template <int NCH, bool ALIGNED>
 __global__ __launch_bounds__(256) void k_rows(const uint8_t* __restrict__ frames,
-                                              const uint8_t* __restrict__ bg, const SegCfg c,
+                                              const uint8_t* __restrict__ bg, const SegCfg c, const int order,
                                               uint32_t* __restrict__ frame_ctr,
                                               uint32_t* __restrict__ row_cnt,
                                               uint32_t* __restrict__ row_off,
                                               uint32_t* __restrict__ tmp_runs) {
     const int lane = lane_id();
-    const int wave = threadIdx.x >> 6;
-    // frame index fastest: blocks that run together read the same background rows (L2 / MALL hits)
-    const int f = blockIdx.x % c.B;
-    const int y = (blockIdx.x / c.B) * 4 + wave;
-    if (y >= c.H) return;
     const int W = c.W;
-    const uint8_t* fp = frames + ((size_t)f * c.H + y) * W;
-    const uint8_t* bp = bg + (size_t)y * W;
+    const uint32_t ntask = (uint32_t)c.B * (uint32_t)c.H;
+    const uint32_t nwave = gridDim.x * 4u;
+    uint32_t task = blockIdx.x * 4u + (threadIdx.x >> 6);
+    if (task >= ntask) return;
 
     uint4 a[NCH], b[NCH];
+    auto issue = [&](uint32_t t) {
+        const uint32_t f = (order & 1) == 0 ? t % (uint32_t)c.B : t / (uint32_t)c.H;
+        const uint32_t y = (order & 1) == 0 ? t / (uint32_t)c.B : t % (uint32_t)c.H;
+        const uint8_t* fp = frames + ((size_t)f * c.H + y) * W;
+        const uint8_t* bp = bg + (size_t)y * W;
 #pragma unroll
-    for (int ch = 0; ch < NCH; ++ch) {
-        const int x = ch * 1024 + lane * 16;
-        if (x < W) {
-            a[ch] = load16<ALIGNED>(fp, x, W);
-            b[ch] = load16<ALIGNED>(bp, x, W);
-        } else {
-            a[ch] = make_uint4(0, 0, 0, 0);
-            b[ch] = make_uint4(0, 0, 0, 0);
+        for (int ch = 0; ch < NCH; ++ch) {
+            const int x = ch * 1024 + lane * 16;
+            if (x < W) {
+                a[ch] = load16<ALIGNED>(fp, x, W);
+                b[ch] = load16<ALIGNED>(bp, x, W);
+            } else {
+                a[ch] = make_uint4(0, 0, 0, 0);
+                b[ch] = make_uint4(0, 0, 0, 0);
+            }
         }
-    }
-    uint32_t m[NCH];
-    bool any = false;
+    };
+    issue(task);
+    for (; task < ntask; task += nwave) {
+        const uint32_t f = (order & 1) == 0 ? task % (uint32_t)c.B : task / (uint32_t)c.H;
+        const uint32_t y = (order & 1) == 0 ? task / (uint32_t)c.B : task % (uint32_t)c.H;
+        uint32_t m[NCH];
+        bool any = false;
 #pragma unroll
-    for (int ch = 0; ch < NCH; ++ch) {
-        const int x = ch * 1024 + lane * 16;
-        uint32_t mm = 0;
-        if (x < W) {
-            mm = mask16(a[ch], b[ch], c);
-            if (!ALIGNED && x + 16 > W) mm &= (1u << (W - x)) - 1u;
+        for (int ch = 0; ch < NCH; ++ch) {
+            const int x = ch * 1024 + lane * 16;
+            uint32_t mm = 0;
+            if (x < W) {
+                mm = (order & 512) ? ((a[ch].x ^ b[ch].x) == 0x12345u) : mask16(a[ch], b[ch], c);
+                if (!ALIGNED && x + 16 > W) mm &= (1u << (W - x)) - 1u;
+            }
+            m[ch] = mm;
+            any |= mm != 0;
         }
-        m[ch] = mm;
-        any |= mm != 0;
-    }
-    const size_t ri = (size_t)f * c.H + y;
-    if (!__any(any)) {                       // most rows: no foreground at all
-        if (lane == 0) { row_cnt[ri] = 0; row_off[ri] = 0; }
-        return;
-    }
+        if (order & 256) any = false;
+        // registers a/b are free again: prefetch the next row while this one is finished
+        if (task + nwave < ntask) issue(task + nwave);
 
-    // run starts / ends per chunk.  bit j of en = "a run ended at pixel j-1".
-    uint32_t st[NCH], en[NCH], pre[NCH];     // pre = exclusive prefix (starts | ends << 16) incl. earlier chunks
-    uint32_t carry = 0, tot = 0;             // carry: last pixel of previous chunk set; tot: packed row totals
-#pragma unroll
-    for (int ch = 0; ch < NCH; ++ch) {
-        const uint32_t mm = m[ch];
-        if (__ballot(mm != 0) == 0 && carry == 0) { st[ch] = 0; en[ch] = 0; pre[ch] = tot; continue; }
-        uint32_t up = __shfl_up(mm >> 15, 1);
-        if (lane == 0) up = carry;
-        const uint32_t prevmask = ((mm << 1) | (up & 1u)) & 0xffffu;
-        const uint32_t s = mm & ~prevmask;
-        const uint32_t e = ~mm & prevmask;
-        const uint32_t v = __popc(s) | (__popc(e) << 16);
-        const uint32_t incl = wave_incl_scan(v);
-        st[ch] = s; en[ch] = e; pre[ch] = tot + incl - v;
-        tot += __shfl(incl, 63);
-        carry = __shfl(mm >> 15, 63) & 1u;
-    }
-    const uint32_t n_starts = tot & 0xffffu;     // runs in this row (== ends + carry)
-    uint32_t base = 0;
-    if (lane == 0) base = atomicAdd(&frame_ctr[f], n_starts);
-    base = __shfl(base, 0);
-    if (lane == 0) { row_cnt[ri] = n_starts; row_off[ri] = base; }
-    uint16_t* out = reinterpret_cast<uint16_t*>(tmp_runs + (size_t)f * c.R);
-    const uint32_t R = (uint32_t)c.R;
-#pragma unroll
-    for (int ch = 0; ch < NCH; ++ch) {
-        const int xb = ch * 1024 + lane * 16;
-        uint32_t s = st[ch], e = en[ch];
-        uint32_t ks = base + (pre[ch] & 0xffffu), ke = base + (pre[ch] >> 16);
-        while (s) {
-            const int j = __ffs(s) - 1; s &= s - 1;
-            if (ks < R) out[2 * ks] = (uint16_t)(xb + j);
-            ++ks;
+        const size_t ri = (size_t)f * c.H + y;
+        if (!__any(any)) {                       // most rows: no foreground at all
+            if (lane == 0) { row_cnt[ri] = 0; row_off[ri] = 0; }
+            continue;
         }
-        while (e) {
-            const int j = __ffs(e) - 1; e &= e - 1;
-            if (ke < R) out[2 * ke + 1] = (uint16_t)(xb + j - 1);
-            ++ke;
+        // run starts / ends per chunk.  bit j of en = "a run ended at pixel j-1".
+        uint32_t st[NCH], en[NCH], pre[NCH];     // pre = exclusive prefix (starts | ends << 16) incl. earlier chunks
+        uint32_t carry = 0, tot = 0;             // carry: last pixel of previous chunk set; tot: packed row totals
+#pragma unroll
+        for (int ch = 0; ch < NCH; ++ch) {
+            const uint32_t mm = m[ch];
+            if (__ballot(mm != 0) == 0 && carry == 0) { st[ch] = 0; en[ch] = 0; pre[ch] = tot; continue; }
+            uint32_t up = __shfl_up(mm >> 15, 1);
+            if (lane == 0) up = carry;
+            const uint32_t prevmask = ((mm << 1) | (up & 1u)) & 0xffffu;
+            const uint32_t s = mm & ~prevmask;
+            const uint32_t e = ~mm & prevmask;
+            const uint32_t v = __popc(s) | (__popc(e) << 16);
+            const uint32_t incl = wave_incl_scan(v);
+            st[ch] = s; en[ch] = e; pre[ch] = tot + incl - v;
+            tot += __shfl(incl, 63);
+            carry = __shfl(mm >> 15, 63) & 1u;
         }
-    }
-    if (carry && lane == 0) {                // run open at the end of the row closes at W-1
-        const uint32_t ke = base + (tot >> 16);
-        if (ke < R) out[2 * ke + 1] = (uint16_t)(W - 1);
+        const uint32_t n_starts = tot & 0xffffu;     // runs in this row (== ends + carry)
+        // output space: every row owns a fixed slot of ROW_SLOT runs (no atomics: device-scope atomics on a
+        // handful of counters cap at ~90 ops/us per word and were 80% of this kernel); only rows with more
+        // runs than that reserve space in the per-frame overflow area with one atomic.
+        uint32_t base = y * (uint32_t)ROW_SLOT;
+        if (n_starts > (uint32_t)ROW_SLOT) {
+            if (lane == 0) base = (uint32_t)c.H * ROW_SLOT + atomicAdd(&frame_ctr[f * CTR_STRIDE], n_starts);
+            base = __shfl(base, 0);
+        }
+        if (lane == 0) { row_cnt[ri] = n_starts; row_off[ri] = base; }
+        uint16_t* out = reinterpret_cast<uint16_t*>(tmp_runs + (size_t)f * c.T);
+        const uint32_t R = (uint32_t)c.T;
+#pragma unroll
+        for (int ch = 0; ch < NCH; ++ch) {
+            const int xb = ch * 1024 + lane * 16;
+            uint32_t s = st[ch], e = en[ch];
+            uint32_t ks = base + (pre[ch] & 0xffffu), ke = base + (pre[ch] >> 16);
+            while (s) {
+                const int j = __ffs(s) - 1; s &= s - 1;
+                if (ks < R) out[2 * ks] = (uint16_t)(xb + j);
+                ++ks;
+            }
+            while (e) {
+                const int j = __ffs(e) - 1; e &= e - 1;
+                if (ke < R) out[2 * ke + 1] = (uint16_t)(xb + j - 1);
+                ++ke;
+            }
+        }
+        if (carry && lane == 0) {                // run open at the end of the row closes at W-1
+            const uint32_t ke = base + (tot >> 16);
+            if (ke < R) out[2 * ke + 1] = (uint16_t)(W - 1);
+        }
     }
 }
 
 // ---------------------------------------------------------------------------------------------
 // k_rowscan: exclusive scan of runs-per-row, parent init
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_rowscan(const SegCfg c, const uint32_t* __restrict__ row_cnt,
+__global__ __launch_bounds__(256) void k_rowscan(const SegCfg c, const uint32_t* __restrict__ frame_ctr, const uint32_t* __restrict__ row_cnt,
                                                  uint32_t* __restrict__ row_base,
                                                  uint32_t* __restrict__ parent,
                                                  trexhip_frame_info* __restrict__ info) {
@@ -227,7 +249,7 @@ __global__ __launch_bounds__(256) void k_rowscan(const SegCfg c, const uint32_t*
         running += total;
     }
     const uint32_t n = running;
-    const bool overflow = n > (uint32_t)c.R;
+    const bool overflow = n > (uint32_t)c.R || frame_ctr[f * CTR_STRIDE] > (uint32_t)c.R;
     if (threadIdx.x == 0) {
         rb[c.H] = n;
         trexhip_frame_info fi = {};
@@ -275,7 +297,7 @@ __global__ __launch_bounds__(256) void k_link(const SegCfg c, const uint32_t* __
     const size_t ri = (size_t)f * c.H + y;
     const uint32_t cnt = row_cnt[ri];
     if (!cnt) return;
-    const uint32_t* tmp = tmp_runs + (size_t)f * c.R;
+    const uint32_t* tmp = tmp_runs + (size_t)f * c.T;
     const uint32_t off = row_off[ri];
     const uint32_t base = row_base[(size_t)f * (c.H + 1) + y];
     trexhip_run* rr = raster + (size_t)f * c.R;
@@ -415,6 +437,10 @@ __global__ __launch_bounds__(256) void k_blobs(const SegCfg c, const trexhip_run
     const uint32_t bb = s_alloc[0], rb = s_alloc[1], pb = s_alloc[2];
     fi.n_raw_blobs = nraw;
     if (s_alloc[3]) {
+        // the reservation cannot be undone (other frames may have reserved behind it): leave holes that
+        // k_gather and the host skip
+        for (uint32_t k = tid; k < kept; k += 256)
+            if (bb + k < c.pool_blobs) blob_frame[bb + k] = 0xffffffffu;
         if (tid == 0) { fi.flags |= TREXHIP_FRAME_OVERFLOW_OUTPUT; info[f] = fi; }
         return;
     }
@@ -519,6 +545,7 @@ __global__ __launch_bounds__(256) void k_gather(const SegCfg c, const uint8_t* _
     const uint32_t total = min(totals[0], c.pool_blobs);
     for (uint32_t bi = blockIdx.x * 4 + (threadIdx.x >> 6); bi < total; bi += nwaves) {
         const uint32_t f = blob_frame[bi];
+        if (f >= (uint32_t)c.B) continue;          // hole left by a frame that overflowed the pool
         const trexhip_frame_info fi = info[f];
         if (fi.flags) continue;
         trexhip_blob B = blobs[bi];
@@ -577,15 +604,15 @@ __global__ __launch_bounds__(256) void k_gather(const SegCfg c, const uint8_t* _
 // ---------------------------------------------------------------------------------------------
 template <bool ALIGNED>
 static void launch_rows(int nch, dim3 grid, hipStream_t s, const uint8_t* frames, const uint8_t* bg,
-                        const SegCfg& c, uint32_t* ctr, uint32_t* row_cnt, uint32_t* row_off, uint32_t* tmp) {
+                        const SegCfg& c, int order, uint32_t* ctr, uint32_t* row_cnt, uint32_t* row_off, uint32_t* tmp) {
     switch (nch) {
-        case 1: hipLaunchKernelGGL((k_rows<1, ALIGNED>), grid, dim3(256), 0, s, frames, bg, c, ctr, row_cnt, row_off, tmp); break;
-        case 2: hipLaunchKernelGGL((k_rows<2, ALIGNED>), grid, dim3(256), 0, s, frames, bg, c, ctr, row_cnt, row_off, tmp); break;
-        case 3: hipLaunchKernelGGL((k_rows<3, ALIGNED>), grid, dim3(256), 0, s, frames, bg, c, ctr, row_cnt, row_off, tmp); break;
-        case 4: hipLaunchKernelGGL((k_rows<4, ALIGNED>), grid, dim3(256), 0, s, frames, bg, c, ctr, row_cnt, row_off, tmp); break;
+        case 1: hipLaunchKernelGGL((k_rows<1, ALIGNED>), grid, dim3(256), 0, s, frames, bg, c, order, ctr, row_cnt, row_off, tmp); break;
+        case 2: hipLaunchKernelGGL((k_rows<2, ALIGNED>), grid, dim3(256), 0, s, frames, bg, c, order, ctr, row_cnt, row_off, tmp); break;
+        case 3: hipLaunchKernelGGL((k_rows<3, ALIGNED>), grid, dim3(256), 0, s, frames, bg, c, order, ctr, row_cnt, row_off, tmp); break;
+        case 4: hipLaunchKernelGGL((k_rows<4, ALIGNED>), grid, dim3(256), 0, s, frames, bg, c, order, ctr, row_cnt, row_off, tmp); break;
         case 5: case 6:
-                hipLaunchKernelGGL((k_rows<6, ALIGNED>), grid, dim3(256), 0, s, frames, bg, c, ctr, row_cnt, row_off, tmp); break;
-        default: hipLaunchKernelGGL((k_rows<8, ALIGNED>), grid, dim3(256), 0, s, frames, bg, c, ctr, row_cnt, row_off, tmp); break;
+                hipLaunchKernelGGL((k_rows<6, ALIGNED>), grid, dim3(256), 0, s, frames, bg, c, order, ctr, row_cnt, row_off, tmp); break;
+        default: hipLaunchKernelGGL((k_rows<8, ALIGNED>), grid, dim3(256), 0, s, frames, bg, c, order, ctr, row_cnt, row_off, tmp); break;
     }
 }
 
@@ -597,20 +624,21 @@ int launch_segment(trexhip_ctx* ctx, const uint8_t* d_frames, int n) {
     const int nch = (W + 1023) / 1024;
     if (nch > 8) { set_error("frame width > 8192 is not supported yet"); return TREXHIP_E_UNSUPPORTED; }
     stage_begin(ctx, TREXHIP_STAGE_SEGMENT_ALL);
-    TH_CHECK_HIP(hipMemsetAsync(ctx->d_ctr, 0, sizeof(uint32_t) * (ctx->p.max_batch + 4), s));
-    const dim3 grid_rows((unsigned)(((H + 3) / 4) * n));
+    TH_CHECK_HIP(hipMemsetAsync(ctx->d_ctr, 0, sizeof(uint32_t) * ((size_t)ctx->p.max_batch * CTR_STRIDE + 4), s));
+    const unsigned want = (unsigned)(((size_t)H * n + 3) / 4);
+    const dim3 grid_rows(want < (unsigned)ctx->tune_rows_blocks ? want : (unsigned)ctx->tune_rows_blocks);
     const bool aligned = (W % 16 == 0) && ((reinterpret_cast<uintptr_t>(d_frames) & 15) == 0) &&
                          ((reinterpret_cast<uintptr_t>(ctx->d_bg) & 15) == 0);
     stage_begin(ctx, TREXHIP_STAGE_ROWS);
-    if (aligned) launch_rows<true>(nch, grid_rows, s, d_frames, ctx->d_bg, c, ctx->d_ctr, ctx->d_row_cnt, ctx->d_row_off, ctx->d_tmp_runs);
-    else         launch_rows<false>(nch, grid_rows, s, d_frames, ctx->d_bg, c, ctx->d_ctr, ctx->d_row_cnt, ctx->d_row_off, ctx->d_tmp_runs);
+    if (aligned) launch_rows<true>(nch, grid_rows, s, d_frames, ctx->d_bg, c, ctx->tune_rows_order, ctx->d_ctr, ctx->d_row_cnt, ctx->d_row_off, ctx->d_tmp_runs);
+    else         launch_rows<false>(nch, grid_rows, s, d_frames, ctx->d_bg, c, ctx->tune_rows_order, ctx->d_ctr, ctx->d_row_cnt, ctx->d_row_off, ctx->d_tmp_runs);
     stage_end(ctx, TREXHIP_STAGE_ROWS);
-    hipLaunchKernelGGL(k_rowscan, dim3(n), dim3(256), 0, s, c, ctx->d_row_cnt, ctx->d_row_base, ctx->d_parent, ctx->d_info);
+    hipLaunchKernelGGL(k_rowscan, dim3(n), dim3(256), 0, s, c, ctx->d_ctr, ctx->d_row_cnt, ctx->d_row_base, ctx->d_parent, ctx->d_info);
     const dim3 grid_r((unsigned)((n * H + 255) / 256));
     hipLaunchKernelGGL(k_link, grid_r, dim3(256), 0, s, c, ctx->d_row_cnt, ctx->d_row_off, ctx->d_row_base,
                        ctx->d_tmp_runs, ctx->d_raster, ctx->d_parent, ctx->d_info);
     hipLaunchKernelGGL(k_flatten, grid_r, dim3(256), 0, s, c, ctx->d_row_cnt, ctx->d_row_base, ctx->d_parent, ctx->d_info);
-    uint32_t* totals = ctx->d_ctr + ctx->p.max_batch;
+    uint32_t* totals = ctx->d_ctr + (size_t)ctx->p.max_batch * CTR_STRIDE;
     hipLaunchKernelGGL(k_blobs, dim3(n), dim3(256), 0, s, c, ctx->d_raster, ctx->d_parent, ctx->d_root_ord,
                        ctx->d_cnt_runs, ctx->d_cnt_px, ctx->d_cur_run, ctx->d_pix_begin, ctx->d_blob_map, totals, ctx->d_info,
                        ctx->d_blobs, ctx->d_blob_frame, ctx->d_runs);
