@@ -135,9 +135,22 @@ int trexhip_fetch(trexhip_ctx* ctx, trexhip_batch_result* out);
 int trexhip_device_view_get(trexhip_ctx* ctx, trexhip_device_view* out);
 int trexhip_synchronize(trexhip_ctx* ctx);
 
+/* ---- identity network (V118_3) -------------------------------------------------------------
+ * VINetwork::load_weights (ml/VisualIdentification.cpp) / visual_recognition_torch.py:841-921: takes the
+ * flat fp32 blob described in trex_amd/weights.py (state_dict order; tools/convert_weights.py makes it
+ * from a TRex <base>_dict.pth).  BatchNorm is folded and the tensors repacked on load. */
+int trexhip_load_weights(trexhip_ctx* ctx, const void* blob, size_t bytes);
+int trexhip_num_classes(trexhip_ctx* ctx);
+/* VINetwork::probabilities (ml/VisualIdentification.cpp:440-458) -> predict_numpy
+ * (visual_recognition_torch.py:290-352): crops are uint8 NHWC [n][80][80][C] (values 0..255, no
+ * scaling), probs is [n][classes] float32 softmax rows.  d_logits may be NULL. */
+int trexhip_identify_device(trexhip_ctx* ctx, const uint8_t* d_crops, int32_t n, float* d_probs, float* d_logits);
+int trexhip_identify(trexhip_ctx* ctx, const uint8_t* crops, int32_t n, float* probs);
+
 /* live HIP-event timing of the dominant kernels on the ctx stream (bench.py roofline):
  * stage ids TREXHIP_STAGE_* ; returns accumulated milliseconds and launch count since reset */
-enum { TREXHIP_STAGE_ROWS = 0, TREXHIP_STAGE_SEGMENT_ALL = 1, TREXHIP_STAGE_COUNT = 8 };
+enum { TREXHIP_STAGE_ROWS = 0, TREXHIP_STAGE_SEGMENT_ALL = 1, TREXHIP_STAGE_CONV2 = 2, TREXHIP_STAGE_CONV3 = 3,
+       TREXHIP_STAGE_CNN_ALL = 4, TREXHIP_STAGE_CROPS = 5, TREXHIP_STAGE_COUNT = 8 };
 int trexhip_profile_enable(trexhip_ctx* ctx, int32_t on);
 int trexhip_profile_read(trexhip_ctx* ctx, int32_t stage, double* total_ms, int64_t* launches);
 int trexhip_profile_reset(trexhip_ctx* ctx);

@@ -1,0 +1,63 @@
+"""Identity network on the GPU (through the C ABI) vs (a) vectors produced by the reference's own
+network module (tests/golden/cnn_v118_3_*.npz) and (b) the CPU oracle.  Tolerance from BASELINE.json:
+1e-4 absolute on softmax; logits are also compared (2e-3 abs, |logit| up to ~15)."""
+import numpy as np
+import pytest
+import torch
+from oracle import cnn_oracle
+from trex_amd import capi, weights
+from test_cnn_oracle import load_fixture
+
+pytestmark = pytest.mark.gpu
+
+
+def make_net(st, classes):
+    seg = capi.Segmenter(capi.default_params(64, 64, max_batch=1))
+    seg.load_weights(weights.pack_blob(st, classes))
+    assert seg.num_classes() == classes
+    return seg
+
+
+@pytest.mark.parametrize("classes", [8, 100, 256])
+def test_reference_vectors(classes):
+    z, st = load_fixture(classes)
+    seg = make_net(st, classes)
+    sizes = sorted(int(k.split("/")[1]) for k in z.files if k.startswith("probs/"))
+    for n in sizes:
+        crops = weights.synthetic_crops(n, int(z["seed"]) + 1000 + n)
+        probs = seg.probabilities(crops)
+        assert probs.shape == (n, classes)
+        err = np.abs(probs - z[f"probs/{n}"]).max()
+        assert err <= 1e-4, (n, err)
+        assert np.allclose(probs.sum(1), 1.0, atol=1e-5)
+    seg.close()
+
+
+def test_logits_and_device_path_vs_oracle():
+    z, st = load_fixture(100)
+    seg = make_net(st, 100)
+    rng = np.random.default_rng(5)
+    crops = rng.integers(0, 256, (130, 80, 80, 1)).astype(np.uint8)      # dense random crops: worst case for summation order
+    crops[7] = 0                                                          # an empty crop
+    crops[8] = 255
+    d = torch.from_numpy(crops).cuda()
+    probs = torch.empty((130, 100), dtype=torch.float32, device="cuda")
+    logits = torch.empty_like(probs)
+    seg.identify_device(d.data_ptr(), 130, probs.data_ptr(), logits.data_ptr())
+    seg.synchronize()
+    op, ol = cnn_oracle.predict(st, crops, threads=8)
+    assert np.abs(probs.cpu().numpy() - op).max() <= 1e-4
+    assert np.abs(logits.cpu().numpy() - ol).max() <= 2e-3 * max(1.0, np.abs(ol).max() / 10)
+    # batch independence: crop 3 alone gives the same row
+    one = seg.probabilities(crops[3:4])
+    assert np.abs(one[0] - probs[3].cpu().numpy()).max() <= 1e-6
+    seg.close()
+
+
+def test_errors():
+    seg = capi.Segmenter(capi.default_params(64, 64, max_batch=1))
+    with pytest.raises(capi.TrexHipError):          # weights not loaded (VisualIdentification.cpp: status().weights.loaded())
+        seg.probabilities(np.zeros((1, 80, 80, 1), np.uint8))
+    with pytest.raises(capi.TrexHipError):
+        seg.load_weights(b"\0" * 64)
+    seg.close()

@@ -26,7 +26,7 @@ INFO_DTYPE = np.dtype([
 ])
 assert BLOB_DTYPE.itemsize == 96 and RUN_DTYPE.itemsize == 8 and INFO_DTYPE.itemsize == 48
 
-STAGE_ROWS, STAGE_SEGMENT_ALL = 0, 1
+STAGE_ROWS, STAGE_SEGMENT_ALL, STAGE_CONV2, STAGE_CONV3, STAGE_CNN_ALL, STAGE_CROPS = 0, 1, 2, 3, 4, 5
 
 
 class Params(C.Structure):
@@ -66,6 +66,7 @@ SYMBOLS = [
     "trexhip_set_stream", "trexhip_set_background", "trexhip_set_background_device", "trexhip_segment_device",
     "trexhip_segment", "trexhip_fetch", "trexhip_device_view_get", "trexhip_synchronize",
     "trexhip_profile_enable", "trexhip_profile_read", "trexhip_profile_reset",
+    "trexhip_load_weights", "trexhip_num_classes", "trexhip_identify_device", "trexhip_identify",
 ]
 
 
@@ -92,6 +93,10 @@ def lib():
         L.trexhip_profile_enable.argtypes = [C.c_void_p, C.c_int32]
         L.trexhip_profile_read.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
         L.trexhip_profile_reset.argtypes = [C.c_void_p]
+        L.trexhip_load_weights.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+        L.trexhip_num_classes.argtypes = [C.c_void_p]
+        L.trexhip_identify_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]
+        L.trexhip_identify.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]
         _LIB = L
     return _LIB
 
@@ -206,6 +211,26 @@ class Segmenter:
         if rc == -3:
             self.last_capacity_error = lib().trexhip_last_error().decode()
         return out
+
+    # ---- identity network (mirrors VINetwork: load_weights / probabilities) ----
+    def load_weights(self, blob: bytes):
+        buf = (C.c_uint8 * len(blob)).from_buffer_copy(blob)
+        _check(lib().trexhip_load_weights(self._h, buf, len(blob)))
+
+    def num_classes(self):
+        return lib().trexhip_num_classes(self._h)
+
+    def probabilities(self, crops):
+        """crops: uint8 ndarray (n,80,80,C) on the host -> float32 (n,classes) softmax rows."""
+        crops = np.ascontiguousarray(crops, np.uint8)
+        n = crops.shape[0]
+        out = np.empty((n, self.num_classes()), np.float32)
+        _check(lib().trexhip_identify(self._h, crops.ctypes.data_as(C.c_void_p), n, out.ctypes.data_as(C.c_void_p)))
+        return out
+
+    def identify_device(self, d_crops_ptr, n, d_probs_ptr, d_logits_ptr=None):
+        _check(lib().trexhip_identify_device(self._h, C.c_void_p(d_crops_ptr), n, C.c_void_p(d_probs_ptr),
+                                             C.c_void_p(d_logits_ptr) if d_logits_ptr else None))
 
     def device_view(self):
         v = DeviceView()

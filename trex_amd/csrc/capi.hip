@@ -179,6 +179,7 @@ void trexhip_destroy(trexhip_ctx* ctx) {
     if (!ctx) return;
     hipSetDevice(ctx->p.device);
     if (ctx->stream) hipStreamSynchronize(ctx->stream);
+    net_free(ctx);
     void* dev[] = {ctx->d_bg, ctx->d_staging, ctx->d_ctr, ctx->d_row_cnt, ctx->d_row_off, ctx->d_row_base, ctx->d_tmp_runs,
                    ctx->d_raster, ctx->d_parent, ctx->d_root_ord, ctx->d_cnt_runs, ctx->d_cnt_px, ctx->d_cur_run,
                    ctx->d_pix_begin, ctx->d_blob_map, ctx->d_info, ctx->d_blobs, ctx->d_blob_frame, ctx->d_runs, ctx->d_pixels};

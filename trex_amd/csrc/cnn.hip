@@ -1,0 +1,533 @@
+// cnn.hip -- identity network V118_3 forward + softmax on gfx950 (exact fp32, MFMA for the convs).
+//
+// Replaces VINetwork::probabilities -> Python predict() -> predict_numpy
+//   Application/src/tracker/ml/VisualIdentification.cpp:440-485
+//   Application/src/tracker/python/visual_recognition_torch.py:290-352,984-1034
+// for the network visual_identification_network_torch.py:184-258 (V118_3, eval mode):
+//   x = float(u8)  ->  [conv5x5 same -> BN -> ReLU -> maxpool2] x3 -> flatten(NCHW) -> fc1(12800->100)
+//   -> LayerNorm(100) -> ReLU -> fc2(100->classes) -> softmax.
+//
+// Kernels (DESIGN.md "Identity network"):
+//   k_conv1     C_in=1: VALU, one block per crop, u8 crop staged in LDS, fused BN+ReLU+pool
+//   k_conv5<>   conv2/conv3 as 25 shifted GEMMs on v_mfma_f32_32x32x2_f32 (exact fp32):
+//               input patch (+2 halo) of one ci-chunk staged once in LDS, A fragments read from it at
+//               the tap's offset (no im2col), weights per (tap, ci-chunk) double-buffered in LDS,
+//               pixels ordered pool-window-major so the 2x2 max-pool is a max over 4 accumulator
+//               registers of one lane; BN folded into weights/bias; epilogue bias+ReLU+pool
+//   k_fc1       [crops x 12800] x [12800 x 128] MFMA GEMM, LDS tiles
+//   k_head      LayerNorm + ReLU + fc2 + softmax, one wave per crop
+#include "internal.h"
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+namespace trexhip {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// ------------------------------------------------------------------------------------------------
+// conv1: 1 -> 16 channels, 80x80 -> pooled 40x40x16 (NHWC fp32)
+// ------------------------------------------------------------------------------------------------
+template <int CH>
+__global__ __launch_bounds__(256) void k_conv1(const uint8_t* __restrict__ crops, const float* __restrict__ w /*[CH][25][16]*/,
+                                               const float* __restrict__ bias /*[16]*/, float* __restrict__ out, int S) {
+    extern __shared__ float lds[];
+    const int PW = S + 4;
+    float* img = lds;                       // [CH][PW*PW]
+    float* wl = lds + CH * PW * PW;         // [CH*25*16]
+    const int crop = blockIdx.x;
+    const uint8_t* src = crops + (size_t)crop * S * S * CH;
+    for (int i = threadIdx.x; i < CH * PW * PW; i += 256) img[i] = 0.f;
+    for (int i = threadIdx.x; i < CH * 25 * 16; i += 256) wl[i] = w[i];
+    __syncthreads();
+    for (int i = threadIdx.x; i < S * S * CH; i += 256) {
+        const int c = i % CH, p = i / CH, y = p / S, x = p - y * S;
+        img[c * PW * PW + (y + 2) * PW + x + 2] = (float)src[i];       // predict_numpy: float32(u8), no scaling
+    }
+    __syncthreads();
+    const int HW = S / 2;
+    for (int wi = threadIdx.x; wi < HW * HW; wi += 256) {
+        const int wy = wi / HW, wx = wi - wy * HW;
+        float acc[4][16];
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+            for (int co = 0; co < 16; ++co) acc[s][co] = 0.f;
+        for (int c = 0; c < CH; ++c) {
+            float p[6][6];
+#pragma unroll
+            for (int a = 0; a < 6; ++a)
+#pragma unroll
+                for (int b = 0; b < 6; ++b) p[a][b] = img[c * PW * PW + (2 * wy + a) * PW + 2 * wx + b];
+#pragma unroll
+            for (int ky = 0; ky < 5; ++ky)
+#pragma unroll
+                for (int kx = 0; kx < 5; ++kx) {
+                    const float* wt = wl + (c * 25 + ky * 5 + kx) * 16;
+#pragma unroll
+                    for (int co = 0; co < 16; ++co) {
+                        const float ww = wt[co];
+                        acc[0][co] = fmaf(p[ky][kx], ww, acc[0][co]);
+                        acc[1][co] = fmaf(p[ky][kx + 1], ww, acc[1][co]);
+                        acc[2][co] = fmaf(p[ky + 1][kx], ww, acc[2][co]);
+                        acc[3][co] = fmaf(p[ky + 1][kx + 1], ww, acc[3][co]);
+                    }
+                }
+        }
+        float* o = out + ((size_t)crop * HW * HW + wi) * 16;
+#pragma unroll
+        for (int co = 0; co < 16; co += 4) {
+            float4 v;
+            float* vv = &v.x;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float m = fmaxf(fmaxf(acc[0][co + q], acc[1][co + q]), fmaxf(acc[2][co + q], acc[3][co + q]));
+                vv[q] = fmaxf(m + bias[co + q], 0.f);
+            }
+            *reinterpret_cast<float4*>(o + co) = v;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// conv 5x5 'same' + folded BN + ReLU + maxpool2 as 25 shifted GEMMs on fp32 MFMA
+// ------------------------------------------------------------------------------------------------
+template <int CI, int CO, int S, int ROWS, int CIC>
+struct ConvGeom {
+    static constexpr int PW = S + 4, PH = ROWS + 4;
+    static constexpr int STR = CIC + 1;                               // odd pixel stride: conflict-free b32 reads
+    static constexpr int RP0 = PW * STR;
+    static constexpr int RP = RP0 + ((16 - (RP0 % 32)) + 32) % 32;    // row pitch == 16 (mod 32): rows y, y+1 use disjoint banks
+    static constexpr int PATCH = PH * RP;                             // floats
+    static constexpr int BT = CIC * CO;                               // floats per weight tile
+    static constexpr int NPIX = ROWS * S;
+    static constexpr int MT = (NPIX + 31) / 32;
+    static constexpr int NT = CO / 32;
+    static constexpr int WM = 8 / NT;                                 // wave groups along M
+    static constexpr int TPW = (MT + WM - 1) / WM;                    // M tiles per wave
+    static constexpr int LDS_BYTES = (PATCH + 2 * BT) * 4;
+    static constexpr int BPC = S / ROWS;                              // blocks per crop
+};
+
+template <int CI, int CO, int S, int ROWS, int CIC>
+__global__ __launch_bounds__(512) void k_conv5(const float* __restrict__ in /*[N][S][S][CI]*/,
+                                               const float* __restrict__ wp /*[CI/CIC][25][CIC][CO]*/,
+                                               const float* __restrict__ bias /*[CO]*/,
+                                               float* __restrict__ out /*[N][S/2][S/2][CO]*/) {
+    using G = ConvGeom<CI, CO, S, ROWS, CIC>;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* patch = lds;
+    float* Bs = lds + G::PATCH;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int j = lane & 31, h = lane >> 5;
+    const int n = wave % G::NT, mg = wave / G::NT;
+    const int crop = blockIdx.x / G::BPC, row0 = (blockIdx.x % G::BPC) * ROWS;
+    constexpr int WR = S / 2;                                          // pool windows per row
+
+    int aoff[G::TPW];
+#pragma unroll
+    for (int m = 0; m < G::TPW; ++m) {
+        const int p = (mg + G::WM * m) * 32 + j;                       // window-major pixel index
+        int off = 0;
+        if (p < G::NPIX) {
+            const int wi = p >> 2, sub = p & 3;
+            const int wy = wi / WR, wx = wi - wy * WR;
+            off = (2 * wy + (sub >> 1)) * G::RP + (2 * wx + (sub & 1)) * G::STR;
+        }
+        aoff[m] = off + h;
+    }
+    f32x16 acc[G::TPW];
+#pragma unroll
+    for (int m = 0; m < G::TPW; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
+
+    const float* inc = in + (size_t)crop * S * S * CI;
+    constexpr int Q = CIC / 4;                                          // float4 per pixel per chunk
+    constexpr int BV = G::BT / 4;                                       // float4 per weight tile
+    constexpr int BPT = (BV + 511) / 512;                               // float4 per thread per weight tile
+    for (int cc = 0; cc < CI / CIC; ++cc) {
+        __syncthreads();                                                // previous chunk's readers are done
+        for (int idx = tid; idx < G::PH * G::PW * Q; idx += 512) {
+            const int q = idx % Q, px = idx / Q;
+            const int py = px / G::PW, pxx = px - py * G::PW;
+            const int iy = row0 + py - 2, ix = pxx - 2;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);                 // zero padding ('same')
+            if (iy >= 0 && iy < S && ix >= 0 && ix < S)
+                v = *reinterpret_cast<const float4*>(inc + ((size_t)iy * S + ix) * CI + cc * CIC + q * 4);
+            float* d = patch + py * G::RP + pxx * G::STR + q * 4;
+            d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+        }
+        const float4* wsrc = reinterpret_cast<const float4*>(wp + (size_t)cc * 25 * G::BT);
+        for (int i = tid; i < BV; i += 512) reinterpret_cast<float4*>(Bs)[i] = wsrc[i];
+        __syncthreads();
+        for (int tap = 0; tap < 25; ++tap) {
+            const int buf = tap & 1;
+            float4 nb[BPT];
+            if (tap < 24) {
+#pragma unroll
+                for (int u = 0; u < BPT; ++u) {
+                    const int i = tid + u * 512;
+                    if (i < BV) nb[u] = wsrc[(size_t)(tap + 1) * BV + i];
+                }
+            }
+            const int tapoff = (tap / 5) * G::RP + (tap % 5) * G::STR;
+            const float* bsrc = Bs + buf * G::BT + h * CO + n * 32 + j;
+            const float* asrc = patch + tapoff;
+#pragma unroll
+            for (int t = 0; t < CIC / 2; ++t) {
+                const float b = bsrc[2 * t * CO];
+#pragma unroll
+                for (int m = 0; m < G::TPW; ++m) {
+                    const float a = asrc[aoff[m] + 2 * t];
+                    acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[m], 0, 0, 0);
+                }
+            }
+            if (tap < 24) {
+#pragma unroll
+                for (int u = 0; u < BPT; ++u) {
+                    const int i = tid + u * 512;
+                    if (i < BV) reinterpret_cast<float4*>(Bs + (buf ^ 1) * G::BT)[i] = nb[u];
+                }
+            }
+            __syncthreads();
+        }
+    }
+    // epilogue: lane (j,h) holds for g=0..3 the 4 pixels of pool window (tile*8 + 2g + h), channel n*32+j
+    const int co = n * 32 + j;
+    const float bz = bias[co];
+    float* oc = out + (size_t)crop * WR * WR * CO;
+#pragma unroll
+    for (int m = 0; m < G::TPW; ++m) {
+        const int mt = mg + G::WM * m;
+        if (mt >= G::MT) continue;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int wi = mt * 8 + 2 * g + h;
+            if (wi >= G::NPIX / 4) continue;
+            const float v = fmaxf(fmaxf(acc[m][4 * g], acc[m][4 * g + 1]), fmaxf(acc[m][4 * g + 2], acc[m][4 * g + 3]));
+            const int wy = row0 / 2 + wi / WR, wx = wi % WR;
+            oc[((size_t)wy * WR + wx) * CO + co] = fmaxf(v + bz, 0.f);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// fc1: out[N][128] = act[N][K] * W[K][128] + b     (K = 12800, 100 real outputs)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_fc1(const float* __restrict__ act, const float* __restrict__ w /*[K][128]*/,
+                                             const float* __restrict__ bias /*[128]*/, float* __restrict__ out, int n, int K) {
+    __shared__ float As[32 * 33];
+    __shared__ float Bs[32 * 128];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int j = lane & 31, h = lane >> 5;
+    const int m0 = blockIdx.x * 32;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    for (int k0 = 0; k0 < K; k0 += 32) {
+        __syncthreads();
+        {   // A tile: 32 rows x 32 k
+            const int r = tid >> 3, q = tid & 7;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (m0 + r < n) v = *reinterpret_cast<const float4*>(act + (size_t)(m0 + r) * K + k0 + q * 4);
+            float* d = As + r * 33 + q * 4;
+            d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+        }
+        for (int i = tid; i < 32 * 128 / 4; i += 256)
+            reinterpret_cast<float4*>(Bs)[i] = reinterpret_cast<const float4*>(w + (size_t)k0 * 128)[i];
+        __syncthreads();
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+            const float a = As[j * 33 + 2 * t + h];
+            const float b = Bs[(2 * t + h) * 128 + wave * 32 + j];
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+        }
+    }
+    const int co = wave * 32 + j;
+    const float bz = bias[co];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int i = (r & 3) + 8 * (r >> 2) + 4 * h;
+        if (m0 + i < n) out[(size_t)(m0 + i) * 128 + co] = acc[r] + bz;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// head: LayerNorm(100) + ReLU + fc2 + softmax, one wave per crop
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v = fmaxf(v, __shfl_xor(v, d));
+    return v;
+}
+
+__global__ __launch_bounds__(256) void k_head(const float* __restrict__ fc1 /*[N][128]*/, const float* __restrict__ ln_g,
+                                              const float* __restrict__ ln_b, const float* __restrict__ w2t /*[100][C]*/,
+                                              const float* __restrict__ b2, float* __restrict__ probs /*[N][C]*/,
+                                              float* __restrict__ logits_out, int n, int C) {
+    __shared__ float ys[4][128];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int crop = blockIdx.x * 4 + wave;
+    if (crop >= n) return;
+    const float* x = fc1 + (size_t)crop * 128;
+    const float x0 = x[lane], x1 = lane + 64 < 100 ? x[lane + 64] : 0.f;
+    const float mean = wave_sum(x0 + x1) * (1.f / 100.f);
+    const float d0 = x0 - mean, d1 = lane + 64 < 100 ? x1 - mean : 0.f;
+    const float var = wave_sum(d0 * d0 + d1 * d1) * (1.f / 100.f);     // biased variance (nn.LayerNorm)
+    const float rstd = 1.f / sqrtf(var + 1e-5f);
+    ys[wave][lane] = fmaxf(d0 * rstd * ln_g[lane] + ln_b[lane], 0.f);
+    if (lane + 64 < 100) ys[wave][lane + 64] = fmaxf(d1 * rstd * ln_g[lane + 64] + ln_b[lane + 64], 0.f);
+    __builtin_amdgcn_wave_barrier();      // ys[wave] is private to this wave; LDS ops of one wave stay in order
+    // logits: lane = class (stride 64)
+    float mx = -3.4e38f;
+    const int nrep = (C + 63) / 64;
+    float lg[16];                         // up to 1024 classes (track_max_individuals default)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        lg[r] = -3.4e38f;
+        if (r < nrep) {
+            const int c = r * 64 + lane;
+            if (c < C) {
+                float s = b2[c];
+                for (int k = 0; k < 100; ++k) s = fmaf(ys[wave][k], w2t[(size_t)k * C + c], s);
+                lg[r] = s;
+                if (logits_out) logits_out[(size_t)crop * C + c] = s;
+            }
+            mx = fmaxf(mx, lg[r]);
+        }
+    }
+    mx = wave_max(mx);
+    float sum = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+        if (r < nrep) { const int c = r * 64 + lane; if (c < C) { lg[r] = expf(lg[r] - mx); sum += lg[r]; } }
+    sum = wave_sum(sum);
+    const float inv = 1.f / sum;
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+        if (r < nrep) { const int c = r * 64 + lane; if (c < C) probs[(size_t)crop * C + c] = lg[r] * inv; }
+}
+
+// ------------------------------------------------------------------------------------------------
+// host: weight blob -> folded / repacked device tensors
+// ------------------------------------------------------------------------------------------------
+struct Net {
+    int classes = 0, W = 0, H = 0, CH = 0, max_crops = 0;
+    float *w1 = nullptr, *b1 = nullptr, *w2 = nullptr, *b2 = nullptr, *w3 = nullptr, *b3 = nullptr;
+    float *wf1 = nullptr, *bf1 = nullptr, *lng = nullptr, *lnb = nullptr, *wf2t = nullptr, *bf2 = nullptr;
+    float *act1 = nullptr, *act2 = nullptr, *act3 = nullptr, *fc1 = nullptr, *probs = nullptr, *logits = nullptr;
+    uint8_t* crops = nullptr;
+    float* h_probs = nullptr;
+};
+
+static void free_net(Net* n) {
+    if (!n) return;
+    float* d[] = {n->w1, n->b1, n->w2, n->b2, n->w3, n->b3, n->wf1, n->bf1, n->lng, n->lnb, n->wf2t, n->bf2,
+                  n->act1, n->act2, n->act3, n->fc1, n->probs, n->logits};
+    for (float* p : d) if (p) (void)hipFree(p);
+    if (n->crops) (void)hipFree(n->crops);
+    if (n->h_probs) (void)hipHostFree(n->h_probs);
+    delete n;
+}
+
+static int upload(float** dst, const std::vector<float>& v) {
+    TH_CHECK_HIP(hipMalloc(reinterpret_cast<void**>(dst), v.size() * sizeof(float)));
+    TH_CHECK_HIP(hipMemcpy(*dst, v.data(), v.size() * sizeof(float), hipMemcpyHostToDevice));
+    return TREXHIP_OK;
+}
+
+// conv weight [CO][CI][5][5] + BN(eval) -> packed [CI/CIC][25][CIC][CO] (scaled) + bias[CO]
+static void fold_conv(const float* w, const float* b, const float* g, const float* beta, const float* mean, const float* var,
+                      int CO, int CI, int CIC, std::vector<float>& wp, std::vector<float>& bias) {
+    wp.assign((size_t)CO * CI * 25, 0.f);
+    bias.assign(CO, 0.f);
+    for (int co = 0; co < CO; ++co) {
+        const double s = (double)g[co] / std::sqrt((double)var[co] + 1e-5);     // BatchNorm2d eps
+        bias[co] = (float)(((double)b[co] - (double)mean[co]) * s + (double)beta[co]);
+        for (int ci = 0; ci < CI; ++ci)
+            for (int tap = 0; tap < 25; ++tap) {
+                const int cc = ci / CIC, k = ci % CIC;
+                wp[(((size_t)cc * 25 + tap) * CIC + k) * CO + co] = (float)((double)w[((size_t)co * CI + ci) * 25 + tap] * s);
+            }
+    }
+}
+
+int net_load(trexhip_ctx* ctx, const void* blob, size_t bytes) {
+    if (bytes < 32) { set_error("trexhip_load_weights: blob too small"); return TREXHIP_E_INVALID; }
+    int32_t hdr[8];
+    std::memcpy(hdr, blob, 32);
+    if (hdr[0] != 0x57585254 || hdr[1] != 1) { set_error("trexhip_load_weights: bad magic/version"); return TREXHIP_E_INVALID; }
+    const int classes = hdr[2], W = hdr[3], H = hdr[4], CH = hdr[5];
+    if (W != 80 || H != 80) { set_error("trexhip_load_weights: only individual_image_size 80x80 is supported"); return TREXHIP_E_UNSUPPORTED; }
+    if (CH != 1 && CH != 3) { set_error("trexhip_load_weights: channels must be 1 or 3"); return TREXHIP_E_UNSUPPORTED; }
+    if (classes < 1 || classes > 1024) { set_error("trexhip_load_weights: classes must be 1..1024"); return TREXHIP_E_INVALID; }
+    const size_t flat = 128 * (W / 8) * (H / 8);
+    const size_t need = (size_t)16 * CH * 25 + 16 * 5 + (size_t)64 * 16 * 25 + 64 * 5 + (size_t)128 * 64 * 25 + 128 * 5 +
+                        100 * flat + 100 * 3 + (size_t)classes * 100 + classes;
+    if (bytes != 32 + need * 4) { set_error("trexhip_load_weights: blob size does not match its header"); return TREXHIP_E_INVALID; }
+    const float* p = reinterpret_cast<const float*>(static_cast<const char*>(blob) + 32);
+    auto take = [&](size_t count) { const float* q = p; p += count; return q; };
+    const float *c1w = take((size_t)16 * CH * 25), *c1b = take(16), *g1 = take(16), *be1 = take(16), *m1 = take(16), *v1 = take(16);
+    const float *c2w = take((size_t)64 * 16 * 25), *c2b = take(64), *g2 = take(64), *be2 = take(64), *m2 = take(64), *v2 = take(64);
+    const float *c3w = take((size_t)128 * 64 * 25), *c3b = take(128), *g3 = take(128), *be3 = take(128), *m3 = take(128), *v3 = take(128);
+    const float *f1w = take(100 * flat), *f1b = take(100), *lg = take(100), *lb = take(100);
+    const float *f2w = take((size_t)classes * 100), *f2b = take(classes);
+
+    TH_CHECK_HIP(hipSetDevice(ctx->p.device));
+    free_net(static_cast<Net*>(ctx->net));
+    ctx->net = nullptr;
+    Net* net = new Net();
+    net->classes = classes; net->W = W; net->H = H; net->CH = CH;
+    std::vector<float> wp, bias;
+    int rc = TREXHIP_OK;
+#define TRY(x) do { if (rc == TREXHIP_OK) rc = (x); } while (0)
+    {   // conv1: [16][CH][25] -> [CH][25][16]
+        std::vector<float> w1((size_t)CH * 25 * 16), b1(16);
+        for (int co = 0; co < 16; ++co) {
+            const double s = (double)g1[co] / std::sqrt((double)v1[co] + 1e-5);
+            b1[co] = (float)(((double)c1b[co] - (double)m1[co]) * s + (double)be1[co]);
+            for (int c = 0; c < CH; ++c)
+                for (int tap = 0; tap < 25; ++tap)
+                    w1[((size_t)c * 25 + tap) * 16 + co] = (float)((double)c1w[((size_t)co * CH + c) * 25 + tap] * s);
+        }
+        TRY(upload(&net->w1, w1)); TRY(upload(&net->b1, b1));
+    }
+    fold_conv(c2w, c2b, g2, be2, m2, v2, 64, 16, 16, wp, bias);
+    TRY(upload(&net->w2, wp)); TRY(upload(&net->b2, bias));
+    fold_conv(c3w, c3b, g3, be3, m3, v3, 128, 64, 32, wp, bias);
+    TRY(upload(&net->w3, wp)); TRY(upload(&net->b3, bias));
+    {   // fc1 [100][c*100+h*10+w] -> [(h*10+w)*128 + c][128 (o padded)]
+        const int P = (W / 8) * (H / 8);
+        std::vector<float> wf((size_t)flat * 128, 0.f), bf(128, 0.f);
+        for (int o = 0; o < 100; ++o) {
+            bf[o] = f1b[o];
+            for (int c = 0; c < 128; ++c)
+                for (int hw = 0; hw < P; ++hw)
+                    wf[((size_t)hw * 128 + c) * 128 + o] = f1w[(size_t)o * flat + (size_t)c * P + hw];
+        }
+        TRY(upload(&net->wf1, wf)); TRY(upload(&net->bf1, bf));
+    }
+    TRY(upload(&net->lng, std::vector<float>(lg, lg + 100)));
+    TRY(upload(&net->lnb, std::vector<float>(lb, lb + 100)));
+    {
+        std::vector<float> w2t((size_t)100 * classes);
+        for (int c = 0; c < classes; ++c)
+            for (int k = 0; k < 100; ++k) w2t[(size_t)k * classes + c] = f2w[(size_t)c * 100 + k];
+        TRY(upload(&net->wf2t, w2t));
+        TRY(upload(&net->bf2, std::vector<float>(f2b, f2b + classes)));
+    }
+#undef TRY
+    if (rc != TREXHIP_OK) { free_net(net); return rc; }
+    ctx->net = net;
+    return TREXHIP_OK;
+}
+
+static int ensure_act(trexhip_ctx* ctx, Net* net, int n) {
+    if (n <= net->max_crops) return TREXHIP_OK;
+    float** bufs[] = {&net->act1, &net->act2, &net->act3, &net->fc1, &net->probs, &net->logits};
+    for (float** b : bufs) if (*b) { (void)hipFree(*b); *b = nullptr; }
+    if (net->crops) { (void)hipFree(net->crops); net->crops = nullptr; }
+    if (net->h_probs) { (void)hipHostFree(net->h_probs); net->h_probs = nullptr; }
+    const size_t N = n;
+    TH_CHECK_HIP(hipMalloc(reinterpret_cast<void**>(&net->act1), N * 40 * 40 * 16 * 4));
+    TH_CHECK_HIP(hipMalloc(reinterpret_cast<void**>(&net->act2), N * 20 * 20 * 64 * 4));
+    TH_CHECK_HIP(hipMalloc(reinterpret_cast<void**>(&net->act3), N * 10 * 10 * 128 * 4));
+    TH_CHECK_HIP(hipMalloc(reinterpret_cast<void**>(&net->fc1), N * 128 * 4));
+    TH_CHECK_HIP(hipMalloc(reinterpret_cast<void**>(&net->probs), N * net->classes * 4));
+    TH_CHECK_HIP(hipMalloc(reinterpret_cast<void**>(&net->logits), N * net->classes * 4));
+    TH_CHECK_HIP(hipMalloc(reinterpret_cast<void**>(&net->crops), N * net->W * net->H * net->CH));
+    TH_CHECK_HIP(hipHostMalloc(reinterpret_cast<void**>(&net->h_probs), N * net->classes * 4, hipHostMallocDefault));
+    net->max_crops = n;
+    (void)ctx;
+    return TREXHIP_OK;
+}
+
+int net_forward(trexhip_ctx* ctx, const uint8_t* d_crops, int n, float* d_probs, float* d_logits) {
+    Net* net = static_cast<Net*>(ctx->net);
+    hipStream_t s = ctx->stream;
+    using G2 = ConvGeom<16, 64, 40, 20, 16>;
+    using G3 = ConvGeom<64, 128, 20, 20, 32>;
+    static bool attr_done = false;
+    if (!attr_done) {
+        TH_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv5<16, 64, 40, 20, 16>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, G2::LDS_BYTES));
+        TH_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv5<64, 128, 20, 20, 32>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, G3::LDS_BYTES));
+        attr_done = true;
+    }
+    stage_begin(ctx, TREXHIP_STAGE_CNN_ALL);
+    const int S = net->W;
+    const size_t lds1 = ((size_t)net->CH * (S + 4) * (S + 4) + (size_t)net->CH * 25 * 16) * 4;
+    if (net->CH == 1) hipLaunchKernelGGL((k_conv1<1>), dim3(n), dim3(256), lds1, s, d_crops, net->w1, net->b1, net->act1, S);
+    else              hipLaunchKernelGGL((k_conv1<3>), dim3(n), dim3(256), lds1, s, d_crops, net->w1, net->b1, net->act1, S);
+    stage_begin(ctx, TREXHIP_STAGE_CONV2);
+    hipLaunchKernelGGL((k_conv5<16, 64, 40, 20, 16>), dim3(n * G2::BPC), dim3(512), G2::LDS_BYTES, s, net->act1, net->w2, net->b2, net->act2);
+    stage_end(ctx, TREXHIP_STAGE_CONV2);
+    stage_begin(ctx, TREXHIP_STAGE_CONV3);
+    hipLaunchKernelGGL((k_conv5<64, 128, 20, 20, 32>), dim3(n * G3::BPC), dim3(512), G3::LDS_BYTES, s, net->act2, net->w3, net->b3, net->act3);
+    stage_end(ctx, TREXHIP_STAGE_CONV3);
+    hipLaunchKernelGGL(k_fc1, dim3((n + 31) / 32), dim3(256), 0, s, net->act3, net->wf1, net->bf1, net->fc1, n, 12800);
+    hipLaunchKernelGGL(k_head, dim3((n + 3) / 4), dim3(256), 0, s, net->fc1, net->lng, net->lnb, net->wf2t, net->bf2,
+                       d_probs, d_logits, n, net->classes);
+    stage_end(ctx, TREXHIP_STAGE_CNN_ALL);
+    TH_CHECK_HIP(hipGetLastError());
+    return TREXHIP_OK;
+}
+
+}  // namespace trexhip
+
+using namespace trexhip;
+
+extern "C" {
+
+int trexhip_load_weights(trexhip_ctx* ctx, const void* blob, size_t bytes) {
+    if (!ctx || !blob) { set_error("trexhip_load_weights: null argument"); return TREXHIP_E_INVALID; }
+    return net_load(ctx, blob, bytes);
+}
+
+int trexhip_identify_device(trexhip_ctx* ctx, const uint8_t* d_crops, int32_t n, float* d_probs, float* d_logits) {
+    if (!ctx || !d_crops || !d_probs) { set_error("trexhip_identify_device: null argument"); return TREXHIP_E_INVALID; }
+    Net* net = static_cast<Net*>(ctx->net);
+    if (!net) { set_error("trexhip_identify: weights not loaded (VINetwork status().weights.loaded())"); return TREXHIP_E_INVALID; }
+    if (n < 0) { set_error("trexhip_identify: n < 0"); return TREXHIP_E_INVALID; }
+    if (n == 0) return TREXHIP_OK;
+    TH_CHECK_HIP(hipSetDevice(ctx->p.device));
+    int rc = ensure_act(ctx, net, n);
+    if (rc) return rc;
+    return net_forward(ctx, d_crops, n, d_probs, d_logits);
+}
+
+int trexhip_identify(trexhip_ctx* ctx, const uint8_t* crops, int32_t n, float* probs) {
+    if (!ctx || !crops || !probs) { set_error("trexhip_identify: null argument"); return TREXHIP_E_INVALID; }
+    Net* net = static_cast<Net*>(ctx->net);
+    if (!net) { set_error("trexhip_identify: weights not loaded (VINetwork status().weights.loaded())"); return TREXHIP_E_INVALID; }
+    if (n < 0) { set_error("trexhip_identify: n < 0"); return TREXHIP_E_INVALID; }
+    if (n == 0) return TREXHIP_OK;
+    TH_CHECK_HIP(hipSetDevice(ctx->p.device));
+    int rc = ensure_act(ctx, net, n);
+    if (rc) return rc;
+    const size_t cb = (size_t)net->W * net->H * net->CH;
+    TH_CHECK_HIP(hipMemcpyAsync(net->crops, crops, cb * n, hipMemcpyHostToDevice, ctx->stream));
+    rc = net_forward(ctx, net->crops, n, net->probs, nullptr);
+    if (rc) return rc;
+    TH_CHECK_HIP(hipMemcpyAsync(probs, net->probs, (size_t)n * net->classes * 4, hipMemcpyDeviceToHost, ctx->stream));
+    TH_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+    return TREXHIP_OK;
+}
+
+int trexhip_num_classes(trexhip_ctx* ctx) {
+    if (!ctx || !ctx->net) return 0;
+    return static_cast<Net*>(ctx->net)->classes;
+}
+
+}  // extern "C"
+
+namespace trexhip {
+void net_free(trexhip_ctx* ctx) { free_net(static_cast<Net*>(ctx->net)); ctx->net = nullptr; }
+}

@@ -89,6 +89,8 @@ struct trexhip_ctx {
     uint8_t* h_pixels = nullptr;
     uint8_t* h_staging = nullptr;       // pinned upload buffer
 
+    void* net = nullptr;                // trexhip::Net (cnn.hip)
+
     bool profiling = false;
     // tuning knobs (env TREXHIP_ROWS_ORDER / TREXHIP_ROWS_BLOCKS override the defaults)
     int tune_rows_order = 1;
@@ -100,4 +102,5 @@ namespace trexhip {
 int launch_segment(trexhip_ctx* ctx, const uint8_t* d_frames, int n);
 void stage_begin(trexhip_ctx* ctx, int stage);
 void stage_end(trexhip_ctx* ctx, int stage);
+void net_free(trexhip_ctx* ctx);
 }
