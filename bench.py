@@ -1,11 +1,14 @@
 #!/usr/bin/env python3
 """bench.py -- headline benchmark of the MI355X TRex hot path (contract: see the task prompt).
 
-One "step" = one pass of the hot path over one batch of synthetic frames that are already resident
-in HBM: background subtraction + threshold + run extraction + CCL + size filter + blob gather
-(+ tables copied to pinned host memory).  Prints ONE JSON line on rank 0.
+One "step" = one pass of the hot path over one batch of synthetic frames already resident in HBM:
+  detect   background subtraction + threshold + run extraction + CCL + size filter + blob gather,
+           blob/run/pixel tables copied to pinned host memory (what TRex's pv::Frame needs)
+  crops    80x80 crop per blob (individual_image_normalization = none)
+  identify V118_3 forward + softmax for every crop, probabilities copied to the host
+Prints ONE JSON line on rank 0.
 
-    python bench.py --gpus 1 --steps 20 --warmup 3
+    python bench.py --gpus 1 --steps 10 --warmup 2
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 """
 import argparse
@@ -17,14 +20,29 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+FLOP_PER_CROP_CONV3 = 2.0 * 400 * 128 * 1600      # 20x20 px, 128 out channels, K = 25*64
+FLOP_PER_CROP_TOTAL = 2.0 * 126.73e6              # 126.73 M MAC per crop at 100 classes
+
+
+def usable_cores():
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = max(1, min(n, int(int(q) / int(p))))
+    except Exception:
+        pass
+    return n
+
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--config", default="C4")
     ap.add_argument("--batch", type=int, default=0, help="frames resident per step (default 64, C5: 16)")
+    ap.add_argument("--stages", default="all", choices=["all", "segment"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     args = ap.parse_args()
@@ -32,7 +50,7 @@ def main():
     import numpy as np
     import torch
     import torch.distributed as dist
-    from trex_amd import capi, synth
+    from trex_amd import capi, synth, weights
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -46,21 +64,41 @@ def main():
 
     W, H, n_ind, _cid = synth.CONFIGS[args.config]
     B = args.batch or (16 if args.config == "C5" else 64)
+    classes = 256 if args.config == "C5" else 100
+    with_cnn = args.stages == "all"
 
-    # distinct frames per rank (frame-sharded: rank r owns frames r*B .. r*B+B-1 of every step's block)
+    # frame-sharded: rank r owns frames r*B .. r*B+B-1 of every step's block (distinct data per rank)
     frames, bg = synth.batch_torch(args.config, B, dev, t0=rank * B)
-    p = capi.default_params(W, H, device=local, max_batch=B, max_blobs=1024, max_pixels=1 << 18, max_runs=32768)
+    max_blobs = 4 * n_ind
+    p = capi.default_params(W, H, device=local, max_batch=B, max_blobs=max_blobs, max_pixels=1 << 18, max_runs=32768)
     seg = capi.Segmenter(p)
     seg.set_background(bg)
+    state = weights.synthetic_state(classes, 4242)
+    if with_cnn:
+        seg.load_weights(weights.pack_blob(state, classes))
+    pool = B * max_blobs
+    crops = torch.empty((pool, 80, 80), dtype=torch.uint8, device=dev)
+    probs = torch.empty((pool, classes), dtype=torch.float32, device=dev)
+    probs_host = torch.empty((pool, classes), dtype=torch.float32).pin_memory()
+    own = torch.cuda.Stream(device=dev)            # torch-side copies ride on the same stream as the kernels
+    seg.set_stream(own.cuda_stream)
     torch.cuda.synchronize()
 
     def step():
         seg.segment_device(frames.data_ptr(), B)
-        return seg.fetch(copy=False)
+        res = seg.fetch(copy=False)                 # syncs; blob tables now on the host
+        n = sum(len(r.blobs) for r in res)
+        if with_cnn and n:
+            seg.crops_device(crops.data_ptr(), n)
+            seg.identify_device(crops.data_ptr(), n, probs.data_ptr())
+            with torch.cuda.stream(own):
+                probs_host[:n].copy_(probs[:n], non_blocking=True)
+            own.synchronize()
+        return n
 
+    n_blobs = 0
     for _ in range(args.warmup):
-        res = step()
-    n_blobs = sum(len(r.blobs) for r in res) if args.warmup else None
+        n_blobs = step()
 
     def barrier():
         torch.cuda.synchronize()
@@ -73,54 +111,91 @@ def main():
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        res = step()
+        n_blobs = step()
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-    rows_ms, rows_n = seg.profile_read(capi.STAGE_ROWS)
-    all_ms, all_n = seg.profile_read(capi.STAGE_SEGMENT_ALL)
+    prof = {name: seg.profile_read(getattr(capi, "STAGE_" + name)) for name in
+            ("ROWS", "SEGMENT_ALL", "CONV2", "CONV3", "CNN_ALL", "CROPS")}
     seg.profile_enable(False)
+
+    def avg_s(name):
+        ms, n = prof[name]
+        return (ms / n) * 1e-3 if n else 0.0
 
     total_frames = world * B * args.steps
     fps = total_frames / dt
-    # roofline of the dominant kernel (k_rows): algorithmic bytes = 2*W*H per frame (frame + background)
-    alg_bytes = 2.0 * W * H * B
-    rows_avg_s = (rows_ms / max(rows_n, 1)) * 1e-3
-    achieved = alg_bytes / rows_avg_s / 1e9 if rows_avg_s > 0 else 0.0
+    seg_bytes = 2.0 * W * H * B                       # algorithmic bytes of the pixel pass: frame + background
+    rows_s, segall_s = avg_s("ROWS"), avg_s("SEGMENT_ALL")
     out = {
         "metric": "frames/s end-to-end (segment+CNN-ID), 2048x2048 x100 individuals",
         "value": fps, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-        "config": {"workload": f"{args.config}: {W}x{H} gray, {n_ind} individuals/frame, {B} frames resident per step per GPU",
-                   "stages": "bg-sub+threshold+CCL+size-filter+blob-gather+D2H tables (identity CNN not in the timed path yet)",
-                   "frames_per_step_per_gpu": B, "blobs_last_step_rank0": n_blobs, "parallelism": f"frame-sharded x{world}"},
-        "roofline": {"kernel": "k_rows", "bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
-                     "frac": achieved / 8000.0, "traffic": None,
-                     "avg_launch_us": rows_avg_s * 1e6, "launches": rows_n,
-                     "algorithmic_bytes_per_launch": alg_bytes},
-        "segment_pass": {"avg_us": all_ms / max(all_n, 1) * 1e3, "launches": all_n,
-                         "frac_of_hbm_peak": (alg_bytes / (all_ms / max(all_n, 1) * 1e-3) / 8e12) if all_ms > 0 else None},
+        "vs_baseline": None, "dtype": "f32" if with_cnn else "u8", "data": "synthetic",
+        "config": {"workload": f"{args.config}: {W}x{H} gray, {n_ind} individuals/frame, {B} frames resident per step per GPU, "
+                               f"80x80x1 crops, {classes}-way V118_3 (random-init weights)",
+                   "stages": "detect(bg-sub+threshold+CCL+filter+gather, tables->host) + crops(none) + identity CNN fp32 + probs->host"
+                             if with_cnn else "detect only (bg-sub+threshold+CCL+filter+gather, tables->host)",
+                   "frames_per_step_per_gpu": B, "blobs_per_step_rank0": n_blobs, "parallelism": f"frame-sharded x{world}"},
     }
+    seg_roof = {"kernel": "k_rows", "bound": "hbm", "achieved": seg_bytes / rows_s / 1e9 if rows_s else 0.0, "peak": 8000.0,
+                "unit": "GB/s", "frac": seg_bytes / rows_s / 8e12 if rows_s else 0.0, "traffic": None,
+                "avg_launch_us": rows_s * 1e6, "launches": prof["ROWS"][1], "algorithmic_bytes_per_launch": seg_bytes,
+                "whole_detect_pass_us": segall_s * 1e6,
+                "whole_detect_pass_frac": seg_bytes / segall_s / 8e12 if segall_s else None}
+    if with_cnn:
+        c3_s = avg_s("CONV3")
+        fl = FLOP_PER_CROP_CONV3 * n_blobs
+        out["roofline"] = {"kernel": "k_conv5<64,128,20,20,32> (conv3)", "bound": "mfma", "achieved": fl / c3_s / 1e12 if c3_s else 0.0,
+                           "peak": 157.3, "unit": "TFLOP/s", "frac": fl / c3_s / 157.3e12 if c3_s else 0.0, "traffic": None,
+                           "avg_launch_us": c3_s * 1e6, "launches": prof["CONV3"][1], "algorithmic_flop_per_launch": fl,
+                           "peak_note": "dense fp32-input MFMA peak (MI355X_MICROARCH.md); the path computes in exact fp32"}
+        cnn_s = avg_s("CNN_ALL")
+        out["stage_us"] = {"detect": segall_s * 1e6, "crops": avg_s("CROPS") * 1e6, "conv2": avg_s("CONV2") * 1e6,
+                           "conv3": c3_s * 1e6, "cnn_all": cnn_s * 1e6,
+                           "cnn_all_tflops": FLOP_PER_CROP_TOTAL * n_blobs / cnn_s / 1e12 if cnn_s else None}
+        out["roofline_detect"] = seg_roof
+    else:
+        out["roofline"] = seg_roof
+
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        from oracle import oracle
-        ncpu = os.cpu_count() or 1
-        sample = frames[: min(B, 2 * ncpu)].cpu().numpy()
+        from oracle import oracle, cnn_oracle
+        ncpu = usable_cores()
+        torch.set_num_threads(ncpu)
+        k = max(2, min(B, ncpu))
+        sample = frames[:k].cpu().numpy()
         bgh = bg.cpu().numpy()
         op = oracle.make_params(W, H)
-        oracle.segment_batch(sample[:ncpu], bgh, op, ncpu)          # warm up
-        reps, t_cpu, done = 0, 0.0, 0
+        oracle.segment_batch(sample[:2], bgh, op, ncpu)          # warm up
         t1 = time.perf_counter()
-        while time.perf_counter() - t1 < args.cpu_seconds:
+        done = 0
+        while time.perf_counter() - t1 < args.cpu_seconds / (2 if with_cnn else 1):
             oracle.segment_batch(sample, bgh, op, ncpu)
-            done += len(sample)
-        t_cpu = time.perf_counter() - t1
-        out["cpu_baseline"] = {"value": done / t_cpu, "unit": "frames/s", "cores": ncpu, "kind": "port",
-                               "sample": f"{len(sample)} distinct {W}x{H} frames of the same batch, repeated for {t_cpu:.1f} s, "
-                                         f"one frame per OpenMP thread; restatement of TRex RawProcessing+CPULabeling (oracle/), not the TRex binary"}
+            done += k
+        seg_fps = done / (time.perf_counter() - t1)
+        cpu = {"unit": "frames/s", "cores": ncpu, "kind": "port", "detect_frames_per_s": seg_fps}
+        if with_cnn:
+            b_, r_, _ = oracle.segment(sample[0], bgh, op)
+            cr = np.stack([oracle.crop_none(sample[0], bgh, bb, r_) for bb in b_])[..., None]
+            cnn_oracle.predict(state, cr[:8], threads=ncpu)
+            t2 = time.perf_counter()
+            reps = 0
+            while time.perf_counter() - t2 < args.cpu_seconds / 2:
+                cnn_oracle.predict(state, cr, threads=ncpu)
+                reps += 1
+            cnn_fps = reps / (time.perf_counter() - t2)
+            cpu["identify_frames_per_s"] = cnn_fps
+            cpu["value"] = 1.0 / (1.0 / seg_fps + 1.0 / cnn_fps)
+            cpu["sample"] = (f"detect: {k} distinct frames of the batch, one per OpenMP thread, repeated {args.cpu_seconds / 2:.0f} s; "
+                             f"identify: the {len(cr)} crops of frame 0 through a torch-CPU restatement of V118_3 ({ncpu} threads), "
+                             f"repeated {args.cpu_seconds / 2:.0f} s; restatements under oracle/, not the TRex binary")
+        else:
+            cpu["value"] = seg_fps
+            cpu["sample"] = f"{k} distinct frames of the batch, one per OpenMP thread, repeated {args.cpu_seconds:.0f} s; oracle/ restatement"
+        out["cpu_baseline"] = cpu
     if rank == 0:
         print(json.dumps(out))
     seg.close()

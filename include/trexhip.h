@@ -135,6 +135,15 @@ int trexhip_fetch(trexhip_ctx* ctx, trexhip_batch_result* out);
 int trexhip_device_view_get(trexhip_ctx* ctx, trexhip_device_view* out);
 int trexhip_synchronize(trexhip_ctx* ctx);
 
+/* ---- crops ------------------------------------------------------------------------------------
+ * constraints::diff_image (tracking/FilterCache.cpp:265-294): one out_w x out_h uint8 crop per blob of the
+ * last segmented batch, pooled order (blob i of trexhip_fetch == crop i).  n_blobs = total_blobs of that
+ * batch.  normalization: individual_image_normalization (none only, for now).  difference: 0 = grey
+ * values, 1 = |bg - p|, 2 = max(bg - p, 0)  (track_background_subtraction, FilterCache.cpp:171-175). */
+enum { TREXHIP_NORMALIZE_NONE = 0, TREXHIP_NORMALIZE_MOMENTS = 1, TREXHIP_NORMALIZE_POSTURE = 2 };
+int trexhip_crops_device(trexhip_ctx* ctx, uint8_t* d_crops, int32_t n_blobs, int32_t out_w, int32_t out_h,
+                         int32_t normalization, int32_t difference);
+
 /* ---- identity network (V118_3) -------------------------------------------------------------
  * VINetwork::load_weights (ml/VisualIdentification.cpp) / visual_recognition_torch.py:841-921: takes the
  * flat fp32 blob described in trex_amd/weights.py (state_dict order; tools/convert_weights.py makes it

@@ -160,3 +160,37 @@ def threshold_blob(runs, pixels, bg, method, threshold, connectivity=8):
 
 def bid(x0, x1, y, n):
     return int(lib().oracle_bid(x0, x1, y, n))
+
+
+def crop_none(frame, bg, blob, runs, out_w=80, out_h=80, difference=0, invert=False):
+    """constraints::diff_image with individual_image_normalization=none
+    (Application/src/tracker/tracking/FilterCache.cpp:157-235 calculate_diff_image, :265-294):
+    paint the blob into its bounding box, then centre-pad with zeros / centre-cut to the output size.
+    difference: 0 grey values, 1 |bg-p|, 2 max(bg-p,0) (track_background_subtraction :171-175)."""
+    bw = int(blob["x1"]) - int(blob["x0"]) + 1
+    bh = int(blob["y1"]) - int(blob["y0"]) + 1
+    img = np.zeros((bh, bw), np.uint8)
+    rs = runs[blob["run_begin"]:blob["run_begin"] + blob["n_runs"]]
+    for r in rs:
+        y, x0, x1 = int(r["y"]), int(r["x0"]), int(r["x1"])
+        p = frame[y, x0:x1 + 1].astype(np.int32)
+        if invert:
+            p = 255 - p
+        if difference:
+            b = bg[y, x0:x1 + 1].astype(np.int32)
+            p = np.abs(b - p) if difference == 1 else np.maximum(b - p, 0)
+        img[y - int(blob["y0"]), x0 - int(blob["x0"]):x1 - int(blob["x0"]) + 1] = p
+    padded = img
+    left = right = top = bottom = 0
+    if padded.shape[1] < out_w:                       # :184-188
+        left = out_w - padded.shape[1]; right = left // 2; left -= right
+    if padded.shape[0] < out_h:                       # :190-194
+        top = out_h - padded.shape[0]; bottom = top // 2; top -= bottom
+    if left or right or top or bottom:
+        padded = np.pad(padded, ((top, bottom), (left, right)))
+    if padded.shape[1] > out_w or padded.shape[0] > out_h:   # :212-226
+        left = padded.shape[1] - out_w; right = left // 2; left -= right
+        top = padded.shape[0] - out_h; bottom = top // 2; top -= bottom
+        padded = padded[top:padded.shape[0] - bottom, left:padded.shape[1] - right]
+    assert padded.shape == (out_h, out_w)
+    return padded
