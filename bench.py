@@ -79,21 +79,34 @@ def main():
     pool = B * max_blobs
     crops = torch.empty((pool, 80, 80), dtype=torch.uint8, device=dev)
     probs = torch.empty((pool, classes), dtype=torch.float32, device=dev)
-    probs_host = torch.empty((pool, classes), dtype=torch.float32).pin_memory()
+    from trex_amd import dist as tdist
+    rows = B * n_ind * 5 // 4                       # fixed table rows per rank per step (all-gather needs equal sizes)
+    table = torch.zeros((rows, tdist.HDR + classes), dtype=torch.int32, device=dev)
+    table_host = torch.empty((world * rows, tdist.HDR + classes), dtype=torch.int32).pin_memory() if rank == 0 else None
     own = torch.cuda.Stream(device=dev)            # torch-side copies ride on the same stream as the kernels
     seg.set_stream(own.cuda_stream)
     torch.cuda.synchronize()
 
+    step_no = [0]
+
     def step():
         seg.segment_device(frames.data_ptr(), B)
-        res = seg.fetch(copy=False)                 # syncs; blob tables now on the host
+        res = seg.fetch(copy=False)                 # syncs; blob/run/pixel tables now on this rank's host
         n = sum(len(r.blobs) for r in res)
-        if with_cnn and n:
-            seg.crops_device(crops.data_ptr(), n)
-            seg.identify_device(crops.data_ptr(), n, probs.data_ptr())
+        assert n <= rows, "identity table too small"
+        if with_cnn:
+            if n:
+                seg.crops_device(crops.data_ptr(), n)
+                seg.identify_device(crops.data_ptr(), n, probs.data_ptr())
+            # per-blob identity table -> (all-gather over RCCL/xGMI) -> rank 0's host, for the sequential matcher
+            frame_base = (step_no[0] * world + rank) * B
+            seg.export_id_table(probs.data_ptr(), n, classes, frame_base, table.data_ptr(), rows)
             with torch.cuda.stream(own):
-                probs_host[:n].copy_(probs[:n], non_blocking=True)
+                g = tdist.all_gather_tables(table) if world > 1 else table
+                if rank == 0:
+                    table_host.copy_(g, non_blocking=True)
             own.synchronize()
+        step_no[0] += 1
         return n
 
     n_blobs = 0
@@ -137,7 +150,7 @@ def main():
         "vs_baseline": None, "dtype": "f32" if with_cnn else "u8", "data": "synthetic",
         "config": {"workload": f"{args.config}: {W}x{H} gray, {n_ind} individuals/frame, {B} frames resident per step per GPU, "
                                f"80x80x1 crops, {classes}-way V118_3 (random-init weights)",
-                   "stages": "detect(bg-sub+threshold+CCL+filter+gather, tables->host) + crops(none) + identity CNN fp32 + probs->host"
+                   "stages": "detect(bg-sub+threshold+CCL+filter+gather, tables->host) + crops(none) + identity CNN fp32 + per-blob ID table (all-gathered when N>1) -> rank-0 host"
                              if with_cnn else "detect only (bg-sub+threshold+CCL+filter+gather, tables->host)",
                    "frames_per_step_per_gpu": B, "blobs_per_step_rank0": n_blobs, "parallelism": f"frame-sharded x{world}"},
     }

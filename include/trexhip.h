@@ -156,6 +156,15 @@ int trexhip_num_classes(trexhip_ctx* ctx);
 int trexhip_identify_device(trexhip_ctx* ctx, const uint8_t* d_crops, int32_t n, float* d_probs, float* d_logits);
 int trexhip_identify(trexhip_ctx* ctx, const uint8_t* crops, int32_t n, float* probs);
 
+/* ---- multi-GPU hand-off --------------------------------------------------------------------
+ * Fixed-size per-blob identity table of the last batch, written to caller-owned device memory
+ * (e.g. a torch tensor that is then all-gathered over RCCL/xGMI to rank 0, whose sequential matcher
+ * consumes it -- Tracker::predicted, tracking/Tracker.cpp:237-247).  Row = 8 x u32 header
+ * {global frame index = frame_base + frame, pv::bid, n_pixels, x0|y0<<16, x1|y1<<16, centroid x (f32),
+ * centroid y (f32), valid} followed by `classes` float probabilities.  Rows >= n_blobs are zeroed. */
+int trexhip_export_id_table_device(trexhip_ctx* ctx, const float* d_probs, int32_t n_blobs, int32_t classes,
+                                   uint32_t frame_base, void* d_table, int32_t max_rows);
+
 /* live HIP-event timing of the dominant kernels on the ctx stream (bench.py roofline):
  * stage ids TREXHIP_STAGE_* ; returns accumulated milliseconds and launch count since reset */
 enum { TREXHIP_STAGE_ROWS = 0, TREXHIP_STAGE_SEGMENT_ALL = 1, TREXHIP_STAGE_CONV2 = 2, TREXHIP_STAGE_CONV3 = 3,

@@ -66,7 +66,7 @@ SYMBOLS = [
     "trexhip_set_stream", "trexhip_set_background", "trexhip_set_background_device", "trexhip_segment_device",
     "trexhip_segment", "trexhip_fetch", "trexhip_device_view_get", "trexhip_synchronize",
     "trexhip_profile_enable", "trexhip_profile_read", "trexhip_profile_reset",
-    "trexhip_crops_device", "trexhip_load_weights", "trexhip_num_classes", "trexhip_identify_device", "trexhip_identify",
+    "trexhip_crops_device", "trexhip_export_id_table_device", "trexhip_load_weights", "trexhip_num_classes", "trexhip_identify_device", "trexhip_identify",
 ]
 
 
@@ -94,6 +94,7 @@ def lib():
         L.trexhip_profile_read.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
         L.trexhip_profile_reset.argtypes = [C.c_void_p]
         L.trexhip_crops_device.argtypes = [C.c_void_p, C.c_void_p] + [C.c_int32] * 5
+        L.trexhip_export_id_table_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_uint32, C.c_void_p, C.c_int32]
         L.trexhip_load_weights.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
         L.trexhip_num_classes.argtypes = [C.c_void_p]
         L.trexhip_identify_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]
@@ -216,6 +217,11 @@ class Segmenter:
     def crops_device(self, d_crops_ptr, n_blobs, out_w=80, out_h=80, normalization=0, difference=0):
         """constraints::diff_image for every blob of the last batch -> uint8 [n_blobs][out_h][out_w] at d_crops_ptr."""
         _check(lib().trexhip_crops_device(self._h, C.c_void_p(d_crops_ptr), n_blobs, out_w, out_h, normalization, difference))
+
+    def export_id_table(self, d_probs_ptr, n_blobs, classes, frame_base, d_table_ptr, max_rows):
+        """Fixed-size per-blob identity table (8 header words + classes floats per row) into caller memory."""
+        _check(lib().trexhip_export_id_table_device(self._h, C.c_void_p(d_probs_ptr) if d_probs_ptr else None, n_blobs,
+                                                    classes, frame_base, C.c_void_p(d_table_ptr), max_rows))
 
     # ---- identity network (mirrors VINetwork: load_weights / probabilities) ----
     def load_weights(self, blob: bytes):

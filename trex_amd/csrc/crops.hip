@@ -85,3 +85,50 @@ int trexhip_crops_device(trexhip_ctx* ctx, uint8_t* d_crops, int32_t n_blobs, in
 }
 
 }  // extern "C"
+
+// ------------------------------------------------------------------------------------------------
+// per-blob identity table: the fixed-size record that frame-sharded ranks all-gather over xGMI for
+// the sequential matcher on rank 0 (consumer: Tracker::predicted, Tracker.cpp:237-247)
+// row = 8 header words + C probabilities:
+//   [0] global frame index  [1] pv::bid  [2] n_pixels  [3] x0 | y0<<16  [4] x1 | y1<<16
+//   [5] centroid x (float)  [6] centroid y (float)     [7] 1 = valid row
+// ------------------------------------------------------------------------------------------------
+namespace trexhip {
+__global__ __launch_bounds__(256) void k_id_table(const trexhip_frame_info* __restrict__ info,
+                                                  const uint32_t* __restrict__ blob_frame,
+                                                  const trexhip_blob* __restrict__ blobs, const float* __restrict__ probs,
+                                                  int n, int C, int B, uint32_t frame_base, uint32_t* __restrict__ table,
+                                                  int max_rows) {
+    const int row = blockIdx.x;
+    uint32_t* out = table + (size_t)row * (8 + C);
+    bool valid = row < n;
+    uint32_t f = 0;
+    if (valid) { f = blob_frame[row]; valid = f < (uint32_t)B && info[f].flags == 0; }
+    if (threadIdx.x == 0) {
+        uint32_t hdr[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (valid) {
+            const trexhip_blob b = blobs[row];
+            hdr[0] = frame_base + f; hdr[1] = b.bid; hdr[2] = b.n_pixels;
+            hdr[3] = b.x0 | ((uint32_t)b.y0 << 16); hdr[4] = b.x1 | ((uint32_t)b.y1 << 16);
+            hdr[5] = __float_as_uint((float)((double)b.m10 / (double)b.n_pixels));
+            hdr[6] = __float_as_uint((float)((double)b.m01 / (double)b.n_pixels));
+            hdr[7] = 1u;
+        }
+        for (int i = 0; i < 8; ++i) out[i] = hdr[i];
+    }
+    for (int c = threadIdx.x; c < C; c += 256)
+        out[8 + c] = (valid && probs) ? __float_as_uint(probs[(size_t)row * C + c]) : 0u;
+}
+}  // namespace trexhip
+
+extern "C" int trexhip_export_id_table_device(trexhip_ctx* ctx, const float* d_probs, int32_t n_blobs, int32_t classes,
+                                              uint32_t frame_base, void* d_table, int32_t max_rows) {
+    if (!ctx || !d_table) { trexhip::set_error("trexhip_export_id_table_device: null argument"); return TREXHIP_E_INVALID; }
+    if (n_blobs < 0 || max_rows < n_blobs || classes < 0) { trexhip::set_error("trexhip_export_id_table_device: need 0 <= n_blobs <= max_rows"); return TREXHIP_E_INVALID; }
+    if (max_rows == 0) return TREXHIP_OK;
+    TH_CHECK_HIP(hipSetDevice(ctx->p.device));
+    hipLaunchKernelGGL(trexhip::k_id_table, dim3(max_rows), dim3(256), 0, ctx->stream, ctx->d_info, ctx->d_blob_frame, ctx->d_blobs,
+                       d_probs, n_blobs, classes, ctx->last_n, frame_base, static_cast<uint32_t*>(d_table), max_rows);
+    TH_CHECK_HIP(hipGetLastError());
+    return TREXHIP_OK;
+}
