@@ -130,6 +130,10 @@ int trexhip_set_background_device(trexhip_ctx* ctx, const uint8_t* d_gray);
  * generate_binary + CPULabeling::run + size filter for n gray frames. */
 int trexhip_segment_device(trexhip_ctx* ctx, const uint8_t* d_frames, int32_t n);
 int trexhip_segment(trexhip_ctx* ctx, const uint8_t* const* frames, int32_t stride, int32_t n);
+/* the same for the BGR / BGRA tile images TRex actually hands over (BackgroundSubtraction.cpp:162-180):
+ * channels 3 or 4; color_channel < 0 (or >= channels) = cv::cvtColor(BGR2GRAY / BGRA2GRAY), else that channel */
+int trexhip_segment_color(trexhip_ctx* ctx, const uint8_t* const* frames, int32_t stride, int32_t n,
+                          int32_t channels, int32_t color_channel);
 /* wait for the last segment call and copy its tables to pinned host memory */
 int trexhip_fetch(trexhip_ctx* ctx, trexhip_batch_result* out);
 int trexhip_device_view_get(trexhip_ctx* ctx, trexhip_device_view* out);

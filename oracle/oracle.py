@@ -194,3 +194,11 @@ def crop_none(frame, bg, blob, runs, out_w=80, out_h=80, difference=0, invert=Fa
         padded = padded[top:padded.shape[0] - bottom, left:padded.shape[1] - right]
     assert padded.shape == (out_h, out_w)
     return padded
+
+
+def bgr2gray(img):
+    """cv::cvtColor(BGR2GRAY / BGRA2GRAY) on 8-bit data (BackgroundSubtraction.cpp:167,170), restated from
+    OpenCV's published fixed-point path: (B*1868 + G*9617 + R*4899 + (1<<13)) >> 14.  [recalled, unpinned:
+    no OpenCV in the build image; cmn::bgr2gray uses in Application/Tests/test_pixels.cpp:43,52]"""
+    a = img.astype(np.uint32)
+    return ((a[..., 0] * 1868 + a[..., 1] * 9617 + a[..., 2] * 4899 + 8192) >> 14).astype(np.uint8)

@@ -1,0 +1,197 @@
+// C++ test of the host adapter (trex_amd/host) through the C ABI, checked against the CPU oracle.
+// Reads like the reference's own plumbing test (Application/Tests/test_segmenter.cpp:95-235: 64x48
+// frames with an 8x8 white square moving 3 px/frame) but also checks blob CONTENTS bit for bit.
+#include <cassert>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <random>
+#include "../../trex_amd/host/HipBackgroundSubtraction.h"
+#include "../../trex_amd/host/HipVINetwork.h"
+#include "../../oracle/trex_oracle.h"
+
+using namespace track;
+
+#define CHECK(x) do { if (!(x)) { std::fprintf(stderr, "CHECK failed %s:%d: %s\n", __FILE__, __LINE__, #x); std::exit(1); } } while (0)
+
+static cmn::Image::Ptr gray_to_bgr(const std::vector<uint8_t>& g, int W, int H, int ch, std::mt19937& rng, bool same_channels) {
+    auto im = cmn::Image::Make(H, W, ch);
+    for (int i = 0; i < W * H; ++i)
+        for (int c = 0; c < ch; ++c) im->data()[i * ch + c] = same_channels || c == 3 ? g[i] : (uint8_t)(rng() & 0xff);
+    return im;
+}
+static std::vector<uint8_t> bgr2gray(const cmn::Image& im) {
+    std::vector<uint8_t> g((size_t)im.rows * im.cols);
+    for (size_t i = 0; i < g.size(); ++i) {
+        const uint8_t* p = im.data() + i * im.dims;
+        g[i] = (uint8_t)((p[0] * 1868u + p[1] * 9617u + p[2] * 4899u + 8192u) >> 14);
+    }
+    return g;
+}
+
+static void compare_with_oracle(const pv::Frame& frame, const std::vector<uint8_t>& gray, const std::vector<uint8_t>& bg, int W, int H,
+                                const oracle_params& op) {
+    oracle_frame* of = oracle_segment(gray.data(), bg.data(), &op);
+    int32_t nb, nr, np;
+    oracle_frame_counts(of, &nb, &nr, &np);
+    std::vector<oracle_blob> blobs(nb); std::vector<oracle_run> runs(nr); std::vector<uint8_t> px(np);
+    oracle_frame_copy(of, blobs.data(), runs.data(), px.data());
+    oracle_frame_free(of);
+    CHECK(frame.n() == nb);
+    CHECK((int)frame.mask().size() == nb && (int)frame.pixels().size() == nb);
+    for (int b = 0; b < nb; ++b) {
+        const auto& lines = *frame.mask()[b];
+        CHECK(lines.size() == blobs[b].n_runs);
+        for (uint32_t j = 0; j < blobs[b].n_runs; ++j) {
+            const oracle_run& r = runs[blobs[b].run_begin + j];
+            CHECK(lines[j] == cmn::HorizontalLine(r.y, r.x0, r.x1));
+            if (j) CHECK(lines[j - 1] < lines[j]);                     // pv.cpp:505-508 ordering invariant
+        }
+        const auto& p = *frame.pixels()[b];
+        CHECK(p.size() == blobs[b].n_pixels);                          // pv.cpp:512
+        CHECK(std::memcmp(p.data(), px.data() + blobs[b].pix_begin, p.size()) == 0);
+    }
+    (void)W; (void)H;
+}
+
+int main(int argc, char** argv) {
+    std::mt19937 rng(7);
+    const int W = 64, H = 48;
+    HipBackgroundSubtraction::Settings s;
+    s.max_batch = 4;
+    const auto type = detect::ObjectDetectionType::hip_background_subtraction;
+    HipBackgroundSubtraction::register_hip_backend(type, s, W, H);
+    const detect::BackendHooks* hooks = detect::backend(type);
+    CHECK(hooks && hooks->init && hooks->apply && hooks->set_background && hooks->fps && hooks->deinit);
+    hooks->init();
+
+    oracle_params op; std::memset(&op, 0, sizeof(op));
+    op.width = W; op.height = H; op.threshold = 15; op.threshold_maximum = 255; op.enable_difference = 1;
+    op.absolute_difference = 1; op.zero_is_background = 1; op.connectivity = 8; op.closing_size = 3; op.cm_per_pixel = 1.0;
+
+    // --- no background yet: the future must carry an exception (BackgroundSubtraction.cpp:58-73 waits; we refuse) ---
+    {
+        TileImage t; t.images.push_back(cmn::Image::Make(H, W, 3));
+        auto f = HipBackgroundSubtraction::apply(std::move(t));
+        bool threw = false;
+        try { f.get(); } catch (const std::exception&) { threw = true; }
+        CHECK(threw);
+    }
+    std::vector<uint8_t> bg(W * H, 0);
+    { auto b = cmn::Image::Make(H, W, 1); std::memcpy(b->data(), bg.data(), bg.size()); hooks->set_background(b); }
+
+    // --- the reference's moving square, handed over as BGR tiles, 4 tiles per apply() ---
+    const size_t pool_before = buffers::TileBuffers::get().size();
+    int callbacks = 0;
+    for (int t0 = 0; t0 < 12; t0 += 4) {
+        std::vector<TileImage> tiles;
+        std::vector<std::future<SegmentationData>> futs;
+        std::vector<std::vector<uint8_t>> grays;
+        for (int t = t0; t < t0 + 4; ++t) {
+            std::vector<uint8_t> g(W * H, 0);
+            for (int y = 20; y < 28; ++y) for (int x = 3 * t; x < 3 * t + 8; ++x) g[y * W + x] = 255;
+            TileImage tile;
+            tile.images.push_back(gray_to_bgr(g, W, H, 3 + (t & 1), rng, true));
+            tile.data.image = cmn::Image::Make(H, W, 3);
+            tile.data.image->set_to((uint8_t)t);
+            tile.promise = std::make_unique<std::promise<SegmentationData>>();
+            futs.push_back(tile.promise->get_future());
+            tile.callback = [&callbacks]() { ++callbacks; };
+            grays.push_back(g);
+            tiles.emplace_back(std::move(tile));
+        }
+        // mixed BGR/BGRA in one batch is refused; run them one tile at a time instead when channel counts differ
+        for (size_t k = 0; k < tiles.size(); ++k) {
+            std::vector<TileImage> one; one.emplace_back(std::move(tiles[k]));
+            hooks->apply(std::move(one));
+        }
+        for (size_t k = 0; k < futs.size(); ++k) {
+            SegmentationData d = futs[k].get();
+            CHECK(d.frame.n() == 1);
+            CHECK(d.frame.pixels()[0]->size() == 64);
+            CHECK((*d.frame.mask()[0])[0] == cmn::HorizontalLine(20, 3 * (t0 + k), 3 * (t0 + k) + 7));
+            CHECK(d.image && d.image->data()[0] == (uint8_t)(t0 + k));      // original frame untouched
+            compare_with_oracle(d.frame, grays[k], bg, W, H, op);
+        }
+    }
+    CHECK(callbacks == 12);
+    CHECK(buffers::TileBuffers::get().size() == pool_before + 12 + 1);      // every tile image handed back (+1 from the error case)
+    CHECK(hooks->fps() > 0);
+
+    // --- a whole batch of random colour tiles in ONE apply(): contents vs oracle through cvtColor ---
+    {
+        std::vector<uint8_t> bg2(W * H);
+        for (auto& v : bg2) v = 100 + (rng() % 20);
+        auto b = cmn::Image::Make(H, W, 1); std::memcpy(b->data(), bg2.data(), bg2.size()); hooks->set_background(b);
+        std::vector<TileImage> tiles; std::vector<std::future<SegmentationData>> futs; std::vector<std::vector<uint8_t>> grays;
+        for (int k = 0; k < 4; ++k) {
+            std::vector<uint8_t> dummy(W * H, 0);
+            TileImage tile; tile.images.push_back(gray_to_bgr(dummy, W, H, 3, rng, false));
+            for (int i = 0; i < 40; ++i) {   // dark bars
+                int y = rng() % H, x = rng() % (W - 10), l = 1 + rng() % 9;
+                for (int q = 0; q < l; ++q) for (int c = 0; c < 3; ++c) tile.images[0]->data()[(y * W + x + q) * 3 + c] = rng() % 30;
+            }
+            grays.push_back(bgr2gray(*tile.images[0]));
+            tile.promise = std::make_unique<std::promise<SegmentationData>>();
+            futs.push_back(tile.promise->get_future());
+            tiles.emplace_back(std::move(tile));
+        }
+        hooks->apply(std::move(tiles));
+        for (int k = 0; k < 4; ++k) { SegmentationData d = futs[k].get(); compare_with_oracle(d.frame, grays[k], bg2, W, H, op); }
+    }
+    // --- wrong channel count -> exception through the future (BackgroundSubtraction.cpp:179) ---
+    {
+        TileImage t; t.images.push_back(cmn::Image::Make(H, W, 1));
+        auto f = HipBackgroundSubtraction::apply(std::move(t));
+        bool threw = false;
+        try { f.get(); } catch (const std::exception&) { threw = true; }
+        CHECK(threw);
+    }
+    // --- TileImage destroyed with a live promise raises inside the future (core/TileImage.cpp:13-21) ---
+    {
+        std::future<SegmentationData> f;
+        { TileImage t; t.promise = std::make_unique<std::promise<SegmentationData>>(); f = t.promise->get_future(); }
+        bool threw = false;
+        try { f.get(); } catch (const std::exception&) { threw = true; }
+        CHECK(threw);
+    }
+    hooks->deinit();
+
+    // --- identity facade: files written by the pytest wrapper: weights blob, crops, expected probabilities ---
+    if (argc >= 4) {
+        auto slurp = [](const char* p) { std::ifstream f(p, std::ios::binary); return std::vector<char>((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>()); };
+        auto blob = slurp(argv[1]); auto crops = slurp(argv[2]); auto expect = slurp(argv[3]);
+        HipVINetwork net(0);
+        CHECK(!net.weights_loaded());
+        {   // probabilities before load_weights -> error through the future
+            std::vector<cmn::Image::Ptr> ims; ims.push_back(cmn::Image::Make(80, 80, 1));
+            auto f = net.probabilities(std::move(ims), [](auto&&, auto&&) {});
+            bool threw = false; try { f.get(); } catch (const std::exception&) { threw = true; } CHECK(threw);
+        }
+        net.load_weights(blob.data(), blob.size());
+        const int C = net.num_classes();
+        const size_t n = crops.size() / 6400;
+        CHECK(expect.size() == n * C * sizeof(float));
+        std::vector<cmn::Image::Ptr> ims;
+        for (size_t i = 0; i < n; ++i) { auto im = cmn::Image::Make(80, 80, 1); std::memcpy(im->data(), crops.data() + i * 6400, 6400); ims.push_back(std::move(im)); }
+        std::vector<std::vector<float>> values; std::vector<float> indexes;
+        net.probabilities(std::move(ims), [&](std::vector<std::vector<float>>&& v, std::vector<float>&& idx) { values = std::move(v); indexes = std::move(idx); }).get();
+        CHECK(values.size() == n && indexes.size() == n);
+        const float* e = reinterpret_cast<const float*>(expect.data());
+        double worst = 0;
+        for (size_t i = 0; i < n; ++i) { CHECK(indexes[i] == (float)i); for (int c = 0; c < C; ++c) worst = std::max(worst, (double)std::fabs(values[i][c] - e[i * C + c])); }
+        CHECK(worst <= 1e-4);
+        auto flat = HipVINetwork::transform_results(n + 2, indexes, values);
+        CHECK(flat.size() == (n + 2) * C && flat[(n + 1) * C] == -1.f && flat[0] == values[0][0]);
+        CHECK(HipVINetwork::batch_size_for(8) == 64 && HipVINetwork::batch_size_for(100) == 128 && HipVINetwork::batch_size_for(65) == 128);
+        {   // wrong crop size
+            std::vector<cmn::Image::Ptr> bad; bad.push_back(cmn::Image::Make(64, 64, 1));
+            auto f = net.probabilities(std::move(bad), [](auto&&, auto&&) {});
+            bool threw = false; try { f.get(); } catch (const std::exception&) { threw = true; } CHECK(threw);
+        }
+        std::printf("identity facade ok: %zu crops, %d classes, max |dp| = %.3g\n", n, C, worst);
+    }
+    std::printf("host adapter ok\n");
+    return 0;
+}

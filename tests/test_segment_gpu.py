@@ -183,3 +183,25 @@ def test_errors():
     seg.close()
     with pytest.raises(capi.TrexHipError):
         capi.Segmenter(capi.default_params(70000, 64))
+
+
+@pytest.mark.parametrize("channels,color_channel", [(3, -1), (4, -1), (3, 1), (4, 2), (3, 7)])
+def test_colour_tile_input(channels, color_channel):
+    # what TRex really hands over: BGR / BGRA tile images (BackgroundSubtraction.cpp:162-180)
+    rng = np.random.default_rng(channels * 10 + color_channel)
+    H, W = 96, 256
+    col = rng.integers(0, 256, (2, H, W, channels)).astype(np.uint8)
+    col[:, 20:40, 30:90] //= 8
+    bg = np.full((H, W), 140, np.uint8)
+    if 0 <= color_channel < channels:
+        gray = col[..., color_channel]
+    else:
+        gray = oracle.bgr2gray(col)
+    p = capi.default_params(W, H, max_batch=2, max_blobs=32768, threshold=40)
+    seg = capi.Segmenter(p)
+    seg.set_background(bg)
+    seg.segment_color_host([c for c in col], color_channel)
+    res = seg.fetch()
+    for r, g in zip(res, gray):
+        assert_frame_equal(r, np.ascontiguousarray(g), bg, threshold=40)
+    seg.close()

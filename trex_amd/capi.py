@@ -64,7 +64,7 @@ class TrexHipError(RuntimeError):
 SYMBOLS = [
     "trexhip_abi_version", "trexhip_last_error", "trexhip_default_params", "trexhip_create", "trexhip_destroy",
     "trexhip_set_stream", "trexhip_set_background", "trexhip_set_background_device", "trexhip_segment_device",
-    "trexhip_segment", "trexhip_fetch", "trexhip_device_view_get", "trexhip_synchronize",
+    "trexhip_segment", "trexhip_segment_color", "trexhip_fetch", "trexhip_device_view_get", "trexhip_synchronize",
     "trexhip_profile_enable", "trexhip_profile_read", "trexhip_profile_reset",
     "trexhip_crops_device", "trexhip_export_id_table_device", "trexhip_load_weights", "trexhip_num_classes", "trexhip_identify_device", "trexhip_identify",
 ]
@@ -87,6 +87,7 @@ def lib():
         L.trexhip_set_background_device.argtypes = [C.c_void_p, C.c_void_p]
         L.trexhip_segment_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int32]
         L.trexhip_segment.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.c_int32, C.c_int32]
+        L.trexhip_segment_color.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.c_int32, C.c_int32, C.c_int32, C.c_int32]
         L.trexhip_fetch.argtypes = [C.c_void_p, C.POINTER(BatchResult)]
         L.trexhip_device_view_get.argtypes = [C.c_void_p, C.POINTER(DeviceView)]
         L.trexhip_synchronize.argtypes = [C.c_void_p]
@@ -185,6 +186,13 @@ class Segmenter:
         ptrs = (C.c_void_p * len(frames))(*[f.ctypes.data for f in frames])
         stride = frames[0].shape[1] if frames else self.params.width
         _check(lib().trexhip_segment(self._h, ptrs, stride, len(frames)))
+
+    def segment_color_host(self, frames, color_channel=-1):
+        """frames: list of uint8 [H,W,3|4] BGR/BGRA host images (what TRex's TileImage holds)."""
+        frames = [np.ascontiguousarray(f, np.uint8) for f in frames]
+        ch = frames[0].shape[2]
+        ptrs = (C.c_void_p * len(frames))(*[f.ctypes.data for f in frames])
+        _check(lib().trexhip_segment_color(self._h, ptrs, frames[0].shape[1] * ch, len(frames), ch, color_channel))
 
     def synchronize(self):
         _check(lib().trexhip_synchronize(self._h))

@@ -7,6 +7,7 @@
 // the output size: pad = out - size, right = pad/2, left = pad - right (:184-194); cut likewise (:212-226)).
 // One workgroup = one blob of the last segmented batch, in pooled order.
 #include "internal.h"
+#include <cstring>
 
 namespace trexhip {
 
@@ -131,4 +132,82 @@ extern "C" int trexhip_export_id_table_device(trexhip_ctx* ctx, const float* d_p
                        d_probs, n_blobs, classes, ctx->last_n, frame_base, static_cast<uint32_t*>(d_table), max_rows);
     TH_CHECK_HIP(hipGetLastError());
     return TREXHIP_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// colour reduce in front of the detect stage (BackgroundSubtraction.cpp:162-180): cv::cvtColor
+// BGR2GRAY / BGRA2GRAY (8-bit fixed point: (B*1868 + G*9617 + R*4899 + 8192) >> 14) or a channel pick
+// (color_channel).  4 pixels per thread, 12/16-byte loads, 4-byte stores.
+// ------------------------------------------------------------------------------------------------
+namespace trexhip {
+template <int CH>
+__global__ __launch_bounds__(256) void k_to_gray(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst, size_t npix4,
+                                                 int color_channel) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= npix4) return;
+    uint32_t w[CH];
+    const uint32_t* s = reinterpret_cast<const uint32_t*>(src) + i * CH;
+#pragma unroll
+    for (int k = 0; k < CH; ++k) w[k] = s[k];
+    uint32_t out = 0;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        uint32_t c[4] = {0, 0, 0, 0};
+#pragma unroll
+        for (int k = 0; k < CH; ++k) {
+            const int byte = p * CH + k;
+            c[k] = (w[byte >> 2] >> (8 * (byte & 3))) & 0xffu;
+        }
+        uint32_t g;
+        if (color_channel >= 0) g = c[color_channel & 3];
+        else g = (c[0] * 1868u + c[1] * 9617u + c[2] * 4899u + 8192u) >> 14;
+        out |= g << (8 * p);
+    }
+    reinterpret_cast<uint32_t*>(dst)[i] = out;
+}
+
+int launch_to_gray(trexhip_ctx* ctx, const uint8_t* d_color, uint8_t* d_gray, size_t npix, int channels, int color_channel) {
+    const size_t n4 = npix / 4;
+    const dim3 grid((unsigned)((n4 + 255) / 256));
+    if (channels == 3) hipLaunchKernelGGL((k_to_gray<3>), grid, dim3(256), 0, ctx->stream, d_color, d_gray, n4, color_channel);
+    else               hipLaunchKernelGGL((k_to_gray<4>), grid, dim3(256), 0, ctx->stream, d_color, d_gray, n4, color_channel);
+    TH_CHECK_HIP(hipGetLastError());
+    return TREXHIP_OK;
+}
+}  // namespace trexhip
+
+extern "C" int trexhip_segment_color(trexhip_ctx* ctx, const uint8_t* const* frames, int32_t stride, int32_t n,
+                                     int32_t channels, int32_t color_channel) {
+    using namespace trexhip;
+    if (!ctx || !frames) { set_error("trexhip_segment_color: null argument"); return TREXHIP_E_INVALID; }
+    if (!ctx->has_bg) { set_error("trexhip_segment_color: background image not set"); return TREXHIP_E_INVALID; }
+    if (n < 0 || n > ctx->p.max_batch) { set_error("trexhip_segment_color: n outside 0..max_batch"); return TREXHIP_E_INVALID; }
+    if (channels != 3 && channels != 4) {   // BackgroundSubtraction.cpp:179 throws for anything else
+        set_error("Invalid number of channels in input image for the network."); return TREXHIP_E_INVALID;
+    }
+    if (color_channel >= channels) color_channel = -1;                 // BackgroundSubtraction.cpp:163-164
+    const size_t W = ctx->p.width, H = ctx->p.height;
+    if ((W * H) % 4 != 0) { set_error("trexhip_segment_color: width*height must be a multiple of 4"); return TREXHIP_E_UNSUPPORTED; }
+    if ((size_t)stride < W * channels) { set_error("trexhip_segment_color: stride < width*channels"); return TREXHIP_E_INVALID; }
+    TH_CHECK_HIP(hipSetDevice(ctx->p.device));
+    if (n == 0) { ctx->last_n = 0; ctx->fetched = false; return TREXHIP_OK; }
+    if (!ctx->d_staging) {
+        TH_CHECK_HIP(hipMalloc(reinterpret_cast<void**>(&ctx->d_staging), (size_t)ctx->p.max_batch * W * H + 16));
+        TH_CHECK_HIP(hipHostMalloc(reinterpret_cast<void**>(&ctx->h_staging), (size_t)ctx->p.max_batch * W * H, hipHostMallocDefault));
+    }
+    if (!ctx->d_color) {
+        TH_CHECK_HIP(hipMalloc(reinterpret_cast<void**>(&ctx->d_color), (size_t)ctx->p.max_batch * W * H * 4 + 16));
+        TH_CHECK_HIP(hipHostMalloc(reinterpret_cast<void**>(&ctx->h_color), (size_t)ctx->p.max_batch * W * H * 4, hipHostMallocDefault));
+    }
+    TH_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+    const size_t row = W * channels;
+    for (int i = 0; i < n; ++i) {
+        if (!frames[i]) { set_error("trexhip_segment_color: null frame pointer"); return TREXHIP_E_INVALID; }
+        uint8_t* dst = ctx->h_color + (size_t)i * H * row;
+        for (size_t y = 0; y < H; ++y) std::memcpy(dst + y * row, frames[i] + y * (size_t)stride, row);
+    }
+    TH_CHECK_HIP(hipMemcpyAsync(ctx->d_color, ctx->h_color, (size_t)n * H * row, hipMemcpyHostToDevice, ctx->stream));
+    int rc = launch_to_gray(ctx, ctx->d_color, ctx->d_staging, (size_t)n * W * H, channels, color_channel);
+    if (rc) return rc;
+    return launch_segment(ctx, ctx->d_staging, n);
 }

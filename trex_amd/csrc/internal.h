@@ -88,6 +88,8 @@ struct trexhip_ctx {
     trexhip_run* h_runs = nullptr;
     uint8_t* h_pixels = nullptr;
     uint8_t* h_staging = nullptr;       // pinned upload buffer
+    uint8_t* d_color = nullptr;         // BGR/BGRA frames of the colour-input API
+    uint8_t* h_color = nullptr;
 
     void* net = nullptr;                // trexhip::Net (cnn.hip)
 

@@ -1,0 +1,176 @@
+// HipBackgroundSubtraction.h -- the detection backend TRex talks to, implemented on libtrexhip.
+//
+// Same surface as track::BackgroundSubtraction (Application/src/tracker/python/BackgroundSubtraction.h:10-26):
+// set_background / apply / deinit / fps, plus register_hip_backend() which installs detect::BackendHooks
+// (python/BackendRegistry.h:10-19) exactly like register_yolo_backend does (python/YOLO.cpp:1738-1747).
+// The contract of apply(std::vector<TileImage>&&) follows BackgroundSubtraction.cpp:146-342 line by line:
+//   read tile.images (BGR/BGRA, pooled) -> blobs in full-frame coordinates -> frame.set_encoding ->
+//   frame.add_object(pair) per kept blob (< UINT16_MAX lines) -> promise->set_value(std::move(tile.data)) ;
+//   on error promise->set_exception ; then ALWAYS tile.callback() (exceptions swallowed) and every image
+//   back to buffers::TileBuffers ; finally one fps sample (tiles / seconds).
+// Header-only; inside a TRex build define TREXHIP_WITH_TREX so TRex's own headers supply the types.
+#pragma once
+#ifdef TREXHIP_WITH_TREX
+#include <commons.pc.h>
+#include <core/TileImage.h>
+#include <core/TileBuffers.h>
+#include <python/BackendRegistry.h>
+#else
+#include "trex_types.h"
+#endif
+#include <chrono>
+#include <shared_mutex>
+#include <string>
+#include "../../include/trexhip.h"
+
+namespace track {
+
+struct HipBackgroundSubtraction {
+    struct Settings {                 // the values BackgroundSubtraction::apply / RawProcessing read
+        int detect_threshold = 15, threshold_maximum = 255;
+        bool detect_threshold_is_absolute = true, enable_difference = true, image_invert = false;
+        int color_channel = -1;       // std::optional<uint8_t> color_channel; <0 = none
+        double cm_per_pixel = 1.0;
+        std::vector<std::pair<double, double>> detect_size_filter;
+        cmn::meta_encoding_t meta_encoding = cmn::meta_encoding_t::gray;
+        int device = 0, max_batch = 8;
+    };
+
+    static void init(const Settings& s, uint32_t width, uint32_t height) {
+        auto& d = data();
+        std::unique_lock g(d.gpu_mutex);
+        if (d.ctx) { trexhip_destroy(d.ctx); d.ctx = nullptr; }
+        d.settings = s;
+        trexhip_params p;
+        trexhip_default_params(&p, (int32_t)width, (int32_t)height);
+        p.device = s.device; p.max_batch = s.max_batch;
+        p.threshold = s.detect_threshold; p.threshold_maximum = s.threshold_maximum;
+        p.absolute_difference = s.detect_threshold_is_absolute; p.enable_difference = s.enable_difference;
+        p.image_invert = s.image_invert; p.cm_per_pixel = s.cm_per_pixel;
+        p.n_ranges = (int32_t)s.detect_size_filter.size();
+        for (int i = 0; i < p.n_ranges && i < 8; ++i) { p.ranges[2 * i] = s.detect_size_filter[i].first; p.ranges[2 * i + 1] = s.detect_size_filter[i].second; }
+        check(trexhip_create(&p, &d.ctx));
+        d.has_background = false;
+    }
+
+    // BackgroundSubtraction::set_background -> Data::set (BackgroundSubtraction.cpp:86-101)
+    static void set_background(const cmn::Image::Ptr& average) {
+        auto& d = data();
+        std::unique_lock g(d.gpu_mutex);
+        if (!average) { d.has_background = false; return; }
+        if (!d.ctx) throw std::runtime_error("HipBackgroundSubtraction: not initialised");
+        if (average->dims != 1) throw std::runtime_error("HipBackgroundSubtraction: background must be a gray image");
+        check(trexhip_set_background(d.ctx, average->data(), (int32_t)average->cols));
+        d.has_background = true;
+    }
+
+    // BackgroundSubtraction::apply(TileImage&&) (BackgroundSubtraction.cpp:107-116): synchronous variant of the
+    // pipeline enqueue -- the caller's PipelineManager thread calls apply(vector) below
+    static std::future<SegmentationData> apply(TileImage&& tiled) {
+        if (tiled.promise) throw std::runtime_error("Tiled.promise was already set.");
+        tiled.promise = std::make_unique<std::promise<SegmentationData>>();
+        auto f = tiled.promise->get_future();
+        std::vector<TileImage> v;
+        v.emplace_back(std::move(tiled));
+        apply(std::move(v));
+        return f;
+    }
+
+    static void apply(std::vector<TileImage>&& tiled) {
+        const auto t0 = std::chrono::steady_clock::now();
+        auto& d = data();
+        std::shared_lock guard(d.gpu_mutex);                        // BackgroundSubtraction.cpp:130
+        // one device batch per call: all tiles' first images (1 tile == full frame for bg-sub, DetectionTypes.cpp:294-295)
+        size_t i = 0;
+        std::string batch_error;
+        std::vector<const uint8_t*> ptrs;
+        int channels = 0;
+        bool ok = d.ctx && d.has_background;
+        if (!ok) batch_error = "Background image not set";
+        if (ok) {
+            for (auto& tile : tiled)
+                for (auto& image : tile.images) {
+                    if (image->dims != 3 && image->dims != 4) { ok = false; batch_error = "Invalid number of channels in input image for the network."; }
+                    if (channels == 0) channels = (int)image->dims;
+                    if ((int)image->dims != channels) { ok = false; batch_error = "mixed channel counts in one batch"; }
+                    ptrs.push_back(image->data());
+                }
+        }
+        trexhip_batch_result res{};
+        if (ok && !ptrs.empty()) {
+            if ((int)ptrs.size() > d.settings.max_batch) { ok = false; batch_error = "more tile images than max_batch"; }
+            else if (trexhip_segment_color(d.ctx, ptrs.data(), (int32_t)(tiled[0].images[0]->cols * channels), (int32_t)ptrs.size(),
+                                           channels, d.settings.color_channel) != 0 ||
+                     trexhip_fetch(d.ctx, &res) != 0) { ok = false; batch_error = trexhip_last_error(); }
+        }
+        size_t img_index = 0;
+        for (auto&& tile : tiled) {
+            try {
+                if (!ok) throw std::runtime_error(batch_error);
+                tile.data.frame.set_encoding(d.settings.meta_encoding);            // :303
+                for (size_t k = 0; k < tile.images.size(); ++k, ++img_index) {
+                    const trexhip_frame_info& fi = res.frames[img_index];
+                    for (uint32_t b = 0; b < fi.n_blobs; ++b) {
+                        const trexhip_blob& B = res.blobs[fi.blob_begin + b];
+                        if (B.n_runs >= UINT16_MAX) continue;                       // :306-313
+                        auto lines = std::make_unique<std::vector<cmn::HorizontalLine>>();
+                        lines->reserve(B.n_runs);
+                        const trexhip_run* r = res.runs + fi.run_begin + B.run_begin;
+                        for (uint32_t j = 0; j < B.n_runs; ++j) lines->emplace_back(r[j].y, r[j].x0, r[j].x1);
+                        const uint8_t* px = res.pixels + fi.pix_begin + B.pix_begin;
+                        auto pixels = std::make_unique<cmn::PixelArray_t>(px, px + B.n_pixels);
+                        tile.data.frame.add_object(cmn::blob::Pair(std::move(lines), std::move(pixels), 0));   // :305-314
+                    }
+                }
+                tile.promise->set_value(std::move(tile.data));                      // :319
+                tile.promise = nullptr;
+            } catch (...) {
+                if (tile.promise) { tile.promise->set_exception(std::current_exception()); tile.promise = nullptr; }   // :322-325
+            }
+            try { if (tile.callback) tile.callback(); } catch (...) {}              // :328-334
+            for (auto& image : tile.images) buffers::TileBuffers::get().move_back(std::move(image));   // :336-339
+            tile.images.clear();
+            ++i;
+        }
+        if (!tiled.empty()) {
+            const double el = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+            d.add_time_sample(double(tiled.size()) / el);                           // :344-346
+        }
+    }
+
+    static void deinit() {
+        auto& d = data();
+        std::unique_lock g(d.gpu_mutex);
+        if (d.ctx) { trexhip_destroy(d.ctx); d.ctx = nullptr; }
+        d.has_background = false;
+    }
+    static double fps() { return data().fps(); }
+    static bool is_initializing() { return false; }
+
+    // detect::register_backend(type, hooks) -- python/BackendRegistry.h:19; pattern of register_yolo_backend
+    static void register_hip_backend(detect::ObjectDetectionType::Class type, const Settings& s, uint32_t w, uint32_t h) {
+        detect::BackendHooks hooks;
+        hooks.init = [s, w, h]() { HipBackgroundSubtraction::init(s, w, h); };
+        hooks.deinit = []() { HipBackgroundSubtraction::deinit(); };
+        hooks.is_initializing = []() { return HipBackgroundSubtraction::is_initializing(); };
+        hooks.fps = []() { return HipBackgroundSubtraction::fps(); };
+        hooks.apply = [](std::vector<TileImage>&& tiles) { HipBackgroundSubtraction::apply(std::move(tiles)); };
+        hooks.set_background = [](const cmn::Image::Ptr& bg) { HipBackgroundSubtraction::set_background(bg); };
+        detect::register_backend(type, std::move(hooks));
+    }
+
+private:
+    struct Data {
+        trexhip_ctx* ctx = nullptr;
+        Settings settings;
+        bool has_background = false;
+        double time = 0, samples = 0;
+        std::shared_mutex gpu_mutex, time_mutex;
+        double fps() { std::shared_lock g(time_mutex); return samples == 0 ? 0 : time / samples; }   // :25-30
+        void add_time_sample(double s) { std::unique_lock g(time_mutex); time += s; samples++; }        // :31-35
+    };
+    static Data& data() { static Data d; return d; }
+    static void check(int rc) { if (rc != 0) throw std::runtime_error(std::string("libtrexhip: ") + trexhip_last_error()); }
+};
+
+}  // namespace track

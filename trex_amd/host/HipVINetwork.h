@@ -1,0 +1,91 @@
+// HipVINetwork.h -- identity-network facade on libtrexhip with the surface of Python::VINetwork
+// (Application/src/tracker/ml/VisualIdentification.h:32,115-133,189):
+//   probabilities(std::vector<Image::Ptr>&&, callback)  -> callback(values[N][classes], indexes[N])
+//   transform_results (VisualIdentification.cpp:809-830)  N x M flat, -1 for missing rows
+//   batch size rule (VisualIdentification.cpp:112-118)
+// Errors surface as exceptions through the returned future, like SoftException does in the reference (:481-484).
+#pragma once
+#ifdef TREXHIP_WITH_TREX
+#include <commons.pc.h>
+#include <misc/Image.h>
+#else
+#include "trex_types.h"
+#endif
+#include <functional>
+#include <future>
+#include <string>
+#include <vector>
+#include "../../include/trexhip.h"
+
+namespace track {
+
+struct HipVINetwork {
+    using callback_t = std::function<void(std::vector<std::vector<float>>&&, std::vector<float>&&)>;
+
+    explicit HipVINetwork(int device = 0) {
+        trexhip_params p;
+        trexhip_default_params(&p, 64, 64);      // the detect buffers are unused by this facade
+        p.device = device; p.max_batch = 1; p.max_runs = 64; p.max_blobs = 1; p.max_pixels = 64;
+        check(trexhip_create(&p, &_ctx));
+    }
+    ~HipVINetwork() { trexhip_destroy(_ctx); }
+    HipVINetwork(const HipVINetwork&) = delete;
+
+    // VINetwork::load_weights: flat blob made by tools/convert_weights.py / trex_amd/weights.py
+    void load_weights(const void* blob, size_t bytes) { check(trexhip_load_weights(_ctx, blob, bytes)); }
+    bool weights_loaded() const { return trexhip_num_classes(_ctx) > 0; }
+    int num_classes() const { return trexhip_num_classes(_ctx); }
+
+    static size_t batch_size_for(size_t n_ids) {        // VisualIdentification.cpp:112-118
+        size_t b = n_ids > 64 ? n_ids : 64;
+        if (b < 128) { size_t p = 1; while (p < b) p <<= 1; return p; }
+        return 128;
+    }
+
+    std::future<void> probabilities(std::vector<cmn::Image::Ptr>&& images, callback_t&& callback) {
+        std::promise<void> prom;
+        auto fut = prom.get_future();
+        try {
+            if (!weights_loaded()) throw std::runtime_error("weights not loaded");
+            const int C = num_classes();
+            std::vector<uint8_t> crops;
+            size_t per = 0;
+            for (auto& im : images) {
+                if (!im) throw std::runtime_error("null image");
+                if (im->rows != 80 || im->cols != 80) throw std::runtime_error("Invalid image size (expected individual_image_size 80x80)");  // visual_recognition_torch.py:1006-1018
+                if (per == 0) per = im->size();
+                if (im->size() != per) throw std::runtime_error("Invalid image channels");
+                crops.insert(crops.end(), im->data(), im->data() + im->size());
+            }
+            std::vector<float> flat(images.size() * (size_t)C);
+            if (!images.empty()) check(trexhip_identify(_ctx, crops.data(), (int32_t)images.size(), flat.data()));
+            std::vector<std::vector<float>> values(images.size());
+            std::vector<float> indexes(images.size());
+            for (size_t i = 0; i < images.size(); ++i) {
+                values[i].assign(flat.begin() + i * C, flat.begin() + (i + 1) * C);
+                indexes[i] = (float)i;                                        // visual_recognition_torch.py:1024-1028
+            }
+            callback(std::move(values), std::move(indexes));
+            prom.set_value();
+        } catch (...) { prom.set_exception(std::current_exception()); }
+        return fut;
+    }
+
+    // VisualIdentification.cpp:809-830
+    static std::vector<float> transform_results(size_t n_images, const std::vector<float>& indexes,
+                                                const std::vector<std::vector<float>>& values) {
+        const size_t M = values.empty() ? 0 : values.front().size();
+        std::vector<float> out(n_images * M, -1.f);
+        for (size_t i = 0; i < values.size() && i < indexes.size(); ++i) {
+            const size_t idx = (size_t)indexes[i];
+            if (idx < n_images) std::copy(values[i].begin(), values[i].end(), out.begin() + idx * M);
+        }
+        return out;
+    }
+
+private:
+    trexhip_ctx* _ctx = nullptr;
+    static void check(int rc) { if (rc != 0) throw std::runtime_error(std::string("libtrexhip: ") + trexhip_last_error()); }
+};
+
+}  // namespace track
