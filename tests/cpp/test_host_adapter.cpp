@@ -116,7 +116,7 @@ int main(int argc, char** argv) {
         }
     }
     CHECK(callbacks == 12);
-    CHECK(buffers::TileBuffers::get().size() == pool_before + 12 + 1);      // every tile image handed back (+1 from the error case)
+    CHECK(buffers::TileBuffers::get().size() == pool_before + 12);          // every tile image handed back to the pool
     CHECK(hooks->fps() > 0);
 
     // --- a whole batch of random colour tiles in ONE apply(): contents vs oracle through cvtColor ---
