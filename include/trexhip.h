@@ -64,6 +64,11 @@ typedef struct trexhip_params {
     double  ranges[16];          /* [start,end) pairs in cm^2                                        */
 } trexhip_params;
 
+/* size class of a re-thresholded blob against track_size_filter (tracking/Tracker.cpp:864-912) */
+#define TREXHIP_BLOB_IN_RANGE    0u   /* fish_size.in_range_of_one -> commit                     */
+#define TREXHIP_BLOB_BELOW_RANGE 1u   /* recount < max_range().start -> filter_out(OutsideRange) */
+#define TREXHIP_BLOB_BIG         2u   /* otherwise -> big_blob                                    */
+
 /* HorizontalLine{y,x0,x1}, x1 inclusive (pv.cpp:509); 8 bytes */
 typedef struct trexhip_run { uint16_t x0, x1, y, pad; } trexhip_run;
 
@@ -76,6 +81,8 @@ typedef struct trexhip_blob {
     uint16_t x0, y0, x1, y1;        /* inclusive bounding box                                */
     uint32_t bid;                   /* pv::bid of the blob (13/13/6-bit hash of first line)  */
     uint32_t px_min_max;            /* min | max << 8 of the grey values                     */
+    uint32_t parent;                /* re-threshold results: pooled index of the detect blob; else 0xFFFFFFFF */
+    uint32_t flags;                 /* re-threshold results: TREXHIP_BLOB_* size class; else 0 */
     uint64_t m10, m01;              /* sum x, sum y                                          */
     uint64_t m20, m11, m02;         /* sum x^2, sum x*y, sum y^2                             */
     uint64_t sp, spx, spy;          /* sum p, sum p*x, sum p*y                               */
@@ -138,6 +145,17 @@ int trexhip_segment_color(trexhip_ctx* ctx, const uint8_t* const* frames, int32_
 int trexhip_fetch(trexhip_ctx* ctx, trexhip_batch_result* out);
 int trexhip_device_view_get(trexhip_ctx* ctx, trexhip_device_view* out);
 int trexhip_synchronize(trexhip_ctx* ctx);
+
+/* ---- track-stage re-threshold -----------------------------------------------------------------
+ * Tracker::prefilter's arithmetic (tracking/Tracker.cpp:765-849): for every kept blob of the last segmented
+ * batch, pixel::threshold_blob(blob, threshold, background) -- keep a pixel iff diff >= threshold with
+ * method 0 = |bg-p| (track_threshold_is_absolute), 1 = max(bg-p,0) (signed), 2 = p (no background
+ * subtraction); runs split where pixels fail, survivors re-labelled into sub-blobs.  Nothing is dropped:
+ * each sub-blob carries `parent` (pooled index of its detect blob) and `flags` (TREXHIP_BLOB_* class
+ * against size_ranges = track_size_filter, cm^2), so the host applies prefilter's remaining policy
+ * (recount = sum of n_pixels over a parent's sub-blobs).  Results are a second table set. */
+int trexhip_rethreshold_device(trexhip_ctx* ctx, int32_t threshold, int32_t method, const double* size_ranges, int32_t n_ranges);
+int trexhip_fetch_rethreshold(trexhip_ctx* ctx, trexhip_batch_result* out);
 
 /* ---- crops ------------------------------------------------------------------------------------
  * constraints::diff_image (tracking/FilterCache.cpp:265-294): one out_w x out_h uint8 crop per blob of the

@@ -15,11 +15,11 @@ RUN_DTYPE = np.dtype([("x0", "<u2"), ("x1", "<u2"), ("y", "<u2"), ("pad", "<u2")
 BLOB_DTYPE = np.dtype([
     ("run_begin", "<u4"), ("n_runs", "<u4"), ("pix_begin", "<u4"), ("n_pixels", "<u4"),
     ("x0", "<u2"), ("y0", "<u2"), ("x1", "<u2"), ("y1", "<u2"),
-    ("bid", "<u4"), ("px_min_max", "<u4"),
+    ("bid", "<u4"), ("px_min_max", "<u4"), ("parent", "<u4"), ("flags", "<u4"),
     ("m10", "<u8"), ("m01", "<u8"), ("m20", "<u8"), ("m11", "<u8"), ("m02", "<u8"),
     ("sp", "<u8"), ("spx", "<u8"), ("spy", "<u8"),
 ])
-assert BLOB_DTYPE.itemsize == 96 and RUN_DTYPE.itemsize == 8
+assert BLOB_DTYPE.itemsize == 104 and RUN_DTYPE.itemsize == 8
 
 
 class Params(C.Structure):
@@ -86,6 +86,9 @@ def lib():
         L.oracle_threshold_blob.restype = C.c_void_p
         L.oracle_threshold_blob.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32,
                                             C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32]
+        L.oracle_rethreshold_frame.restype = C.c_void_p
+        L.oracle_rethreshold_frame.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
+                                               C.c_int32, C.c_void_p, C.c_int32, C.c_double, C.c_int32]
         L.oracle_bid.restype = C.c_uint32
         L.oracle_bid.argtypes = [C.c_uint32] * 4
         del u8p
@@ -202,3 +205,18 @@ def bgr2gray(img):
     no OpenCV in the build image; cmn::bgr2gray uses in Application/Tests/test_pixels.cpp:43,52]"""
     a = img.astype(np.uint32)
     return ((a[..., 0] * 1868 + a[..., 1] * 9617 + a[..., 2] * 4899 + 8192) >> 14).astype(np.uint8)
+
+
+def rethreshold_frame(frame, bg, params, method, threshold, size_ranges=(), invert=False):
+    """Detect stage followed by Tracker::prefilter's threshold_blob on every kept blob -> (blobs, runs, pixels)
+    of the sub-blobs, with parent / flags filled (see trex_oracle.h)."""
+    frame = np.ascontiguousarray(frame, np.uint8)
+    bg = np.ascontiguousarray(bg, np.uint8)
+    L = lib()
+    h = L.oracle_segment(_ptr(frame), _ptr(bg), C.byref(params))
+    rng = np.ascontiguousarray(np.array(size_ranges, np.float64).reshape(-1))
+    h2 = L.oracle_rethreshold_frame(h, _ptr(frame), _ptr(bg), params.width, params.height, method, threshold,
+                                    params.connectivity, _ptr(rng) if len(rng) else None, len(rng) // 2,
+                                    params.cm_per_pixel, 1 if invert else 0)
+    L.oracle_frame_free(h)
+    return _take_frame(h2)

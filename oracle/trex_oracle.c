@@ -217,7 +217,7 @@ static oracle_frame* label_image(const uint8_t* bin, const uint8_t* img_px, int 
         int32_t k = new_idx[b];
         if (k < 0) continue;
         oracle_blob* B = &f->blobs[k];
-        B->run_begin = ro; B->pix_begin = po; B->n_runs = 0; B->n_pixels = 0;
+        B->run_begin = ro; B->pix_begin = po; B->n_runs = 0; B->n_pixels = 0; B->parent = 0xFFFFFFFFu; B->flags = 0;
         B->x0 = B->y0 = 0xFFFF; B->x1 = B->y1 = 0;
         ro += cnt_runs[b]; po += (uint32_t)cnt_px[b];
     }
@@ -366,5 +366,48 @@ oracle_frame* oracle_threshold_blob(const oracle_run* runs, int32_t n_runs, cons
         B->bid = oracle_bid(r0.x0, r0.x1, r0.y, B->n_runs);
     }
     free(bin); free(val);
+    return f;
+}
+
+
+oracle_frame* oracle_rethreshold_frame(const oracle_frame* detect, const uint8_t* frame, const uint8_t* bg, int32_t width,
+                                       int32_t height, int32_t method, int32_t threshold, int32_t connectivity,
+                                       const double* ranges, int32_t n_ranges, double cm_per_pixel, int32_t invert) {
+    /* paint the survivors of every kept detect blob into one scratch image tagged with (blob index + 1), label it,
+     * then read each sub-blob's parent back from the tag of its first pixel.  Blobs of different parents can never
+     * touch (they were separate 8-connected components), so one labelling pass over the frame is equivalent to
+     * threshold_blob per blob (Tracker.cpp:833-837). */
+    const size_t N = (size_t)width * height;
+    uint8_t* bin = (uint8_t*)calloc(N, 1);
+    uint8_t* val = (uint8_t*)calloc(N, 1);
+    uint32_t* tag = (uint32_t*)calloc(N, sizeof(uint32_t));
+    for (int32_t k = 0; k < detect->n_blobs; ++k) {
+        const oracle_blob* B = &detect->blobs[k];
+        for (uint32_t i = 0; i < B->n_runs; ++i) {
+            const oracle_run r = detect->runs[B->run_begin + i];
+            for (int x = r.x0; x <= r.x1; ++x) {
+                const size_t o = (size_t)r.y * width + x;
+                int p = frame[o];
+                if (invert) p = 255 - p;
+                if (diff_method(p, bg[o], method) >= threshold) { bin[o] = 255; val[o] = (uint8_t)p; tag[o] = (uint32_t)k + 1; }
+            }
+        }
+    }
+    oracle_frame* f = label_image(bin, val, width, height, connectivity, NULL);
+    float sqcm = (float)(cm_per_pixel * cm_per_pixel);
+    for (int32_t k = 0; k < f->n_blobs; ++k) {
+        oracle_blob* B = &f->blobs[k];
+        const oracle_run r0 = f->runs[B->run_begin];
+        B->parent = tag[(size_t)r0.y * width + r0.x0] - 1;
+        uint32_t cat = 0;
+        if (n_ranges > 0) {
+            double v = (double)((float)B->n_pixels * sqcm);
+            int in = 0; double mn = ranges[0];
+            for (int i = 0; i < n_ranges; ++i) { if (v >= ranges[2 * i] && v < ranges[2 * i + 1]) in = 1; if (ranges[2 * i] < mn) mn = ranges[2 * i]; }
+            if (!in) cat = v < mn ? 1u : 2u;       /* Tracker.cpp:908-912 */
+        }
+        B->flags = cat;
+    }
+    free(bin); free(val); free(tag);
     return f;
 }

@@ -52,6 +52,8 @@ typedef struct oracle_blob {
     uint16_t x0, y0, x1, y1;     /* inclusive bounding box */
     uint32_t bid;                /* pv::bid hash of the first run */
     uint32_t px_min_max;         /* min | max << 8 */
+    uint32_t parent;             /* re-threshold: index of the detect blob, else 0xFFFFFFFF */
+    uint32_t flags;              /* re-threshold: size class 0 in range / 1 below / 2 big */
     uint64_t m10, m01;           /* sum x, sum y over pixels */
     uint64_t m20, m11, m02;      /* sum x^2, sum x*y, sum y^2 */
     uint64_t sp, spx, spy;       /* sum p, sum p*x, sum p*y (p = grey value) */
@@ -87,6 +89,12 @@ oracle_frame* oracle_threshold_blob(const oracle_run* runs, int32_t n_runs, cons
                                     const uint8_t* bg, int32_t bg_stride, int32_t width, int32_t height,
                                     int32_t method, int32_t threshold, int32_t connectivity);
 
+/* Tracker::prefilter arithmetic for a whole frame (tracking/Tracker.cpp:765-912): threshold_blob on every blob of
+ * `detect` (an oracle_segment result), sub-blobs in raster order of their first run, each with parent = index of
+ * its detect blob and flags = size class against `ranges` (cm^2, half open). */
+oracle_frame* oracle_rethreshold_frame(const oracle_frame* detect, const uint8_t* frame, const uint8_t* bg, int32_t width,
+                                       int32_t height, int32_t method, int32_t threshold, int32_t connectivity,
+                                       const double* ranges, int32_t n_ranges, double cm_per_pixel, int32_t invert);
 uint32_t oracle_bid(uint32_t x0, uint32_t x1, uint32_t y, uint32_t n_runs);
 
 #ifdef __cplusplus

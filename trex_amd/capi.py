@@ -15,7 +15,7 @@ RUN_DTYPE = np.dtype([("x0", "<u2"), ("x1", "<u2"), ("y", "<u2"), ("pad", "<u2")
 BLOB_DTYPE = np.dtype([
     ("run_begin", "<u4"), ("n_runs", "<u4"), ("pix_begin", "<u4"), ("n_pixels", "<u4"),
     ("x0", "<u2"), ("y0", "<u2"), ("x1", "<u2"), ("y1", "<u2"),
-    ("bid", "<u4"), ("px_min_max", "<u4"),
+    ("bid", "<u4"), ("px_min_max", "<u4"), ("parent", "<u4"), ("flags", "<u4"),
     ("m10", "<u8"), ("m01", "<u8"), ("m20", "<u8"), ("m11", "<u8"), ("m02", "<u8"),
     ("sp", "<u8"), ("spx", "<u8"), ("spy", "<u8"),
 ])
@@ -24,7 +24,7 @@ INFO_DTYPE = np.dtype([
     ("blob_begin", "<u4"), ("run_begin", "<u4"), ("pix_begin", "<u4"),
     ("n_raw_runs", "<u4"), ("n_raw_blobs", "<u4"), ("flags", "<u4"), ("reserved", "<u4", (3,)),
 ])
-assert BLOB_DTYPE.itemsize == 96 and RUN_DTYPE.itemsize == 8 and INFO_DTYPE.itemsize == 48
+assert BLOB_DTYPE.itemsize == 104 and RUN_DTYPE.itemsize == 8 and INFO_DTYPE.itemsize == 48
 
 STAGE_ROWS, STAGE_SEGMENT_ALL, STAGE_CONV2, STAGE_CONV3, STAGE_CNN_ALL, STAGE_CROPS = 0, 1, 2, 3, 4, 5
 
@@ -64,7 +64,7 @@ class TrexHipError(RuntimeError):
 SYMBOLS = [
     "trexhip_abi_version", "trexhip_last_error", "trexhip_default_params", "trexhip_create", "trexhip_destroy",
     "trexhip_set_stream", "trexhip_set_background", "trexhip_set_background_device", "trexhip_segment_device",
-    "trexhip_segment", "trexhip_segment_color", "trexhip_fetch", "trexhip_device_view_get", "trexhip_synchronize",
+    "trexhip_segment", "trexhip_segment_color", "trexhip_rethreshold_device", "trexhip_fetch_rethreshold", "trexhip_fetch", "trexhip_device_view_get", "trexhip_synchronize",
     "trexhip_profile_enable", "trexhip_profile_read", "trexhip_profile_reset",
     "trexhip_crops_device", "trexhip_export_id_table_device", "trexhip_load_weights", "trexhip_num_classes", "trexhip_identify_device", "trexhip_identify",
 ]
@@ -88,6 +88,8 @@ def lib():
         L.trexhip_segment_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int32]
         L.trexhip_segment.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.c_int32, C.c_int32]
         L.trexhip_segment_color.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.c_int32, C.c_int32, C.c_int32, C.c_int32]
+        L.trexhip_rethreshold_device.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int32]
+        L.trexhip_fetch_rethreshold.argtypes = [C.c_void_p, C.POINTER(BatchResult)]
         L.trexhip_fetch.argtypes = [C.c_void_p, C.POINTER(BatchResult)]
         L.trexhip_device_view_get.argtypes = [C.c_void_p, C.POINTER(DeviceView)]
         L.trexhip_synchronize.argtypes = [C.c_void_p]
@@ -197,9 +199,9 @@ class Segmenter:
     def synchronize(self):
         _check(lib().trexhip_synchronize(self._h))
 
-    def fetch(self, copy=True):
+    def fetch(self, copy=True, rethreshold=False):
         r = BatchResult()
-        rc = lib().trexhip_fetch(self._h, C.byref(r))
+        rc = (lib().trexhip_fetch_rethreshold if rethreshold else lib().trexhip_fetch)(self._h, C.byref(r))
         if rc != 0 and rc != -3:
             _check(rc)
         info = _from_addr(r.frames, r.n_frames, INFO_DTYPE)
@@ -250,6 +252,12 @@ class Segmenter:
     def identify_device(self, d_crops_ptr, n, d_probs_ptr, d_logits_ptr=None):
         _check(lib().trexhip_identify_device(self._h, C.c_void_p(d_crops_ptr), n, C.c_void_p(d_probs_ptr),
                                              C.c_void_p(d_logits_ptr) if d_logits_ptr else None))
+
+    def rethreshold(self, threshold, method=0, size_ranges=()):
+        """Tracker::prefilter's threshold_blob for every blob of the last batch; fetch(rethreshold=True) reads it."""
+        rng = np.ascontiguousarray(np.array(size_ranges, np.float64).reshape(-1))
+        _check(lib().trexhip_rethreshold_device(self._h, threshold, method, rng.ctypes.data_as(C.c_void_p) if len(rng) else None,
+                                                len(rng) // 2))
 
     def device_view(self):
         v = DeviceView()

@@ -94,6 +94,8 @@ static int fill_cfg(trexhip_ctx* ctx) {
 
 using namespace trexhip;
 
+static void pass2_free(trexhip_ctx* ctx);
+
 extern "C" {
 
 int trexhip_abi_version(void) { return TREXHIP_ABI_VERSION; }
@@ -180,6 +182,7 @@ void trexhip_destroy(trexhip_ctx* ctx) {
     hipSetDevice(ctx->p.device);
     if (ctx->stream) hipStreamSynchronize(ctx->stream);
     net_free(ctx);
+    pass2_free(ctx);
     void* dev[] = {ctx->d_bg, ctx->d_staging, ctx->d_ctr, ctx->d_row_cnt, ctx->d_row_off, ctx->d_row_base, ctx->d_tmp_runs,
                    ctx->d_raster, ctx->d_parent, ctx->d_root_ord, ctx->d_cnt_runs, ctx->d_cnt_px, ctx->d_cur_run,
                    ctx->d_pix_begin, ctx->d_blob_map, ctx->d_info, ctx->d_blobs, ctx->d_blob_frame, ctx->d_runs, ctx->d_pixels, ctx->d_color};
@@ -296,6 +299,71 @@ int trexhip_fetch(trexhip_ctx* ctx, trexhip_batch_result* out) {
             rc = TREXHIP_E_CAPACITY;
         }
     return rc;
+}
+
+static int pass2_alloc(trexhip_ctx* ctx) {
+    Pass2& q = ctx->pass2;
+    if (q.allocated) return TREXHIP_OK;
+    const size_t B = ctx->p.max_batch, H = ctx->p.height, R = ctx->p.max_runs, NB = ctx->p.max_blobs, P = ctx->p.max_pixels;
+    int rc = TREXHIP_OK;
+#define TRY(x) do { if (rc == TREXHIP_OK) rc = (x); } while (0)
+    TRY(dmalloc(&q.d_sub_cnt, B * R)); TRY(dmalloc(&q.d_sub_base, B * R)); TRY(dmalloc(&q.d_row_base, B * (H + 1)));
+    TRY(dmalloc(&q.d_row_cnt, B * H)); TRY(dmalloc(&q.d_run_parent, B * R)); TRY(dmalloc(&q.d_raster, B * R));
+    TRY(dmalloc(&q.d_parent, B * R)); TRY(dmalloc(&q.d_root_ord, B * R)); TRY(dmalloc(&q.d_cnt_runs, B * R));
+    TRY(dmalloc(&q.d_cnt_px, B * R)); TRY(dmalloc(&q.d_cur_run, B * R)); TRY(dmalloc(&q.d_pix_begin, B * R));
+    TRY(dmalloc(&q.d_blob_map, B * R)); TRY(dmalloc(&q.d_totals, 4)); TRY(dmalloc(&q.d_info, B));
+    TRY(dmalloc(&q.d_blobs, B * NB)); TRY(dmalloc(&q.d_blob_frame, B * NB)); TRY(dmalloc(&q.d_runs, B * R)); TRY(dmalloc(&q.d_pixels, B * P));
+    TRY(hmalloc(&q.h_info, B)); TRY(hmalloc(&q.h_totals, 4)); TRY(hmalloc(&q.h_blobs, B * NB)); TRY(hmalloc(&q.h_runs, B * R)); TRY(hmalloc(&q.h_pixels, B * P));
+#undef TRY
+    q.allocated = rc == TREXHIP_OK;
+    return rc;
+}
+
+static void pass2_free(trexhip_ctx* ctx) {
+    Pass2& q = ctx->pass2;
+    void* dev[] = {q.d_sub_cnt, q.d_sub_base, q.d_row_base, q.d_row_cnt, q.d_run_parent, q.d_raster, q.d_parent, q.d_root_ord, q.d_cnt_runs,
+                   q.d_cnt_px, q.d_cur_run, q.d_pix_begin, q.d_blob_map, q.d_totals, q.d_info, q.d_blobs, q.d_blob_frame, q.d_runs, q.d_pixels};
+    for (void* p : dev) if (p) hipFree(p);
+    void* host[] = {q.h_info, q.h_totals, q.h_blobs, q.h_runs, q.h_pixels};
+    for (void* p : host) if (p) hipHostFree(p);
+    q = Pass2();
+}
+
+int trexhip_rethreshold_device(trexhip_ctx* ctx, int32_t threshold, int32_t method, const double* size_ranges, int32_t n_ranges) {
+    if (!ctx) { set_error("trexhip_rethreshold_device: null ctx"); return TREXHIP_E_INVALID; }
+    if (method < 0 || method > 2) { set_error("trexhip_rethreshold_device: method must be 0 (absolute), 1 (sign) or 2 (none)"); return TREXHIP_E_INVALID; }
+    if (n_ranges < 0 || n_ranges > 8 || (n_ranges && !size_ranges)) { set_error("trexhip_rethreshold_device: bad size ranges"); return TREXHIP_E_INVALID; }
+    if (!ctx->d_frames || ctx->last_n == 0) { set_error("trexhip_rethreshold_device: no segmented batch"); return TREXHIP_E_INVALID; }
+    TH_CHECK_HIP(hipSetDevice(ctx->p.device));
+    int rc = pass2_alloc(ctx);
+    if (rc) return rc;
+    return launch_rethreshold(ctx, threshold, method, size_ranges, n_ranges);
+}
+
+int trexhip_fetch_rethreshold(trexhip_ctx* ctx, trexhip_batch_result* out) {
+    if (!ctx || !out) { set_error("trexhip_fetch_rethreshold: null argument"); return TREXHIP_E_INVALID; }
+    Pass2& q = ctx->pass2;
+    if (!q.allocated || q.valid_n == 0) { set_error("trexhip_fetch_rethreshold: no re-thresholded batch"); return TREXHIP_E_INVALID; }
+    TH_CHECK_HIP(hipSetDevice(ctx->p.device));
+    std::memset(out, 0, sizeof(*out));
+    const int n = q.valid_n;
+    out->n_frames = n;
+    out->frames = q.h_info; out->blobs = q.h_blobs; out->runs = q.h_runs; out->pixels = q.h_pixels;
+    hipStream_t s = ctx->stream;
+    TH_CHECK_HIP(hipMemcpyAsync(q.h_info, q.d_info, sizeof(trexhip_frame_info) * n, hipMemcpyDeviceToHost, s));
+    TH_CHECK_HIP(hipMemcpyAsync(q.h_totals, q.d_totals, sizeof(uint32_t) * 4, hipMemcpyDeviceToHost, s));
+    TH_CHECK_HIP(hipStreamSynchronize(s));
+    const uint32_t tb = q.h_totals[0] < ctx->cfg.pool_blobs ? q.h_totals[0] : ctx->cfg.pool_blobs;
+    const uint32_t tr = q.h_totals[1] < ctx->cfg.pool_runs ? q.h_totals[1] : ctx->cfg.pool_runs;
+    const uint32_t tp = q.h_totals[2] < ctx->cfg.pool_pixels ? q.h_totals[2] : ctx->cfg.pool_pixels;
+    if (tb) TH_CHECK_HIP(hipMemcpyAsync(q.h_blobs, q.d_blobs, sizeof(trexhip_blob) * tb, hipMemcpyDeviceToHost, s));
+    if (tr) TH_CHECK_HIP(hipMemcpyAsync(q.h_runs, q.d_runs, sizeof(trexhip_run) * tr, hipMemcpyDeviceToHost, s));
+    if (tp) TH_CHECK_HIP(hipMemcpyAsync(q.h_pixels, q.d_pixels, tp, hipMemcpyDeviceToHost, s));
+    TH_CHECK_HIP(hipStreamSynchronize(s));
+    out->total_blobs = tb; out->total_runs = tr; out->total_pixels = tp;
+    for (int i = 0; i < n; ++i)
+        if (q.h_info[i].flags) { set_error("a frame exceeded capacity during re-threshold: raise max_runs/max_blobs/max_pixels"); return TREXHIP_E_CAPACITY; }
+    return TREXHIP_OK;
 }
 
 int trexhip_device_view_get(trexhip_ctx* ctx, trexhip_device_view* out) {

@@ -49,6 +49,28 @@ struct Stage {
 
 }  // namespace trexhip
 
+namespace trexhip {
+// second CCL pass (track-stage re-threshold): its own run-level state and pooled outputs
+struct Pass2 {
+    bool allocated = false;
+    int valid_n = 0;
+    uint32_t *d_sub_cnt = nullptr, *d_sub_base = nullptr, *d_row_base = nullptr, *d_row_cnt = nullptr, *d_run_parent = nullptr;
+    trexhip_run* d_raster = nullptr;
+    uint32_t *d_parent = nullptr, *d_root_ord = nullptr, *d_cnt_runs = nullptr, *d_cnt_px = nullptr, *d_cur_run = nullptr,
+             *d_pix_begin = nullptr, *d_totals = nullptr, *d_blob_frame = nullptr;
+    int32_t* d_blob_map = nullptr;
+    trexhip_frame_info* d_info = nullptr;
+    trexhip_blob* d_blobs = nullptr;
+    trexhip_run* d_runs = nullptr;
+    uint8_t* d_pixels = nullptr;
+    trexhip_frame_info* h_info = nullptr;
+    uint32_t* h_totals = nullptr;
+    trexhip_blob* h_blobs = nullptr;
+    trexhip_run* h_runs = nullptr;
+    uint8_t* h_pixels = nullptr;
+};
+}
+
 struct trexhip_ctx {
     trexhip_params p;
     trexhip::SegCfg cfg;
@@ -92,6 +114,7 @@ struct trexhip_ctx {
     uint8_t* h_color = nullptr;
 
     void* net = nullptr;                // trexhip::Net (cnn.hip)
+    trexhip::Pass2 pass2;
 
     bool profiling = false;
     // tuning knobs (env TREXHIP_ROWS_ORDER / TREXHIP_ROWS_BLOCKS override the defaults)
@@ -105,4 +128,5 @@ int launch_segment(trexhip_ctx* ctx, const uint8_t* d_frames, int n);
 void stage_begin(trexhip_ctx* ctx, int stage);
 void stage_end(trexhip_ctx* ctx, int stage);
 void net_free(trexhip_ctx* ctx);
+int launch_rethreshold(trexhip_ctx* ctx, int thr, int method, const double* ranges, int n_ranges);
 }

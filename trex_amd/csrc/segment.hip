@@ -361,7 +361,8 @@ __global__ __launch_bounds__(256) void k_blobs(const SegCfg c, const trexhip_run
                                                uint32_t* __restrict__ pix_begin, int32_t* __restrict__ blob_map, uint32_t* __restrict__ totals,
                                                trexhip_frame_info* __restrict__ info,
                                                trexhip_blob* __restrict__ blobs, uint32_t* __restrict__ blob_frame,
-                                               trexhip_run* __restrict__ out_runs) {
+                                               trexhip_run* __restrict__ out_runs, const int classify,
+                                               const uint32_t* __restrict__ run_parent) {
     __shared__ uint32_t lds[8];
     __shared__ uint32_t s_alloc[4];
     __shared__ uint32_t s_cursor[CURSOR_LDS];
@@ -413,7 +414,7 @@ __global__ __launch_bounds__(256) void k_blobs(const SegCfg c, const trexhip_run
         uint32_t nr = 0, np = 0, keep = 0;
         if (o < nraw) {
             nr = ld_relaxed(cr + o); np = ld_relaxed(cp + o);
-            keep = (size_ok(np, c) && nr < 65535u) ? 1u : 0u;
+            keep = ((classify || size_ok(np, c)) && nr < 65535u) ? 1u : 0u;
         }
         uint32_t t0, t1, t2;
         const uint32_t e0 = block_excl_scan(keep, lds, t0);
@@ -452,9 +453,24 @@ __global__ __launch_bounds__(256) void k_blobs(const SegCfg c, const trexhip_run
         B.run_begin = cur[o];
         B.n_runs = ld_relaxed(cr + o);
         B.pix_begin = pbg[o];
+        B.parent = 0xffffffffu;
+        if (classify) {   // Tracker.cpp:864-912: in range -> commit, below the smallest range -> filtered out, else big blob
+            const uint32_t np = ld_relaxed(cp + o);
+            uint32_t cat = 0;
+            if (!size_ok(np, c)) {
+                double mn = c.ranges[0];
+                for (int i = 1; i < c.n_ranges; ++i) mn = c.ranges[2 * i] < mn ? c.ranges[2 * i] : mn;
+                cat = ((double)((float)np * c.sqcm) < mn) ? TREXHIP_BLOB_BELOW_RANGE : TREXHIP_BLOB_BIG;
+            }
+            B.flags = cat;
+        }
         blobs[bb + k] = B;
         blob_frame[bb + k] = (uint32_t)f;
     }
+    __syncthreads();
+    if (run_parent)                      // re-threshold pass: a sub-blob inherits the detect blob of its root run
+        for (uint32_t r = tid; r < n; r += 256)
+            if (lab[r] == r) { const int32_t k = bmap[ord[r]]; if (k >= 0) blobs[bb + k].parent = run_parent[fo + r]; }
     const bool lds_cursor = kept <= (uint32_t)CURSOR_LDS;
     if (lds_cursor)
         for (uint32_t o = tid; o < nraw; o += 256) {
@@ -641,7 +657,7 @@ int launch_segment(trexhip_ctx* ctx, const uint8_t* d_frames, int n) {
     uint32_t* totals = ctx->d_ctr + (size_t)ctx->p.max_batch * CTR_STRIDE;
     hipLaunchKernelGGL(k_blobs, dim3(n), dim3(256), 0, s, c, ctx->d_raster, ctx->d_parent, ctx->d_root_ord,
                        ctx->d_cnt_runs, ctx->d_cnt_px, ctx->d_cur_run, ctx->d_pix_begin, ctx->d_blob_map, totals, ctx->d_info,
-                       ctx->d_blobs, ctx->d_blob_frame, ctx->d_runs);
+                       ctx->d_blobs, ctx->d_blob_frame, ctx->d_runs, 0, (const uint32_t*)nullptr);
     hipLaunchKernelGGL(k_gather, dim3(1024), dim3(256), 0, s, c, d_frames, totals, ctx->d_info, ctx->d_blob_frame,
                        ctx->d_blobs, ctx->d_runs, ctx->d_pixels);
     stage_end(ctx, TREXHIP_STAGE_SEGMENT_ALL);
@@ -649,6 +665,156 @@ int launch_segment(trexhip_ctx* ctx, const uint8_t* d_frames, int n) {
     ctx->d_frames = d_frames;
     ctx->last_n = n;
     ctx->fetched = false;
+    ctx->pass2.valid_n = 0;
+    return TREXHIP_OK;
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// track-stage re-threshold (Tracker::prefilter -> pv::Blob::recount + pixel::threshold_blob,
+// tracking/Tracker.cpp:765-849; semantics pinned by Application/Tests/test_pixels.cpp: keep a pixel iff
+// diff(bg, p) >= threshold, runs split where pixels fail, survivors re-labelled).
+// Works on the detect pass's raster-ordered runs: count sub-runs per run -> scan -> write sub-runs
+// (raster order is preserved, so the second CCL pass needs no sort) -> k_link2 -> k_flatten -> k_blobs
+// (classify instead of drop) -> k_gather.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ bool track_pass(int p, int b, int method, int thr) {
+    const int d = method == 0 ? abs(b - p) : (method == 1 ? max(b - p, 0) : p);
+    return d >= thr;
+}
+
+// thread per image row: for every run of a KEPT detect blob count (write=0) or emit (write=1) its sub-runs
+template <int WRITE>
+__global__ __launch_bounds__(256) void k_sub(const SegCfg c, const uint8_t* __restrict__ frames, const uint8_t* __restrict__ bg,
+                                             const uint32_t* __restrict__ row_base, const trexhip_run* __restrict__ raster,
+                                             const uint32_t* __restrict__ label, const uint32_t* __restrict__ root_ord,
+                                             const int32_t* __restrict__ blob_map, const trexhip_frame_info* __restrict__ info,
+                                             const int method, const int thr, uint32_t* __restrict__ sub_cnt,
+                                             const uint32_t* __restrict__ sub_base, trexhip_run* __restrict__ raster2,
+                                             uint32_t* __restrict__ run_parent2) {
+    const int gid = blockIdx.x * 256 + threadIdx.x;
+    if (gid >= c.B * c.H) return;
+    const int f = gid / c.H, y = gid - f * c.H;
+    const trexhip_frame_info fi = info[f];
+    if (fi.flags) return;
+    const uint32_t* rb = row_base + (size_t)f * (c.H + 1);
+    const size_t fo = (size_t)f * c.R;
+    const uint8_t* img = frames + ((size_t)f * c.H + y) * c.W;
+    const uint8_t* bgr = bg + (size_t)y * c.W;
+    for (uint32_t r = rb[y]; r < rb[y + 1]; ++r) {
+        const int32_t k = blob_map[fo + root_ord[fo + label[fo + r]]];
+        uint32_t n = 0;
+        if (k >= 0) {
+            const trexhip_run q = raster[fo + r];
+            uint32_t out = WRITE ? sub_base[fo + r] : 0;
+            int open = -1;
+            for (int x = q.x0; x <= q.x1; ++x) {
+                int p = img[x];
+                if (c.invert) p = 255 - p;
+                const bool ok = track_pass(p, bgr[x], method, thr);
+                if (ok && open < 0) open = x;
+                if (!ok && open >= 0) {
+                    if (WRITE) { trexhip_run s; s.x0 = (uint16_t)open; s.x1 = (uint16_t)(x - 1); s.y = (uint16_t)y; s.pad = 0;
+                                 raster2[fo + out] = s; run_parent2[fo + out] = fi.blob_begin + (uint32_t)k; ++out; }
+                    ++n; open = -1;
+                }
+            }
+            if (open >= 0) {
+                if (WRITE) { trexhip_run s; s.x0 = (uint16_t)open; s.x1 = q.x1; s.y = (uint16_t)y; s.pad = 0;
+                             raster2[fo + out] = s; run_parent2[fo + out] = fi.blob_begin + (uint32_t)k; }
+                ++n;
+            }
+        }
+        if (!WRITE) sub_cnt[fo + r] = n;
+    }
+}
+
+// block per frame: exclusive scan of sub-run counts in raster order -> sub_base, second-pass row tables, parent init
+__global__ __launch_bounds__(256) void k_sub_scan(const SegCfg c, const trexhip_frame_info* __restrict__ info1,
+                                                  const uint32_t* __restrict__ row_base1, const uint32_t* __restrict__ sub_cnt,
+                                                  uint32_t* __restrict__ sub_base, uint32_t* __restrict__ row_base2,
+                                                  uint32_t* __restrict__ row_cnt2, uint32_t* __restrict__ parent2,
+                                                  trexhip_frame_info* __restrict__ info2) {
+    __shared__ uint32_t lds[8];
+    const int f = blockIdx.x;
+    const trexhip_frame_info fi = info1[f];
+    trexhip_frame_info out = {};
+    if (fi.flags) { if (threadIdx.x == 0) { out.flags = fi.flags; info2[f] = out; } return; }
+    const size_t fo = (size_t)f * c.R;
+    const uint32_t n = fi.n_raw_runs;
+    uint32_t running = 0;
+    for (uint32_t b0 = 0; b0 < n; b0 += 256) {
+        const uint32_t r = b0 + threadIdx.x;
+        const uint32_t v = r < n ? sub_cnt[fo + r] : 0;
+        uint32_t total;
+        const uint32_t ex = block_excl_scan(v, lds, total);
+        if (r < n) sub_base[fo + r] = running + ex;
+        running += total;
+    }
+    const uint32_t n2 = running;
+    __threadfence_block();
+    __syncthreads();
+    const uint32_t* rb1 = row_base1 + (size_t)f * (c.H + 1);
+    uint32_t* rb2 = row_base2 + (size_t)f * (c.H + 1);
+    for (int y = threadIdx.x; y <= c.H; y += 256) {
+        const uint32_t r = rb1[y];
+        rb2[y] = r < n ? sub_base[fo + r] : n2;
+    }
+    __threadfence_block();
+    __syncthreads();
+    for (int y = threadIdx.x; y < c.H; y += 256) row_cnt2[(size_t)f * c.H + y] = rb2[y + 1] - rb2[y];
+    const bool overflow = n2 > (uint32_t)c.R;
+    if (threadIdx.x == 0) { out.n_raw_runs = n2; out.flags = overflow ? TREXHIP_FRAME_OVERFLOW_RUNS : 0u; info2[f] = out; }
+    if (!overflow) for (uint32_t r = threadIdx.x; r < n2; r += 256) parent2[fo + r] = r;
+}
+
+// thread per row: union the sub-runs of row y with the touching sub-runs of row y-1 (both already in raster order)
+__global__ __launch_bounds__(256) void k_link2(const SegCfg c, const uint32_t* __restrict__ row_base,
+                                               const trexhip_run* __restrict__ raster, uint32_t* __restrict__ parent,
+                                               const trexhip_frame_info* __restrict__ info) {
+    const int gid = blockIdx.x * 256 + threadIdx.x;
+    if (gid >= c.B * c.H) return;
+    const int f = gid / c.H, y = gid - f * c.H;
+    if (y == 0 || info[f].flags) return;
+    const uint32_t* rb = row_base + (size_t)f * (c.H + 1);
+    uint32_t j = rb[y - 1], i = rb[y];
+    const uint32_t je = rb[y], ie = rb[y + 1];
+    if (i >= ie || j >= je) return;
+    const trexhip_run* rr = raster + (size_t)f * c.R;
+    uint32_t* par = parent + (size_t)f * c.R;
+    trexhip_run cur = rr[i], prv = rr[j];
+    const int slack = c.slack;
+    for (;;) {
+        if ((int)prv.x1 + slack >= (int)cur.x0 && (int)cur.x1 + slack >= (int)prv.x0) uf_union(par, j, i);
+        if (prv.x1 < cur.x1) { if (++j >= je) break; prv = rr[j]; }
+        else                 { if (++i >= ie) break; cur = rr[i]; }
+    }
+}
+
+int launch_rethreshold(trexhip_ctx* ctx, int thr, int method, const double* ranges, int n_ranges) {
+    Pass2& q = ctx->pass2;
+    SegCfg c = ctx->cfg;
+    const int n = ctx->last_n;
+    c.B = n;
+    c.n_ranges = n_ranges;
+    for (int i = 0; i < 2 * n_ranges; ++i) c.ranges[i] = ranges[i];
+    hipStream_t s = ctx->stream;
+    const dim3 grid_r((unsigned)((n * c.H + 255) / 256));
+    TH_CHECK_HIP(hipMemsetAsync(q.d_totals, 0, sizeof(uint32_t) * 4, s));
+    hipLaunchKernelGGL((k_sub<0>), grid_r, dim3(256), 0, s, c, ctx->d_frames, ctx->d_bg, ctx->d_row_base, ctx->d_raster, ctx->d_parent,
+                       ctx->d_root_ord, ctx->d_blob_map, ctx->d_info, method, thr, q.d_sub_cnt, q.d_sub_base, q.d_raster, q.d_run_parent);
+    hipLaunchKernelGGL(k_sub_scan, dim3(n), dim3(256), 0, s, c, ctx->d_info, ctx->d_row_base, q.d_sub_cnt, q.d_sub_base, q.d_row_base,
+                       q.d_row_cnt, q.d_parent, q.d_info);
+    hipLaunchKernelGGL((k_sub<1>), grid_r, dim3(256), 0, s, c, ctx->d_frames, ctx->d_bg, ctx->d_row_base, ctx->d_raster, ctx->d_parent,
+                       ctx->d_root_ord, ctx->d_blob_map, ctx->d_info, method, thr, q.d_sub_cnt, q.d_sub_base, q.d_raster, q.d_run_parent);
+    hipLaunchKernelGGL(k_link2, grid_r, dim3(256), 0, s, c, q.d_row_base, q.d_raster, q.d_parent, q.d_info);
+    hipLaunchKernelGGL(k_flatten, grid_r, dim3(256), 0, s, c, q.d_row_cnt, q.d_row_base, q.d_parent, q.d_info);
+    hipLaunchKernelGGL(k_blobs, dim3(n), dim3(256), 0, s, c, q.d_raster, q.d_parent, q.d_root_ord, q.d_cnt_runs, q.d_cnt_px, q.d_cur_run,
+                       q.d_pix_begin, q.d_blob_map, q.d_totals, q.d_info, q.d_blobs, q.d_blob_frame, q.d_runs, 1, q.d_run_parent);
+    hipLaunchKernelGGL(k_gather, dim3(1024), dim3(256), 0, s, c, ctx->d_frames, q.d_totals, q.d_info, q.d_blob_frame, q.d_blobs,
+                       q.d_runs, q.d_pixels);
+    TH_CHECK_HIP(hipGetLastError());
+    q.valid_n = n;
     return TREXHIP_OK;
 }
 
