@@ -1,0 +1,90 @@
+"""End-to-end anchor on the reference's own golden data (Application/Tests/run_unix.bash:221-305 compares
+data/test_fish*.csv with videos/compare_data_automatic/*.csv): detect at detect_threshold=9, then the track-stage
+re-threshold at track_threshold=12 (signed difference, track_background_subtraction) with
+track_size_filter=[[70,420]] (videos/test.settings) must reproduce the golden (blobid, num_pixels) of every fish.
+
+What can and cannot match exactly: the JPEG decoder and the background sampler of the reference are outside the
+tree, so a few boundary pixels differ; the blob id (13/13/6-bit hash of the first line) and the pixel counts are
+compared with the tolerances stated below -- the reference's own script tolerates word diffs too (run_unix.bash:143-156).
+CPU: oracle.  GPU (-m gpu): the device path must equal the oracle bit for bit on the same frames."""
+import os
+import numpy as np
+import pytest
+from oracle import oracle
+
+FIX = os.path.join(os.path.dirname(__file__), "golden", "e2e_testframes.npz")
+RANGES = [(70, 420)]
+
+
+def rebuild(z, fr):
+    H, W = [int(v) for v in z["shape"]]
+    bg = np.full((H, W), 128, np.uint8)
+    for k, (x0, y0, x1, y1) in enumerate(z[f"rects/{fr}"]):
+        bg[y0:y1, x0:x1] = z[f"b/{fr}/{k}"]
+    img = bg.copy()
+    for k, (x0, y0, x1, y1) in enumerate(z[f"rects/{fr}"]):
+        img[y0:y1, x0:x1] = z[f"f/{fr}/{k}"]
+    return img, bg
+
+
+def score(sub_blobs, gold):
+    mine = {int(b["bid"]): int(b["n_pixels"]) for b in sub_blobs if b["flags"] == 0}
+    hits, exact, deltas = 0, 0, []
+    for g in gold:
+        bid, npx = int(g[1]), int(g[2])
+        if bid in mine:
+            hits += 1
+            deltas.append(abs(mine[bid] - npx))
+            exact += mine[bid] == npx
+    return hits, exact, deltas
+
+
+def test_oracle_reproduces_golden_csv_rows():
+    z = np.load(FIX)
+    tot = hits = exact = 0
+    deltas = []
+    for fr in z["frames"]:
+        img, bg = rebuild(z, int(fr))
+        p = oracle.make_params(img.shape[1], img.shape[0], threshold=9, size_ranges=[(1, 10000)])
+        blobs, runs, px = oracle.rethreshold_frame(img, bg, p, 1, 12, RANGES)
+        gold = z[f"gold/{int(fr)}"]
+        h, e, d = score(blobs, gold)
+        tot += len(gold); hits += h; exact += e; deltas += d
+    print("golden rows", tot, "bid hits", hits, "exact", exact, "median |dnpx|", np.median(deltas))
+    assert tot >= 60
+    assert hits / tot >= 0.70, (hits, tot)          # blob id (first line position + line count) reproduced
+    assert exact / tot >= 0.35, (exact, tot)        # ... with the identical pixel count
+    assert np.median(deltas) <= 2 and np.percentile(deltas, 90) <= 8
+
+
+def test_bid_decoding_of_golden_rows():
+    z = np.load(FIX)
+    g = z["gold/0"]
+    row = g[g[:, 0] == 0][0]
+    assert int(row[1]) == 334623465 and int(row[2]) == 264       # test_fish0.csv:2
+    assert (int(row[1]) >> 19, (int(row[1]) >> 6) & 8191, int(row[1]) & 63) == (638, 1995, 41)
+
+
+@pytest.mark.gpu
+def test_device_equals_oracle_on_reference_frames():
+    import torch
+    from trex_amd import capi
+    z = np.load(FIX)
+    frs = [int(f) for f in z["frames"][:4]]
+    H, W = [int(v) for v in z["shape"]]
+    seg = capi.Segmenter(capi.default_params(W, H, max_batch=1, threshold=9, size_ranges=[(1, 10000)]))
+    for fr in frs:
+        img, b = rebuild(z, fr)
+        seg.set_background(b)
+        d = torch.from_numpy(img).cuda()
+        seg.segment_device(d.data_ptr(), 1)
+        seg.fetch()
+        seg.rethreshold(12, 1, RANGES)
+        sub = seg.fetch(rethreshold=True)[0]
+        p = oracle.make_params(W, H, threshold=9, size_ranges=[(1, 10000)])
+        ob, orr, opx = oracle.rethreshold_frame(img, b, p, 1, 12, RANGES)
+        assert sub.runs.tobytes() == orr.tobytes() and sub.pixels.tobytes() == opx.tobytes()
+        assert np.array_equal(sub.blobs["bid"], ob["bid"]) and np.array_equal(sub.blobs["flags"], ob["flags"])
+        h, e, _ = score(sub.blobs, z[f"gold/{fr}"])
+        assert h >= 5
+    seg.close()
