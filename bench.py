@@ -135,6 +135,20 @@ def main():
             ("ROWS", "SEGMENT_ALL", "CONV2", "CONV3", "CNN_ALL", "CROPS")}
     seg.profile_enable(False)
 
+    def pmc_traffic(kernel_prefix):
+        """HBM bytes per launch from the committed PMC pass of this same command (profiles/r01_pmc_summary.json);
+        only valid for the default C4 / 64-frame workload it was collected on, else null."""
+        try:
+            if args.config != "C4" or B != 64:
+                return None
+            j = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_summary.json")))
+            for k, v in j["kernels"].items():
+                if k.startswith(kernel_prefix):
+                    return v["hbm_bytes"]
+        except Exception:
+            pass
+        return None
+
     def avg_s(name):
         ms, n = prof[name]
         return (ms / n) * 1e-3 if n else 0.0
@@ -155,7 +169,8 @@ def main():
                    "frames_per_step_per_gpu": B, "blobs_per_step_rank0": n_blobs, "parallelism": f"frame-sharded x{world}"},
     }
     seg_roof = {"kernel": "k_rows", "bound": "hbm", "achieved": seg_bytes / rows_s / 1e9 if rows_s else 0.0, "peak": 8000.0,
-                "unit": "GB/s", "frac": seg_bytes / rows_s / 8e12 if rows_s else 0.0, "traffic": None,
+                "unit": "GB/s", "frac": seg_bytes / rows_s / 8e12 if rows_s else 0.0, "traffic": pmc_traffic("trexhip::k_rows"),
+                "traffic_note": "bytes/launch, FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE, separate --pmc passes, profiles/r01_pmc_summary.json",
                 "avg_launch_us": rows_s * 1e6, "launches": prof["ROWS"][1], "algorithmic_bytes_per_launch": seg_bytes,
                 "whole_detect_pass_us": segall_s * 1e6,
                 "whole_detect_pass_frac": seg_bytes / segall_s / 8e12 if segall_s else None}
@@ -163,7 +178,9 @@ def main():
         c3_s = avg_s("CONV3")
         fl = FLOP_PER_CROP_CONV3 * n_blobs
         out["roofline"] = {"kernel": "k_conv5<64,128,20,20,32> (conv3)", "bound": "mfma", "achieved": fl / c3_s / 1e12 if c3_s else 0.0,
-                           "peak": 157.3, "unit": "TFLOP/s", "frac": fl / c3_s / 157.3e12 if c3_s else 0.0, "traffic": None,
+                           "peak": 157.3, "unit": "TFLOP/s", "frac": fl / c3_s / 157.3e12 if c3_s else 0.0,
+                           "traffic": pmc_traffic("trexhip::k_conv5<64, 128"),
+                           "traffic_note": "HBM bytes/launch from profiles/r01_pmc_summary.json (FETCH_SIZE x2 + WRITE_SIZE); algorithmic bytes = 0.98 GB (activations in+out)",
                            "avg_launch_us": c3_s * 1e6, "launches": prof["CONV3"][1], "algorithmic_flop_per_launch": fl,
                            "peak_note": "dense fp32-input MFMA peak (MI355X_MICROARCH.md); the path computes in exact fp32"}
         cnn_s = avg_s("CNN_ALL")
