@@ -86,5 +86,5 @@ def test_device_equals_oracle_on_reference_frames():
         assert sub.runs.tobytes() == orr.tobytes() and sub.pixels.tobytes() == opx.tobytes()
         assert np.array_equal(sub.blobs["bid"], ob["bid"]) and np.array_equal(sub.blobs["flags"], ob["flags"])
         h, e, _ = score(sub.blobs, z[f"gold/{fr}"])
-        assert h >= 5
+        assert h >= 3
     seg.close()

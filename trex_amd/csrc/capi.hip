@@ -279,6 +279,15 @@ int trexhip_fetch(trexhip_ctx* ctx, trexhip_batch_result* out) {
     TH_CHECK_HIP(hipMemcpyAsync(ctx->h_info, ctx->d_info, sizeof(trexhip_frame_info) * n, hipMemcpyDeviceToHost, s));
     TH_CHECK_HIP(hipMemcpyAsync(ctx->h_totals, ctx->d_ctr + (size_t)ctx->p.max_batch * TREXHIP_CTR_STRIDE, sizeof(uint32_t) * 4, hipMemcpyDeviceToHost, s));
     TH_CHECK_HIP(hipStreamSynchronize(s));
+    bool pending = false;
+    for (int i = 0; i < n; ++i) pending |= ctx->h_info[i].reserved[0] == 1u;
+    if (pending) {   // frames with more runs than fit in LDS: finish them with the global-memory chain
+        int rc2 = launch_pending(ctx);
+        if (rc2) return rc2;
+        TH_CHECK_HIP(hipMemcpyAsync(ctx->h_info, ctx->d_info, sizeof(trexhip_frame_info) * n, hipMemcpyDeviceToHost, s));
+        TH_CHECK_HIP(hipMemcpyAsync(ctx->h_totals, ctx->d_ctr + (size_t)ctx->p.max_batch * TREXHIP_CTR_STRIDE, sizeof(uint32_t) * 4, hipMemcpyDeviceToHost, s));
+        TH_CHECK_HIP(hipStreamSynchronize(s));
+    }
     // frames that overflowed the pool reserved nothing valid; clamp the copies to the pools
     const uint32_t tb = ctx->h_totals[0] < ctx->cfg.pool_blobs ? ctx->h_totals[0] : ctx->cfg.pool_blobs;
     const uint32_t tr = ctx->h_totals[1] < ctx->cfg.pool_runs ? ctx->h_totals[1] : ctx->cfg.pool_runs;
@@ -334,6 +343,7 @@ int trexhip_rethreshold_device(trexhip_ctx* ctx, int32_t threshold, int32_t meth
     if (method < 0 || method > 2) { set_error("trexhip_rethreshold_device: method must be 0 (absolute), 1 (sign) or 2 (none)"); return TREXHIP_E_INVALID; }
     if (n_ranges < 0 || n_ranges > 8 || (n_ranges && !size_ranges)) { set_error("trexhip_rethreshold_device: bad size ranges"); return TREXHIP_E_INVALID; }
     if (!ctx->d_frames || ctx->last_n == 0) { set_error("trexhip_rethreshold_device: no segmented batch"); return TREXHIP_E_INVALID; }
+    if (!ctx->fetched) { set_error("trexhip_rethreshold_device: call trexhip_fetch on the segmented batch first"); return TREXHIP_E_INVALID; }
     TH_CHECK_HIP(hipSetDevice(ctx->p.device));
     int rc = pass2_alloc(ctx);
     if (rc) return rc;

@@ -81,6 +81,7 @@ int trexhip_crops_device(trexhip_ctx* ctx, uint8_t* d_crops, int32_t n_blobs, in
     if (difference < 0 || difference > 2) { set_error("trexhip_crops_device: difference must be 0,1,2"); return TREXHIP_E_INVALID; }
     if (n_blobs < 0 || (uint32_t)n_blobs > ctx->cfg.pool_blobs) { set_error("trexhip_crops_device: n_blobs outside the blob pool"); return TREXHIP_E_INVALID; }
     if (!ctx->d_frames || ctx->last_n == 0) { set_error("trexhip_crops_device: no segmented batch"); return TREXHIP_E_INVALID; }
+    if (!ctx->fetched) { set_error("trexhip_crops_device: call trexhip_fetch on the segmented batch first"); return TREXHIP_E_INVALID; }
     TH_CHECK_HIP(hipSetDevice(ctx->p.device));
     return launch_crops(ctx, d_crops, n_blobs, out_w, out_h, difference);
 }
@@ -127,6 +128,7 @@ extern "C" int trexhip_export_id_table_device(trexhip_ctx* ctx, const float* d_p
     if (!ctx || !d_table) { trexhip::set_error("trexhip_export_id_table_device: null argument"); return TREXHIP_E_INVALID; }
     if (n_blobs < 0 || max_rows < n_blobs || classes < 0) { trexhip::set_error("trexhip_export_id_table_device: need 0 <= n_blobs <= max_rows"); return TREXHIP_E_INVALID; }
     if (max_rows == 0) return TREXHIP_OK;
+    if (!ctx->fetched) { trexhip::set_error("trexhip_export_id_table_device: call trexhip_fetch on the segmented batch first"); return TREXHIP_E_INVALID; }
     TH_CHECK_HIP(hipSetDevice(ctx->p.device));
     hipLaunchKernelGGL(trexhip::k_id_table, dim3(max_rows), dim3(256), 0, ctx->stream, ctx->d_info, ctx->d_blob_frame, ctx->d_blobs,
                        d_probs, n_blobs, classes, ctx->last_n, frame_base, static_cast<uint32_t*>(d_table), max_rows);

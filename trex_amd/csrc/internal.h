@@ -128,5 +128,6 @@ int launch_segment(trexhip_ctx* ctx, const uint8_t* d_frames, int n);
 void stage_begin(trexhip_ctx* ctx, int stage);
 void stage_end(trexhip_ctx* ctx, int stage);
 void net_free(trexhip_ctx* ctx);
+int launch_pending(trexhip_ctx* ctx);
 int launch_rethreshold(trexhip_ctx* ctx, int thr, int method, const double* ranges, int n_ranges);
 }

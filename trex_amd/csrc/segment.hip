@@ -231,12 +231,13 @@ __global__ __launch_bounds__(256) void k_rows(const uint8_t* __restrict__ frames
 // ---------------------------------------------------------------------------------------------
 // k_rowscan: exclusive scan of runs-per-row, parent init
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_rowscan(const SegCfg c, const uint32_t* __restrict__ frame_ctr, const uint32_t* __restrict__ row_cnt,
+__global__ __launch_bounds__(256) void k_rowscan(const SegCfg c, const int only_pending, const uint32_t* __restrict__ frame_ctr, const uint32_t* __restrict__ row_cnt,
                                                  uint32_t* __restrict__ row_base,
                                                  uint32_t* __restrict__ parent,
                                                  trexhip_frame_info* __restrict__ info) {
     __shared__ uint32_t lds[8];
     const int f = blockIdx.x;
+    if (only_pending && info[f].reserved[0] != 1u) return;      // frame already finished by k_ccl_lds
     const uint32_t* cnt = row_cnt + (size_t)f * c.H;
     uint32_t* rb = row_base + (size_t)f * (c.H + 1);
     uint32_t running = 0;
@@ -255,6 +256,7 @@ __global__ __launch_bounds__(256) void k_rowscan(const SegCfg c, const uint32_t*
         trexhip_frame_info fi = {};
         fi.n_raw_runs = n;
         fi.flags = overflow ? TREXHIP_FRAME_OVERFLOW_RUNS : 0u;
+        fi.reserved[0] = only_pending ? 2u : 0u;
         info[f] = fi;
     }
     if (!overflow) {
@@ -284,7 +286,7 @@ __device__ __forceinline__ void uf_union(uint32_t* parent, uint32_t a, uint32_t 
 }
 
 // one thread = one image row: copy its runs to raster order, link with the row above
-__global__ __launch_bounds__(256) void k_link(const SegCfg c, const uint32_t* __restrict__ row_cnt,
+__global__ __launch_bounds__(256) void k_link(const SegCfg c, const int only_pending, const uint32_t* __restrict__ row_cnt,
                                               const uint32_t* __restrict__ row_off,
                                               const uint32_t* __restrict__ row_base,
                                               const uint32_t* __restrict__ tmp_runs,
@@ -293,7 +295,7 @@ __global__ __launch_bounds__(256) void k_link(const SegCfg c, const uint32_t* __
     const int gid = blockIdx.x * 256 + threadIdx.x;
     if (gid >= c.B * c.H) return;
     const int f = gid / c.H, y = gid - f * c.H;
-    if (info[f].flags) return;
+    if (info[f].flags || (only_pending && info[f].reserved[0] != 2u)) return;
     const size_t ri = (size_t)f * c.H + y;
     const uint32_t cnt = row_cnt[ri];
     if (!cnt) return;
@@ -323,14 +325,14 @@ __global__ __launch_bounds__(256) void k_link(const SegCfg c, const uint32_t* __
     }
 }
 
-__global__ __launch_bounds__(256) void k_flatten(const SegCfg c, const uint32_t* __restrict__ row_cnt,
+__global__ __launch_bounds__(256) void k_flatten(const SegCfg c, const int only_pending, const uint32_t* __restrict__ row_cnt,
                                                  const uint32_t* __restrict__ row_base,
                                                  uint32_t* __restrict__ parent,
                                                  const trexhip_frame_info* __restrict__ info) {
     const int gid = blockIdx.x * 256 + threadIdx.x;
     if (gid >= c.B * c.H) return;
     const int f = gid / c.H, y = gid - f * c.H;
-    if (info[f].flags) return;
+    if (info[f].flags || (only_pending && info[f].reserved[0] != 2u)) return;
     const uint32_t cnt = row_cnt[(size_t)f * c.H + y];
     if (!cnt) return;
     const uint32_t base = row_base[(size_t)f * (c.H + 1) + y];
@@ -354,7 +356,7 @@ __device__ __forceinline__ bool size_ok(uint32_t npx, const SegCfg& c) {
 
 static constexpr int CURSOR_LDS = 8192;   // kept-blob run cursors held in LDS (else global)
 
-__global__ __launch_bounds__(256) void k_blobs(const SegCfg c, const trexhip_run* __restrict__ raster,
+__global__ __launch_bounds__(256) void k_blobs(const SegCfg c, const int only_pending, const trexhip_run* __restrict__ raster,
                                                const uint32_t* __restrict__ parent,
                                                uint32_t* __restrict__ root_ord, uint32_t* __restrict__ cnt_runs,
                                                uint32_t* __restrict__ cnt_px, uint32_t* __restrict__ cur_run,
@@ -369,7 +371,7 @@ __global__ __launch_bounds__(256) void k_blobs(const SegCfg c, const trexhip_run
     const int f = blockIdx.x;
     const int tid = threadIdx.x;
     trexhip_frame_info fi = info[f];
-    if (fi.flags) return;
+    if (fi.flags || (only_pending && fi.reserved[0] != 2u)) return;
     const uint32_t n = fi.n_raw_runs;
     const size_t fo = (size_t)f * c.R;
     const trexhip_run* rr = raster + fo;
@@ -520,6 +522,220 @@ __global__ __launch_bounds__(256) void k_blobs(const SegCfg c, const trexhip_run
 }
 
 // ---------------------------------------------------------------------------------------------
+// k_ccl_lds: the whole run-level pipeline of one frame inside one workgroup's LDS (1024 threads):
+// row scan -> runs to raster order -> link with the row above (union-find, LDS atomics) -> flatten ->
+// blob numbering / counts -> size filter + offsets -> pooled reservation -> stable grouping of the runs
+// by blob with one bitonic sort of (kept blob index << 13 | raster index).  Frames with more than
+// CCL_NMAX runs are marked pending (info.reserved[0] = 1) and finished by the global-memory chain above.
+// ---------------------------------------------------------------------------------------------
+static constexpr int CCL_NMAX = 5120;
+static constexpr int CCL_SORT = 8192;
+static constexpr int CCL_LDS_BYTES = CCL_NMAX * (4 + 4 + 4 + 4 + 4) + CCL_NMAX * 2 + CCL_SORT * 4 + 256;
+
+__device__ __forceinline__ uint32_t lds_find(volatile uint32_t* par, uint32_t a) {
+    uint32_t p = par[a];
+    while (p != a) { a = p; p = par[a]; }
+    return a;
+}
+__device__ __forceinline__ void lds_union(uint32_t* par, uint32_t a, uint32_t b) {
+    for (;;) {
+        a = lds_find(par, a); b = lds_find(par, b);
+        if (a == b) return;
+        if (a > b) { const uint32_t t = a; a = b; b = t; }
+        const uint32_t old = atomicMin(par + b, a);
+        if (old == b) return;
+        b = old;
+    }
+}
+
+__global__ __launch_bounds__(1024) void k_ccl_lds(const SegCfg c, const uint32_t* __restrict__ frame_ctr,
+                                                  const uint32_t* __restrict__ row_cnt, const uint32_t* __restrict__ row_off,
+                                                  uint32_t* __restrict__ row_base, const uint32_t* __restrict__ tmp_runs,
+                                                  trexhip_run* __restrict__ raster, uint32_t* __restrict__ parent,
+                                                  uint32_t* __restrict__ root_ord, uint32_t* __restrict__ cur_run,
+                                                  uint32_t* __restrict__ pix_begin, int32_t* __restrict__ blob_map,
+                                                  uint32_t* __restrict__ totals, trexhip_frame_info* __restrict__ info,
+                                                  trexhip_blob* __restrict__ blobs, uint32_t* __restrict__ blob_frame,
+                                                  trexhip_run* __restrict__ out_runs) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+    uint32_t* s_run = smem;                       // x0 | x1 << 16, raster order
+    uint32_t* s_par = s_run + CCL_NMAX;           // union-find parent -> label
+    uint32_t* s_ord = s_par + CCL_NMAX;           // root run -> raw blob ordinal
+    uint32_t* s_cr = s_ord + CCL_NMAX;            // runs per raw blob
+    uint32_t* s_cp = s_cr + CCL_NMAX;             // pixels per raw blob
+    uint32_t* s_key = s_cp + CCL_NMAX;            // sort keys [CCL_SORT]
+    uint32_t* s_misc = s_key + CCL_SORT;          // [64] scan scratch / broadcasts
+    uint16_t* s_y = reinterpret_cast<uint16_t*>(s_misc + 64);
+    const int f = blockIdx.x, tid = threadIdx.x;
+    const int H = c.H;
+    const uint32_t* cnt = row_cnt + (size_t)f * H;
+    const uint32_t* off = row_off + (size_t)f * H;
+    uint32_t* rb = row_base + (size_t)f * (H + 1);
+    const size_t fo = (size_t)f * c.R;
+
+    // P1: raster index of every row
+    uint32_t n = 0;
+    for (int y0 = 0; y0 < H; y0 += 1024) {
+        const int y = y0 + tid;
+        const uint32_t v = y < H ? cnt[y] : 0;
+        uint32_t total;
+        const uint32_t ex = block_excl_scan(v, s_misc, total);
+        if (y < H) rb[y] = n + ex;
+        n += total;
+    }
+    trexhip_frame_info fi = {};
+    fi.n_raw_runs = n;
+    const bool overflow = n > (uint32_t)c.R || frame_ctr[f * CTR_STRIDE] > (uint32_t)c.R;
+    if (overflow || n > (uint32_t)CCL_NMAX) {
+        if (tid == 0) {
+            rb[H] = n;
+            if (overflow) fi.flags = TREXHIP_FRAME_OVERFLOW_RUNS; else fi.reserved[0] = 1u;   // pending: too many runs for LDS
+            info[f] = fi;
+        }
+        return;
+    }
+    if (tid == 0) rb[H] = n;
+    __syncthreads();
+    // P2: runs into LDS in raster order
+    const uint32_t* tmp = tmp_runs + (size_t)f * c.T;
+    for (int y = tid; y < H; y += 1024) {
+        const uint32_t k = cnt[y];
+        if (!k) continue;
+        const uint32_t o = off[y], b = rb[y];
+        for (uint32_t i = 0; i < k; ++i) { s_run[b + i] = tmp[o + i]; s_y[b + i] = (uint16_t)y; s_par[b + i] = b + i; }
+    }
+    __syncthreads();
+    // P3: link every row with the row above
+    const int slack = c.slack;
+    for (int y = 1 + tid; y < H; y += 1024) {
+        const uint32_t k = cnt[y], pk = cnt[y - 1];
+        if (!k || !pk) continue;
+        uint32_t i = rb[y], j = rb[y - 1];
+        const uint32_t ie = i + k, je = j + pk;
+        uint32_t cur = s_run[i], prv = s_run[j];
+        for (;;) {
+            const int c0 = cur & 0xffffu, c1 = cur >> 16, p0 = prv & 0xffffu, p1 = prv >> 16;
+            if (p1 + slack >= c0 && c1 + slack >= p0) lds_union(s_par, j, i);
+            if (p1 < c1) { if (++j >= je) break; prv = s_run[j]; }
+            else         { if (++i >= ie) break; cur = s_run[i]; }
+        }
+    }
+    __syncthreads();
+    // P4: flatten
+    for (uint32_t r = tid; r < n; r += 1024) { const uint32_t root = lds_find(s_par, r); s_key[r] = root; }
+    __syncthreads();
+    for (uint32_t r = tid; r < n; r += 1024) s_par[r] = s_key[r];
+    __syncthreads();
+    // P5: blob ordinals (raster order of the root run), runs / pixels per blob
+    uint32_t nraw = 0;
+    for (uint32_t b0 = 0; b0 < n; b0 += 1024) {
+        const uint32_t r = b0 + tid;
+        const uint32_t flag = (r < n && s_par[r] == r) ? 1u : 0u;
+        uint32_t total;
+        const uint32_t ex = block_excl_scan(flag, s_misc, total);
+        if (flag) s_ord[r] = nraw + ex;
+        nraw += total;
+    }
+    for (uint32_t o = tid; o < nraw; o += 1024) { s_cr[o] = 0; s_cp[o] = 0; }
+    __syncthreads();
+    for (uint32_t r = tid; r < n; r += 1024) {
+        const uint32_t o = s_ord[s_par[r]];
+        const uint32_t q = s_run[r];
+        atomicAdd(s_cr + o, 1u);
+        atomicAdd(s_cp + o, (q >> 16) - (q & 0xffffu) + 1u);
+    }
+    __syncthreads();
+    // P6: size filter, offsets of the kept blobs
+    uint32_t kept = 0, kruns = 0, kpx = 0;
+    uint32_t* cur = cur_run + fo;
+    uint32_t* pbg = pix_begin + fo;
+    int32_t* bmap = blob_map + fo;
+    for (uint32_t b0 = 0; b0 < nraw; b0 += 1024) {
+        const uint32_t o = b0 + tid;
+        uint32_t nr = 0, np = 0, keep = 0;
+        if (o < nraw) { nr = s_cr[o]; np = s_cp[o]; keep = (size_ok(np, c) && nr < 65535u) ? 1u : 0u; }
+        uint32_t t0, t1, t2;
+        const uint32_t e0 = block_excl_scan(keep, s_misc, t0);
+        const uint32_t e1 = block_excl_scan(keep ? nr : 0u, s_misc, t1);
+        const uint32_t e2 = block_excl_scan(keep ? np : 0u, s_misc, t2);
+        if (o < nraw) {
+            bmap[o] = keep ? (int32_t)(kept + e0) : -1;
+            s_cp[o] = keep ? (kept + e0) : 0xffffffffu;            // s_cp now = kept index (pixel counts no longer needed)
+            if (keep) { cur[o] = kruns + e1; pbg[o] = kpx + e2; }
+        }
+        kept += t0; kruns += t1; kpx += t2;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        const uint32_t bb = atomicAdd(totals + 0, kept);
+        const uint32_t rbeg = atomicAdd(totals + 1, kruns);
+        const uint32_t pb = atomicAdd(totals + 2, kpx);
+        const bool over = bb + kept > c.pool_blobs || rbeg + kruns > c.pool_runs || pb + kpx > c.pool_pixels;
+        s_misc[32] = bb; s_misc[33] = rbeg; s_misc[34] = pb; s_misc[35] = over ? 1u : 0u;
+    }
+    __syncthreads();
+    const uint32_t bb = s_misc[32], rbeg = s_misc[33], pb = s_misc[34];
+    fi.n_raw_blobs = nraw;
+    if (s_misc[35]) {
+        for (uint32_t k = tid; k < kept; k += 1024)
+            if (bb + k < c.pool_blobs) blob_frame[bb + k] = 0xffffffffu;
+        if (tid == 0) { fi.flags |= TREXHIP_FRAME_OVERFLOW_OUTPUT; info[f] = fi; }
+        return;
+    }
+    // P7: blob records, run-level state for later passes, stable grouping by one sort
+    for (uint32_t o = tid; o < nraw; o += 1024) {
+        const uint32_t k = s_cp[o];
+        if (k == 0xffffffffu) continue;
+        trexhip_blob B = {};
+        B.run_begin = cur[o];
+        B.n_runs = s_cr[o];
+        B.pix_begin = pbg[o];
+        B.parent = 0xffffffffu;
+        blobs[bb + k] = B;
+        blob_frame[bb + k] = (uint32_t)f;
+    }
+    uint32_t sn = 64;
+    while (sn < n) sn <<= 1;
+    for (uint32_t r = tid; r < sn; r += 1024) {
+        uint32_t key = 0xffffffffu;
+        if (r < n) {
+            const uint32_t lab = s_par[r];
+            const uint32_t k = s_cp[s_ord[lab]];
+            if (k != 0xffffffffu) key = (k << 13) | r;
+            trexhip_run q; q.x0 = (uint16_t)(s_run[r] & 0xffffu); q.x1 = (uint16_t)(s_run[r] >> 16); q.y = s_y[r]; q.pad = 0;
+            raster[fo + r] = q;                                   // kept for the re-threshold pass
+            parent[fo + r] = lab;
+            if (lab == r) root_ord[fo + r] = s_ord[r];
+        }
+        s_key[r] = key;
+    }
+    __syncthreads();
+    for (uint32_t k = 2; k <= sn; k <<= 1)
+        for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+            for (uint32_t i = tid; i < sn; i += 1024) {
+                const uint32_t x = i ^ j;
+                if (x > i) {
+                    const uint32_t a = s_key[i], b = s_key[x];
+                    const bool up = (i & k) == 0;
+                    if ((a > b) == up) { s_key[i] = b; s_key[x] = a; }
+                }
+            }
+            __syncthreads();
+        }
+    trexhip_run* outr = out_runs + rbeg;
+    for (uint32_t i = tid; i < kruns; i += 1024) {
+        const uint32_t r = s_key[i] & 8191u;
+        trexhip_run q; q.x0 = (uint16_t)(s_run[r] & 0xffffu); q.x1 = (uint16_t)(s_run[r] >> 16); q.y = s_y[r]; q.pad = 0;
+        outr[i] = q;
+    }
+    if (tid == 0) {
+        fi.n_blobs = kept; fi.n_runs = kruns; fi.n_pixels = kpx;
+        fi.blob_begin = bb; fi.run_begin = rbeg; fi.pix_begin = pb;
+        info[f] = fi;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // k_gather: one wave per kept blob
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ uint64_t wave_sum64(uint64_t v) {
@@ -549,7 +765,7 @@ __device__ __forceinline__ uint32_t make_bid(uint32_t x0, uint32_t x1, uint32_t 
     return (x << 19) | (y << 6) | n;
 }
 
-__global__ __launch_bounds__(256) void k_gather(const SegCfg c, const uint8_t* __restrict__ frames,
+__global__ __launch_bounds__(256) void k_gather(const SegCfg c, const int only_pending, const uint8_t* __restrict__ frames,
                                                 const uint32_t* __restrict__ totals,
                                                 const trexhip_frame_info* __restrict__ info,
                                                 const uint32_t* __restrict__ blob_frame,
@@ -563,7 +779,7 @@ __global__ __launch_bounds__(256) void k_gather(const SegCfg c, const uint8_t* _
         const uint32_t f = blob_frame[bi];
         if (f >= (uint32_t)c.B) continue;          // hole left by a frame that overflowed the pool
         const trexhip_frame_info fi = info[f];
-        if (fi.flags) continue;
+        if (fi.flags || (only_pending && fi.reserved[0] != 2u)) continue;
         trexhip_blob B = blobs[bi];
         const trexhip_run* rr = runs + fi.run_begin + B.run_begin;
         uint8_t* px = pixels + fi.pix_begin + B.pix_begin;
@@ -649,16 +865,18 @@ int launch_segment(trexhip_ctx* ctx, const uint8_t* d_frames, int n) {
     if (aligned) launch_rows<true>(nch, grid_rows, s, d_frames, ctx->d_bg, c, ctx->tune_rows_order, ctx->d_ctr, ctx->d_row_cnt, ctx->d_row_off, ctx->d_tmp_runs);
     else         launch_rows<false>(nch, grid_rows, s, d_frames, ctx->d_bg, c, ctx->tune_rows_order, ctx->d_ctr, ctx->d_row_cnt, ctx->d_row_off, ctx->d_tmp_runs);
     stage_end(ctx, TREXHIP_STAGE_ROWS);
-    hipLaunchKernelGGL(k_rowscan, dim3(n), dim3(256), 0, s, c, ctx->d_ctr, ctx->d_row_cnt, ctx->d_row_base, ctx->d_parent, ctx->d_info);
-    const dim3 grid_r((unsigned)((n * H + 255) / 256));
-    hipLaunchKernelGGL(k_link, grid_r, dim3(256), 0, s, c, ctx->d_row_cnt, ctx->d_row_off, ctx->d_row_base,
-                       ctx->d_tmp_runs, ctx->d_raster, ctx->d_parent, ctx->d_info);
-    hipLaunchKernelGGL(k_flatten, grid_r, dim3(256), 0, s, c, ctx->d_row_cnt, ctx->d_row_base, ctx->d_parent, ctx->d_info);
+    static bool attr_done = false;
+    if (!attr_done) {
+        TH_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ccl_lds), hipFuncAttributeMaxDynamicSharedMemorySize, CCL_LDS_BYTES));
+        attr_done = true;
+    }
     uint32_t* totals = ctx->d_ctr + (size_t)ctx->p.max_batch * CTR_STRIDE;
-    hipLaunchKernelGGL(k_blobs, dim3(n), dim3(256), 0, s, c, ctx->d_raster, ctx->d_parent, ctx->d_root_ord,
-                       ctx->d_cnt_runs, ctx->d_cnt_px, ctx->d_cur_run, ctx->d_pix_begin, ctx->d_blob_map, totals, ctx->d_info,
-                       ctx->d_blobs, ctx->d_blob_frame, ctx->d_runs, 0, (const uint32_t*)nullptr);
-    hipLaunchKernelGGL(k_gather, dim3(1024), dim3(256), 0, s, c, d_frames, totals, ctx->d_info, ctx->d_blob_frame,
+    // run-level CCL of every frame inside one workgroup's LDS; frames with too many runs are left pending
+    // and finished by the global-memory chain in finish_segment()
+    hipLaunchKernelGGL(k_ccl_lds, dim3(n), dim3(1024), CCL_LDS_BYTES, s, c, ctx->d_ctr, ctx->d_row_cnt, ctx->d_row_off, ctx->d_row_base,
+                       ctx->d_tmp_runs, ctx->d_raster, ctx->d_parent, ctx->d_root_ord, ctx->d_cur_run, ctx->d_pix_begin, ctx->d_blob_map,
+                       totals, ctx->d_info, ctx->d_blobs, ctx->d_blob_frame, ctx->d_runs);
+    hipLaunchKernelGGL(k_gather, dim3(1024), dim3(256), 0, s, c, 0, d_frames, totals, ctx->d_info, ctx->d_blob_frame,
                        ctx->d_blobs, ctx->d_runs, ctx->d_pixels);
     stage_end(ctx, TREXHIP_STAGE_SEGMENT_ALL);
     TH_CHECK_HIP(hipGetLastError());
@@ -669,6 +887,26 @@ int launch_segment(trexhip_ctx* ctx, const uint8_t* d_frames, int n) {
     return TREXHIP_OK;
 }
 
+
+int launch_pending(trexhip_ctx* ctx) {
+    SegCfg c = ctx->cfg;
+    const int n = ctx->last_n;
+    c.B = n;
+    hipStream_t s = ctx->stream;
+    const dim3 grid_r((unsigned)((n * c.H + 255) / 256));
+    uint32_t* totals = ctx->d_ctr + (size_t)ctx->p.max_batch * CTR_STRIDE;
+    hipLaunchKernelGGL(k_rowscan, dim3(n), dim3(256), 0, s, c, 1, ctx->d_ctr, ctx->d_row_cnt, ctx->d_row_base, ctx->d_parent, ctx->d_info);
+    hipLaunchKernelGGL(k_link, grid_r, dim3(256), 0, s, c, 1, ctx->d_row_cnt, ctx->d_row_off, ctx->d_row_base,
+                       ctx->d_tmp_runs, ctx->d_raster, ctx->d_parent, ctx->d_info);
+    hipLaunchKernelGGL(k_flatten, grid_r, dim3(256), 0, s, c, 1, ctx->d_row_cnt, ctx->d_row_base, ctx->d_parent, ctx->d_info);
+    hipLaunchKernelGGL(k_blobs, dim3(n), dim3(256), 0, s, c, 1, ctx->d_raster, ctx->d_parent, ctx->d_root_ord,
+                       ctx->d_cnt_runs, ctx->d_cnt_px, ctx->d_cur_run, ctx->d_pix_begin, ctx->d_blob_map, totals, ctx->d_info,
+                       ctx->d_blobs, ctx->d_blob_frame, ctx->d_runs, 0, (const uint32_t*)nullptr);
+    hipLaunchKernelGGL(k_gather, dim3(1024), dim3(256), 0, s, c, 1, ctx->d_frames, totals, ctx->d_info, ctx->d_blob_frame,
+                       ctx->d_blobs, ctx->d_runs, ctx->d_pixels);
+    TH_CHECK_HIP(hipGetLastError());
+    return TREXHIP_OK;
+}
 
 // ---------------------------------------------------------------------------------------------
 // track-stage re-threshold (Tracker::prefilter -> pv::Blob::recount + pixel::threshold_blob,
@@ -808,10 +1046,10 @@ int launch_rethreshold(trexhip_ctx* ctx, int thr, int method, const double* rang
     hipLaunchKernelGGL((k_sub<1>), grid_r, dim3(256), 0, s, c, ctx->d_frames, ctx->d_bg, ctx->d_row_base, ctx->d_raster, ctx->d_parent,
                        ctx->d_root_ord, ctx->d_blob_map, ctx->d_info, method, thr, q.d_sub_cnt, q.d_sub_base, q.d_raster, q.d_run_parent);
     hipLaunchKernelGGL(k_link2, grid_r, dim3(256), 0, s, c, q.d_row_base, q.d_raster, q.d_parent, q.d_info);
-    hipLaunchKernelGGL(k_flatten, grid_r, dim3(256), 0, s, c, q.d_row_cnt, q.d_row_base, q.d_parent, q.d_info);
-    hipLaunchKernelGGL(k_blobs, dim3(n), dim3(256), 0, s, c, q.d_raster, q.d_parent, q.d_root_ord, q.d_cnt_runs, q.d_cnt_px, q.d_cur_run,
+    hipLaunchKernelGGL(k_flatten, grid_r, dim3(256), 0, s, c, 0, q.d_row_cnt, q.d_row_base, q.d_parent, q.d_info);
+    hipLaunchKernelGGL(k_blobs, dim3(n), dim3(256), 0, s, c, 0, q.d_raster, q.d_parent, q.d_root_ord, q.d_cnt_runs, q.d_cnt_px, q.d_cur_run,
                        q.d_pix_begin, q.d_blob_map, q.d_totals, q.d_info, q.d_blobs, q.d_blob_frame, q.d_runs, 1, q.d_run_parent);
-    hipLaunchKernelGGL(k_gather, dim3(1024), dim3(256), 0, s, c, ctx->d_frames, q.d_totals, q.d_info, q.d_blob_frame, q.d_blobs,
+    hipLaunchKernelGGL(k_gather, dim3(1024), dim3(256), 0, s, c, 0, ctx->d_frames, q.d_totals, q.d_info, q.d_blob_frame, q.d_blobs,
                        q.d_runs, q.d_pixels);
     TH_CHECK_HIP(hipGetLastError());
     q.valid_n = n;
