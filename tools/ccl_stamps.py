@@ -1,0 +1,18 @@
+import os, sys, ctypes as C
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ["TREXHIP_CCL_STOP"] = "-1"
+import torch
+from trex_amd import capi, synth
+B = 64
+W, H, _, _ = synth.CONFIGS["C4"]
+frames, bg = synth.batch_torch("C4", B, "cuda")
+seg = capi.Segmenter(capi.default_params(W, H, max_batch=B, max_blobs=1024, max_pixels=1 << 18, max_runs=32768))
+seg.set_background(bg)
+L = capi.lib()
+L.trexhip_debug_read.argtypes = [C.c_void_p, C.c_void_p, C.c_int32]
+for it in range(3):
+    seg.segment_device(frames.data_ptr(), B); seg.synchronize()
+    buf = (C.c_ulonglong * 16)()
+    L.trexhip_debug_read(seg.handle, buf, 16)
+    v = list(buf)[:9]
+    print([v[i + 1] - v[i] for i in range(8)], "total", v[8] - v[0])

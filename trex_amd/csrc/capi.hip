@@ -141,7 +141,8 @@ int trexhip_create(const trexhip_params* p, trexhip_ctx** out) {
     ctx->p = *p;
     fill_cfg(ctx);
     if (const char* e = std::getenv("TREXHIP_ROWS_ORDER")) ctx->tune_rows_order = std::atoi(e);
-    if (const char* e = std::getenv("TREXHIP_ROWS_BLOCKS")) ctx->tune_rows_blocks = std::atoi(e) > 0 ? std::atoi(e) : 2048;
+    if (const char* e = std::getenv("TREXHIP_CCL_STOP")) ctx->tune_ccl_stop = std::atoi(e);
+    if (const char* e = std::getenv("TREXHIP_ROWS_BLOCKS")) ctx->tune_rows_blocks = std::atoi(e) > 0 ? std::atoi(e) : 8192;
     const size_t B = p->max_batch, H = p->height, W = p->width, R = p->max_runs, NB = p->max_blobs, P = p->max_pixels;
     int rc = TREXHIP_OK;
 #define TRY(x) do { if (rc == TREXHIP_OK) rc = (x); } while (0)
@@ -380,6 +381,13 @@ int trexhip_device_view_get(trexhip_ctx* ctx, trexhip_device_view* out) {
     if (!ctx || !out) { set_error("trexhip_device_view_get: null argument"); return TREXHIP_E_INVALID; }
     out->frames = ctx->d_info; out->blobs = ctx->d_blobs; out->runs = ctx->d_runs; out->pixels = ctx->d_pixels;
     out->totals = ctx->d_ctr + (size_t)ctx->p.max_batch * TREXHIP_CTR_STRIDE; out->blob_frame = ctx->d_blob_frame;
+    return TREXHIP_OK;
+}
+
+int trexhip_debug_read(trexhip_ctx* ctx, unsigned long long* out, int32_t n) {   /* dev only: phase stamps of k_ccl_lds */
+    if (!ctx || !out) return TREXHIP_E_INVALID;
+    TH_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+    TH_CHECK_HIP(hipMemcpy(out, ctx->d_cnt_px, sizeof(unsigned long long) * n, hipMemcpyDeviceToHost));
     return TREXHIP_OK;
 }
 

@@ -37,21 +37,46 @@ __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v) {
     return v;
 }
 
-// exclusive scan over a 256-thread block; lds must hold >= 8 uint32
+// exclusive scan over a block of up to 1024 threads; lds must hold >= 16 uint32
 __device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t* lds, uint32_t& total) {
     const uint32_t lane = lane_id(), wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
-    uint32_t incl = wave_incl_scan(v);
+    const uint32_t incl = wave_incl_scan(v);
     __syncthreads();                       // lds reuse
     if (lane == 63) lds[wave] = incl;
     __syncthreads();
-    uint32_t off = 0, tot = 0;
-    for (uint32_t w = 0; w < nw; ++w) {
-        uint32_t s = lds[w];
-        if (w < wave) off += s;
-        tot += s;
-    }
-    total = tot;
+    // every wave scans the (<= 16) wave totals itself: lanes 0..nw-1 hold them
+    const uint32_t part = lane < nw ? lds[lane] : 0u;
+    uint32_t pi = part;
+#pragma unroll
+    for (int d = 1; d < 16; d <<= 1) { const uint32_t t = __shfl_up(pi, d); if (lane >= (uint32_t)d) pi += t; }
+    total = __shfl(pi, nw - 1);
+    const uint32_t off = __shfl(pi - part, wave);
     return off + incl - v;
+}
+
+// three exclusive scans at once (one barrier pair)
+__device__ __forceinline__ void block_excl_scan3(uint32_t a, uint32_t b, uint32_t c3, uint32_t* lds, uint32_t* ex, uint32_t* tot) {
+    const uint32_t lane = lane_id(), wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    const uint32_t ia = wave_incl_scan(a), ib = wave_incl_scan(b), ic = wave_incl_scan(c3);
+    __syncthreads();
+    if (lane == 63) { lds[wave] = ia; lds[16 + wave] = ib; lds[32 + wave] = ic; }
+    __syncthreads();
+    const uint32_t in[3] = {ia, ib, ic}, v[3] = {a, b, c3};
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+        const uint32_t part = lane < nw ? lds[16 * q + lane] : 0u;
+        uint32_t pi = part;
+#pragma unroll
+        for (int d = 1; d < 16; d <<= 1) { const uint32_t t = __shfl_up(pi, d); if (lane >= (uint32_t)d) pi += t; }
+        tot[q] = __shfl(pi, nw - 1);
+        ex[q] = __shfl(pi - part, wave) + in[q] - v[q];
+    }
+}
+
+__device__ __forceinline__ uint32_t wmax32(uint32_t v) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v = max(v, (uint32_t)__shfl_xor(v, d));
+    return v;
 }
 
 __device__ __forceinline__ uint32_t ld_relaxed(const uint32_t* p) {
@@ -534,7 +559,11 @@ static constexpr int CCL_LDS_BYTES = CCL_NMAX * (4 + 4 + 4 + 4 + 4) + CCL_NMAX *
 
 __device__ __forceinline__ uint32_t lds_find(volatile uint32_t* par, uint32_t a) {
     uint32_t p = par[a];
-    while (p != a) { a = p; p = par[a]; }
+    while (p != a) {
+        const uint32_t g = par[p];
+        if (g != p) par[a] = g;            // path halving: parents only ever move towards the root, so this is race-safe
+        a = p; p = g;
+    }
     return a;
 }
 __device__ __forceinline__ void lds_union(uint32_t* par, uint32_t a, uint32_t b) {
@@ -556,7 +585,9 @@ __global__ __launch_bounds__(1024) void k_ccl_lds(const SegCfg c, const uint32_t
                                                   uint32_t* __restrict__ pix_begin, int32_t* __restrict__ blob_map,
                                                   uint32_t* __restrict__ totals, trexhip_frame_info* __restrict__ info,
                                                   trexhip_blob* __restrict__ blobs, uint32_t* __restrict__ blob_frame,
-                                                  trexhip_run* __restrict__ out_runs) {
+                                                  trexhip_run* __restrict__ out_runs, const int dbg_stop,
+                                                  unsigned long long* __restrict__ dbg) {
+#define CCL_STAMP(i) do { if (dbg_stop == -1 && blockIdx.x == 0 && threadIdx.x == 0) dbg[i] = __builtin_readcyclecounter(); } while (0)
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     uint32_t* s_run = smem;                       // x0 | x1 << 16, raster order
     uint32_t* s_par = s_run + CCL_NMAX;           // union-find parent -> label
@@ -573,6 +604,7 @@ __global__ __launch_bounds__(1024) void k_ccl_lds(const SegCfg c, const uint32_t
     uint32_t* rb = row_base + (size_t)f * (H + 1);
     const size_t fo = (size_t)f * c.R;
 
+    CCL_STAMP(0);
     // P1: raster index of every row
     uint32_t n = 0;
     for (int y0 = 0; y0 < H; y0 += 1024) {
@@ -580,9 +612,10 @@ __global__ __launch_bounds__(1024) void k_ccl_lds(const SegCfg c, const uint32_t
         const uint32_t v = y < H ? cnt[y] : 0;
         uint32_t total;
         const uint32_t ex = block_excl_scan(v, s_misc, total);
-        if (y < H) rb[y] = n + ex;
+        if (y < H) { rb[y] = n + ex; if (y < CCL_SORT - 1) s_key[y] = n + ex; }
         n += total;
     }
+    const bool rb_lds = H < CCL_SORT;              // row_base also lives in LDS (s_key is idle until P4)
     trexhip_frame_info fi = {};
     fi.n_raw_runs = n;
     const bool overflow = n > (uint32_t)c.R || frame_ctr[f * CTR_STRIDE] > (uint32_t)c.R;
@@ -594,38 +627,50 @@ __global__ __launch_bounds__(1024) void k_ccl_lds(const SegCfg c, const uint32_t
         }
         return;
     }
-    if (tid == 0) rb[H] = n;
+    if (tid == 0) { rb[H] = n; if (rb_lds) s_key[H] = n; }
     __syncthreads();
+    if (dbg_stop == 1) return;
+    CCL_STAMP(1);
     // P2: runs into LDS in raster order
     const uint32_t* tmp = tmp_runs + (size_t)f * c.T;
     for (int y = tid; y < H; y += 1024) {
-        const uint32_t k = cnt[y];
+        const uint32_t b = rb_lds ? s_key[y] : rb[y];
+        const uint32_t k = (rb_lds ? s_key[y + 1] : rb[y + 1]) - b;
         if (!k) continue;
-        const uint32_t o = off[y], b = rb[y];
+        const uint32_t o = off[y];
         for (uint32_t i = 0; i < k; ++i) { s_run[b + i] = tmp[o + i]; s_y[b + i] = (uint16_t)y; s_par[b + i] = b + i; }
     }
     __syncthreads();
-    // P3: link every row with the row above
+    if (dbg_stop == 2) return;
+    CCL_STAMP(2);
+    // P3: link every run with the touching runs of the row above (thread per run, binary search for the first candidate)
     const int slack = c.slack;
-    for (int y = 1 + tid; y < H; y += 1024) {
-        const uint32_t k = cnt[y], pk = cnt[y - 1];
-        if (!k || !pk) continue;
-        uint32_t i = rb[y], j = rb[y - 1];
-        const uint32_t ie = i + k, je = j + pk;
-        uint32_t cur = s_run[i], prv = s_run[j];
-        for (;;) {
-            const int c0 = cur & 0xffffu, c1 = cur >> 16, p0 = prv & 0xffffu, p1 = prv >> 16;
-            if (p1 + slack >= c0 && c1 + slack >= p0) lds_union(s_par, j, i);
-            if (p1 < c1) { if (++j >= je) break; prv = s_run[j]; }
-            else         { if (++i >= ie) break; cur = s_run[i]; }
+    for (uint32_t r = tid; r < n; r += 1024) {
+        const int y = s_y[r];
+        if (y == 0) continue;
+        uint32_t lo = rb_lds ? s_key[y - 1] : rb[y - 1];
+        const uint32_t je = rb_lds ? s_key[y] : rb[y];
+        if (lo >= je) continue;
+        const uint32_t cur = s_run[r];
+        const int c0 = cur & 0xffffu, c1 = cur >> 16;
+        uint32_t hi = je;                                  // first run of the row above with x1 + slack >= c0
+        while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if ((int)(s_run[mid] >> 16) + slack >= c0) hi = mid; else lo = mid + 1; }
+        for (uint32_t j = lo; j < je; ++j) {
+            const uint32_t prv = s_run[j];
+            if ((int)(prv & 0xffffu) > c1 + slack) break;
+            lds_union(s_par, j, r);
         }
     }
     __syncthreads();
+    if (dbg_stop == 3) return;
+    CCL_STAMP(3);
     // P4: flatten
     for (uint32_t r = tid; r < n; r += 1024) { const uint32_t root = lds_find(s_par, r); s_key[r] = root; }
     __syncthreads();
     for (uint32_t r = tid; r < n; r += 1024) s_par[r] = s_key[r];
     __syncthreads();
+    if (dbg_stop == 4) return;
+    CCL_STAMP(4);
     // P5: blob ordinals (raster order of the root run), runs / pixels per blob
     uint32_t nraw = 0;
     for (uint32_t b0 = 0; b0 < n; b0 += 1024) {
@@ -645,6 +690,8 @@ __global__ __launch_bounds__(1024) void k_ccl_lds(const SegCfg c, const uint32_t
         atomicAdd(s_cp + o, (q >> 16) - (q & 0xffffu) + 1u);
     }
     __syncthreads();
+    if (dbg_stop == 5) return;
+    CCL_STAMP(5);
     // P6: size filter, offsets of the kept blobs
     uint32_t kept = 0, kruns = 0, kpx = 0;
     uint32_t* cur = cur_run + fo;
@@ -654,10 +701,9 @@ __global__ __launch_bounds__(1024) void k_ccl_lds(const SegCfg c, const uint32_t
         const uint32_t o = b0 + tid;
         uint32_t nr = 0, np = 0, keep = 0;
         if (o < nraw) { nr = s_cr[o]; np = s_cp[o]; keep = (size_ok(np, c) && nr < 65535u) ? 1u : 0u; }
-        uint32_t t0, t1, t2;
-        const uint32_t e0 = block_excl_scan(keep, s_misc, t0);
-        const uint32_t e1 = block_excl_scan(keep ? nr : 0u, s_misc, t1);
-        const uint32_t e2 = block_excl_scan(keep ? np : 0u, s_misc, t2);
+        uint32_t ex3[3], tot3[3];
+        block_excl_scan3(keep, keep ? nr : 0u, keep ? np : 0u, s_misc, ex3, tot3);
+        const uint32_t e0 = ex3[0], e1 = ex3[1], e2 = ex3[2], t0 = tot3[0], t1 = tot3[1], t2 = tot3[2];
         if (o < nraw) {
             bmap[o] = keep ? (int32_t)(kept + e0) : -1;
             s_cp[o] = keep ? (kept + e0) : 0xffffffffu;            // s_cp now = kept index (pixel counts no longer needed)
@@ -667,9 +713,11 @@ __global__ __launch_bounds__(1024) void k_ccl_lds(const SegCfg c, const uint32_t
     }
     __syncthreads();
     if (tid == 0) {
-        const uint32_t bb = atomicAdd(totals + 0, kept);
-        const uint32_t rbeg = atomicAdd(totals + 1, kruns);
+        // totals[0],[1] = blobs, runs reserved with ONE 64-bit atomic; totals[2] = pixels
+        const unsigned long long br = atomicAdd(reinterpret_cast<unsigned long long*>(totals),
+                                                (unsigned long long)kept | ((unsigned long long)kruns << 32));
         const uint32_t pb = atomicAdd(totals + 2, kpx);
+        const uint32_t bb = (uint32_t)br, rbeg = (uint32_t)(br >> 32);
         const bool over = bb + kept > c.pool_blobs || rbeg + kruns > c.pool_runs || pb + kpx > c.pool_pixels;
         s_misc[32] = bb; s_misc[33] = rbeg; s_misc[34] = pb; s_misc[35] = over ? 1u : 0u;
     }
@@ -682,6 +730,8 @@ __global__ __launch_bounds__(1024) void k_ccl_lds(const SegCfg c, const uint32_t
         if (tid == 0) { fi.flags |= TREXHIP_FRAME_OVERFLOW_OUTPUT; info[f] = fi; }
         return;
     }
+    if (dbg_stop == 6) return;
+    CCL_STAMP(6);
     // P7: blob records, run-level state for later passes, stable grouping by one sort
     for (uint32_t o = tid; o < nraw; o += 1024) {
         const uint32_t k = s_cp[o];
@@ -694,45 +744,102 @@ __global__ __launch_bounds__(1024) void k_ccl_lds(const SegCfg c, const uint32_t
         blobs[bb + k] = B;
         blob_frame[bb + k] = (uint32_t)f;
     }
-    uint32_t sn = 64;
-    while (sn < n) sn <<= 1;
-    for (uint32_t r = tid; r < sn; r += 1024) {
-        uint32_t key = 0xffffffffu;
-        if (r < n) {
-            const uint32_t lab = s_par[r];
-            const uint32_t k = s_cp[s_ord[lab]];
-            if (k != 0xffffffffu) key = (k << 13) | r;
-            trexhip_run q; q.x0 = (uint16_t)(s_run[r] & 0xffffu); q.x1 = (uint16_t)(s_run[r] >> 16); q.y = s_y[r]; q.pad = 0;
-            raster[fo + r] = q;                                   // kept for the re-threshold pass
-            parent[fo + r] = lab;
-            if (lab == r) root_ord[fo + r] = s_ord[r];
-        }
-        s_key[r] = key;
+    // run-level state for the re-threshold pass
+    for (uint32_t r = tid; r < n; r += 1024) {
+        const uint32_t lab = s_par[r];
+        trexhip_run q; q.x0 = (uint16_t)(s_run[r] & 0xffffu); q.x1 = (uint16_t)(s_run[r] >> 16); q.y = s_y[r]; q.pad = 0;
+        raster[fo + r] = q;
+        parent[fo + r] = lab;
+        if (lab == r) root_ord[fo + r] = s_ord[r];
     }
+    if (dbg_stop == 7) return;
+    CCL_STAMP(7);
+    // largest kept blob decides the grouping strategy (block-uniform)
+    uint32_t mx = 0;
+    for (uint32_t o = tid; o < nraw; o += 1024) if (s_cp[o] != 0xffffffffu) mx = max(mx, s_cr[o]);
+    mx = wmax32(mx);
     __syncthreads();
-    for (uint32_t k = 2; k <= sn; k <<= 1)
-        for (uint32_t j = k >> 1; j > 0; j >>= 1) {
-            for (uint32_t i = tid; i < sn; i += 1024) {
-                const uint32_t x = i ^ j;
-                if (x > i) {
-                    const uint32_t a = s_key[i], b = s_key[x];
-                    const bool up = (i & k) == 0;
-                    if ((a > b) == up) { s_key[i] = b; s_key[x] = a; }
+    if ((tid & 63) == 0) s_misc[40 + (tid >> 6)] = mx;
+    __syncthreads();
+    mx = 0;
+    for (int w = 0; w < 16; ++w) mx = max(mx, s_misc[40 + w]);
+    trexhip_run* outr = out_runs + rbeg;
+    if (mx <= 512u && kept <= (uint32_t)(CCL_SORT - CCL_NMAX)) {
+        // (1) scatter raster indices into each blob's segment in arbitrary order (LDS atomics on a per-blob cursor),
+        // (2) one wave per blob ranks its runs by counting smaller raster indices -> sorted order, written straight out
+        uint32_t* s_cursor = s_ord;                               // s_ord is free once the keys are known
+        __syncthreads();
+        uint32_t my_k[CCL_NMAX / 1024];                           // each thread keeps its runs' kept index (n <= 5*1024)
+#pragma unroll
+        for (int u = 0; u < CCL_NMAX / 1024; ++u) {
+            const uint32_t r = tid + u * 1024;
+            my_k[u] = r < n ? s_cp[s_ord[s_par[r]]] : 0xffffffffu;
+        }
+        __syncthreads();
+        for (uint32_t o = tid; o < nraw; o += 1024) { const uint32_t k = s_cp[o]; if (k != 0xffffffffu) { s_key[CCL_NMAX + k] = cur[o]; } }
+        __syncthreads();
+        // s_key[CCL_NMAX + k] = segment begin of kept blob k (kept <= CCL_SORT - CCL_NMAX is checked below)
+        for (uint32_t k = tid; k < kept; k += 1024) s_cursor[k] = 0;
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < CCL_NMAX / 1024; ++u) {
+            const uint32_t r = tid + u * 1024;
+            const uint32_t k = my_k[u];
+            if (k == 0xffffffffu) continue;
+            const uint32_t slot = atomicAdd(s_cursor + k, 1u);
+            s_key[s_key[CCL_NMAX + k] + slot] = r;               // segment storage: s_key[0 .. kruns)
+        }
+        __syncthreads();
+        const uint32_t lane = tid & 63, wave = tid >> 6;
+        for (uint32_t k = wave; k < kept; k += 16) {
+            const uint32_t beg = s_key[CCL_NMAX + k], cntk = s_cursor[k];
+            for (uint32_t e0 = 0; e0 < cntk; e0 += 64) {
+                const uint32_t e = e0 + lane;
+                const uint32_t mine = e < cntk ? s_key[beg + e] : 0xffffffffu;
+                uint32_t rank = 0;
+                if (cntk <= 64u) { for (uint32_t t = 0; t < cntk; ++t) rank += (uint32_t)__builtin_amdgcn_readlane((int)mine, (int)t) < mine ? 1u : 0u; }
+                else             { for (uint32_t t = 0; t < cntk; ++t) rank += s_key[beg + t] < mine ? 1u : 0u; }
+                if (e < cntk) {
+                    trexhip_run q; q.x0 = (uint16_t)(s_run[mine] & 0xffffu); q.x1 = (uint16_t)(s_run[mine] >> 16); q.y = s_y[mine]; q.pad = 0;
+                    outr[beg + rank] = q;
                 }
             }
-            __syncthreads();
         }
-    trexhip_run* outr = out_runs + rbeg;
-    for (uint32_t i = tid; i < kruns; i += 1024) {
-        const uint32_t r = s_key[i] & 8191u;
-        trexhip_run q; q.x0 = (uint16_t)(s_run[r] & 0xffffu); q.x1 = (uint16_t)(s_run[r] >> 16); q.y = s_y[r]; q.pad = 0;
-        outr[i] = q;
+    } else {
+        uint32_t sn = 64;
+        while (sn < n) sn <<= 1;
+        __syncthreads();
+        for (uint32_t r = tid; r < sn; r += 1024) {
+            uint32_t key = 0xffffffffu;
+            if (r < n) { const uint32_t k = s_cp[s_ord[s_par[r]]]; if (k != 0xffffffffu) key = (k << 13) | r; }
+            s_key[r] = key;
+        }
+        __syncthreads();
+        for (uint32_t k = 2; k <= sn; k <<= 1)
+            for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+                for (uint32_t i = tid; i < sn; i += 1024) {
+                    const uint32_t x = i ^ j;
+                    if (x > i) {
+                        const uint32_t a = s_key[i], b2 = s_key[x];
+                        const bool up = (i & k) == 0;
+                        if ((a > b2) == up) { s_key[i] = b2; s_key[x] = a; }
+                    }
+                }
+                __syncthreads();
+            }
+        for (uint32_t i = tid; i < kruns; i += 1024) {
+            const uint32_t r = s_key[i] & 8191u;
+            trexhip_run q; q.x0 = (uint16_t)(s_run[r] & 0xffffu); q.x1 = (uint16_t)(s_run[r] >> 16); q.y = s_y[r]; q.pad = 0;
+            outr[i] = q;
+        }
     }
+    CCL_STAMP(8);
     if (tid == 0) {
         fi.n_blobs = kept; fi.n_runs = kruns; fi.n_pixels = kpx;
         fi.blob_begin = bb; fi.run_begin = rbeg; fi.pix_begin = pb;
         info[f] = fi;
     }
+#undef CCL_STAMP
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -875,7 +982,7 @@ int launch_segment(trexhip_ctx* ctx, const uint8_t* d_frames, int n) {
     // and finished by the global-memory chain in finish_segment()
     hipLaunchKernelGGL(k_ccl_lds, dim3(n), dim3(1024), CCL_LDS_BYTES, s, c, ctx->d_ctr, ctx->d_row_cnt, ctx->d_row_off, ctx->d_row_base,
                        ctx->d_tmp_runs, ctx->d_raster, ctx->d_parent, ctx->d_root_ord, ctx->d_cur_run, ctx->d_pix_begin, ctx->d_blob_map,
-                       totals, ctx->d_info, ctx->d_blobs, ctx->d_blob_frame, ctx->d_runs);
+                       totals, ctx->d_info, ctx->d_blobs, ctx->d_blob_frame, ctx->d_runs, ctx->tune_ccl_stop, reinterpret_cast<unsigned long long*>(ctx->d_cnt_px));
     hipLaunchKernelGGL(k_gather, dim3(1024), dim3(256), 0, s, c, 0, d_frames, totals, ctx->d_info, ctx->d_blob_frame,
                        ctx->d_blobs, ctx->d_runs, ctx->d_pixels);
     stage_end(ctx, TREXHIP_STAGE_SEGMENT_ALL);
