@@ -29,12 +29,12 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 // conv1: 1 -> 16 channels, 80x80 -> pooled 40x40x16 (NHWC fp32)
 // ------------------------------------------------------------------------------------------------
 template <int CH>
-__global__ __launch_bounds__(256) void k_conv1(const uint8_t* __restrict__ crops, const float* __restrict__ w /*[CH][25][16]*/,
-                                               const float* __restrict__ bias /*[16]*/, float* __restrict__ out, int S) {
-    extern __shared__ float lds[];
+__global__ __launch_bounds__(256, 2) void k_conv1(const uint8_t* __restrict__ crops, const float* __restrict__ w /*[CH][25][16]*/,
+                                                  const float* __restrict__ bias /*[16]*/, float* __restrict__ out, int S) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
     const int PW = S + 4;
-    float* img = lds;                       // [CH][PW*PW]
-    float* wl = lds + CH * PW * PW;         // [CH*25*16]
+    float* wl = lds;                        // [CH*25*16]  (first: 16-byte aligned for float4 reads)
+    float* img = lds + CH * 25 * 16;        // [CH][PW*PW]
     const int crop = blockIdx.x;
     const uint8_t* src = crops + (size_t)crop * S * S * CH;
     for (int i = threadIdx.x; i < CH * PW * PW; i += 256) img[i] = 0.f;
@@ -50,29 +50,34 @@ __global__ __launch_bounds__(256) void k_conv1(const uint8_t* __restrict__ crops
         const int wy = wi / HW, wx = wi - wy * HW;
         float acc[4][16];
 #pragma unroll
-        for (int s = 0; s < 4; ++s)
+        for (int s4 = 0; s4 < 4; ++s4)
 #pragma unroll
-            for (int co = 0; co < 16; ++co) acc[s][co] = 0.f;
+            for (int co = 0; co < 16; ++co) acc[s4][co] = 0.f;
         for (int c = 0; c < CH; ++c) {
-            float p[6][6];
+            const float* base = img + c * PW * PW + (2 * wy) * PW + 2 * wx;
+#pragma unroll 1
+            for (int ky = 0; ky < 5; ++ky) {
+                float r0[6], r1[6];                                     // two input rows feed output rows 0 and 1 of the window
 #pragma unroll
-            for (int a = 0; a < 6; ++a)
-#pragma unroll
-                for (int b = 0; b < 6; ++b) p[a][b] = img[c * PW * PW + (2 * wy + a) * PW + 2 * wx + b];
-#pragma unroll
-            for (int ky = 0; ky < 5; ++ky)
+                for (int b6 = 0; b6 < 6; ++b6) { r0[b6] = base[ky * PW + b6]; r1[b6] = base[(ky + 1) * PW + b6]; }
 #pragma unroll
                 for (int kx = 0; kx < 5; ++kx) {
-                    const float* wt = wl + (c * 25 + ky * 5 + kx) * 16;
+                    const float4* wt = reinterpret_cast<const float4*>(wl + (c * 25 + ky * 5 + kx) * 16);
 #pragma unroll
-                    for (int co = 0; co < 16; ++co) {
-                        const float ww = wt[co];
-                        acc[0][co] = fmaf(p[ky][kx], ww, acc[0][co]);
-                        acc[1][co] = fmaf(p[ky][kx + 1], ww, acc[1][co]);
-                        acc[2][co] = fmaf(p[ky + 1][kx], ww, acc[2][co]);
-                        acc[3][co] = fmaf(p[ky + 1][kx + 1], ww, acc[3][co]);
+                    for (int q4 = 0; q4 < 4; ++q4) {
+                        const float4 wv = wt[q4];
+                        const float ww[4] = {wv.x, wv.y, wv.z, wv.w};
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const int co = q4 * 4 + q;
+                            acc[0][co] = fmaf(r0[kx], ww[q], acc[0][co]);
+                            acc[1][co] = fmaf(r0[kx + 1], ww[q], acc[1][co]);
+                            acc[2][co] = fmaf(r1[kx], ww[q], acc[2][co]);
+                            acc[3][co] = fmaf(r1[kx + 1], ww[q], acc[3][co]);
+                        }
                     }
                 }
+            }
         }
         float* o = out + ((size_t)crop * HW * HW + wi) * 16;
 #pragma unroll
@@ -217,33 +222,48 @@ __global__ __launch_bounds__(512) void k_conv5(const float* __restrict__ in /*[N
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_fc1(const float* __restrict__ act, const float* __restrict__ w /*[K][128]*/,
                                              const float* __restrict__ bias /*[128]*/, float* __restrict__ out, int n, int K) {
-    __shared__ float As[32 * 33];
-    __shared__ float Bs[32 * 128];
+    __shared__ float As[2][32 * 33];
+    __shared__ __attribute__((aligned(16))) float Bs[2][32 * 128];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int j = lane & 31, h = lane >> 5;
     const int m0 = blockIdx.x * 32;
+    const int ar = tid >> 3, aq = tid & 7;                 // A tile: 32 rows x 8 float4
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-    for (int k0 = 0; k0 < K; k0 += 32) {
-        __syncthreads();
-        {   // A tile: 32 rows x 32 k
-            const int r = tid >> 3, q = tid & 7;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (m0 + r < n) v = *reinterpret_cast<const float4*>(act + (size_t)(m0 + r) * K + k0 + q * 4);
-            float* d = As + r * 33 + q * 4;
-            d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
-        }
-        for (int i = tid; i < 32 * 128 / 4; i += 256)
-            reinterpret_cast<float4*>(Bs)[i] = reinterpret_cast<const float4*>(w + (size_t)k0 * 128)[i];
-        __syncthreads();
+    float4 na, nb0, nb1, nb2, nb3;
+    const bool arow = m0 + ar < n;
+    const float* asrc = act + (size_t)(m0 + ar) * K + aq * 4;
+    const float4* wsrc = reinterpret_cast<const float4*>(w) + tid;
+#define FC1_FETCH(k0)                                                                                  \
+    do {                                                                                               \
+        na = arow ? *reinterpret_cast<const float4*>(asrc + (k0)) : make_float4(0.f, 0.f, 0.f, 0.f);   \
+        const float4* ws_ = wsrc + (size_t)(k0) * 32;                                                  \
+        nb0 = ws_[0]; nb1 = ws_[256]; nb2 = ws_[512]; nb3 = ws_[768];                                  \
+    } while (0)
+#define FC1_STASH(buf)                                                                                 \
+    do {                                                                                               \
+        float* d_ = As[buf] + ar * 33 + aq * 4;                                                        \
+        d_[0] = na.x; d_[1] = na.y; d_[2] = na.z; d_[3] = na.w;                                        \
+        float4* b_ = reinterpret_cast<float4*>(Bs[buf]) + tid;                                         \
+        b_[0] = nb0; b_[256] = nb1; b_[512] = nb2; b_[768] = nb3;                                      \
+    } while (0)
+    FC1_FETCH(0);
+    FC1_STASH(0);
+    __syncthreads();
+    const int nk = K / 32;
+    for (int kc = 0; kc < nk; ++kc) {
+        const int buf = kc & 1;
+        if (kc + 1 < nk) FC1_FETCH((kc + 1) * 32);          // next K chunk -> registers, overlaps the MFMAs below
+        const float* as = As[buf] + j * 33 + h;
+        const float* bs = Bs[buf] + h * 128 + wave * 32 + j;
 #pragma unroll
-        for (int t = 0; t < 16; ++t) {
-            const float a = As[j * 33 + 2 * t + h];
-            const float b = Bs[(2 * t + h) * 128 + wave * 32 + j];
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
-        }
+        for (int t = 0; t < 16; ++t) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(as[2 * t], bs[2 * t * 128], acc, 0, 0, 0);
+        if (kc + 1 < nk) FC1_STASH(buf ^ 1);
+        __syncthreads();
     }
+#undef FC1_FETCH
+#undef FC1_STASH
     const int co = wave * 32 + j;
     const float bz = bias[co];
 #pragma unroll
