@@ -205,3 +205,19 @@ def test_colour_tile_input(channels, color_channel):
     for r, g in zip(res, gray):
         assert_frame_equal(r, np.ascontiguousarray(g), bg, threshold=40)
     seg.close()
+
+
+@pytest.mark.parametrize("kw", [dict(use_closing=1, closing_size=3), dict(dilation_size=1), dict(dilation_size=-1),
+                                 dict(use_closing=1, closing_size=5, dilation_size=2), dict(dilation_size=-3),
+                                 dict(use_closing=1, closing_size=4), dict(use_closing=1, closing_size=15, dilation_size=7)])
+@pytest.mark.parametrize("shape", [(90, 70), (2048, 64), (1000, 37)])
+def test_morphology_bit_exact(kw, shape):
+    # use_closing / dilation_size (core/default_config.cpp:1163-1165): device bit-mask morphology vs the oracle,
+    # whose morphology is itself cross-checked against scipy.ndimage (tests/test_oracle_scipy.py)
+    W, H = shape
+    rng = np.random.default_rng(W + H + len(kw))
+    fr, bg = synth.random_scene(rng, W, H, density=0.2)
+    fr[rng.random((H, W)) < 0.01] = 0          # zero-valued pixels under the mask stay background
+    fr[0, :] = 5; fr[:, W - 1] = 7             # foreground on the borders (border handling of the element)
+    res = run_gpu(fr[None], bg, **kw)
+    assert_frame_equal(res[0], fr, bg, **kw)

@@ -129,8 +129,9 @@ int trexhip_create(const trexhip_params* p, trexhip_ctx** out) {
     }
     if (p->connectivity != 8 && p->connectivity != 4) { set_error("trexhip_create: connectivity must be 4 or 8"); return TREXHIP_E_INVALID; }
     if (p->n_ranges < 0 || p->n_ranges > 8) { set_error("trexhip_create: n_ranges must be 0..8"); return TREXHIP_E_INVALID; }
-    if (p->dilation_size != 0 || p->use_closing) {
-        set_error("trexhip_create: dilation_size / use_closing are not implemented on the device yet"); return TREXHIP_E_UNSUPPORTED;
+    if ((p->use_closing && (p->closing_size < 1 || p->closing_size > 15)) || p->dilation_size > 7 || p->dilation_size < -7) {
+        set_error("trexhip_create: structuring elements larger than 15x15 are not supported (closing_size <= 15, |dilation_size| <= 7)");
+        return TREXHIP_E_UNSUPPORTED;
     }
     int ndev = 0;
     TH_CHECK_HIP(hipGetDeviceCount(&ndev));
@@ -167,6 +168,11 @@ int trexhip_create(const trexhip_params* p, trexhip_ctx** out) {
     TRY(dmalloc(&ctx->d_blob_frame, B * NB));
     TRY(dmalloc(&ctx->d_runs, B * R));
     TRY(dmalloc(&ctx->d_pixels, B * P));
+    if (p->use_closing || p->dilation_size != 0) {
+        const size_t WBw = (W + 31) / 32;
+        TRY(dmalloc(&ctx->d_bits[0], B * H * WBw + 4));
+        TRY(dmalloc(&ctx->d_bits[1], B * H * WBw + 4));
+    }
     TRY(hmalloc(&ctx->h_info, B));
     TRY(hmalloc(&ctx->h_totals, 4));
     TRY(hmalloc(&ctx->h_blobs, B * NB));
@@ -186,7 +192,7 @@ void trexhip_destroy(trexhip_ctx* ctx) {
     pass2_free(ctx);
     void* dev[] = {ctx->d_bg, ctx->d_staging, ctx->d_ctr, ctx->d_row_cnt, ctx->d_row_off, ctx->d_row_base, ctx->d_tmp_runs,
                    ctx->d_raster, ctx->d_parent, ctx->d_root_ord, ctx->d_cnt_runs, ctx->d_cnt_px, ctx->d_cur_run,
-                   ctx->d_pix_begin, ctx->d_blob_map, ctx->d_info, ctx->d_blobs, ctx->d_blob_frame, ctx->d_runs, ctx->d_pixels, ctx->d_color};
+                   ctx->d_pix_begin, ctx->d_blob_map, ctx->d_info, ctx->d_blobs, ctx->d_blob_frame, ctx->d_runs, ctx->d_pixels, ctx->d_color, ctx->d_bits[0], ctx->d_bits[1]};
     for (void* p : dev) if (p) hipFree(p);
     void* host[] = {ctx->h_info, ctx->h_totals, ctx->h_blobs, ctx->h_runs, ctx->h_pixels, ctx->h_staging, ctx->h_color};
     for (void* p : host) if (p) hipHostFree(p);

@@ -110,6 +110,7 @@ struct trexhip_ctx {
     trexhip_run* h_runs = nullptr;
     uint8_t* h_pixels = nullptr;
     uint8_t* h_staging = nullptr;       // pinned upload buffer
+    uint32_t* d_bits[2] = {nullptr, nullptr};   // 1 bit/pixel masks for the optional morphology [B][H][ceil(W/32)]
     uint8_t* d_color = nullptr;         // BGR/BGRA frames of the colour-input API
     uint8_t* h_color = nullptr;
 
@@ -130,5 +131,6 @@ void stage_begin(trexhip_ctx* ctx, int stage);
 void stage_end(trexhip_ctx* ctx, int stage);
 void net_free(trexhip_ctx* ctx);
 int launch_pending(trexhip_ctx* ctx);
+int launch_morphology(trexhip_ctx* ctx, const uint8_t* d_frames, int n, const uint32_t** result);
 int launch_rethreshold(trexhip_ctx* ctx, int thr, int method, const double* ranges, int n_ranges);
 }

@@ -148,9 +148,10 @@ __global__ __launch_bounds__(256) void k_rows(const uint8_t* __restrict__ frames
                                               uint32_t* __restrict__ frame_ctr,
                                               uint32_t* __restrict__ row_cnt,
                                               uint32_t* __restrict__ row_off,
-                                              uint32_t* __restrict__ tmp_runs) {
+                                              uint32_t* __restrict__ tmp_runs, const uint32_t* __restrict__ bits) {
     const int lane = lane_id();
     const int W = c.W;
+    const int WB = (W + 31) / 32;
     const uint32_t ntask = (uint32_t)c.B * (uint32_t)c.H;
     const uint32_t nwave = gridDim.x * 4u;
     uint32_t task = blockIdx.x * 4u + (threadIdx.x >> 6);
@@ -185,6 +186,21 @@ __global__ __launch_bounds__(256) void k_rows(const uint8_t* __restrict__ frames
             const int x = ch * 1024 + lane * 16;
             uint32_t mm = 0;
             if (x < W) {
+                if (bits) {                       // thresholded + morphed mask computed by morph.hip; still "grey under mask"
+                    const uint16_t* bh = reinterpret_cast<const uint16_t*>(bits + ((size_t)f * c.H + y) * WB);
+                    mm = bh[x >> 4];
+                    if (c.zero_bg) {
+                        const uint32_t w4[4] = {a[ch].x, a[ch].y, a[ch].z, a[ch].w};
+                        uint32_t nz = 0;
+#pragma unroll
+                        for (int q = 0; q < 16; ++q) {
+                            uint32_t px = (w4[q >> 2] >> (8 * (q & 3))) & 0xffu;
+                            if (c.invert) px = 255u - px;
+                            nz |= (uint32_t)(px != 0u) << q;
+                        }
+                        mm &= nz;
+                    }
+                } else
                 mm = (order & 512) ? ((a[ch].x ^ b[ch].x) == 0x12345u) : mask16(a[ch], b[ch], c);
                 if (!ALIGNED && x + 16 > W) mm &= (1u << (W - x)) - 1u;
             }
@@ -943,15 +959,15 @@ __global__ __launch_bounds__(256) void k_gather(const SegCfg c, const int only_p
 // ---------------------------------------------------------------------------------------------
 template <bool ALIGNED>
 static void launch_rows(int nch, dim3 grid, hipStream_t s, const uint8_t* frames, const uint8_t* bg,
-                        const SegCfg& c, int order, uint32_t* ctr, uint32_t* row_cnt, uint32_t* row_off, uint32_t* tmp) {
+                        const SegCfg& c, int order, uint32_t* ctr, uint32_t* row_cnt, uint32_t* row_off, uint32_t* tmp, const uint32_t* bits) {
     switch (nch) {
-        case 1: hipLaunchKernelGGL((k_rows<1, ALIGNED>), grid, dim3(256), 0, s, frames, bg, c, order, ctr, row_cnt, row_off, tmp); break;
-        case 2: hipLaunchKernelGGL((k_rows<2, ALIGNED>), grid, dim3(256), 0, s, frames, bg, c, order, ctr, row_cnt, row_off, tmp); break;
-        case 3: hipLaunchKernelGGL((k_rows<3, ALIGNED>), grid, dim3(256), 0, s, frames, bg, c, order, ctr, row_cnt, row_off, tmp); break;
-        case 4: hipLaunchKernelGGL((k_rows<4, ALIGNED>), grid, dim3(256), 0, s, frames, bg, c, order, ctr, row_cnt, row_off, tmp); break;
+        case 1: hipLaunchKernelGGL((k_rows<1, ALIGNED>), grid, dim3(256), 0, s, frames, bg, c, order, ctr, row_cnt, row_off, tmp, bits); break;
+        case 2: hipLaunchKernelGGL((k_rows<2, ALIGNED>), grid, dim3(256), 0, s, frames, bg, c, order, ctr, row_cnt, row_off, tmp, bits); break;
+        case 3: hipLaunchKernelGGL((k_rows<3, ALIGNED>), grid, dim3(256), 0, s, frames, bg, c, order, ctr, row_cnt, row_off, tmp, bits); break;
+        case 4: hipLaunchKernelGGL((k_rows<4, ALIGNED>), grid, dim3(256), 0, s, frames, bg, c, order, ctr, row_cnt, row_off, tmp, bits); break;
         case 5: case 6:
-                hipLaunchKernelGGL((k_rows<6, ALIGNED>), grid, dim3(256), 0, s, frames, bg, c, order, ctr, row_cnt, row_off, tmp); break;
-        default: hipLaunchKernelGGL((k_rows<8, ALIGNED>), grid, dim3(256), 0, s, frames, bg, c, order, ctr, row_cnt, row_off, tmp); break;
+                hipLaunchKernelGGL((k_rows<6, ALIGNED>), grid, dim3(256), 0, s, frames, bg, c, order, ctr, row_cnt, row_off, tmp, bits); break;
+        default: hipLaunchKernelGGL((k_rows<8, ALIGNED>), grid, dim3(256), 0, s, frames, bg, c, order, ctr, row_cnt, row_off, tmp, bits); break;
     }
 }
 
@@ -968,9 +984,14 @@ int launch_segment(trexhip_ctx* ctx, const uint8_t* d_frames, int n) {
     const dim3 grid_rows(want < (unsigned)ctx->tune_rows_blocks ? want : (unsigned)ctx->tune_rows_blocks);
     const bool aligned = (W % 16 == 0) && ((reinterpret_cast<uintptr_t>(d_frames) & 15) == 0) &&
                          ((reinterpret_cast<uintptr_t>(ctx->d_bg) & 15) == 0);
+    const uint32_t* bits = nullptr;
+    if (ctx->p.use_closing || ctx->p.dilation_size != 0) {
+        int rcm = launch_morphology(ctx, d_frames, n, &bits);
+        if (rcm) return rcm;
+    }
     stage_begin(ctx, TREXHIP_STAGE_ROWS);
-    if (aligned) launch_rows<true>(nch, grid_rows, s, d_frames, ctx->d_bg, c, ctx->tune_rows_order, ctx->d_ctr, ctx->d_row_cnt, ctx->d_row_off, ctx->d_tmp_runs);
-    else         launch_rows<false>(nch, grid_rows, s, d_frames, ctx->d_bg, c, ctx->tune_rows_order, ctx->d_ctr, ctx->d_row_cnt, ctx->d_row_off, ctx->d_tmp_runs);
+    if (aligned) launch_rows<true>(nch, grid_rows, s, d_frames, ctx->d_bg, c, ctx->tune_rows_order, ctx->d_ctr, ctx->d_row_cnt, ctx->d_row_off, ctx->d_tmp_runs, bits);
+    else         launch_rows<false>(nch, grid_rows, s, d_frames, ctx->d_bg, c, ctx->tune_rows_order, ctx->d_ctr, ctx->d_row_cnt, ctx->d_row_off, ctx->d_tmp_runs, bits);
     stage_end(ctx, TREXHIP_STAGE_ROWS);
     static bool attr_done = false;
     if (!attr_done) {
