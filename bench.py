@@ -43,6 +43,8 @@ def main():
     ap.add_argument("--config", default="C4")
     ap.add_argument("--batch", type=int, default=0, help="frames resident per step (default 64, C5: 16)")
     ap.add_argument("--stages", default="all", choices=["all", "segment"])
+    ap.add_argument("--cnn-mode", default="bf16x6", choices=["fp32", "bf16x6", "bf16x3"],
+                    help="arithmetic of conv2/conv3: exact fp32 MFMA or the fp32-equivalent 6-product bf16 split (default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     args = ap.parse_args()
@@ -76,6 +78,7 @@ def main():
     state = weights.synthetic_state(classes, 4242)
     if with_cnn:
         seg.load_weights(weights.pack_blob(state, classes))
+        seg.set_identity_precision({"fp32": 0, "bf16x6": 1, "bf16x3": 2}[args.cnn_mode])
     pool = B * max_blobs
     crops = torch.empty((pool, 80, 80), dtype=torch.uint8, device=dev)
     probs = torch.empty((pool, classes), dtype=torch.float32, device=dev)
@@ -161,7 +164,7 @@ def main():
         "metric": "frames/s end-to-end (segment+CNN-ID), 2048x2048 x100 individuals",
         "value": fps, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "f32" if with_cnn else "u8", "data": "synthetic",
+        "vs_baseline": None, "dtype": ({"fp32": "f32", "bf16x6": "bf16x6-split (fp32-equivalent: 3 bf16 pieces per operand, 6 MFMA products, fp32 accumulate)", "bf16x3": "bf16x3-split"}[args.cnn_mode] if with_cnn else "u8"), "data": "synthetic",
         "config": {"workload": f"{args.config}: {W}x{H} gray, {n_ind} individuals/frame, {B} frames resident per step per GPU, "
                                f"80x80x1 crops, {classes}-way V118_3 (random-init weights)",
                    "stages": "detect(bg-sub+threshold+CCL+filter+gather, tables->host) + crops(none) + identity CNN fp32 + per-blob ID table (all-gathered when N>1) -> rank-0 host"
@@ -177,12 +180,17 @@ def main():
     if with_cnn:
         c3_s = avg_s("CONV3")
         fl = FLOP_PER_CROP_CONV3 * n_blobs
-        out["roofline"] = {"kernel": "k_conv5<64,128,20,20,32> (conv3)", "bound": "mfma", "achieved": fl / c3_s / 1e12 if c3_s else 0.0,
-                           "peak": 157.3, "unit": "TFLOP/s", "frac": fl / c3_s / 157.3e12 if c3_s else 0.0,
-                           "traffic": pmc_traffic("trexhip::k_conv5<64, 128"),
+        nprod = {"fp32": 1, "bf16x6": 6, "bf16x3": 3}[args.cnn_mode]
+        peak = 157.3 if args.cnn_mode == "fp32" else 2500.0
+        kname = "k_conv5<64,128,20,20,32> (conv3, fp32 MFMA)" if args.cnn_mode == "fp32" else f"k_conv5_bf16<64,128,20,20,{nprod}> (conv3, bf16 MFMA x{nprod} per fp32 product)"
+        out["roofline"] = {"kernel": kname, "bound": "mfma", "achieved": fl / c3_s / 1e12 if c3_s else 0.0,
+                           "peak": peak, "unit": "TFLOP/s", "frac": fl / c3_s / (peak * 1e12) if c3_s else 0.0,
+                           "mfma_products_per_algorithmic_product": nprod,
+                           "mfma_issue_frac": nprod * fl / c3_s / (peak * 1e12) if c3_s else 0.0,
+                           "traffic": pmc_traffic("trexhip::k_conv5<64, 128") if args.cnn_mode == "fp32" else None,
                            "traffic_note": "HBM bytes/launch from profiles/r01_pmc_summary.json (FETCH_SIZE x2 + WRITE_SIZE); algorithmic bytes = 0.98 GB (activations in+out)",
                            "avg_launch_us": c3_s * 1e6, "launches": prof["CONV3"][1], "algorithmic_flop_per_launch": fl,
-                           "peak_note": "dense fp32-input MFMA peak (MI355X_MICROARCH.md); the path computes in exact fp32"}
+                           "peak_note": "achieved counts ALGORITHMIC flops (2 per fp32 multiply-add); peak is the dense MFMA peak of the instruction used (fp32: 157.3, bf16: 2500 TFLOP/s, MI355X_MICROARCH.md); in the split modes every algorithmic product costs `mfma_products_per_algorithmic_product` bf16 MFMA products, so the matrix pipe is busy mfma_issue_frac of its peak"}
         cnn_s = avg_s("CNN_ALL")
         out["stage_us"] = {"detect": segall_s * 1e6, "crops": avg_s("CROPS") * 1e6, "conv2": avg_s("CONV2") * 1e6,
                            "conv3": c3_s * 1e6, "cnn_all": cnn_s * 1e6,

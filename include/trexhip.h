@@ -172,6 +172,11 @@ int trexhip_crops_device(trexhip_ctx* ctx, uint8_t* d_crops, int32_t n_blobs, in
  * from a TRex <base>_dict.pth).  BatchNorm is folded and the tensors repacked on load. */
 int trexhip_load_weights(trexhip_ctx* ctx, const void* blob, size_t bytes);
 int trexhip_num_classes(trexhip_ctx* ctx);
+/* arithmetic of the two large convolutions: exact fp32 MFMA, or fp32-equivalent on the bf16 matrix cores (each
+ * operand split into 3 bf16 pieces, 6 piece products per product; default), or the 3-product variant
+ * (~2^-16 relative per product; NOT within the 1e-4 softmax bar in general -- for experiments only) */
+enum { TREXHIP_CNN_FP32 = 0, TREXHIP_CNN_BF16X6 = 1, TREXHIP_CNN_BF16X3 = 2 };
+int trexhip_set_identity_precision(trexhip_ctx* ctx, int32_t mode);
 /* VINetwork::probabilities (ml/VisualIdentification.cpp:440-458) -> predict_numpy
  * (visual_recognition_torch.py:290-352): crops are uint8 NHWC [n][80][80][C] (values 0..255, no
  * scaling), probs is [n][classes] float32 softmax rows.  d_logits may be NULL. */

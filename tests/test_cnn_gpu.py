@@ -18,10 +18,12 @@ def make_net(st, classes):
     return seg
 
 
+@pytest.mark.parametrize("mode", [capi.CNN_FP32, capi.CNN_BF16X6])
 @pytest.mark.parametrize("classes", [8, 100, 256])
-def test_reference_vectors(classes):
+def test_reference_vectors(classes, mode):
     z, st = load_fixture(classes)
     seg = make_net(st, classes)
+    seg.set_identity_precision(mode)
     sizes = sorted(int(k.split("/")[1]) for k in z.files if k.startswith("probs/"))
     for n in sizes:
         crops = weights.synthetic_crops(n, int(z["seed"]) + 1000 + n)
@@ -33,9 +35,11 @@ def test_reference_vectors(classes):
     seg.close()
 
 
-def test_logits_and_device_path_vs_oracle():
+@pytest.mark.parametrize("mode", [capi.CNN_FP32, capi.CNN_BF16X6])
+def test_logits_and_device_path_vs_oracle(mode):
     z, st = load_fixture(100)
     seg = make_net(st, 100)
+    seg.set_identity_precision(mode)
     rng = np.random.default_rng(5)
     crops = rng.integers(0, 256, (130, 80, 80, 1)).astype(np.uint8)      # dense random crops: worst case for summation order
     crops[7] = 0                                                          # an empty crop
@@ -60,4 +64,22 @@ def test_errors():
         seg.probabilities(np.zeros((1, 80, 80, 1), np.uint8))
     with pytest.raises(capi.TrexHipError):
         seg.load_weights(b"\0" * 64)
+    seg.close()
+
+
+def test_precision_modes_error_ladder():
+    """fp32 MFMA and the 6-product bf16 split agree to fp32 rounding; the 3-product split is ~2^-16 per product
+    (reported, not asserted against the bar)."""
+    z, st = load_fixture(100)
+    seg = make_net(st, 100)
+    rng = np.random.default_rng(9)
+    crops = rng.integers(0, 256, (64, 80, 80, 1)).astype(np.uint8)
+    ref, ref_logits = cnn_oracle.predict(st, crops, threads=8)
+    errs = {}
+    for mode in (capi.CNN_FP32, capi.CNN_BF16X6, capi.CNN_BF16X3):
+        seg.set_identity_precision(mode)
+        errs[mode] = float(np.abs(seg.probabilities(crops) - ref).max())
+    print("max |dp| vs oracle: fp32 %.3g  bf16x6 %.3g  bf16x3 %.3g" % (errs[0], errs[1], errs[2]))
+    assert errs[capi.CNN_FP32] <= 1e-4 and errs[capi.CNN_BF16X6] <= 1e-4
+    assert errs[capi.CNN_BF16X6] <= 20 * max(errs[capi.CNN_FP32], 1e-7)
     seg.close()

@@ -26,6 +26,7 @@ INFO_DTYPE = np.dtype([
 ])
 assert BLOB_DTYPE.itemsize == 104 and RUN_DTYPE.itemsize == 8 and INFO_DTYPE.itemsize == 48
 
+CNN_FP32, CNN_BF16X6, CNN_BF16X3 = 0, 1, 2
 STAGE_ROWS, STAGE_SEGMENT_ALL, STAGE_CONV2, STAGE_CONV3, STAGE_CNN_ALL, STAGE_CROPS = 0, 1, 2, 3, 4, 5
 
 
@@ -66,7 +67,7 @@ SYMBOLS = [
     "trexhip_set_stream", "trexhip_set_background", "trexhip_set_background_device", "trexhip_segment_device",
     "trexhip_segment", "trexhip_segment_color", "trexhip_rethreshold_device", "trexhip_fetch_rethreshold", "trexhip_fetch", "trexhip_device_view_get", "trexhip_synchronize",
     "trexhip_profile_enable", "trexhip_profile_read", "trexhip_profile_reset",
-    "trexhip_crops_device", "trexhip_export_id_table_device", "trexhip_load_weights", "trexhip_num_classes", "trexhip_identify_device", "trexhip_identify",
+    "trexhip_crops_device", "trexhip_export_id_table_device", "trexhip_load_weights", "trexhip_set_identity_precision", "trexhip_num_classes", "trexhip_identify_device", "trexhip_identify",
 ]
 
 
@@ -100,6 +101,7 @@ def lib():
         L.trexhip_export_id_table_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_uint32, C.c_void_p, C.c_int32]
         L.trexhip_load_weights.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
         L.trexhip_num_classes.argtypes = [C.c_void_p]
+        L.trexhip_set_identity_precision.argtypes = [C.c_void_p, C.c_int32]
         L.trexhip_identify_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]
         L.trexhip_identify.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]
         _LIB = L
@@ -237,6 +239,10 @@ class Segmenter:
     def load_weights(self, blob: bytes):
         buf = (C.c_uint8 * len(blob)).from_buffer_copy(blob)
         _check(lib().trexhip_load_weights(self._h, buf, len(blob)))
+
+    def set_identity_precision(self, mode):
+        """0 = exact fp32 MFMA, 1 = bf16x6 split (fp32-equivalent), 2 = bf16x3 (experiments)."""
+        _check(lib().trexhip_set_identity_precision(self._h, mode))
 
     def num_classes(self):
         return lib().trexhip_num_classes(self._h)

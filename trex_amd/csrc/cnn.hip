@@ -218,6 +218,169 @@ __global__ __launch_bounds__(512) void k_conv5(const float* __restrict__ in /*[N
 }
 
 // ------------------------------------------------------------------------------------------------
+// the same convolution on the bf16 matrix cores with fp32-equivalent accuracy: every fp32 operand is split
+// into three bf16 pieces x = x1 + x2 + x3 (x1 = bf16(x), x2 = bf16(x - x1), x3 = bf16(x - x1 - x2); 24
+// mantissa bits in total) and a product a*w is formed from the six piece products whose order is >= 2^-16
+// (a1w1, a1w2, a2w1, a1w3, a2w2, a3w1; NTERMS = 3 keeps only the first three).  bf16 x bf16 products are
+// exact in fp32 and the MFMA accumulates in fp32, so what is dropped is ~3 * 2^-24 relative per product --
+// the size of fp32 rounding itself.  v_mfma_f32_32x32x16_bf16 runs at 16x the rate of the fp32 MFMA, so six
+// of them per product are 2.7x faster than v_mfma_f32_32x32x2_f32.
+// Layouts: activations are split while the patch is staged (three patches [pixel][16 ci] bf16, 48-byte pixel
+// stride); weights are pre-split on the host as [ci-chunk][tap][piece][k/8][co][8].
+// ------------------------------------------------------------------------------------------------
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ uint32_t bf16_rne(float x) {
+    uint32_t u = __float_as_uint(x);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return u >> 16;
+}
+__device__ __forceinline__ void split3(float x, uint32_t& p1, uint32_t& p2, uint32_t& p3) {
+    p1 = bf16_rne(x);
+    const float r1 = x - __uint_as_float(p1 << 16);
+    p2 = bf16_rne(r1);
+    const float r2 = r1 - __uint_as_float(p2 << 16);
+    p3 = bf16_rne(r2);
+}
+
+template <int CI, int CO, int S, int ROWS>
+struct ConvGeomB {
+    static constexpr int CIC = 16;
+    static constexpr int PW = S + 4, PH = ROWS + 4;
+    static constexpr int PSTRIDE = 48;                                // bytes per pixel (32 data + 16 pad)
+    static constexpr int PATCH = PH * PW * PSTRIDE;                   // bytes per piece
+    static constexpr int BT = 3 * 2 * CO * 16;                        // bytes per weight tile (3 pieces x 2 k-octets)
+    static constexpr int NPIX = ROWS * S;
+    static constexpr int MT = (NPIX + 31) / 32;
+    static constexpr int NT = CO / 32;
+    static constexpr int WM = 8 / NT;
+    static constexpr int TPW = (MT + WM - 1) / WM;
+    static constexpr int LDS_BYTES = 3 * PATCH + 2 * BT;
+    static constexpr int BPC = S / ROWS;
+};
+
+template <int CI, int CO, int S, int ROWS, int NTERMS>
+__global__ __launch_bounds__(512) void k_conv5_bf16(const float* __restrict__ in /*[N][S][S][CI]*/,
+                                                    const uint4* __restrict__ wp /*[CI/16][25][3][2][CO] x 16 B*/,
+                                                    const float* __restrict__ bias, float* __restrict__ out) {
+    using G = ConvGeomB<CI, CO, S, ROWS>;
+    extern __shared__ __attribute__((aligned(16))) uint8_t ldsb[];
+    uint8_t* patch = ldsb;                       // 3 pieces
+    uint8_t* Bs = ldsb + 3 * G::PATCH;           // 2 buffers
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int j = lane & 31, h = lane >> 5;
+    const int n = wave % G::NT, mg = wave / G::NT;
+    const int crop = blockIdx.x / G::BPC, row0 = (blockIdx.x % G::BPC) * ROWS;
+    constexpr int WR = S / 2;
+
+    int aoff[G::TPW];
+#pragma unroll
+    for (int m = 0; m < G::TPW; ++m) {
+        const int p = (mg + G::WM * m) * 32 + j;
+        int off = 0;
+        if (p < G::NPIX) {
+            const int wi = p >> 2, sub = p & 3;
+            const int wy = wi / WR, wx = wi - wy * WR;
+            off = ((2 * wy + (sub >> 1)) * G::PW + (2 * wx + (sub & 1))) * G::PSTRIDE;
+        }
+        aoff[m] = off + h * 16;
+    }
+    f32x16 acc[G::TPW];
+#pragma unroll
+    for (int m = 0; m < G::TPW; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
+
+    const float* inc = in + (size_t)crop * S * S * CI;
+    constexpr int BV = G::BT / 16;                                      // uint4 per weight tile
+    constexpr int BPT = (BV + 511) / 512;
+    for (int cc = 0; cc < CI / 16; ++cc) {
+        __syncthreads();
+        for (int idx = tid; idx < G::PH * G::PW * 4; idx += 512) {      // 4 float4 per pixel
+            const int q = idx & 3, px = idx >> 2;
+            const int py = px / G::PW, pxx = px - py * G::PW;
+            const int iy = row0 + py - 2, ix = pxx - 2;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (iy >= 0 && iy < S && ix >= 0 && ix < S)
+                v = *reinterpret_cast<const float4*>(inc + ((size_t)iy * S + ix) * CI + cc * 16 + q * 4);
+            uint32_t a1[4], a2[4], a3[4];
+            split3(v.x, a1[0], a2[0], a3[0]); split3(v.y, a1[1], a2[1], a3[1]);
+            split3(v.z, a1[2], a2[2], a3[2]); split3(v.w, a1[3], a2[3], a3[3]);
+            uint8_t* d = patch + px * G::PSTRIDE + q * 8;
+            *reinterpret_cast<uint2*>(d) = make_uint2(a1[0] | (a1[1] << 16), a1[2] | (a1[3] << 16));
+            *reinterpret_cast<uint2*>(d + G::PATCH) = make_uint2(a2[0] | (a2[1] << 16), a2[2] | (a2[3] << 16));
+            *reinterpret_cast<uint2*>(d + 2 * G::PATCH) = make_uint2(a3[0] | (a3[1] << 16), a3[2] | (a3[3] << 16));
+        }
+        const uint4* wsrc = wp + (size_t)cc * 25 * BV;
+        for (int i = tid; i < BV; i += 512) reinterpret_cast<uint4*>(Bs)[i] = wsrc[i];
+        __syncthreads();
+        for (int tap = 0; tap < 25; ++tap) {
+            const int buf = tap & 1;
+            uint4 nb[BPT];
+            if (tap < 24) {
+#pragma unroll
+                for (int u = 0; u < BPT; ++u) { const int i = tid + u * 512; if (i < BV) nb[u] = wsrc[(size_t)(tap + 1) * BV + i]; }
+            }
+            const int tapoff = ((tap / 5) * G::PW + (tap % 5)) * G::PSTRIDE;
+            const uint8_t* bsrc = Bs + buf * G::BT + (h * CO + n * 32 + j) * 16;
+            const bf16x8 b1 = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(bsrc));
+            const bf16x8 b2 = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(bsrc + 2 * CO * 16));
+            const bf16x8 b3 = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(bsrc + 4 * CO * 16));
+            const uint8_t* asrc = patch + tapoff;
+#define LDA(m, piece) __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(asrc + aoff[m] + (piece) * G::PATCH))
+#define MF(a, b, m) acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[m], 0, 0, 0)
+            // two output tiles at a time: their accumulation chains are interleaved so that consecutive MFMAs never
+            // depend on each other (a dependent 32x32x16 chain issues at half rate)
+#pragma unroll
+            for (int m = 0; m + 1 < G::TPW; m += 2) {
+                const bf16x8 p1 = LDA(m, 0), p2 = LDA(m, 1), q1 = LDA(m + 1, 0), q2 = LDA(m + 1, 1);
+                if (NTERMS == 6) {
+                    const bf16x8 p3 = LDA(m, 2), q3 = LDA(m + 1, 2);
+                    MF(p3, b1, m); MF(q3, b1, m + 1);
+                    MF(p2, b2, m); MF(q2, b2, m + 1);
+                    MF(p1, b3, m); MF(q1, b3, m + 1);
+                }
+                MF(p2, b1, m); MF(q2, b1, m + 1);
+                MF(p1, b2, m); MF(q1, b2, m + 1);
+                MF(p1, b1, m); MF(q1, b1, m + 1);
+            }
+            if (G::TPW & 1) {
+                constexpr int m = G::TPW - 1;
+                const bf16x8 p1 = LDA(m, 0), p2 = LDA(m, 1);
+                if (NTERMS == 6) {
+                    const bf16x8 p3 = LDA(m, 2);
+                    MF(p3, b1, m); MF(p2, b2, m); MF(p1, b3, m);
+                }
+                MF(p2, b1, m); MF(p1, b2, m); MF(p1, b1, m);
+            }
+#undef LDA
+#undef MF
+            if (tap < 24) {
+#pragma unroll
+                for (int u = 0; u < BPT; ++u) { const int i = tid + u * 512; if (i < BV) reinterpret_cast<uint4*>(Bs + (buf ^ 1) * G::BT)[i] = nb[u]; }
+            }
+            __syncthreads();
+        }
+    }
+    const int co = n * 32 + j;
+    const float bz = bias[co];
+    float* oc = out + (size_t)crop * WR * WR * CO;
+#pragma unroll
+    for (int m = 0; m < G::TPW; ++m) {
+        const int mt = mg + G::WM * m;
+        if (mt >= G::MT) continue;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int wi = mt * 8 + 2 * g + h;
+            if (wi >= G::NPIX / 4) continue;
+            const float v = fmaxf(fmaxf(acc[m][4 * g], acc[m][4 * g + 1]), fmaxf(acc[m][4 * g + 2], acc[m][4 * g + 3]));
+            const int wy = row0 / 2 + wi / WR, wx = wi % WR;
+            oc[((size_t)wy * WR + wx) * CO + co] = fmaxf(v + bz, 0.f);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // fc1: out[N][128] = act[N][K] * W[K][128] + b     (K = 12800, 100 real outputs)
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_fc1(const float* __restrict__ act, const float* __restrict__ w /*[K][128]*/,
@@ -339,6 +502,7 @@ __global__ __launch_bounds__(256) void k_head(const float* __restrict__ fc1 /*[N
 // ------------------------------------------------------------------------------------------------
 struct Net {
     int classes = 0, W = 0, H = 0, CH = 0, max_crops = 0;
+    uint4 *w2s = nullptr, *w3s = nullptr;      // bf16-split conv weights
     float *w1 = nullptr, *b1 = nullptr, *w2 = nullptr, *b2 = nullptr, *w3 = nullptr, *b3 = nullptr;
     float *wf1 = nullptr, *bf1 = nullptr, *lng = nullptr, *lnb = nullptr, *wf2t = nullptr, *bf2 = nullptr;
     float *act1 = nullptr, *act2 = nullptr, *act3 = nullptr, *fc1 = nullptr, *probs = nullptr, *logits = nullptr;
@@ -351,6 +515,8 @@ static void free_net(Net* n) {
     float* d[] = {n->w1, n->b1, n->w2, n->b2, n->w3, n->b3, n->wf1, n->bf1, n->lng, n->lnb, n->wf2t, n->bf2,
                   n->act1, n->act2, n->act3, n->fc1, n->probs, n->logits};
     for (float* p : d) if (p) (void)hipFree(p);
+    if (n->w2s) (void)hipFree(n->w2s);
+    if (n->w3s) (void)hipFree(n->w3s);
     if (n->crops) (void)hipFree(n->crops);
     if (n->h_probs) (void)hipHostFree(n->h_probs);
     delete n;
@@ -376,6 +542,36 @@ static void fold_conv(const float* w, const float* b, const float* g, const floa
                 wp[(((size_t)cc * 25 + tap) * CIC + k) * CO + co] = (float)((double)w[((size_t)co * CI + ci) * 25 + tap] * s);
             }
     }
+}
+
+static uint16_t h_bf16_rne(float x) {
+    uint32_t u; std::memcpy(&u, &x, 4);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
+static float h_bf16_to_f(uint16_t b) { uint32_t u = (uint32_t)b << 16; float f; std::memcpy(&f, &u, 4); return f; }
+
+// packed fp32 conv weights [cc][25][CIC][CO] (CIC = 16 here) -> three bf16 pieces laid out [cc][tap][piece][k/8][co][8]
+static int upload_split(uint4** dst, const std::vector<float>& wp, int CI, int CO) {
+    const int ncc = CI / 16;
+    std::vector<uint16_t> o((size_t)ncc * 25 * 3 * 2 * CO * 8);
+    for (int cc = 0; cc < ncc; ++cc)
+        for (int tap = 0; tap < 25; ++tap)
+            for (int k = 0; k < 16; ++k)
+                for (int co = 0; co < CO; ++co) {
+                    const float x = wp[(((size_t)cc * 25 + tap) * 16 + k) * CO + co];
+                    const uint16_t p1 = h_bf16_rne(x);
+                    const float r1 = x - h_bf16_to_f(p1);
+                    const uint16_t p2 = h_bf16_rne(r1);
+                    const float r2 = r1 - h_bf16_to_f(p2);
+                    const uint16_t p3 = h_bf16_rne(r2);
+                    const uint16_t pc[3] = {p1, p2, p3};
+                    for (int s = 0; s < 3; ++s)
+                        o[(((((size_t)cc * 25 + tap) * 3 + s) * 2 + k / 8) * CO + co) * 8 + (k & 7)] = pc[s];
+                }
+    TH_CHECK_HIP(hipMalloc(reinterpret_cast<void**>(dst), o.size() * 2));
+    TH_CHECK_HIP(hipMemcpy(*dst, o.data(), o.size() * 2, hipMemcpyHostToDevice));
+    return TREXHIP_OK;
 }
 
 int net_load(trexhip_ctx* ctx, const void* blob, size_t bytes) {
@@ -420,6 +616,9 @@ int net_load(trexhip_ctx* ctx, const void* blob, size_t bytes) {
     }
     fold_conv(c2w, c2b, g2, be2, m2, v2, 64, 16, 16, wp, bias);
     TRY(upload(&net->w2, wp)); TRY(upload(&net->b2, bias));
+    TRY(upload_split(&net->w2s, wp, 16, 64));
+    fold_conv(c3w, c3b, g3, be3, m3, v3, 128, 64, 16, wp, bias);       // 16-channel chunks for the bf16 path
+    TRY(upload_split(&net->w3s, wp, 64, 128));
     fold_conv(c3w, c3b, g3, be3, m3, v3, 128, 64, 32, wp, bias);
     TRY(upload(&net->w3, wp)); TRY(upload(&net->b3, bias));
     {   // fc1 [100][c*100+h*10+w] -> [(h*10+w)*128 + c][128 (o padded)]
@@ -479,6 +678,10 @@ int net_forward(trexhip_ctx* ctx, const uint8_t* d_crops, int n, float* d_probs,
                                          hipFuncAttributeMaxDynamicSharedMemorySize, G2::LDS_BYTES));
         TH_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv5<64, 128, 20, 20, 32>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, G3::LDS_BYTES));
+        TH_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv5_bf16<16, 64, 40, 10, 6>), hipFuncAttributeMaxDynamicSharedMemorySize, ConvGeomB<16, 64, 40, 10>::LDS_BYTES));
+        TH_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv5_bf16<16, 64, 40, 10, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, ConvGeomB<16, 64, 40, 10>::LDS_BYTES));
+        TH_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv5_bf16<64, 128, 20, 20, 6>), hipFuncAttributeMaxDynamicSharedMemorySize, ConvGeomB<64, 128, 20, 20>::LDS_BYTES));
+        TH_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv5_bf16<64, 128, 20, 20, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, ConvGeomB<64, 128, 20, 20>::LDS_BYTES));
         attr_done = true;
     }
     stage_begin(ctx, TREXHIP_STAGE_CNN_ALL);
@@ -486,11 +689,24 @@ int net_forward(trexhip_ctx* ctx, const uint8_t* d_crops, int n, float* d_probs,
     const size_t lds1 = ((size_t)net->CH * (S + 4) * (S + 4) + (size_t)net->CH * 25 * 16) * 4;
     if (net->CH == 1) hipLaunchKernelGGL((k_conv1<1>), dim3(n), dim3(256), lds1, s, d_crops, net->w1, net->b1, net->act1, S);
     else              hipLaunchKernelGGL((k_conv1<3>), dim3(n), dim3(256), lds1, s, d_crops, net->w1, net->b1, net->act1, S);
+    using B2 = ConvGeomB<16, 64, 40, 10>;
+    using B3 = ConvGeomB<64, 128, 20, 20>;
+    const int mode = ctx->cnn_mode;
     stage_begin(ctx, TREXHIP_STAGE_CONV2);
-    hipLaunchKernelGGL((k_conv5<16, 64, 40, 20, 16>), dim3(n * G2::BPC), dim3(512), G2::LDS_BYTES, s, net->act1, net->w2, net->b2, net->act2);
+    if (mode == TREXHIP_CNN_FP32)
+        hipLaunchKernelGGL((k_conv5<16, 64, 40, 20, 16>), dim3(n * G2::BPC), dim3(512), G2::LDS_BYTES, s, net->act1, net->w2, net->b2, net->act2);
+    else if (mode == TREXHIP_CNN_BF16X6)
+        hipLaunchKernelGGL((k_conv5_bf16<16, 64, 40, 10, 6>), dim3(n * B2::BPC), dim3(512), B2::LDS_BYTES, s, net->act1, net->w2s, net->b2, net->act2);
+    else
+        hipLaunchKernelGGL((k_conv5_bf16<16, 64, 40, 10, 3>), dim3(n * B2::BPC), dim3(512), B2::LDS_BYTES, s, net->act1, net->w2s, net->b2, net->act2);
     stage_end(ctx, TREXHIP_STAGE_CONV2);
     stage_begin(ctx, TREXHIP_STAGE_CONV3);
-    hipLaunchKernelGGL((k_conv5<64, 128, 20, 20, 32>), dim3(n * G3::BPC), dim3(512), G3::LDS_BYTES, s, net->act2, net->w3, net->b3, net->act3);
+    if (mode == TREXHIP_CNN_FP32)
+        hipLaunchKernelGGL((k_conv5<64, 128, 20, 20, 32>), dim3(n * G3::BPC), dim3(512), G3::LDS_BYTES, s, net->act2, net->w3, net->b3, net->act3);
+    else if (mode == TREXHIP_CNN_BF16X6)
+        hipLaunchKernelGGL((k_conv5_bf16<64, 128, 20, 20, 6>), dim3(n * B3::BPC), dim3(512), B3::LDS_BYTES, s, net->act2, net->w3s, net->b3, net->act3);
+    else
+        hipLaunchKernelGGL((k_conv5_bf16<64, 128, 20, 20, 3>), dim3(n * B3::BPC), dim3(512), B3::LDS_BYTES, s, net->act2, net->w3s, net->b3, net->act3);
     stage_end(ctx, TREXHIP_STAGE_CONV3);
     hipLaunchKernelGGL(k_fc1, dim3((n + 31) / 32), dim3(256), 0, s, net->act3, net->wf1, net->bf1, net->fc1, n, 12800);
     hipLaunchKernelGGL(k_head, dim3((n + 3) / 4), dim3(256), 0, s, net->fc1, net->lng, net->lnb, net->wf2t, net->bf2,
@@ -538,6 +754,12 @@ int trexhip_identify(trexhip_ctx* ctx, const uint8_t* crops, int32_t n, float* p
     if (rc) return rc;
     TH_CHECK_HIP(hipMemcpyAsync(probs, net->probs, (size_t)n * net->classes * 4, hipMemcpyDeviceToHost, ctx->stream));
     TH_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+    return TREXHIP_OK;
+}
+
+int trexhip_set_identity_precision(trexhip_ctx* ctx, int32_t mode) {
+    if (!ctx || mode < 0 || mode > 2) { set_error("trexhip_set_identity_precision: mode must be TREXHIP_CNN_FP32 / _BF16X6 / _BF16X3"); return TREXHIP_E_INVALID; }
+    ctx->cnn_mode = mode;
     return TREXHIP_OK;
 }
 

@@ -116,6 +116,7 @@ struct trexhip_ctx {
 
     void* net = nullptr;                // trexhip::Net (cnn.hip)
     trexhip::Pass2 pass2;
+    int cnn_mode = 0;                   // TREXHIP_CNN_*
 
     bool profiling = false;
     // tuning knobs (env TREXHIP_ROWS_ORDER / TREXHIP_ROWS_BLOCKS override the defaults)
