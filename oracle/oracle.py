@@ -36,6 +36,24 @@ class Params(C.Structure):
     ]
 
 
+class PostureParams(C.Structure):
+    """Settings read by posture::calculate_posture / Outline (core/default_config.cpp:888-898, defaults below)."""
+    _fields_ = [("outline_resample", C.c_float), ("outline_smooth_samples", C.c_int32), ("outline_smooth_step", C.c_int32),
+                ("outline_approximate", C.c_int32), ("outline_curvature_range_ratio", C.c_float),
+                ("midline_walk_offset", C.c_float), ("max_points", C.c_int32)]
+
+
+class PostureInfo(C.Structure):
+    _fields_ = [("status", C.c_int32), ("n_outline", C.c_int32), ("n_segments", C.c_int32), ("tail_index", C.c_int32),
+                ("head_index", C.c_int32), ("n_traced", C.c_int32)]
+
+
+def posture_params(outline_resample=1.0, outline_smooth_samples=4, outline_smooth_step=1, outline_approximate=3,
+                   outline_curvature_range_ratio=0.03, midline_walk_offset=0.025, max_points=2048):
+    return PostureParams(outline_resample, outline_smooth_samples, outline_smooth_step, outline_approximate,
+                         outline_curvature_range_ratio, midline_walk_offset, max_points)
+
+
 def make_params(width, height, threshold=15, threshold_maximum=255, enable_difference=1,
                 absolute_difference=1, image_invert=0, inclusive=0, zero_is_background=1,
                 connectivity=8, dilation_size=0, use_closing=0, closing_size=3,
@@ -57,7 +75,7 @@ def make_params(width, height, threshold=15, threshold_maximum=255, enable_diffe
 
 def build(force=False):
     so = os.path.join(_HERE, "liboracle.so")
-    src = [os.path.join(_HERE, f) for f in ("trex_oracle.c", "trex_oracle.h")]
+    src = [os.path.join(_HERE, f) for f in ("trex_oracle.c", "trex_posture.c", "trex_oracle.h")]
     if force or not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in src if os.path.exists(s)):
         subprocess.check_call(["make", "-C", _HERE, "-s", "-B"])
     return so
@@ -89,6 +107,10 @@ def lib():
         L.oracle_rethreshold_frame.restype = C.c_void_p
         L.oracle_rethreshold_frame.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                                C.c_int32, C.c_void_p, C.c_int32, C.c_double, C.c_int32]
+        L.oracle_posture.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.POINTER(PostureParams), C.c_void_p, C.c_void_p,
+                                     C.POINTER(PostureInfo)]
+        L.oracle_outline_resample.argtypes = [C.c_void_p, C.c_int32, C.c_float, C.c_void_p, C.c_int32]
+        L.oracle_trace_outline.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_int32]
         L.oracle_bid.restype = C.c_uint32
         L.oracle_bid.argtypes = [C.c_uint32] * 4
         del u8p
@@ -220,3 +242,30 @@ def rethreshold_frame(frame, bg, params, method, threshold, size_ranges=(), inve
                                     params.cm_per_pixel, 1 if invert else 0)
     L.oracle_frame_free(h)
     return _take_frame(h2)
+
+
+def posture(runs, origin, pp=None):
+    """posture::calculate_posture for one blob given its lines: -> (info dict, outline [n,2] f32, segments [m,4] f32
+    (pos.x, pos.y, height, l_length)); coordinates relative to `origin` (the blob's bounds().pos())."""
+    pp = pp or posture_params()
+    runs = np.ascontiguousarray(runs, RUN_DTYPE)
+    out = np.zeros((pp.max_points, 2), np.float32)
+    seg = np.zeros((pp.max_points, 4), np.float32)
+    info = PostureInfo()
+    lib().oracle_posture(_ptr(runs), len(runs), int(origin[0]), int(origin[1]), C.byref(pp), _ptr(out), _ptr(seg), C.byref(info))
+    d = {k: getattr(info, k) for k, _ in PostureInfo._fields_}
+    return d, out[:info.n_outline].copy(), seg[:info.n_segments].copy()
+
+
+def outline_resample(points, distance, cap=100000):
+    pts = np.ascontiguousarray(points, np.float32)
+    out = np.zeros((cap, 2), np.float32)
+    n = lib().oracle_outline_resample(_ptr(pts), len(pts), distance, _ptr(out), cap)
+    return out[:n].copy()
+
+
+def trace_outline(runs, origin=(0, 0), cap=100000):
+    runs = np.ascontiguousarray(runs, RUN_DTYPE)
+    out = np.zeros((cap, 2), np.float32)
+    n = lib().oracle_trace_outline(_ptr(runs), len(runs), int(origin[0]), int(origin[1]), _ptr(out), cap)
+    return out[:n].copy()

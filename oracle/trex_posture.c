@@ -1,0 +1,268 @@
+/*
+ * trex_posture.c -- CPU restatement of posture::calculate_posture for ONE blob (TEST INFRASTRUCTURE ONLY).
+ *
+ * Follows Application/src/tracker/tracking/Posture.cpp:305-399 and Outline.cpp:
+ *   outline of the (thresholded) blob   pixel::find_outer_points          [commons, NOT IN TREE]
+ *   Outline::resample                   Outline.cpp:724-766               in tree, pinned by Tests/test_outlines.cpp:53-95
+ *   smooth_outline / Outline::smooth    Outline.cpp:330-378,380-..        in tree
+ *   Outline::offset_to_middle           Outline.cpp:454-718               in tree, but built on periodic::* [commons, NOT IN TREE]:
+ *       differentiate_and_test_clockwise, eft, ieft, curvature, find_peaks
+ *   Outline::calculate_midline          Outline.cpp:768-868               in tree (two-pointer walk)
+ *
+ * PARITY STATUS: resample / smooth / the midline walk follow in-tree source line by line.  The pieces that live in
+ * the un-vendored commons are restated from their published algorithms and are UNPINNED:
+ *   - outline = outer boundary of the pixel set walked along pixel edges clockwise (image coordinates), emitting
+ *     every pixel-corner and every edge midpoint (half-pixel lattice), 8-connected turns; first vertex = top-left
+ *     corner of the first pixel of the first line;
+ *   - elliptic Fourier transform = Kuhl & Giardina (1982) in the form used by the pyefd package, order
+ *     `outline_approximate`, inverse sampled at N uniform parameters around `center` (mean of the points);
+ *   - curvature = Menger curvature over i-r, i, i+r (the formula left commented out in Outline.cpp:305-312), absolute;
+ *   - peaks = strict/plateau-start local maxima of that curvature; tail = highest peak (peak_mode pointy,
+ *     Outline.cpp:624-625), head = peak farthest from the tail in circular index distance (:668-681).
+ * All arithmetic in float (Float2_t), no FMA contraction (compiled with -ffp-contract=off).
+ */
+#include "trex_oracle.h"
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+typedef struct { float x, y; } v2;
+
+/* ---- blob membership through a row table -------------------------------------------------------- */
+typedef struct { const oracle_run* runs; int n; int y0, y1; int* row_start; } rowtab;
+
+static int in_blob(const rowtab* t, int x, int y) {
+    if (y < t->y0 || y > t->y1) return 0;
+    for (int i = t->row_start[y - t->y0]; i < t->row_start[y - t->y0 + 1]; ++i)
+        if (x >= t->runs[i].x0 && x <= t->runs[i].x1) return 1;
+    return 0;
+}
+
+/* outer boundary on the half-pixel lattice; returns number of points or -1 if cap is exceeded */
+static int trace_outline(const oracle_run* runs, int n_runs, int ox, int oy, v2* out, int cap) {
+    rowtab t; t.runs = runs; t.n = n_runs; t.y0 = runs[0].y; t.y1 = runs[n_runs - 1].y;
+    const int rows = t.y1 - t.y0 + 1;
+    t.row_start = (int*)malloc((size_t)(rows + 1) * sizeof(int));
+    int r = 0;
+    for (int y = 0; y < rows; ++y) { t.row_start[y] = r; while (r < n_runs && runs[r].y == t.y0 + y) ++r; }
+    t.row_start[rows] = n_runs;
+    /* doubled coordinates: pixel (x,y) has corners (2x+-1, 2y+-1) */
+    const int sx = 2 * runs[0].x0 - 1, sy = 2 * runs[0].y - 1;
+    int vx = sx, vy = sy, dx = 1, dy = 0, n = 0;
+    do {
+        if (n + 2 > cap) { free(t.row_start); return -1; }
+        out[n].x = 0.5f * (float)(vx - 2 * ox); out[n].y = 0.5f * (float)(vy - 2 * oy); ++n;                 /* corner   */
+        out[n].x = 0.5f * (float)(vx + dx - 2 * ox); out[n].y = 0.5f * (float)(vy + dy - 2 * oy); ++n;       /* midpoint */
+        vx += 2 * dx; vy += 2 * dy;
+        const int lx = dy, ly = -dx, rx = -dy, ry = dx;          /* left / right of the walking direction (y points down) */
+        const int plx = (vx + dx + lx) / 2, ply = (vy + dy + ly) / 2;
+        const int prx = (vx + dx + rx) / 2, pry = (vy + dy + ry) / 2;
+        if (in_blob(&t, plx, ply)) { dx = lx; dy = ly; }         /* diagonal neighbours count: 8-connectivity */
+        else if (in_blob(&t, prx, pry)) { /* straight on */ }
+        else { dx = rx; dy = ry; }
+    } while (!(vx == sx && vy == sy && dx == 1 && dy == 0));
+    free(t.row_start);
+    return n;
+}
+
+/* ---- Outline::resample (Outline.cpp:724-766) ------------------------------------------------------ */
+int oracle_outline_resample(const float* pts_xy, int L, float resampling_distance, float* out_xy, int cap) {
+    if (resampling_distance <= 0 || L <= 1) { memcpy(out_xy, pts_xy, (size_t)L * 2 * sizeof(float)); return L; }
+    const v2* p = (const v2*)pts_xy; v2* o = (v2*)out_xy;
+    float walked = 0.0f; int n = 0;
+    for (int i = 0; i < L; ++i) {
+        int i1 = i + 1; if (i1 >= L) i1 -= L;
+        const v2 pt0 = p[i], pt1 = p[i1];
+        const v2 line = { pt1.x - pt0.x, pt1.y - pt0.y };
+        const float len = sqrtf(line.x * line.x + line.y * line.y);
+        walked += len;
+        const float percent = len / resampling_distance;
+        float walked_percent = walked / resampling_distance;
+        int offset = 0;
+        while (walked_percent >= 1.0) {
+            const float tt = (float)((double)offset * 1.0 / (double)percent);
+            if (n >= cap) return -1;
+            o[n].x = pt0.x + line.x * tt; o[n].y = pt0.y + line.y * tt; ++n;
+            offset++;
+            walked -= resampling_distance;
+            walked_percent -= 1.0f;
+        }
+    }
+    return n;
+}
+
+/* ---- smooth_outline (Outline.cpp:330-378) ----------------------------------------------------------- */
+static int smooth_outline(const v2* p, int L, int range, int step, v2* out) {
+    if (!(L > range)) return 0;
+    const float step_row = (float)range * (float)step;
+    float w[64]; int nw = 0; float sum = 0;
+    for (int i = (int)-step_row; i <= step_row; i += step) { const float val = (step_row - fabsf((float)i)) / step_row; sum += val; w[nw++] = val; }
+    for (int i = 0; i < nw; ++i) w[i] /= sum;
+    for (int i = 0; i < L; ++i) {
+        v2 pt = {0, 0}; int s = 0;
+        for (long j = (long)((float)i - step_row); j <= (float)i + step_row; j += step) {
+            long idx = j; while (idx < 0) idx += L; while (idx >= L) idx -= L;
+            pt.x += p[idx].x * w[s]; pt.y += p[idx].y * w[s]; ++s;
+        }
+        out[i] = pt;
+    }
+    return 1;
+}
+
+/* ---- periodic::* restatements (unpinned, see header) ---------------------------------------------- */
+static void eft_ieft(const v2* p, int N, int order, v2 center, v2* out) {
+    float* t = (float*)malloc((size_t)(N + 1) * sizeof(float));
+    t[0] = 0;
+    for (int i = 0; i < N; ++i) {
+        const v2 q = p[(i + 1) % N];
+        const float dx = q.x - p[i].x, dy = q.y - p[i].y;
+        t[i + 1] = t[i] + sqrtf(dx * dx + dy * dy);
+    }
+    const float T = t[N];
+    float a[16], b[16], c[16], d[16];
+    const float PI = 3.14159265358979323846f;
+    for (int n = 1; n <= order; ++n) {
+        float sa = 0, sb = 0, sc = 0, sd = 0;
+        for (int i = 0; i < N; ++i) {
+            const v2 q = p[(i + 1) % N];
+            const float dx = q.x - p[i].x, dy = q.y - p[i].y;
+            const float dt = t[i + 1] - t[i];
+            if (dt <= 0) continue;
+            const float ph1 = 2.0f * PI * (float)n * t[i + 1] / T, ph0 = 2.0f * PI * (float)n * t[i] / T;
+            const float dc = cosf(ph1) - cosf(ph0), ds = sinf(ph1) - sinf(ph0);
+            sa += dx / dt * dc; sb += dx / dt * ds; sc += dy / dt * dc; sd += dy / dt * ds;
+        }
+        const float k = T / (2.0f * (float)(n * n) * PI * PI);
+        a[n] = k * sa; b[n] = k * sb; c[n] = k * sc; d[n] = k * sd;
+    }
+    for (int k = 0; k < N; ++k) {
+        const float tt = (float)k / (float)N;
+        float x = center.x, y = center.y;
+        for (int n = 1; n <= order; ++n) {
+            const float ph = 2.0f * PI * (float)n * tt;
+            const float cs = cosf(ph), sn = sinf(ph);
+            x += a[n] * cs + b[n] * sn; y += c[n] * cs + d[n] * sn;
+        }
+        out[k].x = x; out[k].y = y;
+    }
+    free(t);
+}
+
+static void curvature_abs(const v2* p, int N, int r, float* out) {
+    for (int i = 0; i < N; ++i) {
+        const v2 p1 = p[((i - r) % N + N) % N], p2 = p[i], p3 = p[(i + r) % N];
+        const float cr = (p2.x - p1.x) * (p3.y - p2.y) - (p2.y - p1.y) * (p3.x - p2.x);
+        const float d12 = (p2.x - p1.x) * (p2.x - p1.x) + (p2.y - p1.y) * (p2.y - p1.y);
+        const float d23 = (p3.x - p2.x) * (p3.x - p2.x) + (p3.y - p2.y) * (p3.y - p2.y);
+        const float d13 = (p3.x - p1.x) * (p3.x - p1.x) + (p3.y - p1.y) * (p3.y - p1.y);
+        const float den = sqrtf(d12 * d23 * d13);
+        out[i] = den > 0 ? fabsf(2.0f * cr / den) : 0.0f;
+    }
+}
+
+typedef struct oracle_posture_params {
+    float outline_resample; int32_t outline_smooth_samples, outline_smooth_step, outline_approximate;
+    float outline_curvature_range_ratio, midline_walk_offset; int32_t max_points;
+} oracle_posture_params;
+typedef struct oracle_posture_info { int32_t status, n_outline, n_segments, tail_index, head_index, n_traced; } oracle_posture_info;
+
+/* status: 0 ok, 1 empty blob/outline, 2 capacity, 3 no curvature peak, 4 too few midline segments */
+int oracle_posture(const oracle_run* runs, int32_t n_runs, int32_t origin_x, int32_t origin_y, const oracle_posture_params* P,
+                   float* outline_xy, float* segments /* pos.x pos.y height l_length */, oracle_posture_info* info) {
+    memset(info, 0, sizeof(*info));
+    if (n_runs <= 0) { info->status = 1; return 1; }
+    const int cap = P->max_points;
+    v2* A = (v2*)malloc((size_t)cap * sizeof(v2)); v2* B = (v2*)malloc((size_t)cap * sizeof(v2));
+    float* curv = (float*)malloc((size_t)cap * sizeof(float));
+    int rc = 0;
+    int n = trace_outline(runs, n_runs, origin_x, origin_y, A, cap);
+    if (n < 0) { rc = 2; goto done; }
+    info->n_traced = n;
+    n = oracle_outline_resample((float*)A, n, P->outline_resample, (float*)B, cap);          /* Posture.cpp:355 */
+    if (n < 0) { rc = 2; goto done; }
+    if (n == 0) { rc = 1; goto done; }
+    /* Outline::calculate_midline (Outline.cpp:768-868) */
+    v2* pts = B; v2* other = A;
+    if (P->outline_smooth_samples > 0 && smooth_outline(pts, n, P->outline_smooth_samples, P->outline_smooth_step, other)) { v2* t = pts; pts = other; other = t; }
+    {   /* offset_to_middle (Outline.cpp:454-718) */
+        float sum = 0;                                                              /* clockwise test (shoelace, y down) */
+        for (int i = 0; i < n; ++i) { const v2 q = pts[(i + 1) % n]; sum += pts[i].x * q.y - q.x * pts[i].y; }
+        if (sum < 0) for (int i = 0; i < n / 2; ++i) { v2 t = pts[i]; pts[i] = pts[n - 1 - i]; pts[n - 1 - i] = t; }
+        if (P->outline_approximate > 0) {
+            v2 center = {0, 0};
+            for (int i = 0; i < n; ++i) { center.x += pts[i].x; center.y += pts[i].y; }
+            center.x /= (float)n; center.y /= (float)n;
+            eft_ieft(pts, n, P->outline_approximate, center, other);
+            v2* t = pts; pts = other; other = t;
+        }
+        int r = (int)(P->outline_curvature_range_ratio * (float)n); if (r < 1) r = 1;
+        curvature_abs(pts, n, r, curv);
+        int tail = -1; float best = -1;
+        for (int i = 0; i < n; ++i) {
+            const float c0 = curv[(i - 1 + n) % n], c1 = curv[i], c2 = curv[(i + 1) % n];
+            if (c1 > c0 && c1 >= c2 && c1 > best) { best = c1; tail = i; }
+        }
+        if (tail < 0) { rc = 3; goto done; }
+        int head = -1; float maxd = 0;
+        for (int i = 0; i < n; ++i) {
+            const float c0 = curv[(i - 1 + n) % n], c1 = curv[i], c2 = curv[(i + 1) % n];
+            if (!(c1 > c0 && c1 >= c2)) continue;
+            float dd;
+            if (i >= tail) dd = fminf(fabsf((float)(i - tail)), fabsf((float)(i - tail - n)));
+            else dd = fminf(fabsf((float)(tail - i)), fabsf((float)(tail - i - n)));
+            if (dd > maxd) { maxd = dd; head = i; }
+        }
+        /* rotate so that the tail is point 0 (Outline.cpp:707) */
+        for (int i = 0; i < n; ++i) other[i] = pts[(i + tail) % n];
+        { v2* t = pts; pts = other; other = t; }
+        info->tail_index = 0;
+        info->head_index = head < 0 ? -1 : ((head - tail) % n + n) % n;
+    }
+    memcpy(outline_xy, pts, (size_t)n * sizeof(v2));
+    info->n_outline = n;
+    if (n <= 1) { rc = 1; goto done; }
+    {   /* the two-pointer walk (Outline.cpp:790-857) */
+        const int L = n;
+        int idx_r = 1, idx_l = -1, ns = 0;
+        float mo = P->midline_walk_offset * (float)L; if (mo < 3.0f) mo = 3.0f;
+        const int max_offset = (int)mo;
+        while (idx_r < L + idx_l) {
+            v2 pt_r = {0, 0}; v2 pt_l = pts[L + idx_l];
+            float min_d = 3.402823466e38f; int min_idx = -1;
+            for (int i = 0; i < max_offset; ++i) {
+                if (idx_r + i >= L) break;
+                const v2 pt = pts[idx_r + i];
+                const float dx = pt.x - pt_l.x, dy = pt.y - pt_l.y, len = sqrtf(dx * dx + dy * dy);
+                if (len < min_d) { min_d = len; min_idx = idx_r + i; }
+            }
+            if (min_idx != -1) { pt_r = pts[min_idx]; idx_r = min_idx; }
+            min_d = 3.402823466e38f; min_idx = 1;
+            for (int i = 0; i < max_offset; ++i) {
+                if (idx_l - i <= -L) break;
+                const v2 pt = pts[L + idx_l - i];
+                const float dx = pt_r.x - pt.x, dy = pt_r.y - pt.y, len = sqrtf(dx * dx + dy * dy);
+                if (len < min_d) { min_d = len; min_idx = idx_l - i; }
+            }
+            if (min_idx != 1) { pt_l = pts[L + min_idx]; idx_l = min_idx; }
+            const float lx = pt_r.x - pt_l.x, ly = pt_r.y - pt_l.y;
+            const v2 m = { pt_l.x + lx * 0.5f, pt_l.y + ly * 0.5f };
+            segments[4 * ns + 0] = m.x; segments[4 * ns + 1] = m.y;
+            segments[4 * ns + 2] = sqrtf(lx * lx + ly * ly);
+            segments[4 * ns + 3] = sqrtf((m.x - pt_l.x) * (m.x - pt_l.x) + (m.y - pt_l.y) * (m.y - pt_l.y));
+            ++ns;
+            idx_r++; idx_l--;
+        }
+        info->n_segments = ns;
+        if (ns <= 2) rc = 4;
+    }
+done:
+    info->status = rc;
+    free(A); free(B); free(curv);
+    return rc;
+}
+
+/* outline tracing alone (tests) */
+int oracle_trace_outline(const oracle_run* runs, int32_t n_runs, int32_t ox, int32_t oy, float* out_xy, int32_t cap) {
+    if (n_runs <= 0) return 0;
+    return trace_outline(runs, n_runs, ox, oy, (v2*)out_xy, cap);
+}
