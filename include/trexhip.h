@@ -157,6 +157,31 @@ int trexhip_synchronize(trexhip_ctx* ctx);
 int trexhip_rethreshold_device(trexhip_ctx* ctx, int32_t threshold, int32_t method, const double* size_ranges, int32_t n_ranges);
 int trexhip_fetch_rethreshold(trexhip_ctx* ctx, trexhip_batch_result* out);
 
+/* ---- posture (outline -> midline) -----------------------------------------------------------------
+ * posture::calculate_posture (tracking/Posture.cpp:305-399) for every blob of a table of the last batch
+ * (table 0 = detect blobs, 1 = re-thresholded sub-blobs, i.e. the caller picks track_posture_threshold through
+ * trexhip_rethreshold_device; the reference's retry loop "threshold += 2 until a midline is found" is the caller's:
+ * call again with a higher threshold for the blobs whose status is not 0).
+ * Outputs (caller-owned device memory, pooled order like trexhip_fetch):
+ *   outline  [n_blobs][max_points] float2   resampled, smoothed, EFT-approximated outline rotated so that point 0 is
+ *                                           the tail (what Outline holds after calculate_midline), relative to the
+ *                                           blob's bounds().pos()
+ *   segments [n_blobs][max_points/2+1] float4 = MidlineSegment{pos.x, pos.y, height, l_length} (Outline.h:241-250)
+ *   info     [n_blobs] status 0 ok / 1 empty / 2 capacity / 3 no curvature peak / 4 too few midline segments */
+typedef struct trexhip_posture_params {
+    float   outline_resample;               /* core/default_config.cpp:898  (1)    */
+    int32_t outline_smooth_samples;         /* :890 (4)                            */
+    int32_t outline_smooth_step;            /* :889 (1)                            */
+    int32_t outline_approximate;            /* :888 (3)                            */
+    float   outline_curvature_range_ratio;  /* :891 (0.03)                         */
+    float   midline_walk_offset;            /* :892 (0.025)                        */
+    int32_t max_points;                     /* capacity per blob, 8..1024          */
+} trexhip_posture_params;
+typedef struct trexhip_posture_info { int32_t status, n_outline, n_segments, tail_index, head_index, n_traced, reserved[2]; } trexhip_posture_info;
+void trexhip_default_posture_params(trexhip_posture_params* p);
+int trexhip_posture_device(trexhip_ctx* ctx, int32_t table, const trexhip_posture_params* pp, int32_t n_blobs,
+                           float* d_outline, float* d_segments, trexhip_posture_info* d_info);
+
 /* ---- crops ------------------------------------------------------------------------------------
  * constraints::diff_image (tracking/FilterCache.cpp:265-294): one out_w x out_h uint8 crop per blob of the
  * last segmented batch, pooled order (blob i of trexhip_fetch == crop i).  n_blobs = total_blobs of that
@@ -195,7 +220,7 @@ int trexhip_export_id_table_device(trexhip_ctx* ctx, const float* d_probs, int32
 /* live HIP-event timing of the dominant kernels on the ctx stream (bench.py roofline):
  * stage ids TREXHIP_STAGE_* ; returns accumulated milliseconds and launch count since reset */
 enum { TREXHIP_STAGE_ROWS = 0, TREXHIP_STAGE_SEGMENT_ALL = 1, TREXHIP_STAGE_CONV2 = 2, TREXHIP_STAGE_CONV3 = 3,
-       TREXHIP_STAGE_CNN_ALL = 4, TREXHIP_STAGE_CROPS = 5, TREXHIP_STAGE_COUNT = 8 };
+       TREXHIP_STAGE_CNN_ALL = 4, TREXHIP_STAGE_CROPS = 5, TREXHIP_STAGE_POSTURE = 6, TREXHIP_STAGE_COUNT = 8 };
 int trexhip_profile_enable(trexhip_ctx* ctx, int32_t on);
 int trexhip_profile_read(trexhip_ctx* ctx, int32_t stage, double* total_ms, int64_t* launches);
 int trexhip_profile_reset(trexhip_ctx* ctx);

@@ -27,7 +27,7 @@ INFO_DTYPE = np.dtype([
 assert BLOB_DTYPE.itemsize == 104 and RUN_DTYPE.itemsize == 8 and INFO_DTYPE.itemsize == 48
 
 CNN_FP32, CNN_BF16X6, CNN_BF16X3 = 0, 1, 2
-STAGE_ROWS, STAGE_SEGMENT_ALL, STAGE_CONV2, STAGE_CONV3, STAGE_CNN_ALL, STAGE_CROPS = 0, 1, 2, 3, 4, 5
+STAGE_ROWS, STAGE_SEGMENT_ALL, STAGE_CONV2, STAGE_CONV3, STAGE_CNN_ALL, STAGE_CROPS, STAGE_POSTURE = 0, 1, 2, 3, 4, 5, 6
 
 
 class Params(C.Structure):
@@ -41,6 +41,16 @@ class Params(C.Structure):
         ("closing_size", C.c_int32), ("n_ranges", C.c_int32),
         ("cm_per_pixel", C.c_double), ("ranges", C.c_double * 16),
     ]
+
+
+class PostureParams(C.Structure):
+    _fields_ = [("outline_resample", C.c_float), ("outline_smooth_samples", C.c_int32), ("outline_smooth_step", C.c_int32),
+                ("outline_approximate", C.c_int32), ("outline_curvature_range_ratio", C.c_float),
+                ("midline_walk_offset", C.c_float), ("max_points", C.c_int32)]
+
+
+POSTURE_INFO_DTYPE = np.dtype([("status", "<i4"), ("n_outline", "<i4"), ("n_segments", "<i4"), ("tail_index", "<i4"),
+                               ("head_index", "<i4"), ("n_traced", "<i4"), ("reserved", "<i4", (2,))])
 
 
 class BatchResult(C.Structure):
@@ -67,7 +77,7 @@ SYMBOLS = [
     "trexhip_set_stream", "trexhip_set_background", "trexhip_set_background_device", "trexhip_segment_device",
     "trexhip_segment", "trexhip_segment_color", "trexhip_rethreshold_device", "trexhip_fetch_rethreshold", "trexhip_fetch", "trexhip_device_view_get", "trexhip_synchronize",
     "trexhip_profile_enable", "trexhip_profile_read", "trexhip_profile_reset",
-    "trexhip_crops_device", "trexhip_export_id_table_device", "trexhip_load_weights", "trexhip_set_identity_precision", "trexhip_num_classes", "trexhip_identify_device", "trexhip_identify",
+    "trexhip_default_posture_params", "trexhip_posture_device", "trexhip_crops_device", "trexhip_export_id_table_device", "trexhip_load_weights", "trexhip_set_identity_precision", "trexhip_num_classes", "trexhip_identify_device", "trexhip_identify",
 ]
 
 
@@ -97,6 +107,9 @@ def lib():
         L.trexhip_profile_enable.argtypes = [C.c_void_p, C.c_int32]
         L.trexhip_profile_read.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
         L.trexhip_profile_reset.argtypes = [C.c_void_p]
+        L.trexhip_default_posture_params.argtypes = [C.POINTER(PostureParams)]
+        L.trexhip_default_posture_params.restype = None
+        L.trexhip_posture_device.argtypes = [C.c_void_p, C.c_int32, C.POINTER(PostureParams), C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]
         L.trexhip_crops_device.argtypes = [C.c_void_p, C.c_void_p] + [C.c_int32] * 5
         L.trexhip_export_id_table_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_uint32, C.c_void_p, C.c_int32]
         L.trexhip_load_weights.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
@@ -225,6 +238,16 @@ class Segmenter:
         if rc == -3:
             self.last_capacity_error = lib().trexhip_last_error().decode()
         return out
+
+    def posture_device(self, n_blobs, d_outline_ptr, d_segments_ptr, d_info_ptr, table=0, **kw):
+        """posture::calculate_posture for every blob of the detect (0) or re-threshold (1) table; see include/trexhip.h."""
+        pp = PostureParams()
+        lib().trexhip_default_posture_params(C.byref(pp))
+        for k, v in kw.items():
+            setattr(pp, k, v)
+        _check(lib().trexhip_posture_device(self._h, table, C.byref(pp), n_blobs, C.c_void_p(d_outline_ptr),
+                                            C.c_void_p(d_segments_ptr), C.c_void_p(d_info_ptr)))
+        return pp
 
     def crops_device(self, d_crops_ptr, n_blobs, out_w=80, out_h=80, normalization=0, difference=0):
         """constraints::diff_image for every blob of the last batch -> uint8 [n_blobs][out_h][out_w] at d_crops_ptr."""

@@ -3,7 +3,7 @@
 // RawProcessing::generate_binary applies, after the threshold, `use_closing` (cv::dilate then cv::erode with a
 // closing_size ellipse) and `dilation_size` (dilate for > 0, erode for < 0, ellipse of size 2|d|+1)
 // (settings: Application/src/tracker/core/default_config.cpp:1163-1165; body in the un-vendored commons --
-// restated in oracle/trex_oracle.c and cross-checked against scipy.ndimage there).
+// semantics chosen where the reference is unpinned: DESIGN.md section 2).
 //
 //   k_threshold_bits  the k_rows pixel test, but the 16-bit lane masks are packed into a bit image
 //   k_morph_bits      binary dilate / erode with a structuring element given as one column span per row
@@ -108,7 +108,7 @@ __global__ __launch_bounds__(256) void k_morph_bits(const uint32_t* __restrict__
     }
 }
 
-// OpenCV getStructuringElement(MORPH_ELLIPSE, Size(k,k)) as per-row spans (published algorithm, see the oracle)
+// OpenCV getStructuringElement(MORPH_ELLIPSE, Size(k,k)) as per-row spans (OpenCV's published algorithm: morph.dispatch.cpp)
 static MorphElem ellipse_spans(int k) {
     MorphElem e{};
     e.k = k;

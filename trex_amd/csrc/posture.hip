@@ -1,0 +1,330 @@
+// posture.hip -- posture::calculate_posture for every blob of a segmented batch, one wave per blob.
+//
+// Replaces Application/src/tracker/tracking/Posture.cpp:305-399 (one threshold iteration: the blob table handed in is
+// either the detect table or the re-threshold table, i.e. threshold_get_biggest_blob is done by the caller choosing
+// the sub-blob) and Outline.cpp:
+//   outline of the blob (pixel::find_outer_points, commons)     -> trace on the half-pixel lattice (definition: DESIGN.md section 2)
+//   Outline::resample              Outline.cpp:724-766            sequential float walk, lane 0, same operation order
+//   smooth_outline                 Outline.cpp:330-378            one lane per point
+//   Outline::offset_to_middle      Outline.cpp:454-718            clockwise test, EFT(order) -> inverse, curvature, tail/head
+//   Outline::calculate_midline     Outline.cpp:768-868            two-pointer walk, lane 0
+// Everything of one blob lives in the wave's slice of LDS (runs, row table, two point buffers, curvature).
+// The float pipeline is compiled without FMA contraction (-ffp-contract=off in the Makefile) so resample / smooth /
+// walk reproduce the CPU operation order; the transcendental part (EFT) agrees to float rounding.
+#include "internal.h"
+
+namespace trexhip {
+
+static constexpr int P_NP = 1024;      // points per blob held in LDS
+static constexpr int P_NR = 1024;      // runs per blob held in LDS
+static constexpr int P_ROWS = 512;     // rows per blob
+static constexpr int P_WAVE_LDS = P_NP * 8 * 2 + P_NP * 4 * 2 + P_NR * 4 + (P_ROWS + 2) * 4;   // bytes per wave
+
+struct PostureCfg {
+    float outline_resample; int smooth_samples, smooth_step, approximate;
+    float curvature_range_ratio, midline_walk_offset; int max_points;
+};
+
+__device__ __forceinline__ float wsum(float v) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d);
+    return v;
+}
+
+__device__ __forceinline__ bool in_blob(const uint32_t* s_runs, const int* s_row, int y0, int y1, int x, int y) {
+    if (y < y0 || y > y1) return false;
+    for (int i = s_row[y - y0]; i < s_row[y - y0 + 1]; ++i) {
+        const uint32_t r = s_runs[i];
+        if (x >= (int)(r & 0xffffu) && x <= (int)(r >> 16)) return true;
+    }
+    return false;
+}
+
+__global__ __launch_bounds__(256) void k_posture(const PostureCfg P, const trexhip_frame_info* __restrict__ info,
+                                                 const uint32_t* __restrict__ blob_frame, const trexhip_blob* __restrict__ blobs,
+                                                 const trexhip_run* __restrict__ runs, int n_blobs, int B,
+                                                 float2* __restrict__ out_outline, float4* __restrict__ out_segments,
+                                                 trexhip_posture_info* __restrict__ out_info) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t plds[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int bi = blockIdx.x * 4 + wave;
+    if (bi >= n_blobs) return;
+    uint8_t* base = plds + (size_t)wave * P_WAVE_LDS;
+    float2* bufA = reinterpret_cast<float2*>(base);
+    float2* bufB = bufA + P_NP;
+    float* s_curv = reinterpret_cast<float*>(bufB + P_NP);
+    float* s_t = s_curv + P_NP;
+    uint32_t* s_runs = reinterpret_cast<uint32_t*>(s_t + P_NP);
+    int* s_row = reinterpret_cast<int*>(s_runs + P_NR);
+
+    trexhip_posture_info res = {};
+    const int cap = min(P.max_points, P_NP);
+    const uint32_t f = blob_frame[bi];
+    bool ok = f < (uint32_t)B;
+    trexhip_frame_info fi = {};
+    if (ok) { fi = info[f]; ok = fi.flags == 0; }
+    if (!ok) { if (lane == 0) { res.status = 1; out_info[bi] = res; } return; }
+    const trexhip_blob Bl = blobs[bi];
+    const int n_runs = (int)Bl.n_runs, y0 = Bl.y0, y1 = Bl.y1, rows = y1 - y0 + 1;
+    if (n_runs == 0) { if (lane == 0) { res.status = 1; out_info[bi] = res; } return; }
+    if (n_runs > P_NR || rows > P_ROWS) { if (lane == 0) { res.status = 2; out_info[bi] = res; } return; }
+    const trexhip_run* rr = runs + fi.run_begin + Bl.run_begin;
+    for (int i = lane; i < n_runs; i += 64) {
+        const trexhip_run q = rr[i];
+        s_runs[i] = (uint32_t)q.x0 | ((uint32_t)q.x1 << 16);
+        if (i == 0 || rr[i - 1].y != q.y) s_row[q.y - y0] = i;
+    }
+    if (lane == 0) s_row[rows] = n_runs;
+    __builtin_amdgcn_wave_barrier();
+    const int ox = Bl.x0, oy = Bl.y0;                       // coordinates relative to the blob's bounds().pos() (Posture.cpp:336)
+
+    // ---- outline on the half-pixel lattice + resample: sequential, lane 0 ----
+    int n = 0, status = 0;
+    if (lane == 0) {
+        const int fx = (int)(s_runs[0] & 0xffffu);
+        const int sx = 2 * fx - 1, sy = 2 * y0 - 1;
+        int vx = sx, vy = sy, dx = 1, dy = 0, nt = 0;
+        do {
+            if (nt + 2 > P_NP) { status = 2; break; }
+            bufA[nt++] = make_float2(0.5f * (float)(vx - 2 * ox), 0.5f * (float)(vy - 2 * oy));
+            bufA[nt++] = make_float2(0.5f * (float)(vx + dx - 2 * ox), 0.5f * (float)(vy + dy - 2 * oy));
+            vx += 2 * dx; vy += 2 * dy;
+            const int lx = dy, ly = -dx, rx = -dy, ry = dx;
+            if (in_blob(s_runs, s_row, y0, y1, (vx + dx + lx) / 2, (vy + dy + ly) / 2)) { dx = lx; dy = ly; }
+            else if (in_blob(s_runs, s_row, y0, y1, (vx + dx + rx) / 2, (vy + dy + ry) / 2)) { }
+            else { dx = rx; dy = ry; }
+        } while (!(vx == sx && vy == sy && dx == 1 && dy == 0));
+        res.n_traced = nt;
+        if (!status) {   // Outline::resample (Outline.cpp:724-766)
+            const float rd = P.outline_resample;
+            if (rd <= 0.f || nt <= 1) { for (int i = 0; i < nt; ++i) bufB[i] = bufA[i]; n = nt; }
+            else {
+                float walked = 0.0f;
+                for (int i = 0; i < nt && !status; ++i) {
+                    int i1 = i + 1; if (i1 >= nt) i1 -= nt;
+                    const float2 pt0 = bufA[i], pt1 = bufA[i1];
+                    const float lxn = pt1.x - pt0.x, lyn = pt1.y - pt0.y;
+                    const float len = __fsqrt_rn(lxn * lxn + lyn * lyn);
+                    walked += len;
+                    const float percent = len / rd;
+                    float wp = walked / rd;
+                    int offset = 0;
+                    while (wp >= 1.0f) {
+                        const float tt = (float)((double)offset * 1.0 / (double)percent);
+                        if (n >= cap) { status = 2; break; }
+                        bufB[n++] = make_float2(pt0.x + lxn * tt, pt0.y + lyn * tt);
+                        offset++;
+                        walked -= rd;
+                        wp -= 1.0f;
+                    }
+                }
+            }
+            if (!status && n == 0) status = 1;
+        }
+    }
+    n = __shfl(n, 0); status = __shfl(status, 0); res.n_traced = __shfl(res.n_traced, 0);
+    __builtin_amdgcn_wave_barrier();
+    if (status) { if (lane == 0) { res.status = status; out_info[bi] = res; } return; }
+
+    float2* pts = bufB; float2* other = bufA;
+    // ---- smooth_outline (Outline.cpp:330-378): triangular weights over +-range*step ----
+    if (P.smooth_samples > 0 && n > P.smooth_samples) {
+        const float step_row = (float)P.smooth_samples * (float)P.smooth_step;
+        float w[33]; int nw = 0; float sum = 0.f;
+        for (int i = (int)-step_row; i <= step_row && nw < 33; i += P.smooth_step) { const float val = (step_row - fabsf((float)i)) / step_row; sum += val; w[nw++] = val; }
+        for (int i = lane; i < n; i += 64) {
+            float2 pt = make_float2(0.f, 0.f); int s = 0;
+            for (long j = (long)((float)i - step_row); j <= (float)i + step_row; j += P.smooth_step) {
+                long idx = j; while (idx < 0) idx += n; while (idx >= n) idx -= n;
+                const float ww = w[s] / sum; ++s;
+                pt.x += pts[idx].x * ww; pt.y += pts[idx].y * ww;
+            }
+            other[i] = pt;
+        }
+        __builtin_amdgcn_wave_barrier();
+        float2* t = pts; pts = other; other = t;
+    }
+    // ---- offset_to_middle: clockwise test ----
+    {
+        float part = 0.f;
+        for (int i = lane; i < n; i += 64) { const float2 a = pts[i], q = pts[(i + 1) % n]; part += a.x * q.y - q.x * a.y; }
+        if (wsum(part) < 0.f) {
+            for (int i = lane; i < n; i += 64) other[i] = pts[n - 1 - i];
+            __builtin_amdgcn_wave_barrier();
+            float2* t = pts; pts = other; other = t;
+        }
+    }
+    // ---- EFT (order) -> inverse at n uniform parameters around the centre ----
+    if (P.approximate > 0) {
+        float cxp = 0.f, cyp = 0.f;
+        for (int i = lane; i < n; i += 64) { cxp += pts[i].x; cyp += pts[i].y; }
+        const float cx = wsum(cxp) / (float)n, cy = wsum(cyp) / (float)n;
+        // cumulative arc length (wave scan over chunks of 64 segments)
+        float run = 0.f;
+        for (int i0 = 0; i0 < n; i0 += 64) {
+            const int i = i0 + lane;
+            float dt = 0.f;
+            if (i < n) { const float2 a = pts[i], q = pts[(i + 1) % n]; dt = __fsqrt_rn((q.x - a.x) * (q.x - a.x) + (q.y - a.y) * (q.y - a.y)); }
+            float incl = dt;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) { const float t = __shfl_up(incl, d); if (lane >= d) incl += t; }
+            if (i < n) s_t[i] = run + incl - dt;                 // t at the START of segment i
+            run += __shfl(incl, 63);
+        }
+        const float T = run;
+        __builtin_amdgcn_wave_barrier();
+        const float PI = 3.14159265358979323846f;
+        float ca[4][4];                                           // [harmonic 1..3][a b c d]
+        const int order = min(P.approximate, 3);
+        for (int h = 1; h <= order; ++h) {
+            float sa = 0.f, sb = 0.f, sc = 0.f, sd = 0.f;
+            for (int i = lane; i < n; i += 64) {
+                const float2 a = pts[i], q = pts[(i + 1) % n];
+                const float t0 = s_t[i], t1 = (i + 1 < n) ? s_t[i + 1] : T;
+                const float dt = t1 - t0;
+                if (dt <= 0.f) continue;
+                const float ph1 = 2.0f * PI * (float)h * t1 / T, ph0 = 2.0f * PI * (float)h * t0 / T;
+                const float dc = cosf(ph1) - cosf(ph0), ds = sinf(ph1) - sinf(ph0);
+                const float ddx = q.x - a.x, ddy = q.y - a.y;
+                sa += ddx / dt * dc; sb += ddx / dt * ds; sc += ddy / dt * dc; sd += ddy / dt * ds;
+            }
+            const float k = T / (2.0f * (float)(h * h) * PI * PI);
+            ca[h][0] = k * wsum(sa); ca[h][1] = k * wsum(sb); ca[h][2] = k * wsum(sc); ca[h][3] = k * wsum(sd);
+        }
+        for (int i = lane; i < n; i += 64) {
+            const float tt = (float)i / (float)n;
+            float x = cx, y = cy;
+            for (int h = 1; h <= order; ++h) {
+                const float ph = 2.0f * PI * (float)h * tt;
+                const float cs = cosf(ph), sn = sinf(ph);
+                x += ca[h][0] * cs + ca[h][1] * sn; y += ca[h][2] * cs + ca[h][3] * sn;
+            }
+            other[i] = make_float2(x, y);
+        }
+        __builtin_amdgcn_wave_barrier();
+        float2* t = pts; pts = other; other = t;
+    }
+    // ---- curvature, tail = highest peak, head = farthest peak ----
+    int r = (int)(P.curvature_range_ratio * (float)n); if (r < 1) r = 1;
+    for (int i = lane; i < n; i += 64) {
+        const float2 p1 = pts[((i - r) % n + n) % n], p2 = pts[i], p3 = pts[(i + r) % n];
+        const float cr = (p2.x - p1.x) * (p3.y - p2.y) - (p2.y - p1.y) * (p3.x - p2.x);
+        const float d12 = (p2.x - p1.x) * (p2.x - p1.x) + (p2.y - p1.y) * (p2.y - p1.y);
+        const float d23 = (p3.x - p2.x) * (p3.x - p2.x) + (p3.y - p2.y) * (p3.y - p2.y);
+        const float d13 = (p3.x - p1.x) * (p3.x - p1.x) + (p3.y - p1.y) * (p3.y - p1.y);
+        const float den = __fsqrt_rn(d12 * d23 * d13);
+        s_curv[i] = den > 0.f ? fabsf(2.0f * cr / den) : 0.0f;
+    }
+    __builtin_amdgcn_wave_barrier();
+    float best = -1.f; int tail = 0x7fffffff;
+    for (int i = lane; i < n; i += 64) {
+        const float c0 = s_curv[(i - 1 + n) % n], c1 = s_curv[i], c2 = s_curv[(i + 1) % n];
+        if (c1 > c0 && c1 >= c2 && c1 > best) { best = c1; tail = i; }        // per lane: first index of its maximum
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        const float ob = __shfl_xor(best, d); const int ot = __shfl_xor(tail, d);
+        if (ob > best || (ob == best && ot < tail)) { best = ob; tail = ot; }
+    }
+    if (tail == 0x7fffffff || best < 0.f) { if (lane == 0) { res.status = 3; res.n_outline = n; out_info[bi] = res; } return; }
+    float maxd = 0.f; int head = 0x7fffffff;
+    for (int i = lane; i < n; i += 64) {
+        const float c0 = s_curv[(i - 1 + n) % n], c1 = s_curv[i], c2 = s_curv[(i + 1) % n];
+        if (!(c1 > c0 && c1 >= c2)) continue;
+        float dd;
+        if (i >= tail) dd = fminf(fabsf((float)(i - tail)), fabsf((float)(i - tail - n)));
+        else dd = fminf(fabsf((float)(tail - i)), fabsf((float)(tail - i - n)));
+        if (dd > maxd) { maxd = dd; head = i; }
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        const float od = __shfl_xor(maxd, d); const int oh = __shfl_xor(head, d);
+        if (od > maxd || (od == maxd && oh < head)) { maxd = od; head = oh; }
+    }
+    // rotate so that the tail is point 0 (Outline.cpp:707); this is the outline the caller gets
+    float2* oo = out_outline + (size_t)bi * P.max_points;
+    for (int i = lane; i < n; i += 64) { const float2 v = pts[(i + tail) % n]; other[i] = v; oo[i] = v; }
+    __builtin_amdgcn_wave_barrier();
+    { float2* t = pts; pts = other; other = t; }
+    res.n_outline = n; res.tail_index = 0;
+    res.head_index = head == 0x7fffffff ? -1 : ((head - tail) % n + n) % n;
+    if (n <= 1) { if (lane == 0) { res.status = 1; out_info[bi] = res; } return; }
+    // ---- the two-pointer walk (Outline.cpp:790-857), lane 0 ----
+    if (lane == 0) {
+        const int L = n;
+        int idx_r = 1, idx_l = -1, ns = 0;
+        float mo = P.midline_walk_offset * (float)L; if (mo < 3.0f) mo = 3.0f;
+        const int max_offset = (int)mo;
+        float4* so = out_segments + (size_t)bi * (P.max_points / 2 + 1);
+        while (idx_r < L + idx_l) {
+            float2 pt_r = make_float2(0.f, 0.f); float2 pt_l = pts[L + idx_l];
+            float min_d = 3.402823466e38f; int min_idx = -1;
+            for (int i = 0; i < max_offset; ++i) {
+                if (idx_r + i >= L) break;
+                const float2 pt = pts[idx_r + i];
+                const float ddx = pt.x - pt_l.x, ddy = pt.y - pt_l.y, len = __fsqrt_rn(ddx * ddx + ddy * ddy);
+                if (len < min_d) { min_d = len; min_idx = idx_r + i; }
+            }
+            if (min_idx != -1) { pt_r = pts[min_idx]; idx_r = min_idx; }
+            min_d = 3.402823466e38f; min_idx = 1;
+            for (int i = 0; i < max_offset; ++i) {
+                if (idx_l - i <= -L) break;
+                const float2 pt = pts[L + idx_l - i];
+                const float ddx = pt_r.x - pt.x, ddy = pt_r.y - pt.y, len = __fsqrt_rn(ddx * ddx + ddy * ddy);
+                if (len < min_d) { min_d = len; min_idx = idx_l - i; }
+            }
+            if (min_idx != 1) { pt_l = pts[L + min_idx]; idx_l = min_idx; }
+            const float lx = pt_r.x - pt_l.x, ly = pt_r.y - pt_l.y;
+            const float mx = pt_l.x + lx * 0.5f, my = pt_l.y + ly * 0.5f;
+            if (ns <= P.max_points / 2)
+                so[ns] = make_float4(mx, my, __fsqrt_rn(lx * lx + ly * ly), __fsqrt_rn((mx - pt_l.x) * (mx - pt_l.x) + (my - pt_l.y) * (my - pt_l.y)));
+            ++ns;
+            idx_r++; idx_l--;
+        }
+        res.n_segments = ns;
+        res.status = ns <= 2 ? 4 : 0;
+        out_info[bi] = res;
+    }
+}
+
+}  // namespace trexhip
+
+using namespace trexhip;
+
+extern "C" int trexhip_posture_device(trexhip_ctx* ctx, int32_t table, const trexhip_posture_params* pp, int32_t n_blobs,
+                                      float* d_outline, float* d_segments, trexhip_posture_info* d_info) {
+    if (!ctx || !pp || !d_outline || !d_segments || !d_info) { set_error("trexhip_posture_device: null argument"); return TREXHIP_E_INVALID; }
+    if (pp->max_points < 8 || pp->max_points > P_NP) { set_error("trexhip_posture_device: max_points must be in 8..1024"); return TREXHIP_E_INVALID; }
+    if (pp->outline_smooth_samples < 0 || pp->outline_smooth_samples * (pp->outline_smooth_step > 0 ? pp->outline_smooth_step : 1) > 16 || pp->outline_smooth_step < 1) {
+        set_error("trexhip_posture_device: outline_smooth_samples*outline_smooth_step must be <= 16"); return TREXHIP_E_UNSUPPORTED;
+    }
+    if (pp->outline_approximate > 3) { set_error("trexhip_posture_device: outline_approximate > 3 is not supported"); return TREXHIP_E_UNSUPPORTED; }
+    if (!ctx->d_frames || ctx->last_n == 0 || !ctx->fetched) { set_error("trexhip_posture_device: segment and fetch a batch first"); return TREXHIP_E_INVALID; }
+    if (n_blobs < 0 || (uint32_t)n_blobs > ctx->cfg.pool_blobs) { set_error("trexhip_posture_device: n_blobs outside the blob pool"); return TREXHIP_E_INVALID; }
+    if (n_blobs == 0) return TREXHIP_OK;
+    const trexhip_frame_info* info = ctx->d_info; const uint32_t* bf = ctx->d_blob_frame; const trexhip_blob* bl = ctx->d_blobs; const trexhip_run* ru = ctx->d_runs;
+    if (table == 1) {
+        if (!ctx->pass2.allocated || ctx->pass2.valid_n == 0) { set_error("trexhip_posture_device: no re-thresholded batch"); return TREXHIP_E_INVALID; }
+        info = ctx->pass2.d_info; bf = ctx->pass2.d_blob_frame; bl = ctx->pass2.d_blobs; ru = ctx->pass2.d_runs;
+    } else if (table != 0) { set_error("trexhip_posture_device: table must be 0 (detect) or 1 (re-threshold)"); return TREXHIP_E_INVALID; }
+    TH_CHECK_HIP(hipSetDevice(ctx->p.device));
+    static bool attr_done = false;
+    if (!attr_done) {
+        TH_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_posture), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * P_WAVE_LDS));
+        attr_done = true;
+    }
+    PostureCfg P{pp->outline_resample, pp->outline_smooth_samples, pp->outline_smooth_step, pp->outline_approximate,
+                 pp->outline_curvature_range_ratio, pp->midline_walk_offset, pp->max_points};
+    stage_begin(ctx, TREXHIP_STAGE_POSTURE);
+    hipLaunchKernelGGL(k_posture, dim3((n_blobs + 3) / 4), dim3(256), 4 * P_WAVE_LDS, ctx->stream, P, info, bf, bl, ru, n_blobs, ctx->last_n,
+                       reinterpret_cast<float2*>(d_outline), reinterpret_cast<float4*>(d_segments), d_info);
+    stage_end(ctx, TREXHIP_STAGE_POSTURE);
+    TH_CHECK_HIP(hipGetLastError());
+    return TREXHIP_OK;
+}
+
+extern "C" void trexhip_default_posture_params(trexhip_posture_params* p) {
+    if (!p) return;
+    p->outline_resample = 1.0f; p->outline_smooth_samples = 4; p->outline_smooth_step = 1; p->outline_approximate = 3;
+    p->outline_curvature_range_ratio = 0.03f; p->midline_walk_offset = 0.025f; p->max_points = 512;
+}
