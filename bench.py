@@ -45,6 +45,7 @@ def main():
     ap.add_argument("--stages", default="all", choices=["all", "segment"])
     ap.add_argument("--cnn-mode", default="bf16x6", choices=["fp32", "bf16x6", "bf16x3"],
                     help="arithmetic of conv2/conv3: exact fp32 MFMA or the fp32-equivalent 6-product bf16 split (default)")
+    ap.add_argument("--with-posture", action="store_true", help="also run posture (outline -> midline) for every blob inside the timed step (configs C3/C5)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     args = ap.parse_args()
@@ -86,6 +87,11 @@ def main():
     rows = B * n_ind * 5 // 4                       # fixed table rows per rank per step (all-gather needs equal sizes)
     table = torch.zeros((rows, tdist.HDR + classes), dtype=torch.int32, device=dev)
     table_host = torch.empty((world * rows, tdist.HDR + classes), dtype=torch.int32).pin_memory() if rank == 0 else None
+    MP = 256
+    if args.with_posture:
+        p_outline = torch.empty((pool, MP, 2), dtype=torch.float32, device=dev)
+        p_segs = torch.empty((pool, MP // 2 + 1, 4), dtype=torch.float32, device=dev)
+        p_info = torch.empty((pool, 8), dtype=torch.int32, device=dev)
     own = torch.cuda.Stream(device=dev)            # torch-side copies ride on the same stream as the kernels
     seg.set_stream(own.cuda_stream)
     torch.cuda.synchronize()
@@ -97,6 +103,8 @@ def main():
         res = seg.fetch(copy=False)                 # syncs; blob/run/pixel tables now on this rank's host
         n = sum(len(r.blobs) for r in res)
         assert n <= rows, "identity table too small"
+        if args.with_posture and n:
+            seg.posture_device(n, p_outline.data_ptr(), p_segs.data_ptr(), p_info.data_ptr(), max_points=MP)
         if with_cnn:
             if n:
                 seg.crops_device(crops.data_ptr(), n)
@@ -135,7 +143,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     prof = {name: seg.profile_read(getattr(capi, "STAGE_" + name)) for name in
-            ("ROWS", "SEGMENT_ALL", "CONV2", "CONV3", "CNN_ALL", "CROPS")}
+            ("ROWS", "SEGMENT_ALL", "CONV2", "CONV3", "CNN_ALL", "CROPS", "POSTURE")}
     seg.profile_enable(False)
 
     def pmc_traffic(kernel_prefix):
@@ -192,7 +200,7 @@ def main():
                            "avg_launch_us": c3_s * 1e6, "launches": prof["CONV3"][1], "algorithmic_flop_per_launch": fl,
                            "peak_note": "achieved counts ALGORITHMIC flops (2 per fp32 multiply-add); peak is the dense MFMA peak of the instruction used (fp32: 157.3, bf16: 2500 TFLOP/s, MI355X_MICROARCH.md); in the split modes every algorithmic product costs `mfma_products_per_algorithmic_product` bf16 MFMA products, so the matrix pipe is busy mfma_issue_frac of its peak"}
         cnn_s = avg_s("CNN_ALL")
-        out["stage_us"] = {"detect": segall_s * 1e6, "crops": avg_s("CROPS") * 1e6, "conv2": avg_s("CONV2") * 1e6,
+        out["stage_us"] = {"detect": segall_s * 1e6, "posture": avg_s("POSTURE") * 1e6 if args.with_posture else None, "crops": avg_s("CROPS") * 1e6, "conv2": avg_s("CONV2") * 1e6,
                            "conv3": c3_s * 1e6, "cnn_all": cnn_s * 1e6,
                            "cnn_all_tflops": FLOP_PER_CROP_TOTAL * n_blobs / cnn_s / 1e12 if cnn_s else None}
         out["roofline_detect"] = seg_roof

@@ -15,10 +15,11 @@
 
 namespace trexhip {
 
-static constexpr int P_NP = 1024;      // points per blob held in LDS
-static constexpr int P_NR = 1024;      // runs per blob held in LDS
-static constexpr int P_ROWS = 512;     // rows per blob
-static constexpr int P_WAVE_LDS = P_NP * 8 * 2 + P_NP * 4 * 2 + P_NR * 4 + (P_ROWS + 2) * 4;   // bytes per wave
+static constexpr int P_NP = 1024;      // largest max_points
+static constexpr int P_NR = 512;       // runs per blob held in LDS
+static constexpr int P_ROWS = 254;     // rows per blob
+// bytes of LDS per wave for a given point capacity: two point buffers, curvature, arc length, runs, row table
+__host__ __device__ constexpr int posture_wave_lds(int np) { return np * 8 * 2 + np * 4 * 2 + P_NR * 4 + (P_ROWS + 2) * 4; }
 
 struct PostureCfg {
     float outline_resample; int smooth_samples, smooth_step, approximate;
@@ -49,16 +50,17 @@ __global__ __launch_bounds__(256) void k_posture(const PostureCfg P, const trexh
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int bi = blockIdx.x * 4 + wave;
     if (bi >= n_blobs) return;
-    uint8_t* base = plds + (size_t)wave * P_WAVE_LDS;
+    const int NPc = P.max_points;                           // point capacity = LDS layout stride
+    uint8_t* base = plds + (size_t)wave * posture_wave_lds(NPc);
     float2* bufA = reinterpret_cast<float2*>(base);
-    float2* bufB = bufA + P_NP;
-    float* s_curv = reinterpret_cast<float*>(bufB + P_NP);
-    float* s_t = s_curv + P_NP;
-    uint32_t* s_runs = reinterpret_cast<uint32_t*>(s_t + P_NP);
+    float2* bufB = bufA + NPc;
+    float* s_curv = reinterpret_cast<float*>(bufB + NPc);
+    float* s_t = s_curv + NPc;
+    uint32_t* s_runs = reinterpret_cast<uint32_t*>(s_t + NPc);
     int* s_row = reinterpret_cast<int*>(s_runs + P_NR);
 
     trexhip_posture_info res = {};
-    const int cap = min(P.max_points, P_NP);
+    const int cap = NPc;
     const uint32_t f = blob_frame[bi];
     bool ok = f < (uint32_t)B;
     trexhip_frame_info fi = {};
@@ -85,7 +87,7 @@ __global__ __launch_bounds__(256) void k_posture(const PostureCfg P, const trexh
         const int sx = 2 * fx - 1, sy = 2 * y0 - 1;
         int vx = sx, vy = sy, dx = 1, dy = 0, nt = 0;
         do {
-            if (nt + 2 > P_NP) { status = 2; break; }
+            if (nt + 2 > NPc) { status = 2; break; }
             bufA[nt++] = make_float2(0.5f * (float)(vx - 2 * ox), 0.5f * (float)(vy - 2 * oy));
             bufA[nt++] = make_float2(0.5f * (float)(vx + dx - 2 * ox), 0.5f * (float)(vy + dy - 2 * oy));
             vx += 2 * dx; vy += 2 * dy;
@@ -294,7 +296,7 @@ using namespace trexhip;
 extern "C" int trexhip_posture_device(trexhip_ctx* ctx, int32_t table, const trexhip_posture_params* pp, int32_t n_blobs,
                                       float* d_outline, float* d_segments, trexhip_posture_info* d_info) {
     if (!ctx || !pp || !d_outline || !d_segments || !d_info) { set_error("trexhip_posture_device: null argument"); return TREXHIP_E_INVALID; }
-    if (pp->max_points < 8 || pp->max_points > P_NP) { set_error("trexhip_posture_device: max_points must be in 8..1024"); return TREXHIP_E_INVALID; }
+    if (pp->max_points < 8 || pp->max_points > P_NP || (pp->max_points & 1)) { set_error("trexhip_posture_device: max_points must be even and in 8..1024"); return TREXHIP_E_INVALID; }
     if (pp->outline_smooth_samples < 0 || pp->outline_smooth_samples * (pp->outline_smooth_step > 0 ? pp->outline_smooth_step : 1) > 16 || pp->outline_smooth_step < 1) {
         set_error("trexhip_posture_device: outline_smooth_samples*outline_smooth_step must be <= 16"); return TREXHIP_E_UNSUPPORTED;
     }
@@ -308,15 +310,16 @@ extern "C" int trexhip_posture_device(trexhip_ctx* ctx, int32_t table, const tre
         info = ctx->pass2.d_info; bf = ctx->pass2.d_blob_frame; bl = ctx->pass2.d_blobs; ru = ctx->pass2.d_runs;
     } else if (table != 0) { set_error("trexhip_posture_device: table must be 0 (detect) or 1 (re-threshold)"); return TREXHIP_E_INVALID; }
     TH_CHECK_HIP(hipSetDevice(ctx->p.device));
-    static bool attr_done = false;
-    if (!attr_done) {
-        TH_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_posture), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * P_WAVE_LDS));
-        attr_done = true;
+    const int lds_bytes = 4 * posture_wave_lds(pp->max_points);
+    static int attr_bytes = 0;
+    if (lds_bytes > attr_bytes) {
+        TH_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_posture), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
+        attr_bytes = lds_bytes;
     }
     PostureCfg P{pp->outline_resample, pp->outline_smooth_samples, pp->outline_smooth_step, pp->outline_approximate,
                  pp->outline_curvature_range_ratio, pp->midline_walk_offset, pp->max_points};
     stage_begin(ctx, TREXHIP_STAGE_POSTURE);
-    hipLaunchKernelGGL(k_posture, dim3((n_blobs + 3) / 4), dim3(256), 4 * P_WAVE_LDS, ctx->stream, P, info, bf, bl, ru, n_blobs, ctx->last_n,
+    hipLaunchKernelGGL(k_posture, dim3((n_blobs + 3) / 4), dim3(256), lds_bytes, ctx->stream, P, info, bf, bl, ru, n_blobs, ctx->last_n,
                        reinterpret_cast<float2*>(d_outline), reinterpret_cast<float4*>(d_segments), d_info);
     stage_end(ctx, TREXHIP_STAGE_POSTURE);
     TH_CHECK_HIP(hipGetLastError());
