@@ -43,7 +43,7 @@ def main():
     ap.add_argument("--config", default="C4")
     ap.add_argument("--batch", type=int, default=0, help="frames resident per step (default 64, C5: 16)")
     ap.add_argument("--stages", default="all", choices=["all", "segment"])
-    ap.add_argument("--cnn-mode", default="bf16x6", choices=["fp32", "bf16x6", "bf16x3"],
+    ap.add_argument("--cnn-mode", default="bf16x6", choices=["fp32", "bf16x6", "bf16x3", "fp16x3"],
                     help="arithmetic of conv2/conv3: exact fp32 MFMA or the fp32-equivalent 6-product bf16 split (default)")
     ap.add_argument("--with-posture", action="store_true", help="also run posture (outline -> midline) for every blob inside the timed step (configs C3/C5)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -79,7 +79,7 @@ def main():
     state = weights.synthetic_state(classes, 4242)
     if with_cnn:
         seg.load_weights(weights.pack_blob(state, classes))
-        seg.set_identity_precision({"fp32": 0, "bf16x6": 1, "bf16x3": 2}[args.cnn_mode])
+        seg.set_identity_precision({"fp32": 0, "bf16x6": 1, "bf16x3": 2, "fp16x3": 3}[args.cnn_mode])
     pool = B * max_blobs
     crops = torch.empty((pool, 80, 80), dtype=torch.uint8, device=dev)
     probs = torch.empty((pool, classes), dtype=torch.float32, device=dev)
@@ -172,7 +172,7 @@ def main():
         "metric": "frames/s end-to-end (segment+CNN-ID), 2048x2048 x100 individuals",
         "value": fps, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": ({"fp32": "f32", "bf16x6": "bf16x6-split (fp32-equivalent: 3 bf16 pieces per operand, 6 MFMA products, fp32 accumulate)", "bf16x3": "bf16x3-split"}[args.cnn_mode] if with_cnn else "u8"), "data": "synthetic",
+        "vs_baseline": None, "dtype": ({"fp32": "f32", "bf16x6": "bf16x6-split (fp32-equivalent: 3 bf16 pieces per operand, 6 MFMA products, fp32 accumulate)", "bf16x3": "bf16x3-split", "fp16x3": "fp16x3-split (fp32-class: 2 fp16 pieces per operand = 22 mantissa bits, 3 MFMA products, fp32 accumulate, range-guarded)"}[args.cnn_mode] if with_cnn else "u8"), "data": "synthetic",
         "config": {"workload": f"{args.config}: {W}x{H} gray, {n_ind} individuals/frame, {B} frames resident per step per GPU, "
                                f"80x80x1 crops, {classes}-way V118_3 (random-init weights)",
                    "stages": "detect(bg-sub+threshold+CCL+filter+gather, tables->host) + crops(none) + identity CNN fp32 + per-blob ID table (all-gathered when N>1) -> rank-0 host"
@@ -188,9 +188,9 @@ def main():
     if with_cnn:
         c3_s = avg_s("CONV3")
         fl = FLOP_PER_CROP_CONV3 * n_blobs
-        nprod = {"fp32": 1, "bf16x6": 6, "bf16x3": 3}[args.cnn_mode]
+        nprod = {"fp32": 1, "bf16x6": 6, "bf16x3": 3, "fp16x3": 3}[args.cnn_mode]
         peak = 157.3 if args.cnn_mode == "fp32" else 2500.0
-        kname = "k_conv5<64,128,20,20,32> (conv3, fp32 MFMA)" if args.cnn_mode == "fp32" else f"k_conv5_bf16<64,128,20,20,{nprod}> (conv3, bf16 MFMA x{nprod} per fp32 product)"
+        kname = "k_conv5<64,128,20,20,32> (conv3, fp32 MFMA)" if args.cnn_mode == "fp32" else f"k_conv5_split<64,128,20,20,{args.cnn_mode}> (conv3, 16-bit MFMA x{nprod} per fp32 product)"
         out["roofline"] = {"kernel": kname, "bound": "mfma", "achieved": fl / c3_s / 1e12 if c3_s else 0.0,
                            "peak": peak, "unit": "TFLOP/s", "frac": fl / c3_s / (peak * 1e12) if c3_s else 0.0,
                            "mfma_products_per_algorithmic_product": nprod,

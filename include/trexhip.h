@@ -200,7 +200,7 @@ int trexhip_num_classes(trexhip_ctx* ctx);
 /* arithmetic of the two large convolutions: exact fp32 MFMA, or fp32-equivalent on the bf16 matrix cores (each
  * operand split into 3 bf16 pieces, 6 piece products per product; default), or the 3-product variant
  * (~2^-16 relative per product; NOT within the 1e-4 softmax bar in general -- for experiments only) */
-enum { TREXHIP_CNN_FP32 = 0, TREXHIP_CNN_BF16X6 = 1, TREXHIP_CNN_BF16X3 = 2 };
+enum { TREXHIP_CNN_FP32 = 0, TREXHIP_CNN_BF16X6 = 1, TREXHIP_CNN_BF16X3 = 2, TREXHIP_CNN_FP16X3 = 3 };
 int trexhip_set_identity_precision(trexhip_ctx* ctx, int32_t mode);
 /* VINetwork::probabilities (ml/VisualIdentification.cpp:440-458) -> predict_numpy
  * (visual_recognition_torch.py:290-352): crops are uint8 NHWC [n][80][80][C] (values 0..255, no

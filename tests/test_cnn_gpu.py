@@ -18,7 +18,7 @@ def make_net(st, classes):
     return seg
 
 
-@pytest.mark.parametrize("mode", [capi.CNN_FP32, capi.CNN_BF16X6])
+@pytest.mark.parametrize("mode", [capi.CNN_FP32, capi.CNN_BF16X6, capi.CNN_FP16X3])
 @pytest.mark.parametrize("classes", [8, 100, 256])
 def test_reference_vectors(classes, mode):
     z, st = load_fixture(classes)
@@ -35,7 +35,7 @@ def test_reference_vectors(classes, mode):
     seg.close()
 
 
-@pytest.mark.parametrize("mode", [capi.CNN_FP32, capi.CNN_BF16X6])
+@pytest.mark.parametrize("mode", [capi.CNN_FP32, capi.CNN_BF16X6, capi.CNN_FP16X3])
 def test_logits_and_device_path_vs_oracle(mode):
     z, st = load_fixture(100)
     seg = make_net(st, 100)
@@ -76,10 +76,31 @@ def test_precision_modes_error_ladder():
     crops = rng.integers(0, 256, (64, 80, 80, 1)).astype(np.uint8)
     ref, ref_logits = cnn_oracle.predict(st, crops, threads=8)
     errs = {}
-    for mode in (capi.CNN_FP32, capi.CNN_BF16X6, capi.CNN_BF16X3):
+    for mode in (capi.CNN_FP32, capi.CNN_BF16X6, capi.CNN_BF16X3, capi.CNN_FP16X3):
         seg.set_identity_precision(mode)
         errs[mode] = float(np.abs(seg.probabilities(crops) - ref).max())
-    print("max |dp| vs oracle: fp32 %.3g  bf16x6 %.3g  bf16x3 %.3g" % (errs[0], errs[1], errs[2]))
+    print("max |dp| vs oracle: fp32 %.3g  bf16x6 %.3g  bf16x3 %.3g  fp16x3 %.3g" % (errs[0], errs[1], errs[2], errs[3]))
     assert errs[capi.CNN_FP32] <= 1e-4 and errs[capi.CNN_BF16X6] <= 1e-4
     assert errs[capi.CNN_BF16X6] <= 20 * max(errs[capi.CNN_FP32], 1e-7)
+    assert errs[capi.CNN_FP16X3] <= 20 * max(errs[capi.CNN_FP32], 1e-7)
+    seg.close()
+
+
+def test_fp16_range_overflow_falls_back_on_the_device():
+    """Activations beyond the fp16 range (|a| >= 65520) cannot be split into fp16 pieces: the kernel raises a flag and the
+    guarded bf16x6 re-run replaces the result -- same answer as the exact path, never a silent inf/NaN."""
+    st = weights.synthetic_state(8, 31)
+    st = {k: v.copy() for k, v in st.items()}
+    st["conv1.weight"] *= 4000.0            # conv1 outputs ~1e5..1e6 => conv2's input leaves the fp16 range
+    st["bn1.running_var"] = np.full(16, 1.0, np.float32); st["bn1.running_mean"] = np.zeros(16, np.float32)
+    st["bn2.running_var"] = np.full(64, 1e10, np.float32)   # bring the scale back down so later layers stay finite
+    crops = weights.synthetic_crops(5, 77)
+    ref, _ = cnn_oracle.predict(st, crops, threads=4)
+    assert np.all(np.isfinite(ref))
+    seg = make_net(st, 8)
+    seg.set_identity_precision(capi.CNN_FP16X3)
+    got = seg.probabilities(crops)
+    assert np.all(np.isfinite(got)) and np.abs(got - ref).max() <= 1e-4
+    seg.set_identity_precision(capi.CNN_FP32)
+    assert np.abs(seg.probabilities(crops) - ref).max() <= 1e-4
     seg.close()

@@ -26,7 +26,7 @@ INFO_DTYPE = np.dtype([
 ])
 assert BLOB_DTYPE.itemsize == 104 and RUN_DTYPE.itemsize == 8 and INFO_DTYPE.itemsize == 48
 
-CNN_FP32, CNN_BF16X6, CNN_BF16X3 = 0, 1, 2
+CNN_FP32, CNN_BF16X6, CNN_BF16X3, CNN_FP16X3 = 0, 1, 2, 3
 STAGE_ROWS, STAGE_SEGMENT_ALL, STAGE_CONV2, STAGE_CONV3, STAGE_CNN_ALL, STAGE_CROPS, STAGE_POSTURE = 0, 1, 2, 3, 4, 5, 6
 
 

@@ -229,6 +229,7 @@ __global__ __launch_bounds__(512) void k_conv5(const float* __restrict__ in /*[N
 // stride); weights are pre-split on the host as [ci-chunk][tap][piece][k/8][co][8].
 // ------------------------------------------------------------------------------------------------
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
 __device__ __forceinline__ uint32_t bf16_rne(float x) {
     uint32_t u = __float_as_uint(x);
@@ -242,31 +243,55 @@ __device__ __forceinline__ void split3(float x, uint32_t& p1, uint32_t& p2, uint
     const float r2 = r1 - __uint_as_float(p2 << 16);
     p3 = bf16_rne(r2);
 }
+// fp16 variant: two pieces x = h1 + h2 carry 22 mantissa bits (plus an absolute floor of 3e-8 from fp16 subnormals),
+// so the three products h1g1, h1g2, h2g1 are already fp32-class.  fp16 cannot hold |x| >= 65520: such a value raises
+// the overflow flag and the host reruns the layer stack with the bf16 split (never a silent wrong answer).
+__device__ __forceinline__ void split2h(float x, uint32_t& p1, uint32_t& p2, bool& ovf) {
+    const _Float16 h1 = (_Float16)x;
+    ovf |= !(fabsf(x) < 65520.0f);
+    const float r1 = x - (float)h1;
+    const _Float16 h2 = (_Float16)r1;
+    p1 = __builtin_bit_cast(uint16_t, h1);
+    p2 = __builtin_bit_cast(uint16_t, h2);
+}
 
-template <int CI, int CO, int S, int ROWS>
+template <int KIND> struct SplitK;      // KIND 0 = bf16 (3 pieces), 1 = fp16 (2 pieces)
+template <> struct SplitK<0> { static constexpr int NP = 3; using frag = bf16x8; };
+template <> struct SplitK<1> { static constexpr int NP = 2; using frag = f16x8; };
+
+__device__ __forceinline__ f32x16 mfma16(bf16x8 a, bf16x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
+__device__ __forceinline__ f32x16 mfma16(f16x8 a, f16x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
+
+template <int CI, int CO, int S, int ROWS, int NP>
 struct ConvGeomB {
     static constexpr int CIC = 16;
     static constexpr int PW = S + 4, PH = ROWS + 4;
     static constexpr int PSTRIDE = 48;                                // bytes per pixel (32 data + 16 pad)
     static constexpr int PATCH = PH * PW * PSTRIDE;                   // bytes per piece
-    static constexpr int BT = 3 * 2 * CO * 16;                        // bytes per weight tile (3 pieces x 2 k-octets)
+    static constexpr int BT = NP * 2 * CO * 16;                       // bytes per weight tile (NP pieces x 2 k-octets)
     static constexpr int NPIX = ROWS * S;
     static constexpr int MT = (NPIX + 31) / 32;
     static constexpr int NT = CO / 32;
     static constexpr int WM = 8 / NT;
     static constexpr int TPW = (MT + WM - 1) / WM;
-    static constexpr int LDS_BYTES = 3 * PATCH + 2 * BT;
+    static constexpr int LDS_BYTES = NP * PATCH + 2 * BT;
     static constexpr int BPC = S / ROWS;
 };
 
-template <int CI, int CO, int S, int ROWS, int NTERMS>
-__global__ __launch_bounds__(512) void k_conv5_bf16(const float* __restrict__ in /*[N][S][S][CI]*/,
-                                                    const uint4* __restrict__ wp /*[CI/16][25][3][2][CO] x 16 B*/,
-                                                    const float* __restrict__ bias, float* __restrict__ out) {
-    using G = ConvGeomB<CI, CO, S, ROWS>;
+// KIND 0: NTERMS 6 (a3b1 a2b2 a1b3 a2b1 a1b2 a1b1) or 3 (last three);  KIND 1: NTERMS 3 (a2b1 a1b2 a1b1)
+template <int CI, int CO, int S, int ROWS, int KIND, int NTERMS>
+__global__ __launch_bounds__(512) void k_conv5_split(const float* __restrict__ in /*[N][S][S][CI]*/,
+                                                     const uint4* __restrict__ wp /*[CI/16][25][NP][2][CO] x 16 B*/,
+                                                     const float* __restrict__ bias, float* __restrict__ out,
+                                                     const float out_scale, uint32_t* __restrict__ overflow,
+                                                     const uint32_t* __restrict__ guard) {
+    if (guard && *guard == 0u) return;            // re-run pass: only when the fp16 pass flagged an overflow
+    using K = SplitK<KIND>;
+    using frag = typename K::frag;
+    using G = ConvGeomB<CI, CO, S, ROWS, K::NP>;
     extern __shared__ __attribute__((aligned(16))) uint8_t ldsb[];
-    uint8_t* patch = ldsb;                       // 3 pieces
-    uint8_t* Bs = ldsb + 3 * G::PATCH;           // 2 buffers
+    uint8_t* patch = ldsb;                       // NP pieces
+    uint8_t* Bs = ldsb + K::NP * G::PATCH;       // 2 buffers
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int j = lane & 31, h = lane >> 5;
     const int n = wave % G::NT, mg = wave / G::NT;
@@ -294,6 +319,7 @@ __global__ __launch_bounds__(512) void k_conv5_bf16(const float* __restrict__ in
     const float* inc = in + (size_t)crop * S * S * CI;
     constexpr int BV = G::BT / 16;                                      // uint4 per weight tile
     constexpr int BPT = (BV + 511) / 512;
+    bool ovf = false;
     for (int cc = 0; cc < CI / 16; ++cc) {
         __syncthreads();
         for (int idx = tid; idx < G::PH * G::PW * 4; idx += 512) {      // 4 float4 per pixel
@@ -304,12 +330,17 @@ __global__ __launch_bounds__(512) void k_conv5_bf16(const float* __restrict__ in
             if (iy >= 0 && iy < S && ix >= 0 && ix < S)
                 v = *reinterpret_cast<const float4*>(inc + ((size_t)iy * S + ix) * CI + cc * 16 + q * 4);
             uint32_t a1[4], a2[4], a3[4];
-            split3(v.x, a1[0], a2[0], a3[0]); split3(v.y, a1[1], a2[1], a3[1]);
-            split3(v.z, a1[2], a2[2], a3[2]); split3(v.w, a1[3], a2[3], a3[3]);
+            if (KIND == 0) {
+                split3(v.x, a1[0], a2[0], a3[0]); split3(v.y, a1[1], a2[1], a3[1]);
+                split3(v.z, a1[2], a2[2], a3[2]); split3(v.w, a1[3], a2[3], a3[3]);
+            } else {
+                split2h(v.x, a1[0], a2[0], ovf); split2h(v.y, a1[1], a2[1], ovf);
+                split2h(v.z, a1[2], a2[2], ovf); split2h(v.w, a1[3], a2[3], ovf);
+            }
             uint8_t* d = patch + px * G::PSTRIDE + q * 8;
             *reinterpret_cast<uint2*>(d) = make_uint2(a1[0] | (a1[1] << 16), a1[2] | (a1[3] << 16));
             *reinterpret_cast<uint2*>(d + G::PATCH) = make_uint2(a2[0] | (a2[1] << 16), a2[2] | (a2[3] << 16));
-            *reinterpret_cast<uint2*>(d + 2 * G::PATCH) = make_uint2(a3[0] | (a3[1] << 16), a3[2] | (a3[3] << 16));
+            if (KIND == 0) *reinterpret_cast<uint2*>(d + 2 * G::PATCH) = make_uint2(a3[0] | (a3[1] << 16), a3[2] | (a3[3] << 16));
         }
         const uint4* wsrc = wp + (size_t)cc * 25 * BV;
         for (int i = tid; i < BV; i += 512) reinterpret_cast<uint4*>(Bs)[i] = wsrc[i];
@@ -323,32 +354,18 @@ __global__ __launch_bounds__(512) void k_conv5_bf16(const float* __restrict__ in
             }
             const int tapoff = ((tap / 5) * G::PW + (tap % 5)) * G::PSTRIDE;
             const uint8_t* bsrc = Bs + buf * G::BT + (h * CO + n * 32 + j) * 16;
-            const bf16x8 b1 = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(bsrc));
-            const bf16x8 b2 = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(bsrc + 2 * CO * 16));
-            const bf16x8 b3 = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(bsrc + 4 * CO * 16));
+            const frag b1 = __builtin_bit_cast(frag, *reinterpret_cast<const uint4*>(bsrc));
+            const frag b2 = __builtin_bit_cast(frag, *reinterpret_cast<const uint4*>(bsrc + 2 * CO * 16));
+            frag b3 = b1;
+            if (K::NP == 3) b3 = __builtin_bit_cast(frag, *reinterpret_cast<const uint4*>(bsrc + 4 * CO * 16));
             const uint8_t* asrc = patch + tapoff;
-#define LDA(m, piece) __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(asrc + aoff[m] + (piece) * G::PATCH))
-#define MF(a, b, m) acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[m], 0, 0, 0)
-            // two output tiles at a time: their accumulation chains are interleaved so that consecutive MFMAs never
-            // depend on each other (a dependent 32x32x16 chain issues at half rate)
+#define LDA(m, piece) __builtin_bit_cast(frag, *reinterpret_cast<const uint4*>(asrc + aoff[m] + (piece) * G::PATCH))
+#define MF(a, b, m) acc[m] = mfma16(a, b, acc[m])
 #pragma unroll
-            for (int m = 0; m + 1 < G::TPW; m += 2) {
-                const bf16x8 p1 = LDA(m, 0), p2 = LDA(m, 1), q1 = LDA(m + 1, 0), q2 = LDA(m + 1, 1);
-                if (NTERMS == 6) {
-                    const bf16x8 p3 = LDA(m, 2), q3 = LDA(m + 1, 2);
-                    MF(p3, b1, m); MF(q3, b1, m + 1);
-                    MF(p2, b2, m); MF(q2, b2, m + 1);
-                    MF(p1, b3, m); MF(q1, b3, m + 1);
-                }
-                MF(p2, b1, m); MF(q2, b1, m + 1);
-                MF(p1, b2, m); MF(q1, b2, m + 1);
-                MF(p1, b1, m); MF(q1, b1, m + 1);
-            }
-            if (G::TPW & 1) {
-                constexpr int m = G::TPW - 1;
-                const bf16x8 p1 = LDA(m, 0), p2 = LDA(m, 1);
-                if (NTERMS == 6) {
-                    const bf16x8 p3 = LDA(m, 2);
+            for (int m = 0; m < G::TPW; ++m) {
+                const frag p1 = LDA(m, 0), p2 = LDA(m, 1);
+                if (KIND == 0 && NTERMS == 6) {
+                    const frag p3 = LDA(m, 2);
                     MF(p3, b1, m); MF(p2, b2, m); MF(p1, b3, m);
                 }
                 MF(p2, b1, m); MF(p1, b2, m); MF(p1, b1, m);
@@ -362,6 +379,7 @@ __global__ __launch_bounds__(512) void k_conv5_bf16(const float* __restrict__ in
             __syncthreads();
         }
     }
+    if (KIND == 1 && __any(ovf) && lane == 0) atomicOr(overflow, 1u);
     const int co = n * 32 + j;
     const float bz = bias[co];
     float* oc = out + (size_t)crop * WR * WR * CO;
@@ -375,7 +393,7 @@ __global__ __launch_bounds__(512) void k_conv5_bf16(const float* __restrict__ in
             if (wi >= G::NPIX / 4) continue;
             const float v = fmaxf(fmaxf(acc[m][4 * g], acc[m][4 * g + 1]), fmaxf(acc[m][4 * g + 2], acc[m][4 * g + 3]));
             const int wy = row0 / 2 + wi / WR, wx = wi % WR;
-            oc[((size_t)wy * WR + wx) * CO + co] = fmaxf(v + bz, 0.f);
+            oc[((size_t)wy * WR + wx) * CO + co] = fmaxf(v * out_scale + bz, 0.f);     // out_scale undoes the weight scaling (fp16 pieces)
         }
     }
 }
@@ -384,7 +402,9 @@ __global__ __launch_bounds__(512) void k_conv5_bf16(const float* __restrict__ in
 // fc1: out[N][128] = act[N][K] * W[K][128] + b     (K = 12800, 100 real outputs)
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_fc1(const float* __restrict__ act, const float* __restrict__ w /*[K][128]*/,
-                                             const float* __restrict__ bias /*[128]*/, float* __restrict__ out, int n, int K) {
+                                             const float* __restrict__ bias /*[128]*/, float* __restrict__ out, int n, int K,
+                                             const uint32_t* __restrict__ guard) {
+    if (guard && *guard == 0u) return;
     __shared__ float As[2][32 * 33];
     __shared__ __attribute__((aligned(16))) float Bs[2][32 * 128];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -453,7 +473,8 @@ __device__ __forceinline__ float wave_max(float v) {
 __global__ __launch_bounds__(256) void k_head(const float* __restrict__ fc1 /*[N][128]*/, const float* __restrict__ ln_g,
                                               const float* __restrict__ ln_b, const float* __restrict__ w2t /*[100][C]*/,
                                               const float* __restrict__ b2, float* __restrict__ probs /*[N][C]*/,
-                                              float* __restrict__ logits_out, int n, int C) {
+                                              float* __restrict__ logits_out, int n, int C, const uint32_t* __restrict__ guard) {
+    if (guard && *guard == 0u) return;
     __shared__ float ys[4][128];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int crop = blockIdx.x * 4 + wave;
@@ -503,6 +524,9 @@ __global__ __launch_bounds__(256) void k_head(const float* __restrict__ fc1 /*[N
 struct Net {
     int classes = 0, W = 0, H = 0, CH = 0, max_crops = 0;
     uint4 *w2s = nullptr, *w3s = nullptr;      // bf16-split conv weights
+    uint4 *w2h = nullptr, *w3h = nullptr;      // fp16-split conv weights (scaled by a power of two)
+    float inv2h = 1.f, inv3h = 1.f;
+    uint32_t* d_ovf = nullptr;
     float *w1 = nullptr, *b1 = nullptr, *w2 = nullptr, *b2 = nullptr, *w3 = nullptr, *b3 = nullptr;
     float *wf1 = nullptr, *bf1 = nullptr, *lng = nullptr, *lnb = nullptr, *wf2t = nullptr, *bf2 = nullptr;
     float *act1 = nullptr, *act2 = nullptr, *act3 = nullptr, *fc1 = nullptr, *probs = nullptr, *logits = nullptr;
@@ -517,6 +541,9 @@ static void free_net(Net* n) {
     for (float* p : d) if (p) (void)hipFree(p);
     if (n->w2s) (void)hipFree(n->w2s);
     if (n->w3s) (void)hipFree(n->w3s);
+    if (n->w2h) (void)hipFree(n->w2h);
+    if (n->w3h) (void)hipFree(n->w3h);
+    if (n->d_ovf) (void)hipFree(n->d_ovf);
     if (n->crops) (void)hipFree(n->crops);
     if (n->h_probs) (void)hipHostFree(n->h_probs);
     delete n;
@@ -574,6 +601,33 @@ static int upload_split(uint4** dst, const std::vector<float>& wp, int CI, int C
     return TREXHIP_OK;
 }
 
+// the same for the fp16 split: two pieces of w * 2^k, k chosen so that max|w| * 2^k is in [8192, 16384)
+static int upload_split_f16(uint4** dst, float* inv_scale, const std::vector<float>& wp, int CI, int CO) {
+    float mx = 0.f;
+    for (float v : wp) mx = std::fmax(mx, std::fabs(v));
+    int k = 0;
+    if (mx > 0.f) { k = (int)std::floor(std::log2(16384.0 / (double)mx)); if (k > 24) k = 24; if (k < -24) k = -24; }
+    const float sc = std::ldexp(1.0f, k);
+    *inv_scale = std::ldexp(1.0f, -k);
+    const int ncc = CI / 16;
+    std::vector<uint16_t> o((size_t)ncc * 25 * 2 * 2 * CO * 8);
+    for (int cc = 0; cc < ncc; ++cc)
+        for (int tap = 0; tap < 25; ++tap)
+            for (int kk = 0; kk < 16; ++kk)
+                for (int co = 0; co < CO; ++co) {
+                    const float x = wp[(((size_t)cc * 25 + tap) * 16 + kk) * CO + co] * sc;
+                    const _Float16 h1 = (_Float16)x;
+                    const _Float16 h2 = (_Float16)(x - (float)h1);
+                    uint16_t pc[2];
+                    std::memcpy(&pc[0], &h1, 2); std::memcpy(&pc[1], &h2, 2);
+                    for (int s = 0; s < 2; ++s)
+                        o[(((((size_t)cc * 25 + tap) * 2 + s) * 2 + kk / 8) * CO + co) * 8 + (kk & 7)] = pc[s];
+                }
+    TH_CHECK_HIP(hipMalloc(reinterpret_cast<void**>(dst), o.size() * 2));
+    TH_CHECK_HIP(hipMemcpy(*dst, o.data(), o.size() * 2, hipMemcpyHostToDevice));
+    return TREXHIP_OK;
+}
+
 int net_load(trexhip_ctx* ctx, const void* blob, size_t bytes) {
     if (bytes < 32) { set_error("trexhip_load_weights: blob too small"); return TREXHIP_E_INVALID; }
     int32_t hdr[8];
@@ -617,8 +671,11 @@ int net_load(trexhip_ctx* ctx, const void* blob, size_t bytes) {
     fold_conv(c2w, c2b, g2, be2, m2, v2, 64, 16, 16, wp, bias);
     TRY(upload(&net->w2, wp)); TRY(upload(&net->b2, bias));
     TRY(upload_split(&net->w2s, wp, 16, 64));
+    TRY(upload_split_f16(&net->w2h, &net->inv2h, wp, 16, 64));
     fold_conv(c3w, c3b, g3, be3, m3, v3, 128, 64, 16, wp, bias);       // 16-channel chunks for the bf16 path
     TRY(upload_split(&net->w3s, wp, 64, 128));
+    TRY(upload_split_f16(&net->w3h, &net->inv3h, wp, 64, 128));
+    if (rc == TREXHIP_OK && hipMalloc(reinterpret_cast<void**>(&net->d_ovf), 4) != hipSuccess) rc = TREXHIP_E_DEVICE;
     fold_conv(c3w, c3b, g3, be3, m3, v3, 128, 64, 32, wp, bias);
     TRY(upload(&net->w3, wp)); TRY(upload(&net->b3, bias));
     {   // fc1 [100][c*100+h*10+w] -> [(h*10+w)*128 + c][128 (o padded)]
@@ -678,10 +735,12 @@ int net_forward(trexhip_ctx* ctx, const uint8_t* d_crops, int n, float* d_probs,
                                          hipFuncAttributeMaxDynamicSharedMemorySize, G2::LDS_BYTES));
         TH_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv5<64, 128, 20, 20, 32>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, G3::LDS_BYTES));
-        TH_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv5_bf16<16, 64, 40, 10, 6>), hipFuncAttributeMaxDynamicSharedMemorySize, ConvGeomB<16, 64, 40, 10>::LDS_BYTES));
-        TH_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv5_bf16<16, 64, 40, 10, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, ConvGeomB<16, 64, 40, 10>::LDS_BYTES));
-        TH_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv5_bf16<64, 128, 20, 20, 6>), hipFuncAttributeMaxDynamicSharedMemorySize, ConvGeomB<64, 128, 20, 20>::LDS_BYTES));
-        TH_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv5_bf16<64, 128, 20, 20, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, ConvGeomB<64, 128, 20, 20>::LDS_BYTES));
+#define SET_ATTR(CI_, CO_, S_, ROWS_, KIND_, NT_)                                                                                      \
+        TH_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv5_split<CI_, CO_, S_, ROWS_, KIND_, NT_>),                     \
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (ConvGeomB<CI_, CO_, S_, ROWS_, SplitK<KIND_>::NP>::LDS_BYTES)))
+        SET_ATTR(16, 64, 40, 10, 0, 6); SET_ATTR(16, 64, 40, 10, 0, 3); SET_ATTR(16, 64, 40, 10, 1, 3);
+        SET_ATTR(64, 128, 20, 20, 0, 6); SET_ATTR(64, 128, 20, 20, 0, 3); SET_ATTR(64, 128, 20, 20, 1, 3);
+#undef SET_ATTR
         attr_done = true;
     }
     stage_begin(ctx, TREXHIP_STAGE_CNN_ALL);
@@ -689,29 +748,41 @@ int net_forward(trexhip_ctx* ctx, const uint8_t* d_crops, int n, float* d_probs,
     const size_t lds1 = ((size_t)net->CH * (S + 4) * (S + 4) + (size_t)net->CH * 25 * 16) * 4;
     if (net->CH == 1) hipLaunchKernelGGL((k_conv1<1>), dim3(n), dim3(256), lds1, s, d_crops, net->w1, net->b1, net->act1, S);
     else              hipLaunchKernelGGL((k_conv1<3>), dim3(n), dim3(256), lds1, s, d_crops, net->w1, net->b1, net->act1, S);
-    using B2 = ConvGeomB<16, 64, 40, 10>;
-    using B3 = ConvGeomB<64, 128, 20, 20>;
     const int mode = ctx->cnn_mode;
+    if (mode == TREXHIP_CNN_FP16X3) TH_CHECK_HIP(hipMemsetAsync(net->d_ovf, 0, 4, s));
+#define LAUNCH_SPLIT2 LAUNCH_SPLIT
     stage_begin(ctx, TREXHIP_STAGE_CONV2);
+#define LAUNCH_SPLIT(CI_, CO_, S_, ROWS_, KIND_, NT_, in_, w_, b_, out_, sc_, guard_)                                                    \
+    hipLaunchKernelGGL((k_conv5_split<CI_, CO_, S_, ROWS_, KIND_, NT_>), dim3(n * (ConvGeomB<CI_, CO_, S_, ROWS_, SplitK<KIND_>::NP>::BPC)), \
+                       dim3(512), (ConvGeomB<CI_, CO_, S_, ROWS_, SplitK<KIND_>::NP>::LDS_BYTES), s, in_, w_, b_, out_, sc_, net->d_ovf, guard_)
     if (mode == TREXHIP_CNN_FP32)
         hipLaunchKernelGGL((k_conv5<16, 64, 40, 20, 16>), dim3(n * G2::BPC), dim3(512), G2::LDS_BYTES, s, net->act1, net->w2, net->b2, net->act2);
-    else if (mode == TREXHIP_CNN_BF16X6)
-        hipLaunchKernelGGL((k_conv5_bf16<16, 64, 40, 10, 6>), dim3(n * B2::BPC), dim3(512), B2::LDS_BYTES, s, net->act1, net->w2s, net->b2, net->act2);
-    else
-        hipLaunchKernelGGL((k_conv5_bf16<16, 64, 40, 10, 3>), dim3(n * B2::BPC), dim3(512), B2::LDS_BYTES, s, net->act1, net->w2s, net->b2, net->act2);
+    else if (mode == TREXHIP_CNN_BF16X6) LAUNCH_SPLIT(16, 64, 40, 10, 0, 6, net->act1, net->w2s, net->b2, net->act2, 1.0f, (const uint32_t*)nullptr);
+    else if (mode == TREXHIP_CNN_BF16X3) LAUNCH_SPLIT(16, 64, 40, 10, 0, 3, net->act1, net->w2s, net->b2, net->act2, 1.0f, (const uint32_t*)nullptr);
+    else                                 LAUNCH_SPLIT(16, 64, 40, 10, 1, 3, net->act1, net->w2h, net->b2, net->act2, net->inv2h, (const uint32_t*)nullptr);
     stage_end(ctx, TREXHIP_STAGE_CONV2);
     stage_begin(ctx, TREXHIP_STAGE_CONV3);
     if (mode == TREXHIP_CNN_FP32)
         hipLaunchKernelGGL((k_conv5<64, 128, 20, 20, 32>), dim3(n * G3::BPC), dim3(512), G3::LDS_BYTES, s, net->act2, net->w3, net->b3, net->act3);
-    else if (mode == TREXHIP_CNN_BF16X6)
-        hipLaunchKernelGGL((k_conv5_bf16<64, 128, 20, 20, 6>), dim3(n * B3::BPC), dim3(512), B3::LDS_BYTES, s, net->act2, net->w3s, net->b3, net->act3);
-    else
-        hipLaunchKernelGGL((k_conv5_bf16<64, 128, 20, 20, 3>), dim3(n * B3::BPC), dim3(512), B3::LDS_BYTES, s, net->act2, net->w3s, net->b3, net->act3);
+    else if (mode == TREXHIP_CNN_BF16X6) LAUNCH_SPLIT(64, 128, 20, 20, 0, 6, net->act2, net->w3s, net->b3, net->act3, 1.0f, (const uint32_t*)nullptr);
+    else if (mode == TREXHIP_CNN_BF16X3) LAUNCH_SPLIT(64, 128, 20, 20, 0, 3, net->act2, net->w3s, net->b3, net->act3, 1.0f, (const uint32_t*)nullptr);
+    else                                 LAUNCH_SPLIT(64, 128, 20, 20, 1, 3, net->act2, net->w3h, net->b3, net->act3, net->inv3h, (const uint32_t*)nullptr);
     stage_end(ctx, TREXHIP_STAGE_CONV3);
-    hipLaunchKernelGGL(k_fc1, dim3((n + 31) / 32), dim3(256), 0, s, net->act3, net->wf1, net->bf1, net->fc1, n, 12800);
+    hipLaunchKernelGGL(k_fc1, dim3((n + 31) / 32), dim3(256), 0, s, net->act3, net->wf1, net->bf1, net->fc1, n, 12800, (const uint32_t*)nullptr);
     hipLaunchKernelGGL(k_head, dim3((n + 3) / 4), dim3(256), 0, s, net->fc1, net->lng, net->lnb, net->wf2t, net->bf2,
-                       d_probs, d_logits, n, net->classes);
+                       d_probs, d_logits, n, net->classes, (const uint32_t*)nullptr);
+    if (mode == TREXHIP_CNN_FP16X3) {
+        // guarded re-run with the bf16 split: every workgroup returns at once unless an activation left the fp16 range
+        const uint32_t* g = net->d_ovf;
+        LAUNCH_SPLIT2(16, 64, 40, 10, 0, 6, net->act1, net->w2s, net->b2, net->act2, 1.0f, g);
+        LAUNCH_SPLIT2(64, 128, 20, 20, 0, 6, net->act2, net->w3s, net->b3, net->act3, 1.0f, g);
+        hipLaunchKernelGGL(k_fc1, dim3((n + 31) / 32), dim3(256), 0, s, net->act3, net->wf1, net->bf1, net->fc1, n, 12800, g);
+        hipLaunchKernelGGL(k_head, dim3((n + 3) / 4), dim3(256), 0, s, net->fc1, net->lng, net->lnb, net->wf2t, net->bf2,
+                           d_probs, d_logits, n, net->classes, g);
+    }
     stage_end(ctx, TREXHIP_STAGE_CNN_ALL);
+#undef LAUNCH_SPLIT
+#undef LAUNCH_SPLIT2
     TH_CHECK_HIP(hipGetLastError());
     return TREXHIP_OK;
 }
@@ -758,7 +829,7 @@ int trexhip_identify(trexhip_ctx* ctx, const uint8_t* crops, int32_t n, float* p
 }
 
 int trexhip_set_identity_precision(trexhip_ctx* ctx, int32_t mode) {
-    if (!ctx || mode < 0 || mode > 2) { set_error("trexhip_set_identity_precision: mode must be TREXHIP_CNN_FP32 / _BF16X6 / _BF16X3"); return TREXHIP_E_INVALID; }
+    if (!ctx || mode < 0 || mode > 3) { set_error("trexhip_set_identity_precision: mode must be one of TREXHIP_CNN_*"); return TREXHIP_E_INVALID; }
     ctx->cnn_mode = mode;
     return TREXHIP_OK;
 }
