@@ -43,8 +43,8 @@ def main():
     ap.add_argument("--config", default="C4")
     ap.add_argument("--batch", type=int, default=0, help="frames resident per step (default 64, C5: 16)")
     ap.add_argument("--stages", default="all", choices=["all", "segment"])
-    ap.add_argument("--cnn-mode", default="bf16x6", choices=["fp32", "bf16x6", "bf16x3", "fp16x3"],
-                    help="arithmetic of conv2/conv3: exact fp32 MFMA or the fp32-equivalent 6-product bf16 split (default)")
+    ap.add_argument("--cnn-mode", default="fp16x3", choices=["fp32", "bf16x6", "bf16x3", "fp16x3"],
+                    help="arithmetic of conv2/conv3: fp16x3 = 2-piece fp16 split, fp32-class error, range-guarded (default); bf16x6 = 3-piece bf16 split; fp32 = exact fp32 MFMA")
     ap.add_argument("--with-posture", action="store_true", help="also run posture (outline -> midline) for every blob inside the timed step (configs C3/C5)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
