@@ -175,7 +175,7 @@ def main():
         "vs_baseline": None, "dtype": ({"fp32": "f32", "bf16x6": "bf16x6-split (fp32-equivalent: 3 bf16 pieces per operand, 6 MFMA products, fp32 accumulate)", "bf16x3": "bf16x3-split", "fp16x3": "fp16x3-split (fp32-class: 2 fp16 pieces per operand = 22 mantissa bits, 3 MFMA products, fp32 accumulate, range-guarded)"}[args.cnn_mode] if with_cnn else "u8"), "data": "synthetic",
         "config": {"workload": f"{args.config}: {W}x{H} gray, {n_ind} individuals/frame, {B} frames resident per step per GPU, "
                                f"80x80x1 crops, {classes}-way V118_3 (random-init weights)",
-                   "stages": "detect(bg-sub+threshold+CCL+filter+gather, tables->host) + crops(none) + identity CNN fp32 + per-blob ID table (all-gathered when N>1) -> rank-0 host"
+                   "stages": "detect(bg-sub+threshold+CCL+filter+gather, tables->host) + crops(none) + identity CNN (V118_3) + per-blob ID table (all-gathered when N>1) -> rank-0 host"
                              if with_cnn else "detect only (bg-sub+threshold+CCL+filter+gather, tables->host)",
                    "frames_per_step_per_gpu": B, "blobs_per_step_rank0": n_blobs, "parallelism": f"frame-sharded x{world}"},
     }
@@ -195,7 +195,7 @@ def main():
                            "peak": peak, "unit": "TFLOP/s", "frac": fl / c3_s / (peak * 1e12) if c3_s else 0.0,
                            "mfma_products_per_algorithmic_product": nprod,
                            "mfma_issue_frac": nprod * fl / c3_s / (peak * 1e12) if c3_s else 0.0,
-                           "traffic": pmc_traffic("trexhip::k_conv5<64, 128") if args.cnn_mode == "fp32" else None,
+                           "traffic": pmc_traffic("trexhip::k_conv5_split<64, 128, 20, 20, 1, 3") if args.cnn_mode == "fp16x3" else None,
                            "traffic_note": "HBM bytes/launch from profiles/r01_pmc_summary.json (FETCH_SIZE x2 + WRITE_SIZE); algorithmic bytes = 0.98 GB (activations in+out)",
                            "avg_launch_us": c3_s * 1e6, "launches": prof["CONV3"][1], "algorithmic_flop_per_launch": fl,
                            "peak_note": "achieved counts ALGORITHMIC flops (2 per fp32 multiply-add); peak is the dense MFMA peak of the instruction used (fp32: 157.3, bf16: 2500 TFLOP/s, MI355X_MICROARCH.md); in the split modes every algorithmic product costs `mfma_products_per_algorithmic_product` bf16 MFMA products, so the matrix pipe is busy mfma_issue_frac of its peak"}
