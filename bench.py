@@ -46,6 +46,7 @@ def main():
     ap.add_argument("--cnn-mode", default="fp16x3", choices=["fp32", "bf16x6", "bf16x3", "fp16x3"],
                     help="arithmetic of conv2/conv3: fp16x3 = 2-piece fp16 split, fp32-class error, range-guarded (default); bf16x6 = 3-piece bf16 split; fp32 = exact fp32 MFMA")
     ap.add_argument("--with-posture", action="store_true", help="also run posture (outline -> midline) for every blob inside the timed step (configs C3/C5)")
+    ap.add_argument("--no-pipeline", dest="pipeline", action="store_false", help="one context, strictly serial steps (no overlap of detect(i+1) with identity(i))")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     args = ap.parse_args()
@@ -73,56 +74,90 @@ def main():
     # frame-sharded: rank r owns frames r*B .. r*B+B-1 of every step's block (distinct data per rank)
     frames, bg = synth.batch_torch(args.config, B, dev, t0=rank * B)
     max_blobs = 4 * n_ind
-    p = capi.default_params(W, H, device=local, max_batch=B, max_blobs=max_blobs, max_pixels=1 << 18, max_runs=32768)
-    seg = capi.Segmenter(p)
-    seg.set_background(bg)
     state = weights.synthetic_state(classes, 4242)
-    if with_cnn:
-        seg.load_weights(weights.pack_blob(state, classes))
-        seg.set_identity_precision({"fp32": 0, "bf16x6": 1, "bf16x3": 2, "fp16x3": 3}[args.cnn_mode])
-    pool = B * max_blobs
-    crops = torch.empty((pool, 80, 80), dtype=torch.uint8, device=dev)
-    probs = torch.empty((pool, classes), dtype=torch.float32, device=dev)
     from trex_amd import dist as tdist
+    pool = B * max_blobs
     rows = B * n_ind * 5 // 4                       # fixed table rows per rank per step (all-gather needs equal sizes)
-    table = torch.zeros((rows, tdist.HDR + classes), dtype=torch.int32, device=dev)
-    table_host = torch.empty((world * rows, tdist.HDR + classes), dtype=torch.int32).pin_memory() if rank == 0 else None
     MP = 256
-    if args.with_posture:
-        p_outline = torch.empty((pool, MP, 2), dtype=torch.float32, device=dev)
-        p_segs = torch.empty((pool, MP // 2 + 1, 4), dtype=torch.float32, device=dev)
-        p_info = torch.empty((pool, 8), dtype=torch.int32, device=dev)
-    own = torch.cuda.Stream(device=dev)            # torch-side copies ride on the same stream as the kernels
-    seg.set_stream(own.cuda_stream)
+
+    class Lane:
+        """One context + its buffers + its stream.  Two lanes are software-pipelined: while lane A's identity network
+        works on batch i, lane B runs the detect stage of batch i+1 and its tables travel to the host."""
+        def __init__(self):
+            p = capi.default_params(W, H, device=local, max_batch=B, max_blobs=max_blobs, max_pixels=1 << 18, max_runs=32768)
+            self.seg = capi.Segmenter(p)
+            self.seg.set_background(bg)
+            if with_cnn:
+                self.seg.load_weights(weights.pack_blob(state, classes))
+                self.seg.set_identity_precision({"fp32": 0, "bf16x6": 1, "bf16x3": 2, "fp16x3": 3}[args.cnn_mode])
+            self.crops = torch.empty((pool, 80, 80), dtype=torch.uint8, device=dev)
+            self.probs = torch.empty((pool, classes), dtype=torch.float32, device=dev)
+            self.table = torch.zeros((rows, tdist.HDR + classes), dtype=torch.int32, device=dev)
+            self.table_host = torch.empty((world * rows, tdist.HDR + classes), dtype=torch.int32).pin_memory() if rank == 0 else None
+            if args.with_posture:
+                self.p_outline = torch.empty((pool, MP, 2), dtype=torch.float32, device=dev)
+                self.p_segs = torch.empty((pool, MP // 2 + 1, 4), dtype=torch.float32, device=dev)
+                self.p_info = torch.empty((pool, 8), dtype=torch.int32, device=dev)
+            self.stream = torch.cuda.Stream(device=dev)   # torch-side copies ride on the same stream as the kernels
+            self.seg.set_stream(self.stream.cuda_stream)
+            self.n = 0
+            self.done = torch.cuda.Event()
+            self.after = None                       # lane whose identity stage must finish before this lane's starts
+
+        def detect(self):
+            self.seg.segment_device(frames.data_ptr(), B)
+
+        def identify(self, step_idx):
+            seg = self.seg
+            res = seg.fetch(copy=False)             # waits for detect; blob/run/pixel tables now on this rank's host
+            n = self.n = sum(len(r.blobs) for r in res)
+            assert n <= rows, "identity table too small"
+            if self.after is not None:              # keep one identity stage on the GPU at a time: only detect(i+1) overlaps it
+                self.stream.wait_event(self.after.done)
+            if args.with_posture and n:
+                seg.posture_device(n, self.p_outline.data_ptr(), self.p_segs.data_ptr(), self.p_info.data_ptr(), max_points=MP)
+            if with_cnn:
+                if n:
+                    seg.crops_device(self.crops.data_ptr(), n)
+                    seg.identify_device(self.crops.data_ptr(), n, self.probs.data_ptr())
+                # per-blob identity table -> (all-gather over RCCL/xGMI) -> rank 0's host, for the sequential matcher
+                frame_base = (step_idx * world + rank) * B
+                seg.export_id_table(self.probs.data_ptr(), n, classes, frame_base, self.table.data_ptr(), rows)
+                with torch.cuda.stream(self.stream):
+                    g = tdist.all_gather_tables(self.table) if world > 1 else self.table
+                    if rank == 0:
+                        self.table_host.copy_(g, non_blocking=True)
+            self.done.record(self.stream)
+
+        def drain(self):
+            self.stream.synchronize()
+
+    lanes = [Lane(), Lane()] if args.pipeline else [Lane()]
+    if len(lanes) == 2:
+        lanes[0].after, lanes[1].after = lanes[1], lanes[0]
+        lanes[0].done.record(lanes[0].stream); lanes[1].done.record(lanes[1].stream)
+    seg = lanes[0].seg
     torch.cuda.synchronize()
 
-    step_no = [0]
+    def run(k):
+        """k steps = k batches through detect -> (posture) -> crops -> identity -> table on the host."""
+        L = len(lanes)
+        lanes[0].detect()
+        for i in range(k):
+            cur = lanes[i % L]
+            cur.identify(i)                         # enqueue everything downstream of detect(i)
+            if i + 1 < k:
+                nxt = lanes[(i + 1) % L]
+                if L > 1:
+                    nxt.drain()                     # its previous batch (i-1) is complete: table_host consumed by the matcher
+                else:
+                    cur.drain()
+                nxt.detect()                        # detect(i+1) overlaps the identity network of batch i
+        for ln in lanes:
+            ln.drain()
+        return lanes[(k - 1) % L].n
 
-    def step():
-        seg.segment_device(frames.data_ptr(), B)
-        res = seg.fetch(copy=False)                 # syncs; blob/run/pixel tables now on this rank's host
-        n = sum(len(r.blobs) for r in res)
-        assert n <= rows, "identity table too small"
-        if args.with_posture and n:
-            seg.posture_device(n, p_outline.data_ptr(), p_segs.data_ptr(), p_info.data_ptr(), max_points=MP)
-        if with_cnn:
-            if n:
-                seg.crops_device(crops.data_ptr(), n)
-                seg.identify_device(crops.data_ptr(), n, probs.data_ptr())
-            # per-blob identity table -> (all-gather over RCCL/xGMI) -> rank 0's host, for the sequential matcher
-            frame_base = (step_no[0] * world + rank) * B
-            seg.export_id_table(probs.data_ptr(), n, classes, frame_base, table.data_ptr(), rows)
-            with torch.cuda.stream(own):
-                g = tdist.all_gather_tables(table) if world > 1 else table
-                if rank == 0:
-                    table_host.copy_(g, non_blocking=True)
-            own.synchronize()
-        step_no[0] += 1
-        return n
-
-    n_blobs = 0
-    for _ in range(args.warmup):
-        n_blobs = step()
+    n_blobs = run(args.warmup) if args.warmup else 0
 
     def barrier():
         torch.cuda.synchronize()
@@ -130,21 +165,37 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    seg.profile_enable(True)
-    seg.profile_reset()
+    for ln in lanes:
+        ln.seg.profile_enable(True)
+        ln.seg.profile_reset()
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        n_blobs = step()
+    n_blobs = run(args.steps)
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-    prof = {name: seg.profile_read(getattr(capi, "STAGE_" + name)) for name in
-            ("ROWS", "SEGMENT_ALL", "CONV2", "CONV3", "CNN_ALL", "CROPS", "POSTURE")}
-    seg.profile_enable(False)
+    prof = {}
+    for name in ("ROWS", "SEGMENT_ALL", "CONV2", "CONV3", "CNN_ALL", "CROPS", "POSTURE"):
+        ms = cnt = 0
+        for ln in lanes:
+            a_, b_ = ln.seg.profile_read(getattr(capi, "STAGE_" + name))
+            ms += a_; cnt += b_
+        prof[name] = (ms, cnt)
+    # the detect stage overlaps the identity network of the previous batch when two lanes are pipelined, so its in-flight
+    # HIP-event durations include time lost to sharing the CUs; its roofline is taken from a short serial pass afterwards
+    if len(lanes) > 1:
+        ln0 = lanes[0]
+        ln0.seg.profile_reset()
+        for _ in range(5):
+            ln0.detect()
+            ln0.seg.fetch(copy=False)
+        prof["ROWS"] = ln0.seg.profile_read(capi.STAGE_ROWS)
+        prof["SEGMENT_ALL"] = ln0.seg.profile_read(capi.STAGE_SEGMENT_ALL)
+    for ln in lanes:
+        ln.seg.profile_enable(False)
 
     def pmc_traffic(kernel_prefix):
         """HBM bytes per launch from the committed PMC pass of this same command (profiles/r01_pmc_summary.json);
@@ -177,13 +228,13 @@ def main():
                                f"80x80x1 crops, {classes}-way V118_3 (random-init weights)",
                    "stages": "detect(bg-sub+threshold+CCL+filter+gather, tables->host) + crops(none) + identity CNN (V118_3) + per-blob ID table (all-gathered when N>1) -> rank-0 host"
                              if with_cnn else "detect only (bg-sub+threshold+CCL+filter+gather, tables->host)",
-                   "frames_per_step_per_gpu": B, "blobs_per_step_rank0": n_blobs, "parallelism": f"frame-sharded x{world}"},
+                   "frames_per_step_per_gpu": B, "pipelined_lanes": len(lanes), "blobs_per_step_rank0": n_blobs, "parallelism": f"frame-sharded x{world}"},
     }
     seg_roof = {"kernel": "k_rows", "bound": "hbm", "achieved": seg_bytes / rows_s / 1e9 if rows_s else 0.0, "peak": 8000.0,
                 "unit": "GB/s", "frac": seg_bytes / rows_s / 8e12 if rows_s else 0.0, "traffic": pmc_traffic("trexhip::k_rows"),
                 "traffic_note": "bytes/launch, FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE, separate --pmc passes, profiles/r01_pmc_summary.json",
                 "avg_launch_us": rows_s * 1e6, "launches": prof["ROWS"][1], "algorithmic_bytes_per_launch": seg_bytes,
-                "whole_detect_pass_us": segall_s * 1e6,
+                "whole_detect_pass_us": segall_s * 1e6, "timing": "HIP events on the kernel stream; 5 serial detect passes after the timed region when lanes are pipelined (in-flight the stage shares the GPU with the identity network)",
                 "whole_detect_pass_frac": seg_bytes / segall_s / 8e12 if segall_s else None}
     if with_cnn:
         c3_s = avg_s("CONV3")
@@ -244,7 +295,8 @@ def main():
         out["cpu_baseline"] = cpu
     if rank == 0:
         print(json.dumps(out))
-    seg.close()
+    for ln in lanes:
+        ln.seg.close()
     if world > 1:
         dist.destroy_process_group()
 
