@@ -133,6 +133,12 @@ int trexhip_set_stream(trexhip_ctx* ctx, void* hip_stream);
 int trexhip_set_background(trexhip_ctx* ctx, const uint8_t* gray, int32_t stride);
 int trexhip_set_background_device(trexhip_ctx* ctx, const uint8_t* d_gray);
 
+/* background model from n sampled gray frames in HBM ("next" row of SURVEY.md 8f: Segmenter::trigger_average_generator,
+ * ui/Segmenter.cpp:467-566; averaging_method grabber/misc/default_config.cpp:131): method 0 = mean (float accumulation in
+ * sample order, rounded half-to-even), 1 = max, 2 = min; the result becomes the context's background. */
+int trexhip_generate_average_device(trexhip_ctx* ctx, const uint8_t* d_frames, int32_t n, int32_t method);
+int trexhip_get_background(trexhip_ctx* ctx, uint8_t* gray, int32_t stride);
+
 /* BackgroundSubtraction::apply(std::vector<TileImage>&&) hot loop (BackgroundSubtraction.cpp:146-316):
  * generate_binary + CPULabeling::run + size filter for n gray frames. */
 int trexhip_segment_device(trexhip_ctx* ctx, const uint8_t* d_frames, int32_t n);

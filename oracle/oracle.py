@@ -269,3 +269,18 @@ def trace_outline(runs, origin=(0, 0), cap=100000):
     out = np.zeros((cap, 2), np.float32)
     n = lib().oracle_trace_outline(_ptr(runs), len(runs), int(origin[0]), int(origin[1]), _ptr(out), cap)
     return out[:n].copy()
+
+
+def generate_average(frames, method=0):
+    """Background from sampled gray frames: mean (float32 accumulation in sample order, cv::Mat::convertTo rounding =
+    half to even), max or min (averaging_method, grabber/misc/default_config.cpp:131; sampler body in commons).  The mean
+    variant reproduces the reference's golden CSVs best among the candidates tried."""
+    frames = np.asarray(frames)
+    if method == 1:
+        return frames.max(0).astype(np.uint8)
+    if method == 2:
+        return frames.min(0).astype(np.uint8)
+    acc = np.zeros(frames.shape[1:], np.float32)
+    for f in frames:
+        acc += f.astype(np.float32)
+    return np.clip(np.rint(acc / np.float32(len(frames))), 0, 255).astype(np.uint8)

@@ -221,3 +221,18 @@ def test_morphology_bit_exact(kw, shape):
     fr[0, :] = 5; fr[:, W - 1] = 7             # foreground on the borders (border handling of the element)
     res = run_gpu(fr[None], bg, **kw)
     assert_frame_equal(res[0], fr, bg, **kw)
+
+
+@pytest.mark.parametrize("method", [0, 1, 2])
+def test_background_from_samples(method):
+    rng = np.random.default_rng(method)
+    H, W, n = 48, 160, 37
+    fr = rng.integers(0, 256, (n, H, W)).astype(np.uint8)
+    fr[:, 3, :] = np.arange(n)[:, None] % 2 * 255          # means ending in .5 exercise the rounding rule
+    seg = capi.Segmenter(capi.default_params(W, H, max_batch=1))
+    d = torch.from_numpy(fr).cuda()
+    got = seg.generate_average(d.data_ptr(), n, method)
+    assert np.array_equal(got, oracle.generate_average(fr, method))
+    seg.segment_device(d.data_ptr(), 1)                    # the generated image is the context's background now
+    seg.fetch()
+    seg.close()

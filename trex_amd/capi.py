@@ -74,7 +74,7 @@ class TrexHipError(RuntimeError):
 # every symbol include/trexhip.h declares (tests check the library exports all of them)
 SYMBOLS = [
     "trexhip_abi_version", "trexhip_last_error", "trexhip_default_params", "trexhip_create", "trexhip_destroy",
-    "trexhip_set_stream", "trexhip_set_background", "trexhip_set_background_device", "trexhip_segment_device",
+    "trexhip_set_stream", "trexhip_set_background", "trexhip_set_background_device", "trexhip_generate_average_device", "trexhip_get_background", "trexhip_segment_device",
     "trexhip_segment", "trexhip_segment_color", "trexhip_rethreshold_device", "trexhip_fetch_rethreshold", "trexhip_fetch", "trexhip_device_view_get", "trexhip_synchronize",
     "trexhip_profile_enable", "trexhip_profile_read", "trexhip_profile_reset",
     "trexhip_default_posture_params", "trexhip_posture_device", "trexhip_crops_device", "trexhip_export_id_table_device", "trexhip_load_weights", "trexhip_set_identity_precision", "trexhip_num_classes", "trexhip_identify_device", "trexhip_identify",
@@ -96,6 +96,8 @@ def lib():
         L.trexhip_set_stream.argtypes = [C.c_void_p, C.c_void_p]
         L.trexhip_set_background.argtypes = [C.c_void_p, C.c_void_p, C.c_int32]
         L.trexhip_set_background_device.argtypes = [C.c_void_p, C.c_void_p]
+        L.trexhip_generate_average_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32]
+        L.trexhip_get_background.argtypes = [C.c_void_p, C.c_void_p, C.c_int32]
         L.trexhip_segment_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int32]
         L.trexhip_segment.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.c_int32, C.c_int32]
         L.trexhip_segment_color.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.c_int32, C.c_int32, C.c_int32, C.c_int32]
@@ -193,6 +195,13 @@ class Segmenter:
         else:
             assert bg.is_cuda and bg.is_contiguous() and bg.numel() == self.params.height * self.params.width
             _check(lib().trexhip_set_background_device(self._h, C.c_void_p(bg.data_ptr())))
+
+    def generate_average(self, d_frames_ptr, n, method=0):
+        """Background = per-pixel mean (0) / max (1) / min (2) of n HBM-resident gray frames; returns it as numpy."""
+        _check(lib().trexhip_generate_average_device(self._h, C.c_void_p(d_frames_ptr), n, method))
+        out = np.empty((self.params.height, self.params.width), np.uint8)
+        _check(lib().trexhip_get_background(self._h, out.ctypes.data_as(C.c_void_p), out.shape[1]))
+        return out
 
     def segment_device(self, d_ptr, n):
         """Enqueue the detect stage for n HBM-resident gray frames at device address d_ptr."""

@@ -745,6 +745,7 @@ int net_forward(trexhip_ctx* ctx, const uint8_t* d_crops, int n, float* d_probs,
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (ConvGeomB<CI_, CO_, S_, ROWS_, SplitK<KIND_>::NP, CIC_>::LDS_BYTES)))
         SET_ATTR(16, 64, 40, 10, 0, 6); SET_ATTR(16, 64, 40, 10, 0, 3); SET_ATTR(16, 64, 40, 10, 1, 3);
         SET_ATTR(64, 128, 20, 20, 0, 6); SET_ATTR(64, 128, 20, 20, 0, 3); SET_ATTR(64, 128, 20, 20, 1, 3);
+        SET_ATTR(16, 64, 40, 20, 1, 3); SET_ATTR(64, 128, 20, 10, 1, 3);
 #undef SET_ATTR
 #undef SET_ATTRC
         attr_done = true;
@@ -766,6 +767,7 @@ int net_forward(trexhip_ctx* ctx, const uint8_t* d_crops, int n, float* d_probs,
         hipLaunchKernelGGL((k_conv5<16, 64, 40, 20, 16>), dim3(n * G2::BPC), dim3(512), G2::LDS_BYTES, s, net->act1, net->w2, net->b2, net->act2);
     else if (mode == TREXHIP_CNN_BF16X6) LAUNCH_SPLIT(16, 64, 40, 10, 0, 6, net->act1, net->w2s, net->b2, net->act2, 1.0f, (const uint32_t*)nullptr);
     else if (mode == TREXHIP_CNN_BF16X3) LAUNCH_SPLIT(16, 64, 40, 10, 0, 3, net->act1, net->w2s, net->b2, net->act2, 1.0f, (const uint32_t*)nullptr);
+    else if (ctx->tune_conv_geom & 1)    LAUNCH_SPLIT(16, 64, 40, 20, 1, 3, net->act1, net->w2h, net->b2, net->act2, net->inv2h, (const uint32_t*)nullptr);
     else                                 LAUNCH_SPLIT(16, 64, 40, 10, 1, 3, net->act1, net->w2h, net->b2, net->act2, net->inv2h, (const uint32_t*)nullptr);
     stage_end(ctx, TREXHIP_STAGE_CONV2);
     stage_begin(ctx, TREXHIP_STAGE_CONV3);
@@ -773,6 +775,7 @@ int net_forward(trexhip_ctx* ctx, const uint8_t* d_crops, int n, float* d_probs,
         hipLaunchKernelGGL((k_conv5<64, 128, 20, 20, 32>), dim3(n * G3::BPC), dim3(512), G3::LDS_BYTES, s, net->act2, net->w3, net->b3, net->act3);
     else if (mode == TREXHIP_CNN_BF16X6) LAUNCH_SPLIT(64, 128, 20, 20, 0, 6, net->act2, net->w3s, net->b3, net->act3, 1.0f, (const uint32_t*)nullptr);
     else if (mode == TREXHIP_CNN_BF16X3) LAUNCH_SPLIT(64, 128, 20, 20, 0, 3, net->act2, net->w3s, net->b3, net->act3, 1.0f, (const uint32_t*)nullptr);
+    else if (ctx->tune_conv_geom & 2)    LAUNCH_SPLIT(64, 128, 20, 10, 1, 3, net->act2, net->w3h, net->b3, net->act3, net->inv3h, (const uint32_t*)nullptr);
     else                                 LAUNCH_SPLIT(64, 128, 20, 20, 1, 3, net->act2, net->w3h, net->b3, net->act3, net->inv3h, (const uint32_t*)nullptr);   // 32-channel chunks (CIC=32) measured slower: 3.7 vs 3.0 ms
     stage_end(ctx, TREXHIP_STAGE_CONV3);
     hipLaunchKernelGGL(k_fc1, dim3((n + 31) / 32), dim3(256), 0, s, net->act3, net->wf1, net->bf1, net->fc1, n, 12800, (const uint32_t*)nullptr);

@@ -213,3 +213,75 @@ extern "C" int trexhip_segment_color(trexhip_ctx* ctx, const uint8_t* const* fra
     if (rc) return rc;
     return launch_segment(ctx, ctx->d_staging, n);
 }
+
+// ------------------------------------------------------------------------------------------------
+// background model from sampled frames (Segmenter::trigger_average_generator, ui/Segmenter.cpp:467-566 ->
+// VideoSource::generate_average [commons]; settings averaging_method / average_samples,
+// grabber/misc/default_config.cpp:131-132): per pixel mean (float accumulation in sample order, rounded
+// half-to-even like cv::Mat::convertTo), max or min over n gray frames.  16 pixels per thread.
+// ------------------------------------------------------------------------------------------------
+namespace trexhip {
+__global__ __launch_bounds__(256) void k_average(const uint8_t* __restrict__ frames, uint8_t* __restrict__ bg, size_t npix16,
+                                                 size_t frame_stride, int n, int method) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= npix16) return;
+    float acc[16];
+    uint32_t ext[4];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) acc[k] = 0.f;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) ext[w] = method == 2 ? 0xffffffffu : 0u;
+    for (int f = 0; f < n; ++f) {
+        const uint4 v = *reinterpret_cast<const uint4*>(frames + (size_t)f * frame_stride + i * 16);
+        const uint32_t w4[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int w = 0; w < 4; ++w)
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const uint32_t p = (w4[w] >> (8 * b)) & 0xffu;
+                if (method == 0) acc[4 * w + b] += (float)p;
+                else {
+                    const uint32_t c = (ext[w] >> (8 * b)) & 0xffu;
+                    const uint32_t r = method == 1 ? max(c, p) : min(c, p);
+                    ext[w] = (ext[w] & ~(0xffu << (8 * b))) | (r << (8 * b));
+                }
+            }
+    }
+    if (method == 0) {
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            uint32_t o = 0;
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const float m = acc[4 * w + b] / (float)n;
+                o |= (uint32_t)min(max((int)rintf(m), 0), 255) << (8 * b);
+            }
+            ext[w] = o;
+        }
+    }
+    *reinterpret_cast<uint4*>(bg + i * 16) = make_uint4(ext[0], ext[1], ext[2], ext[3]);
+}
+}  // namespace trexhip
+
+extern "C" int trexhip_generate_average_device(trexhip_ctx* ctx, const uint8_t* d_frames, int32_t n, int32_t method) {
+    using namespace trexhip;
+    if (!ctx || !d_frames) { set_error("trexhip_generate_average_device: null argument"); return TREXHIP_E_INVALID; }
+    if (n < 1) { set_error("trexhip_generate_average_device: need at least one sample"); return TREXHIP_E_INVALID; }
+    if (method < 0 || method > 2) { set_error("trexhip_generate_average_device: averaging_method mode is not implemented (0 mean, 1 max, 2 min)"); return TREXHIP_E_UNSUPPORTED; }
+    const size_t npix = (size_t)ctx->p.width * ctx->p.height;
+    if (npix % 16 != 0 || (reinterpret_cast<uintptr_t>(d_frames) & 15)) { set_error("trexhip_generate_average_device: width*height must be a multiple of 16 and the frames 16-byte aligned"); return TREXHIP_E_UNSUPPORTED; }
+    TH_CHECK_HIP(hipSetDevice(ctx->p.device));
+    const size_t n16 = npix / 16;
+    hipLaunchKernelGGL(k_average, dim3((unsigned)((n16 + 255) / 256)), dim3(256), 0, ctx->stream, d_frames, ctx->d_bg, n16, npix, n, method);
+    TH_CHECK_HIP(hipGetLastError());
+    TH_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+    ctx->has_bg = true;
+    return TREXHIP_OK;
+}
+
+extern "C" int trexhip_get_background(trexhip_ctx* ctx, uint8_t* gray, int32_t stride) {
+    using namespace trexhip;
+    if (!ctx || !gray || !ctx->has_bg) { set_error("trexhip_get_background: no background"); return TREXHIP_E_INVALID; }
+    TH_CHECK_HIP(hipMemcpy2D(gray, stride, ctx->d_bg, ctx->p.width, ctx->p.width, ctx->p.height, hipMemcpyDeviceToHost));
+    return TREXHIP_OK;
+}

@@ -122,6 +122,7 @@ struct trexhip_ctx {
     // tuning knobs (env TREXHIP_ROWS_ORDER / TREXHIP_ROWS_BLOCKS override the defaults)
     int tune_rows_order = 0;
     int tune_rows_blocks = 8192;
+    int tune_conv_geom = 0;             // dev only: alternative conv tilings (TREXHIP_CONV_GEOM)
     int tune_ccl_stop = 0;              // dev only: stop k_ccl_lds after phase N (TREXHIP_CCL_STOP)
     trexhip::Stage stages[TREXHIP_STAGE_COUNT];
 };
