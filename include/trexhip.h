@@ -161,6 +161,11 @@ int trexhip_synchronize(trexhip_ctx* ctx);
  * against size_ranges = track_size_filter, cm^2), so the host applies prefilter's remaining policy
  * (recount = sum of n_pixels over a parent's sub-blobs).  Results are a second table set. */
 int trexhip_rethreshold_device(trexhip_ctx* ctx, int32_t threshold, int32_t method, const double* size_ranges, int32_t n_ranges);
+/* the same with one threshold per detect blob (device array indexed by pooled blob index; negative = skip the blob):
+ * the building block of SplitBlob::apply_threshold (tracking/SplitBlob.cpp:130-164), which tries different thresholds on
+ * different merged blobs; the search over thresholds stays with the caller */
+int trexhip_rethreshold_per_blob_device(trexhip_ctx* ctx, int32_t threshold, const int32_t* d_blob_thresholds, int32_t method,
+                                        const double* size_ranges, int32_t n_ranges);
 int trexhip_fetch_rethreshold(trexhip_ctx* ctx, trexhip_batch_result* out);
 
 /* ---- posture (outline -> midline) -----------------------------------------------------------------

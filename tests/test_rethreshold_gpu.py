@@ -74,3 +74,29 @@ def test_threshold_zero_is_identity_and_golden_semantics():
     assert sub[0].pixels.tolist() == [0, 10, 20, 30, 40, 50, 150, 160, 170, 180, 190]
     det, sub = run(f[None], bg, 50, 1, [], detect_kw=dict(threshold=0, inclusive=1, zero_is_background=0, enable_difference=0))
     assert [(int(r["y"]), int(r["x0"]), int(r["x1"])) for r in sub[0].runs] == [(0, 0, 5)]
+
+
+def test_per_blob_thresholds():
+    # SplitBlob::apply_threshold (SplitBlob.cpp:130-164) tries a different threshold on every merged blob
+    fr, bg = synth.batch("C2", 1)
+    n, H, W = fr.shape
+    seg = capi.Segmenter(capi.default_params(W, H, max_batch=1))
+    seg.set_background(bg)
+    d = torch.from_numpy(fr).cuda()
+    seg.segment_device(d.data_ptr(), 1)
+    det = seg.fetch()[0]
+    thr = np.array([(-1 if k % 5 == 4 else 20 + 3 * k) for k in range(len(det.blobs))], np.int32)
+    dthr = torch.from_numpy(thr).cuda()
+    seg.rethreshold_per_blob(dthr.data_ptr(), method=0)
+    sub = seg.fetch(rethreshold=True)[0]
+    for k, b in enumerate(det.blobs):
+        mine = sub.blobs[sub.blobs["parent"] == det.info["blob_begin"] + k]
+        if thr[k] < 0:
+            assert len(mine) == 0
+            continue
+        rs = det.runs[b["run_begin"]:b["run_begin"] + b["n_runs"]]
+        px = det.pixels[b["pix_begin"]:b["pix_begin"] + b["n_pixels"]]
+        ob, orr, opx = oracle.threshold_blob(rs, px, bg, 0, int(thr[k]))
+        assert sorted(mine["n_pixels"].tolist()) == sorted(ob["n_pixels"].tolist())
+        assert sorted(mine["bid"].tolist()) == sorted(ob["bid"].tolist())
+    seg.close()

@@ -75,7 +75,7 @@ class TrexHipError(RuntimeError):
 SYMBOLS = [
     "trexhip_abi_version", "trexhip_last_error", "trexhip_default_params", "trexhip_create", "trexhip_destroy",
     "trexhip_set_stream", "trexhip_set_background", "trexhip_set_background_device", "trexhip_generate_average_device", "trexhip_get_background", "trexhip_segment_device",
-    "trexhip_segment", "trexhip_segment_color", "trexhip_rethreshold_device", "trexhip_fetch_rethreshold", "trexhip_fetch", "trexhip_device_view_get", "trexhip_synchronize",
+    "trexhip_segment", "trexhip_segment_color", "trexhip_rethreshold_device", "trexhip_rethreshold_per_blob_device", "trexhip_fetch_rethreshold", "trexhip_fetch", "trexhip_device_view_get", "trexhip_synchronize",
     "trexhip_profile_enable", "trexhip_profile_read", "trexhip_profile_reset",
     "trexhip_default_posture_params", "trexhip_posture_device", "trexhip_crops_device", "trexhip_export_id_table_device", "trexhip_load_weights", "trexhip_set_identity_precision", "trexhip_num_classes", "trexhip_identify_device", "trexhip_identify",
 ]
@@ -102,6 +102,7 @@ def lib():
         L.trexhip_segment.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.c_int32, C.c_int32]
         L.trexhip_segment_color.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.c_int32, C.c_int32, C.c_int32, C.c_int32]
         L.trexhip_rethreshold_device.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int32]
+        L.trexhip_rethreshold_per_blob_device.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32]
         L.trexhip_fetch_rethreshold.argtypes = [C.c_void_p, C.POINTER(BatchResult)]
         L.trexhip_fetch.argtypes = [C.c_void_p, C.POINTER(BatchResult)]
         L.trexhip_device_view_get.argtypes = [C.c_void_p, C.POINTER(DeviceView)]
@@ -290,6 +291,12 @@ class Segmenter:
     def identify_device(self, d_crops_ptr, n, d_probs_ptr, d_logits_ptr=None):
         _check(lib().trexhip_identify_device(self._h, C.c_void_p(d_crops_ptr), n, C.c_void_p(d_probs_ptr),
                                              C.c_void_p(d_logits_ptr) if d_logits_ptr else None))
+
+    def rethreshold_per_blob(self, d_thresholds_ptr, method=0, size_ranges=(), threshold=0):
+        """SplitBlob::apply_threshold building block: one threshold per detect blob (int32 device array, pooled order; <0 skips)."""
+        rng = np.ascontiguousarray(np.array(size_ranges, np.float64).reshape(-1))
+        _check(lib().trexhip_rethreshold_per_blob_device(self._h, threshold, C.c_void_p(d_thresholds_ptr), method,
+                                                         rng.ctypes.data_as(C.c_void_p) if len(rng) else None, len(rng) // 2))
 
     def rethreshold(self, threshold, method=0, size_ranges=()):
         """Tracker::prefilter's threshold_blob for every blob of the last batch; fetch(rethreshold=True) reads it."""

@@ -95,6 +95,8 @@ static int fill_cfg(trexhip_ctx* ctx) {
 using namespace trexhip;
 
 static void pass2_free(trexhip_ctx* ctx);
+extern "C" int trexhip_rethreshold_per_blob_device(trexhip_ctx* ctx, int32_t threshold, const int32_t* d_blob_thresholds, int32_t method,
+                                                   const double* size_ranges, int32_t n_ranges);
 
 extern "C" {
 
@@ -347,6 +349,11 @@ static void pass2_free(trexhip_ctx* ctx) {
 }
 
 int trexhip_rethreshold_device(trexhip_ctx* ctx, int32_t threshold, int32_t method, const double* size_ranges, int32_t n_ranges) {
+    return trexhip_rethreshold_per_blob_device(ctx, threshold, nullptr, method, size_ranges, n_ranges);
+}
+
+int trexhip_rethreshold_per_blob_device(trexhip_ctx* ctx, int32_t threshold, const int32_t* d_blob_thresholds, int32_t method,
+                                        const double* size_ranges, int32_t n_ranges) {
     if (!ctx) { set_error("trexhip_rethreshold_device: null ctx"); return TREXHIP_E_INVALID; }
     if (method < 0 || method > 2) { set_error("trexhip_rethreshold_device: method must be 0 (absolute), 1 (sign) or 2 (none)"); return TREXHIP_E_INVALID; }
     if (n_ranges < 0 || n_ranges > 8 || (n_ranges && !size_ranges)) { set_error("trexhip_rethreshold_device: bad size ranges"); return TREXHIP_E_INVALID; }
@@ -355,7 +362,7 @@ int trexhip_rethreshold_device(trexhip_ctx* ctx, int32_t threshold, int32_t meth
     TH_CHECK_HIP(hipSetDevice(ctx->p.device));
     int rc = pass2_alloc(ctx);
     if (rc) return rc;
-    return launch_rethreshold(ctx, threshold, method, size_ranges, n_ranges);
+    return launch_rethreshold(ctx, threshold, method, size_ranges, n_ranges, d_blob_thresholds);
 }
 
 int trexhip_fetch_rethreshold(trexhip_ctx* ctx, trexhip_batch_result* out) {

@@ -134,5 +134,5 @@ void stage_end(trexhip_ctx* ctx, int stage);
 void net_free(trexhip_ctx* ctx);
 int launch_pending(trexhip_ctx* ctx);
 int launch_morphology(trexhip_ctx* ctx, const uint8_t* d_frames, int n, const uint32_t** result);
-int launch_rethreshold(trexhip_ctx* ctx, int thr, int method, const double* ranges, int n_ranges);
+int launch_rethreshold(trexhip_ctx* ctx, int thr, int method, const double* ranges, int n_ranges, const int32_t* d_blob_thr);
 }

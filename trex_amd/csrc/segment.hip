@@ -1055,7 +1055,8 @@ __global__ __launch_bounds__(256) void k_sub(const SegCfg c, const uint8_t* __re
                                              const uint32_t* __restrict__ row_base, const trexhip_run* __restrict__ raster,
                                              const uint32_t* __restrict__ label, const uint32_t* __restrict__ root_ord,
                                              const int32_t* __restrict__ blob_map, const trexhip_frame_info* __restrict__ info,
-                                             const int method, const int thr, uint32_t* __restrict__ sub_cnt,
+                                             const int method, const int thr_all, const int32_t* __restrict__ blob_thr,
+                                             uint32_t* __restrict__ sub_cnt,
                                              const uint32_t* __restrict__ sub_base, trexhip_run* __restrict__ raster2,
                                              uint32_t* __restrict__ run_parent2) {
     const int gid = blockIdx.x * 256 + threadIdx.x;
@@ -1070,7 +1071,9 @@ __global__ __launch_bounds__(256) void k_sub(const SegCfg c, const uint8_t* __re
     for (uint32_t r = rb[y]; r < rb[y + 1]; ++r) {
         const int32_t k = blob_map[fo + root_ord[fo + label[fo + r]]];
         uint32_t n = 0;
-        if (k >= 0) {
+        // per-blob thresholds (SplitBlob::apply_threshold tries different thresholds per blob); negative = leave the blob out
+        const int thr = (k >= 0 && blob_thr) ? blob_thr[fi.blob_begin + k] : thr_all;
+        if (k >= 0 && thr >= 0) {
             const trexhip_run q = raster[fo + r];
             uint32_t out = WRITE ? sub_base[fo + r] : 0;
             int open = -1;
@@ -1157,7 +1160,7 @@ __global__ __launch_bounds__(256) void k_link2(const SegCfg c, const uint32_t* _
     }
 }
 
-int launch_rethreshold(trexhip_ctx* ctx, int thr, int method, const double* ranges, int n_ranges) {
+int launch_rethreshold(trexhip_ctx* ctx, int thr, int method, const double* ranges, int n_ranges, const int32_t* d_blob_thr) {
     Pass2& q = ctx->pass2;
     SegCfg c = ctx->cfg;
     const int n = ctx->last_n;
@@ -1168,11 +1171,11 @@ int launch_rethreshold(trexhip_ctx* ctx, int thr, int method, const double* rang
     const dim3 grid_r((unsigned)((n * c.H + 255) / 256));
     TH_CHECK_HIP(hipMemsetAsync(q.d_totals, 0, sizeof(uint32_t) * 4, s));
     hipLaunchKernelGGL((k_sub<0>), grid_r, dim3(256), 0, s, c, ctx->d_frames, ctx->d_bg, ctx->d_row_base, ctx->d_raster, ctx->d_parent,
-                       ctx->d_root_ord, ctx->d_blob_map, ctx->d_info, method, thr, q.d_sub_cnt, q.d_sub_base, q.d_raster, q.d_run_parent);
+                       ctx->d_root_ord, ctx->d_blob_map, ctx->d_info, method, thr, d_blob_thr, q.d_sub_cnt, q.d_sub_base, q.d_raster, q.d_run_parent);
     hipLaunchKernelGGL(k_sub_scan, dim3(n), dim3(256), 0, s, c, ctx->d_info, ctx->d_row_base, q.d_sub_cnt, q.d_sub_base, q.d_row_base,
                        q.d_row_cnt, q.d_parent, q.d_info);
     hipLaunchKernelGGL((k_sub<1>), grid_r, dim3(256), 0, s, c, ctx->d_frames, ctx->d_bg, ctx->d_row_base, ctx->d_raster, ctx->d_parent,
-                       ctx->d_root_ord, ctx->d_blob_map, ctx->d_info, method, thr, q.d_sub_cnt, q.d_sub_base, q.d_raster, q.d_run_parent);
+                       ctx->d_root_ord, ctx->d_blob_map, ctx->d_info, method, thr, d_blob_thr, q.d_sub_cnt, q.d_sub_base, q.d_raster, q.d_run_parent);
     hipLaunchKernelGGL(k_link2, grid_r, dim3(256), 0, s, c, q.d_row_base, q.d_raster, q.d_parent, q.d_info);
     hipLaunchKernelGGL(k_flatten, grid_r, dim3(256), 0, s, c, 0, q.d_row_cnt, q.d_row_base, q.d_parent, q.d_info);
     hipLaunchKernelGGL(k_blobs, dim3(n), dim3(256), 0, s, c, 0, q.d_raster, q.d_parent, q.d_root_ord, q.d_cnt_runs, q.d_cnt_px, q.d_cur_run,
