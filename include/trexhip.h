@@ -196,11 +196,19 @@ int trexhip_posture_device(trexhip_ctx* ctx, int32_t table, const trexhip_postur
 /* ---- crops ------------------------------------------------------------------------------------
  * constraints::diff_image (tracking/FilterCache.cpp:265-294): one out_w x out_h uint8 crop per blob of the
  * last segmented batch, pooled order (blob i of trexhip_fetch == crop i).  n_blobs = total_blobs of that
- * batch.  normalization: individual_image_normalization (none only, for now).  difference: 0 = grey
+ * batch.  normalization: individual_image_normalization none or moments (posture / legacy: next function).  difference: 0 = grey
  * values, 1 = |bg - p|, 2 = max(bg - p, 0)  (track_background_subtraction, FilterCache.cpp:171-175). */
 enum { TREXHIP_NORMALIZE_NONE = 0, TREXHIP_NORMALIZE_MOMENTS = 1, TREXHIP_NORMALIZE_POSTURE = 2 };
 int trexhip_crops_device(trexhip_ctx* ctx, uint8_t* d_crops, int32_t n_blobs, int32_t out_w, int32_t out_h,
                          int32_t normalization, int32_t difference);
+
+/* posture / legacy normalisation (FilterCache.cpp:267-274): the caller supplies, per blob in pooled order, the 2x3 row-major
+ * float matrix of Midline::transform(normalize).toCV() (Outline.cpp:1237-1255) and the (median) midline length; the library
+ * applies normalize_image (FilterCache.cpp:21-115): translate(size/2) . scale(individual_image_scale) .
+ * translate(len*0.4 | legacy: (-len/2, 0)) . tr, then cv::warpAffine INTER_LINEAR in OpenCV's 8-bit fixed point. */
+int trexhip_crops_transformed_device(trexhip_ctx* ctx, uint8_t* d_crops, int32_t n_blobs, int32_t out_w, int32_t out_h,
+                                     const float* transforms, const float* midline_lengths, int32_t use_legacy,
+                                     float image_scale, int32_t difference);
 
 /* ---- identity network (V118_3) -------------------------------------------------------------
  * VINetwork::load_weights (ml/VisualIdentification.cpp) / visual_recognition_torch.py:841-921: takes the

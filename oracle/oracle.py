@@ -111,6 +111,9 @@ def lib():
                                      C.POINTER(PostureInfo)]
         L.oracle_outline_resample.argtypes = [C.c_void_p, C.c_int32, C.c_float, C.c_void_p, C.c_int32]
         L.oracle_trace_outline.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_int32]
+        L.oracle_normalize_transform.argtypes = [C.c_void_p, C.c_float, C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_void_p]
+        L.oracle_moments_transform.argtypes = [C.c_void_p, C.c_void_p]
+        L.oracle_warp_affine_u8.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32]
         L.oracle_bid.restype = C.c_uint32
         L.oracle_bid.argtypes = [C.c_uint32] * 4
         del u8p
@@ -284,3 +287,43 @@ def generate_average(frames, method=0):
     for f in frames:
         acc += f.astype(np.float32)
     return np.clip(np.rint(acc / np.float32(len(frames))), 0, 255).astype(np.uint8)
+
+
+def crop_normalized(frame, bg, blob, runs, tr6=None, midline_length=0.0, legacy=False, out_w=80, out_h=80, scale=1.0,
+                    difference=0, invert=False):
+    """constraints::diff_image with individual_image_normalization = moments (tr6 None: FilterCache.cpp:276-288) or
+    posture / legacy (tr6 = Midline::transform(...).toCV() supplied by the caller, :267-274): imageFromLines into the
+    bounding box, normalize_image's transform, cv::warpAffine INTER_LINEAR (FilterCache.cpp:21-115)."""
+    bw = int(blob["x1"]) - int(blob["x0"]) + 1
+    bh = int(blob["y1"]) - int(blob["y0"]) + 1
+    img = crop_none(frame, bg, blob, runs, out_w=bw, out_h=bh, difference=difference, invert=invert)
+    L = lib()
+    if tr6 is None:
+        tr = np.zeros(6, np.float32)
+        b1 = np.ascontiguousarray(np.array([blob], BLOB_DTYPE))
+        L.oracle_moments_transform(_ptr(b1), _ptr(tr))
+        midline_length = 0.0
+    else:
+        tr = np.ascontiguousarray(tr6, np.float32)
+    M = np.zeros(6, np.float32)
+    L.oracle_normalize_transform(_ptr(tr), midline_length, 1 if legacy else 0, out_w, out_h, scale, _ptr(M))
+    out = np.zeros((out_h, out_w), np.uint8)
+    img = np.ascontiguousarray(img)
+    L.oracle_warp_affine_u8(_ptr(img), bw, bh, _ptr(M), _ptr(out), out_w, out_h)
+    return out, M
+
+
+def warp_affine(src, M6, out_w, out_h):
+    """cv::warpAffine(src, M, (out_w,out_h), INTER_LINEAR, BORDER_CONSTANT 0) in OpenCV's 8-bit fixed point."""
+    src = np.ascontiguousarray(src, np.uint8)
+    M = np.ascontiguousarray(M6, np.float32)
+    out = np.zeros((out_h, out_w), np.uint8)
+    lib().oracle_warp_affine_u8(_ptr(src), src.shape[1], src.shape[0], _ptr(M), _ptr(out), out_w, out_h)
+    return out
+
+
+def normalize_transform(tr6, midline_length, legacy, out_w, out_h, scale):
+    tr = np.ascontiguousarray(tr6, np.float32)
+    M = np.zeros(6, np.float32)
+    lib().oracle_normalize_transform(_ptr(tr), float(midline_length), 1 if legacy else 0, out_w, out_h, float(scale), _ptr(M))
+    return M

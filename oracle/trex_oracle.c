@@ -411,3 +411,79 @@ oracle_frame* oracle_rethreshold_frame(const oracle_frame* detect, const uint8_t
     free(bin); free(val); free(tag);
     return f;
 }
+
+/* ------------------------------------------------------------------ normalised crops (moments / posture) */
+/* gui::Transform (commons, NOT IN TREE) restated as the SFML-style 3x3 affine it is used as in
+ * FilterCache.cpp:50-63 / Outline.cpp:1237-1255: translate / scale / rotate(degrees) post-multiply. */
+typedef struct { float m[6]; } aff_t;                        /* [m0 m1 m2; m3 m4 m5] */
+static aff_t aff_identity(void) { aff_t a = {{1, 0, 0, 0, 1, 0}}; return a; }
+static aff_t aff_mul(aff_t a, aff_t b) {
+    aff_t c;
+    c.m[0] = a.m[0] * b.m[0] + a.m[1] * b.m[3]; c.m[1] = a.m[0] * b.m[1] + a.m[1] * b.m[4]; c.m[2] = a.m[0] * b.m[2] + a.m[1] * b.m[5] + a.m[2];
+    c.m[3] = a.m[3] * b.m[0] + a.m[4] * b.m[3]; c.m[4] = a.m[3] * b.m[1] + a.m[4] * b.m[4]; c.m[5] = a.m[3] * b.m[2] + a.m[4] * b.m[5] + a.m[5];
+    return c;
+}
+static aff_t aff_translate(aff_t a, float x, float y) { aff_t t = {{1, 0, x, 0, 1, y}}; return aff_mul(a, t); }
+static aff_t aff_scale(aff_t a, float s) { aff_t t = {{s, 0, 0, 0, s, 0}}; return aff_mul(a, t); }
+static aff_t aff_rotate_deg(aff_t a, float deg) {
+    const float rad = deg * 3.141592654f / 180.f;
+    const float c = cosf(rad), s = sinf(rad);
+    aff_t t = {{c, -s, 0, s, c, 0}};
+    return aff_mul(a, t);
+}
+
+/* normalize_image's transform (FilterCache.cpp:50-63): translate(size/2) . scale . translate(len*0.4 | (-len/2,0)) . tr */
+void oracle_normalize_transform(const float* tr6, float midline_length, int32_t use_legacy, int32_t out_w, int32_t out_h,
+                                float scale, float* M6) {
+    aff_t t = aff_identity();
+    t = aff_translate(t, (float)out_w * 0.5f, (float)out_h * 0.5f);
+    t = aff_scale(t, scale);
+    if (use_legacy) t = aff_translate(t, -midline_length * 0.5f, 0.f);
+    else            t = aff_translate(t, midline_length * 0.4f, midline_length * 0.4f);       /* Vec2(scalar) */
+    aff_t in; memcpy(in.m, tr6, sizeof(in.m));
+    t = aff_mul(t, in);
+    memcpy(M6, t.m, sizeof(t.m));
+}
+
+/* individual_image_normalization = moments (FilterCache.cpp:276-288): rotate(DEGREE(-orientation + pi/4)) . translate(-size/2)
+ * with pv::Blob::orientation() = 0.5 * atan2(2 mu11, mu20 - mu02) from the blob's central moments [commons, restated] */
+void oracle_moments_transform(const oracle_blob* B, float* tr6) {
+    const float n = (float)B->n_pixels;
+    const float cx = (float)B->m10 / n, cy = (float)B->m01 / n;
+    const float mu20 = (float)B->m20 / n - cx * cx, mu02 = (float)B->m02 / n - cy * cy, mu11 = (float)B->m11 / n - cx * cy;
+    const float orientation = 0.5f * atan2f(2.f * mu11, mu20 - mu02);
+    const float angle = (-orientation + 3.14159265358979323846f * 0.25f) * 180.f / 3.14159265358979323846f;   /* DEGREE() */
+    aff_t t = aff_identity();
+    t = aff_rotate_deg(t, angle);
+    t = aff_translate(t, -(float)(B->x1 - B->x0 + 1) * 0.5f, -(float)(B->y1 - B->y0 + 1) * 0.5f);
+    memcpy(tr6, t.m, sizeof(t.m));
+}
+
+/* cv::warpAffine(src, dst, M, dsize, INTER_LINEAR, BORDER_CONSTANT 0) for 8-bit single channel, restated from OpenCV's
+ * published fixed-point path (imgwarp.cpp: AB_BITS 10, INTER_BITS 5, INTER_REMAP_COEF_BITS 15) -- unpinned: no OpenCV here */
+void oracle_warp_affine_u8(const uint8_t* src, int32_t sw, int32_t sh, const float* M6, uint8_t* dst, int32_t dw, int32_t dh) {
+    double M[6];
+    for (int i = 0; i < 6; ++i) M[i] = M6[i];
+    double D = M[0] * M[4] - M[1] * M[3];
+    D = D != 0 ? 1. / D : 0;
+    const double A11 = M[4] * D, A22 = M[0] * D;
+    M[0] = A11; M[1] *= -D; M[3] *= -D; M[4] = A22;
+    const double b1 = -M[0] * M[2] - M[1] * M[5], b2 = -M[3] * M[2] - M[4] * M[5];
+    M[2] = b1; M[5] = b2;
+    const int AB_SCALE = 1024, round_delta = 16;
+    for (int y = 0; y < dh; ++y) {
+        const int X0 = (int)lrint((M[1] * y + M[2]) * AB_SCALE) + round_delta;
+        const int Y0 = (int)lrint((M[4] * y + M[5]) * AB_SCALE) + round_delta;
+        for (int x = 0; x < dw; ++x) {
+            const int X = (X0 + (int)lrint(M[0] * x * AB_SCALE)) >> 5, Y = (Y0 + (int)lrint(M[3] * x * AB_SCALE)) >> 5;
+            const int sx = X >> 5, sy = Y >> 5, fx = X & 31, fy = Y & 31;
+            int v[4];
+            for (int k = 0; k < 4; ++k) {
+                const int xx = sx + (k & 1), yy = sy + (k >> 1);
+                v[k] = (xx >= 0 && xx < sw && yy >= 0 && yy < sh) ? src[(size_t)yy * sw + xx] : 0;
+            }
+            const int w00 = (32 - fy) * (32 - fx) * 32, w01 = (32 - fy) * fx * 32, w10 = fy * (32 - fx) * 32, w11 = fy * fx * 32;
+            dst[(size_t)y * dw + x] = (uint8_t)((v[0] * w00 + v[1] * w01 + v[2] * w10 + v[3] * w11 + (1 << 14)) >> 15);
+        }
+    }
+}

@@ -95,6 +95,10 @@ oracle_frame* oracle_threshold_blob(const oracle_run* runs, int32_t n_runs, cons
 oracle_frame* oracle_rethreshold_frame(const oracle_frame* detect, const uint8_t* frame, const uint8_t* bg, int32_t width,
                                        int32_t height, int32_t method, int32_t threshold, int32_t connectivity,
                                        const double* ranges, int32_t n_ranges, double cm_per_pixel, int32_t invert);
+/* normalised crops (FilterCache.cpp:21-115,276-288): transforms are row-major 2x3 float [m0 m1 m2; m3 m4 m5] */
+void oracle_normalize_transform(const float* tr6, float midline_length, int32_t use_legacy, int32_t out_w, int32_t out_h, float scale, float* M6);
+void oracle_moments_transform(const oracle_blob* B, float* tr6);
+void oracle_warp_affine_u8(const uint8_t* src, int32_t sw, int32_t sh, const float* M6, uint8_t* dst, int32_t dw, int32_t dh);
 uint32_t oracle_bid(uint32_t x0, uint32_t x1, uint32_t y, uint32_t n_runs);
 
 #ifdef __cplusplus

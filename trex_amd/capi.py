@@ -77,7 +77,7 @@ SYMBOLS = [
     "trexhip_set_stream", "trexhip_set_background", "trexhip_set_background_device", "trexhip_generate_average_device", "trexhip_get_background", "trexhip_segment_device",
     "trexhip_segment", "trexhip_segment_color", "trexhip_rethreshold_device", "trexhip_rethreshold_per_blob_device", "trexhip_fetch_rethreshold", "trexhip_fetch", "trexhip_device_view_get", "trexhip_synchronize",
     "trexhip_profile_enable", "trexhip_profile_read", "trexhip_profile_reset",
-    "trexhip_default_posture_params", "trexhip_posture_device", "trexhip_crops_device", "trexhip_export_id_table_device", "trexhip_load_weights", "trexhip_set_identity_precision", "trexhip_num_classes", "trexhip_identify_device", "trexhip_identify",
+    "trexhip_default_posture_params", "trexhip_posture_device", "trexhip_crops_device", "trexhip_crops_transformed_device", "trexhip_export_id_table_device", "trexhip_load_weights", "trexhip_set_identity_precision", "trexhip_num_classes", "trexhip_identify_device", "trexhip_identify",
 ]
 
 
@@ -113,6 +113,7 @@ def lib():
         L.trexhip_default_posture_params.argtypes = [C.POINTER(PostureParams)]
         L.trexhip_default_posture_params.restype = None
         L.trexhip_posture_device.argtypes = [C.c_void_p, C.c_int32, C.POINTER(PostureParams), C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.trexhip_crops_transformed_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_float, C.c_int32]
         L.trexhip_crops_device.argtypes = [C.c_void_p, C.c_void_p] + [C.c_int32] * 5
         L.trexhip_export_id_table_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_uint32, C.c_void_p, C.c_int32]
         L.trexhip_load_weights.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
@@ -262,6 +263,13 @@ class Segmenter:
     def crops_device(self, d_crops_ptr, n_blobs, out_w=80, out_h=80, normalization=0, difference=0):
         """constraints::diff_image for every blob of the last batch -> uint8 [n_blobs][out_h][out_w] at d_crops_ptr."""
         _check(lib().trexhip_crops_device(self._h, C.c_void_p(d_crops_ptr), n_blobs, out_w, out_h, normalization, difference))
+
+    def crops_transformed_device(self, d_crops_ptr, transforms, midline_lengths, out_w=80, out_h=80, legacy=False, scale=1.0, difference=0):
+        """posture / legacy normalisation with caller-supplied Midline::transform matrices (host float32 [n,6]) and lengths [n]."""
+        tr = np.ascontiguousarray(transforms, np.float32)
+        ln = np.ascontiguousarray(midline_lengths, np.float32)
+        _check(lib().trexhip_crops_transformed_device(self._h, C.c_void_p(d_crops_ptr), len(tr), out_w, out_h, tr.ctypes.data_as(C.c_void_p),
+                                                      ln.ctypes.data_as(C.c_void_p), 1 if legacy else 0, scale, difference))
 
     def export_id_table(self, d_probs_ptr, n_blobs, classes, frame_base, d_table_ptr, max_rows):
         """Fixed-size per-blob identity table (8 header words + classes floats per row) into caller memory."""

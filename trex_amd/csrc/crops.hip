@@ -7,7 +7,9 @@
 // the output size: pad = out - size, right = pad/2, left = pad - right (:184-194); cut likewise (:212-226)).
 // One workgroup = one blob of the last segmented batch, in pooled order.
 #include "internal.h"
+#include <cmath>
 #include <cstring>
+#include <vector>
 
 namespace trexhip {
 
@@ -52,6 +54,9 @@ __global__ __launch_bounds__(256) void k_crops_none(const SegCfg c, const uint8_
     }
 }
 
+int launch_crops_warp(trexhip_ctx* ctx, uint8_t* d_crops, int n, int OW, int OH, int diff_mode, const float* tr6, const float* lengths,
+                      bool legacy, float scale);
+
 int launch_crops(trexhip_ctx* ctx, uint8_t* d_crops, int n, int OW, int OH, int diff_mode) {
     if (n <= 0) return TREXHIP_OK;
     SegCfg c = ctx->cfg;
@@ -73,8 +78,8 @@ extern "C" {
 int trexhip_crops_device(trexhip_ctx* ctx, uint8_t* d_crops, int32_t n_blobs, int32_t out_w, int32_t out_h,
                          int32_t normalization, int32_t difference) {
     if (!ctx || !d_crops) { set_error("trexhip_crops_device: null argument"); return TREXHIP_E_INVALID; }
-    if (normalization != TREXHIP_NORMALIZE_NONE) {
-        set_error("trexhip_crops_device: only individual_image_normalization=none is implemented on the device");
+    if (normalization != TREXHIP_NORMALIZE_NONE && normalization != TREXHIP_NORMALIZE_MOMENTS) {
+        set_error("trexhip_crops_device: posture / legacy normalisation need the caller's Midline::transform: use trexhip_crops_transformed_device");
         return TREXHIP_E_UNSUPPORTED;
     }
     if (out_w <= 0 || out_h <= 0 || (out_w * out_h) % 16 != 0) { set_error("trexhip_crops_device: output size must be a multiple of 16 bytes"); return TREXHIP_E_INVALID; }
@@ -83,6 +88,8 @@ int trexhip_crops_device(trexhip_ctx* ctx, uint8_t* d_crops, int32_t n_blobs, in
     if (!ctx->d_frames || ctx->last_n == 0) { set_error("trexhip_crops_device: no segmented batch"); return TREXHIP_E_INVALID; }
     if (!ctx->fetched) { set_error("trexhip_crops_device: call trexhip_fetch on the segmented batch first"); return TREXHIP_E_INVALID; }
     TH_CHECK_HIP(hipSetDevice(ctx->p.device));
+    if (normalization == TREXHIP_NORMALIZE_MOMENTS)
+        return launch_crops_warp(ctx, d_crops, n_blobs, out_w, out_h, difference, nullptr, nullptr, false, 1.0f);
     return launch_crops(ctx, d_crops, n_blobs, out_w, out_h, difference);
 }
 
@@ -284,4 +291,164 @@ extern "C" int trexhip_get_background(trexhip_ctx* ctx, uint8_t* gray, int32_t s
     if (!ctx || !gray || !ctx->has_bg) { set_error("trexhip_get_background: no background"); return TREXHIP_E_INVALID; }
     TH_CHECK_HIP(hipMemcpy2D(gray, stride, ctx->d_bg, ctx->p.width, ctx->p.width, ctx->p.height, hipMemcpyDeviceToHost));
     return TREXHIP_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// normalised crops: individual_image_normalization = moments / posture / legacy
+// (constraints::diff_image -> calculate_normalized_diff_image -> normalize_image, tracking/FilterCache.cpp:21-115,265-294)
+//   image of the blob in its bounding box (imageFromLines) --cv::warpAffine(INTER_LINEAR, BORDER_CONSTANT)--> out_w x out_h
+// The per-blob 2x3 transform is composed on the host exactly like normalize_image does (translate(size/2), scale,
+// translate(len*0.4 | -len/2), combine(tr)), inverted in double like cv::warpAffine, and the device does OpenCV's 8-bit
+// fixed-point bilinear (AB_BITS 10, INTER_BITS 5, coefficient bits 15): integer arithmetic only, so the result does not
+// depend on device float rounding.  tr = rotate(-orientation + 45 deg) . translate(-size/2) for `moments`
+// (FilterCache.cpp:276-288; orientation from the blob's central moments), or Midline::transform(...) supplied by the
+// caller for `posture` / `legacy` (Outline.cpp:1237-1255).
+// ------------------------------------------------------------------------------------------------
+namespace trexhip {
+
+struct Aff { float m[6]; };
+static Aff aff_mul(const Aff& a, const Aff& b) {
+    Aff c;
+    c.m[0] = a.m[0] * b.m[0] + a.m[1] * b.m[3]; c.m[1] = a.m[0] * b.m[1] + a.m[1] * b.m[4]; c.m[2] = a.m[0] * b.m[2] + a.m[1] * b.m[5] + a.m[2];
+    c.m[3] = a.m[3] * b.m[0] + a.m[4] * b.m[3]; c.m[4] = a.m[3] * b.m[1] + a.m[4] * b.m[4]; c.m[5] = a.m[3] * b.m[2] + a.m[4] * b.m[5] + a.m[5];
+    return c;
+}
+static Aff aff_translate(const Aff& a, float x, float y) { const Aff t = {{1, 0, x, 0, 1, y}}; return aff_mul(a, t); }
+static Aff aff_scale(const Aff& a, float s) { const Aff t = {{s, 0, 0, 0, s, 0}}; return aff_mul(a, t); }
+static Aff aff_rotate_deg(const Aff& a, float deg) {
+    const float rad = deg * 3.141592654f / 180.f;
+    const float c = std::cos(rad), s = std::sin(rad);
+    const Aff t = {{c, -s, 0, s, c, 0}};
+    return aff_mul(a, t);
+}
+
+static constexpr int W_NR = 2048;      // lines of one blob held in LDS
+
+__global__ __launch_bounds__(256) void k_crops_warp(const SegCfg c, const uint8_t* __restrict__ frames, const uint8_t* __restrict__ bg,
+                                                    const trexhip_frame_info* __restrict__ info, const uint32_t* __restrict__ blob_frame,
+                                                    const trexhip_blob* __restrict__ blobs, const trexhip_run* __restrict__ runs,
+                                                    const double* __restrict__ minv /*[n][6] inverse maps*/, uint8_t* __restrict__ crops,
+                                                    int OW, int OH, int diff_mode) {
+    __shared__ uint32_t s_runs[W_NR];
+    __shared__ int s_row[1024 + 2];
+    const uint32_t bi = blockIdx.x;
+    uint8_t* out = crops + (size_t)bi * OW * OH;
+    const uint32_t f = blob_frame[bi];
+    bool ok = f < (uint32_t)c.B;
+    trexhip_frame_info fi = {};
+    if (ok) { fi = info[f]; ok = fi.flags == 0; }
+    trexhip_blob B = {};
+    if (ok) { B = blobs[bi]; ok = B.n_runs <= (uint32_t)W_NR && (B.y1 - B.y0 + 1) <= 1024; }
+    if (!ok) { for (int i = threadIdx.x; i < OW * OH; i += 256) out[i] = 0; return; }
+    const trexhip_run* rr = runs + fi.run_begin + B.run_begin;
+    const int y0 = B.y0, rows = B.y1 - B.y0 + 1;
+    for (int i = threadIdx.x; i < (int)B.n_runs; i += 256) {
+        const trexhip_run q = rr[i];
+        s_runs[i] = (uint32_t)q.x0 | ((uint32_t)q.x1 << 16);
+        if (i == 0 || rr[i - 1].y != q.y) s_row[q.y - y0] = i;
+    }
+    if (threadIdx.x == 0) s_row[rows] = (int)B.n_runs;
+    __syncthreads();
+    const double* M = minv + (size_t)bi * 6;
+    const double m0 = M[0], m1 = M[1], m2 = M[2], m3 = M[3], m4 = M[4], m5 = M[5];
+    const int sw = B.x1 - B.x0 + 1, sh = rows;
+    const uint8_t* img = frames + (size_t)f * c.H * c.W;
+    for (int i = threadIdx.x; i < OW * OH; i += 256) {
+        const int y = i / OW, x = i - y * OW;
+        const int X0 = __double2int_rn((m1 * y + m2) * 1024.0) + 16, Y0 = __double2int_rn((m4 * y + m5) * 1024.0) + 16;
+        const int X = (X0 + __double2int_rn(m0 * x * 1024.0)) >> 5, Y = (Y0 + __double2int_rn(m3 * x * 1024.0)) >> 5;
+        const int sx = X >> 5, sy = Y >> 5, fx = X & 31, fy = Y & 31;
+        int v[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int xx = sx + (k & 1), yy = sy + (k >> 1);
+            int p = 0;
+            if (xx >= 0 && xx < sw && yy >= 0 && yy < sh) {
+                const int ax = xx + B.x0;
+                bool in = false;
+                for (int r = s_row[yy]; r < s_row[yy + 1]; ++r) { const uint32_t q = s_runs[r]; if (ax >= (int)(q & 0xffffu) && ax <= (int)(q >> 16)) { in = true; break; } }
+                if (in) {
+                    p = img[(size_t)(yy + y0) * c.W + ax];
+                    if (c.invert) p = 255 - p;
+                    if (diff_mode) { const int b = bg[(size_t)(yy + y0) * c.W + ax]; p = diff_mode == 1 ? abs(b - p) : max(b - p, 0); }
+                }
+            }
+            v[k] = p;
+        }
+        const int w00 = (32 - fy) * (32 - fx) * 32, w01 = (32 - fy) * fx * 32, w10 = fy * (32 - fx) * 32, w11 = fy * fx * 32;
+        out[i] = (uint8_t)((v[0] * w00 + v[1] * w01 + v[2] * w10 + v[3] * w11 + (1 << 14)) >> 15);
+    }
+}
+
+// forward transform of normalize_image (FilterCache.cpp:50-63) and its inverse as cv::warpAffine computes it
+static void compose_and_invert(const Aff& tr, float midline_length, bool legacy, int OW, int OH, float scale, double* out6) {
+    Aff t = {{1, 0, 0, 0, 1, 0}};
+    t = aff_translate(t, (float)OW * 0.5f, (float)OH * 0.5f);
+    t = aff_scale(t, scale);
+    if (legacy) t = aff_translate(t, -midline_length * 0.5f, 0.f);
+    else        t = aff_translate(t, midline_length * 0.4f, midline_length * 0.4f);
+    t = aff_mul(t, tr);
+    double M[6];
+    for (int i = 0; i < 6; ++i) M[i] = t.m[i];
+    double D = M[0] * M[4] - M[1] * M[3];
+    D = D != 0 ? 1. / D : 0;
+    const double A11 = M[4] * D, A22 = M[0] * D;
+    M[0] = A11; M[1] *= -D; M[3] *= -D; M[4] = A22;
+    const double b1 = -M[0] * M[2] - M[1] * M[5], b2 = -M[3] * M[2] - M[4] * M[5];
+    M[2] = b1; M[5] = b2;
+    for (int i = 0; i < 6; ++i) out6[i] = M[i];
+}
+
+int launch_crops_warp(trexhip_ctx* ctx, uint8_t* d_crops, int n, int OW, int OH, int diff_mode, const float* tr6, const float* lengths,
+                      bool legacy, float scale) {
+    // tr6 == nullptr: `moments` -- orientation from the integer moments of the fetched blob table (host copy)
+    std::vector<double> minv((size_t)n * 6);
+    for (int i = 0; i < n; ++i) {
+        Aff tr;
+        float len = 0.f;
+        if (tr6) { std::memcpy(tr.m, tr6 + (size_t)i * 6, sizeof(tr.m)); len = lengths ? lengths[i] : 0.f; }
+        else {
+            const trexhip_blob& B = ctx->h_blobs[i];
+            const float np_ = (float)B.n_pixels;
+            const float cx = (float)B.m10 / np_, cy = (float)B.m01 / np_;
+            const float mu20 = (float)B.m20 / np_ - cx * cx, mu02 = (float)B.m02 / np_ - cy * cy, mu11 = (float)B.m11 / np_ - cx * cy;
+            const float orientation = 0.5f * std::atan2(2.f * mu11, mu20 - mu02);      // pv::Blob::orientation()
+            const float angle = (-orientation + 3.14159265358979323846f * 0.25f) * 180.f / 3.14159265358979323846f;
+            Aff t = {{1, 0, 0, 0, 1, 0}};
+            t = aff_rotate_deg(t, angle);
+            tr = aff_translate(t, -(float)(B.x1 - B.x0 + 1) * 0.5f, -(float)(B.y1 - B.y0 + 1) * 0.5f);
+        }
+        compose_and_invert(tr, len, legacy, OW, OH, scale, &minv[(size_t)i * 6]);
+    }
+    if (ctx->warp_cap < n) {
+        if (ctx->d_warp) (void)hipFree(ctx->d_warp);
+        ctx->d_warp = nullptr; ctx->warp_cap = 0;
+        TH_CHECK_HIP(hipMalloc(reinterpret_cast<void**>(&ctx->d_warp), (size_t)n * 6 * sizeof(double)));
+        ctx->warp_cap = n;
+    }
+    TH_CHECK_HIP(hipMemcpyAsync(ctx->d_warp, minv.data(), minv.size() * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    TH_CHECK_HIP(hipStreamSynchronize(ctx->stream));        // minv lives on this stack frame
+    SegCfg c = ctx->cfg;
+    c.B = ctx->last_n;
+    stage_begin(ctx, TREXHIP_STAGE_CROPS);
+    hipLaunchKernelGGL(k_crops_warp, dim3(n), dim3(256), 0, ctx->stream, c, ctx->d_frames, ctx->d_bg, ctx->d_info, ctx->d_blob_frame,
+                       ctx->d_blobs, ctx->d_runs, ctx->d_warp, d_crops, OW, OH, diff_mode);
+    stage_end(ctx, TREXHIP_STAGE_CROPS);
+    TH_CHECK_HIP(hipGetLastError());
+    return TREXHIP_OK;
+}
+
+}  // namespace trexhip
+
+extern "C" int trexhip_crops_transformed_device(trexhip_ctx* ctx, uint8_t* d_crops, int32_t n_blobs, int32_t out_w, int32_t out_h,
+                                                const float* transforms, const float* midline_lengths, int32_t use_legacy,
+                                                float image_scale, int32_t difference) {
+    using namespace trexhip;
+    if (!ctx || !d_crops || !transforms) { set_error("trexhip_crops_transformed_device: null argument"); return TREXHIP_E_INVALID; }
+    if (out_w <= 0 || out_h <= 0 || difference < 0 || difference > 2) { set_error("trexhip_crops_transformed_device: bad argument"); return TREXHIP_E_INVALID; }
+    if (!ctx->d_frames || ctx->last_n == 0 || !ctx->fetched) { set_error("trexhip_crops_transformed_device: segment and fetch a batch first"); return TREXHIP_E_INVALID; }
+    if (n_blobs < 0 || (uint32_t)n_blobs > ctx->cfg.pool_blobs) { set_error("trexhip_crops_transformed_device: n_blobs outside the blob pool"); return TREXHIP_E_INVALID; }
+    if (n_blobs == 0) return TREXHIP_OK;
+    TH_CHECK_HIP(hipSetDevice(ctx->p.device));
+    return launch_crops_warp(ctx, d_crops, n_blobs, out_w, out_h, difference, transforms, midline_lengths, use_legacy != 0, image_scale);
 }

@@ -110,6 +110,8 @@ struct trexhip_ctx {
     trexhip_run* h_runs = nullptr;
     uint8_t* h_pixels = nullptr;
     uint8_t* h_staging = nullptr;       // pinned upload buffer
+    double* d_warp = nullptr;           // per-blob inverse affine maps of the normalised crops
+    int warp_cap = 0;
     uint32_t* d_bits[2] = {nullptr, nullptr};   // 1 bit/pixel masks for the optional morphology [B][H][ceil(W/32)]
     uint8_t* d_color = nullptr;         // BGR/BGRA frames of the colour-input API
     uint8_t* h_color = nullptr;
