@@ -193,6 +193,24 @@ void trexhip_default_posture_params(trexhip_posture_params* p);
 int trexhip_posture_device(trexhip_ctx* ctx, int32_t table, const trexhip_posture_params* pp, int32_t n_blobs,
                            float* d_outline, float* d_segments, trexhip_posture_info* d_info);
 
+/* Midline::post_process (no movement information, posture_direction_smoothing = 0; Outline.cpp:895-1060) followed by
+ * Midline::normalize() (Outline.cpp:1270-1454; call site Individual.cpp:1369-1372) for every blob of a posture call.
+ *   d_segments: the segments buffer of trexhip_posture_device (same max_points); post-processed IN PLACE (head part straightened)
+ *   d_midline : [n_blobs][midline_resolution] float4 = MidlineSegment{pos.x,pos.y,height,l_length}, head at the origin
+ *   info      : status 0 ok / 1 no midline / 2 resampling did not yield midline_resolution points (normalize() == nullptr);
+ *               len, angle, offset = Midline::len() / angle() / offset() (blob-local coordinates, like the outline) */
+typedef struct trexhip_midline_params {
+    int32_t midline_resolution;             /* core/default_config.cpp:894 (25)   */
+    float   midline_stiff_percentage;       /* :893 (0.15)                        */
+    int32_t midline_invert;                 /* :901 (false)                       */
+    int32_t midline_start_with_head;        /* :900 (false)                       */
+} trexhip_midline_params;
+typedef struct trexhip_midline_info { int32_t status, n; float len, angle, offx, offy; int32_t reserved[2]; } trexhip_midline_info;
+void trexhip_default_midline_params(trexhip_midline_params* p);
+int trexhip_midline_device(trexhip_ctx* ctx, const trexhip_midline_params* mp, int32_t n_blobs, int32_t max_points,
+                           const trexhip_posture_info* d_posture_info, float* d_segments, float* d_midline,
+                           trexhip_midline_info* d_midline_info);
+
 /* ---- crops ------------------------------------------------------------------------------------
  * constraints::diff_image (tracking/FilterCache.cpp:265-294): one out_w x out_h uint8 crop per blob of the
  * last segmented batch, pooled order (blob i of trexhip_fetch == crop i).  n_blobs = total_blobs of that
@@ -209,6 +227,13 @@ int trexhip_crops_device(trexhip_ctx* ctx, uint8_t* d_crops, int32_t n_blobs, in
 int trexhip_crops_transformed_device(trexhip_ctx* ctx, uint8_t* d_crops, int32_t n_blobs, int32_t out_w, int32_t out_h,
                                      const float* transforms, const float* midline_lengths, int32_t use_legacy,
                                      float image_scale, int32_t difference);
+/* the same with tr = Midline::transform(posture | legacy) built from trexhip_midline_device's info (device pointer, pooled
+ * order; blobs without a midline get an all-zero crop: diff_image returns nullptr for them, FilterCache.cpp:268-270).
+ * midline_lengths: host array, the individuals' median midline length per blob (FilterCache.cpp:272), or NULL to use
+ * each blob's own Midline::len(). */
+int trexhip_crops_posture_device(trexhip_ctx* ctx, uint8_t* d_crops, int32_t n_blobs, int32_t out_w, int32_t out_h,
+                                 const trexhip_midline_info* d_midline_info, const float* midline_lengths, int32_t use_legacy,
+                                 float image_scale, int32_t difference);
 
 /* ---- identity network (V118_3) -------------------------------------------------------------
  * VINetwork::load_weights (ml/VisualIdentification.cpp) / visual_recognition_torch.py:841-921: takes the

@@ -114,6 +114,9 @@ def lib():
         L.oracle_normalize_transform.argtypes = [C.c_void_p, C.c_float, C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_void_p]
         L.oracle_moments_transform.argtypes = [C.c_void_p, C.c_void_p]
         L.oracle_warp_affine_u8.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32]
+        L.oracle_midline_post_process.argtypes = [C.c_void_p, C.c_int32, C.c_float, C.c_int32, C.c_int32]
+        L.oracle_midline_normalize.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_float, C.c_void_p, C.c_void_p]
+        L.oracle_midline_transform.argtypes = [C.c_float, C.c_float, C.c_float, C.c_int32, C.c_void_p]
         L.oracle_bid.restype = C.c_uint32
         L.oracle_bid.argtypes = [C.c_uint32] * 4
         del u8p
@@ -327,3 +330,26 @@ def normalize_transform(tr6, midline_length, legacy, out_w, out_h, scale):
     M = np.zeros(6, np.float32)
     lib().oracle_normalize_transform(_ptr(tr), float(midline_length), 1 if legacy else 0, out_w, out_h, float(scale), _ptr(M))
     return M
+
+
+MIDLINE_INFO_DTYPE = np.dtype([("status", "<i4"), ("n", "<i4"), ("len", "<f4"), ("angle", "<f4"), ("offx", "<f4"), ("offy", "<f4"),
+                               ("reserved", "<i4", (2,))])
+
+
+def midline_normalize(segments, resolution=25, stiff=0.15, invert=False, start_with_head=False):
+    """Midline::post_process (no movement information) followed by Midline::normalize() (Individual.cpp:1369-1372).
+    returns (info, processed raw segments [n,4], normalised segments [resolution,4])."""
+    s = np.ascontiguousarray(segments, np.float32).copy()
+    info = np.zeros(1, MIDLINE_INFO_DTYPE)
+    out = np.zeros((resolution, 4), np.float32)
+    if lib().oracle_midline_post_process(_ptr(s), len(s), stiff, 1 if invert else 0, 1 if start_with_head else 0) != 0:
+        info["status"] = 1
+        return info[0], s, out
+    lib().oracle_midline_normalize(_ptr(s), len(s), resolution, stiff, _ptr(out), _ptr(info))
+    return info[0], s, out
+
+
+def midline_transform(angle, offx, offy, legacy=False):
+    tr = np.zeros(6, np.float32)
+    lib().oracle_midline_transform(float(angle), float(offx), float(offy), 1 if legacy else 0, _ptr(tr))
+    return tr

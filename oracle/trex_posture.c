@@ -266,3 +266,143 @@ int oracle_trace_outline(const oracle_run* runs, int32_t n_runs, int32_t ox, int
     if (n_runs <= 0) return 0;
     return trace_outline(runs, n_runs, ox, oy, (v2*)out_xy, cap);
 }
+
+/* ---- Midline::post_process (movement = none) + Midline::normalize (Outline.cpp:895-1060, 1270-1454) ---------------------
+ * in : raw midline of calculate_midline, tail first; out: `resolution` segments, head at the origin, rotated by -angle+pi
+ * (Individual.cpp:1369-1372: post_process, then normalize()).  Float2_t = float, the `double` accumulators of normalize
+ * are kept.  UNPINNED pieces (commons, NOT IN TREE): Vec2::normalize() of a zero vector returns zero; Vec2 * double is
+ * computed in double and narrowed per component; the axis loop of post_process stops before segments().at(size)
+ * (which would throw in the reference).  status: 0 ok, 1 <2 segments / zero length, 2 resampling did not give `resolution`
+ * points (normalize returns nullptr, :1378-1380). */
+typedef struct oracle_midline_info { int32_t status, n; float len, angle, offx, offy; int32_t reserved[2]; } oracle_midline_info;
+
+static v2 v2norm(v2 a) { const float L = sqrtf(a.x * a.x + a.y * a.y); v2 r = {0, 0}; if (L > 0) { r.x = a.x / L; r.y = a.y / L; } return r; }
+static float v2len(float x, float y) { return sqrtf(x * x + y * y); }
+
+static float midline_calculate_angle(const float* s4, int n, float stiff) {            /* Outline.cpp:1114-1124 */
+    if (n < 2) return 0;
+    float center = (float)(n - 2) - (float)n * stiff; if (center < 0) center = 0;
+    const int start = (int)center;
+    const float rest = center - (float)start;
+    const int s1 = start + 1 < n ? start + 1 : n - 1;
+    const float lx = s4[4 * (n - 1)] - (s4[4 * start] * (1 - rest) + s4[4 * s1] * rest);
+    const float ly = s4[4 * (n - 1) + 1] - (s4[4 * start + 1] * (1 - rest) + s4[4 * s1 + 1] * rest);
+    return atan2f(ly, lx);
+}
+
+int oracle_midline_post_process(float* s4, int n, float stiff, int invert, int start_with_head) {      /* :895-1060 */
+    if (n <= 2) return 1;
+    const int needs_invert = !invert;
+    int rev = needs_invert ? !start_with_head : start_with_head;
+    if (rev) for (int i = 0; i < n / 2; ++i) for (int k = 0; k < 4; ++k) { float t = s4[4 * i + k]; s4[4 * i + k] = s4[4 * (n - 1 - i) + k]; s4[4 * (n - 1 - i) + k] = t; }
+    if (stiff > 0) {
+        float cf = roundf((float)n * stiff) + 1; if ((float)n - 1 < cf) cf = (float)n - 1;
+        const int center = (int)cf;
+        const v2 cp = { s4[4 * center], s4[4 * center + 1] };
+        double eo = (double)center + ((double)n * 0.1 > 0.0 ? (double)n * 0.1 : 0.0); if ((double)n < eo) eo = (double)n;
+        const int extra = (int)eo;
+        v2 axis = {0, 0}; unsigned count = 0;
+        for (int i = center; i < extra && i + 1 < n; ++i) {
+            v2 d = { s4[4 * i] - s4[4 * (i + 1)], s4[4 * i + 1] - s4[4 * (i + 1) + 1] };
+            d = v2norm(d); axis.x += d.x; axis.y += d.y; ++count;
+        }
+        if (count > 0) { axis.x /= (float)count; axis.y /= (float)count; }
+        /* copy.at(i) - copy.at(i-1): lengths of the ORIGINAL segments */
+        float* L = (float*)malloc((size_t)(center + 1) * sizeof(float));
+        for (int i = center; i > 0; --i) L[i] = v2len(s4[4 * i] - s4[4 * (i - 1)], s4[4 * i + 1] - s4[4 * (i - 1) + 1]);
+        for (int i = center; i > 0; --i) {
+            const v2 p1 = { s4[4 * i], s4[4 * i + 1] };
+            v2 dc = { s4[4 * (i - 1)] - cp.x, s4[4 * (i - 1) + 1] - cp.y };
+            dc = v2norm(dc);
+            /* (direction_to_center + axis) * 0.5 : Vec2 * double */
+            v2 t = { (float)((double)(dc.x + axis.x) * 0.5), (float)((double)(dc.y + axis.y) * 0.5) };
+            t = v2norm(t);
+            s4[4 * (i - 1)] = p1.x + L[i] * t.x; s4[4 * (i - 1) + 1] = p1.y + L[i] * t.y;
+        }
+        free(L);
+    }
+    for (int i = 0; i < n / 2; ++i) for (int k = 0; k < 4; ++k) { float t = s4[4 * i + k]; s4[4 * i + k] = s4[4 * (n - 1 - i) + k]; s4[4 * (n - 1 - i) + k] = t; }   /* :1057 */
+    return 0;
+}
+
+int oracle_midline_normalize(const float* s4, int n, int resolution, float stiff, float* out4, oracle_midline_info* info) {   /* :1270-1454 */
+    memset(info, 0, sizeof(*info));
+    if (n < 2) { info->status = 1; return 1; }
+    double len = 0.0;
+    for (int i = 1; i < n; ++i) len += v2len(s4[4 * i] - s4[4 * (i - 1)], s4[4 * i + 1] - s4[4 * (i - 1) + 1]);
+    if (len == 0.0) { info->status = 1; return 1; }
+    const int max_segments = resolution - 1;
+    const double step = len / (double)max_segments;
+    float* red = (float*)malloc((size_t)(n + resolution + 8) * 4 * sizeof(float));
+    int nr = 0, cap = n + resolution + 8;
+    memcpy(red, s4, 4 * sizeof(float)); nr = 1;
+    int index = 0;
+    double last_pt_distance = 0.0, distance;
+    for (distance = 0.0; distance <= len && index < n - 1;) {
+        while (distance - last_pt_distance < step && index < n - 1) {
+            const float local_d = v2len(s4[4 * (index + 1)] - s4[4 * index], s4[4 * (index + 1) + 1] - s4[4 * index + 1]);
+            distance += local_d;
+            index++;
+        }
+        float off = (float)(distance - last_pt_distance);
+        if (off < step) break;
+        while (off >= step) {
+            off = (float)((double)off - step);
+            if (nr >= cap) break;
+            /* index > 0 always holds here (the inner while advanced it at least once or the loop broke) */
+            const float* s0 = s4 + 4 * (index - 1); const float* s1 = s4 + 4 * index;
+            const float lx = s1[0] - s0[0], ly = s1[1] - s0[1];
+            const float local_d = v2len(lx, ly);
+            float percent = off;
+            if (local_d > 0) percent /= local_d;
+            percent = 1.f - percent;
+            float* o = red + 4 * nr++;
+            o[0] = s0[0] + lx * percent; o[1] = s0[1] + ly * percent;
+            o[2] = (float)((double)(s0[2] * percent) + (double)s1[2] * (1.0 - (double)percent));
+            o[3] = s0[3] > s1[3] ? s0[3] : s1[3];
+            const double q = 1.0 - (double)percent;
+            last_pt_distance = distance - (double)v2len((float)((double)lx * q), (float)((double)ly * q));
+        }
+    }
+    {
+        const float dx = red[4 * (nr - 1)] - s4[4 * (n - 1)], dy = red[4 * (nr - 1) + 1] - s4[4 * (n - 1) + 1];
+        if (v2len(dx, dy) >= 0.01f && nr < cap) { memcpy(red + 4 * nr, s4 + 4 * (n - 1), 4 * sizeof(float)); ++nr; }
+    }
+    info->n = nr;
+    if (nr != resolution) { free(red); info->status = 2; return 2; }
+    {
+        float percent = v2len(red[4] - red[0], red[5] - red[1]);
+        if (len > 0) percent = (float)((double)percent / len);
+        red[2] = (float)((double)(red[4 + 2] * percent) + (double)red[2] * (1.0 - (double)percent));
+    }
+    len = 0.0;
+    for (int i = 1; i < nr; ++i) len += v2len(red[4 * i] - red[4 * (i - 1)], red[4 * i + 1] - red[4 * (i - 1) + 1]);
+    const float ang0 = midline_calculate_angle(red, nr, stiff);
+    const float angle = (float)(-(double)ang0 + 3.14159265358979323846);          /* Float2_t(-a + M_PI): double add, narrowed */
+    const float offx = red[4 * (nr - 1)], offy = red[4 * (nr - 1) + 1];
+    /* tf.rotate(DEGREE(angle)); tf.translate(-offx,-offy) */
+    const float deg = angle * 180.f / 3.14159265358979323846f;      /* DEGREE(), as in oracle_moments_transform */
+    const float rad = deg * 3.141592654f / 180.f;
+    const float c = cosf(rad), s = sinf(rad);
+    const float m0 = c, m1 = -s, m2 = c * -offx + -s * -offy, m3 = s, m4 = c, m5 = s * -offx + c * -offy;
+    float fx = 0, fy = 0;
+    for (int i = nr - 1, k = 0; i >= 0; --i, ++k) {
+        const float x = red[4 * i], y = red[4 * i + 1];
+        float px = m0 * x + m1 * y + m2, py = m3 * x + m4 * y + m5;
+        if (k == 0) { fx = px; fy = py; }
+        out4[4 * k] = px - fx; out4[4 * k + 1] = py - fy; out4[4 * k + 2] = red[4 * i + 2]; out4[4 * k + 3] = red[4 * i + 3];
+    }
+    info->len = (float)len; info->angle = ang0; info->offx = offx; info->offy = offy;
+    free(red);
+    return 0;
+}
+
+/* Midline::transform(normalization) (Outline.cpp:1237-1255), front() = 0: translate(-front) . rotate(DEGREE(-angle + pi/4 | pi)) . translate(-offset) */
+void oracle_midline_transform(float angle, float offx, float offy, int legacy, float* tr6) {
+    const float a = (float)(-(double)angle + (legacy ? 3.14159265358979323846 : 3.14159265358979323846 * 0.25));
+    const float deg = a * 180.f / 3.14159265358979323846f;
+    const float rad = deg * 3.141592654f / 180.f;
+    const float c = cosf(rad), s = sinf(rad);
+    tr6[0] = c; tr6[1] = -s; tr6[2] = c * -offx + -s * -offy;
+    tr6[3] = s; tr6[4] = c;  tr6[5] = s * -offx + c * -offy;
+}

@@ -101,3 +101,94 @@ def test_rethreshold_table_and_capacity():
     compare(res, outline, segs, info, oracle.posture_params(max_points=512))
     res, outline, segs, info = run_posture(fr, bg, max_points=32)
     assert np.all(info["status"] == 2)                                            # outline longer than the capacity
+
+
+@pytest.mark.parametrize("kw", [dict(), dict(midline_resolution=12, midline_stiff_percentage=0.3), dict(midline_stiff_percentage=0.0),
+                                 dict(midline_invert=1), dict(midline_start_with_head=1)])
+def test_midline_post_process_and_normalize(kw):
+    # Midline::post_process + normalize (Outline.cpp:895-1060,1270-1454) on the device's own raw segments vs the CPU restatement
+    fr, bg = synth.batch("C2", 2)
+    n, H, W = fr.shape
+    seg = capi.Segmenter(capi.default_params(W, H, max_batch=n))
+    seg.set_background(bg)
+    d = torch.from_numpy(fr).cuda()
+    seg.segment_device(d.data_ptr(), n)
+    res = seg.fetch()
+    total = sum(len(r.blobs) for r in res)
+    MP = 512
+    R = kw.get("midline_resolution", 25)
+    outline = torch.zeros((total, MP, 2), dtype=torch.float32, device="cuda")
+    segs = torch.zeros((total, MP // 2 + 1, 4), dtype=torch.float32, device="cuda")
+    info = torch.zeros((total, 8), dtype=torch.int32, device="cuda")
+    seg.posture_device(total, outline.data_ptr(), segs.data_ptr(), info.data_ptr())
+    seg.synchronize()
+    raw = segs.cpu().numpy().copy()
+    pinfo = info.cpu().numpy().view(capi.POSTURE_INFO_DTYPE).reshape(-1)
+    mid = torch.zeros((total, R, 4), dtype=torch.float32, device="cuda")
+    minfo = torch.zeros((total, 8), dtype=torch.int32, device="cuda")
+    seg.midline_device(total, MP, info.data_ptr(), segs.data_ptr(), mid.data_ptr(), minfo.data_ptr(), **kw)
+    seg.synchronize()
+    proc = segs.cpu().numpy(); mid = mid.cpu().numpy()
+    minfo = minfo.cpu().numpy().view(capi.MIDLINE_INFO_DTYPE).reshape(-1)
+    n_ok = 0
+    for bi in range(total):
+        ns = int(pinfo[bi]["n_segments"])
+        if pinfo[bi]["status"] != 0:
+            assert minfo[bi]["status"] == 1
+            continue
+        oi, oproc, onorm = oracle.midline_normalize(raw[bi, :ns], resolution=R, stiff=kw.get("midline_stiff_percentage", 0.15),
+                                                    invert=bool(kw.get("midline_invert", 0)), start_with_head=bool(kw.get("midline_start_with_head", 0)))
+        gi = minfo[bi]
+        assert gi["status"] == oi["status"] and gi["n"] == oi["n"], (bi, gi, oi)
+        # post_process is sqrt / divide / multiply / add only: bit-exact
+        assert np.array_equal(proc[bi, :ns], oproc), bi
+        if oi["status"] != 0:
+            continue
+        n_ok += 1
+        assert gi["offx"] == oi["offx"] and gi["offy"] == oi["offy"]
+        assert abs(gi["len"] - oi["len"]) <= 1e-4 * oi["len"]
+        assert abs(gi["angle"] - oi["angle"]) <= 1e-5
+        assert np.abs(mid[bi] - onorm).max() <= 1e-3
+    assert n_ok > 0.8 * total
+    seg.close()
+
+
+@pytest.mark.parametrize("legacy", [False, True])
+def test_crops_posture_normalisation(legacy):
+    # individual_image_normalization = posture / legacy end to end on the device: posture -> midline -> transform -> warp.
+    # The crop is checked bit-exactly against the CPU restatement fed with the device's Midline::angle()/offset().
+    fr, bg = synth.batch("C2", 2)
+    n, H, W = fr.shape
+    seg = capi.Segmenter(capi.default_params(W, H, max_batch=n))
+    seg.set_background(bg)
+    d = torch.from_numpy(fr).cuda()
+    seg.segment_device(d.data_ptr(), n)
+    res = seg.fetch()
+    total = sum(len(r.blobs) for r in res)
+    MP = 512
+    outline = torch.zeros((total, MP, 2), dtype=torch.float32, device="cuda")
+    segs = torch.zeros((total, MP // 2 + 1, 4), dtype=torch.float32, device="cuda")
+    info = torch.zeros((total, 8), dtype=torch.int32, device="cuda")
+    mid = torch.zeros((total, 25, 4), dtype=torch.float32, device="cuda")
+    minfo = torch.zeros((total, 8), dtype=torch.int32, device="cuda")
+    seg.posture_device(total, outline.data_ptr(), segs.data_ptr(), info.data_ptr())
+    seg.midline_device(total, MP, info.data_ptr(), segs.data_ptr(), mid.data_ptr(), minfo.data_ptr())
+    crops = torch.full((total, 80, 80), 9, dtype=torch.uint8, device="cuda")
+    seg.crops_posture_device(crops.data_ptr(), total, minfo.data_ptr(), legacy=legacy)
+    seg.synchronize()
+    crops = crops.cpu().numpy()
+    mi = minfo.cpu().numpy().view(capi.MIDLINE_INFO_DTYPE).reshape(-1)
+    filled = 0
+    for r, f in zip(res, fr):
+        for k, b in enumerate(r.blobs):
+            bi = int(r.info["blob_begin"]) + k
+            if mi[bi]["status"] != 0:
+                assert crops[bi].sum() == 0
+                continue
+            tr = oracle.midline_transform(mi[bi]["angle"], mi[bi]["offx"], mi[bi]["offy"], legacy)
+            want, _ = oracle.crop_normalized(f, bg, b, r.runs, tr6=tr, midline_length=float(mi[bi]["len"]), legacy=legacy)
+            assert np.array_equal(crops[bi], want), bi
+            # the whole animal must land inside the crop: same pixel mass as the un-normalised crop within interpolation loss
+            filled += crops[bi].sum() > 0.7 * oracle.crop_none(f, bg, b, r.runs).sum()
+    assert filled > 0.8 * total
+    seg.close()

@@ -87,3 +87,64 @@ def test_golden_midline_length_anchor():
                     ratios.append(np.linalg.norm(np.diff(seg[:, :2], axis=0), axis=1).sum() / gold[int(b["bid"])])
     assert len(ratios) >= 8
     assert 0.95 < np.median(ratios) < 1.06 and min(ratios) > 0.9 and max(ratios) < 1.12, (np.median(ratios), min(ratios), max(ratios))
+
+
+def _ellipse_midline(th=0.3):
+    yy, xx = np.mgrid[0:70, 0:120]
+    u = (xx - 60) * np.cos(th) + (yy - 35) * np.sin(th); v = -(xx - 60) * np.sin(th) + (yy - 35) * np.cos(th)
+    mask = (u / 40.0) ** 2 + (v / 8.0) ** 2 <= 1
+    info, outline, seg = oracle.posture(runs_of(mask), (0, 0))
+    assert info["status"] == 0
+    return seg
+
+
+@pytest.mark.parametrize("th", [0.0, 0.3, 1.2, 2.5])
+def test_midline_normalize_properties(th):
+    # Midline::post_process + normalize (Outline.cpp:895-1060,1270-1454): 25 equally spaced points, head at the origin,
+    # body pointing along -x after the rotation by -angle + pi, length preserved
+    seg = _ellipse_midline(th)
+    info, proc, norm = oracle.midline_normalize(seg)
+    assert info["status"] == 0 and info["n"] == 25
+    assert np.all(norm[0, :2] == 0)
+    d = np.linalg.norm(np.diff(norm[:, :2], axis=0), axis=1)
+    assert abs(d.sum() - info["len"]) < 1e-3
+    assert d.std() < 0.05 * d.mean()
+    raw_len = np.linalg.norm(np.diff(proc[:, :2], axis=0), axis=1).sum()
+    assert abs(raw_len - info["len"]) < 0.02 * raw_len
+    # the stiff part (tail end of the normalised midline is the far end): the far end lies on the +x axis direction
+    # defined by calculate_angle: the vector from the interpolated point at index 19.25 (counted from the tail) to the head
+    # maps onto the negative x axis
+    tail_first = norm[::-1, :2]
+    p = tail_first[19] * 0.75 + tail_first[20] * 0.25
+    v = tail_first[-1] - p
+    assert abs(np.arctan2(v[1], v[0])) > np.pi - 1e-3 or abs(np.arctan2(v[1], v[0]) - np.pi) < 1e-3
+    # ellipse: long axis direction modulo pi
+    a = (info["angle"] - th) % np.pi
+    assert min(a, np.pi - a) < 0.12
+    # post_process only moves the stiff (head) part: segments at the tail side are untouched
+    assert np.array_equal(proc[: len(seg) // 2], seg[: len(seg) // 2])
+    # and keeps the segment lengths of the part it straightens
+    l0 = np.linalg.norm(np.diff(seg[:, :2], axis=0), axis=1); l1 = np.linalg.norm(np.diff(proc[:, :2], axis=0), axis=1)
+    assert np.allclose(l0, l1, atol=1e-4)
+
+
+def test_midline_normalize_degenerate():
+    info, _, _ = oracle.midline_normalize(np.zeros((1, 4), np.float32))
+    assert info["status"] == 1
+    info, _, _ = oracle.midline_normalize(np.zeros((5, 4), np.float32))       # zero length
+    assert info["status"] == 1
+    # straight line: exact resampling
+    s = np.zeros((11, 4), np.float32); s[:, 0] = np.arange(11) * 2.4; s[:, 2] = 3
+    info, proc, norm = oracle.midline_normalize(s, stiff=0.0)
+    assert info["status"] == 0 and abs(info["len"] - 24.0) < 1e-4
+    assert np.allclose(np.abs(norm[:, 0]), np.arange(25) * 1.0, atol=1e-4) and np.allclose(norm[:, 1], 0, atol=1e-4)
+
+
+def test_midline_transform_maps_head_offset_to_origin():
+    seg = _ellipse_midline(0.7)
+    info, proc, norm = oracle.midline_normalize(seg)
+    for legacy in (False, True):
+        tr = oracle.midline_transform(info["angle"], info["offx"], info["offy"], legacy)
+        p = np.array([info["offx"], info["offy"]], np.float32)
+        q = tr.reshape(2, 3)[:, :2] @ p + tr.reshape(2, 3)[:, 2]
+        assert np.allclose(q, 0, atol=1e-3)

@@ -49,6 +49,13 @@ class PostureParams(C.Structure):
                 ("midline_walk_offset", C.c_float), ("max_points", C.c_int32)]
 
 
+class MidlineParams(C.Structure):
+    _fields_ = [("midline_resolution", C.c_int32), ("midline_stiff_percentage", C.c_float), ("midline_invert", C.c_int32),
+                ("midline_start_with_head", C.c_int32)]
+
+
+MIDLINE_INFO_DTYPE = np.dtype([("status", "<i4"), ("n", "<i4"), ("len", "<f4"), ("angle", "<f4"), ("offx", "<f4"), ("offy", "<f4"),
+                               ("reserved", "<i4", (2,))])
 POSTURE_INFO_DTYPE = np.dtype([("status", "<i4"), ("n_outline", "<i4"), ("n_segments", "<i4"), ("tail_index", "<i4"),
                                ("head_index", "<i4"), ("n_traced", "<i4"), ("reserved", "<i4", (2,))])
 
@@ -77,7 +84,7 @@ SYMBOLS = [
     "trexhip_set_stream", "trexhip_set_background", "trexhip_set_background_device", "trexhip_generate_average_device", "trexhip_get_background", "trexhip_segment_device",
     "trexhip_segment", "trexhip_segment_color", "trexhip_rethreshold_device", "trexhip_rethreshold_per_blob_device", "trexhip_fetch_rethreshold", "trexhip_fetch", "trexhip_device_view_get", "trexhip_synchronize",
     "trexhip_profile_enable", "trexhip_profile_read", "trexhip_profile_reset",
-    "trexhip_default_posture_params", "trexhip_posture_device", "trexhip_crops_device", "trexhip_crops_transformed_device", "trexhip_export_id_table_device", "trexhip_load_weights", "trexhip_set_identity_precision", "trexhip_num_classes", "trexhip_identify_device", "trexhip_identify",
+    "trexhip_default_posture_params", "trexhip_posture_device", "trexhip_crops_device", "trexhip_crops_transformed_device", "trexhip_crops_posture_device", "trexhip_default_midline_params", "trexhip_midline_device", "trexhip_export_id_table_device", "trexhip_load_weights", "trexhip_set_identity_precision", "trexhip_num_classes", "trexhip_identify_device", "trexhip_identify",
 ]
 
 
@@ -110,6 +117,10 @@ def lib():
         L.trexhip_profile_enable.argtypes = [C.c_void_p, C.c_int32]
         L.trexhip_profile_read.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
         L.trexhip_profile_reset.argtypes = [C.c_void_p]
+        L.trexhip_default_midline_params.argtypes = [C.POINTER(MidlineParams)]
+        L.trexhip_default_midline_params.restype = None
+        L.trexhip_midline_device.argtypes = [C.c_void_p, C.POINTER(MidlineParams), C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.trexhip_crops_posture_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_float, C.c_int32]
         L.trexhip_default_posture_params.argtypes = [C.POINTER(PostureParams)]
         L.trexhip_default_posture_params.restype = None
         L.trexhip_posture_device.argtypes = [C.c_void_p, C.c_int32, C.POINTER(PostureParams), C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]
@@ -263,6 +274,20 @@ class Segmenter:
     def crops_device(self, d_crops_ptr, n_blobs, out_w=80, out_h=80, normalization=0, difference=0):
         """constraints::diff_image for every blob of the last batch -> uint8 [n_blobs][out_h][out_w] at d_crops_ptr."""
         _check(lib().trexhip_crops_device(self._h, C.c_void_p(d_crops_ptr), n_blobs, out_w, out_h, normalization, difference))
+
+    def midline_device(self, n_blobs, max_points, d_posture_info_ptr, d_segments_ptr, d_midline_ptr, d_midline_info_ptr, **kw):
+        """Midline::post_process + normalize for every blob of a posture call; see include/trexhip.h."""
+        mp = MidlineParams()
+        lib().trexhip_default_midline_params(C.byref(mp))
+        for k, v in kw.items():
+            setattr(mp, k, v)
+        _check(lib().trexhip_midline_device(self._h, C.byref(mp), n_blobs, max_points, C.c_void_p(d_posture_info_ptr), C.c_void_p(d_segments_ptr),
+                                            C.c_void_p(d_midline_ptr), C.c_void_p(d_midline_info_ptr)))
+
+    def crops_posture_device(self, d_crops_ptr, n_blobs, d_midline_info_ptr, midline_lengths=None, out_w=80, out_h=80, legacy=False, scale=1.0, difference=0):
+        ln = None if midline_lengths is None else np.ascontiguousarray(midline_lengths, np.float32)
+        _check(lib().trexhip_crops_posture_device(self._h, C.c_void_p(d_crops_ptr), n_blobs, out_w, out_h, C.c_void_p(d_midline_info_ptr),
+                                                  None if ln is None else ln.ctypes.data_as(C.c_void_p), 1 if legacy else 0, scale, difference))
 
     def crops_transformed_device(self, d_crops_ptr, transforms, midline_lengths, out_w=80, out_h=80, legacy=False, scale=1.0, difference=0):
         """posture / legacy normalisation with caller-supplied Midline::transform matrices (host float32 [n,6]) and lengths [n]."""

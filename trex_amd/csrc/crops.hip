@@ -55,7 +55,7 @@ __global__ __launch_bounds__(256) void k_crops_none(const SegCfg c, const uint8_
 }
 
 int launch_crops_warp(trexhip_ctx* ctx, uint8_t* d_crops, int n, int OW, int OH, int diff_mode, const float* tr6, const float* lengths,
-                      bool legacy, float scale);
+                      bool legacy, float scale, const uint8_t* valid);
 
 int launch_crops(trexhip_ctx* ctx, uint8_t* d_crops, int n, int OW, int OH, int diff_mode) {
     if (n <= 0) return TREXHIP_OK;
@@ -89,7 +89,7 @@ int trexhip_crops_device(trexhip_ctx* ctx, uint8_t* d_crops, int32_t n_blobs, in
     if (!ctx->fetched) { set_error("trexhip_crops_device: call trexhip_fetch on the segmented batch first"); return TREXHIP_E_INVALID; }
     TH_CHECK_HIP(hipSetDevice(ctx->p.device));
     if (normalization == TREXHIP_NORMALIZE_MOMENTS)
-        return launch_crops_warp(ctx, d_crops, n_blobs, out_w, out_h, difference, nullptr, nullptr, false, 1.0f);
+        return launch_crops_warp(ctx, d_crops, n_blobs, out_w, out_h, difference, nullptr, nullptr, false, 1.0f, nullptr);
     return launch_crops(ctx, d_crops, n_blobs, out_w, out_h, difference);
 }
 
@@ -400,7 +400,7 @@ static void compose_and_invert(const Aff& tr, float midline_length, bool legacy,
 }
 
 int launch_crops_warp(trexhip_ctx* ctx, uint8_t* d_crops, int n, int OW, int OH, int diff_mode, const float* tr6, const float* lengths,
-                      bool legacy, float scale) {
+                      bool legacy, float scale, const uint8_t* valid) {
     // tr6 == nullptr: `moments` -- orientation from the integer moments of the fetched blob table (host copy)
     std::vector<double> minv((size_t)n * 6);
     for (int i = 0; i < n; ++i) {
@@ -419,6 +419,8 @@ int launch_crops_warp(trexhip_ctx* ctx, uint8_t* d_crops, int n, int OW, int OH,
             tr = aff_translate(t, -(float)(B.x1 - B.x0 + 1) * 0.5f, -(float)(B.y1 - B.y0 + 1) * 0.5f);
         }
         compose_and_invert(tr, len, legacy, OW, OH, scale, &minv[(size_t)i * 6]);
+        // no midline: every source coordinate far outside the image -> all-zero crop
+        if (valid && !valid[i]) { double* m = &minv[(size_t)i * 6]; m[0] = m[1] = m[3] = m[4] = 0; m[2] = m[5] = -1.0e6; }
     }
     if (ctx->warp_cap < n) {
         if (ctx->d_warp) (void)hipFree(ctx->d_warp);
@@ -450,5 +452,5 @@ extern "C" int trexhip_crops_transformed_device(trexhip_ctx* ctx, uint8_t* d_cro
     if (n_blobs < 0 || (uint32_t)n_blobs > ctx->cfg.pool_blobs) { set_error("trexhip_crops_transformed_device: n_blobs outside the blob pool"); return TREXHIP_E_INVALID; }
     if (n_blobs == 0) return TREXHIP_OK;
     TH_CHECK_HIP(hipSetDevice(ctx->p.device));
-    return launch_crops_warp(ctx, d_crops, n_blobs, out_w, out_h, difference, transforms, midline_lengths, use_legacy != 0, image_scale);
+    return launch_crops_warp(ctx, d_crops, n_blobs, out_w, out_h, difference, transforms, midline_lengths, use_legacy != 0, image_scale, nullptr);
 }

@@ -106,7 +106,7 @@ __global__ __launch_bounds__(256) void k_posture(const PostureCfg P, const trexh
                     int i1 = i + 1; if (i1 >= nt) i1 -= nt;
                     const float2 pt0 = bufA[i], pt1 = bufA[i1];
                     const float lxn = pt1.x - pt0.x, lyn = pt1.y - pt0.y;
-                    const float len = __fsqrt_rn(lxn * lxn + lyn * lyn);
+                    const float len = sqrtf(lxn * lxn + lyn * lyn);
                     walked += len;
                     const float percent = len / rd;
                     float wp = walked / rd;
@@ -166,7 +166,7 @@ __global__ __launch_bounds__(256) void k_posture(const PostureCfg P, const trexh
         for (int i0 = 0; i0 < n; i0 += 64) {
             const int i = i0 + lane;
             float dt = 0.f;
-            if (i < n) { const float2 a = pts[i], q = pts[(i + 1) % n]; dt = __fsqrt_rn((q.x - a.x) * (q.x - a.x) + (q.y - a.y) * (q.y - a.y)); }
+            if (i < n) { const float2 a = pts[i], q = pts[(i + 1) % n]; dt = sqrtf((q.x - a.x) * (q.x - a.x) + (q.y - a.y) * (q.y - a.y)); }
             float incl = dt;
 #pragma unroll
             for (int d = 1; d < 64; d <<= 1) { const float t = __shfl_up(incl, d); if (lane >= d) incl += t; }
@@ -214,7 +214,7 @@ __global__ __launch_bounds__(256) void k_posture(const PostureCfg P, const trexh
         const float d12 = (p2.x - p1.x) * (p2.x - p1.x) + (p2.y - p1.y) * (p2.y - p1.y);
         const float d23 = (p3.x - p2.x) * (p3.x - p2.x) + (p3.y - p2.y) * (p3.y - p2.y);
         const float d13 = (p3.x - p1.x) * (p3.x - p1.x) + (p3.y - p1.y) * (p3.y - p1.y);
-        const float den = __fsqrt_rn(d12 * d23 * d13);
+        const float den = sqrtf(d12 * d23 * d13);
         s_curv[i] = den > 0.f ? fabsf(2.0f * cr / den) : 0.0f;
     }
     __builtin_amdgcn_wave_barrier();
@@ -264,7 +264,7 @@ __global__ __launch_bounds__(256) void k_posture(const PostureCfg P, const trexh
             for (int i = 0; i < max_offset; ++i) {
                 if (idx_r + i >= L) break;
                 const float2 pt = pts[idx_r + i];
-                const float ddx = pt.x - pt_l.x, ddy = pt.y - pt_l.y, len = __fsqrt_rn(ddx * ddx + ddy * ddy);
+                const float ddx = pt.x - pt_l.x, ddy = pt.y - pt_l.y, len = sqrtf(ddx * ddx + ddy * ddy);
                 if (len < min_d) { min_d = len; min_idx = idx_r + i; }
             }
             if (min_idx != -1) { pt_r = pts[min_idx]; idx_r = min_idx; }
@@ -272,14 +272,14 @@ __global__ __launch_bounds__(256) void k_posture(const PostureCfg P, const trexh
             for (int i = 0; i < max_offset; ++i) {
                 if (idx_l - i <= -L) break;
                 const float2 pt = pts[L + idx_l - i];
-                const float ddx = pt_r.x - pt.x, ddy = pt_r.y - pt.y, len = __fsqrt_rn(ddx * ddx + ddy * ddy);
+                const float ddx = pt_r.x - pt.x, ddy = pt_r.y - pt.y, len = sqrtf(ddx * ddx + ddy * ddy);
                 if (len < min_d) { min_d = len; min_idx = idx_l - i; }
             }
             if (min_idx != 1) { pt_l = pts[L + min_idx]; idx_l = min_idx; }
             const float lx = pt_r.x - pt_l.x, ly = pt_r.y - pt_l.y;
             const float mx = pt_l.x + lx * 0.5f, my = pt_l.y + ly * 0.5f;
             if (ns <= P.max_points / 2)
-                so[ns] = make_float4(mx, my, __fsqrt_rn(lx * lx + ly * ly), __fsqrt_rn((mx - pt_l.x) * (mx - pt_l.x) + (my - pt_l.y) * (my - pt_l.y)));
+                so[ns] = make_float4(mx, my, sqrtf(lx * lx + ly * ly), sqrtf((mx - pt_l.x) * (mx - pt_l.x) + (my - pt_l.y) * (my - pt_l.y)));
             ++ns;
             idx_r++; idx_l--;
         }
