@@ -47,6 +47,7 @@ def main():
                     help="arithmetic of conv2/conv3: fp16x3 = 2-piece fp16 split, fp32-class error, range-guarded (default); bf16x6 = 3-piece bf16 split; fp32 = exact fp32 MFMA")
     ap.add_argument("--with-posture", action="store_true", help="also run posture (outline -> midline) for every blob inside the timed step (configs C3/C5)")
     ap.add_argument("--no-pipeline", dest="pipeline", action="store_false", help="one context, strictly serial steps (no overlap of detect(i+1) with identity(i))")
+    ap.add_argument("--lanes", type=int, default=2, help="software-pipeline depth: contexts whose batches are in flight (detect of batch i+L-1 is issued while the identity network works on batch i)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     args = ap.parse_args()
@@ -132,27 +133,30 @@ def main():
         def drain(self):
             self.stream.synchronize()
 
-    lanes = [Lane(), Lane()] if args.pipeline else [Lane()]
-    if len(lanes) == 2:
-        lanes[0].after, lanes[1].after = lanes[1], lanes[0]
-        lanes[0].done.record(lanes[0].stream); lanes[1].done.record(lanes[1].stream)
+    lanes = [Lane() for _ in range(max(2, args.lanes))] if args.pipeline else [Lane()]
+    if len(lanes) > 1:
+        for k, ln in enumerate(lanes):
+            ln.after = lanes[(k - 1) % len(lanes)]
+            ln.done.record(ln.stream)
     seg = lanes[0].seg
     torch.cuda.synchronize()
 
     def run(k):
         """k steps = k batches through detect -> (posture) -> crops -> identity -> table on the host."""
         L = len(lanes)
-        lanes[0].detect()
+        D = max(1, L - 1)                           # detect runs D batches ahead of the identity network
+        for i in range(min(D, k)):
+            lanes[i % L].detect()
         for i in range(k):
             cur = lanes[i % L]
             cur.identify(i)                         # enqueue everything downstream of detect(i)
-            if i + 1 < k:
-                nxt = lanes[(i + 1) % L]
+            if i + D < k:
+                nxt = lanes[(i + D) % L]
                 if L > 1:
-                    nxt.drain()                     # its previous batch (i-1) is complete: table_host consumed by the matcher
+                    nxt.drain()                     # its previous batch (i+D-L) is complete: table_host consumed by the matcher
                 else:
                     cur.drain()
-                nxt.detect()                        # detect(i+1) overlaps the identity network of batch i
+                nxt.detect()                        # detect(i+D) overlaps the identity network of batches i-1 / i
         for ln in lanes:
             ln.drain()
         return lanes[(k - 1) % L].n
@@ -241,12 +245,12 @@ def main():
         fl = FLOP_PER_CROP_CONV3 * n_blobs
         nprod = {"fp32": 1, "bf16x6": 6, "bf16x3": 3, "fp16x3": 3}[args.cnn_mode]
         peak = 157.3 if args.cnn_mode == "fp32" else 2500.0
-        kname = "k_conv5<64,128,20,20,32> (conv3, fp32 MFMA)" if args.cnn_mode == "fp32" else f"k_conv5_split<64,128,20,20,{args.cnn_mode}> (conv3, 16-bit MFMA x{nprod} per fp32 product)"
+        kname = "k_conv5<64,128,20,20,32> (conv3, fp32 MFMA)" if args.cnn_mode == "fp32" else (f"k_conv5_stream<64,128,20,20,8> (conv3, fp16 MFMA x{nprod} per fp32 product)" if args.cnn_mode == "fp16x3" else f"k_conv5_split<64,128,20,20,{args.cnn_mode}> (conv3, 16-bit MFMA x{nprod} per fp32 product)")
         out["roofline"] = {"kernel": kname, "bound": "mfma", "achieved": fl / c3_s / 1e12 if c3_s else 0.0,
                            "peak": peak, "unit": "TFLOP/s", "frac": fl / c3_s / (peak * 1e12) if c3_s else 0.0,
                            "mfma_products_per_algorithmic_product": nprod,
                            "mfma_issue_frac": nprod * fl / c3_s / (peak * 1e12) if c3_s else 0.0,
-                           "traffic": pmc_traffic("trexhip::k_conv5_split<64, 128, 20, 20, 1, 3") if args.cnn_mode == "fp16x3" else None,
+                           "traffic": pmc_traffic("trexhip::k_conv5_stream<64, 128, 20, 20, 8>") if args.cnn_mode == "fp16x3" else None,
                            "traffic_note": "HBM bytes/launch from profiles/r01_pmc_summary.json (FETCH_SIZE x2 + WRITE_SIZE); algorithmic bytes = 0.98 GB (activations in+out)",
                            "avg_launch_us": c3_s * 1e6, "launches": prof["CONV3"][1], "algorithmic_flop_per_launch": fl,
                            "peak_note": "achieved counts ALGORITHMIC flops (2 per fp32 multiply-add); peak is the dense MFMA peak of the instruction used (fp32: 157.3, bf16: 2500 TFLOP/s, MI355X_MICROARCH.md); in the split modes every algorithmic product costs `mfma_products_per_algorithmic_product` bf16 MFMA products, so the matrix pipe is busy mfma_issue_frac of its peak"}

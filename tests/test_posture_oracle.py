@@ -70,7 +70,7 @@ def test_midline_of_an_ellipse_follows_its_long_axis():
 
 def test_golden_midline_length_anchor():
     """midline_length column of videos/compare_data_automatic (Midline::len() of the normalised midline, about 39-40 px for
-    these fish) vs the raw midline polyline of this restatement on the same blobs: same animal length: measured median ratio 1.006 (0.993 .. 1.04 over 48 fish-frames; the golden column is rounded to integers)."""
+    these fish) vs Midline::len() of this restatement (post_process + normalize) on the same blobs: same animal length: measured median ratio 1.006 (0.993 .. 1.04 over 48 fish-frames; the golden column is rounded to integers)."""
     from test_golden_e2e import FIX, rebuild, RANGES
     z = np.load(FIX)
     ratios = []
@@ -84,7 +84,9 @@ def test_golden_midline_length_anchor():
                 rs = runs[b["run_begin"]:b["run_begin"] + b["n_runs"]]
                 info, outline, seg = oracle.posture(rs, (int(b["x0"]), int(b["y0"])), oracle.posture_params(outline_resample=0.5))
                 if info["status"] == 0:
-                    ratios.append(np.linalg.norm(np.diff(seg[:, :2], axis=0), axis=1).sum() / gold[int(b["bid"])])
+                    mi, _, _ = oracle.midline_normalize(seg)            # Midline::len() of the normalised midline is what the column holds
+                    assert mi["status"] == 0 and mi["n"] == 25
+                    ratios.append(float(mi["len"]) / gold[int(b["bid"])])
     assert len(ratios) >= 8
     assert 0.95 < np.median(ratios) < 1.06 and min(ratios) > 0.9 and max(ratios) < 1.12, (np.median(ratios), min(ratios), max(ratios))
 

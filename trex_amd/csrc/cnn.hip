@@ -403,6 +403,165 @@ __global__ __launch_bounds__(512) void k_conv5_split(const float* __restrict__ i
 }
 
 // ------------------------------------------------------------------------------------------------
+// k_conv5_stream: the fp16 two-piece convolution without a barrier in the tap loop.
+//   * weight fragments go global(L2) -> VGPR directly, prefetched two taps ahead (the pre-split weight image is laid out
+//     exactly as the MFMA B operand wants it: [chunk][tap][piece][k-octet][co] x 16 B, so a half-wave reads 512 contiguous
+//     bytes); nothing but the activation patch lives in LDS, so waves never wait for each other inside a chunk;
+//   * with more than one 16-channel chunk the patch is double-buffered and the next chunk is staged (global load, fp16
+//     split, LDS store) in slices between the taps of the current one: one barrier per chunk instead of 26;
+//   * patch rows are padded so that the row pitch is 8 (mod 16) in 16-byte slots: the 16 lanes of one ds_read_b128 lane
+//     group (MI355X guide, LDS table) then hit 16 distinct slots.
+// ------------------------------------------------------------------------------------------------
+template <int CI, int CO, int S, int ROWS, int WAVES>
+struct ConvGeomS {
+    static constexpr int CIC = 16;
+    static constexpr int PW = S + 4, PH = ROWS + 4;
+    static constexpr int PSTRIDE = 48;                                  // 16 fp16 + 16 B pad per pixel
+    static constexpr int RP0 = PW * PSTRIDE;
+    static constexpr int PADU = ((8 - (RP0 / 16) % 16) + 16) % 16;
+    static constexpr int RP = RP0 + PADU * 16;                          // row pitch, bytes
+    static constexpr int PATCH = PH * RP;                               // bytes per piece
+    static constexpr int NCH = CI / CIC;
+    static constexpr int NBUF = NCH > 1 ? 2 : 1;
+    static constexpr int LDS_BYTES = NBUF * 2 * PATCH;
+    static constexpr int NTHR = WAVES * 64;
+    static constexpr int NPIX = ROWS * S;
+    static constexpr int MT = (NPIX + 31) / 32;
+    static constexpr int NT = CO / 32;
+    static constexpr int WM = WAVES / NT;
+    static constexpr int TPW = (MT + WM - 1) / WM;
+    static constexpr int BPC = S / ROWS;
+    static constexpr int BV = 2 * 2 * CO;                               // uint4 per tap tile: pieces x k-octets x co
+    static constexpr int NQ = PH * PW * 4;                              // float4 per staged chunk
+    static constexpr int NITEMS = (NQ + NTHR - 1) / NTHR;
+};
+
+template <int CI, int CO, int S, int ROWS, int WAVES>
+__global__ __launch_bounds__(WAVES * 64) void k_conv5_stream(const float* __restrict__ in /*[N][S][S][CI]*/,
+                                                             const uint4* __restrict__ wp /*[CI/16][25][2][2][CO] x 16 B*/,
+                                                             const float* __restrict__ bias, float* __restrict__ out,
+                                                             const float out_scale, uint32_t* __restrict__ overflow) {
+    using G = ConvGeomS<CI, CO, S, ROWS, WAVES>;
+    static_assert(G::NCH == 1 || G::NITEMS <= 5, "staging slices do not fit between the taps");
+    extern __shared__ __attribute__((aligned(16))) uint8_t ldsb[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int j = lane & 31, h = lane >> 5;
+    const int n = wave % G::NT, mg = wave / G::NT;
+    const int crop = blockIdx.x / G::BPC, row0 = (blockIdx.x % G::BPC) * ROWS;
+    constexpr int WR = S / 2;
+
+    int aoff[G::TPW];
+#pragma unroll
+    for (int m = 0; m < G::TPW; ++m) {
+        const int p = (mg + G::WM * m) * 32 + j;
+        int off = 0;
+        if (p < G::NPIX) {
+            const int wi = p >> 2, sub = p & 3;
+            const int wy = wi / WR, wx = wi - wy * WR;
+            off = (2 * wy + (sub >> 1)) * G::RP + (2 * wx + (sub & 1)) * G::PSTRIDE;
+        }
+        aoff[m] = off + h * 16;
+    }
+    f32x16 acc[G::TPW];
+#pragma unroll
+    for (int m = 0; m < G::TPW; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
+
+    const float* inc = in + (size_t)crop * S * S * CI;
+    bool ovf = false;
+    // one staged item: float4 of 4 input channels of one patch pixel -> two fp16 pieces in LDS
+#define STG_LOAD(v_, item_, cc_)                                                                                              \
+    do {                                                                                                                      \
+        const int idx_ = tid + (item_) * G::NTHR;                                                                             \
+        v_ = make_float4(0.f, 0.f, 0.f, 0.f);                                                                                 \
+        if (idx_ < G::NQ) {                                                                                                   \
+            const int px_ = idx_ >> 2, q_ = idx_ & 3;                                                                         \
+            const int py_ = px_ / G::PW, pxx_ = px_ - py_ * G::PW;                                                            \
+            const int iy_ = row0 + py_ - 2, ix_ = pxx_ - 2;                                                                   \
+            if (iy_ >= 0 && iy_ < S && ix_ >= 0 && ix_ < S)                                                                   \
+                v_ = *reinterpret_cast<const float4*>(inc + ((size_t)iy_ * S + ix_) * CI + (cc_) * 16 + q_ * 4);              \
+        }                                                                                                                     \
+    } while (0)
+#define STG_STORE(v_, item_, base_)                                                                                           \
+    do {                                                                                                                      \
+        const int idx_ = tid + (item_) * G::NTHR;                                                                             \
+        if (idx_ < G::NQ) {                                                                                                   \
+            const int px_ = idx_ >> 2, q_ = idx_ & 3;                                                                         \
+            const int py_ = px_ / G::PW, pxx_ = px_ - py_ * G::PW;                                                            \
+            uint32_t a1_[4], a2_[4];                                                                                          \
+            split2h(v_.x, a1_[0], a2_[0], ovf); split2h(v_.y, a1_[1], a2_[1], ovf);                                           \
+            split2h(v_.z, a1_[2], a2_[2], ovf); split2h(v_.w, a1_[3], a2_[3], ovf);                                           \
+            uint8_t* d_ = (base_) + py_ * G::RP + pxx_ * G::PSTRIDE + q_ * 8;                                                 \
+            *reinterpret_cast<uint2*>(d_) = make_uint2(a1_[0] | (a1_[1] << 16), a1_[2] | (a1_[3] << 16));                     \
+            *reinterpret_cast<uint2*>(d_ + G::PATCH) = make_uint2(a2_[0] | (a2_[1] << 16), a2_[2] | (a2_[3] << 16));          \
+        }                                                                                                                     \
+    } while (0)
+
+    // B fragments of this lane: k-octet h, output channel n*32+j; piece 1 is 2*CO uint4 further
+    const uint4* wl = wp + (h * CO + n * 32 + j);
+    uint4 bq[5][2];
+    bq[0][0] = wl[0]; bq[0][1] = wl[2 * CO];
+    bq[1][0] = wl[G::BV]; bq[1][1] = wl[G::BV + 2 * CO];
+    for (int it = 0; it < G::NITEMS; ++it) {       // first chunk: staged up front
+        float4 v;
+        STG_LOAD(v, it, 0);
+        STG_STORE(v, it, ldsb);
+    }
+    __syncthreads();
+    for (int cc = 0; cc < G::NCH; ++cc) {
+        const uint8_t* pbase = ldsb + (G::NBUF > 1 ? (cc & 1) * 2 * G::PATCH : 0);
+        uint8_t* nbase = ldsb + (G::NBUF > 1 ? ((cc + 1) & 1) * 2 * G::PATCH : 0);
+        const bool more = cc + 1 < G::NCH;
+        const uint4* wc = wl + (size_t)cc * 25 * G::BV;
+        float4 sv = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int tap = 0; tap < 25; ++tap) {
+            if (tap + 2 < 25 || more) {            // weights two taps ahead (runs into the next chunk's first taps)
+                bq[(tap + 2) % 5][0] = wc[(size_t)(tap + 2) * G::BV];
+                bq[(tap + 2) % 5][1] = wc[(size_t)(tap + 2) * G::BV + 2 * CO];
+            }
+            if (G::NCH > 1 && more) {
+                if (tap % 5 == 0 && tap / 5 < G::NITEMS) STG_LOAD(sv, tap / 5, cc + 1);
+                if (tap % 5 == 3 && tap / 5 < G::NITEMS) STG_STORE(sv, tap / 5, nbase);
+            }
+            const uint8_t* asrc = pbase + ((tap / 5) * G::RP + (tap % 5) * G::PSTRIDE);
+            const f16x8 b1 = __builtin_bit_cast(f16x8, bq[tap % 5][0]);
+            const f16x8 b2 = __builtin_bit_cast(f16x8, bq[tap % 5][1]);
+#pragma unroll
+            for (int m = 0; m < G::TPW; ++m) {
+                const f16x8 p1 = __builtin_bit_cast(f16x8, *reinterpret_cast<const uint4*>(asrc + aoff[m]));
+                const f16x8 p2 = __builtin_bit_cast(f16x8, *reinterpret_cast<const uint4*>(asrc + aoff[m] + G::PATCH));
+                acc[m] = mfma16(p2, b1, acc[m]);
+                acc[m] = mfma16(p1, b2, acc[m]);
+                acc[m] = mfma16(p1, b1, acc[m]);
+            }
+        }
+        if (G::NCH > 1) __syncthreads();
+    }
+#undef STG_LOAD
+#undef STG_STORE
+    if (__any(ovf) && lane == 0) atomicOr(overflow, 1u);
+    const int co = n * 32 + j;
+    const float bz = bias[co];
+    float* oc = out + (size_t)crop * WR * WR * CO;
+#pragma unroll
+    for (int m = 0; m < G::TPW; ++m) {
+        const int mt = mg + G::WM * m;
+        if (mt >= G::MT) continue;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int wi = mt * 8 + 2 * g + h;
+            if (wi >= G::NPIX / 4) continue;
+            const float v = fmaxf(fmaxf(acc[m][4 * g], acc[m][4 * g + 1]), fmaxf(acc[m][4 * g + 2], acc[m][4 * g + 3]));
+            const int wy = row0 / 2 + wi / WR, wx = wi % WR;
+            oc[((size_t)wy * WR + wx) * CO + co] = fmaxf(v * out_scale + bz, 0.f);
+        }
+    }
+}
+
+static constexpr int FC1_KSPLIT = 5;      // 12800 = 5 x 2560: 5x the workgroups (200 -> 1000 at 6400 crops), partials summed in k_head
+// ------------------------------------------------------------------------------------------------
 // fc1: out[N][128] = act[N][K] * W[K][128] + b     (K = 12800, 100 real outputs)
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_fc1(const float* __restrict__ act, const float* __restrict__ w /*[K][128]*/,
@@ -414,14 +573,17 @@ __global__ __launch_bounds__(256) void k_fc1(const float* __restrict__ act, cons
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int j = lane & 31, h = lane >> 5;
     const int m0 = blockIdx.x * 32;
+    // split-K: blockIdx.y takes K/gridDim.y consecutive inputs and writes its own partial plane (summed in k_head, fixed order)
+    const int kspan = K / (int)gridDim.y, kbeg = (int)blockIdx.y * kspan;
+    out += (size_t)blockIdx.y * n * 128;
     const int ar = tid >> 3, aq = tid & 7;                 // A tile: 32 rows x 8 float4
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
     float4 na, nb0, nb1, nb2, nb3;
     const bool arow = m0 + ar < n;
-    const float* asrc = act + (size_t)(m0 + ar) * K + aq * 4;
-    const float4* wsrc = reinterpret_cast<const float4*>(w) + tid;
+    const float* asrc = act + (size_t)(m0 + ar) * K + kbeg + aq * 4;
+    const float4* wsrc = reinterpret_cast<const float4*>(w) + (size_t)kbeg * 32 + tid;
 #define FC1_FETCH(k0)                                                                                  \
     do {                                                                                               \
         na = arow ? *reinterpret_cast<const float4*>(asrc + (k0)) : make_float4(0.f, 0.f, 0.f, 0.f);   \
@@ -438,7 +600,7 @@ __global__ __launch_bounds__(256) void k_fc1(const float* __restrict__ act, cons
     FC1_FETCH(0);
     FC1_STASH(0);
     __syncthreads();
-    const int nk = K / 32;
+    const int nk = kspan / 32;
     for (int kc = 0; kc < nk; ++kc) {
         const int buf = kc & 1;
         if (kc + 1 < nk) FC1_FETCH((kc + 1) * 32);          // next K chunk -> registers, overlaps the MFMAs below
@@ -452,7 +614,7 @@ __global__ __launch_bounds__(256) void k_fc1(const float* __restrict__ act, cons
 #undef FC1_FETCH
 #undef FC1_STASH
     const int co = wave * 32 + j;
-    const float bz = bias[co];
+    const float bz = blockIdx.y == 0 ? bias[co] : 0.f;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int i = (r & 3) + 8 * (r >> 2) + 4 * h;
@@ -477,14 +639,19 @@ __device__ __forceinline__ float wave_max(float v) {
 __global__ __launch_bounds__(256) void k_head(const float* __restrict__ fc1 /*[N][128]*/, const float* __restrict__ ln_g,
                                               const float* __restrict__ ln_b, const float* __restrict__ w2t /*[100][C]*/,
                                               const float* __restrict__ b2, float* __restrict__ probs /*[N][C]*/,
-                                              float* __restrict__ logits_out, int n, int C, const uint32_t* __restrict__ guard) {
+                                              float* __restrict__ logits_out, int n, int C, const uint32_t* __restrict__ guard, int ksplit) {
     if (guard && *guard == 0u) return;
     __shared__ float ys[4][128];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int crop = blockIdx.x * 4 + wave;
     if (crop >= n) return;
     const float* x = fc1 + (size_t)crop * 128;
-    const float x0 = x[lane], x1 = lane + 64 < 100 ? x[lane + 64] : 0.f;
+    float x0 = x[lane], x1 = lane + 64 < 100 ? x[lane + 64] : 0.f;
+    for (int s = 1; s < ksplit; ++s) {                     // fc1 partial planes of the split-K launch, fixed order
+        const float* xs = x + (size_t)s * n * 128;
+        x0 += xs[lane];
+        if (lane + 64 < 100) x1 += xs[lane + 64];
+    }
     const float mean = wave_sum(x0 + x1) * (1.f / 100.f);
     const float d0 = x0 - mean, d1 = lane + 64 < 100 ? x1 - mean : 0.f;
     const float var = wave_sum(d0 * d0 + d1 * d1) * (1.f / 100.f);     // biased variance (nn.LayerNorm)
@@ -718,7 +885,7 @@ static int ensure_act(trexhip_ctx* ctx, Net* net, int n) {
     TH_CHECK_HIP(hipMalloc(reinterpret_cast<void**>(&net->act1), N * 40 * 40 * 16 * 4));
     TH_CHECK_HIP(hipMalloc(reinterpret_cast<void**>(&net->act2), N * 20 * 20 * 64 * 4));
     TH_CHECK_HIP(hipMalloc(reinterpret_cast<void**>(&net->act3), N * 10 * 10 * 128 * 4));
-    TH_CHECK_HIP(hipMalloc(reinterpret_cast<void**>(&net->fc1), N * 128 * 4));
+    TH_CHECK_HIP(hipMalloc(reinterpret_cast<void**>(&net->fc1), N * 128 * 4 * FC1_KSPLIT));
     TH_CHECK_HIP(hipMalloc(reinterpret_cast<void**>(&net->probs), N * net->classes * 4));
     TH_CHECK_HIP(hipMalloc(reinterpret_cast<void**>(&net->logits), N * net->classes * 4));
     TH_CHECK_HIP(hipMalloc(reinterpret_cast<void**>(&net->crops), N * net->W * net->H * net->CH));
@@ -746,6 +913,10 @@ int net_forward(trexhip_ctx* ctx, const uint8_t* d_crops, int n, float* d_probs,
         SET_ATTR(16, 64, 40, 10, 0, 6); SET_ATTR(16, 64, 40, 10, 0, 3); SET_ATTR(16, 64, 40, 10, 1, 3);
         SET_ATTR(64, 128, 20, 20, 0, 6); SET_ATTR(64, 128, 20, 20, 0, 3); SET_ATTR(64, 128, 20, 20, 1, 3);
         SET_ATTR(16, 64, 40, 20, 1, 3); SET_ATTR(64, 128, 20, 10, 1, 3);
+        TH_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv5_stream<16, 64, 40, 10, 4>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (ConvGeomS<16, 64, 40, 10, 4>::LDS_BYTES)));
+        TH_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv5_stream<64, 128, 20, 20, 8>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (ConvGeomS<64, 128, 20, 20, 8>::LDS_BYTES)));
 #undef SET_ATTR
 #undef SET_ATTRC
         attr_done = true;
@@ -767,6 +938,9 @@ int net_forward(trexhip_ctx* ctx, const uint8_t* d_crops, int n, float* d_probs,
         hipLaunchKernelGGL((k_conv5<16, 64, 40, 20, 16>), dim3(n * G2::BPC), dim3(512), G2::LDS_BYTES, s, net->act1, net->w2, net->b2, net->act2);
     else if (mode == TREXHIP_CNN_BF16X6) LAUNCH_SPLIT(16, 64, 40, 10, 0, 6, net->act1, net->w2s, net->b2, net->act2, 1.0f, (const uint32_t*)nullptr);
     else if (mode == TREXHIP_CNN_BF16X3) LAUNCH_SPLIT(16, 64, 40, 10, 0, 3, net->act1, net->w2s, net->b2, net->act2, 1.0f, (const uint32_t*)nullptr);
+    else if (!(ctx->tune_conv_geom & 4))
+        hipLaunchKernelGGL((k_conv5_stream<16, 64, 40, 10, 4>), dim3(n * (ConvGeomS<16, 64, 40, 10, 4>::BPC)), dim3(256),
+                           (ConvGeomS<16, 64, 40, 10, 4>::LDS_BYTES), s, net->act1, net->w2h, net->b2, net->act2, net->inv2h, net->d_ovf);
     else if (ctx->tune_conv_geom & 1)    LAUNCH_SPLIT(16, 64, 40, 20, 1, 3, net->act1, net->w2h, net->b2, net->act2, net->inv2h, (const uint32_t*)nullptr);
     else                                 LAUNCH_SPLIT(16, 64, 40, 10, 1, 3, net->act1, net->w2h, net->b2, net->act2, net->inv2h, (const uint32_t*)nullptr);
     stage_end(ctx, TREXHIP_STAGE_CONV2);
@@ -775,20 +949,23 @@ int net_forward(trexhip_ctx* ctx, const uint8_t* d_crops, int n, float* d_probs,
         hipLaunchKernelGGL((k_conv5<64, 128, 20, 20, 32>), dim3(n * G3::BPC), dim3(512), G3::LDS_BYTES, s, net->act2, net->w3, net->b3, net->act3);
     else if (mode == TREXHIP_CNN_BF16X6) LAUNCH_SPLIT(64, 128, 20, 20, 0, 6, net->act2, net->w3s, net->b3, net->act3, 1.0f, (const uint32_t*)nullptr);
     else if (mode == TREXHIP_CNN_BF16X3) LAUNCH_SPLIT(64, 128, 20, 20, 0, 3, net->act2, net->w3s, net->b3, net->act3, 1.0f, (const uint32_t*)nullptr);
+    else if (!(ctx->tune_conv_geom & 8))
+        hipLaunchKernelGGL((k_conv5_stream<64, 128, 20, 20, 8>), dim3(n * (ConvGeomS<64, 128, 20, 20, 8>::BPC)), dim3(512),
+                           (ConvGeomS<64, 128, 20, 20, 8>::LDS_BYTES), s, net->act2, net->w3h, net->b3, net->act3, net->inv3h, net->d_ovf);
     else if (ctx->tune_conv_geom & 2)    LAUNCH_SPLIT(64, 128, 20, 10, 1, 3, net->act2, net->w3h, net->b3, net->act3, net->inv3h, (const uint32_t*)nullptr);
     else                                 LAUNCH_SPLIT(64, 128, 20, 20, 1, 3, net->act2, net->w3h, net->b3, net->act3, net->inv3h, (const uint32_t*)nullptr);   // 32-channel chunks (CIC=32) measured slower: 3.7 vs 3.0 ms
     stage_end(ctx, TREXHIP_STAGE_CONV3);
-    hipLaunchKernelGGL(k_fc1, dim3((n + 31) / 32), dim3(256), 0, s, net->act3, net->wf1, net->bf1, net->fc1, n, 12800, (const uint32_t*)nullptr);
+    hipLaunchKernelGGL(k_fc1, dim3((n + 31) / 32, FC1_KSPLIT), dim3(256), 0, s, net->act3, net->wf1, net->bf1, net->fc1, n, 12800, (const uint32_t*)nullptr);
     hipLaunchKernelGGL(k_head, dim3((n + 3) / 4), dim3(256), 0, s, net->fc1, net->lng, net->lnb, net->wf2t, net->bf2,
-                       d_probs, d_logits, n, net->classes, (const uint32_t*)nullptr);
+                       d_probs, d_logits, n, net->classes, (const uint32_t*)nullptr, FC1_KSPLIT);
     if (mode == TREXHIP_CNN_FP16X3) {
         // guarded re-run with the bf16 split: every workgroup returns at once unless an activation left the fp16 range
         const uint32_t* g = net->d_ovf;
         LAUNCH_SPLIT2(16, 64, 40, 10, 0, 6, net->act1, net->w2s, net->b2, net->act2, 1.0f, g);
         LAUNCH_SPLIT2(64, 128, 20, 20, 0, 6, net->act2, net->w3s, net->b3, net->act3, 1.0f, g);
-        hipLaunchKernelGGL(k_fc1, dim3((n + 31) / 32), dim3(256), 0, s, net->act3, net->wf1, net->bf1, net->fc1, n, 12800, g);
+        hipLaunchKernelGGL(k_fc1, dim3((n + 31) / 32, FC1_KSPLIT), dim3(256), 0, s, net->act3, net->wf1, net->bf1, net->fc1, n, 12800, g);
         hipLaunchKernelGGL(k_head, dim3((n + 3) / 4), dim3(256), 0, s, net->fc1, net->lng, net->lnb, net->wf2t, net->bf2,
-                           d_probs, d_logits, n, net->classes, g);
+                           d_probs, d_logits, n, net->classes, g, FC1_KSPLIT);
     }
     stage_end(ctx, TREXHIP_STAGE_CNN_ALL);
 #undef LAUNCH_SPLIT
