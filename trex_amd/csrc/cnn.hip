@@ -468,6 +468,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_conv5_stream(const float* __rest
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
 
+    const bool last_tile = mg + G::WM * (G::TPW - 1) < G::MT;
     const float* inc = in + (size_t)crop * S * S * CI;
     bool ovf = false;
     // one staged item: float4 of 4 input channels of one patch pixel -> two fp16 pieces in LDS
@@ -530,6 +531,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_conv5_stream(const float* __rest
             const f16x8 b2 = __builtin_bit_cast(f16x8, bq[tap % 5][1]);
 #pragma unroll
             for (int m = 0; m < G::TPW; ++m) {
+                if (m == G::TPW - 1 && !last_tile) continue;       // wave-uniform: this M-group has one tile less
                 const f16x8 p1 = __builtin_bit_cast(f16x8, *reinterpret_cast<const uint4*>(asrc + aoff[m]));
                 const f16x8 p2 = __builtin_bit_cast(f16x8, *reinterpret_cast<const uint4*>(asrc + aoff[m] + G::PATCH));
                 acc[m] = mfma16(p2, b1, acc[m]);
