@@ -146,6 +146,7 @@ int trexhip_create(const trexhip_params* p, trexhip_ctx** out) {
     if (const char* e = std::getenv("TREXHIP_ROWS_ORDER")) ctx->tune_rows_order = std::atoi(e);
     if (const char* e = std::getenv("TREXHIP_CONV_GEOM")) ctx->tune_conv_geom = std::atoi(e);
     if (const char* e = std::getenv("TREXHIP_CCL_STOP")) ctx->tune_ccl_stop = std::atoi(e);
+    if (const char* e = std::getenv("TREXHIP_SEG_GROUPS")) ctx->tune_seg_groups = std::atoi(e);
     if (const char* e = std::getenv("TREXHIP_ROWS_BLOCKS")) ctx->tune_rows_blocks = std::atoi(e) > 0 ? std::atoi(e) : 8192;
     const size_t B = p->max_batch, H = p->height, W = p->width, R = p->max_runs, NB = p->max_blobs, P = p->max_pixels;
     int rc = TREXHIP_OK;
@@ -200,6 +201,10 @@ void trexhip_destroy(trexhip_ctx* ctx) {
     void* host[] = {ctx->h_info, ctx->h_totals, ctx->h_blobs, ctx->h_runs, ctx->h_pixels, ctx->h_staging, ctx->h_color};
     for (void* p : host) if (p) hipHostFree(p);
     stage_free(ctx);
+    if (ctx->aux_stream) {
+        (void)hipStreamDestroy(ctx->aux_stream);
+        for (hipEvent_t e : ctx->ev_grp) if (e) (void)hipEventDestroy(e);
+    }
     if (ctx->own_stream) hipStreamDestroy(ctx->own_stream);
     delete ctx;
 }

@@ -95,6 +95,77 @@ __global__ __launch_bounds__(256, 2) void k_conv1(const uint8_t* __restrict__ cr
 }
 
 // ------------------------------------------------------------------------------------------------
+// conv1 on the matrix cores (1 input channel): the u8 crop is exact in fp16, the folded weights are split into two fp16
+// pieces (scaled by a power of two), so two v_mfma_f32_16x16x32_f16 products per term are fp32-class.
+//   M (16 rows)  = 8 windows x 2 image rows; a window is 8 consecutive padded pixels starting at x4 = 0,4,8,...
+//   K (32)       = 4 kernel rows x 8 window slots (second MFMA: kernel row 4, the other 24 k are zero weights)
+//   N (16)       = output channels
+// One A fragment serves the four outputs x4+s, s = 0..3, through four weight matrices with the taps shifted by s slots
+// (slot = kx + s <= 7), so every LDS read starts at a multiple of 4 pixels (8-byte aligned).  The accumulator layout
+// (lane: column co, rows 4g..4g+3 = two windows x two image rows) makes the 2x2 max-pool a max over registers of one lane.
+// ------------------------------------------------------------------------------------------------
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8_c1 __attribute__((ext_vector_type(8)));
+
+__global__ __launch_bounds__(256) void k_conv1_mfma(const uint8_t* __restrict__ crops, const uint4* __restrict__ wtab /*[16][64]*/,
+                                                    const float* __restrict__ bias, float* __restrict__ out, const float inv_scale) {
+    constexpr int S = 80, PH = 84, PITCH = 88;              // halves per padded row (176 B: rows land on distinct bank groups)
+    __shared__ __attribute__((aligned(16))) _Float16 img[PH * PITCH];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int crop = blockIdx.x;
+    const uint8_t* src = crops + (size_t)crop * S * S;
+    for (int i = tid; i < PH * PITCH / 2; i += 256) {        // two pixels per thread-iteration
+        const int row = i / (PITCH / 2), c2 = (i - row * (PITCH / 2)) * 2;
+        _Float16 v0 = (_Float16)0.f, v1 = (_Float16)0.f;
+        const int y = row - 2, x = c2 - 2;
+        if (y >= 0 && y < S) {
+            if (x >= 0 && x < S) v0 = (_Float16)(float)src[y * S + x];
+            if (x + 1 >= 0 && x + 1 < S) v1 = (_Float16)(float)src[y * S + x + 1];
+        }
+        img[row * PITCH + c2] = v0; img[row * PITCH + c2 + 1] = v1;
+    }
+    uint4 bf[16];
+#pragma unroll
+    for (int f = 0; f < 16; ++f) bf[f] = wtab[f * 64 + lane];
+    __syncthreads();
+    const int r = lane & 15, q = lane >> 4;
+    const int co = r;
+    const float bz = bias[co];
+    float* oc = out + (size_t)crop * 40 * 40 * 16;
+    for (int tile = wave; tile < 100; tile += 4) {
+        const int wdx = tile * 8 + (r >> 1);
+        const int yp = wdx / 20, x4 = (wdx - yp * 20) * 4;
+        const int row = 2 * yp + (r & 1);
+        const _Float16* p1 = img + (row + q) * PITCH + x4;
+        const _Float16* p2 = img + (row + 4) * PITCH + x4;
+        uint4 a1u, a2u;
+        { const uint2 lo = *reinterpret_cast<const uint2*>(p1), hi = *reinterpret_cast<const uint2*>(p1 + 4); a1u = make_uint4(lo.x, lo.y, hi.x, hi.y); }
+        { const uint2 lo = *reinterpret_cast<const uint2*>(p2), hi = *reinterpret_cast<const uint2*>(p2 + 4); a2u = make_uint4(lo.x, lo.y, hi.x, hi.y); }
+        const f16x8_c1 a1 = __builtin_bit_cast(f16x8_c1, a1u), a2 = __builtin_bit_cast(f16x8_c1, a2u);
+        f32x4 acc[4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            f32x4 c = {0.f, 0.f, 0.f, 0.f};
+            c = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, __builtin_bit_cast(f16x8_c1, bf[s * 4 + 1]), c, 0, 0, 0);   // low pieces first
+            c = __builtin_amdgcn_mfma_f32_16x16x32_f16(a2, __builtin_bit_cast(f16x8_c1, bf[s * 4 + 3]), c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, __builtin_bit_cast(f16x8_c1, bf[s * 4 + 0]), c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_16x16x32_f16(a2, __builtin_bit_cast(f16x8_c1, bf[s * 4 + 2]), c, 0, 0, 0);
+            acc[s] = c;
+        }
+#pragma unroll
+        for (int pos = 0; pos < 2; ++pos) {
+            const int wp = tile * 8 + 2 * q + pos;
+            const int y2 = wp / 20, xw = wp - y2 * 20;
+            const float m0 = fmaxf(fmaxf(acc[0][2 * pos], acc[0][2 * pos + 1]), fmaxf(acc[1][2 * pos], acc[1][2 * pos + 1]));
+            const float m1 = fmaxf(fmaxf(acc[2][2 * pos], acc[2][2 * pos + 1]), fmaxf(acc[3][2 * pos], acc[3][2 * pos + 1]));
+            float* o = oc + ((size_t)y2 * 40 + 2 * xw) * 16 + co;
+            o[0] = fmaxf(m0 * inv_scale + bz, 0.f);
+            o[16] = fmaxf(m1 * inv_scale + bz, 0.f);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // conv 5x5 'same' + folded BN + ReLU + maxpool2 as 25 shifted GEMMs on fp32 MFMA
 // ------------------------------------------------------------------------------------------------
 template <int CI, int CO, int S, int ROWS, int CIC>
@@ -699,6 +770,8 @@ struct Net {
     uint4 *w2s = nullptr, *w3s = nullptr;      // bf16-split conv weights
     uint4 *w2h = nullptr, *w3h = nullptr;      // fp16-split conv weights (scaled by a power of two)
     float inv2h = 1.f, inv3h = 1.f;
+    uint4* w1h = nullptr;                      // conv1 B fragments (16 fragments x 64 lanes), fp16 pieces of the folded weights
+    float inv1h = 1.f;
     uint32_t* d_ovf = nullptr;
     float *w1 = nullptr, *b1 = nullptr, *w2 = nullptr, *b2 = nullptr, *w3 = nullptr, *b3 = nullptr;
     float *wf1 = nullptr, *bf1 = nullptr, *lng = nullptr, *lnb = nullptr, *wf2t = nullptr, *bf2 = nullptr;
@@ -716,6 +789,7 @@ static void free_net(Net* n) {
     if (n->w3s) (void)hipFree(n->w3s);
     if (n->w2h) (void)hipFree(n->w2h);
     if (n->w3h) (void)hipFree(n->w3h);
+    if (n->w1h) (void)hipFree(n->w1h);
     if (n->d_ovf) (void)hipFree(n->d_ovf);
     if (n->crops) (void)hipFree(n->crops);
     if (n->h_probs) (void)hipHostFree(n->h_probs);
@@ -840,6 +914,34 @@ int net_load(trexhip_ctx* ctx, const void* blob, size_t bytes) {
                     w1[((size_t)c * 25 + tap) * 16 + co] = (float)((double)c1w[((size_t)co * CH + c) * 25 + tap] * s);
         }
         TRY(upload(&net->w1, w1)); TRY(upload(&net->b1, b1));
+        if (CH == 1 && rc == TREXHIP_OK) {   // B fragments of k_conv1_mfma: [shift s][mfma 0: ky 0..3 | 1: ky 4][piece hi|lo][lane] x 8 halves
+            float mx = 0.f;
+            for (float v : w1) mx = std::fmax(mx, std::fabs(v));
+            int k = 0;
+            if (mx > 0.f) { k = (int)std::floor(std::log2(16384.0 / (double)mx)); if (k > 24) k = 24; if (k < -24) k = -24; }
+            const float sc = std::ldexp(1.0f, k);
+            net->inv1h = std::ldexp(1.0f, -k);
+            std::vector<uint16_t> tab((size_t)16 * 64 * 8, 0);
+            for (int s = 0; s < 4; ++s)
+                for (int mf = 0; mf < 2; ++mf)
+                    for (int lane = 0; lane < 64; ++lane) {
+                        const int co = lane & 15, q = lane >> 4;
+                        const int ky = mf == 0 ? q : (q == 0 ? 4 : -1);
+                        for (int slot = 0; slot < 8; ++slot) {
+                            const int kx = slot - s;
+                            float x = 0.f;
+                            if (ky >= 0 && kx >= 0 && kx < 5) x = w1[(size_t)(ky * 5 + kx) * 16 + co] * sc;
+                            const _Float16 h1 = (_Float16)x;
+                            const _Float16 h2 = (_Float16)(x - (float)h1);
+                            uint16_t pc[2];
+                            std::memcpy(&pc[0], &h1, 2); std::memcpy(&pc[1], &h2, 2);
+                            for (int piece = 0; piece < 2; ++piece)
+                                tab[((size_t)((s * 2 + mf) * 2 + piece) * 64 + lane) * 8 + slot] = pc[piece];
+                        }
+                    }
+            if (hipMalloc(reinterpret_cast<void**>(&net->w1h), tab.size() * 2) != hipSuccess ||
+                hipMemcpy(net->w1h, tab.data(), tab.size() * 2, hipMemcpyHostToDevice) != hipSuccess) rc = TREXHIP_E_DEVICE;
+        }
     }
     fold_conv(c2w, c2b, g2, be2, m2, v2, 64, 16, 16, wp, bias);
     TRY(upload(&net->w2, wp)); TRY(upload(&net->b2, bias));
@@ -926,7 +1028,8 @@ int net_forward(trexhip_ctx* ctx, const uint8_t* d_crops, int n, float* d_probs,
     stage_begin(ctx, TREXHIP_STAGE_CNN_ALL);
     const int S = net->W;
     const size_t lds1 = ((size_t)net->CH * (S + 4) * (S + 4) + (size_t)net->CH * 25 * 16) * 4;
-    if (net->CH == 1) hipLaunchKernelGGL((k_conv1<1>), dim3(n), dim3(256), lds1, s, d_crops, net->w1, net->b1, net->act1, S);
+    if (net->CH == 1 && !(ctx->tune_conv_geom & 16)) hipLaunchKernelGGL(k_conv1_mfma, dim3(n), dim3(256), 0, s, d_crops, net->w1h, net->b1, net->act1, net->inv1h);
+    else if (net->CH == 1) hipLaunchKernelGGL((k_conv1<1>), dim3(n), dim3(256), lds1, s, d_crops, net->w1, net->b1, net->act1, S);
     else              hipLaunchKernelGGL((k_conv1<3>), dim3(n), dim3(256), lds1, s, d_crops, net->w1, net->b1, net->act1, S);
     const int mode = ctx->cnn_mode;
     if (mode == TREXHIP_CNN_FP16X3) TH_CHECK_HIP(hipMemsetAsync(net->d_ovf, 0, 4, s));

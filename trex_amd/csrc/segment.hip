@@ -148,7 +148,7 @@ __global__ __launch_bounds__(256) void k_rows(const uint8_t* __restrict__ frames
                                               uint32_t* __restrict__ frame_ctr,
                                               uint32_t* __restrict__ row_cnt,
                                               uint32_t* __restrict__ row_off,
-                                              uint32_t* __restrict__ tmp_runs, const uint32_t* __restrict__ bits) {
+                                              uint32_t* __restrict__ tmp_runs, const uint32_t* __restrict__ bits, const uint32_t f0) {
     const int lane = lane_id();
     const int W = c.W;
     const int WB = (W + 31) / 32;
@@ -159,7 +159,7 @@ __global__ __launch_bounds__(256) void k_rows(const uint8_t* __restrict__ frames
 
     uint4 a[NCH], b[NCH];
     auto issue = [&](uint32_t t) {
-        const uint32_t f = (order & 1) == 0 ? t % (uint32_t)c.B : t / (uint32_t)c.H;
+        const uint32_t f = f0 + ((order & 1) == 0 ? t % (uint32_t)c.B : t / (uint32_t)c.H);     // c.B = frames of this launch
         const uint32_t y = (order & 1) == 0 ? t / (uint32_t)c.B : t % (uint32_t)c.H;
         const uint8_t* fp = frames + ((size_t)f * c.H + y) * W;
         const uint8_t* bp = bg + (size_t)y * W;
@@ -177,7 +177,7 @@ __global__ __launch_bounds__(256) void k_rows(const uint8_t* __restrict__ frames
     };
     issue(task);
     for (; task < ntask; task += nwave) {
-        const uint32_t f = (order & 1) == 0 ? task % (uint32_t)c.B : task / (uint32_t)c.H;
+        const uint32_t f = f0 + ((order & 1) == 0 ? task % (uint32_t)c.B : task / (uint32_t)c.H);
         const uint32_t y = (order & 1) == 0 ? task / (uint32_t)c.B : task % (uint32_t)c.H;
         uint32_t m[NCH];
         bool any = false;
@@ -602,7 +602,7 @@ __global__ __launch_bounds__(1024) void k_ccl_lds(const SegCfg c, const uint32_t
                                                   uint32_t* __restrict__ totals, trexhip_frame_info* __restrict__ info,
                                                   trexhip_blob* __restrict__ blobs, uint32_t* __restrict__ blob_frame,
                                                   trexhip_run* __restrict__ out_runs, const int dbg_stop,
-                                                  unsigned long long* __restrict__ dbg) {
+                                                  unsigned long long* __restrict__ dbg, const int f0) {
 #define CCL_STAMP(i) do { if (dbg_stop == -1 && blockIdx.x == 0 && threadIdx.x == 0) dbg[i] = __builtin_readcyclecounter(); } while (0)
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     uint32_t* s_run = smem;                       // x0 | x1 << 16, raster order
@@ -613,7 +613,7 @@ __global__ __launch_bounds__(1024) void k_ccl_lds(const SegCfg c, const uint32_t
     uint32_t* s_key = s_cp + CCL_NMAX;            // sort keys [CCL_SORT]
     uint32_t* s_misc = s_key + CCL_SORT;          // [64] scan scratch / broadcasts
     uint16_t* s_y = reinterpret_cast<uint16_t*>(s_misc + 64);
-    const int f = blockIdx.x, tid = threadIdx.x;
+    const int f = blockIdx.x + f0, tid = threadIdx.x;
     const int H = c.H;
     const uint32_t* cnt = row_cnt + (size_t)f * H;
     const uint32_t* off = row_off + (size_t)f * H;
@@ -894,13 +894,13 @@ __global__ __launch_bounds__(256) void k_gather(const SegCfg c, const int only_p
                                                 const uint32_t* __restrict__ blob_frame,
                                                 trexhip_blob* __restrict__ blobs,
                                                 const trexhip_run* __restrict__ runs,
-                                                uint8_t* __restrict__ pixels) {
+                                                uint8_t* __restrict__ pixels, const uint32_t f0, const uint32_t f1) {
     const uint32_t lane = lane_id();
     const uint32_t nwaves = gridDim.x * 4;
     const uint32_t total = min(totals[0], c.pool_blobs);
     for (uint32_t bi = blockIdx.x * 4 + (threadIdx.x >> 6); bi < total; bi += nwaves) {
         const uint32_t f = blob_frame[bi];
-        if (f >= (uint32_t)c.B) continue;          // hole left by a frame that overflowed the pool
+        if (f >= (uint32_t)c.B || f < f0 || f >= f1) continue;   // hole left by a frame that overflowed the pool / another group's frame
         const trexhip_frame_info fi = info[f];
         if (fi.flags || (only_pending && fi.reserved[0] != 2u)) continue;
         trexhip_blob B = blobs[bi];
@@ -959,15 +959,15 @@ __global__ __launch_bounds__(256) void k_gather(const SegCfg c, const int only_p
 // ---------------------------------------------------------------------------------------------
 template <bool ALIGNED>
 static void launch_rows(int nch, dim3 grid, hipStream_t s, const uint8_t* frames, const uint8_t* bg,
-                        const SegCfg& c, int order, uint32_t* ctr, uint32_t* row_cnt, uint32_t* row_off, uint32_t* tmp, const uint32_t* bits) {
+                        const SegCfg& c, int order, uint32_t* ctr, uint32_t* row_cnt, uint32_t* row_off, uint32_t* tmp, const uint32_t* bits, uint32_t f0) {
     switch (nch) {
-        case 1: hipLaunchKernelGGL((k_rows<1, ALIGNED>), grid, dim3(256), 0, s, frames, bg, c, order, ctr, row_cnt, row_off, tmp, bits); break;
-        case 2: hipLaunchKernelGGL((k_rows<2, ALIGNED>), grid, dim3(256), 0, s, frames, bg, c, order, ctr, row_cnt, row_off, tmp, bits); break;
-        case 3: hipLaunchKernelGGL((k_rows<3, ALIGNED>), grid, dim3(256), 0, s, frames, bg, c, order, ctr, row_cnt, row_off, tmp, bits); break;
-        case 4: hipLaunchKernelGGL((k_rows<4, ALIGNED>), grid, dim3(256), 0, s, frames, bg, c, order, ctr, row_cnt, row_off, tmp, bits); break;
+        case 1: hipLaunchKernelGGL((k_rows<1, ALIGNED>), grid, dim3(256), 0, s, frames, bg, c, order, ctr, row_cnt, row_off, tmp, bits, f0); break;
+        case 2: hipLaunchKernelGGL((k_rows<2, ALIGNED>), grid, dim3(256), 0, s, frames, bg, c, order, ctr, row_cnt, row_off, tmp, bits, f0); break;
+        case 3: hipLaunchKernelGGL((k_rows<3, ALIGNED>), grid, dim3(256), 0, s, frames, bg, c, order, ctr, row_cnt, row_off, tmp, bits, f0); break;
+        case 4: hipLaunchKernelGGL((k_rows<4, ALIGNED>), grid, dim3(256), 0, s, frames, bg, c, order, ctr, row_cnt, row_off, tmp, bits, f0); break;
         case 5: case 6:
-                hipLaunchKernelGGL((k_rows<6, ALIGNED>), grid, dim3(256), 0, s, frames, bg, c, order, ctr, row_cnt, row_off, tmp, bits); break;
-        default: hipLaunchKernelGGL((k_rows<8, ALIGNED>), grid, dim3(256), 0, s, frames, bg, c, order, ctr, row_cnt, row_off, tmp, bits); break;
+                hipLaunchKernelGGL((k_rows<6, ALIGNED>), grid, dim3(256), 0, s, frames, bg, c, order, ctr, row_cnt, row_off, tmp, bits, f0); break;
+        default: hipLaunchKernelGGL((k_rows<8, ALIGNED>), grid, dim3(256), 0, s, frames, bg, c, order, ctr, row_cnt, row_off, tmp, bits, f0); break;
     }
 }
 
@@ -989,23 +989,51 @@ int launch_segment(trexhip_ctx* ctx, const uint8_t* d_frames, int n) {
         int rcm = launch_morphology(ctx, d_frames, n, &bits);
         if (rcm) return rcm;
     }
-    stage_begin(ctx, TREXHIP_STAGE_ROWS);
-    if (aligned) launch_rows<true>(nch, grid_rows, s, d_frames, ctx->d_bg, c, ctx->tune_rows_order, ctx->d_ctr, ctx->d_row_cnt, ctx->d_row_off, ctx->d_tmp_runs, bits);
-    else         launch_rows<false>(nch, grid_rows, s, d_frames, ctx->d_bg, c, ctx->tune_rows_order, ctx->d_ctr, ctx->d_row_cnt, ctx->d_row_off, ctx->d_tmp_runs, bits);
-    stage_end(ctx, TREXHIP_STAGE_ROWS);
     static bool attr_done = false;
     if (!attr_done) {
         TH_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ccl_lds), hipFuncAttributeMaxDynamicSharedMemorySize, CCL_LDS_BYTES));
         attr_done = true;
     }
     uint32_t* totals = ctx->d_ctr + (size_t)ctx->p.max_batch * CTR_STRIDE;
-    // run-level CCL of every frame inside one workgroup's LDS; frames with too many runs are left pending
-    // and finished by the global-memory chain in finish_segment()
-    hipLaunchKernelGGL(k_ccl_lds, dim3(n), dim3(1024), CCL_LDS_BYTES, s, c, ctx->d_ctr, ctx->d_row_cnt, ctx->d_row_off, ctx->d_row_base,
-                       ctx->d_tmp_runs, ctx->d_raster, ctx->d_parent, ctx->d_root_ord, ctx->d_cur_run, ctx->d_pix_begin, ctx->d_blob_map,
-                       totals, ctx->d_info, ctx->d_blobs, ctx->d_blob_frame, ctx->d_runs, ctx->tune_ccl_stop, reinterpret_cast<unsigned long long*>(ctx->d_cnt_px));
-    hipLaunchKernelGGL(k_gather, dim3(1024), dim3(256), 0, s, c, 0, d_frames, totals, ctx->d_info, ctx->d_blob_frame,
-                       ctx->d_blobs, ctx->d_runs, ctx->d_pixels);
+    // The batch is cut into groups of frames: the pixel pass of group g+1 (HBM-bound, every CU) runs on the caller's stream
+    // while the labelling + gather of group g (latency-bound, one workgroup per frame) run on an auxiliary stream.
+    int G = ctx->tune_seg_groups;
+    if (G > 8) G = 8;
+    if (G < 1 || n < 2 * G) G = 1;
+    if (G > 1 && !ctx->aux_stream) {
+        TH_CHECK_HIP(hipStreamCreateWithFlags(&ctx->aux_stream, hipStreamNonBlocking));
+        for (int g = 0; g < 9; ++g) TH_CHECK_HIP(hipEventCreateWithFlags(&ctx->ev_grp[g], hipEventDisableTiming));
+    }
+    const int gs = (n + G - 1) / G;
+    stage_begin(ctx, TREXHIP_STAGE_ROWS);
+    for (int g = 0; g < G; ++g) {
+        const int f0 = g * gs, f1 = (g + 1) * gs < n ? (g + 1) * gs : n;
+        if (f0 >= f1) break;
+        SegCfg cg = c;
+        cg.B = f1 - f0;
+        const unsigned wantg = (unsigned)(((size_t)H * cg.B + 3) / 4);
+        const dim3 grid_g(wantg < (unsigned)ctx->tune_rows_blocks ? wantg : (unsigned)ctx->tune_rows_blocks);
+        if (aligned) launch_rows<true>(nch, grid_g, s, d_frames, ctx->d_bg, cg, ctx->tune_rows_order, ctx->d_ctr, ctx->d_row_cnt, ctx->d_row_off, ctx->d_tmp_runs, bits, (uint32_t)f0);
+        else         launch_rows<false>(nch, grid_g, s, d_frames, ctx->d_bg, cg, ctx->tune_rows_order, ctx->d_ctr, ctx->d_row_cnt, ctx->d_row_off, ctx->d_tmp_runs, bits, (uint32_t)f0);
+        if (g == G - 1) stage_end(ctx, TREXHIP_STAGE_ROWS);
+        hipStream_t t = s;
+        if (G > 1) {
+            TH_CHECK_HIP(hipEventRecord(ctx->ev_grp[g], s));
+            TH_CHECK_HIP(hipStreamWaitEvent(ctx->aux_stream, ctx->ev_grp[g], 0));
+            t = ctx->aux_stream;
+        }
+        // run-level CCL of every frame inside one workgroup's LDS; frames with too many runs are left pending
+        // and finished by the global-memory chain in finish_segment()
+        hipLaunchKernelGGL(k_ccl_lds, dim3(f1 - f0), dim3(1024), CCL_LDS_BYTES, t, c, ctx->d_ctr, ctx->d_row_cnt, ctx->d_row_off, ctx->d_row_base,
+                           ctx->d_tmp_runs, ctx->d_raster, ctx->d_parent, ctx->d_root_ord, ctx->d_cur_run, ctx->d_pix_begin, ctx->d_blob_map,
+                           totals, ctx->d_info, ctx->d_blobs, ctx->d_blob_frame, ctx->d_runs, ctx->tune_ccl_stop, reinterpret_cast<unsigned long long*>(ctx->d_cnt_px), f0);
+        hipLaunchKernelGGL(k_gather, dim3(G > 1 ? 256 : 1024), dim3(256), 0, t, c, 0, d_frames, totals, ctx->d_info, ctx->d_blob_frame,
+                           ctx->d_blobs, ctx->d_runs, ctx->d_pixels, (uint32_t)f0, (uint32_t)f1);
+    }
+    if (G > 1) {
+        TH_CHECK_HIP(hipEventRecord(ctx->ev_grp[8], ctx->aux_stream));
+        TH_CHECK_HIP(hipStreamWaitEvent(s, ctx->ev_grp[8], 0));
+    }
     stage_end(ctx, TREXHIP_STAGE_SEGMENT_ALL);
     TH_CHECK_HIP(hipGetLastError());
     ctx->d_frames = d_frames;
@@ -1031,7 +1059,7 @@ int launch_pending(trexhip_ctx* ctx) {
                        ctx->d_cnt_runs, ctx->d_cnt_px, ctx->d_cur_run, ctx->d_pix_begin, ctx->d_blob_map, totals, ctx->d_info,
                        ctx->d_blobs, ctx->d_blob_frame, ctx->d_runs, 0, (const uint32_t*)nullptr);
     hipLaunchKernelGGL(k_gather, dim3(1024), dim3(256), 0, s, c, 1, ctx->d_frames, totals, ctx->d_info, ctx->d_blob_frame,
-                       ctx->d_blobs, ctx->d_runs, ctx->d_pixels);
+                       ctx->d_blobs, ctx->d_runs, ctx->d_pixels, 0u, (uint32_t)n);
     TH_CHECK_HIP(hipGetLastError());
     return TREXHIP_OK;
 }
@@ -1181,7 +1209,7 @@ int launch_rethreshold(trexhip_ctx* ctx, int thr, int method, const double* rang
     hipLaunchKernelGGL(k_blobs, dim3(n), dim3(256), 0, s, c, 0, q.d_raster, q.d_parent, q.d_root_ord, q.d_cnt_runs, q.d_cnt_px, q.d_cur_run,
                        q.d_pix_begin, q.d_blob_map, q.d_totals, q.d_info, q.d_blobs, q.d_blob_frame, q.d_runs, 1, q.d_run_parent);
     hipLaunchKernelGGL(k_gather, dim3(1024), dim3(256), 0, s, c, 0, ctx->d_frames, q.d_totals, q.d_info, q.d_blob_frame, q.d_blobs,
-                       q.d_runs, q.d_pixels);
+                       q.d_runs, q.d_pixels, 0u, (uint32_t)n);
     TH_CHECK_HIP(hipGetLastError());
     q.valid_n = n;
     return TREXHIP_OK;
