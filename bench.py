@@ -46,12 +46,16 @@ def main():
     ap.add_argument("--cnn-mode", default="fp16x3", choices=["fp32", "bf16x6", "bf16x3", "fp16x3"],
                     help="arithmetic of conv2/conv3: fp16x3 = 2-piece fp16 split, fp32-class error, range-guarded (default); bf16x6 = 3-piece bf16 split; fp32 = exact fp32 MFMA")
     ap.add_argument("--with-posture", action="store_true", help="also run posture (outline -> midline) for every blob inside the timed step (configs C3/C5)")
+    ap.add_argument("--normalize", default="none", choices=["none", "moments", "posture"],
+                    help="individual_image_normalization of the identity crops; posture = outline -> midline -> Midline::transform -> warpAffine (implies --with-posture)")
     ap.add_argument("--no-pipeline", dest="pipeline", action="store_false", help="one context, strictly serial steps (no overlap of detect(i+1) with identity(i))")
     ap.add_argument("--lanes", type=int, default=2, help="software-pipeline depth: contexts whose batches are in flight (detect of batch i+L-1 is issued while the identity network works on batch i)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     args = ap.parse_args()
 
+    if args.normalize == "posture":
+        args.with_posture = True
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -99,6 +103,8 @@ def main():
                 self.p_outline = torch.empty((pool, MP, 2), dtype=torch.float32, device=dev)
                 self.p_segs = torch.empty((pool, MP // 2 + 1, 4), dtype=torch.float32, device=dev)
                 self.p_info = torch.empty((pool, 8), dtype=torch.int32, device=dev)
+                self.p_mid = torch.empty((pool, 25, 4), dtype=torch.float32, device=dev)
+                self.p_minfo = torch.empty((pool, 8), dtype=torch.int32, device=dev)
             self.stream = torch.cuda.Stream(device=dev)   # torch-side copies ride on the same stream as the kernels
             self.seg.set_stream(self.stream.cuda_stream)
             self.n = 0
@@ -117,9 +123,13 @@ def main():
                 self.stream.wait_event(self.after.done)
             if args.with_posture and n:
                 seg.posture_device(n, self.p_outline.data_ptr(), self.p_segs.data_ptr(), self.p_info.data_ptr(), max_points=MP)
+                seg.midline_device(n, MP, self.p_info.data_ptr(), self.p_segs.data_ptr(), self.p_mid.data_ptr(), self.p_minfo.data_ptr())
             if with_cnn:
                 if n:
-                    seg.crops_device(self.crops.data_ptr(), n)
+                    if args.normalize == "posture":
+                        seg.crops_posture_device(self.crops.data_ptr(), n, self.p_minfo.data_ptr())
+                    else:
+                        seg.crops_device(self.crops.data_ptr(), n, normalization=1 if args.normalize == "moments" else 0)
                     seg.identify_device(self.crops.data_ptr(), n, self.probs.data_ptr())
                 # per-blob identity table -> (all-gather over RCCL/xGMI) -> rank 0's host, for the sequential matcher
                 frame_base = (step_idx * world + rank) * B
@@ -232,7 +242,7 @@ def main():
                                f"80x80x1 crops, {classes}-way V118_3 (random-init weights)",
                    "stages": "detect(bg-sub+threshold+CCL+filter+gather, tables->host) + crops(none) + identity CNN (V118_3) + per-blob ID table (all-gathered when N>1) -> rank-0 host"
                              if with_cnn else "detect only (bg-sub+threshold+CCL+filter+gather, tables->host)",
-                   "frames_per_step_per_gpu": B, "pipelined_lanes": len(lanes), "blobs_per_step_rank0": n_blobs, "parallelism": f"frame-sharded x{world}"},
+                   "frames_per_step_per_gpu": B, "posture": bool(args.with_posture), "individual_image_normalization": args.normalize, "pipelined_lanes": len(lanes), "blobs_per_step_rank0": n_blobs, "parallelism": f"frame-sharded x{world}"},
     }
     seg_roof = {"kernel": "k_rows", "bound": "hbm", "achieved": seg_bytes / rows_s / 1e9 if rows_s else 0.0, "peak": 8000.0,
                 "unit": "GB/s", "frac": seg_bytes / rows_s / 8e12 if rows_s else 0.0, "traffic": pmc_traffic("trexhip::k_rows"),

@@ -633,7 +633,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_conv5_stream(const float* __rest
     }
 }
 
-static constexpr int FC1_KSPLIT = 5;      // 12800 = 5 x 2560: 5x the workgroups (200 -> 1000 at 6400 crops), partials summed in k_head
+static constexpr int FC1_KSPLIT = 10;     // 12800 = 10 x 1280: 500 workgroups at 6400 crops (5: 129 us, 10: 92 us, 20: 102 us + slower head); partial planes summed in k_head
 // ------------------------------------------------------------------------------------------------
 // fc1: out[N][128] = act[N][K] * W[K][128] + b     (K = 12800, 100 real outputs)
 // ------------------------------------------------------------------------------------------------
@@ -693,6 +693,97 @@ __global__ __launch_bounds__(256) void k_fc1(const float* __restrict__ act, cons
         const int i = (r & 3) + 8 * (r >> 2) + 4 * h;
         if (m0 + i < n) out[(size_t)(m0 + i) * 128 + co] = acc[r] + bz;
     }
+}
+
+// ------------------------------------------------------------------------------------------------
+// fc1 on the fp16 matrix cores (default with the fp16 split convolutions): 128 crops x 128 outputs x 1/5 of K per block.
+// Activations are split into two fp16 pieces while a 128 x 32 chunk is staged in LDS (80-byte row pitch: the 16 lanes of a
+// ds_read_b128 group hit 16 distinct slots); weight fragments stream L2 -> VGPR from the pre-split image
+// [k-octet][piece][co] x 8 halves.  3 MFMA products per product, fp32 accumulate; an activation outside the fp16 range
+// raises the same flag as the convolutions (guarded fp32 re-run).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_fc1_split(const float* __restrict__ act, const uint4* __restrict__ wq /*[K/8][2][128]*/,
+                                                   const float* __restrict__ bias, float* __restrict__ out, int n, int K,
+                                                   const float out_scale, uint32_t* __restrict__ overflow) {
+    constexpr int RPB = 80;                                     // bytes per staged row (32 halves + 16 pad)
+    __shared__ __attribute__((aligned(16))) uint8_t As[2][2][128 * RPB];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int j = lane & 31, h = lane >> 5;
+    const int m0 = blockIdx.x * 128;
+    const int kspan = K / (int)gridDim.y, kbeg = (int)blockIdx.y * kspan;
+    out += (size_t)blockIdx.y * n * 128;
+    f32x16 acc[4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
+    bool ovf = false;
+    float4 na[4];
+    uint4 nb[2][2];
+    const uint4* wl = wq + (size_t)(kbeg / 8) * 256 + wave * 32 + j;     // + (ko*2 + piece)*128
+#define FCS_FETCH(kc)                                                                                                      \
+    do {                                                                                                                   \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                                    \
+            const int idx = tid + 256 * i, row = idx >> 3, q = idx & 7;                                                    \
+            na[i] = m0 + row < n ? *reinterpret_cast<const float4*>(act + (size_t)(m0 + row) * K + kbeg + (kc) * 32 + q * 4) \
+                                 : make_float4(0.f, 0.f, 0.f, 0.f);                                                        \
+        }                                                                                                                  \
+        _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) {                                                                 \
+            const uint4* w_ = wl + (size_t)((kc) * 4 + 2 * ks + h) * 256;                                                  \
+            nb[ks][0] = w_[0]; nb[ks][1] = w_[128];                                                                        \
+        }                                                                                                                  \
+    } while (0)
+#define FCS_STASH(buf)                                                                                                     \
+    do {                                                                                                                   \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                                    \
+            const int idx = tid + 256 * i, row = idx >> 3, q = idx & 7;                                                    \
+            uint32_t a1[4], a2[4];                                                                                         \
+            split2h(na[i].x, a1[0], a2[0], ovf); split2h(na[i].y, a1[1], a2[1], ovf);                                      \
+            split2h(na[i].z, a1[2], a2[2], ovf); split2h(na[i].w, a1[3], a2[3], ovf);                                      \
+            uint8_t* d = As[buf][0] + row * RPB + q * 8;                                                                   \
+            *reinterpret_cast<uint2*>(d) = make_uint2(a1[0] | (a1[1] << 16), a1[2] | (a1[3] << 16));                       \
+            *reinterpret_cast<uint2*>(d + 128 * RPB) = make_uint2(a2[0] | (a2[1] << 16), a2[2] | (a2[3] << 16));           \
+        }                                                                                                                  \
+    } while (0)
+    FCS_FETCH(0);
+    FCS_STASH(0);
+    uint4 cb[2][2] = {{nb[0][0], nb[0][1]}, {nb[1][0], nb[1][1]}};
+    __syncthreads();
+    const int nk = kspan / 32;
+    for (int kc = 0; kc < nk; ++kc) {
+        const int buf = kc & 1;
+        if (kc + 1 < nk) FCS_FETCH(kc + 1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const f16x8 b1 = __builtin_bit_cast(f16x8, cb[ks][0]), b2 = __builtin_bit_cast(f16x8, cb[ks][1]);
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                const uint8_t* a = As[buf][0] + (32 * m + j) * RPB + (2 * ks + h) * 16;
+                const f16x8 p1 = __builtin_bit_cast(f16x8, *reinterpret_cast<const uint4*>(a));
+                const f16x8 p2 = __builtin_bit_cast(f16x8, *reinterpret_cast<const uint4*>(a + 128 * RPB));
+                acc[m] = mfma16(p2, b1, acc[m]);
+                acc[m] = mfma16(p1, b2, acc[m]);
+                acc[m] = mfma16(p1, b1, acc[m]);
+            }
+        }
+        if (kc + 1 < nk) {
+            FCS_STASH(buf ^ 1);
+            cb[0][0] = nb[0][0]; cb[0][1] = nb[0][1]; cb[1][0] = nb[1][0]; cb[1][1] = nb[1][1];
+        }
+        __syncthreads();
+    }
+#undef FCS_FETCH
+#undef FCS_STASH
+    if (__any(ovf) && lane == 0) atomicOr(overflow, 1u);
+    const int co = wave * 32 + j;
+    const float bz = blockIdx.y == 0 ? bias[co] : 0.f;
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int i = 32 * m + (r & 3) + 8 * (r >> 2) + 4 * h;
+            if (m0 + i < n) out[(size_t)(m0 + i) * 128 + co] = acc[m][r] * out_scale + bz;
+        }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -770,6 +861,8 @@ struct Net {
     uint4 *w2s = nullptr, *w3s = nullptr;      // bf16-split conv weights
     uint4 *w2h = nullptr, *w3h = nullptr;      // fp16-split conv weights (scaled by a power of two)
     float inv2h = 1.f, inv3h = 1.f;
+    uint4* wf1h = nullptr;                     // fc1 weights, fp16 pieces in MFMA B layout [K/8][2][128] x 8 halves
+    float invf1h = 1.f;
     uint4* w1h = nullptr;                      // conv1 B fragments (16 fragments x 64 lanes), fp16 pieces of the folded weights
     float inv1h = 1.f;
     uint32_t* d_ovf = nullptr;
@@ -790,6 +883,7 @@ static void free_net(Net* n) {
     if (n->w2h) (void)hipFree(n->w2h);
     if (n->w3h) (void)hipFree(n->w3h);
     if (n->w1h) (void)hipFree(n->w1h);
+    if (n->wf1h) (void)hipFree(n->wf1h);
     if (n->d_ovf) (void)hipFree(n->d_ovf);
     if (n->crops) (void)hipFree(n->crops);
     if (n->h_probs) (void)hipHostFree(n->h_probs);
@@ -963,6 +1057,26 @@ int net_load(trexhip_ctx* ctx, const void* blob, size_t bytes) {
                     wf[((size_t)hw * 128 + c) * 128 + o] = f1w[(size_t)o * flat + (size_t)c * P + hw];
         }
         TRY(upload(&net->wf1, wf)); TRY(upload(&net->bf1, bf));
+        if (rc == TREXHIP_OK) {      // the same matrix as two fp16 pieces per weight, MFMA B-operand order
+            float mx = 0.f;
+            for (float v : wf) mx = std::fmax(mx, std::fabs(v));
+            int k = 0;
+            if (mx > 0.f) { k = (int)std::floor(std::log2(16384.0 / (double)mx)); if (k > 24) k = 24; if (k < -24) k = -24; }
+            const float sc = std::ldexp(1.0f, k);
+            net->invf1h = std::ldexp(1.0f, -k);
+            std::vector<uint16_t> o((size_t)flat * 128 * 2);
+            for (size_t kk = 0; kk < flat; ++kk)
+                for (int co = 0; co < 128; ++co) {
+                    const float x = wf[kk * 128 + co] * sc;
+                    const _Float16 h1 = (_Float16)x;
+                    const _Float16 h2 = (_Float16)(x - (float)h1);
+                    uint16_t pc[2];
+                    std::memcpy(&pc[0], &h1, 2); std::memcpy(&pc[1], &h2, 2);
+                    for (int s = 0; s < 2; ++s) o[(((kk / 8) * 2 + s) * 128 + co) * 8 + (kk & 7)] = pc[s];
+                }
+            if (hipMalloc(reinterpret_cast<void**>(&net->wf1h), o.size() * 2) != hipSuccess ||
+                hipMemcpy(net->wf1h, o.data(), o.size() * 2, hipMemcpyHostToDevice) != hipSuccess) rc = TREXHIP_E_DEVICE;
+        }
     }
     TRY(upload(&net->lng, std::vector<float>(lg, lg + 100)));
     TRY(upload(&net->lnb, std::vector<float>(lb, lb + 100)));
@@ -1060,7 +1174,10 @@ int net_forward(trexhip_ctx* ctx, const uint8_t* d_crops, int n, float* d_probs,
     else if (ctx->tune_conv_geom & 2)    LAUNCH_SPLIT(64, 128, 20, 10, 1, 3, net->act2, net->w3h, net->b3, net->act3, net->inv3h, (const uint32_t*)nullptr);
     else                                 LAUNCH_SPLIT(64, 128, 20, 20, 1, 3, net->act2, net->w3h, net->b3, net->act3, net->inv3h, (const uint32_t*)nullptr);   // 32-channel chunks (CIC=32) measured slower: 3.7 vs 3.0 ms
     stage_end(ctx, TREXHIP_STAGE_CONV3);
-    hipLaunchKernelGGL(k_fc1, dim3((n + 31) / 32, FC1_KSPLIT), dim3(256), 0, s, net->act3, net->wf1, net->bf1, net->fc1, n, 12800, (const uint32_t*)nullptr);
+    if (mode == TREXHIP_CNN_FP16X3 && !(ctx->tune_conv_geom & 32))
+        hipLaunchKernelGGL(k_fc1_split, dim3((n + 127) / 128, FC1_KSPLIT), dim3(256), 0, s, net->act3, net->wf1h, net->bf1, net->fc1, n, 12800, net->invf1h, net->d_ovf);
+    else
+        hipLaunchKernelGGL(k_fc1, dim3((n + 31) / 32, FC1_KSPLIT), dim3(256), 0, s, net->act3, net->wf1, net->bf1, net->fc1, n, 12800, (const uint32_t*)nullptr);
     hipLaunchKernelGGL(k_head, dim3((n + 3) / 4), dim3(256), 0, s, net->fc1, net->lng, net->lnb, net->wf2t, net->bf2,
                        d_probs, d_logits, n, net->classes, (const uint32_t*)nullptr, FC1_KSPLIT);
     if (mode == TREXHIP_CNN_FP16X3) {
