@@ -114,15 +114,21 @@ __global__ __launch_bounds__(256) void k_conv1_mfma(const uint8_t* __restrict__ 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int crop = blockIdx.x;
     const uint8_t* src = crops + (size_t)crop * S * S;
-    for (int i = tid; i < PH * PITCH / 2; i += 256) {        // two pixels per thread-iteration
-        const int row = i / (PITCH / 2), c2 = (i - row * (PITCH / 2)) * 2;
-        _Float16 v0 = (_Float16)0.f, v1 = (_Float16)0.f;
-        const int y = row - 2, x = c2 - 2;
-        if (y >= 0 && y < S) {
-            if (x >= 0 && x < S) v0 = (_Float16)(float)src[y * S + x];
-            if (x + 1 >= 0 && x + 1 < S) v1 = (_Float16)(float)src[y * S + x + 1];
+    // zero the padded image, then 16 pixels per thread: one 16-byte load of the crop row, 16 halves into LDS
+    for (int i = tid; i < PH * PITCH * 2 / 16; i += 256) reinterpret_cast<uint4*>(img)[i] = make_uint4(0, 0, 0, 0);
+    __shared__ __attribute__((aligned(16))) float tr[4][64 * 17];      // per-wave transpose buffer of the epilogue
+    __syncthreads();
+    for (int i = tid; i < S * S / 16; i += 256) {
+        const int y = i / (S / 16), c16 = (i - y * (S / 16)) * 16;
+        const uint4 v = reinterpret_cast<const uint4*>(src)[i];
+        const uint32_t w4[4] = {v.x, v.y, v.z, v.w};
+        uint32_t* d = reinterpret_cast<uint32_t*>(img + (y + 2) * PITCH + 2 + c16);     // 4-byte aligned (2 + c16 is even)
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const uint32_t b0 = (w4[k >> 1] >> (16 * (k & 1))) & 0xffu, b1 = (w4[k >> 1] >> (16 * (k & 1) + 8)) & 0xffu;
+            const _Float16 h0 = (_Float16)(float)b0, h1 = (_Float16)(float)b1;
+            d[k] = (uint32_t)__builtin_bit_cast(uint16_t, h0) | ((uint32_t)__builtin_bit_cast(uint16_t, h1) << 16);
         }
-        img[row * PITCH + c2] = v0; img[row * PITCH + c2 + 1] = v1;
     }
     uint4 bf[16];
 #pragma unroll
@@ -152,16 +158,23 @@ __global__ __launch_bounds__(256) void k_conv1_mfma(const uint8_t* __restrict__ 
             c = __builtin_amdgcn_mfma_f32_16x16x32_f16(a2, __builtin_bit_cast(f16x8_c1, bf[s * 4 + 2]), c, 0, 0, 0);
             acc[s] = c;
         }
+        // lane (co, q) holds 4 consecutive pooled pixels of channel co; through LDS to one float4 (4 channels of one pixel) per lane
+        float* tw = tr[wave];
 #pragma unroll
         for (int pos = 0; pos < 2; ++pos) {
-            const int wp = tile * 8 + 2 * q + pos;
-            const int y2 = wp / 20, xw = wp - y2 * 20;
             const float m0 = fmaxf(fmaxf(acc[0][2 * pos], acc[0][2 * pos + 1]), fmaxf(acc[1][2 * pos], acc[1][2 * pos + 1]));
             const float m1 = fmaxf(fmaxf(acc[2][2 * pos], acc[2][2 * pos + 1]), fmaxf(acc[3][2 * pos], acc[3][2 * pos + 1]));
-            float* o = oc + ((size_t)y2 * 40 + 2 * xw) * 16 + co;
-            o[0] = fmaxf(m0 * inv_scale + bz, 0.f);
-            o[16] = fmaxf(m1 * inv_scale + bz, 0.f);
+            tw[(4 * q + 2 * pos) * 17 + co] = fmaxf(m0 * inv_scale + bz, 0.f);
+            tw[(4 * q + 2 * pos + 1) * 17 + co] = fmaxf(m1 * inv_scale + bz, 0.f);
         }
+        __builtin_amdgcn_wave_barrier();
+        {
+            const int px = lane >> 2, c4 = (lane & 3) * 4;                 // 16 pooled pixels x 4 channel quads
+            const float* s = tw + px * 17 + c4;
+            const float4 v = make_float4(s[0], s[1], s[2], s[3]);
+            *reinterpret_cast<float4*>(oc + ((size_t)tile * 16 + px) * 16 + c4) = v;
+        }
+        __builtin_amdgcn_wave_barrier();
     }
 }
 
