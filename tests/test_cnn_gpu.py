@@ -104,3 +104,23 @@ def test_fp16_range_overflow_falls_back_on_the_device():
     seg.set_identity_precision(capi.CNN_FP32)
     assert np.abs(seg.probabilities(crops) - ref).max() <= 1e-4
     seg.close()
+
+
+def test_unaligned_crop_buffer_and_both_conv1_kernels_agree():
+    # the matrix-core conv1 needs 16-byte aligned crops; an odd device pointer must take the VALU kernel and give the same answer
+    z, st = load_fixture(100)
+    seg = make_net(st, 100)
+    rng = np.random.default_rng(11)
+    crops = rng.integers(0, 256, (37, 80, 80, 1)).astype(np.uint8)
+    raw = torch.zeros(37 * 6400 + 64, dtype=torch.uint8, device="cuda")
+    pa = torch.empty((37, 100), dtype=torch.float32, device="cuda"); pb = torch.empty_like(pa)
+    off = (16 - raw.data_ptr() % 16) % 16
+    raw[off:off + 37 * 6400] = torch.from_numpy(crops.reshape(-1)).cuda()
+    seg.identify_device(raw.data_ptr() + off, 37, pa.data_ptr())
+    raw[off + 3:off + 3 + 37 * 6400] = torch.from_numpy(crops.reshape(-1)).cuda()
+    seg.identify_device(raw.data_ptr() + off + 3, 37, pb.data_ptr())
+    seg.synchronize()
+    op, _ = cnn_oracle.predict(st, crops, threads=8)
+    assert np.abs(pa.cpu().numpy() - op).max() <= 1e-4 and np.abs(pb.cpu().numpy() - op).max() <= 1e-4
+    assert np.abs(pa.cpu().numpy() - pb.cpu().numpy()).max() <= 1e-5
+    seg.close()

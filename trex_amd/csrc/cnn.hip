@@ -1155,7 +1155,8 @@ int net_forward(trexhip_ctx* ctx, const uint8_t* d_crops, int n, float* d_probs,
     stage_begin(ctx, TREXHIP_STAGE_CNN_ALL);
     const int S = net->W;
     const size_t lds1 = ((size_t)net->CH * (S + 4) * (S + 4) + (size_t)net->CH * 25 * 16) * 4;
-    if (net->CH == 1 && !(ctx->tune_conv_geom & 16)) hipLaunchKernelGGL(k_conv1_mfma, dim3(n), dim3(256), 0, s, d_crops, net->w1h, net->b1, net->act1, net->inv1h);
+    // the matrix-core conv1 reads the crops with 16-byte loads: unaligned crop buffers take the VALU kernel
+    if (net->CH == 1 && !(ctx->tune_conv_geom & 16) && (reinterpret_cast<uintptr_t>(d_crops) & 15) == 0) hipLaunchKernelGGL(k_conv1_mfma, dim3(n), dim3(256), 0, s, d_crops, net->w1h, net->b1, net->act1, net->inv1h);
     else if (net->CH == 1) hipLaunchKernelGGL((k_conv1<1>), dim3(n), dim3(256), lds1, s, d_crops, net->w1, net->b1, net->act1, S);
     else              hipLaunchKernelGGL((k_conv1<3>), dim3(n), dim3(256), lds1, s, d_crops, net->w1, net->b1, net->act1, S);
     const int mode = ctx->cnn_mode;
