@@ -119,8 +119,6 @@ def main():
             res = seg.fetch(copy=False)             # waits for detect; blob/run/pixel tables now on this rank's host
             n = self.n = sum(len(r.blobs) for r in res)
             assert n <= rows, "identity table too small"
-            if self.after is not None:              # keep one identity stage on the GPU at a time: only detect(i+1) overlaps it
-                self.stream.wait_event(self.after.done)
             if args.with_posture and n:
                 seg.posture_device(n, self.p_outline.data_ptr(), self.p_segs.data_ptr(), self.p_info.data_ptr(), max_points=MP)
                 seg.midline_device(n, MP, self.p_info.data_ptr(), self.p_segs.data_ptr(), self.p_mid.data_ptr(), self.p_minfo.data_ptr())
@@ -130,7 +128,10 @@ def main():
                         seg.crops_posture_device(self.crops.data_ptr(), n, self.p_minfo.data_ptr())
                     else:
                         seg.crops_device(self.crops.data_ptr(), n, normalization=1 if args.normalize == "moments" else 0)
+                    if self.after is not None:      # one identity network on the matrix cores at a time; posture / crops above and the
+                        self.stream.wait_event(self.after.done)   # table hand-off below overlap the other lane's network
                     seg.identify_device(self.crops.data_ptr(), n, self.probs.data_ptr())
+                self.done.record(self.stream)
                 # per-blob identity table -> (all-gather over RCCL/xGMI) -> rank 0's host, for the sequential matcher
                 frame_base = (step_idx * world + rank) * B
                 seg.export_id_table(self.probs.data_ptr(), n, classes, frame_base, self.table.data_ptr(), rows)
@@ -138,7 +139,8 @@ def main():
                     g = tdist.all_gather_tables(self.table) if world > 1 else self.table
                     if rank == 0:
                         self.table_host.copy_(g, non_blocking=True)
-            self.done.record(self.stream)
+            else:
+                self.done.record(self.stream)
 
         def drain(self):
             self.stream.synchronize()
