@@ -1146,6 +1146,8 @@ int net_forward(trexhip_ctx* ctx, const uint8_t* d_crops, int n, float* d_probs,
         SET_ATTR(16, 64, 40, 20, 1, 3); SET_ATTR(64, 128, 20, 10, 1, 3);
         TH_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv5_stream<16, 64, 40, 10, 4>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (ConvGeomS<16, 64, 40, 10, 4>::LDS_BYTES)));
+        TH_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv5_stream<16, 64, 40, 8, 4>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (ConvGeomS<16, 64, 40, 8, 4>::LDS_BYTES)));
         TH_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv5_stream<64, 128, 20, 20, 8>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (ConvGeomS<64, 128, 20, 20, 8>::LDS_BYTES)));
 #undef SET_ATTR
@@ -1171,6 +1173,9 @@ int net_forward(trexhip_ctx* ctx, const uint8_t* d_crops, int n, float* d_probs,
         hipLaunchKernelGGL((k_conv5<16, 64, 40, 20, 16>), dim3(n * G2::BPC), dim3(512), G2::LDS_BYTES, s, net->act1, net->w2, net->b2, net->act2);
     else if (mode == TREXHIP_CNN_BF16X6) LAUNCH_SPLIT(16, 64, 40, 10, 0, 6, net->act1, net->w2s, net->b2, net->act2, 1.0f, (const uint32_t*)nullptr);
     else if (mode == TREXHIP_CNN_BF16X3) LAUNCH_SPLIT(16, 64, 40, 10, 0, 3, net->act1, net->w2s, net->b2, net->act2, 1.0f, (const uint32_t*)nullptr);
+    else if (!(ctx->tune_conv_geom & (4 | 64)))   // 8 output rows per workgroup: 320 pixels = exactly 10 M-tiles, 3 workgroups per CU (1.15 ms; 10 rows: 1.31 ms)
+        hipLaunchKernelGGL((k_conv5_stream<16, 64, 40, 8, 4>), dim3(n * (ConvGeomS<16, 64, 40, 8, 4>::BPC)), dim3(256),
+                           (ConvGeomS<16, 64, 40, 8, 4>::LDS_BYTES), s, net->act1, net->w2h, net->b2, net->act2, net->inv2h, net->d_ovf);
     else if (!(ctx->tune_conv_geom & 4))
         hipLaunchKernelGGL((k_conv5_stream<16, 64, 40, 10, 4>), dim3(n * (ConvGeomS<16, 64, 40, 10, 4>::BPC)), dim3(256),
                            (ConvGeomS<16, 64, 40, 10, 4>::LDS_BYTES), s, net->act1, net->w2h, net->b2, net->act2, net->inv2h, net->d_ovf);
