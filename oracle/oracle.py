@@ -114,6 +114,8 @@ def lib():
         L.oracle_normalize_transform.argtypes = [C.c_void_p, C.c_float, C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_void_p]
         L.oracle_moments_transform.argtypes = [C.c_void_p, C.c_void_p]
         L.oracle_warp_affine_u8.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32]
+        L.oracle_posture_auto.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
+                                          C.POINTER(PostureParams), C.c_void_p, C.c_void_p, C.POINTER(PostureInfo), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
         L.oracle_midline_post_process.argtypes = [C.c_void_p, C.c_int32, C.c_float, C.c_int32, C.c_int32]
         L.oracle_midline_normalize.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_float, C.c_void_p, C.c_void_p]
         L.oracle_midline_transform.argtypes = [C.c_float, C.c_float, C.c_float, C.c_int32, C.c_void_p]
@@ -353,3 +355,21 @@ def midline_transform(angle, offx, offy, legacy=False):
     tr = np.zeros(6, np.float32)
     lib().oracle_midline_transform(float(angle), float(offx), float(offy), 1 if legacy else 0, _ptr(tr))
     return tr
+
+
+def posture_auto(runs, pixels, bg, method=0, start_threshold=0, pp=None):
+    """posture::calculate_posture with its threshold retry loop (Posture.cpp:305-399) for one blob given as runs + pixels
+    (full-frame coordinates).  returns (info dict incl. threshold / iterations, outline [n,2], segments [m,4])."""
+    runs = np.ascontiguousarray(runs, RUN_DTYPE)
+    pixels = np.ascontiguousarray(pixels, np.uint8)
+    bg = np.ascontiguousarray(bg, np.uint8)
+    pp = pp or posture_params()
+    out = np.zeros((pp.max_points, 2), np.float32)
+    seg = np.zeros((pp.max_points, 4), np.float32)
+    info = PostureInfo()
+    thr, it = C.c_int32(), C.c_int32()
+    lib().oracle_posture_auto(_ptr(runs), len(runs), _ptr(pixels), _ptr(bg), bg.shape[1], bg.shape[1], bg.shape[0], method, start_threshold,
+                              C.byref(pp), _ptr(out), _ptr(seg), C.byref(info), C.byref(thr), C.byref(it))
+    d = {k: getattr(info, k) for k, _ in PostureInfo._fields_}
+    d["threshold"] = thr.value; d["iterations"] = it.value
+    return d, out[:info.n_outline].copy(), seg[:info.n_segments].copy()

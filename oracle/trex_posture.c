@@ -202,7 +202,7 @@ int oracle_posture(const oracle_run* runs, int32_t n_runs, int32_t origin_x, int
             const float c0 = curv[(i - 1 + n) % n], c1 = curv[i], c2 = curv[(i + 1) % n];
             if (c1 > c0 && c1 >= c2 && c1 > best) { best = c1; tail = i; }
         }
-        if (tail < 0) { rc = 3; goto done; }
+        if (tail < 0) { rc = 3; memcpy(outline_xy, pts, (size_t)n * sizeof(v2)); info->n_outline = n; goto done; }   /* the outline stays available (first_outline fallback, Posture.cpp:361-368) */
         int head = -1; float maxd = 0;
         for (int i = 0; i < n; ++i) {
             const float c0 = curv[(i - 1 + n) % n], c1 = curv[i], c2 = curv[(i + 1) % n];
@@ -405,4 +405,68 @@ void oracle_midline_transform(float angle, float offx, float offy, int legacy, f
     const float c = cosf(rad), s = sinf(rad);
     tr6[0] = c; tr6[1] = -s; tr6[2] = c * -offx + -s * -offy;
     tr6[3] = s; tr6[4] = c;  tr6[5] = s * -offx + c * -offy;
+}
+
+
+/* ---- posture::calculate_posture with its threshold retry loop (Posture.cpp:305-399) -------------------------------------------
+ * threshold = track_posture_threshold; repeat: biggest sub-blob of the blob at `threshold` (pixel::threshold_get_biggest_blob,
+ * commons: restated as threshold_blob + largest pixel count, first wins ties; posture_closing_steps = 0), coordinates relative
+ * to the ORIGINAL blob's bounds().pos() (:336), outline -> resample -> calculate_midline; success returns at once, otherwise
+ * threshold += 2 until the thresholded blob has fewer than max(1, initial/10) pixels or threshold >= start + 100.  When no
+ * threshold works the first outline that could be traced is returned without a midline (:383-391).
+ * info->status: 0 ok, else the status of the LAST attempt; *threshold_used = threshold of the returned result (success) or of the
+ * first outline (fallback) or -1; *iterations = attempts made. */
+int oracle_posture_auto(const oracle_run* runs, int32_t n_runs, const uint8_t* pixels, const uint8_t* bg, int32_t bg_stride,
+                        int32_t width, int32_t height, int32_t method, int32_t start_threshold, const oracle_posture_params* P,
+                        float* outline_xy, float* segments, oracle_posture_info* info, int32_t* threshold_used, int32_t* iterations) {
+    memset(info, 0, sizeof(*info));
+    *threshold_used = -1; *iterations = 0;
+    if (n_runs <= 0) { info->status = 1; return 1; }
+    int ox = 65535, oy = 65535; uint64_t initial = 0;
+    for (int i = 0; i < n_runs; ++i) {
+        if (runs[i].x0 < ox) ox = runs[i].x0;
+        if (runs[i].y < oy) oy = runs[i].y;
+        initial += (uint64_t)(runs[i].x1 - runs[i].x0 + 1);
+    }
+    const uint64_t minimum = initial / 10u > 1u ? initial / 10u : 1u;
+    float* first = NULL; int first_n = 0, first_thr = -1;
+    int threshold = start_threshold, rc = 1;
+    oracle_posture_info last; memset(&last, 0, sizeof(last)); last.status = 1;
+    for (;;) {
+        oracle_frame* fr = oracle_threshold_blob(runs, n_runs, pixels, bg, bg_stride, width, height, method, threshold, 8);
+        int nb, nr, np;
+        oracle_frame_counts(fr, &nb, &nr, &np);
+        uint64_t count = 0;
+        ++*iterations;
+        if (nb > 0) {
+            oracle_blob* bl = (oracle_blob*)malloc((size_t)nb * sizeof(oracle_blob));
+            oracle_run* rr = (oracle_run*)malloc((size_t)(nr > 0 ? nr : 1) * sizeof(oracle_run));
+            uint8_t* px = (uint8_t*)malloc((size_t)(np > 0 ? np : 1));
+            oracle_frame_copy(fr, bl, rr, px);
+            int best = 0;
+            for (int k = 1; k < nb; ++k) if (bl[k].n_pixels > bl[best].n_pixels) best = k;
+            count = bl[best].n_pixels;
+            rc = oracle_posture(rr + bl[best].run_begin, (int32_t)bl[best].n_runs, ox, oy, P, outline_xy, segments, &last);
+            free(bl); free(rr); free(px);
+            if (rc == 0) { oracle_frame_free(fr); *info = last; *threshold_used = threshold; free(first); return 0; }
+            if (!first && last.n_outline > 0) {
+                first = (float*)malloc((size_t)last.n_outline * 2 * sizeof(float));
+                memcpy(first, outline_xy, (size_t)last.n_outline * 2 * sizeof(float));
+                first_n = last.n_outline; first_thr = threshold;
+            }
+        } else { rc = 1; memset(&last, 0, sizeof(last)); last.status = 1; }
+        oracle_frame_free(fr);
+        threshold += 2;
+        if (count < minimum || threshold >= start_threshold + 100) break;
+    }
+    *info = last;
+    info->n_segments = 0;
+    info->n_outline = 0;
+    if (first) {
+        memcpy(outline_xy, first, (size_t)first_n * 2 * sizeof(float));
+        info->n_outline = first_n; *threshold_used = first_thr;
+        free(first);
+    }
+    if (info->status == 0) info->status = 1;
+    return info->status;
 }

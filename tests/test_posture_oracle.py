@@ -150,3 +150,50 @@ def test_midline_transform_maps_head_offset_to_origin():
         p = np.array([info["offx"], info["offy"]], np.float32)
         q = tr.reshape(2, 3)[:, :2] @ p + tr.reshape(2, 3)[:, 2]
         assert np.allclose(q, 0, atol=1e-3)
+
+
+def test_threshold_retry_loop_equals_one_pass_plus_fallback():
+    """posture::calculate_posture retries with threshold += 2 while the midline fails (Posture.cpp:331-381).  In this
+    restatement only blobs too small for a midline fail, they keep failing while they shrink, and the loop ends in the
+    first-outline fallback (:383-391) -- i.e. exactly what ONE pass returns (status 3/4 with its outline).  That is why the
+    device path runs one pass per call; this test keeps the claim honest on ~170 adversarial blobs."""
+    rng = np.random.default_rng(0)
+    H, W = 64, 96
+    n_retry = n_total = 0
+    for trial in range(160):
+        bg = np.full((H, W), 200, np.uint8)
+        fr = bg.copy()
+        yy, xx = np.mgrid[0:H, 0:W]
+        cx, cy = 48 + rng.integers(-5, 5), 32 + rng.integers(-4, 4)
+        th = rng.uniform(0, np.pi)
+        u = (xx - cx) * np.cos(th) + (yy - cy) * np.sin(th); v = -(xx - cx) * np.sin(th) + (yy - cy) * np.cos(th)
+        kind = trial % 4
+        if kind == 0:
+            fr[(u / rng.uniform(1, 3)) ** 2 + (v / rng.uniform(0.6, 1.5)) ** 2 <= 1] = 200 - rng.integers(20, 90)
+        elif kind == 1:
+            halo = ((u / 22.0) ** 2 + (v / 12.0) ** 2 <= 1) & (rng.random((H, W)) < 0.75)
+            fr[halo] = 200 - rng.integers(16, 24)
+            fr[(u / 16.0) ** 2 + (v / 4.0) ** 2 <= 1] = 110
+        elif kind == 2:
+            fr[(np.abs(v) < 1.2) & (np.abs(u) < 14)] = 182
+            fr[((u + 14) / 10.0) ** 2 + (v / 3.0) ** 2 <= 1] = 120
+            fr[((u - 14) / 3.0) ** 2 + (v / 10.0) ** 2 <= 1] = 140
+        else:
+            rr_ = np.hypot(u, v)
+            fr[(rr_ > 9) & (rr_ < 11)] = 180
+            fr[(rr_ > 9) & (rr_ < 11) & (u > 3)] = 100
+        blobs, runs, px = oracle.segment(fr, bg, oracle.make_params(W, H, threshold=15))
+        for b in blobs:
+            rs = runs[b["run_begin"]:b["run_begin"] + b["n_runs"]]; pp = px[b["pix_begin"]:b["pix_begin"] + b["n_pixels"]]
+            auto, ol_a, sg_a = oracle.posture_auto(rs, pp, bg, method=0, start_threshold=0)
+            one, ol_1, sg_1 = oracle.posture(rs, (int(b["x0"]), int(b["y0"])))
+            n_total += 1
+            if one["status"] == 0:
+                assert auto["status"] == 0 and auto["iterations"] == 1 and auto["threshold"] == 0
+                assert np.array_equal(ol_a, ol_1) and np.array_equal(sg_a, sg_1)
+            else:
+                n_retry += 1
+                assert auto["status"] != 0 and auto["iterations"] > 1 and auto["n_segments"] == 0
+                assert auto["threshold"] in (0, -1)
+                assert np.array_equal(ol_a, ol_1)          # the first outline == the outline of the single pass
+    assert n_total > 150 and n_retry >= 10

@@ -228,7 +228,12 @@ __global__ __launch_bounds__(256) void k_posture(const PostureCfg P, const trexh
         const float ob = __shfl_xor(best, d); const int ot = __shfl_xor(tail, d);
         if (ob > best || (ob == best && ot < tail)) { best = ob; tail = ot; }
     }
-    if (tail == 0x7fffffff || best < 0.f) { if (lane == 0) { res.status = 3; res.n_outline = n; out_info[bi] = res; } return; }
+    if (tail == 0x7fffffff || best < 0.f) {     // no curvature peak: the outline stays available (first_outline fallback, Posture.cpp:361-368)
+        float2* of = out_outline + (size_t)bi * P.max_points;
+        for (int i = lane; i < n; i += 64) of[i] = pts[i];
+        if (lane == 0) { res.status = 3; res.n_outline = n; out_info[bi] = res; }
+        return;
+    }
     float maxd = 0.f; int head = 0x7fffffff;
     for (int i = lane; i < n; i += 64) {
         const float c0 = s_curv[(i - 1 + n) % n], c1 = s_curv[i], c2 = s_curv[(i + 1) % n];
