@@ -50,6 +50,8 @@ def main():
                     help="individual_image_normalization of the identity crops; posture = outline -> midline -> Midline::transform -> warpAffine (implies --with-posture)")
     ap.add_argument("--no-pipeline", dest="pipeline", action="store_false", help="one context, strictly serial steps (no overlap of detect(i+1) with identity(i))")
     ap.add_argument("--lanes", type=int, default=2, help="software-pipeline depth: contexts whose batches are in flight (detect of batch i+L-1 is issued while the identity network works on batch i)")
+    ap.add_argument("--no-detect-priority", dest="detect_priority", action="store_false",
+                    help="keep the detect stage on the lane's own stream (default: a high-priority stream per lane, so that its short kernels get compute units as soon as the other lane's identity network frees some)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     args = ap.parse_args()
@@ -107,11 +109,14 @@ def main():
                 self.p_minfo = torch.empty((pool, 8), dtype=torch.int32, device=dev)
             self.stream = torch.cuda.Stream(device=dev)   # torch-side copies ride on the same stream as the kernels
             self.seg.set_stream(self.stream.cuda_stream)
+            self.hi = torch.cuda.Stream(device=dev, priority=-1) if args.detect_priority else None
             self.n = 0
             self.done = torch.cuda.Event()
             self.after = None                       # lane whose identity stage must finish before this lane's starts
 
         def detect(self):
+            if self.hi is not None:
+                self.seg.set_stream(self.hi.cuda_stream)
             self.seg.segment_device(frames.data_ptr(), B)
 
         def identify(self, step_idx):
@@ -119,6 +124,8 @@ def main():
             res = seg.fetch(copy=False)             # waits for detect; blob/run/pixel tables now on this rank's host
             n = self.n = sum(len(r.blobs) for r in res)
             assert n <= rows, "identity table too small"
+            if self.hi is not None:
+                seg.set_stream(self.stream.cuda_stream)
             if args.with_posture and n:
                 seg.posture_device(n, self.p_outline.data_ptr(), self.p_segs.data_ptr(), self.p_info.data_ptr(), max_points=MP)
                 seg.midline_device(n, MP, self.p_info.data_ptr(), self.p_segs.data_ptr(), self.p_mid.data_ptr(), self.p_minfo.data_ptr())

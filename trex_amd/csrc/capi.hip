@@ -143,6 +143,7 @@ int trexhip_create(const trexhip_params* p, trexhip_ctx** out) {
     if (!ctx) { set_error("out of host memory"); return TREXHIP_E_NOMEM; }
     ctx->p = *p;
     fill_cfg(ctx);
+    { int cus = 0; if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, p->device) == hipSuccess && cus > 0) ctx->n_cus = cus; }
     if (const char* e = std::getenv("TREXHIP_ROWS_ORDER")) ctx->tune_rows_order = std::atoi(e);
     if (const char* e = std::getenv("TREXHIP_CONV_GEOM")) ctx->tune_conv_geom = std::atoi(e);
     if (const char* e = std::getenv("TREXHIP_CCL_STOP")) ctx->tune_ccl_stop = std::atoi(e);

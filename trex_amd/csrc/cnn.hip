@@ -520,18 +520,22 @@ struct ConvGeomS {
     static constexpr int NITEMS = (NQ + NTHR - 1) / NTHR;
 };
 
-template <int CI, int CO, int S, int ROWS, int WAVES>
+template <int CI, int CO, int S, int ROWS, int WAVES, bool PERSIST = false>
 __global__ __launch_bounds__(WAVES * 64) void k_conv5_stream(const float* __restrict__ in /*[N][S][S][CI]*/,
                                                              const uint4* __restrict__ wp /*[CI/16][25][2][2][CO] x 16 B*/,
                                                              const float* __restrict__ bias, float* __restrict__ out,
-                                                             const float out_scale, uint32_t* __restrict__ overflow) {
+                                                             const float out_scale, uint32_t* __restrict__ overflow, const int n_units) {
     using G = ConvGeomS<CI, CO, S, ROWS, WAVES>;
     static_assert(G::NCH == 1 || G::NITEMS <= 5, "staging slices do not fit between the taps");
+    static_assert(G::NCH == 1 || G::NCH % 2 == 0, "buffer parity must survive the unit loop");
     extern __shared__ __attribute__((aligned(16))) uint8_t ldsb[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int j = lane & 31, h = lane >> 5;
     const int n = wave % G::NT, mg = wave / G::NT;
-    const int crop = blockIdx.x / G::BPC, row0 = (blockIdx.x % G::BPC) * ROWS;
+    // a unit = ROWS output rows of one crop.  gridDim.x == n_units: one unit per workgroup; fewer workgroups: each walks the
+    // units with a grid stride and (multi-chunk layers) stages the next unit's first chunk under the current unit's last one.
+    int unit = blockIdx.x;
+    if (unit >= n_units) return;
     constexpr int WR = S / 2;
 
     int aoff[G::TPW];
@@ -546,26 +550,19 @@ __global__ __launch_bounds__(WAVES * 64) void k_conv5_stream(const float* __rest
         }
         aoff[m] = off + h * 16;
     }
-    f32x16 acc[G::TPW];
-#pragma unroll
-    for (int m = 0; m < G::TPW; ++m)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
-
     const bool last_tile = mg + G::WM * (G::TPW - 1) < G::MT;
-    const float* inc = in + (size_t)crop * S * S * CI;
     bool ovf = false;
     // one staged item: float4 of 4 input channels of one patch pixel -> two fp16 pieces in LDS
-#define STG_LOAD(v_, item_, cc_)                                                                                              \
+#define STG_LOAD(v_, item_, inc_, row0_, cc_)                                                                                 \
     do {                                                                                                                      \
         const int idx_ = tid + (item_) * G::NTHR;                                                                             \
         v_ = make_float4(0.f, 0.f, 0.f, 0.f);                                                                                 \
         if (idx_ < G::NQ) {                                                                                                   \
             const int px_ = idx_ >> 2, q_ = idx_ & 3;                                                                         \
             const int py_ = px_ / G::PW, pxx_ = px_ - py_ * G::PW;                                                            \
-            const int iy_ = row0 + py_ - 2, ix_ = pxx_ - 2;                                                                   \
+            const int iy_ = (row0_) + py_ - 2, ix_ = pxx_ - 2;                                                                \
             if (iy_ >= 0 && iy_ < S && ix_ >= 0 && ix_ < S)                                                                   \
-                v_ = *reinterpret_cast<const float4*>(inc + ((size_t)iy_ * S + ix_) * CI + (cc_) * 16 + q_ * 4);              \
+                v_ = *reinterpret_cast<const float4*>((inc_) + ((size_t)iy_ * S + ix_) * CI + (cc_) * 16 + q_ * 4);           \
         }                                                                                                                     \
     } while (0)
 #define STG_STORE(v_, item_, base_)                                                                                           \
@@ -588,62 +585,94 @@ __global__ __launch_bounds__(WAVES * 64) void k_conv5_stream(const float* __rest
     uint4 bq[5][2];
     bq[0][0] = wl[0]; bq[0][1] = wl[2 * CO];
     bq[1][0] = wl[G::BV]; bq[1][1] = wl[G::BV + 2 * CO];
-    for (int it = 0; it < G::NITEMS; ++it) {       // first chunk: staged up front
-        float4 v;
-        STG_LOAD(v, it, 0);
-        STG_STORE(v, it, ldsb);
-    }
-    __syncthreads();
-    for (int cc = 0; cc < G::NCH; ++cc) {
-        const uint8_t* pbase = ldsb + (G::NBUF > 1 ? (cc & 1) * 2 * G::PATCH : 0);
-        uint8_t* nbase = ldsb + (G::NBUF > 1 ? ((cc + 1) & 1) * 2 * G::PATCH : 0);
-        const bool more = cc + 1 < G::NCH;
-        const uint4* wc = wl + (size_t)cc * 25 * G::BV;
-        float4 sv = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-        for (int tap = 0; tap < 25; ++tap) {
-            if (tap + 2 < 25 || more) {            // weights two taps ahead (runs into the next chunk's first taps)
-                bq[(tap + 2) % 5][0] = wc[(size_t)(tap + 2) * G::BV];
-                bq[(tap + 2) % 5][1] = wc[(size_t)(tap + 2) * G::BV + 2 * CO];
+    const int co = n * 32 + j;
+    const float bz = bias[co];
+    int crop = unit / G::BPC, row0 = (unit % G::BPC) * ROWS;
+    const float* inc = in + (size_t)crop * S * S * CI;
+    bool staged = false;                               // the current unit's first chunk is already in LDS
+    for (;;) {
+        if (!staged) {
+            if (G::NCH == 1 && unit != (int)blockIdx.x) __syncthreads();     // single buffer: the previous unit must be done with it
+            for (int it = 0; it < G::NITEMS; ++it) {
+                float4 v;
+                STG_LOAD(v, it, inc, row0, 0);
+                STG_STORE(v, it, ldsb);
             }
-            if (G::NCH > 1 && more) {
-                if (tap % 5 == 0 && tap / 5 < G::NITEMS) STG_LOAD(sv, tap / 5, cc + 1);
-                if (tap % 5 == 3 && tap / 5 < G::NITEMS) STG_STORE(sv, tap / 5, nbase);
-            }
-            const uint8_t* asrc = pbase + ((tap / 5) * G::RP + (tap % 5) * G::PSTRIDE);
-            const f16x8 b1 = __builtin_bit_cast(f16x8, bq[tap % 5][0]);
-            const f16x8 b2 = __builtin_bit_cast(f16x8, bq[tap % 5][1]);
+            __syncthreads();
+        }
+        f32x16 acc[G::TPW];
 #pragma unroll
-            for (int m = 0; m < G::TPW; ++m) {
-                if (m == G::TPW - 1 && !last_tile) continue;       // wave-uniform: this M-group has one tile less
-                const f16x8 p1 = __builtin_bit_cast(f16x8, *reinterpret_cast<const uint4*>(asrc + aoff[m]));
-                const f16x8 p2 = __builtin_bit_cast(f16x8, *reinterpret_cast<const uint4*>(asrc + aoff[m] + G::PATCH));
-                acc[m] = mfma16(p2, b1, acc[m]);
-                acc[m] = mfma16(p1, b2, acc[m]);
-                acc[m] = mfma16(p1, b1, acc[m]);
+        for (int m = 0; m < G::TPW; ++m)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
+        const int next_unit = unit + (int)gridDim.x;
+        const bool have_next = PERSIST && next_unit < n_units;       // !PERSIST: gridDim.x == n_units, one unit per workgroup
+        const int crop_n = next_unit / G::BPC, row0_n = (next_unit % G::BPC) * ROWS;
+        const float* inc_n = in + (size_t)crop_n * S * S * CI;
+        for (int cc = 0; cc < G::NCH; ++cc) {
+            const uint8_t* pbase = ldsb + (G::NBUF > 1 ? (cc & 1) * 2 * G::PATCH : 0);
+            uint8_t* nbase = ldsb + (G::NBUF > 1 ? ((cc + 1) & 1) * 2 * G::PATCH : 0);
+            const bool more_c = cc + 1 < G::NCH;
+            const bool more_w = more_c || have_next;                         // weights of a following chunk are needed
+            const bool more_s = G::NCH > 1 && more_w;                        // ... and its patch can be staged under this chunk
+            const float* sinc = more_c ? inc : inc_n;
+            const int srow0 = more_c ? row0 : row0_n, scc = more_c ? cc + 1 : 0;
+            const uint4* wc = wl + (size_t)cc * 25 * G::BV;
+            const uint4* wn = wl + (size_t)scc * 25 * G::BV;
+            float4 sv = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int tap = 0; tap < 25; ++tap) {
+                if (tap + 2 < 25) {                // weights two taps ahead (runs into the following chunk's first taps)
+                    bq[(tap + 2) % 5][0] = wc[(size_t)(tap + 2) * G::BV];
+                    bq[(tap + 2) % 5][1] = wc[(size_t)(tap + 2) * G::BV + 2 * CO];
+                } else if (more_w) {
+                    bq[(tap + 2) % 5][0] = wn[(size_t)(tap + 2 - 25) * G::BV];
+                    bq[(tap + 2) % 5][1] = wn[(size_t)(tap + 2 - 25) * G::BV + 2 * CO];
+                }
+                if (more_s) {
+                    if (tap % 5 == 0 && tap / 5 < G::NITEMS) STG_LOAD(sv, tap / 5, sinc, srow0, scc);
+                    if (tap % 5 == 3 && tap / 5 < G::NITEMS) STG_STORE(sv, tap / 5, nbase);
+                }
+                const uint8_t* asrc = pbase + ((tap / 5) * G::RP + (tap % 5) * G::PSTRIDE);
+                const f16x8 b1 = __builtin_bit_cast(f16x8, bq[tap % 5][0]);
+                const f16x8 b2 = __builtin_bit_cast(f16x8, bq[tap % 5][1]);
+#pragma unroll
+                for (int m = 0; m < G::TPW; ++m) {
+                    if (m == G::TPW - 1 && !last_tile) continue;       // wave-uniform: this M-group has one tile less
+                    const f16x8 p1 = __builtin_bit_cast(f16x8, *reinterpret_cast<const uint4*>(asrc + aoff[m]));
+                    const f16x8 p2 = __builtin_bit_cast(f16x8, *reinterpret_cast<const uint4*>(asrc + aoff[m] + G::PATCH));
+                    acc[m] = mfma16(p2, b1, acc[m]);
+                    acc[m] = mfma16(p1, b2, acc[m]);
+                    acc[m] = mfma16(p1, b1, acc[m]);
+                }
+            }
+            if (G::NCH > 1) __syncthreads();
+        }
+        float* oc = out + (size_t)crop * WR * WR * CO;
+#pragma unroll
+        for (int m = 0; m < G::TPW; ++m) {
+            const int mt = mg + G::WM * m;
+            if (mt >= G::MT) continue;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int wi = mt * 8 + 2 * g + h;
+                if (wi >= G::NPIX / 4) continue;
+                const float v = fmaxf(fmaxf(acc[m][4 * g], acc[m][4 * g + 1]), fmaxf(acc[m][4 * g + 2], acc[m][4 * g + 3]));
+                const int wy = row0 / 2 + wi / WR, wx = wi % WR;
+                oc[((size_t)wy * WR + wx) * CO + co] = fmaxf(v * out_scale + bz, 0.f);
             }
         }
-        if (G::NCH > 1) __syncthreads();
+        if (!PERSIST || !have_next) break;
+        unit = next_unit; crop = crop_n; row0 = row0_n; inc = inc_n;
+        staged = G::NCH > 1;                           // multi-chunk layers staged it under the last chunk
+        if (G::NCH == 1) {                             // single chunk: weights of taps 0,1 again
+            bq[0][0] = wl[0]; bq[0][1] = wl[2 * CO];
+            bq[1][0] = wl[G::BV]; bq[1][1] = wl[G::BV + 2 * CO];
+        }
     }
 #undef STG_LOAD
 #undef STG_STORE
     if (__any(ovf) && lane == 0) atomicOr(overflow, 1u);
-    const int co = n * 32 + j;
-    const float bz = bias[co];
-    float* oc = out + (size_t)crop * WR * WR * CO;
-#pragma unroll
-    for (int m = 0; m < G::TPW; ++m) {
-        const int mt = mg + G::WM * m;
-        if (mt >= G::MT) continue;
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const int wi = mt * 8 + 2 * g + h;
-            if (wi >= G::NPIX / 4) continue;
-            const float v = fmaxf(fmaxf(acc[m][4 * g], acc[m][4 * g + 1]), fmaxf(acc[m][4 * g + 2], acc[m][4 * g + 3]));
-            const int wy = row0 / 2 + wi / WR, wx = wi % WR;
-            oc[((size_t)wy * WR + wx) * CO + co] = fmaxf(v * out_scale + bz, 0.f);
-        }
-    }
 }
 
 static constexpr int FC1_KSPLIT = 10;     // 12800 = 10 x 1280: 500 workgroups at 6400 crops (5: 129 us, 10: 92 us, 20: 102 us + slower head); partial planes summed in k_head
@@ -1148,7 +1177,7 @@ int net_forward(trexhip_ctx* ctx, const uint8_t* d_crops, int n, float* d_probs,
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (ConvGeomS<16, 64, 40, 10, 4>::LDS_BYTES)));
         TH_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv5_stream<16, 64, 40, 8, 4>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (ConvGeomS<16, 64, 40, 8, 4>::LDS_BYTES)));
-        TH_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv5_stream<64, 128, 20, 20, 8>),
+        TH_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv5_stream<64, 128, 20, 20, 8, true>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (ConvGeomS<64, 128, 20, 20, 8>::LDS_BYTES)));
 #undef SET_ATTR
 #undef SET_ATTRC
@@ -1175,10 +1204,10 @@ int net_forward(trexhip_ctx* ctx, const uint8_t* d_crops, int n, float* d_probs,
     else if (mode == TREXHIP_CNN_BF16X3) LAUNCH_SPLIT(16, 64, 40, 10, 0, 3, net->act1, net->w2s, net->b2, net->act2, 1.0f, (const uint32_t*)nullptr);
     else if (!(ctx->tune_conv_geom & (4 | 64)))   // 8 output rows per workgroup: 320 pixels = exactly 10 M-tiles, 3 workgroups per CU (1.15 ms; 10 rows: 1.31 ms)
         hipLaunchKernelGGL((k_conv5_stream<16, 64, 40, 8, 4>), dim3(n * (ConvGeomS<16, 64, 40, 8, 4>::BPC)), dim3(256),
-                           (ConvGeomS<16, 64, 40, 8, 4>::LDS_BYTES), s, net->act1, net->w2h, net->b2, net->act2, net->inv2h, net->d_ovf);
+                           (ConvGeomS<16, 64, 40, 8, 4>::LDS_BYTES), s, net->act1, net->w2h, net->b2, net->act2, net->inv2h, net->d_ovf, n * (ConvGeomS<16, 64, 40, 8, 4>::BPC));
     else if (!(ctx->tune_conv_geom & 4))
         hipLaunchKernelGGL((k_conv5_stream<16, 64, 40, 10, 4>), dim3(n * (ConvGeomS<16, 64, 40, 10, 4>::BPC)), dim3(256),
-                           (ConvGeomS<16, 64, 40, 10, 4>::LDS_BYTES), s, net->act1, net->w2h, net->b2, net->act2, net->inv2h, net->d_ovf);
+                           (ConvGeomS<16, 64, 40, 10, 4>::LDS_BYTES), s, net->act1, net->w2h, net->b2, net->act2, net->inv2h, net->d_ovf, n * (ConvGeomS<16, 64, 40, 10, 4>::BPC));
     else if (ctx->tune_conv_geom & 1)    LAUNCH_SPLIT(16, 64, 40, 20, 1, 3, net->act1, net->w2h, net->b2, net->act2, net->inv2h, (const uint32_t*)nullptr);
     else                                 LAUNCH_SPLIT(16, 64, 40, 10, 1, 3, net->act1, net->w2h, net->b2, net->act2, net->inv2h, (const uint32_t*)nullptr);
     stage_end(ctx, TREXHIP_STAGE_CONV2);
@@ -1188,8 +1217,10 @@ int net_forward(trexhip_ctx* ctx, const uint8_t* d_crops, int n, float* d_probs,
     else if (mode == TREXHIP_CNN_BF16X6) LAUNCH_SPLIT(64, 128, 20, 20, 0, 6, net->act2, net->w3s, net->b3, net->act3, 1.0f, (const uint32_t*)nullptr);
     else if (mode == TREXHIP_CNN_BF16X3) LAUNCH_SPLIT(64, 128, 20, 20, 0, 3, net->act2, net->w3s, net->b3, net->act3, 1.0f, (const uint32_t*)nullptr);
     else if (!(ctx->tune_conv_geom & 8))
-        hipLaunchKernelGGL((k_conv5_stream<64, 128, 20, 20, 8>), dim3(n * (ConvGeomS<64, 128, 20, 20, 8>::BPC)), dim3(512),
-                           (ConvGeomS<64, 128, 20, 20, 8>::LDS_BYTES), s, net->act2, net->w3h, net->b3, net->act3, net->inv3h, net->d_ovf);
+        // one workgroup per CU (110 KB LDS, 256 VGPRs): persistent workgroups walk the crops and stage the next crop's first
+        // chunk under the current crop's last one (TREXHIP_CONV_GEOM bit 7: one workgroup per crop instead)
+        hipLaunchKernelGGL((k_conv5_stream<64, 128, 20, 20, 8, true>), dim3((ctx->tune_conv_geom & 128) || n < ctx->n_cus ? n : ctx->n_cus), dim3(512),
+                           (ConvGeomS<64, 128, 20, 20, 8>::LDS_BYTES), s, net->act2, net->w3h, net->b3, net->act3, net->inv3h, net->d_ovf, n);
     else if (ctx->tune_conv_geom & 2)    LAUNCH_SPLIT(64, 128, 20, 10, 1, 3, net->act2, net->w3h, net->b3, net->act3, net->inv3h, (const uint32_t*)nullptr);
     else                                 LAUNCH_SPLIT(64, 128, 20, 20, 1, 3, net->act2, net->w3h, net->b3, net->act3, net->inv3h, (const uint32_t*)nullptr);   // 32-channel chunks (CIC=32) measured slower: 3.7 vs 3.0 ms
     stage_end(ctx, TREXHIP_STAGE_CONV3);
