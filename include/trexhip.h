@@ -147,6 +147,11 @@ int trexhip_segment(trexhip_ctx* ctx, const uint8_t* const* frames, int32_t stri
  * channels 3 or 4; color_channel < 0 (or >= channels) = cv::cvtColor(BGR2GRAY / BGRA2GRAY), else that channel */
 int trexhip_segment_color(trexhip_ctx* ctx, const uint8_t* const* frames, int32_t stride, int32_t n,
                           int32_t channels, int32_t color_channel);
+/* device buffers for callers that do not link the HIP runtime themselves (the C++ adapters in trex_amd/host): plain
+ * hipMalloc / hipFree / stream-ordered device-to-host copy (synchronous on return) on the context's device and stream */
+int trexhip_device_alloc(trexhip_ctx* ctx, size_t bytes, void** out_device_ptr);
+int trexhip_device_free(trexhip_ctx* ctx, void* device_ptr);
+int trexhip_copy_to_host(trexhip_ctx* ctx, void* host_dst, const void* device_src, size_t bytes);
 /* wait for the last segment call and copy its tables to pinned host memory */
 int trexhip_fetch(trexhip_ctx* ctx, trexhip_batch_result* out);
 int trexhip_device_view_get(trexhip_ctx* ctx, trexhip_device_view* out);

@@ -9,6 +9,8 @@
 #include <random>
 #include "../../trex_amd/host/HipBackgroundSubtraction.h"
 #include "../../trex_amd/host/HipVINetwork.h"
+#include "../../trex_amd/host/HipPosture.h"
+#include <cmath>
 #include "../../oracle/trex_oracle.h"
 
 using namespace track;
@@ -148,6 +150,18 @@ int main(int argc, char** argv) {
         try { f.get(); } catch (const std::exception&) { threw = true; }
         CHECK(threw);
     }
+    // --- unsupported encodings (rgb8 / r3g3b2) raise through the future like the reference's "Invalid image mode" (:188) ---
+    {
+        auto& st = HipBackgroundSubtraction::settings();
+        const auto keep = st.meta_encoding;
+        st.meta_encoding = cmn::meta_encoding_t::rgb8;
+        TileImage t; t.images.push_back(cmn::Image::Make(H, W, 3));
+        auto f = HipBackgroundSubtraction::apply(std::move(t));
+        bool threw = false;
+        try { f.get(); } catch (const std::exception&) { threw = true; }
+        CHECK(threw);
+        st.meta_encoding = keep;
+    }
     // --- TileImage destroyed with a live promise raises inside the future (core/TileImage.cpp:13-21) ---
     {
         std::future<SegmentationData> f;
@@ -155,6 +169,67 @@ int main(int argc, char** argv) {
         bool threw = false;
         try { f.get(); } catch (const std::exception&) { threw = true; }
         CHECK(threw);
+    }
+    // --- posture + identity crops of a batch through the adapters (posture::calculate_posture / constraints::diff_image) ---
+    {
+        const int PW = 256, PH = 128;
+        trexhip_params p; trexhip_default_params(&p, PW, PH); p.max_batch = 2;
+        trexhip_ctx* ctx = nullptr;
+        CHECK(trexhip_create(&p, &ctx) == 0);
+        std::vector<uint8_t> pbg((size_t)PW * PH, 200), f0 = pbg, f1 = pbg;
+        auto ellipse = [&](std::vector<uint8_t>& f, float cx, float cy, float a, float b, float th) {
+            for (int y = 0; y < PH; ++y) for (int x = 0; x < PW; ++x) {
+                const float u = (x - cx) * std::cos(th) + (y - cy) * std::sin(th), v = -(x - cx) * std::sin(th) + (y - cy) * std::cos(th);
+                if (u * u / (a * a) + v * v / (b * b) <= 1.f) f[(size_t)y * PW + x] = (uint8_t)(60 + (x + y) % 50);
+            }
+        };
+        ellipse(f0, 60, 40, 22, 6, 0.3f); ellipse(f0, 180, 80, 18, 5, 2.0f); ellipse(f1, 120, 64, 25, 7, 1.1f);
+        f1[10 * PW + 10] = 20;                                                   // a single-pixel blob: outline but no midline
+        CHECK(trexhip_set_background(ctx, pbg.data(), PW) == 0);
+        const uint8_t* fp[2] = {f0.data(), f1.data()};
+        CHECK(trexhip_segment(ctx, fp, PW, 2) == 0);
+        trexhip_batch_result res{};
+        CHECK(trexhip_fetch(ctx, &res) == 0);
+        CHECK(res.total_blobs == 4);
+        {   // the adapter owns device buffers of the context: it goes out of scope before trexhip_destroy
+        HipPosture hp(ctx);
+        HipPosture::Settings ps;
+        std::vector<HipPosture::Expected> r;
+        try { r = hp.calculate_posture(0, (int)res.total_blobs, ps); }
+        catch (const std::exception& e) { std::fprintf(stderr, "calculate_posture: %s\n", e.what()); std::exit(1); }
+        CHECK(r.size() == 4);
+        int with_midline = 0;
+        for (size_t b = 0; b < r.size(); ++b) {
+            CHECK((bool)r[b]);
+            CHECK(!r[b].value.outline.empty());
+            const trexhip_blob& B = res.blobs[b];
+            if (B.n_pixels == 1) { CHECK(!r[b].value.midline && !r[b].value.normalized_midline); CHECK(r[b].value.outline.size() >= 3 && r[b].value.outline.size() <= 8); continue; }
+            ++with_midline;
+            CHECK(r[b].value.midline && r[b].value.midline->size() > 5 && !r[b].value.midline->is_normalized());
+            Midline& nm = *r[b].value.normalized_midline;
+            CHECK(nm.is_normalized() && nm.size() == 25);
+            CHECK(nm.segments()[0].pos == cmn::Vec2(0.f, 0.f));                  // head at the origin (Outline.cpp:1436-1441)
+            CHECK(nm.len() > 25.f && nm.len() < 60.f);                           // long axes 36..50 px
+            double l = 0;
+            for (size_t i = 1; i < nm.size(); ++i) l += std::hypot(nm.segments()[i].pos.x - nm.segments()[i - 1].pos.x, nm.segments()[i].pos.y - nm.segments()[i - 1].pos.y);
+            CHECK(std::fabs(l - nm.len()) < 1e-2);
+        }
+        CHECK(with_midline == 3);
+        for (int mode = 0; mode < 4; ++mode) {
+            std::vector<cmn::Image::Ptr> imgs;
+            try { imgs = hp.diff_images(mode, (int)res.total_blobs, 80, 80, nullptr, 1.0f, 0); }
+            catch (const std::exception& e) { std::fprintf(stderr, "diff_images mode %d: %s\n", mode, e.what()); std::exit(1); }
+            CHECK(imgs.size() == 4);
+            for (size_t b = 0; b < imgs.size(); ++b) {
+                if (mode >= 2 && res.blobs[b].n_pixels == 1) { CHECK(!imgs[b]); continue; }
+                CHECK(imgs[b] && imgs[b]->rows == 80 && imgs[b]->cols == 80 && imgs[b]->dims == 1);
+                uint64_t sum = 0; for (size_t i = 0; i < imgs[b]->size(); ++i) sum += imgs[b]->data()[i];
+                CHECK(sum > 0);
+                if (mode == 0) CHECK(sum == res.blobs[b].sp);                    // un-normalised crop holds exactly the blob's grey values
+            }
+        }
+        }
+        trexhip_destroy(ctx);
     }
     hooks->deinit();
 

@@ -210,6 +210,31 @@ void trexhip_destroy(trexhip_ctx* ctx) {
     delete ctx;
 }
 
+int trexhip_device_alloc(trexhip_ctx* ctx, size_t bytes, void** out_device_ptr) {
+    if (!ctx || !out_device_ptr) { set_error("trexhip_device_alloc: null argument"); return TREXHIP_E_INVALID; }
+    *out_device_ptr = nullptr;
+    TH_CHECK_HIP(hipSetDevice(ctx->p.device));
+    TH_CHECK_HIP(hipMalloc(out_device_ptr, bytes ? bytes : 1));
+    return TREXHIP_OK;
+}
+
+int trexhip_device_free(trexhip_ctx* ctx, void* device_ptr) {
+    if (!ctx) { set_error("null ctx"); return TREXHIP_E_INVALID; }
+    if (!device_ptr) return TREXHIP_OK;
+    TH_CHECK_HIP(hipSetDevice(ctx->p.device));
+    TH_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+    TH_CHECK_HIP(hipFree(device_ptr));
+    return TREXHIP_OK;
+}
+
+int trexhip_copy_to_host(trexhip_ctx* ctx, void* host_dst, const void* device_src, size_t bytes) {
+    if (!ctx || (bytes && (!host_dst || !device_src))) { set_error("trexhip_copy_to_host: null argument"); return TREXHIP_E_INVALID; }
+    TH_CHECK_HIP(hipSetDevice(ctx->p.device));
+    if (bytes) TH_CHECK_HIP(hipMemcpyAsync(host_dst, device_src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    TH_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+    return TREXHIP_OK;
+}
+
 int trexhip_set_stream(trexhip_ctx* ctx, void* hip_stream) {
     if (!ctx) { set_error("null ctx"); return TREXHIP_E_INVALID; }
     TH_CHECK_HIP(hipStreamSynchronize(ctx->stream));

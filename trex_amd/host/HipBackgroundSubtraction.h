@@ -87,6 +87,10 @@ struct HipBackgroundSubtraction {
         int channels = 0;
         bool ok = d.ctx && d.has_background;
         if (!ok) batch_error = "Background image not set";
+        // gray / binary only: the colour arithmetic of RawProcessing::generate_binary (rgb8, r3g3b2) is not part of this library
+        if (ok && d.settings.meta_encoding != cmn::meta_encoding_t::gray && d.settings.meta_encoding != cmn::meta_encoding_t::binary) {
+            ok = false; batch_error = "Invalid image mode for the HIP background-subtraction backend (meta_encoding must be gray or binary)";   // cf. BackgroundSubtraction.cpp:188
+        }
         if (ok) {
             for (auto& tile : tiled)
                 for (auto& image : tile.images) {
@@ -158,6 +162,9 @@ struct HipBackgroundSubtraction {
         hooks.set_background = [](const cmn::Image::Ptr& bg) { HipBackgroundSubtraction::set_background(bg); };
         detect::register_backend(type, std::move(hooks));
     }
+
+    // the reference re-reads its settings on every apply() (BackgroundSubtraction.cpp:132-143); callers update these in place
+    static Settings& settings() { return data().settings; }
 
 private:
     struct Data {

@@ -9,6 +9,7 @@
 //   SegmentationData       Application/src/tracker/core/TaskPipeline.h:87-118
 //   TileImage              Application/src/tracker/core/TileImage.h:33-75, TileImage.cpp:13-21 (dtor contract)
 //   detect::BackendHooks   Application/src/tracker/python/BackendRegistry.h:10-24
+//   track::Outline/Midline/MidlineSegment  Application/src/tracker/tracking/Outline.h:241-300 (members used by HipPosture.h only)
 #pragma once
 #include <cstdint>
 #include <functional>
@@ -46,6 +47,14 @@ struct HorizontalLine {
 };
 
 using PixelArray_t = std::vector<uint8_t>;
+
+struct Vec2 {
+    float x = 0, y = 0;
+    Vec2() = default;
+    Vec2(float x_, float y_) : x(x_), y(y_) {}
+    bool operator==(const Vec2& o) const { return x == o.x && y == o.y; }
+};
+using Float2_t = float;
 
 enum class meta_encoding_t { gray, r3g3b2, rgb8, binary };
 
@@ -149,3 +158,38 @@ inline void register_backend(ObjectDetectionType::Class type, BackendHooks hooks
 inline void unregister_backend(ObjectDetectionType::Class type) { registry().erase(type); }
 inline const BackendHooks* backend(ObjectDetectionType::Class type) { auto it = registry().find(type); return it == registry().end() ? nullptr : &it->second; }
 }  // namespace track::detect
+
+namespace track {
+struct MidlineSegment {                                  // tracking/Outline.h:241-250
+    cmn::Float2_t height = 0, l_length = 0;
+    cmn::Vec2 pos;
+};
+class Midline {                                          // tracking/Outline.h:252-300 (GETTER_NCONST members)
+public:
+    using Ptr = std::unique_ptr<Midline>;
+    cmn::Float2_t& len() { return _len; }
+    cmn::Float2_t& angle() { return _angle; }
+    cmn::Vec2& offset() { return _offset; }
+    std::vector<MidlineSegment>& segments() { return _segments; }
+    long& head_index() { return _head_index; }
+    long& tail_index() { return _tail_index; }
+    bool& is_normalized() { return _is_normalized; }
+    bool empty() const { return _segments.empty(); }
+    size_t size() const { return _segments.size(); }
+private:
+    cmn::Float2_t _len = 0, _angle = 0;
+    cmn::Vec2 _offset;
+    std::vector<MidlineSegment> _segments;
+    long _head_index = -1, _tail_index = -1;
+    bool _is_normalized = false;
+};
+class Outline {                                          // tracking/Outline.h (replace_points / points / size / empty)
+public:
+    void replace_points(std::unique_ptr<std::vector<cmn::Vec2>>&& p) { _points = std::move(p); }
+    const std::vector<cmn::Vec2>& points() const { static const std::vector<cmn::Vec2> none; return _points ? *_points : none; }
+    size_t size() const { return _points ? _points->size() : 0; }
+    bool empty() const { return size() == 0; }
+private:
+    std::unique_ptr<std::vector<cmn::Vec2>> _points;
+};
+}  // namespace track
