@@ -79,6 +79,30 @@ __global__ __launch_bounds__(256) void k_posture(const PostureCfg P, const trexh
     if (lane == 0) s_row[rows] = n_runs;
     __builtin_amdgcn_wave_barrier();
     const int ox = Bl.x0, oy = Bl.y0;                       // coordinates relative to the blob's bounds().pos() (Posture.cpp:336)
+    // blobs at most 64 pixels wide: one 64-bit occupancy word per row (in the curvature / arc-length arrays, idle until the
+    // outline exists) makes the membership test of the boundary walk a single LDS read
+    const int bx0 = Bl.x0;
+    const bool use_bm = (int)Bl.x1 - (int)Bl.x0 < 64 && rows <= NPc;
+    uint32_t* bm = reinterpret_cast<uint32_t*>(s_curv);
+    if (use_bm) {
+        for (int i = lane; i < rows * 2; i += 64) bm[i] = 0u;
+        __builtin_amdgcn_wave_barrier();
+        for (int i = lane; i < n_runs; i += 64) {
+            const trexhip_run q = rr[i];
+            const int a = (int)q.x0 - bx0, len = (int)q.x1 - (int)q.x0 + 1;
+            const unsigned long long m = (len >= 64 ? ~0ull : ((1ull << len) - 1ull)) << a;
+            if ((uint32_t)m) atomicOr(&bm[2 * (q.y - y0)], (uint32_t)m);
+            if ((uint32_t)(m >> 32)) atomicOr(&bm[2 * (q.y - y0) + 1], (uint32_t)(m >> 32));
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    auto inside = [&](int x, int y) -> bool {
+        if (!use_bm) return in_blob(s_runs, s_row, y0, y1, x, y);
+        if (y < y0 || y > y1) return false;
+        const int xr = x - bx0;
+        if ((unsigned)xr >= 64u) return false;
+        return (bm[2 * (y - y0) + (xr >> 5)] >> (xr & 31)) & 1u;
+    };
 
     // ---- outline on the half-pixel lattice + resample: sequential, lane 0 ----
     int n = 0, status = 0;
@@ -92,13 +116,33 @@ __global__ __launch_bounds__(256) void k_posture(const PostureCfg P, const trexh
             bufA[nt++] = make_float2(0.5f * (float)(vx + dx - 2 * ox), 0.5f * (float)(vy + dy - 2 * oy));
             vx += 2 * dx; vy += 2 * dy;
             const int lx = dy, ly = -dx, rx = -dy, ry = dx;
-            if (in_blob(s_runs, s_row, y0, y1, (vx + dx + lx) / 2, (vy + dy + ly) / 2)) { dx = lx; dy = ly; }
-            else if (in_blob(s_runs, s_row, y0, y1, (vx + dx + rx) / 2, (vy + dy + ry) / 2)) { }
+            if (inside((vx + dx + lx) / 2, (vy + dy + ly) / 2)) { dx = lx; dy = ly; }
+            else if (inside((vx + dx + rx) / 2, (vy + dy + ry) / 2)) { }
             else { dx = rx; dy = ry; }
         } while (!(vx == sx && vy == sy && dx == 1 && dy == 0));
         res.n_traced = nt;
-        if (!status) {   // Outline::resample (Outline.cpp:724-766)
-            const float rd = P.outline_resample;
+    }
+    int nt_all = __shfl(res.n_traced, 0);
+    status = __shfl(status, 0);
+    res.n_traced = nt_all;
+    __builtin_amdgcn_wave_barrier();
+    // Outline::resample (Outline.cpp:724-766).  Every segment of the lattice outline is exactly 0.5 long, so when 2 * resample
+    // distance is a whole number k all of the reference's float arithmetic is exact and it emits the start point of every k-th
+    // segment: done by all lanes.  Any other distance takes the sequential walk (same operation order as the reference).
+    const float rd = P.outline_resample;
+    const float k2 = rd * 2.0f;
+    const bool lattice = rd > 0.f && k2 == floorf(k2) && k2 <= 1024.f;
+    if (!status && lattice && nt_all > 1) {
+        const int k = (int)k2;
+        n = nt_all / k;
+        if (n > cap) { status = 2; n = 0; }
+        else {
+            for (int jx = lane; jx < n; jx += 64) bufB[jx] = bufA[(jx + 1) * k - 1];
+            if (n == 0) status = 1;
+        }
+    } else if (lane == 0) {
+        const int nt = nt_all;
+        if (!status) {
             if (rd <= 0.f || nt <= 1) { for (int i = 0; i < nt; ++i) bufB[i] = bufA[i]; n = nt; }
             else {
                 float walked = 0.0f;
@@ -124,7 +168,7 @@ __global__ __launch_bounds__(256) void k_posture(const PostureCfg P, const trexh
             if (!status && n == 0) status = 1;
         }
     }
-    n = __shfl(n, 0); status = __shfl(status, 0); res.n_traced = __shfl(res.n_traced, 0);
+    if (!(lattice && nt_all > 1)) { n = __shfl(n, 0); status = __shfl(status, 0); }
     __builtin_amdgcn_wave_barrier();
     if (status) { if (lane == 0) { res.status = status; out_info[bi] = res; } return; }
 
@@ -256,41 +300,66 @@ __global__ __launch_bounds__(256) void k_posture(const PostureCfg P, const trexh
     res.n_outline = n; res.tail_index = 0;
     res.head_index = head == 0x7fffffff ? -1 : ((head - tail) % n + n) % n;
     if (n <= 1) { if (lane == 0) { res.status = 1; out_info[bi] = res; } return; }
-    // ---- the two-pointer walk (Outline.cpp:790-857), lane 0 ----
-    if (lane == 0) {
+    // ---- the two-pointer walk (Outline.cpp:790-857): control flow is wave-uniform, the max_offset candidates of each
+    // search are evaluated one per lane and reduced to the FIRST minimum (the sequential `len < min_d` rule) ----
+    {
         const int L = n;
         int idx_r = 1, idx_l = -1, ns = 0;
         float mo = P.midline_walk_offset * (float)L; if (mo < 3.0f) mo = 3.0f;
         const int max_offset = (int)mo;
         float4* so = out_segments + (size_t)bi * (P.max_points / 2 + 1);
+        const float BIG = 3.402823466e38f;
+        int red = 1; while (red < max_offset && red < 64) red <<= 1;     // lanes taking part in one search (power of two)
         while (idx_r < L + idx_l) {
             float2 pt_r = make_float2(0.f, 0.f); float2 pt_l = pts[L + idx_l];
-            float min_d = 3.402823466e38f; int min_idx = -1;
-            for (int i = 0; i < max_offset; ++i) {
-                if (idx_r + i >= L) break;
-                const float2 pt = pts[idx_r + i];
-                const float ddx = pt.x - pt_l.x, ddy = pt.y - pt_l.y, len = sqrtf(ddx * ddx + ddy * ddy);
-                if (len < min_d) { min_d = len; min_idx = idx_r + i; }
+            int min_idx = -1; float best1 = BIG;
+            for (int i0 = 0; i0 < max_offset; i0 += 64) {           // one pass unless max_offset > 64
+                const int i = i0 + lane;
+                float len = BIG; int idx = 0x7fffffff;
+                if (i < max_offset && idx_r + i < L) {
+                    const float2 pt = pts[idx_r + i];
+                    const float ddx = pt.x - pt_l.x, ddy = pt.y - pt_l.y;
+                    len = sqrtf(ddx * ddx + ddy * ddy); idx = idx_r + i;
+                    if (!(len < BIG)) { len = BIG; idx = 0x7fffffff; }
+                }
+                float bl = len; int bidx = idx;
+#define WALK_STEP(d_) if (red > (d_)) { const float ol = __shfl_xor(bl, d_); const int oi = __shfl_xor(bidx, d_); if (ol < bl || (ol == bl && oi < bidx)) { bl = ol; bidx = oi; } }
+                WALK_STEP(1) WALK_STEP(2) WALK_STEP(4) WALK_STEP(8) WALK_STEP(16) WALK_STEP(32)      // constant distances: DPP for the short ones
+#undef WALK_STEP
+                if (bidx != 0x7fffffff && bl < best1) { best1 = bl; min_idx = bidx; }    // strict `<`: earlier candidates keep ties
+                if (max_offset <= 64) break;
             }
             if (min_idx != -1) { pt_r = pts[min_idx]; idx_r = min_idx; }
-            min_d = 3.402823466e38f; min_idx = 1;
-            for (int i = 0; i < max_offset; ++i) {
-                if (idx_l - i <= -L) break;
-                const float2 pt = pts[L + idx_l - i];
-                const float ddx = pt_r.x - pt.x, ddy = pt_r.y - pt.y, len = sqrtf(ddx * ddx + ddy * ddy);
-                if (len < min_d) { min_d = len; min_idx = idx_l - i; }
+            int min_idx2 = 1; float best2 = BIG;
+            for (int i0 = 0; i0 < max_offset; i0 += 64) {
+                const int i = i0 + lane;
+                float len = BIG; int key = 0x7fffffff;
+                if (i < max_offset && idx_l - i > -L) {
+                    const float2 pt = pts[L + idx_l - i];
+                    const float ddx = pt_r.x - pt.x, ddy = pt_r.y - pt.y;
+                    len = sqrtf(ddx * ddx + ddy * ddy); key = i;
+                    if (!(len < BIG)) { len = BIG; key = 0x7fffffff; }
+                }
+                float bl = len; int bk = key;
+#define WALK_STEP(d_) if (red > (d_)) { const float ol = __shfl_xor(bl, d_); const int ok2 = __shfl_xor(bk, d_); if (ol < bl || (ol == bl && ok2 < bk)) { bl = ol; bk = ok2; } }
+                WALK_STEP(1) WALK_STEP(2) WALK_STEP(4) WALK_STEP(8) WALK_STEP(16) WALK_STEP(32)
+#undef WALK_STEP
+                if (bk != 0x7fffffff && bl < best2) { best2 = bl; min_idx2 = idx_l - bk; }
+                if (max_offset <= 64) break;
             }
-            if (min_idx != 1) { pt_l = pts[L + min_idx]; idx_l = min_idx; }
+            if (min_idx2 != 1) { pt_l = pts[L + min_idx2]; idx_l = min_idx2; }
             const float lx = pt_r.x - pt_l.x, ly = pt_r.y - pt_l.y;
             const float mx = pt_l.x + lx * 0.5f, my = pt_l.y + ly * 0.5f;
-            if (ns <= P.max_points / 2)
+            if (lane == 0 && ns <= P.max_points / 2)
                 so[ns] = make_float4(mx, my, sqrtf(lx * lx + ly * ly), sqrtf((mx - pt_l.x) * (mx - pt_l.x) + (my - pt_l.y) * (my - pt_l.y)));
             ++ns;
             idx_r++; idx_l--;
         }
-        res.n_segments = ns;
-        res.status = ns <= 2 ? 4 : 0;
-        out_info[bi] = res;
+        if (lane == 0) {
+            res.n_segments = ns;
+            res.status = ns <= 2 ? 4 : 0;
+            out_info[bi] = res;
+        }
     }
 }
 

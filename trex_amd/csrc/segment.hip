@@ -923,13 +923,41 @@ __global__ __launch_bounds__(256) void k_gather(const SegCfg c, const int only_p
                 const uint8_t* src = img + (size_t)q.y * c.W;
                 const uint64_t y = q.y;
                 uint64_t rp = 0;                                       // sum of grey values of this run
-                for (uint32_t x = q.x0; x <= q.x1; ++x) {
-                    uint32_t p = src[x];
-                    if (c.invert) p = 255u - p;
-                    px[off++] = (uint8_t)p;
-                    m10 += x; m20 += (uint64_t)x * x;
-                    rp += p; spx += (uint64_t)p * x;
-                    pmin = min(pmin, p); pmax = max(pmax, p);
+                // 8 pixels per step: the byte loads of a step are independent, so a run costs len/8 memory round trips, not len
+                uint32_t x = q.x0;
+                for (; x + 7 <= (uint32_t)q.x1; x += 8) {
+                    uint32_t v[8];
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) v[k] = src[x + k];
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) {
+                        uint32_t p = v[k];
+                        if (c.invert) p = 255u - p;
+                        px[off + k] = (uint8_t)p;
+                        const uint32_t xx = x + k;
+                        m10 += xx; m20 += (uint64_t)xx * xx;
+                        rp += p; spx += (uint64_t)p * xx;
+                        pmin = min(pmin, p); pmax = max(pmax, p);
+                    }
+                    off += 8;
+                }
+                {
+                    uint32_t v[8];
+                    const uint32_t rem = (uint32_t)q.x1 + 1u - x;          // 0..7 pixels left
+#pragma unroll
+                    for (int k = 0; k < 7; ++k) v[k] = (uint32_t)k < rem ? src[x + k] : 0u;
+#pragma unroll
+                    for (int k = 0; k < 7; ++k) {
+                        if ((uint32_t)k >= rem) break;
+                        uint32_t p = v[k];
+                        if (c.invert) p = 255u - p;
+                        px[off + k] = (uint8_t)p;
+                        const uint32_t xx = x + k;
+                        m10 += xx; m20 += (uint64_t)xx * xx;
+                        rp += p; spx += (uint64_t)p * xx;
+                        pmin = min(pmin, p); pmax = max(pmax, p);
+                    }
+                    off += rem;
                 }
                 const uint64_t L = len;
                 const uint64_t sx = (uint64_t)(q.x0 + q.x1) * L / 2;   // sum of x over the run
