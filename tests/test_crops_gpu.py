@@ -50,7 +50,8 @@ def test_crops_moments_bit_exact(difference):
     # individual_image_normalization = moments (FilterCache.cpp:276-288): orientation from the blob's moments, warpAffine
     fr, bg = synth.batch("C2", 2)
     fr = fr.copy()
-    fr[0, 100:230, 300:420] = 10           # larger than the crop
+    fr[0, 100:230, 300:420] = 10           # larger than the crop (bounding box still painted into LDS)
+    fr[1, 300:480, 500:650] = np.arange(150, dtype=np.uint8)[None, :] % 90      # bounding box beyond the LDS image: per-tap line tests
     seg, res, d = _segment(fr, bg)
     total = sum(len(r.blobs) for r in res)
     crops = torch.full((total, 80, 80), 77, dtype=torch.uint8, device="cuda")

@@ -1,6 +1,6 @@
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/ks
-rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ks -- python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-pipeline --steps 5 --warmup 2 > /tmp/ks.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ks -- python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-pipeline --steps 5 --warmup 2 $KSTATS_ARGS > /tmp/ks.log 2>&1
 f=$(find /tmp/ks -name '*kernel_stats.csv' | head -1)
 python - "$f" <<'PY'
 import csv, sys

@@ -323,6 +323,8 @@ static Aff aff_rotate_deg(const Aff& a, float deg) {
 }
 
 static constexpr int W_NR = 2048;      // lines of one blob held in LDS
+static constexpr int W_OUT = 256;      // output rows / columns with tabulated fixed-point terms
+static constexpr int W_IMG = 16384;    // bounding boxes up to this many pixels are painted into LDS
 
 __global__ __launch_bounds__(256) void k_crops_warp(const SegCfg c, const uint8_t* __restrict__ frames, const uint8_t* __restrict__ bg,
                                                     const trexhip_frame_info* __restrict__ info, const uint32_t* __restrict__ blob_frame,
@@ -353,24 +355,59 @@ __global__ __launch_bounds__(256) void k_crops_warp(const SegCfg c, const uint8_
     const double m0 = M[0], m1 = M[1], m2 = M[2], m3 = M[3], m4 = M[4], m5 = M[5];
     const int sw = B.x1 - B.x0 + 1, sh = rows;
     const uint8_t* img = frames + (size_t)f * c.H * c.W;
+    // imageFromLines: the blob's pixels (raw or background difference) on black over its bounding box.  Small boxes are painted
+    // into LDS once (then the four taps of every output pixel are plain LDS reads); larger ones test line membership per tap.
+    __shared__ uint8_t s_img[W_IMG];
+    const bool staged = sw * sh <= W_IMG;
+    if (staged) {
+        for (int i = threadIdx.x; i < (sw * sh + 3) / 4; i += 256) reinterpret_cast<uint32_t*>(s_img)[i] = 0u;
+        __syncthreads();
+        for (int r = threadIdx.x; r < (int)B.n_runs; r += 256) {
+            const uint32_t q = s_runs[r];
+            const int xa = (int)(q & 0xffffu), xb = (int)(q >> 16), yy = (int)rr[r].y;
+            for (int ax = xa; ax <= xb; ++ax) {
+                int p = img[(size_t)yy * c.W + ax];
+                if (c.invert) p = 255 - p;
+                if (diff_mode) { const int bgv = bg[(size_t)yy * c.W + ax]; p = diff_mode == 1 ? abs(bgv - p) : max(bgv - p, 0); }
+                s_img[(yy - y0) * sw + (ax - B.x0)] = (uint8_t)p;
+            }
+        }
+        __syncthreads();
+    }
+    // cv::warpAffine's fixed-point coordinates: a row term and a column term per axis (AB_BITS 10), once per row / column
+    __shared__ int s_rx[W_OUT], s_ry[W_OUT], s_cx[W_OUT], s_cy[W_OUT];
+    const bool tabled = OW <= W_OUT && OH <= W_OUT;
+    if (tabled) {
+        for (int i = threadIdx.x; i < OH; i += 256) { s_rx[i] = __double2int_rn((m1 * i + m2) * 1024.0) + 16; s_ry[i] = __double2int_rn((m4 * i + m5) * 1024.0) + 16; }
+        for (int i = threadIdx.x; i < OW; i += 256) { s_cx[i] = __double2int_rn(m0 * i * 1024.0); s_cy[i] = __double2int_rn(m3 * i * 1024.0); }
+        __syncthreads();
+    }
     for (int i = threadIdx.x; i < OW * OH; i += 256) {
         const int y = i / OW, x = i - y * OW;
-        const int X0 = __double2int_rn((m1 * y + m2) * 1024.0) + 16, Y0 = __double2int_rn((m4 * y + m5) * 1024.0) + 16;
-        const int X = (X0 + __double2int_rn(m0 * x * 1024.0)) >> 5, Y = (Y0 + __double2int_rn(m3 * x * 1024.0)) >> 5;
+        int X, Y;
+        if (tabled) { X = (s_rx[y] + s_cx[x]) >> 5; Y = (s_ry[y] + s_cy[x]) >> 5; }
+        else {
+            const int X0 = __double2int_rn((m1 * y + m2) * 1024.0) + 16, Y0 = __double2int_rn((m4 * y + m5) * 1024.0) + 16;
+            X = (X0 + __double2int_rn(m0 * x * 1024.0)) >> 5; Y = (Y0 + __double2int_rn(m3 * x * 1024.0)) >> 5;
+        }
         const int sx = X >> 5, sy = Y >> 5, fx = X & 31, fy = Y & 31;
+        if (sx < -1 || sx >= sw || sy < -1 || sy >= sh) { out[i] = 0; continue; }      // all four taps outside the bounding box
         int v[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const int xx = sx + (k & 1), yy = sy + (k >> 1);
             int p = 0;
             if (xx >= 0 && xx < sw && yy >= 0 && yy < sh) {
-                const int ax = xx + B.x0;
-                bool in = false;
-                for (int r = s_row[yy]; r < s_row[yy + 1]; ++r) { const uint32_t q = s_runs[r]; if (ax >= (int)(q & 0xffffu) && ax <= (int)(q >> 16)) { in = true; break; } }
-                if (in) {
-                    p = img[(size_t)(yy + y0) * c.W + ax];
-                    if (c.invert) p = 255 - p;
-                    if (diff_mode) { const int b = bg[(size_t)(yy + y0) * c.W + ax]; p = diff_mode == 1 ? abs(b - p) : max(b - p, 0); }
+                if (staged) p = s_img[yy * sw + xx];
+                else {
+                    const int ax = xx + B.x0;
+                    bool in = false;
+                    for (int r = s_row[yy]; r < s_row[yy + 1]; ++r) { const uint32_t q = s_runs[r]; if (ax >= (int)(q & 0xffffu) && ax <= (int)(q >> 16)) { in = true; break; } }
+                    if (in) {
+                        p = img[(size_t)(yy + y0) * c.W + ax];
+                        if (c.invert) p = 255 - p;
+                        if (diff_mode) { const int bgv = bg[(size_t)(yy + y0) * c.W + ax]; p = diff_mode == 1 ? abs(bgv - p) : max(bgv - p, 0); }
+                    }
                 }
             }
             v[k] = p;
