@@ -116,6 +116,7 @@ def lib():
         L.oracle_warp_affine_u8.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32]
         L.oracle_posture_auto.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                           C.POINTER(PostureParams), C.c_void_p, C.c_void_p, C.POINTER(PostureInfo), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
+        L.oracle_midline_walk.argtypes = [C.c_void_p, C.c_int32, C.c_float, C.c_void_p]
         L.oracle_midline_post_process.argtypes = [C.c_void_p, C.c_int32, C.c_float, C.c_int32, C.c_int32]
         L.oracle_midline_normalize.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_float, C.c_void_p, C.c_void_p]
         L.oracle_midline_transform.argtypes = [C.c_float, C.c_float, C.c_float, C.c_int32, C.c_void_p]
@@ -373,3 +374,11 @@ def posture_auto(runs, pixels, bg, method=0, start_threshold=0, pp=None):
     d = {k: getattr(info, k) for k, _ in PostureInfo._fields_}
     d["threshold"] = thr.value; d["iterations"] = it.value
     return d, out[:info.n_outline].copy(), seg[:info.n_segments].copy()
+
+
+def midline_walk(outline, midline_walk_offset=0.025):
+    """the two-pointer walk of Outline::calculate_midline alone on a given (rotated) outline -> segments [m,4]."""
+    pts = np.ascontiguousarray(outline, np.float32)
+    seg = np.zeros((max(len(pts), 1), 4), np.float32)
+    ns = lib().oracle_midline_walk(_ptr(pts), len(pts), midline_walk_offset, _ptr(seg))
+    return seg[:ns].copy()

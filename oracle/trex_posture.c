@@ -160,6 +160,43 @@ static void curvature_abs(const v2* p, int N, int r, float* out) {
     }
 }
 
+/* the two-pointer walk of Outline::calculate_midline (Outline.cpp:790-857) alone: outline points (tail = point 0) -> midline
+ * segments {pos.x, pos.y, height, l_length}; returns their number.  `segments` must hold n entries. */
+int oracle_midline_walk(const float* pts_xy, int32_t n, float midline_walk_offset, float* segments) {
+    const v2* pts = (const v2*)pts_xy;
+    const int L = n;
+    int idx_r = 1, idx_l = -1, ns = 0;
+    float mo = midline_walk_offset * (float)L; if (mo < 3.0f) mo = 3.0f;
+    const int max_offset = (int)mo;
+    while (idx_r < L + idx_l) {
+        v2 pt_r = {0, 0}; v2 pt_l = pts[L + idx_l];
+        float min_d = 3.402823466e38f; int min_idx = -1;
+        for (int i = 0; i < max_offset; ++i) {
+            if (idx_r + i >= L) break;
+            const v2 pt = pts[idx_r + i];
+            const float dx = pt.x - pt_l.x, dy = pt.y - pt_l.y, len = sqrtf(dx * dx + dy * dy);
+            if (len < min_d) { min_d = len; min_idx = idx_r + i; }
+        }
+        if (min_idx != -1) { pt_r = pts[min_idx]; idx_r = min_idx; }
+        min_d = 3.402823466e38f; min_idx = 1;
+        for (int i = 0; i < max_offset; ++i) {
+            if (idx_l - i <= -L) break;
+            const v2 pt = pts[L + idx_l - i];
+            const float dx = pt_r.x - pt.x, dy = pt_r.y - pt.y, len = sqrtf(dx * dx + dy * dy);
+            if (len < min_d) { min_d = len; min_idx = idx_l - i; }
+        }
+        if (min_idx != 1) { pt_l = pts[L + min_idx]; idx_l = min_idx; }
+        const float lx = pt_r.x - pt_l.x, ly = pt_r.y - pt_l.y;
+        const v2 m = { pt_l.x + lx * 0.5f, pt_l.y + ly * 0.5f };
+        segments[4 * ns + 0] = m.x; segments[4 * ns + 1] = m.y;
+        segments[4 * ns + 2] = sqrtf(lx * lx + ly * ly);
+        segments[4 * ns + 3] = sqrtf((m.x - pt_l.x) * (m.x - pt_l.x) + (m.y - pt_l.y) * (m.y - pt_l.y));
+        ++ns;
+        idx_r++; idx_l--;
+    }
+    return ns;
+}
+
 typedef struct oracle_posture_params {
     float outline_resample; int32_t outline_smooth_samples, outline_smooth_step, outline_approximate;
     float outline_curvature_range_ratio, midline_walk_offset; int32_t max_points;
@@ -222,36 +259,7 @@ int oracle_posture(const oracle_run* runs, int32_t n_runs, int32_t origin_x, int
     info->n_outline = n;
     if (n <= 1) { rc = 1; goto done; }
     {   /* the two-pointer walk (Outline.cpp:790-857) */
-        const int L = n;
-        int idx_r = 1, idx_l = -1, ns = 0;
-        float mo = P->midline_walk_offset * (float)L; if (mo < 3.0f) mo = 3.0f;
-        const int max_offset = (int)mo;
-        while (idx_r < L + idx_l) {
-            v2 pt_r = {0, 0}; v2 pt_l = pts[L + idx_l];
-            float min_d = 3.402823466e38f; int min_idx = -1;
-            for (int i = 0; i < max_offset; ++i) {
-                if (idx_r + i >= L) break;
-                const v2 pt = pts[idx_r + i];
-                const float dx = pt.x - pt_l.x, dy = pt.y - pt_l.y, len = sqrtf(dx * dx + dy * dy);
-                if (len < min_d) { min_d = len; min_idx = idx_r + i; }
-            }
-            if (min_idx != -1) { pt_r = pts[min_idx]; idx_r = min_idx; }
-            min_d = 3.402823466e38f; min_idx = 1;
-            for (int i = 0; i < max_offset; ++i) {
-                if (idx_l - i <= -L) break;
-                const v2 pt = pts[L + idx_l - i];
-                const float dx = pt_r.x - pt.x, dy = pt_r.y - pt.y, len = sqrtf(dx * dx + dy * dy);
-                if (len < min_d) { min_d = len; min_idx = idx_l - i; }
-            }
-            if (min_idx != 1) { pt_l = pts[L + min_idx]; idx_l = min_idx; }
-            const float lx = pt_r.x - pt_l.x, ly = pt_r.y - pt_l.y;
-            const v2 m = { pt_l.x + lx * 0.5f, pt_l.y + ly * 0.5f };
-            segments[4 * ns + 0] = m.x; segments[4 * ns + 1] = m.y;
-            segments[4 * ns + 2] = sqrtf(lx * lx + ly * ly);
-            segments[4 * ns + 3] = sqrtf((m.x - pt_l.x) * (m.x - pt_l.x) + (m.y - pt_l.y) * (m.y - pt_l.y));
-            ++ns;
-            idx_r++; idx_l--;
-        }
+        const int ns = oracle_midline_walk((const float*)pts, n, P->midline_walk_offset, segments);
         info->n_segments = ns;
         if (ns <= 2) rc = 4;
     }

@@ -33,13 +33,18 @@ def run_posture(frames, bg, table=0, thr=None, **kw):
 
 
 def compare(res, outline, segs, info, pp, min_ok=0.97):
-    n_cmp = n_same = 0
+    n_cmp = n_same = n_close = 0
     for r in res:
         for k, b in enumerate(r.blobs):
             bi = int(r.info["blob_begin"]) + k
             rs = r.runs[b["run_begin"]:b["run_begin"] + b["n_runs"]]
             oi, oo, osg = oracle.posture(rs, (int(b["x0"]), int(b["y0"])), pp)
             gi = info[bi]
+            if b["n_runs"] > 512 or int(b["y1"]) - int(b["y0"]) + 1 > 254:      # beyond the device's per-blob LDS capacity
+                assert gi["status"] == 2
+                continue
+            if {int(gi["status"]), int(oi["status"])} == {3, 4} and oi["n_outline"] < 8:
+                continue                                                          # degenerate 3..7-point outline: no midline either way
             assert gi["status"] == oi["status"], (bi, gi, oi)
             assert gi["n_traced"] == oi["n_traced"]
             if oi["status"] not in (0, 4):
@@ -48,14 +53,21 @@ def compare(res, outline, segs, info, pp, min_ok=0.97):
             n_cmp += 1
             # same multiset of outline points up to the rotation (tail choice)
             go = outline[bi, :gi["n_outline"]]
+            # the midline walk is exact arithmetic on the outline it is given: the device's segments must equal the CPU walk of
+            # the device's own outline bit for bit (first-minimum rule of the candidate search included)
+            gs = segs[bi, :gi["n_segments"]]
+            ws = oracle.midline_walk(go, pp.midline_walk_offset)
+            assert len(ws) == gi["n_segments"] and np.array_equal(gs[:len(ws)], ws[:segs.shape[1]]), bi
             if gi["n_segments"] == oi["n_segments"] and np.abs(go - oo).max() <= 1e-3 and gi["head_index"] == oi["head_index"]:
                 n_same += 1
-                gs = segs[bi, :gi["n_segments"]]
-                assert np.abs(gs - osg).max() <= 2e-3
+                # against the oracle's own outline (EFT differs by float rounding) the pairing can flip at a near-tie of two
+                # candidate distances; that is rare
+                n_close += np.abs(gs - osg).max() <= 2e-3
             else:   # near-tie of a curvature peak (float rounding of cos/sin): the outline must still be the same closed curve
                 d = np.abs(go[:, None, :] - oo[None, :, :]).max(2).min(1)
                 assert d.max() <= 1e-3
     assert n_cmp > 0 and n_same / n_cmp >= min_ok, (n_same, n_cmp)
+    assert n_same - n_close <= max(1, 0.05 * n_same), (n_close, n_same)
     return n_cmp
 
 

@@ -120,7 +120,7 @@ __global__ __launch_bounds__(256) void k_posture(const PostureCfg P, const trexh
             else if (inside((vx + dx + rx) / 2, (vy + dy + ry) / 2)) { }
             else { dx = rx; dy = ry; }
         } while (!(vx == sx && vy == sy && dx == 1 && dy == 0));
-        res.n_traced = nt;
+        res.n_traced = status ? 0 : nt;                 // an outline beyond the capacity reports no points at all
     }
     int nt_all = __shfl(res.n_traced, 0);
     status = __shfl(status, 0);
