@@ -124,3 +124,22 @@ def test_unaligned_crop_buffer_and_both_conv1_kernels_agree():
     assert np.abs(pa.cpu().numpy() - op).max() <= 1e-4 and np.abs(pb.cpu().numpy() - op).max() <= 1e-4
     assert np.abs(pa.cpu().numpy() - pb.cpu().numpy()).max() <= 1e-5
     seg.close()
+
+
+@pytest.mark.parametrize("n", [1, 2, 127, 129, 255, 257, 300, 515])
+def test_batch_sizes_around_the_tile_and_grid_boundaries(n):
+    # fc1 works on 128-crop tiles, conv3 on a persistent grid of one workgroup per CU (256), conv2 on 5 workgroups per crop:
+    # crop counts around those boundaries must give the same rows as the oracle and as a run of the same crops in another order
+    z, st = load_fixture(100)
+    seg = make_net(st, 100)
+    rng = np.random.default_rng(n)
+    crops = weights.synthetic_crops(n, n) if hasattr(weights, "synthetic_crops") else rng.integers(0, 256, (n, 80, 80, 1)).astype(np.uint8)
+    p = seg.probabilities(crops)
+    op, _ = cnn_oracle.predict(st, crops, threads=8)
+    assert p.shape == (n, 100)
+    assert np.abs(p - op).max() <= 1e-4
+    if n > 2:
+        perm = rng.permutation(n)
+        p2 = seg.probabilities(crops[perm])
+        assert np.abs(p2 - p[perm]).max() <= 1e-6
+    seg.close()
