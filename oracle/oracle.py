@@ -120,6 +120,13 @@ def lib():
         L.oracle_midline_post_process.argtypes = [C.c_void_p, C.c_int32, C.c_float, C.c_int32, C.c_int32]
         L.oracle_midline_normalize.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_float, C.c_void_p, C.c_void_p]
         L.oracle_midline_transform.argtypes = [C.c_float, C.c_float, C.c_float, C.c_int32, C.c_void_p]
+        L.oracle_vec_to_r3g3b2.restype = C.c_uint8
+        L.oracle_vec_to_r3g3b2.argtypes = [C.c_uint8] * 3
+        L.oracle_r3g3b2_to_vec.argtypes = [C.c_uint8, C.c_void_p]
+        L.oracle_bgr2gray.restype = C.c_uint8
+        L.oracle_bgr2gray.argtypes = [C.c_uint8] * 3
+        L.oracle_line_without_grid_enc.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
+                                                   C.c_int32, C.c_void_p, C.c_void_p, C.POINTER(C.c_int32)]
         L.oracle_bid.restype = C.c_uint32
         L.oracle_bid.argtypes = [C.c_uint32] * 4
         del u8p
@@ -382,3 +389,36 @@ def midline_walk(outline, midline_walk_offset=0.025):
     seg = np.zeros((max(len(pts), 1), 4), np.float32)
     ns = lib().oracle_midline_walk(_ptr(pts), len(pts), midline_walk_offset, _ptr(seg))
     return seg[:ns].copy()
+
+
+ENC_GRAY, ENC_R3G3B2, ENC_RGB8 = 0, 1, 2       # order of cmn::meta_encoding_t
+
+
+def vec_to_r3g3b2(c0, c1, c2):
+    return int(lib().oracle_vec_to_r3g3b2(int(c0), int(c1), int(c2)))
+
+
+def r3g3b2_to_vec(code):
+    out = np.zeros(3, np.uint8)
+    lib().oracle_r3g3b2_to_vec(int(code), _ptr(out))
+    return out
+
+
+def convert_to_r3g3b2(img):
+    """convert_to_r3g3b2<3|4>: H x W x {3,4} (BGR[A] memory order) -> H x W codes."""
+    img = np.asarray(img, np.uint8)
+    return (((img[..., 0] >> 6) << 6) | ((img[..., 1] >> 5) << 3) | (img[..., 2] >> 5)).astype(np.uint8)
+
+
+def line_without_grid_enc(runs, pixels, pixel_enc, bg, bg_enc, method, threshold):
+    """line_without_grid for gray / r3g3b2 / rgb8 pixel arrays against a gray or rgb8 background image (H x W [x 3])."""
+    runs = np.ascontiguousarray(runs, RUN_DTYPE)
+    pixels = np.ascontiguousarray(pixels, np.uint8)
+    pc = 3 if pixel_enc == ENC_RGB8 else 1
+    out_runs = np.zeros(max(len(pixels), 1), RUN_DTYPE)
+    out_px = np.zeros(max(len(pixels), 1), np.uint8)
+    n_px = C.c_int32()
+    bg = np.ascontiguousarray(bg, np.uint8)
+    n = lib().oracle_line_without_grid_enc(_ptr(runs), len(runs), _ptr(pixels), pixel_enc, _ptr(bg), bg.shape[1], bg_enc, method, threshold,
+                                           _ptr(out_runs), _ptr(out_px), C.byref(n_px))
+    return out_runs[:n].copy(), out_px[:n_px.value * pc].copy()

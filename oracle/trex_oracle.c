@@ -487,3 +487,49 @@ void oracle_warp_affine_u8(const uint8_t* src, int32_t sw, int32_t sh, const flo
         }
     }
 }
+
+/* ---- colour encodings (meta_encoding rgb8 / r3g3b2) ---------------------------------------------------------------------------
+ * vec_to_r3g3b2 / r3g3b2_to_vec / convert_to_r3g3b2 live in the un-vendored commons; their bit layout is PINNED by the literal
+ * vectors of Application/Tests/test_pixels.cpp:629-795: code = (c0 >> 6) << 6 | (c1 >> 5) << 3 | (c2 >> 5) with c0 the FIRST
+ * channel in memory (B of a BGR image), decode = {(code >> 6) << 6, ((code >> 3) & 7) << 5, (code & 7) << 5}.
+ * The value a colour pixel is thresholded on is its grey value (cmn::bgr2gray, commons): pinned to agree with
+ * cv::cvtColor(BGR2GRAY) on the vectors of test_pixels.cpp:1073-1166,1289-1380,1381-1529; restated as OpenCV's 8-bit fixed point. */
+uint8_t oracle_vec_to_r3g3b2(uint8_t c0, uint8_t c1, uint8_t c2) { return (uint8_t)(((c0 >> 6) << 6) | ((c1 >> 5) << 3) | (c2 >> 5)); }
+void oracle_r3g3b2_to_vec(uint8_t code, uint8_t* out3) {
+    out3[0] = (uint8_t)((code >> 6) << 6); out3[1] = (uint8_t)(((code >> 3) & 7) << 5); out3[2] = (uint8_t)((code & 7) << 5);
+}
+uint8_t oracle_bgr2gray(uint8_t b, uint8_t g, uint8_t r) { return (uint8_t)((b * 1868u + g * 9617u + r * 4899u + 8192u) >> 14); }
+
+/* encoding: 0 gray (1 B/px), 1 r3g3b2 (1 B/px), 2 rgb8 (3 B/px) -- the order of cmn::meta_encoding_t */
+static int enc_channels(int enc) { return enc == 2 ? 3 : 1; }
+static int diffable(const uint8_t* p, int enc) {
+    if (enc == 2) return oracle_bgr2gray(p[0], p[1], p[2]);
+    if (enc == 1) { uint8_t v[3]; oracle_r3g3b2_to_vec(p[0], v); return oracle_bgr2gray(v[0], v[1], v[2]); }
+    return p[0];
+}
+
+/* line_without_grid<InputInfo, OutputInfo{gray}, DifferenceMethod> for the three input encodings (test_pixels.cpp:915-1071):
+ * pixels hold enc_channels(pixel_enc) bytes per pixel, the background enc_channels(bg_enc) per pixel (gray or rgb8); a pixel is
+ * kept iff diff(grey(bg), grey(px)) >= threshold and keeps all of its bytes. */
+int32_t oracle_line_without_grid_enc(const oracle_run* runs, int32_t n_runs, const uint8_t* pixels, int32_t pixel_enc,
+                                     const uint8_t* bg, int32_t bg_stride_px, int32_t bg_enc, int32_t method, int32_t threshold,
+                                     oracle_run* out_runs, uint8_t* out_pixels, int32_t* n_out_pixels) {
+    const int pc = enc_channels(pixel_enc), bc = enc_channels(bg_enc);
+    int32_t no = 0, np = 0;
+    const uint8_t* px = pixels;
+    for (int32_t i = 0; i < n_runs; ++i) {
+        int open = 0; oracle_run cur = {0, 0, 0, 0};
+        for (int x = runs[i].x0; x <= runs[i].x1; ++x, px += pc) {
+            const int b = bg ? diffable(bg + ((size_t)runs[i].y * bg_stride_px + x) * bc, bg_enc) : 0;
+            if (diff_method(diffable(px, pixel_enc), b, method) >= threshold) {
+                if (!open) { open = 1; cur.x0 = (uint16_t)x; cur.y = runs[i].y; cur.pad = 0; }
+                cur.x1 = (uint16_t)x;
+                for (int c = 0; c < pc; ++c) out_pixels[np * pc + c] = px[c];
+                ++np;
+            } else if (open) { out_runs[no++] = cur; open = 0; }
+        }
+        if (open) out_runs[no++] = cur;
+    }
+    *n_out_pixels = np;
+    return no;
+}

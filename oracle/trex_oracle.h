@@ -100,6 +100,13 @@ void oracle_normalize_transform(const float* tr6, float midline_length, int32_t 
 void oracle_moments_transform(const oracle_blob* B, float* tr6);
 void oracle_warp_affine_u8(const uint8_t* src, int32_t sw, int32_t sh, const float* M6, uint8_t* dst, int32_t dw, int32_t dh);
 uint32_t oracle_bid(uint32_t x0, uint32_t x1, uint32_t y, uint32_t n_runs);
+/* colour encodings: layout pinned by test_pixels.cpp:629-795; encoding 0 gray, 1 r3g3b2, 2 rgb8 */
+uint8_t oracle_vec_to_r3g3b2(uint8_t c0, uint8_t c1, uint8_t c2);
+void oracle_r3g3b2_to_vec(uint8_t code, uint8_t* out3);
+uint8_t oracle_bgr2gray(uint8_t b, uint8_t g, uint8_t r);
+int32_t oracle_line_without_grid_enc(const oracle_run* runs, int32_t n_runs, const uint8_t* pixels, int32_t pixel_enc,
+                                     const uint8_t* bg, int32_t bg_stride_px, int32_t bg_enc, int32_t method, int32_t threshold,
+                                     oracle_run* out_runs, uint8_t* out_pixels, int32_t* n_out_pixels);
 
 #ifdef __cplusplus
 }
