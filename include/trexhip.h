@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define TREXHIP_ABI_VERSION 1
+#define TREXHIP_ABI_VERSION 2
 
 enum {
     TREXHIP_OK = 0,
@@ -62,7 +62,14 @@ typedef struct trexhip_params {
     int32_t n_ranges;            /* detect_size_filter, 0 = accept all                               */
     double  cm_per_pixel;
     double  ranges[16];          /* [start,end) pairs in cm^2                                        */
+    /* meta_encoding of the produced pixel arrays (Background::meta_encoding(), BackgroundSubtraction.cpp:132,151-186):
+     * TREXHIP_ENC_GRAY 1 B/px grey value; TREXHIP_ENC_R3G3B2 1 B/px colour code (convert_to_r3g3b2, layout pinned by
+     * Tests/test_pixels.cpp:629-795); TREXHIP_ENC_RGB8 3 B/px in the input's memory order (BGRA2BGR).  The colour encodings
+     * need colour input (trexhip_segment_color*); detection itself always works on cv::cvtColor(BGR2GRAY) (or color_channel). */
+    int32_t pixel_encoding;
+    int32_t reserved_[3];
 } trexhip_params;
+enum { TREXHIP_ENC_GRAY = 0, TREXHIP_ENC_R3G3B2 = 1, TREXHIP_ENC_RGB8 = 2 };   /* order of cmn::meta_encoding_t */
 
 /* size class of a re-thresholded blob against track_size_filter (tracking/Tracker.cpp:864-912) */
 #define TREXHIP_BLOB_IN_RANGE    0u   /* fish_size.in_range_of_one -> commit                     */
@@ -103,7 +110,9 @@ typedef struct trexhip_batch_result {
     const trexhip_frame_info* frames;   /* [n_frames]                                        */
     const trexhip_blob* blobs;          /* [total_blobs]; run_begin/pix_begin are FRAME-relative */
     const trexhip_run* runs;            /* [total_runs]                                      */
-    const uint8_t* pixels;              /* [total_pixels]                                    */
+    const uint8_t* pixels;              /* [total_pixels * pixel_channels]                   */
+    uint32_t pixel_channels;            /* bytes per pixel: 1 (gray, r3g3b2) or 3 (rgb8); pix_begin / n_pixels count PIXELS */
+    uint32_t reserved_;
 } trexhip_batch_result;
 
 /* Device view of the same tables (for downstream device stages and torch interop). */
@@ -147,6 +156,8 @@ int trexhip_segment(trexhip_ctx* ctx, const uint8_t* const* frames, int32_t stri
  * channels 3 or 4; color_channel < 0 (or >= channels) = cv::cvtColor(BGR2GRAY / BGRA2GRAY), else that channel */
 int trexhip_segment_color(trexhip_ctx* ctx, const uint8_t* const* frames, int32_t stride, int32_t n,
                           int32_t channels, int32_t color_channel);
+/* the same for n contiguous colour frames already in HBM ([n][height][width][channels]) */
+int trexhip_segment_color_device(trexhip_ctx* ctx, const uint8_t* d_color_frames, int32_t n, int32_t channels, int32_t color_channel);
 /* device buffers for callers that do not link the HIP runtime themselves (the C++ adapters in trex_amd/host): plain
  * hipMalloc / hipFree / stream-ordered device-to-host copy (synchronous on return) on the context's device and stream */
 int trexhip_device_alloc(trexhip_ctx* ctx, size_t bytes, void** out_device_ptr);

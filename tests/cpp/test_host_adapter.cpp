@@ -150,7 +150,7 @@ int main(int argc, char** argv) {
         try { f.get(); } catch (const std::exception&) { threw = true; }
         CHECK(threw);
     }
-    // --- unsupported encodings (rgb8 / r3g3b2) raise through the future like the reference's "Invalid image mode" (:188) ---
+    // --- meta_encoding changed without re-initialising raises through the future like the reference's "Invalid image mode" (:188) ---
     {
         auto& st = HipBackgroundSubtraction::settings();
         const auto keep = st.meta_encoding;
@@ -161,6 +161,29 @@ int main(int argc, char** argv) {
         try { f.get(); } catch (const std::exception&) { threw = true; }
         CHECK(threw);
         st.meta_encoding = keep;
+    }
+    // --- rgb8: the same lines, 3 bytes per pixel in memory order, frame encoding rgb8 (pv.cpp:512-517) ---
+    {
+        HipBackgroundSubtraction::Settings s2 = HipBackgroundSubtraction::settings();
+        s2.meta_encoding = cmn::meta_encoding_t::rgb8;
+        HipBackgroundSubtraction::init(s2, W, H);
+        std::vector<uint8_t> bg2(W * H, 120);
+        auto b = cmn::Image::Make(H, W, 1); std::memcpy(b->data(), bg2.data(), bg2.size()); HipBackgroundSubtraction::set_background(b);
+        std::vector<uint8_t> dummy(W * H, 120);
+        TileImage tile; tile.images.push_back(gray_to_bgr(dummy, W, H, 4, rng, true));
+        uint8_t* im = tile.images[0]->data();
+        for (int x = 10; x < 20; ++x) { uint8_t* q = im + (size_t)(5 * W + x) * 4; q[0] = (uint8_t)x; q[1] = (uint8_t)(2 * x); q[2] = (uint8_t)(3 * x); }
+        auto f = HipBackgroundSubtraction::apply(std::move(tile));
+        SegmentationData d = f.get();
+        CHECK(d.frame.encoding() == cmn::meta_encoding_t::rgb8);
+        CHECK(d.frame.n() == 1);
+        CHECK((*d.frame.mask()[0])[0] == cmn::HorizontalLine(5, 10, 19));
+        const auto& px = *d.frame.pixels()[0];
+        CHECK(px.size() == 30);
+        for (int x = 10; x < 20; ++x) CHECK(px[3 * (x - 10)] == x && px[3 * (x - 10) + 1] == 2 * x && px[3 * (x - 10) + 2] == 3 * x);
+        s2.meta_encoding = cmn::meta_encoding_t::gray;
+        HipBackgroundSubtraction::init(s2, W, H);
+        HipBackgroundSubtraction::set_background(b);
     }
     // --- TileImage destroyed with a live promise raises inside the future (core/TileImage.cpp:13-21) ---
     {

@@ -25,7 +25,9 @@ def test_library_exports_every_declared_symbol():
     for s in declared:
         assert hasattr(lib, s), f"libtrexhip.so does not export {s}"
     assert sorted(capi.SYMBOLS) == declared, "capi.SYMBOLS out of date with include/trexhip.h"
-    assert lib.trexhip_abi_version() == 1
+    import re
+    header = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "include", "trexhip.h")).read()
+    assert lib.trexhip_abi_version() == int(re.search(r"#define TREXHIP_ABI_VERSION (\d+)", header).group(1))
 
 
 def test_struct_layouts_match_header(tmp_path):

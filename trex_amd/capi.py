@@ -40,6 +40,7 @@ class Params(C.Structure):
         ("connectivity", C.c_int32), ("dilation_size", C.c_int32), ("use_closing", C.c_int32),
         ("closing_size", C.c_int32), ("n_ranges", C.c_int32),
         ("cm_per_pixel", C.c_double), ("ranges", C.c_double * 16),
+        ("pixel_encoding", C.c_int32), ("reserved_", C.c_int32 * 3),
     ]
 
 
@@ -64,7 +65,11 @@ class BatchResult(C.Structure):
     _fields_ = [
         ("n_frames", C.c_int32), ("total_blobs", C.c_uint32), ("total_runs", C.c_uint32), ("total_pixels", C.c_uint32),
         ("frames", C.c_void_p), ("blobs", C.c_void_p), ("runs", C.c_void_p), ("pixels", C.c_void_p),
+        ("pixel_channels", C.c_uint32), ("reserved_", C.c_uint32),
     ]
+
+
+ENC_GRAY, ENC_R3G3B2, ENC_RGB8 = 0, 1, 2        # pixel_encoding, order of cmn::meta_encoding_t
 
 
 class DeviceView(C.Structure):
@@ -82,7 +87,7 @@ class TrexHipError(RuntimeError):
 SYMBOLS = [
     "trexhip_abi_version", "trexhip_last_error", "trexhip_default_params", "trexhip_create", "trexhip_destroy",
     "trexhip_set_stream", "trexhip_set_background", "trexhip_set_background_device", "trexhip_generate_average_device", "trexhip_get_background", "trexhip_segment_device",
-    "trexhip_segment", "trexhip_segment_color", "trexhip_rethreshold_device", "trexhip_rethreshold_per_blob_device", "trexhip_fetch_rethreshold", "trexhip_fetch", "trexhip_device_view_get", "trexhip_synchronize",
+    "trexhip_segment", "trexhip_segment_color", "trexhip_segment_color_device", "trexhip_rethreshold_device", "trexhip_rethreshold_per_blob_device", "trexhip_fetch_rethreshold", "trexhip_fetch", "trexhip_device_view_get", "trexhip_synchronize",
     "trexhip_profile_enable", "trexhip_profile_read", "trexhip_profile_reset",
     "trexhip_default_posture_params", "trexhip_posture_device", "trexhip_crops_device", "trexhip_device_alloc", "trexhip_device_free", "trexhip_copy_to_host", "trexhip_crops_transformed_device", "trexhip_crops_posture_device", "trexhip_default_midline_params", "trexhip_midline_device", "trexhip_export_id_table_device", "trexhip_load_weights", "trexhip_set_identity_precision", "trexhip_num_classes", "trexhip_identify_device", "trexhip_identify",
 ]
@@ -108,6 +113,7 @@ def lib():
         L.trexhip_segment_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int32]
         L.trexhip_segment.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.c_int32, C.c_int32]
         L.trexhip_segment_color.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.c_int32, C.c_int32, C.c_int32, C.c_int32]
+        L.trexhip_segment_color_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32]
         L.trexhip_rethreshold_device.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int32]
         L.trexhip_rethreshold_per_blob_device.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32]
         L.trexhip_fetch_rethreshold.argtypes = [C.c_void_p, C.POINTER(BatchResult)]
@@ -233,6 +239,10 @@ class Segmenter:
         ptrs = (C.c_void_p * len(frames))(*[f.ctypes.data for f in frames])
         _check(lib().trexhip_segment_color(self._h, ptrs, frames[0].shape[1] * ch, len(frames), ch, color_channel))
 
+    def segment_color_device(self, d_color_ptr, n, channels, color_channel=-1):
+        """n contiguous colour frames [n,H,W,channels] already in HBM."""
+        _check(lib().trexhip_segment_color_device(self._h, C.c_void_p(d_color_ptr), n, channels, color_channel))
+
     def synchronize(self):
         _check(lib().trexhip_synchronize(self._h))
 
@@ -244,7 +254,8 @@ class Segmenter:
         info = _from_addr(r.frames, r.n_frames, INFO_DTYPE)
         blobs = _from_addr(r.blobs, r.total_blobs, BLOB_DTYPE)
         runs = _from_addr(r.runs, r.total_runs, RUN_DTYPE)
-        pixels = _from_addr(r.pixels, r.total_pixels, np.dtype(np.uint8))
+        pc = int(r.pixel_channels) or 1                       # bytes per pixel: 3 for the rgb8 pixel encoding
+        pixels = _from_addr(r.pixels, r.total_pixels * pc, np.dtype(np.uint8))
         out = []
         for i in range(r.n_frames):
             fi = info[i]
@@ -253,7 +264,7 @@ class Segmenter:
                 continue
             b = blobs[fi["blob_begin"]:fi["blob_begin"] + fi["n_blobs"]]
             ru = runs[fi["run_begin"]:fi["run_begin"] + fi["n_runs"]]
-            px = pixels[fi["pix_begin"]:fi["pix_begin"] + fi["n_pixels"]]
+            px = pixels[int(fi["pix_begin"]) * pc:(int(fi["pix_begin"]) + int(fi["n_pixels"])) * pc]
             if copy:
                 b, ru, px = b.copy(), ru.copy(), px.copy()
             out.append(FrameResult(fi.copy(), b, ru, px))

@@ -118,6 +118,7 @@ void trexhip_default_params(trexhip_params* p, int32_t width, int32_t height) {
     p->connectivity = 8;
     p->dilation_size = 0; p->use_closing = 0; p->closing_size = 3;
     p->n_ranges = 0; p->cm_per_pixel = 1.0;
+    p->pixel_encoding = TREXHIP_ENC_GRAY;
 }
 
 int trexhip_create(const trexhip_params* p, trexhip_ctx** out) {
@@ -135,6 +136,10 @@ int trexhip_create(const trexhip_params* p, trexhip_ctx** out) {
         set_error("trexhip_create: structuring elements larger than 15x15 are not supported (closing_size <= 15, |dilation_size| <= 7)");
         return TREXHIP_E_UNSUPPORTED;
     }
+    if (p->pixel_encoding < 0 || p->pixel_encoding > 2) { set_error("trexhip_create: pixel_encoding must be TREXHIP_ENC_GRAY / R3G3B2 / RGB8"); return TREXHIP_E_INVALID; }
+    if (p->pixel_encoding != TREXHIP_ENC_GRAY && p->image_invert) {
+        set_error("trexhip_create: image_invert with a colour pixel_encoding is not supported"); return TREXHIP_E_UNSUPPORTED;
+    }
     int ndev = 0;
     TH_CHECK_HIP(hipGetDeviceCount(&ndev));
     if (p->device < 0 || p->device >= ndev) { set_error("trexhip_create: no such HIP device"); return TREXHIP_E_DEVICE; }
@@ -142,6 +147,7 @@ int trexhip_create(const trexhip_params* p, trexhip_ctx** out) {
     trexhip_ctx* ctx = new (std::nothrow) trexhip_ctx();
     if (!ctx) { set_error("out of host memory"); return TREXHIP_E_NOMEM; }
     ctx->p = *p;
+    ctx->pix_ch = p->pixel_encoding == TREXHIP_ENC_RGB8 ? 3 : 1;
     fill_cfg(ctx);
     { int cus = 0; if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, p->device) == hipSuccess && cus > 0) ctx->n_cus = cus; }
     if (const char* e = std::getenv("TREXHIP_ROWS_ORDER")) ctx->tune_rows_order = std::atoi(e);
@@ -172,7 +178,7 @@ int trexhip_create(const trexhip_params* p, trexhip_ctx** out) {
     TRY(dmalloc(&ctx->d_blobs, B * NB));
     TRY(dmalloc(&ctx->d_blob_frame, B * NB));
     TRY(dmalloc(&ctx->d_runs, B * R));
-    TRY(dmalloc(&ctx->d_pixels, B * P));
+    TRY(dmalloc(&ctx->d_pixels, B * P * ctx->pix_ch));
     if (p->use_closing || p->dilation_size != 0) {
         const size_t WBw = (W + 31) / 32;
         TRY(dmalloc(&ctx->d_bits[0], B * H * WBw + 4));
@@ -182,7 +188,7 @@ int trexhip_create(const trexhip_params* p, trexhip_ctx** out) {
     TRY(hmalloc(&ctx->h_totals, 4));
     TRY(hmalloc(&ctx->h_blobs, B * NB));
     TRY(hmalloc(&ctx->h_runs, B * R));
-    TRY(hmalloc(&ctx->h_pixels, B * P));
+    TRY(hmalloc(&ctx->h_pixels, B * P * ctx->pix_ch));
 #undef TRY
     if (rc != TREXHIP_OK) { trexhip_destroy(ctx); return rc; }
     *out = ctx;
@@ -272,6 +278,8 @@ static int check_segment_args(trexhip_ctx* ctx, const void* frames, int32_t n) {
 int trexhip_segment_device(trexhip_ctx* ctx, const uint8_t* d_frames, int32_t n) {
     int rc = check_segment_args(ctx, d_frames, n);
     if (rc) return rc;
+    if (ctx->pix_ch != 1 || ctx->p.pixel_encoding != TREXHIP_ENC_GRAY) { set_error("trexhip_segment_device: a colour pixel_encoding needs colour input (trexhip_segment_color*)"); return TREXHIP_E_INVALID; }
+    ctx->d_color_src = nullptr; ctx->color_ch = 0;
     TH_CHECK_HIP(hipSetDevice(ctx->p.device));
     if (n == 0) { ctx->last_n = 0; ctx->fetched = false; return TREXHIP_OK; }
     return launch_segment(ctx, d_frames, n);
@@ -280,6 +288,8 @@ int trexhip_segment_device(trexhip_ctx* ctx, const uint8_t* d_frames, int32_t n)
 int trexhip_segment(trexhip_ctx* ctx, const uint8_t* const* frames, int32_t stride, int32_t n) {
     int rc = check_segment_args(ctx, frames, n);
     if (rc) return rc;
+    if (ctx->p.pixel_encoding != TREXHIP_ENC_GRAY) { set_error("trexhip_segment: a colour pixel_encoding needs colour input (trexhip_segment_color*)"); return TREXHIP_E_INVALID; }
+    ctx->d_color_src = nullptr; ctx->color_ch = 0;
     if (stride < ctx->p.width) { set_error("trexhip_segment: stride < width"); return TREXHIP_E_INVALID; }
     TH_CHECK_HIP(hipSetDevice(ctx->p.device));
     if (n == 0) { ctx->last_n = 0; ctx->fetched = false; return TREXHIP_OK; }
@@ -315,6 +325,7 @@ int trexhip_fetch(trexhip_ctx* ctx, trexhip_batch_result* out) {
     const int n = ctx->last_n;
     out->n_frames = n;
     out->frames = ctx->h_info; out->blobs = ctx->h_blobs; out->runs = ctx->h_runs; out->pixels = ctx->h_pixels;
+    out->pixel_channels = (uint32_t)ctx->pix_ch; out->reserved_ = 0;
     if (n == 0) return TREXHIP_OK;
     hipStream_t s = ctx->stream;
     TH_CHECK_HIP(hipMemcpyAsync(ctx->h_info, ctx->d_info, sizeof(trexhip_frame_info) * n, hipMemcpyDeviceToHost, s));
@@ -335,7 +346,7 @@ int trexhip_fetch(trexhip_ctx* ctx, trexhip_batch_result* out) {
     const uint32_t tp = ctx->h_totals[2] < ctx->cfg.pool_pixels ? ctx->h_totals[2] : ctx->cfg.pool_pixels;
     if (tb) TH_CHECK_HIP(hipMemcpyAsync(ctx->h_blobs, ctx->d_blobs, sizeof(trexhip_blob) * tb, hipMemcpyDeviceToHost, s));
     if (tr) TH_CHECK_HIP(hipMemcpyAsync(ctx->h_runs, ctx->d_runs, sizeof(trexhip_run) * tr, hipMemcpyDeviceToHost, s));
-    if (tp) TH_CHECK_HIP(hipMemcpyAsync(ctx->h_pixels, ctx->d_pixels, tp, hipMemcpyDeviceToHost, s));
+    if (tp) TH_CHECK_HIP(hipMemcpyAsync(ctx->h_pixels, ctx->d_pixels, (size_t)tp * ctx->pix_ch, hipMemcpyDeviceToHost, s));
     TH_CHECK_HIP(hipStreamSynchronize(s));
     out->total_blobs = tb; out->total_runs = tr; out->total_pixels = tp;
     ctx->fetched = true;
@@ -362,8 +373,8 @@ static int pass2_alloc(trexhip_ctx* ctx) {
     TRY(dmalloc(&q.d_parent, B * R)); TRY(dmalloc(&q.d_root_ord, B * R)); TRY(dmalloc(&q.d_cnt_runs, B * R));
     TRY(dmalloc(&q.d_cnt_px, B * R)); TRY(dmalloc(&q.d_cur_run, B * R)); TRY(dmalloc(&q.d_pix_begin, B * R));
     TRY(dmalloc(&q.d_blob_map, B * R)); TRY(dmalloc(&q.d_totals, 4)); TRY(dmalloc(&q.d_info, B));
-    TRY(dmalloc(&q.d_blobs, B * NB)); TRY(dmalloc(&q.d_blob_frame, B * NB)); TRY(dmalloc(&q.d_runs, B * R)); TRY(dmalloc(&q.d_pixels, B * P));
-    TRY(hmalloc(&q.h_info, B)); TRY(hmalloc(&q.h_totals, 4)); TRY(hmalloc(&q.h_blobs, B * NB)); TRY(hmalloc(&q.h_runs, B * R)); TRY(hmalloc(&q.h_pixels, B * P));
+    TRY(dmalloc(&q.d_blobs, B * NB)); TRY(dmalloc(&q.d_blob_frame, B * NB)); TRY(dmalloc(&q.d_runs, B * R)); TRY(dmalloc(&q.d_pixels, B * P * ctx->pix_ch));
+    TRY(hmalloc(&q.h_info, B)); TRY(hmalloc(&q.h_totals, 4)); TRY(hmalloc(&q.h_blobs, B * NB)); TRY(hmalloc(&q.h_runs, B * R)); TRY(hmalloc(&q.h_pixels, B * P * ctx->pix_ch));
 #undef TRY
     q.allocated = rc == TREXHIP_OK;
     return rc;
@@ -405,6 +416,7 @@ int trexhip_fetch_rethreshold(trexhip_ctx* ctx, trexhip_batch_result* out) {
     const int n = q.valid_n;
     out->n_frames = n;
     out->frames = q.h_info; out->blobs = q.h_blobs; out->runs = q.h_runs; out->pixels = q.h_pixels;
+    out->pixel_channels = (uint32_t)ctx->pix_ch; out->reserved_ = 0;
     hipStream_t s = ctx->stream;
     TH_CHECK_HIP(hipMemcpyAsync(q.h_info, q.d_info, sizeof(trexhip_frame_info) * n, hipMemcpyDeviceToHost, s));
     TH_CHECK_HIP(hipMemcpyAsync(q.h_totals, q.d_totals, sizeof(uint32_t) * 4, hipMemcpyDeviceToHost, s));
@@ -414,7 +426,7 @@ int trexhip_fetch_rethreshold(trexhip_ctx* ctx, trexhip_batch_result* out) {
     const uint32_t tp = q.h_totals[2] < ctx->cfg.pool_pixels ? q.h_totals[2] : ctx->cfg.pool_pixels;
     if (tb) TH_CHECK_HIP(hipMemcpyAsync(q.h_blobs, q.d_blobs, sizeof(trexhip_blob) * tb, hipMemcpyDeviceToHost, s));
     if (tr) TH_CHECK_HIP(hipMemcpyAsync(q.h_runs, q.d_runs, sizeof(trexhip_run) * tr, hipMemcpyDeviceToHost, s));
-    if (tp) TH_CHECK_HIP(hipMemcpyAsync(q.h_pixels, q.d_pixels, tp, hipMemcpyDeviceToHost, s));
+    if (tp) TH_CHECK_HIP(hipMemcpyAsync(q.h_pixels, q.d_pixels, (size_t)tp * ctx->pix_ch, hipMemcpyDeviceToHost, s));
     TH_CHECK_HIP(hipStreamSynchronize(s));
     out->total_blobs = tb; out->total_runs = tr; out->total_pixels = tp;
     for (int i = 0; i < n; ++i)

@@ -19,10 +19,11 @@ __global__ __launch_bounds__(256) void k_crops_none(const SegCfg c, const uint8_
                                                     const uint32_t* __restrict__ blob_frame,
                                                     const trexhip_blob* __restrict__ blobs,
                                                     const trexhip_run* __restrict__ runs, uint8_t* __restrict__ crops,
-                                                    int OW, int OH, int diff_mode /*0 raw, 1 |bg-p|, 2 max(bg-p,0)*/) {
+                                                    int OW, int OH, int diff_mode /*0 raw, 1 |bg-p|, 2 max(bg-p,0)*/,
+                                                    const uint8_t* __restrict__ color, int color_ch, int och /*1 grey, 3 rgb8*/) {
     const uint32_t bi = blockIdx.x;
-    uint8_t* out = crops + (size_t)bi * OW * OH;
-    for (int i = threadIdx.x * 16; i < OW * OH; i += 256 * 16) *reinterpret_cast<uint4*>(out + i) = make_uint4(0, 0, 0, 0);
+    uint8_t* out = crops + (size_t)bi * OW * OH * och;
+    for (int i = threadIdx.x * 16; i < OW * OH * och; i += 256 * 16) *reinterpret_cast<uint4*>(out + i) = make_uint4(0, 0, 0, 0);
     const uint32_t f = blob_frame[bi];
     if (f >= (uint32_t)c.B) return;
     const trexhip_frame_info fi = info[f];
@@ -43,6 +44,12 @@ __global__ __launch_bounds__(256) void k_crops_none(const SegCfg c, const uint8_
         for (int x = q.x0 + (threadIdx.x & 15); x <= q.x1; x += 16) {
             const int ox = x - (int)B.x0 + sx;
             if (ox < 0 || ox >= OW) continue;
+            if (och == 3) {                                   // rgb8: the colour pixel itself (imageFromLines, Tests/test_pixels.cpp:1381-1460)
+                const uint8_t* s = color + (((size_t)f * c.H + q.y) * c.W + x) * color_ch;
+                uint8_t* d = out + ((size_t)oy * OW + ox) * 3;
+                d[0] = s[0]; d[1] = s[1]; d[2] = s[2];
+                continue;
+            }
             int p = img[(size_t)q.y * c.W + x];
             if (c.invert) p = 255 - p;
             if (diff_mode) {
@@ -63,7 +70,8 @@ int launch_crops(trexhip_ctx* ctx, uint8_t* d_crops, int n, int OW, int OH, int 
     c.B = ctx->last_n;
     stage_begin(ctx, TREXHIP_STAGE_CROPS);
     hipLaunchKernelGGL(k_crops_none, dim3(n), dim3(256), 0, ctx->stream, c, ctx->d_frames, ctx->d_bg, ctx->d_info,
-                       ctx->d_blob_frame, ctx->d_blobs, ctx->d_runs, d_crops, OW, OH, diff_mode);
+                       ctx->d_blob_frame, ctx->d_blobs, ctx->d_runs, d_crops, OW, OH, diff_mode, ctx->d_color_src, ctx->color_ch,
+                       ctx->p.pixel_encoding == TREXHIP_ENC_RGB8 ? 3 : 1);
     stage_end(ctx, TREXHIP_STAGE_CROPS);
     TH_CHECK_HIP(hipGetLastError());
     return TREXHIP_OK;
@@ -78,6 +86,11 @@ extern "C" {
 int trexhip_crops_device(trexhip_ctx* ctx, uint8_t* d_crops, int32_t n_blobs, int32_t out_w, int32_t out_h,
                          int32_t normalization, int32_t difference) {
     if (!ctx || !d_crops) { set_error("trexhip_crops_device: null argument"); return TREXHIP_E_INVALID; }
+    if (ctx->p.pixel_encoding == TREXHIP_ENC_R3G3B2) { set_error("trexhip_crops_device: crops of r3g3b2 pixel arrays are not implemented"); return TREXHIP_E_UNSUPPORTED; }
+    if (ctx->p.pixel_encoding == TREXHIP_ENC_RGB8 && (normalization != TREXHIP_NORMALIZE_NONE || difference != 0)) {
+        set_error("trexhip_crops_device: rgb8 crops are implemented for normalization none, raw pixels only"); return TREXHIP_E_UNSUPPORTED;
+    }
+    if (ctx->p.pixel_encoding == TREXHIP_ENC_RGB8 && (out_w * out_h * 3) % 16 != 0) { set_error("trexhip_crops_device: out_w*out_h*3 must be a multiple of 16"); return TREXHIP_E_UNSUPPORTED; }
     if (normalization != TREXHIP_NORMALIZE_NONE && normalization != TREXHIP_NORMALIZE_MOMENTS) {
         set_error("trexhip_crops_device: posture / legacy normalisation need the caller's Midline::transform: use trexhip_crops_transformed_device");
         return TREXHIP_E_UNSUPPORTED;
@@ -218,6 +231,29 @@ extern "C" int trexhip_segment_color(trexhip_ctx* ctx, const uint8_t* const* fra
     TH_CHECK_HIP(hipMemcpyAsync(ctx->d_color, ctx->h_color, (size_t)n * H * row, hipMemcpyHostToDevice, ctx->stream));
     int rc = launch_to_gray(ctx, ctx->d_color, ctx->d_staging, (size_t)n * W * H, channels, color_channel);
     if (rc) return rc;
+    ctx->d_color_src = ctx->d_color; ctx->color_ch = channels;       // the colour pixel encodings gather from here
+    return launch_segment(ctx, ctx->d_staging, n);
+}
+
+extern "C" int trexhip_segment_color_device(trexhip_ctx* ctx, const uint8_t* d_color_frames, int32_t n, int32_t channels, int32_t color_channel) {
+    using namespace trexhip;
+    if (!ctx || !d_color_frames) { set_error("trexhip_segment_color_device: null argument"); return TREXHIP_E_INVALID; }
+    if (!ctx->has_bg) { set_error("trexhip_segment_color_device: background image not set"); return TREXHIP_E_INVALID; }
+    if (n < 0 || n > ctx->p.max_batch) { set_error("trexhip_segment_color_device: n outside 0..max_batch"); return TREXHIP_E_INVALID; }
+    if (channels != 3 && channels != 4) { set_error("Invalid number of channels in input image for the network."); return TREXHIP_E_INVALID; }
+    if (color_channel >= channels) color_channel = -1;
+    const size_t W = ctx->p.width, H = ctx->p.height;
+    if ((W * H) % 4 != 0) { set_error("trexhip_segment_color_device: width*height must be a multiple of 4"); return TREXHIP_E_UNSUPPORTED; }
+    if (reinterpret_cast<uintptr_t>(d_color_frames) & 3) { set_error("trexhip_segment_color_device: colour frames must be 4-byte aligned"); return TREXHIP_E_INVALID; }
+    TH_CHECK_HIP(hipSetDevice(ctx->p.device));
+    if (n == 0) { ctx->last_n = 0; ctx->fetched = false; return TREXHIP_OK; }
+    if (!ctx->d_staging) {
+        TH_CHECK_HIP(hipMalloc(reinterpret_cast<void**>(&ctx->d_staging), (size_t)ctx->p.max_batch * W * H + 16));
+        TH_CHECK_HIP(hipHostMalloc(reinterpret_cast<void**>(&ctx->h_staging), (size_t)ctx->p.max_batch * W * H, hipHostMallocDefault));
+    }
+    int rc = launch_to_gray(ctx, d_color_frames, ctx->d_staging, (size_t)n * W * H, channels, color_channel);
+    if (rc) return rc;
+    ctx->d_color_src = d_color_frames; ctx->color_ch = channels;
     return launch_segment(ctx, ctx->d_staging, n);
 }
 
@@ -438,6 +474,7 @@ static void compose_and_invert(const Aff& tr, float midline_length, bool legacy,
 
 int launch_crops_warp(trexhip_ctx* ctx, uint8_t* d_crops, int n, int OW, int OH, int diff_mode, const float* tr6, const float* lengths,
                       bool legacy, float scale, const uint8_t* valid) {
+    if (ctx->p.pixel_encoding != TREXHIP_ENC_GRAY) { set_error("normalised crops of colour pixel encodings are not implemented"); return TREXHIP_E_UNSUPPORTED; }
     // tr6 == nullptr: `moments` -- orientation from the integer moments of the fetched blob table (host copy)
     std::vector<double> minv((size_t)n * 6);
     for (int i = 0; i < n; ++i) {

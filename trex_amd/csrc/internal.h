@@ -125,6 +125,9 @@ struct trexhip_ctx {
     int tune_rows_order = 0;
     int tune_rows_blocks = 8192;
     int tune_conv_geom = 0;             // dev only: alternative conv tilings (TREXHIP_CONV_GEOM)
+    int pix_ch = 1;                     // bytes per output pixel (pixel_encoding)
+    const uint8_t* d_color_src = nullptr; // colour frames of the last segment_color* call ([n][H][W][color_ch])
+    int color_ch = 0;
     int n_cus = 256;                    // compute units of the device (persistent kernels size their grids with it)
     int tune_seg_groups = 1;            // >1: pixel pass of frame group g+1 on the caller stream, labelling of g on an auxiliary stream (TREXHIP_SEG_GROUPS); measured SLOWER (cross-stream events cost 30-50 us each: 159 -> 266 us at 2 groups), kept off
     hipStream_t aux_stream = nullptr;   // labelling + gather of a group while the next group's pixel pass runs

@@ -888,13 +888,22 @@ __device__ __forceinline__ uint32_t make_bid(uint32_t x0, uint32_t x1, uint32_t 
     return (x << 19) | (y << 6) | n;
 }
 
+// pixel of a colour encoding: rgb8 = the first three bytes in memory order (BGRA2BGR), r3g3b2 = the code of convert_to_r3g3b2
+// (first channel 2 bits on top, then 3 + 3: layout pinned by Tests/test_pixels.cpp:629-795)
+__device__ __forceinline__ void store_colour(uint8_t* px, uint32_t index, const uint8_t* src, int enc) {
+    const uint32_t c0 = src[0], c1 = src[1], c2 = src[2];
+    if (enc == 2) { px[3 * index] = (uint8_t)c0; px[3 * index + 1] = (uint8_t)c1; px[3 * index + 2] = (uint8_t)c2; }
+    else px[index] = (uint8_t)(((c0 >> 6) << 6) | ((c1 >> 5) << 3) | (c2 >> 5));
+}
+
 __global__ __launch_bounds__(256) void k_gather(const SegCfg c, const int only_pending, const uint8_t* __restrict__ frames,
                                                 const uint32_t* __restrict__ totals,
                                                 const trexhip_frame_info* __restrict__ info,
                                                 const uint32_t* __restrict__ blob_frame,
                                                 trexhip_blob* __restrict__ blobs,
                                                 const trexhip_run* __restrict__ runs,
-                                                uint8_t* __restrict__ pixels, const uint32_t f0, const uint32_t f1) {
+                                                uint8_t* __restrict__ pixels, const uint32_t f0, const uint32_t f1,
+                                                const uint8_t* __restrict__ color, const int color_ch, const int enc) {
     const uint32_t lane = lane_id();
     const uint32_t nwaves = gridDim.x * 4;
     const uint32_t total = min(totals[0], c.pool_blobs);
@@ -905,8 +914,9 @@ __global__ __launch_bounds__(256) void k_gather(const SegCfg c, const int only_p
         if (fi.flags || (only_pending && fi.reserved[0] != 2u)) continue;
         trexhip_blob B = blobs[bi];
         const trexhip_run* rr = runs + fi.run_begin + B.run_begin;
-        uint8_t* px = pixels + fi.pix_begin + B.pix_begin;
+        uint8_t* px = pixels + (size_t)(fi.pix_begin + B.pix_begin) * (enc == 2 ? 3 : 1);
         const uint8_t* img = frames + (size_t)f * c.H * c.W;
+        const uint8_t* cimg = enc ? color + (size_t)f * c.H * c.W * color_ch : nullptr;   // colour source of the r3g3b2 / rgb8 pixel arrays
         uint64_t m10 = 0, m01 = 0, m20 = 0, m11 = 0, m02 = 0, sp = 0, spx = 0, spy = 0;
         uint32_t x0 = 0xffff, x1 = 0, y0 = 0xffff, y1 = 0, pmin = 255, pmax = 0, po = 0;
         for (uint32_t b0 = 0; b0 < B.n_runs; b0 += 64) {
@@ -933,8 +943,9 @@ __global__ __launch_bounds__(256) void k_gather(const SegCfg c, const int only_p
                     for (int k = 0; k < 8; ++k) {
                         uint32_t p = v[k];
                         if (c.invert) p = 255u - p;
-                        px[off + k] = (uint8_t)p;
                         const uint32_t xx = x + k;
+                        if (!enc) px[off + k] = (uint8_t)p;
+                        else store_colour(px, off + k, cimg + ((size_t)q.y * c.W + xx) * color_ch, enc);
                         m10 += xx; m20 += (uint64_t)xx * xx;
                         rp += p; spx += (uint64_t)p * xx;
                         pmin = min(pmin, p); pmax = max(pmax, p);
@@ -951,8 +962,9 @@ __global__ __launch_bounds__(256) void k_gather(const SegCfg c, const int only_p
                         if ((uint32_t)k >= rem) break;
                         uint32_t p = v[k];
                         if (c.invert) p = 255u - p;
-                        px[off + k] = (uint8_t)p;
                         const uint32_t xx = x + k;
+                        if (!enc) px[off + k] = (uint8_t)p;
+                        else store_colour(px, off + k, cimg + ((size_t)q.y * c.W + xx) * color_ch, enc);
                         m10 += xx; m20 += (uint64_t)xx * xx;
                         rp += p; spx += (uint64_t)p * xx;
                         pmin = min(pmin, p); pmax = max(pmax, p);
@@ -1056,7 +1068,7 @@ int launch_segment(trexhip_ctx* ctx, const uint8_t* d_frames, int n) {
                            ctx->d_tmp_runs, ctx->d_raster, ctx->d_parent, ctx->d_root_ord, ctx->d_cur_run, ctx->d_pix_begin, ctx->d_blob_map,
                            totals, ctx->d_info, ctx->d_blobs, ctx->d_blob_frame, ctx->d_runs, ctx->tune_ccl_stop, reinterpret_cast<unsigned long long*>(ctx->d_cnt_px), f0);
         hipLaunchKernelGGL(k_gather, dim3(G > 1 ? 256 : 1024), dim3(256), 0, t, c, 0, d_frames, totals, ctx->d_info, ctx->d_blob_frame,
-                           ctx->d_blobs, ctx->d_runs, ctx->d_pixels, (uint32_t)f0, (uint32_t)f1);
+                           ctx->d_blobs, ctx->d_runs, ctx->d_pixels, (uint32_t)f0, (uint32_t)f1, ctx->d_color_src, ctx->color_ch, ctx->p.pixel_encoding);
     }
     if (G > 1) {
         TH_CHECK_HIP(hipEventRecord(ctx->ev_grp[8], ctx->aux_stream));
@@ -1087,7 +1099,7 @@ int launch_pending(trexhip_ctx* ctx) {
                        ctx->d_cnt_runs, ctx->d_cnt_px, ctx->d_cur_run, ctx->d_pix_begin, ctx->d_blob_map, totals, ctx->d_info,
                        ctx->d_blobs, ctx->d_blob_frame, ctx->d_runs, 0, (const uint32_t*)nullptr);
     hipLaunchKernelGGL(k_gather, dim3(1024), dim3(256), 0, s, c, 1, ctx->d_frames, totals, ctx->d_info, ctx->d_blob_frame,
-                       ctx->d_blobs, ctx->d_runs, ctx->d_pixels, 0u, (uint32_t)n);
+                       ctx->d_blobs, ctx->d_runs, ctx->d_pixels, 0u, (uint32_t)n, ctx->d_color_src, ctx->color_ch, ctx->p.pixel_encoding);
     TH_CHECK_HIP(hipGetLastError());
     return TREXHIP_OK;
 }
@@ -1237,7 +1249,7 @@ int launch_rethreshold(trexhip_ctx* ctx, int thr, int method, const double* rang
     hipLaunchKernelGGL(k_blobs, dim3(n), dim3(256), 0, s, c, 0, q.d_raster, q.d_parent, q.d_root_ord, q.d_cnt_runs, q.d_cnt_px, q.d_cur_run,
                        q.d_pix_begin, q.d_blob_map, q.d_totals, q.d_info, q.d_blobs, q.d_blob_frame, q.d_runs, 1, q.d_run_parent);
     hipLaunchKernelGGL(k_gather, dim3(1024), dim3(256), 0, s, c, 0, ctx->d_frames, q.d_totals, q.d_info, q.d_blob_frame, q.d_blobs,
-                       q.d_runs, q.d_pixels, 0u, (uint32_t)n);
+                       q.d_runs, q.d_pixels, 0u, (uint32_t)n, ctx->d_color_src, ctx->color_ch, ctx->p.pixel_encoding);
     TH_CHECK_HIP(hipGetLastError());
     q.valid_n = n;
     return TREXHIP_OK;

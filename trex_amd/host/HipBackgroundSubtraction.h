@@ -47,6 +47,10 @@ struct HipBackgroundSubtraction {
         p.threshold = s.detect_threshold; p.threshold_maximum = s.threshold_maximum;
         p.absolute_difference = s.detect_threshold_is_absolute; p.enable_difference = s.enable_difference;
         p.image_invert = s.image_invert; p.cm_per_pixel = s.cm_per_pixel;
+        // pixel arrays in the frame's meta_encoding (the encoding is fixed per context: it sizes the pixel pool)
+        p.pixel_encoding = s.meta_encoding == cmn::meta_encoding_t::rgb8 ? TREXHIP_ENC_RGB8
+                         : s.meta_encoding == cmn::meta_encoding_t::r3g3b2 ? TREXHIP_ENC_R3G3B2 : TREXHIP_ENC_GRAY;
+        d.context_encoding = s.meta_encoding;
         p.n_ranges = (int32_t)s.detect_size_filter.size();
         for (int i = 0; i < p.n_ranges && i < 8; ++i) { p.ranges[2 * i] = s.detect_size_filter[i].first; p.ranges[2 * i + 1] = s.detect_size_filter[i].second; }
         check(trexhip_create(&p, &d.ctx));
@@ -87,9 +91,11 @@ struct HipBackgroundSubtraction {
         int channels = 0;
         bool ok = d.ctx && d.has_background;
         if (!ok) batch_error = "Background image not set";
-        // gray / binary only: the colour arithmetic of RawProcessing::generate_binary (rgb8, r3g3b2) is not part of this library
-        if (ok && d.settings.meta_encoding != cmn::meta_encoding_t::gray && d.settings.meta_encoding != cmn::meta_encoding_t::binary) {
-            ok = false; batch_error = "Invalid image mode for the HIP background-subtraction backend (meta_encoding must be gray or binary)";   // cf. BackgroundSubtraction.cpp:188
+        // the context was created for one pixel encoding (gray and binary share the gray arrays; add_object drops the pixels of binary)
+        if (ok) {
+            const auto want = d.settings.meta_encoding == cmn::meta_encoding_t::binary ? cmn::meta_encoding_t::gray : d.settings.meta_encoding;
+            const auto have = d.context_encoding == cmn::meta_encoding_t::binary ? cmn::meta_encoding_t::gray : d.context_encoding;
+            if (want != have) { ok = false; batch_error = "Invalid image mode: meta_encoding changed after init() (re-initialise the backend)"; }   // cf. BackgroundSubtraction.cpp:188
         }
         if (ok) {
             for (auto& tile : tiled)
@@ -121,8 +127,8 @@ struct HipBackgroundSubtraction {
                         lines->reserve(B.n_runs);
                         const trexhip_run* r = res.runs + fi.run_begin + B.run_begin;
                         for (uint32_t j = 0; j < B.n_runs; ++j) lines->emplace_back(r[j].y, r[j].x0, r[j].x1);
-                        const uint8_t* px = res.pixels + fi.pix_begin + B.pix_begin;
-                        auto pixels = std::make_unique<cmn::PixelArray_t>(px, px + B.n_pixels);
+                        const uint8_t* px = res.pixels + (size_t)(fi.pix_begin + B.pix_begin) * res.pixel_channels;
+                        auto pixels = std::make_unique<cmn::PixelArray_t>(px, px + (size_t)B.n_pixels * res.pixel_channels);   // pv.cpp:512
                         tile.data.frame.add_object(cmn::blob::Pair(std::move(lines), std::move(pixels), 0));   // :305-314
                     }
                 }
@@ -170,6 +176,7 @@ private:
     struct Data {
         trexhip_ctx* ctx = nullptr;
         Settings settings;
+        cmn::meta_encoding_t context_encoding = cmn::meta_encoding_t::gray;
         bool has_background = false;
         double time = 0, samples = 0;
         std::shared_mutex gpu_mutex, time_mutex;
