@@ -143,3 +143,17 @@ def test_batch_sizes_around_the_tile_and_grid_boundaries(n):
         p2 = seg.probabilities(crops[perm])
         assert np.abs(p2 - p[perm]).max() <= 1e-6
     seg.close()
+
+
+@pytest.mark.parametrize("mode", [capi.CNN_FP32, capi.CNN_FP16X3])
+def test_three_channel_network(mode):
+    # meta_encoding rgb8: V118_3 with 3 input channels (PermuteAxesWrapper: NHWC u8 -> NCHW float, no scaling)
+    st = weights.synthetic_state(20, 31, channels=3)
+    crops = weights.synthetic_crops(70, 9, channels=3)
+    seg = capi.Segmenter(capi.default_params(64, 64, max_batch=1))
+    seg.load_weights(weights.pack_blob(st, 20, channels=3))
+    seg.set_identity_precision(mode)
+    p = seg.probabilities(crops)
+    op, _ = cnn_oracle.predict(st, crops, threads=8)
+    assert np.abs(p - op).max() <= 1e-4
+    seg.close()

@@ -112,3 +112,29 @@ def test_rgb8_crops_and_gray_api_guard():
     with pytest.raises(capi.TrexHipError):
         seg.crops_device(crops.ctypes.data, n, normalization=1)               # normalised colour crops: not implemented
     seg.close()
+
+
+def test_rgb8_end_to_end_identity():
+    # detect on colour tiles -> raw rgb8 crops on the device -> 3-channel V118_3: equal to the CPU network on the CPU-built crops
+    from oracle import cnn_oracle
+    from trex_amd import weights
+    fr, bgc = scene(8, H=160, W=256, ch=4)
+    W, H = bgc.shape[1], bgc.shape[0]
+    st = weights.synthetic_state(12, 5, channels=3)
+    seg = capi.Segmenter(capi.default_params(W, H, max_batch=1, pixel_encoding=capi.ENC_RGB8))
+    seg.set_background(oracle.bgr2gray(bgc[..., :3]))
+    seg.load_weights(weights.pack_blob(st, 12, channels=3))
+    seg.segment_color_host([fr])
+    r = seg.fetch()[0]
+    n = len(r.blobs)
+    assert n >= 5
+    crops = torch.zeros((n, 80, 80, 3), dtype=torch.uint8, device="cuda")
+    probs = torch.zeros((n, 12), dtype=torch.float32, device="cuda")
+    seg.crops_device(crops.data_ptr(), n)
+    seg.identify_device(crops.data_ptr(), n, probs.data_ptr())
+    seg.synchronize()
+    cpu_crops = np.stack([np.stack([oracle.crop_none(fr[..., c], np.zeros((H, W), np.uint8), b, r.runs) for c in range(3)], axis=-1) for b in r.blobs])
+    assert np.array_equal(crops.cpu().numpy(), cpu_crops)
+    op, _ = cnn_oracle.predict(st, cpu_crops, threads=8)
+    assert np.abs(probs.cpu().numpy() - op).max() <= 1e-4
+    seg.close()
