@@ -178,6 +178,81 @@ __global__ __launch_bounds__(256) void k_conv1_mfma(const uint8_t* __restrict__ 
     }
 }
 
+// the same for 3-channel crops (meta_encoding rgb8): one fp16 plane per channel in LDS; per shift four MFMAs of K = 32:
+// channel 0 / 1 / 2 with kernel rows 0..3, and a fourth whose k-octets 0..2 hold kernel row 4 of the three channels
+__global__ __launch_bounds__(256) void k_conv1_mfma3(const uint8_t* __restrict__ crops /*[N][80][80][3]*/, const uint4* __restrict__ wtab /*[32][64]*/,
+                                                     const float* __restrict__ bias, float* __restrict__ out, const float inv_scale) {
+    constexpr int S = 80, PH = 84, PITCH = 88, PLANE = PH * PITCH;
+    __shared__ __attribute__((aligned(16))) _Float16 img[3 * PLANE];
+    __shared__ __attribute__((aligned(16))) float tr[4][64 * 17];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int crop = blockIdx.x;
+    const uint32_t* src = reinterpret_cast<const uint32_t*>(crops + (size_t)crop * S * S * 3);
+    for (int i = tid; i < 3 * PLANE * 2 / 16; i += 256) reinterpret_cast<uint4*>(img)[i] = make_uint4(0, 0, 0, 0);
+    __syncthreads();
+    for (int i = tid; i < S * S / 4; i += 256) {               // 4 pixels = 12 bytes = 3 dwords per step
+        const int y = i / (S / 4), x = (i - y * (S / 4)) * 4;
+        const uint32_t w0 = src[3 * i], w1 = src[3 * i + 1], w2 = src[3 * i + 2];
+        const uint32_t by[12] = {w0 & 0xff, (w0 >> 8) & 0xff, (w0 >> 16) & 0xff, w0 >> 24, w1 & 0xff, (w1 >> 8) & 0xff, (w1 >> 16) & 0xff, w1 >> 24,
+                                 w2 & 0xff, (w2 >> 8) & 0xff, (w2 >> 16) & 0xff, w2 >> 24};
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            uint32_t* d = reinterpret_cast<uint32_t*>(img + c * PLANE + (y + 2) * PITCH + 2 + x);
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const _Float16 h0 = (_Float16)(float)by[(2 * k) * 3 + c], h1 = (_Float16)(float)by[(2 * k + 1) * 3 + c];
+                d[k] = (uint32_t)__builtin_bit_cast(uint16_t, h0) | ((uint32_t)__builtin_bit_cast(uint16_t, h1) << 16);
+            }
+        }
+    }
+    uint4 bf[32];
+#pragma unroll
+    for (int f = 0; f < 32; ++f) bf[f] = wtab[f * 64 + lane];
+    __syncthreads();
+    const int r = lane & 15, q = lane >> 4;
+    const int co = r;
+    const float bz = bias[co];
+    float* oc = out + (size_t)crop * 40 * 40 * 16;
+    for (int tile = wave; tile < 100; tile += 4) {
+        const int wdx = tile * 8 + (r >> 1);
+        const int yp = wdx / 20, x4 = (wdx - yp * 20) * 4;
+        const int row = 2 * yp + (r & 1);
+        f16x8_c1 a[4];
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            // m < 3: channel m, kernel row q; m == 3: kernel row 4 of channel q (the fourth k-octet meets zero weights)
+            const _Float16* pp = m < 3 ? img + m * PLANE + (row + q) * PITCH + x4 : img + (q < 3 ? q : 0) * PLANE + (row + 4) * PITCH + x4;
+            const uint2 lo = *reinterpret_cast<const uint2*>(pp), hi = *reinterpret_cast<const uint2*>(pp + 4);
+            a[m] = __builtin_bit_cast(f16x8_c1, make_uint4(lo.x, lo.y, hi.x, hi.y));
+        }
+        f32x4 acc[4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            f32x4 c = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int m = 0; m < 4; ++m) c = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[m], __builtin_bit_cast(f16x8_c1, bf[(s * 4 + m) * 2 + 1]), c, 0, 0, 0);   // low pieces first
+#pragma unroll
+            for (int m = 0; m < 4; ++m) c = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[m], __builtin_bit_cast(f16x8_c1, bf[(s * 4 + m) * 2 + 0]), c, 0, 0, 0);
+            acc[s] = c;
+        }
+        float* tw = tr[wave];
+#pragma unroll
+        for (int pos = 0; pos < 2; ++pos) {
+            const float m0 = fmaxf(fmaxf(acc[0][2 * pos], acc[0][2 * pos + 1]), fmaxf(acc[1][2 * pos], acc[1][2 * pos + 1]));
+            const float m1 = fmaxf(fmaxf(acc[2][2 * pos], acc[2][2 * pos + 1]), fmaxf(acc[3][2 * pos], acc[3][2 * pos + 1]));
+            tw[(4 * q + 2 * pos) * 17 + co] = fmaxf(m0 * inv_scale + bz, 0.f);
+            tw[(4 * q + 2 * pos + 1) * 17 + co] = fmaxf(m1 * inv_scale + bz, 0.f);
+        }
+        __builtin_amdgcn_wave_barrier();
+        {
+            const int px = lane >> 2, c4 = (lane & 3) * 4;
+            const float* sp = tw + px * 17 + c4;
+            *reinterpret_cast<float4*>(oc + ((size_t)tile * 16 + px) * 16 + c4) = make_float4(sp[0], sp[1], sp[2], sp[3]);
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // conv 5x5 'same' + folded BN + ReLU + maxpool2 as 25 shifted GEMMs on fp32 MFMA
 // ------------------------------------------------------------------------------------------------
@@ -1050,6 +1125,34 @@ int net_load(trexhip_ctx* ctx, const void* blob, size_t bytes) {
                     w1[((size_t)c * 25 + tap) * 16 + co] = (float)((double)c1w[((size_t)co * CH + c) * 25 + tap] * s);
         }
         TRY(upload(&net->w1, w1)); TRY(upload(&net->b1, b1));
+        if (CH == 3 && rc == TREXHIP_OK) {   // B fragments of k_conv1_mfma3: [shift s][mfma m][piece hi|lo][lane] x 8 halves
+            float mx = 0.f;
+            for (float v : w1) mx = std::fmax(mx, std::fabs(v));
+            int k = 0;
+            if (mx > 0.f) { k = (int)std::floor(std::log2(16384.0 / (double)mx)); if (k > 24) k = 24; if (k < -24) k = -24; }
+            const float sc = std::ldexp(1.0f, k);
+            net->inv1h = std::ldexp(1.0f, -k);
+            std::vector<uint16_t> tab((size_t)32 * 64 * 8, 0);
+            for (int s = 0; s < 4; ++s)
+                for (int m = 0; m < 4; ++m)
+                    for (int lane = 0; lane < 64; ++lane) {
+                        const int co = lane & 15, q = lane >> 4;
+                        const int ch = m < 3 ? m : q, ky = m < 3 ? q : 4;
+                        for (int slot = 0; slot < 8; ++slot) {
+                            const int kx = slot - s;
+                            float x = 0.f;
+                            if (ch < 3 && kx >= 0 && kx < 5) x = w1[((size_t)ch * 25 + ky * 5 + kx) * 16 + co] * sc;
+                            const _Float16 h1 = (_Float16)x;
+                            const _Float16 h2 = (_Float16)(x - (float)h1);
+                            uint16_t pc[2];
+                            std::memcpy(&pc[0], &h1, 2); std::memcpy(&pc[1], &h2, 2);
+                            for (int piece = 0; piece < 2; ++piece)
+                                tab[((size_t)((s * 4 + m) * 2 + piece) * 64 + lane) * 8 + slot] = pc[piece];
+                        }
+                    }
+            if (hipMalloc(reinterpret_cast<void**>(&net->w1h), tab.size() * 2) != hipSuccess ||
+                hipMemcpy(net->w1h, tab.data(), tab.size() * 2, hipMemcpyHostToDevice) != hipSuccess) rc = TREXHIP_E_DEVICE;
+        }
         if (CH == 1 && rc == TREXHIP_OK) {   // B fragments of k_conv1_mfma: [shift s][mfma 0: ky 0..3 | 1: ky 4][piece hi|lo][lane] x 8 halves
             float mx = 0.f;
             for (float v : w1) mx = std::fmax(mx, std::fabs(v));
@@ -1189,6 +1292,7 @@ int net_forward(trexhip_ctx* ctx, const uint8_t* d_crops, int n, float* d_probs,
     // the matrix-core conv1 reads the crops with 16-byte loads: unaligned crop buffers take the VALU kernel
     if (net->CH == 1 && !(ctx->tune_conv_geom & 16) && (reinterpret_cast<uintptr_t>(d_crops) & 15) == 0) hipLaunchKernelGGL(k_conv1_mfma, dim3(n), dim3(256), 0, s, d_crops, net->w1h, net->b1, net->act1, net->inv1h);
     else if (net->CH == 1) hipLaunchKernelGGL((k_conv1<1>), dim3(n), dim3(256), lds1, s, d_crops, net->w1, net->b1, net->act1, S);
+    else if (net->CH == 3 && !(ctx->tune_conv_geom & 16) && (reinterpret_cast<uintptr_t>(d_crops) & 15) == 0) hipLaunchKernelGGL(k_conv1_mfma3, dim3(n), dim3(256), 0, s, d_crops, net->w1h, net->b1, net->act1, net->inv1h);
     else              hipLaunchKernelGGL((k_conv1<3>), dim3(n), dim3(256), lds1, s, d_crops, net->w1, net->b1, net->act1, S);
     const int mode = ctx->cnn_mode;
     if (mode == TREXHIP_CNN_FP16X3) TH_CHECK_HIP(hipMemsetAsync(net->d_ovf, 0, 4, s));
