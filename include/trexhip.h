@@ -257,9 +257,12 @@ int trexhip_crops_posture_device(trexhip_ctx* ctx, uint8_t* d_crops, int32_t n_b
  * from a TRex <base>_dict.pth).  BatchNorm is folded and the tensors repacked on load. */
 int trexhip_load_weights(trexhip_ctx* ctx, const void* blob, size_t bytes);
 int trexhip_num_classes(trexhip_ctx* ctx);
-/* arithmetic of the two large convolutions: exact fp32 MFMA, or fp32-equivalent on the bf16 matrix cores (each
- * operand split into 3 bf16 pieces, 6 piece products per product; default), or the 3-product variant
- * (~2^-16 relative per product; NOT within the 1e-4 softmax bar in general -- for experiments only) */
+/* arithmetic of conv1..fc1.  All modes but BF16X3 meet the 1e-4 softmax bar against the fp32 reference network:
+ *   TREXHIP_CNN_FP16X3 (default): every fp32 operand as two fp16 pieces (22 mantissa bits), 3 piece products per product on the
+ *       fp16 matrix cores, fp32 accumulate; an activation outside the fp16 range raises a device flag and the layer stack is
+ *       re-run by the BF16X6 kernels (never a silent wrong answer);
+ *   TREXHIP_CNN_BF16X6: three bf16 pieces, 6 piece products;  TREXHIP_CNN_FP32: exact fp32 MFMA (v_mfma_f32_32x32x2_f32);
+ *   TREXHIP_CNN_BF16X3: three piece products only (~2^-16 relative per product) -- for experiments. */
 enum { TREXHIP_CNN_FP32 = 0, TREXHIP_CNN_BF16X6 = 1, TREXHIP_CNN_BF16X3 = 2, TREXHIP_CNN_FP16X3 = 3 };
 int trexhip_set_identity_precision(trexhip_ctx* ctx, int32_t mode);
 /* VINetwork::probabilities (ml/VisualIdentification.cpp:440-458) -> predict_numpy

@@ -118,7 +118,7 @@ struct trexhip_ctx {
 
     void* net = nullptr;                // trexhip::Net (cnn.hip)
     trexhip::Pass2 pass2;
-    int cnn_mode = 0;                   // TREXHIP_CNN_*
+    int cnn_mode = TREXHIP_CNN_FP16X3;  // TREXHIP_CNN_*: fp32-class arithmetic on the fp16 matrix cores, range-guarded
 
     bool profiling = false;
     // tuning knobs (env TREXHIP_ROWS_ORDER / TREXHIP_ROWS_BLOCKS override the defaults)
