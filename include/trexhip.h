@@ -230,7 +230,8 @@ int trexhip_midline_device(trexhip_ctx* ctx, const trexhip_midline_params* mp, i
 /* ---- crops ------------------------------------------------------------------------------------
  * constraints::diff_image (tracking/FilterCache.cpp:265-294): one out_w x out_h uint8 crop per blob of the
  * last segmented batch, pooled order (blob i of trexhip_fetch == crop i).  n_blobs = total_blobs of that
- * batch.  normalization: individual_image_normalization none or moments (posture / legacy: next function).  difference: 0 = grey
+ * batch ([n][out_h][out_w][3] for the rgb8 pixel encoding, raw pixels only).  normalization: individual_image_normalization none or
+ * moments (posture / legacy: next function).  difference: 0 = grey
  * values, 1 = |bg - p|, 2 = max(bg - p, 0)  (track_background_subtraction, FilterCache.cpp:171-175). */
 enum { TREXHIP_NORMALIZE_NONE = 0, TREXHIP_NORMALIZE_MOMENTS = 1, TREXHIP_NORMALIZE_POSTURE = 2 };
 int trexhip_crops_device(trexhip_ctx* ctx, uint8_t* d_crops, int32_t n_blobs, int32_t out_w, int32_t out_h,

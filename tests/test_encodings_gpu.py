@@ -109,8 +109,37 @@ def test_rgb8_crops_and_gray_api_guard():
         for c in range(3):                                                   # every channel = the un-normalised gray crop of that channel image
             want = oracle.crop_none(fr[..., c], np.zeros((H, W), np.uint8), b, r.runs)
             assert np.array_equal(crops[k, :, :, c], want), (k, c)
+    # moments / posture normalisation: every channel is warped independently with the same transform and line mask
+    d_crops = torch.zeros((n, 80, 80, 3), dtype=torch.uint8, device="cuda")
+    seg.crops_device(d_crops.data_ptr(), n, normalization=1)
+    seg.synchronize()
+    got = d_crops.cpu().numpy()
+    zero = np.zeros((H, W), np.uint8)
+    for k, b in enumerate(r.blobs):
+        for c in range(3):
+            want, _ = oracle.crop_normalized(fr[..., c], zero, b, r.runs)
+            assert np.array_equal(got[k, :, :, c], want), ("moments", k, c)
+    MP = 512
+    outline = torch.zeros((n, MP, 2), dtype=torch.float32, device="cuda"); segs = torch.zeros((n, MP // 2 + 1, 4), dtype=torch.float32, device="cuda")
+    info = torch.zeros((n, 8), dtype=torch.int32, device="cuda"); mid = torch.zeros((n, 25, 4), dtype=torch.float32, device="cuda"); minfo = torch.zeros((n, 8), dtype=torch.int32, device="cuda")
+    seg.posture_device(n, outline.data_ptr(), segs.data_ptr(), info.data_ptr(), max_points=MP)
+    seg.midline_device(n, MP, info.data_ptr(), segs.data_ptr(), mid.data_ptr(), minfo.data_ptr())
+    seg.crops_posture_device(d_crops.data_ptr(), n, minfo.data_ptr())
+    seg.synchronize()
+    got = d_crops.cpu().numpy(); mi = minfo.cpu().numpy().view(capi.MIDLINE_INFO_DTYPE).reshape(-1)
+    n_ok = 0
+    for k, b in enumerate(r.blobs):
+        if mi[k]["status"] != 0:
+            assert got[k].sum() == 0
+            continue
+        n_ok += 1
+        tr = oracle.midline_transform(mi[k]["angle"], mi[k]["offx"], mi[k]["offy"], False)
+        for c in range(3):
+            want, _ = oracle.crop_normalized(fr[..., c], zero, b, r.runs, tr6=tr, midline_length=float(mi[k]["len"]))
+            assert np.array_equal(got[k, :, :, c], want), ("posture", k, c)
+    assert n_ok >= 3
     with pytest.raises(capi.TrexHipError):
-        seg.crops_device(crops.ctypes.data, n, normalization=1)               # normalised colour crops: not implemented
+        seg.crops_device(d_crops.data_ptr(), n, difference=1)                  # background-difference colour crops: not implemented
     seg.close()
 
 

@@ -87,8 +87,8 @@ int trexhip_crops_device(trexhip_ctx* ctx, uint8_t* d_crops, int32_t n_blobs, in
                          int32_t normalization, int32_t difference) {
     if (!ctx || !d_crops) { set_error("trexhip_crops_device: null argument"); return TREXHIP_E_INVALID; }
     if (ctx->p.pixel_encoding == TREXHIP_ENC_R3G3B2) { set_error("trexhip_crops_device: crops of r3g3b2 pixel arrays are not implemented"); return TREXHIP_E_UNSUPPORTED; }
-    if (ctx->p.pixel_encoding == TREXHIP_ENC_RGB8 && (normalization != TREXHIP_NORMALIZE_NONE || difference != 0)) {
-        set_error("trexhip_crops_device: rgb8 crops are implemented for normalization none, raw pixels only"); return TREXHIP_E_UNSUPPORTED;
+    if (ctx->p.pixel_encoding == TREXHIP_ENC_RGB8 && difference != 0) {
+        set_error("trexhip_crops_device: rgb8 crops hold the raw colour pixels: background-difference crops are not implemented"); return TREXHIP_E_UNSUPPORTED;
     }
     if (ctx->p.pixel_encoding == TREXHIP_ENC_RGB8 && (out_w * out_h * 3) % 16 != 0) { set_error("trexhip_crops_device: out_w*out_h*3 must be a multiple of 16"); return TREXHIP_E_UNSUPPORTED; }
     if (normalization != TREXHIP_NORMALIZE_NONE && normalization != TREXHIP_NORMALIZE_MOMENTS) {
@@ -366,18 +366,19 @@ __global__ __launch_bounds__(256) void k_crops_warp(const SegCfg c, const uint8_
                                                     const trexhip_frame_info* __restrict__ info, const uint32_t* __restrict__ blob_frame,
                                                     const trexhip_blob* __restrict__ blobs, const trexhip_run* __restrict__ runs,
                                                     const double* __restrict__ minv /*[n][6] inverse maps*/, uint8_t* __restrict__ crops,
-                                                    int OW, int OH, int diff_mode) {
+                                                    int OW, int OH, int diff_mode, const uint8_t* __restrict__ color, int color_ch,
+                                                    int och /*1 grey, 3 rgb8 (raw pixels, channels warped independently)*/) {
     __shared__ uint32_t s_runs[W_NR];
     __shared__ int s_row[1024 + 2];
     const uint32_t bi = blockIdx.x;
-    uint8_t* out = crops + (size_t)bi * OW * OH;
+    uint8_t* out = crops + (size_t)bi * OW * OH * och;
     const uint32_t f = blob_frame[bi];
     bool ok = f < (uint32_t)c.B;
     trexhip_frame_info fi = {};
     if (ok) { fi = info[f]; ok = fi.flags == 0; }
     trexhip_blob B = {};
     if (ok) { B = blobs[bi]; ok = B.n_runs <= (uint32_t)W_NR && (B.y1 - B.y0 + 1) <= 1024; }
-    if (!ok) { for (int i = threadIdx.x; i < OW * OH; i += 256) out[i] = 0; return; }
+    if (!ok) { for (int i = threadIdx.x; i < OW * OH * och; i += 256) out[i] = 0; return; }
     const trexhip_run* rr = runs + fi.run_begin + B.run_begin;
     const int y0 = B.y0, rows = B.y1 - B.y0 + 1;
     for (int i = threadIdx.x; i < (int)B.n_runs; i += 256) {
@@ -389,24 +390,29 @@ __global__ __launch_bounds__(256) void k_crops_warp(const SegCfg c, const uint8_
     __syncthreads();
     const double* M = minv + (size_t)bi * 6;
     const double m0 = M[0], m1 = M[1], m2 = M[2], m3 = M[3], m4 = M[4], m5 = M[5];
-    const int sw = B.x1 - B.x0 + 1, sh = rows;
+    const int sw = B.x1 - B.x0 + 1, sh = rows, plane = sw * sh;
     const uint8_t* img = frames + (size_t)f * c.H * c.W;
-    // imageFromLines: the blob's pixels (raw or background difference) on black over its bounding box.  Small boxes are painted
-    // into LDS once (then the four taps of every output pixel are plain LDS reads); larger ones test line membership per tap.
+    const uint8_t* cimg = och == 3 ? color + (size_t)f * c.H * c.W * color_ch : nullptr;
+    // value of the blob image at a member pixel: grey (raw or background difference) or one colour channel
+    auto source = [&](int ay, int ax, int ch) -> int {
+        if (och == 3) return cimg[((size_t)ay * c.W + ax) * color_ch + ch];
+        int p = img[(size_t)ay * c.W + ax];
+        if (c.invert) p = 255 - p;
+        if (diff_mode) { const int bgv = bg[(size_t)ay * c.W + ax]; p = diff_mode == 1 ? abs(bgv - p) : max(bgv - p, 0); }
+        return p;
+    };
+    // imageFromLines: the blob's pixels on black over its bounding box.  Small boxes are painted into LDS once (then the four
+    // taps of every output pixel are plain LDS reads); larger ones test line membership per tap.
     __shared__ uint8_t s_img[W_IMG];
-    const bool staged = sw * sh <= W_IMG;
+    const bool staged = plane * och <= W_IMG;
     if (staged) {
-        for (int i = threadIdx.x; i < (sw * sh + 3) / 4; i += 256) reinterpret_cast<uint32_t*>(s_img)[i] = 0u;
+        for (int i = threadIdx.x; i < (plane * och + 3) / 4; i += 256) reinterpret_cast<uint32_t*>(s_img)[i] = 0u;
         __syncthreads();
         for (int r = threadIdx.x; r < (int)B.n_runs; r += 256) {
             const uint32_t q = s_runs[r];
             const int xa = (int)(q & 0xffffu), xb = (int)(q >> 16), yy = (int)rr[r].y;
-            for (int ax = xa; ax <= xb; ++ax) {
-                int p = img[(size_t)yy * c.W + ax];
-                if (c.invert) p = 255 - p;
-                if (diff_mode) { const int bgv = bg[(size_t)yy * c.W + ax]; p = diff_mode == 1 ? abs(bgv - p) : max(bgv - p, 0); }
-                s_img[(yy - y0) * sw + (ax - B.x0)] = (uint8_t)p;
-            }
+            for (int ax = xa; ax <= xb; ++ax)
+                for (int ch = 0; ch < och; ++ch) s_img[ch * plane + (yy - y0) * sw + (ax - B.x0)] = (uint8_t)source(yy, ax, ch);
         }
         __syncthreads();
     }
@@ -427,29 +433,29 @@ __global__ __launch_bounds__(256) void k_crops_warp(const SegCfg c, const uint8_
             X = (X0 + __double2int_rn(m0 * x * 1024.0)) >> 5; Y = (Y0 + __double2int_rn(m3 * x * 1024.0)) >> 5;
         }
         const int sx = X >> 5, sy = Y >> 5, fx = X & 31, fy = Y & 31;
-        if (sx < -1 || sx >= sw || sy < -1 || sy >= sh) { out[i] = 0; continue; }      // all four taps outside the bounding box
-        int v[4];
+        if (sx < -1 || sx >= sw || sy < -1 || sy >= sh) { for (int ch = 0; ch < och; ++ch) out[i * och + ch] = 0; continue; }   // all four taps outside the box
+        bool in[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const int xx = sx + (k & 1), yy = sy + (k >> 1);
-            int p = 0;
-            if (xx >= 0 && xx < sw && yy >= 0 && yy < sh) {
-                if (staged) p = s_img[yy * sw + xx];
-                else {
-                    const int ax = xx + B.x0;
-                    bool in = false;
-                    for (int r = s_row[yy]; r < s_row[yy + 1]; ++r) { const uint32_t q = s_runs[r]; if (ax >= (int)(q & 0xffffu) && ax <= (int)(q >> 16)) { in = true; break; } }
-                    if (in) {
-                        p = img[(size_t)(yy + y0) * c.W + ax];
-                        if (c.invert) p = 255 - p;
-                        if (diff_mode) { const int bgv = bg[(size_t)(yy + y0) * c.W + ax]; p = diff_mode == 1 ? abs(bgv - p) : max(bgv - p, 0); }
-                    }
-                }
+            in[k] = xx >= 0 && xx < sw && yy >= 0 && yy < sh;
+            if (in[k] && !staged) {
+                const int ax = xx + B.x0;
+                bool member = false;
+                for (int r = s_row[yy]; r < s_row[yy + 1]; ++r) { const uint32_t q = s_runs[r]; if (ax >= (int)(q & 0xffffu) && ax <= (int)(q >> 16)) { member = true; break; } }
+                in[k] = member;
             }
-            v[k] = p;
         }
         const int w00 = (32 - fy) * (32 - fx) * 32, w01 = (32 - fy) * fx * 32, w10 = fy * (32 - fx) * 32, w11 = fy * fx * 32;
-        out[i] = (uint8_t)((v[0] * w00 + v[1] * w01 + v[2] * w10 + v[3] * w11 + (1 << 14)) >> 15);
+        for (int ch = 0; ch < och; ++ch) {
+            int v[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int xx = sx + (k & 1), yy = sy + (k >> 1);
+                v[k] = !in[k] ? 0 : staged ? (int)s_img[ch * plane + yy * sw + xx] : source(yy + y0, xx + B.x0, ch);
+            }
+            out[i * och + ch] = (uint8_t)((v[0] * w00 + v[1] * w01 + v[2] * w10 + v[3] * w11 + (1 << 14)) >> 15);
+        }
     }
 }
 
@@ -474,7 +480,8 @@ static void compose_and_invert(const Aff& tr, float midline_length, bool legacy,
 
 int launch_crops_warp(trexhip_ctx* ctx, uint8_t* d_crops, int n, int OW, int OH, int diff_mode, const float* tr6, const float* lengths,
                       bool legacy, float scale, const uint8_t* valid) {
-    if (ctx->p.pixel_encoding != TREXHIP_ENC_GRAY) { set_error("normalised crops of colour pixel encodings are not implemented"); return TREXHIP_E_UNSUPPORTED; }
+    if (ctx->p.pixel_encoding == TREXHIP_ENC_R3G3B2) { set_error("crops of r3g3b2 pixel arrays are not implemented"); return TREXHIP_E_UNSUPPORTED; }
+    if (ctx->p.pixel_encoding == TREXHIP_ENC_RGB8 && diff_mode != 0) { set_error("rgb8 crops hold the raw colour pixels: background-difference crops are not implemented"); return TREXHIP_E_UNSUPPORTED; }
     // tr6 == nullptr: `moments` -- orientation from the integer moments of the fetched blob table (host copy)
     std::vector<double> minv((size_t)n * 6);
     for (int i = 0; i < n; ++i) {
@@ -508,7 +515,8 @@ int launch_crops_warp(trexhip_ctx* ctx, uint8_t* d_crops, int n, int OW, int OH,
     c.B = ctx->last_n;
     stage_begin(ctx, TREXHIP_STAGE_CROPS);
     hipLaunchKernelGGL(k_crops_warp, dim3(n), dim3(256), 0, ctx->stream, c, ctx->d_frames, ctx->d_bg, ctx->d_info, ctx->d_blob_frame,
-                       ctx->d_blobs, ctx->d_runs, ctx->d_warp, d_crops, OW, OH, diff_mode);
+                       ctx->d_blobs, ctx->d_runs, ctx->d_warp, d_crops, OW, OH, diff_mode, ctx->d_color_src, ctx->color_ch,
+                       ctx->p.pixel_encoding == TREXHIP_ENC_RGB8 ? 3 : 1);
     stage_end(ctx, TREXHIP_STAGE_CROPS);
     TH_CHECK_HIP(hipGetLastError());
     return TREXHIP_OK;
