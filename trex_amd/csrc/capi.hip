@@ -216,6 +216,8 @@ void trexhip_destroy(trexhip_ctx* ctx) {
     delete ctx;
 }
 
+int trexhip_pixel_channels(trexhip_ctx* ctx) { return ctx ? ctx->pix_ch : 0; }
+
 int trexhip_device_alloc(trexhip_ctx* ctx, size_t bytes, void** out_device_ptr) {
     if (!ctx || !out_device_ptr) { set_error("trexhip_device_alloc: null argument"); return TREXHIP_E_INVALID; }
     *out_device_ptr = nullptr;

@@ -126,7 +126,8 @@ public:
                                              float individual_image_scale, int difference) {
         std::vector<cmn::Image::Ptr> out((size_t)n_blobs);
         if (n_blobs <= 0) return out;
-        const size_t each = (size_t)out_w * out_h;
+        const int ch = trexhip_pixel_channels(_ctx);                 // 3 for meta_encoding rgb8
+        const size_t each = (size_t)out_w * out_h * (size_t)ch;
         if (_crops_cap < each * n_blobs) {
             if (_d_crops) (void)trexhip_device_free(_ctx, _d_crops);
             _d_crops = nullptr; _crops_cap = 0;
@@ -145,7 +146,7 @@ public:
         check(trexhip_copy_to_host(_ctx, host.data(), _d_crops, host.size()));
         for (int b = 0; b < n_blobs; ++b) {
             if (normalize >= 2 && _minfo[(size_t)b].status != 0) continue;          // no midline -> nullptr
-            auto img = cmn::Image::Make((uint32_t)out_h, (uint32_t)out_w, 1);
+            auto img = cmn::Image::Make((uint32_t)out_h, (uint32_t)out_w, (uint32_t)ch);
             std::memcpy(img->data(), host.data() + (size_t)b * each, each);
             out[(size_t)b] = std::move(img);
         }
