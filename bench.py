@@ -48,6 +48,8 @@ def main():
     ap.add_argument("--with-posture", action="store_true", help="also run posture (outline -> midline) for every blob inside the timed step (configs C3/C5)")
     ap.add_argument("--normalize", default="none", choices=["none", "moments", "posture"],
                     help="individual_image_normalization of the identity crops; posture = outline -> midline -> Midline::transform -> warpAffine (implies --with-posture)")
+    ap.add_argument("--encoding", default="gray", choices=["gray", "rgb8"],
+                    help="meta_encoding: gray = the BASELINE workload (gray frames); rgb8 = BGRA frames in HBM -> cvtColor on the device, 3-byte pixel arrays, 3-channel crops and network")
     ap.add_argument("--no-pipeline", dest="pipeline", action="store_false", help="one context, strictly serial steps (no overlap of detect(i+1) with identity(i))")
     ap.add_argument("--lanes", type=int, default=2, help="software-pipeline depth: contexts whose batches are in flight (detect of batch i+L-1 is issued while the identity network works on batch i)")
     ap.add_argument("--no-detect-priority", dest="detect_priority", action="store_false",
@@ -80,8 +82,11 @@ def main():
 
     # frame-sharded: rank r owns frames r*B .. r*B+B-1 of every step's block (distinct data per rank)
     frames, bg = synth.batch_torch(args.config, B, dev, t0=rank * B)
+    rgb = args.encoding == "rgb8"
+    if rgb:     # the same scenes as BGRA tiles (what TRex's TileImage holds for meta_encoding rgb8)
+        frames_c = torch.stack([frames, frames, frames, torch.full_like(frames, 255)], dim=-1).contiguous()
     max_blobs = 4 * n_ind
-    state = weights.synthetic_state(classes, 4242)
+    state = weights.synthetic_state(classes, 4242, channels=3 if args.encoding == "rgb8" else 1)
     from trex_amd import dist as tdist
     pool = B * max_blobs
     rows = B * n_ind * 5 // 4                       # fixed table rows per rank per step (all-gather needs equal sizes)
@@ -91,13 +96,14 @@ def main():
         """One context + its buffers + its stream.  Two lanes are software-pipelined: while lane A's identity network
         works on batch i, lane B runs the detect stage of batch i+1 and its tables travel to the host."""
         def __init__(self):
-            p = capi.default_params(W, H, device=local, max_batch=B, max_blobs=max_blobs, max_pixels=1 << 18, max_runs=32768)
+            p = capi.default_params(W, H, device=local, max_batch=B, max_blobs=max_blobs, max_pixels=1 << 18, max_runs=32768,
+                                    pixel_encoding=capi.ENC_RGB8 if rgb else capi.ENC_GRAY)
             self.seg = capi.Segmenter(p)
             self.seg.set_background(bg)
             if with_cnn:
-                self.seg.load_weights(weights.pack_blob(state, classes))
+                self.seg.load_weights(weights.pack_blob(state, classes, channels=3 if rgb else 1))
                 self.seg.set_identity_precision({"fp32": 0, "bf16x6": 1, "bf16x3": 2, "fp16x3": 3}[args.cnn_mode])
-            self.crops = torch.empty((pool, 80, 80), dtype=torch.uint8, device=dev)
+            self.crops = torch.empty((pool, 80, 80, 3) if rgb else (pool, 80, 80), dtype=torch.uint8, device=dev)
             self.probs = torch.empty((pool, classes), dtype=torch.float32, device=dev)
             self.table = torch.zeros((rows, tdist.HDR + classes), dtype=torch.int32, device=dev)
             self.table_host = torch.empty((world * rows, tdist.HDR + classes), dtype=torch.int32).pin_memory() if rank == 0 else None
@@ -117,7 +123,10 @@ def main():
         def detect(self):
             if self.hi is not None:
                 self.seg.set_stream(self.hi.cuda_stream)
-            self.seg.segment_device(frames.data_ptr(), B)
+            if rgb:
+                self.seg.segment_color_device(frames_c.data_ptr(), B, 4)
+            else:
+                self.seg.segment_device(frames.data_ptr(), B)
 
         def identify(self, step_idx):
             seg = self.seg
@@ -251,7 +260,7 @@ def main():
                                f"80x80x1 crops, {classes}-way V118_3 (random-init weights)",
                    "stages": "detect(bg-sub+threshold+CCL+filter+gather, tables->host) + crops(none) + identity CNN (V118_3) + per-blob ID table (all-gathered when N>1) -> rank-0 host"
                              if with_cnn else "detect only (bg-sub+threshold+CCL+filter+gather, tables->host)",
-                   "frames_per_step_per_gpu": B, "posture": bool(args.with_posture), "individual_image_normalization": args.normalize, "pipelined_lanes": len(lanes), "blobs_per_step_rank0": n_blobs, "parallelism": f"frame-sharded x{world}"},
+                   "frames_per_step_per_gpu": B, "encoding": args.encoding, "posture": bool(args.with_posture), "individual_image_normalization": args.normalize, "pipelined_lanes": len(lanes), "blobs_per_step_rank0": n_blobs, "parallelism": f"frame-sharded x{world}"},
     }
     seg_roof = {"kernel": "k_rows", "bound": "hbm", "achieved": seg_bytes / rows_s / 1e9 if rows_s else 0.0, "peak": 8000.0,
                 "unit": "GB/s", "frac": seg_bytes / rows_s / 8e12 if rows_s else 0.0, "traffic": pmc_traffic("trexhip::k_rows"),
