@@ -67,7 +67,6 @@ int main(int argc, char** argv) {
     const detect::BackendHooks* hooks = detect::backend(type);
     CHECK(hooks && hooks->init && hooks->apply && hooks->set_background && hooks->fps && hooks->deinit);
     hooks->init();
-
     oracle_params op; std::memset(&op, 0, sizeof(op));
     op.width = W; op.height = H; op.threshold = 15; op.threshold_maximum = 255; op.enable_difference = 1;
     op.absolute_difference = 1; op.zero_is_background = 1; op.connectivity = 8; op.closing_size = 3; op.cm_per_pixel = 1.0;
@@ -79,6 +78,32 @@ int main(int argc, char** argv) {
         bool threw = false;
         try { f.get(); } catch (const std::exception&) { threw = true; }
         CHECK(threw);
+    }
+    // the backend registers its pipeline PAUSED (BackgroundSubtraction.cpp:50-56): tiles enqueued through the manager -- what
+    // Detection::apply(TileImage&&) does (Detection.cpp:124-146) -- wait for the first background and are then served in order
+    {
+        auto& mgr = detect::pipeline_manager(type);
+        CHECK(mgr.is_paused());
+        std::vector<std::future<SegmentationData>> futs;
+        for (int k = 0; k < 3; ++k) {
+            std::vector<uint8_t> g(W * H, 100);
+            for (int x = 4 + k; x < 12 + k; ++x) g[7 * W + x] = 10;
+            TileImage tile; tile.images.push_back(gray_to_bgr(g, W, H, 3, rng, true));
+            tile.promise = std::make_unique<std::promise<SegmentationData>>();
+            futs.push_back(tile.promise->get_future());
+            mgr.enqueue(std::move(tile));
+        }
+        CHECK(mgr.pending() == 3);
+        CHECK(futs[0].wait_for(std::chrono::milliseconds(0)) != std::future_status::ready);
+        std::vector<uint8_t> bgq(W * H, 100);
+        auto b = cmn::Image::Make(H, W, 1); std::memcpy(b->data(), bgq.data(), bgq.size());
+        hooks->set_background(b);                                       // un-pauses the manager (BackgroundSubtraction.cpp:86-99)
+        CHECK(!mgr.is_paused() && mgr.pending() == 0);
+        for (int k = 0; k < 3; ++k) {
+            SegmentationData d = futs[k].get();
+            CHECK(d.frame.n() == 1);
+            CHECK((*d.frame.mask()[0])[0] == cmn::HorizontalLine(7, 4 + k, 11 + k));
+        }
     }
     std::vector<uint8_t> bg(W * H, 0);
     { auto b = cmn::Image::Make(H, W, 1); std::memcpy(b->data(), bg.data(), bg.size()); hooks->set_background(b); }
@@ -255,6 +280,7 @@ int main(int argc, char** argv) {
         trexhip_destroy(ctx);
     }
     hooks->deinit();
+    CHECK(detect::try_pipeline_manager(type) == nullptr);               // deinit unregisters the pipeline (BackgroundSubtraction.cpp:118-120)
 
     // --- identity facade: files written by the pytest wrapper: weights blob, crops, expected probabilities ---
     if (argc >= 4) {

@@ -15,10 +15,12 @@
 #include <core/TileImage.h>
 #include <core/TileBuffers.h>
 #include <python/BackendRegistry.h>
+#include <python/PipelineRegistry.h>
 #else
 #include "trex_types.h"
 #endif
 #include <chrono>
+#include <thread>
 #include <shared_mutex>
 #include <string>
 #include "../../include/trexhip.h"
@@ -66,6 +68,8 @@ struct HipBackgroundSubtraction {
         if (average->dims != 1) throw std::runtime_error("HipBackgroundSubtraction: background must be a gray image");
         check(trexhip_set_background(d.ctx, average->data(), (int32_t)average->cols));
         d.has_background = true;
+        g.unlock();
+        if (d.has_type) if (auto* m = detect::try_pipeline_manager(d.type)) m->set_paused(false);   // BackgroundSubtraction.cpp:86-99
     }
 
     // BackgroundSubtraction::apply(TileImage&&) (BackgroundSubtraction.cpp:107-116): synchronous variant of the
@@ -150,6 +154,11 @@ struct HipBackgroundSubtraction {
 
     static void deinit() {
         auto& d = data();
+        if (d.has_type) {                                              // BackgroundSubtraction::deinit (BackgroundSubtraction.cpp:118-120)
+            if (auto* m = detect::try_pipeline_manager(d.type)) m->clean_up();
+            detect::unregister_pipeline(d.type);
+            d.has_type = false;
+        }
         std::unique_lock g(d.gpu_mutex);
         if (d.ctx) { trexhip_destroy(d.ctx); d.ctx = nullptr; }
         d.has_background = false;
@@ -160,7 +169,17 @@ struct HipBackgroundSubtraction {
     // detect::register_backend(type, hooks) -- python/BackendRegistry.h:19; pattern of register_yolo_backend
     static void register_hip_backend(detect::ObjectDetectionType::Class type, const Settings& s, uint32_t w, uint32_t h) {
         detect::BackendHooks hooks;
-        hooks.init = [s, w, h]() { HipBackgroundSubtraction::init(s, w, h); };
+        // the constructor of BackgroundSubtraction registers the pipeline PAUSED and waits for the background inside the
+        // callback (BackgroundSubtraction.cpp:50-82); Detection::apply(TileImage&&) enqueues into that manager (Detection.cpp:124-146)
+        hooks.init = [s, w, h, type]() {
+            HipBackgroundSubtraction::init(s, w, h);
+            data().type = type; data().has_type = true;
+            detect::register_pipeline(type, (size_t)(s.max_batch > 0 ? s.max_batch : 1), /*start_paused=*/true, [type](std::vector<TileImage>&& images) {
+                auto* m = detect::try_pipeline_manager(type);
+                while (!data().has_background && m && !m->is_terminated()) std::this_thread::sleep_for(std::chrono::milliseconds(100));
+                if (!m || !m->is_terminated()) HipBackgroundSubtraction::apply(std::move(images));
+            });
+        };
         hooks.deinit = []() { HipBackgroundSubtraction::deinit(); };
         hooks.is_initializing = []() { return HipBackgroundSubtraction::is_initializing(); };
         hooks.fps = []() { return HipBackgroundSubtraction::fps(); };
@@ -176,6 +195,8 @@ private:
     struct Data {
         trexhip_ctx* ctx = nullptr;
         Settings settings;
+        detect::ObjectDetectionType::Class type{};
+        bool has_type = false;
         cmn::meta_encoding_t context_encoding = cmn::meta_encoding_t::gray;
         bool has_background = false;
         double time = 0, samples = 0;

@@ -9,6 +9,7 @@
 //   SegmentationData       Application/src/tracker/core/TaskPipeline.h:87-118
 //   TileImage              Application/src/tracker/core/TileImage.h:33-75, TileImage.cpp:13-21 (dtor contract)
 //   detect::BackendHooks   Application/src/tracker/python/BackendRegistry.h:10-24
+//   PipelineManager / register_pipeline  Application/src/tracker/core/TaskPipeline.h:200-330, python/PipelineRegistry.h:12-33 (synchronous stand-in)
 //   track::Outline/Midline/MidlineSegment  Application/src/tracker/tracking/Outline.h:241-300 (members used by HipPosture.h only)
 #pragma once
 #include <cstdint>
@@ -157,6 +158,48 @@ inline std::map<int, BackendHooks>& registry() { static std::map<int, BackendHoo
 inline void register_backend(ObjectDetectionType::Class type, BackendHooks hooks) { registry()[type] = std::move(hooks); }   // BackendRegistry.cpp:23-25
 inline void unregister_backend(ObjectDetectionType::Class type) { registry().erase(type); }
 inline const BackendHooks* backend(ObjectDetectionType::Class type) { auto it = registry().find(type); return it == registry().end() ? nullptr : &it->second; }
+}  // namespace track::detect
+
+// PipelineManager<Data> (core/TaskPipeline.h): collects enqueued items into batches and hands them to the backend's callback
+// on a worker thread; `paused` holds them back until the backend is ready.  This stand-in keeps the same interface and
+// ordering but runs the callback synchronously inside enqueue() / set_paused(false).
+template <typename Data>
+class PipelineManager {
+public:
+    PipelineManager(size_t batch_size, bool start_paused, std::function<void(std::vector<Data>&&)> cb)
+        : _batch(batch_size ? batch_size : 1), _paused(start_paused), _cb(std::move(cb)) {}
+    void enqueue(Data&& d) { _queue.emplace_back(std::move(d)); if (!_paused) flush(); }
+    void set_paused(bool v) { _paused = v; if (!_paused) flush(); }
+    bool is_paused() const { return _paused; }
+    bool is_terminated() const { return _terminated; }
+    void terminate() { _terminated = true; }
+    void clean_up() { _queue.clear(); }
+    size_t pending() const { return _queue.size(); }
+private:
+    void flush() {
+        while (!_queue.empty() && !_terminated) {
+            std::vector<Data> batch;
+            while (!_queue.empty() && batch.size() < _batch) { batch.emplace_back(std::move(_queue.front())); _queue.erase(_queue.begin()); }
+            _cb(std::move(batch));
+        }
+    }
+    size_t _batch; bool _paused, _terminated = false;
+    std::function<void(std::vector<Data>&&)> _cb;
+    std::vector<Data> _queue;
+};
+
+namespace track::detect {
+inline std::map<int, std::unique_ptr<PipelineManager<TileImage>>>& pipelines() { static std::map<int, std::unique_ptr<PipelineManager<TileImage>>> m; return m; }
+inline void register_pipeline(ObjectDetectionType::Class type, size_t batch_size, bool start_paused, std::function<void(std::vector<TileImage>&&)> cb) {   // PipelineRegistry.h:12-16
+    pipelines()[type] = std::make_unique<PipelineManager<TileImage>>(batch_size, start_paused, std::move(cb));
+}
+inline void unregister_pipeline(ObjectDetectionType::Class type) { pipelines().erase(type); }                                                                // :19
+inline PipelineManager<TileImage>* try_pipeline_manager(ObjectDetectionType::Class type) { auto it = pipelines().find(type); return it == pipelines().end() ? nullptr : it->second.get(); }
+inline PipelineManager<TileImage>& pipeline_manager(ObjectDetectionType::Class type) {                                                                        // :22
+    auto* m = try_pipeline_manager(type);
+    if (!m) throw std::runtime_error("no pipeline registered for this detection type");
+    return *m;
+}
 }  // namespace track::detect
 
 namespace track {
