@@ -308,6 +308,17 @@ int main(int argc, char** argv) {
         CHECK(worst <= 1e-4);
         auto flat = HipVINetwork::transform_results(n + 2, indexes, values);
         CHECK(flat.size() == (n + 2) * C && flat[(n + 1) * C] == -1.f && flat[0] == values[0][0]);
+        {   // synchronous probabilities + paverages (VisualIdentification.h:110-180)
+            std::vector<cmn::Image::Ptr> again;
+            for (size_t i = 0; i < n; ++i) { auto im = cmn::Image::Make(80, 80, 1); std::memcpy(im->data(), crops.data() + i * 6400, 6400); again.emplace_back(std::move(im)); }
+            std::vector<int> ids(n);
+            for (size_t i = 0; i < n; ++i) ids[i] = (int)(i % 2);
+            auto av = net.paverages(ids, std::move(again));
+            CHECK(av.size() == 2 && av[0].values.size() == (size_t)C && av[0].samples + av[1].samples == (float)n);
+            double m0 = 0; int c0 = 0;
+            for (size_t i = 0; i < n; i += 2) { m0 += e[i * C + 0]; ++c0; }
+            CHECK(std::fabs(av[0].values[0] - m0 / c0) <= 1e-4);
+        }
         CHECK(HipVINetwork::batch_size_for(8) == 64 && HipVINetwork::batch_size_for(100) == 128 && HipVINetwork::batch_size_for(65) == 128);
         {   // wrong crop size
             std::vector<cmn::Image::Ptr> bad; bad.push_back(cmn::Image::Make(64, 64, 1));

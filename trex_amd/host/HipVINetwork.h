@@ -13,6 +13,7 @@
 #endif
 #include <functional>
 #include <future>
+#include <map>
 #include <string>
 #include <vector>
 #include "../../include/trexhip.h"
@@ -81,6 +82,33 @@ struct HipVINetwork {
             if (idx < n_images) std::copy(values[i].begin(), values[i].end(), out.begin() + idx * M);
         }
         return out;
+    }
+
+    // synchronous form (VisualIdentification.h:110-133): N x M flat, rows of images without a result are -1
+    std::vector<float> probabilities(std::vector<cmn::Image::Ptr>&& images) {
+        const size_t N = images.size();
+        std::vector<float> flat;
+        probabilities(std::move(images), [&](std::vector<std::vector<float>>&& values, std::vector<float>&& indexes) {
+            flat = transform_results(N, indexes, values);
+        }).get();
+        return flat;
+    }
+
+    // VINetwork::paverages (VisualIdentification.h:145-180): mean probability row per individual id over its images
+    struct Average { float samples = 0; std::vector<float> values; };
+    template <typename Idx>
+    std::map<Idx, Average> paverages(const std::vector<Idx>& ids, std::vector<cmn::Image::Ptr>&& images) {
+        const auto probs = probabilities(std::move(images));
+        const size_t M = (size_t)num_classes();
+        std::map<Idx, Average> averages;
+        for (size_t i = 0; i < ids.size() && (i + 1) * M <= probs.size(); ++i) {
+            Average& av = averages[ids[i]];
+            if (av.values.empty()) av.values.assign(M, 0.f);
+            ++av.samples;
+            for (size_t k = 0; k < M; ++k) av.values[k] += probs[i * M + k];
+        }
+        for (auto& kv : averages) for (float& v : kv.second.values) v /= kv.second.samples;
+        return averages;
     }
 
 private:
