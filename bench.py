@@ -273,12 +273,12 @@ def main():
         fl = FLOP_PER_CROP_CONV3 * n_blobs
         nprod = {"fp32": 1, "bf16x6": 6, "bf16x3": 3, "fp16x3": 3}[args.cnn_mode]
         peak = 157.3 if args.cnn_mode == "fp32" else 2500.0
-        kname = "k_conv5<64,128,20,20,32> (conv3, fp32 MFMA)" if args.cnn_mode == "fp32" else (f"k_conv5_stream<64,128,20,20,8> (conv3, fp16 MFMA x{nprod} per fp32 product)" if args.cnn_mode == "fp16x3" else f"k_conv5_split<64,128,20,20,{args.cnn_mode}> (conv3, 16-bit MFMA x{nprod} per fp32 product)")
+        kname = "k_conv5<64,128,20,20,32> (conv3, fp32 MFMA)" if args.cnn_mode == "fp32" else (f"k_conv5_stream<64,128,20,20,8,persistent> (conv3, fp16 MFMA x{nprod} per fp32 product)" if args.cnn_mode == "fp16x3" else f"k_conv5_split<64,128,20,20,{args.cnn_mode}> (conv3, 16-bit MFMA x{nprod} per fp32 product)")
         out["roofline"] = {"kernel": kname, "bound": "mfma", "achieved": fl / c3_s / 1e12 if c3_s else 0.0,
                            "peak": peak, "unit": "TFLOP/s", "frac": fl / c3_s / (peak * 1e12) if c3_s else 0.0,
                            "mfma_products_per_algorithmic_product": nprod,
                            "mfma_issue_frac": nprod * fl / c3_s / (peak * 1e12) if c3_s else 0.0,
-                           "traffic": pmc_traffic("trexhip::k_conv5_stream<64, 128, 20, 20, 8>") if args.cnn_mode == "fp16x3" else None,
+                           "traffic": pmc_traffic("trexhip::k_conv5_stream<64, 128, 20, 20, 8") if args.cnn_mode == "fp16x3" else None,
                            "traffic_note": "HBM bytes/launch from profiles/r01_pmc_summary.json (FETCH_SIZE x2 + WRITE_SIZE); algorithmic bytes = 0.98 GB (activations in+out)",
                            "avg_launch_us": c3_s * 1e6, "launches": prof["CONV3"][1], "algorithmic_flop_per_launch": fl,
                            "peak_note": "achieved counts ALGORITHMIC flops (2 per fp32 multiply-add); peak is the dense MFMA peak of the instruction used (fp32: 157.3, bf16: 2500 TFLOP/s, MI355X_MICROARCH.md); in the split modes every algorithmic product costs `mfma_products_per_algorithmic_product` bf16 MFMA products, so the matrix pipe is busy mfma_issue_frac of its peak"}
