@@ -14,5 +14,5 @@ for it in range(3):
     seg.segment_device(frames.data_ptr(), B); seg.synchronize()
     buf = (C.c_ulonglong * 16)()
     L.trexhip_debug_read(seg.handle, buf, 16)
-    v = list(buf)[:9]
-    print([v[i + 1] - v[i] for i in range(8)], "total", v[8] - v[0])
+    v = list(buf)[:10]
+    print([v[i + 1] - v[i] for i in range(8)], "total", v[8] - v[0], "| P7b: setup+scatter", v[9] - v[7], "rank+write", v[8] - v[9])

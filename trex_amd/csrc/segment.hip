@@ -806,21 +806,59 @@ __global__ __launch_bounds__(1024) void k_ccl_lds(const SegCfg c, const uint32_t
             s_key[s_key[CCL_NMAX + k] + slot] = r;               // segment storage: s_key[0 .. kruns)
         }
         __syncthreads();
+        CCL_STAMP(9);
+        // (2) every blob's segment is sorted by raster index: an in-register bitonic network per blob -- two blobs per wave (32
+        //     lanes each) when both have at most 32 lines, one per wave up to 64 lines, rank-by-counting through LDS beyond that
         const uint32_t lane = tid & 63, wave = tid >> 6;
-        for (uint32_t k = wave; k < kept; k += 16) {
-            const uint32_t beg = s_key[CCL_NMAX + k], cntk = s_cursor[k];
-            for (uint32_t e0 = 0; e0 < cntk; e0 += 64) {
-                const uint32_t e = e0 + lane;
-                const uint32_t mine = e < cntk ? s_key[beg + e] : 0xffffffffu;
-                uint32_t rank = 0;
-                if (cntk <= 64u) { for (uint32_t t = 0; t < cntk; ++t) rank += (uint32_t)__builtin_amdgcn_readlane((int)mine, (int)t) < mine ? 1u : 0u; }
-                else             { for (uint32_t t = 0; t < cntk; ++t) rank += s_key[beg + t] < mine ? 1u : 0u; }
-                if (e < cntk) {
-                    trexhip_run q; q.x0 = (uint16_t)(s_run[mine] & 0xffffu); q.x1 = (uint16_t)(s_run[mine] >> 16); q.y = s_y[mine]; q.pad = 0;
-                    outr[beg + rank] = q;
+#define CCL_SORT_STEP(kk_, jj_) { const uint32_t o_ = (uint32_t)__shfl_xor((int)v, jj_); const bool lo_ = ((lane & (jj_)) == 0) == ((lane & (kk_)) == 0); v = lo_ ? min(v, o_) : max(v, o_); }
+#define CCL_SORT32(v)                                                                                                   \
+        CCL_SORT_STEP(2, 1) CCL_SORT_STEP(4, 2) CCL_SORT_STEP(4, 1) CCL_SORT_STEP(8, 4) CCL_SORT_STEP(8, 2) CCL_SORT_STEP(8, 1)    \
+        CCL_SORT_STEP(16, 8) CCL_SORT_STEP(16, 4) CCL_SORT_STEP(16, 2) CCL_SORT_STEP(16, 1)                                        \
+        CCL_SORT_STEP(32, 16) CCL_SORT_STEP(32, 8) CCL_SORT_STEP(32, 4) CCL_SORT_STEP(32, 2) CCL_SORT_STEP(32, 1)
+        auto emit = [&](uint32_t beg, uint32_t e, uint32_t cntk, uint32_t r) {
+            if (e < cntk) {
+                trexhip_run q; q.x0 = (uint16_t)(s_run[r] & 0xffffu); q.x1 = (uint16_t)(s_run[r] >> 16); q.y = s_y[r]; q.pad = 0;
+                outr[beg + e] = q;
+            }
+        };
+        for (uint32_t k0 = wave * 2; k0 < kept; k0 += 32) {
+            const uint32_t cA = s_cursor[k0], cB = k0 + 1 < kept ? s_cursor[k0 + 1] : 0u;
+            if (cA <= 32u && cB <= 32u) {
+                const uint32_t k = k0 + (lane >> 5), e = lane & 31u;
+                const bool live = k < kept;
+                const uint32_t beg = live ? s_key[CCL_NMAX + k] : 0u, cntk = live ? (lane < 32 ? cA : cB) : 0u;
+                uint32_t v = e < cntk ? s_key[beg + e] : 0xffffffffu;
+                // lanes 32..63 sort ascending as well: the direction bit of the last stage (lane & 32) is flipped for them
+                CCL_SORT_STEP(2, 1) CCL_SORT_STEP(4, 2) CCL_SORT_STEP(4, 1) CCL_SORT_STEP(8, 4) CCL_SORT_STEP(8, 2) CCL_SORT_STEP(8, 1)
+                CCL_SORT_STEP(16, 8) CCL_SORT_STEP(16, 4) CCL_SORT_STEP(16, 2) CCL_SORT_STEP(16, 1)
+                { const uint32_t o_ = (uint32_t)__shfl_xor((int)v, 16); v = (lane & 16) == 0 ? min(v, o_) : max(v, o_); }
+                { const uint32_t o_ = (uint32_t)__shfl_xor((int)v, 8);  v = (lane & 8) == 0 ? min(v, o_) : max(v, o_); }
+                { const uint32_t o_ = (uint32_t)__shfl_xor((int)v, 4);  v = (lane & 4) == 0 ? min(v, o_) : max(v, o_); }
+                { const uint32_t o_ = (uint32_t)__shfl_xor((int)v, 2);  v = (lane & 2) == 0 ? min(v, o_) : max(v, o_); }
+                { const uint32_t o_ = (uint32_t)__shfl_xor((int)v, 1);  v = (lane & 1) == 0 ? min(v, o_) : max(v, o_); }
+                emit(beg, e, cntk, v);
+            } else {
+                for (uint32_t k = k0; k < k0 + 2 && k < kept; ++k) {
+                    const uint32_t beg = s_key[CCL_NMAX + k], cntk = k == k0 ? cA : cB;
+                    if (cntk <= 64u) {
+                        uint32_t v = lane < cntk ? s_key[beg + lane] : 0xffffffffu;
+                        CCL_SORT32(v)
+                        CCL_SORT_STEP(64, 32) CCL_SORT_STEP(64, 16) CCL_SORT_STEP(64, 8) CCL_SORT_STEP(64, 4) CCL_SORT_STEP(64, 2) CCL_SORT_STEP(64, 1)
+                        emit(beg, lane, cntk, v);
+                    } else {
+                        for (uint32_t e0 = 0; e0 < cntk; e0 += 64) {
+                            const uint32_t e = e0 + lane;
+                            const uint32_t mine = e < cntk ? s_key[beg + e] : 0xffffffffu;
+                            uint32_t rank = 0;
+                            for (uint32_t t = 0; t < cntk; ++t) rank += s_key[beg + t] < mine ? 1u : 0u;
+                            if (e < cntk) emit(beg, rank, cntk, mine);
+                        }
+                    }
                 }
             }
         }
+#undef CCL_SORT32
+#undef CCL_SORT_STEP
     } else {
         uint32_t sn = 64;
         while (sn < n) sn <<= 1;
