@@ -41,7 +41,7 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--config", default="C4")
-    ap.add_argument("--batch", type=int, default=0, help="frames resident per step (default 64, C5: 16)")
+    ap.add_argument("--batch", type=int, default=0, help="frames resident in HBM per step (default 256, C5: 64): large batches amortise the latency-bound labelling / gather stages (one workgroup per frame) over the HBM-bound pixel pass")
     ap.add_argument("--stages", default="all", choices=["all", "segment"])
     ap.add_argument("--cnn-mode", default="fp16x3", choices=["fp32", "bf16x6", "bf16x3", "fp16x3"],
                     help="arithmetic of conv2/conv3: fp16x3 = 2-piece fp16 split, fp32-class error, range-guarded (default); bf16x6 = 3-piece bf16 split; fp32 = exact fp32 MFMA")
@@ -76,7 +76,7 @@ def main():
     dev = torch.device("cuda", local)
 
     W, H, n_ind, _cid = synth.CONFIGS[args.config]
-    B = args.batch or (16 if args.config == "C5" else 64)
+    B = args.batch or (64 if args.config == "C5" else 256)
     classes = 256 if args.config == "C5" else 100
     with_cnn = args.stages == "all"
 
@@ -231,9 +231,9 @@ def main():
 
     def pmc_traffic(kernel_prefix):
         """HBM bytes per launch from the committed PMC pass of this same command (profiles/r01_pmc_summary.json);
-        only valid for the default C4 / 64-frame workload it was collected on, else null."""
+        only valid for the default C4 / 256-frame workload it was collected on, else null."""
         try:
-            if args.config != "C4" or B != 64:
+            if args.config != "C4" or B != 256:
                 return None
             j = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_summary.json")))
             for k, v in j["kernels"].items():
