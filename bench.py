@@ -54,6 +54,7 @@ def main():
     ap.add_argument("--lanes", type=int, default=2, help="software-pipeline depth: contexts whose batches are in flight (detect of batch i+L-1 is issued while the identity network works on batch i)")
     ap.add_argument("--no-detect-priority", dest="detect_priority", action="store_false",
                     help="keep the detect stage on the lane's own stream (default: a high-priority stream per lane, so that its short kernels get compute units as soon as the other lane's identity network frees some)")
+    ap.add_argument("--force-dist", action="store_true", help="dev: run the torch.distributed (RCCL) code path even with a single rank")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     args = ap.parse_args()
@@ -68,11 +69,14 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    use_dist = world > 1 or args.force_dist
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+        os.environ.setdefault("MASTER_PORT", "29577")
     assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback)"
     torch.cuda.set_device(local)
+    if use_dist:       # one process per GPU; backend "nccl" is RCCL over xGMI on ROCm
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
     dev = torch.device("cuda", local)
 
     W, H, n_ind, _cid = synth.CONFIGS[args.config]
@@ -152,7 +156,7 @@ def main():
                 frame_base = (step_idx * world + rank) * B
                 seg.export_id_table(self.probs.data_ptr(), n, classes, frame_base, self.table.data_ptr(), rows)
                 with torch.cuda.stream(self.stream):
-                    g = tdist.all_gather_tables(self.table) if world > 1 else self.table
+                    g = tdist.all_gather_tables(self.table) if use_dist else self.table
                     if rank == 0:
                         self.table_host.copy_(g, non_blocking=True)
             else:
@@ -193,7 +197,7 @@ def main():
 
     def barrier():
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -205,7 +209,7 @@ def main():
     n_blobs = run(args.steps)
     barrier()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -329,7 +333,7 @@ def main():
         print(json.dumps(out))
     for ln in lanes:
         ln.seg.close()
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 
