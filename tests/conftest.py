@@ -26,3 +26,13 @@ def pytest_collection_modifyitems(config, items):
     for item in items:
         if "gpu" in item.keywords:
             item.add_marker(skip)
+
+
+@pytest.fixture(scope="session", autouse=True)
+def _built_libraries():
+    """The suites need libtrexhip.so and the oracle library: build them (seconds, cross-compiles without a GPU) when the tree
+    is fresh, e.g. when the tests run before __graft_entry__.build()."""
+    if not (os.path.exists(os.path.join(ROOT, "trex_amd", "libtrexhip.so")) and os.path.exists(os.path.join(ROOT, "oracle", "liboracle.so"))):
+        import __graft_entry__ as entry
+        entry.build()
+    yield
