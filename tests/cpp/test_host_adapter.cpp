@@ -193,7 +193,8 @@ int main(int argc, char** argv) {
         s2.meta_encoding = cmn::meta_encoding_t::rgb8;
         HipBackgroundSubtraction::init(s2, W, H);
         std::vector<uint8_t> bg2(W * H, 120);
-        auto b = cmn::Image::Make(H, W, 1); std::memcpy(b->data(), bg2.data(), bg2.size()); HipBackgroundSubtraction::set_background(b);
+        auto b = cmn::Image::Make(H, W, 1); std::memcpy(b->data(), bg2.data(), bg2.size());
+        HipBackgroundSubtraction::set_background(gray_to_bgr(bg2, W, H, 3, rng, true));      // a colour average is reduced to grey like the frames
         std::vector<uint8_t> dummy(W * H, 120);
         TileImage tile; tile.images.push_back(gray_to_bgr(dummy, W, H, 4, rng, true));
         uint8_t* im = tile.images[0]->data();
