@@ -971,42 +971,28 @@ __global__ __launch_bounds__(256) void k_gather(const SegCfg c, const int only_p
                 const uint8_t* src = img + (size_t)q.y * c.W;
                 const uint64_t y = q.y;
                 uint64_t rp = 0;                                       // sum of grey values of this run
-                // 8 pixels per step: the byte loads of a step are independent, so a run costs len/8 memory round trips, not len
+                // 8 pixels per step: the byte loads of a step are independent, so a run costs len/8 memory round trips, not len;
+                // the sums of one step fit 32 bits (8 * 8191^2 < 2^30) and are widened once per step
                 uint32_t x = q.x0;
-                for (; x + 7 <= (uint32_t)q.x1; x += 8) {
+                for (; x <= (uint32_t)q.x1; x += 8) {
+                    const uint32_t rem = min(8u, (uint32_t)q.x1 + 1u - x);
                     uint32_t v[8];
 #pragma unroll
-                    for (int k = 0; k < 8; ++k) v[k] = src[x + k];
+                    for (int k = 0; k < 8; ++k) v[k] = (uint32_t)k < rem ? src[x + k] : 0u;
+                    uint32_t s10 = 0, s20 = 0, sp_ = 0, spx_ = 0;
 #pragma unroll
                     for (int k = 0; k < 8; ++k) {
-                        uint32_t p = v[k];
-                        if (c.invert) p = 255u - p;
-                        const uint32_t xx = x + k;
-                        if (!enc) px[off + k] = (uint8_t)p;
-                        else store_colour(px, off + k, cimg + ((size_t)q.y * c.W + xx) * color_ch, enc);
-                        m10 += xx; m20 += (uint64_t)xx * xx;
-                        rp += p; spx += (uint64_t)p * xx;
-                        pmin = min(pmin, p); pmax = max(pmax, p);
-                    }
-                    off += 8;
-                }
-                {
-                    uint32_t v[8];
-                    const uint32_t rem = (uint32_t)q.x1 + 1u - x;          // 0..7 pixels left
-#pragma unroll
-                    for (int k = 0; k < 7; ++k) v[k] = (uint32_t)k < rem ? src[x + k] : 0u;
-#pragma unroll
-                    for (int k = 0; k < 7; ++k) {
                         if ((uint32_t)k >= rem) break;
                         uint32_t p = v[k];
                         if (c.invert) p = 255u - p;
                         const uint32_t xx = x + k;
                         if (!enc) px[off + k] = (uint8_t)p;
                         else store_colour(px, off + k, cimg + ((size_t)q.y * c.W + xx) * color_ch, enc);
-                        m10 += xx; m20 += (uint64_t)xx * xx;
-                        rp += p; spx += (uint64_t)p * xx;
+                        s10 += xx; s20 += xx * xx;
+                        sp_ += p; spx_ += p * xx;
                         pmin = min(pmin, p); pmax = max(pmax, p);
                     }
+                    m10 += s10; m20 += s20; rp += sp_; spx += spx_;
                     off += rem;
                 }
                 const uint64_t L = len;
@@ -1105,7 +1091,7 @@ int launch_segment(trexhip_ctx* ctx, const uint8_t* d_frames, int n) {
         hipLaunchKernelGGL(k_ccl_lds, dim3(f1 - f0), dim3(1024), CCL_LDS_BYTES, t, c, ctx->d_ctr, ctx->d_row_cnt, ctx->d_row_off, ctx->d_row_base,
                            ctx->d_tmp_runs, ctx->d_raster, ctx->d_parent, ctx->d_root_ord, ctx->d_cur_run, ctx->d_pix_begin, ctx->d_blob_map,
                            totals, ctx->d_info, ctx->d_blobs, ctx->d_blob_frame, ctx->d_runs, ctx->tune_ccl_stop, reinterpret_cast<unsigned long long*>(ctx->d_cnt_px), f0);
-        hipLaunchKernelGGL(k_gather, dim3(G > 1 ? 256 : 1024), dim3(256), 0, t, c, 0, d_frames, totals, ctx->d_info, ctx->d_blob_frame,
+        hipLaunchKernelGGL(k_gather, dim3(G > 1 ? 256 : 2048), dim3(256), 0, t, c, 0, d_frames, totals, ctx->d_info, ctx->d_blob_frame,
                            ctx->d_blobs, ctx->d_runs, ctx->d_pixels, (uint32_t)f0, (uint32_t)f1, ctx->d_color_src, ctx->color_ch, ctx->p.pixel_encoding);
     }
     if (G > 1) {
