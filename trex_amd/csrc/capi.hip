@@ -430,6 +430,7 @@ int trexhip_fetch_rethreshold(trexhip_ctx* ctx, trexhip_batch_result* out) {
     if (tr) TH_CHECK_HIP(hipMemcpyAsync(q.h_runs, q.d_runs, sizeof(trexhip_run) * tr, hipMemcpyDeviceToHost, s));
     if (tp) TH_CHECK_HIP(hipMemcpyAsync(q.h_pixels, q.d_pixels, (size_t)tp * ctx->pix_ch, hipMemcpyDeviceToHost, s));
     TH_CHECK_HIP(hipStreamSynchronize(s));
+    q.fetched = true;
     out->total_blobs = tb; out->total_runs = tr; out->total_pixels = tp;
     for (int i = 0; i < n; ++i)
         if (q.h_info[i].flags) { set_error("a frame exceeded capacity during re-threshold: raise max_runs/max_blobs/max_pixels"); return TREXHIP_E_CAPACITY; }

@@ -54,6 +54,7 @@ namespace trexhip {
 struct Pass2 {
     bool allocated = false;
     int valid_n = 0;
+    bool fetched = false;               // the host tables below hold the last re-threshold batch
     uint32_t *d_sub_cnt = nullptr, *d_sub_base = nullptr, *d_row_base = nullptr, *d_row_cnt = nullptr, *d_run_parent = nullptr;
     trexhip_run* d_raster = nullptr;
     uint32_t *d_parent = nullptr, *d_root_ord = nullptr, *d_cnt_runs = nullptr, *d_cnt_px = nullptr, *d_cur_run = nullptr,

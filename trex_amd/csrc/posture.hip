@@ -19,11 +19,14 @@ static constexpr int P_NP = 1024;      // largest max_points
 static constexpr int P_NR = 512;       // runs per blob held in LDS
 static constexpr int P_ROWS = 254;     // rows per blob
 // bytes of LDS per wave for a given point capacity: two point buffers, curvature, arc length, runs, row table
-__host__ __device__ constexpr int posture_wave_lds(int np) { return np * 8 * 2 + np * 4 * 2 + P_NR * 4 + (P_ROWS + 2) * 4; }
+// (nr / nrows = line and row capacity of this launch: the host sizes them to the largest blob of the fetched table, so that more
+// blobs fit into a CU's LDS -- the kernel is a chain of LDS / memory latencies and lives on the number of blobs in flight)
+__host__ __device__ constexpr int posture_wave_lds(int np, int nr, int nrows) { return np * 8 * 2 + np * 4 * 2 + nr * 4 + (nrows + 2) * 4; }
 
 struct PostureCfg {
     float outline_resample; int smooth_samples, smooth_step, approximate;
     float curvature_range_ratio, midline_walk_offset; int max_points;
+    int nr_cap, rows_cap;            // <= P_NR, P_ROWS
 };
 
 __device__ __forceinline__ float wsum(float v) {
@@ -51,13 +54,13 @@ __global__ __launch_bounds__(256) void k_posture(const PostureCfg P, const trexh
     const int bi = blockIdx.x * 4 + wave;
     if (bi >= n_blobs) return;
     const int NPc = P.max_points;                           // point capacity = LDS layout stride
-    uint8_t* base = plds + (size_t)wave * posture_wave_lds(NPc);
+    uint8_t* base = plds + (size_t)wave * posture_wave_lds(NPc, P.nr_cap, P.rows_cap);
     float2* bufA = reinterpret_cast<float2*>(base);
     float2* bufB = bufA + NPc;
     float* s_curv = reinterpret_cast<float*>(bufB + NPc);
     float* s_t = s_curv + NPc;
     uint32_t* s_runs = reinterpret_cast<uint32_t*>(s_t + NPc);
-    int* s_row = reinterpret_cast<int*>(s_runs + P_NR);
+    int* s_row = reinterpret_cast<int*>(s_runs + P.nr_cap);
 
     trexhip_posture_info res = {};
     const int cap = NPc;
@@ -69,7 +72,7 @@ __global__ __launch_bounds__(256) void k_posture(const PostureCfg P, const trexh
     const trexhip_blob Bl = blobs[bi];
     const int n_runs = (int)Bl.n_runs, y0 = Bl.y0, y1 = Bl.y1, rows = y1 - y0 + 1;
     if (n_runs == 0) { if (lane == 0) { res.status = 1; out_info[bi] = res; } return; }
-    if (n_runs > P_NR || rows > P_ROWS) { if (lane == 0) { res.status = 2; out_info[bi] = res; } return; }
+    if (n_runs > P.nr_cap || rows > P.rows_cap) { if (lane == 0) { res.status = 2; out_info[bi] = res; } return; }
     const trexhip_run* rr = runs + fi.run_begin + Bl.run_begin;
     for (int i = lane; i < n_runs; i += 64) {
         const trexhip_run q = rr[i];
@@ -384,14 +387,34 @@ extern "C" int trexhip_posture_device(trexhip_ctx* ctx, int32_t table, const tre
         info = ctx->pass2.d_info; bf = ctx->pass2.d_blob_frame; bl = ctx->pass2.d_blobs; ru = ctx->pass2.d_runs;
     } else if (table != 0) { set_error("trexhip_posture_device: table must be 0 (detect) or 1 (re-threshold)"); return TREXHIP_E_INVALID; }
     TH_CHECK_HIP(hipSetDevice(ctx->p.device));
-    const int lds_bytes = 4 * posture_wave_lds(pp->max_points);
+    // line / row capacity of this launch from the fetched host tables (full capacity when they are not at hand)
+    int nr_cap = P_NR, rows_cap = P_ROWS;
+    {
+        const trexhip_blob* hb = table == 0 ? ctx->h_blobs : ctx->pass2.h_blobs;
+        const bool fetched = table == 0 ? ctx->fetched : ctx->pass2.fetched;
+        if (hb && fetched) {
+            uint32_t mr = 1, mrows = 1;
+            for (int i = 0; i < n_blobs; ++i) {
+                const trexhip_blob& b = hb[i];
+                if (b.n_runs <= (uint32_t)P_NR && (uint32_t)(b.y1 - b.y0 + 1) <= (uint32_t)P_ROWS) {   // larger ones report status 2 anyway
+                    mr = b.n_runs > mr ? b.n_runs : mr;
+                    const uint32_t rws = (uint32_t)(b.y1 - b.y0 + 1);
+                    mrows = rws > mrows ? rws : mrows;
+                }
+            }
+            nr_cap = (int)((mr + 31u) & ~31u); rows_cap = (int)((mrows + 29u) / 32u * 32u + 30u);      // (rows_cap + 2) * 4 stays 16-byte friendly
+            if (nr_cap > P_NR) nr_cap = P_NR;
+            if (rows_cap > P_ROWS) rows_cap = P_ROWS;
+        }
+    }
+    const int lds_bytes = 4 * posture_wave_lds(pp->max_points, nr_cap, rows_cap);
     static int attr_bytes = 0;
     if (lds_bytes > attr_bytes) {
         TH_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_posture), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
         attr_bytes = lds_bytes;
     }
     PostureCfg P{pp->outline_resample, pp->outline_smooth_samples, pp->outline_smooth_step, pp->outline_approximate,
-                 pp->outline_curvature_range_ratio, pp->midline_walk_offset, pp->max_points};
+                 pp->outline_curvature_range_ratio, pp->midline_walk_offset, pp->max_points, nr_cap, rows_cap};
     stage_begin(ctx, TREXHIP_STAGE_POSTURE);
     hipLaunchKernelGGL(k_posture, dim3((n_blobs + 3) / 4), dim3(256), lds_bytes, ctx->stream, P, info, bf, bl, ru, n_blobs, ctx->last_n,
                        reinterpret_cast<float2*>(d_outline), reinterpret_cast<float4*>(d_segments), d_info);

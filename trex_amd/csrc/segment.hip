@@ -1104,6 +1104,7 @@ int launch_segment(trexhip_ctx* ctx, const uint8_t* d_frames, int n) {
     ctx->last_n = n;
     ctx->fetched = false;
     ctx->pass2.valid_n = 0;
+    ctx->pass2.fetched = false;
     return TREXHIP_OK;
 }
 
@@ -1276,6 +1277,7 @@ int launch_rethreshold(trexhip_ctx* ctx, int thr, int method, const double* rang
                        q.d_runs, q.d_pixels, 0u, (uint32_t)n, ctx->d_color_src, ctx->color_ch, ctx->p.pixel_encoding);
     TH_CHECK_HIP(hipGetLastError());
     q.valid_n = n;
+    q.fetched = false;
     return TREXHIP_OK;
 }
 
