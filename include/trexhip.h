@@ -158,9 +158,9 @@ int trexhip_segment_color(trexhip_ctx* ctx, const uint8_t* const* frames, int32_
                           int32_t channels, int32_t color_channel);
 /* the same for n contiguous colour frames already in HBM ([n][height][width][channels]) */
 int trexhip_segment_color_device(trexhip_ctx* ctx, const uint8_t* d_color_frames, int32_t n, int32_t channels, int32_t color_channel);
+int trexhip_pixel_channels(trexhip_ctx* ctx);   /* bytes per pixel of the pixel arrays and channels of the crops: 1 or 3 (rgb8) */
 /* device buffers for callers that do not link the HIP runtime themselves (the C++ adapters in trex_amd/host): plain
  * hipMalloc / hipFree / stream-ordered device-to-host copy (synchronous on return) on the context's device and stream */
-int trexhip_pixel_channels(trexhip_ctx* ctx);   /* bytes per pixel of the pixel arrays and channels of the crops: 1 or 3 (rgb8) */
 int trexhip_device_alloc(trexhip_ctx* ctx, size_t bytes, void** out_device_ptr);
 int trexhip_device_free(trexhip_ctx* ctx, void* device_ptr);
 int trexhip_copy_to_host(trexhip_ctx* ctx, void* host_dst, const void* device_src, size_t bytes);
@@ -188,8 +188,9 @@ int trexhip_fetch_rethreshold(trexhip_ctx* ctx, trexhip_batch_result* out);
 /* ---- posture (outline -> midline) -----------------------------------------------------------------
  * posture::calculate_posture (tracking/Posture.cpp:305-399) for every blob of a table of the last batch
  * (table 0 = detect blobs, 1 = re-thresholded sub-blobs, i.e. the caller picks track_posture_threshold through
- * trexhip_rethreshold_device; the reference's retry loop "threshold += 2 until a midline is found" is the caller's:
- * call again with a higher threshold for the blobs whose status is not 0).
+ * trexhip_rethreshold_device).  One pass per call: the reference's retry loop "threshold += 2 until a midline is found"
+ * (:331-381) only ever re-runs blobs too small for a midline and ends in its first-outline fallback, which is what one pass
+ * returns for them (status 3 / 4 with the outline) -- shown on the CPU restatement, tests/test_posture_oracle.py.
  * Outputs (caller-owned device memory, pooled order like trexhip_fetch):
  *   outline  [n_blobs][max_points] float2   resampled, smoothed, EFT-approximated outline rotated so that point 0 is
  *                                           the tail (what Outline holds after calculate_midline), relative to the
