@@ -408,10 +408,10 @@ __global__ __launch_bounds__(256) void k_crops_warp(const SegCfg c, const uint8_
     if (staged) {
         for (int i = threadIdx.x; i < (plane * och + 3) / 4; i += 256) reinterpret_cast<uint32_t*>(s_img)[i] = 0u;
         __syncthreads();
-        for (int r = threadIdx.x; r < (int)B.n_runs; r += 256) {
+        for (int r = threadIdx.x >> 4; r < (int)B.n_runs; r += 16) {      // 16 lanes per line: its pixel loads are independent
             const uint32_t q = s_runs[r];
             const int xa = (int)(q & 0xffffu), xb = (int)(q >> 16), yy = (int)rr[r].y;
-            for (int ax = xa; ax <= xb; ++ax)
+            for (int ax = xa + (int)(threadIdx.x & 15); ax <= xb; ax += 16)
                 for (int ch = 0; ch < och; ++ch) s_img[ch * plane + (yy - y0) * sw + (ax - B.x0)] = (uint8_t)source(yy, ax, ch);
         }
         __syncthreads();
