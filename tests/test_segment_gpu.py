@@ -236,3 +236,34 @@ def test_background_from_samples(method):
     seg.segment_device(d.data_ptr(), 1)                    # the generated image is the context's background now
     seg.fetch()
     seg.close()
+
+
+def test_two_contexts_from_two_threads():
+    # two contexts (own streams) driven concurrently from two host threads -- the software-pipelined lanes of bench.py and the
+    # detect / identity threads of TRex: results must not depend on the interleaving
+    import threading
+    rng = np.random.default_rng(21)
+    scenes = [synth.random_scene(rng, 640, 360, density=0.01) for _ in range(4)]
+    errors = []
+
+    def worker(k):
+        try:
+            fr, bg = scenes[k % 2]
+            seg = capi.Segmenter(capi.default_params(640, 360, max_batch=2, max_blobs=32768))
+            seg.set_background(bg)
+            for it in range(6):
+                fr2, _ = scenes[(k + it) % 4]
+                frames = np.stack([fr, np.where(bg == fr2, fr, fr2)])
+                d = torch.from_numpy(frames).cuda()
+                seg.segment_device(d.data_ptr(), 2)
+                res = seg.fetch()
+                for r, f in zip(res, frames):
+                    assert_frame_equal(r, f, bg)
+            seg.close()
+        except Exception as e:          # noqa: BLE001
+            errors.append(repr(e)[:300])
+
+    ts = [threading.Thread(target=worker, args=(k,)) for k in range(2)]
+    for t in ts: t.start()
+    for t in ts: t.join()
+    assert not errors, errors

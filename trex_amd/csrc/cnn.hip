@@ -1263,8 +1263,7 @@ int net_forward(trexhip_ctx* ctx, const uint8_t* d_crops, int n, float* d_probs,
     hipStream_t s = ctx->stream;
     using G2 = ConvGeom<16, 64, 40, 20, 16>;
     using G3 = ConvGeom<64, 128, 20, 20, 32>;
-    static bool attr_done = false;
-    if (!attr_done) {
+    if (!ctx->attr_cnn) {
         TH_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv5<16, 64, 40, 20, 16>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, G2::LDS_BYTES));
         TH_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv5<64, 128, 20, 20, 32>),
@@ -1284,7 +1283,7 @@ int net_forward(trexhip_ctx* ctx, const uint8_t* d_crops, int n, float* d_probs,
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (ConvGeomS<64, 128, 20, 20, 8>::LDS_BYTES)));
 #undef SET_ATTR
 #undef SET_ATTRC
-        attr_done = true;
+        ctx->attr_cnn = true;
     }
     stage_begin(ctx, TREXHIP_STAGE_CNN_ALL);
     const int S = net->W;

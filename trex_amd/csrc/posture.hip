@@ -408,10 +408,9 @@ extern "C" int trexhip_posture_device(trexhip_ctx* ctx, int32_t table, const tre
         }
     }
     const int lds_bytes = 4 * posture_wave_lds(pp->max_points, nr_cap, rows_cap);
-    static int attr_bytes = 0;
-    if (lds_bytes > attr_bytes) {
+    if (lds_bytes > ctx->attr_posture_bytes) {
         TH_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_posture), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
-        attr_bytes = lds_bytes;
+        ctx->attr_posture_bytes = lds_bytes;
     }
     PostureCfg P{pp->outline_resample, pp->outline_smooth_samples, pp->outline_smooth_step, pp->outline_approximate,
                  pp->outline_curvature_range_ratio, pp->midline_walk_offset, pp->max_points, nr_cap, rows_cap};

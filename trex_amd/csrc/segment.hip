@@ -1053,10 +1053,9 @@ int launch_segment(trexhip_ctx* ctx, const uint8_t* d_frames, int n) {
         int rcm = launch_morphology(ctx, d_frames, n, &bits);
         if (rcm) return rcm;
     }
-    static bool attr_done = false;
-    if (!attr_done) {
+    if (!ctx->attr_ccl) {
         TH_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ccl_lds), hipFuncAttributeMaxDynamicSharedMemorySize, CCL_LDS_BYTES));
-        attr_done = true;
+        ctx->attr_ccl = true;
     }
     uint32_t* totals = ctx->d_ctr + (size_t)ctx->p.max_batch * CTR_STRIDE;
     // The batch is cut into groups of frames: the pixel pass of group g+1 (HBM-bound, every CU) runs on the caller's stream
