@@ -232,7 +232,8 @@ int trexhip_midline_device(trexhip_ctx* ctx, const trexhip_midline_params* mp, i
 /* ---- crops ------------------------------------------------------------------------------------
  * constraints::diff_image (tracking/FilterCache.cpp:265-294): one out_w x out_h uint8 crop per blob of the
  * last segmented batch, pooled order (blob i of trexhip_fetch == crop i).  n_blobs = total_blobs of that
- * batch ([n][out_h][out_w][3] for the rgb8 pixel encoding, raw pixels only).  normalization: individual_image_normalization none or
+ * batch ([n][out_h][out_w][3] for the rgb8 pixel encoding, colour codes warped with nearest neighbour for r3g3b2; raw pixels
+ * only for the colour encodings).  normalization: individual_image_normalization none or
  * moments (posture / legacy: next function).  difference: 0 = grey
  * values, 1 = |bg - p|, 2 = max(bg - p, 0)  (track_background_subtraction, FilterCache.cpp:171-175). */
 enum { TREXHIP_NORMALIZE_NONE = 0, TREXHIP_NORMALIZE_MOMENTS = 1, TREXHIP_NORMALIZE_POSTURE = 2 };

@@ -114,6 +114,7 @@ def lib():
         L.oracle_normalize_transform.argtypes = [C.c_void_p, C.c_float, C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_void_p]
         L.oracle_moments_transform.argtypes = [C.c_void_p, C.c_void_p]
         L.oracle_warp_affine_u8.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32]
+        L.oracle_warp_affine_nearest_u8.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32]
         L.oracle_posture_auto.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                           C.POINTER(PostureParams), C.c_void_p, C.c_void_p, C.POINTER(PostureInfo), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
         L.oracle_midline_walk.argtypes = [C.c_void_p, C.c_int32, C.c_float, C.c_void_p]
@@ -303,7 +304,7 @@ def generate_average(frames, method=0):
 
 
 def crop_normalized(frame, bg, blob, runs, tr6=None, midline_length=0.0, legacy=False, out_w=80, out_h=80, scale=1.0,
-                    difference=0, invert=False):
+                    difference=0, invert=False, nearest=False):
     """constraints::diff_image with individual_image_normalization = moments (tr6 None: FilterCache.cpp:276-288) or
     posture / legacy (tr6 = Midline::transform(...).toCV() supplied by the caller, :267-274): imageFromLines into the
     bounding box, normalize_image's transform, cv::warpAffine INTER_LINEAR (FilterCache.cpp:21-115)."""
@@ -322,7 +323,7 @@ def crop_normalized(frame, bg, blob, runs, tr6=None, midline_length=0.0, legacy=
     L.oracle_normalize_transform(_ptr(tr), midline_length, 1 if legacy else 0, out_w, out_h, scale, _ptr(M))
     out = np.zeros((out_h, out_w), np.uint8)
     img = np.ascontiguousarray(img)
-    L.oracle_warp_affine_u8(_ptr(img), bw, bh, _ptr(M), _ptr(out), out_w, out_h)
+    (L.oracle_warp_affine_nearest_u8 if nearest else L.oracle_warp_affine_u8)(_ptr(img), bw, bh, _ptr(M), _ptr(out), out_w, out_h)
     return out, M
 
 

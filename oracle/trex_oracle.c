@@ -488,6 +488,28 @@ void oracle_warp_affine_u8(const uint8_t* src, int32_t sw, int32_t sh, const flo
     }
 }
 
+/* cv::warpAffine(INTER_NEAREST, BORDER_CONSTANT 0) as OpenCV computes it: the same fixed-point coordinates with
+ * round_delta = AB_SCALE / 2 and X = (X0 + adelta) >> AB_BITS (used for r3g3b2 crops, FilterCache.cpp:70-73) */
+void oracle_warp_affine_nearest_u8(const uint8_t* src, int32_t sw, int32_t sh, const float* M6, uint8_t* dst, int32_t dw, int32_t dh) {
+    double M[6];
+    for (int i = 0; i < 6; ++i) M[i] = M6[i];
+    double D = M[0] * M[4] - M[1] * M[3];
+    D = D != 0 ? 1. / D : 0;
+    const double A11 = M[4] * D, A22 = M[0] * D;
+    M[0] = A11; M[1] *= -D; M[3] *= -D; M[4] = A22;
+    const double b1 = -M[0] * M[2] - M[1] * M[5], b2 = -M[3] * M[2] - M[4] * M[5];
+    M[2] = b1; M[5] = b2;
+    const int AB_SCALE = 1024, round_delta = 512;
+    for (int y = 0; y < dh; ++y) {
+        const int X0 = (int)lrint((M[1] * y + M[2]) * AB_SCALE) + round_delta;
+        const int Y0 = (int)lrint((M[4] * y + M[5]) * AB_SCALE) + round_delta;
+        for (int x = 0; x < dw; ++x) {
+            const int sx = (X0 + (int)lrint(M[0] * x * AB_SCALE)) >> 10, sy = (Y0 + (int)lrint(M[3] * x * AB_SCALE)) >> 10;
+            dst[(size_t)y * dw + x] = (sx >= 0 && sx < sw && sy >= 0 && sy < sh) ? src[(size_t)sy * sw + sx] : 0;
+        }
+    }
+}
+
 /* ---- colour encodings (meta_encoding rgb8 / r3g3b2) ---------------------------------------------------------------------------
  * vec_to_r3g3b2 / r3g3b2_to_vec / convert_to_r3g3b2 live in the un-vendored commons; their bit layout is PINNED by the literal
  * vectors of Application/Tests/test_pixels.cpp:629-795: code = (c0 >> 6) << 6 | (c1 >> 5) << 3 | (c2 >> 5) with c0 the FIRST

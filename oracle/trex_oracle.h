@@ -99,6 +99,7 @@ oracle_frame* oracle_rethreshold_frame(const oracle_frame* detect, const uint8_t
 void oracle_normalize_transform(const float* tr6, float midline_length, int32_t use_legacy, int32_t out_w, int32_t out_h, float scale, float* M6);
 void oracle_moments_transform(const oracle_blob* B, float* tr6);
 void oracle_warp_affine_u8(const uint8_t* src, int32_t sw, int32_t sh, const float* M6, uint8_t* dst, int32_t dw, int32_t dh);
+void oracle_warp_affine_nearest_u8(const uint8_t* src, int32_t sw, int32_t sh, const float* M6, uint8_t* dst, int32_t dw, int32_t dh);
 uint32_t oracle_bid(uint32_t x0, uint32_t x1, uint32_t y, uint32_t n_runs);
 /* colour encodings: layout pinned by test_pixels.cpp:629-795; encoding 0 gray, 1 r3g3b2, 2 rgb8 */
 uint8_t oracle_vec_to_r3g3b2(uint8_t c0, uint8_t c1, uint8_t c2);

@@ -60,3 +60,20 @@ def test_normalize_transform_composition():
         want = (T1 @ S @ T2 @ H(tr))[:2].reshape(-1)
         got = oracle.normalize_transform(tr, ln, legacy, 80, 80, s)
         assert np.allclose(got, want, atol=1e-4)
+
+
+def test_nearest_warp_picks_source_pixels():
+    # INTER_NEAREST (r3g3b2 crops): every output is a source pixel or the border value, identity is a copy
+    src = _smooth(50, 60, 3)
+    M = np.array([0.8, -0.6, 25.0, 0.6, 0.8, -5.0], np.float32)
+    got = np.zeros((80, 80), np.uint8)
+    oracle.lib().oracle_warp_affine_nearest_u8(oracle._ptr(np.ascontiguousarray(src)), 60, 50, oracle._ptr(M), oracle._ptr(got), 80, 80)
+    A = np.array([[M[0], M[1]], [M[3], M[4]]], np.float64); Ainv = np.linalg.inv(A); off = -Ainv @ np.array([M[2], M[5]], np.float64)
+    yy, xx = np.mgrid[0:80, 0:80]
+    sx = np.rint(Ainv[0, 0] * xx + Ainv[0, 1] * yy + off[0]).astype(int); sy = np.rint(Ainv[1, 0] * xx + Ainv[1, 1] * yy + off[1]).astype(int)
+    inside = (sx >= 0) & (sx < 60) & (sy >= 0) & (sy < 50)
+    want = np.where(inside, src[np.clip(sy, 0, 49), np.clip(sx, 0, 59)], 0)
+    assert (got != want).mean() < 0.02                      # only ties of the rounding at the 1/1024 grid may differ
+    ident = np.zeros((50, 60), np.uint8)
+    oracle.lib().oracle_warp_affine_nearest_u8(oracle._ptr(np.ascontiguousarray(src)), 60, 50, oracle._ptr(np.array([1, 0, 0, 0, 1, 0], np.float32)), oracle._ptr(ident), 60, 50)
+    assert np.array_equal(ident, src)

@@ -167,3 +167,45 @@ def test_rgb8_end_to_end_identity():
     op, _ = cnn_oracle.predict(st, cpu_crops, threads=8)
     assert np.abs(probs.cpu().numpy() - op).max() <= 1e-4
     seg.close()
+
+
+def test_r3g3b2_crops_codes_and_nearest_warp():
+    # r3g3b2: crops hold the colour codes; normalised crops are warped with nearest neighbour (FilterCache.cpp:70-73)
+    fr, bgc = scene(9, ch=3)
+    W, H = bgc.shape[1], bgc.shape[0]
+    codes = oracle.convert_to_r3g3b2(fr)
+    zero = np.zeros((H, W), np.uint8)
+    seg = capi.Segmenter(capi.default_params(W, H, max_batch=1, pixel_encoding=capi.ENC_R3G3B2))
+    seg.set_background(oracle.bgr2gray(bgc))
+    seg.segment_color_host([fr])
+    r = seg.fetch()[0]
+    n = len(r.blobs)
+    assert n >= 5
+    d = torch.full((n, 80, 80), 3, dtype=torch.uint8, device="cuda")
+    seg.crops_device(d.data_ptr(), n)
+    seg.synchronize()
+    got = d.cpu().numpy()
+    for k, b in enumerate(r.blobs):
+        assert np.array_equal(got[k], oracle.crop_none(codes, zero, b, r.runs)), k
+    seg.crops_device(d.data_ptr(), n, normalization=1)
+    seg.synchronize()
+    got = d.cpu().numpy()
+    for k, b in enumerate(r.blobs):
+        want, _ = oracle.crop_normalized(codes, zero, b, r.runs, nearest=True)
+        assert np.array_equal(got[k], want), ("moments", k)
+        assert set(np.unique(got[k])) <= set(np.unique(codes[int(b["y0"]):int(b["y1"]) + 1, int(b["x0"]):int(b["x1"]) + 1])) | {0}   # no interpolated codes
+    MP = 512
+    outline = torch.zeros((n, MP, 2), dtype=torch.float32, device="cuda"); segs = torch.zeros((n, MP // 2 + 1, 4), dtype=torch.float32, device="cuda")
+    info = torch.zeros((n, 8), dtype=torch.int32, device="cuda"); mid = torch.zeros((n, 25, 4), dtype=torch.float32, device="cuda"); minfo = torch.zeros((n, 8), dtype=torch.int32, device="cuda")
+    seg.posture_device(n, outline.data_ptr(), segs.data_ptr(), info.data_ptr(), max_points=MP)
+    seg.midline_device(n, MP, info.data_ptr(), segs.data_ptr(), mid.data_ptr(), minfo.data_ptr())
+    seg.crops_posture_device(d.data_ptr(), n, minfo.data_ptr(), scale=0.8)
+    seg.synchronize()
+    got = d.cpu().numpy(); mi = minfo.cpu().numpy().view(capi.MIDLINE_INFO_DTYPE).reshape(-1)
+    for k, b in enumerate(r.blobs):
+        if mi[k]["status"] != 0:
+            continue
+        tr = oracle.midline_transform(mi[k]["angle"], mi[k]["offx"], mi[k]["offy"], False)
+        want, _ = oracle.crop_normalized(codes, zero, b, r.runs, tr6=tr, midline_length=float(mi[k]["len"]), scale=0.8, nearest=True)
+        assert np.array_equal(got[k], want), ("posture", k)
+    seg.close()

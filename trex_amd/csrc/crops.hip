@@ -20,7 +20,7 @@ __global__ __launch_bounds__(256) void k_crops_none(const SegCfg c, const uint8_
                                                     const trexhip_blob* __restrict__ blobs,
                                                     const trexhip_run* __restrict__ runs, uint8_t* __restrict__ crops,
                                                     int OW, int OH, int diff_mode /*0 raw, 1 |bg-p|, 2 max(bg-p,0)*/,
-                                                    const uint8_t* __restrict__ color, int color_ch, int och /*1 grey, 3 rgb8*/) {
+                                                    const uint8_t* __restrict__ color, int color_ch, int och /*1 grey or r3g3b2 code, 3 rgb8*/, int enc) {
     const uint32_t bi = blockIdx.x;
     uint8_t* out = crops + (size_t)bi * OW * OH * och;
     for (int i = threadIdx.x * 16; i < OW * OH * och; i += 256 * 16) *reinterpret_cast<uint4*>(out + i) = make_uint4(0, 0, 0, 0);
@@ -50,6 +50,11 @@ __global__ __launch_bounds__(256) void k_crops_none(const SegCfg c, const uint8_
                 d[0] = s[0]; d[1] = s[1]; d[2] = s[2];
                 continue;
             }
+            if (enc == TREXHIP_ENC_R3G3B2) {                  // the colour code of the pixel (convert_to_r3g3b2)
+                const uint8_t* s = color + (((size_t)f * c.H + q.y) * c.W + x) * color_ch;
+                out[oy * OW + ox] = (uint8_t)(((s[0] >> 6) << 6) | ((s[1] >> 5) << 3) | (s[2] >> 5));
+                continue;
+            }
             int p = img[(size_t)q.y * c.W + x];
             if (c.invert) p = 255 - p;
             if (diff_mode) {
@@ -71,7 +76,7 @@ int launch_crops(trexhip_ctx* ctx, uint8_t* d_crops, int n, int OW, int OH, int 
     stage_begin(ctx, TREXHIP_STAGE_CROPS);
     hipLaunchKernelGGL(k_crops_none, dim3(n), dim3(256), 0, ctx->stream, c, ctx->d_frames, ctx->d_bg, ctx->d_info,
                        ctx->d_blob_frame, ctx->d_blobs, ctx->d_runs, d_crops, OW, OH, diff_mode, ctx->d_color_src, ctx->color_ch,
-                       ctx->p.pixel_encoding == TREXHIP_ENC_RGB8 ? 3 : 1);
+                       ctx->p.pixel_encoding == TREXHIP_ENC_RGB8 ? 3 : 1, ctx->p.pixel_encoding);
     stage_end(ctx, TREXHIP_STAGE_CROPS);
     TH_CHECK_HIP(hipGetLastError());
     return TREXHIP_OK;
@@ -86,9 +91,8 @@ extern "C" {
 int trexhip_crops_device(trexhip_ctx* ctx, uint8_t* d_crops, int32_t n_blobs, int32_t out_w, int32_t out_h,
                          int32_t normalization, int32_t difference) {
     if (!ctx || !d_crops) { set_error("trexhip_crops_device: null argument"); return TREXHIP_E_INVALID; }
-    if (ctx->p.pixel_encoding == TREXHIP_ENC_R3G3B2) { set_error("trexhip_crops_device: crops of r3g3b2 pixel arrays are not implemented"); return TREXHIP_E_UNSUPPORTED; }
-    if (ctx->p.pixel_encoding == TREXHIP_ENC_RGB8 && difference != 0) {
-        set_error("trexhip_crops_device: rgb8 crops hold the raw colour pixels: background-difference crops are not implemented"); return TREXHIP_E_UNSUPPORTED;
+    if (ctx->p.pixel_encoding != TREXHIP_ENC_GRAY && difference != 0) {
+        set_error("trexhip_crops_device: crops of the colour encodings hold the raw pixels / codes: background-difference crops are not implemented"); return TREXHIP_E_UNSUPPORTED;
     }
     if (ctx->p.pixel_encoding == TREXHIP_ENC_RGB8 && (out_w * out_h * 3) % 16 != 0) { set_error("trexhip_crops_device: out_w*out_h*3 must be a multiple of 16"); return TREXHIP_E_UNSUPPORTED; }
     if (normalization != TREXHIP_NORMALIZE_NONE && normalization != TREXHIP_NORMALIZE_MOMENTS) {
@@ -367,7 +371,7 @@ __global__ __launch_bounds__(256) void k_crops_warp(const SegCfg c, const uint8_
                                                     const trexhip_blob* __restrict__ blobs, const trexhip_run* __restrict__ runs,
                                                     const double* __restrict__ minv /*[n][6] inverse maps*/, uint8_t* __restrict__ crops,
                                                     int OW, int OH, int diff_mode, const uint8_t* __restrict__ color, int color_ch,
-                                                    int och /*1 grey, 3 rgb8 (raw pixels, channels warped independently)*/) {
+                                                    int och /*1 grey or r3g3b2 code, 3 rgb8 (raw pixels, channels warped independently)*/, int enc) {
     __shared__ uint32_t s_runs[W_NR];
     __shared__ int s_row[1024 + 2];
     const uint32_t bi = blockIdx.x;
@@ -392,10 +396,12 @@ __global__ __launch_bounds__(256) void k_crops_warp(const SegCfg c, const uint8_
     const double m0 = M[0], m1 = M[1], m2 = M[2], m3 = M[3], m4 = M[4], m5 = M[5];
     const int sw = B.x1 - B.x0 + 1, sh = rows, plane = sw * sh;
     const uint8_t* img = frames + (size_t)f * c.H * c.W;
-    const uint8_t* cimg = och == 3 ? color + (size_t)f * c.H * c.W * color_ch : nullptr;
+    const uint8_t* cimg = enc != TREXHIP_ENC_GRAY ? color + (size_t)f * c.H * c.W * color_ch : nullptr;
+    const bool nearest = enc == TREXHIP_ENC_R3G3B2;          // colour codes are not interpolated (FilterCache.cpp:70-73: INTER_NEAREST)
     // value of the blob image at a member pixel: grey (raw or background difference) or one colour channel
     auto source = [&](int ay, int ax, int ch) -> int {
         if (och == 3) return cimg[((size_t)ay * c.W + ax) * color_ch + ch];
+        if (nearest) { const uint8_t* s = cimg + ((size_t)ay * c.W + ax) * color_ch; return ((s[0] >> 6) << 6) | ((s[1] >> 5) << 3) | (s[2] >> 5); }
         int p = img[(size_t)ay * c.W + ax];
         if (c.invert) p = 255 - p;
         if (diff_mode) { const int bgv = bg[(size_t)ay * c.W + ax]; p = diff_mode == 1 ? abs(bgv - p) : max(bgv - p, 0); }
@@ -420,18 +426,34 @@ __global__ __launch_bounds__(256) void k_crops_warp(const SegCfg c, const uint8_
     __shared__ int s_rx[W_OUT], s_ry[W_OUT], s_cx[W_OUT], s_cy[W_OUT];
     const bool tabled = OW <= W_OUT && OH <= W_OUT;
     if (tabled) {
-        for (int i = threadIdx.x; i < OH; i += 256) { s_rx[i] = __double2int_rn((m1 * i + m2) * 1024.0) + 16; s_ry[i] = __double2int_rn((m4 * i + m5) * 1024.0) + 16; }
+        const int rd = nearest ? 512 : 16;                      // round_delta: AB_SCALE/2 (nearest) or AB_SCALE/INTER_TAB_SIZE/2
+        for (int i = threadIdx.x; i < OH; i += 256) { s_rx[i] = __double2int_rn((m1 * i + m2) * 1024.0) + rd; s_ry[i] = __double2int_rn((m4 * i + m5) * 1024.0) + rd; }
         for (int i = threadIdx.x; i < OW; i += 256) { s_cx[i] = __double2int_rn(m0 * i * 1024.0); s_cy[i] = __double2int_rn(m3 * i * 1024.0); }
         __syncthreads();
     }
     for (int i = threadIdx.x; i < OW * OH; i += 256) {
         const int y = i / OW, x = i - y * OW;
         int X, Y;
-        if (tabled) { X = (s_rx[y] + s_cx[x]) >> 5; Y = (s_ry[y] + s_cy[x]) >> 5; }
+        if (tabled) { X = s_rx[y] + s_cx[x]; Y = s_ry[y] + s_cy[x]; }
         else {
-            const int X0 = __double2int_rn((m1 * y + m2) * 1024.0) + 16, Y0 = __double2int_rn((m4 * y + m5) * 1024.0) + 16;
-            X = (X0 + __double2int_rn(m0 * x * 1024.0)) >> 5; Y = (Y0 + __double2int_rn(m3 * x * 1024.0)) >> 5;
+            const int rd = nearest ? 512 : 16;
+            X = __double2int_rn((m1 * y + m2) * 1024.0) + rd + __double2int_rn(m0 * x * 1024.0);
+            Y = __double2int_rn((m4 * y + m5) * 1024.0) + rd + __double2int_rn(m3 * x * 1024.0);
         }
+        if (nearest) {                                           // X >> AB_BITS is the source pixel
+            const int nx = X >> 10, ny = Y >> 10;
+            int p = 0;
+            if (nx >= 0 && nx < sw && ny >= 0 && ny < sh) {
+                if (staged) p = s_img[ny * sw + nx];
+                else {
+                    const int ax = nx + B.x0;
+                    for (int r = s_row[ny]; r < s_row[ny + 1]; ++r) { const uint32_t q = s_runs[r]; if (ax >= (int)(q & 0xffffu) && ax <= (int)(q >> 16)) { p = source(ny + y0, ax, 0); break; } }
+                }
+            }
+            out[i] = (uint8_t)p;
+            continue;
+        }
+        X >>= 5; Y >>= 5;
         const int sx = X >> 5, sy = Y >> 5, fx = X & 31, fy = Y & 31;
         if (sx < -1 || sx >= sw || sy < -1 || sy >= sh) { for (int ch = 0; ch < och; ++ch) out[i * och + ch] = 0; continue; }   // all four taps outside the box
         bool in[4];
@@ -480,8 +502,7 @@ static void compose_and_invert(const Aff& tr, float midline_length, bool legacy,
 
 int launch_crops_warp(trexhip_ctx* ctx, uint8_t* d_crops, int n, int OW, int OH, int diff_mode, const float* tr6, const float* lengths,
                       bool legacy, float scale, const uint8_t* valid) {
-    if (ctx->p.pixel_encoding == TREXHIP_ENC_R3G3B2) { set_error("crops of r3g3b2 pixel arrays are not implemented"); return TREXHIP_E_UNSUPPORTED; }
-    if (ctx->p.pixel_encoding == TREXHIP_ENC_RGB8 && diff_mode != 0) { set_error("rgb8 crops hold the raw colour pixels: background-difference crops are not implemented"); return TREXHIP_E_UNSUPPORTED; }
+    if (ctx->p.pixel_encoding != TREXHIP_ENC_GRAY && diff_mode != 0) { set_error("crops of the colour encodings hold the raw pixels / codes: background-difference crops are not implemented"); return TREXHIP_E_UNSUPPORTED; }
     // tr6 == nullptr: `moments` -- orientation from the integer moments of the fetched blob table (host copy)
     std::vector<double> minv((size_t)n * 6);
     for (int i = 0; i < n; ++i) {
@@ -516,7 +537,7 @@ int launch_crops_warp(trexhip_ctx* ctx, uint8_t* d_crops, int n, int OW, int OH,
     stage_begin(ctx, TREXHIP_STAGE_CROPS);
     hipLaunchKernelGGL(k_crops_warp, dim3(n), dim3(256), 0, ctx->stream, c, ctx->d_frames, ctx->d_bg, ctx->d_info, ctx->d_blob_frame,
                        ctx->d_blobs, ctx->d_runs, ctx->d_warp, d_crops, OW, OH, diff_mode, ctx->d_color_src, ctx->color_ch,
-                       ctx->p.pixel_encoding == TREXHIP_ENC_RGB8 ? 3 : 1);
+                       ctx->p.pixel_encoding == TREXHIP_ENC_RGB8 ? 3 : 1, ctx->p.pixel_encoding);
     stage_end(ctx, TREXHIP_STAGE_CROPS);
     TH_CHECK_HIP(hipGetLastError());
     return TREXHIP_OK;
