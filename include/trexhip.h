@@ -185,6 +185,47 @@ int trexhip_rethreshold_per_blob_device(trexhip_ctx* ctx, int32_t threshold, con
                                         const double* size_ranges, int32_t n_ranges);
 int trexhip_fetch_rethreshold(trexhip_ctx* ctx, trexhip_batch_result* out);
 
+/* ---- splitting merged blobs: SplitBlob's threshold search -----------------------------------------------
+ * SplitBlob::split (tracking/SplitBlob.cpp:419-800) for blob_split_algorithm threshold / threshold_approximate: for every detect blob
+ * of the last batch with presumed_nr[blob] > 0 (PrefilterBlobs::split_big's split_expectation::number, PrefilterBlobs.cpp:217-236;
+ * <= 0 = not a candidate) find the smallest threshold at which pixel::threshold_blob on the blob's difference values
+ * (apply_threshold :130-179) is accepted by evaluate_result_multiple (:193-255).  The reference re-labels the blob on the CPU for
+ * every tried threshold; here one wave per blob keeps the difference values in LDS.  Large blobs, which the reference searches
+ * with 4 pool threads (:735-760), get the deterministic sequential result (identical for `threshold`, see oracle/trex_split.c).
+ *   d_thresholds [n_blobs] int32: the threshold to hand to trexhip_rethreshold_per_blob_device (which then yields the sub-blobs
+ *                                 threshold_blob returns), or -1 when the blob cannot be split / is no candidate
+ *   d_info       [n_blobs]: what the search saw.  Of the sub-blobs, those with n_pixels * cm^2 < min_size_bound are not part
+ *                           of SplitBlob::split's result (:204-221); the rest is returned sorted by (num_pixels, blob_id) descending
+ *                           and shifted by -bounds().pos() (:166-172), which the caller does on the fetched table.
+ * Needs a fetched batch (n_blobs = total_blobs).  Blobs with more than 16384 pixels or 1024 lines (or 2048 lines after
+ * thresholding) report status 2 and no threshold. */
+typedef struct trexhip_split_params {
+    int32_t track_threshold;                 /* core/default_config.cpp track_threshold            */
+    int32_t track_posture_threshold;
+    int32_t calculate_posture;               /* initial threshold = (calculate_posture ? max(both) : track_threshold) + 1 (:512) */
+    int32_t algorithm;                       /* blob_split_algorithm: 0 none, 1 threshold (default, :923), 2 threshold_approximate */
+    float   blob_split_max_shrink;           /* :921 (0.2) */
+    float   blob_split_global_shrink_limit;  /* :922 (0.2) */
+    int32_t n_ranges;                        /* track_size_filter, cm^2, at most 8 ranges */
+    int32_t reserved_;
+    double  size_ranges[16];
+} trexhip_split_params;
+typedef struct trexhip_split_info {
+    int32_t threshold;                       /* best_match.threshold as the reference records it, or -1 */
+    int32_t effective_threshold;             /* the threshold apply_threshold really used for it (clamped to the blob's smallest difference) */
+    int32_t status;                          /* 0 searched, 2 capacity, 3 not a candidate / frame overflowed */
+    int32_t initial_action;                  /* split::Action of the first try: 1 KEEP_ABORT, 2 REMOVE, 3 ABORT, 4 TOO_FEW, 5 SKIP */
+    int32_t n_result;                        /* blobs SplitBlob::split returns */
+    int32_t n_evaluated;                     /* labelling passes spent on the blob */
+    int32_t min_pixel, max_pixel;            /* range of the difference values (:142-156) */
+    float   first_size;                      /* size of the biggest sub-blob at the first try, cm^2 (:530-531) */
+    float   reserved_;
+    double  min_size_bound;
+} trexhip_split_info;
+void trexhip_default_split_params(trexhip_split_params* p);
+int trexhip_split_search_device(trexhip_ctx* ctx, const trexhip_split_params* sp, int32_t method, const int32_t* d_presumed_nr,
+                                int32_t n_blobs, int32_t* d_thresholds, trexhip_split_info* d_info);
+
 /* ---- posture (outline -> midline) -----------------------------------------------------------------
  * posture::calculate_posture (tracking/Posture.cpp:305-399) for every blob of a table of the last batch
  * (table 0 = detect blobs, 1 = re-thresholded sub-blobs, i.e. the caller picks track_posture_threshold through

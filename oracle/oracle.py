@@ -75,7 +75,7 @@ def make_params(width, height, threshold=15, threshold_maximum=255, enable_diffe
 
 def build(force=False):
     so = os.path.join(_HERE, "liboracle.so")
-    src = [os.path.join(_HERE, f) for f in ("trex_oracle.c", "trex_posture.c", "trex_oracle.h")]
+    src = [os.path.join(_HERE, f) for f in ("trex_oracle.c", "trex_posture.c", "trex_split.c", "trex_oracle.h")]
     if force or not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in src if os.path.exists(s)):
         subprocess.check_call(["make", "-C", _HERE, "-s", "-B"])
     return so
@@ -128,6 +128,8 @@ def lib():
         L.oracle_bgr2gray.argtypes = [C.c_uint8] * 3
         L.oracle_line_without_grid_enc.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_int32,
                                                    C.c_int32, C.c_void_p, C.c_void_p, C.POINTER(C.c_int32)]
+        L.oracle_split_search.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
+                                          C.POINTER(SplitParams), C.c_int32, C.POINTER(SplitInfo)]
         L.oracle_bid.restype = C.c_uint32
         L.oracle_bid.argtypes = [C.c_uint32] * 4
         del u8p
@@ -423,3 +425,40 @@ def line_without_grid_enc(runs, pixels, pixel_enc, bg, bg_enc, method, threshold
     n = lib().oracle_line_without_grid_enc(_ptr(runs), len(runs), _ptr(pixels), pixel_enc, _ptr(bg), bg.shape[1], bg_enc, method, threshold,
                                            _ptr(out_runs), _ptr(out_px), C.byref(n_px))
     return out_runs[:n].copy(), out_px[:n_px.value * pc].copy()
+
+
+class SplitParams(C.Structure):
+    _fields_ = [("initial_threshold", C.c_int32), ("algorithm", C.c_int32), ("blob_split_max_shrink", C.c_float),
+                ("blob_split_global_shrink_limit", C.c_float), ("cm_per_pixel", C.c_float), ("n_ranges", C.c_int32), ("ranges", C.c_double * 16)]
+
+
+class SplitInfo(C.Structure):
+    _fields_ = [("threshold", C.c_int32), ("effective_threshold", C.c_int32), ("initial_action", C.c_int32), ("n_result", C.c_int32),
+                ("n_tried", C.c_int32), ("min_pixel", C.c_int32), ("max_pixel", C.c_int32), ("first_size", C.c_float), ("min_size_bound", C.c_double)]
+
+
+SPLIT_ACTIONS = ("KEEP", "KEEP_ABORT", "REMOVE", "ABORT", "TOO_FEW", "SKIP", "NO_CHANCE")
+
+
+def split_params(track_threshold=15, track_posture_threshold=15, calculate_posture=True, algorithm=1, max_shrink=0.2, global_shrink_limit=0.2,
+                 cm_per_pixel=1.0, size_ranges=()):
+    """SplitBlob settings (defaults: core/default_config.cpp:921-923); algorithm 1 = threshold, 2 = threshold_approximate"""
+    p = SplitParams()
+    p.initial_threshold = (max(track_threshold, track_posture_threshold) if calculate_posture else track_threshold) + 1
+    p.algorithm = algorithm
+    p.blob_split_max_shrink, p.blob_split_global_shrink_limit, p.cm_per_pixel = max_shrink, global_shrink_limit, cm_per_pixel
+    p.n_ranges = len(size_ranges)
+    for i, (a, b) in enumerate(size_ranges):
+        p.ranges[2 * i], p.ranges[2 * i + 1] = a, b
+    return p
+
+
+def split_search(runs, pixels, bg, method, params, presumed_nr, connectivity=8):
+    """SplitBlob::split's threshold search for ONE blob (full-frame runs + grey pixels).  Returns SplitInfo."""
+    runs = np.ascontiguousarray(runs, RUN_DTYPE)
+    pixels = np.ascontiguousarray(pixels, np.uint8)
+    bg = np.ascontiguousarray(bg, np.uint8)
+    out = SplitInfo()
+    lib().oracle_split_search(_ptr(runs), len(runs), _ptr(pixels), _ptr(bg), bg.shape[1], bg.shape[1], bg.shape[0], method, connectivity,
+                              C.byref(params), presumed_nr, C.byref(out))
+    return out

@@ -109,6 +109,26 @@ int32_t oracle_line_without_grid_enc(const oracle_run* runs, int32_t n_runs, con
                                      const uint8_t* bg, int32_t bg_stride_px, int32_t bg_enc, int32_t method, int32_t threshold,
                                      oracle_run* out_runs, uint8_t* out_pixels, int32_t* n_out_pixels);
 
+/* blob splitting by threshold search (tracking/SplitBlob.cpp:130-255,419-800); trex_split.c */
+typedef struct oracle_split_params {
+    int32_t initial_threshold;        /* (calculate_posture ? max(track_threshold, track_posture_threshold) : track_threshold) + 1, :512 */
+    int32_t algorithm;                /* blob_split_algorithm: 0 none, 1 threshold, 2 threshold_approximate */
+    float blob_split_max_shrink, blob_split_global_shrink_limit;
+    float cm_per_pixel;
+    int32_t n_ranges;                 /* track_size_filter */
+    double ranges[16];
+} oracle_split_params;
+typedef struct oracle_split_info {
+    int32_t threshold;                /* best_match.threshold or -1 */
+    int32_t effective_threshold;      /* the threshold apply_threshold really used for it (>= min_pixel) */
+    int32_t initial_action, n_result, n_tried, min_pixel, max_pixel;
+    float first_size;
+    double min_size_bound;            /* blobs below it were removed from the result (evaluate_result_multiple) */
+} oracle_split_info;
+void oracle_split_search(const oracle_run* runs, int32_t n_runs, const uint8_t* pixels, const uint8_t* bg, int32_t bg_stride,
+                         int32_t width, int32_t height, int32_t method, int32_t connectivity, const oracle_split_params* P,
+                         int32_t presumed_nr, oracle_split_info* out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -55,6 +55,15 @@ class MidlineParams(C.Structure):
                 ("midline_start_with_head", C.c_int32)]
 
 
+class SplitParams(C.Structure):
+    _fields_ = [("track_threshold", C.c_int32), ("track_posture_threshold", C.c_int32), ("calculate_posture", C.c_int32), ("algorithm", C.c_int32),
+                ("blob_split_max_shrink", C.c_float), ("blob_split_global_shrink_limit", C.c_float), ("n_ranges", C.c_int32), ("reserved_", C.c_int32),
+                ("size_ranges", C.c_double * 16)]
+
+
+SPLIT_INFO_DTYPE = np.dtype([("threshold", "<i4"), ("effective_threshold", "<i4"), ("status", "<i4"), ("initial_action", "<i4"), ("n_result", "<i4"),
+                             ("n_evaluated", "<i4"), ("min_pixel", "<i4"), ("max_pixel", "<i4"), ("first_size", "<f4"), ("reserved_", "<f4"),
+                             ("min_size_bound", "<f8")])
 MIDLINE_INFO_DTYPE = np.dtype([("status", "<i4"), ("n", "<i4"), ("len", "<f4"), ("angle", "<f4"), ("offx", "<f4"), ("offy", "<f4"),
                                ("reserved", "<i4", (2,))])
 POSTURE_INFO_DTYPE = np.dtype([("status", "<i4"), ("n_outline", "<i4"), ("n_segments", "<i4"), ("tail_index", "<i4"),
@@ -89,7 +98,7 @@ SYMBOLS = [
     "trexhip_set_stream", "trexhip_set_background", "trexhip_set_background_device", "trexhip_generate_average_device", "trexhip_get_background", "trexhip_segment_device",
     "trexhip_segment", "trexhip_segment_color", "trexhip_segment_color_device", "trexhip_rethreshold_device", "trexhip_rethreshold_per_blob_device", "trexhip_fetch_rethreshold", "trexhip_fetch", "trexhip_device_view_get", "trexhip_synchronize",
     "trexhip_profile_enable", "trexhip_profile_read", "trexhip_profile_reset",
-    "trexhip_default_posture_params", "trexhip_posture_device", "trexhip_crops_device", "trexhip_pixel_channels", "trexhip_device_alloc", "trexhip_device_free", "trexhip_copy_to_host", "trexhip_crops_transformed_device", "trexhip_crops_posture_device", "trexhip_default_midline_params", "trexhip_midline_device", "trexhip_export_id_table_device", "trexhip_load_weights", "trexhip_set_identity_precision", "trexhip_num_classes", "trexhip_identify_device", "trexhip_identify",
+    "trexhip_default_posture_params", "trexhip_posture_device", "trexhip_crops_device", "trexhip_pixel_channels", "trexhip_device_alloc", "trexhip_device_free", "trexhip_copy_to_host", "trexhip_crops_transformed_device", "trexhip_crops_posture_device", "trexhip_default_midline_params", "trexhip_midline_device", "trexhip_default_split_params", "trexhip_split_search_device", "trexhip_export_id_table_device", "trexhip_load_weights", "trexhip_set_identity_precision", "trexhip_num_classes", "trexhip_identify_device", "trexhip_identify",
 ]
 
 
@@ -126,6 +135,9 @@ def lib():
         L.trexhip_default_midline_params.argtypes = [C.POINTER(MidlineParams)]
         L.trexhip_default_midline_params.restype = None
         L.trexhip_midline_device.argtypes = [C.c_void_p, C.POINTER(MidlineParams), C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.trexhip_default_split_params.argtypes = [C.POINTER(SplitParams)]
+        L.trexhip_default_split_params.restype = None
+        L.trexhip_split_search_device.argtypes = [C.c_void_p, C.POINTER(SplitParams), C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]
         L.trexhip_crops_posture_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_float, C.c_int32]
         L.trexhip_default_posture_params.argtypes = [C.POINTER(PostureParams)]
         L.trexhip_default_posture_params.restype = None
@@ -294,6 +306,18 @@ class Segmenter:
             setattr(mp, k, v)
         _check(lib().trexhip_midline_device(self._h, C.byref(mp), n_blobs, max_points, C.c_void_p(d_posture_info_ptr), C.c_void_p(d_segments_ptr),
                                             C.c_void_p(d_midline_ptr), C.c_void_p(d_midline_info_ptr)))
+
+    def split_search_device(self, d_presumed_ptr, n_blobs, d_thresholds_ptr, d_info_ptr, method=1, size_ranges=(), **kw):
+        """SplitBlob's threshold search for the detect blobs with presumed_nr > 0; see include/trexhip.h."""
+        sp = SplitParams()
+        lib().trexhip_default_split_params(C.byref(sp))
+        for k, v in kw.items():
+            setattr(sp, k, v)
+        sp.n_ranges = len(size_ranges)
+        for i, (a, b) in enumerate(size_ranges):
+            sp.size_ranges[2 * i], sp.size_ranges[2 * i + 1] = a, b
+        _check(lib().trexhip_split_search_device(self._h, C.byref(sp), method, C.c_void_p(d_presumed_ptr), n_blobs, C.c_void_p(d_thresholds_ptr),
+                                                 C.c_void_p(d_info_ptr)))
 
     def crops_posture_device(self, d_crops_ptr, n_blobs, d_midline_info_ptr, midline_lengths=None, out_w=80, out_h=80, legacy=False, scale=1.0, difference=0):
         ln = None if midline_lengths is None else np.ascontiguousarray(midline_lengths, np.float32)
