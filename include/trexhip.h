@@ -160,10 +160,11 @@ int trexhip_segment_color(trexhip_ctx* ctx, const uint8_t* const* frames, int32_
 int trexhip_segment_color_device(trexhip_ctx* ctx, const uint8_t* d_color_frames, int32_t n, int32_t channels, int32_t color_channel);
 int trexhip_pixel_channels(trexhip_ctx* ctx);   /* bytes per pixel of the pixel arrays and channels of the crops: 1 or 3 (rgb8) */
 /* device buffers for callers that do not link the HIP runtime themselves (the C++ adapters in trex_amd/host): plain
- * hipMalloc / hipFree / stream-ordered device-to-host copy (synchronous on return) on the context's device and stream */
+ * hipMalloc / hipFree / stream-ordered device-to-host and host-to-device copies (synchronous on return) on the context's device and stream */
 int trexhip_device_alloc(trexhip_ctx* ctx, size_t bytes, void** out_device_ptr);
 int trexhip_device_free(trexhip_ctx* ctx, void* device_ptr);
 int trexhip_copy_to_host(trexhip_ctx* ctx, void* host_dst, const void* device_src, size_t bytes);
+int trexhip_copy_to_device(trexhip_ctx* ctx, void* device_dst, const void* host_src, size_t bytes);
 /* wait for the last segment call and copy its tables to pinned host memory */
 int trexhip_fetch(trexhip_ctx* ctx, trexhip_batch_result* out);
 int trexhip_device_view_get(trexhip_ctx* ctx, trexhip_device_view* out);

@@ -10,6 +10,7 @@
 #include "../../trex_amd/host/HipBackgroundSubtraction.h"
 #include "../../trex_amd/host/HipVINetwork.h"
 #include "../../trex_amd/host/HipPosture.h"
+#include "../../trex_amd/host/HipSplitBlob.h"
 #include <cmath>
 #include "../../oracle/trex_oracle.h"
 
@@ -276,6 +277,64 @@ int main(int argc, char** argv) {
                 CHECK(sum > 0);
                 if (mode == 0) CHECK(sum == res.blobs[b].sp);                    // un-normalised crop holds exactly the blob's grey values
             }
+        }
+        }
+        trexhip_destroy(ctx);
+    }
+    {   // --- SplitBlob::split for merged individuals (PrefilterBlobs.cpp:235-236) through HipSplitBlob ---
+        const int SW = 256, SH = 128;
+        trexhip_params p; trexhip_default_params(&p, SW, SH); p.max_batch = 1;
+        trexhip_ctx* ctx = nullptr;
+        CHECK(trexhip_create(&p, &ctx) == 0);
+        std::vector<uint8_t> sbg((size_t)SW * SH), fr;
+        for (int y = 0; y < SH; ++y) for (int x = 0; x < SW; ++x) sbg[(size_t)y * SW + x] = (uint8_t)(140 + ((x * 3 + y * 5) & 31) - 16);
+        fr = sbg;
+        auto body = [&](float cx, float cy, float a, float b, float amp) {      // darkness falls off from the body axis
+            for (int y = 0; y < SH; ++y) for (int x = 0; x < SW; ++x) {
+                const float r2 = (x - cx) * (x - cx) / (a * a) + (y - cy) * (y - cy) / (b * b);
+                const float d = amp * std::min(1.f, std::max(0.f, 1.15f - r2));
+                const int v = (int)sbg[(size_t)y * SW + x] - (int)std::lround(d);
+                if (d > 0 && v < fr[(size_t)y * SW + x]) fr[(size_t)y * SW + x] = (uint8_t)std::max(0, v);
+            }
+        };
+        body(70, 50, 18, 5, 90); body(72, 59, 17, 5, 80);                       // two touching individuals = one detect blob
+        body(180, 60, 18, 5, 85);                                               // a single one
+        CHECK(trexhip_set_background(ctx, sbg.data(), SW) == 0);
+        const uint8_t* fp[1] = {fr.data()};
+        CHECK(trexhip_segment(ctx, fp, SW, 1) == 0);
+        trexhip_batch_result res{};
+        CHECK(trexhip_fetch(ctx, &res) == 0);
+        CHECK(res.total_blobs == 2);
+        {
+        HipSplitBlob sb(ctx);
+        HipSplitBlob::Settings ss;
+        ss.track_size_filter = {{40.0, 330.0}};
+        ss.track_threshold_is_absolute = false;
+        std::vector<HipSplitBlob::Split> r;
+        try { r = sb.split({{0u, 2}, {1u, 2}}, res, ss); }
+        catch (const std::exception& e) { std::fprintf(stderr, "HipSplitBlob::split: %s\n", e.what()); std::exit(1); }
+        CHECK(r.size() == 2);
+        // the CPU restatement of SplitBlob::split on the same blobs
+        oracle_split_params op{};
+        op.initial_threshold = 16; op.algorithm = 1; op.blob_split_max_shrink = 0.2f; op.blob_split_global_shrink_limit = 0.2f; op.cm_per_pixel = 1.f;
+        op.n_ranges = 1; op.ranges[0] = 40; op.ranges[1] = 330;
+        for (int b = 0; b < 2; ++b) {
+            const trexhip_blob& B = res.blobs[b];
+            std::vector<oracle_run> orr(B.n_runs);
+            for (uint32_t i = 0; i < B.n_runs; ++i) { const trexhip_run& q = res.runs[res.frames[0].run_begin + B.run_begin + i]; orr[i].x0 = q.x0; orr[i].x1 = q.x1; orr[i].y = q.y; orr[i].pad = 0; }
+            oracle_split_info oi{};
+            oracle_split_search(orr.data(), (int32_t)B.n_runs, res.pixels + res.frames[0].pix_begin + B.pix_begin, sbg.data(), SW, SW, SH, 1, 8, &op, 2, &oi);
+            CHECK(r[b].threshold == oi.threshold);
+            CHECK((int)r[b].blobs.size() == oi.n_result);
+        }
+        CHECK(r[0].threshold > 16 && r[0].blobs.size() >= 2);                   // the pair separates above the track threshold
+        CHECK(r[1].threshold == -1 && r[1].blobs.empty());                      // one individual cannot be split into two
+        size_t prev = SIZE_MAX;
+        for (auto& pr : r[0].blobs) {                                           // descending sizes, lines relative to the big blob, pixels match lines
+            size_t n = 0;
+            for (auto& l : *pr.lines) { n += (size_t)l.x1 - l.x0 + 1; CHECK(l.y <= res.blobs[0].y1 - res.blobs[0].y0 && l.x1 <= res.blobs[0].x1 - res.blobs[0].x0); }
+            CHECK(pr.pixels && pr.pixels->size() == n && n <= prev);
+            prev = n;
         }
         }
         trexhip_destroy(ctx);

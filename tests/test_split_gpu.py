@@ -11,9 +11,11 @@ from split_cases import merged_scene
 pytestmark = pytest.mark.gpu
 
 
-def device_search(frames, bg, presumed_of, method=1, ranges=(), detect_threshold=15, **kw):
+def device_search(frames, bg, presumed_of, method=1, ranges=(), detect_threshold=15, detect_kw=None, **kw):
     n, H, W = frames.shape
-    seg = capi.Segmenter(capi.default_params(W, H, max_batch=n, max_blobs=4096, threshold=detect_threshold))
+    dkw = dict(threshold=detect_threshold)
+    dkw.update(detect_kw or {})
+    seg = capi.Segmenter(capi.default_params(W, H, max_batch=n, max_blobs=4096, **dkw))
     seg.set_background(bg)
     d = torch.from_numpy(frames).cuda()
     seg.segment_device(d.data_ptr(), n)

@@ -98,7 +98,7 @@ SYMBOLS = [
     "trexhip_set_stream", "trexhip_set_background", "trexhip_set_background_device", "trexhip_generate_average_device", "trexhip_get_background", "trexhip_segment_device",
     "trexhip_segment", "trexhip_segment_color", "trexhip_segment_color_device", "trexhip_rethreshold_device", "trexhip_rethreshold_per_blob_device", "trexhip_fetch_rethreshold", "trexhip_fetch", "trexhip_device_view_get", "trexhip_synchronize",
     "trexhip_profile_enable", "trexhip_profile_read", "trexhip_profile_reset",
-    "trexhip_default_posture_params", "trexhip_posture_device", "trexhip_crops_device", "trexhip_pixel_channels", "trexhip_device_alloc", "trexhip_device_free", "trexhip_copy_to_host", "trexhip_crops_transformed_device", "trexhip_crops_posture_device", "trexhip_default_midline_params", "trexhip_midline_device", "trexhip_default_split_params", "trexhip_split_search_device", "trexhip_export_id_table_device", "trexhip_load_weights", "trexhip_set_identity_precision", "trexhip_num_classes", "trexhip_identify_device", "trexhip_identify",
+    "trexhip_default_posture_params", "trexhip_posture_device", "trexhip_crops_device", "trexhip_pixel_channels", "trexhip_device_alloc", "trexhip_device_free", "trexhip_copy_to_host", "trexhip_copy_to_device", "trexhip_crops_transformed_device", "trexhip_crops_posture_device", "trexhip_default_midline_params", "trexhip_midline_device", "trexhip_default_split_params", "trexhip_split_search_device", "trexhip_export_id_table_device", "trexhip_load_weights", "trexhip_set_identity_precision", "trexhip_num_classes", "trexhip_identify_device", "trexhip_identify",
 ]
 
 

@@ -243,6 +243,14 @@ int trexhip_copy_to_host(trexhip_ctx* ctx, void* host_dst, const void* device_sr
     return TREXHIP_OK;
 }
 
+int trexhip_copy_to_device(trexhip_ctx* ctx, void* device_dst, const void* host_src, size_t bytes) {
+    if (!ctx || (bytes && (!device_dst || !host_src))) { set_error("trexhip_copy_to_device: null argument"); return TREXHIP_E_INVALID; }
+    TH_CHECK_HIP(hipSetDevice(ctx->p.device));
+    if (bytes) TH_CHECK_HIP(hipMemcpyAsync(device_dst, host_src, bytes, hipMemcpyHostToDevice, ctx->stream));
+    TH_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+    return TREXHIP_OK;
+}
+
 int trexhip_set_stream(trexhip_ctx* ctx, void* hip_stream) {
     if (!ctx) { set_error("null ctx"); return TREXHIP_E_INVALID; }
     TH_CHECK_HIP(hipStreamSynchronize(ctx->stream));
