@@ -110,3 +110,23 @@ def test_capacity_and_errors():
     with pytest.raises(capi.TrexHipError):
         seg.split_search_device(1, 1, 1, 1)                   # no batch yet
     seg.close()
+
+
+def test_large_class_blobs():
+    # blobs beyond the small size class (> 2048 pixels or > 256 lines) take the second launch: 3x upscaled scene
+    fr, bg, _ = merged_scene(21, n_groups=5)
+    fr3, bg3 = np.kron(fr, np.ones((3, 3), np.uint8)), np.kron(bg, np.ones((3, 3), np.uint8))
+    ranges = [(360, 2970)]
+    det, presumed, thr, info, sub = device_search(fr3[None], bg3, lambda r: np.full(len(r.blobs), 2), 1, ranges)
+    sp = oracle.split_params(size_ranges=ranges)
+    r = det[0]
+    big = found = 0
+    for k, b in enumerate(r.blobs):
+        runs = r.runs[b["run_begin"]:b["run_begin"] + b["n_runs"]]
+        px = r.pixels[b["pix_begin"]:b["pix_begin"] + b["n_pixels"]]
+        want = oracle.split_search(runs, px, bg3, 1, sp, 2)
+        assert info[k]["status"] == 0
+        assert (info[k]["threshold"], info[k]["n_result"], info[k]["first_size"]) == (want.threshold, want.n_result, want.first_size)
+        big += b["n_pixels"] > 2048
+        found += want.threshold >= 0 and b["n_pixels"] > 2048
+    assert big >= 3 and found >= 1

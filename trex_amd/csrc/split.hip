@@ -13,9 +13,11 @@
 
 namespace trexhip {
 
-static constexpr int S_PX = 16384;     // pixels per blob held in LDS
+// two size classes: most merged blobs are a few hundred pixels, and the kernel lives on the number of blobs in flight per CU
+static constexpr int S_PX = 16384;     // pixels per blob held in LDS (large class)
 static constexpr int S_RUNS = 1024;    // lines per blob
 static constexpr int S_SUB = 2048;     // lines after thresholding
+static constexpr int S_PX_SMALL = 2048, S_RUNS_SMALL = 256, S_SUB_SMALL = 1024;   // 2048 pixels cannot make more than 1024 lines
 
 enum { A_KEEP = 0, A_KEEP_ABORT = 1, A_REMOVE = 2, A_ABORT = 3, A_TOO_FEW = 4, A_SKIP = 5, A_NO_CHANCE = 6 };
 
@@ -70,6 +72,7 @@ __device__ __forceinline__ bool split_in_range(const SplitCfg& C, float cmsq) { 
     return false;
 }
 
+template <int S_PX, int S_RUNS, int S_SUB, int MIN_PX, int MIN_RUNS>
 __global__ __launch_bounds__(64) void k_split_search(const SplitCfg C, const uint8_t* __restrict__ frames, const uint8_t* __restrict__ bg,
                                                      const trexhip_frame_info* __restrict__ info, const uint32_t* __restrict__ blob_frame,
                                                      const trexhip_blob* __restrict__ blobs, const trexhip_run* __restrict__ runs,
@@ -98,7 +101,12 @@ __global__ __launch_bounds__(64) void k_split_search(const SplitCfg C, const uin
     if (!ok) { if (lane == 0) { res.status = 3; out_info[bi] = res; out_thr[bi] = -1; } return; }
     const trexhip_blob Bl = blobs[bi];
     const int n_runs = (int)Bl.n_runs, npx = (int)Bl.n_pixels;
-    if (n_runs > S_RUNS || npx > S_PX || n_runs == 0) { if (lane == 0) { res.status = n_runs ? 2 : 3; out_info[bi] = res; out_thr[bi] = -1; } return; }
+    if (npx <= MIN_PX && n_runs <= MIN_RUNS) return;           // the small-class launch handles it
+    if (n_runs > S_RUNS || npx > S_PX || n_runs == 0) {
+        if (MIN_PX == 0 && n_runs && npx <= trexhip::S_PX && n_runs <= trexhip::S_RUNS) return;   // left to the large-class launch
+        if (lane == 0) { res.status = n_runs ? 2 : 3; out_info[bi] = res; out_thr[bi] = -1; }
+        return;
+    }
 
     // ---- the blob's lines and pixel offsets ----
     const trexhip_run* rr = runs + fi.run_begin + Bl.run_begin;
@@ -301,8 +309,10 @@ int launch_split_search(trexhip_ctx* ctx, const trexhip_split_params* sp, int me
         if (C.max_start == -1 || C.ranges[2 * i] < C.max_start) C.max_start = C.ranges[2 * i];
         if (C.max_end == -1 || C.ranges[2 * i + 1] > C.max_end) C.max_end = C.ranges[2 * i + 1];
     }
-    hipLaunchKernelGGL(k_split_search, dim3((unsigned)n_blobs), dim3(64), 0, ctx->stream, C, ctx->d_frames, ctx->d_bg, ctx->d_info, ctx->d_blob_frame,
-                       ctx->d_blobs, ctx->d_runs, d_presumed, n_blobs, d_thr, d_info);
+    hipLaunchKernelGGL((k_split_search<S_PX_SMALL, S_RUNS_SMALL, S_SUB_SMALL, 0, 0>), dim3((unsigned)n_blobs), dim3(64), 0, ctx->stream, C, ctx->d_frames,
+                       ctx->d_bg, ctx->d_info, ctx->d_blob_frame, ctx->d_blobs, ctx->d_runs, d_presumed, n_blobs, d_thr, d_info);
+    hipLaunchKernelGGL((k_split_search<S_PX, S_RUNS, S_SUB, S_PX_SMALL, S_RUNS_SMALL>), dim3((unsigned)n_blobs), dim3(64), 0, ctx->stream, C, ctx->d_frames,
+                       ctx->d_bg, ctx->d_info, ctx->d_blob_frame, ctx->d_blobs, ctx->d_runs, d_presumed, n_blobs, d_thr, d_info);
     TH_CHECK_HIP(hipGetLastError());
     return TREXHIP_OK;
 }
