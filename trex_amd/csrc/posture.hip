@@ -27,6 +27,7 @@ struct PostureCfg {
     float outline_resample; int smooth_samples, smooth_step, approximate;
     float curvature_range_ratio, midline_walk_offset; int max_points;
     int nr_cap, rows_cap;            // <= P_NR, P_ROWS
+    int stop;                        // dev only: return after phase N (TREXHIP_POSTURE_STOP)
 };
 
 __device__ __forceinline__ float wsum(float v) {
@@ -107,9 +108,96 @@ __global__ __launch_bounds__(256) void k_posture(const PostureCfg P, const trexh
         return (bm[2 * (y - y0) + (xr >> 5)] >> (xr & 31)) & 1u;
     };
 
-    // ---- outline on the half-pixel lattice + resample: sequential, lane 0 ----
+    // ---- outline on the half-pixel lattice ----
+    // The boundary is a permutation of directed pixel sides: side k of pixel p (k = 0 top, moving +x; 1 right, +y; 2 bottom, -x;
+    // 3 left, -y; the blob on the right hand) is followed by the left-turn side of the pixel ahead-left if that pixel is set, else
+    // the same side of the pixel ahead, else the next side of p itself -- exactly the turn rule of the sequential walk below.  All
+    // sides are numbered (per row and direction: popcounts of bit masks), every lane computes successors, pointer jumping ranks
+    // the cycle through the start side (top side of the first pixel), and each side emits its two points at its rank: ~100
+    // dependent steps of one lane become ~10 short passes of the whole wave.  Needs the one-word-per-row bitmap, rows <= max_points/2
+    // and at most max_points sides (holes included); anything else takes the sequential walk.
     int n = 0, status = 0;
-    if (lane == 0) {
+    bool traced = false;
+    if (use_bm && rows * 2 <= NPc) {
+        uint16_t* base16 = reinterpret_cast<uint16_t*>(bufA);              // first side id per (row, direction)
+        uint32_t* jmp0 = reinterpret_cast<uint32_t*>(bufB);                // next id | hops to the last side << 16, double buffered
+        uint32_t* jmp1 = jmp0 + NPc;
+        uint32_t* geo = reinterpret_cast<uint32_t*>(s_t);                  // x | row << 8 | direction << 16
+        auto row64 = [&](int yr) -> unsigned long long {
+            return (yr < 0 || yr >= rows) ? 0ull : ((unsigned long long)bm[2 * yr] | ((unsigned long long)bm[2 * yr + 1] << 32));
+        };
+        auto side_mask = [&](int yr, int k) -> unsigned long long {
+            const unsigned long long R = row64(yr);
+            return k == 0 ? R & ~row64(yr - 1) : (k == 1 ? R & ~(R >> 1) : (k == 2 ? R & ~row64(yr + 1) : R & ~(R << 1)));
+        };
+        const int items = rows * 4;
+        uint32_t running = 0;
+        for (int i0 = 0; i0 < items; i0 += 64) {
+            const int it = i0 + lane;
+            const uint32_t cnt = it < items ? (uint32_t)__popcll(side_mask(it >> 2, it & 3)) : 0u;
+            uint32_t incl = cnt;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) { const uint32_t t = (uint32_t)__shfl_up((int)incl, d); if (lane >= d) incl += t; }
+            if (it < items) base16[it] = (uint16_t)(running + incl - cnt);
+            running += (uint32_t)__shfl((int)incl, 63);
+        }
+        const int E = (int)running;
+        if (E <= NPc) {
+            __builtin_amdgcn_wave_barrier();
+            for (int it = lane; it < items; it += 64) {
+                const int yr = it >> 2, k = it & 3;
+                unsigned long long m = side_mask(yr, k);
+                uint32_t e = base16[it];
+                const int ddx = k == 0 ? 1 : (k == 2 ? -1 : 0), ddy = k == 1 ? 1 : (k == 3 ? -1 : 0);
+                const int kl = (k + 3) & 3;
+                const int lx = kl == 0 ? 1 : (kl == 2 ? -1 : 0), ly = kl == 1 ? 1 : (kl == 3 ? -1 : 0);
+                while (m) {
+                    const int xr = __builtin_ctzll(m);
+                    m &= m - 1;
+                    int tx = xr + ddx + lx, ty = yr + ddy + ly, tk = kl;                 // ahead-left: turn left
+                    if (!((unsigned)tx < 64u && ((row64(ty) >> tx) & 1ull))) {
+                        tx = xr + ddx; ty = yr + ddy; tk = k;                            // ahead: straight on
+                        if (!((unsigned)tx < 64u && ((row64(ty) >> tx) & 1ull))) { tx = xr; ty = yr; tk = (k + 1) & 3; }   // turn right
+                    }
+                    const uint32_t tid = (uint32_t)base16[ty * 4 + tk] + (uint32_t)__popcll(side_mask(ty, tk) & ((1ull << tx) - 1ull));
+                    // the side whose successor is the start side (id 0: first top side of the first row) ends the cycle
+                    jmp0[e] = tid == 0u ? e : (tid | (1u << 16));
+                    geo[e] = (uint32_t)xr | ((uint32_t)yr << 8) | ((uint32_t)k << 16);
+                    ++e;
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+            uint32_t* cur = jmp0; uint32_t* oth = jmp1;
+            for (int span = 1; span < E; span <<= 1) {
+                for (int e = lane; e < E; e += 64) {
+                    const uint32_t v = cur[e], w = cur[v & 0xffffu];
+                    oth[e] = (w & 0xffffu) | (((v >> 16) + (w >> 16)) << 16);
+                }
+                __builtin_amdgcn_wave_barrier();
+                uint32_t* t = cur; cur = oth; oth = t;
+            }
+            const uint32_t first = cur[0];
+            const int len = (int)(first >> 16) + 1;                                     // sides on the outer cycle
+            const int nt = 2 * len;
+            if (nt > NPc) { status = 2; res.n_traced = 0; }
+            else {
+                for (int e = lane; e < E; e += 64) {
+                    const uint32_t v = cur[e];
+                    if ((v & 0xffffu) != (first & 0xffffu)) continue;                    // a hole's boundary
+                    const int pos = (int)(first >> 16) - (int)(v >> 16);
+                    const uint32_t g = geo[e];
+                    const int xr = (int)(g & 0xffu), yr = (int)((g >> 8) & 0xffu), k = (int)(g >> 16);
+                    const int vx = 2 * xr + ((k == 1 || k == 2) ? 1 : -1), vy = 2 * yr + ((k >= 2) ? 1 : -1);   // doubled, blob-relative
+                    const int ddx = k == 0 ? 1 : (k == 2 ? -1 : 0), ddy = k == 1 ? 1 : (k == 3 ? -1 : 0);
+                    bufA[2 * pos] = make_float2(0.5f * (float)vx, 0.5f * (float)vy);
+                    bufA[2 * pos + 1] = make_float2(0.5f * (float)(vx + ddx), 0.5f * (float)(vy + ddy));
+                }
+                res.n_traced = nt;
+            }
+            traced = true;
+        }
+    }
+    if (!traced && lane == 0) {
         const int fx = (int)(s_runs[0] & 0xffffu);
         const int sx = 2 * fx - 1, sy = 2 * y0 - 1;
         int vx = sx, vy = sy, dx = 1, dy = 0, nt = 0;
@@ -125,8 +213,9 @@ __global__ __launch_bounds__(256) void k_posture(const PostureCfg P, const trexh
         } while (!(vx == sx && vy == sy && dx == 1 && dy == 0));
         res.n_traced = status ? 0 : nt;                 // an outline beyond the capacity reports no points at all
     }
-    int nt_all = __shfl(res.n_traced, 0);
-    status = __shfl(status, 0);
+    if (P.stop == 1) return;
+    int nt_all = traced ? res.n_traced : __shfl(res.n_traced, 0);
+    if (!traced) status = __shfl(status, 0);
     res.n_traced = nt_all;
     __builtin_amdgcn_wave_barrier();
     // Outline::resample (Outline.cpp:724-766).  Every segment of the lattice outline is exactly 0.5 long, so when 2 * resample
@@ -175,6 +264,7 @@ __global__ __launch_bounds__(256) void k_posture(const PostureCfg P, const trexh
     __builtin_amdgcn_wave_barrier();
     if (status) { if (lane == 0) { res.status = status; out_info[bi] = res; } return; }
 
+    if (P.stop == 2) return;
     float2* pts = bufB; float2* other = bufA;
     // ---- smooth_outline (Outline.cpp:330-378): triangular weights over +-range*step ----
     if (P.smooth_samples > 0 && n > P.smooth_samples) {
@@ -253,6 +343,7 @@ __global__ __launch_bounds__(256) void k_posture(const PostureCfg P, const trexh
         __builtin_amdgcn_wave_barrier();
         float2* t = pts; pts = other; other = t;
     }
+    if (P.stop == 3) return;
     // ---- curvature, tail = highest peak, head = farthest peak ----
     int r = (int)(P.curvature_range_ratio * (float)n); if (r < 1) r = 1;
     for (int i = lane; i < n; i += 64) {
@@ -303,6 +394,7 @@ __global__ __launch_bounds__(256) void k_posture(const PostureCfg P, const trexh
     res.n_outline = n; res.tail_index = 0;
     res.head_index = head == 0x7fffffff ? -1 : ((head - tail) % n + n) % n;
     if (n <= 1) { if (lane == 0) { res.status = 1; out_info[bi] = res; } return; }
+    if (P.stop == 4) return;
     // ---- the two-pointer walk (Outline.cpp:790-857): control flow is wave-uniform, the max_offset candidates of each
     // search are evaluated one per lane and reduced to the FIRST minimum (the sequential `len < min_d` rule) ----
     {
@@ -413,7 +505,8 @@ extern "C" int trexhip_posture_device(trexhip_ctx* ctx, int32_t table, const tre
         ctx->attr_posture_bytes = lds_bytes;
     }
     PostureCfg P{pp->outline_resample, pp->outline_smooth_samples, pp->outline_smooth_step, pp->outline_approximate,
-                 pp->outline_curvature_range_ratio, pp->midline_walk_offset, pp->max_points, nr_cap, rows_cap};
+                 pp->outline_curvature_range_ratio, pp->midline_walk_offset, pp->max_points, nr_cap, rows_cap, 0};
+    if (const char* e = std::getenv("TREXHIP_POSTURE_STOP")) P.stop = std::atoi(e);
     stage_begin(ctx, TREXHIP_STAGE_POSTURE);
     hipLaunchKernelGGL(k_posture, dim3((n_blobs + 3) / 4), dim3(256), lds_bytes, ctx->stream, P, info, bf, bl, ru, n_blobs, ctx->last_n,
                        reinterpret_cast<float2*>(d_outline), reinterpret_cast<float4*>(d_segments), d_info);
