@@ -85,7 +85,8 @@ def test_synthetic_individuals():
 
 
 @pytest.mark.parametrize("kw", [dict(outline_resample=0.5), dict(outline_resample=2.0, outline_smooth_samples=0),
-                                 dict(outline_approximate=0), dict(outline_approximate=1, midline_walk_offset=0.1)])
+                                 dict(outline_approximate=0), dict(outline_approximate=1, midline_walk_offset=0.1),
+                                 dict(outline_resample=0.5, midline_walk_offset=0.45), dict(midline_walk_offset=0.07), dict(outline_resample=0.5, midline_walk_offset=0.06)])
 def test_setting_variants_and_odd_shapes(kw):
     rng = np.random.default_rng(3)
     H, W = 160, 320
@@ -104,7 +105,7 @@ def test_setting_variants_and_odd_shapes(kw):
     res, outline, segs, info = run_posture(fr[None], bg, **kw)
     # order-1 EFT turns every outline into an exact ellipse whose two tips have EQUAL curvature: the tail is a coin flip
     # decided by float rounding there, so only the closed curve is compared for that variant
-    compare(res, outline, segs, info, oracle.posture_params(max_points=512, **kw), min_ok=0.0 if kw.get("outline_approximate") == 1 else 0.8)
+    compare(res, outline, segs, info, oracle.posture_params(max_points=512, **kw), min_ok=0.0 if kw.get("outline_approximate") == 1 else (0.6 if "midline_walk_offset" in kw else 0.8))   # the random discs have near-tied curvature peaks
 
 
 def test_rethreshold_table_and_capacity():

@@ -24,7 +24,7 @@ for case in range(n_cases):
     if rng.random() < 0.5: kw["outline_resample"] = float(rng.choice([0.5, 1.0, 1.5, 2.0, 0.7, 1.3]))
     if rng.random() < 0.3: kw["outline_smooth_samples"] = int(rng.choice([0, 2, 6]))
     if rng.random() < 0.3: kw["outline_approximate"] = int(rng.choice([0, 2, 3]))
-    if rng.random() < 0.3: kw["midline_walk_offset"] = float(rng.choice([0.01, 0.05, 0.1]))
+    if rng.random() < 0.3: kw["midline_walk_offset"] = float(rng.choice([0.01, 0.05, 0.1, 0.2, 0.45]))
     try:
         res, outline, segs, info = run_posture(fr[None], bg, max_points=1024, **kw)
         total += compare(res, outline, segs, info, oracle.posture_params(max_points=1024, **kw), min_ok=0.0)

@@ -12,6 +12,7 @@
 // The float pipeline is compiled without FMA contraction (-ffp-contract=off in the Makefile) so resample / smooth /
 // walk reproduce the CPU operation order; the transcendental part (EFT) agrees to float rounding.
 #include "internal.h"
+#include <type_traits>
 
 namespace trexhip {
 
@@ -316,26 +317,37 @@ __global__ __launch_bounds__(256) void k_posture(const PostureCfg P, const trexh
         float ca[4][4];                                           // [harmonic 1..3][a b c d]
         const int order = min(P.approximate, 3);
         for (int h = 1; h <= order; ++h) {
+            // cos / sin of the phase at every point once (segment i ends where segment i + 1 starts: same expression, same value),
+            // kept in the spare point buffer
+            for (int i = lane; i < n; i += 64) {
+                float sn, cs;
+                sincosf(2.0f * PI * (float)h * s_t[i] / T, &sn, &cs);
+                other[i] = make_float2(cs, sn);
+            }
+            float snE, csE;
+            sincosf(2.0f * PI * (float)h * T / T, &snE, &csE);
+            __builtin_amdgcn_wave_barrier();
             float sa = 0.f, sb = 0.f, sc = 0.f, sd = 0.f;
             for (int i = lane; i < n; i += 64) {
                 const float2 a = pts[i], q = pts[(i + 1) % n];
                 const float t0 = s_t[i], t1 = (i + 1 < n) ? s_t[i + 1] : T;
                 const float dt = t1 - t0;
                 if (dt <= 0.f) continue;
-                const float ph1 = 2.0f * PI * (float)h * t1 / T, ph0 = 2.0f * PI * (float)h * t0 / T;
-                const float dc = cosf(ph1) - cosf(ph0), ds = sinf(ph1) - sinf(ph0);
+                const float2 c0 = other[i], c1 = (i + 1 < n) ? other[i + 1] : make_float2(csE, snE);
+                const float dc = c1.x - c0.x, ds = c1.y - c0.y;
                 const float ddx = q.x - a.x, ddy = q.y - a.y;
                 sa += ddx / dt * dc; sb += ddx / dt * ds; sc += ddy / dt * dc; sd += ddy / dt * ds;
             }
             const float k = T / (2.0f * (float)(h * h) * PI * PI);
             ca[h][0] = k * wsum(sa); ca[h][1] = k * wsum(sb); ca[h][2] = k * wsum(sc); ca[h][3] = k * wsum(sd);
+            __builtin_amdgcn_wave_barrier();
         }
         for (int i = lane; i < n; i += 64) {
             const float tt = (float)i / (float)n;
             float x = cx, y = cy;
             for (int h = 1; h <= order; ++h) {
-                const float ph = 2.0f * PI * (float)h * tt;
-                const float cs = cosf(ph), sn = sinf(ph);
+                float sn, cs;
+                sincosf(2.0f * PI * (float)h * tt, &sn, &cs);
                 x += ca[h][0] * cs + ca[h][1] * sn; y += ca[h][2] * cs + ca[h][3] * sn;
             }
             other[i] = make_float2(x, y);
@@ -396,7 +408,9 @@ __global__ __launch_bounds__(256) void k_posture(const PostureCfg P, const trexh
     if (n <= 1) { if (lane == 0) { res.status = 1; out_info[bi] = res; } return; }
     if (P.stop == 4) return;
     // ---- the two-pointer walk (Outline.cpp:790-857): control flow is wave-uniform, the max_offset candidates of each
-    // search are evaluated one per lane and reduced to the FIRST minimum (the sequential `len < min_d` rule) ----
+    // search are evaluated one per lane and reduced to the FIRST minimum (the sequential `len < min_d` rule).  The kernel is bound
+    // by instruction issue, so the loop only keeps what the next iteration depends on: the pair of outline indices of every
+    // segment goes to LDS and the segments themselves (two square roots each) are computed by all lanes afterwards. ----
     {
         const int L = n;
         int idx_r = 1, idx_l = -1, ns = 0;
@@ -404,11 +418,67 @@ __global__ __launch_bounds__(256) void k_posture(const PostureCfg P, const trexh
         const int max_offset = (int)mo;
         float4* so = out_segments + (size_t)bi * (P.max_points / 2 + 1);
         const float BIG = 3.402823466e38f;
-        int red = 1; while (red < max_offset && red < 64) red <<= 1;     // lanes taking part in one search (power of two)
+        uint32_t* s_pair = reinterpret_cast<uint32_t*>(s_curv);          // curvature is done: right index (0xffff = none) | left index << 16
+        const int seg_cap = P.max_points / 2 + 1;
+        auto walk = [&](auto REDC) {
+            constexpr int RED = decltype(REDC)::value;                   // lanes taking part in one search (power of two >= max_offset)
+            while (idx_r < L + idx_l) {
+                const float2 pl0 = pts[L + idx_l];
+                float len = BIG; int idx = 0x7fffffff;
+                if (lane < max_offset && idx_r + lane < L) {
+                    const float2 pt = pts[idx_r + lane];
+                    const float ddx = pt.x - pl0.x, ddy = pt.y - pl0.y;
+                    len = sqrtf(ddx * ddx + ddy * ddy); idx = idx_r + lane;
+                    if (!(len < BIG)) { len = BIG; idx = 0x7fffffff; }
+                }
+#pragma unroll
+                for (int d = 1; d < RED; d <<= 1) {
+                    const float ol = __shfl_xor(len, d); const int oi = __shfl_xor(idx, d);
+                    if (ol < len || (ol == len && oi < idx)) { len = ol; idx = oi; }
+                }
+                float2 pt_r = make_float2(0.f, 0.f);
+                uint32_t used_r = 0xffffu;
+                if (idx != 0x7fffffff) { pt_r = pts[idx]; idx_r = idx; used_r = (uint32_t)idx; }
+                float len2 = BIG; int key = 0x7fffffff;
+                if (lane < max_offset && idx_l - lane > -L) {
+                    const float2 pt = pts[L + idx_l - lane];
+                    const float ddx = pt_r.x - pt.x, ddy = pt_r.y - pt.y;
+                    len2 = sqrtf(ddx * ddx + ddy * ddy); key = lane;
+                    if (!(len2 < BIG)) { len2 = BIG; key = 0x7fffffff; }
+                }
+#pragma unroll
+                for (int d = 1; d < RED; d <<= 1) {
+                    const float ol = __shfl_xor(len2, d); const int ok2 = __shfl_xor(key, d);
+                    if (ol < len2 || (ol == len2 && ok2 < key)) { len2 = ol; key = ok2; }
+                }
+                if (key != 0x7fffffff) idx_l -= key;
+                if (lane == 0 && ns < seg_cap) s_pair[ns] = used_r | ((uint32_t)(L + idx_l) << 16);
+                ++ns;
+                idx_r++; idx_l--;
+            }
+        };
+        if (max_offset <= 64) {
+            if (max_offset <= 4) walk(std::integral_constant<int, 4>{});
+            else if (max_offset <= 8) walk(std::integral_constant<int, 8>{});
+            else if (max_offset <= 16) walk(std::integral_constant<int, 16>{});
+            else walk(std::integral_constant<int, 64>{});
+            __builtin_amdgcn_wave_barrier();
+            const int nseg = ns < seg_cap ? ns : seg_cap;
+            for (int i = lane; i < nseg; i += 64) {
+                const uint32_t pr = s_pair[i];
+                const float2 pt_r = (pr & 0xffffu) == 0xffffu ? make_float2(0.f, 0.f) : pts[pr & 0xffffu];
+                const float2 pt_l = pts[pr >> 16];
+                const float lx = pt_r.x - pt_l.x, ly = pt_r.y - pt_l.y;
+                const float mx = pt_l.x + lx * 0.5f, my = pt_l.y + ly * 0.5f;
+                so[i] = make_float4(mx, my, sqrtf(lx * lx + ly * ly), sqrtf((mx - pt_l.x) * (mx - pt_l.x) + (my - pt_l.y) * (my - pt_l.y)));
+            }
+        } else {
+        // more candidates than lanes (midline_walk_offset * points > 64): several passes per search
+        int red = 64;
         while (idx_r < L + idx_l) {
             float2 pt_r = make_float2(0.f, 0.f); float2 pt_l = pts[L + idx_l];
             int min_idx = -1; float best1 = BIG;
-            for (int i0 = 0; i0 < max_offset; i0 += 64) {           // one pass unless max_offset > 64
+            for (int i0 = 0; i0 < max_offset; i0 += 64) {
                 const int i = i0 + lane;
                 float len = BIG; int idx = 0x7fffffff;
                 if (i < max_offset && idx_r + i < L) {
@@ -418,11 +488,9 @@ __global__ __launch_bounds__(256) void k_posture(const PostureCfg P, const trexh
                     if (!(len < BIG)) { len = BIG; idx = 0x7fffffff; }
                 }
                 float bl = len; int bidx = idx;
-#define WALK_STEP(d_) if (red > (d_)) { const float ol = __shfl_xor(bl, d_); const int oi = __shfl_xor(bidx, d_); if (ol < bl || (ol == bl && oi < bidx)) { bl = ol; bidx = oi; } }
-                WALK_STEP(1) WALK_STEP(2) WALK_STEP(4) WALK_STEP(8) WALK_STEP(16) WALK_STEP(32)      // constant distances: DPP for the short ones
-#undef WALK_STEP
+#pragma unroll
+                for (int d = 1; d < 64; d <<= 1) { const float ol = __shfl_xor(bl, d); const int oi = __shfl_xor(bidx, d); if (ol < bl || (ol == bl && oi < bidx)) { bl = ol; bidx = oi; } }
                 if (bidx != 0x7fffffff && bl < best1) { best1 = bl; min_idx = bidx; }    // strict `<`: earlier candidates keep ties
-                if (max_offset <= 64) break;
             }
             if (min_idx != -1) { pt_r = pts[min_idx]; idx_r = min_idx; }
             int min_idx2 = 1; float best2 = BIG;
@@ -436,11 +504,9 @@ __global__ __launch_bounds__(256) void k_posture(const PostureCfg P, const trexh
                     if (!(len < BIG)) { len = BIG; key = 0x7fffffff; }
                 }
                 float bl = len; int bk = key;
-#define WALK_STEP(d_) if (red > (d_)) { const float ol = __shfl_xor(bl, d_); const int ok2 = __shfl_xor(bk, d_); if (ol < bl || (ol == bl && ok2 < bk)) { bl = ol; bk = ok2; } }
-                WALK_STEP(1) WALK_STEP(2) WALK_STEP(4) WALK_STEP(8) WALK_STEP(16) WALK_STEP(32)
-#undef WALK_STEP
+#pragma unroll
+                for (int d = 1; d < 64; d <<= 1) { const float ol = __shfl_xor(bl, d); const int ok2 = __shfl_xor(bk, d); if (ol < bl || (ol == bl && ok2 < bk)) { bl = ol; bk = ok2; } }
                 if (bk != 0x7fffffff && bl < best2) { best2 = bl; min_idx2 = idx_l - bk; }
-                if (max_offset <= 64) break;
             }
             if (min_idx2 != 1) { pt_l = pts[L + min_idx2]; idx_l = min_idx2; }
             const float lx = pt_r.x - pt_l.x, ly = pt_r.y - pt_l.y;
@@ -449,6 +515,8 @@ __global__ __launch_bounds__(256) void k_posture(const PostureCfg P, const trexh
                 so[ns] = make_float4(mx, my, sqrtf(lx * lx + ly * ly), sqrtf((mx - pt_l.x) * (mx - pt_l.x) + (my - pt_l.y) * (my - pt_l.y)));
             ++ns;
             idx_r++; idx_l--;
+        }
+        (void)red;
         }
         if (lane == 0) {
             res.n_segments = ns;
