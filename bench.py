@@ -134,8 +134,8 @@ def main():
 
         def identify(self, step_idx):
             seg = self.seg
-            res = seg.fetch(copy=False)             # waits for detect; blob/run/pixel tables now on this rank's host
-            n = self.n = sum(len(r.blobs) for r in res)
+            res = seg.fetch_raw()                   # waits for detect; blob/run/pixel tables now on this rank's host (pinned)
+            n = self.n = int(res.total_blobs)
             assert n <= rows, "identity table too small"
             if self.hi is not None:
                 seg.set_stream(self.stream.cuda_stream)

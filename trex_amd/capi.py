@@ -258,6 +258,16 @@ class Segmenter:
     def synchronize(self):
         _check(lib().trexhip_synchronize(self._h))
 
+    def fetch_raw(self, rethreshold=False):
+        """trexhip_fetch without building per-frame views: the BatchResult struct (counts + pointers into the context's pinned tables)."""
+        r = BatchResult()
+        rc = (lib().trexhip_fetch_rethreshold if rethreshold else lib().trexhip_fetch)(self._h, C.byref(r))
+        if rc != 0 and rc != -3:
+            _check(rc)
+        if rc == -3:
+            self.last_capacity_error = lib().trexhip_last_error().decode()
+        return r
+
     def fetch(self, copy=True, rethreshold=False):
         r = BatchResult()
         rc = (lib().trexhip_fetch_rethreshold if rethreshold else lib().trexhip_fetch)(self._h, C.byref(r))
