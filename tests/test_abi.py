@@ -32,14 +32,18 @@ def test_library_exports_every_declared_symbol():
 
 def test_struct_layouts_match_header(tmp_path):
     src = tmp_path / "sz.c"
-    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "trexhip.h"\nint main(){printf("%zu %zu %zu %zu %zu %zu %zu\\n",'
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "trexhip.h"\nint main(){printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\\n",'
                    'sizeof(trexhip_params),sizeof(trexhip_run),sizeof(trexhip_blob),sizeof(trexhip_frame_info),'
-                   'sizeof(trexhip_batch_result),offsetof(trexhip_params,cm_per_pixel),offsetof(trexhip_blob,m10));return 0;}\n')
+                   'sizeof(trexhip_batch_result),offsetof(trexhip_params,cm_per_pixel),offsetof(trexhip_blob,m10),'
+                   'sizeof(trexhip_split_params),offsetof(trexhip_split_params,size_ranges),sizeof(trexhip_split_info),'
+                   'offsetof(trexhip_split_info,min_size_bound));return 0;}\n')
     exe = tmp_path / "sz"
     subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
     got = [int(x) for x in subprocess.check_output([str(exe)]).split()]
     assert got == [C.sizeof(capi.Params), capi.RUN_DTYPE.itemsize, capi.BLOB_DTYPE.itemsize, capi.INFO_DTYPE.itemsize,
-                   C.sizeof(capi.BatchResult), capi.Params.cm_per_pixel.offset, capi.BLOB_DTYPE.fields["m10"][1]]
+                   C.sizeof(capi.BatchResult), capi.Params.cm_per_pixel.offset, capi.BLOB_DTYPE.fields["m10"][1],
+                   C.sizeof(capi.SplitParams), capi.SplitParams.size_ranges.offset, capi.SPLIT_INFO_DTYPE.itemsize,
+                   capi.SPLIT_INFO_DTYPE.fields["min_size_bound"][1]]
 
 
 def test_oracle_and_product_share_table_layouts():

@@ -183,6 +183,8 @@ def test_errors():
     seg.close()
     with pytest.raises(capi.TrexHipError):
         capi.Segmenter(capi.default_params(70000, 64))
+    with pytest.raises(capi.TrexHipError):      # pooled tables are indexed with 32 bits
+        capi.Segmenter(capi.default_params(64, 64, max_batch=8192, max_pixels=1 << 20))
 
 
 @pytest.mark.parametrize("channels,color_channel", [(3, -1), (4, -1), (3, 1), (4, 2), (3, 7)])

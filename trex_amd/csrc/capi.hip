@@ -130,6 +130,10 @@ int trexhip_create(const trexhip_params* p, trexhip_ctx** out) {
     if (p->max_batch <= 0 || p->max_runs <= 0 || p->max_blobs <= 0 || p->max_pixels <= 0) {
         set_error("trexhip_create: capacities must be positive"); return TREXHIP_E_INVALID;
     }
+    if ((uint64_t)p->max_batch * (uint64_t)p->max_pixels > 0xffffffffull || (uint64_t)p->max_batch * (uint64_t)p->max_runs > 0xffffffffull ||
+        (uint64_t)p->max_batch * (uint64_t)p->max_blobs > 0xffffffffull) {
+        set_error("trexhip_create: max_batch * max_pixels / max_runs / max_blobs must stay below 2^32 (pooled tables are indexed with 32 bits)"); return TREXHIP_E_INVALID;
+    }
     if (p->connectivity != 8 && p->connectivity != 4) { set_error("trexhip_create: connectivity must be 4 or 8"); return TREXHIP_E_INVALID; }
     if (p->n_ranges < 0 || p->n_ranges > 8) { set_error("trexhip_create: n_ranges must be 0..8"); return TREXHIP_E_INVALID; }
     if ((p->use_closing && (p->closing_size < 1 || p->closing_size > 15)) || p->dilation_size > 7 || p->dilation_size < -7) {
