@@ -141,6 +141,12 @@ int trexhip_set_stream(trexhip_ctx* ctx, void* hip_stream);
 /* BackgroundSubtraction::set_background -> Data::set (BackgroundSubtraction.cpp:86-101) */
 int trexhip_set_background(trexhip_ctx* ctx, const uint8_t* gray, int32_t stride);
 int trexhip_set_background_device(trexhip_ctx* ctx, const uint8_t* d_gray);
+/* Background(image, meta_encoding_t::rgb8): a BGR / BGRA background.  Detection and the track-stage thresholds keep using its
+ * cv::cvtColor(BGR2GRAY) (or the picked color_channel, as in trexhip_segment_color), which this call also installs as the gray
+ * background; the colour image stays resident for the per-channel background-difference crops of the rgb8 pixel encoding
+ * (imageFromLines' `differences`, Application/Tests/test_pixels.cpp:1381-1479). */
+int trexhip_set_background_color(trexhip_ctx* ctx, const uint8_t* bgr, int32_t stride_bytes, int32_t channels, int32_t color_channel);
+int trexhip_set_background_color_device(trexhip_ctx* ctx, const uint8_t* d_bgr, int32_t channels, int32_t color_channel);
 
 /* background model from n sampled gray frames in HBM ("next" row of SURVEY.md 8f: Segmenter::trigger_average_generator,
  * ui/Segmenter.cpp:467-566; averaging_method grabber/misc/default_config.cpp:131): method 0 = mean (float accumulation in
@@ -274,8 +280,8 @@ int trexhip_midline_device(trexhip_ctx* ctx, const trexhip_midline_params* mp, i
 /* ---- crops ------------------------------------------------------------------------------------
  * constraints::diff_image (tracking/FilterCache.cpp:265-294): one out_w x out_h uint8 crop per blob of the
  * last segmented batch, pooled order (blob i of trexhip_fetch == crop i).  n_blobs = total_blobs of that
- * batch ([n][out_h][out_w][3] for the rgb8 pixel encoding, colour codes warped with nearest neighbour for r3g3b2; raw pixels
- * only for the colour encodings).  normalization: individual_image_normalization none or
+ * batch ([n][out_h][out_w][3] for the rgb8 pixel encoding, colour codes warped with nearest neighbour for r3g3b2; the difference modes of rgb8 are per-channel
+ * differences against the colour background of trexhip_set_background_color, r3g3b2 crops hold raw codes only).  normalization: individual_image_normalization none or
  * moments (posture / legacy: next function).  difference: 0 = grey
  * values, 1 = |bg - p|, 2 = max(bg - p, 0)  (track_background_subtraction, FilterCache.cpp:171-175). */
 enum { TREXHIP_NORMALIZE_NONE = 0, TREXHIP_NORMALIZE_MOMENTS = 1, TREXHIP_NORMALIZE_POSTURE = 2 };

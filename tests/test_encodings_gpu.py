@@ -139,7 +139,75 @@ def test_rgb8_crops_and_gray_api_guard():
             assert np.array_equal(got[k, :, :, c], want), ("posture", k, c)
     assert n_ok >= 3
     with pytest.raises(capi.TrexHipError):
-        seg.crops_device(d_crops.data_ptr(), n, difference=1)                  # background-difference colour crops: not implemented
+        seg.crops_device(d_crops.data_ptr(), n, difference=1)                  # background-difference colour crops need the colour background
+    seg.close()
+
+
+def test_rgb8_difference_crops_need_and_use_the_colour_background():
+    # Background(image, rgb8): per-channel differences (ImageFromLines.RGB8AbsoluteThresholdWithBackground, Tests/test_pixels.cpp:1381-1479)
+    rng = np.random.default_rng(9)
+    fr, bgc = scene(8, ch=3)
+    bgc = np.clip(bgc.astype(int) + rng.integers(-40, 40, bgc.shape), 0, 255).astype(np.uint8)        # a textured colour background
+    fr = np.where((fr == 150).all(axis=2, keepdims=True), bgc, fr)
+    W, H = bgc.shape[1], bgc.shape[0]
+    seg = capi.Segmenter(capi.default_params(W, H, max_batch=1, pixel_encoding=capi.ENC_RGB8))
+    seg.set_background_color(bgc)
+    assert np.array_equal(seg.get_background(), oracle.bgr2gray(bgc))          # detection works on its cvtColor image
+    seg.segment_color_host([fr])
+    r = seg.fetch()[0]
+    n = len(r.blobs)
+    assert n >= 5
+    d_crops = torch.zeros((n, 80, 80, 3), dtype=torch.uint8, device="cuda")
+    MP = 512
+    outline = torch.zeros((n, MP, 2), dtype=torch.float32, device="cuda"); segs = torch.zeros((n, MP // 2 + 1, 4), dtype=torch.float32, device="cuda")
+    info = torch.zeros((n, 8), dtype=torch.int32, device="cuda"); mid = torch.zeros((n, 25, 4), dtype=torch.float32, device="cuda"); minfo = torch.zeros((n, 8), dtype=torch.int32, device="cuda")
+    seg.posture_device(n, outline.data_ptr(), segs.data_ptr(), info.data_ptr(), max_points=MP)
+    seg.midline_device(n, MP, info.data_ptr(), segs.data_ptr(), mid.data_ptr(), minfo.data_ptr())
+    seg.synchronize()                                                          # the context has its own stream
+    mi = minfo.cpu().numpy().view(capi.MIDLINE_INFO_DTYPE).reshape(-1)
+    for diff in (1, 2):
+        seg.crops_device(d_crops.data_ptr(), n, difference=diff)
+        seg.synchronize()
+        got = d_crops.cpu().numpy()
+        for k, b in enumerate(r.blobs):
+            for c in range(3):
+                assert np.array_equal(got[k, :, :, c], oracle.crop_none(fr[..., c], bgc[..., c], b, r.runs, difference=diff)), ("none", diff, k, c)
+        seg.crops_device(d_crops.data_ptr(), n, normalization=1, difference=diff)
+        seg.synchronize()
+        got = d_crops.cpu().numpy()
+        for k, b in enumerate(r.blobs):
+            for c in range(3):
+                want, _ = oracle.crop_normalized(fr[..., c], bgc[..., c], b, r.runs, difference=diff)
+                assert np.array_equal(got[k, :, :, c], want), ("moments", diff, k, c)
+        seg.crops_posture_device(d_crops.data_ptr(), n, minfo.data_ptr(), difference=diff)
+        seg.synchronize()
+        got = d_crops.cpu().numpy()
+        for k, b in enumerate(r.blobs):
+            if mi[k]["status"] != 0:
+                continue
+            tr = oracle.midline_transform(mi[k]["angle"], mi[k]["offx"], mi[k]["offy"], False)
+            for c in range(3):
+                want, _ = oracle.crop_normalized(fr[..., c], bgc[..., c], b, r.runs, tr6=tr, midline_length=float(mi[k]["len"]), difference=diff)
+                assert np.array_equal(got[k, :, :, c], want), ("posture", diff, k, c)
+    seg.close()
+    # the reference's own vector: 4x2 rgb8 blob on an rgb8 background, threshold 25, `differences` image
+    blob = np.array([(25, 25, 25), (110, 110, 110), (80, 80, 80), (10, 200, 10), (30, 30, 30), (95, 95, 95), (200, 200, 200), (100, 100, 100)], np.uint8)
+    frame = blob.reshape(2, 4, 3)
+    bgv = np.array([[30, 50, 70, 90], [40, 60, 80, 100]], np.uint8)
+    bg3 = np.repeat(bgv[:, :, None], 3, axis=2)
+    seg = capi.Segmenter(capi.default_params(4, 2, max_batch=1, pixel_encoding=capi.ENC_RGB8, threshold=25, inclusive=1))
+    seg.set_background_color(bg3)
+    seg.segment_color_host([frame])
+    r = seg.fetch()[0]
+    assert len(r.blobs) == 1 and r.blobs[0]["n_pixels"] == 4                    # recount 4, one 8-connected blob
+    crop = torch.zeros((1, 4, 4, 3), dtype=torch.uint8, device="cuda")
+    seg.crops_device(crop.data_ptr(), 1, out_w=4, out_h=4, difference=1)
+    seg.synchronize()
+    got = crop.cpu().numpy()[0]
+    # bounding box x 1..3, y 0..1 centred in 4x4: one column / row of padding on the left / top
+    assert got[1, 1].tolist() == [60, 60, 60] and got[1, 3].tolist() == [80, 110, 80]
+    assert got[2, 1].tolist() == [35, 35, 35] and got[2, 2].tolist() == [120, 120, 120]
+    assert got.sum() == 180 + 270 + 105 + 360
     seg.close()
 
 

@@ -80,3 +80,22 @@ def test_rgb8_background_subtraction_uses_all_channels():
     for blob in [(200, 10, 10), (10, 200, 10), (10, 10, 200), (200, 200, 200)]:
         r, p = oracle.line_without_grid_enc(R((0, 0, 0)), np.array(blob, np.uint8), oracle.ENC_RGB8, bg, oracle.ENC_RGB8, ABS, 20)
         assert lines(r) == [(0, 0, 0)] and p.tolist() == list(blob)
+
+
+def test_rgb8_difference_image_reference_vector():
+    # ImageFromLines.RGB8AbsoluteThresholdWithBackground (Tests/test_pixels.cpp:1381-1479): the `differences` image of an rgb8 blob
+    # against an rgb8 background is the per-channel absolute difference of the pixels that pass the threshold
+    blob = np.array([(25, 25, 25), (110, 110, 110), (80, 80, 80), (10, 200, 10), (30, 30, 30), (95, 95, 95), (200, 200, 200), (100, 100, 100)], np.uint8)
+    frame = blob.reshape(2, 4, 3)
+    bgc = _bg_4x2()
+    r, _ = oracle.line_without_grid_enc(R((0, 0, 3), (1, 0, 3)), blob.reshape(-1), oracle.ENC_RGB8, bgc, oracle.ENC_RGB8, ABS, 25)
+    kept = np.zeros(1, oracle.BLOB_DTYPE)[0]
+    kept["x0"], kept["y0"], kept["x1"], kept["y1"], kept["run_begin"], kept["n_runs"] = 0, 0, 3, 1, 0, len(r)
+    diff = np.stack([oracle.crop_none(frame[..., c], bgc[..., c], kept, r, out_w=4, out_h=2, difference=1) for c in range(3)], axis=-1)
+    expected = np.array([[(0, 0, 0), (60, 60, 60), (0, 0, 0), (80, 110, 80)],
+                         [(0, 0, 0), (35, 35, 35), (120, 120, 120), (0, 0, 0)]], np.uint8)
+    assert np.array_equal(diff, expected)
+    image = np.stack([oracle.crop_none(frame[..., c], bgc[..., c], kept, r, out_w=4, out_h=2) for c in range(3)], axis=-1)
+    expected_image = np.array([[(0, 0, 0), (110, 110, 110), (0, 0, 0), (10, 200, 10)],
+                               [(0, 0, 0), (95, 95, 95), (200, 200, 200), (0, 0, 0)]], np.uint8)
+    assert np.array_equal(image, expected_image)

@@ -95,7 +95,7 @@ class TrexHipError(RuntimeError):
 # every symbol include/trexhip.h declares (tests check the library exports all of them)
 SYMBOLS = [
     "trexhip_abi_version", "trexhip_last_error", "trexhip_default_params", "trexhip_create", "trexhip_destroy",
-    "trexhip_set_stream", "trexhip_set_background", "trexhip_set_background_device", "trexhip_generate_average_device", "trexhip_get_background", "trexhip_segment_device",
+    "trexhip_set_stream", "trexhip_set_background", "trexhip_set_background_device", "trexhip_set_background_color", "trexhip_set_background_color_device", "trexhip_generate_average_device", "trexhip_get_background", "trexhip_segment_device",
     "trexhip_segment", "trexhip_segment_color", "trexhip_segment_color_device", "trexhip_rethreshold_device", "trexhip_rethreshold_per_blob_device", "trexhip_fetch_rethreshold", "trexhip_fetch", "trexhip_device_view_get", "trexhip_synchronize",
     "trexhip_profile_enable", "trexhip_profile_read", "trexhip_profile_reset",
     "trexhip_default_posture_params", "trexhip_posture_device", "trexhip_crops_device", "trexhip_pixel_channels", "trexhip_device_alloc", "trexhip_device_free", "trexhip_copy_to_host", "trexhip_copy_to_device", "trexhip_crops_transformed_device", "trexhip_crops_posture_device", "trexhip_default_midline_params", "trexhip_midline_device", "trexhip_default_split_params", "trexhip_split_search_device", "trexhip_export_id_table_device", "trexhip_load_weights", "trexhip_set_identity_precision", "trexhip_num_classes", "trexhip_identify_device", "trexhip_identify",
@@ -117,6 +117,8 @@ def lib():
         L.trexhip_set_stream.argtypes = [C.c_void_p, C.c_void_p]
         L.trexhip_set_background.argtypes = [C.c_void_p, C.c_void_p, C.c_int32]
         L.trexhip_set_background_device.argtypes = [C.c_void_p, C.c_void_p]
+        L.trexhip_set_background_color.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32]
+        L.trexhip_set_background_color_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32]
         L.trexhip_generate_average_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32]
         L.trexhip_get_background.argtypes = [C.c_void_p, C.c_void_p, C.c_int32]
         L.trexhip_segment_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int32]
@@ -234,6 +236,12 @@ class Segmenter:
         _check(lib().trexhip_get_background(self._h, out.ctypes.data_as(C.c_void_p), out.shape[1]))
         return out
 
+    def get_background(self):
+        """The context's gray background as numpy uint8 [H,W]."""
+        out = np.empty((self.params.height, self.params.width), np.uint8)
+        _check(lib().trexhip_get_background(self._h, out.ctypes.data_as(C.c_void_p), out.shape[1]))
+        return out
+
     def segment_device(self, d_ptr, n):
         """Enqueue the detect stage for n HBM-resident gray frames at device address d_ptr."""
         _check(lib().trexhip_segment_device(self._h, C.c_void_p(d_ptr), n))
@@ -243,6 +251,12 @@ class Segmenter:
         ptrs = (C.c_void_p * len(frames))(*[f.ctypes.data for f in frames])
         stride = frames[0].shape[1] if frames else self.params.width
         _check(lib().trexhip_segment(self._h, ptrs, stride, len(frames)))
+
+    def set_background_color(self, bgc, color_channel=-1):
+        """bgc: numpy uint8 [H,W,3|4] BGR / BGRA background (Background(image, rgb8)); also installs its gray image."""
+        bgc = np.ascontiguousarray(bgc, np.uint8)
+        assert bgc.shape[:2] == (self.params.height, self.params.width)
+        _check(lib().trexhip_set_background_color(self._h, bgc.ctypes.data_as(C.c_void_p), bgc.shape[1] * bgc.shape[2], bgc.shape[2], color_channel))
 
     def segment_color_host(self, frames, color_channel=-1):
         """frames: list of uint8 [H,W,3|4] BGR/BGRA host images (what TRex's TileImage holds)."""

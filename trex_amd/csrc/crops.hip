@@ -20,7 +20,8 @@ __global__ __launch_bounds__(256) void k_crops_none(const SegCfg c, const uint8_
                                                     const trexhip_blob* __restrict__ blobs,
                                                     const trexhip_run* __restrict__ runs, uint8_t* __restrict__ crops,
                                                     int OW, int OH, int diff_mode /*0 raw, 1 |bg-p|, 2 max(bg-p,0)*/,
-                                                    const uint8_t* __restrict__ color, int color_ch, int och /*1 grey or r3g3b2 code, 3 rgb8*/, int enc) {
+                                                    const uint8_t* __restrict__ color, int color_ch, int och /*1 grey or r3g3b2 code, 3 rgb8*/, int enc,
+                                                    const uint8_t* __restrict__ bgc, int bgc_ch) {
     const uint32_t bi = blockIdx.x;
     uint8_t* out = crops + (size_t)bi * OW * OH * och;
     for (int i = threadIdx.x * 16; i < OW * OH * och; i += 256 * 16) *reinterpret_cast<uint4*>(out + i) = make_uint4(0, 0, 0, 0);
@@ -47,7 +48,11 @@ __global__ __launch_bounds__(256) void k_crops_none(const SegCfg c, const uint8_
             if (och == 3) {                                   // rgb8: the colour pixel itself (imageFromLines, Tests/test_pixels.cpp:1381-1460)
                 const uint8_t* s = color + (((size_t)f * c.H + q.y) * c.W + x) * color_ch;
                 uint8_t* d = out + ((size_t)oy * OW + ox) * 3;
-                d[0] = s[0]; d[1] = s[1]; d[2] = s[2];
+                if (diff_mode) {                              // per-channel background difference (imageFromLines' `differences`, Tests/test_pixels.cpp:1462-1479)
+                    const uint8_t* b3 = bgc + ((size_t)q.y * c.W + x) * bgc_ch;
+#pragma unroll
+                    for (int ch = 0; ch < 3; ++ch) d[ch] = (uint8_t)(diff_mode == 1 ? abs((int)b3[ch] - (int)s[ch]) : max((int)b3[ch] - (int)s[ch], 0));
+                } else { d[0] = s[0]; d[1] = s[1]; d[2] = s[2]; }
                 continue;
             }
             if (enc == TREXHIP_ENC_R3G3B2) {                  // the colour code of the pixel (convert_to_r3g3b2)
@@ -68,6 +73,7 @@ __global__ __launch_bounds__(256) void k_crops_none(const SegCfg c, const uint8_
 
 int launch_crops_warp(trexhip_ctx* ctx, uint8_t* d_crops, int n, int OW, int OH, int diff_mode, const float* tr6, const float* lengths,
                       bool legacy, float scale, const uint8_t* valid);
+int check_colour_difference(trexhip_ctx* ctx, int difference, const char* who);
 
 int launch_crops(trexhip_ctx* ctx, uint8_t* d_crops, int n, int OW, int OH, int diff_mode) {
     if (n <= 0) return TREXHIP_OK;
@@ -76,9 +82,19 @@ int launch_crops(trexhip_ctx* ctx, uint8_t* d_crops, int n, int OW, int OH, int 
     stage_begin(ctx, TREXHIP_STAGE_CROPS);
     hipLaunchKernelGGL(k_crops_none, dim3(n), dim3(256), 0, ctx->stream, c, ctx->d_frames, ctx->d_bg, ctx->d_info,
                        ctx->d_blob_frame, ctx->d_blobs, ctx->d_runs, d_crops, OW, OH, diff_mode, ctx->d_color_src, ctx->color_ch,
-                       ctx->p.pixel_encoding == TREXHIP_ENC_RGB8 ? 3 : 1, ctx->p.pixel_encoding);
+                       ctx->p.pixel_encoding == TREXHIP_ENC_RGB8 ? 3 : 1, ctx->p.pixel_encoding, ctx->d_bg_color, ctx->bg_color_ch);
     stage_end(ctx, TREXHIP_STAGE_CROPS);
     TH_CHECK_HIP(hipGetLastError());
+    return TREXHIP_OK;
+}
+
+// background-difference crops of a colour encoding: rgb8 with a colour background (trexhip_set_background_color)
+int check_colour_difference(trexhip_ctx* ctx, int difference, const char* who) {
+    if (ctx->p.pixel_encoding == TREXHIP_ENC_GRAY || difference == 0) return TREXHIP_OK;
+    if (ctx->p.pixel_encoding != TREXHIP_ENC_RGB8) {
+        set_error(std::string(who) + ": r3g3b2 crops hold the colour codes: background-difference crops are not implemented for them"); return TREXHIP_E_UNSUPPORTED;
+    }
+    if (!ctx->d_bg_color) { set_error(std::string(who) + ": background-difference crops of rgb8 pixels need the colour background (trexhip_set_background_color)"); return TREXHIP_E_INVALID; }
     return TREXHIP_OK;
 }
 
@@ -91,9 +107,7 @@ extern "C" {
 int trexhip_crops_device(trexhip_ctx* ctx, uint8_t* d_crops, int32_t n_blobs, int32_t out_w, int32_t out_h,
                          int32_t normalization, int32_t difference) {
     if (!ctx || !d_crops) { set_error("trexhip_crops_device: null argument"); return TREXHIP_E_INVALID; }
-    if (ctx->p.pixel_encoding != TREXHIP_ENC_GRAY && difference != 0) {
-        set_error("trexhip_crops_device: crops of the colour encodings hold the raw pixels / codes: background-difference crops are not implemented"); return TREXHIP_E_UNSUPPORTED;
-    }
+    if (int rc = check_colour_difference(ctx, difference, "trexhip_crops_device")) return rc;
     if (ctx->p.pixel_encoding == TREXHIP_ENC_RGB8 && (out_w * out_h * 3) % 16 != 0) { set_error("trexhip_crops_device: out_w*out_h*3 must be a multiple of 16"); return TREXHIP_E_UNSUPPORTED; }
     if (normalization != TREXHIP_NORMALIZE_NONE && normalization != TREXHIP_NORMALIZE_MOMENTS) {
         set_error("trexhip_crops_device: posture / legacy normalisation need the caller's Midline::transform: use trexhip_crops_transformed_device");
@@ -261,6 +275,46 @@ extern "C" int trexhip_segment_color_device(trexhip_ctx* ctx, const uint8_t* d_c
     return launch_segment(ctx, ctx->d_staging, n);
 }
 
+// Background(image, meta_encoding_t::rgb8): the colour background stays resident for the per-channel difference crops, the detection
+// and the track threshold keep working on its cv::cvtColor(BGR2GRAY) (Tests/test_pixels.cpp:1385-1400 builds both from one image and
+// expects the same masks)
+static int set_background_color_common(trexhip_ctx* ctx, int32_t channels, int32_t color_channel) {
+    using namespace trexhip;
+    const size_t W = ctx->p.width, H = ctx->p.height;
+    int rc = launch_to_gray(ctx, ctx->d_bg_color, ctx->d_bg, W * H, channels, color_channel >= channels ? -1 : color_channel);
+    if (rc) return rc;
+    TH_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+    ctx->bg_color_ch = channels;
+    ctx->has_bg = true;
+    return TREXHIP_OK;
+}
+static int alloc_background_color(trexhip_ctx* ctx, int32_t channels) {
+    using namespace trexhip;
+    const size_t W = ctx->p.width, H = ctx->p.height;
+    if (channels != 3 && channels != 4) { set_error("trexhip_set_background_color: channels must be 3 (BGR) or 4 (BGRA)"); return TREXHIP_E_INVALID; }
+    if ((W * H) % 4 != 0) { set_error("trexhip_set_background_color: width*height must be a multiple of 4"); return TREXHIP_E_UNSUPPORTED; }
+    TH_CHECK_HIP(hipSetDevice(ctx->p.device));
+    if (ctx->d_bg_color && ctx->bg_color_ch != channels) { (void)hipFree(ctx->d_bg_color); ctx->d_bg_color = nullptr; ctx->bg_color_ch = 0; }
+    if (!ctx->d_bg_color) TH_CHECK_HIP(hipMalloc(reinterpret_cast<void**>(&ctx->d_bg_color), W * H * (size_t)channels));
+    return TREXHIP_OK;
+}
+extern "C" int trexhip_set_background_color(trexhip_ctx* ctx, const uint8_t* bgr, int32_t stride, int32_t channels, int32_t color_channel) {
+    using namespace trexhip;
+    if (!ctx || !bgr) { set_error("trexhip_set_background_color: null argument"); return TREXHIP_E_INVALID; }
+    if (stride < ctx->p.width * channels) { set_error("trexhip_set_background_color: stride < width * channels"); return TREXHIP_E_INVALID; }
+    if (int rc = alloc_background_color(ctx, channels)) return rc;
+    TH_CHECK_HIP(hipMemcpy2DAsync(ctx->d_bg_color, (size_t)ctx->p.width * channels, bgr, stride, (size_t)ctx->p.width * channels, ctx->p.height,
+                                  hipMemcpyHostToDevice, ctx->stream));
+    return set_background_color_common(ctx, channels, color_channel);
+}
+extern "C" int trexhip_set_background_color_device(trexhip_ctx* ctx, const uint8_t* d_bgr, int32_t channels, int32_t color_channel) {
+    using namespace trexhip;
+    if (!ctx || !d_bgr) { set_error("trexhip_set_background_color_device: null argument"); return TREXHIP_E_INVALID; }
+    if (int rc = alloc_background_color(ctx, channels)) return rc;
+    TH_CHECK_HIP(hipMemcpyAsync(ctx->d_bg_color, d_bgr, (size_t)ctx->p.width * ctx->p.height * channels, hipMemcpyDeviceToDevice, ctx->stream));
+    return set_background_color_common(ctx, channels, color_channel);
+}
+
 // ------------------------------------------------------------------------------------------------
 // background model from sampled frames (Segmenter::trigger_average_generator, ui/Segmenter.cpp:467-566 ->
 // VideoSource::generate_average [commons]; settings averaging_method / average_samples,
@@ -371,7 +425,8 @@ __global__ __launch_bounds__(256) void k_crops_warp(const SegCfg c, const uint8_
                                                     const trexhip_blob* __restrict__ blobs, const trexhip_run* __restrict__ runs,
                                                     const double* __restrict__ minv /*[n][6] inverse maps*/, uint8_t* __restrict__ crops,
                                                     int OW, int OH, int diff_mode, const uint8_t* __restrict__ color, int color_ch,
-                                                    int och /*1 grey or r3g3b2 code, 3 rgb8 (raw pixels, channels warped independently)*/, int enc) {
+                                                    int och /*1 grey or r3g3b2 code, 3 rgb8 (channels warped independently)*/, int enc,
+                                                    const uint8_t* __restrict__ bgc, int bgc_ch) {
     __shared__ uint32_t s_runs[W_NR];
     __shared__ int s_row[1024 + 2];
     const uint32_t bi = blockIdx.x;
@@ -400,7 +455,12 @@ __global__ __launch_bounds__(256) void k_crops_warp(const SegCfg c, const uint8_
     const bool nearest = enc == TREXHIP_ENC_R3G3B2;          // colour codes are not interpolated (FilterCache.cpp:70-73: INTER_NEAREST)
     // value of the blob image at a member pixel: grey (raw or background difference) or one colour channel
     auto source = [&](int ay, int ax, int ch) -> int {
-        if (och == 3) return cimg[((size_t)ay * c.W + ax) * color_ch + ch];
+        if (och == 3) {
+            const int p3 = cimg[((size_t)ay * c.W + ax) * color_ch + ch];
+            if (!diff_mode) return p3;
+            const int b3 = bgc[((size_t)ay * c.W + ax) * bgc_ch + ch];                  // per-channel background difference
+            return diff_mode == 1 ? abs(b3 - p3) : max(b3 - p3, 0);
+        }
         if (nearest) { const uint8_t* s = cimg + ((size_t)ay * c.W + ax) * color_ch; return ((s[0] >> 6) << 6) | ((s[1] >> 5) << 3) | (s[2] >> 5); }
         int p = img[(size_t)ay * c.W + ax];
         if (c.invert) p = 255 - p;
@@ -502,7 +562,7 @@ static void compose_and_invert(const Aff& tr, float midline_length, bool legacy,
 
 int launch_crops_warp(trexhip_ctx* ctx, uint8_t* d_crops, int n, int OW, int OH, int diff_mode, const float* tr6, const float* lengths,
                       bool legacy, float scale, const uint8_t* valid) {
-    if (ctx->p.pixel_encoding != TREXHIP_ENC_GRAY && diff_mode != 0) { set_error("crops of the colour encodings hold the raw pixels / codes: background-difference crops are not implemented"); return TREXHIP_E_UNSUPPORTED; }
+    if (int rc = check_colour_difference(ctx, diff_mode, "normalised crops")) return rc;
     // tr6 == nullptr: `moments` -- orientation from the integer moments of the fetched blob table (host copy)
     std::vector<double> minv((size_t)n * 6);
     for (int i = 0; i < n; ++i) {
@@ -537,7 +597,7 @@ int launch_crops_warp(trexhip_ctx* ctx, uint8_t* d_crops, int n, int OW, int OH,
     stage_begin(ctx, TREXHIP_STAGE_CROPS);
     hipLaunchKernelGGL(k_crops_warp, dim3(n), dim3(256), 0, ctx->stream, c, ctx->d_frames, ctx->d_bg, ctx->d_info, ctx->d_blob_frame,
                        ctx->d_blobs, ctx->d_runs, ctx->d_warp, d_crops, OW, OH, diff_mode, ctx->d_color_src, ctx->color_ch,
-                       ctx->p.pixel_encoding == TREXHIP_ENC_RGB8 ? 3 : 1, ctx->p.pixel_encoding);
+                       ctx->p.pixel_encoding == TREXHIP_ENC_RGB8 ? 3 : 1, ctx->p.pixel_encoding, ctx->d_bg_color, ctx->bg_color_ch);
     stage_end(ctx, TREXHIP_STAGE_CROPS);
     TH_CHECK_HIP(hipGetLastError());
     return TREXHIP_OK;

@@ -132,6 +132,8 @@ struct trexhip_ctx {
     int pix_ch = 1;                     // bytes per output pixel (pixel_encoding)
     const uint8_t* d_color_src = nullptr; // colour frames of the last segment_color* call ([n][H][W][color_ch])
     int color_ch = 0;
+    uint8_t* d_bg_color = nullptr;      // colour background ([H][W][bg_color_ch]) for the difference crops of the rgb8 encoding
+    int bg_color_ch = 0;
     int n_cus = 256;                    // compute units of the device (persistent kernels size their grids with it)
     int tune_seg_groups = 1;            // >1: pixel pass of frame group g+1 on the caller stream, labelling of g on an auxiliary stream (TREXHIP_SEG_GROUPS); measured SLOWER (cross-stream events cost 30-50 us each: 159 -> 266 us at 2 groups), kept off
     hipStream_t aux_stream = nullptr;   // labelling + gather of a group while the next group's pixel pass runs

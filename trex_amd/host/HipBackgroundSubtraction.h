@@ -67,14 +67,19 @@ struct HipBackgroundSubtraction {
         if (!d.ctx) throw std::runtime_error("HipBackgroundSubtraction: not initialised");
         if (average->dims == 1) check(trexhip_set_background(d.ctx, average->data(), (int32_t)average->cols));
         else if (average->dims == 3 || average->dims == 4) {
-            // a colour average (meta_encoding rgb8): detection thresholds grey differences, so the model is reduced like the frames
-            // are (cv::cvtColor BGR2GRAY, 8-bit fixed point) -- or to the selected color_channel
-            std::vector<uint8_t> gray((size_t)average->rows * average->cols);
-            const uint8_t* p = average->data();
+            // a colour average (Background(image, rgb8)): detection thresholds grey differences, so the library reduces the model like
+            // the frames (cv::cvtColor BGR2GRAY, 8-bit fixed point -- or the selected color_channel) and keeps the colour image for
+            // the per-channel difference crops
             const int cc = d.settings.color_channel;
-            for (size_t i = 0; i < gray.size(); ++i, p += average->dims)
-                gray[i] = cc >= 0 && cc < (int)average->dims ? p[cc] : (uint8_t)((p[0] * 1868u + p[1] * 9617u + p[2] * 4899u + 8192u) >> 14);
-            check(trexhip_set_background(d.ctx, gray.data(), (int32_t)average->cols));
+            if (((size_t)average->rows * average->cols) % 4 == 0)
+                check(trexhip_set_background_color(d.ctx, average->data(), (int32_t)(average->cols * average->dims), (int32_t)average->dims, cc));
+            else {                                                  // odd pixel counts: gray model only
+                std::vector<uint8_t> gray((size_t)average->rows * average->cols);
+                const uint8_t* p = average->data();
+                for (size_t i = 0; i < gray.size(); ++i, p += average->dims)
+                    gray[i] = cc >= 0 && cc < (int)average->dims ? p[cc] : (uint8_t)((p[0] * 1868u + p[1] * 9617u + p[2] * 4899u + 8192u) >> 14);
+                check(trexhip_set_background(d.ctx, gray.data(), (int32_t)average->cols));
+            }
         } else throw std::runtime_error("HipBackgroundSubtraction: background must have 1, 3 or 4 channels");
         d.has_background = true;
         g.unlock();
