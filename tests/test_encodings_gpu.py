@@ -161,6 +161,7 @@ def test_rgb8_difference_crops_need_and_use_the_colour_background():
     MP = 512
     outline = torch.zeros((n, MP, 2), dtype=torch.float32, device="cuda"); segs = torch.zeros((n, MP // 2 + 1, 4), dtype=torch.float32, device="cuda")
     info = torch.zeros((n, 8), dtype=torch.int32, device="cuda"); mid = torch.zeros((n, 25, 4), dtype=torch.float32, device="cuda"); minfo = torch.zeros((n, 8), dtype=torch.int32, device="cuda")
+    torch.cuda.synchronize()                                                   # the buffers were zeroed on torch's stream, the context has its own
     seg.posture_device(n, outline.data_ptr(), segs.data_ptr(), info.data_ptr(), max_points=MP)
     seg.midline_device(n, MP, info.data_ptr(), segs.data_ptr(), mid.data_ptr(), minfo.data_ptr())
     seg.synchronize()                                                          # the context has its own stream
@@ -201,6 +202,7 @@ def test_rgb8_difference_crops_need_and_use_the_colour_background():
     r = seg.fetch()[0]
     assert len(r.blobs) == 1 and r.blobs[0]["n_pixels"] == 4                    # recount 4, one 8-connected blob
     crop = torch.zeros((1, 4, 4, 3), dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()
     seg.crops_device(crop.data_ptr(), 1, out_w=4, out_h=4, difference=1)
     seg.synchronize()
     got = crop.cpu().numpy()[0]

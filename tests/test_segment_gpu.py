@@ -251,12 +251,13 @@ def test_two_contexts_from_two_threads():
     def worker(k):
         try:
             fr, bg = scenes[k % 2]
-            seg = capi.Segmenter(capi.default_params(640, 360, max_batch=2, max_blobs=32768))
+            seg = capi.Segmenter(capi.default_params(640, 360, max_batch=2, max_blobs=32768), stream=None)   # the context's own stream
             seg.set_background(bg)
             for it in range(6):
                 fr2, _ = scenes[(k + it) % 4]
                 frames = np.stack([fr, np.where(bg == fr2, fr, fr2)])
                 d = torch.from_numpy(frames).cuda()
+                torch.cuda.synchronize()            # the upload ran on torch's stream
                 seg.segment_device(d.data_ptr(), 2)
                 res = seg.fetch()
                 for r, f in zip(res, frames):

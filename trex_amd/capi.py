@@ -191,13 +191,27 @@ class FrameResult:
         self.info, self.blobs, self.runs, self.pixels = info, blobs, runs, pixels
 
 
+HIP_STREAM_LEGACY = 1        # hipStreamLegacy: the explicit handle of the legacy default stream (hip_runtime_api.h)
+
+
 class Segmenter:
     """Host-side handle mirroring TRex's BackgroundSubtraction (set_background / apply / fps / deinit)."""
 
-    def __init__(self, params):
+    def __init__(self, params, stream="torch"):
+        """stream: "torch" = enqueue on torch's current stream of the device when torch is loaded (callers hand torch tensors to
+        the context, so torch's own fills / copies and the context's kernels must be ordered); None = the context's own
+        non-blocking stream (the library default); or a hipStream_t value."""
         self.params = params
         self._h = C.c_void_p()
         _check(lib().trexhip_create(C.byref(params), C.byref(self._h)))
+        if stream == "torch":
+            import sys
+            torch = sys.modules.get("torch")
+            if torch is not None and torch.cuda.is_available():
+                s = torch.cuda.current_stream(params.device).cuda_stream
+                self.set_stream(s if s else HIP_STREAM_LEGACY)     # torch's default stream is the legacy null stream
+        elif stream:
+            self.set_stream(stream)
 
     def close(self):
         if self._h:

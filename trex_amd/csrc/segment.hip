@@ -18,6 +18,8 @@
 //               output, stable scatter of the runs into per-blob sorted lists
 //   k_gather    1 wave = 1 kept blob: gather grey values, bounding box, integer moments, bid
 #include "internal.h"
+#include <cstddef>
+#include <cstdlib>
 
 namespace trexhip {
 
@@ -907,6 +909,38 @@ __device__ __forceinline__ uint64_t wave_sum64(uint64_t v) {
     }
     return v;
 }
+// Eight per-lane values -> eight wave totals with 10 exchanges instead of 48: three transposing butterfly steps halve the number of
+// values a lane carries (a lane keeps one half and hands the other half to its partner), three plain steps finish.  Afterwards every
+// lane holds the total of quantity q(lane) = 4 * bit0 + 2 * bit1 + bit2 of its lane index.
+__device__ __forceinline__ uint64_t shfl_xor64(uint64_t v, int d) {
+    const uint32_t lo = __shfl_xor((uint32_t)v, d), hi = __shfl_xor((uint32_t)(v >> 32), d);
+    return ((uint64_t)hi << 32) | lo;
+}
+__device__ __forceinline__ uint64_t wave_sum8x64(const uint64_t (&v)[8], uint32_t lane) {
+    uint64_t w[4], u[2];
+    const bool b0 = lane & 1u, b1 = lane & 2u, b2 = lane & 4u;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) w[j] = (b0 ? v[4 + j] : v[j]) + shfl_xor64(b0 ? v[j] : v[4 + j], 1);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) u[j] = (b1 ? w[2 + j] : w[j]) + shfl_xor64(b1 ? w[j] : w[2 + j], 2);
+    uint64_t t = (b2 ? u[1] : u[0]) + shfl_xor64(b2 ? u[0] : u[1], 4);
+    t += shfl_xor64(t, 8); t += shfl_xor64(t, 16); t += shfl_xor64(t, 32);
+    return t;
+}
+__device__ __forceinline__ uint32_t wave_min8x32(const uint32_t (&v)[8], uint32_t lane) {
+    uint32_t w[4], u[2];
+    const bool b0 = lane & 1u, b1 = lane & 2u, b2 = lane & 4u;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) w[j] = min(b0 ? v[4 + j] : v[j], (uint32_t)__shfl_xor(b0 ? v[j] : v[4 + j], 1));
+#pragma unroll
+    for (int j = 0; j < 2; ++j) u[j] = min(b1 ? w[2 + j] : w[j], (uint32_t)__shfl_xor(b1 ? w[j] : w[2 + j], 2));
+    uint32_t t = min(b2 ? u[1] : u[0], (uint32_t)__shfl_xor(b2 ? u[0] : u[1], 4));
+    t = min(t, (uint32_t)__shfl_xor(t, 8)); t = min(t, (uint32_t)__shfl_xor(t, 16)); t = min(t, (uint32_t)__shfl_xor(t, 32));
+    return t;
+}
+// lane that holds quantity q after the two reductions above
+static_assert(offsetof(trexhip_blob, spy) - offsetof(trexhip_blob, m10) == 56, "k_gather writes the eight sums as an array");
+__device__ __forceinline__ constexpr int lane_of_q(int q) { return ((q >> 2) & 1) | (((q >> 1) & 1) << 1) | ((q & 1) << 2); }
 __device__ __forceinline__ uint32_t wave_min32(uint32_t v) {
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) v = min(v, (uint32_t)__shfl_xor(v, d));
@@ -988,8 +1022,8 @@ __global__ __launch_bounds__(256) void k_gather(const SegCfg c, const int only_p
                         const uint32_t xx = x + k;
                         if (!enc) px[off + k] = (uint8_t)p;
                         else store_colour(px, off + k, cimg + ((size_t)q.y * c.W + xx) * color_ch, enc);
-                        s10 += xx; s20 += xx * xx;
-                        sp_ += p; spx_ += p * xx;
+                        s10 += xx; s20 += __umul24(xx, xx);                 // x < 8192, p < 256: 24-bit multiplies run at full rate
+                        sp_ += p; spx_ += __umul24(p, xx);
                         pmin = min(pmin, p); pmax = max(pmax, p);
                     }
                     m10 += s10; m20 += s20; rp += sp_; spx += spx_;
@@ -1001,19 +1035,24 @@ __global__ __launch_bounds__(256) void k_gather(const SegCfg c, const int only_p
                 sp += rp; spy += rp * y;
             }
         }
-        m10 = wave_sum64(m10); m01 = wave_sum64(m01); m20 = wave_sum64(m20); m11 = wave_sum64(m11);
-        m02 = wave_sum64(m02); sp = wave_sum64(sp); spx = wave_sum64(spx); spy = wave_sum64(spy);
-        x0 = wave_min32(x0); y0 = wave_min32(y0); x1 = wave_max32(x1); y1 = wave_max32(y1);
-        pmin = wave_min32(pmin); pmax = wave_max32(pmax);
+        // all eight sums / six extrema of the blob with two transposing reductions
+        const uint64_t sums[8] = {m10, m01, m20, m11, m02, sp, spx, spy};          // = the order of the fields in trexhip_blob
+        const uint64_t tot = wave_sum8x64(sums, lane);
+        const uint32_t ext[8] = {x0, y0, ~x1, ~y1, pmin, ~pmax, 0xffffffffu, 0xffffffffu};
+        const uint32_t te = wave_min8x32(ext, lane);
+        x0 = __shfl(te, lane_of_q(0)); y0 = __shfl(te, lane_of_q(1)); x1 = ~__shfl(te, lane_of_q(2)); y1 = ~__shfl(te, lane_of_q(3));
+        pmin = __shfl(te, lane_of_q(4)); pmax = ~__shfl(te, lane_of_q(5));
+        trexhip_blob* out = blobs + bi;
+        if (lane < 8) {
+            const uint32_t q = 4u * (lane & 1u) + 2u * ((lane >> 1) & 1u) + ((lane >> 2) & 1u);
+            (&out->m10)[q] = tot;
+        }
         if (lane == 0) {
             const trexhip_run first = rr[0];
-            B.n_pixels = po;
-            B.x0 = (uint16_t)x0; B.y0 = (uint16_t)y0; B.x1 = (uint16_t)x1; B.y1 = (uint16_t)y1;
-            B.bid = make_bid(first.x0, first.x1, first.y, B.n_runs);
-            B.px_min_max = pmin | (pmax << 8);
-            B.m10 = m10; B.m01 = m01; B.m20 = m20; B.m11 = m11; B.m02 = m02;
-            B.sp = sp; B.spx = spx; B.spy = spy;
-            blobs[bi] = B;
+            out->n_pixels = po;
+            out->x0 = (uint16_t)x0; out->y0 = (uint16_t)y0; out->x1 = (uint16_t)x1; out->y1 = (uint16_t)y1;
+            out->bid = make_bid(first.x0, first.x1, first.y, B.n_runs);
+            out->px_min_max = pmin | (pmax << 8);
         }
     }
 }
@@ -1090,7 +1129,8 @@ int launch_segment(trexhip_ctx* ctx, const uint8_t* d_frames, int n) {
         hipLaunchKernelGGL(k_ccl_lds, dim3(f1 - f0), dim3(1024), CCL_LDS_BYTES, t, c, ctx->d_ctr, ctx->d_row_cnt, ctx->d_row_off, ctx->d_row_base,
                            ctx->d_tmp_runs, ctx->d_raster, ctx->d_parent, ctx->d_root_ord, ctx->d_cur_run, ctx->d_pix_begin, ctx->d_blob_map,
                            totals, ctx->d_info, ctx->d_blobs, ctx->d_blob_frame, ctx->d_runs, ctx->tune_ccl_stop, reinterpret_cast<unsigned long long*>(ctx->d_cnt_px), f0);
-        hipLaunchKernelGGL(k_gather, dim3(G > 1 ? 256 : 2048), dim3(256), 0, t, c, 0, d_frames, totals, ctx->d_info, ctx->d_blob_frame,
+        static const int gather_blocks_env = std::getenv("TREXHIP_GATHER_BLOCKS") ? std::atoi(std::getenv("TREXHIP_GATHER_BLOCKS")) : 0;
+        hipLaunchKernelGGL(k_gather, dim3(G > 1 ? 256 : (gather_blocks_env > 0 ? gather_blocks_env : 2048)), dim3(256), 0, t, c, 0, d_frames, totals, ctx->d_info, ctx->d_blob_frame,
                            ctx->d_blobs, ctx->d_runs, ctx->d_pixels, (uint32_t)f0, (uint32_t)f1, ctx->d_color_src, ctx->color_ch, ctx->p.pixel_encoding);
     }
     if (G > 1) {
