@@ -968,6 +968,7 @@ __device__ __forceinline__ void store_colour(uint8_t* px, uint32_t index, const 
     else px[index] = (uint8_t)(((c0 >> 6) << 6) | ((c1 >> 5) << 3) | (c2 >> 5));
 }
 
+template <bool COLOUR>
 __global__ __launch_bounds__(256) void k_gather(const SegCfg c, const int only_pending, const uint8_t* __restrict__ frames,
                                                 const uint32_t* __restrict__ totals,
                                                 const trexhip_frame_info* __restrict__ info,
@@ -975,7 +976,8 @@ __global__ __launch_bounds__(256) void k_gather(const SegCfg c, const int only_p
                                                 trexhip_blob* __restrict__ blobs,
                                                 const trexhip_run* __restrict__ runs,
                                                 uint8_t* __restrict__ pixels, const uint32_t f0, const uint32_t f1,
-                                                const uint8_t* __restrict__ color, const int color_ch, const int enc) {
+                                                const uint8_t* __restrict__ color, const int color_ch, const int enc_) {
+    const int enc = COLOUR ? enc_ : 0;                     // the gray instantiation carries no colour addressing at all
     const uint32_t lane = lane_id();
     const uint32_t nwaves = gridDim.x * 4;
     const uint32_t total = min(totals[0], c.pool_blobs);
@@ -1059,6 +1061,8 @@ __global__ __launch_bounds__(256) void k_gather(const SegCfg c, const int only_p
 
 // ---------------------------------------------------------------------------------------------
 // host side launch
+#define LAUNCH_GATHER(grid_, stream_, ...) do { if (ctx->p.pixel_encoding != TREXHIP_ENC_GRAY) hipLaunchKernelGGL((k_gather<true>), grid_, dim3(256), 0, stream_, __VA_ARGS__); \
+                                                 else hipLaunchKernelGGL((k_gather<false>), grid_, dim3(256), 0, stream_, __VA_ARGS__); } while (0)
 // ---------------------------------------------------------------------------------------------
 template <bool ALIGNED>
 static void launch_rows(int nch, dim3 grid, hipStream_t s, const uint8_t* frames, const uint8_t* bg,
@@ -1130,7 +1134,7 @@ int launch_segment(trexhip_ctx* ctx, const uint8_t* d_frames, int n) {
                            ctx->d_tmp_runs, ctx->d_raster, ctx->d_parent, ctx->d_root_ord, ctx->d_cur_run, ctx->d_pix_begin, ctx->d_blob_map,
                            totals, ctx->d_info, ctx->d_blobs, ctx->d_blob_frame, ctx->d_runs, ctx->tune_ccl_stop, reinterpret_cast<unsigned long long*>(ctx->d_cnt_px), f0);
         static const int gather_blocks_env = std::getenv("TREXHIP_GATHER_BLOCKS") ? std::atoi(std::getenv("TREXHIP_GATHER_BLOCKS")) : 0;
-        hipLaunchKernelGGL(k_gather, dim3(G > 1 ? 256 : (gather_blocks_env > 0 ? gather_blocks_env : 2048)), dim3(256), 0, t, c, 0, d_frames, totals, ctx->d_info, ctx->d_blob_frame,
+        LAUNCH_GATHER(dim3(G > 1 ? 256 : (gather_blocks_env > 0 ? gather_blocks_env : 2048)), t, c, 0, d_frames, totals, ctx->d_info, ctx->d_blob_frame,
                            ctx->d_blobs, ctx->d_runs, ctx->d_pixels, (uint32_t)f0, (uint32_t)f1, ctx->d_color_src, ctx->color_ch, ctx->p.pixel_encoding);
     }
     if (G > 1) {
@@ -1162,7 +1166,7 @@ int launch_pending(trexhip_ctx* ctx) {
     hipLaunchKernelGGL(k_blobs, dim3(n), dim3(256), 0, s, c, 1, ctx->d_raster, ctx->d_parent, ctx->d_root_ord,
                        ctx->d_cnt_runs, ctx->d_cnt_px, ctx->d_cur_run, ctx->d_pix_begin, ctx->d_blob_map, totals, ctx->d_info,
                        ctx->d_blobs, ctx->d_blob_frame, ctx->d_runs, 0, (const uint32_t*)nullptr);
-    hipLaunchKernelGGL(k_gather, dim3(1024), dim3(256), 0, s, c, 1, ctx->d_frames, totals, ctx->d_info, ctx->d_blob_frame,
+    LAUNCH_GATHER(dim3(1024), s, c, 1, ctx->d_frames, totals, ctx->d_info, ctx->d_blob_frame,
                        ctx->d_blobs, ctx->d_runs, ctx->d_pixels, 0u, (uint32_t)n, ctx->d_color_src, ctx->color_ch, ctx->p.pixel_encoding);
     TH_CHECK_HIP(hipGetLastError());
     return TREXHIP_OK;
@@ -1312,7 +1316,7 @@ int launch_rethreshold(trexhip_ctx* ctx, int thr, int method, const double* rang
     hipLaunchKernelGGL(k_flatten, grid_r, dim3(256), 0, s, c, 0, q.d_row_cnt, q.d_row_base, q.d_parent, q.d_info);
     hipLaunchKernelGGL(k_blobs, dim3(n), dim3(256), 0, s, c, 0, q.d_raster, q.d_parent, q.d_root_ord, q.d_cnt_runs, q.d_cnt_px, q.d_cur_run,
                        q.d_pix_begin, q.d_blob_map, q.d_totals, q.d_info, q.d_blobs, q.d_blob_frame, q.d_runs, 1, q.d_run_parent);
-    hipLaunchKernelGGL(k_gather, dim3(1024), dim3(256), 0, s, c, 0, ctx->d_frames, q.d_totals, q.d_info, q.d_blob_frame, q.d_blobs,
+    LAUNCH_GATHER(dim3(1024), s, c, 0, ctx->d_frames, q.d_totals, q.d_info, q.d_blob_frame, q.d_blobs,
                        q.d_runs, q.d_pixels, 0u, (uint32_t)n, ctx->d_color_src, ctx->color_ch, ctx->p.pixel_encoding);
     TH_CHECK_HIP(hipGetLastError());
     q.valid_n = n;
