@@ -160,9 +160,16 @@ __global__ __launch_bounds__(256) void k_rows(const uint8_t* __restrict__ frames
     if (task >= ntask) return;
 
     uint4 a[NCH], b[NCH];
-    auto issue = [&](uint32_t t) {
-        const uint32_t f = f0 + ((order & 1) == 0 ? t % (uint32_t)c.B : t / (uint32_t)c.H);     // c.B = frames of this launch
-        const uint32_t y = (order & 1) == 0 ? t / (uint32_t)c.B : t % (uint32_t)c.H;
+    // (frame, row) of a task without a division per row: the wave's first task is divided once, every further one is the previous
+    // plus a constant step with one carry (the two udiv sequences were ~40 % of the instructions of a row without foreground)
+    const bool frame_fastest = (order & 1) == 0;
+    const uint32_t modulus = frame_fastest ? (uint32_t)c.B : (uint32_t)c.H;           // c.B = frames of this launch
+    const uint32_t step_lo = nwave % modulus, step_hi = nwave / modulus;
+    uint32_t cur_lo = task % modulus, cur_hi = task / modulus;                      // lo = fastest index, hi = the other
+    auto advance = [&](uint32_t& lo, uint32_t& hi) { lo += step_lo; hi += step_hi; if (lo >= modulus) { lo -= modulus; ++hi; } };
+    auto issue = [&](uint32_t lo, uint32_t hi) {
+        const uint32_t f = f0 + (frame_fastest ? lo : hi);
+        const uint32_t y = frame_fastest ? hi : lo;
         const uint8_t* fp = frames + ((size_t)f * c.H + y) * W;
         const uint8_t* bp = bg + (size_t)y * W;
 #pragma unroll
@@ -177,10 +184,11 @@ __global__ __launch_bounds__(256) void k_rows(const uint8_t* __restrict__ frames
             }
         }
     };
-    issue(task);
+    issue(cur_lo, cur_hi);
     for (; task < ntask; task += nwave) {
-        const uint32_t f = f0 + ((order & 1) == 0 ? task % (uint32_t)c.B : task / (uint32_t)c.H);
-        const uint32_t y = (order & 1) == 0 ? task / (uint32_t)c.B : task % (uint32_t)c.H;
+        const uint32_t f = f0 + (frame_fastest ? cur_lo : cur_hi);
+        const uint32_t y = frame_fastest ? cur_hi : cur_lo;
+        advance(cur_lo, cur_hi);                             // now the next task's coordinates
         uint32_t m[NCH];
         bool any = false;
 #pragma unroll
@@ -211,7 +219,7 @@ __global__ __launch_bounds__(256) void k_rows(const uint8_t* __restrict__ frames
         }
         if (order & 256) any = false;
         // registers a/b are free again: prefetch the next row while this one is finished
-        if (task + nwave < ntask) issue(task + nwave);
+        if (task + nwave < ntask) issue(cur_lo, cur_hi);
 
         const size_t ri = (size_t)f * c.H + y;
         if (!__any(any)) {                       // most rows: no foreground at all
