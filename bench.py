@@ -109,8 +109,10 @@ def main():
                 self.seg.set_identity_precision({"fp32": 0, "bf16x6": 1, "bf16x3": 2, "fp16x3": 3}[args.cnn_mode])
             self.crops = torch.empty((pool, 80, 80, 3) if rgb else (pool, 80, 80), dtype=torch.uint8, device=dev)
             self.probs = torch.empty((pool, classes), dtype=torch.float32, device=dev)
-            self.table = torch.zeros((rows, tdist.HDR + classes), dtype=torch.int32, device=dev)
-            self.table_host = torch.empty((world * rows, tdist.HDR + classes), dtype=torch.int32).pin_memory() if rank == 0 else None
+            # per-blob record for rank 0's matcher: header + probabilities, with posture also second moments + normalised midline
+            rowlen = (tdist.HDR_EX + classes + 3 * 25) if args.with_posture else (tdist.HDR + classes)
+            self.table = torch.zeros((rows, rowlen), dtype=torch.int32, device=dev)
+            self.table_host = torch.empty((world * rows, rowlen), dtype=torch.int32).pin_memory() if rank == 0 else None
             if args.with_posture:
                 self.p_outline = torch.empty((pool, MP, 2), dtype=torch.float32, device=dev)
                 self.p_segs = torch.empty((pool, MP // 2 + 1, 4), dtype=torch.float32, device=dev)
@@ -154,7 +156,11 @@ def main():
                 self.done.record(self.stream)
                 # per-blob identity table -> (all-gather over RCCL/xGMI) -> rank 0's host, for the sequential matcher
                 frame_base = (step_idx * world + rank) * B
-                seg.export_id_table(self.probs.data_ptr(), n, classes, frame_base, self.table.data_ptr(), rows)
+                if args.with_posture:
+                    seg.export_id_table_ex(self.probs.data_ptr(), n, classes, frame_base, self.table.data_ptr(), rows,
+                                           self.p_mid.data_ptr() if n else 0, self.p_minfo.data_ptr() if n else 0, 25)
+                else:
+                    seg.export_id_table(self.probs.data_ptr(), n, classes, frame_base, self.table.data_ptr(), rows)
                 with torch.cuda.stream(self.stream):
                     g = tdist.all_gather_tables(self.table) if use_dist else self.table
                     if rank == 0:

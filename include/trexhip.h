@@ -331,6 +331,13 @@ int trexhip_identify(trexhip_ctx* ctx, const uint8_t* crops, int32_t n, float* p
  * centroid y (f32), valid} followed by `classes` float probabilities.  Rows >= n_blobs are zeroed. */
 int trexhip_export_id_table_device(trexhip_ctx* ctx, const float* d_probs, int32_t n_blobs, int32_t classes,
                                    uint32_t frame_base, void* d_table, int32_t max_rows);
+/* the full record of one blob for the all-gather: row = 16 x u32 {the 8 header words above, central second moments per pixel
+ * mu20, mu11, mu02 (f32), Midline::len / angle / offset.x / offset.y (f32) and the midline status (-1 when no posture is handed in)}
+ * + `classes` probabilities + midline_resolution x {x, y, height} (f32) of the normalised midline (zero unless status 0).
+ * d_midline / d_midline_info = outputs of trexhip_midline_device, or both NULL. */
+int trexhip_export_id_table_ex_device(trexhip_ctx* ctx, const float* d_probs, int32_t n_blobs, int32_t classes, uint32_t frame_base,
+                                      const float* d_midline, const trexhip_midline_info* d_midline_info, int32_t midline_resolution,
+                                      void* d_table, int32_t max_rows);
 
 /* live HIP-event timing of the dominant kernels on the ctx stream (bench.py roofline):
  * stage ids TREXHIP_STAGE_* ; returns accumulated milliseconds and launch count since reset */

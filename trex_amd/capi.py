@@ -98,7 +98,7 @@ SYMBOLS = [
     "trexhip_set_stream", "trexhip_set_background", "trexhip_set_background_device", "trexhip_set_background_color", "trexhip_set_background_color_device", "trexhip_generate_average_device", "trexhip_get_background", "trexhip_segment_device",
     "trexhip_segment", "trexhip_segment_color", "trexhip_segment_color_device", "trexhip_rethreshold_device", "trexhip_rethreshold_per_blob_device", "trexhip_fetch_rethreshold", "trexhip_fetch", "trexhip_device_view_get", "trexhip_synchronize",
     "trexhip_profile_enable", "trexhip_profile_read", "trexhip_profile_reset",
-    "trexhip_default_posture_params", "trexhip_posture_device", "trexhip_crops_device", "trexhip_pixel_channels", "trexhip_device_alloc", "trexhip_device_free", "trexhip_copy_to_host", "trexhip_copy_to_device", "trexhip_crops_transformed_device", "trexhip_crops_posture_device", "trexhip_default_midline_params", "trexhip_midline_device", "trexhip_default_split_params", "trexhip_split_search_device", "trexhip_export_id_table_device", "trexhip_load_weights", "trexhip_set_identity_precision", "trexhip_num_classes", "trexhip_identify_device", "trexhip_identify",
+    "trexhip_default_posture_params", "trexhip_posture_device", "trexhip_crops_device", "trexhip_pixel_channels", "trexhip_device_alloc", "trexhip_device_free", "trexhip_copy_to_host", "trexhip_copy_to_device", "trexhip_crops_transformed_device", "trexhip_crops_posture_device", "trexhip_default_midline_params", "trexhip_midline_device", "trexhip_default_split_params", "trexhip_split_search_device", "trexhip_export_id_table_device", "trexhip_export_id_table_ex_device", "trexhip_load_weights", "trexhip_set_identity_precision", "trexhip_num_classes", "trexhip_identify_device", "trexhip_identify",
 ]
 
 
@@ -147,6 +147,7 @@ def lib():
         L.trexhip_crops_transformed_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_float, C.c_int32]
         L.trexhip_crops_device.argtypes = [C.c_void_p, C.c_void_p] + [C.c_int32] * 5
         L.trexhip_export_id_table_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_uint32, C.c_void_p, C.c_int32]
+        L.trexhip_export_id_table_ex_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32]
         L.trexhip_load_weights.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
         L.trexhip_num_classes.argtypes = [C.c_void_p]
         L.trexhip_set_identity_precision.argtypes = [C.c_void_p, C.c_int32]
@@ -368,6 +369,13 @@ class Segmenter:
         ln = np.ascontiguousarray(midline_lengths, np.float32)
         _check(lib().trexhip_crops_transformed_device(self._h, C.c_void_p(d_crops_ptr), len(tr), out_w, out_h, tr.ctypes.data_as(C.c_void_p),
                                                       ln.ctypes.data_as(C.c_void_p), 1 if legacy else 0, scale, difference))
+
+    def export_id_table_ex(self, d_probs_ptr, n_blobs, classes, frame_base, d_table_ptr, max_rows, d_midline_ptr=0, d_midline_info_ptr=0, midline_resolution=0):
+        """Full per-blob record (16 header words + classes floats + 3 * midline_resolution floats per row); see include/trexhip.h."""
+        _check(lib().trexhip_export_id_table_ex_device(self._h, C.c_void_p(d_probs_ptr) if d_probs_ptr else None, n_blobs, classes, frame_base,
+                                                       C.c_void_p(d_midline_ptr) if d_midline_ptr else None,
+                                                       C.c_void_p(d_midline_info_ptr) if d_midline_info_ptr else None, midline_resolution,
+                                                       C.c_void_p(d_table_ptr), max_rows))
 
     def export_id_table(self, d_probs_ptr, n_blobs, classes, frame_base, d_table_ptr, max_rows):
         """Fixed-size per-blob identity table (8 header words + classes floats per row) into caller memory."""

@@ -174,6 +174,67 @@ extern "C" int trexhip_export_id_table_device(trexhip_ctx* ctx, const float* d_p
     return TREXHIP_OK;
 }
 
+// the full per-blob record of SURVEY.md 8(e): header + second moments + midline pose, probabilities, normalised midline points
+namespace trexhip {
+__global__ __launch_bounds__(256) void k_id_table_ex(const trexhip_frame_info* __restrict__ info, const uint32_t* __restrict__ blob_frame,
+                                                     const trexhip_blob* __restrict__ blobs, const float* __restrict__ probs,
+                                                     const float4* __restrict__ midline, const trexhip_midline_info* __restrict__ minfo,
+                                                     int n, int C, int R, int B, uint32_t frame_base, uint32_t* __restrict__ table) {
+    const int row = blockIdx.x;
+    const int rowlen = 16 + C + 3 * R;
+    uint32_t* out = table + (size_t)row * rowlen;
+    bool valid = row < n;
+    uint32_t f = 0;
+    if (valid) { f = blob_frame[row]; valid = f < (uint32_t)B && info[f].flags == 0; }
+    int mstatus = -1;
+    if (threadIdx.x == 0) {
+        uint32_t hdr[16];
+        for (int i = 0; i < 16; ++i) hdr[i] = 0;
+        if (valid) {
+            const trexhip_blob b = blobs[row];
+            const double np_ = (double)b.n_pixels, cx = (double)b.m10 / np_, cy = (double)b.m01 / np_;
+            hdr[0] = frame_base + f; hdr[1] = b.bid; hdr[2] = b.n_pixels;
+            hdr[3] = b.x0 | ((uint32_t)b.y0 << 16); hdr[4] = b.x1 | ((uint32_t)b.y1 << 16);
+            hdr[5] = __float_as_uint((float)cx); hdr[6] = __float_as_uint((float)cy); hdr[7] = 1u;
+            hdr[8] = __float_as_uint((float)((double)b.m20 / np_ - cx * cx));          // central second moments per pixel
+            hdr[9] = __float_as_uint((float)((double)b.m11 / np_ - cx * cy));
+            hdr[10] = __float_as_uint((float)((double)b.m02 / np_ - cy * cy));
+            hdr[15] = 0xffffffffu;                                                      // midline status: -1 = no posture handed in
+            if (minfo) {
+                const trexhip_midline_info m = minfo[row];
+                hdr[11] = __float_as_uint(m.len); hdr[12] = __float_as_uint(m.angle);
+                hdr[13] = __float_as_uint(m.offx); hdr[14] = __float_as_uint(m.offy); hdr[15] = (uint32_t)m.status;
+            }
+        }
+        for (int i = 0; i < 16; ++i) out[i] = hdr[i];
+    }
+    if (valid && minfo) mstatus = minfo[row].status;
+    for (int c = threadIdx.x; c < C; c += 256)
+        out[16 + c] = (valid && probs) ? __float_as_uint(probs[(size_t)row * C + c]) : 0u;
+    for (int i = threadIdx.x; i < R; i += 256) {
+        float4 p = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (valid && midline && mstatus == 0) p = midline[(size_t)row * R + i];          // MidlineSegment{pos.x, pos.y, height, l_length}
+        out[16 + C + 3 * i] = __float_as_uint(p.x); out[16 + C + 3 * i + 1] = __float_as_uint(p.y); out[16 + C + 3 * i + 2] = __float_as_uint(p.z);
+    }
+}
+}  // namespace trexhip
+
+extern "C" int trexhip_export_id_table_ex_device(trexhip_ctx* ctx, const float* d_probs, int32_t n_blobs, int32_t classes, uint32_t frame_base,
+                                                 const float* d_midline, const trexhip_midline_info* d_midline_info, int32_t midline_resolution,
+                                                 void* d_table, int32_t max_rows) {
+    if (!ctx || !d_table) { trexhip::set_error("trexhip_export_id_table_ex_device: null argument"); return TREXHIP_E_INVALID; }
+    if (n_blobs < 0 || max_rows < n_blobs || classes < 0 || midline_resolution < 0 || midline_resolution > 256) { trexhip::set_error("trexhip_export_id_table_ex_device: need 0 <= n_blobs <= max_rows, 0 <= midline_resolution <= 256"); return TREXHIP_E_INVALID; }
+    if ((d_midline == nullptr) != (d_midline_info == nullptr)) { trexhip::set_error("trexhip_export_id_table_ex_device: midline points and infos come together"); return TREXHIP_E_INVALID; }
+    if (max_rows == 0) return TREXHIP_OK;
+    if (!ctx->fetched) { trexhip::set_error("trexhip_export_id_table_ex_device: call trexhip_fetch on the segmented batch first"); return TREXHIP_E_INVALID; }
+    TH_CHECK_HIP(hipSetDevice(ctx->p.device));
+    hipLaunchKernelGGL(trexhip::k_id_table_ex, dim3(max_rows), dim3(256), 0, ctx->stream, ctx->d_info, ctx->d_blob_frame, ctx->d_blobs, d_probs,
+                       reinterpret_cast<const float4*>(d_midline), d_midline_info, n_blobs, classes, midline_resolution, ctx->last_n, frame_base,
+                       static_cast<uint32_t*>(d_table));
+    TH_CHECK_HIP(hipGetLastError());
+    return TREXHIP_OK;
+}
+
 // ------------------------------------------------------------------------------------------------
 // colour reduce in front of the detect stage (BackgroundSubtraction.cpp:162-180): cv::cvtColor
 // BGR2GRAY / BGRA2GRAY (8-bit fixed point: (B*1868 + G*9617 + R*4899 + 8192) >> 14) or a channel pick
