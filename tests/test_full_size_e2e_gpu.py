@@ -1,0 +1,64 @@
+"""The headline workload at full size (C4: 2048x2048, 100 individuals, 100 classes), device-resident like bench.py: the oracle is too slow
+for whole batches here, so the batch is checked through size-independent properties and one frame / a sample of crops against the oracle."""
+import numpy as np
+import pytest
+import torch
+from oracle import oracle, cnn_oracle
+from trex_amd import capi, synth, weights, dist as tdist
+
+pytestmark = pytest.mark.gpu
+
+
+def test_c4_detect_crops_identify_table():
+    B, classes = 16, 100
+    frames, bg = synth.batch_torch("C4", 8, "cuda")
+    frames = torch.cat([frames, frames.flip(0)]).contiguous()            # every scene twice: frame i == frame 15 - i
+    H, W = frames.shape[1:]
+    seg = capi.Segmenter(capi.default_params(W, H, max_batch=B, max_blobs=400, max_pixels=1 << 18, max_runs=32768))
+    seg.set_background(bg)
+    st = weights.synthetic_state(classes, 4242)
+    seg.load_weights(weights.pack_blob(st, classes))
+    seg.segment_device(frames.data_ptr(), B)
+    res = seg.fetch()
+    n = sum(len(r.blobs) for r in res)
+    assert n == 100 * B and all(len(r.blobs) == 100 for r in res)
+    fr_host = frames.cpu().numpy()
+    bg_host = bg.cpu().numpy() if hasattr(bg, "cpu") else bg
+    # detect: pixel count = thresholded pixels of the frame; one frame bit-exact against the oracle
+    for f in (0, 7):
+        d = np.abs(fr_host[f].astype(np.int16) - bg_host.astype(np.int16)) > 15
+        assert int(res[f].blobs["n_pixels"].sum()) == int(d.sum())
+    ob, orr, opx = oracle.segment(fr_host[3], bg_host, oracle.make_params(W, H))
+    assert res[3].runs.tobytes() == orr.tobytes() and res[3].pixels.tobytes() == opx.tobytes()
+    assert np.array_equal(res[3].blobs["bid"], ob["bid"]) and np.array_equal(res[3].blobs["m11"], ob["m11"])
+    # crops: every crop holds exactly its blob's grey values (blobs are smaller than 80x80: nothing is cut)
+    crops = torch.zeros((n, 80, 80), dtype=torch.uint8, device="cuda")
+    probs = torch.zeros((n, classes), dtype=torch.float32, device="cuda")
+    seg.crops_device(crops.data_ptr(), n)
+    seg.identify_device(crops.data_ptr(), n, probs.data_ptr())
+    table = torch.zeros((n + 7, tdist.HDR + classes), dtype=torch.int32, device="cuda")
+    seg.export_id_table(probs.data_ptr(), n, classes, 4000, table.data_ptr(), n + 7)
+    seg.synchronize()
+    c = crops.cpu().numpy(); p = probs.cpu().numpy(); t = table.cpu().numpy().view(np.uint32)
+    sums = c.reshape(n, -1).astype(np.int64).sum(1)
+    for r in res:
+        bb = int(r.info["blob_begin"])
+        assert np.array_equal(sums[bb:bb + len(r.blobs)], r.blobs["sp"].astype(np.int64))
+        assert np.array_equal((c[bb:bb + len(r.blobs)].reshape(len(r.blobs), -1) != 0).sum(1), r.blobs["n_pixels"])     # no grey value is 0 here
+    # identity: rows are distributions; the same scene gives the same rows wherever it sits in the batch
+    assert np.allclose(p.sum(1), 1.0, atol=1e-5) and (p >= 0).all()
+    for f in range(8):
+        a, b = res[f], res[15 - f]
+        pa = p[int(a.info["blob_begin"]):int(a.info["blob_begin"]) + 100]; pb = p[int(b.info["blob_begin"]):int(b.info["blob_begin"]) + 100]
+        assert np.array_equal(a.blobs["bid"], b.blobs["bid"]) and np.array_equal(pa, pb)
+    # a sample of crops through the CPU restatement of the network: 1e-4 on softmax (BASELINE.json)
+    pick = np.linspace(0, n - 1, 24).astype(int)
+    want, _ = cnn_oracle.predict(st, c[pick][..., None], threads=8)
+    assert np.abs(p[pick] - want).max() <= 1e-4
+    # table: one valid row per blob, frame indices and probabilities in place, padding rows zero
+    assert int(t[:, 7].sum()) == n and not t[n:].any()
+    merged = tdist.merge_tables(t)
+    assert len(merged) == n and np.all(np.diff(merged[:, 0].astype(np.int64)) >= 0)
+    assert set(np.unique(merged[:, 0]).tolist()) == set(range(4000, 4000 + B))
+    assert np.array_equal(t[:n, tdist.HDR:].view(np.float32), p)
+    seg.close()
