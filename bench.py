@@ -55,10 +55,19 @@ def main():
     ap.add_argument("--no-detect-priority", dest="detect_priority", action="store_false",
                     help="keep the detect stage on the lane's own stream (default: a high-priority stream per lane, so that its short kernels get compute units as soon as the other lane's identity network frees some)")
     ap.add_argument("--force-dist", action="store_true", help="dev: run the torch.distributed (RCCL) code path even with a single rank")
+    ap.add_argument("--force-all", action="store_true", help="run exactly the stages given on the command line instead of the preset of the named config")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     args = ap.parse_args()
 
+    # the named configurations of BASELINE.json: C2 = bg-sub + CCL only, C3 = + posture (no network), C4 = + identity network,
+    # C5 = everything (posture, posture-normalised crops, network, full per-blob record)
+    if args.config == "C2" and args.stages == "all" and not args.force_all:
+        args.stages = "segment"
+    if args.config == "C3" and args.stages == "all" and not args.force_all:
+        args.stages = "segment"; args.with_posture = True
+    if args.config == "C5" and args.normalize == "none" and not args.force_all:
+        args.normalize = "posture"
     if args.normalize == "posture":
         args.with_posture = True
     import numpy as np
@@ -262,7 +271,8 @@ def main():
     seg_bytes = 2.0 * W * H * B                       # algorithmic bytes of the pixel pass: frame + background
     rows_s, segall_s = avg_s("ROWS"), avg_s("SEGMENT_ALL")
     out = {
-        "metric": "frames/s end-to-end (segment+CNN-ID), 2048x2048 x100 individuals",
+        "metric": "frames/s end-to-end (segment+CNN-ID), 2048x2048 x100 individuals" if (args.config == "C4" and with_cnn) else
+                  f"frames/s ({'segment' + ('+posture' if args.with_posture else '') + ('+CNN-ID' if with_cnn else '')}), {W}x{H} x{n_ind} individuals ({args.config})",
         "value": fps, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": ({"fp32": "f32", "bf16x6": "bf16x6-split (fp32-equivalent: 3 bf16 pieces per operand, 6 MFMA products, fp32 accumulate)", "bf16x3": "bf16x3-split", "fp16x3": "fp16x3-split (fp32-class: 2 fp16 pieces per operand = 22 mantissa bits, 3 MFMA products, fp32 accumulate, range-guarded)"}[args.cnn_mode] if with_cnn else "u8"), "data": "synthetic",
