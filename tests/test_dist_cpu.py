@@ -5,6 +5,7 @@ import os
 import sys
 import numpy as np
 import pytest
+from oracle import tables as otables
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
@@ -47,7 +48,7 @@ def _table_for(frames, bg, first, classes, max_rows):
     n = sum(len(b) for b in res)
     rng = np.random.default_rng(100 + first)
     probs = rng.random((n, classes)).astype(np.float32)
-    return tdist.table_from_blobs(res, first, probs, classes, max_rows)
+    return otables.table_from_blobs(res, first, probs, classes, max_rows)
 
 
 def _worker(rank, world, port, q):

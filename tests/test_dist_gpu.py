@@ -1,5 +1,6 @@
 import numpy as np
 import pytest
+from oracle import tables as otables
 import torch
 from trex_amd import capi, synth, dist as tdist
 
@@ -27,7 +28,7 @@ def test_id_table_kernel_matches_host_builder():
     for f in order:
         r = res[f]
         bb = int(r.info["blob_begin"])
-        t = tdist.table_from_blobs([r], 1000 + f, pr[bb:bb + len(r.blobs)], C_, len(r.blobs))
+        t = otables.table_from_blobs([r], 1000 + f, pr[bb:bb + len(r.blobs)], C_, len(r.blobs))
         want[bb:bb + len(r.blobs)] = t
     got = table.cpu().numpy().view(np.uint32)
     assert np.array_equal(got, want)
@@ -68,7 +69,7 @@ def test_full_record_kernel_matches_host_builder():
         for f in order:
             r = res[f]
             bb = int(r.info["blob_begin"]); k = len(r.blobs)
-            want[bb:bb + k] = tdist.table_ex_from_blobs([r], 500 + f, pr[bb:bb + k], C_, k, md[bb:bb + k] if with_midline else None,
+            want[bb:bb + k] = otables.table_ex_from_blobs([r], 500 + f, pr[bb:bb + k], C_, k, md[bb:bb + k] if with_midline else None,
                                                         mi[bb:bb + k] if with_midline else None, R)
         got = table.cpu().numpy().view(np.uint32)
         assert np.array_equal(got, want), with_midline
