@@ -65,7 +65,8 @@ def compare(res, outline, segs, info, pp, min_ok=0.97):
                 n_close += np.abs(gs - osg).max() <= 2e-3
             else:   # near-tie of a curvature peak (float rounding of cos/sin): the outline must still be the same closed curve
                 d = np.abs(go[:, None, :] - oo[None, :, :]).max(2).min(1)
-                assert d.max() <= 1e-3
+                # float sums over the outline in a different order (lanes + tree vs sequential): the bound grows with the number of points
+                assert d.max() <= 1e-3 * max(1.0, gi["n_outline"] / 200.0)
     assert n_cmp > 0 and n_same / n_cmp >= min_ok, (n_same, n_cmp)
     assert n_same - n_close <= max(1, 0.05 * n_same), (n_close, n_same)
     return n_cmp

@@ -423,11 +423,14 @@ __global__ __launch_bounds__(256) void k_posture(const PostureCfg P, const trexh
         auto walk = [&](auto REDC) {
             constexpr int RED = decltype(REDC)::value;                   // lanes taking part in one search (power of two >= max_offset)
             while (idx_r < L + idx_l) {
+                // the three LDS reads of an iteration depend only on the indices of the previous one: one round trip, not four
+                const bool cand_r = lane < max_offset && idx_r + lane < L, cand_l = lane < max_offset && idx_l - lane > -L;
                 const float2 pl0 = pts[L + idx_l];
+                const float2 cr = cand_r ? pts[idx_r + lane] : make_float2(0.f, 0.f);
+                const float2 cl = cand_l ? pts[L + idx_l - lane] : make_float2(0.f, 0.f);
                 float len = BIG; int idx = 0x7fffffff;
-                if (lane < max_offset && idx_r + lane < L) {
-                    const float2 pt = pts[idx_r + lane];
-                    const float ddx = pt.x - pl0.x, ddy = pt.y - pl0.y;
+                if (cand_r) {
+                    const float ddx = cr.x - pl0.x, ddy = cr.y - pl0.y;
                     len = sqrtf(ddx * ddx + ddy * ddy); idx = idx_r + lane;
                     if (!(len < BIG)) { len = BIG; idx = 0x7fffffff; }
                 }
@@ -436,13 +439,19 @@ __global__ __launch_bounds__(256) void k_posture(const PostureCfg P, const trexh
                     const float ol = __shfl_xor(len, d); const int oi = __shfl_xor(idx, d);
                     if (ol < len || (ol == len && oi < idx)) { len = ol; idx = oi; }
                 }
+                // the winner's point comes out of its lane's registers (v_readlane), and the state stays wave-uniform
                 float2 pt_r = make_float2(0.f, 0.f);
                 uint32_t used_r = 0xffffu;
-                if (idx != 0x7fffffff) { pt_r = pts[idx]; idx_r = idx; used_r = (uint32_t)idx; }
+                const int idx0 = __builtin_amdgcn_readfirstlane(idx);
+                if (idx0 != 0x7fffffff) {
+                    const int wl = idx0 - __builtin_amdgcn_readfirstlane(idx_r);
+                    pt_r.x = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cr.x), wl));
+                    pt_r.y = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cr.y), wl));
+                    idx_r = idx0; used_r = (uint32_t)idx0;
+                }
                 float len2 = BIG; int key = 0x7fffffff;
-                if (lane < max_offset && idx_l - lane > -L) {
-                    const float2 pt = pts[L + idx_l - lane];
-                    const float ddx = pt_r.x - pt.x, ddy = pt_r.y - pt.y;
+                if (cand_l) {
+                    const float ddx = pt_r.x - cl.x, ddy = pt_r.y - cl.y;
                     len2 = sqrtf(ddx * ddx + ddy * ddy); key = lane;
                     if (!(len2 < BIG)) { len2 = BIG; key = 0x7fffffff; }
                 }
@@ -451,7 +460,8 @@ __global__ __launch_bounds__(256) void k_posture(const PostureCfg P, const trexh
                     const float ol = __shfl_xor(len2, d); const int ok2 = __shfl_xor(key, d);
                     if (ol < len2 || (ol == len2 && ok2 < key)) { len2 = ol; key = ok2; }
                 }
-                if (key != 0x7fffffff) idx_l -= key;
+                const int key0 = __builtin_amdgcn_readfirstlane(key);
+                if (key0 != 0x7fffffff) idx_l -= key0;
                 if (lane == 0 && ns < seg_cap) s_pair[ns] = used_r | ((uint32_t)(L + idx_l) << 16);
                 ++ns;
                 idx_r++; idx_l--;
