@@ -196,6 +196,14 @@ def main():
             lanes[i % L].detect()
         for i in range(k):
             cur = lanes[i % L]
+            if not with_cnn and L > 1 and i + D < k:
+                # no network to keep fed: issue detect(i+D) BEFORE blocking on the tables of batch i, so that their copy to the host
+                # overlaps the next pixel pass (with the network the order below keeps the matrix cores' queue non-empty instead)
+                nxt = lanes[(i + D) % L]
+                nxt.drain()
+                nxt.detect()
+                cur.identify(i)
+                continue
             cur.identify(i)                         # enqueue everything downstream of detect(i)
             if i + D < k:
                 nxt = lanes[(i + D) % L]
