@@ -599,7 +599,8 @@ template <int CI, int CO, int S, int ROWS, int WAVES, bool PERSIST = false>
 __global__ __launch_bounds__(WAVES * 64) void k_conv5_stream(const float* __restrict__ in /*[N][S][S][CI]*/,
                                                              const uint4* __restrict__ wp /*[CI/16][25][2][2][CO] x 16 B*/,
                                                              const float* __restrict__ bias, float* __restrict__ out,
-                                                             const float out_scale, uint32_t* __restrict__ overflow, const int n_units) {
+                                                             const float out_scale, uint32_t* __restrict__ overflow, const int n_units,
+                                                             uint32_t* __restrict__ unit_ctr /*persistent: zeroed counter handing out units*/) {
     using G = ConvGeomS<CI, CO, S, ROWS, WAVES>;
     static_assert(G::NCH == 1 || G::NITEMS <= 5, "staging slices do not fit between the taps");
     static_assert(G::NCH == 1 || G::NCH % 2 == 0, "buffer parity must survive the unit loop");
@@ -609,6 +610,10 @@ __global__ __launch_bounds__(WAVES * 64) void k_conv5_stream(const float* __rest
     const int n = wave % G::NT, mg = wave / G::NT;
     // a unit = ROWS output rows of one crop.  gridDim.x == n_units: one unit per workgroup; fewer workgroups: each walks the
     // units with a grid stride and (multi-chunk layers) stages the next unit's first chunk under the current unit's last one.
+    // Persistent multi-chunk layers take their further units from a counter (first come, first served) instead of a fixed stride:
+    // a workgroup that gets its CU late -- the detect stream or a collective was running there -- just takes fewer units.
+    constexpr bool DYNAMIC = PERSIST && G::NCH > 1;
+    __shared__ int s_next_unit;
     int unit = blockIdx.x;
     if (unit >= n_units) return;
     constexpr int WR = S / 2;
@@ -680,11 +685,18 @@ __global__ __launch_bounds__(WAVES * 64) void k_conv5_stream(const float* __rest
         for (int m = 0; m < G::TPW; ++m)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
-        const int next_unit = unit + (int)gridDim.x;
-        const bool have_next = PERSIST && next_unit < n_units;       // !PERSIST: gridDim.x == n_units, one unit per workgroup
-        const int crop_n = next_unit / G::BPC, row0_n = (next_unit % G::BPC) * ROWS;
+        int next_unit = unit + (int)gridDim.x;
+        bool have_next = PERSIST && next_unit < n_units;             // !PERSIST: gridDim.x == n_units, one unit per workgroup
+        int crop_n = next_unit / G::BPC, row0_n = (next_unit % G::BPC) * ROWS;
         const float* inc_n = in + (size_t)crop_n * S * S * CI;
+        if (DYNAMIC && tid == 0) s_next_unit = (int)atomicAdd(unit_ctr, 1u) + (int)gridDim.x;   // read by everyone after the first chunk's barrier
         for (int cc = 0; cc < G::NCH; ++cc) {
+            if (DYNAMIC && cc == G::NCH - 1) {                       // the last chunk stages the next unit: now its number is needed
+                next_unit = s_next_unit;
+                have_next = next_unit < n_units;
+                crop_n = next_unit / G::BPC; row0_n = (next_unit % G::BPC) * ROWS;
+                inc_n = in + (size_t)crop_n * S * S * CI;
+            }
             const uint8_t* pbase = ldsb + (G::NBUF > 1 ? (cc & 1) * 2 * G::PATCH : 0);
             uint8_t* nbase = ldsb + (G::NBUF > 1 ? ((cc + 1) & 1) * 2 * G::PATCH : 0);
             const bool more_c = cc + 1 < G::NCH;
@@ -1189,7 +1201,7 @@ int net_load(trexhip_ctx* ctx, const void* blob, size_t bytes) {
     fold_conv(c3w, c3b, g3, be3, m3, v3, 128, 64, 16, wp, bias);       // 16-channel chunks for the bf16 path
     TRY(upload_split(&net->w3s, wp, 64, 128));
     TRY(upload_split_f16(&net->w3h, &net->inv3h, wp, 64, 128));
-    if (rc == TREXHIP_OK && hipMalloc(reinterpret_cast<void**>(&net->d_ovf), 4) != hipSuccess) rc = TREXHIP_E_DEVICE;
+    if (rc == TREXHIP_OK && hipMalloc(reinterpret_cast<void**>(&net->d_ovf), 8) != hipSuccess) rc = TREXHIP_E_DEVICE;
     fold_conv(c3w, c3b, g3, be3, m3, v3, 128, 64, 32, wp, bias);
     TRY(upload(&net->w3, wp)); TRY(upload(&net->b3, bias));
     {   // fc1 [100][c*100+h*10+w] -> [(h*10+w)*128 + c][128 (o padded)]
@@ -1294,7 +1306,7 @@ int net_forward(trexhip_ctx* ctx, const uint8_t* d_crops, int n, float* d_probs,
     else if (net->CH == 3 && !(ctx->tune_conv_geom & 16) && (reinterpret_cast<uintptr_t>(d_crops) & 15) == 0) hipLaunchKernelGGL(k_conv1_mfma3, dim3(n), dim3(256), 0, s, d_crops, net->w1h, net->b1, net->act1, net->inv1h);
     else              hipLaunchKernelGGL((k_conv1<3>), dim3(n), dim3(256), lds1, s, d_crops, net->w1, net->b1, net->act1, S);
     const int mode = ctx->cnn_mode;
-    if (mode == TREXHIP_CNN_FP16X3) TH_CHECK_HIP(hipMemsetAsync(net->d_ovf, 0, 4, s));
+    if (mode == TREXHIP_CNN_FP16X3) TH_CHECK_HIP(hipMemsetAsync(net->d_ovf, 0, 8, s));     // [0] fp16 range flag, [1] unit counter of the persistent conv3
 #define LAUNCH_SPLIT2 LAUNCH_SPLIT
     stage_begin(ctx, TREXHIP_STAGE_CONV2);
 #define LAUNCH_SPLIT(CI_, CO_, S_, ROWS_, KIND_, NT_, in_, w_, b_, out_, sc_, guard_) LAUNCH_SPLITC(CI_, CO_, S_, ROWS_, KIND_, NT_, 16, in_, w_, b_, out_, sc_, guard_)
@@ -1307,10 +1319,10 @@ int net_forward(trexhip_ctx* ctx, const uint8_t* d_crops, int n, float* d_probs,
     else if (mode == TREXHIP_CNN_BF16X3) LAUNCH_SPLIT(16, 64, 40, 10, 0, 3, net->act1, net->w2s, net->b2, net->act2, 1.0f, (const uint32_t*)nullptr);
     else if (!(ctx->tune_conv_geom & (4 | 64)))   // 8 output rows per workgroup: 320 pixels = exactly 10 M-tiles, 3 workgroups per CU (1.15 ms; 10 rows: 1.31 ms)
         hipLaunchKernelGGL((k_conv5_stream<16, 64, 40, 8, 4>), dim3(n * (ConvGeomS<16, 64, 40, 8, 4>::BPC)), dim3(256),
-                           (ConvGeomS<16, 64, 40, 8, 4>::LDS_BYTES), s, net->act1, net->w2h, net->b2, net->act2, net->inv2h, net->d_ovf, n * (ConvGeomS<16, 64, 40, 8, 4>::BPC));
+                           (ConvGeomS<16, 64, 40, 8, 4>::LDS_BYTES), s, net->act1, net->w2h, net->b2, net->act2, net->inv2h, net->d_ovf, n * (ConvGeomS<16, 64, 40, 8, 4>::BPC), (uint32_t*)nullptr);
     else if (!(ctx->tune_conv_geom & 4))
         hipLaunchKernelGGL((k_conv5_stream<16, 64, 40, 10, 4>), dim3(n * (ConvGeomS<16, 64, 40, 10, 4>::BPC)), dim3(256),
-                           (ConvGeomS<16, 64, 40, 10, 4>::LDS_BYTES), s, net->act1, net->w2h, net->b2, net->act2, net->inv2h, net->d_ovf, n * (ConvGeomS<16, 64, 40, 10, 4>::BPC));
+                           (ConvGeomS<16, 64, 40, 10, 4>::LDS_BYTES), s, net->act1, net->w2h, net->b2, net->act2, net->inv2h, net->d_ovf, n * (ConvGeomS<16, 64, 40, 10, 4>::BPC), (uint32_t*)nullptr);
     else if (ctx->tune_conv_geom & 1)    LAUNCH_SPLIT(16, 64, 40, 20, 1, 3, net->act1, net->w2h, net->b2, net->act2, net->inv2h, (const uint32_t*)nullptr);
     else                                 LAUNCH_SPLIT(16, 64, 40, 10, 1, 3, net->act1, net->w2h, net->b2, net->act2, net->inv2h, (const uint32_t*)nullptr);
     stage_end(ctx, TREXHIP_STAGE_CONV2);
@@ -1323,7 +1335,7 @@ int net_forward(trexhip_ctx* ctx, const uint8_t* d_crops, int n, float* d_probs,
         // one workgroup per CU (110 KB LDS, 256 VGPRs): persistent workgroups walk the crops and stage the next crop's first
         // chunk under the current crop's last one (TREXHIP_CONV_GEOM bit 7: one workgroup per crop instead)
         hipLaunchKernelGGL((k_conv5_stream<64, 128, 20, 20, 8, true>), dim3((ctx->tune_conv_geom & 128) || n < ctx->n_cus ? n : ctx->n_cus), dim3(512),
-                           (ConvGeomS<64, 128, 20, 20, 8>::LDS_BYTES), s, net->act2, net->w3h, net->b3, net->act3, net->inv3h, net->d_ovf, n);
+                           (ConvGeomS<64, 128, 20, 20, 8>::LDS_BYTES), s, net->act2, net->w3h, net->b3, net->act3, net->inv3h, net->d_ovf, n, net->d_ovf + 1);
     else if (ctx->tune_conv_geom & 2)    LAUNCH_SPLIT(64, 128, 20, 10, 1, 3, net->act2, net->w3h, net->b3, net->act3, net->inv3h, (const uint32_t*)nullptr);
     else                                 LAUNCH_SPLIT(64, 128, 20, 20, 1, 3, net->act2, net->w3h, net->b3, net->act3, net->inv3h, (const uint32_t*)nullptr);   // 32-channel chunks (CIC=32) measured slower: 3.7 vs 3.0 ms
     stage_end(ctx, TREXHIP_STAGE_CONV3);
