@@ -62,3 +62,58 @@ def test_c4_detect_crops_identify_table():
     assert set(np.unique(merged[:, 0]).tolist()) == set(range(4000, 4000 + B))
     assert np.array_equal(t[:n, tdist.HDR:].view(np.float32), p)
     seg.close()
+
+
+def test_c5_detect_posture_crops_identify_full_record():
+    # 4096x4096, 256 individuals, 256 classes, posture-normalised crops, the full per-blob record (BASELINE.json config 5)
+    from oracle import tables as otables
+    B, classes, MP, R = 4, 256, 256, 25
+    frames, bg = synth.batch_torch("C5", 2, "cuda")
+    frames = torch.cat([frames, frames.flip(0)]).contiguous()            # frame i == frame 3 - i
+    H, W = frames.shape[1:]
+    seg = capi.Segmenter(capi.default_params(W, H, max_batch=B, max_blobs=1024, max_pixels=1 << 18, max_runs=32768))
+    seg.set_background(bg)
+    st = weights.synthetic_state(classes, 99)
+    seg.load_weights(weights.pack_blob(st, classes))
+    seg.segment_device(frames.data_ptr(), B)
+    res = seg.fetch()
+    n = sum(len(r.blobs) for r in res)
+    assert n == 256 * B
+    outline = torch.zeros((n, MP, 2), dtype=torch.float32, device="cuda"); segs = torch.zeros((n, MP // 2 + 1, 4), dtype=torch.float32, device="cuda")
+    info = torch.zeros((n, 8), dtype=torch.int32, device="cuda"); mid = torch.zeros((n, R, 4), dtype=torch.float32, device="cuda")
+    minfo = torch.zeros((n, 8), dtype=torch.int32, device="cuda")
+    crops = torch.zeros((n, 80, 80), dtype=torch.uint8, device="cuda")
+    probs = torch.zeros((n, classes), dtype=torch.float32, device="cuda")
+    rowlen = otables.HDR_EX + classes + 3 * R
+    table = torch.zeros((n, rowlen), dtype=torch.int32, device="cuda")
+    seg.posture_device(n, outline.data_ptr(), segs.data_ptr(), info.data_ptr(), max_points=MP)
+    seg.midline_device(n, MP, info.data_ptr(), segs.data_ptr(), mid.data_ptr(), minfo.data_ptr())
+    seg.crops_posture_device(crops.data_ptr(), n, minfo.data_ptr())
+    seg.identify_device(crops.data_ptr(), n, probs.data_ptr())
+    seg.export_id_table_ex(probs.data_ptr(), n, classes, 0, table.data_ptr(), n, mid.data_ptr(), minfo.data_ptr(), R)
+    seg.synchronize()
+    pi = info.cpu().numpy().view(capi.POSTURE_INFO_DTYPE).reshape(-1); mi = minfo.cpu().numpy().view(capi.MIDLINE_INFO_DTYPE).reshape(-1)
+    c = crops.cpu().numpy(); p = probs.cpu().numpy(); md = mid.cpu().numpy(); t = table.cpu().numpy().view(np.uint32)
+    assert (pi["status"] == 0).all() and (mi["status"] == 0).all()       # every synthetic individual yields a midline
+    assert np.all((mi["len"] > 25) & (mi["len"] < 50))                   # ellipses with an 36 px long axis
+    assert np.allclose(p.sum(1), 1.0, atol=1e-5)
+    fr_host = frames[:1].cpu().numpy()[0]; bg_host = bg.cpu().numpy() if hasattr(bg, "cpu") else bg
+    for f in range(2):                                                   # the same scene anywhere in the batch: the same midlines, crops, rows
+        a, b = res[f], res[3 - f]
+        sa, sb = slice(int(a.info["blob_begin"]), int(a.info["blob_begin"]) + 256), slice(int(b.info["blob_begin"]), int(b.info["blob_begin"]) + 256)
+        assert np.array_equal(md[sa], md[sb]) and np.array_equal(c[sa], c[sb]) and np.array_equal(p[sa], p[sb])
+    # frame 0 against the CPU restatements: posture-normalised crops bit-exact given the device's midline pose, network within 1e-4
+    r0 = res[0]; b0 = int(r0.info["blob_begin"])
+    for k in range(0, 256, 37):
+        tr = oracle.midline_transform(mi[b0 + k]["angle"], mi[b0 + k]["offx"], mi[b0 + k]["offy"], False)
+        want, _ = oracle.crop_normalized(fr_host, bg_host, r0.blobs[k], r0.runs, tr6=tr, midline_length=float(mi[b0 + k]["len"]))
+        assert np.array_equal(c[b0 + k], want), k
+    pick = b0 + np.arange(0, 256, 16)
+    want, _ = cnn_oracle.predict(st, c[pick][..., None], threads=8)
+    assert np.abs(p[pick] - want).max() <= 1e-4
+    # the full record of frame 0 against its numpy restatement
+    wt = otables.table_ex_from_blobs([r0], 0 + 0, p[b0:b0 + 256], classes, 256, md[b0:b0 + 256], mi[b0:b0 + 256], R)
+    wt[:, 0] = t[b0:b0 + 256, 0]                                         # global frame index: frame 0 sits wherever it reserved its pool range
+    assert np.array_equal(t[b0:b0 + 256], wt)
+    assert set(np.unique(t[:, 0]).tolist()) == {0, 1, 2, 3}
+    seg.close()

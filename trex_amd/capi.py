@@ -388,7 +388,8 @@ class Segmenter:
         _check(lib().trexhip_load_weights(self._h, buf, len(blob)))
 
     def set_identity_precision(self, mode):
-        """0 = exact fp32 MFMA, 1 = bf16x6 split (fp32-equivalent), 2 = bf16x3 (experiments)."""
+        """TREXHIP_CNN_*: 0 = exact fp32 MFMA, 1 = bf16x6 split (fp32-equivalent), 2 = bf16x3 (experiments), 3 = fp16x3 split (default:
+        fp32-class on the fp16 matrix cores, range-guarded)."""
         _check(lib().trexhip_set_identity_precision(self._h, mode))
 
     def num_classes(self):
