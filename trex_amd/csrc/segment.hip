@@ -279,6 +279,116 @@ __global__ __launch_bounds__(256) void k_rows(const uint8_t* __restrict__ frames
     }
 }
 
+// The same pass with 32 pixels per lane (two 16-byte loads per array): one wave covers 2048 pixels per chunk, so a 2048-wide row is
+// ONE chunk -- one ballot / scan / extraction round per row instead of two.  Aligned frames of a width that is a multiple of 32, no
+// morphology mask; everything else takes k_rows above.
+template <int NCH>
+__global__ __launch_bounds__(256) void k_rows32(const uint8_t* __restrict__ frames,
+                                                const uint8_t* __restrict__ bg, const SegCfg c, const int order,
+                                                uint32_t* __restrict__ frame_ctr,
+                                                uint32_t* __restrict__ row_cnt,
+                                                uint32_t* __restrict__ row_off,
+                                                uint32_t* __restrict__ tmp_runs, const uint32_t f0) {
+    const int lane = lane_id();
+    const int W = c.W;
+    const uint32_t ntask = (uint32_t)c.B * (uint32_t)c.H;
+    const uint32_t nwave = gridDim.x * 4u;
+    uint32_t task = blockIdx.x * 4u + (threadIdx.x >> 6);
+    if (task >= ntask) return;
+
+    uint4 a[NCH][2], b[NCH][2];
+    const bool frame_fastest = (order & 1) == 0;
+    const uint32_t modulus = frame_fastest ? (uint32_t)c.B : (uint32_t)c.H;
+    const uint32_t step_lo = nwave % modulus, step_hi = nwave / modulus;
+    uint32_t cur_lo = task % modulus, cur_hi = task / modulus;
+    auto advance = [&](uint32_t& lo, uint32_t& hi) { lo += step_lo; hi += step_hi; if (lo >= modulus) { lo -= modulus; ++hi; } };
+    auto issue = [&](uint32_t lo, uint32_t hi) {
+        const uint32_t f = f0 + (frame_fastest ? lo : hi);
+        const uint32_t y = frame_fastest ? hi : lo;
+        const uint8_t* fp = frames + ((size_t)f * c.H + y) * W;
+        const uint8_t* bp = bg + (size_t)y * W;
+#pragma unroll
+        for (int ch = 0; ch < NCH; ++ch) {
+            const int x = ch * 2048 + lane * 32;
+            if (x < W) {
+                a[ch][0] = *reinterpret_cast<const uint4*>(fp + x); a[ch][1] = *reinterpret_cast<const uint4*>(fp + x + 16);
+                b[ch][0] = *reinterpret_cast<const uint4*>(bp + x); b[ch][1] = *reinterpret_cast<const uint4*>(bp + x + 16);
+            } else {
+                a[ch][0] = a[ch][1] = b[ch][0] = b[ch][1] = make_uint4(0, 0, 0, 0);
+            }
+        }
+    };
+    issue(cur_lo, cur_hi);
+    for (; task < ntask; task += nwave) {
+        const uint32_t f = f0 + (frame_fastest ? cur_lo : cur_hi);
+        const uint32_t y = frame_fastest ? cur_hi : cur_lo;
+        advance(cur_lo, cur_hi);
+        uint32_t m[NCH];
+        bool any = false;
+#pragma unroll
+        for (int ch = 0; ch < NCH; ++ch) {
+            const int x = ch * 2048 + lane * 32;
+            uint32_t mm = 0;
+            if (x < W) mm = mask16(a[ch][0], b[ch][0], c) | (mask16(a[ch][1], b[ch][1], c) << 16);
+            m[ch] = mm;
+            any |= mm != 0;
+        }
+        if (task + nwave < ntask) issue(cur_lo, cur_hi);
+
+        const size_t ri = (size_t)f * c.H + y;
+        if (!__any(any)) {
+            if (lane == 0) { row_cnt[ri] = 0; row_off[ri] = 0; }
+            continue;
+        }
+        uint32_t st[NCH], en[NCH], pre[NCH];
+        uint32_t carry = 0, tot = 0;
+#pragma unroll
+        for (int ch = 0; ch < NCH; ++ch) {
+            const uint32_t mm = m[ch];
+            if (NCH > 1 && __ballot(mm != 0) == 0 && carry == 0) { st[ch] = 0; en[ch] = 0; pre[ch] = tot; continue; }
+            uint32_t up = __shfl_up(mm >> 31, 1);
+            if (lane == 0) up = carry;
+            const uint32_t prevmask = (mm << 1) | (up & 1u);
+            const uint32_t s = mm & ~prevmask;
+            const uint32_t e = ~mm & prevmask;
+            const uint32_t v = __popc(s) | (__popc(e) << 16);
+            const uint32_t incl = wave_incl_scan(v);
+            st[ch] = s; en[ch] = e; pre[ch] = tot + incl - v;
+            tot += __shfl(incl, 63);
+            carry = __shfl(mm >> 31, 63) & 1u;
+        }
+        const uint32_t n_starts = tot & 0xffffu;
+        uint32_t base = y * (uint32_t)ROW_SLOT;
+        if (n_starts > (uint32_t)ROW_SLOT) {
+            if (lane == 0) base = (uint32_t)c.H * ROW_SLOT + atomicAdd(&frame_ctr[f * CTR_STRIDE], n_starts);
+            base = __shfl(base, 0);
+        }
+        if (lane == 0) { row_cnt[ri] = n_starts; row_off[ri] = base; }
+        uint16_t* out = reinterpret_cast<uint16_t*>(tmp_runs + (size_t)f * c.T);
+        const uint32_t R = (uint32_t)c.T;
+#pragma unroll
+        for (int ch = 0; ch < NCH; ++ch) {
+            const int xb = ch * 2048 + lane * 32;
+            uint32_t s = st[ch], e = en[ch];
+            uint32_t ks = base + (pre[ch] & 0xffffu), ke = base + (pre[ch] >> 16);
+            while (s) {
+                const int j = __ffs(s) - 1; s &= s - 1;
+                if (ks < R) out[2 * ks] = (uint16_t)(xb + j);
+                ++ks;
+            }
+            while (e) {
+                const int j = __ffs(e) - 1; e &= e - 1;
+                if (ke < R) out[2 * ke + 1] = (uint16_t)(xb + j - 1);
+                ++ke;
+            }
+        }
+        if (carry && lane == 0) {
+            const uint32_t ke = base + (tot >> 16);
+            if (ke < R) out[2 * ke + 1] = (uint16_t)(W - 1);
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // k_rowscan: exclusive scan of runs-per-row, parent init
 // ---------------------------------------------------------------------------------------------
@@ -1127,6 +1237,16 @@ int launch_segment(trexhip_ctx* ctx, const uint8_t* d_frames, int n) {
         cg.B = f1 - f0;
         const unsigned wantg = (unsigned)(((size_t)H * cg.B + 3) / 4);
         const dim3 grid_g(wantg < (unsigned)ctx->tune_rows_blocks ? wantg : (unsigned)ctx->tune_rows_blocks);
+        const int nch32 = (W + 2047) / 2048;
+        const bool wide = aligned && !bits && W % 32 == 0 && nch32 <= 4 && W >= 1024 && !(ctx->tune_rows_order & 1024);   // TREXHIP_ROWS_ORDER bit 10: 16 pixels per lane
+        if (wide) {
+            switch (nch32) {
+                case 1: hipLaunchKernelGGL((k_rows32<1>), grid_g, dim3(256), 0, s, d_frames, ctx->d_bg, cg, ctx->tune_rows_order, ctx->d_ctr, ctx->d_row_cnt, ctx->d_row_off, ctx->d_tmp_runs, (uint32_t)f0); break;
+                case 2: hipLaunchKernelGGL((k_rows32<2>), grid_g, dim3(256), 0, s, d_frames, ctx->d_bg, cg, ctx->tune_rows_order, ctx->d_ctr, ctx->d_row_cnt, ctx->d_row_off, ctx->d_tmp_runs, (uint32_t)f0); break;
+                case 3: hipLaunchKernelGGL((k_rows32<3>), grid_g, dim3(256), 0, s, d_frames, ctx->d_bg, cg, ctx->tune_rows_order, ctx->d_ctr, ctx->d_row_cnt, ctx->d_row_off, ctx->d_tmp_runs, (uint32_t)f0); break;
+                default: hipLaunchKernelGGL((k_rows32<4>), grid_g, dim3(256), 0, s, d_frames, ctx->d_bg, cg, ctx->tune_rows_order, ctx->d_ctr, ctx->d_row_cnt, ctx->d_row_off, ctx->d_tmp_runs, (uint32_t)f0); break;
+            }
+        } else
         if (aligned) launch_rows<true>(nch, grid_g, s, d_frames, ctx->d_bg, cg, ctx->tune_rows_order, ctx->d_ctr, ctx->d_row_cnt, ctx->d_row_off, ctx->d_tmp_runs, bits, (uint32_t)f0);
         else         launch_rows<false>(nch, grid_g, s, d_frames, ctx->d_bg, cg, ctx->tune_rows_order, ctx->d_ctr, ctx->d_row_cnt, ctx->d_row_off, ctx->d_tmp_runs, bits, (uint32_t)f0);
         if (g == G - 1) stage_end(ctx, TREXHIP_STAGE_ROWS);
