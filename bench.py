@@ -296,6 +296,7 @@ def main():
                 "avg_launch_us": rows_s * 1e6, "launches": prof["ROWS"][1], "algorithmic_bytes_per_launch": seg_bytes,
                 "whole_detect_pass_us": segall_s * 1e6, "timing": "HIP events on the kernel stream; 5 serial detect passes after the timed region when lanes are pipelined (in-flight the stage shares the GPU with the identity network)",
                 "whole_detect_pass_frac": seg_bytes / segall_s / 8e12 if segall_s else None,
+                "note": "algorithmic bytes = frame + background per pixel (SURVEY.md 8d counts the background even when L2/MALL serves it); the measured HBM traffic is `traffic` (about half), so `frac` can pass 1",
                 # also against the copy bandwidth measured on this part (MI355X_MICROARCH.md: 6.29 TB/s)
                 "frac_of_measured_copy_bw": seg_bytes / rows_s / 6.29e12 if rows_s else None,
                 "whole_detect_pass_frac_of_measured_copy_bw": seg_bytes / segall_s / 6.29e12 if segall_s else None}

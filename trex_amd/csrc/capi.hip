@@ -158,7 +158,7 @@ int trexhip_create(const trexhip_params* p, trexhip_ctx** out) {
     if (const char* e = std::getenv("TREXHIP_CONV_GEOM")) ctx->tune_conv_geom = std::atoi(e);
     if (const char* e = std::getenv("TREXHIP_CCL_STOP")) ctx->tune_ccl_stop = std::atoi(e);
     if (const char* e = std::getenv("TREXHIP_SEG_GROUPS")) ctx->tune_seg_groups = std::atoi(e);
-    if (const char* e = std::getenv("TREXHIP_ROWS_BLOCKS")) ctx->tune_rows_blocks = std::atoi(e) > 0 ? std::atoi(e) : 8192;
+    if (const char* e = std::getenv("TREXHIP_ROWS_BLOCKS")) { ctx->tune_rows_blocks = std::atoi(e) > 0 ? std::atoi(e) : 8192; ctx->tune_rows_blocks_set = true; }
     const size_t B = p->max_batch, H = p->height, W = p->width, R = p->max_runs, NB = p->max_blobs, P = p->max_pixels;
     int rc = TREXHIP_OK;
 #define TRY(x) do { if (rc == TREXHIP_OK) rc = (x); } while (0)

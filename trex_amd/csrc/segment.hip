@@ -1236,9 +1236,13 @@ int launch_segment(trexhip_ctx* ctx, const uint8_t* d_frames, int n) {
         SegCfg cg = c;
         cg.B = f1 - f0;
         const unsigned wantg = (unsigned)(((size_t)H * cg.B + 3) / 4);
-        const dim3 grid_g(wantg < (unsigned)ctx->tune_rows_blocks ? wantg : (unsigned)ctx->tune_rows_blocks);
         const int nch32 = (W + 2047) / 2048;
         const bool wide = aligned && !bits && W % 32 == 0 && nch32 <= 4 && W >= 1024 && !(ctx->tune_rows_order & 1024);   // TREXHIP_ROWS_ORDER bit 10: 16 pixels per lane
+        // rows per wave: the wide kernel is fastest with ~4 rows per wave (measured at 256 frames of 2048^2: 8192 blocks 266 us, 16384: 260,
+        // 32768 = 4 rows per wave: 250, 65536: 268); TREXHIP_ROWS_BLOCKS overrides
+        unsigned cap = (unsigned)ctx->tune_rows_blocks;
+        if (wide && !ctx->tune_rows_blocks_set) { cap = wantg / 4; if (cap < 2048u) cap = 2048u; }
+        const dim3 grid_g(wantg < cap ? wantg : cap);
         if (wide) {
             switch (nch32) {
                 case 1: hipLaunchKernelGGL((k_rows32<1>), grid_g, dim3(256), 0, s, d_frames, ctx->d_bg, cg, ctx->tune_rows_order, ctx->d_ctr, ctx->d_row_cnt, ctx->d_row_off, ctx->d_tmp_runs, (uint32_t)f0); break;
