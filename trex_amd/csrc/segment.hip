@@ -613,9 +613,9 @@ __global__ __launch_bounds__(256) void k_blobs(const SegCfg c, const int only_pe
         const int32_t k = bmap[o];
         if (k < 0) continue;
         trexhip_blob B = {};
-        B.run_begin = cur[o];
+        B.run_begin = cur[o] + rb;        // POOLED offsets until k_gather, which needs no frame table to find the lines, makes them frame-relative
         B.n_runs = ld_relaxed(cr + o);
-        B.pix_begin = pbg[o];
+        B.pix_begin = pbg[o] + pb;
         B.parent = 0xffffffffu;
         if (classify) {   // Tracker.cpp:864-912: in range -> commit, below the smallest range -> filtered out, else big blob
             const uint32_t np = ld_relaxed(cp + o);
@@ -873,9 +873,9 @@ __global__ __launch_bounds__(1024) void k_ccl_lds(const SegCfg c, const uint32_t
         const uint32_t k = s_cp[o];
         if (k == 0xffffffffu) continue;
         trexhip_blob B = {};
-        B.run_begin = cur[o];
+        B.run_begin = cur[o] + rbeg;      // POOLED offsets until k_gather makes them frame-relative
         B.n_runs = s_cr[o];
-        B.pix_begin = pbg[o];
+        B.pix_begin = pbg[o] + pb;
         B.parent = 0xffffffffu;
         blobs[bb + k] = B;
         blob_frame[bb + k] = (uint32_t)f;
@@ -1101,12 +1101,12 @@ __global__ __launch_bounds__(256) void k_gather(const SegCfg c, const int only_p
     const uint32_t total = min(totals[0], c.pool_blobs);
     for (uint32_t bi = blockIdx.x * 4 + (threadIdx.x >> 6); bi < total; bi += nwaves) {
         const uint32_t f = blob_frame[bi];
+        trexhip_blob B = blobs[bi];                              // independent of the frame table: run_begin / pix_begin are pooled offsets here
         if (f >= (uint32_t)c.B || f < f0 || f >= f1) continue;   // hole left by a frame that overflowed the pool / another group's frame
-        const trexhip_frame_info fi = info[f];
-        if (fi.flags || (only_pending && fi.reserved[0] != 2u)) continue;
-        trexhip_blob B = blobs[bi];
-        const trexhip_run* rr = runs + fi.run_begin + B.run_begin;
-        uint8_t* px = pixels + (size_t)(fi.pix_begin + B.pix_begin) * (enc == 2 ? 3 : 1);
+        const trexhip_frame_info fi = info[f];                   // off the critical path unless only_pending
+        if (only_pending && fi.reserved[0] != 2u) continue;
+        const trexhip_run* rr = runs + B.run_begin;
+        uint8_t* px = pixels + (size_t)B.pix_begin * (enc == 2 ? 3 : 1);
         const uint8_t* img = frames + (size_t)f * c.H * c.W;
         const uint8_t* cimg = enc ? color + (size_t)f * c.H * c.W * color_ch : nullptr;   // colour source of the r3g3b2 / rgb8 pixel arrays
         uint64_t m10 = 0, m01 = 0, m20 = 0, m11 = 0, m02 = 0, sp = 0, spx = 0, spy = 0;
@@ -1170,6 +1170,7 @@ __global__ __launch_bounds__(256) void k_gather(const SegCfg c, const int only_p
         if (lane == 0) {
             const trexhip_run first = rr[0];
             out->n_pixels = po;
+            out->run_begin = B.run_begin - fi.run_begin; out->pix_begin = B.pix_begin - fi.pix_begin;    // the ABI's frame-relative offsets
             out->x0 = (uint16_t)x0; out->y0 = (uint16_t)y0; out->x1 = (uint16_t)x1; out->y1 = (uint16_t)y1;
             out->bid = make_bid(first.x0, first.x1, first.y, B.n_runs);
             out->px_min_max = pmin | (pmax << 8);
