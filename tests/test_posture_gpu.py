@@ -45,6 +45,13 @@ def compare(res, outline, segs, info, pp, min_ok=0.97):
                 continue
             if {int(gi["status"]), int(oi["status"])} == {3, 4} and oi["n_outline"] < 8:
                 continue                                                          # degenerate 3..7-point outline: no midline either way
+            if {int(gi["status"]), int(oi["status"])} == {0, 4} and oi["n_outline"] < 16 and gi["n_outline"] == oi["n_outline"]:
+                # a handful of pixels (plus sign, 2x2 square): the outline is a symmetric polygon whose equal curvature peaks are told apart by
+                # float rounding only, and the walk from another peak yields 2 instead of 3 segments.  The device's count must still be the
+                # CPU walk of its own outline.
+                go = outline[bi, :gi["n_outline"]]
+                assert len(oracle.midline_walk(go, pp.midline_walk_offset)) == gi["n_segments"]
+                continue
             assert gi["status"] == oi["status"], (bi, gi, oi)
             assert gi["n_traced"] == oi["n_traced"]
             if oi["status"] not in (0, 4):
