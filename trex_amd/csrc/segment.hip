@@ -1034,6 +1034,7 @@ __device__ __forceinline__ uint64_t shfl_xor64(uint64_t v, int d) {
     const uint32_t lo = __shfl_xor((uint32_t)v, d), hi = __shfl_xor((uint32_t)(v >> 32), d);
     return ((uint64_t)hi << 32) | lo;
 }
+template <int LANES = 64>
 __device__ __forceinline__ uint64_t wave_sum8x64(const uint64_t (&v)[8], uint32_t lane) {
     uint64_t w[4], u[2];
     const bool b0 = lane & 1u, b1 = lane & 2u, b2 = lane & 4u;
@@ -1042,9 +1043,12 @@ __device__ __forceinline__ uint64_t wave_sum8x64(const uint64_t (&v)[8], uint32_
 #pragma unroll
     for (int j = 0; j < 2; ++j) u[j] = (b1 ? w[2 + j] : w[j]) + shfl_xor64(b1 ? w[j] : w[2 + j], 2);
     uint64_t t = (b2 ? u[1] : u[0]) + shfl_xor64(b2 ? u[0] : u[1], 4);
-    t += shfl_xor64(t, 8); t += shfl_xor64(t, 16); t += shfl_xor64(t, 32);
+    t += shfl_xor64(t, 8);
+    if (LANES > 16) t += shfl_xor64(t, 16);
+    if (LANES > 32) t += shfl_xor64(t, 32);
     return t;
 }
+template <int LANES = 64>
 __device__ __forceinline__ uint32_t wave_min8x32(const uint32_t (&v)[8], uint32_t lane) {
     uint32_t w[4], u[2];
     const bool b0 = lane & 1u, b1 = lane & 2u, b2 = lane & 4u;
@@ -1053,7 +1057,9 @@ __device__ __forceinline__ uint32_t wave_min8x32(const uint32_t (&v)[8], uint32_
 #pragma unroll
     for (int j = 0; j < 2; ++j) u[j] = min(b1 ? w[2 + j] : w[j], (uint32_t)__shfl_xor(b1 ? w[j] : w[2 + j], 2));
     uint32_t t = min(b2 ? u[1] : u[0], (uint32_t)__shfl_xor(b2 ? u[0] : u[1], 4));
-    t = min(t, (uint32_t)__shfl_xor(t, 8)); t = min(t, (uint32_t)__shfl_xor(t, 16)); t = min(t, (uint32_t)__shfl_xor(t, 32));
+    t = min(t, (uint32_t)__shfl_xor(t, 8));
+    if (LANES > 16) t = min(t, (uint32_t)__shfl_xor(t, 16));
+    if (LANES > 32) t = min(t, (uint32_t)__shfl_xor(t, 32));
     return t;
 }
 // lane that holds quantity q after the two reductions above
@@ -1086,7 +1092,9 @@ __device__ __forceinline__ void store_colour(uint8_t* px, uint32_t index, const 
     else px[index] = (uint8_t)(((c0 >> 6) << 6) | ((c1 >> 5) << 3) | (c2 >> 5));
 }
 
-template <bool COLOUR>
+// LPB lanes per blob: 64 (a wave per blob) or 32 (two blobs per wave: most blobs have fewer than 32 lines, and the kernel is a chain of
+// dependent loads -- blob record -> lines -> pixels -- whose throughput is the number of blobs in flight)
+template <bool COLOUR, int LPB>
 __global__ __launch_bounds__(256) void k_gather(const SegCfg c, const int only_pending, const uint8_t* __restrict__ frames,
                                                 const uint32_t* __restrict__ totals,
                                                 const trexhip_frame_info* __restrict__ info,
@@ -1096,29 +1104,41 @@ __global__ __launch_bounds__(256) void k_gather(const SegCfg c, const int only_p
                                                 uint8_t* __restrict__ pixels, const uint32_t f0, const uint32_t f1,
                                                 const uint8_t* __restrict__ color, const int color_ch, const int enc_) {
     const int enc = COLOUR ? enc_ : 0;                     // the gray instantiation carries no colour addressing at all
+    constexpr uint32_t BPW = 64 / LPB;                     // blobs per wave
     const uint32_t lane = lane_id();
+    const uint32_t sub = lane & (LPB - 1), part = lane / LPB, part_base = part * LPB;
     const uint32_t nwaves = gridDim.x * 4;
     const uint32_t total = min(totals[0], c.pool_blobs);
-    for (uint32_t bi = blockIdx.x * 4 + (threadIdx.x >> 6); bi < total; bi += nwaves) {
-        const uint32_t f = blob_frame[bi];
-        trexhip_blob B = blobs[bi];                              // independent of the frame table: run_begin / pix_begin are pooled offsets here
-        if (f >= (uint32_t)c.B || f < f0 || f >= f1) continue;   // hole left by a frame that overflowed the pool / another group's frame
-        const trexhip_frame_info fi = info[f];                   // off the critical path unless only_pending
-        if (only_pending && fi.reserved[0] != 2u) continue;
+    for (uint32_t bw = (blockIdx.x * 4 + (threadIdx.x >> 6)) * BPW; bw < total; bw += nwaves * BPW) {
+        const uint32_t bi = bw + part;
+        bool active = bi < total;
+        uint32_t f = 0;
+        trexhip_blob B = {};
+        if (active) { f = blob_frame[bi]; B = blobs[bi]; }       // independent of the frame table: run_begin / pix_begin are pooled offsets here
+        active = active && f < (uint32_t)c.B && f >= f0 && f < f1;   // else: hole left by a frame that overflowed the pool / another group's frame
+        trexhip_frame_info fi = {};
+        if (active) fi = info[f];                                // off the critical path unless only_pending
+        if (only_pending && fi.reserved[0] != 2u) active = false;
+        const uint32_t n_runs = active ? B.n_runs : 0u;
+        uint32_t nr_max = n_runs;
+        if (BPW > 1) nr_max = max(nr_max, (uint32_t)__shfl_xor((int)nr_max, 32));
+        if (BPW > 2) nr_max = max(nr_max, (uint32_t)__shfl_xor((int)nr_max, 16));
         const trexhip_run* rr = runs + B.run_begin;
         uint8_t* px = pixels + (size_t)B.pix_begin * (enc == 2 ? 3 : 1);
         const uint8_t* img = frames + (size_t)f * c.H * c.W;
         const uint8_t* cimg = enc ? color + (size_t)f * c.H * c.W * color_ch : nullptr;   // colour source of the r3g3b2 / rgb8 pixel arrays
         uint64_t m10 = 0, m01 = 0, m20 = 0, m11 = 0, m02 = 0, sp = 0, spx = 0, spy = 0;
         uint32_t x0 = 0xffff, x1 = 0, y0 = 0xffff, y1 = 0, pmin = 255, pmax = 0, po = 0;
-        for (uint32_t b0 = 0; b0 < B.n_runs; b0 += 64) {
-            const uint32_t i = b0 + lane;
+        for (uint32_t b0 = 0; b0 < nr_max; b0 += LPB) {
+            const uint32_t i = b0 + sub;
             trexhip_run q = {};
             uint32_t len = 0;
-            if (i < B.n_runs) { q = rr[i]; len = (uint32_t)(q.x1 - q.x0 + 1); }
-            const uint32_t incl = wave_incl_scan(len);
+            if (i < n_runs) { q = rr[i]; len = (uint32_t)(q.x1 - q.x0 + 1); }
+            uint32_t incl = len;
+#pragma unroll
+            for (int d = 1; d < LPB; d <<= 1) { const uint32_t t = __shfl_up(incl, d); if (sub >= (uint32_t)d) incl += t; }
             uint32_t off = po + incl - len;
-            po += __shfl(incl, 63);
+            po += __shfl(incl, part_base + LPB - 1);
             if (len) {
                 x0 = min(x0, (uint32_t)q.x0); x1 = max(x1, (uint32_t)q.x1);
                 y0 = min(y0, (uint32_t)q.y);  y1 = max(y1, (uint32_t)q.y);
@@ -1155,19 +1175,21 @@ __global__ __launch_bounds__(256) void k_gather(const SegCfg c, const int only_p
                 sp += rp; spy += rp * y;
             }
         }
-        // all eight sums / six extrema of the blob with two transposing reductions
+        // all eight sums / six extrema of the blob with two transposing reductions (over the blob's LPB lanes)
         const uint64_t sums[8] = {m10, m01, m20, m11, m02, sp, spx, spy};          // = the order of the fields in trexhip_blob
-        const uint64_t tot = wave_sum8x64(sums, lane);
+        const uint64_t tot = wave_sum8x64<LPB>(sums, lane);
         const uint32_t ext[8] = {x0, y0, ~x1, ~y1, pmin, ~pmax, 0xffffffffu, 0xffffffffu};
-        const uint32_t te = wave_min8x32(ext, lane);
-        x0 = __shfl(te, lane_of_q(0)); y0 = __shfl(te, lane_of_q(1)); x1 = ~__shfl(te, lane_of_q(2)); y1 = ~__shfl(te, lane_of_q(3));
-        pmin = __shfl(te, lane_of_q(4)); pmax = ~__shfl(te, lane_of_q(5));
+        const uint32_t te = wave_min8x32<LPB>(ext, lane);
+        x0 = __shfl(te, part_base + lane_of_q(0)); y0 = __shfl(te, part_base + lane_of_q(1));
+        x1 = ~__shfl(te, part_base + lane_of_q(2)); y1 = ~__shfl(te, part_base + lane_of_q(3));
+        pmin = __shfl(te, part_base + lane_of_q(4)); pmax = ~__shfl(te, part_base + lane_of_q(5));
+        if (!active) continue;
         trexhip_blob* out = blobs + bi;
-        if (lane < 8) {
-            const uint32_t q = 4u * (lane & 1u) + 2u * ((lane >> 1) & 1u) + ((lane >> 2) & 1u);
+        if (sub < 8) {
+            const uint32_t q = 4u * (sub & 1u) + 2u * ((sub >> 1) & 1u) + ((sub >> 2) & 1u);
             (&out->m10)[q] = tot;
         }
-        if (lane == 0) {
+        if (sub == 0) {
             const trexhip_run first = rr[0];
             out->n_pixels = po;
             out->run_begin = B.run_begin - fi.run_begin; out->pix_begin = B.pix_begin - fi.pix_begin;    // the ABI's frame-relative offsets
@@ -1180,8 +1202,8 @@ __global__ __launch_bounds__(256) void k_gather(const SegCfg c, const int only_p
 
 // ---------------------------------------------------------------------------------------------
 // host side launch
-#define LAUNCH_GATHER(grid_, stream_, ...) do { if (ctx->p.pixel_encoding != TREXHIP_ENC_GRAY) hipLaunchKernelGGL((k_gather<true>), grid_, dim3(256), 0, stream_, __VA_ARGS__); \
-                                                 else hipLaunchKernelGGL((k_gather<false>), grid_, dim3(256), 0, stream_, __VA_ARGS__); } while (0)
+#define LAUNCH_GATHER(grid_, stream_, ...) do { if (ctx->p.pixel_encoding != TREXHIP_ENC_GRAY) hipLaunchKernelGGL((k_gather<true, 64>), grid_, dim3(256), 0, stream_, __VA_ARGS__); \
+                                                 else hipLaunchKernelGGL((k_gather<false, 32>), grid_, dim3(256), 0, stream_, __VA_ARGS__); } while (0)
 // ---------------------------------------------------------------------------------------------
 template <bool ALIGNED>
 static void launch_rows(int nch, dim3 grid, hipStream_t s, const uint8_t* frames, const uint8_t* bg,
