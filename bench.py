@@ -50,6 +50,8 @@ def main():
                     help="individual_image_normalization of the identity crops; posture = outline -> midline -> Midline::transform -> warpAffine (implies --with-posture)")
     ap.add_argument("--encoding", default="gray", choices=["gray", "rgb8"],
                     help="meta_encoding: gray = the BASELINE workload (gray frames); rgb8 = BGRA frames in HBM -> cvtColor on the device, 3-byte pixel arrays, 3-channel crops and network")
+    ap.add_argument("--input", default="gray", choices=["gray", "bgra"],
+                    help="bgra: the tiles as TRex hands them over (BGRA, BackgroundSubtraction.cpp:162-180): cv::cvtColor runs on the device inside the timed step (as-deployed secondary row of SURVEY 8d; --encoding rgb8 implies it)")
     ap.add_argument("--no-pipeline", dest="pipeline", action="store_false", help="one context, strictly serial steps (no overlap of detect(i+1) with identity(i))")
     ap.add_argument("--lanes", type=int, default=2, help="software-pipeline depth: contexts whose batches are in flight (detect of batch i+L-1 is issued while the identity network works on batch i)")
     ap.add_argument("--no-detect-priority", dest="detect_priority", action="store_false",
@@ -96,7 +98,8 @@ def main():
     # frame-sharded: rank r owns frames r*B .. r*B+B-1 of every step's block (distinct data per rank)
     frames, bg = synth.batch_torch(args.config, B, dev, t0=rank * B)
     rgb = args.encoding == "rgb8"
-    if rgb:     # the same scenes as BGRA tiles (what TRex's TileImage holds for meta_encoding rgb8)
+    bgra_in = rgb or args.input == "bgra"
+    if bgra_in:     # the same scenes as BGRA tiles (what TRex's TileImage holds)
         frames_c = torch.stack([frames, frames, frames, torch.full_like(frames, 255)], dim=-1).contiguous()
     max_blobs = 4 * n_ind
     state = weights.synthetic_state(classes, 4242, channels=3 if args.encoding == "rgb8" else 1)
@@ -138,7 +141,7 @@ def main():
         def detect(self):
             if self.hi is not None:
                 self.seg.set_stream(self.hi.cuda_stream)
-            if rgb:
+            if bgra_in:
                 self.seg.segment_color_device(frames_c.data_ptr(), B, 4)
             else:
                 self.seg.segment_device(frames.data_ptr(), B)
@@ -288,7 +291,7 @@ def main():
                                f"80x80x1 crops, {classes}-way V118_3 (random-init weights)",
                    "stages": "detect(bg-sub+threshold+CCL+filter+gather, tables->host) + crops(none) + identity CNN (V118_3) + per-blob ID table (all-gathered when N>1) -> rank-0 host"
                              if with_cnn else "detect only (bg-sub+threshold+CCL+filter+gather, tables->host)",
-                   "frames_per_step_per_gpu": B, "encoding": args.encoding, "posture": bool(args.with_posture), "individual_image_normalization": args.normalize, "pipelined_lanes": len(lanes), "blobs_per_step_rank0": n_blobs, "parallelism": f"frame-sharded x{world}"},
+                   "frames_per_step_per_gpu": B, "encoding": args.encoding, "input": "bgra tiles (cvtColor on the device inside the step)" if bgra_in else "gray frames", "posture": bool(args.with_posture), "individual_image_normalization": args.normalize, "pipelined_lanes": len(lanes), "blobs_per_step_rank0": n_blobs, "parallelism": f"frame-sharded x{world}"},
     }
     seg_roof = {"kernel": "k_rows", "bound": "hbm", "achieved": seg_bytes / rows_s / 1e9 if rows_s else 0.0, "peak": 8000.0,
                 "unit": "GB/s", "frac": seg_bytes / rows_s / 8e12 if rows_s else 0.0, "traffic": pmc_traffic("trexhip::k_rows"),

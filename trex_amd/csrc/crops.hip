@@ -261,7 +261,7 @@ __global__ __launch_bounds__(256) void k_to_gray(const uint8_t* __restrict__ src
         }
         uint32_t g;
         if (color_channel >= 0) g = c[color_channel & 3];
-        else g = (c[0] * 1868u + c[1] * 9617u + c[2] * 4899u + 8192u) >> 14;
+        else g = (__umul24(c[0], 1868u) + __umul24(c[1], 9617u) + __umul24(c[2], 4899u) + 8192u) >> 14;   // 24-bit multiplies: full rate (v_mul_lo_u32 is quarter rate)
         out |= g << (8 * p);
     }
     reinterpret_cast<uint32_t*>(dst)[i] = out;
