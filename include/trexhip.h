@@ -244,7 +244,8 @@ int trexhip_split_search_device(trexhip_ctx* ctx, const trexhip_split_params* sp
  *                                           the tail (what Outline holds after calculate_midline), relative to the
  *                                           blob's bounds().pos()
  *   segments [n_blobs][max_points/2+1] float4 = MidlineSegment{pos.x, pos.y, height, l_length} (Outline.h:241-250)
- *   info     [n_blobs] status 0 ok / 1 empty / 2 capacity / 3 no curvature peak / 4 too few midline segments */
+ *   info     [n_blobs] status 0 ok / 1 empty / 2 capacity (more than max_points traced outline points, 2048 lines or 1022 rows) /
+ *                      3 no curvature peak / 4 too few midline segments */
 typedef struct trexhip_posture_params {
     float   outline_resample;               /* core/default_config.cpp:898  (1)    */
     int32_t outline_smooth_samples;         /* :890 (4)                            */
@@ -252,7 +253,7 @@ typedef struct trexhip_posture_params {
     int32_t outline_approximate;            /* :888 (3)                            */
     float   outline_curvature_range_ratio;  /* :891 (0.03)                         */
     float   midline_walk_offset;            /* :892 (0.025)                        */
-    int32_t max_points;                     /* capacity per blob, 8..1024          */
+    int32_t max_points;                     /* capacity per blob (outline points; the traced lattice outline has 2 per pixel edge), even, 8..4096 */
 } trexhip_posture_params;
 typedef struct trexhip_posture_info { int32_t status, n_outline, n_segments, tail_index, head_index, n_traced, reserved[2]; } trexhip_posture_info;
 void trexhip_default_posture_params(trexhip_posture_params* p);

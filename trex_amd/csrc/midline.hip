@@ -153,7 +153,7 @@ extern "C" int trexhip_midline_device(trexhip_ctx* ctx, const trexhip_midline_pa
     if (!ctx || !mp || !d_posture_info || !d_segments || !d_midline || !d_midline_info) { set_error("trexhip_midline_device: null argument"); return TREXHIP_E_INVALID; }
     if (mp->midline_resolution < 3 || mp->midline_resolution > 256) { set_error("trexhip_midline_device: midline_resolution must be in 3..256"); return TREXHIP_E_INVALID; }
     if (!(mp->midline_stiff_percentage >= 0.f) || mp->midline_stiff_percentage >= 1.f) { set_error("trexhip_midline_device: midline_stiff_percentage must be in [0,1)"); return TREXHIP_E_INVALID; }
-    if (max_points < 8 || max_points > 1024 || (max_points & 1)) { set_error("trexhip_midline_device: max_points must match the posture call"); return TREXHIP_E_INVALID; }
+    if (max_points < 8 || max_points > 4096 || (max_points & 1)) { set_error("trexhip_midline_device: max_points must match the posture call"); return TREXHIP_E_INVALID; }
     if (n_blobs < 0) { set_error("trexhip_midline_device: negative n_blobs"); return TREXHIP_E_INVALID; }
     if (n_blobs == 0) return TREXHIP_OK;
     TH_CHECK_HIP(hipSetDevice(ctx->p.device));

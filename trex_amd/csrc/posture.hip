@@ -16,9 +16,9 @@
 
 namespace trexhip {
 
-static constexpr int P_NP = 1024;      // largest max_points
-static constexpr int P_NR = 512;       // runs per blob held in LDS
-static constexpr int P_ROWS = 254;     // rows per blob
+static constexpr int P_NP = 4096;      // largest max_points (one blob per workgroup beyond ~1300: the LDS of a CU holds fewer large blobs)
+static constexpr int P_NR = 2048;      // runs per blob held in LDS
+static constexpr int P_ROWS = 1022;    // rows per blob
 // bytes of LDS per wave for a given point capacity: two point buffers, curvature, arc length, runs, row table
 // (nr / nrows = line and row capacity of this launch: the host sizes them to the largest blob of the fetched table, so that more
 // blobs fit into a CU's LDS -- the kernel is a chain of LDS / memory latencies and lives on the number of blobs in flight)
@@ -53,7 +53,7 @@ __global__ __launch_bounds__(256) void k_posture(const PostureCfg P, const trexh
                                                  trexhip_posture_info* __restrict__ out_info) {
     extern __shared__ __attribute__((aligned(16))) uint8_t plds[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int bi = blockIdx.x * 4 + wave;
+    const int bi = blockIdx.x * (int)(blockDim.x >> 6) + wave;   // 4, 2 or 1 blobs per workgroup (LDS per blob)
     if (bi >= n_blobs) return;
     const int NPc = P.max_points;                           // point capacity = LDS layout stride
     uint8_t* base = plds + (size_t)wave * posture_wave_lds(NPc, P.nr_cap, P.rows_cap);
@@ -163,7 +163,7 @@ __global__ __launch_bounds__(256) void k_posture(const PostureCfg P, const trexh
                     const uint32_t tid = (uint32_t)base16[ty * 4 + tk] + (uint32_t)__popcll(side_mask(ty, tk) & ((1ull << tx) - 1ull));
                     // the side whose successor is the start side (id 0: first top side of the first row) ends the cycle
                     jmp0[e] = tid == 0u ? e : (tid | (1u << 16));
-                    geo[e] = (uint32_t)xr | ((uint32_t)yr << 8) | ((uint32_t)k << 16);
+                    geo[e] = (uint32_t)xr | ((uint32_t)yr << 6) | ((uint32_t)k << 16);      // x < 64, row < 1024
                     ++e;
                 }
             }
@@ -187,7 +187,7 @@ __global__ __launch_bounds__(256) void k_posture(const PostureCfg P, const trexh
                     if ((v & 0xffffu) != (first & 0xffffu)) continue;                    // a hole's boundary
                     const int pos = (int)(first >> 16) - (int)(v >> 16);
                     const uint32_t g = geo[e];
-                    const int xr = (int)(g & 0xffu), yr = (int)((g >> 8) & 0xffu), k = (int)(g >> 16);
+                    const int xr = (int)(g & 0x3fu), yr = (int)((g >> 6) & 0x3ffu), k = (int)(g >> 16);
                     const int vx = 2 * xr + ((k == 1 || k == 2) ? 1 : -1), vy = 2 * yr + ((k >= 2) ? 1 : -1);   // doubled, blob-relative
                     const int ddx = k == 0 ? 1 : (k == 2 ? -1 : 0), ddy = k == 1 ? 1 : (k == 3 ? -1 : 0);
                     bufA[2 * pos] = make_float2(0.5f * (float)vx, 0.5f * (float)vy);
@@ -543,7 +543,7 @@ using namespace trexhip;
 extern "C" int trexhip_posture_device(trexhip_ctx* ctx, int32_t table, const trexhip_posture_params* pp, int32_t n_blobs,
                                       float* d_outline, float* d_segments, trexhip_posture_info* d_info) {
     if (!ctx || !pp || !d_outline || !d_segments || !d_info) { set_error("trexhip_posture_device: null argument"); return TREXHIP_E_INVALID; }
-    if (pp->max_points < 8 || pp->max_points > P_NP || (pp->max_points & 1)) { set_error("trexhip_posture_device: max_points must be even and in 8..1024"); return TREXHIP_E_INVALID; }
+    if (pp->max_points < 8 || pp->max_points > P_NP || (pp->max_points & 1)) { set_error("trexhip_posture_device: max_points must be even and in 8..4096"); return TREXHIP_E_INVALID; }
     if (pp->outline_smooth_samples < 0 || pp->outline_smooth_samples * (pp->outline_smooth_step > 0 ? pp->outline_smooth_step : 1) > 16 || pp->outline_smooth_step < 1) {
         set_error("trexhip_posture_device: outline_smooth_samples*outline_smooth_step must be <= 16"); return TREXHIP_E_UNSUPPORTED;
     }
@@ -577,7 +577,11 @@ extern "C" int trexhip_posture_device(trexhip_ctx* ctx, int32_t table, const tre
             if (rows_cap > P_ROWS) rows_cap = P_ROWS;
         }
     }
-    const int lds_bytes = 4 * posture_wave_lds(pp->max_points, nr_cap, rows_cap);
+    // blobs per workgroup: 4 while their LDS fits a CU comfortably, else 2 or 1 (large max_points / large blobs)
+    const int wave_lds = posture_wave_lds(pp->max_points, nr_cap, rows_cap);
+    int wpb = 4;
+    while (wpb > 1 && wpb * wave_lds > 150 * 1024) wpb >>= 1;
+    const int lds_bytes = wpb * wave_lds;
     if (lds_bytes > ctx->attr_posture_bytes) {
         TH_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_posture), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
         ctx->attr_posture_bytes = lds_bytes;
@@ -586,7 +590,7 @@ extern "C" int trexhip_posture_device(trexhip_ctx* ctx, int32_t table, const tre
                  pp->outline_curvature_range_ratio, pp->midline_walk_offset, pp->max_points, nr_cap, rows_cap, 0};
     if (const char* e = std::getenv("TREXHIP_POSTURE_STOP")) P.stop = std::atoi(e);
     stage_begin(ctx, TREXHIP_STAGE_POSTURE);
-    hipLaunchKernelGGL(k_posture, dim3((n_blobs + 3) / 4), dim3(256), lds_bytes, ctx->stream, P, info, bf, bl, ru, n_blobs, ctx->last_n,
+    hipLaunchKernelGGL(k_posture, dim3((n_blobs + wpb - 1) / wpb), dim3(wpb * 64), lds_bytes, ctx->stream, P, info, bf, bl, ru, n_blobs, ctx->last_n,
                        reinterpret_cast<float2*>(d_outline), reinterpret_cast<float4*>(d_segments), d_info);
     stage_end(ctx, TREXHIP_STAGE_POSTURE);
     TH_CHECK_HIP(hipGetLastError());

@@ -31,7 +31,7 @@ public:
         uint32_t midline_resolution = 25;
         float midline_stiff_percentage = 0.15f;
         bool midline_invert = false, midline_start_with_head = false;
-        int max_points = 512;                           // capacity per blob (points of the resampled outline)
+        int max_points = 512;                           // capacity per blob: traced lattice points = 2 per pixel edge of the outline; even, up to 4096
     };
     struct Result {                                     // posture::Result (Posture.h:34-38)
         Outline outline;
