@@ -204,8 +204,8 @@ int trexhip_fetch_rethreshold(trexhip_ctx* ctx, trexhip_batch_result* out);
  *   d_info       [n_blobs]: what the search saw.  Of the sub-blobs, those with n_pixels * cm^2 < min_size_bound are not part
  *                           of SplitBlob::split's result (:204-221); the rest is returned sorted by (num_pixels, blob_id) descending
  *                           and shifted by -bounds().pos() (:166-172), which the caller does on the fetched table.
- * Needs a fetched batch (n_blobs = total_blobs).  Blobs with more than 16384 pixels or 1024 lines (or 2048 lines after
- * thresholding) report status 2 and no threshold. */
+ * Needs a fetched batch (n_blobs = total_blobs).  Three size classes by LDS need (2048 / 16384 / 61440 pixels per blob); blobs with
+ * more than 61440 pixels or 2048 lines (or 4096 lines after thresholding) report status 2 and no threshold. */
 typedef struct trexhip_split_params {
     int32_t track_threshold;                 /* core/default_config.cpp track_threshold            */
     int32_t track_posture_threshold;

@@ -130,3 +130,29 @@ def test_large_class_blobs():
         big += b["n_pixels"] > 2048
         found += want.threshold >= 0 and b["n_pixels"] > 2048
     assert big >= 3 and found >= 1
+
+
+def test_huge_class_blobs():
+    # two merged large animals (> 16384 pixels together): the third size class (one blob per CU, 134 KB of LDS), launched only when needed
+    H, W = 400, 768
+    yy, xx = np.mgrid[0:H, 0:W].astype(np.float32)
+    bg = (140 + ((np.arange(W)[None, :] * 3 + np.arange(H)[:, None] * 5) & 31) - 16).astype(np.uint8)
+    depth = np.zeros((H, W), np.float32)
+    for cx, cy, a, b, amp in [(380, 150, 200, 30, 95), (385, 203, 195, 29, 85), (120, 350, 40, 12, 80), (135, 368, 38, 11, 75)]:
+        r2 = ((xx - cx) / a) ** 2 + ((yy - cy) / b) ** 2
+        depth = np.maximum(depth, amp * np.clip(1.15 - r2, 0, 1))
+    fr = np.clip(bg.astype(int) - np.rint(depth).astype(int), 0, 255).astype(np.uint8)
+    ranges = [(2000, 30000), (100, 1700)]
+    det, presumed, thr, info, sub = device_search(fr[None], bg, lambda r: np.full(len(r.blobs), 2), 1, ranges)
+    r = det[0]
+    sp = oracle.split_params(size_ranges=ranges)
+    sizes = sorted(int(b["n_pixels"]) for b in r.blobs)
+    assert len(sizes) == 2 and 16384 < sizes[1] <= 61440 and sizes[0] < 16384, sizes
+    for k, b in enumerate(r.blobs):
+        runs = r.runs[b["run_begin"]:b["run_begin"] + b["n_runs"]]
+        px = r.pixels[b["pix_begin"]:b["pix_begin"] + b["n_pixels"]]
+        want = oracle.split_search(runs, px, bg, 1, sp, 2)
+        assert info[k]["status"] == 0
+        assert (info[k]["threshold"], info[k]["n_result"], info[k]["first_size"], info[k]["min_pixel"], info[k]["max_pixel"]) == \
+               (want.threshold, want.n_result, want.first_size, want.min_pixel, want.max_pixel), k
+        assert want.threshold > 16                                  # both pairs separate above the track threshold

@@ -18,6 +18,8 @@ static constexpr int S_PX = 16384;     // pixels per blob held in LDS (large cla
 static constexpr int S_RUNS = 1024;    // lines per blob
 static constexpr int S_SUB = 2048;     // lines after thresholding
 static constexpr int S_PX_SMALL = 2048, S_RUNS_SMALL = 256, S_SUB_SMALL = 1024;   // 2048 pixels cannot make more than 1024 lines
+static constexpr int S_PX_HUGE = 61440, S_RUNS_HUGE = 2048, S_SUB_HUGE = 4096;   // two merged 600-row animals; pixel offsets stay 16-bit
+constexpr int split_lds_bytes(int px, int runs, int sub) { return runs * 4 + sub * 12 + 1024 + runs * 2 + (runs + 2) * 2 + sub * 2 + 256 + px; }
 
 enum { A_KEEP = 0, A_KEEP_ABORT = 1, A_REMOVE = 2, A_ABORT = 3, A_TOO_FEW = 4, A_SKIP = 5, A_NO_CHANCE = 6 };
 
@@ -78,16 +80,18 @@ __global__ __launch_bounds__(64) void k_split_search(const SplitCfg C, const uin
                                                      const trexhip_blob* __restrict__ blobs, const trexhip_run* __restrict__ runs,
                                                      const int32_t* __restrict__ presumed, int n_blobs, int32_t* __restrict__ out_thr,
                                                      trexhip_split_info* __restrict__ out_info) {
-    __shared__ __attribute__((aligned(16))) uint8_t s_d[S_PX];
-    __shared__ uint32_t s_rx[S_RUNS];
-    __shared__ uint16_t s_ry[S_RUNS];
-    __shared__ uint16_t s_roff[S_RUNS + 1];
-    __shared__ uint32_t s_sx[S_SUB];
-    __shared__ uint16_t s_sy[S_SUB];
-    __shared__ uint32_t s_par[S_SUB];
-    __shared__ uint32_t s_size[S_SUB];
-    __shared__ uint32_t s_hist[256];
-    __shared__ uint8_t s_cache[256];
+    // dynamic LDS (the largest size class needs more than the 64 KB a static allocation may have), carved by descending alignment
+    extern __shared__ __attribute__((aligned(16))) uint8_t s_lds[];
+    uint32_t* s_rx = reinterpret_cast<uint32_t*>(s_lds);
+    uint32_t* s_sx = s_rx + S_RUNS;
+    uint32_t* s_par = s_sx + S_SUB;
+    uint32_t* s_size = s_par + S_SUB;
+    uint32_t* s_hist = s_size + S_SUB;
+    uint16_t* s_ry = reinterpret_cast<uint16_t*>(s_hist + 256);
+    uint16_t* s_roff = s_ry + S_RUNS;
+    uint16_t* s_sy = s_roff + (S_RUNS + 2);
+    uint8_t* s_cache = reinterpret_cast<uint8_t*>(s_sy + S_SUB);
+    uint8_t* s_d = s_cache + 256;
 
     const int bi = blockIdx.x, lane = threadIdx.x;
     if (bi >= n_blobs) return;
@@ -101,9 +105,13 @@ __global__ __launch_bounds__(64) void k_split_search(const SplitCfg C, const uin
     if (!ok) { if (lane == 0) { res.status = 3; out_info[bi] = res; out_thr[bi] = -1; } return; }
     const trexhip_blob Bl = blobs[bi];
     const int n_runs = (int)Bl.n_runs, npx = (int)Bl.n_pixels;
-    if (npx <= MIN_PX && n_runs <= MIN_RUNS) return;           // the small-class launch handles it
+    if (npx <= MIN_PX && n_runs <= MIN_RUNS) return;           // a smaller size class handles it
     if (n_runs > S_RUNS || npx > S_PX || n_runs == 0) {
-        if (MIN_PX == 0 && n_runs && npx <= trexhip::S_PX && n_runs <= trexhip::S_RUNS) return;   // left to the large-class launch
+        if (n_runs && npx <= S_PX_HUGE && n_runs <= S_RUNS_HUGE && S_PX < S_PX_HUGE) {
+            // left to a larger size class; the host launches the last one only when the batch holds such a blob, so mark it beyond capacity first
+            if (S_PX == trexhip::S_PX && lane == 0) { res.status = 2; out_info[bi] = res; out_thr[bi] = -1; }
+            return;
+        }
         if (lane == 0) { res.status = n_runs ? 2 : 3; out_info[bi] = res; out_thr[bi] = -1; }
         return;
     }
@@ -309,10 +317,25 @@ int launch_split_search(trexhip_ctx* ctx, const trexhip_split_params* sp, int me
         if (C.max_start == -1 || C.ranges[2 * i] < C.max_start) C.max_start = C.ranges[2 * i];
         if (C.max_end == -1 || C.ranges[2 * i + 1] > C.max_end) C.max_end = C.ranges[2 * i + 1];
     }
-    hipLaunchKernelGGL((k_split_search<S_PX_SMALL, S_RUNS_SMALL, S_SUB_SMALL, 0, 0>), dim3((unsigned)n_blobs), dim3(64), 0, ctx->stream, C, ctx->d_frames,
+    hipLaunchKernelGGL((k_split_search<S_PX_SMALL, S_RUNS_SMALL, S_SUB_SMALL, 0, 0>), dim3((unsigned)n_blobs), dim3(64),
+                       split_lds_bytes(S_PX_SMALL, S_RUNS_SMALL, S_SUB_SMALL), ctx->stream, C, ctx->d_frames,
                        ctx->d_bg, ctx->d_info, ctx->d_blob_frame, ctx->d_blobs, ctx->d_runs, d_presumed, n_blobs, d_thr, d_info);
-    hipLaunchKernelGGL((k_split_search<S_PX, S_RUNS, S_SUB, S_PX_SMALL, S_RUNS_SMALL>), dim3((unsigned)n_blobs), dim3(64), 0, ctx->stream, C, ctx->d_frames,
+    hipLaunchKernelGGL((k_split_search<S_PX, S_RUNS, S_SUB, S_PX_SMALL, S_RUNS_SMALL>), dim3((unsigned)n_blobs), dim3(64),
+                       split_lds_bytes(S_PX, S_RUNS, S_SUB), ctx->stream, C, ctx->d_frames,
                        ctx->d_bg, ctx->d_info, ctx->d_blob_frame, ctx->d_blobs, ctx->d_runs, d_presumed, n_blobs, d_thr, d_info);
+    // the third size class (134 KB of LDS: one blob per CU) only when the fetched tables hold a blob of that size
+    bool huge = false;
+    for (int i = 0; i < n_blobs && !huge; ++i) huge = ctx->h_blobs[i].n_pixels > (uint32_t)S_PX || ctx->h_blobs[i].n_runs > (uint32_t)S_RUNS;
+    if (huge) {
+        const int bytes = split_lds_bytes(S_PX_HUGE, S_RUNS_HUGE, S_SUB_HUGE);
+        if (!ctx->attr_split) {
+            TH_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_split_search<S_PX_HUGE, S_RUNS_HUGE, S_SUB_HUGE, S_PX, S_RUNS>),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+            ctx->attr_split = true;
+        }
+        hipLaunchKernelGGL((k_split_search<S_PX_HUGE, S_RUNS_HUGE, S_SUB_HUGE, S_PX, S_RUNS>), dim3((unsigned)n_blobs), dim3(64), bytes, ctx->stream, C,
+                           ctx->d_frames, ctx->d_bg, ctx->d_info, ctx->d_blob_frame, ctx->d_blobs, ctx->d_runs, d_presumed, n_blobs, d_thr, d_info);
+    }
     TH_CHECK_HIP(hipGetLastError());
     return TREXHIP_OK;
 }

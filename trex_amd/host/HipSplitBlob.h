@@ -44,7 +44,7 @@ public:
         uint32_t blob = 0;
         int threshold = -1;                             // best_match.threshold, -1: "could not find anything" (:797-799)
         std::vector<cmn::blob::Pair> blobs;             // what SplitBlob::split returns (empty when nothing was found)
-        bool beyond_capacity = false;                   // the blob does not fit the device search (> 16384 pixels / 1024 lines): caller keeps it unsplit
+        bool beyond_capacity = false;                   // the blob does not fit the device search (> 61440 pixels / 2048 lines): caller keeps it unsplit
     };
 
     explicit HipSplitBlob(trexhip_ctx* ctx) : _ctx(ctx) {}        // must be destroyed before trexhip_destroy(ctx)
