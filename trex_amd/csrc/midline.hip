@@ -13,6 +13,7 @@ namespace trexhip {
 
 struct MidlineCfg { int resolution; float stiff; int invert, start_with_head, stride; };
 
+static constexpr int M_CAP = 48;        // segments per blob worked on in LDS (48 x 64 lanes x 16 B = 48 KB per workgroup)
 __device__ __forceinline__ float vlen(float x, float y) { return sqrtf(x * x + y * y); }
 __device__ __forceinline__ float2 vnorm(float x, float y) { const float L = vlen(x, y); return L > 0 ? make_float2((x / L), (y / L)) : make_float2(0.f, 0.f); }
 
@@ -25,9 +26,17 @@ __global__ __launch_bounds__(64) void k_midline(const MidlineCfg C, const trexhi
     const trexhip_posture_info pi = pinfo[b];
     const int n = pi.n_segments;
     if (pi.status != 0 || n <= 2) { I.status = 1; minfo[b] = I; return; }
-    float4* S = segs + (size_t)b * C.stride;
+    // The algorithm below walks the blob's segment list about six times, one lane per blob: done in global memory every access of a wave
+    // touches 64 cache lines.  Lists of at most M_CAP segments are worked on in the lane's LDS column (one pass in, one pass out).
+    float4* Sg = segs + (size_t)b * C.stride;
+    __shared__ float4 s_seg[M_CAP * 64];
+    const bool in_lds = n <= M_CAP;
+    if (in_lds) for (int i = 0; i < n; ++i) s_seg[i * 64 + threadIdx.x] = Sg[i];
+    const int sstride = in_lds ? 64 : 1;
+    float4* Sb = in_lds ? s_seg + threadIdx.x : Sg;          // generic pointer: LDS column or the global list
+#define S(i_) Sb[(i_) * sstride]
     const bool rev = C.invert ? (C.start_with_head != 0) : (C.start_with_head == 0);
-#define PS(i) S[rev ? n - 1 - (i) : (i)]
+#define PS(i) S(rev ? n - 1 - (i) : (i))
     if (C.stiff > 0) {
         float cf = roundf((float)n * C.stiff) + 1.f; if ((float)n - 1.f < cf) cf = (float)n - 1.f;
         const int center = (int)cf;
@@ -55,29 +64,30 @@ __global__ __launch_bounds__(64) void k_midline(const MidlineCfg C, const trexhi
         }
     }
 #undef PS
-    if (!rev) for (int i = 0; i < n / 2; ++i) { const float4 t = S[i]; S[i] = S[n - 1 - i]; S[n - 1 - i] = t; }
+    if (!rev) for (int i = 0; i < n / 2; ++i) { const float4 t = S(i); S(i) = S(n - 1 - i); S(n - 1 - i) = t; }
+    if (in_lds) for (int i = 0; i < n; ++i) Sg[i] = S(i);     // the post-processed list is an output (in place)
     // ---- normalize --------------------------------------------------------------------------------
     double len = 0.0;
     {
-        float4 a = S[0];
-        for (int i = 1; i < n; ++i) { const float4 q = S[i]; len += (double)vlen(q.x - a.x, q.y - a.y); a = q; }
+        float4 a = S(0);
+        for (int i = 1; i < n; ++i) { const float4 q = S(i); len += (double)vlen(q.x - a.x, q.y - a.y); a = q; }
     }
     if (len == 0.0) { I.status = 1; minfo[b] = I; return; }
     const int R = C.resolution;
     const double step = len / (double)(R - 1);
     int nr = 1, index = 0;
-    float4 last = S[0];
+    float4 last = S(0);
     out[0] = last;
     double last_pt_distance = 0.0, distance = 0.0;
     while (distance <= len && index < n - 1) {
         while (distance - last_pt_distance < step && index < n - 1) {
-            const float4 a = S[index], q = S[index + 1];
+            const float4 a = S(index), q = S(index + 1);
             distance += (double)vlen(q.x - a.x, q.y - a.y);
             index++;
         }
         float off = (float)(distance - last_pt_distance);
         if ((double)off < step) break;
-        const float4 s0 = S[index - 1], s1 = S[index];
+        const float4 s0 = S(index - 1), s1 = S(index);
         const float lx = s1.x - s0.x, ly = s1.y - s0.y;
         const float local_d = vlen(lx, ly);
         while ((double)off >= step) {
@@ -97,7 +107,7 @@ __global__ __launch_bounds__(64) void k_midline(const MidlineCfg C, const trexhi
         }
     }
     {
-        const float4 e = S[n - 1];
+        const float4 e = S(n - 1);
         if (vlen(last.x - e.x, last.y - e.y) >= 0.01f) { if (nr < R) out[nr] = e; ++nr; }
     }
     I.n = nr;
@@ -138,6 +148,7 @@ __global__ __launch_bounds__(64) void k_midline(const MidlineCfg C, const trexhi
     }
     I.len = (float)len; I.angle = ang0; I.offx = A.x; I.offy = A.y;
     minfo[b] = I;
+#undef S
 }
 
 int launch_crops_warp(trexhip_ctx* ctx, uint8_t* d_crops, int n, int OW, int OH, int diff_mode, const float* tr6, const float* lengths,
