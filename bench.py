@@ -360,12 +360,22 @@ def main():
             cpu["value"] = seg_fps
             cpu["sample"] = f"{k} distinct frames of the batch, one per OpenMP thread, repeated {args.cpu_seconds:.0f} s; oracle/ restatement"
         out["cpu_baseline"] = cpu
-    if rank == 0:
-        print(json.dumps(out))
     for ln in lanes:
         ln.seg.close()
     if use_dist:
+        sys.stdout.flush()
+        dist.barrier()                      # every rank is done talking before rank 0 writes its line
         dist.destroy_process_group()
+    # the ONE JSON line is the last thing this process writes: whatever the runtime libraries left in the C stdio buffer (RCCL prints a
+    # version banner there) goes out first
+    import ctypes
+    sys.stdout.flush()
+    try:
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
+    if rank == 0:
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":
