@@ -154,9 +154,14 @@ int trexhip_create(const trexhip_params* p, trexhip_ctx** out) {
     ctx->pix_ch = p->pixel_encoding == TREXHIP_ENC_RGB8 ? 3 : 1;
     fill_cfg(ctx);
     { int cus = 0; if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, p->device) == hipSuccess && cus > 0) ctx->n_cus = cus; }
-    if (const char* e = std::getenv("TREXHIP_ROWS_ORDER")) ctx->tune_rows_order = std::atoi(e);
+    // tuning knobs of the default build only choose between schedules / tilings that give identical results.  The knobs that
+    // stop a kernel half-way or skip work (profiling aids) exist only in a -DTREXHIP_DEV_KNOBS build.
+    if (const char* e = std::getenv("TREXHIP_ROWS_ORDER")) ctx->tune_rows_order = std::atoi(e) & (1 | 1024);
     if (const char* e = std::getenv("TREXHIP_CONV_GEOM")) ctx->tune_conv_geom = std::atoi(e);
+#ifdef TREXHIP_DEV_KNOBS
+    if (const char* e = std::getenv("TREXHIP_ROWS_ORDER")) ctx->tune_rows_order = std::atoi(e);
     if (const char* e = std::getenv("TREXHIP_CCL_STOP")) ctx->tune_ccl_stop = std::atoi(e);
+#endif
     if (const char* e = std::getenv("TREXHIP_SEG_GROUPS")) ctx->tune_seg_groups = std::atoi(e);
     if (const char* e = std::getenv("TREXHIP_ROWS_BLOCKS")) { ctx->tune_rows_blocks = std::atoi(e) > 0 ? std::atoi(e) : 8192; ctx->tune_rows_blocks_set = true; }
     const size_t B = p->max_batch, H = p->height, W = p->width, R = p->max_runs, NB = p->max_blobs, P = p->max_pixels;

@@ -762,6 +762,261 @@ __global__ __launch_bounds__(WAVES * 64) void k_conv5_stream(const float* __rest
     if (__any(ovf) && lane == 0) atomicOr(overflow, 1u);
 }
 
+// B^T of F(4,5), points (0, 1, -1, 2, -2, 1/2, -1/2, inf): 8 consecutive inputs -> 8 positions
+__device__ __forceinline__ void wino_bt(const float d0, const float d1, const float d2, const float d3, const float d4, const float d5,
+                                        const float d6, const float d7, float* __restrict__ u) {
+    u[0] = fmaf(5.25f, d2 - d4, d6 - d0);
+    u[7] = fmaf(5.25f, d3 - d5, d7 - d1);
+    const float e1 = fmaf(-4.25f, d4, d2 + d6), o1 = fmaf(-4.25f, d3, d1 + d5);
+    u[1] = e1 + o1; u[2] = e1 - o1;
+    const float e2 = fmaf(-1.25f, d4, fmaf(0.25f, d2, d6)), o2 = fmaf(2.f, d5, fmaf(-2.5f, d3, 0.5f * d1));
+    u[3] = e2 + o2; u[4] = e2 - o2;
+    const float e3 = fmaf(-5.f, d4, fmaf(4.f, d2, d6)), o3 = fmaf(0.5f, d5, fmaf(-2.5f, d3, 2.f * d1));
+    u[5] = e3 + o3; u[6] = e3 - o3;
+}
+// A^T of F(4,5): 8 position sums -> 4 outputs
+__device__ __forceinline__ void wino_at(const float m0, const float m1, const float m2, const float m3, const float m4, const float m5,
+                                        const float m6, const float m7, float* __restrict__ y) {
+    const float e1 = m1 + m2, o1 = m1 - m2, e2 = m3 + m4, o2 = m3 - m4, e3 = m5 + m6, o3 = m5 - m6;
+    y[0] = (m0 + e1) + (e2 + e3);
+    y[1] = fmaf(0.5f, o3, fmaf(2.f, o2, o1));
+    y[2] = fmaf(0.25f, e3, fmaf(4.f, e2, e1));
+    y[3] = fmaf(0.125f, o3, fmaf(8.f, o2, o1)) + m7;
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_conv5_wino: conv 5x5 'same' as a one-dimensional Winograd convolution F(4,5) along x (Cook-Toom, points 0, +-1, +-2, +-1/2, inf),
+// direct along y: per kernel row ky, 8 products give 4 neighbouring outputs instead of 20 -> 40 position GEMMs over "tiles"
+// (4 outputs in a row) replace 25 tap GEMMs over pixels = 0.4x the matrix work of the direct form.  An exact reformulation
+// (visual_identification_network_torch.py:184-258 computes the same sums); measured error ladder in DESIGN.md.
+//   * input transform U = B^T d (8 inputs -> 8 positions, fp32 VALU) while a row is staged; each U is then split into two fp16
+//     pieces like the direct kernel, three piece products per product on v_mfma_f32_32x32x16_f16, fp32 accumulate;
+//   * weights are transformed on the host (G w, in double), scaled by a power of two, pre-split, stored as the MFMA B operand
+//     [chunk][ky][position][piece][k-octet][co] x 16 B and streamed L2 -> VGPR two taps ahead;
+//   * M = 32 tiles.  Tiles are numbered through the whole batch, row-pair-major ((crop, y/2), tx, y&1), so every M-tile is full
+//     whatever S is (conv3: 100 tiles per crop = 3.125 M-tiles) and the 2x2 max-pool is a max over two accumulator registers of
+//     one lane (rows y, y+1) and two of the four outputs of a tile; a pass = WM*TPW M-tiles, its real input rows (+2 halo
+//     above / below, clipped at the crop: out-of-crop rows read a zero row) are contiguous in the batch's row numbering;
+//   * 8 position accumulators per M-tile: TPW M-tiles per wave = TPW*128 accumulator registers, one wave per SIMD;
+//   * output transform Y = A^T M, bias, ReLU, pool in the epilogue.
+// LDS: [buffer][piece][row slot][tx][position][16 ci] fp16, slot 0 = zeros; double-buffered over the 16-channel chunks
+// (the next chunk / next pass is transformed and stored in slices between the taps of the current one).
+// ------------------------------------------------------------------------------------------------
+template <int CI, int CO, int S, int TPW>
+struct WinoGeom {
+    static constexpr int CIC = 16, NCH = CI / CIC;
+    static constexpr int TPR = S / 4, TPP = 2 * TPR, TPC = S * TPR;     // tiles per row / row pair / crop
+    static constexpr int NT = CO / 32, WM = NT >= 4 ? 1 : 4 / NT, WAVES = NT * WM, NTHR = WAVES * 64;
+    static constexpr int MB = WM * TPW * 32;                            // tiles per pass
+    static constexpr int MAXPAIRS = (MB + TPP - 2) / TPP + 1;
+    static constexpr int NR = 2 * MAXPAIRS + 4;                         // real input rows a pass can need
+    static constexpr int TS = 8 * 32 + 16;                              // bytes per tile and piece: 8 positions x 16 halves + 16 pad
+    static constexpr int RP0 = TPR * TS;
+    static constexpr int RP = RP0 + (((8 - (RP0 / 16) % 16) + 16) % 16) * 16;   // row pitch == 8 (mod 16) 16-byte slots
+    static constexpr int PLANE = (NR + 1) * RP;                         // one piece; slot 0 = the zero row
+    static constexpr int BUF = 2 * PLANE;
+    static constexpr int LDS_BYTES = 2 * BUF;
+    static constexpr int BV = 2 * 2 * CO;                               // uint4 per (ky, position): pieces x k-octets x co
+    static constexpr int IPR = TPR * 8;                                 // staging items per row: tile x channel pair
+    static constexpr int NQ = NR * IPR;
+    static constexpr int NITEMS = (NQ + NTHR - 1) / NTHR;
+    static_assert(S % 4 == 0 && CO % 32 == 0 && CI % 16 == 0, "geometry");
+    static_assert(NITEMS * 8 <= 40, "staging slices do not fit between the 40 taps");
+    static_assert(LDS_BYTES <= 160 * 1024, "LDS");
+};
+
+// rows qmin .. qmin+nrows-1 (batch row numbering q = crop*S + y) that the tiles [T0, T0+MB) of a pass read
+template <class G, int S>
+__device__ __forceinline__ void wino_pass_rows(const int pass, const int total_tiles, int& qmin, int& nrows) {
+    const int T0 = pass * G::MB;
+    int TL = T0 + G::MB - 1;
+    if (TL > total_tiles - 1) TL = total_tiles - 1;
+    const int gp0 = T0 / G::TPP, gpl = TL / G::TPP;                     // first / last row pair (batch numbering)
+    const int y0 = (2 * gp0) % S, yl = (2 * gpl) % S + 1;
+    qmin = 2 * gp0 - (y0 >= 2 ? 2 : 0);
+    const int qmax = 2 * gpl + 1 + (yl + 2 <= S - 1 ? 2 : 0);
+    nrows = qmax - qmin + 1;
+}
+
+__device__ __forceinline__ uint32_t pack_h2(const _Float16 a, const _Float16 b) {
+    return (uint32_t)__builtin_bit_cast(uint16_t, a) | ((uint32_t)__builtin_bit_cast(uint16_t, b) << 16);
+}
+
+template <int CI, int CO, int S, int TPW>
+__global__ __launch_bounds__((WinoGeom<CI, CO, S, TPW>::NTHR)) void k_conv5_wino(const float* __restrict__ in /*[N][S][S][CI]*/,
+                                                                               const uint4* __restrict__ wp /*[CI/16][5][8][2][2][CO] x 16 B*/,
+                                                                               const float* __restrict__ bias, float* __restrict__ out,
+                                                                               const float out_scale, uint32_t* __restrict__ overflow,
+                                                                               const int n_crops, uint32_t* __restrict__ pass_ctr) {
+    using G = WinoGeom<CI, CO, S, TPW>;
+    extern __shared__ __attribute__((aligned(16))) uint8_t ldsb[];
+    __shared__ int s_next_pass;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int j = lane & 31, h = lane >> 5;
+    const int n = wave % G::NT, mg = wave / G::NT;
+    const int total_tiles = n_crops * G::TPC;
+    const int n_pass = (total_tiles + G::MB - 1) / G::MB;
+    int pass = blockIdx.x;
+    if (pass >= n_pass) return;
+    bool ovf = false;
+
+    // the zero row (slot 0) of both pieces of both buffers
+    for (int i = tid; i < 4 * (G::RP / 16); i += G::NTHR) {
+        const int pl = i / (G::RP / 16), o = i - pl * (G::RP / 16);
+        *reinterpret_cast<uint4*>(ldsb + pl * G::PLANE + o * 16) = make_uint4(0, 0, 0, 0);
+    }
+
+    // one staged item = one tile (8 input pixels) x 2 input channels of one row: 8 x 8-byte loads -> 8 positions -> 2 pieces
+#define WSTG_LOAD(d_, item_, cc_, qmin_, nrows_)                                                                                \
+    do {                                                                                                                        \
+        const int idx_ = tid + (item_) * G::NTHR;                                                                               \
+        const int s_ = idx_ / G::IPR, r_ = idx_ - s_ * G::IPR;                                                                  \
+        const int tx_ = r_ >> 3, cp_ = r_ & 7;                                                                                  \
+        const float* src_ = in + ((size_t)((qmin_) + s_) * S) * CI + (cc_) * 16 + cp_ * 2;                                      \
+        _Pragma("unroll") for (int k_ = 0; k_ < 8; ++k_) {                                                                      \
+            const int ix_ = 4 * tx_ - 2 + k_;                                                                                   \
+            d_[k_] = make_float2(0.f, 0.f);                                                                                     \
+            if (s_ < (nrows_) && ix_ >= 0 && ix_ < S) d_[k_] = *reinterpret_cast<const float2*>(src_ + (size_t)ix_ * CI);      \
+        }                                                                                                                       \
+    } while (0)
+#define WSTG_STORE(d_, item_, base_, nrows_)                                                                                    \
+    do {                                                                                                                        \
+        const int idx_ = tid + (item_) * G::NTHR;                                                                               \
+        const int s_ = idx_ / G::IPR, r_ = idx_ - s_ * G::IPR;                                                                  \
+        const int tx_ = r_ >> 3, cp_ = r_ & 7;                                                                                  \
+        if (s_ < (nrows_)) {                                                                                                    \
+            float ux_[8], uy_[8];                                                                                               \
+            wino_bt(d_[0].x, d_[1].x, d_[2].x, d_[3].x, d_[4].x, d_[5].x, d_[6].x, d_[7].x, ux_);                               \
+            wino_bt(d_[0].y, d_[1].y, d_[2].y, d_[3].y, d_[4].y, d_[5].y, d_[6].y, d_[7].y, uy_);                               \
+            uint8_t* dst_ = (base_) + (s_ + 1) * G::RP + tx_ * G::TS + cp_ * 4;                                                 \
+            _Pragma("unroll") for (int p_ = 0; p_ < 8; ++p_) {                                                                  \
+                uint32_t a1_, a2_, b1_, b2_;                                                                                    \
+                split2h(ux_[p_], a1_, a2_, ovf); split2h(uy_[p_], b1_, b2_, ovf);                                               \
+                *reinterpret_cast<uint32_t*>(dst_ + p_ * 32) = a1_ | (b1_ << 16);                                               \
+                *reinterpret_cast<uint32_t*>(dst_ + p_ * 32 + G::PLANE) = a2_ | (b2_ << 16);                                    \
+            }                                                                                                                   \
+        }                                                                                                                       \
+    } while (0)
+
+    const uint4* wl = wp + (h * CO + n * 32 + j);
+    const int co = n * 32 + j;
+    const float bz = bias[co];
+    int qmin, nrows;
+    wino_pass_rows<G, S>(pass, total_tiles, qmin, nrows);
+    {   // first pass: its first chunk
+        for (int it = 0; it < G::NITEMS; ++it) {
+            float2 d[8];
+            WSTG_LOAD(d, it, 0, qmin, nrows);
+            WSTG_STORE(d, it, ldsb, nrows);
+        }
+    }
+    __syncthreads();
+    uint4 bq[4][2];                                     // ring of 4: 40 taps per chunk keep the phase
+    bq[0][0] = wl[0]; bq[0][1] = wl[2 * CO];
+    bq[1][0] = wl[G::BV]; bq[1][1] = wl[G::BV + 2 * CO];
+    int bufsel = 0;
+    for (;;) {
+        // A-operand byte offsets of this lane's TPW tiles, one per kernel row (out-of-crop rows -> the zero row)
+        int aoff[TPW][5];
+        const int T0 = pass * G::MB + mg * TPW * 32;
+#pragma unroll
+        for (int m = 0; m < TPW; ++m) {
+            int T = T0 + m * 32 + j;
+            if (T > total_tiles - 1) T = total_tiles - 1;
+            const int gp = T / G::TPP, r2 = T - gp * G::TPP;
+            const int tx = r2 >> 1, qo = 2 * gp + (r2 & 1), y = qo % S;
+#pragma unroll
+            for (int ky = 0; ky < 5; ++ky) {
+                const int iy = y + ky - 2;
+                aoff[m][ky] = ((iy >= 0 && iy < S) ? (qo + ky - 2 - qmin + 1) * G::RP : 0) + tx * G::TS + h * 16;
+            }
+        }
+        f32x16 acc[TPW][8];
+#pragma unroll
+        for (int m = 0; m < TPW; ++m)
+#pragma unroll
+            for (int p = 0; p < 8; ++p)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[m][p][r] = 0.f;
+
+        int next_pass = pass + (int)gridDim.x;
+        if (tid == 0) s_next_pass = (int)atomicAdd(pass_ctr, 1u) + (int)gridDim.x;   // read by everyone after the first chunk's barrier
+        bool have_next = false;
+        int qmin_n = 0, nrows_n = 0;
+        for (int cc = 0; cc < G::NCH; ++cc) {
+            const bool last_c = cc == G::NCH - 1;
+            if (last_c) {
+                if (G::NCH == 1) __syncthreads();
+                next_pass = s_next_pass;
+                have_next = next_pass < n_pass;
+                if (have_next) wino_pass_rows<G, S>(next_pass, total_tiles, qmin_n, nrows_n);
+            }
+            const uint8_t* pbase = ldsb + bufsel * G::BUF;
+            uint8_t* nbase = ldsb + (bufsel ^ 1) * G::BUF;
+            const bool more_w = !last_c || have_next;                    // a following chunk exists: its weights and its patch
+            const int scc = last_c ? 0 : cc + 1;
+            const int sqmin = last_c ? qmin_n : qmin, snrows = more_w ? (last_c ? nrows_n : nrows) : 0;
+            const uint4* wc = wl + (size_t)cc * 40 * G::BV;
+            const uint4* wn = wl + (size_t)scc * 40 * G::BV;
+            float2 sd[8];
+#pragma clang loop unroll(full)
+            for (int t = 0; t < 40; ++t) {
+                if (t + 2 < 40) {
+                    bq[(t + 2) % 4][0] = wc[(size_t)(t + 2) * G::BV];
+                    bq[(t + 2) % 4][1] = wc[(size_t)(t + 2) * G::BV + 2 * CO];
+                } else if (more_w) {
+                    bq[(t + 2) % 4][0] = wn[(size_t)(t + 2 - 40) * G::BV];
+                    bq[(t + 2) % 4][1] = wn[(size_t)(t + 2 - 40) * G::BV + 2 * CO];
+                }
+                if (t % 8 == 0 && t / 8 < G::NITEMS) WSTG_LOAD(sd, t / 8, scc, sqmin, snrows);
+                if (t % 8 == 5 && t / 8 < G::NITEMS) WSTG_STORE(sd, t / 8, nbase, snrows);
+                const int ky = t / 8, p = t % 8;
+                const uint8_t* asrc = pbase + p * 32;
+                const f16x8 b1 = __builtin_bit_cast(f16x8, bq[t % 4][0]);
+                const f16x8 b2 = __builtin_bit_cast(f16x8, bq[t % 4][1]);
+#pragma unroll
+                for (int m = 0; m < TPW; ++m) {
+                    const f16x8 p1 = __builtin_bit_cast(f16x8, *reinterpret_cast<const uint4*>(asrc + aoff[m][ky]));
+                    const f16x8 p2 = __builtin_bit_cast(f16x8, *reinterpret_cast<const uint4*>(asrc + aoff[m][ky] + G::PLANE));
+                    acc[m][p] = mfma16(p2, b1, acc[m][p]);
+                    acc[m][p] = mfma16(p1, b2, acc[m][p]);
+                    acc[m][p] = mfma16(p1, b1, acc[m][p]);
+                }
+                __builtin_amdgcn_sched_barrier(0);                  // keep the taps apart: hoisting loads across them costs registers
+            }
+            __syncthreads();
+            bufsel ^= 1;
+        }
+        // epilogue: Y = A^T M per tile, max over the 2x2 pool window (rows y, y+1 = registers r, r+1; outputs 0,1 / 2,3), bias, ReLU
+#pragma unroll
+        for (int m = 0; m < TPW; ++m) {
+#pragma unroll
+            for (int rr = 0; rr < 8; ++rr) {
+                const int r = 2 * rr;
+                const int i = (r & 3) + 8 * (r >> 2) + 4 * h;
+                const int T = T0 + m * 32 + i;
+                float ya[4], yb[4];
+                wino_at(acc[m][0][r], acc[m][1][r], acc[m][2][r], acc[m][3][r], acc[m][4][r], acc[m][5][r], acc[m][6][r], acc[m][7][r], ya);
+                wino_at(acc[m][0][r + 1], acc[m][1][r + 1], acc[m][2][r + 1], acc[m][3][r + 1], acc[m][4][r + 1], acc[m][5][r + 1], acc[m][6][r + 1], acc[m][7][r + 1], yb);
+                const float v0 = fmaxf(fmaxf(ya[0], ya[1]), fmaxf(yb[0], yb[1]));
+                const float v1 = fmaxf(fmaxf(ya[2], ya[3]), fmaxf(yb[2], yb[3]));
+                if (T < total_tiles) {
+                    const int gp = T / G::TPP, tx = (T - gp * G::TPP) >> 1;
+                    float* o = out + ((size_t)gp * (S / 2) + 2 * tx) * CO + co;
+                    o[0] = fmaxf(v0 * out_scale + bz, 0.f);
+                    o[CO] = fmaxf(v1 * out_scale + bz, 0.f);
+                }
+                __builtin_amdgcn_sched_barrier(0);                  // one register pair at a time: reading all 256 accumulators first spills
+            }
+        }
+        if (!have_next) break;
+        pass = next_pass; qmin = qmin_n; nrows = nrows_n;
+    }
+#undef WSTG_LOAD
+#undef WSTG_STORE
+    if (__any(ovf) && lane == 0) atomicOr(overflow, 1u);
+}
+
 static constexpr int FC1_KSPLIT = 10;     // 12800 = 10 x 1280: 500 workgroups at 6400 crops (5: 129 us, 10: 92 us, 20: 102 us + slower head); partial planes summed in k_head
 // ------------------------------------------------------------------------------------------------
 // fc1: out[N][128] = act[N][K] * W[K][128] + b     (K = 12800, 100 real outputs)
@@ -990,6 +1245,8 @@ struct Net {
     uint4 *w2s = nullptr, *w3s = nullptr;      // bf16-split conv weights
     uint4 *w2h = nullptr, *w3h = nullptr;      // fp16-split conv weights (scaled by a power of two)
     float inv2h = 1.f, inv3h = 1.f;
+    uint4 *w2w = nullptr, *w3w = nullptr;      // Winograd F(4,5)-domain conv weights, fp16 pieces (k_conv5_wino)
+    float inv2w = 1.f, inv3w = 1.f;
     uint4* wf1h = nullptr;                     // fc1 weights, fp16 pieces in MFMA B layout [K/8][2][128] x 8 halves
     float invf1h = 1.f;
     uint4* w1h = nullptr;                      // conv1 B fragments (16 fragments x 64 lanes), fp16 pieces of the folded weights
@@ -1011,6 +1268,8 @@ static void free_net(Net* n) {
     if (n->w3s) (void)hipFree(n->w3s);
     if (n->w2h) (void)hipFree(n->w2h);
     if (n->w3h) (void)hipFree(n->w3h);
+    if (n->w2w) (void)hipFree(n->w2w);
+    if (n->w3w) (void)hipFree(n->w3w);
     if (n->w1h) (void)hipFree(n->w1h);
     if (n->wf1h) (void)hipFree(n->wf1h);
     if (n->d_ovf) (void)hipFree(n->d_ovf);
@@ -1092,6 +1351,51 @@ static int upload_split_f16(uint4** dst, float* inv_scale, const std::vector<flo
                     std::memcpy(&pc[0], &h1, 2); std::memcpy(&pc[1], &h2, 2);
                     for (int s = 0; s < 2; ++s)
                         o[(((((size_t)cc * 25 + tap) * 2 + s) * KO + kk / 8) * CO + co) * 8 + (kk & 7)] = pc[s];
+                }
+    TH_CHECK_HIP(hipMalloc(reinterpret_cast<void**>(dst), o.size() * 2));
+    TH_CHECK_HIP(hipMemcpy(*dst, o.data(), o.size() * 2, hipMemcpyHostToDevice));
+    return TREXHIP_OK;
+}
+
+// Winograd-domain weights of k_conv5_wino: Wt[ky][p] = sum_kx G[p][kx] w[ky][kx] (double), scaled by a power of two so that
+// max|Wt| is in [8192, 16384), two fp16 pieces, laid out [cc][ky][p][piece][k-octet][co] x 8 halves
+static int upload_wino_f16(uint4** dst, float* inv_scale, const std::vector<float>& wp /*[cc][25][16][CO]*/, int CI, int CO) {
+    static const double Gm[8][5] = {{-1, 0, 0, 0, 0},
+                                    {-2.0 / 9, -2.0 / 9, -2.0 / 9, -2.0 / 9, -2.0 / 9},
+                                    {-2.0 / 9, 2.0 / 9, -2.0 / 9, 2.0 / 9, -2.0 / 9},
+                                    {1.0 / 90, 1.0 / 45, 2.0 / 45, 4.0 / 45, 8.0 / 45},
+                                    {1.0 / 90, -1.0 / 45, 2.0 / 45, -4.0 / 45, 8.0 / 45},
+                                    {32.0 / 45, 16.0 / 45, 8.0 / 45, 4.0 / 45, 2.0 / 45},
+                                    {32.0 / 45, -16.0 / 45, 8.0 / 45, -4.0 / 45, 2.0 / 45},
+                                    {0, 0, 0, 0, 1}};
+    const int ncc = CI / 16;
+    std::vector<double> wt((size_t)ncc * 40 * 16 * CO);
+    double mx = 0.0;
+    for (int cc = 0; cc < ncc; ++cc)
+        for (int ky = 0; ky < 5; ++ky)
+            for (int p = 0; p < 8; ++p)
+                for (int kk = 0; kk < 16; ++kk)
+                    for (int co = 0; co < CO; ++co) {
+                        double a = 0.0;
+                        for (int kx = 0; kx < 5; ++kx) a += Gm[p][kx] * (double)wp[(((size_t)cc * 25 + ky * 5 + kx) * 16 + kk) * CO + co];
+                        wt[(((size_t)cc * 40 + ky * 8 + p) * 16 + kk) * CO + co] = a;
+                        mx = std::fmax(mx, std::fabs(a));
+                    }
+    int k = 0;
+    if (mx > 0.0) { k = (int)std::floor(std::log2(16384.0 / mx)); if (k > 24) k = 24; if (k < -24) k = -24; }
+    *inv_scale = std::ldexp(1.0f, -k);
+    std::vector<uint16_t> o((size_t)ncc * 40 * 2 * 2 * CO * 8);
+    for (int cc = 0; cc < ncc; ++cc)
+        for (int t = 0; t < 40; ++t)
+            for (int kk = 0; kk < 16; ++kk)
+                for (int co = 0; co < CO; ++co) {
+                    const float x = (float)std::ldexp(wt[(((size_t)cc * 40 + t) * 16 + kk) * CO + co], k);
+                    const _Float16 h1 = (_Float16)x;
+                    const _Float16 h2 = (_Float16)(x - (float)h1);
+                    uint16_t pc[2];
+                    std::memcpy(&pc[0], &h1, 2); std::memcpy(&pc[1], &h2, 2);
+                    for (int sidx = 0; sidx < 2; ++sidx)
+                        o[(((((size_t)cc * 40 + t) * 2 + sidx) * 2 + kk / 8) * CO + co) * 8 + (kk & 7)] = pc[sidx];
                 }
     TH_CHECK_HIP(hipMalloc(reinterpret_cast<void**>(dst), o.size() * 2));
     TH_CHECK_HIP(hipMemcpy(*dst, o.data(), o.size() * 2, hipMemcpyHostToDevice));
@@ -1198,9 +1502,11 @@ int net_load(trexhip_ctx* ctx, const void* blob, size_t bytes) {
     TRY(upload(&net->w2, wp)); TRY(upload(&net->b2, bias));
     TRY(upload_split(&net->w2s, wp, 16, 64));
     TRY(upload_split_f16(&net->w2h, &net->inv2h, wp, 16, 64));
+    TRY(upload_wino_f16(&net->w2w, &net->inv2w, wp, 16, 64));
     fold_conv(c3w, c3b, g3, be3, m3, v3, 128, 64, 16, wp, bias);       // 16-channel chunks for the bf16 path
     TRY(upload_split(&net->w3s, wp, 64, 128));
     TRY(upload_split_f16(&net->w3h, &net->inv3h, wp, 64, 128));
+    TRY(upload_wino_f16(&net->w3w, &net->inv3w, wp, 64, 128));
     if (rc == TREXHIP_OK && hipMalloc(reinterpret_cast<void**>(&net->d_ovf), 8) != hipSuccess) rc = TREXHIP_E_DEVICE;
     fold_conv(c3w, c3b, g3, be3, m3, v3, 128, 64, 32, wp, bias);
     TRY(upload(&net->w3, wp)); TRY(upload(&net->b3, bias));
@@ -1293,6 +1599,8 @@ int net_forward(trexhip_ctx* ctx, const uint8_t* d_crops, int n, float* d_probs,
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (ConvGeomS<16, 64, 40, 8, 4>::LDS_BYTES)));
         TH_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv5_stream<64, 128, 20, 20, 8, true>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (ConvGeomS<64, 128, 20, 20, 8>::LDS_BYTES)));
+        TH_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv5_wino<64, 128, 20, 2>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (WinoGeom<64, 128, 20, 2>::LDS_BYTES)));
 #undef SET_ATTR
 #undef SET_ATTRC
         ctx->attr_cnn = true;
@@ -1331,6 +1639,13 @@ int net_forward(trexhip_ctx* ctx, const uint8_t* d_crops, int n, float* d_probs,
         hipLaunchKernelGGL((k_conv5<64, 128, 20, 20, 32>), dim3(n * G3::BPC), dim3(512), G3::LDS_BYTES, s, net->act2, net->w3, net->b3, net->act3);
     else if (mode == TREXHIP_CNN_BF16X6) LAUNCH_SPLIT(64, 128, 20, 20, 0, 6, net->act2, net->w3s, net->b3, net->act3, 1.0f, (const uint32_t*)nullptr);
     else if (mode == TREXHIP_CNN_BF16X3) LAUNCH_SPLIT(64, 128, 20, 20, 0, 3, net->act2, net->w3s, net->b3, net->act3, 1.0f, (const uint32_t*)nullptr);
+    else if (!(ctx->tune_conv_geom & 256)) {
+        // Winograd F(4,5) along x: 0.4x the matrix work of the direct form (TREXHIP_CONV_GEOM bit 8: the direct kernels below)
+        using GW = WinoGeom<64, 128, 20, 2>;
+        const int n_pass = (n * GW::TPC + GW::MB - 1) / GW::MB;
+        hipLaunchKernelGGL((k_conv5_wino<64, 128, 20, 2>), dim3(n_pass < ctx->n_cus ? n_pass : ctx->n_cus), dim3(GW::NTHR), GW::LDS_BYTES, s,
+                           net->act2, net->w3w, net->b3, net->act3, net->inv3w, net->d_ovf, n, net->d_ovf + 1);
+    }
     else if (!(ctx->tune_conv_geom & 8))
         // one workgroup per CU (110 KB LDS, 256 VGPRs): persistent workgroups walk the crops and stage the next crop's first
         // chunk under the current crop's last one (TREXHIP_CONV_GEOM bit 7: one workgroup per crop instead)

@@ -24,6 +24,11 @@ static constexpr int P_ROWS = 1022;    // rows per blob
 // blobs fit into a CU's LDS -- the kernel is a chain of LDS / memory latencies and lives on the number of blobs in flight)
 __host__ __device__ constexpr int posture_wave_lds(int np, int nr, int nrows) { return np * 8 * 2 + np * 4 * 2 + nr * 4 + (nrows + 2) * 4; }
 
+#ifdef TREXHIP_DEV_KNOBS
+#define POSTURE_STOP(n) do { if (P.stop == (n)) return; } while (0)
+#else
+#define POSTURE_STOP(n) do { } while (0)
+#endif
 struct PostureCfg {
     float outline_resample; int smooth_samples, smooth_step, approximate;
     float curvature_range_ratio, midline_walk_offset; int max_points;
@@ -214,7 +219,7 @@ __global__ __launch_bounds__(256) void k_posture(const PostureCfg P, const trexh
         } while (!(vx == sx && vy == sy && dx == 1 && dy == 0));
         res.n_traced = status ? 0 : nt;                 // an outline beyond the capacity reports no points at all
     }
-    if (P.stop == 1) return;
+    POSTURE_STOP(1);
     int nt_all = traced ? res.n_traced : __shfl(res.n_traced, 0);
     if (!traced) status = __shfl(status, 0);
     res.n_traced = nt_all;
@@ -265,7 +270,7 @@ __global__ __launch_bounds__(256) void k_posture(const PostureCfg P, const trexh
     __builtin_amdgcn_wave_barrier();
     if (status) { if (lane == 0) { res.status = status; out_info[bi] = res; } return; }
 
-    if (P.stop == 2) return;
+    POSTURE_STOP(2);
     float2* pts = bufB; float2* other = bufA;
     // ---- smooth_outline (Outline.cpp:330-378): triangular weights over +-range*step ----
     if (P.smooth_samples > 0 && n > P.smooth_samples) {
@@ -355,7 +360,7 @@ __global__ __launch_bounds__(256) void k_posture(const PostureCfg P, const trexh
         __builtin_amdgcn_wave_barrier();
         float2* t = pts; pts = other; other = t;
     }
-    if (P.stop == 3) return;
+    POSTURE_STOP(3);
     // ---- curvature, tail = highest peak, head = farthest peak ----
     int r = (int)(P.curvature_range_ratio * (float)n); if (r < 1) r = 1;
     for (int i = lane; i < n; i += 64) {
@@ -406,7 +411,7 @@ __global__ __launch_bounds__(256) void k_posture(const PostureCfg P, const trexh
     res.n_outline = n; res.tail_index = 0;
     res.head_index = head == 0x7fffffff ? -1 : ((head - tail) % n + n) % n;
     if (n <= 1) { if (lane == 0) { res.status = 1; out_info[bi] = res; } return; }
-    if (P.stop == 4) return;
+    POSTURE_STOP(4);
     // ---- the two-pointer walk (Outline.cpp:790-857): control flow is wave-uniform, the max_offset candidates of each
     // search are evaluated one per lane and reduced to the FIRST minimum (the sequential `len < min_d` rule).  The kernel is bound
     // by instruction issue, so the loop only keeps what the next iteration depends on: the pair of outline indices of every
@@ -588,7 +593,9 @@ extern "C" int trexhip_posture_device(trexhip_ctx* ctx, int32_t table, const tre
     }
     PostureCfg P{pp->outline_resample, pp->outline_smooth_samples, pp->outline_smooth_step, pp->outline_approximate,
                  pp->outline_curvature_range_ratio, pp->midline_walk_offset, pp->max_points, nr_cap, rows_cap, 0};
+#ifdef TREXHIP_DEV_KNOBS
     if (const char* e = std::getenv("TREXHIP_POSTURE_STOP")) P.stop = std::atoi(e);
+#endif
     stage_begin(ctx, TREXHIP_STAGE_POSTURE);
     hipLaunchKernelGGL(k_posture, dim3((n_blobs + wpb - 1) / wpb), dim3(wpb * 64), lds_bytes, ctx->stream, P, info, bf, bl, ru, n_blobs, ctx->last_n,
                        reinterpret_cast<float2*>(d_outline), reinterpret_cast<float4*>(d_segments), d_info);

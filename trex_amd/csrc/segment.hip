@@ -211,13 +211,19 @@ __global__ __launch_bounds__(256) void k_rows(const uint8_t* __restrict__ frames
                         mm &= nz;
                     }
                 } else
+#ifdef TREXHIP_DEV_KNOBS
                 mm = (order & 512) ? ((a[ch].x ^ b[ch].x) == 0x12345u) : mask16(a[ch], b[ch], c);
+#else
+                mm = mask16(a[ch], b[ch], c);
+#endif
                 if (!ALIGNED && x + 16 > W) mm &= (1u << (W - x)) - 1u;
             }
             m[ch] = mm;
             any |= mm != 0;
         }
+#ifdef TREXHIP_DEV_KNOBS
         if (order & 256) any = false;
+#endif
         // registers a/b are free again: prefetch the next row while this one is finished
         if (task + nwave < ntask) issue(cur_lo, cur_hi);
 
@@ -723,7 +729,13 @@ __global__ __launch_bounds__(1024) void k_ccl_lds(const SegCfg c, const uint32_t
                                                   trexhip_blob* __restrict__ blobs, uint32_t* __restrict__ blob_frame,
                                                   trexhip_run* __restrict__ out_runs, const int dbg_stop,
                                                   unsigned long long* __restrict__ dbg, const int f0) {
+#ifdef TREXHIP_DEV_KNOBS
 #define CCL_STAMP(i) do { if (dbg_stop == -1 && blockIdx.x == 0 && threadIdx.x == 0) dbg[i] = __builtin_readcyclecounter(); } while (0)
+#define CCL_STOP(n) do { if (dbg_stop == (n)) return; } while (0)
+#else
+#define CCL_STAMP(i) do { } while (0)
+#define CCL_STOP(n) do { } while (0)
+#endif
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     uint32_t* s_run = smem;                       // x0 | x1 << 16, raster order
     uint32_t* s_par = s_run + CCL_NMAX;           // union-find parent -> label
@@ -765,7 +777,7 @@ __global__ __launch_bounds__(1024) void k_ccl_lds(const SegCfg c, const uint32_t
     }
     if (tid == 0) { rb[H] = n; if (rb_lds) s_key[H] = n; }
     __syncthreads();
-    if (dbg_stop == 1) return;
+    CCL_STOP(1);
     CCL_STAMP(1);
     // P2: runs into LDS in raster order
     const uint32_t* tmp = tmp_runs + (size_t)f * c.T;
@@ -777,7 +789,7 @@ __global__ __launch_bounds__(1024) void k_ccl_lds(const SegCfg c, const uint32_t
         for (uint32_t i = 0; i < k; ++i) { s_run[b + i] = tmp[o + i]; s_y[b + i] = (uint16_t)y; s_par[b + i] = b + i; }
     }
     __syncthreads();
-    if (dbg_stop == 2) return;
+    CCL_STOP(2);
     CCL_STAMP(2);
     // P3: link every run with the touching runs of the row above (thread per run, binary search for the first candidate)
     const int slack = c.slack;
@@ -798,14 +810,14 @@ __global__ __launch_bounds__(1024) void k_ccl_lds(const SegCfg c, const uint32_t
         }
     }
     __syncthreads();
-    if (dbg_stop == 3) return;
+    CCL_STOP(3);
     CCL_STAMP(3);
     // P4: flatten
     for (uint32_t r = tid; r < n; r += 1024) { const uint32_t root = lds_find(s_par, r); s_key[r] = root; }
     __syncthreads();
     for (uint32_t r = tid; r < n; r += 1024) s_par[r] = s_key[r];
     __syncthreads();
-    if (dbg_stop == 4) return;
+    CCL_STOP(4);
     CCL_STAMP(4);
     // P5: blob ordinals (raster order of the root run), runs / pixels per blob
     uint32_t nraw = 0;
@@ -826,7 +838,7 @@ __global__ __launch_bounds__(1024) void k_ccl_lds(const SegCfg c, const uint32_t
         atomicAdd(s_cp + o, (q >> 16) - (q & 0xffffu) + 1u);
     }
     __syncthreads();
-    if (dbg_stop == 5) return;
+    CCL_STOP(5);
     CCL_STAMP(5);
     // P6: size filter, offsets of the kept blobs
     uint32_t kept = 0, kruns = 0, kpx = 0;
@@ -866,7 +878,7 @@ __global__ __launch_bounds__(1024) void k_ccl_lds(const SegCfg c, const uint32_t
         if (tid == 0) { fi.flags |= TREXHIP_FRAME_OVERFLOW_OUTPUT; info[f] = fi; }
         return;
     }
-    if (dbg_stop == 6) return;
+    CCL_STOP(6);
     CCL_STAMP(6);
     // P7: blob records, run-level state for later passes, stable grouping by one sort
     for (uint32_t o = tid; o < nraw; o += 1024) {
@@ -888,7 +900,7 @@ __global__ __launch_bounds__(1024) void k_ccl_lds(const SegCfg c, const uint32_t
         parent[fo + r] = lab;
         if (lab == r) root_ord[fo + r] = s_ord[r];
     }
-    if (dbg_stop == 7) return;
+    CCL_STOP(7);
     CCL_STAMP(7);
     // largest kept blob decides the grouping strategy (block-uniform)
     uint32_t mx = 0;
@@ -1014,6 +1026,7 @@ __global__ __launch_bounds__(1024) void k_ccl_lds(const SegCfg c, const uint32_t
         info[f] = fi;
     }
 #undef CCL_STAMP
+#undef CCL_STOP
 }
 
 // ---------------------------------------------------------------------------------------------
