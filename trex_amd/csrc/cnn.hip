@@ -842,6 +842,17 @@ __device__ __forceinline__ uint32_t pack_h2(const _Float16 a, const _Float16 b) 
     return (uint32_t)__builtin_bit_cast(uint16_t, a) | ((uint32_t)__builtin_bit_cast(uint16_t, b) << 16);
 }
 
+// one fp32 value -> two fp16 pieces, round-toward-zero packing of two values at a time (v_cvt_pkrtz_f16_f32): the first piece may be
+// any fp16 near x (the residual x - h1 is exact in fp32), the second loses at most one unit of the 22nd bit
+typedef __fp16 h2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void split2h_pair(const float a, const float b, uint32_t& p1, uint32_t& p2) {
+    const h2_t h1 = __builtin_amdgcn_cvt_pkrtz(a, b);
+    const float ra = fmaf((float)h1[0], -1.0f, a), rb = fmaf((float)h1[1], -1.0f, b);
+    const h2_t h2 = __builtin_amdgcn_cvt_pkrtz(ra, rb);
+    p1 = __builtin_bit_cast(uint32_t, h1);
+    p2 = __builtin_bit_cast(uint32_t, h2);
+}
+
 template <int CI, int CO, int S, int TPW>
 __global__ __launch_bounds__((WinoGeom<CI, CO, S, TPW>::NTHR)) void k_conv5_wino(const float* __restrict__ in /*[N][S][S][CI]*/,
                                                                                const uint4* __restrict__ wp /*[CI/16][5][8][2][2][CO] x 16 B*/,
@@ -849,6 +860,7 @@ __global__ __launch_bounds__((WinoGeom<CI, CO, S, TPW>::NTHR)) void k_conv5_wino
                                                                                const float out_scale, uint32_t* __restrict__ overflow,
                                                                                const int n_crops, uint32_t* __restrict__ pass_ctr) {
     using G = WinoGeom<CI, CO, S, TPW>;
+    static_assert(TPW == 2, "the tap body interleaves two M-tiles");
     extern __shared__ __attribute__((aligned(16))) uint8_t ldsb[];
     __shared__ int s_next_pass;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -858,7 +870,7 @@ __global__ __launch_bounds__((WinoGeom<CI, CO, S, TPW>::NTHR)) void k_conv5_wino
     const int n_pass = (total_tiles + G::MB - 1) / G::MB;
     int pass = blockIdx.x;
     if (pass >= n_pass) return;
-    bool ovf = false;
+    float mxabs = 0.f;                                   // largest |input| staged by this lane (fp16 range guard, see the end)
 
     // the zero row (slot 0) of both pieces of both buffers
     for (int i = tid; i < 4 * (G::RP / 16); i += G::NTHR) {
@@ -866,57 +878,77 @@ __global__ __launch_bounds__((WinoGeom<CI, CO, S, TPW>::NTHR)) void k_conv5_wino
         *reinterpret_cast<uint4*>(ldsb + pl * G::PLANE + o * 16) = make_uint4(0, 0, 0, 0);
     }
 
-    // one staged item = one tile (8 input pixels) x 2 input channels of one row: 8 x 8-byte loads -> 8 positions -> 2 pieces
-#define WSTG_LOAD(d_, item_, cc_, qmin_, nrows_)                                                                                \
+    // Staging, branch-free so that it can sit between the MFMAs of the taps: one item = one tile (8 input pixels) x 4 input channels
+    // of one row.  Rows past the pass's last row repeat that row (same bytes to the same place), columns outside the crop are
+    // loaded from the clamped column and zeroed.  Steps of an item: L (8 x 16-byte loads), T (B^T of one channel), S (split two
+    // positions of two channels into fp16 pieces, one 4-byte store per piece and position).
+    float4 sd[8];
+    float su[2][8];
+    int sdst = 0, sflag = 0;
+#define WS_L(item_, cc_, qmin_, nrows_)                                                                                         \
     do {                                                                                                                        \
         const int idx_ = tid + (item_) * G::NTHR;                                                                               \
-        const int s_ = idx_ / G::IPR, r_ = idx_ - s_ * G::IPR;                                                                  \
-        const int tx_ = r_ >> 3, cp_ = r_ & 7;                                                                                  \
-        const float* src_ = in + ((size_t)((qmin_) + s_) * S) * CI + (cc_) * 16 + cp_ * 2;                                      \
+        int s_ = idx_ / (G::TPR * 4);                                                                                           \
+        const int r_ = idx_ - s_ * (G::TPR * 4);                                                                                \
+        const int tx_ = r_ >> 2, cq_ = r_ & 3;                                                                                  \
+        s_ = s_ < (nrows_) ? s_ : (nrows_) - 1;                                                                                 \
+        const float* src_ = in + ((size_t)((qmin_) + s_) * S) * CI + (cc_) * 16 + cq_ * 4;                                      \
         _Pragma("unroll") for (int k_ = 0; k_ < 8; ++k_) {                                                                      \
-            const int ix_ = 4 * tx_ - 2 + k_;                                                                                   \
-            d_[k_] = make_float2(0.f, 0.f);                                                                                     \
-            if (s_ < (nrows_) && ix_ >= 0 && ix_ < S) d_[k_] = *reinterpret_cast<const float2*>(src_ + (size_t)ix_ * CI);      \
+            int ix_ = 4 * tx_ - 2 + k_;                                                                                         \
+            ix_ = ix_ < 0 ? 0 : (ix_ > S - 1 ? S - 1 : ix_);                                                                    \
+            { const f32x4 v_ = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(src_ + (size_t)ix_ * CI)); sd[k_] = make_float4(v_[0], v_[1], v_[2], v_[3]); }                                                 \
         }                                                                                                                       \
+        sdst = (s_ + 1) * G::RP + tx_ * G::TS + cq_ * 8;                                                                        \
+        sflag = (tx_ == 0 ? 1 : 0) | (tx_ == G::TPR - 1 ? 2 : 0);                                                               \
     } while (0)
-#define WSTG_STORE(d_, item_, base_, nrows_)                                                                                    \
+#define WS_T(which_, comp_)                                                                                                     \
     do {                                                                                                                        \
-        const int idx_ = tid + (item_) * G::NTHR;                                                                               \
-        const int s_ = idx_ / G::IPR, r_ = idx_ - s_ * G::IPR;                                                                  \
-        const int tx_ = r_ >> 3, cp_ = r_ & 7;                                                                                  \
-        if (s_ < (nrows_)) {                                                                                                    \
-            float ux_[8], uy_[8];                                                                                               \
-            wino_bt(d_[0].x, d_[1].x, d_[2].x, d_[3].x, d_[4].x, d_[5].x, d_[6].x, d_[7].x, ux_);                               \
-            wino_bt(d_[0].y, d_[1].y, d_[2].y, d_[3].y, d_[4].y, d_[5].y, d_[6].y, d_[7].y, uy_);                               \
-            uint8_t* dst_ = (base_) + (s_ + 1) * G::RP + tx_ * G::TS + cp_ * 4;                                                 \
-            _Pragma("unroll") for (int p_ = 0; p_ < 8; ++p_) {                                                                  \
-                uint32_t a1_, a2_, b1_, b2_;                                                                                    \
-                split2h(ux_[p_], a1_, a2_, ovf); split2h(uy_[p_], b1_, b2_, ovf);                                               \
-                *reinterpret_cast<uint32_t*>(dst_ + p_ * 32) = a1_ | (b1_ << 16);                                               \
-                *reinterpret_cast<uint32_t*>(dst_ + p_ * 32 + G::PLANE) = a2_ | (b2_ << 16);                                    \
-            }                                                                                                                   \
+        const float d0_ = (sflag & 1) ? 0.f : sd[0].comp_, d1_ = (sflag & 1) ? 0.f : sd[1].comp_;                               \
+        const float d6_ = (sflag & 2) ? 0.f : sd[6].comp_, d7_ = (sflag & 2) ? 0.f : sd[7].comp_;                               \
+        mxabs = fmaxf(fmaxf(mxabs, fabsf(sd[2].comp_)), fmaxf(fabsf(sd[3].comp_), fmaxf(fabsf(sd[4].comp_), fabsf(sd[5].comp_)))); \
+        mxabs = fmaxf(fmaxf(mxabs, fabsf(d0_)), fmaxf(fabsf(d1_), fmaxf(fabsf(d6_), fabsf(d7_))));                              \
+        wino_bt(d0_, d1_, sd[2].comp_, sd[3].comp_, sd[4].comp_, sd[5].comp_, d6_, d7_, su[which_]);                            \
+    } while (0)
+#define WS_S(pp_, half_, base_)                                                                                                 \
+    do {                                                                                                                        \
+        _Pragma("unroll") for (int q_ = 0; q_ < 2; ++q_) {                                                                      \
+            uint32_t a1_, a2_;                                                                                                  \
+            split2h_pair(su[0][2 * (pp_) + q_], su[1][2 * (pp_) + q_], a1_, a2_);                                               \
+            uint8_t* dst_ = (base_) + sdst + (2 * (pp_) + q_) * 32 + (half_) * 4;                                               \
+            *reinterpret_cast<uint32_t*>(dst_) = a1_;                                                                           \
+            *reinterpret_cast<uint32_t*>(dst_ + G::PLANE) = a2_;                                                                \
         }                                                                                                                       \
     } while (0)
+    // the 20 tap slots of one item: load, then (transform x, y, four stores), (transform z, w, four stores)
+#define WS_STEP(st_, item_, cc_, qmin_, nrows_, base_)                                                                          \
+    do {                                                                                                                        \
+        if ((st_) == 0) WS_L(item_, cc_, qmin_, nrows_);                                                                        \
+        if ((st_) == 4) WS_T(0, x);                                                                                             \
+        if ((st_) == 5) WS_T(1, y);                                                                                             \
+        if ((st_) >= 6 && (st_) <= 9) WS_S((st_) - 6, 0, base_);                                                                \
+        if ((st_) == 10) WS_T(0, z);                                                                                            \
+        if ((st_) == 11) WS_T(1, w);                                                                                            \
+        if ((st_) >= 12 && (st_) <= 15) WS_S((st_) - 12, 1, base_);                                                             \
+    } while (0)
+    constexpr int NIT = (G::NR * G::TPR * 4 + G::NTHR - 1) / G::NTHR;     // items per thread and chunk
+    static_assert(NIT * 20 <= 40, "staging steps do not fit between the 40 taps");
 
     const uint4* wl = wp + (h * CO + n * 32 + j);
     const int co = n * 32 + j;
     const float bz = bias[co];
     int qmin, nrows;
     wino_pass_rows<G, S>(pass, total_tiles, qmin, nrows);
-    {   // first pass: its first chunk
-        for (int it = 0; it < G::NITEMS; ++it) {
-            float2 d[8];
-            WSTG_LOAD(d, it, 0, qmin, nrows);
-            WSTG_STORE(d, it, ldsb, nrows);
-        }
-    }
+    for (int it = 0; it < NIT; ++it)                                       // first pass: its first chunk
+#pragma unroll
+        for (int st = 0; st < 16; ++st) WS_STEP(st, it, 0, qmin, nrows, ldsb);
     __syncthreads();
-    uint4 bq[4][2];                                     // ring of 4: 40 taps per chunk keep the phase
-    bq[0][0] = wl[0]; bq[0][1] = wl[2 * CO];
-    bq[1][0] = wl[G::BV]; bq[1][1] = wl[G::BV + 2 * CO];
+    constexpr int BD = 3;                               // weight fragments are loaded BD taps ahead (L2 / MALL latency under load)
+    uint4 bq[8][2];                                     // ring of 8: 40 taps per chunk keep the phase
+#pragma unroll
+    for (int t = 0; t < BD; ++t) { bq[t][0] = wl[(size_t)t * G::BV]; bq[t][1] = wl[(size_t)t * G::BV + 2 * CO]; }
     int bufsel = 0;
     for (;;) {
-        // A-operand byte offsets of this lane's TPW tiles, one per kernel row (out-of-crop rows -> the zero row)
+        // A-operand byte offsets of this lane's two tiles, one per kernel row (out-of-crop rows -> the zero row)
         int aoff[TPW][5];
         const int T0 = pass * G::MB + mg * TPW * 32;
 #pragma unroll
@@ -942,7 +974,7 @@ __global__ __launch_bounds__((WinoGeom<CI, CO, S, TPW>::NTHR)) void k_conv5_wino
         int next_pass = pass + (int)gridDim.x;
         if (tid == 0) s_next_pass = (int)atomicAdd(pass_ctr, 1u) + (int)gridDim.x;   // read by everyone after the first chunk's barrier
         bool have_next = false;
-        int qmin_n = 0, nrows_n = 0;
+        int qmin_n = qmin, nrows_n = nrows;
         for (int cc = 0; cc < G::NCH; ++cc) {
             const bool last_c = cc == G::NCH - 1;
             if (last_c) {
@@ -953,68 +985,108 @@ __global__ __launch_bounds__((WinoGeom<CI, CO, S, TPW>::NTHR)) void k_conv5_wino
             }
             const uint8_t* pbase = ldsb + bufsel * G::BUF;
             uint8_t* nbase = ldsb + (bufsel ^ 1) * G::BUF;
-            const bool more_w = !last_c || have_next;                    // a following chunk exists: its weights and its patch
+            // what is staged under this chunk: the next chunk of this pass, or the first chunk of the next pass (without one: this
+            // pass's first chunk once more, into the buffer nobody reads again -- cheaper than a branch around every slice)
             const int scc = last_c ? 0 : cc + 1;
-            const int sqmin = last_c ? qmin_n : qmin, snrows = more_w ? (last_c ? nrows_n : nrows) : 0;
+            const int sqmin = last_c ? qmin_n : qmin, snrows = last_c ? nrows_n : nrows;
             const uint4* wc = wl + (size_t)cc * 40 * G::BV;
             const uint4* wn = wl + (size_t)scc * 40 * G::BV;
-            float2 sd[8];
+            uint4 af[2][TPW][2];
+#pragma unroll
+            for (int m = 0; m < TPW; ++m) {
+                af[0][m][0] = *reinterpret_cast<const uint4*>(pbase + aoff[m][0]);
+                af[0][m][1] = *reinterpret_cast<const uint4*>(pbase + aoff[m][0] + G::PLANE);
+            }
 #pragma clang loop unroll(full)
             for (int t = 0; t < 40; ++t) {
-                if (t + 2 < 40) {
-                    bq[(t + 2) % 4][0] = wc[(size_t)(t + 2) * G::BV];
-                    bq[(t + 2) % 4][1] = wc[(size_t)(t + 2) * G::BV + 2 * CO];
-                } else if (more_w) {
-                    bq[(t + 2) % 4][0] = wn[(size_t)(t + 2 - 40) * G::BV];
-                    bq[(t + 2) % 4][1] = wn[(size_t)(t + 2 - 40) * G::BV + 2 * CO];
-                }
-                if (t % 8 == 0 && t / 8 < G::NITEMS) WSTG_LOAD(sd, t / 8, scc, sqmin, snrows);
-                if (t % 8 == 5 && t / 8 < G::NITEMS) WSTG_STORE(sd, t / 8, nbase, snrows);
-                const int ky = t / 8, p = t % 8;
-                const uint8_t* asrc = pbase + p * 32;
-                const f16x8 b1 = __builtin_bit_cast(f16x8, bq[t % 4][0]);
-                const f16x8 b2 = __builtin_bit_cast(f16x8, bq[t % 4][1]);
+                const int cur = t & 1, nxt = cur ^ 1;
+                if (t + 1 < 40) {                                    // A fragments of the next tap
+                    const uint8_t* an = pbase + ((t + 1) % 8) * 32;
 #pragma unroll
-                for (int m = 0; m < TPW; ++m) {
-                    const f16x8 p1 = __builtin_bit_cast(f16x8, *reinterpret_cast<const uint4*>(asrc + aoff[m][ky]));
-                    const f16x8 p2 = __builtin_bit_cast(f16x8, *reinterpret_cast<const uint4*>(asrc + aoff[m][ky] + G::PLANE));
-                    acc[m][p] = mfma16(p2, b1, acc[m][p]);
-                    acc[m][p] = mfma16(p1, b2, acc[m][p]);
-                    acc[m][p] = mfma16(p1, b1, acc[m][p]);
+                    for (int m = 0; m < TPW; ++m) {
+                        af[nxt][m][0] = *reinterpret_cast<const uint4*>(an + aoff[m][(t + 1) / 8]);
+                        af[nxt][m][1] = *reinterpret_cast<const uint4*>(an + aoff[m][(t + 1) / 8] + G::PLANE);
+                    }
                 }
-                __builtin_amdgcn_sched_barrier(0);                  // keep the taps apart: hoisting loads across them costs registers
+                if (t + BD < 40) {                                   // B fragments BD taps ahead
+                    bq[(t + BD) % 8][0] = wc[(size_t)(t + BD) * G::BV];
+                    bq[(t + BD) % 8][1] = wc[(size_t)(t + BD) * G::BV + 2 * CO];
+                } else {
+                    bq[(t + BD) % 8][0] = wn[(size_t)(t + BD - 40) * G::BV];
+                    bq[(t + BD) % 8][1] = wn[(size_t)(t + BD - 40) * G::BV + 2 * CO];
+                }
+                if (t / 20 < NIT) WS_STEP(t % 20, t / 20, scc, sqmin, snrows, nbase);
+                const int p = t % 8;
+                const f16x8 b1 = __builtin_bit_cast(f16x8, bq[t % 8][0]);
+                const f16x8 b2 = __builtin_bit_cast(f16x8, bq[t % 8][1]);
+                const f16x8 a10 = __builtin_bit_cast(f16x8, af[cur][0][0]), a20 = __builtin_bit_cast(f16x8, af[cur][0][1]);
+                const f16x8 a11 = __builtin_bit_cast(f16x8, af[cur][1][0]), a21 = __builtin_bit_cast(f16x8, af[cur][1][1]);
+                acc[0][p] = mfma16(a20, b1, acc[0][p]);
+                acc[1][p] = mfma16(a21, b1, acc[1][p]);
+                acc[0][p] = mfma16(a10, b2, acc[0][p]);
+                acc[1][p] = mfma16(a11, b2, acc[1][p]);
+                acc[0][p] = mfma16(a10, b1, acc[0][p]);
+                acc[1][p] = mfma16(a11, b1, acc[1][p]);
+                // issue order inside a tap: next tap's A reads and the weight loads first (their latency hides under this tap's
+                // MFMAs), then the six MFMAs with the staging slice spread between them
+                __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+                __builtin_amdgcn_sched_group_barrier(0x020, 10, 0);
+#pragma unroll
+                for (int g = 0; g < 6; ++g) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x206, 8, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);                  // keep the taps apart
             }
             __syncthreads();
             bufsel ^= 1;
         }
-        // epilogue: Y = A^T M per tile, max over the 2x2 pool window (rows y, y+1 = registers r, r+1; outputs 0,1 / 2,3), bias, ReLU
+        // epilogue: Y = A^T M per tile (16-wide, one M-tile at a time: the four outputs of all 16 accumulator rows of a lane), then the
+        // max over the 2x2 pool window (rows y, y+1 = registers r, r+1; outputs 0,1 / 2,3), bias, ReLU
 #pragma unroll
         for (int m = 0; m < TPW; ++m) {
+            f32x16 y0, y1, y2, y3;
+            {
+                const f32x16 e1 = acc[m][1] + acc[m][2], o1 = acc[m][1] - acc[m][2];
+                y0 = acc[m][0] + e1; y1 = o1; y2 = e1; y3 = o1 + acc[m][7];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            {
+                const f32x16 e2 = acc[m][3] + acc[m][4], o2 = acc[m][3] - acc[m][4];
+                y0 += e2; y1 += 2.f * o2; y2 += 4.f * e2; y3 += 8.f * o2;
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            {
+                const f32x16 e3 = acc[m][5] + acc[m][6], o3 = acc[m][5] - acc[m][6];
+                y0 += e3; y1 += 0.5f * o3; y2 += 0.25f * e3; y3 += 0.125f * o3;
+            }
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int rr = 0; rr < 8; ++rr) {
                 const int r = 2 * rr;
                 const int i = (r & 3) + 8 * (r >> 2) + 4 * h;
                 const int T = T0 + m * 32 + i;
-                float ya[4], yb[4];
-                wino_at(acc[m][0][r], acc[m][1][r], acc[m][2][r], acc[m][3][r], acc[m][4][r], acc[m][5][r], acc[m][6][r], acc[m][7][r], ya);
-                wino_at(acc[m][0][r + 1], acc[m][1][r + 1], acc[m][2][r + 1], acc[m][3][r + 1], acc[m][4][r + 1], acc[m][5][r + 1], acc[m][6][r + 1], acc[m][7][r + 1], yb);
-                const float v0 = fmaxf(fmaxf(ya[0], ya[1]), fmaxf(yb[0], yb[1]));
-                const float v1 = fmaxf(fmaxf(ya[2], ya[3]), fmaxf(yb[2], yb[3]));
+                const float v0 = fmaxf(fmaxf(y0[r], y1[r]), fmaxf(y0[r + 1], y1[r + 1]));
+                const float v1 = fmaxf(fmaxf(y2[r], y3[r]), fmaxf(y2[r + 1], y3[r + 1]));
                 if (T < total_tiles) {
                     const int gp = T / G::TPP, tx = (T - gp * G::TPP) >> 1;
                     float* o = out + ((size_t)gp * (S / 2) + 2 * tx) * CO + co;
-                    o[0] = fmaxf(v0 * out_scale + bz, 0.f);
-                    o[CO] = fmaxf(v1 * out_scale + bz, 0.f);
+                    __builtin_nontemporal_store(fmaxf(v0 * out_scale + bz, 0.f), o);
+                    __builtin_nontemporal_store(fmaxf(v1 * out_scale + bz, 0.f), o + CO);
                 }
-                __builtin_amdgcn_sched_barrier(0);                  // one register pair at a time: reading all 256 accumulators first spills
             }
+            __builtin_amdgcn_sched_barrier(0);
         }
         if (!have_next) break;
         pass = next_pass; qmin = qmin_n; nrows = nrows_n;
     }
-#undef WSTG_LOAD
-#undef WSTG_STORE
-    if (__any(ovf) && lane == 0) atomicOr(overflow, 1u);
+#undef WS_L
+#undef WS_T
+#undef WS_S
+#undef WS_STEP
+    // fp16 range guard: |B^T d| <= 15 max|d| (largest absolute row sum of B^T), so inputs below 65520 / 15 cannot overflow a piece.
+    // Larger (or non-finite) inputs raise the flag and the host-side guard re-runs the layer stack with the bf16 kernels.
+    if (__any(!(mxabs < 4368.0f)) && lane == 0) atomicOr(overflow, 1u);
 }
 
 static constexpr int FC1_KSPLIT = 10;     // 12800 = 10 x 1280: 500 workgroups at 6400 crops (5: 129 us, 10: 92 us, 20: 102 us + slower head); partial planes summed in k_head
