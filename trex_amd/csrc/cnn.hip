@@ -799,7 +799,7 @@ __device__ __forceinline__ void wino_at(const float m0, const float m1, const fl
 //     above / below, clipped at the crop: out-of-crop rows read a zero row) are contiguous in the batch's row numbering;
 //   * 8 position accumulators per M-tile: TPW M-tiles per wave = TPW*128 accumulator registers, one wave per SIMD;
 //   * output transform Y = A^T M, bias, ReLU, pool in the epilogue.
-// LDS: [buffer][piece][row slot][tx][position][16 ci] fp16, slot 0 = zeros; double-buffered over the 16-channel chunks
+// LDS: [buffer][piece][row slot][position][tx][16 ci] fp16, slot 0 = zeros; double-buffered over the 16-channel chunks
 // (the next chunk / next pass is transformed and stored in slices between the taps of the current one).
 // ------------------------------------------------------------------------------------------------
 template <int CI, int CO, int S, int TPW>
@@ -810,9 +810,11 @@ struct WinoGeom {
     static constexpr int MB = WM * TPW * 32;                            // tiles per pass
     static constexpr int MAXPAIRS = (MB + TPP - 2) / TPP + 1;
     static constexpr int NR = 2 * MAXPAIRS + 4;                         // real input rows a pass can need
-    static constexpr int TS = 8 * 32 + 16;                              // bytes per tile and piece: 8 positions x 16 halves + 16 pad
-    static constexpr int RP0 = TPR * TS;
-    static constexpr int RP = RP0 + (((8 - (RP0 / 16) % 16) + 16) % 16) * 16;   // row pitch == 8 (mod 16) 16-byte slots
+    static constexpr int PS = TPR * 32;                                 // bytes per position of a row: tiles x 16 halves
+    static constexpr int RP0 = 8 * PS;
+    // row pitch: == 5 (mod 8) 16-byte slots when a row pair holds 10 tiles, so that the 16 lanes of a ds_read_b128 lane group
+    // (tiles i, i+1 = rows y, y+1 of one column, then the next column) fall into 16 different slots
+    static constexpr int RP = RP0 + (((5 - (RP0 / 16) % 8) + 8) % 8) * 16;
     static constexpr int PLANE = (NR + 1) * RP;                         // one piece; slot 0 = the zero row
     static constexpr int BUF = 2 * PLANE;
     static constexpr int LDS_BYTES = 2 * BUF;
@@ -842,6 +844,20 @@ __device__ __forceinline__ uint32_t pack_h2(const _Float16 a, const _Float16 b) 
     return (uint32_t)__builtin_bit_cast(uint16_t, a) | ((uint32_t)__builtin_bit_cast(uint16_t, b) << 16);
 }
 
+// raw buffer loads (SGPR resource + SGPR offset + 32-bit lane offset): no 64-bit address arithmetic on the VALU
+typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, const uint32_t bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, bytes, 0x00020000);
+}
+__device__ __forceinline__ uint4 buf_load16(const __amdgpu_buffer_rsrc_t r, const int voff, const int soff) {
+    const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);
+    return make_uint4(v[0], v[1], v[2], v[3]);
+}
+__device__ __forceinline__ float4 buf_load16f_nt(const __amdgpu_buffer_rsrc_t r, const int voff, const int soff) {
+    const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 2);      // nt: streamed once, keep the weights in L2
+    return make_float4(__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]), __uint_as_float(v[3]));
+}
+
 // one fp32 value -> two fp16 pieces, round-toward-zero packing of two values at a time (v_cvt_pkrtz_f16_f32): the first piece may be
 // any fp16 near x (the residual x - h1 is exact in fp32), the second loses at most one unit of the 22nd bit
 typedef __fp16 h2_t __attribute__((ext_vector_type(2)));
@@ -853,7 +869,7 @@ __device__ __forceinline__ void split2h_pair(const float a, const float b, uint3
     p2 = __builtin_bit_cast(uint32_t, h2);
 }
 
-template <int CI, int CO, int S, int TPW>
+template <int CI, int CO, int S, int TPW, int DBG = 0>
 __global__ __launch_bounds__((WinoGeom<CI, CO, S, TPW>::NTHR)) void k_conv5_wino(const float* __restrict__ in /*[N][S][S][CI]*/,
                                                                                const uint4* __restrict__ wp /*[CI/16][5][8][2][2][CO] x 16 B*/,
                                                                                const float* __restrict__ bias, float* __restrict__ out,
@@ -882,70 +898,100 @@ __global__ __launch_bounds__((WinoGeom<CI, CO, S, TPW>::NTHR)) void k_conv5_wino
     // of one row.  Rows past the pass's last row repeat that row (same bytes to the same place), columns outside the crop are
     // loaded from the clamped column and zeroed.  Steps of an item: L (8 x 16-byte loads), T (B^T of one channel), S (split two
     // positions of two channels into fp16 pieces, one 4-byte store per piece and position).
-    float4 sd[8];
+    float4 sdb[2][8];                                   // two items in flight: both are loaded at the head of a chunk, long before their use
     float su[2][8];
-    int sdst = 0, sflag = 0;
+    int sdstb[2] = {0, 0}, sflagb[2] = {0, 0};
+    __amdgpu_buffer_rsrc_t srs = make_rsrc(in, 0);
+    // L: the eight loads of item item_ into buffer item_
 #define WS_L(item_, cc_, qmin_, nrows_)                                                                                         \
     do {                                                                                                                        \
         const int idx_ = tid + (item_) * G::NTHR;                                                                               \
         int s_ = idx_ / (G::TPR * 4);                                                                                           \
         const int r_ = idx_ - s_ * (G::TPR * 4);                                                                                \
-        const int tx_ = r_ >> 2, cq_ = r_ & 3;                                                                                  \
+        const int cq_ = r_ & 3, tx_ = r_ >> 2;                                                                                  \
         s_ = s_ < (nrows_) ? s_ : (nrows_) - 1;                                                                                 \
-        const float* src_ = in + ((size_t)((qmin_) + s_) * S) * CI + (cc_) * 16 + cq_ * 4;                                      \
+        srs = make_rsrc(in + ((size_t)((DBG & 16) ? 0 : (qmin_)) * S) * CI, (uint32_t)(G::NR * S * CI * 4));                    \
+        const int soff_ = s_ * (S * CI * 4) + (cc_) * 64 + cq_ * 16;                                                            \
+        sdstb[item_] = (s_ + 1) * G::RP + tx_ * 32 + cq_ * 8;                                                                   \
+        sflagb[item_] = (tx_ == 0 ? 1 : 0) | (tx_ == G::TPR - 1 ? 2 : 0);                                                       \
         _Pragma("unroll") for (int k_ = 0; k_ < 8; ++k_) {                                                                      \
             int ix_ = 4 * tx_ - 2 + k_;                                                                                         \
             ix_ = ix_ < 0 ? 0 : (ix_ > S - 1 ? S - 1 : ix_);                                                                    \
-            { const f32x4 v_ = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(src_ + (size_t)ix_ * CI)); sd[k_] = make_float4(v_[0], v_[1], v_[2], v_[3]); }                                                 \
+            sdb[item_][k_] = buf_load16f_nt(srs, soff_ + ix_ * (CI * 4), 0);                                                    \
         }                                                                                                                       \
-        sdst = (s_ + 1) * G::RP + tx_ * G::TS + cq_ * 8;                                                                        \
-        sflag = (tx_ == 0 ? 1 : 0) | (tx_ == G::TPR - 1 ? 2 : 0);                                                               \
     } while (0)
-#define WS_T(which_, comp_)                                                                                                     \
+    // T: B^T of one channel in two halves (positions 0, 7, 1, 2 then 3..6); the range guard rides on the first half
+#define WS_T(item_, which_, comp_, hf_)                                                                                         \
     do {                                                                                                                        \
-        const float d0_ = (sflag & 1) ? 0.f : sd[0].comp_, d1_ = (sflag & 1) ? 0.f : sd[1].comp_;                               \
-        const float d6_ = (sflag & 2) ? 0.f : sd[6].comp_, d7_ = (sflag & 2) ? 0.f : sd[7].comp_;                               \
-        mxabs = fmaxf(fmaxf(mxabs, fabsf(sd[2].comp_)), fmaxf(fabsf(sd[3].comp_), fmaxf(fabsf(sd[4].comp_), fabsf(sd[5].comp_)))); \
-        mxabs = fmaxf(fmaxf(mxabs, fabsf(d0_)), fmaxf(fabsf(d1_), fmaxf(fabsf(d6_), fabsf(d7_))));                              \
-        wino_bt(d0_, d1_, sd[2].comp_, sd[3].comp_, sd[4].comp_, sd[5].comp_, d6_, d7_, su[which_]);                            \
+        const int sflag = sflagb[item_];                                                                                        \
+        const float4* sd = sdb[item_];                                                                                          \
+        const float d1_ = (sflag & 1) ? 0.f : sd[1].comp_, d6_ = (sflag & 2) ? 0.f : sd[6].comp_;                               \
+        const float d2_ = sd[2].comp_, d3_ = sd[3].comp_, d4_ = sd[4].comp_, d5_ = sd[5].comp_;                                 \
+        if ((hf_) == 0) {                                                                                                       \
+            const float d0_ = (sflag & 1) ? 0.f : sd[0].comp_, d7_ = (sflag & 2) ? 0.f : sd[7].comp_;                           \
+            mxabs = fmaxf(fmaxf(mxabs, fabsf(d2_)), fmaxf(fabsf(d3_), fmaxf(fabsf(d4_), fabsf(d5_))));                          \
+            mxabs = fmaxf(fmaxf(mxabs, fabsf(d0_)), fmaxf(fabsf(d1_), fmaxf(fabsf(d6_), fabsf(d7_))));                          \
+            su[which_][0] = fmaf(5.25f, d2_ - d4_, d6_ - d0_);                                                                  \
+            su[which_][7] = fmaf(5.25f, d3_ - d5_, d7_ - d1_);                                                                  \
+            const float e1_ = fmaf(-4.25f, d4_, d2_ + d6_), o1_ = fmaf(-4.25f, d3_, d1_ + d5_);                                 \
+            su[which_][1] = e1_ + o1_; su[which_][2] = e1_ - o1_;                                                               \
+        } else {                                                                                                                \
+            const float e2_ = fmaf(-1.25f, d4_, fmaf(0.25f, d2_, d6_)), o2_ = fmaf(2.f, d5_, fmaf(-2.5f, d3_, 0.5f * d1_));     \
+            su[which_][3] = e2_ + o2_; su[which_][4] = e2_ - o2_;                                                               \
+            const float e3_ = fmaf(-5.f, d4_, fmaf(4.f, d2_, d6_)), o3_ = fmaf(0.5f, d5_, fmaf(-2.5f, d3_, 2.f * d1_));         \
+            su[which_][5] = e3_ + o3_; su[which_][6] = e3_ - o3_;                                                               \
+        }                                                                                                                       \
     } while (0)
-#define WS_S(pp_, half_, base_)                                                                                                 \
+    // S: four positions (4*pq_ .. 4*pq_+3) of two channels -> fp16 pieces, one 4-byte store per piece and position
+#define WS_S(item_, pq_, half_, base_)                                                                                          \
     do {                                                                                                                        \
-        _Pragma("unroll") for (int q_ = 0; q_ < 2; ++q_) {                                                                      \
+        _Pragma("unroll") for (int q_ = 0; q_ < 4; ++q_) {                                                                      \
             uint32_t a1_, a2_;                                                                                                  \
-            split2h_pair(su[0][2 * (pp_) + q_], su[1][2 * (pp_) + q_], a1_, a2_);                                               \
-            uint8_t* dst_ = (base_) + sdst + (2 * (pp_) + q_) * 32 + (half_) * 4;                                               \
+            split2h_pair(su[0][4 * (pq_) + q_], su[1][4 * (pq_) + q_], a1_, a2_);                                               \
+            uint8_t* dst_ = (base_) + sdstb[item_] + (4 * (pq_) + q_) * G::PS + (half_) * 4;                                    \
             *reinterpret_cast<uint32_t*>(dst_) = a1_;                                                                           \
             *reinterpret_cast<uint32_t*>(dst_ + G::PLANE) = a2_;                                                                \
         }                                                                                                                       \
     } while (0)
-    // the 20 tap slots of one item: load, then (transform x, y, four stores), (transform z, w, four stores)
-#define WS_STEP(st_, item_, cc_, qmin_, nrows_, base_)                                                                          \
+    // the 12 compute slots of one item: transform x, y (4) | stores (2) | transform z, w (4) | stores (2)
+#define WS_STEP(st_, item_, base_)                                                                                              \
     do {                                                                                                                        \
-        if ((st_) == 0) WS_L(item_, cc_, qmin_, nrows_);                                                                        \
-        if ((st_) == 4) WS_T(0, x);                                                                                             \
-        if ((st_) == 5) WS_T(1, y);                                                                                             \
-        if ((st_) >= 6 && (st_) <= 9) WS_S((st_) - 6, 0, base_);                                                                \
-        if ((st_) == 10) WS_T(0, z);                                                                                            \
-        if ((st_) == 11) WS_T(1, w);                                                                                            \
-        if ((st_) >= 12 && (st_) <= 15) WS_S((st_) - 12, 1, base_);                                                             \
+        if ((st_) == 0) WS_T(item_, 0, x, 0);                                                                                   \
+        if ((st_) == 1) WS_T(item_, 0, x, 1);                                                                                   \
+        if ((st_) == 2) WS_T(item_, 1, y, 0);                                                                                   \
+        if ((st_) == 3) WS_T(item_, 1, y, 1);                                                                                   \
+        if ((st_) == 4) WS_S(item_, 0, 0, base_);                                                                               \
+        if ((st_) == 5) WS_S(item_, 1, 0, base_);                                                                               \
+        if ((st_) == 6) WS_T(item_, 0, z, 0);                                                                                   \
+        if ((st_) == 7) WS_T(item_, 0, z, 1);                                                                                   \
+        if ((st_) == 8) WS_T(item_, 1, w, 0);                                                                                   \
+        if ((st_) == 9) WS_T(item_, 1, w, 1);                                                                                   \
+        if ((st_) == 10) WS_S(item_, 0, 1, base_);                                                                              \
+        if ((st_) == 11) WS_S(item_, 1, 1, base_);                                                                              \
     } while (0)
     constexpr int NIT = (G::NR * G::TPR * 4 + G::NTHR - 1) / G::NTHR;     // items per thread and chunk
-    static_assert(NIT * 20 <= 40, "staging steps do not fit between the 40 taps");
+    static_assert(NIT == 2, "two staging items per thread and chunk, 20 taps each");
 
-    const uint4* wl = wp + (h * CO + n * 32 + j);
+    const __amdgpu_buffer_rsrc_t wrs = make_rsrc(wp, (uint32_t)(G::NCH * 40 * G::BV * 16));   // weights: SGPR resource + SGPR tap offset + lane offset
+    const int boff = (h * CO + n * 32 + j) * 16;
     const int co = n * 32 + j;
     const float bz = bias[co];
     int qmin, nrows;
     wino_pass_rows<G, S>(pass, total_tiles, qmin, nrows);
-    for (int it = 0; it < NIT; ++it)                                       // first pass: its first chunk
 #pragma unroll
-        for (int st = 0; st < 16; ++st) WS_STEP(st, it, 0, qmin, nrows, ldsb);
+    for (int it = 0; it < NIT; ++it) {                                     // first pass: its first chunk
+        WS_L(it, 0, qmin, nrows);
+#pragma unroll
+        for (int st = 0; st < 12; ++st) WS_STEP(st, it, ldsb);
+    }
     __syncthreads();
     constexpr int BD = 3;                               // weight fragments are loaded BD taps ahead (L2 / MALL latency under load)
     uint4 bq[8][2];                                     // ring of 8: 40 taps per chunk keep the phase
 #pragma unroll
-    for (int t = 0; t < BD; ++t) { bq[t][0] = wl[(size_t)t * G::BV]; bq[t][1] = wl[(size_t)t * G::BV + 2 * CO]; }
+    for (int t = 0; t < BD; ++t) {
+        bq[t][0] = buf_load16(wrs, boff, t * G::BV * 16);
+        bq[t][1] = buf_load16(wrs, boff, t * G::BV * 16 + 2 * CO * 16);
+    }
     int bufsel = 0;
     for (;;) {
         // A-operand byte offsets of this lane's two tiles, one per kernel row (out-of-crop rows -> the zero row)
@@ -960,7 +1006,7 @@ __global__ __launch_bounds__((WinoGeom<CI, CO, S, TPW>::NTHR)) void k_conv5_wino
 #pragma unroll
             for (int ky = 0; ky < 5; ++ky) {
                 const int iy = y + ky - 2;
-                aoff[m][ky] = ((iy >= 0 && iy < S) ? (qo + ky - 2 - qmin + 1) * G::RP : 0) + tx * G::TS + h * 16;
+                aoff[m][ky] = ((iy >= 0 && iy < S) ? (qo + ky - 2 - qmin + 1) * G::RP : 0) + tx * 32 + h * 16;
             }
         }
         f32x16 acc[TPW][8];
@@ -989,8 +1035,7 @@ __global__ __launch_bounds__((WinoGeom<CI, CO, S, TPW>::NTHR)) void k_conv5_wino
             // pass's first chunk once more, into the buffer nobody reads again -- cheaper than a branch around every slice)
             const int scc = last_c ? 0 : cc + 1;
             const int sqmin = last_c ? qmin_n : qmin, snrows = last_c ? nrows_n : nrows;
-            const uint4* wc = wl + (size_t)cc * 40 * G::BV;
-            const uint4* wn = wl + (size_t)scc * 40 * G::BV;
+            const int wc = cc * 40 * G::BV * 16, wn = scc * 40 * G::BV * 16;
             uint4 af[2][TPW][2];
 #pragma unroll
             for (int m = 0; m < TPW; ++m) {
@@ -1000,22 +1045,25 @@ __global__ __launch_bounds__((WinoGeom<CI, CO, S, TPW>::NTHR)) void k_conv5_wino
 #pragma clang loop unroll(full)
             for (int t = 0; t < 40; ++t) {
                 const int cur = t & 1, nxt = cur ^ 1;
-                if (t + 1 < 40) {                                    // A fragments of the next tap
-                    const uint8_t* an = pbase + ((t + 1) % 8) * 32;
+                if (!(DBG & 8) && t + 1 < 40) {                                    // A fragments of the next tap
+                    const uint8_t* an = pbase + ((t + 1) % 8) * G::PS;
 #pragma unroll
                     for (int m = 0; m < TPW; ++m) {
                         af[nxt][m][0] = *reinterpret_cast<const uint4*>(an + aoff[m][(t + 1) / 8]);
                         af[nxt][m][1] = *reinterpret_cast<const uint4*>(an + aoff[m][(t + 1) / 8] + G::PLANE);
                     }
                 }
-                if (t + BD < 40) {                                   // B fragments BD taps ahead
-                    bq[(t + BD) % 8][0] = wc[(size_t)(t + BD) * G::BV];
-                    bq[(t + BD) % 8][1] = wc[(size_t)(t + BD) * G::BV + 2 * CO];
-                } else {
-                    bq[(t + BD) % 8][0] = wn[(size_t)(t + BD - 40) * G::BV];
-                    bq[(t + BD) % 8][1] = wn[(size_t)(t + BD - 40) * G::BV + 2 * CO];
+                if (!(DBG & 4)) {                                    // B fragments BD taps ahead
+                    const int wt = t + BD < 40 ? wc + (t + BD) * G::BV * 16 : wn + (t + BD - 40) * G::BV * 16;
+                    bq[(t + BD) % 8][0] = buf_load16(wrs, boff, wt);
+                    bq[(t + BD) % 8][1] = buf_load16(wrs, boff, wt + 2 * CO * 16);
                 }
-                if (t / 20 < NIT) WS_STEP(t % 20, t / 20, scc, sqmin, snrows, nbase);
+                if (!(DBG & 1)) {                                    // item 0: load at tap 0, slots 6..17; item 1: load at tap 20, slots 26..37
+                    if (t == 0) WS_L(0, scc, sqmin, snrows);
+                    if (t == 20) WS_L(1, scc, sqmin, snrows);
+                    if (t >= 6 && t < 18) WS_STEP(t - 6, 0, nbase);
+                    if (t >= 26 && t < 38) WS_STEP(t - 26, 1, nbase);
+                }
                 const int p = t % 8;
                 const f16x8 b1 = __builtin_bit_cast(f16x8, bq[t % 8][0]);
                 const f16x8 b2 = __builtin_bit_cast(f16x8, bq[t % 8][1]);
@@ -1044,7 +1092,7 @@ __global__ __launch_bounds__((WinoGeom<CI, CO, S, TPW>::NTHR)) void k_conv5_wino
         // epilogue: Y = A^T M per tile (16-wide, one M-tile at a time: the four outputs of all 16 accumulator rows of a lane), then the
         // max over the 2x2 pool window (rows y, y+1 = registers r, r+1; outputs 0,1 / 2,3), bias, ReLU
 #pragma unroll
-        for (int m = 0; m < TPW; ++m) {
+        for (int m = 0; m < ((DBG & 2) ? 0 : TPW); ++m) {
             f32x16 y0, y1, y2, y3;
             {
                 const f32x16 e1 = acc[m][1] + acc[m][2], o1 = acc[m][1] - acc[m][2];
@@ -1076,6 +1124,12 @@ __global__ __launch_bounds__((WinoGeom<CI, CO, S, TPW>::NTHR)) void k_conv5_wino
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
+        }
+        if (DBG & 2) {
+#pragma unroll
+            for (int m = 0; m < TPW; ++m)
+#pragma unroll
+                for (int p = 0; p < 8; ++p) asm volatile("" :: "a"(acc[m][p]));
         }
         if (!have_next) break;
         pass = next_pass; qmin = qmin_n; nrows = nrows_n;
@@ -1671,8 +1725,12 @@ int net_forward(trexhip_ctx* ctx, const uint8_t* d_crops, int n, float* d_probs,
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (ConvGeomS<16, 64, 40, 8, 4>::LDS_BYTES)));
         TH_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv5_stream<64, 128, 20, 20, 8, true>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (ConvGeomS<64, 128, 20, 20, 8>::LDS_BYTES)));
-        TH_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv5_wino<64, 128, 20, 2>),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (WinoGeom<64, 128, 20, 2>::LDS_BYTES)));
+#define WA(D_) TH_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv5_wino<64, 128, 20, 2, D_>), hipFuncAttributeMaxDynamicSharedMemorySize, (WinoGeom<64, 128, 20, 2>::LDS_BYTES)))
+        WA(0);
+#ifdef TREXHIP_DEV_KNOBS
+        WA(1); WA(2); WA(3); WA(4); WA(7); WA(8); WA(15); WA(12); WA(16);
+#endif
+#undef WA
 #undef SET_ATTR
 #undef SET_ATTRC
         ctx->attr_cnn = true;
@@ -1715,8 +1773,13 @@ int net_forward(trexhip_ctx* ctx, const uint8_t* d_crops, int n, float* d_probs,
         // Winograd F(4,5) along x: 0.4x the matrix work of the direct form (TREXHIP_CONV_GEOM bit 8: the direct kernels below)
         using GW = WinoGeom<64, 128, 20, 2>;
         const int n_pass = (n * GW::TPC + GW::MB - 1) / GW::MB;
-        hipLaunchKernelGGL((k_conv5_wino<64, 128, 20, 2>), dim3(n_pass < ctx->n_cus ? n_pass : ctx->n_cus), dim3(GW::NTHR), GW::LDS_BYTES, s,
-                           net->act2, net->w3w, net->b3, net->act3, net->inv3w, net->d_ovf, n, net->d_ovf + 1);
+#define WL(D_) hipLaunchKernelGGL((k_conv5_wino<64, 128, 20, 2, D_>), dim3(n_pass < ctx->n_cus ? n_pass : ctx->n_cus), dim3(GW::NTHR), GW::LDS_BYTES, s, net->act2, net->w3w, net->b3, net->act3, net->inv3w, net->d_ovf, n, net->d_ovf + 1)
+#ifdef TREXHIP_DEV_KNOBS   // ablations (tools/time_wino.py): 1 no staging, 2 no epilogue, 4 no weight loads, 8 no A reads, 16 staging loads from one hot row
+        switch ((ctx->tune_conv_geom >> 12) & 15) { case 1: WL(1); break; case 2: WL(2); break; case 3: WL(3); break; case 4: WL(4); break; case 7: WL(7); break; case 8: WL(8); break; case 15: WL(15); break; case 12: WL(12); break; case 6: WL(16); break; default: WL(0); }
+#else
+        WL(0);
+#endif
+#undef WL
     }
     else if (!(ctx->tune_conv_geom & 8))
         // one workgroup per CU (110 KB LDS, 256 VGPRs): persistent workgroups walk the crops and stage the next crop's first
