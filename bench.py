@@ -103,121 +103,18 @@ def main():
         frames_c = torch.stack([frames, frames, frames, torch.full_like(frames, 255)], dim=-1).contiguous()
     max_blobs = 4 * n_ind
     state = weights.synthetic_state(classes, 4242, channels=3 if args.encoding == "rgb8" else 1)
-    from trex_amd import dist as tdist
-    pool = B * max_blobs
-    rows = B * n_ind * 5 // 4                       # fixed table rows per rank per step (all-gather needs equal sizes)
-    MP = 256
-
-    class Lane:
-        """One context + its buffers + its stream.  Two lanes are software-pipelined: while lane A's identity network
-        works on batch i, lane B runs the detect stage of batch i+1 and its tables travel to the host."""
-        def __init__(self):
-            p = capi.default_params(W, H, device=local, max_batch=B, max_blobs=max_blobs, max_pixels=1 << 18, max_runs=32768,
-                                    pixel_encoding=capi.ENC_RGB8 if rgb else capi.ENC_GRAY)
-            self.seg = capi.Segmenter(p)
-            self.seg.set_background(bg)
-            if with_cnn:
-                self.seg.load_weights(weights.pack_blob(state, classes, channels=3 if rgb else 1))
-                self.seg.set_identity_precision({"fp32": 0, "bf16x6": 1, "bf16x3": 2, "fp16x3": 3}[args.cnn_mode])
-            self.crops = torch.empty((pool, 80, 80, 3) if rgb else (pool, 80, 80), dtype=torch.uint8, device=dev)
-            self.probs = torch.empty((pool, classes), dtype=torch.float32, device=dev)
-            # per-blob record for rank 0's matcher: header + probabilities, with posture also second moments + normalised midline (SURVEY 8e)
-            rowlen = (tdist.HDR_EX + classes + 3 * 25) if args.with_posture else (tdist.HDR + classes)
-            self.table = torch.zeros((rows, rowlen), dtype=torch.int32, device=dev)
-            self.table_host = torch.empty((world * rows, rowlen), dtype=torch.int32).pin_memory() if rank == 0 else None
-            if args.with_posture:
-                self.p_outline = torch.empty((pool, MP, 2), dtype=torch.float32, device=dev)
-                self.p_segs = torch.empty((pool, MP // 2 + 1, 4), dtype=torch.float32, device=dev)
-                self.p_info = torch.empty((pool, 8), dtype=torch.int32, device=dev)
-                self.p_mid = torch.empty((pool, 25, 4), dtype=torch.float32, device=dev)
-                self.p_minfo = torch.empty((pool, 8), dtype=torch.int32, device=dev)
-            self.stream = torch.cuda.Stream(device=dev)   # torch-side copies ride on the same stream as the kernels
-            self.seg.set_stream(self.stream.cuda_stream)
-            self.hi = torch.cuda.Stream(device=dev, priority=-1) if args.detect_priority else None
-            self.n = 0
-            self.done = torch.cuda.Event()
-            self.after = None                       # lane whose identity stage must finish before this lane's starts
-
-        def detect(self):
-            if self.hi is not None:
-                self.seg.set_stream(self.hi.cuda_stream)
-            if bgra_in:
-                self.seg.segment_color_device(frames_c.data_ptr(), B, 4)
-            else:
-                self.seg.segment_device(frames.data_ptr(), B)
-
-        def identify(self, step_idx):
-            seg = self.seg
-            res = seg.fetch_raw()                   # waits for detect; blob/run/pixel tables now on this rank's host (pinned)
-            n = self.n = int(res.total_blobs)
-            assert n <= rows, "identity table too small"
-            if self.hi is not None:
-                seg.set_stream(self.stream.cuda_stream)
-            if args.with_posture and n:
-                seg.posture_device(n, self.p_outline.data_ptr(), self.p_segs.data_ptr(), self.p_info.data_ptr(), max_points=MP)
-                seg.midline_device(n, MP, self.p_info.data_ptr(), self.p_segs.data_ptr(), self.p_mid.data_ptr(), self.p_minfo.data_ptr())
-            if with_cnn:
-                if n:
-                    if args.normalize == "posture":
-                        seg.crops_posture_device(self.crops.data_ptr(), n, self.p_minfo.data_ptr())
-                    else:
-                        seg.crops_device(self.crops.data_ptr(), n, normalization=1 if args.normalize == "moments" else 0)
-                    if self.after is not None:      # one identity network on the matrix cores at a time; posture / crops above and the
-                        self.stream.wait_event(self.after.done)   # table hand-off below overlap the other lane's network
-                    seg.identify_device(self.crops.data_ptr(), n, self.probs.data_ptr())
-                self.done.record(self.stream)
-                # per-blob identity table -> (all-gather over RCCL/xGMI) -> rank 0's host, for the sequential matcher
-                frame_base = (step_idx * world + rank) * B
-                if args.with_posture:
-                    seg.export_id_table_ex(self.probs.data_ptr(), n, classes, frame_base, self.table.data_ptr(), rows,
-                                           self.p_mid.data_ptr() if n else 0, self.p_minfo.data_ptr() if n else 0, 25)
-                else:
-                    seg.export_id_table(self.probs.data_ptr(), n, classes, frame_base, self.table.data_ptr(), rows)
-                with torch.cuda.stream(self.stream):
-                    g = tdist.all_gather_tables(self.table) if use_dist else self.table
-                    if rank == 0:
-                        self.table_host.copy_(g, non_blocking=True)
-            else:
-                self.done.record(self.stream)
-
-        def drain(self):
-            self.stream.synchronize()
-
-    lanes = [Lane() for _ in range(max(2, args.lanes))] if args.pipeline else [Lane()]
-    if len(lanes) > 1:
-        for k, ln in enumerate(lanes):
-            ln.after = lanes[(k - 1) % len(lanes)]
-            ln.done.record(ln.stream)
+    from trex_amd.pipeline import Pipeline
+    # the lanes, their buffers and the step schedule live in trex_amd/pipeline.py (the same object tests/test_bench_shape_gpu.py checks)
+    pipe = Pipeline(W, H, n_ind, B, classes, bg, weights.pack_blob(state, classes, channels=3 if rgb else 1) if with_cnn else None,
+                    local=local, rank=rank, world=world, use_dist=use_dist, with_cnn=with_cnn, with_posture=args.with_posture,
+                    normalize=args.normalize, rgb=rgb, bgra_in=bgra_in, cnn_mode=args.cnn_mode, lanes=args.lanes, pipeline=args.pipeline,
+                    detect_priority=args.detect_priority)
+    lanes = pipe.lanes
     seg = lanes[0].seg
-    torch.cuda.synchronize()
+    frames_ptr = frames_c.data_ptr() if bgra_in else frames.data_ptr()
 
     def run(k):
-        """k steps = k batches through detect -> (posture) -> crops -> identity -> table on the host."""
-        L = len(lanes)
-        D = max(1, L - 1)                           # detect runs D batches ahead of the identity network
-        for i in range(min(D, k)):
-            lanes[i % L].detect()
-        for i in range(k):
-            cur = lanes[i % L]
-            if not with_cnn and L > 1 and i + D < k:
-                # no network to keep fed: issue detect(i+D) BEFORE blocking on the tables of batch i, so that their copy to the host
-                # overlaps the next pixel pass (with the network the order below keeps the matrix cores' queue non-empty instead)
-                nxt = lanes[(i + D) % L]
-                nxt.drain()
-                nxt.detect()
-                cur.identify(i)
-                continue
-            cur.identify(i)                         # enqueue everything downstream of detect(i)
-            if i + D < k:
-                nxt = lanes[(i + D) % L]
-                if L > 1:
-                    nxt.drain()                     # its previous batch (i+D-L) is complete: table_host consumed by the matcher
-                else:
-                    cur.drain()
-                nxt.detect()                        # detect(i+D) overlaps the identity network of batches i-1 / i
-        for ln in lanes:
-            ln.drain()
-        return lanes[(k - 1) % L].n
+        return pipe.run(k, frames_ptr)
 
     n_blobs = run(args.warmup) if args.warmup else 0
 
@@ -252,7 +149,7 @@ def main():
         ln0 = lanes[0]
         ln0.seg.profile_reset()
         for _ in range(5):
-            ln0.detect()
+            ln0.detect(frames_ptr)
             ln0.seg.fetch(copy=False)
         prof["ROWS"] = ln0.seg.profile_read(capi.STAGE_ROWS)
         prof["SEGMENT_ALL"] = ln0.seg.profile_read(capi.STAGE_SEGMENT_ALL)
