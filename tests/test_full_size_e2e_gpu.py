@@ -117,3 +117,48 @@ def test_c5_detect_posture_crops_identify_full_record():
     assert np.array_equal(t[b0:b0 + 256], wt)
     assert set(np.unique(t[:, 0]).tolist()) == {0, 1, 2, 3}
     seg.close()
+
+
+def test_c3_posture_and_midline_at_2048():
+    # BASELINE.json config 3 at its full frame size: bg-sub + CCL + posture (outline -> midline -> normalised midline), every blob of two
+    # frames against the CPU oracle (same comparison as tests/test_posture_gpu.py, which works on the 1280x720 frames)
+    from test_posture_gpu import run_posture, compare, check_midline
+    fr, bg = synth.batch("C3", 2)
+    assert fr.shape[1:] == (2048, 2048)
+    res, outline, segs, info = run_posture(fr, bg)
+    assert all(len(r.blobs) == 100 for r in res)
+    n = compare(res, outline, segs, info, oracle.posture_params(max_points=512))
+    assert n == 200
+    assert (info["status"] == 0).mean() > 0.95
+    n_ok, total = check_midline(fr, bg, min_ok=0.9)
+    assert total == 200
+
+
+def test_c3_pipeline_like_bench():
+    # `bench.py --config C3`: detect + posture + midline, no network, two lanes, detect issued before the host blocks on the tables
+    from trex_amd.pipeline import Pipeline
+    B = 64
+    W, H, n_ind, _ = synth.CONFIGS["C3"]
+    frames, bg = synth.batch_torch("C3", B, "cuda")
+    pipe = Pipeline(W, H, n_ind, B, 100, bg, None, with_cnn=False, with_posture=True)
+    got = []
+
+    def on_batch(step, ln):
+        n = int(ln.res.total_blobs)
+        pi = ln.p_info[:n].cpu().numpy().view(capi.POSTURE_INFO_DTYPE).reshape(-1)
+        mi = ln.p_minfo[:n].cpu().numpy().view(capi.MIDLINE_INFO_DTYPE).reshape(-1)
+        assert n == n_ind * B and (pi["status"] == 0).mean() > 0.95 and np.array_equal(pi["status"] == 0, mi["status"] != 1)
+        ok = mi["status"] == 0
+        assert ok.mean() > 0.9 and np.all((mi["len"][ok] > 25) & (mi["len"][ok] < 50))      # 36 px long ellipses
+        info = capi._from_addr(ln.res.frames, ln.res.n_frames, capi.INFO_DTYPE)
+        o = np.argsort(info["blob_begin"])
+        got.append((pi["n_outline"].copy(), mi["len"].copy(), info["blob_begin"].copy()))
+
+    pipe.run(3, frames.data_ptr(), on_batch=on_batch)
+    # the same resident frames in every step: per frame the same outlines and midline lengths, whichever lane and pool position
+    a_no, a_len, a_bb = got[0]
+    for no, ln_, bb in got[1:]:
+        for f in range(0, B, 7):
+            assert np.array_equal(no[bb[f]:bb[f] + n_ind], a_no[a_bb[f]:a_bb[f] + n_ind])
+            assert np.array_equal(ln_[bb[f]:bb[f] + n_ind], a_len[a_bb[f]:a_bb[f] + n_ind])
+    pipe.close()

@@ -127,8 +127,12 @@ def test_rethreshold_table_and_capacity():
 @pytest.mark.parametrize("kw", [dict(), dict(midline_resolution=12, midline_stiff_percentage=0.3), dict(midline_stiff_percentage=0.0),
                                  dict(midline_invert=1), dict(midline_start_with_head=1)])
 def test_midline_post_process_and_normalize(kw):
-    # Midline::post_process + normalize (Outline.cpp:895-1060,1270-1454) on the device's own raw segments vs the CPU restatement
     fr, bg = synth.batch("C2", 2)
+    check_midline(fr, bg, **kw)
+
+
+def check_midline(fr, bg, min_ok=0.8, **kw):
+    # Midline::post_process + normalize (Outline.cpp:895-1060,1270-1454) on the device's own raw segments vs the CPU restatement
     n, H, W = fr.shape
     seg = capi.Segmenter(capi.default_params(W, H, max_batch=n))
     seg.set_background(bg)
@@ -170,8 +174,9 @@ def test_midline_post_process_and_normalize(kw):
         assert abs(gi["len"] - oi["len"]) <= 1e-4 * oi["len"]
         assert abs(gi["angle"] - oi["angle"]) <= 1e-5
         assert np.abs(mid[bi] - onorm).max() <= 1e-3
-    assert n_ok > 0.8 * total
+    assert n_ok > min_ok * total
     seg.close()
+    return n_ok, total
 
 
 @pytest.mark.parametrize("legacy", [False, True])
