@@ -2,64 +2,53 @@
 data/test_fish*.csv with videos/compare_data_automatic/*.csv): detect at detect_threshold=9, then the track-stage
 re-threshold at track_threshold=12 (signed difference, track_background_subtraction) with
 track_size_filter=[[70,420]] (videos/test.settings) must reproduce the golden (blobid, num_pixels) of every fish.
+ALL 200 shipped frames, all 1459 golden rows (fixture: tests/golden/e2e_testframes.npz, generator make_e2e_fixture.py).
 
 What can and cannot match exactly: the JPEG decoder and the background sampler of the reference are outside the
 tree, so a few boundary pixels differ; the blob id (13/13/6-bit hash of the first line) and the pixel counts are
 compared with the tolerances stated below -- the reference's own script tolerates word diffs too (run_unix.bash:143-156).
+
+What this anchor pins and what it does not (tools/e2e_ablation.py, table in DESIGN.md section 2): the track threshold sharply
+(+-1 drops the exact matches from 48 % to < 0.5 %) and 8- over 4-connectivity (76 % vs 69 % blob ids); it can NOT see the detect
+threshold or its strictness (every detect threshold below the track threshold gives the same rows) -- asserted below so that the
+statement stays true.
 CPU: oracle.  GPU (-m gpu): the device path must equal the oracle bit for bit on the same frames."""
-import os
 import numpy as np
 import pytest
 from oracle import oracle
-
-FIX = os.path.join(os.path.dirname(__file__), "golden", "e2e_testframes.npz")
-RANGES = [(70, 420)]
+from e2e_golden import Golden, RANGES, run_variant, score
 
 
-def rebuild(z, fr):
-    H, W = [int(v) for v in z["shape"]]
-    bg = np.full((H, W), 128, np.uint8)
-    for k, (x0, y0, x1, y1) in enumerate(z[f"rects/{fr}"]):
-        bg[y0:y1, x0:x1] = z[f"b/{fr}/{k}"]
-    img = bg.copy()
-    for k, (x0, y0, x1, y1) in enumerate(z[f"rects/{fr}"]):
-        img[y0:y1, x0:x1] = z[f"f/{fr}/{k}"]
-    return img, bg
-
-
-def score(sub_blobs, gold):
-    mine = {int(b["bid"]): int(b["n_pixels"]) for b in sub_blobs if b["flags"] == 0}
-    hits, exact, deltas = 0, 0, []
-    for g in gold:
-        bid, npx = int(g[1]), int(g[2])
-        if bid in mine:
-            hits += 1
-            deltas.append(abs(mine[bid] - npx))
-            exact += mine[bid] == npx
-    return hits, exact, deltas
-
-
-def test_oracle_reproduces_golden_csv_rows():
-    z = np.load(FIX)
-    tot = hits = exact = 0
-    deltas = []
-    for fr in z["frames"]:
-        img, bg = rebuild(z, int(fr))
-        p = oracle.make_params(img.shape[1], img.shape[0], threshold=9, size_ranges=[(1, 10000)])
-        blobs, runs, px = oracle.rethreshold_frame(img, bg, p, 1, 12, RANGES)
-        gold = z[f"gold/{int(fr)}"]
-        h, e, d = score(blobs, gold)
-        tot += len(gold); hits += h; exact += e; deltas += d
+def test_oracle_reproduces_golden_csv_rows_on_all_200_frames():
+    G = Golden()
+    assert len(G.frames) == 200
+    tot, hits, exact, deltas = run_variant(G, oracle)
     print("golden rows", tot, "bid hits", hits, "exact", exact, "median |dnpx|", np.median(deltas))
-    assert tot >= 60
-    assert hits / tot >= 0.70, (hits, tot)          # blob id (first line position + line count) reproduced
-    assert exact / tot >= 0.35, (exact, tot)        # ... with the identical pixel count
-    assert np.median(deltas) <= 2 and np.percentile(deltas, 90) <= 8
+    assert tot == 1459
+    assert hits / tot >= 0.75, (hits, tot)          # blob id (first line position + line count) reproduced
+    assert exact / tot >= 0.47, (exact, tot)        # ... with the identical pixel count
+    assert np.median(deltas) == 0 and np.percentile(deltas, 90) <= 8
+
+
+def test_what_the_golden_data_discriminates():
+    G = Golden()
+    sub = range(0, 200, 4)
+    base = run_variant(G, oracle, frames=sub)[:3]
+    # sharply: the track threshold
+    for thr in (11, 13):
+        tot, hits, exact, _ = run_variant(G, oracle, track_threshold=thr, frames=sub)
+        assert exact <= 0.02 * tot and hits < 0.8 * base[1]
+    # clearly: 8-connectivity over 4
+    tot, hits, exact, _ = run_variant(G, oracle, connectivity=4, frames=sub)
+    assert hits < base[1] and exact < base[2]
+    # not at all: strictness and value of the detect threshold (anything below the track threshold)
+    for kw in (dict(inclusive=1), dict(detect_threshold=8), dict(detect_threshold=11)):
+        assert run_variant(G, oracle, frames=sub, **kw)[:3] == base
 
 
 def test_bid_decoding_of_golden_rows():
-    z = np.load(FIX)
-    g = z["gold/0"]
+    G = Golden()
+    _, _, g = G.rebuild(0)
     row = g[g[:, 0] == 0][0]
     assert int(row[1]) == 334623465 and int(row[2]) == 264       # test_fish0.csv:2
     assert (int(row[1]) >> 19, (int(row[1]) >> 6) & 8191, int(row[1]) & 63) == (638, 1995, 41)
@@ -69,22 +58,22 @@ def test_bid_decoding_of_golden_rows():
 def test_device_equals_oracle_on_reference_frames():
     import torch
     from trex_amd import capi
-    z = np.load(FIX)
-    frs = [int(f) for f in z["frames"][:4]]
-    H, W = [int(v) for v in z["shape"]]
-    seg = capi.Segmenter(capi.default_params(W, H, max_batch=1, threshold=9, size_ranges=[(1, 10000)]))
-    for fr in frs:
-        img, b = rebuild(z, fr)
+    G = Golden()
+    seg = capi.Segmenter(capi.default_params(G.W, G.H, max_batch=1, threshold=9, size_ranges=[(1, 10000)]))
+    tot = hits = 0
+    for i in range(0, 200, 8):
+        img, b, gold = G.rebuild(i)
         seg.set_background(b)
         d = torch.from_numpy(img).cuda()
         seg.segment_device(d.data_ptr(), 1)
         seg.fetch()
         seg.rethreshold(12, 1, RANGES)
         sub = seg.fetch(rethreshold=True)[0]
-        p = oracle.make_params(W, H, threshold=9, size_ranges=[(1, 10000)])
+        p = oracle.make_params(G.W, G.H, threshold=9, size_ranges=[(1, 10000)])
         ob, orr, opx = oracle.rethreshold_frame(img, b, p, 1, 12, RANGES)
         assert sub.runs.tobytes() == orr.tobytes() and sub.pixels.tobytes() == opx.tobytes()
         assert np.array_equal(sub.blobs["bid"], ob["bid"]) and np.array_equal(sub.blobs["flags"], ob["flags"])
-        h, e, _ = score(sub.blobs, z[f"gold/{fr}"])
-        assert h >= 3
+        h, e, _ = score(sub.blobs, gold)
+        tot += len(gold); hits += h
+    assert hits >= 0.7 * tot
     seg.close()
