@@ -22,14 +22,14 @@
 extern "C" {
 #endif
 
-#define TREXHIP_ABI_VERSION 2
+#define TREXHIP_ABI_VERSION 3
 
 enum {
     TREXHIP_OK = 0,
     TREXHIP_E_INVALID = -1,    /* bad argument / not initialised (e.g. no background yet)   */
     TREXHIP_E_DEVICE = -2,     /* HIP runtime error                                         */
     TREXHIP_E_CAPACITY = -3,   /* a frame exceeded max_runs / pooled output capacity         */
-    TREXHIP_E_UNSUPPORTED = -4,
+    TREXHIP_E_UNSUPPORTED = -4, /* a setting of the reference that this library does not implement was switched on   */
     TREXHIP_E_NOMEM = -5
 };
 
@@ -67,7 +67,14 @@ typedef struct trexhip_params {
      * Tests/test_pixels.cpp:629-795); TREXHIP_ENC_RGB8 3 B/px in the input's memory order (BGRA2BGR).  The colour encodings
      * need colour input (trexhip_segment_color*); detection itself always works on cv::cvtColor(BGR2GRAY) (or color_channel). */
     int32_t pixel_encoding;
-    int32_t reserved_[3];
+    /* Pre-processing options of RawProcessing::generate_binary that are NOT implemented (their arithmetic lives in the un-vendored
+     * commons and nothing in the tree pins it).  They are part of the parameter block so that a caller can hand over what TRex's
+     * settings say: any non-default value makes trexhip_create fail with TREXHIP_E_UNSUPPORTED -- never a silently different mask.
+     *   image_adjust (+ image_contrast_increase / image_brightness_increase / image_square_brightness), blur_difference,
+     *   equalize_histogram, correct_luminance      grabber/misc/default_config.cpp:121-129
+     *   use_adaptive_threshold (+ adaptive_threshold_scale)                         core/default_config.cpp:1161-1162 */
+    int32_t image_adjust, blur_difference, equalize_histogram, correct_luminance, use_adaptive_threshold;
+    int32_t reserved_[2];
 } trexhip_params;
 enum { TREXHIP_ENC_GRAY = 0, TREXHIP_ENC_R3G3B2 = 1, TREXHIP_ENC_RGB8 = 2 };   /* order of cmn::meta_encoding_t */
 
@@ -210,7 +217,7 @@ typedef struct trexhip_split_params {
     int32_t track_threshold;                 /* core/default_config.cpp track_threshold            */
     int32_t track_posture_threshold;
     int32_t calculate_posture;               /* initial threshold = (calculate_posture ? max(both) : track_threshold) + 1 (:512) */
-    int32_t algorithm;                       /* blob_split_algorithm: 0 none, 1 threshold (default, :923), 2 threshold_approximate */
+    int32_t algorithm;                       /* blob_split_algorithm: 0 none, 1 threshold (default, :923), 2 threshold_approximate; 3 fill (cv::watershed, :419-485) and 4 fill_approximate are refused with TREXHIP_E_UNSUPPORTED */
     float   blob_split_max_shrink;           /* :921 (0.2) */
     float   blob_split_global_shrink_limit;  /* :922 (0.2) */
     int32_t n_ranges;                        /* track_size_filter, cm^2, at most 8 ranges */
@@ -254,6 +261,11 @@ typedef struct trexhip_posture_params {
     float   outline_curvature_range_ratio;  /* :891 (0.03)                         */
     float   midline_walk_offset;            /* :892 (0.025)                        */
     int32_t max_points;                     /* capacity per blob (outline points; the traced lattice outline has 2 per pixel edge), even, 8..4096 */
+    /* not implemented, refused with TREXHIP_E_UNSUPPORTED when switched on (never silently ignored):
+     *   posture_closing_steps > 0 (Posture.cpp:335, morphological closing inside threshold_get_biggest_blob),
+     *   peak_mode = broad (1; Outline.cpp:627-661; 0 = pointy, the default :897),
+     *   posture_direction_smoothing > 0 (the movement-history flip of Midline::post_process needs the tracker's previous frames) */
+    int32_t posture_closing_steps, peak_mode, posture_direction_smoothing;
 } trexhip_posture_params;
 typedef struct trexhip_posture_info { int32_t status, n_outline, n_segments, tail_index, head_index, n_traced, reserved[2]; } trexhip_posture_info;
 void trexhip_default_posture_params(trexhip_posture_params* p);
@@ -310,6 +322,7 @@ int trexhip_crops_posture_device(trexhip_ctx* ctx, uint8_t* d_crops, int32_t n_b
  * from a TRex <base>_dict.pth).  BatchNorm is folded and the tensors repacked on load. */
 int trexhip_load_weights(trexhip_ctx* ctx, const void* blob, size_t bytes);
 int trexhip_num_classes(trexhip_ctx* ctx);
+int trexhip_network_channels(trexhip_ctx* ctx);   /* channels of the crops the loaded network expects (1 or 3); 0 without weights */
 /* arithmetic of conv1..fc1.  All modes but BF16X3 meet the 1e-4 softmax bar against the fp32 reference network:
  *   TREXHIP_CNN_FP16X3 (default): every fp32 operand as two fp16 pieces (22 mantissa bits), 3 piece products per product on the
  *       fp16 matrix cores, fp32 accumulate; an activation outside the fp16 range raises a device flag and the layer stack is

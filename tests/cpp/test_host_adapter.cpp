@@ -212,6 +212,62 @@ int main(int argc, char** argv) {
         HipBackgroundSubtraction::init(s2, W, H);
         HipBackgroundSubtraction::set_background(b);
     }
+    // --- a setting of the reference this backend does not implement is refused at init(), not silently ignored ---
+    {
+        const HipBackgroundSubtraction::Settings keep = HipBackgroundSubtraction::settings();
+        for (int which = 0; which < 5; ++which) {
+            HipBackgroundSubtraction::Settings s3 = keep;
+            if (which == 0) s3.image_adjust = true;
+            if (which == 1) s3.blur_difference = 3;
+            if (which == 2) s3.equalize_histogram = true;
+            if (which == 3) s3.correct_luminance = true;
+            if (which == 4) s3.use_adaptive_threshold = true;
+            bool threw = false; std::string what;
+            try { HipBackgroundSubtraction::init(s3, W, H); } catch (const std::exception& e) { threw = true; what = e.what(); }
+            CHECK(threw && what.find("not implemented") != std::string::npos);
+        }
+        HipBackgroundSubtraction::init(keep, W, H);
+        std::vector<uint8_t> bg3(W * H, 120);
+        auto b3 = cmn::Image::Make(H, W, 1); std::memcpy(b3->data(), bg3.data(), bg3.size());
+        HipBackgroundSubtraction::set_background(b3);
+    }
+    // --- a tile of the wrong size fails through the future instead of reading past the image ---
+    {
+        TileImage t; t.images.push_back(cmn::Image::Make(H / 2, W, 3));
+        auto f = HipBackgroundSubtraction::apply(std::move(t));
+        bool threw = false;
+        try { f.get(); } catch (const std::exception&) { threw = true; }
+        CHECK(threw);
+    }
+    // --- one frame beyond the capacities fails ALONE: the other frames of the batch are delivered ---
+    {
+        HipBackgroundSubtraction::Settings s4 = HipBackgroundSubtraction::settings();
+        const HipBackgroundSubtraction::Settings keep = s4;
+        s4.max_blobs = 8; s4.max_batch = 4;
+        HipBackgroundSubtraction::init(s4, W, H);
+        std::vector<uint8_t> bg4(W * H, 120);
+        auto b4 = cmn::Image::Make(H, W, 1); std::memcpy(b4->data(), bg4.data(), bg4.size());
+        HipBackgroundSubtraction::set_background(b4);
+        std::vector<TileImage> tiles; std::vector<std::future<SegmentationData>> futs;
+        for (int k = 0; k < 3; ++k) {
+            std::vector<uint8_t> g(W * H, 120);
+            const int nb = k == 1 ? 40 : 3;                                   // frame 1 holds 40 blobs: more than the whole pool (max_batch * max_blobs = 32)
+            for (int i = 0; i < nb; ++i) for (int q = 0; q < 4; ++q) g[(size_t)(2 + 6 * (i / 10)) * W + 3 + 6 * (i % 10) + q] = 10;
+            TileImage tile; tile.images.push_back(gray_to_bgr(g, W, H, 3, rng, true));
+            tile.promise = std::make_unique<std::promise<SegmentationData>>();
+            futs.push_back(tile.promise->get_future());
+            tiles.emplace_back(std::move(tile));
+        }
+        hooks->apply(std::move(tiles));
+        for (int k = 0; k < 3; ++k) {
+            bool threw = false; std::string what; int n = -1;
+            try { SegmentationData d = futs[k].get(); n = (int)d.frame.n(); } catch (const std::exception& e) { threw = true; what = e.what(); }
+            if (k == 1) CHECK(threw && what.find("capacity") != std::string::npos);
+            else CHECK(!threw && n == 3);
+        }
+        HipBackgroundSubtraction::init(keep, W, H);
+        HipBackgroundSubtraction::set_background(b4);
+    }
     // --- TileImage destroyed with a live promise raises inside the future (core/TileImage.cpp:13-21) ---
     {
         std::future<SegmentationData> f;
@@ -382,6 +438,11 @@ int main(int argc, char** argv) {
         CHECK(HipVINetwork::batch_size_for(8) == 64 && HipVINetwork::batch_size_for(100) == 128 && HipVINetwork::batch_size_for(65) == 128);
         {   // wrong crop size
             std::vector<cmn::Image::Ptr> bad; bad.push_back(cmn::Image::Make(64, 64, 1));
+            auto f = net.probabilities(std::move(bad), [](auto&&, auto&&) {});
+            bool threw = false; try { f.get(); } catch (const std::exception&) { threw = true; } CHECK(threw);
+        }
+        {   // 3-channel crops into a 1-channel network: refused before anything is read past the images
+            std::vector<cmn::Image::Ptr> bad; bad.push_back(cmn::Image::Make(80, 80, 3)); bad.push_back(cmn::Image::Make(80, 80, 3));
             auto f = net.probabilities(std::move(bad), [](auto&&, auto&&) {});
             bool threw = false; try { f.get(); } catch (const std::exception&) { threw = true; } CHECK(threw);
         }

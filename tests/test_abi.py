@@ -76,3 +76,13 @@ def test_no_gpu_means_loud_failure():
         pytest.skip("GPU present")
     with pytest.raises(capi.TrexHipError):
         capi.Segmenter(capi.default_params(64, 64))
+
+
+@pytest.mark.parametrize("name", ["image_adjust", "blur_difference", "equalize_histogram", "correct_luminance", "use_adaptive_threshold"])
+def test_unimplemented_settings_are_refused_not_ignored(name):
+    # parameter validation happens before the device is touched, so this runs without a GPU
+    p = capi.default_params(64, 64, **{name: 1})
+    h = C.c_void_p()
+    rc = capi.lib().trexhip_create(C.byref(p), C.byref(h))
+    assert rc == -4 and h.value is None                                   # TREXHIP_E_UNSUPPORTED
+    assert name.encode() in capi.lib().trexhip_last_error()

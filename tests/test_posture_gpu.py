@@ -256,3 +256,11 @@ def test_large_animals_take_fewer_blobs_per_workgroup():
             ws = oracle.midline_walk(go, pp.midline_walk_offset)
             assert np.array_equal(segs[k, :gi["n_segments"]], ws)
         assert ok == (3 if mp == 4096 else 1)
+
+
+@pytest.mark.parametrize("kw", [dict(posture_closing_steps=1), dict(peak_mode=1), dict(posture_direction_smoothing=2)])
+def test_unimplemented_posture_settings_are_refused(kw):
+    fr, bg = synth.batch("C2", 1)
+    with pytest.raises(capi.TrexHipError) as e:
+        run_posture(fr, bg, **kw)
+    assert e.value.code == -4 and "not implemented" in str(e.value)

@@ -107,7 +107,7 @@ def test_adversarial_patterns():
     f = bg.copy(); f[:, 1023] = 9; f[:, 1024] = 9; f[5, 1000:1100] = 9; frames.append(f)   # chunk boundary
     f = bg.copy(); f[xx % 3 == 0] = 9; frames.append(f)                           # many 1-px runs per row
     for conn in (8, 4):
-        res = run_gpu(np.stack(frames), bg, connectivity=conn, max_runs=200000)
+        res = run_gpu(np.stack(frames), bg, connectivity=conn, max_runs=200000, max_blobs=131072)   # the 4-connected checkerboard alone is 98304 blobs (capacities are per frame)
         for r, fr in zip(res, frames):
             assert_frame_equal(r, fr, bg, connectivity=conn)
     assert len(res[4].blobs) == 0 and res[4].info["n_raw_runs"] == 0

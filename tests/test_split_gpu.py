@@ -109,6 +109,10 @@ def test_capacity_and_errors():
     seg = capi.Segmenter(capi.default_params(W, H, max_batch=1))
     with pytest.raises(capi.TrexHipError):
         seg.split_search_device(1, 1, 1, 1)                   # no batch yet
+    for alg in (3, 4):                                        # blob_split_algorithm fill / fill_approximate (cv::watershed): refused, not ignored
+        with pytest.raises(capi.TrexHipError) as e:
+            seg.split_search_device(1, 1, 1, 1, algorithm=alg)
+        assert e.value.code == -4
     seg.close()
 
 

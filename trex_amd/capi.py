@@ -40,14 +40,18 @@ class Params(C.Structure):
         ("connectivity", C.c_int32), ("dilation_size", C.c_int32), ("use_closing", C.c_int32),
         ("closing_size", C.c_int32), ("n_ranges", C.c_int32),
         ("cm_per_pixel", C.c_double), ("ranges", C.c_double * 16),
-        ("pixel_encoding", C.c_int32), ("reserved_", C.c_int32 * 3),
+        ("pixel_encoding", C.c_int32),
+        # not implemented: any non-zero value makes trexhip_create return TREXHIP_E_UNSUPPORTED
+        ("image_adjust", C.c_int32), ("blur_difference", C.c_int32), ("equalize_histogram", C.c_int32), ("correct_luminance", C.c_int32),
+        ("use_adaptive_threshold", C.c_int32), ("reserved_", C.c_int32 * 2),
     ]
 
 
 class PostureParams(C.Structure):
     _fields_ = [("outline_resample", C.c_float), ("outline_smooth_samples", C.c_int32), ("outline_smooth_step", C.c_int32),
                 ("outline_approximate", C.c_int32), ("outline_curvature_range_ratio", C.c_float),
-                ("midline_walk_offset", C.c_float), ("max_points", C.c_int32)]
+                ("midline_walk_offset", C.c_float), ("max_points", C.c_int32),
+                ("posture_closing_steps", C.c_int32), ("peak_mode", C.c_int32), ("posture_direction_smoothing", C.c_int32)]
 
 
 class MidlineParams(C.Structure):
@@ -94,7 +98,7 @@ class TrexHipError(RuntimeError):
 
 # every symbol include/trexhip.h declares (tests check the library exports all of them)
 SYMBOLS = [
-    "trexhip_abi_version", "trexhip_last_error", "trexhip_default_params", "trexhip_create", "trexhip_destroy",
+    "trexhip_abi_version", "trexhip_network_channels", "trexhip_last_error", "trexhip_default_params", "trexhip_create", "trexhip_destroy",
     "trexhip_set_stream", "trexhip_set_background", "trexhip_set_background_device", "trexhip_set_background_color", "trexhip_set_background_color_device", "trexhip_generate_average_device", "trexhip_get_background", "trexhip_segment_device",
     "trexhip_segment", "trexhip_segment_color", "trexhip_segment_color_device", "trexhip_rethreshold_device", "trexhip_rethreshold_per_blob_device", "trexhip_fetch_rethreshold", "trexhip_fetch", "trexhip_device_view_get", "trexhip_synchronize",
     "trexhip_profile_enable", "trexhip_profile_read", "trexhip_profile_reset",
@@ -150,6 +154,7 @@ def lib():
         L.trexhip_export_id_table_ex_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32]
         L.trexhip_load_weights.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
         L.trexhip_num_classes.argtypes = [C.c_void_p]
+        L.trexhip_network_channels.argtypes = [C.c_void_p]
         L.trexhip_set_identity_precision.argtypes = [C.c_void_p, C.c_int32]
         L.trexhip_identify_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]
         L.trexhip_identify.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]

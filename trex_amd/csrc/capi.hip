@@ -87,6 +87,7 @@ static int fill_cfg(trexhip_ctx* ctx) {
     c.pool_blobs = (uint32_t)p.max_batch * (uint32_t)p.max_blobs;
     c.pool_runs = (uint32_t)p.max_batch * (uint32_t)p.max_runs;
     c.pool_pixels = (uint32_t)p.max_batch * (uint32_t)p.max_pixels;
+    c.cap_blobs = (uint32_t)p.max_blobs; c.cap_pixels = (uint32_t)p.max_pixels;
     return TREXHIP_OK;
 }
 
@@ -135,6 +136,15 @@ int trexhip_create(const trexhip_params* p, trexhip_ctx** out) {
         set_error("trexhip_create: max_batch * max_pixels / max_runs / max_blobs must stay below 2^32 (pooled tables are indexed with 32 bits)"); return TREXHIP_E_INVALID;
     }
     if (p->connectivity != 8 && p->connectivity != 4) { set_error("trexhip_create: connectivity must be 4 or 8"); return TREXHIP_E_INVALID; }
+    {   // settings of the reference that are not implemented: refuse, never diverge silently
+        const struct { int32_t v; const char* name; } off[] = {{p->image_adjust, "image_adjust"}, {p->blur_difference, "blur_difference"},
+            {p->equalize_histogram, "equalize_histogram"}, {p->correct_luminance, "correct_luminance"}, {p->use_adaptive_threshold, "use_adaptive_threshold"}};
+        for (const auto& o : off)
+            if (o.v != 0) {
+                set_error(std::string("trexhip_create: ") + o.name + " is not implemented by this backend (RawProcessing's optional pre-processing); switch it off or use the CPU detector");
+                return TREXHIP_E_UNSUPPORTED;
+            }
+    }
     if (p->n_ranges < 0 || p->n_ranges > 8) { set_error("trexhip_create: n_ranges must be 0..8"); return TREXHIP_E_INVALID; }
     if ((p->use_closing && (p->closing_size < 1 || p->closing_size > 15)) || p->dilation_size > 7 || p->dilation_size < -7) {
         set_error("trexhip_create: structuring elements larger than 15x15 are not supported (closing_size <= 15, |dilation_size| <= 7)");

@@ -2138,6 +2138,11 @@ int trexhip_num_classes(trexhip_ctx* ctx) {
     return static_cast<Net*>(ctx->net)->classes;
 }
 
+int trexhip_network_channels(trexhip_ctx* ctx) {
+    if (!ctx || !ctx->net) return 0;
+    return static_cast<Net*>(ctx->net)->CH;
+}
+
 }  // extern "C"
 
 namespace trexhip {

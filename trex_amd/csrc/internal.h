@@ -35,6 +35,7 @@ struct SegCfg {
     float sqcm;
     double ranges[16];
     uint32_t pool_blobs, pool_runs, pool_pixels;
+    uint32_t cap_blobs, cap_pixels;   // per frame (max_blobs, max_pixels): a frame beyond them fails alone, before it reserves pooled space
 };
 
 // live kernel timing: event pairs are recorded on the ctx stream and only read (folded) on

@@ -553,6 +553,10 @@ extern "C" int trexhip_posture_device(trexhip_ctx* ctx, int32_t table, const tre
         set_error("trexhip_posture_device: outline_smooth_samples*outline_smooth_step must be <= 16"); return TREXHIP_E_UNSUPPORTED;
     }
     if (pp->outline_approximate > 3) { set_error("trexhip_posture_device: outline_approximate > 3 is not supported"); return TREXHIP_E_UNSUPPORTED; }
+    // settings whose arithmetic is not built (it lives in the un-vendored commons and nothing in the tree pins it): refuse
+    if (pp->posture_closing_steps != 0) { set_error("trexhip_posture_device: posture_closing_steps > 0 is not implemented (closing inside pixel::threshold_get_biggest_blob, Posture.cpp:335)"); return TREXHIP_E_UNSUPPORTED; }
+    if (pp->peak_mode != 0) { set_error("trexhip_posture_device: peak_mode = broad is not implemented (needs periodic::find_peaks' peak ranges / integrals, Outline.cpp:627-661); only pointy"); return TREXHIP_E_UNSUPPORTED; }
+    if (pp->posture_direction_smoothing != 0) { set_error("trexhip_posture_device: posture_direction_smoothing > 0 is not implemented (Midline::post_process' movement history is tracker state)"); return TREXHIP_E_UNSUPPORTED; }
     if (!ctx->d_frames || ctx->last_n == 0 || !ctx->fetched) { set_error("trexhip_posture_device: segment and fetch a batch first"); return TREXHIP_E_INVALID; }
     if (n_blobs < 0 || (uint32_t)n_blobs > ctx->cfg.pool_blobs) { set_error("trexhip_posture_device: n_blobs outside the blob pool"); return TREXHIP_E_INVALID; }
     if (n_blobs == 0) return TREXHIP_OK;
@@ -608,4 +612,5 @@ extern "C" void trexhip_default_posture_params(trexhip_posture_params* p) {
     if (!p) return;
     p->outline_resample = 1.0f; p->outline_smooth_samples = 4; p->outline_smooth_step = 1; p->outline_approximate = 3;
     p->outline_curvature_range_ratio = 0.03f; p->midline_walk_offset = 0.025f; p->max_points = 512;
+    p->posture_closing_steps = 0; p->peak_mode = 0; p->posture_direction_smoothing = 0;
 }

@@ -595,6 +595,13 @@ __global__ __launch_bounds__(256) void k_blobs(const SegCfg c, const int only_pe
         }
         kept += t0; kruns += t1; kpx += t2;
     }
+    // a frame beyond its own capacities fails alone and reserves nothing: the pool (max_batch x the per-frame capacities) then
+    // always has room for the other frames of the batch
+    if (kept > c.cap_blobs || kpx > c.cap_pixels) {
+        fi.n_raw_blobs = nraw;
+        if (tid == 0) { fi.flags |= TREXHIP_FRAME_OVERFLOW_OUTPUT; info[f] = fi; }
+        return;
+    }
     // reserve pooled output (blobs, runs, pixels) for this frame
     if (tid == 0) {
         const uint32_t bb = atomicAdd(totals + 0, kept);
@@ -860,6 +867,11 @@ __global__ __launch_bounds__(1024) void k_ccl_lds(const SegCfg c, const uint32_t
         kept += t0; kruns += t1; kpx += t2;
     }
     __syncthreads();
+    if (kept > c.cap_blobs || kpx > c.cap_pixels) {        // beyond this frame's own capacities: fails alone, reserves nothing (see k_blobs)
+        fi.n_raw_blobs = nraw;
+        if (tid == 0) { fi.flags |= TREXHIP_FRAME_OVERFLOW_OUTPUT; info[f] = fi; }
+        return;
+    }
     if (tid == 0) {
         // totals[0],[1] = blobs, runs reserved with ONE 64-bit atomic; totals[2] = pixels
         const unsigned long long br = atomicAdd(reinterpret_cast<unsigned long long*>(totals),

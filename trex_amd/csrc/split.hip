@@ -355,7 +355,8 @@ extern "C" int trexhip_split_search_device(trexhip_ctx* ctx, const trexhip_split
                                            int32_t n_blobs, int32_t* d_thresholds, trexhip_split_info* d_info) {
     if (!ctx || !sp || !d_presumed_nr || !d_thresholds || !d_info) { set_error("trexhip_split_search_device: null argument"); return TREXHIP_E_INVALID; }
     if (method < 0 || method > 2) { set_error("trexhip_split_search_device: method must be 0 (absolute), 1 (signed) or 2 (none)"); return TREXHIP_E_INVALID; }
-    if (sp->algorithm < 0 || sp->algorithm > 2) { set_error("trexhip_split_search_device: algorithm must be 0 (none), 1 (threshold) or 2 (threshold_approximate); the watershed algorithm is not built"); return TREXHIP_E_INVALID; }
+    if (sp->algorithm == 3 || sp->algorithm == 4) { set_error("trexhip_split_search_device: blob_split_algorithm = fill / fill_approximate (cv::watershed, SplitBlob.cpp:419-485) is not implemented by this backend"); return TREXHIP_E_UNSUPPORTED; }
+    if (sp->algorithm < 0 || sp->algorithm > 2) { set_error("trexhip_split_search_device: algorithm must be 0 (none), 1 (threshold) or 2 (threshold_approximate)"); return TREXHIP_E_INVALID; }
     if (sp->n_ranges < 0 || sp->n_ranges > 8) { set_error("trexhip_split_search_device: at most 8 size ranges"); return TREXHIP_E_INVALID; }
     if (!ctx->d_frames || ctx->last_n == 0 || !ctx->fetched) { set_error("trexhip_split_search_device: segment and fetch a batch first"); return TREXHIP_E_INVALID; }
     if (n_blobs < 0 || (uint32_t)n_blobs > ctx->cfg.pool_blobs) { set_error("trexhip_split_search_device: n_blobs outside the blob pool"); return TREXHIP_E_INVALID; }

@@ -19,6 +19,7 @@
 #else
 #include "trex_types.h"
 #endif
+#include <algorithm>
 #include <chrono>
 #include <thread>
 #include <shared_mutex>
@@ -36,6 +37,16 @@ struct HipBackgroundSubtraction {
         std::vector<std::pair<double, double>> detect_size_filter;
         cmn::meta_encoding_t meta_encoding = cmn::meta_encoding_t::gray;
         int device = 0, max_batch = 8;
+        // capacities per frame (0 = scaled with the frame size in init()): raw horizontal lines, kept blobs, kept foreground pixels.
+        // A frame that exceeds one fails alone (its promise gets the exception); the other frames of the batch are delivered.
+        int max_runs = 0, max_blobs = 0, max_pixels = 0;
+        // optional pre-processing of RawProcessing::generate_binary that this backend does NOT implement: init() throws when TRex's
+        // settings switch one on (grabber/misc/default_config.cpp:121-129, core/default_config.cpp:1161-1162) -- never a silent divergence
+        bool image_adjust = false, equalize_histogram = false, correct_luminance = false, use_adaptive_threshold = false;
+        int blur_difference = 0;
+        // morphology that IS implemented (core/default_config.cpp:1163-1165)
+        int dilation_size = 0, closing_size = 3;
+        bool use_closing = false;
     };
 
     static void init(const Settings& s, uint32_t width, uint32_t height) {
@@ -49,6 +60,14 @@ struct HipBackgroundSubtraction {
         p.threshold = s.detect_threshold; p.threshold_maximum = s.threshold_maximum;
         p.absolute_difference = s.detect_threshold_is_absolute; p.enable_difference = s.enable_difference;
         p.image_invert = s.image_invert; p.cm_per_pixel = s.cm_per_pixel;
+        p.dilation_size = s.dilation_size; p.use_closing = s.use_closing; p.closing_size = s.closing_size;
+        p.image_adjust = s.image_adjust; p.blur_difference = s.blur_difference; p.equalize_histogram = s.equalize_histogram;
+        p.correct_luminance = s.correct_luminance; p.use_adaptive_threshold = s.use_adaptive_threshold;   // non-default -> trexhip_create refuses
+        // capacities scale with the frame: at most one line per two pixels of a row, one foreground pixel in four, one blob per 32x32 pixels
+        const uint64_t px = (uint64_t)width * height;
+        p.max_runs = s.max_runs > 0 ? s.max_runs : (int32_t)std::min<uint64_t>(std::max<uint64_t>(65536, px / 16), 1u << 22);
+        p.max_pixels = s.max_pixels > 0 ? s.max_pixels : (int32_t)std::min<uint64_t>(std::max<uint64_t>(1u << 20, px / 4), 1u << 26);
+        p.max_blobs = s.max_blobs > 0 ? s.max_blobs : (int32_t)std::min<uint64_t>(std::max<uint64_t>(2048, px / 1024), 1u << 16);
         // pixel arrays in the frame's meta_encoding (the encoding is fixed per context: it sizes the pixel pool)
         p.pixel_encoding = s.meta_encoding == cmn::meta_encoding_t::rgb8 ? TREXHIP_ENC_RGB8
                          : s.meta_encoding == cmn::meta_encoding_t::r3g3b2 ? TREXHIP_ENC_R3G3B2 : TREXHIP_ENC_GRAY;
@@ -56,6 +75,7 @@ struct HipBackgroundSubtraction {
         p.n_ranges = (int32_t)s.detect_size_filter.size();
         for (int i = 0; i < p.n_ranges && i < 8; ++i) { p.ranges[2 * i] = s.detect_size_filter[i].first; p.ranges[2 * i + 1] = s.detect_size_filter[i].second; }
         check(trexhip_create(&p, &d.ctx));
+        d.width = width; d.height = height;
         d.has_background = false;
     }
 
@@ -101,7 +121,9 @@ struct HipBackgroundSubtraction {
     static void apply(std::vector<TileImage>&& tiled) {
         const auto t0 = std::chrono::steady_clock::now();
         auto& d = data();
-        std::shared_lock guard(d.gpu_mutex);                        // BackgroundSubtraction.cpp:130
+        // the reference takes a shared lock here (BackgroundSubtraction.cpp:130) because its per-call state is thread-local; this backend
+        // has ONE device context (staging buffers, pinned result tables), so concurrent apply() calls are serialised
+        std::unique_lock guard(d.gpu_mutex);
         // one device batch per call: all tiles' first images (1 tile == full frame for bg-sub, DetectionTypes.cpp:294-295)
         size_t i = 0;
         std::string batch_error;
@@ -121,23 +143,37 @@ struct HipBackgroundSubtraction {
                     if (image->dims != 3 && image->dims != 4) { ok = false; batch_error = "Invalid number of channels in input image for the network."; }
                     if (channels == 0) channels = (int)image->dims;
                     if ((int)image->dims != channels) { ok = false; batch_error = "mixed channel counts in one batch"; }
+                    // the reference asserts the tile size against the average image (BackgroundSubtraction.cpp:195-199); a smaller tile
+                    // would make the upload read past the image
+                    if (image->cols != d.width || image->rows != d.height) { ok = false; batch_error = "tile image size does not match the size the backend was initialised with"; }
                     ptrs.push_back(image->data());
                 }
         }
         trexhip_batch_result res{};
         if (ok && !ptrs.empty()) {
             if ((int)ptrs.size() > d.settings.max_batch) { ok = false; batch_error = "more tile images than max_batch"; }
-            else if (trexhip_segment_color(d.ctx, ptrs.data(), (int32_t)(tiled[0].images[0]->cols * channels), (int32_t)ptrs.size(),
-                                           channels, d.settings.color_channel) != 0 ||
-                     trexhip_fetch(d.ctx, &res) != 0) { ok = false; batch_error = trexhip_last_error(); }
+            else if (trexhip_segment_color(d.ctx, ptrs.data(), (int32_t)(d.width * (uint32_t)channels), (int32_t)ptrs.size(),
+                                           channels, d.settings.color_channel) != 0) { ok = false; batch_error = trexhip_last_error(); }
+            else {
+                // TREXHIP_E_CAPACITY is per frame: the tables stay valid for every frame whose frame_info.flags is 0, only the flagged
+                // frames fail (the reference has no capacity limits and handles each tile on its own, BackgroundSubtraction.cpp:146-342)
+                const int rc = trexhip_fetch(d.ctx, &res);
+                if (rc != 0 && rc != TREXHIP_E_CAPACITY) { ok = false; batch_error = trexhip_last_error(); }
+            }
         }
         size_t img_index = 0;
         for (auto&& tile : tiled) {
             try {
                 if (!ok) throw std::runtime_error(batch_error);
                 tile.data.frame.set_encoding(d.settings.meta_encoding);            // :303
-                for (size_t k = 0; k < tile.images.size(); ++k, ++img_index) {
-                    const trexhip_frame_info& fi = res.frames[img_index];
+                for (size_t k = 0; k < tile.images.size(); ++k) {
+                    const trexhip_frame_info& fi = res.frames[img_index + k];
+                    if (fi.flags != 0)
+                        throw std::runtime_error("frame exceeds the backend's capacity (" + std::string((fi.flags & TREXHIP_FRAME_OVERFLOW_RUNS) ? "max_runs" : "max_blobs / max_pixels") +
+                                                 "): raise HipBackgroundSubtraction::Settings::max_runs / max_blobs / max_pixels");
+                }
+                for (size_t k = 0; k < tile.images.size(); ++k) {
+                    const trexhip_frame_info& fi = res.frames[img_index + k];
                     for (uint32_t b = 0; b < fi.n_blobs; ++b) {
                         const trexhip_blob& B = res.blobs[fi.blob_begin + b];
                         if (B.n_runs >= UINT16_MAX) continue;                       // :306-313
@@ -155,6 +191,7 @@ struct HipBackgroundSubtraction {
             } catch (...) {
                 if (tile.promise) { tile.promise->set_exception(std::current_exception()); tile.promise = nullptr; }   // :322-325
             }
+            img_index += tile.images.size();
             try { if (tile.callback) tile.callback(); } catch (...) {}              // :328-334
             for (auto& image : tile.images) buffers::TileBuffers::get().move_back(std::move(image));   // :336-339
             tile.images.clear();
@@ -208,6 +245,7 @@ struct HipBackgroundSubtraction {
 private:
     struct Data {
         trexhip_ctx* ctx = nullptr;
+        uint32_t width = 0, height = 0;
         Settings settings;
         detect::ObjectDetectionType::Class type{};
         bool has_type = false;

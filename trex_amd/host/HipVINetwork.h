@@ -50,12 +50,11 @@ struct HipVINetwork {
             if (!weights_loaded()) throw std::runtime_error("weights not loaded");
             const int C = num_classes();
             std::vector<uint8_t> crops;
-            size_t per = 0;
+            const size_t per = (size_t)80 * 80 * (size_t)trexhip_network_channels(_ctx);     // what the network was built for
             for (auto& im : images) {
                 if (!im) throw std::runtime_error("null image");
                 if (im->rows != 80 || im->cols != 80) throw std::runtime_error("Invalid image size (expected individual_image_size 80x80)");  // visual_recognition_torch.py:1006-1018
-                if (per == 0) per = im->size();
-                if (im->size() != per) throw std::runtime_error("Invalid image channels");
+                if (im->size() != per) throw std::runtime_error("Invalid image channels (the network expects " + std::to_string(trexhip_network_channels(_ctx)) + ")");
                 crops.insert(crops.end(), im->data(), im->data() + im->size());
             }
             std::vector<float> flat(images.size() * (size_t)C);
