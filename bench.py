@@ -50,8 +50,8 @@ def main():
                     help="individual_image_normalization of the identity crops; posture = outline -> midline -> Midline::transform -> warpAffine (implies --with-posture)")
     ap.add_argument("--encoding", default="gray", choices=["gray", "rgb8"],
                     help="meta_encoding: gray = the BASELINE workload (gray frames); rgb8 = BGRA frames in HBM -> cvtColor on the device, 3-byte pixel arrays, 3-channel crops and network")
-    ap.add_argument("--input", default="gray", choices=["gray", "bgra"],
-                    help="bgra: the tiles as TRex hands them over (BGRA, BackgroundSubtraction.cpp:162-180): cv::cvtColor runs on the device inside the timed step (as-deployed secondary row of SURVEY 8d; --encoding rgb8 implies it)")
+    ap.add_argument("--input", default="gray", choices=["gray", "bgra", "host-gray", "host-bgra"],
+                    help="bgra: the tiles as TRex hands them over (BGRA, BackgroundSubtraction.cpp:162-180), resident in HBM: cv::cvtColor runs on the device inside the timed step; host-bgra / host-gray: the same tiles in PAGEABLE HOST memory, through trexhip_segment_color / trexhip_segment -- the PCIe-inclusive as-deployed row of SURVEY 8d (never the headline value)")
     ap.add_argument("--no-pipeline", dest="pipeline", action="store_false", help="one context, strictly serial steps (no overlap of detect(i+1) with identity(i))")
     ap.add_argument("--lanes", type=int, default=2, help="software-pipeline depth: contexts whose batches are in flight (detect of batch i+L-1 is issued while the identity network works on batch i)")
     ap.add_argument("--no-detect-priority", dest="detect_priority", action="store_false",
@@ -98,9 +98,14 @@ def main():
     # frame-sharded: rank r owns frames r*B .. r*B+B-1 of every step's block (distinct data per rank)
     frames, bg = synth.batch_torch(args.config, B, dev, t0=rank * B)
     rgb = args.encoding == "rgb8"
-    bgra_in = rgb or args.input == "bgra"
+    host_in = args.input.startswith("host-")
+    bgra_in = rgb or args.input in ("bgra", "host-bgra")
     if bgra_in:     # the same scenes as BGRA tiles (what TRex's TileImage holds)
         frames_c = torch.stack([frames, frames, frames, torch.full_like(frames, 255)], dim=-1).contiguous()
+    host_frames = None
+    if host_in:     # distinct pageable buffers, one per tile, like TRex's pooled Image::Ptr
+        src = frames_c if bgra_in else frames
+        host_frames = [np.ascontiguousarray(src[i].cpu().numpy()) for i in range(B)]
     max_blobs = 4 * n_ind
     state = weights.synthetic_state(classes, 4242, channels=3 if args.encoding == "rgb8" else 1)
     from trex_amd.pipeline import Pipeline
@@ -108,7 +113,7 @@ def main():
     pipe = Pipeline(W, H, n_ind, B, classes, bg, weights.pack_blob(state, classes, channels=3 if rgb else 1) if with_cnn else None,
                     local=local, rank=rank, world=world, use_dist=use_dist, with_cnn=with_cnn, with_posture=args.with_posture,
                     normalize=args.normalize, rgb=rgb, bgra_in=bgra_in, cnn_mode=args.cnn_mode, lanes=args.lanes, pipeline=args.pipeline,
-                    detect_priority=args.detect_priority)
+                    detect_priority=args.detect_priority, host_frames=host_frames)
     lanes = pipe.lanes
     seg = lanes[0].seg
     frames_ptr = frames_c.data_ptr() if bgra_in else frames.data_ptr()
@@ -188,7 +193,7 @@ def main():
                                f"80x80x1 crops, {classes}-way V118_3 (random-init weights)",
                    "stages": "detect(bg-sub+threshold+CCL+filter+gather, tables->host) + crops(none) + identity CNN (V118_3) + per-blob ID table (all-gathered when N>1) -> rank-0 host"
                              if with_cnn else "detect only (bg-sub+threshold+CCL+filter+gather, tables->host)",
-                   "frames_per_step_per_gpu": B, "encoding": args.encoding, "input": "bgra tiles (cvtColor on the device inside the step)" if bgra_in else "gray frames", "posture": bool(args.with_posture), "individual_image_normalization": args.normalize, "pipelined_lanes": len(lanes), "blobs_per_step_rank0": n_blobs, "parallelism": f"frame-sharded x{world}"},
+                   "frames_per_step_per_gpu": B, "encoding": args.encoding, "input": ("host " if host_in else "") + ("bgra tiles (cvtColor on the device inside the step)" if bgra_in else "gray frames") + (" in pageable host memory, PCIe inside the step" if host_in else " resident in HBM"), "posture": bool(args.with_posture), "individual_image_normalization": args.normalize, "pipelined_lanes": len(lanes), "blobs_per_step_rank0": n_blobs, "parallelism": f"frame-sharded x{world}"},
     }
     seg_roof = {"kernel": "k_rows", "bound": "hbm", "achieved": seg_bytes / rows_s / 1e9 if rows_s else 0.0, "peak": 8000.0,
                 "unit": "GB/s", "frac": seg_bytes / rows_s / 8e12 if rows_s else 0.0, "traffic": pmc_traffic("trexhip::k_rows"),
@@ -200,6 +205,15 @@ def main():
                 # also against the copy bandwidth measured on this part (MI355X_MICROARCH.md: 6.29 TB/s)
                 "frac_of_measured_copy_bw": seg_bytes / rows_s / 6.29e12 if rows_s else None,
                 "whole_detect_pass_frac_of_measured_copy_bw": seg_bytes / segall_s / 6.29e12 if segall_s else None}
+    if host_in:
+        bytes_step = float(B * W * H * (4 if bgra_in else 1))
+        up = [ln.seg.profile_read(capi.STAGE_UPLOAD_COPY) + ln.seg.profile_read(capi.STAGE_UPLOAD_DMA) for ln in lanes]
+        cms = sum(u[0] for u in up); cn = sum(u[1] for u in up); dms = sum(u[2] for u in up); dn = sum(u[3] for u in up)
+        out["host_input"] = {"bytes_per_step": bytes_step, "pcie_GB_per_s": bytes_step * world * args.steps / dt / 1e9, "pcie_peak_GB_per_s": 63.0,
+                             "frac_of_pcie_peak": bytes_step * world * args.steps / dt / 63e9,
+                             "host_copy_ms_per_frame": cms / cn if cn else None, "dma_ms_per_frame": dms / dn if dn else None,
+                             "dma_GB_per_s": (bytes_step / B) / (dms / dn * 1e-3) / 1e9 if dn and dms else None,
+                             "note": "pageable tiles -> pinned ring (host threads) -> HBM (async DMA per frame); the two legs overlap, the segment kernels and the identity network of the previous batch overlap both"}
     if with_cnn:
         c3_s = avg_s("CONV3")
         fl = FLOP_PER_CROP_CONV3 * n_blobs

@@ -356,7 +356,10 @@ int trexhip_export_id_table_ex_device(trexhip_ctx* ctx, const float* d_probs, in
 /* live HIP-event timing of the dominant kernels on the ctx stream (bench.py roofline):
  * stage ids TREXHIP_STAGE_* ; returns accumulated milliseconds and launch count since reset */
 enum { TREXHIP_STAGE_ROWS = 0, TREXHIP_STAGE_SEGMENT_ALL = 1, TREXHIP_STAGE_CONV2 = 2, TREXHIP_STAGE_CONV3 = 3,
-       TREXHIP_STAGE_CNN_ALL = 4, TREXHIP_STAGE_CROPS = 5, TREXHIP_STAGE_POSTURE = 6, TREXHIP_STAGE_COUNT = 8 };
+       TREXHIP_STAGE_CNN_ALL = 4, TREXHIP_STAGE_CROPS = 5, TREXHIP_STAGE_POSTURE = 6,
+       /* host-pointer entry points (trexhip_segment, trexhip_segment_color): per FRAME, always collected -- host milliseconds spent copying
+        * pageable tiles into the pinned ring, and DMA milliseconds (HIP events on the copy stream).  The two legs overlap each other. */
+       TREXHIP_STAGE_UPLOAD_COPY = 8, TREXHIP_STAGE_UPLOAD_DMA = 9, TREXHIP_STAGE_COUNT = 10 };
 int trexhip_profile_enable(trexhip_ctx* ctx, int32_t on);
 int trexhip_profile_read(trexhip_ctx* ctx, int32_t stage, double* total_ms, int64_t* launches);
 int trexhip_profile_reset(trexhip_ctx* ctx);

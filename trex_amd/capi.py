@@ -28,6 +28,7 @@ assert BLOB_DTYPE.itemsize == 104 and RUN_DTYPE.itemsize == 8 and INFO_DTYPE.ite
 
 CNN_FP32, CNN_BF16X6, CNN_BF16X3, CNN_FP16X3 = 0, 1, 2, 3
 STAGE_ROWS, STAGE_SEGMENT_ALL, STAGE_CONV2, STAGE_CONV3, STAGE_CNN_ALL, STAGE_CROPS, STAGE_POSTURE = 0, 1, 2, 3, 4, 5, 6
+STAGE_UPLOAD_COPY, STAGE_UPLOAD_DMA = 8, 9       # host-input legs (per frame): pageable -> pinned copy (host ms), DMA (event ms)
 
 
 class Params(C.Structure):

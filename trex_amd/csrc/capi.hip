@@ -224,6 +224,7 @@ void trexhip_destroy(trexhip_ctx* ctx) {
                    ctx->d_raster, ctx->d_parent, ctx->d_root_ord, ctx->d_cnt_runs, ctx->d_cnt_px, ctx->d_cur_run,
                    ctx->d_pix_begin, ctx->d_blob_map, ctx->d_info, ctx->d_blobs, ctx->d_blob_frame, ctx->d_runs, ctx->d_pixels, ctx->d_color, ctx->d_bits[0], ctx->d_bits[1], ctx->d_warp, ctx->d_bg_color};
     for (void* p : dev) if (p) hipFree(p);
+    upload_free(ctx);
     void* host[] = {ctx->h_info, ctx->h_totals, ctx->h_blobs, ctx->h_runs, ctx->h_pixels, ctx->h_staging, ctx->h_color};
     for (void* p : host) if (p) hipHostFree(p);
     stage_free(ctx);
@@ -326,18 +327,12 @@ int trexhip_segment(trexhip_ctx* ctx, const uint8_t* const* frames, int32_t stri
     if (!ctx->d_staging) {
         rc = dmalloc(&ctx->d_staging, (size_t)ctx->p.max_batch * W * H + 16);
         if (rc) return rc;
-        rc = hmalloc(&ctx->h_staging, (size_t)ctx->p.max_batch * W * H);
-        if (rc) return rc;
     }
-    // the previous batch may still be reading the staging buffers
-    TH_CHECK_HIP(hipStreamSynchronize(ctx->stream));
-    for (int i = 0; i < n; ++i) {
+    for (int i = 0; i < n; ++i)
         if (!frames[i]) { set_error("trexhip_segment: null frame pointer"); return TREXHIP_E_INVALID; }
-        uint8_t* dst = ctx->h_staging + (size_t)i * W * H;
-        if ((size_t)stride == W) std::memcpy(dst, frames[i], W * H);
-        else for (size_t y = 0; y < H; ++y) std::memcpy(dst + y * W, frames[i] + y * (size_t)stride, W);
-    }
-    TH_CHECK_HIP(hipMemcpyAsync(ctx->d_staging, ctx->h_staging, (size_t)n * W * H, hipMemcpyHostToDevice, ctx->stream));
+    // pageable frame -> pinned ring slot (host threads) -> HBM, one async DMA per frame overlapping the next frame's staging (upload.hip)
+    rc = upload_frames(ctx, frames, n, H, W, (size_t)stride, ctx->d_staging, nullptr);
+    if (rc) return rc;
     return launch_segment(ctx, ctx->d_staging, n);
 }
 
@@ -486,6 +481,19 @@ int trexhip_profile_enable(trexhip_ctx* ctx, int32_t on) {
 
 int trexhip_profile_read(trexhip_ctx* ctx, int32_t stage, double* total_ms, int64_t* launches) {
     if (!ctx || stage < 0 || stage >= TREXHIP_STAGE_COUNT) { set_error("trexhip_profile_read: bad argument"); return TREXHIP_E_INVALID; }
+    if (stage == TREXHIP_STAGE_UPLOAD_COPY || stage == TREXHIP_STAGE_UPLOAD_DMA) {     // host-input legs (upload.hip), per frame
+        Uploader& u = ctx->up;
+        if (stage == TREXHIP_STAGE_UPLOAD_DMA)
+            for (int k = 0; k < UP_SLOTS; ++k)
+                if (u.busy[k] && hipEventQuery(u.ev_done[k]) == hipSuccess) {
+                    float ms = 0.f;
+                    if (hipEventElapsedTime(&ms, u.ev_start[k], u.ev_done[k]) == hipSuccess) { u.dma_ms += ms; u.dma_n += u.frames_in[k]; }
+                    u.busy[k] = false;
+                }
+        if (total_ms) *total_ms = stage == TREXHIP_STAGE_UPLOAD_COPY ? u.copy_ms : u.dma_ms;
+        if (launches) *launches = stage == TREXHIP_STAGE_UPLOAD_COPY ? u.copy_n : u.dma_n;
+        return TREXHIP_OK;
+    }
     stage_read(ctx, stage);
     Stage& s = ctx->stages[stage];
     if (total_ms) *total_ms = s.total_ms;
@@ -496,6 +504,9 @@ int trexhip_profile_read(trexhip_ctx* ctx, int32_t stage, double* total_ms, int6
 int trexhip_profile_reset(trexhip_ctx* ctx) {
     if (!ctx) { set_error("null ctx"); return TREXHIP_E_INVALID; }
     for (int i = 0; i < TREXHIP_STAGE_COUNT; ++i) { stage_read(ctx, i); ctx->stages[i].total_ms = 0.0; ctx->stages[i].launches = 0; }
+    for (int k = 0; k < UP_SLOTS; ++k)                       // uploads still in flight belong to the period before the reset
+        if (ctx->up.busy[k]) { (void)hipEventSynchronize(ctx->up.ev_done[k]); ctx->up.busy[k] = false; }
+    ctx->up.copy_ms = ctx->up.dma_ms = 0.0; ctx->up.copy_n = ctx->up.dma_n = 0;
     return TREXHIP_OK;
 }
 

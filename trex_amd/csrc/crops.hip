@@ -294,21 +294,16 @@ extern "C" int trexhip_segment_color(trexhip_ctx* ctx, const uint8_t* const* fra
     if (n == 0) { ctx->last_n = 0; ctx->fetched = false; return TREXHIP_OK; }
     if (!ctx->d_staging) {
         TH_CHECK_HIP(hipMalloc(reinterpret_cast<void**>(&ctx->d_staging), (size_t)ctx->p.max_batch * W * H + 16));
-        TH_CHECK_HIP(hipHostMalloc(reinterpret_cast<void**>(&ctx->h_staging), (size_t)ctx->p.max_batch * W * H, hipHostMallocDefault));
     }
-    if (!ctx->d_color) {
-        TH_CHECK_HIP(hipMalloc(reinterpret_cast<void**>(&ctx->d_color), (size_t)ctx->p.max_batch * W * H * 4 + 16));
-        TH_CHECK_HIP(hipHostMalloc(reinterpret_cast<void**>(&ctx->h_color), (size_t)ctx->p.max_batch * W * H * 4, hipHostMallocDefault));
-    }
-    TH_CHECK_HIP(hipStreamSynchronize(ctx->stream));
-    const size_t row = W * channels;
-    for (int i = 0; i < n; ++i) {
+    if (!ctx->d_color) TH_CHECK_HIP(hipMalloc(reinterpret_cast<void**>(&ctx->d_color), (size_t)ctx->p.max_batch * W * H * 4 + 16));
+    for (int i = 0; i < n; ++i)
         if (!frames[i]) { set_error("trexhip_segment_color: null frame pointer"); return TREXHIP_E_INVALID; }
-        uint8_t* dst = ctx->h_color + (size_t)i * H * row;
-        for (size_t y = 0; y < H; ++y) std::memcpy(dst + y * row, frames[i] + y * (size_t)stride, row);
-    }
-    TH_CHECK_HIP(hipMemcpyAsync(ctx->d_color, ctx->h_color, (size_t)n * H * row, hipMemcpyHostToDevice, ctx->stream));
-    int rc = launch_to_gray(ctx, ctx->d_color, ctx->d_staging, (size_t)n * W * H, channels, color_channel);
+    // frame by frame: pageable tile -> pinned ring slot (host threads) -> HBM (DMA on the copy stream) -> cv::cvtColor on the compute
+    // stream as soon as the frame has landed; the next frame's staging and DMA run meanwhile (upload.hip)
+    const size_t row = W * channels, fpx = W * H;
+    int rc = upload_frames(ctx, frames, n, H, row, (size_t)stride, ctx->d_color, [&](int i0, int cnt) {
+        return launch_to_gray(ctx, ctx->d_color + (size_t)i0 * H * row, ctx->d_staging + (size_t)i0 * fpx, fpx * (size_t)cnt, channels, color_channel);
+    });
     if (rc) return rc;
     ctx->d_color_src = ctx->d_color; ctx->color_ch = channels;       // the colour pixel encodings gather from here
     return launch_segment(ctx, ctx->d_staging, n);
@@ -328,7 +323,6 @@ extern "C" int trexhip_segment_color_device(trexhip_ctx* ctx, const uint8_t* d_c
     if (n == 0) { ctx->last_n = 0; ctx->fetched = false; return TREXHIP_OK; }
     if (!ctx->d_staging) {
         TH_CHECK_HIP(hipMalloc(reinterpret_cast<void**>(&ctx->d_staging), (size_t)ctx->p.max_batch * W * H + 16));
-        TH_CHECK_HIP(hipHostMalloc(reinterpret_cast<void**>(&ctx->h_staging), (size_t)ctx->p.max_batch * W * H, hipHostMallocDefault));
     }
     int rc = launch_to_gray(ctx, d_color_frames, ctx->d_staging, (size_t)n * W * H, channels, color_channel);
     if (rc) return rc;

@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <functional>
 #include <string>
 #include <vector>
 #include "../../include/trexhip.h"
@@ -70,6 +71,23 @@ struct Pass2 {
     trexhip_blob* h_blobs = nullptr;
     trexhip_run* h_runs = nullptr;
     uint8_t* h_pixels = nullptr;
+};
+}
+
+namespace trexhip {
+// host tiles -> HBM (upload.hip): ring of pinned slots, copy stream, host copy threads, timings of the two legs
+enum { UP_SLOTS = 3 };
+static constexpr size_t UP_CHUNK_BYTES = (size_t)32 << 20;   // frames per DMA: about this many bytes
+struct Uploader {
+    hipStream_t copy_stream = nullptr;
+    hipEvent_t ev_start[UP_SLOTS] = {}, ev_done[UP_SLOTS] = {};
+    bool busy[UP_SLOTS] = {};
+    int frames_in[UP_SLOTS] = {};
+    uint8_t* ring = nullptr;            // UP_SLOTS x slot_bytes, pinned
+    size_t slot_bytes = 0;
+    void* pool = nullptr;               // CopyPool
+    double copy_ms = 0.0, dma_ms = 0.0;
+    int64_t copy_n = 0, dma_n = 0;
 };
 }
 
@@ -142,6 +160,7 @@ struct trexhip_ctx {
     hipEvent_t ev_grp[9] = {};
     int tune_ccl_stop = 0;              // dev only: stop k_ccl_lds after phase N (TREXHIP_CCL_STOP)
     trexhip::Stage stages[TREXHIP_STAGE_COUNT];
+    trexhip::Uploader up;
 };
 
 namespace trexhip {
@@ -152,4 +171,8 @@ void net_free(trexhip_ctx* ctx);
 int launch_pending(trexhip_ctx* ctx);
 int launch_morphology(trexhip_ctx* ctx, const uint8_t* d_frames, int n, const uint32_t** result);
 int launch_rethreshold(trexhip_ctx* ctx, int thr, int method, const double* ranges, int n_ranges, const int32_t* d_blob_thr);
+int launch_to_gray(trexhip_ctx* ctx, const uint8_t* d_color, uint8_t* d_gray, size_t npix, int channels, int color_channel);
+void upload_free(trexhip_ctx* ctx);
+int upload_frames(trexhip_ctx* ctx, const uint8_t* const* frames, int n, size_t rows, size_t row_bytes, size_t stride, uint8_t* d_dst,
+                  const std::function<int(int, int)>& after_chunk);
 }

@@ -1,0 +1,155 @@
+// upload.hip -- host tiles -> HBM for the host-pointer entry points (trexhip_segment, trexhip_segment_color): the as-deployed boundary,
+// where TRex hands over pooled BGR / BGRA tile images in pageable host memory (BackgroundSubtraction.cpp:146-180).
+//
+// A frame goes pageable -> pinned ring slot (host threads, rows split between them) -> HBM (one async DMA per frame on a copy stream).
+// The ring has UP_SLOTS slots: while the DMA engine moves frame i, the host threads already fill the slot of frame i+1, and the compute
+// stream reduces frame i-1 to gray (the caller enqueues that behind the frame's event).  The segment kernels then run over the whole
+// batch.  PCIe Gen5 x16 (63 GB/s spec) bounds this path; the timings of the two legs are kept per context (trexhip_profile_read:
+// TREXHIP_STAGE_UPLOAD_COPY = host milliseconds spent filling slots, TREXHIP_STAGE_UPLOAD_DMA = DMA milliseconds from HIP events).
+#include "internal.h"
+#include <algorithm>
+#include <chrono>
+#include <condition_variable>
+#include <cstring>
+#include <functional>
+#include <mutex>
+#include <thread>
+
+namespace trexhip {
+
+// a few persistent host threads that copy row ranges; one job at a time (the ctx is not re-entrant)
+struct CopyPool {
+    std::vector<std::thread> workers;
+    std::mutex mu;
+    std::condition_variable cv_go, cv_done;
+    std::function<void(int, int)> job;      // (worker index, worker count)
+    uint64_t generation = 0;
+    int pending = 0;
+    bool stop = false;
+
+    explicit CopyPool(int n) {
+        for (int w = 0; w < n; ++w)
+            workers.emplace_back([this, w, n]() {
+                uint64_t seen = 0;
+                for (;;) {
+                    std::function<void(int, int)> j;
+                    {
+                        std::unique_lock<std::mutex> g(mu);
+                        cv_go.wait(g, [&] { return stop || generation != seen; });
+                        if (stop) return;
+                        seen = generation;
+                        j = job;
+                    }
+                    j(w + 1, n + 1);                                   // the calling thread is worker 0
+                    {
+                        std::lock_guard<std::mutex> g(mu);
+                        if (--pending == 0) cv_done.notify_one();
+                    }
+                }
+            });
+    }
+    ~CopyPool() {
+        { std::lock_guard<std::mutex> g(mu); stop = true; }
+        cv_go.notify_all();
+        for (auto& t : workers) t.join();
+    }
+    void run(const std::function<void(int, int)>& f) {
+        {
+            std::lock_guard<std::mutex> g(mu);
+            job = f; pending = (int)workers.size(); ++generation;
+        }
+        cv_go.notify_all();
+        f(0, (int)workers.size() + 1);
+        std::unique_lock<std::mutex> g(mu);
+        cv_done.wait(g, [&] { return pending == 0; });
+    }
+};
+
+void upload_free(trexhip_ctx* ctx) {
+    Uploader& u = ctx->up;
+    delete static_cast<CopyPool*>(u.pool); u.pool = nullptr;
+    if (u.ring) { (void)hipHostFree(u.ring); u.ring = nullptr; }
+    for (int s = 0; s < UP_SLOTS; ++s) {
+        if (u.ev_done[s]) { (void)hipEventDestroy(u.ev_done[s]); u.ev_done[s] = nullptr; }
+        if (u.ev_start[s]) { (void)hipEventDestroy(u.ev_start[s]); u.ev_start[s] = nullptr; }
+    }
+    if (u.copy_stream) { (void)hipStreamDestroy(u.copy_stream); u.copy_stream = nullptr; }
+    u.slot_bytes = 0;
+}
+
+static int upload_prepare(trexhip_ctx* ctx, size_t frame_bytes) {   // frame_bytes = bytes of one ring slot (a chunk of whole frames)
+    Uploader& u = ctx->up;
+    if (!u.copy_stream) TH_CHECK_HIP(hipStreamCreateWithFlags(&u.copy_stream, hipStreamNonBlocking));
+    for (int s = 0; s < UP_SLOTS; ++s) {
+        if (!u.ev_done[s]) TH_CHECK_HIP(hipEventCreate(&u.ev_done[s]));
+        if (!u.ev_start[s]) TH_CHECK_HIP(hipEventCreate(&u.ev_start[s]));
+    }
+    if (u.slot_bytes < frame_bytes) {
+        if (u.ring) { TH_CHECK_HIP(hipStreamSynchronize(u.copy_stream)); (void)hipHostFree(u.ring); u.ring = nullptr; }
+        TH_CHECK_HIP(hipHostMalloc(reinterpret_cast<void**>(&u.ring), frame_bytes * UP_SLOTS, hipHostMallocDefault));
+        u.slot_bytes = frame_bytes;
+        for (int s = 0; s < UP_SLOTS; ++s) u.busy[s] = false;
+    }
+    if (!u.pool) {
+        int n = 0;
+        if (const char* e = std::getenv("TREXHIP_UPLOAD_THREADS")) n = std::atoi(e);
+        if (n <= 0) { const unsigned hc = std::thread::hardware_concurrency(); n = hc >= 16 ? 6 : (hc >= 8 ? 4 : (hc >= 4 ? 2 : 1)); }
+        u.pool = new CopyPool(n - 1);
+    }
+    return TREXHIP_OK;
+}
+
+// n frames of `rows` rows x `row_bytes` bytes (source row pitch `stride`) -> d_dst, frame after frame, in chunks of whole frames of
+// about UP_CHUNK_BYTES (one DMA and one event pair per chunk: small transfers do not reach the link rate).  after_chunk(first, count)
+// is called once the chunk's DMA is enqueued, with ctx->stream already ordered behind it (the caller launches the device work of
+// those frames there).
+int upload_frames(trexhip_ctx* ctx, const uint8_t* const* frames, int n, size_t rows, size_t row_bytes, size_t stride, uint8_t* d_dst,
+                  const std::function<int(int, int)>& after_chunk) {
+    const size_t frame_bytes = rows * row_bytes;
+    const int per = (int)std::max<size_t>(1, UP_CHUNK_BYTES / frame_bytes);
+    int rc = upload_prepare(ctx, frame_bytes * (size_t)per);
+    if (rc) return rc;
+    Uploader& u = ctx->up;
+    CopyPool* pool = static_cast<CopyPool*>(u.pool);
+    // the device buffer may still be read by the previous batch
+    TH_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+    double copy_ms = 0.0;
+    int chunk = 0;
+    for (int i0 = 0; i0 < n; i0 += per, ++chunk) {
+        const int cnt = std::min(per, n - i0);
+        const int s = chunk % UP_SLOTS;
+        if (u.busy[s]) {                                              // the DMA that last read this slot must be done; its time is the DMA leg
+            TH_CHECK_HIP(hipEventSynchronize(u.ev_done[s]));
+            float ms = 0.f;
+            if (hipEventElapsedTime(&ms, u.ev_start[s], u.ev_done[s]) == hipSuccess) { u.dma_ms += ms; u.dma_n += u.frames_in[s]; }
+            u.busy[s] = false;
+        }
+        uint8_t* slot = u.ring + (size_t)s * u.slot_bytes;
+        const auto t0 = std::chrono::steady_clock::now();
+        const size_t total_rows = rows * (size_t)cnt;
+        pool->run([=](int w, int nw) {                                // the rows of the whole chunk are dealt to the threads
+            const size_t r0 = total_rows * (size_t)w / (size_t)nw, r1 = total_rows * (size_t)(w + 1) / (size_t)nw;
+            size_t r = r0;
+            while (r < r1) {
+                const size_t f = r / rows, y = r - f * rows;
+                const size_t run = std::min(rows - y, r1 - r);       // rows of this frame in my range
+                const uint8_t* src = frames[i0 + (int)f] + y * stride;
+                uint8_t* dst = slot + f * frame_bytes + y * row_bytes;
+                if (stride == row_bytes) std::memcpy(dst, src, run * row_bytes);
+                else for (size_t k = 0; k < run; ++k) std::memcpy(dst + k * row_bytes, src + k * stride, row_bytes);
+                r += run;
+            }
+        });
+        copy_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        TH_CHECK_HIP(hipEventRecord(u.ev_start[s], u.copy_stream));
+        TH_CHECK_HIP(hipMemcpyAsync(d_dst + (size_t)i0 * frame_bytes, slot, frame_bytes * (size_t)cnt, hipMemcpyHostToDevice, u.copy_stream));
+        TH_CHECK_HIP(hipEventRecord(u.ev_done[s], u.copy_stream));
+        u.busy[s] = true; u.frames_in[s] = cnt;
+        TH_CHECK_HIP(hipStreamWaitEvent(ctx->stream, u.ev_done[s], 0));
+        if (after_chunk) { rc = after_chunk(i0, cnt); if (rc) return rc; }
+    }
+    u.copy_ms += copy_ms; u.copy_n += n;
+    return TREXHIP_OK;
+}
+
+}  // namespace trexhip

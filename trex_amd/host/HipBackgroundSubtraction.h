@@ -215,6 +215,17 @@ struct HipBackgroundSubtraction {
         d.has_background = false;
     }
     static double fps() { return data().fps(); }
+    // the two legs of the tile upload since init(): host milliseconds spent copying pageable tiles into the pinned ring and DMA
+    // milliseconds (they overlap each other: apply() takes about the larger of the two), per the library's own counters
+    static void upload_stats(double& host_copy_ms, double& dma_ms, int64_t& frames) {
+        auto& d = data();
+        std::unique_lock g(d.gpu_mutex);
+        host_copy_ms = dma_ms = 0; frames = 0;
+        if (!d.ctx) return;
+        int64_t n2 = 0;
+        (void)trexhip_profile_read(d.ctx, TREXHIP_STAGE_UPLOAD_COPY, &host_copy_ms, &frames);
+        (void)trexhip_profile_read(d.ctx, TREXHIP_STAGE_UPLOAD_DMA, &dma_ms, &n2);
+    }
     static bool is_initializing() { return false; }
 
     // detect::register_backend(type, hooks) -- python/BackendRegistry.h:19; pattern of register_yolo_backend

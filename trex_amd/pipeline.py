@@ -48,7 +48,12 @@ class Lane:
         pl = self.pl
         if self.hi is not None:
             self.seg.set_stream(self.hi.cuda_stream)
-        if pl.bgra_in:
+        if pl.host_frames is not None:          # the as-deployed boundary: pageable host tiles, PCIe inside the step (upload.hip)
+            if pl.bgra_in:
+                self.seg.segment_color_host(pl.host_frames)
+            else:
+                self.seg.segment_host(pl.host_frames)
+        elif pl.bgra_in:
             self.seg.segment_color_device(frames_ptr, pl.B, 4)
         else:
             self.seg.segment_device(frames_ptr, pl.B)
@@ -95,13 +100,14 @@ class Lane:
 class Pipeline:
     def __init__(self, W, H, n_ind, B, classes, bg, weight_blob=None, *, local=0, rank=0, world=1, use_dist=False, gather=None,
                  with_cnn=True, with_posture=False, normalize="none", rgb=False, bgra_in=False, cnn_mode="fp16x3",
-                 lanes=2, pipeline=True, detect_priority=True):
+                 lanes=2, pipeline=True, detect_priority=True, host_frames=None):
         self.W, self.H, self.B, self.classes, self.bg = W, H, B, classes, bg
         self.local, self.rank, self.world, self.use_dist = local, rank, world, use_dist
         self.gather = gather or tdist.all_gather_tables
         self.dev = torch.device("cuda", local)
         self.with_cnn, self.with_posture, self.rgb, self.bgra_in = with_cnn, with_posture or normalize == "posture", rgb, bgra_in or rgb
         self.weight_blob = weight_blob
+        self.host_frames = host_frames            # list of B numpy frames ([H,W] gray or [H,W,4] BGRA) in pageable host memory, or None
         self.opt = {"normalize": normalize, "cnn_mode": cnn_mode, "detect_priority": detect_priority}
         self.max_blobs = 4 * n_ind
         self.pool = B * self.max_blobs
