@@ -56,7 +56,9 @@ def main():
     ap.add_argument("--lanes", type=int, default=2, help="software-pipeline depth: contexts whose batches are in flight (detect of batch i+L-1 is issued while the identity network works on batch i)")
     ap.add_argument("--no-detect-priority", dest="detect_priority", action="store_false",
                     help="keep the detect stage on the lane's own stream (default: a high-priority stream per lane, so that its short kernels get compute units as soon as the other lane's identity network frees some)")
-    ap.add_argument("--force-dist", action="store_true", help="dev: run the torch.distributed (RCCL) code path even with a single rank")
+    ap.add_argument("--force-dist", action="store_true", help="run the multi-GPU code path (the library's communicator, trexhip_comm_*) even with a single rank")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="weak: --batch frames per GPU per step (default); strong: --batch frames per step in total, split between the GPUs")
     ap.add_argument("--force-all", action="store_true", help="run exactly the stages given on the command line instead of the preset of the named config")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
@@ -92,6 +94,9 @@ def main():
 
     W, H, n_ind, _cid = synth.CONFIGS[args.config]
     B = args.batch or (64 if args.config == "C5" else 256)
+    if args.scaling == "strong":
+        assert B % world == 0, "--scaling strong: the batch must divide by the number of GPUs"
+        B //= world
     classes = 256 if args.config == "C5" else 100
     with_cnn = args.stages == "all"
 
@@ -109,9 +114,15 @@ def main():
     max_blobs = 4 * n_ind
     state = weights.synthetic_state(classes, 4242, channels=3 if args.encoding == "rgb8" else 1)
     from trex_amd.pipeline import Pipeline
+    comm_ids = None
+    if use_dist and world > 1:      # rank 0 makes one ncclUniqueId per lane; torch.distributed is only the side channel that hands them out
+        n_lanes = max(2, args.lanes) if args.pipeline else 1
+        box = [[capi.Comm.unique_id() for _ in range(n_lanes)]] if rank == 0 else [None]
+        dist.broadcast_object_list(box, src=0)
+        comm_ids = box[0]
     # the lanes, their buffers and the step schedule live in trex_amd/pipeline.py (the same object tests/test_bench_shape_gpu.py checks)
     pipe = Pipeline(W, H, n_ind, B, classes, bg, weights.pack_blob(state, classes, channels=3 if rgb else 1) if with_cnn else None,
-                    local=local, rank=rank, world=world, use_dist=use_dist, with_cnn=with_cnn, with_posture=args.with_posture,
+                    local=local, rank=rank, world=world, use_dist=use_dist, comm_ids=comm_ids, with_cnn=with_cnn, with_posture=args.with_posture,
                     normalize=args.normalize, rgb=rgb, bgra_in=bgra_in, cnn_mode=args.cnn_mode, lanes=args.lanes, pipeline=args.pipeline,
                     detect_priority=args.detect_priority, host_frames=host_frames)
     lanes = pipe.lanes
@@ -187,11 +198,11 @@ def main():
         "metric": "frames/s end-to-end (segment+CNN-ID), 2048x2048 x100 individuals" if (args.config == "C4" and with_cnn) else
                   f"frames/s ({'segment' + ('+posture' if args.with_posture else '') + ('+CNN-ID' if with_cnn else '')}), {W}x{H} x{n_ind} individuals ({args.config})",
         "value": fps, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+        "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": args.scaling,
         "vs_baseline": None, "dtype": ({"fp32": "f32", "bf16x6": "bf16x6-split (fp32-equivalent: 3 bf16 pieces per operand, 6 MFMA products, fp32 accumulate)", "bf16x3": "bf16x3-split", "fp16x3": "fp16x3-split (fp32-class: 2 fp16 pieces per operand = 22 mantissa bits, 3 MFMA products, fp32 accumulate, range-guarded)"}[args.cnn_mode] if with_cnn else "u8"), "data": "synthetic",
         "config": {"workload": f"{args.config}: {W}x{H} gray, {n_ind} individuals/frame, {B} frames resident per step per GPU, "
                                f"80x80x1 crops, {classes}-way V118_3 (random-init weights)",
-                   "stages": "detect(bg-sub+threshold+CCL+filter+gather, tables->host) + crops(none) + identity CNN (V118_3) + per-blob ID table (all-gathered when N>1) -> rank-0 host"
+                   "stages": "detect(bg-sub+threshold+CCL+filter+gather, tables->host) + crops(none) + identity CNN (V118_3) + per-blob ID table (gathered on rank 0 over RCCL when N>1: trexhip_comm_gather_device) -> rank-0 host"
                              if with_cnn else "detect only (bg-sub+threshold+CCL+filter+gather, tables->host)",
                    "frames_per_step_per_gpu": B, "encoding": args.encoding, "input": ("host " if host_in else "") + ("bgra tiles (cvtColor on the device inside the step)" if bgra_in else "gray frames") + (" in pageable host memory, PCIe inside the step" if host_in else " resident in HBM"), "posture": bool(args.with_posture), "individual_image_normalization": args.normalize, "pipelined_lanes": len(lanes), "blobs_per_step_rank0": n_blobs, "parallelism": f"frame-sharded x{world}"},
     }

@@ -353,6 +353,22 @@ int trexhip_export_id_table_ex_device(trexhip_ctx* ctx, const float* d_probs, in
                                       const float* d_midline, const trexhip_midline_info* d_midline_info, int32_t midline_resolution,
                                       void* d_table, int32_t max_rows);
 
+/* The collective of the frame-sharded path, owned by the library: one process per GPU, frames dealt to ranks in blocks, and after
+ * every block each rank's table goes to rank 0 (grouped ncclSend / ncclRecv over RCCL -- xGMI inside a node -- on the context's
+ * stream, i.e. ordered behind trexhip_export_id_table*_device): a GATHER, because only rank 0's sequential matcher reads the tables.
+ *   trexhip_comm_unique_id   rank 0: 128 bytes (ncclUniqueId) to hand to every rank by whatever side channel the host program has
+ *   trexhip_comm_create      every rank, collectively (ncclCommInitRank on the context's device); world = 1 needs no id and no RCCL
+ *   trexhip_comm_gather_device  `bytes` from every rank's d_send land at d_recv_rank0 + rank * bytes on rank 0 (world x bytes there;
+ *                            ignored on the other ranks).  Enqueued on the context's stream; trexhip_synchronize waits for it.
+ * RCCL is loaded with dlopen on first use (an instance already in the process is shared). */
+typedef struct trexhip_comm trexhip_comm;
+int trexhip_comm_unique_id(void* id128);
+int trexhip_comm_create(trexhip_ctx* ctx, const void* id128, int32_t rank, int32_t world, trexhip_comm** out);
+void trexhip_comm_destroy(trexhip_comm* comm);
+int trexhip_comm_rank(trexhip_comm* comm);
+int trexhip_comm_world(trexhip_comm* comm);
+int trexhip_comm_gather_device(trexhip_comm* comm, const void* d_send, size_t bytes, void* d_recv_rank0);
+
 /* live HIP-event timing of the dominant kernels on the ctx stream (bench.py roofline):
  * stage ids TREXHIP_STAGE_* ; returns accumulated milliseconds and launch count since reset */
 enum { TREXHIP_STAGE_ROWS = 0, TREXHIP_STAGE_SEGMENT_ALL = 1, TREXHIP_STAGE_CONV2 = 2, TREXHIP_STAGE_CONV3 = 3,

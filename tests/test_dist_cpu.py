@@ -60,10 +60,11 @@ def _worker(rank, world, port, q):
     plan = tdist.shard_plan(len(frames), world, 3)
     (first, cnt), = plan[rank]
     t = _table_for(frames[first:first + cnt], bg, first, 5, 512)
-    gathered = tdist.all_gather_tables(torch.from_numpy(t.view(np.int32)))
-    merged = tdist.merge_tables(gathered.numpy().view(np.uint32))
+    gathered = tdist.gather_tables_torch(torch.from_numpy(t.view(np.int32)))       # gloo stand-in of trexhip_comm_gather_device: rank 0 only
     if rank == 0:
-        q.put(merged)
+        q.put(tdist.merge_tables(gathered.numpy().view(np.uint32)))
+    else:
+        assert gathered is None
     dist.barrier()
     dist.destroy_process_group()
 

@@ -74,3 +74,77 @@ def test_full_record_kernel_matches_host_builder():
         got = table.cpu().numpy().view(np.uint32)
         assert np.array_equal(got, want), with_midline
     seg.close()
+
+
+def _device_table(seg, fr, frame_base, classes=6, seed=0):
+    """segment the frames on the device and build the per-blob table there (probabilities random but seeded)"""
+    n = fr.shape[0]
+    d = torch.from_numpy(fr).cuda()
+    seg.segment_device(d.data_ptr(), n)
+    res = seg.fetch()
+    total = sum(len(r.blobs) for r in res)
+    g = torch.Generator(device="cuda"); g.manual_seed(seed)
+    probs = torch.rand((total, classes), device="cuda", generator=g)
+    rows = 40 * n
+    table = torch.zeros((rows, tdist.HDR + classes), dtype=torch.int32, device="cuda")
+    seg.export_id_table(probs.data_ptr(), total, classes, frame_base, table.data_ptr(), rows)
+    return table, total
+
+
+def test_library_communicator_world_1():
+    # the RCCL code path at world = 1: the gather is the copy of rank 0's own table, enqueued on the context's stream
+    fr, bg = synth.batch("C2", 3)
+    n, H, W = fr.shape
+    seg = capi.Segmenter(capi.default_params(W, H, max_batch=n))
+    seg.set_background(bg)
+    comm = capi.Comm(seg, 0, 1)
+    table, total = _device_table(seg, fr, 700)
+    out = torch.full_like(table, -1)
+    comm.gather_device(table.data_ptr(), table.numel() * 4, out.data_ptr())
+    seg.synchronize()
+    assert torch.equal(out, table) and int((out[:, 7] == 1).sum()) == total
+    assert len(capi.Comm.unique_id()) == 128                            # RCCL is there and answers
+    with pytest.raises(capi.TrexHipError):
+        capi.Comm(seg, 1, 2, None)                                     # world > 1 needs rank 0's unique id
+    comm.close(); seg.close()
+
+
+def _rank_main(rank, world, id_path, out_path):
+    import os, time
+    torch.cuda.set_device(rank)
+    fr, bg = synth.batch("C2", 6)
+    plan = tdist.shard_plan(6, world, 3)
+    (first, cnt), = plan[rank]
+    H, W = fr.shape[1:]
+    seg = capi.Segmenter(capi.default_params(W, H, device=rank, max_batch=cnt))
+    seg.set_background(bg)
+    if rank == 0:
+        uid = capi.Comm.unique_id()
+        with open(id_path + ".tmp", "wb") as f:
+            f.write(uid)
+        os.replace(id_path + ".tmp", id_path)
+    else:
+        while not os.path.exists(id_path):
+            time.sleep(0.05)
+        uid = open(id_path, "rb").read()
+    comm = capi.Comm(seg, rank, world, uid)
+    table, total = _device_table(seg, fr[first:first + cnt], first, seed=rank)
+    recv = torch.zeros((world * table.shape[0], table.shape[1]), dtype=torch.int32, device="cuda") if rank == 0 else None
+    comm.gather_device(table.data_ptr(), table.numel() * 4, recv.data_ptr() if rank == 0 else 0)
+    seg.synchronize()
+    np.save(out_path + f".own{rank}.npy", table.cpu().numpy())
+    if rank == 0:
+        np.save(out_path + ".gathered.npy", recv.cpu().numpy())
+    comm.close(); seg.close()
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs (runs on the multi-GPU tier)")
+def test_library_communicator_two_ranks_device_tables(tmp_path):
+    import torch.multiprocessing as mp
+    idp, outp = str(tmp_path / "uid"), str(tmp_path / "t")
+    mp.spawn(_rank_main, args=(2, idp, outp), nprocs=2, join=True)
+    own = [np.load(outp + f".own{r}.npy") for r in range(2)]
+    got = np.load(outp + ".gathered.npy")
+    assert np.array_equal(got, np.concatenate(own))                      # rank r's rows at r * rows on rank 0
+    merged = tdist.merge_tables(got.view(np.uint32))
+    assert set(np.unique(merged[:, 0]).tolist()) == set(range(6)) and np.all(np.diff(merged[:, 0].astype(np.int64)) >= 0)

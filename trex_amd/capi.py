@@ -99,7 +99,7 @@ class TrexHipError(RuntimeError):
 
 # every symbol include/trexhip.h declares (tests check the library exports all of them)
 SYMBOLS = [
-    "trexhip_abi_version", "trexhip_network_channels", "trexhip_last_error", "trexhip_default_params", "trexhip_create", "trexhip_destroy",
+    "trexhip_abi_version", "trexhip_network_channels", "trexhip_comm_unique_id", "trexhip_comm_create", "trexhip_comm_destroy", "trexhip_comm_rank", "trexhip_comm_world", "trexhip_comm_gather_device", "trexhip_last_error", "trexhip_default_params", "trexhip_create", "trexhip_destroy",
     "trexhip_set_stream", "trexhip_set_background", "trexhip_set_background_device", "trexhip_set_background_color", "trexhip_set_background_color_device", "trexhip_generate_average_device", "trexhip_get_background", "trexhip_segment_device",
     "trexhip_segment", "trexhip_segment_color", "trexhip_segment_color_device", "trexhip_rethreshold_device", "trexhip_rethreshold_per_blob_device", "trexhip_fetch_rethreshold", "trexhip_fetch", "trexhip_device_view_get", "trexhip_synchronize",
     "trexhip_profile_enable", "trexhip_profile_read", "trexhip_profile_reset",
@@ -156,6 +156,13 @@ def lib():
         L.trexhip_load_weights.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
         L.trexhip_num_classes.argtypes = [C.c_void_p]
         L.trexhip_network_channels.argtypes = [C.c_void_p]
+        L.trexhip_comm_unique_id.argtypes = [C.c_void_p]
+        L.trexhip_comm_create.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.POINTER(C.c_void_p)]
+        L.trexhip_comm_destroy.argtypes = [C.c_void_p]
+        L.trexhip_comm_destroy.restype = None
+        L.trexhip_comm_rank.argtypes = [C.c_void_p]
+        L.trexhip_comm_world.argtypes = [C.c_void_p]
+        L.trexhip_comm_gather_device.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
         L.trexhip_set_identity_precision.argtypes = [C.c_void_p, C.c_int32]
         L.trexhip_identify_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]
         L.trexhip_identify.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]
@@ -440,3 +447,27 @@ class Segmenter:
 
     def profile_reset(self):
         _check(lib().trexhip_profile_reset(self._h))
+
+
+class Comm:
+    """The library's communicator (include/trexhip.h: trexhip_comm_*): gather of every rank's table to rank 0 over RCCL."""
+
+    def __init__(self, seg, rank=0, world=1, unique_id=None):
+        self._h = C.c_void_p()
+        self.rank, self.world = rank, world
+        buf = (C.c_char * 128).from_buffer_copy(unique_id) if unique_id is not None else None
+        _check(lib().trexhip_comm_create(seg.handle, buf, rank, world, C.byref(self._h)))
+
+    @staticmethod
+    def unique_id():
+        buf = (C.c_char * 128)()
+        _check(lib().trexhip_comm_unique_id(buf))
+        return bytes(buf)
+
+    def gather_device(self, d_send_ptr, nbytes, d_recv_rank0_ptr):
+        _check(lib().trexhip_comm_gather_device(self._h, C.c_void_p(d_send_ptr), nbytes, C.c_void_p(d_recv_rank0_ptr or 0)))
+
+    def close(self):
+        if self._h:
+            lib().trexhip_comm_destroy(self._h)
+            self._h = C.c_void_p()

@@ -5,7 +5,10 @@ frames are dealt to ranks in contiguous blocks, round-robin; background and netw
 replicated.  The only exchange is the all-gather of fixed-size per-blob identity tables so that the
 order-dependent consumer (TRex's Tracker::add on rank 0, tracking/Tracker.cpp:586-587) sees every frame.
 
-torch.distributed is plumbing here: backend "nccl" is RCCL over xGMI on the GPU box, "gloo" in CPU tests.
+The exchange itself belongs to the library: trexhip_comm_* in include/trexhip.h (trex_amd/csrc/comm.hip: grouped ncclSend / ncclRecv
+to rank 0 over RCCL, capi.Comm in Python) -- that is what trex_amd/pipeline.py and bench.py use.  This module holds the host-side
+logic around it (who gets which frames, how rank 0 orders the rows) and, for the CPU tests (gloo, no GPUs), a torch.distributed
+stand-in of the same gather.
 """
 import numpy as np
 
@@ -24,15 +27,15 @@ def shard_plan(n_frames, world, block):
     return plan
 
 
-def all_gather_tables(table, group=None):
-    """table: torch tensor [rows, rowlen] (int32/uint8 view ok), same shape on every rank.
-    Returns [world*rows, rowlen] on every rank (one collective per batch of frames)."""
+def gather_tables_torch(table, dst=0, group=None):
+    """CPU-test stand-in of trexhip_comm_gather_device: table [rows, rowlen] from every rank -> [world*rows, rowlen] on rank `dst`
+    (None elsewhere), through torch.distributed (gloo)."""
     import torch
     import torch.distributed as dist
-    world = dist.get_world_size(group)
-    out = torch.empty((world * table.shape[0],) + tuple(table.shape[1:]), dtype=table.dtype, device=table.device)
-    dist.all_gather_into_tensor(out, table.contiguous(), group=group)
-    return out
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    parts = [torch.empty_like(table) for _ in range(world)] if rank == dst else None
+    dist.gather(table.contiguous(), parts, dst=dst, group=group)
+    return torch.cat(parts, 0) if rank == dst else None
 
 
 def merge_tables(gathered):

@@ -29,6 +29,12 @@ class Lane:
         # per-blob record for rank 0's matcher: header + probabilities, with posture also second moments + normalised midline
         self.table = torch.zeros((pl.rows, pl.rowlen), dtype=torch.int32, device=dev)
         self.table_host = torch.empty((pl.world * pl.rows, pl.rowlen), dtype=torch.int32).pin_memory() if pl.rank == 0 else None
+        # N > 1: the library's own communicator (one per context) gathers every rank's table on rank 0 (trexhip_comm_gather_device)
+        self.comm = None
+        self.table_all = None
+        if pl.use_dist:
+            self.comm = capi.Comm(self.seg, pl.rank, pl.world, pl.next_comm_id())
+            self.table_all = torch.zeros((pl.world * pl.rows, pl.rowlen), dtype=torch.int32, device=dev) if pl.rank == 0 else None
         if pl.with_posture:
             MP = pl.MP
             self.p_outline = torch.empty((pl.pool, MP, 2), dtype=torch.float32, device=dev)
@@ -86,10 +92,11 @@ class Lane:
                                        self.p_mid.data_ptr() if n else 0, self.p_minfo.data_ptr() if n else 0, 25)
             else:
                 seg.export_id_table(self.probs.data_ptr(), n, pl.classes, frame_base, self.table.data_ptr(), pl.rows)
+            if pl.use_dist:                     # grouped send / recv on the context's stream, behind the table kernel
+                self.comm.gather_device(self.table.data_ptr(), self.table.numel() * 4, self.table_all.data_ptr() if pl.rank == 0 else 0)
             with torch.cuda.stream(self.stream):
-                g = pl.gather(self.table) if pl.use_dist else self.table
                 if pl.rank == 0:
-                    self.table_host.copy_(g, non_blocking=True)
+                    self.table_host.copy_(self.table_all if pl.use_dist else self.table, non_blocking=True)
         else:
             self.done.record(self.stream)
 
@@ -98,12 +105,12 @@ class Lane:
 
 
 class Pipeline:
-    def __init__(self, W, H, n_ind, B, classes, bg, weight_blob=None, *, local=0, rank=0, world=1, use_dist=False, gather=None,
+    def __init__(self, W, H, n_ind, B, classes, bg, weight_blob=None, *, local=0, rank=0, world=1, use_dist=False, comm_ids=None,
                  with_cnn=True, with_posture=False, normalize="none", rgb=False, bgra_in=False, cnn_mode="fp16x3",
                  lanes=2, pipeline=True, detect_priority=True, host_frames=None):
         self.W, self.H, self.B, self.classes, self.bg = W, H, B, classes, bg
         self.local, self.rank, self.world, self.use_dist = local, rank, world, use_dist
-        self.gather = gather or tdist.all_gather_tables
+        self._comm_ids = list(comm_ids or [])     # one ncclUniqueId (128 bytes, made by rank 0) per lane, in lane order
         self.dev = torch.device("cuda", local)
         self.with_cnn, self.with_posture, self.rgb, self.bgra_in = with_cnn, with_posture or normalize == "posture", rgb, bgra_in or rgb
         self.weight_blob = weight_blob
@@ -120,6 +127,12 @@ class Pipeline:
                 ln.after = self.lanes[(k - 1) % len(self.lanes)]
                 ln.done.record(ln.stream)
         torch.cuda.synchronize()
+
+    def next_comm_id(self):
+        if self.world == 1:
+            return None
+        assert self._comm_ids, "Pipeline(use_dist=True, world > 1) needs comm_ids: one trexhip_comm_unique_id() of rank 0 per lane"
+        return self._comm_ids.pop(0)
 
     def run(self, k, frames_ptr, on_batch=None):
         """k steps = k batches through detect -> (posture) -> crops -> identity -> table on the host.  frames_ptr: device pointer of
@@ -162,4 +175,6 @@ class Pipeline:
 
     def close(self):
         for ln in self.lanes:
+            if ln.comm is not None:
+                ln.comm.close()
             ln.seg.close()
