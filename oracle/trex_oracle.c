@@ -427,7 +427,8 @@ static aff_t aff_translate(aff_t a, float x, float y) { aff_t t = {{1, 0, x, 0, 
 static aff_t aff_scale(aff_t a, float s) { aff_t t = {{s, 0, 0, 0, s, 0}}; return aff_mul(a, t); }
 static aff_t aff_rotate_deg(aff_t a, float deg) {
     const float rad = deg * 3.141592654f / 180.f;
-    const float c = cosf(rad), s = sinf(rad);
+    /* correctly rounded float cos / sin (double, narrowed): the one definition CPU, host and device can all meet */
+    const float c = (float)cos((double)rad), s = (float)sin((double)rad);
     aff_t t = {{c, -s, 0, s, c, 0}};
     return aff_mul(a, t);
 }
@@ -451,7 +452,7 @@ void oracle_moments_transform(const oracle_blob* B, float* tr6) {
     const float n = (float)B->n_pixels;
     const float cx = (float)B->m10 / n, cy = (float)B->m01 / n;
     const float mu20 = (float)B->m20 / n - cx * cx, mu02 = (float)B->m02 / n - cy * cy, mu11 = (float)B->m11 / n - cx * cy;
-    const float orientation = 0.5f * atan2f(2.f * mu11, mu20 - mu02);
+    const float orientation = 0.5f * (float)atan2((double)(2.f * mu11), (double)(mu20 - mu02));
     const float angle = (-orientation + 3.14159265358979323846f * 0.25f) * 180.f / 3.14159265358979323846f;   /* DEGREE() */
     aff_t t = aff_identity();
     t = aff_rotate_deg(t, angle);

@@ -410,7 +410,7 @@ void oracle_midline_transform(float angle, float offx, float offy, int legacy, f
     const float a = (float)(-(double)angle + (legacy ? 3.14159265358979323846 : 3.14159265358979323846 * 0.25));
     const float deg = a * 180.f / 3.14159265358979323846f;
     const float rad = deg * 3.141592654f / 180.f;
-    const float c = cosf(rad), s = sinf(rad);
+    const float c = (float)cos((double)rad), s = (float)sin((double)rad);    /* correctly rounded, like trex_oracle.c aff_rotate_deg */
     tr6[0] = c; tr6[1] = -s; tr6[2] = c * -offx + -s * -offy;
     tr6[3] = s; tr6[4] = c;  tr6[5] = s * -offx + c * -offy;
 }

@@ -7,6 +7,7 @@
 // the output size: pad = out - size, right = pad/2, left = pad - right (:184-194); cut likewise (:212-226)).
 // One workgroup = one blob of the last segmented batch, in pooled order.
 #include "internal.h"
+#include "affine.h"
 #include <cmath>
 #include <cstring>
 #include <vector>
@@ -72,7 +73,9 @@ __global__ __launch_bounds__(256) void k_crops_none(const SegCfg c, const uint8_
 }
 
 int launch_crops_warp(trexhip_ctx* ctx, uint8_t* d_crops, int n, int OW, int OH, int diff_mode, const float* tr6, const float* lengths,
-                      bool legacy, float scale, const uint8_t* valid);
+                      bool legacy, float scale);
+int launch_crops_warp_device(trexhip_ctx* ctx, uint8_t* d_crops, int n, int OW, int OH, int diff_mode, const trexhip_midline_info* d_minfo,
+                             const float* d_lengths, bool legacy, float scale);
 int check_colour_difference(trexhip_ctx* ctx, int difference, const char* who);
 
 int launch_crops(trexhip_ctx* ctx, uint8_t* d_crops, int n, int OW, int OH, int diff_mode) {
@@ -119,8 +122,8 @@ int trexhip_crops_device(trexhip_ctx* ctx, uint8_t* d_crops, int32_t n_blobs, in
     if (!ctx->d_frames || ctx->last_n == 0) { set_error("trexhip_crops_device: no segmented batch"); return TREXHIP_E_INVALID; }
     if (!ctx->fetched) { set_error("trexhip_crops_device: call trexhip_fetch on the segmented batch first"); return TREXHIP_E_INVALID; }
     TH_CHECK_HIP(hipSetDevice(ctx->p.device));
-    if (normalization == TREXHIP_NORMALIZE_MOMENTS)
-        return launch_crops_warp(ctx, d_crops, n_blobs, out_w, out_h, difference, nullptr, nullptr, false, 1.0f, nullptr);
+    if (normalization == TREXHIP_NORMALIZE_MOMENTS)      // transform from the blob table's integer moments, built on the device (midline.hip)
+        return launch_crops_warp_device(ctx, d_crops, n_blobs, out_w, out_h, difference, nullptr, nullptr, false, 1.0f);
     return launch_crops(ctx, d_crops, n_blobs, out_w, out_h, difference);
 }
 
@@ -455,22 +458,6 @@ extern "C" int trexhip_get_background(trexhip_ctx* ctx, uint8_t* gray, int32_t s
 // ------------------------------------------------------------------------------------------------
 namespace trexhip {
 
-struct Aff { float m[6]; };
-static Aff aff_mul(const Aff& a, const Aff& b) {
-    Aff c;
-    c.m[0] = a.m[0] * b.m[0] + a.m[1] * b.m[3]; c.m[1] = a.m[0] * b.m[1] + a.m[1] * b.m[4]; c.m[2] = a.m[0] * b.m[2] + a.m[1] * b.m[5] + a.m[2];
-    c.m[3] = a.m[3] * b.m[0] + a.m[4] * b.m[3]; c.m[4] = a.m[3] * b.m[1] + a.m[4] * b.m[4]; c.m[5] = a.m[3] * b.m[2] + a.m[4] * b.m[5] + a.m[5];
-    return c;
-}
-static Aff aff_translate(const Aff& a, float x, float y) { const Aff t = {{1, 0, x, 0, 1, y}}; return aff_mul(a, t); }
-static Aff aff_scale(const Aff& a, float s) { const Aff t = {{s, 0, 0, 0, s, 0}}; return aff_mul(a, t); }
-static Aff aff_rotate_deg(const Aff& a, float deg) {
-    const float rad = deg * 3.141592654f / 180.f;
-    const float c = std::cos(rad), s = std::sin(rad);
-    const Aff t = {{c, -s, 0, s, c, 0}};
-    return aff_mul(a, t);
-}
-
 static constexpr int W_NR = 2048;      // lines of one blob held in LDS
 static constexpr int W_OUT = 256;      // output rows / columns with tabulated fixed-point terms
 static constexpr int W_IMG = 16384;    // bounding boxes up to this many pixels are painted into LDS
@@ -596,57 +583,17 @@ __global__ __launch_bounds__(256) void k_crops_warp(const SegCfg c, const uint8_
     }
 }
 
-// forward transform of normalize_image (FilterCache.cpp:50-63) and its inverse as cv::warpAffine computes it
-static void compose_and_invert(const Aff& tr, float midline_length, bool legacy, int OW, int OH, float scale, double* out6) {
-    Aff t = {{1, 0, 0, 0, 1, 0}};
-    t = aff_translate(t, (float)OW * 0.5f, (float)OH * 0.5f);
-    t = aff_scale(t, scale);
-    if (legacy) t = aff_translate(t, -midline_length * 0.5f, 0.f);
-    else        t = aff_translate(t, midline_length * 0.4f, midline_length * 0.4f);
-    t = aff_mul(t, tr);
-    double M[6];
-    for (int i = 0; i < 6; ++i) M[i] = t.m[i];
-    double D = M[0] * M[4] - M[1] * M[3];
-    D = D != 0 ? 1. / D : 0;
-    const double A11 = M[4] * D, A22 = M[0] * D;
-    M[0] = A11; M[1] *= -D; M[3] *= -D; M[4] = A22;
-    const double b1 = -M[0] * M[2] - M[1] * M[5], b2 = -M[3] * M[2] - M[4] * M[5];
-    M[2] = b1; M[5] = b2;
-    for (int i = 0; i < 6; ++i) out6[i] = M[i];
+static int ensure_warp(trexhip_ctx* ctx, int n) {
+    if (ctx->warp_cap >= n) return TREXHIP_OK;
+    if (ctx->d_warp) (void)hipFree(ctx->d_warp);
+    ctx->d_warp = nullptr; ctx->warp_cap = 0;
+    TH_CHECK_HIP(hipMalloc(reinterpret_cast<void**>(&ctx->d_warp), (size_t)n * 6 * sizeof(double)));
+    ctx->warp_cap = n;
+    return TREXHIP_OK;
 }
 
-int launch_crops_warp(trexhip_ctx* ctx, uint8_t* d_crops, int n, int OW, int OH, int diff_mode, const float* tr6, const float* lengths,
-                      bool legacy, float scale, const uint8_t* valid) {
-    if (int rc = check_colour_difference(ctx, diff_mode, "normalised crops")) return rc;
-    // tr6 == nullptr: `moments` -- orientation from the integer moments of the fetched blob table (host copy)
-    std::vector<double> minv((size_t)n * 6);
-    for (int i = 0; i < n; ++i) {
-        Aff tr;
-        float len = 0.f;
-        if (tr6) { std::memcpy(tr.m, tr6 + (size_t)i * 6, sizeof(tr.m)); len = lengths ? lengths[i] : 0.f; }
-        else {
-            const trexhip_blob& B = ctx->h_blobs[i];
-            const float np_ = (float)B.n_pixels;
-            const float cx = (float)B.m10 / np_, cy = (float)B.m01 / np_;
-            const float mu20 = (float)B.m20 / np_ - cx * cx, mu02 = (float)B.m02 / np_ - cy * cy, mu11 = (float)B.m11 / np_ - cx * cy;
-            const float orientation = 0.5f * std::atan2(2.f * mu11, mu20 - mu02);      // pv::Blob::orientation()
-            const float angle = (-orientation + 3.14159265358979323846f * 0.25f) * 180.f / 3.14159265358979323846f;
-            Aff t = {{1, 0, 0, 0, 1, 0}};
-            t = aff_rotate_deg(t, angle);
-            tr = aff_translate(t, -(float)(B.x1 - B.x0 + 1) * 0.5f, -(float)(B.y1 - B.y0 + 1) * 0.5f);
-        }
-        compose_and_invert(tr, len, legacy, OW, OH, scale, &minv[(size_t)i * 6]);
-        // no midline: every source coordinate far outside the image -> all-zero crop
-        if (valid && !valid[i]) { double* m = &minv[(size_t)i * 6]; m[0] = m[1] = m[3] = m[4] = 0; m[2] = m[5] = -1.0e6; }
-    }
-    if (ctx->warp_cap < n) {
-        if (ctx->d_warp) (void)hipFree(ctx->d_warp);
-        ctx->d_warp = nullptr; ctx->warp_cap = 0;
-        TH_CHECK_HIP(hipMalloc(reinterpret_cast<void**>(&ctx->d_warp), (size_t)n * 6 * sizeof(double)));
-        ctx->warp_cap = n;
-    }
-    TH_CHECK_HIP(hipMemcpyAsync(ctx->d_warp, minv.data(), minv.size() * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
-    TH_CHECK_HIP(hipStreamSynchronize(ctx->stream));        // minv lives on this stack frame
+// the warp itself, from the per-blob inverse maps in ctx->d_warp
+int launch_crops_warp_maps(trexhip_ctx* ctx, uint8_t* d_crops, int n, int OW, int OH, int diff_mode) {
     SegCfg c = ctx->cfg;
     c.B = ctx->last_n;
     stage_begin(ctx, TREXHIP_STAGE_CROPS);
@@ -657,6 +604,25 @@ int launch_crops_warp(trexhip_ctx* ctx, uint8_t* d_crops, int n, int OW, int OH,
     TH_CHECK_HIP(hipGetLastError());
     return TREXHIP_OK;
 }
+
+// caller-supplied Midline::transform matrices (host arrays): composed and inverted on the host, uploaded (the copy from pageable
+// memory is staged by the runtime before the call returns, so the stack vector may go)
+int launch_crops_warp(trexhip_ctx* ctx, uint8_t* d_crops, int n, int OW, int OH, int diff_mode, const float* tr6, const float* lengths,
+                      bool legacy, float scale) {
+    if (int rc = check_colour_difference(ctx, diff_mode, "normalised crops")) return rc;
+    std::vector<double> minv((size_t)n * 6);
+    for (int i = 0; i < n; ++i) {
+        Aff tr;
+        std::memcpy(tr.m, tr6 + (size_t)i * 6, sizeof(tr.m));
+        compose_and_invert(tr, lengths ? lengths[i] : 0.f, legacy, OW, OH, scale, &minv[(size_t)i * 6]);
+    }
+    if (int rc = ensure_warp(ctx, n)) return rc;
+    TH_CHECK_HIP(hipMemcpyAsync(ctx->d_warp, minv.data(), minv.size() * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    TH_CHECK_HIP(hipStreamSynchronize(ctx->stream));        // minv lives on this stack frame
+    return launch_crops_warp_maps(ctx, d_crops, n, OW, OH, diff_mode);
+}
+
+int warp_reserve(trexhip_ctx* ctx, int n) { return ensure_warp(ctx, n); }
 
 }  // namespace trexhip
 
@@ -670,5 +636,5 @@ extern "C" int trexhip_crops_transformed_device(trexhip_ctx* ctx, uint8_t* d_cro
     if (n_blobs < 0 || (uint32_t)n_blobs > ctx->cfg.pool_blobs) { set_error("trexhip_crops_transformed_device: n_blobs outside the blob pool"); return TREXHIP_E_INVALID; }
     if (n_blobs == 0) return TREXHIP_OK;
     TH_CHECK_HIP(hipSetDevice(ctx->p.device));
-    return launch_crops_warp(ctx, d_crops, n_blobs, out_w, out_h, difference, transforms, midline_lengths, use_legacy != 0, image_scale, nullptr);
+    return launch_crops_warp(ctx, d_crops, n_blobs, out_w, out_h, difference, transforms, midline_lengths, use_legacy != 0, image_scale);
 }

@@ -132,6 +132,8 @@ struct trexhip_ctx {
     uint8_t* h_staging = nullptr;       // pinned upload buffer
     double* d_warp = nullptr;           // per-blob inverse affine maps of the normalised crops
     int warp_cap = 0;
+    float* d_len = nullptr;             // per-blob (median) midline lengths handed in by the caller
+    int len_cap = 0;
     uint32_t* d_bits[2] = {nullptr, nullptr};   // 1 bit/pixel masks for the optional morphology [B][H][ceil(W/32)]
     uint8_t* d_color = nullptr;         // BGR/BGRA frames of the colour-input API
     uint8_t* h_color = nullptr;

@@ -6,6 +6,7 @@
 // head at the origin, rotated by -angle+pi) goes to `mid`.  Float2_t = float with the reference's double accumulators;
 // compiled without FMA contraction like posture.hip.
 #include "internal.h"
+#include "affine.h"
 #include <cmath>
 #include <vector>
 
@@ -151,8 +152,44 @@ __global__ __launch_bounds__(64) void k_midline(const MidlineCfg C, const trexhi
 #undef S
 }
 
-int launch_crops_warp(trexhip_ctx* ctx, uint8_t* d_crops, int n, int OW, int OH, int diff_mode, const float* tr6, const float* lengths,
-                      bool legacy, float scale, const uint8_t* valid);
+int launch_crops_warp_maps(trexhip_ctx* ctx, uint8_t* d_crops, int n, int OW, int OH, int diff_mode);
+int warp_reserve(trexhip_ctx* ctx, int n);
+int check_colour_difference(trexhip_ctx* ctx, int difference, const char* who);
+
+// per-blob inverse affine maps of the normalised crops, on the device (no host round trip): one thread per blob.
+//   minfo != null: posture / legacy -- Midline::transform from the midline pose; blobs without a midline get a map that sends every
+//                  output pixel far outside the image (all-zero crop; diff_image returns nullptr for them, FilterCache.cpp:268-270)
+//   minfo == null: moments -- orientation from the integer moments of the blob table
+// This file is compiled with -ffp-contract=off: the floats equal the host's and the CPU checker's.
+__global__ __launch_bounds__(64) void k_warp_maps(const trexhip_midline_info* __restrict__ minfo, const float* __restrict__ lengths,
+                                                  const trexhip_blob* __restrict__ blobs, const int n, const int legacy, const int OW, const int OH,
+                                                  const float scale, double* __restrict__ out) {
+    const int i = blockIdx.x * 64 + threadIdx.x;
+    if (i >= n) return;
+    double* m = out + (size_t)i * 6;
+    Aff tr;
+    float len = 0.f;
+    if (minfo) {
+        const trexhip_midline_info mi = minfo[i];
+        if (mi.status != 0) { m[0] = m[1] = m[3] = m[4] = 0; m[2] = m[5] = -1.0e6; return; }
+        tr = midline_transform(mi.angle, mi.offx, mi.offy, legacy != 0);
+        len = lengths ? lengths[i] : mi.len;
+    } else {
+        const trexhip_blob B = blobs[i];
+        tr = moments_transform((float)B.n_pixels, (float)B.m10, (float)B.m01, (float)B.m20, (float)B.m11, (float)B.m02,
+                               (float)(B.x1 - B.x0 + 1), (float)(B.y1 - B.y0 + 1));
+    }
+    compose_and_invert(tr, len, legacy != 0, OW, OH, scale, m);
+}
+
+int launch_crops_warp_device(trexhip_ctx* ctx, uint8_t* d_crops, int n, int OW, int OH, int diff_mode, const trexhip_midline_info* d_minfo,
+                             const float* d_lengths, bool legacy, float scale) {
+    if (int rc = check_colour_difference(ctx, diff_mode, "normalised crops")) return rc;
+    if (int rc = warp_reserve(ctx, n)) return rc;
+    hipLaunchKernelGGL(k_warp_maps, dim3((n + 63) / 64), dim3(64), 0, ctx->stream, d_minfo, d_lengths, ctx->d_blobs, n, legacy ? 1 : 0, OW, OH, scale, ctx->d_warp);
+    TH_CHECK_HIP(hipGetLastError());
+    return launch_crops_warp_maps(ctx, d_crops, n, OW, OH, diff_mode);
+}
 
 }  // namespace trexhip
 
@@ -180,8 +217,6 @@ extern "C" void trexhip_default_midline_params(trexhip_midline_params* p) {
     p->midline_resolution = 25; p->midline_stiff_percentage = 0.15f; p->midline_invert = 0; p->midline_start_with_head = 0;
 }
 
-// Midline::transform(posture | legacy) with front() = 0 (never set outside the legacy file reader, Output.cpp:406):
-// rotate(DEGREE(-angle + pi/4 | pi)) . translate(-offset), on the host in float like gui::Transform
 extern "C" int trexhip_crops_posture_device(trexhip_ctx* ctx, uint8_t* d_crops, int32_t n_blobs, int32_t out_w, int32_t out_h,
                                             const trexhip_midline_info* d_midline_info, const float* midline_lengths, int32_t use_legacy,
                                             float image_scale, int32_t difference) {
@@ -191,22 +226,18 @@ extern "C" int trexhip_crops_posture_device(trexhip_ctx* ctx, uint8_t* d_crops, 
     if (n_blobs < 0 || (uint32_t)n_blobs > ctx->cfg.pool_blobs) { set_error("trexhip_crops_posture_device: n_blobs outside the blob pool"); return TREXHIP_E_INVALID; }
     if (n_blobs == 0) return TREXHIP_OK;
     TH_CHECK_HIP(hipSetDevice(ctx->p.device));
-    std::vector<trexhip_midline_info> mi((size_t)n_blobs);
-    TH_CHECK_HIP(hipMemcpyAsync(mi.data(), d_midline_info, mi.size() * sizeof(trexhip_midline_info), hipMemcpyDeviceToHost, ctx->stream));
-    TH_CHECK_HIP(hipStreamSynchronize(ctx->stream));
-    std::vector<float> tr((size_t)n_blobs * 6), len((size_t)n_blobs);
-    std::vector<uint8_t> valid((size_t)n_blobs);
-    for (int i = 0; i < n_blobs; ++i) {
-        const trexhip_midline_info& m = mi[(size_t)i];
-        valid[(size_t)i] = m.status == 0;
-        const float a = (float)(-(double)m.angle + (use_legacy ? 3.14159265358979323846 : 3.14159265358979323846 * 0.25));
-        const float deg = a * 180.f / 3.14159265358979323846f;
-        const float rad = deg * 3.141592654f / 180.f;
-        const float c = std::cos(rad), s = std::sin(rad);
-        float* t = &tr[(size_t)i * 6];
-        t[0] = c; t[1] = -s; t[2] = c * -m.offx + -s * -m.offy;
-        t[3] = s; t[4] = c;  t[5] = s * -m.offx + c * -m.offy;
-        len[(size_t)i] = midline_lengths ? midline_lengths[i] : m.len;
+    // the transforms are built on the device from the midline poses (k_warp_maps): no copy of the poses to the host, no stream sync.
+    // The optional per-blob (median) midline lengths are a host array: they are uploaded into a buffer of the context.
+    const float* d_len = nullptr;
+    if (midline_lengths) {
+        if (ctx->len_cap < n_blobs) {
+            if (ctx->d_len) (void)hipFree(ctx->d_len);
+            ctx->d_len = nullptr; ctx->len_cap = 0;
+            TH_CHECK_HIP(hipMalloc(reinterpret_cast<void**>(&ctx->d_len), (size_t)n_blobs * sizeof(float)));
+            ctx->len_cap = n_blobs;
+        }
+        TH_CHECK_HIP(hipMemcpyAsync(ctx->d_len, midline_lengths, (size_t)n_blobs * sizeof(float), hipMemcpyHostToDevice, ctx->stream));   // pageable source: staged before the call returns
+        d_len = ctx->d_len;
     }
-    return launch_crops_warp(ctx, d_crops, n_blobs, out_w, out_h, difference, tr.data(), len.data(), use_legacy != 0, image_scale, valid.data());
+    return launch_crops_warp_device(ctx, d_crops, n_blobs, out_w, out_h, difference, d_midline_info, d_len, use_legacy != 0, image_scale);
 }
