@@ -2,7 +2,7 @@
 // SFML-style 2x3 affine in float (post-multiply), shared by the host path (caller-supplied transforms) and the device kernel that
 // builds the per-blob inverse maps (midline.hip, compiled without FMA contraction so that both give the same floats).
 // cos / sin / atan2 are the correctly rounded float results (computed in double and narrowed): the reference's libm is not part of
-// any parity contract, and a correctly rounded value is the one definition every here (CPU oracle, host, device) can meet.
+// any parity contract, and a correctly rounded value is the one definition that the CPU checker, the host path and the device can all meet.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <cmath>
