@@ -272,6 +272,17 @@ void trexhip_default_posture_params(trexhip_posture_params* p);
 int trexhip_posture_device(trexhip_ctx* ctx, int32_t table, const trexhip_posture_params* pp, int32_t n_blobs,
                            float* d_outline, float* d_segments, trexhip_posture_info* d_info);
 
+/* posture::calculate_posture WITH its retry loop (Posture.cpp:305-399), for every DETECT blob of the last fetched batch: threshold =
+ * track_posture_threshold; repeat { biggest sub-blob at that threshold (pixel::threshold_get_biggest_blob; method as in
+ * trexhip_rethreshold_device) -> outline relative to the original blob -> midline; done on success; else threshold += 2 } until the
+ * sub-blob has fewer than max(1, pixels / 10) pixels or threshold >= track_posture_threshold + 100; without success the first outline
+ * that could be traced is returned without a midline (status of the last attempt, n_segments 0).  Outputs as trexhip_posture_device
+ * (pooled order of the detect table); d_threshold_used / d_iterations ([n_blobs] int32, may be NULL) = the threshold whose result is
+ * returned (-1: none) and the attempts made.  Uses (overwrites) the context's re-threshold tables. */
+int trexhip_posture_auto_device(trexhip_ctx* ctx, const trexhip_posture_params* pp, int32_t method, int32_t track_posture_threshold,
+                                int32_t n_blobs, float* d_outline, float* d_segments, trexhip_posture_info* d_info,
+                                int32_t* d_threshold_used, int32_t* d_iterations);
+
 /* Midline::post_process (no movement information, posture_direction_smoothing = 0; Outline.cpp:895-1060) followed by
  * Midline::normalize() (Outline.cpp:1270-1454; call site Individual.cpp:1369-1372) for every blob of a posture call.
  *   d_segments: the segments buffer of trexhip_posture_device (same max_points); post-processed IN PLACE (head part straightened)

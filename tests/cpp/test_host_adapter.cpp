@@ -343,6 +343,21 @@ int main(int argc, char** argv) {
         try { r = hp.calculate_posture(0, (int)res.total_blobs, ps); }
         catch (const std::exception& e) { std::fprintf(stderr, "calculate_posture: %s\n", e.what()); std::exit(1); }
         CHECK(r.size() == 4);
+        {   // the same blobs through the reference's own loop (posture::calculate_posture: threshold += 2 until a midline is found):
+            // these bodies give a midline at the first threshold, so the results are those of the single pass; refused settings throw
+            std::vector<int32_t> used;
+            auto r2 = hp.calculate_posture((int)res.total_blobs, ps, &used);
+            CHECK(r2.size() == 4 && used.size() == 4);
+            for (size_t b = 0; b < r2.size(); ++b) {
+                CHECK((bool)r2[b] == (bool)r[b] && r2[b].value.outline.size() == r[b].value.outline.size());
+                CHECK((r2[b].value.midline != nullptr) == (r[b].value.midline != nullptr));
+                if (r2[b].value.midline) CHECK(used[b] == ps.track_posture_threshold && r2[b].value.midline->size() == r[b].value.midline->size());
+            }
+            HipPosture::Settings bad = ps; bad.peak_mode_broad = true;
+            bool threw = false; try { (void)hp.calculate_posture((int)res.total_blobs, bad); } catch (const std::exception&) { threw = true; }
+            CHECK(threw);
+            r = hp.calculate_posture(0, (int)res.total_blobs, ps);            // leave the single-pass midlines in place for the crops below
+        }
         int with_midline = 0;
         for (size_t b = 0; b < r.size(); ++b) {
             CHECK((bool)r[b]);

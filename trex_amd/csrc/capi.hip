@@ -222,7 +222,7 @@ void trexhip_destroy(trexhip_ctx* ctx) {
     pass2_free(ctx);
     void* dev[] = {ctx->d_bg, ctx->d_staging, ctx->d_ctr, ctx->d_row_cnt, ctx->d_row_off, ctx->d_row_base, ctx->d_tmp_runs,
                    ctx->d_raster, ctx->d_parent, ctx->d_root_ord, ctx->d_cnt_runs, ctx->d_cnt_px, ctx->d_cur_run,
-                   ctx->d_pix_begin, ctx->d_blob_map, ctx->d_info, ctx->d_blobs, ctx->d_blob_frame, ctx->d_runs, ctx->d_pixels, ctx->d_color, ctx->d_bits[0], ctx->d_bits[1], ctx->d_warp, ctx->d_bg_color, ctx->d_len};
+                   ctx->d_pix_begin, ctx->d_blob_map, ctx->d_info, ctx->d_blobs, ctx->d_blob_frame, ctx->d_runs, ctx->d_pixels, ctx->d_color, ctx->d_bits[0], ctx->d_bits[1], ctx->d_warp, ctx->d_bg_color, ctx->d_len, ctx->d_auto};
     for (void* p : dev) if (p) hipFree(p);
     upload_free(ctx);
     void* host[] = {ctx->h_info, ctx->h_totals, ctx->h_blobs, ctx->h_runs, ctx->h_pixels, ctx->h_staging, ctx->h_color};

@@ -134,6 +134,8 @@ struct trexhip_ctx {
     int warp_cap = 0;
     float* d_len = nullptr;             // per-blob (median) midline lengths handed in by the caller
     int len_cap = 0;
+    void* d_auto = nullptr;             // scratch of trexhip_posture_auto_device (thresholds, selections, first outlines)
+    size_t auto_cap = 0;
     uint32_t* d_bits[2] = {nullptr, nullptr};   // 1 bit/pixel masks for the optional morphology [B][H][ceil(W/32)]
     uint8_t* d_color = nullptr;         // BGR/BGRA frames of the colour-input API
     uint8_t* h_color = nullptr;

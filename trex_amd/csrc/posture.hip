@@ -12,6 +12,7 @@
 // The float pipeline is compiled without FMA contraction (-ffp-contract=off in the Makefile) so resample / smooth /
 // walk reproduce the CPU operation order; the transcendental part (EFT) agrees to float rounding.
 #include "internal.h"
+#include <algorithm>
 #include <type_traits>
 
 namespace trexhip {
@@ -55,7 +56,8 @@ __global__ __launch_bounds__(256) void k_posture(const PostureCfg P, const trexh
                                                  const uint32_t* __restrict__ blob_frame, const trexhip_blob* __restrict__ blobs,
                                                  const trexhip_run* __restrict__ runs, int n_blobs, int B,
                                                  float2* __restrict__ out_outline, float4* __restrict__ out_segments,
-                                                 trexhip_posture_info* __restrict__ out_info) {
+                                                 trexhip_posture_info* __restrict__ out_info,
+                                                 const int32_t* __restrict__ sel, const trexhip_blob* __restrict__ origin) {
     extern __shared__ __attribute__((aligned(16))) uint8_t plds[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int bi = blockIdx.x * (int)(blockDim.x >> 6) + wave;   // 4, 2 or 1 blobs per workgroup (LDS per blob)
@@ -71,12 +73,16 @@ __global__ __launch_bounds__(256) void k_posture(const PostureCfg P, const trexh
 
     trexhip_posture_info res = {};
     const int cap = NPc;
-    const uint32_t f = blob_frame[bi];
+    // sel: output slot bi takes blob sel[bi] of the table (negative: nothing to do for this slot); origin: the blob whose bounds().pos()
+    // the coordinates are relative to (the ORIGINAL blob when a thresholded sub-blob is traced, Posture.cpp:336)
+    const int si = sel ? sel[bi] : bi;
+    if (si < 0) return;
+    const uint32_t f = blob_frame[si];
     bool ok = f < (uint32_t)B;
     trexhip_frame_info fi = {};
     if (ok) { fi = info[f]; ok = fi.flags == 0; }
     if (!ok) { if (lane == 0) { res.status = 1; out_info[bi] = res; } return; }
-    const trexhip_blob Bl = blobs[bi];
+    const trexhip_blob Bl = blobs[si];
     const int n_runs = (int)Bl.n_runs, y0 = Bl.y0, y1 = Bl.y1, rows = y1 - y0 + 1;
     if (n_runs == 0) { if (lane == 0) { res.status = 1; out_info[bi] = res; } return; }
     if (n_runs > P.nr_cap || rows > P.rows_cap) { if (lane == 0) { res.status = 2; out_info[bi] = res; } return; }
@@ -88,7 +94,7 @@ __global__ __launch_bounds__(256) void k_posture(const PostureCfg P, const trexh
     }
     if (lane == 0) s_row[rows] = n_runs;
     __builtin_amdgcn_wave_barrier();
-    const int ox = Bl.x0, oy = Bl.y0;                       // coordinates relative to the blob's bounds().pos() (Posture.cpp:336)
+    const int ox = origin ? (int)origin[bi].x0 : (int)Bl.x0, oy = origin ? (int)origin[bi].y0 : (int)Bl.y0;   // coordinates relative to the blob's bounds().pos() (Posture.cpp:336)
     // blobs at most 64 pixels wide: one 64-bit occupancy word per row (in the curvature / arc-length arrays, idle until the
     // outline exists) makes the membership test of the boundary walk a single LDS read
     const int bx0 = Bl.x0;
@@ -193,7 +199,7 @@ __global__ __launch_bounds__(256) void k_posture(const PostureCfg P, const trexh
                     const int pos = (int)(first >> 16) - (int)(v >> 16);
                     const uint32_t g = geo[e];
                     const int xr = (int)(g & 0x3fu), yr = (int)((g >> 6) & 0x3ffu), k = (int)(g >> 16);
-                    const int vx = 2 * xr + ((k == 1 || k == 2) ? 1 : -1), vy = 2 * yr + ((k >= 2) ? 1 : -1);   // doubled, blob-relative
+                    const int vx = 2 * (xr + bx0 - ox) + ((k == 1 || k == 2) ? 1 : -1), vy = 2 * (yr + y0 - oy) + ((k >= 2) ? 1 : -1);   // doubled, relative to the origin
                     const int ddx = k == 0 ? 1 : (k == 2 ? -1 : 0), ddy = k == 1 ? 1 : (k == 3 ? -1 : 0);
                     bufA[2 * pos] = make_float2(0.5f * (float)vx, 0.5f * (float)vy);
                     bufA[2 * pos + 1] = make_float2(0.5f * (float)(vx + ddx), 0.5f * (float)(vy + ddy));
@@ -602,9 +608,160 @@ extern "C" int trexhip_posture_device(trexhip_ctx* ctx, int32_t table, const tre
 #endif
     stage_begin(ctx, TREXHIP_STAGE_POSTURE);
     hipLaunchKernelGGL(k_posture, dim3((n_blobs + wpb - 1) / wpb), dim3(wpb * 64), lds_bytes, ctx->stream, P, info, bf, bl, ru, n_blobs, ctx->last_n,
-                       reinterpret_cast<float2*>(d_outline), reinterpret_cast<float4*>(d_segments), d_info);
+                       reinterpret_cast<float2*>(d_outline), reinterpret_cast<float4*>(d_segments), d_info, (const int32_t*)nullptr, (const trexhip_blob*)nullptr);
     stage_end(ctx, TREXHIP_STAGE_POSTURE);
     TH_CHECK_HIP(hipGetLastError());
+    return TREXHIP_OK;
+}
+
+// ---- posture::calculate_posture with its retry loop (Posture.cpp:305-399) ---------------------------------------------------------
+// Per detect blob: threshold = track_posture_threshold; repeat { biggest sub-blob at `threshold` (pixel::threshold_get_biggest_blob:
+// re-threshold + largest pixel count, the first wins a tie) -> outline relative to the ORIGINAL blob -> resample -> midline; success
+// ends the loop; else remember the first outline, threshold += 2, stop when that sub-blob had fewer than max(1, initial / 10) pixels or
+// threshold >= track_posture_threshold + 100 }; without success the first outline is returned without a midline (:383-391).
+// On the device every round is: one per-blob re-threshold pass over the still active blobs (trexhip_rethreshold_per_blob_device),
+// k_auto_pick / k_auto_sel (biggest sub-blob per detect blob by a 64-bit atomic max), k_posture on the selected sub-blobs, k_auto_step
+// (one wave per blob: bookkeeping, first-outline copy); the host only reads the number of blobs still active.
+namespace trexhip {
+__global__ void k_auto_init(const int n, const int tpt, int32_t* thr, int32_t* first_n, int32_t* first_thr, int32_t* used, int32_t* iters,
+                            unsigned long long* best, trexhip_posture_info* info) {
+    const int b = blockIdx.x * 256 + threadIdx.x;
+    if (b >= n) return;
+    thr[b] = tpt; first_n[b] = 0; first_thr[b] = -1; used[b] = -1; iters[b] = 0; best[b] = 0ull;
+    trexhip_posture_info z = {}; z.status = 1; info[b] = z;
+}
+__global__ void k_auto_pick(const trexhip_blob* __restrict__ sub, const uint32_t* __restrict__ totals2, const uint32_t pool, const int n,
+                            unsigned long long* best) {
+    const uint32_t s = blockIdx.x * 256u + threadIdx.x;
+    const uint32_t tot = totals2[0] < pool ? totals2[0] : pool;
+    if (s >= tot) return;
+    const trexhip_blob B = sub[s];
+    if (B.parent >= (uint32_t)n || B.n_pixels == 0) return;                       // holes of frames that overflowed carry no parent
+    atomicMax(best + B.parent, ((unsigned long long)B.n_pixels << 32) | (unsigned long long)(0xffffffffu - s));   // most pixels, then the lowest index
+}
+__global__ void k_auto_sel(const int n, const int32_t* thr, const unsigned long long* best, int32_t* sel) {
+    const int b = blockIdx.x * 256 + threadIdx.x;
+    if (b >= n) return;
+    sel[b] = (thr[b] >= 0 && best[b] != 0ull) ? (int32_t)(0xffffffffu - (uint32_t)best[b]) : -1;
+}
+__global__ __launch_bounds__(256) void k_auto_step(const int n, const int tpt, const int max_points, const trexhip_blob* __restrict__ detect,
+                                                   int32_t* thr, const int32_t* sel, unsigned long long* best, int32_t* first_n, int32_t* first_thr,
+                                                   int32_t* used, int32_t* iters, float2* first, float2* outline, trexhip_posture_info* info,
+                                                   uint32_t* active) {
+    const int lane = threadIdx.x & 63, b = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (b >= n) return;
+    const int t = thr[b];
+    if (t < 0) return;
+    const int s = sel[b];
+    const uint32_t count = s >= 0 ? (uint32_t)(best[b] >> 32) : 0u;
+    trexhip_posture_info last = info[b];
+    if (s < 0) { trexhip_posture_info z = {}; z.status = 1; last = z; }
+    __builtin_amdgcn_wave_barrier();
+    if (lane == 0) { iters[b] += 1; best[b] = 0ull; }
+    if (s >= 0 && last.status == 0) { if (lane == 0) { used[b] = t; thr[b] = -1; } return; }      // a midline at the lowest possible threshold
+    float2* mine = outline + (size_t)b * max_points;
+    float2* keep = first + (size_t)b * max_points;
+    int fn = first_n[b];
+    if (s >= 0 && fn == 0 && last.n_outline > 0) {                                    // the first outline that could be traced
+        for (int i = lane; i < last.n_outline; i += 64) keep[i] = mine[i];
+        fn = last.n_outline;
+        if (lane == 0) { first_n[b] = fn; first_thr[b] = t; }
+    }
+    const uint32_t initial = detect[b].n_pixels;
+    const uint32_t minimum = initial / 10u > 1u ? initial / 10u : 1u;
+    const int tn = t + 2;
+    if (count < minimum || tn >= tpt + 100) {                                         // give up: the first outline, no midline
+        __builtin_amdgcn_wave_barrier();
+        for (int i = lane; i < fn; i += 64) mine[i] = keep[i];
+        if (lane == 0) {
+            last.n_outline = fn; last.n_segments = 0;
+            if (last.status == 0) last.status = 1;
+            info[b] = last;
+            used[b] = fn > 0 ? (first_thr[b] >= 0 ? first_thr[b] : t) : -1;
+            thr[b] = -1;
+        }
+        return;
+    }
+    if (lane == 0) { thr[b] = tn; atomicAdd(active, 1u); }
+}
+}  // namespace trexhip
+
+extern "C" int trexhip_posture_auto_device(trexhip_ctx* ctx, const trexhip_posture_params* pp, int32_t method, int32_t track_posture_threshold,
+                                           int32_t n_blobs, float* d_outline, float* d_segments, trexhip_posture_info* d_info,
+                                           int32_t* d_threshold_used, int32_t* d_iterations) {
+    if (!ctx || !pp || !d_outline || !d_segments || !d_info) { set_error("trexhip_posture_auto_device: null argument"); return TREXHIP_E_INVALID; }
+    if (method < 0 || method > 2) { set_error("trexhip_posture_auto_device: method must be 0 (absolute), 1 (sign) or 2 (none)"); return TREXHIP_E_INVALID; }
+    if (track_posture_threshold < 0 || track_posture_threshold > 255) { set_error("trexhip_posture_auto_device: track_posture_threshold must be 0..255"); return TREXHIP_E_INVALID; }
+    // the argument checks of the single pass (capacities, refused settings) by a zero-blob call of it
+    if (int rc = trexhip_posture_device(ctx, 0, pp, 0, d_outline, d_segments, d_info)) return rc;
+    if (n_blobs < 0 || (uint32_t)n_blobs > ctx->cfg.pool_blobs) { set_error("trexhip_posture_auto_device: n_blobs outside the blob pool"); return TREXHIP_E_INVALID; }
+    if (n_blobs == 0) return TREXHIP_OK;
+    TH_CHECK_HIP(hipSetDevice(ctx->p.device));
+    const int n = n_blobs, MPt = pp->max_points;
+    // scratch of the loop, kept by the context
+    const size_t need = (size_t)n * (6 * sizeof(int32_t) + sizeof(unsigned long long) + (size_t)MPt * sizeof(float2)) + 64;
+    if (ctx->auto_cap < need) {
+        if (ctx->d_auto) (void)hipFree(ctx->d_auto);
+        ctx->d_auto = nullptr; ctx->auto_cap = 0;
+        TH_CHECK_HIP(hipMalloc(&ctx->d_auto, need));
+        ctx->auto_cap = need;
+    }
+    uint8_t* base = static_cast<uint8_t*>(ctx->d_auto);
+    unsigned long long* best = reinterpret_cast<unsigned long long*>(base); base += (size_t)n * 8;
+    float2* first = reinterpret_cast<float2*>(base); base += (size_t)n * MPt * sizeof(float2);
+    int32_t* thr = reinterpret_cast<int32_t*>(base); base += (size_t)n * 4;
+    int32_t* sel = reinterpret_cast<int32_t*>(base); base += (size_t)n * 4;
+    int32_t* first_n = reinterpret_cast<int32_t*>(base); base += (size_t)n * 4;
+    int32_t* first_thr = reinterpret_cast<int32_t*>(base); base += (size_t)n * 4;
+    int32_t* used = reinterpret_cast<int32_t*>(base); base += (size_t)n * 4;
+    int32_t* iters = reinterpret_cast<int32_t*>(base); base += (size_t)n * 4;
+    uint32_t* active = reinterpret_cast<uint32_t*>(base);
+    hipStream_t s = ctx->stream;
+    const dim3 g256((unsigned)((n + 255) / 256));
+    hipLaunchKernelGGL(k_auto_init, g256, dim3(256), 0, s, n, (int)track_posture_threshold, thr, first_n, first_thr, used, iters, best, d_info);
+    // LDS capacities of the posture launches: a thresholded sub-blob has at most its parent's rows, and more lines only where a line splits
+    int nr_cap = P_NR, rows_cap = P_ROWS;
+    if (ctx->h_blobs && ctx->fetched) {
+        uint32_t mr = 1, mrows = 1;
+        for (int i = 0; i < n; ++i) {
+            const trexhip_blob& b = ctx->h_blobs[i];
+            const uint32_t rws = (uint32_t)(b.y1 - b.y0 + 1);
+            if (rws <= (uint32_t)P_ROWS) { mr = std::max(mr, std::min<uint32_t>(b.n_runs * 2u, (uint32_t)P_NR)); mrows = std::max(mrows, rws); }
+        }
+        nr_cap = (int)std::min<uint32_t>((mr + 31u) & ~31u, (uint32_t)P_NR);
+        rows_cap = (int)std::min<uint32_t>((mrows + 29u) / 32u * 32u + 30u, (uint32_t)P_ROWS);
+    }
+    const int wave_lds = posture_wave_lds(MPt, nr_cap, rows_cap);
+    int wpb = 4;
+    while (wpb > 1 && wpb * wave_lds > 150 * 1024) wpb >>= 1;
+    const int lds_bytes = wpb * wave_lds;
+    if (lds_bytes > ctx->attr_posture_bytes) {
+        TH_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_posture), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
+        ctx->attr_posture_bytes = lds_bytes;
+    }
+    const PostureCfg P{pp->outline_resample, pp->outline_smooth_samples, pp->outline_smooth_step, pp->outline_approximate,
+                       pp->outline_curvature_range_ratio, pp->midline_walk_offset, pp->max_points, nr_cap, rows_cap, 0};
+    for (int round = 0; round < 51; ++round) {                        // thresholds t, t+2, ..., below t+100
+        int rc = trexhip_rethreshold_per_blob_device(ctx, 0, thr, method, nullptr, 0);     // negative entries (finished blobs) are skipped
+        if (rc) return rc;
+        const Pass2& q = ctx->pass2;
+        TH_CHECK_HIP(hipMemsetAsync(active, 0, 4, s));
+        hipLaunchKernelGGL(k_auto_pick, dim3((ctx->cfg.pool_blobs + 255u) / 256u), dim3(256), 0, s, q.d_blobs, q.d_totals, ctx->cfg.pool_blobs, n, best);
+        hipLaunchKernelGGL(k_auto_sel, g256, dim3(256), 0, s, n, thr, best, sel);
+        stage_begin(ctx, TREXHIP_STAGE_POSTURE);
+        hipLaunchKernelGGL(k_posture, dim3((n + wpb - 1) / wpb), dim3(wpb * 64), lds_bytes, s, P, q.d_info, q.d_blob_frame, q.d_blobs, q.d_runs, n, ctx->last_n,
+                           reinterpret_cast<float2*>(d_outline), reinterpret_cast<float4*>(d_segments), d_info, sel, ctx->d_blobs);
+        stage_end(ctx, TREXHIP_STAGE_POSTURE);
+        hipLaunchKernelGGL(k_auto_step, dim3((n + 3) / 4), dim3(256), 0, s, n, (int)track_posture_threshold, MPt, ctx->d_blobs, thr, sel, best, first_n, first_thr,
+                           used, iters, first, reinterpret_cast<float2*>(d_outline), d_info, active);
+        TH_CHECK_HIP(hipGetLastError());
+        uint32_t still = 0;
+        TH_CHECK_HIP(hipMemcpyAsync(&still, active, 4, hipMemcpyDeviceToHost, s));
+        TH_CHECK_HIP(hipStreamSynchronize(s));
+        if (still == 0) break;
+    }
+    if (d_threshold_used) TH_CHECK_HIP(hipMemcpyAsync(d_threshold_used, used, (size_t)n * 4, hipMemcpyDeviceToDevice, s));
+    if (d_iterations) TH_CHECK_HIP(hipMemcpyAsync(d_iterations, iters, (size_t)n * 4, hipMemcpyDeviceToDevice, s));
     return TREXHIP_OK;
 }
 

@@ -32,6 +32,12 @@ public:
         float midline_stiff_percentage = 0.15f;
         bool midline_invert = false, midline_start_with_head = false;
         int max_points = 512;                           // capacity per blob: traced lattice points = 2 per pixel edge of the outline; even, up to 4096
+        // calculate_posture(n_blobs, settings): the thresholds of posture::calculate_posture's own loop (Posture.cpp:318,335)
+        int track_posture_threshold = 15;               // core/default_config.cpp track_posture_threshold
+        int threshold_method = 0;                       // 0 |bg - p| (track_threshold_is_absolute), 1 max(bg - p, 0), 2 p: as trexhip_rethreshold_device
+        // settings this backend refuses (std::runtime_error from calculate_posture) instead of ignoring them
+        int posture_closing_steps = 0, posture_direction_smoothing = 0;
+        bool peak_mode_broad = false;
     };
     struct Result {                                     // posture::Result (Posture.h:34-38)
         Outline outline;
@@ -50,9 +56,18 @@ public:
     HipPosture(const HipPosture&) = delete;
     HipPosture& operator=(const HipPosture&) = delete;
 
-    // table 0: the detect blobs; table 1: the sub-blobs of the last trexhip_rethreshold*_device call (= the biggest
-    // thresholded blob chosen by the caller, Posture.cpp:335).  One entry per blob, pooled order.
-    std::vector<Expected> calculate_posture(int table, int n_blobs, const Settings& s) {
+    // posture::calculate_posture(Frame_t, pv::BlobWeakPtr) for every detect blob of the batch, WITH the reference's loop: biggest
+    // sub-blob at track_posture_threshold, +2 per failed attempt, first-outline fallback (Posture.cpp:305-399).  One entry per blob,
+    // pooled order.  thresholds_used (optional): the threshold whose result each blob got (-1: nothing could be traced).
+    std::vector<Expected> calculate_posture(int n_blobs, const Settings& s, std::vector<int32_t>* thresholds_used = nullptr) {
+        return run(true, 0, n_blobs, s, thresholds_used);
+    }
+    // one pass over a table as it is: table 0 = the detect blobs, table 1 = the sub-blobs of the caller's last
+    // trexhip_rethreshold*_device call.  One entry per blob of that table, pooled order.
+    std::vector<Expected> calculate_posture(int table, int n_blobs, const Settings& s) { return run(false, table, n_blobs, s, nullptr); }
+
+private:
+    std::vector<Expected> run(bool with_loop, int table, int n_blobs, const Settings& s, std::vector<int32_t>* thresholds_used) {
         std::vector<Expected> out((size_t)n_blobs);
         if (n_blobs <= 0) return out;
         reserve(n_blobs, s);
@@ -61,11 +76,25 @@ public:
         pp.outline_smooth_step = s.outline_smooth_step; pp.outline_approximate = s.outline_approximate;
         pp.outline_curvature_range_ratio = s.outline_curvature_range_ratio; pp.midline_walk_offset = s.midline_walk_offset;
         pp.max_points = s.max_points;
+        pp.posture_closing_steps = s.posture_closing_steps; pp.posture_direction_smoothing = s.posture_direction_smoothing;
+        pp.peak_mode = s.peak_mode_broad ? 1 : 0;                    // non-default values are refused by the library (TREXHIP_E_UNSUPPORTED)
         trexhip_midline_params mp; trexhip_default_midline_params(&mp);
         mp.midline_resolution = (int32_t)s.midline_resolution; mp.midline_stiff_percentage = s.midline_stiff_percentage;
         mp.midline_invert = s.midline_invert; mp.midline_start_with_head = s.midline_start_with_head;
         const size_t SEG = (size_t)s.max_points / 2 + 1, R = s.midline_resolution;
-        check(trexhip_posture_device(_ctx, table, &pp, n_blobs, _d_outline, _d_segments, _d_pinfo));
+        if (with_loop) {
+            int32_t* d_thr = nullptr;
+            if (thresholds_used) check(trexhip_device_alloc(_ctx, (size_t)n_blobs * 4, reinterpret_cast<void**>(&d_thr)));
+            const int rc = trexhip_posture_auto_device(_ctx, &pp, s.threshold_method, s.track_posture_threshold, n_blobs, _d_outline, _d_segments, _d_pinfo, d_thr, nullptr);
+            if (rc == 0 && thresholds_used) {
+                thresholds_used->resize((size_t)n_blobs);
+                (void)trexhip_synchronize(_ctx);
+                (void)trexhip_copy_to_host(_ctx, thresholds_used->data(), d_thr, (size_t)n_blobs * 4);
+            }
+            if (d_thr) (void)trexhip_device_free(_ctx, d_thr);
+            check(rc);
+        } else
+            check(trexhip_posture_device(_ctx, table, &pp, n_blobs, _d_outline, _d_segments, _d_pinfo));
         // the raw midline (Result::midline) is read back before post_process straightens it in place
         std::vector<float> outline((size_t)n_blobs * s.max_points * 2), raw((size_t)n_blobs * SEG * 4), norm((size_t)n_blobs * R * 4);
         std::vector<trexhip_posture_info> pinfo((size_t)n_blobs);
@@ -118,6 +147,7 @@ public:
         return out;
     }
 
+public:
     // constraints::diff_image for every blob of the batch: `normalize` as in individual_image_normalization
     // (0 none, 1 moments, 2 posture, 3 legacy); posture / legacy use the midlines of the last calculate_posture call and the
     // caller's per-blob median midline length (nullptr: each blob's own length); blobs without a midline yield nullptr
