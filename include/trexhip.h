@@ -183,6 +183,17 @@ int trexhip_fetch(trexhip_ctx* ctx, trexhip_batch_result* out);
 int trexhip_device_view_get(trexhip_ctx* ctx, trexhip_device_view* out);
 int trexhip_synchronize(trexhip_ctx* ctx);
 
+/* ---- .pv frame bodies ------------------------------------------------------------------------------
+ * pv::Frame::serialize (ProcessedVideo/pv.cpp:666-703) for every frame of the last fetched batch, on the device, in the layout
+ * pv::Frame::read_from accepts for file version V_6 (pv.cpp:296-420) -- the newest one whose line type is in the reference tree
+ * (LegacyShortHorizontalLine, pv.h:17-52; >= V_7 use commons' ShortHorizontalLine): u8 compression_flag = 0, u64 timestamp, u16 n,
+ * n x {u16 start_y, u16 mask_size, mask_size x {u16 x0, u16 x1 << 1 | eol}, 1 byte per pixel}.  Gray pixel arrays, width <= 32768.
+ *   timestamps  host array [n_frames] (relative to the file header's timestamp) or NULL (zeros)
+ *   d_out       the bodies back to back, in frame order;  d_offsets [n_frames + 1] byte offsets (d_offsets[n_frames] = total bytes;
+ *               when that exceeds `capacity` nothing valid was written: call again with a larger buffer)
+ * The file header (pv.cpp:842-990) and LZO compression are not produced. */
+int trexhip_pack_frames_v6_device(trexhip_ctx* ctx, const uint64_t* timestamps, uint8_t* d_out, size_t capacity, uint64_t* d_offsets);
+
 /* ---- track-stage re-threshold -----------------------------------------------------------------
  * Tracker::prefilter's arithmetic (tracking/Tracker.cpp:765-849): for every kept blob of the last segmented
  * batch, pixel::threshold_blob(blob, threshold, background) -- keep a pixel iff diff >= threshold with

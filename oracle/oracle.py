@@ -75,7 +75,7 @@ def make_params(width, height, threshold=15, threshold_maximum=255, enable_diffe
 
 def build(force=False):
     so = os.path.join(_HERE, "liboracle.so")
-    src = [os.path.join(_HERE, f) for f in ("trex_oracle.c", "trex_posture.c", "trex_split.c", "trex_oracle.h")]
+    src = [os.path.join(_HERE, f) for f in ("trex_oracle.c", "trex_posture.c", "trex_split.c", "trex_pv.c", "trex_oracle.h")]
     if force or not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in src if os.path.exists(s)):
         subprocess.check_call(["make", "-C", _HERE, "-s", "-B"])
     return so
@@ -462,3 +462,29 @@ def split_search(runs, pixels, bg, method, params, presumed_nr, connectivity=8):
     lib().oracle_split_search(_ptr(runs), len(runs), _ptr(pixels), _ptr(bg), bg.shape[1], bg.shape[1], bg.shape[0], method, connectivity,
                               C.byref(params), presumed_nr, C.byref(out))
     return out
+
+
+def pv_serialize_v6(blobs, runs, pixels, timestamp=0):
+    """pv::Frame::serialize in the on-disk layout of file version V_6 (oracle/trex_pv.c); blobs / runs / pixels of ONE frame."""
+    blobs = np.ascontiguousarray(blobs, BLOB_DTYPE); runs = np.ascontiguousarray(runs, RUN_DTYPE); pixels = np.ascontiguousarray(pixels, np.uint8)
+    f = lib().oracle_pv_serialize_v6
+    f.restype = C.c_uint64
+    f.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]
+    n = f(_ptr(blobs), len(blobs), _ptr(runs), _ptr(pixels), timestamp, None)
+    out = np.zeros(n, np.uint8)
+    f(_ptr(blobs), len(blobs), _ptr(runs), _ptr(pixels), timestamp, _ptr(out))
+    return out
+
+
+def pv_read_v6(buf):
+    """pv::Frame::read_from for version V_6: (bytes consumed, timestamp, runs with y, pixels, runs per object, pixels per object)."""
+    buf = np.ascontiguousarray(buf, np.uint8)
+    runs = np.zeros(max(1, len(buf) // 4), RUN_DTYPE); px = np.zeros(max(1, len(buf)), np.uint8)
+    br = np.zeros(65536, np.uint32); bp = np.zeros(65536, np.uint32)
+    ts = C.c_uint64(); n = C.c_int32()
+    f = lib().oracle_pv_read_v6
+    f.restype = C.c_uint64
+    f.argtypes = [C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(C.c_int32), C.c_void_p, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int32]
+    used = f(_ptr(buf), len(buf), C.byref(ts), C.byref(n), _ptr(runs), len(runs), _ptr(px), len(px), _ptr(br), _ptr(bp), 65535)
+    nb = n.value
+    return int(used), int(ts.value), runs[:int(br[:nb].sum())].copy(), px[:int(bp[:nb].sum())].copy(), br[:nb].copy(), bp[:nb].copy()

@@ -103,7 +103,7 @@ SYMBOLS = [
     "trexhip_set_stream", "trexhip_set_background", "trexhip_set_background_device", "trexhip_set_background_color", "trexhip_set_background_color_device", "trexhip_generate_average_device", "trexhip_get_background", "trexhip_segment_device",
     "trexhip_segment", "trexhip_segment_color", "trexhip_segment_color_device", "trexhip_rethreshold_device", "trexhip_rethreshold_per_blob_device", "trexhip_fetch_rethreshold", "trexhip_fetch", "trexhip_device_view_get", "trexhip_synchronize",
     "trexhip_profile_enable", "trexhip_profile_read", "trexhip_profile_reset",
-    "trexhip_default_posture_params", "trexhip_posture_device", "trexhip_posture_auto_device", "trexhip_crops_device", "trexhip_pixel_channels", "trexhip_device_alloc", "trexhip_device_free", "trexhip_copy_to_host", "trexhip_copy_to_device", "trexhip_crops_transformed_device", "trexhip_crops_posture_device", "trexhip_default_midline_params", "trexhip_midline_device", "trexhip_default_split_params", "trexhip_split_search_device", "trexhip_export_id_table_device", "trexhip_export_id_table_ex_device", "trexhip_load_weights", "trexhip_set_identity_precision", "trexhip_num_classes", "trexhip_identify_device", "trexhip_identify",
+    "trexhip_default_posture_params", "trexhip_posture_device", "trexhip_posture_auto_device", "trexhip_pack_frames_v6_device", "trexhip_crops_device", "trexhip_pixel_channels", "trexhip_device_alloc", "trexhip_device_free", "trexhip_copy_to_host", "trexhip_copy_to_device", "trexhip_crops_transformed_device", "trexhip_crops_posture_device", "trexhip_default_midline_params", "trexhip_midline_device", "trexhip_default_split_params", "trexhip_split_search_device", "trexhip_export_id_table_device", "trexhip_export_id_table_ex_device", "trexhip_load_weights", "trexhip_set_identity_precision", "trexhip_num_classes", "trexhip_identify_device", "trexhip_identify",
 ]
 
 
@@ -157,6 +157,7 @@ def lib():
         L.trexhip_load_weights.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
         L.trexhip_num_classes.argtypes = [C.c_void_p]
         L.trexhip_network_channels.argtypes = [C.c_void_p]
+        L.trexhip_pack_frames_v6_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
         L.trexhip_comm_unique_id.argtypes = [C.c_void_p]
         L.trexhip_comm_create.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.POINTER(C.c_void_p)]
         L.trexhip_comm_destroy.argtypes = [C.c_void_p]
@@ -355,6 +356,11 @@ class Segmenter:
             setattr(pp, k, v)
         _check(lib().trexhip_posture_auto_device(self._h, C.byref(pp), method, track_posture_threshold, n_blobs, C.c_void_p(d_outline_ptr),
                                                  C.c_void_p(d_segments_ptr), C.c_void_p(d_info_ptr), C.c_void_p(d_threshold_ptr or 0), C.c_void_p(d_iterations_ptr or 0)))
+
+    def pack_frames_v6_device(self, d_out_ptr, capacity, d_offsets_ptr, timestamps=None):
+        """pv::Frame::serialize bodies (file version V_6 layout) of the last fetched batch; see include/trexhip.h."""
+        ts = np.ascontiguousarray(timestamps, np.uint64) if timestamps is not None else None
+        _check(lib().trexhip_pack_frames_v6_device(self._h, ts.ctypes.data if ts is not None else None, C.c_void_p(d_out_ptr), capacity, C.c_void_p(d_offsets_ptr)))
 
     def crops_device(self, d_crops_ptr, n_blobs, out_w=80, out_h=80, normalization=0, difference=0):
         """constraints::diff_image for every blob of the last batch -> uint8 [n_blobs][out_h][out_w] at d_crops_ptr."""
