@@ -61,7 +61,7 @@ def main():
                     help="weak: --batch frames per GPU per step (default); strong: --batch frames per step in total, split between the GPUs")
     ap.add_argument("--force-all", action="store_true", help="run exactly the stages given on the command line instead of the preset of the named config")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--cpu-seconds", type=float, default=16.0)
     args = ap.parse_args()
 
     # the named configurations of BASELINE.json: C2 = bg-sub + CCL only, C3 = + posture (no network), C4 = + identity network,
@@ -173,12 +173,15 @@ def main():
         ln.seg.profile_enable(False)
 
     def pmc_traffic(kernel_prefix):
-        """HBM bytes per launch from the committed PMC pass of this same command (profiles/r01_pmc_summary.json);
-        only valid for the default C4 / 256-frame workload it was collected on, else null."""
+        """HBM bytes per launch from the committed PMC passes of this same command (profiles/rNN_pmc_summary.json, newest round;
+        separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, corrected as MI355X_MICROARCH.md prescribes); only valid for the
+        default C4 / 256-frame workload they were collected on, else null.  Counters cannot be read from inside this process."""
         try:
-            if args.config != "C4" or B != 256:
+            if args.config != "C4" or B != 256 or host_in or bgra_in or args.scaling != "weak":
                 return None
-            j = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_summary.json")))
+            import glob
+            files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_summary.json")))
+            j = json.load(open(files[-1]))
             for k, v in j["kernels"].items():
                 if k.startswith(kernel_prefix):
                     return v["hbm_bytes"]
@@ -206,16 +209,28 @@ def main():
                              if with_cnn else "detect only (bg-sub+threshold+CCL+filter+gather, tables->host)",
                    "frames_per_step_per_gpu": B, "encoding": args.encoding, "input": ("host " if host_in else "") + ("bgra tiles (cvtColor on the device inside the step)" if bgra_in else "gray frames") + (" in pageable host memory, PCIe inside the step" if host_in else " resident in HBM"), "posture": bool(args.with_posture), "individual_image_normalization": args.normalize, "pipelined_lanes": len(lanes), "blobs_per_step_rank0": n_blobs, "parallelism": f"frame-sharded x{world}"},
     }
-    seg_roof = {"kernel": "k_rows", "bound": "hbm", "achieved": seg_bytes / rows_s / 1e9 if rows_s else 0.0, "peak": 8000.0,
-                "unit": "GB/s", "frac": seg_bytes / rows_s / 8e12 if rows_s else 0.0, "traffic": pmc_traffic("trexhip::k_rows"),
-                "traffic_note": "bytes/launch, FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE, separate --pmc passes, profiles/r01_pmc_summary.json",
+    rows_traffic = pmc_traffic("trexhip::k_rows")
+    pass_traffic = None
+    if rows_traffic is not None:
+        others = [pmc_traffic("trexhip::k_ccl_lds"), pmc_traffic("trexhip::k_gather")]
+        pass_traffic = rows_traffic + sum(x for x in others if x)
+    # The primary fraction is by the HBM bytes the counters saw (the background is re-read from L2 / MALL, not from HBM); the fraction by
+    # the contract's algorithmic bytes (frame + background per pixel) is kept beside it and can pass 1 for that reason.
+    seg_roof = {"kernel": "k_rows32 (pixel pass: subtract / threshold / run extraction)", "bound": "hbm", "peak": 8000.0, "unit": "GB/s",
+                "achieved": (rows_traffic / rows_s / 1e9) if (rows_traffic and rows_s) else (seg_bytes / rows_s / 1e9 if rows_s else 0.0),
+                "frac": (rows_traffic / rows_s / 8e12) if (rows_traffic and rows_s) else (seg_bytes / rows_s / 8e12 if rows_s else 0.0),
+                "frac_basis": "measured HBM traffic per launch (PMC)" if rows_traffic else "algorithmic bytes (no PMC summary for this workload)",
+                "traffic": rows_traffic,
+                "traffic_note": "HBM bytes/launch = FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE, separate --pmc passes, profiles/rNN_pmc_summary.json (collected on this command, not inside this run)",
                 "avg_launch_us": rows_s * 1e6, "launches": prof["ROWS"][1], "algorithmic_bytes_per_launch": seg_bytes,
-                "whole_detect_pass_us": segall_s * 1e6, "timing": "HIP events on the kernel stream; 5 serial detect passes after the timed region when lanes are pipelined (in-flight the stage shares the GPU with the identity network)",
-                "whole_detect_pass_frac": seg_bytes / segall_s / 8e12 if segall_s else None,
-                "note": "algorithmic bytes = frame + background per pixel (SURVEY.md 8d counts the background even when L2/MALL serves it); the measured HBM traffic is `traffic` (about half), so `frac` can pass 1",
-                # also against the copy bandwidth measured on this part (MI355X_MICROARCH.md: 6.29 TB/s)
-                "frac_of_measured_copy_bw": seg_bytes / rows_s / 6.29e12 if rows_s else None,
-                "whole_detect_pass_frac_of_measured_copy_bw": seg_bytes / segall_s / 6.29e12 if segall_s else None}
+                "frac_algorithmic_bytes": seg_bytes / rows_s / 8e12 if rows_s else None,
+                "whole_detect_pass_us": segall_s * 1e6,
+                "whole_detect_pass_frac": (pass_traffic / segall_s / 8e12) if (pass_traffic and segall_s) else None,
+                "whole_detect_pass_frac_algorithmic_bytes": seg_bytes / segall_s / 8e12 if segall_s else None,
+                "whole_detect_pass_traffic": pass_traffic,
+                "timing": "HIP events on the kernel stream; 5 serial detect passes after the timed region when lanes are pipelined (in-flight the stage shares the GPU with the identity network)",
+                "limiter": "k_rows32 is VALU-issue bound (SQ_ACTIVE_INST_VALU = 92 % of the SIMD cycles, profiles/r02_pmc_detect_kernels.txt); k_ccl_lds / k_gather are latency chains of one workgroup per frame / half a wave per blob",
+                "frac_of_measured_copy_bw": ((rows_traffic or seg_bytes) / rows_s / 6.29e12) if rows_s else None}
     if host_in:
         bytes_step = float(B * W * H * (4 if bgra_in else 1))
         up = [ln.seg.profile_read(capi.STAGE_UPLOAD_COPY) + ln.seg.profile_read(capi.STAGE_UPLOAD_DMA) for ln in lanes]
@@ -230,15 +245,19 @@ def main():
         fl = FLOP_PER_CROP_CONV3 * n_blobs
         nprod = {"fp32": 1, "bf16x6": 6, "bf16x3": 3, "fp16x3": 3}[args.cnn_mode]
         peak = 157.3 if args.cnn_mode == "fp32" else 2500.0
-        kname = "k_conv5<64,128,20,20,32> (conv3, fp32 MFMA)" if args.cnn_mode == "fp32" else (f"k_conv5_stream<64,128,20,20,8,persistent> (conv3, fp16 MFMA x{nprod} per fp32 product)" if args.cnn_mode == "fp16x3" else f"k_conv5_split<64,128,20,20,{args.cnn_mode}> (conv3, 16-bit MFMA x{nprod} per fp32 product)")
+        # fp16x3 (default): conv3 runs as a Winograd F(4,5) convolution along x -- 40 position GEMMs over 4-pixel tiles instead of 25 tap
+        # GEMMs over pixels: 6000 MFMA instructions per crop issue 196.6 MFLOP for the layer's 163.84 algorithmic MFLOP (x1.2)
+        wino = args.cnn_mode == "fp16x3" and not (int(os.environ.get("TREXHIP_CONV_GEOM", "0")) & 256)
+        issue_ratio = 1.2 if wino else float(nprod)
+        kname = "k_conv5<64,128,20,20,32> (conv3, fp32 MFMA)" if args.cnn_mode == "fp32" else ("k_conv5_wino<64,128,20,2> (conv3, Winograd F(4,5) along x, fp16 two-piece split: 3 MFMA products per transformed product, fp32 accumulate)" if wino else (f"k_conv5_stream<64,128,20,20,8,persistent> (conv3, fp16 MFMA x{nprod} per fp32 product)" if args.cnn_mode == "fp16x3" else f"k_conv5_split<64,128,20,20,{args.cnn_mode}> (conv3, 16-bit MFMA x{nprod} per fp32 product)"))
         out["roofline"] = {"kernel": kname, "bound": "mfma", "achieved": fl / c3_s / 1e12 if c3_s else 0.0,
                            "peak": peak, "unit": "TFLOP/s", "frac": fl / c3_s / (peak * 1e12) if c3_s else 0.0,
-                           "mfma_products_per_algorithmic_product": nprod,
-                           "mfma_issue_frac": nprod * fl / c3_s / (peak * 1e12) if c3_s else 0.0,
-                           "traffic": pmc_traffic("trexhip::k_conv5_stream<64, 128, 20, 20, 8") if args.cnn_mode == "fp16x3" else None,
-                           "traffic_note": "HBM bytes/launch from profiles/r01_pmc_summary.json (FETCH_SIZE x2 + WRITE_SIZE); algorithmic bytes = 0.98 GB (activations in+out)",
+                           "mfma_flop_issued_per_algorithmic_flop": issue_ratio,
+                           "mfma_issue_frac": issue_ratio * fl / c3_s / (peak * 1e12) if c3_s else 0.0,
+                           "traffic": pmc_traffic("trexhip::k_conv5_wino<64, 128, 20, 2" if wino else "trexhip::k_conv5_stream<64, 128, 20, 20, 8") if args.cnn_mode == "fp16x3" else None,
+                           "traffic_note": "HBM bytes/launch from profiles/rNN_pmc_summary.json (FETCH_SIZE x2 + WRITE_SIZE, separate --pmc passes of this command); algorithmic bytes per launch = activations in + out = " + f"{n_blobs * (20 * 20 * 64 + 10 * 10 * 128) * 4 / 1e9:.2f} GB",
                            "avg_launch_us": c3_s * 1e6, "launches": prof["CONV3"][1], "algorithmic_flop_per_launch": fl,
-                           "peak_note": "achieved counts ALGORITHMIC flops (2 per fp32 multiply-add); peak is the dense MFMA peak of the instruction used (fp32: 157.3, bf16: 2500 TFLOP/s, MI355X_MICROARCH.md); in the split modes every algorithmic product costs `mfma_products_per_algorithmic_product` bf16 MFMA products, so the matrix pipe is busy mfma_issue_frac of its peak"}
+                           "peak_note": "achieved counts ALGORITHMIC flops (2 per fp32 multiply-add); peak is the dense MFMA peak of the instruction used (fp32: 157.3, bf16: 2500 TFLOP/s, MI355X_MICROARCH.md); the matrix pipe issues `mfma_flop_issued_per_algorithmic_flop` flops per algorithmic flop (direct split kernels: 3 or 6 piece products per product; Winograd F(4,5): 0.4 x 3 = 1.2), i.e. it is busy mfma_issue_frac of its peak"}
         cnn_s = avg_s("CNN_ALL")
         out["stage_us"] = {"detect": segall_s * 1e6, "posture": avg_s("POSTURE") * 1e6 if args.with_posture else None, "crops": avg_s("CROPS") * 1e6, "conv2": avg_s("CONV2") * 1e6,
                            "conv3": c3_s * 1e6, "cnn_all": cnn_s * 1e6,
@@ -248,39 +267,50 @@ def main():
         out["roofline"] = seg_roof
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        # the CPU restatement (oracle/: a port, not the TRex binary) on this box's host cores, on a bounded sample of the same workload:
+        # all usable cores (one frame per OpenMP thread / torch intra-op threads) and ONE thread; medians over the repetitions
         from oracle import oracle, cnn_oracle
         ncpu = usable_cores()
-        torch.set_num_threads(ncpu)
+        budget = args.cpu_seconds
+        hsrc = host_frames if (host_in and not bgra_in) else None
         k = max(2, min(B, ncpu))
-        sample = frames[:k].cpu().numpy()
+        sample = np.stack(hsrc[:k]) if hsrc is not None else frames[:k].cpu().numpy()
         bgh = bg.cpu().numpy()
         op = oracle.make_params(W, H)
-        oracle.segment_batch(sample[:2], bgh, op, ncpu)          # warm up
-        t1 = time.perf_counter()
-        done = 0
-        while time.perf_counter() - t1 < args.cpu_seconds / (2 if with_cnn else 1):
-            oracle.segment_batch(sample, bgh, op, ncpu)
-            done += k
-        seg_fps = done / (time.perf_counter() - t1)
-        cpu = {"unit": "frames/s", "cores": ncpu, "kind": "port", "detect_frames_per_s": seg_fps}
+
+        def timed(fn, seconds, min_reps=3, max_reps=50):
+            for _ in range(2):
+                fn()
+            ts = []
+            t_end = time.perf_counter() + seconds
+            while len(ts) < min_reps or (time.perf_counter() < t_end and len(ts) < max_reps):
+                t = time.perf_counter(); fn(); ts.append(time.perf_counter() - t)
+            return float(np.median(ts)), len(ts)
+
+        share = budget / (4.0 if with_cnn else 2.0)
+        t_all, r_all = timed(lambda: oracle.segment_batch(sample, bgh, op, ncpu), share)
+        t_one, r_one = timed(lambda: oracle.segment(sample[0], bgh, op), share, min_reps=20)
+        cpu = {"unit": "frames/s", "cores": ncpu, "kind": "port",
+               "detect_frames_per_s": k / t_all, "detect_frames_per_s_1_thread": 1.0 / t_one,
+               "repetitions": {"detect_all_cores": r_all, "detect_1_thread": r_one}, "statistic": "median"}
         if with_cnn:
             b_, r_, _ = oracle.segment(sample[0], bgh, op)
             cr = np.stack([oracle.crop_none(sample[0], bgh, bb, r_) for bb in b_])[..., None]
-            cnn_oracle.predict(state, cr[:8], threads=ncpu)
-            t2 = time.perf_counter()
-            reps = 0
-            while time.perf_counter() - t2 < args.cpu_seconds / 2:
-                cnn_oracle.predict(state, cr, threads=ncpu)
-                reps += 1
-            cnn_fps = reps / (time.perf_counter() - t2)
+            t_call, r_call = timed(lambda: cnn_oracle.predict(state, cr, threads=ncpu), share)
+            t_c1, r_c1 = timed(lambda: cnn_oracle.predict(state, cr[:10], threads=1), share, min_reps=3)
+            cnn_fps, cnn_fps1 = 1.0 / t_call, 1.0 / (t_c1 * len(cr) / 10.0)
             cpu["identify_frames_per_s"] = cnn_fps
-            cpu["value"] = 1.0 / (1.0 / seg_fps + 1.0 / cnn_fps)
-            cpu["sample"] = (f"detect: {k} distinct frames of the batch, one per OpenMP thread, repeated {args.cpu_seconds / 2:.0f} s; "
-                             f"identify: the {len(cr)} crops of frame 0 through a torch-CPU restatement of V118_3 ({ncpu} threads), "
-                             f"repeated {args.cpu_seconds / 2:.0f} s; restatements under oracle/, not the TRex binary")
+            cpu["identify_frames_per_s_1_thread"] = cnn_fps1
+            cpu["repetitions"].update({"identify_all_cores": r_call, "identify_1_thread": r_c1})
+            cpu["value"] = 1.0 / (t_all / k + 1.0 / cnn_fps)
+            cpu["value_1_thread"] = 1.0 / (t_one + 1.0 / cnn_fps1)
+            cpu["sample"] = (f"detect: {k} distinct frames of the batch, one per OpenMP thread (all cores) / frame 0 alone (1 thread); "
+                             f"identify: the {len(cr)} crops of frame 0 through a torch-CPU restatement of V118_3 ({ncpu} threads) / 10 of them on 1 thread, scaled; "
+                             f"medians, about {budget:.0f} s in total; restatements under oracle/, not the TRex binary")
         else:
-            cpu["value"] = seg_fps
-            cpu["sample"] = f"{k} distinct frames of the batch, one per OpenMP thread, repeated {args.cpu_seconds:.0f} s; oracle/ restatement"
+            cpu["value"] = k / t_all
+            cpu["value_1_thread"] = 1.0 / t_one
+            cpu["sample"] = f"{k} distinct frames of the batch, one per OpenMP thread (all cores) / frame 0 alone (1 thread); medians, about {budget:.0f} s in total; oracle/ restatement"
         out["cpu_baseline"] = cpu
     for ln in lanes:
         ln.seg.close()

@@ -1,9 +1,9 @@
 #!/bin/bash
 # Runs on the MI355X box (through gpurun): kernel-trace stats + two separate PMC passes of the default bench command,
 # filtered to libtrexhip's kernels, written under gpurun_out/prof/ (copy what should be judged into profiles/).
-#   gpurun --timeout 1500 -- 'bash tools/collect_profiles.sh r01'
+#   gpurun --timeout 1500 -- 'bash tools/collect_profiles.sh r02'
 set -u
-TAG=${1:-r01}
+TAG=${1:-r02}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/prof
 mkdir -p "$OUT"
