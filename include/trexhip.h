@@ -157,7 +157,8 @@ int trexhip_set_background_color_device(trexhip_ctx* ctx, const uint8_t* d_bgr, 
 
 /* background model from n sampled gray frames in HBM ("next" row of SURVEY.md 8f: Segmenter::trigger_average_generator,
  * ui/Segmenter.cpp:467-566; averaging_method grabber/misc/default_config.cpp:131): method 0 = mean (float accumulation in
- * sample order, rounded half-to-even), 1 = max, 2 = min; the result becomes the context's background. */
+ * sample order, rounded half-to-even), 1 = max, 2 = min, 3 = mode (most frequent value of the pixel, the smallest wins a tie; at most
+ * 255 samples); the result becomes the context's background. */
 int trexhip_generate_average_device(trexhip_ctx* ctx, const uint8_t* d_frames, int32_t n, int32_t method);
 int trexhip_get_background(trexhip_ctx* ctx, uint8_t* gray, int32_t stride);
 

@@ -299,6 +299,13 @@ def generate_average(frames, method=0):
         return frames.max(0).astype(np.uint8)
     if method == 2:
         return frames.min(0).astype(np.uint8)
+    if method == 3:      # mode: most frequent value per pixel, the smallest wins a tie (commons' sampler is not in the tree: unpinned)
+        n = frames.shape[0]
+        flat = frames.reshape(n, -1)
+        counts = np.zeros((256, flat.shape[1]), np.int32)
+        for f in flat:
+            counts[f, np.arange(flat.shape[1])] += 1
+        return counts.argmax(0).astype(np.uint8).reshape(frames.shape[1:])
     acc = np.zeros(frames.shape[1:], np.float32)
     for f in frames:
         acc += f.astype(np.float32)

@@ -420,17 +420,42 @@ __global__ __launch_bounds__(256) void k_average(const uint8_t* __restrict__ fra
     }
     *reinterpret_cast<uint4*>(bg + i * 16) = make_uint4(ext[0], ext[1], ext[2], ext[3]);
 }
+// averaging_method = mode: the most frequent grey value of every pixel over the samples (the smallest one wins a tie).  One thread per
+// pixel, its 256 one-byte bins in LDS (64 KB per workgroup of 256 pixels; the caller feeds at most 255 samples per bin overflow-free --
+// n <= 255 is checked), bins laid out [value][thread] so that a wave's increments fall into 64 different banks.
+__global__ __launch_bounds__(256) void k_average_mode(const uint8_t* __restrict__ frames, uint8_t* __restrict__ bg, size_t npix, size_t frame_stride, int n) {
+    extern __shared__ uint8_t hist[];                                   // [256 values][256 threads]
+    const int tid = threadIdx.x;
+    const size_t i = (size_t)blockIdx.x * 256 + tid;
+    for (int k = tid; k < 256 * 256 / 4; k += 256) reinterpret_cast<uint32_t*>(hist)[k] = 0u;
+    __syncthreads();
+    if (i < npix)
+        for (int f = 0; f < n; ++f) {
+            const uint32_t p = frames[(size_t)f * frame_stride + i];
+            hist[p * 256u + tid] += 1;
+        }
+    if (i >= npix) return;
+    int best = 0, cnt = hist[tid];
+    for (int v = 1; v < 256; ++v) { const int c = hist[v * 256 + tid]; if (c > cnt) { cnt = c; best = v; } }
+    bg[i] = (uint8_t)best;
+}
 }  // namespace trexhip
 
 extern "C" int trexhip_generate_average_device(trexhip_ctx* ctx, const uint8_t* d_frames, int32_t n, int32_t method) {
     using namespace trexhip;
     if (!ctx || !d_frames) { set_error("trexhip_generate_average_device: null argument"); return TREXHIP_E_INVALID; }
     if (n < 1) { set_error("trexhip_generate_average_device: need at least one sample"); return TREXHIP_E_INVALID; }
-    if (method < 0 || method > 2) { set_error("trexhip_generate_average_device: averaging_method mode is not implemented (0 mean, 1 max, 2 min)"); return TREXHIP_E_UNSUPPORTED; }
+    if (method < 0 || method > 3) { set_error("trexhip_generate_average_device: method must be 0 mean, 1 max, 2 min or 3 mode"); return TREXHIP_E_INVALID; }
+    if (method == 3 && n > 255) { set_error("trexhip_generate_average_device: averaging_method mode takes at most 255 samples (one-byte bins)"); return TREXHIP_E_UNSUPPORTED; }
     const size_t npix = (size_t)ctx->p.width * ctx->p.height;
     if (npix % 16 != 0 || (reinterpret_cast<uintptr_t>(d_frames) & 15)) { set_error("trexhip_generate_average_device: width*height must be a multiple of 16 and the frames 16-byte aligned"); return TREXHIP_E_UNSUPPORTED; }
     TH_CHECK_HIP(hipSetDevice(ctx->p.device));
     const size_t n16 = npix / 16;
+    if (method == 3) {
+        static bool attr = false;
+        if (!attr) { TH_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_average_mode), hipFuncAttributeMaxDynamicSharedMemorySize, 65536)); attr = true; }
+        hipLaunchKernelGGL(k_average_mode, dim3((unsigned)((npix + 255) / 256)), dim3(256), 65536, ctx->stream, d_frames, ctx->d_bg, npix, npix, n);
+    } else
     hipLaunchKernelGGL(k_average, dim3((unsigned)((n16 + 255) / 256)), dim3(256), 0, ctx->stream, d_frames, ctx->d_bg, n16, npix, n, method);
     TH_CHECK_HIP(hipGetLastError());
     TH_CHECK_HIP(hipStreamSynchronize(ctx->stream));
