@@ -853,8 +853,10 @@ __device__ __forceinline__ uint4 buf_load16(const __amdgpu_buffer_rsrc_t r, cons
     const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);
     return make_uint4(v[0], v[1], v[2], v[3]);
 }
-__device__ __forceinline__ float4 buf_load16f_nt(const __amdgpu_buffer_rsrc_t r, const int voff, const int soff) {
-    const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 2);      // nt: streamed once, keep the weights in L2
+__device__ __forceinline__ float4 buf_load16f(const __amdgpu_buffer_rsrc_t r, const int voff, const int soff) {
+    // default cache policy: neighbouring tiles and neighbouring passes read the same pixels (x-overlap of the 8-pixel windows, y-halo),
+    // and L2 has to absorb those re-reads -- with the nt hint every one of them went to HBM (8.4 GB per launch instead of ~4)
+    const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);
     return make_float4(__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]), __uint_as_float(v[3]));
 }
 
@@ -917,7 +919,7 @@ __global__ __launch_bounds__((WinoGeom<CI, CO, S, TPW>::NTHR)) void k_conv5_wino
         _Pragma("unroll") for (int k_ = 0; k_ < 8; ++k_) {                                                                      \
             int ix_ = 4 * tx_ - 2 + k_;                                                                                         \
             ix_ = ix_ < 0 ? 0 : (ix_ > S - 1 ? S - 1 : ix_);                                                                    \
-            sdb[item_][k_] = buf_load16f_nt(srs, soff_ + ix_ * (CI * 4), 0);                                                    \
+            sdb[item_][k_] = buf_load16f(srs, soff_ + ix_ * (CI * 4), 0);                                                    \
         }                                                                                                                       \
     } while (0)
     // T: B^T of one channel in two halves (positions 0, 7, 1, 2 then 3..6); the range guard rides on the first half
@@ -1192,9 +1194,9 @@ __global__ __launch_bounds__(256) void k_conv5_wino1(const float* __restrict__ i
         const int pl = i / (G::RP / 16), o = i - pl * (G::RP / 16);
         *reinterpret_cast<uint4*>(ldsb + pl * G::PLANE + o * 16) = make_uint4(0, 0, 0, 0);
     }
-    float4 sdb[2][8];
+    float4 sd[8];                                        // ONE item in flight (registers are the scarce resource of this kernel)
     float su[2][4];
-    int sdstb[2] = {0, 0}, sflagb[2] = {0, 0};
+    int sdst2[2] = {0, 0}, sflag = 0;              // the store offset of an item is still needed after the next item's load
     __amdgpu_buffer_rsrc_t srs = make_rsrc(in, 0);
 #define W1_L(item_, qmin_, nrows_)                                                                                              \
     do {                                                                                                                        \
@@ -1205,19 +1207,19 @@ __global__ __launch_bounds__(256) void k_conv5_wino1(const float* __restrict__ i
         s_ = s_ < (nrows_) ? s_ : (nrows_) - 1;                                                                                 \
         srs = make_rsrc(in + ((size_t)(qmin_) * S) * CI, (uint32_t)(G::NR * S * CI * 4));                                       \
         const int soff_ = s_ * (S * CI * 4) + cq_ * 16;                                                                         \
-        sdstb[(item_) & 1] = (s_ + 1) * G::RP + tx_ * G::TSB + cq_ * 8;                                                         \
-        sflagb[(item_) & 1] = (tx_ == 0 ? 1 : 0) | (tx_ == G::TPR - 1 ? 2 : 0);                                                 \
+        sdst2[(item_) & 1] = (s_ + 1) * G::RP + tx_ * G::TSB + cq_ * 8;                                                         \
+        sflag = (tx_ == 0 ? 1 : 0) | (tx_ == G::TPR - 1 ? 2 : 0);                                                               \
         _Pragma("unroll") for (int k_ = 0; k_ < 8; ++k_) {                                                                      \
             int ix_ = 4 * tx_ - 2 + k_;                                                                                         \
             ix_ = ix_ < 0 ? 0 : (ix_ > S - 1 ? S - 1 : ix_);                                                                    \
-            sdb[(item_) & 1][k_] = buf_load16f_nt(srs, soff_ + ix_ * (CI * 4), 0);                                              \
+            sd[k_] = buf_load16f(srs, soff_ + ix_ * (CI * 4), 0);                                                               \
         }                                                                                                                       \
     } while (0)
     // B^T rows of one position group for one channel: group 0 -> positions 0, 1, 2, 7; group 1 -> 3, 4, 5, 6
 #define W1_T(item_, grp_, which_, comp_)                                                                                        \
     do {                                                                                                                        \
-        const int sflag_ = sflagb[(item_) & 1];                                                                                 \
-        const float4* sd_ = sdb[(item_) & 1];                                                                                   \
+        const int sflag_ = sflag;                                                                                               \
+        const float4* sd_ = sd;                                                                                                 \
         const float d1_ = (sflag_ & 1) ? 0.f : sd_[1].comp_, d6_ = (sflag_ & 2) ? 0.f : sd_[6].comp_;                           \
         const float d2_ = sd_[2].comp_, d3_ = sd_[3].comp_, d4_ = sd_[4].comp_, d5_ = sd_[5].comp_;                             \
         if ((grp_) == 0) {                                                                                                      \
@@ -1240,7 +1242,7 @@ __global__ __launch_bounds__(256) void k_conv5_wino1(const float* __restrict__ i
         _Pragma("unroll") for (int q_ = 0; q_ < 4; ++q_) {                                                                      \
             uint32_t a1_, a2_;                                                                                                  \
             split2h_pair(su[0][q_], su[1][q_], a1_, a2_);                                                                       \
-            uint8_t* dst_ = (base_) + sdstb[(item_) & 1] + q_ * G::PS + (half_) * 4;                                            \
+            uint8_t* dst_ = (base_) + sdst2[(item_) & 1] + q_ * G::PS + (half_) * 4;                                            \
             *reinterpret_cast<uint32_t*>(dst_) = a1_;                                                                           \
             *reinterpret_cast<uint32_t*>(dst_ + G::PLANE) = a2_;                                                                \
         }                                                                                                                       \
@@ -1253,15 +1255,30 @@ __global__ __launch_bounds__(256) void k_conv5_wino1(const float* __restrict__ i
         if ((st_) == 2) { W1_T(item_, grp_, 0, z); W1_T(item_, grp_, 1, w); }                                                   \
         if ((st_) == 3) W1_S(item_, 1, base_);                                                                                  \
     } while (0)
-    // the staging slots of the 20 taps of a unit: loads of items 0, 1 at taps 0, 1; item k computes at taps 4+4k..7+4k; the loads of
-    // items 2, 3 reuse the register buffers of items 0, 1 as soon as those are done
+    // the staging slots of the 20 taps of a unit, one item at a time: load at taps 0 / 4 / 9 / 14, then transform x, y (+2 taps), store
+    // (+3), transform z, w (+4, before the next item's load in the same slot), store (+5)
 #define W1_SLOT(tl_, grp_, qmin_, nrows_, base_)                                                                                \
     do {                                                                                                                        \
+        if ((tl_) == 2) W1_C(0, 0, grp_, base_);                                                                                \
+        if ((tl_) == 3) W1_C(1, 0, grp_, base_);                                                                                \
+        if ((tl_) == 4) W1_C(2, 0, grp_, base_);                                                                                \
+        if ((tl_) == 5) W1_C(3, 0, grp_, base_);                                                                                \
+        if ((tl_) == 6) W1_C(0, 1, grp_, base_);                                                                                \
+        if ((tl_) == 7) W1_C(1, 1, grp_, base_);                                                                                \
+        if ((tl_) == 8) W1_C(2, 1, grp_, base_);                                                                                \
+        if ((tl_) == 9) W1_C(3, 1, grp_, base_);                                                                                \
+        if ((tl_) == 11) W1_C(0, 2, grp_, base_);                                                                               \
+        if ((tl_) == 12) W1_C(1, 2, grp_, base_);                                                                               \
+        if ((tl_) == 13) W1_C(2, 2, grp_, base_);                                                                               \
+        if ((tl_) == 14) W1_C(3, 2, grp_, base_);                                                                               \
+        if ((tl_) == 16) W1_C(0, 3, grp_, base_);                                                                               \
+        if ((tl_) == 17) W1_C(1, 3, grp_, base_);                                                                               \
+        if ((tl_) == 18) W1_C(2, 3, grp_, base_);                                                                               \
+        if ((tl_) == 19) W1_C(3, 3, grp_, base_);                                                                               \
         if ((tl_) == 0) W1_L(0, qmin_, nrows_);                                                                                 \
-        if ((tl_) == 1) W1_L(1, qmin_, nrows_);                                                                                 \
-        if ((tl_) == 8) W1_L(2, qmin_, nrows_);                                                                                 \
-        if ((tl_) == 12) W1_L(3, qmin_, nrows_);                                                                                \
-        if ((tl_) >= 4) W1_C(((tl_) - 4) % 4, ((tl_) - 4) / 4, grp_, base_);                                                    \
+        if ((tl_) == 4) W1_L(1, qmin_, nrows_);                                                                                 \
+        if ((tl_) == 9) W1_L(2, qmin_, nrows_);                                                                                 \
+        if ((tl_) == 14) W1_L(3, qmin_, nrows_);                                                                                \
     } while (0)
 
     const __amdgpu_buffer_rsrc_t wrs = make_rsrc(wp, (uint32_t)(40 * G::BV * 16));
@@ -2022,8 +2039,8 @@ TH_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv5_wino1<64
     else if (mode == TREXHIP_CNN_BF16X3) LAUNCH_SPLIT(16, 64, 40, 10, 0, 3, net->act1, net->w2s, net->b2, net->act2, 1.0f, (const uint32_t*)nullptr);
     else if (ctx->tune_conv_geom & 512) {
         // Winograd F(4,5) along x for conv2 too: correct (same parity tests) but NOT faster than the direct kernel below on this layer
-        // (6.3 vs 4.7 ms per 25600 crops: with 16 input channels and 64 outputs the input transform + fp16 split per staged value is
-        // not amortised by enough matrix work), so it stays opt-in (TREXHIP_CONV_GEOM bit 9); the persistent pass counter is d_ovf[2]
+        // (4.9 vs 4.6 ms per 25600 crops: with 16 input channels and 64 outputs the input transform + fp16 split per staged value and the
+        // output transform per pass are not amortised by enough matrix work), so it stays opt-in (TREXHIP_CONV_GEOM bit 9); the persistent pass counter is d_ovf[2]
         using GW = WinoGeom1<64, 40>;
         const int n_pass = (n * GW::TPC + GW::MB - 1) / GW::MB;
         hipLaunchKernelGGL((k_conv5_wino1<64, 40>), dim3(n_pass < ctx->n_cus ? n_pass : ctx->n_cus), dim3(256), GW::LDS_BYTES, s,
