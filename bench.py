@@ -56,6 +56,8 @@ def main():
     ap.add_argument("--lanes", type=int, default=2, help="software-pipeline depth: contexts whose batches are in flight (detect of batch i+L-1 is issued while the identity network works on batch i)")
     ap.add_argument("--no-detect-priority", dest="detect_priority", action="store_false",
                     help="keep the detect stage on the lane's own stream (default: a high-priority stream per lane, so that its short kernels get compute units as soon as the other lane's identity network frees some)")
+    ap.add_argument("--gather", choices=["library", "torch"], default="library",
+                    help="N > 1: who owns the RCCL communicator of the per-step table gather to rank 0: libtrexhip (trexhip_comm_*, default) or torch.distributed")
     ap.add_argument("--force-dist", action="store_true", help="run the multi-GPU code path (the library's communicator, trexhip_comm_*) even with a single rank")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                     help="weak: --batch frames per GPU per step (default); strong: --batch frames per step in total, split between the GPUs")
@@ -114,17 +116,45 @@ def main():
     max_blobs = 4 * n_ind
     state = weights.synthetic_state(classes, 4242, channels=3 if args.encoding == "rgb8" else 1)
     from trex_amd.pipeline import Pipeline
-    comm_ids = None
-    if use_dist and world > 1:      # rank 0 makes one ncclUniqueId per lane; torch.distributed is only the side channel that hands them out
-        n_lanes = max(2, args.lanes) if args.pipeline else 1
-        box = [[capi.Comm.unique_id() for _ in range(n_lanes)]] if rank == 0 else [None]
-        dist.broadcast_object_list(box, src=0)
-        comm_ids = box[0]
-    # the lanes, their buffers and the step schedule live in trex_amd/pipeline.py (the same object tests/test_bench_shape_gpu.py checks)
-    pipe = Pipeline(W, H, n_ind, B, classes, bg, weights.pack_blob(state, classes, channels=3 if rgb else 1) if with_cnn else None,
-                    local=local, rank=rank, world=world, use_dist=use_dist, comm_ids=comm_ids, with_cnn=with_cnn, with_posture=args.with_posture,
-                    normalize=args.normalize, rgb=rgb, bgra_in=bgra_in, cnn_mode=args.cnn_mode, lanes=args.lanes, pipeline=args.pipeline,
-                    detect_priority=args.detect_priority, host_frames=host_frames)
+    blob = weights.pack_blob(state, classes, channels=3 if rgb else 1) if with_cnn else None
+
+    def make_pipe(gather):
+        comm_ids = None
+        if gather == "library" and use_dist and world > 1:   # rank 0 makes one ncclUniqueId per lane; torch.distributed only hands them out
+            n_lanes = max(2, args.lanes) if args.pipeline else 1
+            box = [[capi.Comm.unique_id() for _ in range(n_lanes)]] if rank == 0 else [None]
+            dist.broadcast_object_list(box, src=0)
+            comm_ids = box[0]
+        # the lanes, their buffers and the step schedule live in trex_amd/pipeline.py (the same object tests/test_bench_shape_gpu.py checks)
+        return Pipeline(W, H, n_ind, B, classes, bg, blob, local=local, rank=rank, world=world, use_dist=use_dist, comm_ids=comm_ids,
+                        with_cnn=with_cnn, with_posture=args.with_posture, normalize=args.normalize, rgb=rgb, bgra_in=bgra_in,
+                        cnn_mode=args.cnn_mode, lanes=args.lanes, pipeline=args.pipeline, detect_priority=args.detect_priority,
+                        host_frames=host_frames, gather=gather)
+
+    gather_by, pipe = args.gather, None
+    if args.gather == "torch":
+        gather_by, pipe = "torch.distributed", make_pipe("torch")
+    elif use_dist and world > 1:
+        # The table gather belongs to libtrexhip's own RCCL communicator (trexhip_comm_*).  If creating it fails on any rank (e.g. no
+        # loadable librccl), every rank falls back TOGETHER to the same exchange through torch.distributed's communicator -- still RCCL
+        # over xGMI, reported as such in config.gather -- instead of losing the multi-GPU measurement.
+        err = ""
+        try:
+            pipe = make_pipe("library")
+        except Exception as e:      # noqa: BLE001
+            err = "%s: %s" % (type(e).__name__, e)
+        ok = torch.tensor([0 if err else 1], device=dev, dtype=torch.int32)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if int(ok.item()) == 0:
+            if err:
+                print("rank %d: library communicator unavailable (%s); table gather through torch.distributed" % (rank, err), file=sys.stderr)
+            if pipe is not None:
+                pipe.close()
+            gather_by, pipe = "torch.distributed", make_pipe("torch")
+    else:
+        pipe = make_pipe("library")
+    if use_dist and gather_by == "library":
+        gather_by = "libtrexhip (trexhip_comm_gather_device)"
     lanes = pipe.lanes
     seg = lanes[0].seg
     frames_ptr = frames_c.data_ptr() if bgra_in else frames.data_ptr()
@@ -207,7 +237,7 @@ def main():
                                f"80x80x1 crops, {classes}-way V118_3 (random-init weights)",
                    "stages": "detect(bg-sub+threshold+CCL+filter+gather, tables->host) + crops(none) + identity CNN (V118_3) + per-blob ID table (gathered on rank 0 over RCCL when N>1: trexhip_comm_gather_device) -> rank-0 host"
                              if with_cnn else "detect only (bg-sub+threshold+CCL+filter+gather, tables->host)",
-                   "frames_per_step_per_gpu": B, "encoding": args.encoding, "input": ("host " if host_in else "") + ("bgra tiles (cvtColor on the device inside the step)" if bgra_in else "gray frames") + (" in pageable host memory, PCIe inside the step" if host_in else " resident in HBM"), "posture": bool(args.with_posture), "individual_image_normalization": args.normalize, "pipelined_lanes": len(lanes), "blobs_per_step_rank0": n_blobs, "parallelism": f"frame-sharded x{world}"},
+                   "frames_per_step_per_gpu": B, "encoding": args.encoding, "input": ("host " if host_in else "") + ("bgra tiles (cvtColor on the device inside the step)" if bgra_in else "gray frames") + (" in pageable host memory, PCIe inside the step" if host_in else " resident in HBM"), "posture": bool(args.with_posture), "individual_image_normalization": args.normalize, "pipelined_lanes": len(lanes), "blobs_per_step_rank0": n_blobs, "parallelism": f"frame-sharded x{world}", **({"gather": gather_by} if use_dist else {})},
     }
     rows_traffic = pmc_traffic("trexhip::k_rows")
     pass_traffic = None

@@ -33,7 +33,8 @@ class Lane:
         self.comm = None
         self.table_all = None
         if pl.use_dist:
-            self.comm = capi.Comm(self.seg, pl.rank, pl.world, pl.next_comm_id())
+            if pl.gather == "library":
+                self.comm = capi.Comm(self.seg, pl.rank, pl.world, pl.next_comm_id())
             self.table_all = torch.zeros((pl.world * pl.rows, pl.rowlen), dtype=torch.int32, device=dev) if pl.rank == 0 else None
         if pl.with_posture:
             MP = pl.MP
@@ -92,8 +93,12 @@ class Lane:
                                        self.p_mid.data_ptr() if n else 0, self.p_minfo.data_ptr() if n else 0, 25)
             else:
                 seg.export_id_table(self.probs.data_ptr(), n, pl.classes, frame_base, self.table.data_ptr(), pl.rows)
-            if pl.use_dist:                     # grouped send / recv on the context's stream, behind the table kernel
+            if pl.use_dist and self.comm is not None:   # grouped send / recv on the context's stream, behind the table kernel
                 self.comm.gather_device(self.table.data_ptr(), self.table.numel() * 4, self.table_all.data_ptr() if pl.rank == 0 else 0)
+            elif pl.use_dist:                   # gather="torch": the same exchange through torch.distributed's RCCL communicator
+                import torch.distributed as dist
+                with torch.cuda.stream(self.stream):
+                    dist.gather(self.table, list(self.table_all.view(pl.world, pl.rows, pl.rowlen).unbind(0)) if pl.rank == 0 else None, dst=0)
             with torch.cuda.stream(self.stream):
                 if pl.rank == 0:
                     self.table_host.copy_(self.table_all if pl.use_dist else self.table, non_blocking=True)
@@ -107,9 +112,11 @@ class Lane:
 class Pipeline:
     def __init__(self, W, H, n_ind, B, classes, bg, weight_blob=None, *, local=0, rank=0, world=1, use_dist=False, comm_ids=None,
                  with_cnn=True, with_posture=False, normalize="none", rgb=False, bgra_in=False, cnn_mode="fp16x3",
-                 lanes=2, pipeline=True, detect_priority=True, host_frames=None):
+                 lanes=2, pipeline=True, detect_priority=True, host_frames=None, gather="library"):
         self.W, self.H, self.B, self.classes, self.bg = W, H, B, classes, bg
         self.local, self.rank, self.world, self.use_dist = local, rank, world, use_dist
+        assert gather in ("library", "torch")
+        self.gather = gather                      # who owns the RCCL communicator of the table gather: libtrexhip (default) or torch.distributed
         self._comm_ids = list(comm_ids or [])     # one ncclUniqueId (128 bytes, made by rank 0) per lane, in lane order
         self.dev = torch.device("cuda", local)
         self.with_cnn, self.with_posture, self.rgb, self.bgra_in = with_cnn, with_posture or normalize == "posture", rgb, bgra_in or rgb
