@@ -86,3 +86,27 @@ def pack_blob(state, num_classes, channels=1, width=80, height=80):
         assert t.shape == tuple(shp), (name, t.shape, shp)
         parts.append(t.tobytes())
     return b"".join(parts)
+
+
+def unpack_blob(blob):
+    """Inverse of pack_blob: -> (state dict, num_classes, channels)."""
+    hdr = np.frombuffer(blob[:32], np.int32)
+    assert int(hdr[0]) == MAGIC and int(hdr[1]) == 1, "not a TRXW v1 blob"
+    classes, width, height, channels = int(hdr[2]), int(hdr[3]), int(hdr[4]), int(hdr[5])
+    st, off = {}, 32
+    for name, shp in shapes(classes, channels, width, height):
+        cnt = int(np.prod(shp))
+        st[name] = np.frombuffer(blob[off:off + 4 * cnt], np.float32).reshape(shp).copy()
+        off += 4 * cnt
+    assert off == len(blob), "blob size does not match its header"
+    return st, classes, channels
+
+
+def synthetic_train_batch(n, seed, classes, channels=1):
+    """Training inputs as TRexImageDataset hands them over (visual_recognition_torch.py:158-188): NHWC float32 in [0, 255],
+    NOT integer (the augmentation rescales), + integer class labels."""
+    rng = np.random.default_rng(seed)
+    x = synthetic_crops(n, seed + 7, channels).astype(np.float32)
+    x = np.clip(x * rng.uniform(0.85, 1.15, (n, 1, 1, 1)).astype(np.float32) + rng.uniform(0.0, 3.0, x.shape).astype(np.float32) * (x > 0), 0.0, 255.0)
+    y = rng.integers(0, classes, n).astype(np.int32)
+    return np.ascontiguousarray(x, np.float32), y
