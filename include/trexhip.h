@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define TREXHIP_ABI_VERSION 3
+#define TREXHIP_ABI_VERSION 4
 
 enum {
     TREXHIP_OK = 0,
@@ -402,6 +402,46 @@ enum { TREXHIP_STAGE_ROWS = 0, TREXHIP_STAGE_SEGMENT_ALL = 1, TREXHIP_STAGE_CONV
 int trexhip_profile_enable(trexhip_ctx* ctx, int32_t on);
 int trexhip_profile_read(trexhip_ctx* ctx, int32_t stage, double* total_ms, int64_t* launches);
 int trexhip_profile_reset(trexhip_ctx* ctx);
+
+/* ------------------------------------------------------------------------------------------------
+ * Training step of the identity network.
+ * Replaces the body of the batch loop of train(), Application/src/tracker/python/visual_recognition_torch.py:1137-1158
+ * (forward in training mode, nn.CrossEntropyLoss, backward, torch.optim.Adam(lr).step -- criterion / optimizer :1420-1421), for
+ * V118_3 (visual_identification_network_torch.py:184-258) in fp32: the reference's arithmetic on every device but 'cuda', where it
+ * additionally wraps the step in autocast + GradScaler (:1066-1072).  What stays on the host side of the boundary, as in the
+ * reference: the data loader with its augmentation (:158-188, :1325-1336), epochs, validation, ReduceLROnPlateau (-> set_lr) and
+ * early stopping (:1160-1283).
+ *   trexhip_trainer_create     weights = the blob of trexhip_load_weights (state_dict order, running statistics included); the
+ *                              trainer keeps parameters, gradients and Adam moments in HBM
+ *   trexhip_train_step_device  d_inputs [n][80][80][channels] float32 in [0, 255] (NHWC, what TRexImageDataset yields), d_targets
+ *                              [n] class indices.  d_keep_masks: null = the library draws the dropout masks (counter-based hash of
+ *                              seed, step, index); else n*16 + n*64 + n*128 + n*100 bytes, 1 = keep: the masks of Dropout2d after
+ *                              block 1, 2, 3 ([n][C]) and of the Dropout after fc1 ([n][100]) -- how the parity tests inject what
+ *                              the reference drew.  loss / correct (host, optional): mean cross entropy and the number of samples
+ *                              whose arg-max equals the target; passing either makes the call synchronise
+ *   trexhip_trainer_export     the current weights as a blob for trexhip_load_weights (the reference hands its state_dict back)
+ *   trexhip_trainer_read       one tensor in torch's layout; tensor = index in state_dict order (0 conv1.weight ... 23 fc2.bias,
+ *                              running statistics included), kind 0 parameter, 1 gradient of the last step, 2 / 3 Adam moments
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct trexhip_trainer trexhip_trainer;
+typedef struct {
+    int32_t max_batch;          /* largest n of a step (VINetwork: 64..128, ml/VisualIdentification.cpp:112-118)               */
+    float lr;                   /* learning_rate, 0.001 (visual_identification_network.py:151)                                */
+    float beta1, beta2, eps;    /* torch.optim.Adam defaults 0.9, 0.999, 1e-8                                                */
+    float bn_momentum;          /* nn.BatchNorm2d default 0.1                                                                */
+    float dropout;              /* 0.05 for all four dropout layers (visual_identification_network_torch.py:189-208)         */
+    int32_t reserved_;
+    uint64_t seed;              /* of the library's own dropout masks                                                        */
+} trexhip_train_params;
+size_t trexhip_weight_blob_bytes(int32_t classes, int32_t channels);
+int trexhip_trainer_create(trexhip_ctx* ctx, const void* blob, size_t bytes, const trexhip_train_params* params, trexhip_trainer** out);
+void trexhip_trainer_destroy(trexhip_trainer* trainer);
+int trexhip_trainer_set_lr(trexhip_trainer* trainer, float lr);
+int64_t trexhip_trainer_steps(trexhip_trainer* trainer);
+int trexhip_train_step_device(trexhip_trainer* trainer, const float* d_inputs, const int32_t* d_targets, int32_t n, const uint8_t* d_keep_masks,
+                              float* loss, int32_t* correct);
+int trexhip_trainer_read(trexhip_trainer* trainer, int32_t tensor, int32_t kind, float* out, size_t count);
+int trexhip_trainer_export(trexhip_trainer* trainer, void* blob, size_t capacity, size_t* bytes);
 
 #ifdef __cplusplus
 }

@@ -98,12 +98,18 @@ class TrexHipError(RuntimeError):
 
 
 # every symbol include/trexhip.h declares (tests check the library exports all of them)
+class TrainParams(C.Structure):
+    _fields_ = [("max_batch", C.c_int32), ("lr", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float),
+                ("bn_momentum", C.c_float), ("dropout", C.c_float), ("reserved_", C.c_int32), ("seed", C.c_uint64)]
+
+
 SYMBOLS = [
     "trexhip_abi_version", "trexhip_network_channels", "trexhip_comm_unique_id", "trexhip_comm_create", "trexhip_comm_destroy", "trexhip_comm_rank", "trexhip_comm_world", "trexhip_comm_gather_device", "trexhip_last_error", "trexhip_default_params", "trexhip_create", "trexhip_destroy",
     "trexhip_set_stream", "trexhip_set_background", "trexhip_set_background_device", "trexhip_set_background_color", "trexhip_set_background_color_device", "trexhip_generate_average_device", "trexhip_get_background", "trexhip_segment_device",
     "trexhip_segment", "trexhip_segment_color", "trexhip_segment_color_device", "trexhip_rethreshold_device", "trexhip_rethreshold_per_blob_device", "trexhip_fetch_rethreshold", "trexhip_fetch", "trexhip_device_view_get", "trexhip_synchronize",
     "trexhip_profile_enable", "trexhip_profile_read", "trexhip_profile_reset",
     "trexhip_default_posture_params", "trexhip_posture_device", "trexhip_posture_auto_device", "trexhip_pack_frames_v6_device", "trexhip_crops_device", "trexhip_pixel_channels", "trexhip_device_alloc", "trexhip_device_free", "trexhip_copy_to_host", "trexhip_copy_to_device", "trexhip_crops_transformed_device", "trexhip_crops_posture_device", "trexhip_default_midline_params", "trexhip_midline_device", "trexhip_default_split_params", "trexhip_split_search_device", "trexhip_export_id_table_device", "trexhip_export_id_table_ex_device", "trexhip_load_weights", "trexhip_set_identity_precision", "trexhip_num_classes", "trexhip_identify_device", "trexhip_identify",
+    "trexhip_weight_blob_bytes", "trexhip_trainer_create", "trexhip_trainer_destroy", "trexhip_trainer_set_lr", "trexhip_trainer_steps", "trexhip_train_step_device", "trexhip_trainer_read", "trexhip_trainer_export",
 ]
 
 
@@ -168,6 +174,17 @@ def lib():
         L.trexhip_set_identity_precision.argtypes = [C.c_void_p, C.c_int32]
         L.trexhip_identify_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]
         L.trexhip_identify.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]
+        L.trexhip_weight_blob_bytes.argtypes = [C.c_int32, C.c_int32]
+        L.trexhip_weight_blob_bytes.restype = C.c_size_t
+        L.trexhip_trainer_create.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(TrainParams), C.POINTER(C.c_void_p)]
+        L.trexhip_trainer_destroy.argtypes = [C.c_void_p]
+        L.trexhip_trainer_destroy.restype = None
+        L.trexhip_trainer_set_lr.argtypes = [C.c_void_p, C.c_float]
+        L.trexhip_trainer_steps.argtypes = [C.c_void_p]
+        L.trexhip_trainer_steps.restype = C.c_int64
+        L.trexhip_train_step_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_int32)]
+        L.trexhip_trainer_read.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_size_t]
+        L.trexhip_trainer_export.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
         _LIB = L
     return _LIB
 
@@ -463,6 +480,50 @@ class Segmenter:
 
     def profile_reset(self):
         _check(lib().trexhip_profile_reset(self._h))
+
+
+class Trainer:
+    """Training step of the identity network (include/trexhip.h: trexhip_trainer_*, trexhip_train_step_device)."""
+
+    def __init__(self, seg, weight_blob, max_batch, lr=1e-3, beta1=0.9, beta2=0.999, eps=1e-8, bn_momentum=0.1, dropout=0.05, seed=0):
+        self._h = C.c_void_p()
+        p = TrainParams(max_batch=max_batch, lr=lr, beta1=beta1, beta2=beta2, eps=eps, bn_momentum=bn_momentum, dropout=dropout, seed=seed)
+        buf = (C.c_char * len(weight_blob)).from_buffer_copy(weight_blob)
+        _check(lib().trexhip_trainer_create(seg.handle, buf, len(weight_blob), C.byref(p), C.byref(self._h)))
+        hdr = np.frombuffer(weight_blob[:32], np.int32)
+        self.classes, self.channels = int(hdr[2]), int(hdr[5])
+
+    def step_device(self, d_inputs_ptr, d_targets_ptr, n, d_keep_ptr=0, want_loss=True):
+        """-> (mean loss, correct count) when want_loss (synchronises), else None"""
+        loss, correct = C.c_float(), C.c_int32()
+        _check(lib().trexhip_train_step_device(self._h, C.c_void_p(d_inputs_ptr), C.c_void_p(d_targets_ptr), n, C.c_void_p(d_keep_ptr or 0),
+                                               C.byref(loss) if want_loss else None, C.byref(correct) if want_loss else None))
+        return (loss.value, correct.value) if want_loss else None
+
+    def set_lr(self, lr):
+        _check(lib().trexhip_trainer_set_lr(self._h, lr))
+
+    @property
+    def steps(self):
+        return int(lib().trexhip_trainer_steps(self._h))
+
+    def read(self, tensor, kind, shape):
+        """tensor: index in state_dict order (trex_amd.weights.TENSORS); kind 0 parameter, 1 gradient, 2 / 3 Adam moments; torch layout"""
+        out = np.empty(int(np.prod(shape)), np.float32)
+        _check(lib().trexhip_trainer_read(self._h, tensor, kind, out.ctypes.data_as(C.c_void_p), out.size))
+        return out.reshape(shape)
+
+    def export(self):
+        need = int(lib().trexhip_weight_blob_bytes(self.classes, self.channels))
+        buf = (C.c_char * need)()
+        got = C.c_size_t()
+        _check(lib().trexhip_trainer_export(self._h, buf, need, C.byref(got)))
+        return bytes(buf)
+
+    def close(self):
+        if self._h:
+            lib().trexhip_trainer_destroy(self._h)
+            self._h = C.c_void_p()
 
 
 class Comm:

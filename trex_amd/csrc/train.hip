@@ -1,0 +1,1039 @@
+// train.hip -- one optimizer step of the identity network V118_3 on gfx950, fp32.
+//
+// Replaces the body of train()'s batch loop
+//   Application/src/tracker/python/visual_recognition_torch.py:1137-1158
+//       outputs = model(inputs); loss = CrossEntropyLoss(outputs, targets); loss.backward(); optimizer.step(); zero_grad()
+//   (criterion / Adam(lr) :1420-1421; autocast + GradScaler are enabled for device == 'cuda' only, :1066-1072 -- fp32 is the
+//   reference's own arithmetic everywhere else and the parity bar here)
+// for the network visual_identification_network_torch.py:184-258 in TRAINING mode:
+//   [conv5x5 'same' -> BatchNorm2d (batch statistics; running statistics updated, momentum 0.1) -> ReLU -> MaxPool2 ->
+//    Dropout2d(0.05)] x3 -> flatten (NCHW order) -> fc1 -> LayerNorm(100) -> ReLU -> Dropout(0.05) -> fc2 -> cross entropy (mean).
+// Inputs are what TRexImageDataset yields (:158-188): NHWC float32 in [0, 255], integer class labels.
+//
+// Data (all NHWC fp32 in HBM, sized for max_batch at creation): z_i = raw convolution outputs (kept for the backward pass, turned
+// into dz_i in place), a_i = pooled + dropped activations, da_i = their gradients.  Parameters, gradients and the two Adam moments are
+// four flat arrays with one layout (the kernels' layouts, not torch's: conv [ci chunk][tap][ci][co], fc1 [hw][c][o]), so the
+// optimizer is one element-wise launch; import / export / read permute on the host.
+// Kernels: convolutions and data gradients = k_conv5 (conv_f32.h, fp32 MFMA, raw epilogue; the data gradient is the same kernel on
+// flipped + transposed weights); weight gradients = k_t_wgrad (fp32 MFMA, operands straight from L2: one MFMA k-step = two pixels,
+// A = activations at the tap's shift, B = dz); batch-norm statistics and their backward sums in double; everything else VALU.
+// Every reduction has a fixed order: two runs of a step give identical bits.
+#include "internal.h"
+#include "conv_f32.h"
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+namespace trexhip {
+
+enum { T_C1W, T_C1B, T_G1, T_BE1, T_RM1, T_RV1, T_C2W, T_C2B, T_G2, T_BE2, T_RM2, T_RV2, T_C3W, T_C3B, T_G3, T_BE3, T_RM3, T_RV3,
+       T_F1W, T_F1B, T_LNG, T_LNB, T_F2W, T_F2B, T_COUNT };
+
+static constexpr float EPS_BN = 1e-5f, EPS_LN = 1e-5f;
+
+// ------------------------------------------------------------------------------------------------
+// conv1 forward: [n][80][80][CH] float -> z1 [n][80][80][16] = conv + bias.  Block = 4 rows of one crop, one pixel per thread.
+// ------------------------------------------------------------------------------------------------
+template <int CH>
+__global__ __launch_bounds__(320) void k_t_conv1(const float* __restrict__ x, const float* __restrict__ w /*[CH][25][16]*/,
+                                                 const float* __restrict__ b, float* __restrict__ z) {
+    __shared__ float xs[8 * 84 * CH];
+    __shared__ __attribute__((aligned(16))) float ws[CH * 25 * 16];
+    const int tid = threadIdx.x, crop = blockIdx.x / 20, row0 = (blockIdx.x % 20) * 4;
+    for (int idx = tid; idx < 8 * 84 * CH; idx += 320) {
+        const int c = idx % CH, px = (idx / CH) % 84, py = idx / (CH * 84);
+        const int iy = row0 + py - 2, ix = px - 2;
+        xs[idx] = (iy >= 0 && iy < 80 && ix >= 0 && ix < 80) ? x[(((size_t)crop * 80 + iy) * 80 + ix) * CH + c] : 0.f;
+    }
+    for (int idx = tid; idx < CH * 25 * 16; idx += 320) ws[idx] = w[idx];
+    __syncthreads();
+    const int y = tid / 80, xx = tid % 80;
+    float acc[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) acc[k] = 0.f;
+#pragma unroll 1
+    for (int c = 0; c < CH; ++c)
+#pragma unroll 1
+        for (int ky = 0; ky < 5; ++ky)
+#pragma unroll
+            for (int kx = 0; kx < 5; ++kx) {
+                const float v = xs[((y + ky) * 84 + xx + kx) * CH + c];
+                const float4* wv = reinterpret_cast<const float4*>(ws + (c * 25 + ky * 5 + kx) * 16);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float4 t = wv[q];
+                    acc[4 * q] += v * t.x; acc[4 * q + 1] += v * t.y; acc[4 * q + 2] += v * t.z; acc[4 * q + 3] += v * t.w;
+                }
+            }
+    float4* o = reinterpret_cast<float4*>(z + (((size_t)crop * 80 + row0 + y) * 80 + xx) * 16);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) o[q] = make_float4(acc[4 * q] + b[4 * q], acc[4 * q + 1] + b[4 * q + 1], acc[4 * q + 2] + b[4 * q + 2], acc[4 * q + 3] + b[4 * q + 3]);
+}
+
+// ------------------------------------------------------------------------------------------------
+// per-channel sum and sum of squares of d[rows][C], double accumulation, fixed order: partial[block][2][C]
+// ------------------------------------------------------------------------------------------------
+template <int C>
+__global__ __launch_bounds__(256) void k_t_colstats(const float* __restrict__ d, size_t rows, double* __restrict__ partial) {
+    constexpr int LC = C / 4, RL = 256 / LC;
+    __shared__ double sh[RL * C];
+    const int tid = threadIdx.x, cl = tid % LC, rl = tid / LC;
+    double s[4] = {0, 0, 0, 0}, q[4] = {0, 0, 0, 0};
+    for (size_t r = (size_t)blockIdx.x * RL + rl; r < rows; r += (size_t)gridDim.x * RL) {
+        const float4 v = *reinterpret_cast<const float4*>(d + r * C + cl * 4);
+        s[0] += v.x; s[1] += v.y; s[2] += v.z; s[3] += v.w;
+        q[0] += (double)v.x * v.x; q[1] += (double)v.y * v.y; q[2] += (double)v.z * v.z; q[3] += (double)v.w * v.w;
+    }
+    for (int pass = 0; pass < 2; ++pass) {
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 4; ++k) sh[rl * C + cl * 4 + k] = pass ? q[k] : s[k];
+        __syncthreads();
+        if (tid < C) {
+            double t = 0;
+            for (int r = 0; r < RL; ++r) t += sh[r * C + tid];
+            partial[((size_t)blockIdx.x * 2 + pass) * C + tid] = t;
+        }
+    }
+}
+
+// sum over the blocks' partials of one pass, fixed order: 8 lanes per channel take every 8th block, then the 8 lane sums are added in
+// order.  Block = 1024 threads (C <= 128); the result is valid in threads < C.
+__device__ __forceinline__ double sum_partials(const double* __restrict__ partial, int nblocks, int C, int pass, double* sh /*[8][128]*/) {
+    const int c = threadIdx.x & 127, ln = threadIdx.x >> 7;
+    double t = 0;
+    if (c < C)
+        for (int b = ln; b < nblocks; b += 8) t += partial[((size_t)b * 2 + pass) * C + c];
+    __syncthreads();
+    sh[ln * 128 + c] = t;
+    __syncthreads();
+    double r = 0;
+    if (threadIdx.x < C)
+        for (int k = 0; k < 8; ++k) r += sh[k * 128 + threadIdx.x];
+    return r;
+}
+
+// batch statistics -> mean, invstd (biased variance, like the normalisation uses), running statistics updated with the unbiased one
+__global__ __launch_bounds__(1024) void k_t_bn_finalize(const double* __restrict__ partial, int nblocks, int C, double count, float momentum,
+                                                        float* __restrict__ mean, float* __restrict__ invstd, float* __restrict__ run_mean,
+                                                        float* __restrict__ run_var) {
+    __shared__ double sh[8 * 128];
+    const double s = sum_partials(partial, nblocks, C, 0, sh);
+    const double q = sum_partials(partial, nblocks, C, 1, sh);
+    const int c = threadIdx.x;
+    if (c >= C) return;
+    const double m = s / count;
+    double var = q / count - m * m;
+    if (var < 0) var = 0;
+    mean[c] = (float)m;
+    invstd[c] = (float)(1.0 / sqrt(var + (double)EPS_BN));
+    const double unbiased = count > 1 ? var * count / (count - 1) : var;
+    run_mean[c] = (1.f - momentum) * run_mean[c] + momentum * (float)m;
+    run_var[c] = (1.f - momentum) * run_var[c] + momentum * (float)unbiased;
+}
+
+// sum over the partials -> a bias gradient (pass 0 of k_t_colstats)
+__global__ __launch_bounds__(1024) void k_t_sum_finalize(const double* __restrict__ partial, int nblocks, int C, float* __restrict__ out) {
+    __shared__ double sh[8 * 128];
+    const double s = sum_partials(partial, nblocks, C, 0, sh);
+    if ((int)threadIdx.x < C) out[threadIdx.x] = (float)s;
+}
+
+// ------------------------------------------------------------------------------------------------
+// BN (batch statistics) + ReLU + 2x2 max-pool + channel dropout: z [n][S][S][C] -> a [n][S/2][S/2][C]
+// ------------------------------------------------------------------------------------------------
+struct PoolWin { float4 y[4]; };
+
+template <int C>
+__device__ __forceinline__ void load_window(const float* __restrict__ z, int S, int crop, int py, int px, int c4, float4 v[4]) {
+    const float* base = z + (((size_t)crop * S + 2 * py) * S + 2 * px) * C + c4 * 4;
+    v[0] = *reinterpret_cast<const float4*>(base);
+    v[1] = *reinterpret_cast<const float4*>(base + C);
+    v[2] = *reinterpret_cast<const float4*>(base + (size_t)S * C);
+    v[3] = *reinterpret_cast<const float4*>(base + (size_t)S * C + C);
+}
+
+__device__ __forceinline__ float f4get(const float4& v, int k) { return k == 0 ? v.x : k == 1 ? v.y : k == 2 ? v.z : v.w; }
+__device__ __forceinline__ void f4set(float4& v, int k, float x) { if (k == 0) v.x = x; else if (k == 1) v.y = x; else if (k == 2) v.z = x; else v.w = x; }
+
+template <int C>
+__global__ __launch_bounds__(256) void k_t_bn_pool(const float* __restrict__ z, const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                   const float* __restrict__ g, const float* __restrict__ be, const uint8_t* __restrict__ keep /*[n][C]*/,
+                                                   float scale, float* __restrict__ a, int n, int S) {
+    const int H = S / 2;
+    const size_t total = (size_t)n * H * H * (C / 4);
+    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total) return;
+    const int c4 = idx % (C / 4);
+    const size_t pos = idx / (C / 4);
+    const int px = pos % H, py = (pos / H) % H, crop = pos / ((size_t)H * H);
+    float4 v[4];
+    load_window<C>(z, S, crop, py, px, c4, v);
+    float4 out;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int c = c4 * 4 + k;
+        const float alpha = invstd[c] * g[c], beta = be[c] - mean[c] * alpha;
+        float m = f4get(v[0], k) * alpha + beta;
+#pragma unroll
+        for (int q = 1; q < 4; ++q) m = fmaxf(m, f4get(v[q], k) * alpha + beta);
+        m = fmaxf(m, 0.f);
+        f4set(out, k, keep[(size_t)crop * C + c] ? m * scale : 0.f);
+    }
+    *reinterpret_cast<float4*>(a + pos * C + c4 * 4) = out;
+}
+
+// the gradient that reaches the BN output of one pooled element: through dropout, the pool's arg-max (first maximum in scan order,
+// like torch's max_pool2d) and the ReLU gate.  Returns the arg-max position and x-hat there.
+__device__ __forceinline__ float pooled_grad(const float zq[4], float mean, float inv, float alpha, float beta, float da, bool kept, float scale,
+                                             int* arg, float* xhat) {
+    float best = zq[0] * alpha + beta;
+    int bi = 0;
+#pragma unroll
+    for (int q = 1; q < 4; ++q) {
+        const float y = zq[q] * alpha + beta;
+        if (y > best) { best = y; bi = q; }
+    }
+    *arg = bi;
+    *xhat = (zq[bi] - mean) * inv;
+    return (kept && best > 0.f) ? da * scale : 0.f;
+}
+
+// sums of dy and dy * x-hat over (n, y, x) per channel (BN backward), from the pooled gradient: partial[block][2][C]
+template <int C>
+__global__ __launch_bounds__(256) void k_t_pool_bwd_stats(const float* __restrict__ da, const float* __restrict__ z, const float* __restrict__ mean,
+                                                          const float* __restrict__ invstd, const float* __restrict__ g, const float* __restrict__ be,
+                                                          const uint8_t* __restrict__ keep, float scale, int n, int S, double* __restrict__ partial) {
+    constexpr int LC = C / 4, RL = 256 / LC;
+    __shared__ double sh[RL * C];
+    const int tid = threadIdx.x, cl = tid % LC, rl = tid / LC;
+    const int H = S / 2;
+    const size_t rows = (size_t)n * H * H;
+    float mn[4], iv[4], al[4], bt[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int c = cl * 4 + k;
+        mn[k] = mean[c]; iv[k] = invstd[c]; al[k] = iv[k] * g[c]; bt[k] = be[c] - mn[k] * al[k];
+    }
+    double s[4] = {0, 0, 0, 0}, q[4] = {0, 0, 0, 0};
+    for (size_t r = (size_t)blockIdx.x * RL + rl; r < rows; r += (size_t)gridDim.x * RL) {
+        const int px = r % H, py = (r / H) % H, crop = r / ((size_t)H * H);
+        float4 v[4];
+        load_window<C>(z, S, crop, py, px, cl, v);
+        const float4 d = *reinterpret_cast<const float4*>(da + r * C + cl * 4);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float zq[4] = {f4get(v[0], k), f4get(v[1], k), f4get(v[2], k), f4get(v[3], k)};
+            int arg; float xh;
+            const float gy = pooled_grad(zq, mn[k], iv[k], al[k], bt[k], f4get(d, k), keep[(size_t)crop * C + cl * 4 + k] != 0, scale, &arg, &xh);
+            s[k] += gy; q[k] += (double)gy * xh;
+        }
+    }
+    for (int pass = 0; pass < 2; ++pass) {
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 4; ++k) sh[rl * C + cl * 4 + k] = pass ? q[k] : s[k];
+        __syncthreads();
+        if (tid < C) {
+            double t = 0;
+            for (int r = 0; r < RL; ++r) t += sh[r * C + tid];
+            partial[((size_t)blockIdx.x * 2 + pass) * C + tid] = t;
+        }
+    }
+}
+
+// -> sums[0][C] = sum dy (= d beta), sums[1][C] = sum dy x-hat (= d gamma), and the two gradients
+__global__ __launch_bounds__(1024) void k_t_bn_bwd_finalize(const double* __restrict__ partial, int nblocks, int C, float* __restrict__ sums,
+                                                            float* __restrict__ d_gamma, float* __restrict__ d_beta) {
+    __shared__ double sh[8 * 128];
+    const double s = sum_partials(partial, nblocks, C, 0, sh);
+    const double q = sum_partials(partial, nblocks, C, 1, sh);
+    const int c = threadIdx.x;
+    if (c >= C) return;
+    sums[c] = (float)s; sums[C + c] = (float)q;
+    d_beta[c] = (float)s; d_gamma[c] = (float)q;
+}
+
+// dz = gamma * invstd * (dy - mean(dy) - x-hat * mean(dy x-hat)), written over z (dy is non-zero at the pool's arg-max only)
+template <int C>
+__global__ __launch_bounds__(256) void k_t_bn_bwd(const float* __restrict__ da, float* __restrict__ z, const float* __restrict__ mean,
+                                                  const float* __restrict__ invstd, const float* __restrict__ g, const float* __restrict__ be,
+                                                  const uint8_t* __restrict__ keep, float scale, const float* __restrict__ sums, float inv_count, int n, int S) {
+    const int H = S / 2;
+    const size_t total = (size_t)n * H * H * (C / 4);
+    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total) return;
+    const int c4 = idx % (C / 4);
+    const size_t pos = idx / (C / 4);
+    const int px = pos % H, py = (pos / H) % H, crop = pos / ((size_t)H * H);
+    float4 v[4];
+    load_window<C>(z, S, crop, py, px, c4, v);
+    const float4 d = *reinterpret_cast<const float4*>(da + pos * C + c4 * 4);
+    float4 o[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int c = c4 * 4 + k;
+        const float mn = mean[c], iv = invstd[c], gm = g[c], al = iv * gm, bt = be[c] - mn * al;
+        const float zq[4] = {f4get(v[0], k), f4get(v[1], k), f4get(v[2], k), f4get(v[3], k)};
+        int arg; float xh;
+        const float gy = pooled_grad(zq, mn, iv, al, bt, f4get(d, k), keep[(size_t)crop * C + c] != 0, scale, &arg, &xh);
+        const float m1 = sums[c] * inv_count, m2 = sums[C + c] * inv_count;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float xhat = (zq[q] - mn) * iv;
+            f4set(o[q], k, al * ((q == arg ? gy : 0.f) - m1 - xhat * m2));
+        }
+    }
+    float* base = z + (((size_t)crop * S + 2 * py) * S + 2 * px) * C + c4 * 4;
+    *reinterpret_cast<float4*>(base) = o[0];
+    *reinterpret_cast<float4*>(base + C) = o[1];
+    *reinterpret_cast<float4*>(base + (size_t)S * C) = o[2];
+    *reinterpret_cast<float4*>(base + (size_t)S * C + C) = o[3];
+}
+
+// ------------------------------------------------------------------------------------------------
+// fc1: h[n][100] = a3[n][hw][c] . W1c[hw][c][o], as 100 partial planes (one per hw) summed in fixed order by the head kernel
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_t_fc1(const float* __restrict__ a3 /*[n][100][128]*/, const float* __restrict__ w /*[100][128][100]*/,
+                                               float* __restrict__ hpart /*[100][n][100]*/, int n) {
+    __shared__ float As[64 * 65];
+    __shared__ float Ws[64 * 100];
+    const int tid = threadIdx.x, hw = blockIdx.x, n0 = blockIdx.y * 64;
+    const int ng = tid >> 5, og = tid & 31;
+    float acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) acc[i][k] = 0.f;
+    for (int half = 0; half < 2; ++half) {
+        __syncthreads();
+        for (int idx = tid; idx < 64 * 64; idx += 256) {
+            const int i = idx >> 6, c = idx & 63;
+            As[i * 65 + c] = (n0 + i < n) ? a3[((size_t)(n0 + i) * 100 + hw) * 128 + half * 64 + c] : 0.f;
+        }
+        for (int idx = tid; idx < 64 * 100; idx += 256) Ws[idx] = w[((size_t)hw * 128 + half * 64) * 100 + idx];
+        __syncthreads();
+        for (int c = 0; c < 64; ++c) {
+            float wv[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) wv[k] = (og + 32 * k < 100) ? Ws[c * 100 + og + 32 * k] : 0.f;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const float av = As[(ng * 8 + i) * 65 + c];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) acc[i][k] += av * wv[k];
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int nn = n0 + ng * 8 + i;
+        if (nn >= n) continue;
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (og + 32 * k < 100) hpart[((size_t)hw * n + nn) * 100 + og + 32 * k] = acc[i][k];
+    }
+}
+
+// block reduction of one float over 128 threads, fixed order
+__device__ __forceinline__ float block_sum128(float v, float* red) {
+    const int tid = threadIdx.x;
+    __syncthreads();
+    red[tid] = v;
+    __syncthreads();
+    for (int s = 64; s > 0; s >>= 1) {
+        if (tid < s) red[tid] += red[tid + s];
+        __syncthreads();
+    }
+    return red[0];
+}
+__device__ __forceinline__ float block_max128(float v, float* red) {
+    const int tid = threadIdx.x;
+    __syncthreads();
+    red[tid] = v;
+    __syncthreads();
+    for (int s = 64; s > 0; s >>= 1) {
+        if (tid < s) red[tid] = fmaxf(red[tid], red[tid + s]);
+        __syncthreads();
+    }
+    return red[0];
+}
+
+// one block per sample: fc1 bias + LayerNorm + ReLU + dropout + fc2 + softmax cross entropy, and the way back down to d(fc1 output)
+__global__ __launch_bounds__(128) void k_t_head(const float* __restrict__ hpart, int n, const float* __restrict__ b1, const float* __restrict__ lng,
+                                                const float* __restrict__ lnb, const uint8_t* __restrict__ keep /*[n][100]*/, float scale,
+                                                const float* __restrict__ w2 /*[C][100]*/, const float* __restrict__ b2, const int32_t* __restrict__ targets,
+                                                int classes, float* __restrict__ xhat /*[n][100]*/, float* __restrict__ hd /*[n][100]*/,
+                                                float* __restrict__ dl /*[n][C]*/, float* __restrict__ dy /*[n][100]*/, float* __restrict__ dh /*[n][100]*/,
+                                                float* __restrict__ loss /*[n]*/, int32_t* __restrict__ correct /*[n]*/) {
+    __shared__ float red[128];
+    __shared__ float s_d[100];
+    __shared__ float s_dl[1024];
+    __shared__ int s_arg[128];
+    const int tid = threadIdx.x, s = blockIdx.x;
+    const bool act = tid < 100;
+    float h = 0.f;
+    if (act) {
+        h = b1[tid];
+        for (int hw = 0; hw < 100; ++hw) h += hpart[((size_t)hw * n + s) * 100 + tid];
+    }
+    const float mean = block_sum128(act ? h : 0.f, red) * 0.01f;
+    const float dv = act ? h - mean : 0.f;
+    const float var = block_sum128(dv * dv, red) * 0.01f;
+    const float rstd = 1.0f / sqrtf(var + EPS_LN);
+    float xh = 0.f, y = 0.f, d = 0.f;
+    bool kp = false;
+    if (act) {
+        xh = dv * rstd;
+        y = xh * lng[tid] + lnb[tid];
+        kp = keep[(size_t)s * 100 + tid] != 0;
+        d = kp ? fmaxf(y, 0.f) * scale : 0.f;
+        s_d[tid] = d;
+        xhat[(size_t)s * 100 + tid] = xh;
+        hd[(size_t)s * 100 + tid] = d;
+    }
+    __syncthreads();
+    // logits
+    float lmax = -INFINITY;
+    int larg = 0x7fffffff;
+    for (int c = tid; c < classes; c += 128) {
+        float acc = b2[c];
+        const float* wr = w2 + (size_t)c * 100;
+        for (int j = 0; j < 100; ++j) acc += s_d[j] * wr[j];
+        s_dl[c] = acc;
+        if (acc > lmax) { lmax = acc; larg = c; }
+    }
+    const float gmax = block_max128(lmax, red);
+    __syncthreads();
+    s_arg[tid] = (lmax == gmax) ? larg : 0x7fffffff;       // first index of the maximum, like torch.argmax
+    __syncthreads();
+    for (int st = 64; st > 0; st >>= 1) {
+        if (tid < st) s_arg[tid] = min(s_arg[tid], s_arg[tid + st]);
+        __syncthreads();
+    }
+    const int target = targets[s];
+    float se = 0.f;
+    for (int c = tid; c < classes; c += 128) se += expf(s_dl[c] - gmax);
+    const float sum = block_sum128(se, red);
+    const float lse = gmax + logf(sum);
+    if (tid == 0) {
+        loss[s] = lse - s_dl[target];
+        correct[s] = s_arg[0] == target ? 1 : 0;
+    }
+    __syncthreads();
+    const float invn = 1.0f / (float)n;
+    for (int c = tid; c < classes; c += 128) {
+        const float p = expf(s_dl[c] - lse);
+        const float gl = (p - (c == target ? 1.f : 0.f)) * invn;
+        s_dl[c] = gl;
+        dl[(size_t)s * classes + c] = gl;
+    }
+    __syncthreads();
+    float gy = 0.f;
+    if (act) {
+        float dd = 0.f;
+        for (int c = 0; c < classes; ++c) dd += s_dl[c] * w2[(size_t)c * 100 + tid];
+        gy = (kp && y > 0.f) ? dd * scale : 0.f;              // through dropout and the ReLU gate: gradient at the LayerNorm output
+        dy[(size_t)s * 100 + tid] = gy;
+    }
+    // LayerNorm backward: dh = rstd * (dxh - mean(dxh) - xh * mean(dxh * xh)), dxh = gy * gamma
+    const float dxh = act ? gy * lng[tid] : 0.f;
+    const float m1 = block_sum128(dxh, red) * 0.01f;
+    const float m2 = block_sum128(dxh * xh, red) * 0.01f;
+    if (act) dh[(size_t)s * 100 + tid] = rstd * (dxh - m1 - xh * m2);
+}
+
+// parameter gradients of the head: fc2 weight / bias, LayerNorm gamma / beta, fc1 bias; one thread per element, samples in order
+__global__ __launch_bounds__(256) void k_t_head_grads(const float* __restrict__ dl, const float* __restrict__ hd, const float* __restrict__ dy,
+                                                      const float* __restrict__ xhat, const float* __restrict__ dh, int n, int classes,
+                                                      float* __restrict__ g_w2, float* __restrict__ g_b2, float* __restrict__ g_lng, float* __restrict__ g_lnb,
+                                                      float* __restrict__ g_b1) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    const int nw = classes * 100;
+    if (idx < nw) {
+        const int c = idx / 100, j = idx % 100;
+        float acc = 0.f;
+        for (int s = 0; s < n; ++s) acc += dl[(size_t)s * classes + c] * hd[(size_t)s * 100 + j];
+        g_w2[idx] = acc;
+    } else if (idx < nw + classes) {
+        const int c = idx - nw;
+        float acc = 0.f;
+        for (int s = 0; s < n; ++s) acc += dl[(size_t)s * classes + c];
+        g_b2[c] = acc;
+    } else if (idx < nw + classes + 300) {
+        const int k = idx - nw - classes, j = k % 100, which = k / 100;
+        float acc = 0.f;
+        if (which == 0) { for (int s = 0; s < n; ++s) acc += dy[(size_t)s * 100 + j] * xhat[(size_t)s * 100 + j]; g_lng[j] = acc; }
+        else if (which == 1) { for (int s = 0; s < n; ++s) acc += dy[(size_t)s * 100 + j]; g_lnb[j] = acc; }
+        else { for (int s = 0; s < n; ++s) acc += dh[(size_t)s * 100 + j]; g_b1[j] = acc; }
+    }
+}
+
+// fc1 weight gradient: dW1c[hw][c][o] = sum_n a3[n][hw][c] * dh[n][o]
+__global__ __launch_bounds__(256) void k_t_fc1_wgrad(const float* __restrict__ a3, const float* __restrict__ dh, float* __restrict__ gw, int n) {
+    __shared__ float As[64 * 128];
+    __shared__ float Ds[64 * 100];
+    const int tid = threadIdx.x, hw = blockIdx.x;
+    const int c = tid >> 1, o0 = (tid & 1) * 50;
+    float acc[50];
+#pragma unroll
+    for (int k = 0; k < 50; ++k) acc[k] = 0.f;
+    for (int n0 = 0; n0 < n; n0 += 64) {
+        const int cnt = min(64, n - n0);
+        __syncthreads();
+        for (int idx = tid; idx < 64 * 128; idx += 256) {
+            const int i = idx >> 7, cc = idx & 127;
+            As[idx] = i < cnt ? a3[((size_t)(n0 + i) * 100 + hw) * 128 + cc] : 0.f;
+        }
+        for (int idx = tid; idx < 64 * 100; idx += 256) Ds[idx] = (idx / 100) < cnt ? dh[(size_t)n0 * 100 + idx] : 0.f;
+        __syncthreads();
+        for (int i = 0; i < cnt; ++i) {
+            const float av = As[i * 128 + c];
+#pragma unroll
+            for (int k = 0; k < 50; ++k) acc[k] += av * Ds[i * 100 + o0 + k];
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 50; ++k) gw[((size_t)hw * 128 + c) * 100 + o0 + k] = acc[k];
+}
+
+// fc1 data gradient: da3[n][hw][c] = sum_o dh[n][o] * W1c[hw][c][o]
+__global__ __launch_bounds__(256) void k_t_fc1_dgrad(const float* __restrict__ dh, const float* __restrict__ w, float* __restrict__ da3, int n) {
+    __shared__ float Ws[128 * 101];
+    __shared__ float Ds[32 * 100];
+    const int tid = threadIdx.x, hw = blockIdx.x, n0 = blockIdx.y * 32;
+    const int c = tid & 127, ng = tid >> 7;
+    for (int idx = tid; idx < 128 * 100; idx += 256) Ws[(idx / 100) * 101 + idx % 100] = w[(size_t)hw * 12800 + idx];
+    for (int idx = tid; idx < 32 * 100; idx += 256) Ds[idx] = (n0 + idx / 100) < n ? dh[(size_t)n0 * 100 + idx] : 0.f;
+    __syncthreads();
+    float acc[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    for (int o = 0; o < 100; ++o) {
+        const float wv = Ws[c * 101 + o];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[i] += Ds[(ng * 16 + i) * 100 + o] * wv;
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int nn = n0 + ng * 16 + i;
+        if (nn < n) da3[((size_t)nn * 100 + hw) * 128 + c] = acc[i];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// convolution weight gradient on fp32 MFMA: dW[tap][ci][co] = sum over (crop, y, x) a[crop][y+ky-2][x+kx-2][ci] * dz[crop][y][x][co].
+// One 32x32x2 MFMA step contracts over two neighbouring pixels: A = activations (rows = ci, of TP taps when CI < 32), B = dz; both
+// operands come straight from L2 (a lane reads 4 bytes of a 128-byte channel run).  Block = one tap (pair) x one share of the
+// crops; its 8 waves take every 8th pixel pair, their sums are added in LDS: part[share][tap][ci][co].
+// ------------------------------------------------------------------------------------------------
+template <int CI, int CO, int S, int TP>
+__global__ __launch_bounds__(512) void k_t_wgrad(const float* __restrict__ a /*[n][S][S][CI]*/, const float* __restrict__ dz /*[n][S][S][CO]*/,
+                                                 float* __restrict__ part, int n) {
+    constexpr int MI = CI * TP, MT = MI / 32, NT = CO / 32, PP = S * S / 2, WAVES = 8;
+    static_assert(MI % 32 == 0 && CO % 32 == 0, "tile shapes");
+    __shared__ float sum[MT * NT * 16 * 64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 31, h = lane >> 5;
+    const int share = blockIdx.y, shares = gridDim.y;
+    int ky[MT], kx[MT], ci[MT];
+    bool tv[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        const int mi = mt * 32 + j, tap = blockIdx.x * TP + mi / CI;
+        ci[mt] = mi % CI; tv[mt] = tap < 25; ky[mt] = tap / 5 - 2; kx[mt] = tap % 5 - 2;
+    }
+    f32x16 acc[MT][NT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
+    for (int crop = share; crop < n; crop += shares) {
+        const float* ac = a + (size_t)crop * S * S * CI;
+        const float* dc = dz + (size_t)crop * S * S * CO;
+#pragma unroll 4
+        for (int q = wave; q < PP; q += WAVES) {
+            const int p = 2 * q + h, y = p / S, x = p - y * S;
+            float av[MT], bv[NT];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                const int ys = y + ky[mt], xs = x + kx[mt];
+                av[mt] = (tv[mt] && ys >= 0 && ys < S && xs >= 0 && xs < S) ? ac[((size_t)ys * S + xs) * CI + ci[mt]] : 0.f;
+            }
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) bv[nt] = dc[(size_t)p * CO + nt * 32 + j];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[mt], bv[nt], acc[mt][nt], 0, 0, 0);
+        }
+    }
+    // the 8 waves' sums are added in wave order through LDS: one partial per block, the same bits every run
+    for (int w = 0; w < WAVES; ++w) {
+        if (wave == w) {
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        float* d = sum + ((mt * NT + nt) * 16 + r) * 64 + lane;
+                        *d = w == 0 ? acc[mt][nt][r] : *d + acc[mt][nt][r];
+                    }
+        }
+        __syncthreads();
+    }
+    float* pp = part + (size_t)share * 25 * CI * CO;
+    for (int e = tid; e < MT * NT * 16 * 64; e += 512) {
+        const int ln = e & 63, r = (e >> 6) & 15, t = e >> 10, nt = t % NT, mt = t / NT;
+        const int mi = mt * 32 + 8 * (r / 4) + 4 * (ln >> 5) + (r % 4);     // accumulator r of lane (j, h) is row 8 (r / 4) + 4 h + r % 4
+        const int tap = blockIdx.x * TP + mi / CI, c = mi % CI;
+        if (tap < 25) pp[((size_t)tap * CI + c) * CO + nt * 32 + (ln & 31)] = sum[e];
+    }
+}
+
+// sum of the partials in order -> gradient in the parameter layout [ci / CIC][tap][ci % CIC][co]
+__global__ __launch_bounds__(256) void k_t_wgrad_reduce(const float* __restrict__ part, int nparts, int CI, int CO, int CIC, float* __restrict__ g) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    const int total = 25 * CI * CO;
+    if (idx >= total) return;
+    const int co = idx % CO, cic = (idx / CO) % CIC, tap = (idx / (CO * CIC)) % 25, cc = idx / (CO * CIC * 25);
+    const size_t src = ((size_t)tap * CI + cc * CIC + cic) * CO + co;
+    float acc = 0.f;
+    for (int p = 0; p < nparts; ++p) acc += part[(size_t)p * total + src];
+    g[idx] = acc;
+}
+
+// conv1 weight gradient (VALU): block = 8 rows of one crop -> part[block][c][tap][16]
+template <int CH>
+__global__ __launch_bounds__(512) void k_t_wgrad1(const float* __restrict__ x /*[n][80][80][CH]*/, const float* __restrict__ dz /*[n][80][80][16]*/,
+                                                  float* __restrict__ part) {
+    __shared__ float xs[12 * 84 * CH];
+    __shared__ float ds[640 * 16];
+    const int tid = threadIdx.x, crop = blockIdx.x / 10, row0 = (blockIdx.x % 10) * 8;
+    for (int idx = tid; idx < 12 * 84 * CH; idx += 512) {
+        const int c = idx % CH, px = (idx / CH) % 84, py = idx / (CH * 84);
+        const int iy = row0 + py - 2, ix = px - 2;
+        xs[idx] = (iy >= 0 && iy < 80 && ix >= 0 && ix < 80) ? x[(((size_t)crop * 80 + iy) * 80 + ix) * CH + c] : 0.f;
+    }
+    for (int idx = tid; idx < 640 * 16; idx += 512) ds[idx] = dz[((size_t)crop * 80 + row0) * 80 * 16 + idx];
+    __syncthreads();
+    if (tid >= 400) return;
+    const int tap = tid >> 4, co = tid & 15, ky = tap / 5, kx = tap % 5;
+    float acc[CH];
+#pragma unroll
+    for (int c = 0; c < CH; ++c) acc[c] = 0.f;
+#pragma unroll 1
+    for (int y = 0; y < 8; ++y)
+#pragma unroll 4
+        for (int xx = 0; xx < 80; ++xx) {
+            const float d = ds[(y * 80 + xx) * 16 + co];
+#pragma unroll
+            for (int c = 0; c < CH; ++c) acc[c] += xs[((y + ky) * 84 + xx + kx) * CH + c] * d;
+        }
+#pragma unroll
+    for (int c = 0; c < CH; ++c) part[(size_t)blockIdx.x * CH * 400 + c * 400 + tap * 16 + co] = acc[c];
+}
+
+// out[i] = sum over the parts, fixed order: 16 lanes per element take every 16th part, then the lane sums are added in order
+__global__ __launch_bounds__(256) void k_t_reduce(const float* __restrict__ part, int nparts, int count, float* __restrict__ out) {
+    __shared__ float sh[256];
+    const int tid = threadIdx.x, e = tid & 15, ln = tid >> 4, idx = blockIdx.x * 16 + e;
+    float acc = 0.f;
+    if (idx < count)
+        for (int p = ln; p < nparts; p += 16) acc += part[(size_t)p * count + idx];
+    sh[ln * 16 + e] = acc;
+    __syncthreads();
+    if (tid < 16 && idx < count) {
+        float r = 0.f;
+        for (int k = 0; k < 16; ++k) r += sh[k * 16 + tid];
+        out[idx] = r;
+    }
+}
+
+// weights of the data-gradient convolutions: input channels = the forward layer's outputs, taps flipped.
+// wb[cc'][t][cic'][co'] = w_fwd(ci = co', co = cc' * CICB + cic', tap = 24 - t); forward layout [ci / CIC][tap][ci % CIC][co]
+__global__ __launch_bounds__(256) void k_t_repack_bwd(const float* __restrict__ wf, int CI, int CO, int CIC, int COP /*padded output channels*/,
+                                                      int CICB /*input-channel chunk of the data-gradient kernel*/, float* __restrict__ wb) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    const int total = 25 * CO * COP;
+    if (idx >= total) return;
+    const int cop = idx % COP, cicp = (idx / COP) % CICB, t = (idx / (COP * CICB)) % 25, ccp = idx / (COP * CICB * 25);
+    float v = 0.f;
+    if (cop < CI) {
+        const int ci = cop, co = ccp * CICB + cicp, tap = 24 - t;
+        v = wf[(((size_t)(ci / CIC) * 25 + tap) * CIC + ci % CIC) * CO + co];
+    }
+    wb[idx] = v;
+}
+
+struct AdamSkip { uint32_t lo[6], hi[6]; };
+
+// torch.optim.Adam (_single_tensor_adam, no weight decay / amsgrad): m.lerp_(g, 1 - b1); v = v * b2 + (1 - b2) g g;
+// p += -step_size * m / (sqrt(v) / sqrt(bias_correction2) + eps)
+__global__ __launch_bounds__(256) void k_t_adam(float* __restrict__ P, const float* __restrict__ G, float* __restrict__ M, float* __restrict__ V,
+                                                uint32_t total, AdamSkip skip, float w1, float b2, float omb2, float step_size, float bc2_sqrt, float eps) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+#pragma unroll
+    for (int k = 0; k < 6; ++k)
+        if (i >= skip.lo[k] && i < skip.hi[k]) return;          // running statistics are buffers, not parameters
+    const float g = G[i];
+    float m = M[i], v = V[i];
+    m = m + w1 * (g - m);
+    v = v * b2 + (omb2 * g) * g;
+    M[i] = m; V[i] = v;
+    const float denom = sqrtf(v) / bc2_sqrt + eps;
+    P[i] = P[i] + (-step_size) * (m / denom);
+}
+
+__global__ void k_t_loss(const float* __restrict__ loss, const int32_t* __restrict__ correct, int n, float* __restrict__ out /*[2]*/) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    double s = 0;
+    int c = 0;
+    for (int i = 0; i < n; ++i) { s += loss[i]; c += correct[i]; }
+    out[0] = (float)(s / n);
+    out[1] = (float)c;
+}
+
+// keep masks when the caller injects none: one counter-based hash per (step, layer, sample, channel)
+__global__ __launch_bounds__(256) void k_t_masks(uint8_t* __restrict__ keep, size_t count, uint64_t seed, uint64_t step, float p_drop) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= count) return;
+    uint64_t zed = seed + 0x9E3779B97F4A7C15ull * (step * 0x100000001B3ull + i + 1);
+    zed = (zed ^ (zed >> 30)) * 0xBF58476D1CE4E5B9ull;
+    zed = (zed ^ (zed >> 27)) * 0x94D049BB133111EBull;
+    zed ^= zed >> 31;
+    const float u = (float)(zed >> 40) * (1.0f / 16777216.0f);
+    keep[i] = u >= p_drop ? 1 : 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------------
+struct Trainer {
+    trexhip_ctx* ctx = nullptr;
+    int classes = 0, CH = 1, max_n = 0;
+    trexhip_train_params p{};
+    int64_t step = 0;
+    size_t off[T_COUNT + 1] = {}, cnt[T_COUNT] = {};
+    size_t total = 0;
+    float *P = nullptr, *G = nullptr, *M = nullptr, *V = nullptr;
+    float *z1 = nullptr, *a1 = nullptr, *z2 = nullptr, *a2 = nullptr, *z3 = nullptr, *a3 = nullptr, *da3 = nullptr, *da2 = nullptr, *da1 = nullptr;
+    float *wb3 = nullptr, *wb2 = nullptr, *part = nullptr, *stat = nullptr /*3 x (mean, invstd, sums[2]) x 128*/;
+    float *hpart = nullptr, *xhat = nullptr, *hd = nullptr, *dl = nullptr, *dy = nullptr, *dh = nullptr, *loss = nullptr, *out2 = nullptr;
+    int32_t* correct = nullptr;
+    double* red = nullptr;
+    uint8_t* keep = nullptr;
+    size_t part_floats = 0;
+    bool attr = false;
+    std::vector<void*> allocs;
+};
+
+static constexpr int RED_BLOCKS = 256;
+static constexpr int SHARES3 = 16, SHARES2 = 32;
+
+static size_t tensor_count(int t, int classes, int CH) {
+    switch (t) {
+        case T_C1W: return (size_t)16 * CH * 25;
+        case T_C1B: case T_G1: case T_BE1: case T_RM1: case T_RV1: return 16;
+        case T_C2W: return (size_t)64 * 16 * 25;
+        case T_C2B: case T_G2: case T_BE2: case T_RM2: case T_RV2: return 64;
+        case T_C3W: return (size_t)128 * 64 * 25;
+        case T_C3B: case T_G3: case T_BE3: case T_RM3: case T_RV3: return 128;
+        case T_F1W: return (size_t)100 * 12800;
+        case T_F1B: case T_LNG: case T_LNB: return 100;
+        case T_F2W: return (size_t)classes * 100;
+        case T_F2B: return classes;
+    }
+    return 0;
+}
+
+// index inside the tensor in the kernels' layout of element `i` of the torch layout
+static size_t to_internal(int t, size_t i, int CH) {
+    switch (t) {
+        case T_C1W: { const size_t tap = i % 25, c = (i / 25) % CH, co = i / (25 * (size_t)CH); return (c * 25 + tap) * 16 + co; }
+        case T_C2W: { const size_t tap = i % 25, ci = (i / 25) % 16, co = i / 400; return (tap * 16 + ci) * 64 + co; }
+        case T_C3W: { const size_t tap = i % 25, ci = (i / 25) % 64, co = i / 1600; return (((ci / 32) * 25 + tap) * 32 + ci % 32) * 128 + co; }
+        case T_F1W: { const size_t k = i % 12800, o = i / 12800, c = k / 100, hw = k % 100; return (hw * 128 + c) * 100 + o; }
+        default: return i;
+    }
+}
+
+template <class T>
+static int dev_alloc(Trainer* t, T** p, size_t count) {
+    void* q = nullptr;
+    if (hipMalloc(&q, count * sizeof(T)) != hipSuccess) { set_error("trexhip_trainer_create: out of device memory"); return TREXHIP_E_NOMEM; }
+    t->allocs.push_back(q);
+    *p = static_cast<T*>(q);
+    return TREXHIP_OK;
+}
+
+static void trainer_free(Trainer* t) {
+    if (!t) return;
+    for (void* q : t->allocs) (void)hipFree(q);
+    delete t;
+}
+
+using G2F = ConvGeom<16, 64, 40, 20, 16>;
+using G3F = ConvGeom<64, 128, 20, 10, 32>;     // 10-row bands: 2 blocks per crop (a training batch is 64..128 crops, the chip has 256 CUs; 4-row bands measured no faster)
+using G3B = ConvGeom<128, 64, 20, 10, 32>;
+using G2B = ConvGeom<64, 32, 40, 10, 16>;
+
+template <int C>
+static void launch_colstats(hipStream_t s, const float* d, size_t rows, double* red) {
+    hipLaunchKernelGGL((k_t_colstats<C>), dim3(RED_BLOCKS), dim3(256), 0, s, d, rows, red);
+}
+
+template <int CH>
+static void launch_layer1(Trainer* t, hipStream_t s, const float* x, int n) {
+    hipLaunchKernelGGL((k_t_conv1<CH>), dim3(n * 20), dim3(320), 0, s, x, t->P + t->off[T_C1W], t->P + t->off[T_C1B], t->z1);
+}
+template <int CH>
+static void launch_wgrad1(Trainer* t, hipStream_t s, const float* x, int n) {
+    hipLaunchKernelGGL((k_t_wgrad1<CH>), dim3(n * 10), dim3(512), 0, s, x, t->z1, t->part);
+    const int count = CH * 400;
+    hipLaunchKernelGGL(k_t_reduce, dim3((count + 15) / 16), dim3(256), 0, s, t->part, n * 10, count, t->G + t->off[T_C1W]);
+}
+
+template <int C>
+static void bn_forward(Trainer* t, hipStream_t s, int layer, const float* z, float* a, int n, int S, int tg, int tb, int trm, int trv, const uint8_t* keep,
+                       float scale) {
+    float* mean = t->stat + layer * 512;
+    float* invstd = mean + 128;
+    const size_t rows = (size_t)n * S * S;
+    launch_colstats<C>(s, z, rows, t->red);
+    hipLaunchKernelGGL(k_t_bn_finalize, dim3(1), dim3(1024), 0, s, t->red, RED_BLOCKS, C, (double)rows, t->p.bn_momentum, mean, invstd, t->P + t->off[trm],
+                       t->P + t->off[trv]);
+    const size_t total = (size_t)n * (S / 2) * (S / 2) * (C / 4);
+    hipLaunchKernelGGL((k_t_bn_pool<C>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, z, mean, invstd, t->P + t->off[tg], t->P + t->off[tb], keep, scale,
+                       a, n, S);
+}
+
+// da (pooled gradient) -> dz written over z; gradients of gamma, beta and of the convolution bias
+template <int C>
+static void bn_backward(Trainer* t, hipStream_t s, int layer, const float* da, float* z, int n, int S, int tg, int tb, int tcb, const uint8_t* keep, float scale) {
+    float* mean = t->stat + layer * 512;
+    float* invstd = mean + 128;
+    float* sums = mean + 256;
+    hipLaunchKernelGGL((k_t_pool_bwd_stats<C>), dim3(RED_BLOCKS), dim3(256), 0, s, da, z, mean, invstd, t->P + t->off[tg], t->P + t->off[tb], keep, scale, n, S,
+                       t->red);
+    hipLaunchKernelGGL(k_t_bn_bwd_finalize, dim3(1), dim3(1024), 0, s, t->red, RED_BLOCKS, C, sums, t->G + t->off[tg], t->G + t->off[tb]);
+    const size_t total = (size_t)n * (S / 2) * (S / 2) * (C / 4);
+    const float inv_count = (float)(1.0 / ((double)n * S * S));
+    hipLaunchKernelGGL((k_t_bn_bwd<C>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, da, z, mean, invstd, t->P + t->off[tg], t->P + t->off[tb], keep,
+                       scale, sums, inv_count, n, S);
+    launch_colstats<C>(s, z, (size_t)n * S * S, t->red);
+    hipLaunchKernelGGL(k_t_sum_finalize, dim3(1), dim3(1024), 0, s, t->red, RED_BLOCKS, C, t->G + t->off[tcb]);
+}
+
+static int trainer_step(Trainer* t, const float* x, const int32_t* targets, int n, const uint8_t* d_keep, float* h_loss, int32_t* h_correct) {
+    trexhip_ctx* ctx = t->ctx;
+    TH_CHECK_HIP(hipSetDevice(ctx->p.device));
+    hipStream_t s = ctx->stream;
+    if (!t->attr) {
+        TH_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv5<16, 64, 40, 20, 16, CONV_EPI_RAW, 64>), hipFuncAttributeMaxDynamicSharedMemorySize, G2F::LDS_BYTES));
+        TH_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv5<64, 128, 20, 10, 32, CONV_EPI_RAW, 128>), hipFuncAttributeMaxDynamicSharedMemorySize, G3F::LDS_BYTES));
+        TH_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv5<128, 64, 20, 10, 32, CONV_EPI_RAW, 64>), hipFuncAttributeMaxDynamicSharedMemorySize, G3B::LDS_BYTES));
+        TH_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv5<64, 32, 40, 10, 16, CONV_EPI_RAW, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, G2B::LDS_BYTES));
+        t->attr = true;
+    }
+    const float scale = 1.0f / (1.0f - t->p.dropout);
+    const uint8_t* keep = d_keep;
+    if (!keep) {
+        const size_t count = (size_t)n * 308;
+        hipLaunchKernelGGL(k_t_masks, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, s, t->keep, count, t->p.seed, (uint64_t)t->step, t->p.dropout);
+        keep = t->keep;
+    }
+    const uint8_t *k1 = keep, *k2 = keep + (size_t)n * 16, *k3 = keep + (size_t)n * 80, *k4 = keep + (size_t)n * 208;
+    float* P = t->P;
+    float* G = t->G;
+    const size_t* o = t->off;
+    // ---- forward
+    if (t->CH == 1) launch_layer1<1>(t, s, x, n); else launch_layer1<3>(t, s, x, n);
+    bn_forward<16>(t, s, 0, t->z1, t->a1, n, 80, T_G1, T_BE1, T_RM1, T_RV1, k1, scale);
+    hipLaunchKernelGGL((k_conv5<16, 64, 40, 20, 16, CONV_EPI_RAW, 64>), dim3(n * G2F::BPC), dim3(512), G2F::LDS_BYTES, s, t->a1, P + o[T_C2W], P + o[T_C2B], t->z2);
+    bn_forward<64>(t, s, 1, t->z2, t->a2, n, 40, T_G2, T_BE2, T_RM2, T_RV2, k2, scale);
+    hipLaunchKernelGGL((k_conv5<64, 128, 20, 10, 32, CONV_EPI_RAW, 128>), dim3(n * G3F::BPC), dim3(512), G3F::LDS_BYTES, s, t->a2, P + o[T_C3W], P + o[T_C3B], t->z3);
+    bn_forward<128>(t, s, 2, t->z3, t->a3, n, 20, T_G3, T_BE3, T_RM3, T_RV3, k3, scale);
+    hipLaunchKernelGGL(k_t_fc1, dim3(100, (n + 63) / 64), dim3(256), 0, s, t->a3, P + o[T_F1W], t->hpart, n);
+    hipLaunchKernelGGL(k_t_head, dim3(n), dim3(128), 0, s, t->hpart, n, P + o[T_F1B], P + o[T_LNG], P + o[T_LNB], k4, scale, P + o[T_F2W], P + o[T_F2B], targets,
+                       t->classes, t->xhat, t->hd, t->dl, t->dy, t->dh, t->loss, t->correct);
+    // ---- backward
+    {
+        const int cnt = t->classes * 100 + t->classes + 300;
+        hipLaunchKernelGGL(k_t_head_grads, dim3((cnt + 255) / 256), dim3(256), 0, s, t->dl, t->hd, t->dy, t->xhat, t->dh, n, t->classes, G + o[T_F2W], G + o[T_F2B],
+                           G + o[T_LNG], G + o[T_LNB], G + o[T_F1B]);
+    }
+    hipLaunchKernelGGL(k_t_fc1_wgrad, dim3(100), dim3(256), 0, s, t->a3, t->dh, G + o[T_F1W], n);
+    hipLaunchKernelGGL(k_t_fc1_dgrad, dim3(100, (n + 31) / 32), dim3(256), 0, s, t->dh, P + o[T_F1W], t->da3, n);
+    // block 3
+    bn_backward<128>(t, s, 2, t->da3, t->z3, n, 20, T_G3, T_BE3, T_C3B, k3, scale);
+    {
+        const int shares = n < SHARES3 ? n : SHARES3;
+        hipLaunchKernelGGL((k_t_wgrad<64, 128, 20, 1>), dim3(25, shares), dim3(512), 0, s, t->a2, t->z3, t->part, n);
+        hipLaunchKernelGGL(k_t_wgrad_reduce, dim3((25 * 64 * 128 + 255) / 256), dim3(256), 0, s, t->part, shares, 64, 128, 32, G + o[T_C3W]);
+        hipLaunchKernelGGL(k_t_repack_bwd, dim3((25 * 128 * 64 + 255) / 256), dim3(256), 0, s, P + o[T_C3W], 64, 128, 32, 64, 32, t->wb3);
+        hipLaunchKernelGGL((k_conv5<128, 64, 20, 10, 32, CONV_EPI_RAW, 64>), dim3(n * G3B::BPC), dim3(512), G3B::LDS_BYTES, s, t->z3, t->wb3, (const float*)nullptr, t->da2);
+    }
+    // block 2
+    bn_backward<64>(t, s, 1, t->da2, t->z2, n, 40, T_G2, T_BE2, T_C2B, k2, scale);
+    {
+        const int shares = n < SHARES2 ? n : SHARES2;
+        hipLaunchKernelGGL((k_t_wgrad<16, 64, 40, 2>), dim3(13, shares), dim3(512), 0, s, t->a1, t->z2, t->part, n);
+        hipLaunchKernelGGL(k_t_wgrad_reduce, dim3((25 * 16 * 64 + 255) / 256), dim3(256), 0, s, t->part, shares, 16, 64, 16, G + o[T_C2W]);
+        hipLaunchKernelGGL(k_t_repack_bwd, dim3((25 * 64 * 32 + 255) / 256), dim3(256), 0, s, P + o[T_C2W], 16, 64, 16, 32, 16, t->wb2);
+        hipLaunchKernelGGL((k_conv5<64, 32, 40, 10, 16, CONV_EPI_RAW, 16>), dim3(n * G2B::BPC), dim3(512), G2B::LDS_BYTES, s, t->z2, t->wb2, (const float*)nullptr, t->da1);
+    }
+    // block 1
+    bn_backward<16>(t, s, 0, t->da1, t->z1, n, 80, T_G1, T_BE1, T_C1B, k1, scale);
+    if (t->CH == 1) launch_wgrad1<1>(t, s, x, n); else launch_wgrad1<3>(t, s, x, n);
+    // ---- optimizer
+    t->step += 1;
+    {
+        const double b1 = t->p.beta1, b2 = t->p.beta2;
+        const double bc1 = 1.0 - std::pow(b1, (double)t->step), bc2 = 1.0 - std::pow(b2, (double)t->step);
+        AdamSkip skip;
+        const int bufs[6] = {T_RM1, T_RV1, T_RM2, T_RV2, T_RM3, T_RV3};
+        for (int k = 0; k < 6; ++k) { skip.lo[k] = (uint32_t)o[bufs[k]]; skip.hi[k] = (uint32_t)(o[bufs[k]] + t->cnt[bufs[k]]); }
+        hipLaunchKernelGGL(k_t_adam, dim3((unsigned)((t->total + 255) / 256)), dim3(256), 0, s, P, G, t->M, t->V, (uint32_t)t->total, skip, (float)(1.0 - b1), (float)b2,
+                           (float)(1.0 - b2), (float)((double)t->p.lr / bc1), (float)std::sqrt(bc2), t->p.eps);
+    }
+    hipLaunchKernelGGL(k_t_loss, dim3(1), dim3(64), 0, s, t->loss, t->correct, n, t->out2);
+    TH_CHECK_HIP(hipGetLastError());
+    if (h_loss || h_correct) {
+        float two[2];
+        TH_CHECK_HIP(hipMemcpyAsync(two, t->out2, sizeof(two), hipMemcpyDeviceToHost, s));
+        TH_CHECK_HIP(hipStreamSynchronize(s));
+        if (h_loss) *h_loss = two[0];
+        if (h_correct) *h_correct = (int32_t)two[1];
+    }
+    return TREXHIP_OK;
+}
+
+}  // namespace trexhip
+
+struct trexhip_trainer { trexhip::Trainer* t; };
+
+extern "C" {
+
+using namespace trexhip;
+
+size_t trexhip_weight_blob_bytes(int32_t classes, int32_t channels) {
+    size_t n = 0;
+    for (int k = 0; k < T_COUNT; ++k) n += tensor_count(k, classes, channels);
+    return 32 + 4 * n;
+}
+
+int trexhip_trainer_create(trexhip_ctx* ctx, const void* blob, size_t bytes, const trexhip_train_params* p, trexhip_trainer** out) {
+    if (!ctx || !blob || !p || !out) { set_error("trexhip_trainer_create: null argument"); return TREXHIP_E_INVALID; }
+    *out = nullptr;
+    if (bytes < 32) { set_error("trexhip_trainer_create: blob too small"); return TREXHIP_E_INVALID; }
+    int32_t hdr[8];
+    std::memcpy(hdr, blob, 32);
+    if (hdr[0] != 0x57585254 || hdr[1] != 1) { set_error("trexhip_trainer_create: bad magic/version"); return TREXHIP_E_INVALID; }
+    const int classes = hdr[2], CH = hdr[5];
+    if (hdr[3] != 80 || hdr[4] != 80) { set_error("trexhip_trainer_create: only individual_image_size 80x80 is supported"); return TREXHIP_E_UNSUPPORTED; }
+    if (CH != 1 && CH != 3) { set_error("trexhip_trainer_create: channels must be 1 or 3"); return TREXHIP_E_UNSUPPORTED; }
+    if (classes < 1 || classes > 1024) { set_error("trexhip_trainer_create: classes must be 1..1024"); return TREXHIP_E_INVALID; }
+    if (bytes != trexhip_weight_blob_bytes(classes, CH)) { set_error("trexhip_trainer_create: blob size does not match its header"); return TREXHIP_E_INVALID; }
+    if (p->max_batch < 1 || p->max_batch > 4096) { set_error("trexhip_trainer_create: max_batch must be 1..4096"); return TREXHIP_E_INVALID; }
+    if (!(p->lr > 0.f) || !(p->beta1 >= 0.f && p->beta1 < 1.f) || !(p->beta2 >= 0.f && p->beta2 < 1.f) || !(p->eps > 0.f) ||
+        !(p->dropout >= 0.f && p->dropout < 1.f) || !(p->bn_momentum >= 0.f && p->bn_momentum <= 1.f)) {
+        set_error("trexhip_trainer_create: lr > 0, 0 <= beta < 1, eps > 0, 0 <= dropout < 1, 0 <= bn_momentum <= 1 are required");
+        return TREXHIP_E_INVALID;
+    }
+    if (hipSetDevice(ctx->p.device) != hipSuccess) { set_error("trexhip_trainer_create: hipSetDevice failed"); return TREXHIP_E_DEVICE; }
+    Trainer* t = new Trainer();
+    t->ctx = ctx; t->classes = classes; t->CH = CH; t->max_n = p->max_batch; t->p = *p;
+    size_t at = 0;
+    for (int k = 0; k < T_COUNT; ++k) {
+        t->off[k] = at; t->cnt[k] = tensor_count(k, classes, CH);
+        at += (t->cnt[k] + 63) / 64 * 64;
+    }
+    t->off[T_COUNT] = at; t->total = at;
+    const size_t n = (size_t)t->max_n;
+    int rc = TREXHIP_OK;
+#define TRY(x) do { if (rc == TREXHIP_OK) rc = (x); } while (0)
+    TRY(dev_alloc(t, &t->P, at)); TRY(dev_alloc(t, &t->G, at)); TRY(dev_alloc(t, &t->M, at)); TRY(dev_alloc(t, &t->V, at));
+    TRY(dev_alloc(t, &t->z1, n * 6400 * 16)); TRY(dev_alloc(t, &t->a1, n * 1600 * 16)); TRY(dev_alloc(t, &t->z2, n * 1600 * 64));
+    TRY(dev_alloc(t, &t->a2, n * 400 * 64)); TRY(dev_alloc(t, &t->z3, n * 400 * 128)); TRY(dev_alloc(t, &t->a3, n * 100 * 128));
+    TRY(dev_alloc(t, &t->da3, n * 100 * 128)); TRY(dev_alloc(t, &t->da2, n * 400 * 64)); TRY(dev_alloc(t, &t->da1, n * 1600 * 16));
+    TRY(dev_alloc(t, &t->wb3, (size_t)4 * 25 * 32 * 64)); TRY(dev_alloc(t, &t->wb2, (size_t)2 * 25 * 32 * 32));
+    t->part_floats = std::max(std::max((size_t)SHARES3 * 25 * 64 * 128, (size_t)SHARES2 * 25 * 16 * 64), n * 10 * CH * 400);
+    TRY(dev_alloc(t, &t->part, t->part_floats));
+    TRY(dev_alloc(t, &t->stat, (size_t)3 * 512));
+    TRY(dev_alloc(t, &t->hpart, n * 100 * 100)); TRY(dev_alloc(t, &t->xhat, n * 100)); TRY(dev_alloc(t, &t->hd, n * 100));
+    TRY(dev_alloc(t, &t->dl, n * classes)); TRY(dev_alloc(t, &t->dy, n * 100)); TRY(dev_alloc(t, &t->dh, n * 100));
+    TRY(dev_alloc(t, &t->loss, n)); TRY(dev_alloc(t, &t->correct, n)); TRY(dev_alloc(t, &t->out2, 2));
+    TRY(dev_alloc(t, &t->red, (size_t)RED_BLOCKS * 2 * 128)); TRY(dev_alloc(t, &t->keep, n * 308));
+#undef TRY
+    if (rc != TREXHIP_OK) { trainer_free(t); return rc; }
+    std::vector<float> host(at, 0.f);
+    const float* src = reinterpret_cast<const float*>(static_cast<const char*>(blob) + 32);
+    for (int k = 0; k < T_COUNT; ++k) {
+        for (size_t i = 0; i < t->cnt[k]; ++i) host[t->off[k] + to_internal(k, i, CH)] = src[i];
+        src += t->cnt[k];
+    }
+    bool ok = hipMemcpy(t->P, host.data(), at * 4, hipMemcpyHostToDevice) == hipSuccess;
+    ok = ok && hipMemset(t->G, 0, at * 4) == hipSuccess && hipMemset(t->M, 0, at * 4) == hipSuccess && hipMemset(t->V, 0, at * 4) == hipSuccess;
+    if (!ok) { trainer_free(t); set_error("trexhip_trainer_create: upload failed"); return TREXHIP_E_DEVICE; }
+    trexhip_trainer* h = new trexhip_trainer{t};
+    *out = h;
+    return TREXHIP_OK;
+}
+
+void trexhip_trainer_destroy(trexhip_trainer* h) {
+    if (!h) return;
+    if (h->t) { (void)hipSetDevice(h->t->ctx->p.device); (void)hipStreamSynchronize(h->t->ctx->stream); trainer_free(h->t); }
+    delete h;
+}
+
+int trexhip_trainer_set_lr(trexhip_trainer* h, float lr) {
+    if (!h || !(lr > 0.f)) { set_error("trexhip_trainer_set_lr: a trainer and lr > 0 are required"); return TREXHIP_E_INVALID; }
+    h->t->p.lr = lr;
+    return TREXHIP_OK;
+}
+
+int64_t trexhip_trainer_steps(trexhip_trainer* h) { return h ? h->t->step : -1; }
+
+int trexhip_train_step_device(trexhip_trainer* h, const float* d_inputs, const int32_t* d_targets, int32_t n, const uint8_t* d_keep_masks, float* loss,
+                              int32_t* correct) {
+    if (!h || !d_inputs || !d_targets) { set_error("trexhip_train_step_device: null argument"); return TREXHIP_E_INVALID; }
+    if (n < 1 || n > h->t->max_n) { set_error("trexhip_train_step_device: n must be 1..max_batch"); return TREXHIP_E_INVALID; }
+    return trainer_step(h->t, d_inputs, d_targets, n, d_keep_masks, loss, correct);
+}
+
+int trexhip_trainer_read(trexhip_trainer* h, int32_t tensor, int32_t kind, float* out, size_t count) {
+    if (!h || !out || tensor < 0 || tensor >= T_COUNT || kind < 0 || kind > 3) { set_error("trexhip_trainer_read: bad argument"); return TREXHIP_E_INVALID; }
+    Trainer* t = h->t;
+    if (count != t->cnt[tensor]) { set_error("trexhip_trainer_read: count does not match the tensor"); return TREXHIP_E_INVALID; }
+    TH_CHECK_HIP(hipSetDevice(t->ctx->p.device));
+    TH_CHECK_HIP(hipStreamSynchronize(t->ctx->stream));
+    const float* src = kind == 0 ? t->P : kind == 1 ? t->G : kind == 2 ? t->M : t->V;
+    std::vector<float> tmp(count);
+    TH_CHECK_HIP(hipMemcpy(tmp.data(), src + t->off[tensor], count * 4, hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < count; ++i) out[i] = tmp[to_internal(tensor, i, t->CH)];
+    return TREXHIP_OK;
+}
+
+int trexhip_trainer_export(trexhip_trainer* h, void* blob, size_t capacity, size_t* bytes) {
+    if (!h || !blob) { set_error("trexhip_trainer_export: null argument"); return TREXHIP_E_INVALID; }
+    Trainer* t = h->t;
+    const size_t need = trexhip_weight_blob_bytes(t->classes, t->CH);
+    if (bytes) *bytes = need;
+    if (capacity < need) { set_error("trexhip_trainer_export: buffer too small (trexhip_weight_blob_bytes)"); return TREXHIP_E_CAPACITY; }
+    const int32_t hdr[8] = {0x57585254, 1, t->classes, 80, 80, t->CH, 0, 0};
+    std::memcpy(blob, hdr, 32);
+    float* dst = reinterpret_cast<float*>(static_cast<char*>(blob) + 32);
+    for (int k = 0; k < T_COUNT; ++k) {
+        const int rc = trexhip_trainer_read(h, k, 0, dst, t->cnt[k]);
+        if (rc != TREXHIP_OK) return rc;
+        dst += t->cnt[k];
+    }
+    return TREXHIP_OK;
+}
+
+}  // extern "C"
