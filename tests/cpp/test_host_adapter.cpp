@@ -500,6 +500,25 @@ int main(int argc, char** argv) {
             auto f = net.probabilities(std::move(bad), [](auto&&, auto&&) {});
             bool threw = false; try { f.get(); } catch (const std::exception&) { threw = true; } CHECK(threw);
         }
+        {   // training facade: a few steps on one batch lower its loss; the exported weights load back into the inference path
+            HipVINetwork::Trainer tr(net, blob.data(), blob.size(), 64, 0.001f, 7);
+            std::vector<float> x(n * 6400);
+            std::vector<int32_t> y(n);
+            for (size_t i = 0; i < x.size(); ++i) x[i] = 0.97f * (float)(unsigned char)crops[i];
+            for (size_t i = 0; i < n; ++i) y[i] = (int32_t)(i % (size_t)C);
+            auto first = tr.train_batch(x.data(), y.data(), (int)n);
+            HipVINetwork::Trainer::Result last = first;
+            for (int k = 0; k < 5; ++k) last = tr.train_batch(x.data(), y.data(), (int)n);
+            CHECK(std::isfinite(first.loss) && last.loss < first.loss && tr.steps() == 6 && last.correct >= 0 && last.correct <= (int)n);
+            y[0] = C;                                                                   // label out of range: refused (visual_recognition_torch.py:1112)
+            bool threw = false; try { tr.train_batch(x.data(), y.data(), (int)n); } catch (const std::exception&) { threw = true; } CHECK(threw);
+            threw = false; try { tr.train_batch(x.data(), y.data(), 65); } catch (const std::exception&) { threw = true; } CHECK(threw);   // n > max_batch
+            auto w = tr.weights();
+            CHECK(w.size() == blob.size() && std::memcmp(w.data(), blob.data(), 32) == 0 && std::memcmp(w.data(), blob.data(), w.size()) != 0);
+            tr.apply();
+            CHECK(net.num_classes() == C);
+            std::printf("training facade ok: loss %.4f -> %.4f in 6 steps\n", first.loss, last.loss);
+        }
         std::printf("identity facade ok: %zu crops, %d classes, max |dp| = %.3g\n", n, C, worst);
     }
     std::printf("host adapter ok\n");

@@ -38,4 +38,4 @@ def test_host_adapter_runs(tmp_path):
     out = subprocess.run([exe, str(tmp_path / "w.bin"), str(tmp_path / "c.bin"), str(tmp_path / "p.bin")],
                          capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stdout + out.stderr
-    assert "host adapter ok" in out.stdout and "identity facade ok" in out.stdout
+    assert "host adapter ok" in out.stdout and "identity facade ok" in out.stdout and "training facade ok" in out.stdout

@@ -727,6 +727,9 @@ struct Trainer {
     int32_t* correct = nullptr;
     double* red = nullptr;
     uint8_t* keep = nullptr;
+    float* x_stage = nullptr;            // host-pointer entry point: inputs, targets and injected masks staged here
+    int32_t* y_stage = nullptr;
+    uint8_t* keep_stage = nullptr;
     size_t part_floats = 0;
     bool attr = false;
     std::vector<void*> allocs;
@@ -969,6 +972,7 @@ int trexhip_trainer_create(trexhip_ctx* ctx, const void* blob, size_t bytes, con
     TRY(dev_alloc(t, &t->dl, n * classes)); TRY(dev_alloc(t, &t->dy, n * 100)); TRY(dev_alloc(t, &t->dh, n * 100));
     TRY(dev_alloc(t, &t->loss, n)); TRY(dev_alloc(t, &t->correct, n)); TRY(dev_alloc(t, &t->out2, 2));
     TRY(dev_alloc(t, &t->red, (size_t)RED_BLOCKS * 2 * 128)); TRY(dev_alloc(t, &t->keep, n * 308));
+    TRY(dev_alloc(t, &t->x_stage, n * 6400 * CH)); TRY(dev_alloc(t, &t->y_stage, n)); TRY(dev_alloc(t, &t->keep_stage, n * 308));
 #undef TRY
     if (rc != TREXHIP_OK) { trainer_free(t); return rc; }
     std::vector<float> host(at, 0.f);
@@ -1004,6 +1008,23 @@ int trexhip_train_step_device(trexhip_trainer* h, const float* d_inputs, const i
     if (!h || !d_inputs || !d_targets) { set_error("trexhip_train_step_device: null argument"); return TREXHIP_E_INVALID; }
     if (n < 1 || n > h->t->max_n) { set_error("trexhip_train_step_device: n must be 1..max_batch"); return TREXHIP_E_INVALID; }
     return trainer_step(h->t, d_inputs, d_targets, n, d_keep_masks, loss, correct);
+}
+
+int trexhip_train_step(trexhip_trainer* h, const float* inputs, const int32_t* targets, int32_t n, const uint8_t* keep_masks, float* loss, int32_t* correct) {
+    if (!h || !inputs || !targets) { set_error("trexhip_train_step: null argument"); return TREXHIP_E_INVALID; }
+    Trainer* t = h->t;
+    if (n < 1 || n > t->max_n) { set_error("trexhip_train_step: n must be 1..max_batch"); return TREXHIP_E_INVALID; }
+    for (int i = 0; i < n; ++i)
+        if (targets[i] < 0 || targets[i] >= t->classes) { set_error("trexhip_train_step: target class out of range"); return TREXHIP_E_INVALID; }   // visual_recognition_torch.py:1112
+    TH_CHECK_HIP(hipSetDevice(t->ctx->p.device));
+    hipStream_t s = t->ctx->stream;
+    TH_CHECK_HIP(hipMemcpyAsync(t->x_stage, inputs, (size_t)n * 6400 * t->CH * sizeof(float), hipMemcpyHostToDevice, s));
+    TH_CHECK_HIP(hipMemcpyAsync(t->y_stage, targets, (size_t)n * sizeof(int32_t), hipMemcpyHostToDevice, s));
+    if (keep_masks) TH_CHECK_HIP(hipMemcpyAsync(t->keep_stage, keep_masks, (size_t)n * 308, hipMemcpyHostToDevice, s));
+    const int rc = trainer_step(t, t->x_stage, t->y_stage, n, keep_masks ? t->keep_stage : nullptr, loss, correct);
+    if (rc != TREXHIP_OK) return rc;
+    TH_CHECK_HIP(hipStreamSynchronize(s));        // the caller's buffers may go away
+    return TREXHIP_OK;
 }
 
 int trexhip_trainer_read(trexhip_trainer* h, int32_t tensor, int32_t kind, float* out, size_t count) {

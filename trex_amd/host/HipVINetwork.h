@@ -11,6 +11,7 @@
 #else
 #include "trex_types.h"
 #endif
+#include <cstring>
 #include <functional>
 #include <future>
 #include <map>
@@ -109,6 +110,43 @@ struct HipVINetwork {
         for (auto& kv : averages) for (float& v : kv.second.values) v /= kv.second.samples;
         return averages;
     }
+
+    // ---- training -------------------------------------------------------------------------------------------
+    // VINetwork::train (VisualIdentification.cpp:496-806) hands TrainingData to Python's start_learning(), whose batch loop
+    // (visual_recognition_torch.py:1100-1158) is what a Trainer step replaces; epochs, validation, the learning-rate schedule and
+    // early stopping stay with the caller, as they are host logic in the reference too.
+    struct Trainer {
+        // weights: the same blob as load_weights (the reference starts from the network's current state_dict)
+        Trainer(HipVINetwork& net, const void* blob, size_t bytes, int max_batch, float learning_rate = 0.001f, uint64_t seed = 0) : _net(net) {
+            trexhip_train_params p{};
+            p.max_batch = max_batch; p.lr = learning_rate; p.beta1 = 0.9f; p.beta2 = 0.999f; p.eps = 1e-8f; p.bn_momentum = 0.1f; p.dropout = 0.05f; p.seed = seed;
+            check(trexhip_trainer_create(net._ctx, blob, bytes, &p, &_t));
+            std::memcpy(&_classes, static_cast<const char*>(blob) + 8, 4);
+            std::memcpy(&_channels, static_cast<const char*>(blob) + 20, 4);
+        }
+        ~Trainer() { trexhip_trainer_destroy(_t); }
+        Trainer(const Trainer&) = delete;
+        struct Result { float loss; int correct; };
+        // one optimizer step on a batch as the data loader yields it: NHWC float32 in [0, 255], class indices
+        Result train_batch(const float* images, const int32_t* labels, int n) {
+            Result r{};
+            check(trexhip_train_step(_t, images, labels, n, nullptr, &r.loss, &r.correct));
+            return r;
+        }
+        void set_learning_rate(float lr) { check(trexhip_trainer_set_lr(_t, lr)); }          // ReduceLROnPlateau lives with the caller
+        int64_t steps() const { return trexhip_trainer_steps(_t); }
+        std::vector<uint8_t> weights() const {                                                // what the reference serialises back (state_dict)
+            std::vector<uint8_t> blob(trexhip_weight_blob_bytes(_classes, _channels));
+            size_t got = 0;
+            check(trexhip_trainer_export(_t, blob.data(), blob.size(), &got));
+            return blob;
+        }
+        void apply() { const auto w = weights(); _net.load_weights(w.data(), w.size()); }     // the inference path continues with the trained weights
+    private:
+        HipVINetwork& _net;
+        trexhip_trainer* _t = nullptr;
+        int32_t _classes = 0, _channels = 1;
+    };
 
 private:
     trexhip_ctx* _ctx = nullptr;
