@@ -148,6 +148,7 @@ struct trexhip_ctx {
     // tuning knobs (env TREXHIP_ROWS_ORDER / TREXHIP_ROWS_BLOCKS override the defaults)
     int tune_rows_order = 0;
     int tune_rows_blocks = 8192;
+    int tune_rows_k = 0;                // frames per wave of k_rows32b (TREXHIP_ROWS_K; 0 = default 8)
     bool tune_rows_blocks_set = false;  // TREXHIP_ROWS_BLOCKS given: no automatic grid for the wide pixel pass
     int tune_conv_geom = 0;             // dev only: alternative conv tilings (TREXHIP_CONV_GEOM)
     // hipFuncSetAttribute is per device: one process may drive several devices through several contexts

@@ -107,6 +107,42 @@ __device__ __forceinline__ uint32_t exact4(uint32_t a, uint32_t b, const SegCfg&
     return m;
 }
 
+// The common settings (background subtraction on, no image_invert, no threshold_maximum, no zero-background rule, threshold >= 1)
+// as compile-time modes: the generic exact4 computes both difference rules and both bounds for every byte and selects (12 VALU
+// instructions per pixel; it is executed by the whole wave as soon as one lane's word could pass), the specialised one needs 5.
+//   MODE 1: |bg - px| >= tmin (track_absolute_difference)     MODE 2: bg - px >= tmin
+template <int MODE>
+__device__ __forceinline__ uint32_t exact4_fast(uint32_t a, uint32_t b, int tmin) {
+    uint32_t m = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int px = (a >> (8 * i)) & 0xff;
+        const int bg = (b >> (8 * i)) & 0xff;
+        const int d = bg - px;
+        // |d| >= t  <=>  d is outside [-(t - 1), t - 1]  <=>  (unsigned)(d + t - 1) > 2 (t - 1): one add and one compare
+        if (MODE == 1) m |= (uint32_t)((uint32_t)(d + tmin - 1) > (uint32_t)(2 * (tmin - 1))) << i;
+        else m |= (uint32_t)(d >= tmin) << i;
+    }
+    return m;
+}
+
+template <int MODE>
+__device__ __forceinline__ uint32_t mask16_fast(uint4 a, uint4 b, const SegCfg& c) {
+    const uint32_t s0 = __builtin_amdgcn_sad_u8(a.x, b.x, 0u);
+    const uint32_t s1 = __builtin_amdgcn_sad_u8(a.y, b.y, 0u);
+    const uint32_t s2 = __builtin_amdgcn_sad_u8(a.z, b.z, 0u);
+    const uint32_t s3 = __builtin_amdgcn_sad_u8(a.w, b.w, 0u);
+    const uint32_t t = (uint32_t)c.tmin;
+    uint32_t m = 0;
+    if (max(max(s0, s1), max(s2, s3)) >= t) {
+        if (s0 >= t) m |= exact4_fast<MODE>(a.x, b.x, c.tmin);
+        if (s1 >= t) m |= exact4_fast<MODE>(a.y, b.y, c.tmin) << 4;
+        if (s2 >= t) m |= exact4_fast<MODE>(a.z, b.z, c.tmin) << 8;
+        if (s3 >= t) m |= exact4_fast<MODE>(a.w, b.w, c.tmin) << 12;
+    }
+    return m;
+}
+
 // 16 pixels of one lane -> 16-bit foreground mask.  A 4-pixel word is only evaluated exactly when
 // the sum of its absolute differences (one v_sad_u8) could reach the threshold.
 __device__ __forceinline__ uint32_t mask16(uint4 a, uint4 b, const SegCfg& c) {
@@ -288,7 +324,91 @@ __global__ __launch_bounds__(256) void k_rows(const uint8_t* __restrict__ frames
 // The same pass with 32 pixels per lane (two 16-byte loads per array): one wave covers 2048 pixels per chunk, so a 2048-wide row is
 // ONE chunk -- one ballot / scan / extraction round per row instead of two.  Aligned frames of a width that is a multiple of 32, no
 // morphology mask; everything else takes k_rows above.
+// masks of one row-task: 32 pixels per lane per 2048-pixel chunk
+template <int NCH, int MODE>
+__device__ __forceinline__ bool rows32_masks(const uint4 (&a)[NCH][2], const uint4 (&b)[NCH][2], const SegCfg& c, const int lane, const int W,
+                                             const int order, uint32_t (&m)[NCH]) {
+    bool any = false;
+#pragma unroll
+    for (int ch = 0; ch < NCH; ++ch) {
+        const int x = ch * 2048 + lane * 32;
+        uint32_t mm = 0;
+        if (x < W) {
+#ifdef TREXHIP_DEV_KNOBS
+            if (order & 4096) mm = ((a[ch][0].x ^ b[ch][0].x ^ a[ch][1].y ^ b[ch][1].w) == 0x12345u);      // profiling aid: stream only
+            else
+#endif
+            if constexpr (MODE == 0) mm = mask16(a[ch][0], b[ch][0], c) | (mask16(a[ch][1], b[ch][1], c) << 16);
+            else mm = mask16_fast<MODE>(a[ch][0], b[ch][0], c) | (mask16_fast<MODE>(a[ch][1], b[ch][1], c) << 16);
+        }
+        m[ch] = mm;
+        any |= mm != 0;
+    }
+#ifdef TREXHIP_DEV_KNOBS
+    if (order & 8192) any = false;                                                                            // profiling aid: no run extraction
+#endif
+    return any;
+}
+
+// run extraction of one row-task from its masks: row_cnt / row_off and the (x0, x1) pairs in the row's slots (or the overflow area)
 template <int NCH>
+__device__ __forceinline__ void rows32_emit(const uint32_t (&m)[NCH], const bool any, const SegCfg& c, const uint32_t f, const uint32_t y, const int lane,
+                                            const int W, uint32_t* __restrict__ frame_ctr, uint32_t* __restrict__ row_cnt,
+                                            uint32_t* __restrict__ row_off, uint32_t* __restrict__ tmp_runs) {
+    const size_t ri = (size_t)f * c.H + y;
+    if (!__any(any)) {
+        if (lane == 0) { row_cnt[ri] = 0; row_off[ri] = 0; }
+        return;
+    }
+    uint32_t st[NCH], en[NCH], pre[NCH];
+    uint32_t carry = 0, tot = 0;
+#pragma unroll
+    for (int ch = 0; ch < NCH; ++ch) {
+        const uint32_t mm = m[ch];
+        if (NCH > 1 && __ballot(mm != 0) == 0 && carry == 0) { st[ch] = 0; en[ch] = 0; pre[ch] = tot; continue; }
+        uint32_t up = __shfl_up(mm >> 31, 1);
+        if (lane == 0) up = carry;
+        const uint32_t prevmask = (mm << 1) | (up & 1u);
+        const uint32_t s = mm & ~prevmask;
+        const uint32_t e = ~mm & prevmask;
+        const uint32_t v = __popc(s) | (__popc(e) << 16);
+        const uint32_t incl = wave_incl_scan(v);
+        st[ch] = s; en[ch] = e; pre[ch] = tot + incl - v;
+        tot += __shfl(incl, 63);
+        carry = __shfl(mm >> 31, 63) & 1u;
+    }
+    const uint32_t n_starts = tot & 0xffffu;
+    uint32_t base = y * (uint32_t)ROW_SLOT;
+    if (n_starts > (uint32_t)ROW_SLOT) {
+        if (lane == 0) base = (uint32_t)c.H * ROW_SLOT + atomicAdd(&frame_ctr[f * CTR_STRIDE], n_starts);
+        base = __shfl(base, 0);
+    }
+    if (lane == 0) { row_cnt[ri] = n_starts; row_off[ri] = base; }
+    uint16_t* out = reinterpret_cast<uint16_t*>(tmp_runs + (size_t)f * c.T);
+    const uint32_t R = (uint32_t)c.T;
+#pragma unroll
+    for (int ch = 0; ch < NCH; ++ch) {
+        const int xb = ch * 2048 + lane * 32;
+        uint32_t s = st[ch], e = en[ch];
+        uint32_t ks = base + (pre[ch] & 0xffffu), ke = base + (pre[ch] >> 16);
+        while (s) {
+            const int j = __ffs(s) - 1; s &= s - 1;
+            if (ks < R) out[2 * ks] = (uint16_t)(xb + j);
+            ++ks;
+        }
+        while (e) {
+            const int j = __ffs(e) - 1; e &= e - 1;
+            if (ke < R) out[2 * ke + 1] = (uint16_t)(xb + j - 1);
+            ++ke;
+        }
+    }
+    if (carry && lane == 0) {
+        const uint32_t ke = base + (tot >> 16);
+        if (ke < R) out[2 * ke + 1] = (uint16_t)(W - 1);
+    }
+}
+
+template <int NCH, int MODE = 0>
 __global__ __launch_bounds__(256) void k_rows32(const uint8_t* __restrict__ frames,
                                                 const uint8_t* __restrict__ bg, const SegCfg c, const int order,
                                                 uint32_t* __restrict__ frame_ctr,
@@ -330,68 +450,51 @@ __global__ __launch_bounds__(256) void k_rows32(const uint8_t* __restrict__ fram
         const uint32_t y = frame_fastest ? cur_hi : cur_lo;
         advance(cur_lo, cur_hi);
         uint32_t m[NCH];
-        bool any = false;
+        const bool any = rows32_masks<NCH, MODE>(a, b, c, lane, W, order, m);
+        if (task + nwave < ntask) issue(cur_lo, cur_hi);
+        rows32_emit<NCH>(m, any, c, f, y, lane, W, frame_ctr, row_cnt, row_off, tmp_runs);
+    }
+}
+
+// The wide pass with the background row held in registers: a wave takes row y of K consecutive frames (K divides the number of
+// frames of the launch), so the 2 KB background row is loaded once per K frame rows instead of once per frame row -- half the load
+// instructions and half the L2 -> CU traffic of the kernel above.  Wave w: row w / (B / K), frames (w % (B / K)) * K ...
+template <int NCH, int MODE = 0>
+__global__ __launch_bounds__(256) void k_rows32b(const uint8_t* __restrict__ frames,
+                                                 const uint8_t* __restrict__ bg, const SegCfg c, const int order, const int K,
+                                                 uint32_t* __restrict__ frame_ctr,
+                                                 uint32_t* __restrict__ row_cnt,
+                                                 uint32_t* __restrict__ row_off,
+                                                 uint32_t* __restrict__ tmp_runs, const uint32_t f0) {
+    const int lane = lane_id();
+    const int W = c.W;
+    const uint32_t groups = (uint32_t)c.B / (uint32_t)K;
+    const uint32_t wid = blockIdx.x * 4u + (threadIdx.x >> 6);
+    if (wid >= groups * (uint32_t)c.H) return;
+    const uint32_t y = wid / groups, fb = f0 + (wid - y * groups) * (uint32_t)K;
+    uint4 a[NCH][2], b[NCH][2];
+    const uint8_t* bp = bg + (size_t)y * W;
+    auto issue = [&](uint32_t f) {
+        const uint8_t* fp = frames + ((size_t)f * c.H + y) * W;
 #pragma unroll
         for (int ch = 0; ch < NCH; ++ch) {
             const int x = ch * 2048 + lane * 32;
-            uint32_t mm = 0;
-            if (x < W) mm = mask16(a[ch][0], b[ch][0], c) | (mask16(a[ch][1], b[ch][1], c) << 16);
-            m[ch] = mm;
-            any |= mm != 0;
+            if (x < W) { a[ch][0] = *reinterpret_cast<const uint4*>(fp + x); a[ch][1] = *reinterpret_cast<const uint4*>(fp + x + 16); }
+            else a[ch][0] = a[ch][1] = make_uint4(0, 0, 0, 0);
         }
-        if (task + nwave < ntask) issue(cur_lo, cur_hi);
-
-        const size_t ri = (size_t)f * c.H + y;
-        if (!__any(any)) {
-            if (lane == 0) { row_cnt[ri] = 0; row_off[ri] = 0; }
-            continue;
-        }
-        uint32_t st[NCH], en[NCH], pre[NCH];
-        uint32_t carry = 0, tot = 0;
+    };
 #pragma unroll
-        for (int ch = 0; ch < NCH; ++ch) {
-            const uint32_t mm = m[ch];
-            if (NCH > 1 && __ballot(mm != 0) == 0 && carry == 0) { st[ch] = 0; en[ch] = 0; pre[ch] = tot; continue; }
-            uint32_t up = __shfl_up(mm >> 31, 1);
-            if (lane == 0) up = carry;
-            const uint32_t prevmask = (mm << 1) | (up & 1u);
-            const uint32_t s = mm & ~prevmask;
-            const uint32_t e = ~mm & prevmask;
-            const uint32_t v = __popc(s) | (__popc(e) << 16);
-            const uint32_t incl = wave_incl_scan(v);
-            st[ch] = s; en[ch] = e; pre[ch] = tot + incl - v;
-            tot += __shfl(incl, 63);
-            carry = __shfl(mm >> 31, 63) & 1u;
-        }
-        const uint32_t n_starts = tot & 0xffffu;
-        uint32_t base = y * (uint32_t)ROW_SLOT;
-        if (n_starts > (uint32_t)ROW_SLOT) {
-            if (lane == 0) base = (uint32_t)c.H * ROW_SLOT + atomicAdd(&frame_ctr[f * CTR_STRIDE], n_starts);
-            base = __shfl(base, 0);
-        }
-        if (lane == 0) { row_cnt[ri] = n_starts; row_off[ri] = base; }
-        uint16_t* out = reinterpret_cast<uint16_t*>(tmp_runs + (size_t)f * c.T);
-        const uint32_t R = (uint32_t)c.T;
-#pragma unroll
-        for (int ch = 0; ch < NCH; ++ch) {
-            const int xb = ch * 2048 + lane * 32;
-            uint32_t s = st[ch], e = en[ch];
-            uint32_t ks = base + (pre[ch] & 0xffffu), ke = base + (pre[ch] >> 16);
-            while (s) {
-                const int j = __ffs(s) - 1; s &= s - 1;
-                if (ks < R) out[2 * ks] = (uint16_t)(xb + j);
-                ++ks;
-            }
-            while (e) {
-                const int j = __ffs(e) - 1; e &= e - 1;
-                if (ke < R) out[2 * ke + 1] = (uint16_t)(xb + j - 1);
-                ++ke;
-            }
-        }
-        if (carry && lane == 0) {
-            const uint32_t ke = base + (tot >> 16);
-            if (ke < R) out[2 * ke + 1] = (uint16_t)(W - 1);
-        }
+    for (int ch = 0; ch < NCH; ++ch) {
+        const int x = ch * 2048 + lane * 32;
+        if (x < W) { b[ch][0] = *reinterpret_cast<const uint4*>(bp + x); b[ch][1] = *reinterpret_cast<const uint4*>(bp + x + 16); }
+        else b[ch][0] = b[ch][1] = make_uint4(0, 0, 0, 0);
+    }
+    issue(fb);
+    for (int k = 0; k < K; ++k) {
+        uint32_t m[NCH];
+        const bool any = rows32_masks<NCH, MODE>(a, b, c, lane, W, order, m);
+        if (k + 1 < K) issue(fb + k + 1);
+        rows32_emit<NCH>(m, any, c, fb + k, y, lane, W, frame_ctr, row_cnt, row_off, tmp_runs);
     }
 }
 
@@ -1292,12 +1395,25 @@ int launch_segment(trexhip_ctx* ctx, const uint8_t* d_frames, int n) {
         if (wide && !ctx->tune_rows_blocks_set) { cap = wantg / 4; if (cap < 2048u) cap = 2048u; }
         const dim3 grid_g(wantg < cap ? wantg : cap);
         if (wide) {
+            // compile-time modes of the common settings (see exact4_fast); TREXHIP_ROWS_ORDER bit 11 keeps the generic kernel
+            int mode = 0;
+            if (cg.enable_diff && !cg.invert && !cg.zero_bg && cg.tmax >= 255 && cg.tmin >= 1 && !(ctx->tune_rows_order & 2048)) mode = cg.absdiff ? 1 : 2;
+            // background row in registers for K frames (k_rows32b) when K divides the launch's frames; TREXHIP_ROWS_ORDER bit 2 keeps k_rows32
+            int K = 0;
+            if (!(ctx->tune_rows_order & 4)) { const int want = ctx->tune_rows_k > 0 ? ctx->tune_rows_k : 8; for (int k = want; k >= 2; --k) if (cg.B % k == 0) { K = k; break; } }
+            const dim3 grid_b(K ? (unsigned)(((size_t)H * (cg.B / K) + 3) / 4) : 1u);
+            // (k_rows32b is instantiated for one 2048-pixel chunk only: hipcc 7.2 crashes in Machine Copy Propagation on the 2-chunk form)
+#define TH_ROWS32(NCH_, MODE_) do { if (K && NCH_ == 1) hipLaunchKernelGGL((k_rows32b<1, MODE_>), grid_b, dim3(256), 0, s, d_frames, ctx->d_bg, cg, ctx->tune_rows_order, K, ctx->d_ctr, ctx->d_row_cnt, ctx->d_row_off, ctx->d_tmp_runs, (uint32_t)f0); \
+                                    else hipLaunchKernelGGL((k_rows32<NCH_, MODE_>), grid_g, dim3(256), 0, s, d_frames, ctx->d_bg, cg, ctx->tune_rows_order, ctx->d_ctr, ctx->d_row_cnt, ctx->d_row_off, ctx->d_tmp_runs, (uint32_t)f0); } while (0)
+#define TH_ROWS32_M(NCH_) do { if (mode == 1) TH_ROWS32(NCH_, 1); else if (mode == 2) TH_ROWS32(NCH_, 2); else TH_ROWS32(NCH_, 0); } while (0)
             switch (nch32) {
-                case 1: hipLaunchKernelGGL((k_rows32<1>), grid_g, dim3(256), 0, s, d_frames, ctx->d_bg, cg, ctx->tune_rows_order, ctx->d_ctr, ctx->d_row_cnt, ctx->d_row_off, ctx->d_tmp_runs, (uint32_t)f0); break;
-                case 2: hipLaunchKernelGGL((k_rows32<2>), grid_g, dim3(256), 0, s, d_frames, ctx->d_bg, cg, ctx->tune_rows_order, ctx->d_ctr, ctx->d_row_cnt, ctx->d_row_off, ctx->d_tmp_runs, (uint32_t)f0); break;
-                case 3: hipLaunchKernelGGL((k_rows32<3>), grid_g, dim3(256), 0, s, d_frames, ctx->d_bg, cg, ctx->tune_rows_order, ctx->d_ctr, ctx->d_row_cnt, ctx->d_row_off, ctx->d_tmp_runs, (uint32_t)f0); break;
-                default: hipLaunchKernelGGL((k_rows32<4>), grid_g, dim3(256), 0, s, d_frames, ctx->d_bg, cg, ctx->tune_rows_order, ctx->d_ctr, ctx->d_row_cnt, ctx->d_row_off, ctx->d_tmp_runs, (uint32_t)f0); break;
+                case 1: TH_ROWS32_M(1); break;
+                case 2: TH_ROWS32_M(2); break;
+                case 3: TH_ROWS32_M(3); break;
+                default: TH_ROWS32_M(4); break;
             }
+#undef TH_ROWS32_M
+#undef TH_ROWS32
         } else
         if (aligned) launch_rows<true>(nch, grid_g, s, d_frames, ctx->d_bg, cg, ctx->tune_rows_order, ctx->d_ctr, ctx->d_row_cnt, ctx->d_row_off, ctx->d_tmp_runs, bits, (uint32_t)f0);
         else         launch_rows<false>(nch, grid_g, s, d_frames, ctx->d_bg, cg, ctx->tune_rows_order, ctx->d_ctr, ctx->d_row_cnt, ctx->d_row_off, ctx->d_tmp_runs, bits, (uint32_t)f0);
