@@ -136,6 +136,34 @@ def test_one_step_at_vinetwork_batch_size_equals_oracle_and_is_deterministic():
     seg.close()
 
 
+@pytest.mark.parametrize("n,classes,ch", [(1, 2, 1), (67, 257, 3), (33, 1024, 1)])
+def test_ragged_batches_and_class_counts_equal_oracle(n, classes, ch):
+    # a last batch of an epoch is whatever is left (DataLoader drop_last=False, visual_recognition_torch.py:1394-1400); a single sample is legal
+    # for BatchNorm2d because the statistics run over the pixels as well
+    seed, lr = 900 + n, 1e-3
+    state = weights.synthetic_state(classes, seed, channels=ch)
+    x, y = weights.synthetic_train_batch(n, seed + 1, classes, ch)
+    rng = np.random.default_rng(seed)
+    masks = {"d1": rng.random((n, 16)) >= 0.05, "d2": rng.random((n, 64)) >= 0.05, "d3": rng.random((n, 128)) >= 0.05, "d4": rng.random((n, 100)) >= 0.05}
+    adam = tro.new_adam_state(state)
+    new, loss_ref, correct_ref, grads = tro.train_step(state, adam, x, y, masks, lr, threads=16)
+    seg = make_seg()
+    tr = capi.Trainer(seg, weights.pack_blob(state, classes, ch), max_batch=max(n, 4), lr=lr)
+    loss, correct = step(tr, x, y, masks)
+    assert abs(loss - loss_ref) <= 5e-5 * max(1.0, abs(loss_ref)) and correct == correct_ref
+    g = read_all(tr, classes, ch, 1)
+    p = read_all(tr, classes, ch, 0)
+    for k in tro.TRAINABLE:
+        if k in CONV_BIAS:
+            continue
+        tol = GRAD_RTOL * float(np.abs(grads[k]).max()) + 1e-9
+        assert np.abs(g[k] - grads[k]).max() <= tol, (k, float(np.abs(g[k] - grads[k]).max()), tol)
+    for k in tro.BUFFERS:
+        assert np.abs(p[k] - new[k]).max() <= 1e-4 * max(1.0, np.abs(new[k]).max()), k
+    tr.close()
+    seg.close()
+
+
 def test_library_drawn_masks_and_argument_checks():
     classes, ch, n = 10, 3, 9
     state = weights.synthetic_state(classes, 5, channels=ch)
