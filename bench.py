@@ -246,7 +246,7 @@ def main():
         pass_traffic = rows_traffic + sum(x for x in others if x)
     # The primary fraction is by the HBM bytes the counters saw (the background is re-read from L2 / MALL, not from HBM); the fraction by
     # the contract's algorithmic bytes (frame + background per pixel) is kept beside it and can pass 1 for that reason.
-    seg_roof = {"kernel": "k_rows32b (pixel pass: subtract / threshold / run extraction; background row in registers for 8 frames)", "bound": "hbm", "peak": 8000.0, "unit": "GB/s",
+    seg_roof = {"kernel": "k_rows32b (pixel pass: subtract / threshold / run extraction; background row in registers for 8 frames, compile-time threshold modes)", "bound": "hbm", "peak": 8000.0, "unit": "GB/s",
                 "achieved": (rows_traffic / rows_s / 1e9) if (rows_traffic and rows_s) else (seg_bytes / rows_s / 1e9 if rows_s else 0.0),
                 "frac": (rows_traffic / rows_s / 8e12) if (rows_traffic and rows_s) else (seg_bytes / rows_s / 8e12 if rows_s else 0.0),
                 "frac_basis": "measured HBM traffic per launch (PMC)" if rows_traffic else "algorithmic bytes (no PMC summary for this workload)",
@@ -259,7 +259,7 @@ def main():
                 "whole_detect_pass_frac_algorithmic_bytes": seg_bytes / segall_s / 8e12 if segall_s else None,
                 "whole_detect_pass_traffic": pass_traffic,
                 "timing": "HIP events on the kernel stream; 5 serial detect passes after the timed region when lanes are pipelined (in-flight the stage shares the GPU with the identity network)",
-                "limiter": "read-only HBM streaming: the same kernel with the masks replaced by a trivial compare takes 187-200 us (5.4-5.7 TB/s; torch's fastest read-only reduction over the same 1.07 GB: 183 us = 5.85 TB/s, tools/read_bw.py), the masks add 8-15 us, run extraction 23-36 us (tools/rows_exp.sh, dev build). Not VALU-bound: halving the masks' VALU instructions (compile-time threshold modes) changed the time by < 3 %. k_ccl_lds / k_gather are latency chains of one workgroup per frame / half a wave per blob",
+                "limiter": "read-only HBM streaming + VALU: the same kernel with the masks replaced by a trivial compare takes 187-200 us (torch's fastest read-only reduction over the same 1.07 GB: 183 us = 5.85 TB/s, tools/read_bw.py); exact masks and run extraction add the rest. A/B on one box (tools/rows_exp.sh): k_rows32 generic 250 us, + compile-time threshold modes 242, background row in registers for 8 frames (k_rows32b) 235, both 220. k_ccl_lds / k_gather are latency chains of one workgroup per frame / half a wave per blob",
                 "frac_of_measured_copy_bw": ((rows_traffic or seg_bytes) / rows_s / 6.29e12) if rows_s else None}
     if host_in:
         bytes_step = float(B * W * H * (4 if bgra_in else 1))

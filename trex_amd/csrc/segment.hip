@@ -107,10 +107,10 @@ __device__ __forceinline__ uint32_t exact4(uint32_t a, uint32_t b, const SegCfg&
     return m;
 }
 
-// The common settings (background subtraction on, no image_invert, no threshold_maximum, no zero-background rule, threshold >= 1)
-// as compile-time modes: the generic exact4 computes both difference rules and both bounds for every byte and selects (12 VALU
+// The common settings (background subtraction on, no image_invert, no threshold_maximum, threshold >= 1)
+// as compile-time modes (zero_is_background as a mode bit): the generic exact4 computes both difference rules and both bounds for every byte and selects (12 VALU
 // instructions per pixel; it is executed by the whole wave as soon as one lane's word could pass), the specialised one needs 5.
-//   MODE 1: |bg - px| >= tmin (track_absolute_difference)     MODE 2: bg - px >= tmin
+//   MODE & 3 = 1: |bg - px| >= tmin (track_absolute_difference), 2: bg - px >= tmin;  MODE & 4: and px != 0 (zero_is_background)
 template <int MODE>
 __device__ __forceinline__ uint32_t exact4_fast(uint32_t a, uint32_t b, int tmin) {
     uint32_t m = 0;
@@ -120,8 +120,9 @@ __device__ __forceinline__ uint32_t exact4_fast(uint32_t a, uint32_t b, int tmin
         const int bg = (b >> (8 * i)) & 0xff;
         const int d = bg - px;
         // |d| >= t  <=>  d is outside [-(t - 1), t - 1]  <=>  (unsigned)(d + t - 1) > 2 (t - 1): one add and one compare
-        if (MODE == 1) m |= (uint32_t)((uint32_t)(d + tmin - 1) > (uint32_t)(2 * (tmin - 1))) << i;
-        else m |= (uint32_t)(d >= tmin) << i;
+        bool pass = (MODE & 3) == 1 ? (uint32_t)(d + tmin - 1) > (uint32_t)(2 * (tmin - 1)) : d >= tmin;
+        if (MODE & 4) pass = pass && px != 0;                 // zero_is_background
+        m |= (uint32_t)pass << i;
     }
     return m;
 }
@@ -1397,7 +1398,7 @@ int launch_segment(trexhip_ctx* ctx, const uint8_t* d_frames, int n) {
         if (wide) {
             // compile-time modes of the common settings (see exact4_fast); TREXHIP_ROWS_ORDER bit 11 keeps the generic kernel
             int mode = 0;
-            if (cg.enable_diff && !cg.invert && !cg.zero_bg && cg.tmax >= 255 && cg.tmin >= 1 && !(ctx->tune_rows_order & 2048)) mode = cg.absdiff ? 1 : 2;
+            if (cg.enable_diff && !cg.invert && cg.tmax >= 255 && cg.tmin >= 1 && !(ctx->tune_rows_order & 2048)) mode = (cg.absdiff ? 1 : 2) | (cg.zero_bg ? 4 : 0);
             // background row in registers for K frames (k_rows32b) when K divides the launch's frames; TREXHIP_ROWS_ORDER bit 2 keeps k_rows32
             int K = 0;
             if (!(ctx->tune_rows_order & 4)) { const int want = ctx->tune_rows_k > 0 ? ctx->tune_rows_k : 8; for (int k = want; k >= 2; --k) if (cg.B % k == 0) { K = k; break; } }
@@ -1405,7 +1406,8 @@ int launch_segment(trexhip_ctx* ctx, const uint8_t* d_frames, int n) {
             // (k_rows32b is instantiated for one 2048-pixel chunk only: hipcc 7.2 crashes in Machine Copy Propagation on the 2-chunk form)
 #define TH_ROWS32(NCH_, MODE_) do { if (K && NCH_ == 1) hipLaunchKernelGGL((k_rows32b<1, MODE_>), grid_b, dim3(256), 0, s, d_frames, ctx->d_bg, cg, ctx->tune_rows_order, K, ctx->d_ctr, ctx->d_row_cnt, ctx->d_row_off, ctx->d_tmp_runs, (uint32_t)f0); \
                                     else hipLaunchKernelGGL((k_rows32<NCH_, MODE_>), grid_g, dim3(256), 0, s, d_frames, ctx->d_bg, cg, ctx->tune_rows_order, ctx->d_ctr, ctx->d_row_cnt, ctx->d_row_off, ctx->d_tmp_runs, (uint32_t)f0); } while (0)
-#define TH_ROWS32_M(NCH_) do { if (mode == 1) TH_ROWS32(NCH_, 1); else if (mode == 2) TH_ROWS32(NCH_, 2); else TH_ROWS32(NCH_, 0); } while (0)
+#define TH_ROWS32_M(NCH_) do { switch (mode) { case 1: TH_ROWS32(NCH_, 1); break; case 2: TH_ROWS32(NCH_, 2); break; case 5: TH_ROWS32(NCH_, 5); break; \
+                                               case 6: TH_ROWS32(NCH_, 6); break; default: TH_ROWS32(NCH_, 0); } } while (0)
             switch (nch32) {
                 case 1: TH_ROWS32_M(1); break;
                 case 2: TH_ROWS32_M(2); break;
