@@ -18,6 +18,7 @@
 //   k_head      LayerNorm + ReLU + fc2 + softmax, one wave per crop
 #include "internal.h"
 #include "conv_f32.h"
+#include <algorithm>
 #include <cmath>
 #include <cstring>
 #include <vector>
@@ -319,7 +320,7 @@ __global__ __launch_bounds__(512) void k_conv5_split(const float* __restrict__ i
                                                      const uint4* __restrict__ wp /*[CI/16][25][NP][2][CO] x 16 B*/,
                                                      const float* __restrict__ bias, float* __restrict__ out,
                                                      const float out_scale, uint32_t* __restrict__ overflow,
-                                                     const uint32_t* __restrict__ guard) {
+                                                     const uint32_t* __restrict__ guard, const int n_blocks) {
     if (guard && *guard == 0u) return;            // re-run pass: only when the fp16 pass flagged an overflow
     using K = SplitK<KIND>;
     using frag = typename K::frag;
@@ -331,7 +332,11 @@ __global__ __launch_bounds__(512) void k_conv5_split(const float* __restrict__ i
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int j = lane & 31, h = lane >> 5;
     const int n = wave % G::NT, mg = wave / G::NT;
-    const int crop = blockIdx.x / G::BPC, row0 = (blockIdx.x % G::BPC) * ROWS;
+    // grid-stride over the (crop, row band) blocks: the guarded re-run is launched with a small grid, so that the usual case (flag
+    // clear, every workgroup returns at once) costs a few microseconds instead of the launch of n * BPC empty workgroups
+    for (int blk = blockIdx.x; blk < n_blocks; blk += gridDim.x) {
+    if (blk != (int)blockIdx.x) __syncthreads();                      // the previous block's readers are done with the LDS buffers
+    const int crop = blk / G::BPC, row0 = (blk % G::BPC) * ROWS;
     constexpr int WR = S / 2;
 
     int aoff[G::TPW];
@@ -434,6 +439,7 @@ __global__ __launch_bounds__(512) void k_conv5_split(const float* __restrict__ i
             const int wy = row0 / 2 + wi / WR, wx = wi % WR;
             oc[((size_t)wy * WR + wx) * CO + co] = fmaxf(v * out_scale + bz, 0.f);     // out_scale undoes the weight scaling (fp16 pieces)
         }
+    }
     }
 }
 
@@ -1907,8 +1913,11 @@ TH_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv5_wino1<64
     stage_begin(ctx, TREXHIP_STAGE_CONV2);
 #define LAUNCH_SPLIT(CI_, CO_, S_, ROWS_, KIND_, NT_, in_, w_, b_, out_, sc_, guard_) LAUNCH_SPLITC(CI_, CO_, S_, ROWS_, KIND_, NT_, 16, in_, w_, b_, out_, sc_, guard_)
 #define LAUNCH_SPLITC(CI_, CO_, S_, ROWS_, KIND_, NT_, CIC_, in_, w_, b_, out_, sc_, guard_)                                                    \
-    hipLaunchKernelGGL((k_conv5_split<CI_, CO_, S_, ROWS_, KIND_, NT_, CIC_>), dim3(n * (ConvGeomB<CI_, CO_, S_, ROWS_, SplitK<KIND_>::NP, CIC_>::BPC)), \
-                       dim3(512), (ConvGeomB<CI_, CO_, S_, ROWS_, SplitK<KIND_>::NP, CIC_>::LDS_BYTES), s, in_, w_, b_, out_, sc_, net->d_ovf, guard_)
+    hipLaunchKernelGGL((k_conv5_split<CI_, CO_, S_, ROWS_, KIND_, NT_, CIC_>),                                                                      \
+                       dim3((guard_) ? std::min(n * (ConvGeomB<CI_, CO_, S_, ROWS_, SplitK<KIND_>::NP, CIC_>::BPC), 4 * ctx->n_cus)                  \
+                                     : n * (ConvGeomB<CI_, CO_, S_, ROWS_, SplitK<KIND_>::NP, CIC_>::BPC)),                                          \
+                       dim3(512), (ConvGeomB<CI_, CO_, S_, ROWS_, SplitK<KIND_>::NP, CIC_>::LDS_BYTES), s, in_, w_, b_, out_, sc_, net->d_ovf, guard_, \
+                       n * (ConvGeomB<CI_, CO_, S_, ROWS_, SplitK<KIND_>::NP, CIC_>::BPC))
     if (mode == TREXHIP_CNN_FP32)
         hipLaunchKernelGGL((k_conv5<16, 64, 40, 20, 16>), dim3(n * G2::BPC), dim3(512), G2::LDS_BYTES, s, net->act1, net->w2, net->b2, net->act2);
     else if (mode == TREXHIP_CNN_BF16X6) LAUNCH_SPLIT(16, 64, 40, 10, 0, 6, net->act1, net->w2s, net->b2, net->act2, 1.0f, (const uint32_t*)nullptr);
