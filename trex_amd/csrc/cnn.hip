@@ -1056,7 +1056,7 @@ struct WinoGeom1 {
     static_assert(LDS_BYTES + 64 <= 160 * 1024, "LDS");
 };
 
-template <int CO, int S>
+template <int CO, int S, int DBG = 0>      // DBG (dev builds): 1 no staging, 2 no epilogue, 4 no weight loads, 8 no A reads
 __global__ __launch_bounds__(256) void k_conv5_wino1(const float* __restrict__ in /*[N][S][S][16]*/, const uint4* __restrict__ wp /*[5][8][2][2][CO] x 16 B*/,
                                                      const float* __restrict__ bias, float* __restrict__ out, const float out_scale,
                                                      uint32_t* __restrict__ overflow, const int n_crops, uint32_t* __restrict__ pass_ctr) {
@@ -1170,7 +1170,7 @@ __global__ __launch_bounds__(256) void k_conv5_wino1(const float* __restrict__ i
     int qmin, nrows;
     wino_pass_rows<G, S>(pass, total_tiles, qmin, nrows);
 #pragma unroll
-    for (int it = 0; it < G::NIT; ++it) {                                // first pass: position group 0
+    for (int it = 0; it < ((DBG & 1) ? 0 : G::NIT); ++it) {                                // first pass: position group 0
         W1_L(it, qmin, nrows);
 #pragma unroll
         for (int st = 0; st < 4; ++st) W1_C(st, it, 0, ldsb);
@@ -1223,7 +1223,7 @@ __global__ __launch_bounds__(256) void k_conv5_wino1(const float* __restrict__ i
             for (int tl = 0; tl < 20; ++tl) {
                 const int tau = g * 20 + tl;
                 const int cur = tl & 1, nxt = cur ^ 1;
-                if (tl + 1 < 20) {
+                if (!(DBG & 8) && tl + 1 < 20) {
                     const uint8_t* an = pbase + ((tl + 1) % 4) * G::PS;
 #pragma unroll
                     for (int m = 0; m < TPW; ++m) {
@@ -1231,12 +1231,12 @@ __global__ __launch_bounds__(256) void k_conv5_wino1(const float* __restrict__ i
                         af[nxt][m][1] = *reinterpret_cast<const uint4*>(an + aoff[m][(tl + 1) / 4] + G::PLANE);
                     }
                 }
-                {
+                if (!(DBG & 4)) {
                     const int wt = W1_BOFF((tau + BD) % 40);
                     bq[(tau + BD) % 4][0] = buf_load16(wrs, boff, wt);
                     bq[(tau + BD) % 4][1] = buf_load16(wrs, boff, wt + 2 * CO * 16);
                 }
-                W1_SLOT(tl, g ^ 1, sqmin, snrows, nbase);
+                if (!(DBG & 1)) W1_SLOT(tl, g ^ 1, sqmin, snrows, nbase);
                 const int p = W1_POS(tau);
                 const f16x8 b1 = __builtin_bit_cast(f16x8, bq[tau % 4][0]);
                 const f16x8 b2 = __builtin_bit_cast(f16x8, bq[tau % 4][1]);
@@ -1259,8 +1259,14 @@ __global__ __launch_bounds__(256) void k_conv5_wino1(const float* __restrict__ i
             }
             __syncthreads();
         }
+        if (DBG & 2) {
 #pragma unroll
-        for (int m = 0; m < TPW; ++m) {
+            for (int m = 0; m < TPW; ++m)
+#pragma unroll
+                for (int p = 0; p < 8; ++p) asm volatile("" :: "a"(acc[m][p]));
+        }
+#pragma unroll
+        for (int m = 0; m < ((DBG & 2) ? 0 : TPW); ++m) {
             f32x16 y0, y1, y2, y3;
             {
                 const f32x16 e1 = acc[m][1] + acc[m][2], o1 = acc[m][1] - acc[m][2];
@@ -1888,7 +1894,12 @@ int net_forward(trexhip_ctx* ctx, const uint8_t* d_crops, int n, float* d_probs,
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (ConvGeomS<16, 64, 40, 8, 4>::LDS_BYTES)));
         TH_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv5_stream<64, 128, 20, 20, 8, true>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (ConvGeomS<64, 128, 20, 20, 8>::LDS_BYTES)));
-TH_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv5_wino1<64, 40>), hipFuncAttributeMaxDynamicSharedMemorySize, (WinoGeom1<64, 40>::LDS_BYTES)));
+#define W1A(D_) TH_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv5_wino1<64, 40, D_>), hipFuncAttributeMaxDynamicSharedMemorySize, (WinoGeom1<64, 40>::LDS_BYTES)))
+        W1A(0);
+#ifdef TREXHIP_DEV_KNOBS
+        W1A(1); W1A(2); W1A(3); W1A(7); W1A(15); W1A(4); W1A(8);
+#endif
+#undef W1A
 #define WA(D_) TH_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv5_wino<64, 128, 20, 2, D_>), hipFuncAttributeMaxDynamicSharedMemorySize, (WinoGeom<64, 128, 20, 2>::LDS_BYTES)))
         WA(0);
 #ifdef TREXHIP_DEV_KNOBS
@@ -1928,8 +1939,17 @@ TH_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv5_wino1<64
         // output transform per pass are not amortised by enough matrix work), so it stays opt-in (TREXHIP_CONV_GEOM bit 9); the persistent pass counter is d_ovf[2]
         using GW = WinoGeom1<64, 40>;
         const int n_pass = (n * GW::TPC + GW::MB - 1) / GW::MB;
-        hipLaunchKernelGGL((k_conv5_wino1<64, 40>), dim3(n_pass < ctx->n_cus ? n_pass : ctx->n_cus), dim3(256), GW::LDS_BYTES, s,
-                           net->act1, net->w2w, net->b2, net->act2, net->inv2w, net->d_ovf, n, net->d_ovf + 2);
+#define W1K(D_) hipLaunchKernelGGL((k_conv5_wino1<64, 40, D_>), dim3(n_pass < ctx->n_cus ? n_pass : ctx->n_cus), dim3(256), GW::LDS_BYTES, s, \
+                           net->act1, net->w2w, net->b2, net->act2, net->inv2w, net->d_ovf, n, net->d_ovf + 2)
+#ifdef TREXHIP_DEV_KNOBS
+        switch ((ctx->tune_conv_geom >> 12) & 15) {
+            case 1: W1K(1); break; case 2: W1K(2); break; case 3: W1K(3); break; case 7: W1K(7); break; case 15: W1K(15); break;
+            case 4: W1K(4); break; case 8: W1K(8); break; default: W1K(0);
+        }
+#else
+        W1K(0);
+#endif
+#undef W1K
     }
     else if (!(ctx->tune_conv_geom & (4 | 64)))   // 8 output rows per workgroup: 320 pixels = exactly 10 M-tiles, 3 workgroups per CU (1.15 ms; 10 rows: 1.31 ms)
         hipLaunchKernelGGL((k_conv5_stream<16, 64, 40, 8, 4>), dim3(n * (ConvGeomS<16, 64, 40, 8, 4>::BPC)), dim3(256),
