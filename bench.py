@@ -265,11 +265,14 @@ def main():
         bytes_step = float(B * W * H * (4 if bgra_in else 1))
         up = [ln.seg.profile_read(capi.STAGE_UPLOAD_COPY) + ln.seg.profile_read(capi.STAGE_UPLOAD_DMA) for ln in lanes]
         cms = sum(u[0] for u in up); cn = sum(u[1] for u in up); dms = sum(u[2] for u in up); dn = sum(u[3] for u in up)
-        out["host_input"] = {"bytes_per_step": bytes_step, "pcie_GB_per_s": bytes_step * world * args.steps / dt / 1e9, "pcie_peak_GB_per_s": 63.0,
-                             "frac_of_pcie_peak": bytes_step * world * args.steps / dt / 63e9,
+        host_reduced = bgra_in and not rgb          # gray pixel arrays: the upload threads reduce BGRA tiles to gray while they copy (hostcvt.cpp)
+        pcie_step = float(B * W * H) if host_reduced else bytes_step
+        out["host_input"] = {"tile_bytes_per_step": bytes_step, "tile_GB_per_s": bytes_step * world * args.steps / dt / 1e9,
+                             "pcie_bytes_per_step": pcie_step, "pcie_GB_per_s": pcie_step * world * args.steps / dt / 1e9, "pcie_peak_GB_per_s": 63.0,
+                             "frac_of_pcie_peak": pcie_step * world * args.steps / dt / 63e9,
                              "host_copy_ms_per_frame": cms / cn if cn else None, "dma_ms_per_frame": dms / dn if dn else None,
-                             "dma_GB_per_s": (bytes_step / B) / (dms / dn * 1e-3) / 1e9 if dn and dms else None,
-                             "note": "pageable tiles -> pinned ring (host threads) -> HBM (async DMA per frame); the two legs overlap, the segment kernels and the identity network of the previous batch overlap both"}
+                             "dma_GB_per_s": (pcie_step / B) / (dms / dn * 1e-3) / 1e9 if dn and dms else None,
+                             "note": "pageable tiles -> pinned ring (host threads" + (", which reduce the BGRA tiles to gray on the way: a quarter of the tile bytes cross PCIe" if host_reduced else "") + ") -> HBM (async DMA per chunk of frames); the two legs overlap, the segment kernels and the identity network of the previous batch overlap both"}
     if with_cnn:
         c3_s = avg_s("CONV3")
         fl = FLOP_PER_CROP_CONV3 * n_blobs

@@ -74,7 +74,11 @@ typedef struct trexhip_params {
      *   equalize_histogram, correct_luminance      grabber/misc/default_config.cpp:121-129
      *   use_adaptive_threshold (+ adaptive_threshold_scale)                         core/default_config.cpp:1161-1162 */
     int32_t image_adjust, blur_difference, equalize_histogram, correct_luminance, use_adaptive_threshold;
-    int32_t reserved_[2];
+    /* host tiles of a colour format with a gray / binary pixel_encoding (trexhip_segment_color): 0 (default) = the upload threads reduce
+     * the tile to gray while they copy it into the pinned ring (a quarter / a third of the bytes cross PCIe; same fixed-point formula),
+     * 1 = the colour tile is uploaded and reduced on the device.  The colour encodings always upload the colour tile. */
+    int32_t device_color_reduce;
+    int32_t reserved_[1];
 } trexhip_params;
 enum { TREXHIP_ENC_GRAY = 0, TREXHIP_ENC_R3G3B2 = 1, TREXHIP_ENC_RGB8 = 2 };   /* order of cmn::meta_encoding_t */
 

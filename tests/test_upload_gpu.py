@@ -31,15 +31,50 @@ def test_host_paths_equal_device_paths(n):
         col[..., 1] = fr // 2                                           # not a gray image: cvtColor matters
         dc = torch.from_numpy(col).cuda()
         seg.segment_color_device(dc.data_ptr(), n, ch); want_c = tables(seg)
-        seg.segment_color_host([c for c in col]); assert tables(seg) == want_c
+        seg.segment_color_host([c for c in col]); assert tables(seg) == want_c      # default: reduced to gray by the upload threads (hostcvt.cpp)
+        for cc in (0, 1, ch - 1):                                                   # color_channel picks (BackgroundSubtraction.cpp:163-170)
+            seg.segment_color_device(dc.data_ptr(), n, ch, cc); want_cc = tables(seg)
+            seg.segment_color_host([c for c in col], cc); assert tables(seg) == want_cc
     seg.close()
+    # the same tiles uploaded in colour and reduced on the device (device_color_reduce = 1): identical tables
+    seg = capi.Segmenter(capi.default_params(W, H, max_batch=n, device_color_reduce=1))
+    seg.set_background(bg)
+    col = np.repeat(fr[..., None], 4, axis=3); col[..., 1] = fr // 2
+    dc = torch.from_numpy(col).cuda()
+    seg.segment_color_device(dc.data_ptr(), n, 4); want_c = tables(seg)
+    seg.segment_color_host([c for c in col]); assert tables(seg) == want_c
+    seg.close()
+
+
+def test_host_side_gray_reduction_cuts_the_transfer():
+    # BGRA tiles with a gray pixel encoding: the upload threads write one byte per pixel into the pinned ring, a quarter of the bytes
+    # cross PCIe -- per frame the DMA leg must take well under half of what the colour upload takes
+    B = 32
+    frames, bg = synth.batch_torch("C4", B, "cuda")
+    H, W = frames.shape[1:]
+    col = [np.ascontiguousarray(np.repeat(frames[i].cpu().numpy()[..., None], 4, 2)) for i in range(B)]
+    dma = {}
+    for dev in (0, 1):
+        seg = capi.Segmenter(capi.default_params(W, H, max_batch=B, max_blobs=400, max_pixels=1 << 18, max_runs=32768, device_color_reduce=dev))
+        seg.set_background(bg)
+        seg.segment_color_host(col); seg.synchronize()
+        res = tables(seg)
+        seg.profile_reset()
+        seg.segment_color_host(col); seg.synchronize()
+        ms, cnt = seg.profile_read(capi.STAGE_UPLOAD_DMA)
+        assert cnt == B
+        dma[dev] = (ms / cnt, res)
+        seg.close()
+    assert dma[0][1] == dma[1][1]
+    print(f"DMA per frame: host-reduced {dma[0][0]:.3f} ms, colour upload {dma[1][0]:.3f} ms")
+    assert dma[0][0] < 0.5 * dma[1][0]
 
 
 def test_upload_legs_overlap():
     B = 48
     frames, bg = synth.batch_torch("C4", B, "cuda")
     H, W = frames.shape[1:]
-    seg = capi.Segmenter(capi.default_params(W, H, max_batch=B, max_blobs=400, max_pixels=1 << 18, max_runs=32768))
+    seg = capi.Segmenter(capi.default_params(W, H, max_batch=B, max_blobs=400, max_pixels=1 << 18, max_runs=32768, device_color_reduce=1))
     seg.set_background(bg)
     col = [np.ascontiguousarray(np.repeat(frames[i].cpu().numpy()[..., None], 4, 2)) for i in range(B)]      # pageable BGRA tiles
     seg.segment_color_host(col); seg.synchronize()                      # allocations, thread pool

@@ -44,7 +44,7 @@ class Params(C.Structure):
         ("pixel_encoding", C.c_int32),
         # not implemented: any non-zero value makes trexhip_create return TREXHIP_E_UNSUPPORTED
         ("image_adjust", C.c_int32), ("blur_difference", C.c_int32), ("equalize_histogram", C.c_int32), ("correct_luminance", C.c_int32),
-        ("use_adaptive_threshold", C.c_int32), ("reserved_", C.c_int32 * 2),
+        ("use_adaptive_threshold", C.c_int32), ("device_color_reduce", C.c_int32), ("reserved_", C.c_int32 * 1),
     ]
 
 

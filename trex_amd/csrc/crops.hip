@@ -298,12 +298,20 @@ extern "C" int trexhip_segment_color(trexhip_ctx* ctx, const uint8_t* const* fra
     if (!ctx->d_staging) {
         TH_CHECK_HIP(hipMalloc(reinterpret_cast<void**>(&ctx->d_staging), (size_t)ctx->p.max_batch * W * H + 16));
     }
-    if (!ctx->d_color) TH_CHECK_HIP(hipMalloc(reinterpret_cast<void**>(&ctx->d_color), (size_t)ctx->p.max_batch * W * H * 4 + 16));
     for (int i = 0; i < n; ++i)
         if (!frames[i]) { set_error("trexhip_segment_color: null frame pointer"); return TREXHIP_E_INVALID; }
+    const size_t row = W * channels, fpx = W * H;
+    if (ctx->p.pixel_encoding == TREXHIP_ENC_GRAY && !ctx->p.device_color_reduce) {
+        // gray / binary pixel arrays never look at the colour tile again: the upload threads reduce it while they copy (hostcvt.cpp,
+        // the same fixed-point formula as k_to_gray), so a quarter / a third of the bytes cross PCIe
+        int rc = upload_frames(ctx, frames, n, H, row, (size_t)stride, ctx->d_staging, nullptr, channels, color_channel);
+        if (rc) return rc;
+        ctx->d_color_src = nullptr; ctx->color_ch = 0;
+        return launch_segment(ctx, ctx->d_staging, n);
+    }
+    if (!ctx->d_color) TH_CHECK_HIP(hipMalloc(reinterpret_cast<void**>(&ctx->d_color), (size_t)ctx->p.max_batch * W * H * 4 + 16));
     // frame by frame: pageable tile -> pinned ring slot (host threads) -> HBM (DMA on the copy stream) -> cv::cvtColor on the compute
     // stream as soon as the frame has landed; the next frame's staging and DMA run meanwhile (upload.hip)
-    const size_t row = W * channels, fpx = W * H;
     int rc = upload_frames(ctx, frames, n, H, row, (size_t)stride, ctx->d_color, [&](int i0, int cnt) {
         return launch_to_gray(ctx, ctx->d_color + (size_t)i0 * H * row, ctx->d_staging + (size_t)i0 * fpx, fpx * (size_t)cnt, channels, color_channel);
     });

@@ -179,5 +179,5 @@ int launch_rethreshold(trexhip_ctx* ctx, int thr, int method, const double* rang
 int launch_to_gray(trexhip_ctx* ctx, const uint8_t* d_color, uint8_t* d_gray, size_t npix, int channels, int color_channel);
 void upload_free(trexhip_ctx* ctx);
 int upload_frames(trexhip_ctx* ctx, const uint8_t* const* frames, int n, size_t rows, size_t row_bytes, size_t stride, uint8_t* d_dst,
-                  const std::function<int(int, int)>& after_chunk);
+                  const std::function<int(int, int)>& after_chunk, int reduce_channels = 0, int color_channel = -1);
 }

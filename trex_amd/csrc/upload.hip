@@ -93,7 +93,7 @@ static int upload_prepare(trexhip_ctx* ctx, size_t frame_bytes) {   // frame_byt
     if (!u.pool) {
         int n = 0;
         if (const char* e = std::getenv("TREXHIP_UPLOAD_THREADS")) n = std::atoi(e);
-        if (n <= 0) { const unsigned hc = std::thread::hardware_concurrency(); n = hc >= 16 ? 6 : (hc >= 8 ? 4 : (hc >= 4 ? 2 : 1)); }
+        if (n <= 0) { const unsigned hc = std::thread::hardware_concurrency(); n = hc >= 64 ? 16 : (hc >= 32 ? 10 : (hc >= 16 ? 6 : (hc >= 8 ? 4 : (hc >= 4 ? 2 : 1)))); }   // 6 -> 16 threads on the 256-thread box: 4.5 k -> 8 k BGRA frames/s
         u.pool = new CopyPool(n - 1);
     }
     return TREXHIP_OK;
@@ -103,9 +103,14 @@ static int upload_prepare(trexhip_ctx* ctx, size_t frame_bytes) {   // frame_byt
 // about UP_CHUNK_BYTES (one DMA and one event pair per chunk: small transfers do not reach the link rate).  after_chunk(first, count)
 // is called once the chunk's DMA is enqueued, with ctx->stream already ordered behind it (the caller launches the device work of
 // those frames there).
+extern "C" void trexhip_host_reduce_row(const uint8_t* src, uint8_t* dst, size_t npix, int channels, int color_channel);   // hostcvt.cpp
+
+// reduce_channels = 3 / 4: the upload threads reduce the colour rows to gray (or pick color_channel) on their way into the pinned ring
+// (hostcvt.cpp): row_bytes is then the source row, what lands in d_dst is rows x (row_bytes / reduce_channels) bytes per frame.
 int upload_frames(trexhip_ctx* ctx, const uint8_t* const* frames, int n, size_t rows, size_t row_bytes, size_t stride, uint8_t* d_dst,
-                  const std::function<int(int, int)>& after_chunk) {
-    const size_t frame_bytes = rows * row_bytes;
+                  const std::function<int(int, int)>& after_chunk, int reduce_channels, int color_channel) {
+    const size_t out_row = reduce_channels ? row_bytes / (size_t)reduce_channels : row_bytes;
+    const size_t frame_bytes = rows * out_row;
     const int per = (int)std::max<size_t>(1, UP_CHUNK_BYTES / frame_bytes);
     int rc = upload_prepare(ctx, frame_bytes * (size_t)per);
     if (rc) return rc;
@@ -134,8 +139,12 @@ int upload_frames(trexhip_ctx* ctx, const uint8_t* const* frames, int n, size_t 
                 const size_t f = r / rows, y = r - f * rows;
                 const size_t run = std::min(rows - y, r1 - r);       // rows of this frame in my range
                 const uint8_t* src = frames[i0 + (int)f] + y * stride;
-                uint8_t* dst = slot + f * frame_bytes + y * row_bytes;
-                if (stride == row_bytes) std::memcpy(dst, src, run * row_bytes);
+                uint8_t* dst = slot + f * frame_bytes + y * out_row;
+                if (reduce_channels) {
+                    if (stride == row_bytes) trexhip_host_reduce_row(src, dst, run * out_row, reduce_channels, color_channel);
+                    else for (size_t k = 0; k < run; ++k) trexhip_host_reduce_row(src + k * stride, dst + k * out_row, out_row, reduce_channels, color_channel);
+                }
+                else if (stride == row_bytes) std::memcpy(dst, src, run * row_bytes);
                 else for (size_t k = 0; k < run; ++k) std::memcpy(dst + k * row_bytes, src + k * stride, row_bytes);
                 r += run;
             }

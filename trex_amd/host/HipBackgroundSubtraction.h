@@ -37,6 +37,9 @@ struct HipBackgroundSubtraction {
         std::vector<std::pair<double, double>> detect_size_filter;
         cmn::meta_encoding_t meta_encoding = cmn::meta_encoding_t::gray;
         int device = 0, max_batch = 8;
+        // gray / binary encodings: colour tiles are reduced to gray by the upload threads on their way into the pinned ring (a quarter of
+        // the bytes cross PCIe); true = upload the colour tile and reduce on the device (trexhip_params::device_color_reduce)
+        bool device_color_reduce = false;
         // capacities per frame (0 = scaled with the frame size in init()): raw horizontal lines, kept blobs, kept foreground pixels.
         // A frame that exceeds one fails alone (its promise gets the exception); the other frames of the batch are delivered.
         int max_runs = 0, max_blobs = 0, max_pixels = 0;
@@ -56,7 +59,7 @@ struct HipBackgroundSubtraction {
         d.settings = s;
         trexhip_params p;
         trexhip_default_params(&p, (int32_t)width, (int32_t)height);
-        p.device = s.device; p.max_batch = s.max_batch;
+        p.device = s.device; p.max_batch = s.max_batch; p.device_color_reduce = s.device_color_reduce;
         p.threshold = s.detect_threshold; p.threshold_maximum = s.threshold_maximum;
         p.absolute_difference = s.detect_threshold_is_absolute; p.enable_difference = s.enable_difference;
         p.image_invert = s.image_invert; p.cm_per_pixel = s.cm_per_pixel;
