@@ -526,12 +526,12 @@ __global__ __launch_bounds__(256) void k_t_fc1_dgrad(const float* __restrict__ d
 // convolution weight gradient on fp32 MFMA: dW[tap][ci][co] = sum over (crop, y, x) a[crop][y+ky-2][x+kx-2][ci] * dz[crop][y][x][co].
 // One 32x32x2 MFMA step contracts over two neighbouring pixels: A = activations (rows = ci, of TP taps when CI < 32), B = dz; both
 // operands come straight from L2 (a lane reads 4 bytes of a 128-byte channel run).  Block = one tap (pair) x one share of the
-// crops; its 8 waves take every 8th pixel pair, their sums are added in LDS: part[share][tap][ci][co].
+// crops (as many shares as fill the 256 CUs once); its 12 waves take every 12th pixel pair, their sums are added in LDS: part[share][tap][ci][co].
 // ------------------------------------------------------------------------------------------------
 template <int CI, int CO, int S, int TP>
-__global__ __launch_bounds__(512) void k_t_wgrad(const float* __restrict__ a /*[n][S][S][CI]*/, const float* __restrict__ dz /*[n][S][S][CO]*/,
+__global__ __launch_bounds__(768) void k_t_wgrad(const float* __restrict__ a /*[n][S][S][CI]*/, const float* __restrict__ dz /*[n][S][S][CO]*/,
                                                  float* __restrict__ part, int n) {
-    constexpr int MI = CI * TP, MT = MI / 32, NT = CO / 32, PP = S * S / 2, WAVES = 8;
+    constexpr int MI = CI * TP, MT = MI / 32, NT = CO / 32, PP = S * S / 2, WAVES = 12;    // 128 accumulator + ~25 other registers: 3 waves per SIMD
     static_assert(MI % 32 == 0 && CO % 32 == 0, "tile shapes");
     __shared__ float sum[MT * NT * 16 * 64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 31, h = lane >> 5;
@@ -570,7 +570,7 @@ __global__ __launch_bounds__(512) void k_t_wgrad(const float* __restrict__ a /*[
                 for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[mt], bv[nt], acc[mt][nt], 0, 0, 0);
         }
     }
-    // the 8 waves' sums are added in wave order through LDS: one partial per block, the same bits every run
+    // the waves' sums are added in wave order through LDS: one partial per block, the same bits every run
     for (int w = 0; w < WAVES; ++w) {
         if (wave == w) {
 #pragma unroll
@@ -586,7 +586,7 @@ __global__ __launch_bounds__(512) void k_t_wgrad(const float* __restrict__ a /*[
         __syncthreads();
     }
     float* pp = part + (size_t)share * 25 * CI * CO;
-    for (int e = tid; e < MT * NT * 16 * 64; e += 512) {
+    for (int e = tid; e < MT * NT * 16 * 64; e += WAVES * 64) {
         const int ln = e & 63, r = (e >> 6) & 15, t = e >> 10, nt = t % NT, mt = t / NT;
         const int mi = mt * 32 + 8 * (r / 4) + 4 * (ln >> 5) + (r % 4);     // accumulator r of lane (j, h) is row 8 (r / 4) + 4 h + r % 4
         const int tap = blockIdx.x * TP + mi / CI, c = mi % CI;
@@ -736,7 +736,7 @@ struct Trainer {
 };
 
 static constexpr int RED_BLOCKS = 256;
-static constexpr int SHARES3 = 16, SHARES2 = 32;
+static constexpr int SHARES3 = 10, SHARES2 = 19;     // 25 taps x 10 = 250 and 13 tap pairs x 19 = 247 workgroups: one round on 256 CUs
 
 static size_t tensor_count(int t, int classes, int CH) {
     switch (t) {
@@ -876,7 +876,7 @@ static int trainer_step(Trainer* t, const float* x, const int32_t* targets, int 
     bn_backward<128>(t, s, 2, t->da3, t->z3, n, 20, T_G3, T_BE3, T_C3B, k3, scale);
     {
         const int shares = n < SHARES3 ? n : SHARES3;
-        hipLaunchKernelGGL((k_t_wgrad<64, 128, 20, 1>), dim3(25, shares), dim3(512), 0, s, t->a2, t->z3, t->part, n);
+        hipLaunchKernelGGL((k_t_wgrad<64, 128, 20, 1>), dim3(25, shares), dim3(768), 0, s, t->a2, t->z3, t->part, n);
         hipLaunchKernelGGL(k_t_wgrad_reduce, dim3((25 * 64 * 128 + 255) / 256), dim3(256), 0, s, t->part, shares, 64, 128, 32, G + o[T_C3W]);
         hipLaunchKernelGGL(k_t_repack_bwd, dim3((25 * 128 * 64 + 255) / 256), dim3(256), 0, s, P + o[T_C3W], 64, 128, 32, 64, 32, t->wb3);
         hipLaunchKernelGGL((k_conv5<128, 64, 20, 10, 32, CONV_EPI_RAW, 64>), dim3(n * G3B::BPC), dim3(512), G3B::LDS_BYTES, s, t->z3, t->wb3, (const float*)nullptr, t->da2);
@@ -885,7 +885,7 @@ static int trainer_step(Trainer* t, const float* x, const int32_t* targets, int 
     bn_backward<64>(t, s, 1, t->da2, t->z2, n, 40, T_G2, T_BE2, T_C2B, k2, scale);
     {
         const int shares = n < SHARES2 ? n : SHARES2;
-        hipLaunchKernelGGL((k_t_wgrad<16, 64, 40, 2>), dim3(13, shares), dim3(512), 0, s, t->a1, t->z2, t->part, n);
+        hipLaunchKernelGGL((k_t_wgrad<16, 64, 40, 2>), dim3(13, shares), dim3(768), 0, s, t->a1, t->z2, t->part, n);
         hipLaunchKernelGGL(k_t_wgrad_reduce, dim3((25 * 16 * 64 + 255) / 256), dim3(256), 0, s, t->part, shares, 16, 64, 16, G + o[T_C2W]);
         hipLaunchKernelGGL(k_t_repack_bwd, dim3((25 * 64 * 32 + 255) / 256), dim3(256), 0, s, P + o[T_C2W], 16, 64, 16, 32, 16, t->wb2);
         hipLaunchKernelGGL((k_conv5<64, 32, 40, 10, 16, CONV_EPI_RAW, 16>), dim3(n * G2B::BPC), dim3(512), G2B::LDS_BYTES, s, t->z2, t->wb2, (const float*)nullptr, t->da1);
