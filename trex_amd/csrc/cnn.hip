@@ -754,13 +754,13 @@ __device__ __forceinline__ void split2h_pair(const float a, const float b, uint3
 }
 
 template <int CI, int CO, int S, int TPW, int DBG = 0>
-__global__ __launch_bounds__((WinoGeom<CI, CO, S, TPW>::NTHR)) void k_conv5_wino(const float* __restrict__ in /*[N][S][S][CI]*/,
+__global__ __launch_bounds__((WinoGeom<CI, CO, S, TPW>::NTHR), (TPW == 1 ? 2 : 1)) void k_conv5_wino(const float* __restrict__ in /*[N][S][S][CI]*/,
                                                                                const uint4* __restrict__ wp /*[CI/16][5][8][2][2][CO] x 16 B*/,
                                                                                const float* __restrict__ bias, float* __restrict__ out,
                                                                                const float out_scale, uint32_t* __restrict__ overflow,
                                                                                const int n_crops, uint32_t* __restrict__ pass_ctr) {
     using G = WinoGeom<CI, CO, S, TPW>;
-    static_assert(TPW == 2, "the tap body interleaves two M-tiles");
+    static_assert(TPW == 1 || TPW == 2, "one or two M-tiles per wave");     // TPW = 1: 128 accumulator registers, two workgroups per CU
     extern __shared__ __attribute__((aligned(16))) uint8_t ldsb[];
     __shared__ int s_next_pass;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -951,22 +951,23 @@ __global__ __launch_bounds__((WinoGeom<CI, CO, S, TPW>::NTHR)) void k_conv5_wino
                 const int p = t % 8;
                 const f16x8 b1 = __builtin_bit_cast(f16x8, bq[t % 8][0]);
                 const f16x8 b2 = __builtin_bit_cast(f16x8, bq[t % 8][1]);
-                const f16x8 a10 = __builtin_bit_cast(f16x8, af[cur][0][0]), a20 = __builtin_bit_cast(f16x8, af[cur][0][1]);
-                const f16x8 a11 = __builtin_bit_cast(f16x8, af[cur][1][0]), a21 = __builtin_bit_cast(f16x8, af[cur][1][1]);
-                acc[0][p] = mfma16(a20, b1, acc[0][p]);
-                acc[1][p] = mfma16(a21, b1, acc[1][p]);
-                acc[0][p] = mfma16(a10, b2, acc[0][p]);
-                acc[1][p] = mfma16(a11, b2, acc[1][p]);
-                acc[0][p] = mfma16(a10, b1, acc[0][p]);
-                acc[1][p] = mfma16(a11, b1, acc[1][p]);
+                f16x8 a1[TPW], a2[TPW];
+#pragma unroll
+                for (int m = 0; m < TPW; ++m) { a1[m] = __builtin_bit_cast(f16x8, af[cur][m][0]); a2[m] = __builtin_bit_cast(f16x8, af[cur][m][1]); }
+#pragma unroll
+                for (int m = 0; m < TPW; ++m) acc[m][p] = mfma16(a2[m], b1, acc[m][p]);
+#pragma unroll
+                for (int m = 0; m < TPW; ++m) acc[m][p] = mfma16(a1[m], b2, acc[m][p]);
+#pragma unroll
+                for (int m = 0; m < TPW; ++m) acc[m][p] = mfma16(a1[m], b1, acc[m][p]);
                 // issue order inside a tap: next tap's A reads and the weight loads first (their latency hides under this tap's
-                // MFMAs), then the six MFMAs with the staging slice spread between them
-                __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+                // MFMAs), then the MFMAs with the staging slice spread between them
+                __builtin_amdgcn_sched_group_barrier(0x100, 2 * TPW, 0);
                 __builtin_amdgcn_sched_group_barrier(0x020, 10, 0);
 #pragma unroll
-                for (int g = 0; g < 6; ++g) {
+                for (int g = 0; g < 3 * TPW; ++g) {
                     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x206, 8, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x206, TPW == 1 ? 16 : 8, 0);
                 }
                 __builtin_amdgcn_sched_barrier(0);                  // keep the taps apart
             }
@@ -1902,6 +1903,12 @@ int net_forward(trexhip_ctx* ctx, const uint8_t* d_crops, int n, float* d_probs,
 #undef W1A
 #define WA(D_) TH_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv5_wino<64, 128, 20, 2, D_>), hipFuncAttributeMaxDynamicSharedMemorySize, (WinoGeom<64, 128, 20, 2>::LDS_BYTES)))
         WA(0);
+#define WA1(D_) TH_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv5_wino<64, 128, 20, 1, D_>), hipFuncAttributeMaxDynamicSharedMemorySize, (WinoGeom<64, 128, 20, 1>::LDS_BYTES)))
+        WA1(0);
+#ifdef TREXHIP_DEV_KNOBS
+        WA1(1); WA1(2); WA1(3); WA1(4); WA1(7); WA1(15);
+#endif
+#undef WA1
 #ifdef TREXHIP_DEV_KNOBS
         WA(1); WA(2); WA(3); WA(4); WA(7); WA(8); WA(15); WA(12); WA(16);
 #endif
@@ -1965,6 +1972,19 @@ int net_forward(trexhip_ctx* ctx, const uint8_t* d_crops, int n, float* d_probs,
         hipLaunchKernelGGL((k_conv5<64, 128, 20, 20, 32>), dim3(n * G3::BPC), dim3(512), G3::LDS_BYTES, s, net->act2, net->w3, net->b3, net->act3);
     else if (mode == TREXHIP_CNN_BF16X6) LAUNCH_SPLIT(64, 128, 20, 20, 0, 6, net->act2, net->w3s, net->b3, net->act3, 1.0f, (const uint32_t*)nullptr);
     else if (mode == TREXHIP_CNN_BF16X3) LAUNCH_SPLIT(64, 128, 20, 20, 0, 3, net->act2, net->w3s, net->b3, net->act3, 1.0f, (const uint32_t*)nullptr);
+    else if (!(ctx->tune_conv_geom & 256) && (ctx->tune_conv_geom & 1024)) {
+        // one M-tile per wave (128 accumulator registers), two workgroups per CU: TREXHIP_CONV_GEOM bit 10
+        using GW1 = WinoGeom<64, 128, 20, 1>;
+        const int n_pass = (n * GW1::TPC + GW1::MB - 1) / GW1::MB;
+#define WL1(D_) hipLaunchKernelGGL((k_conv5_wino<64, 128, 20, 1, D_>), dim3(n_pass < 2 * ctx->n_cus ? n_pass : 2 * ctx->n_cus), dim3(GW1::NTHR), GW1::LDS_BYTES, s, \
+                           net->act2, net->w3w, net->b3, net->act3, net->inv3w, net->d_ovf, n, net->d_ovf + 1)
+#ifdef TREXHIP_DEV_KNOBS
+        switch ((ctx->tune_conv_geom >> 12) & 15) { case 1: WL1(1); break; case 2: WL1(2); break; case 3: WL1(3); break; case 4: WL1(4); break; case 7: WL1(7); break; case 15: WL1(15); break; default: WL1(0); }
+#else
+        WL1(0);
+#endif
+#undef WL1
+    }
     else if (!(ctx->tune_conv_geom & 256)) {
         // Winograd F(4,5) along x: 0.4x the matrix work of the direct form (TREXHIP_CONV_GEOM bit 8: the direct kernels below)
         using GW = WinoGeom<64, 128, 20, 2>;
