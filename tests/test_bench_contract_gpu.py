@@ -1,0 +1,42 @@
+"""bench.py prints ONE JSON line with the keys the driver reads; the line is the last thing on stdout."""
+import json
+import os
+import subprocess
+import sys
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def run(*extra):
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--batch", "16", *extra],
+                         capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.strip().splitlines() if l.strip()]
+    return json.loads(lines[-1])
+
+
+def test_default_line_has_the_contract_keys():
+    j = run("--cpu-seconds", "2")
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config",
+              "roofline", "cpu_baseline"):
+        assert k in j, k
+    assert j["n_gpus"] == 1 and j["steps"] == 2 and j["warmup"] == 1 and j["higher_is_better"] is True and j["scaling"] == "weak"
+    assert j["unit"] == "frames/s" and j["value"] > 0 and j["vs_baseline"] is None and j["data"] == "synthetic"
+    assert "workload" in j["config"] and "model" not in j["config"]
+    r = j["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in r, k
+    assert r["bound"] in ("hbm", "mfma") and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
+    c = j["cpu_baseline"]
+    for k in ("value", "unit", "cores", "kind", "sample"):
+        assert k in c, k
+    assert c["kind"] in ("port", "reference") and c["value"] > 0 and c["cores"] >= 1
+    assert abs(j["value"] - 16 * 2 / (j["ms_per_step"] * 2e-3)) / j["value"] < 1e-6      # value = frames of the timed steps / their time
+
+
+def test_detect_only_line_reports_an_hbm_roofline():
+    j = run("--no-cpu-baseline", "--stages", "segment")
+    assert j["roofline"]["bound"] == "hbm" and j["roofline"]["unit"] == "GB/s" and j["roofline"]["peak"] == 8000.0
+    assert "cpu_baseline" not in j or j["cpu_baseline"] is None or isinstance(j["cpu_baseline"], dict)
