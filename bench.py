@@ -58,6 +58,7 @@ def main():
                     help="keep the detect stage on the lane's own stream (default: a high-priority stream per lane, so that its short kernels get compute units as soon as the other lane's identity network frees some)")
     ap.add_argument("--gather", choices=["library", "torch"], default="library",
                     help="N > 1: who owns the RCCL communicator of the per-step table gather to rank 0: libtrexhip (trexhip_comm_*, default) or torch.distributed")
+    ap.add_argument("--same-gpu", action="store_true", help="dev: run all ranks of a torchrun launch on GPU 0 (RCCL over loopback sockets): checks the N > 1 code path on a 1-GPU box, not a measurement")
     ap.add_argument("--force-dist", action="store_true", help="run the multi-GPU code path (the library's communicator, trexhip_comm_*) even with a single rank")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                     help="weak: --batch frames per GPU per step (default); strong: --batch frames per step in total, split between the GPUs")
@@ -84,6 +85,12 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.same_gpu:
+        # functional check of the N > 1 code path on a 1-GPU box: every rank on device 0, each claiming its own host id so that RCCL
+        # accepts them and talks over its socket transport on loopback (slow; never a measurement)
+        local = 0
+        os.environ.update({"NCCL_HOSTID": f"trexhip-bench-rank{rank}", "NCCL_SOCKET_IFNAME": "lo", "NCCL_IB_DISABLE": "1", "NCCL_P2P_DISABLE": "1",
+                           "NCCL_SHM_DISABLE": "1", "NCCL_NET_GDR_LEVEL": "0"})
     use_dist = world > 1 or args.force_dist
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -237,7 +244,7 @@ def main():
                                f"80x80x1 crops, {classes}-way V118_3 (random-init weights)",
                    "stages": "detect(bg-sub+threshold+CCL+filter+gather, tables->host) + crops(none) + identity CNN (V118_3) + per-blob ID table (gathered on rank 0 over RCCL when N>1: trexhip_comm_gather_device) -> rank-0 host"
                              if with_cnn else "detect only (bg-sub+threshold+CCL+filter+gather, tables->host)",
-                   "frames_per_step_per_gpu": B, "encoding": args.encoding, "input": ("host " if host_in else "") + ("bgra tiles (cvtColor on the device inside the step)" if bgra_in else "gray frames") + (" in pageable host memory, PCIe inside the step" if host_in else " resident in HBM"), "posture": bool(args.with_posture), "individual_image_normalization": args.normalize, "pipelined_lanes": len(lanes), "blobs_per_step_rank0": n_blobs, "parallelism": f"frame-sharded x{world}", **({"gather": gather_by} if use_dist else {})},
+                   "frames_per_step_per_gpu": B, "encoding": args.encoding, "input": ("host " if host_in else "") + ("bgra tiles (cvtColor on the device inside the step)" if bgra_in else "gray frames") + (" in pageable host memory, PCIe inside the step" if host_in else " resident in HBM"), "posture": bool(args.with_posture), "individual_image_normalization": args.normalize, "pipelined_lanes": len(lanes), "blobs_per_step_rank0": n_blobs, "parallelism": f"frame-sharded x{world}" + (" (all ranks on ONE GPU over loopback sockets: functional check only)" if args.same_gpu else ""), **({"gather": gather_by} if use_dist else {})},
     }
     rows_traffic = pmc_traffic("trexhip::k_rows")
     pass_traffic = None
