@@ -40,3 +40,17 @@ def test_detect_only_line_reports_an_hbm_roofline():
     j = run("--no-cpu-baseline", "--stages", "segment")
     assert j["roofline"]["bound"] == "hbm" and j["roofline"]["unit"] == "GB/s" and j["roofline"]["peak"] == 8000.0
     assert "cpu_baseline" not in j or j["cpu_baseline"] is None or isinstance(j["cpu_baseline"], dict)
+
+
+def test_two_rank_launch_on_one_gpu_runs_the_gather_path():
+    # the driver's N > 1 launch line with every rank on GPU 0 (--same-gpu: RCCL over loopback sockets) -- functional check of the
+    # communicator creation, the per-step gather to rank 0 and the max-over-ranks timing; the value itself means nothing
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                          "--master-port", "29541", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "16",
+                          "--same-gpu", "--no-cpu-baseline"], capture_output=True, text=True, timeout=420, cwd=ROOT)
+    if out.returncode != 0 and ("Duplicate GPU" in out.stderr or "No socket interfaces" in out.stderr):
+        pytest.skip("RCCL cannot run two ranks on one GPU here")
+    assert out.returncode == 0, out.stderr[-3000:]
+    j = json.loads([l for l in out.stdout.strip().splitlines() if l.startswith("{")][-1])
+    assert j["n_gpus"] == 2 and j["scaling"] == "weak" and j["config"]["gather"].startswith("libtrexhip")
+    assert abs(j["value"] - 2 * 16 * 2 / (j["ms_per_step"] * 2e-3)) / j["value"] < 1e-6      # whole-job frames / slowest rank's time
