@@ -184,6 +184,15 @@ def test_library_drawn_masks_and_argument_checks():
         tr.step_device(dx.data_ptr(), dy.data_ptr(), 0)
     with pytest.raises(capi.TrexHipError):
         tr.set_lr(0.0)
+    # a class index out of range in device memory: flagged by the kernel, the synchronising call and later reads are refused
+    x, y = weights.synthetic_train_batch(n, 41, classes, ch)
+    y[3] = classes
+    with pytest.raises(capi.TrexHipError):
+        step(tr, x, y, None)
+    with pytest.raises(capi.TrexHipError):
+        tr.export()
+    with pytest.raises(capi.TrexHipError):
+        tr.step(x, y)                                                 # host entry point: checked before anything is uploaded
     tr.close()
     with pytest.raises(capi.TrexHipError):
         capi.Trainer(seg, weights.pack_blob(state, classes, ch)[:-4], max_batch=16)

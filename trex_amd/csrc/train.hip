@@ -366,7 +366,7 @@ __global__ __launch_bounds__(128) void k_t_head(const float* __restrict__ hpart,
                                                 const float* __restrict__ w2 /*[C][100]*/, const float* __restrict__ b2, const int32_t* __restrict__ targets,
                                                 int classes, float* __restrict__ xhat /*[n][100]*/, float* __restrict__ hd /*[n][100]*/,
                                                 float* __restrict__ dl /*[n][C]*/, float* __restrict__ dy /*[n][100]*/, float* __restrict__ dh /*[n][100]*/,
-                                                float* __restrict__ loss /*[n]*/, int32_t* __restrict__ correct /*[n]*/) {
+                                                float* __restrict__ loss /*[n]*/, int32_t* __restrict__ correct /*[n]*/, int32_t* __restrict__ bad_target) {
     __shared__ float red[128];
     __shared__ float s_d[100];
     __shared__ float s_dl[1024];
@@ -412,7 +412,11 @@ __global__ __launch_bounds__(128) void k_t_head(const float* __restrict__ hpart,
         if (tid < st) s_arg[tid] = min(s_arg[tid], s_arg[tid + st]);
         __syncthreads();
     }
-    const int target = targets[s];
+    int target = targets[s];
+    if (target < 0 || target >= classes) {                 // train() asserts this (visual_recognition_torch.py:1112); here: flag it, the step's result is refused
+        if (tid == 0) atomicOr(bad_target, 1);
+        target = 0;
+    }
     float se = 0.f;
     for (int c = tid; c < classes; c += 128) se += expf(s_dl[c] - gmax);
     const float sum = block_sum128(se, red);
@@ -725,6 +729,7 @@ struct Trainer {
     float *wb3 = nullptr, *wb2 = nullptr, *part = nullptr, *stat = nullptr /*3 x (mean, invstd, sums[2]) x 128*/;
     float *hpart = nullptr, *xhat = nullptr, *hd = nullptr, *dl = nullptr, *dy = nullptr, *dh = nullptr, *loss = nullptr, *out2 = nullptr;
     int32_t* correct = nullptr;
+    int32_t* bad_target = nullptr;       // set by k_t_head when a target is outside 0..classes-1; sticky until read
     double* red = nullptr;
     uint8_t* keep = nullptr;
     float* x_stage = nullptr;            // host-pointer entry point: inputs, targets and injected masks staged here
@@ -832,6 +837,14 @@ static void bn_backward(Trainer* t, hipStream_t s, int layer, const float* da, f
     hipLaunchKernelGGL(k_t_sum_finalize, dim3(1), dim3(1024), 0, s, t->red, RED_BLOCKS, C, t->G + t->off[tcb]);
 }
 
+// a step that saw a target outside 0..classes-1 has updated the parameters with a wrong gradient: every later synchronising call fails
+static int check_targets(Trainer* t) {
+    int32_t bad = 0;
+    TH_CHECK_HIP(hipMemcpy(&bad, t->bad_target, 4, hipMemcpyDeviceToHost));
+    if (bad) { set_error("training step: a target class index was outside 0..classes-1 (the parameters were updated with it; recreate the trainer)"); return TREXHIP_E_INVALID; }
+    return TREXHIP_OK;
+}
+
 static int trainer_step(Trainer* t, const float* x, const int32_t* targets, int n, const uint8_t* d_keep, float* h_loss, int32_t* h_correct) {
     trexhip_ctx* ctx = t->ctx;
     TH_CHECK_HIP(hipSetDevice(ctx->p.device));
@@ -863,7 +876,7 @@ static int trainer_step(Trainer* t, const float* x, const int32_t* targets, int 
     bn_forward<128>(t, s, 2, t->z3, t->a3, n, 20, T_G3, T_BE3, T_RM3, T_RV3, k3, scale);
     hipLaunchKernelGGL(k_t_fc1, dim3(100, (n + 63) / 64), dim3(256), 0, s, t->a3, P + o[T_F1W], t->hpart, n);
     hipLaunchKernelGGL(k_t_head, dim3(n), dim3(128), 0, s, t->hpart, n, P + o[T_F1B], P + o[T_LNG], P + o[T_LNB], k4, scale, P + o[T_F2W], P + o[T_F2B], targets,
-                       t->classes, t->xhat, t->hd, t->dl, t->dy, t->dh, t->loss, t->correct);
+                       t->classes, t->xhat, t->hd, t->dl, t->dy, t->dh, t->loss, t->correct, t->bad_target);
     // ---- backward
     {
         const int cnt = t->classes * 100 + t->classes + 300;
@@ -912,6 +925,7 @@ static int trainer_step(Trainer* t, const float* x, const int32_t* targets, int 
         TH_CHECK_HIP(hipStreamSynchronize(s));
         if (h_loss) *h_loss = two[0];
         if (h_correct) *h_correct = (int32_t)two[1];
+        return check_targets(t);
     }
     return TREXHIP_OK;
 }
@@ -970,7 +984,7 @@ int trexhip_trainer_create(trexhip_ctx* ctx, const void* blob, size_t bytes, con
     TRY(dev_alloc(t, &t->stat, (size_t)3 * 512));
     TRY(dev_alloc(t, &t->hpart, n * 100 * 100)); TRY(dev_alloc(t, &t->xhat, n * 100)); TRY(dev_alloc(t, &t->hd, n * 100));
     TRY(dev_alloc(t, &t->dl, n * classes)); TRY(dev_alloc(t, &t->dy, n * 100)); TRY(dev_alloc(t, &t->dh, n * 100));
-    TRY(dev_alloc(t, &t->loss, n)); TRY(dev_alloc(t, &t->correct, n)); TRY(dev_alloc(t, &t->out2, 2));
+    TRY(dev_alloc(t, &t->loss, n)); TRY(dev_alloc(t, &t->correct, n)); TRY(dev_alloc(t, &t->out2, 2)); TRY(dev_alloc(t, &t->bad_target, 1));
     TRY(dev_alloc(t, &t->red, (size_t)RED_BLOCKS * 2 * 128)); TRY(dev_alloc(t, &t->keep, n * 308));
     TRY(dev_alloc(t, &t->x_stage, n * 6400 * CH)); TRY(dev_alloc(t, &t->y_stage, n)); TRY(dev_alloc(t, &t->keep_stage, n * 308));
 #undef TRY
@@ -982,6 +996,7 @@ int trexhip_trainer_create(trexhip_ctx* ctx, const void* blob, size_t bytes, con
         src += t->cnt[k];
     }
     bool ok = hipMemcpy(t->P, host.data(), at * 4, hipMemcpyHostToDevice) == hipSuccess;
+    ok = ok && hipMemset(t->bad_target, 0, 4) == hipSuccess;
     ok = ok && hipMemset(t->G, 0, at * 4) == hipSuccess && hipMemset(t->M, 0, at * 4) == hipSuccess && hipMemset(t->V, 0, at * 4) == hipSuccess;
     if (!ok) { trainer_free(t); set_error("trexhip_trainer_create: upload failed"); return TREXHIP_E_DEVICE; }
     trexhip_trainer* h = new trexhip_trainer{t};
@@ -1033,6 +1048,7 @@ int trexhip_trainer_read(trexhip_trainer* h, int32_t tensor, int32_t kind, float
     if (count != t->cnt[tensor]) { set_error("trexhip_trainer_read: count does not match the tensor"); return TREXHIP_E_INVALID; }
     TH_CHECK_HIP(hipSetDevice(t->ctx->p.device));
     TH_CHECK_HIP(hipStreamSynchronize(t->ctx->stream));
+    { const int rc = check_targets(t); if (rc != TREXHIP_OK) return rc; }
     const float* src = kind == 0 ? t->P : kind == 1 ? t->G : kind == 2 ? t->M : t->V;
     std::vector<float> tmp(count);
     TH_CHECK_HIP(hipMemcpy(tmp.data(), src + t->off[tensor], count * 4, hipMemcpyDeviceToHost));
