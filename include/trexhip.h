@@ -446,6 +446,10 @@ int trexhip_trainer_set_lr(trexhip_trainer* trainer, float lr);
 int64_t trexhip_trainer_steps(trexhip_trainer* trainer);
 int trexhip_train_step_device(trexhip_trainer* trainer, const float* d_inputs, const int32_t* d_targets, int32_t n, const uint8_t* d_keep_masks,
                               float* loss, int32_t* correct);
+/* model.eval() forward + mean cross entropy + arg-max count of one validation batch (train(), :1171-1190: what ReduceLROnPlateau and the
+ * early-stopping callback are fed); running statistics, nothing dropped; changes nothing in the trainer */
+int trexhip_train_eval_device(trexhip_trainer* trainer, const float* d_inputs, const int32_t* d_targets, int32_t n, float* loss, int32_t* correct);
+int trexhip_train_eval(trexhip_trainer* trainer, const float* inputs, const int32_t* targets, int32_t n, float* loss, int32_t* correct);
 /* the same step from host memory (what the reference's DataLoader yields); targets are range-checked like train() does (:1112) */
 int trexhip_train_step(trexhip_trainer* trainer, const float* inputs, const int32_t* targets, int32_t n, const uint8_t* keep_masks, float* loss,
                        int32_t* correct);

@@ -164,6 +164,31 @@ def test_ragged_batches_and_class_counts_equal_oracle(n, classes, ch):
     seg.close()
 
 
+def test_eval_mode_loss_equals_the_eval_restatement():
+    # validation batches: model.eval() -> running statistics, no dropout; loss = CrossEntropyLoss(logits, targets) (train() :1171-1190)
+    classes, ch, n = 100, 1, 77
+    state = weights.synthetic_state(classes, 61, channels=ch)
+    rng = np.random.default_rng(61)
+    for k in ("bn1", "bn2", "bn3"):                                   # non-trivial running statistics
+        state[k + ".running_mean"] = rng.uniform(-0.5, 0.5, state[k + ".running_mean"].shape).astype(np.float32)
+        state[k + ".running_var"] = rng.uniform(0.5, 2.0, state[k + ".running_var"].shape).astype(np.float32)
+    x, y = weights.synthetic_train_batch(n, 62, classes, ch)
+    x = np.round(x)                                                   # the eval restatement takes 8-bit crops
+    logits = cnn_oracle.forward_logits(state, x.astype(np.uint8), threads=16)
+    z = logits - logits.max(1, keepdims=True)
+    lse = np.log(np.exp(z.astype(np.float64)).sum(1))
+    loss_ref = float(np.mean(lse - z[np.arange(n), y]))
+    correct_ref = int((logits.argmax(1) == y).sum())
+    seg = make_seg()
+    tr = capi.Trainer(seg, weights.pack_blob(state, classes, ch), max_batch=128, lr=1e-3)
+    before = tr.export()
+    loss, correct = tr.evaluate(x, y)
+    assert abs(loss - loss_ref) <= 5e-5 * max(1.0, abs(loss_ref)), (loss, loss_ref)
+    assert correct == correct_ref
+    assert tr.export() == before and tr.steps == 0                    # evaluation changes nothing
+    tr.close(); seg.close()
+
+
 def test_library_drawn_masks_and_argument_checks():
     classes, ch, n = 10, 3, 9
     state = weights.synthetic_state(classes, 5, channels=ch)

@@ -109,7 +109,7 @@ SYMBOLS = [
     "trexhip_segment", "trexhip_segment_color", "trexhip_segment_color_device", "trexhip_rethreshold_device", "trexhip_rethreshold_per_blob_device", "trexhip_fetch_rethreshold", "trexhip_fetch", "trexhip_device_view_get", "trexhip_synchronize",
     "trexhip_profile_enable", "trexhip_profile_read", "trexhip_profile_reset",
     "trexhip_default_posture_params", "trexhip_posture_device", "trexhip_posture_auto_device", "trexhip_pack_frames_v6_device", "trexhip_crops_device", "trexhip_pixel_channels", "trexhip_device_alloc", "trexhip_device_free", "trexhip_copy_to_host", "trexhip_copy_to_device", "trexhip_crops_transformed_device", "trexhip_crops_posture_device", "trexhip_default_midline_params", "trexhip_midline_device", "trexhip_default_split_params", "trexhip_split_search_device", "trexhip_export_id_table_device", "trexhip_export_id_table_ex_device", "trexhip_load_weights", "trexhip_set_identity_precision", "trexhip_num_classes", "trexhip_identify_device", "trexhip_identify",
-    "trexhip_weight_blob_bytes", "trexhip_trainer_create", "trexhip_trainer_destroy", "trexhip_trainer_set_lr", "trexhip_trainer_steps", "trexhip_train_step_device", "trexhip_train_step", "trexhip_trainer_read", "trexhip_trainer_export",
+    "trexhip_weight_blob_bytes", "trexhip_trainer_create", "trexhip_trainer_destroy", "trexhip_trainer_set_lr", "trexhip_trainer_steps", "trexhip_train_step_device", "trexhip_train_step", "trexhip_train_eval_device", "trexhip_train_eval", "trexhip_trainer_read", "trexhip_trainer_export",
 ]
 
 
@@ -184,6 +184,8 @@ def lib():
         L.trexhip_trainer_steps.restype = C.c_int64
         L.trexhip_train_step_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_int32)]
         L.trexhip_train_step.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_int32)]
+        L.trexhip_train_eval_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.POINTER(C.c_float), C.POINTER(C.c_int32)]
+        L.trexhip_train_eval.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.POINTER(C.c_float), C.POINTER(C.c_int32)]
         L.trexhip_trainer_read.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_size_t]
         L.trexhip_trainer_export.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
         _LIB = L
@@ -509,6 +511,14 @@ class Trainer:
         loss, correct = C.c_float(), C.c_int32()
         _check(lib().trexhip_train_step(self._h, x.ctypes.data_as(C.c_void_p), y.ctypes.data_as(C.c_void_p), x.shape[0],
                                         k.ctypes.data_as(C.c_void_p) if k is not None else None, C.byref(loss), C.byref(correct)))
+        return loss.value, correct.value
+
+    def evaluate(self, inputs, targets):
+        """model.eval() forward of one validation batch (host arrays) -> (mean cross entropy, correct count); the trainer is unchanged"""
+        x = np.ascontiguousarray(inputs, np.float32)
+        y = np.ascontiguousarray(targets, np.int32)
+        loss, correct = C.c_float(), C.c_int32()
+        _check(lib().trexhip_train_eval(self._h, x.ctypes.data_as(C.c_void_p), y.ctypes.data_as(C.c_void_p), x.shape[0], C.byref(loss), C.byref(correct)))
         return loss.value, correct.value
 
     def set_lr(self, lr):

@@ -23,6 +23,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstring>
+#include <type_traits>
 #include <vector>
 
 namespace trexhip {
@@ -131,6 +132,14 @@ __global__ __launch_bounds__(1024) void k_t_bn_finalize(const double* __restrict
     const double unbiased = count > 1 ? var * count / (count - 1) : var;
     run_mean[c] = (1.f - momentum) * run_mean[c] + momentum * (float)m;
     run_var[c] = (1.f - momentum) * run_var[c] + momentum * (float)unbiased;
+}
+
+// eval mode: normalise with the running statistics
+__global__ void k_t_bn_from_running(const float* __restrict__ run_mean, const float* __restrict__ run_var, int C, float* __restrict__ mean, float* __restrict__ invstd) {
+    const int c = threadIdx.x;
+    if (c >= C) return;
+    mean[c] = run_mean[c];
+    invstd[c] = (float)(1.0 / sqrt((double)run_var[c] + (double)EPS_BN));
 }
 
 // sum over the partials -> a bias gradient (pass 0 of k_t_colstats)
@@ -845,17 +854,65 @@ static int check_targets(Trainer* t) {
     return TREXHIP_OK;
 }
 
+// forward pass up to the per-sample loss / arg-max (and, as a by-product of k_t_head, the gradient at the fc1 output).  train = batch
+// statistics + dropout masks `keep`; eval = running statistics, nothing dropped (model.eval(), visual_recognition_torch.py:1171-1185)
+static void trainer_forward(Trainer* t, hipStream_t s, const float* x, const int32_t* targets, int n, const uint8_t* keep, float scale, bool train) {
+    const uint8_t *k1 = keep, *k2 = keep + (size_t)n * 16, *k3 = keep + (size_t)n * 80, *k4 = keep + (size_t)n * 208;
+    float* P = t->P;
+    const size_t* o = t->off;
+    auto block = [&](auto tag, int layer, const float* z, float* a, int S, int tg, int tb, int trm, int trv, const uint8_t* kp) {
+        constexpr int C = decltype(tag)::value;
+        if (train) { bn_forward<C>(t, s, layer, z, a, n, S, tg, tb, trm, trv, kp, scale); return; }
+        float* mean = t->stat + layer * 512;
+        float* invstd = mean + 128;
+        hipLaunchKernelGGL(k_t_bn_from_running, dim3(1), dim3(128), 0, s, P + o[trm], P + o[trv], C, mean, invstd);
+        const size_t total = (size_t)n * (S / 2) * (S / 2) * (C / 4);
+        hipLaunchKernelGGL((k_t_bn_pool<C>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, z, mean, invstd, P + o[tg], P + o[tb], kp, scale, a, n, S);
+    };
+    if (t->CH == 1) launch_layer1<1>(t, s, x, n); else launch_layer1<3>(t, s, x, n);
+    block(std::integral_constant<int, 16>{}, 0, t->z1, t->a1, 80, T_G1, T_BE1, T_RM1, T_RV1, k1);
+    hipLaunchKernelGGL((k_conv5<16, 64, 40, 20, 16, CONV_EPI_RAW, 64>), dim3(n * G2F::BPC), dim3(512), G2F::LDS_BYTES, s, t->a1, P + o[T_C2W], P + o[T_C2B], t->z2);
+    block(std::integral_constant<int, 64>{}, 1, t->z2, t->a2, 40, T_G2, T_BE2, T_RM2, T_RV2, k2);
+    hipLaunchKernelGGL((k_conv5<64, 128, 20, 10, 32, CONV_EPI_RAW, 128>), dim3(n * G3F::BPC), dim3(512), G3F::LDS_BYTES, s, t->a2, P + o[T_C3W], P + o[T_C3B], t->z3);
+    block(std::integral_constant<int, 128>{}, 2, t->z3, t->a3, 20, T_G3, T_BE3, T_RM3, T_RV3, k3);
+    hipLaunchKernelGGL(k_t_fc1, dim3(100, (n + 63) / 64), dim3(256), 0, s, t->a3, P + o[T_F1W], t->hpart, n);
+    hipLaunchKernelGGL(k_t_head, dim3(n), dim3(128), 0, s, t->hpart, n, P + o[T_F1B], P + o[T_LNG], P + o[T_LNB], k4, scale, P + o[T_F2W], P + o[T_F2B], targets,
+                       t->classes, t->xhat, t->hd, t->dl, t->dy, t->dh, t->loss, t->correct, t->bad_target);
+}
+
+static int trainer_attrs(Trainer* t) {
+    if (t->attr) return TREXHIP_OK;
+    TH_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv5<16, 64, 40, 20, 16, CONV_EPI_RAW, 64>), hipFuncAttributeMaxDynamicSharedMemorySize, G2F::LDS_BYTES));
+    TH_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv5<64, 128, 20, 10, 32, CONV_EPI_RAW, 128>), hipFuncAttributeMaxDynamicSharedMemorySize, G3F::LDS_BYTES));
+    TH_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv5<128, 64, 20, 10, 32, CONV_EPI_RAW, 64>), hipFuncAttributeMaxDynamicSharedMemorySize, G3B::LDS_BYTES));
+    TH_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv5<64, 32, 40, 10, 16, CONV_EPI_RAW, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, G2B::LDS_BYTES));
+    t->attr = true;
+    return TREXHIP_OK;
+}
+
+// model.eval() forward + mean cross entropy + arg-max count of one validation batch (train(), :1171-1190); changes nothing in the trainer
+static int trainer_eval(Trainer* t, const float* x, const int32_t* targets, int n, float* h_loss, int32_t* h_correct) {
+    trexhip_ctx* ctx = t->ctx;
+    TH_CHECK_HIP(hipSetDevice(ctx->p.device));
+    hipStream_t s = ctx->stream;
+    { const int rc = trainer_attrs(t); if (rc) return rc; }
+    TH_CHECK_HIP(hipMemsetAsync(t->keep, 1, (size_t)n * 308, s));                 // nothing dropped
+    trainer_forward(t, s, x, targets, n, t->keep, 1.0f, false);
+    hipLaunchKernelGGL(k_t_loss, dim3(1), dim3(64), 0, s, t->loss, t->correct, n, t->out2);
+    TH_CHECK_HIP(hipGetLastError());
+    float two[2];
+    TH_CHECK_HIP(hipMemcpyAsync(two, t->out2, sizeof(two), hipMemcpyDeviceToHost, s));
+    TH_CHECK_HIP(hipStreamSynchronize(s));
+    if (h_loss) *h_loss = two[0];
+    if (h_correct) *h_correct = (int32_t)two[1];
+    return check_targets(t);
+}
+
 static int trainer_step(Trainer* t, const float* x, const int32_t* targets, int n, const uint8_t* d_keep, float* h_loss, int32_t* h_correct) {
     trexhip_ctx* ctx = t->ctx;
     TH_CHECK_HIP(hipSetDevice(ctx->p.device));
     hipStream_t s = ctx->stream;
-    if (!t->attr) {
-        TH_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv5<16, 64, 40, 20, 16, CONV_EPI_RAW, 64>), hipFuncAttributeMaxDynamicSharedMemorySize, G2F::LDS_BYTES));
-        TH_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv5<64, 128, 20, 10, 32, CONV_EPI_RAW, 128>), hipFuncAttributeMaxDynamicSharedMemorySize, G3F::LDS_BYTES));
-        TH_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv5<128, 64, 20, 10, 32, CONV_EPI_RAW, 64>), hipFuncAttributeMaxDynamicSharedMemorySize, G3B::LDS_BYTES));
-        TH_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv5<64, 32, 40, 10, 16, CONV_EPI_RAW, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, G2B::LDS_BYTES));
-        t->attr = true;
-    }
+    { const int rc = trainer_attrs(t); if (rc) return rc; }
     const float scale = 1.0f / (1.0f - t->p.dropout);
     const uint8_t* keep = d_keep;
     if (!keep) {
@@ -863,20 +920,11 @@ static int trainer_step(Trainer* t, const float* x, const int32_t* targets, int 
         hipLaunchKernelGGL(k_t_masks, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, s, t->keep, count, t->p.seed, (uint64_t)t->step, t->p.dropout);
         keep = t->keep;
     }
-    const uint8_t *k1 = keep, *k2 = keep + (size_t)n * 16, *k3 = keep + (size_t)n * 80, *k4 = keep + (size_t)n * 208;
     float* P = t->P;
     float* G = t->G;
     const size_t* o = t->off;
-    // ---- forward
-    if (t->CH == 1) launch_layer1<1>(t, s, x, n); else launch_layer1<3>(t, s, x, n);
-    bn_forward<16>(t, s, 0, t->z1, t->a1, n, 80, T_G1, T_BE1, T_RM1, T_RV1, k1, scale);
-    hipLaunchKernelGGL((k_conv5<16, 64, 40, 20, 16, CONV_EPI_RAW, 64>), dim3(n * G2F::BPC), dim3(512), G2F::LDS_BYTES, s, t->a1, P + o[T_C2W], P + o[T_C2B], t->z2);
-    bn_forward<64>(t, s, 1, t->z2, t->a2, n, 40, T_G2, T_BE2, T_RM2, T_RV2, k2, scale);
-    hipLaunchKernelGGL((k_conv5<64, 128, 20, 10, 32, CONV_EPI_RAW, 128>), dim3(n * G3F::BPC), dim3(512), G3F::LDS_BYTES, s, t->a2, P + o[T_C3W], P + o[T_C3B], t->z3);
-    bn_forward<128>(t, s, 2, t->z3, t->a3, n, 20, T_G3, T_BE3, T_RM3, T_RV3, k3, scale);
-    hipLaunchKernelGGL(k_t_fc1, dim3(100, (n + 63) / 64), dim3(256), 0, s, t->a3, P + o[T_F1W], t->hpart, n);
-    hipLaunchKernelGGL(k_t_head, dim3(n), dim3(128), 0, s, t->hpart, n, P + o[T_F1B], P + o[T_LNG], P + o[T_LNB], k4, scale, P + o[T_F2W], P + o[T_F2B], targets,
-                       t->classes, t->xhat, t->hd, t->dl, t->dy, t->dh, t->loss, t->correct, t->bad_target);
+    trainer_forward(t, s, x, targets, n, keep, scale, true);
+    const uint8_t *k1 = keep, *k2 = keep + (size_t)n * 16, *k3 = keep + (size_t)n * 80;
     // ---- backward
     {
         const int cnt = t->classes * 100 + t->classes + 300;
@@ -1040,6 +1088,25 @@ int trexhip_train_step(trexhip_trainer* h, const float* inputs, const int32_t* t
     if (rc != TREXHIP_OK) return rc;
     TH_CHECK_HIP(hipStreamSynchronize(s));        // the caller's buffers may go away
     return TREXHIP_OK;
+}
+
+int trexhip_train_eval_device(trexhip_trainer* h, const float* d_inputs, const int32_t* d_targets, int32_t n, float* loss, int32_t* correct) {
+    if (!h || !d_inputs || !d_targets) { set_error("trexhip_train_eval_device: null argument"); return TREXHIP_E_INVALID; }
+    if (n < 1 || n > h->t->max_n) { set_error("trexhip_train_eval_device: n must be 1..max_batch"); return TREXHIP_E_INVALID; }
+    return trainer_eval(h->t, d_inputs, d_targets, n, loss, correct);
+}
+
+int trexhip_train_eval(trexhip_trainer* h, const float* inputs, const int32_t* targets, int32_t n, float* loss, int32_t* correct) {
+    if (!h || !inputs || !targets) { set_error("trexhip_train_eval: null argument"); return TREXHIP_E_INVALID; }
+    Trainer* t = h->t;
+    if (n < 1 || n > t->max_n) { set_error("trexhip_train_eval: n must be 1..max_batch"); return TREXHIP_E_INVALID; }
+    for (int i = 0; i < n; ++i)
+        if (targets[i] < 0 || targets[i] >= t->classes) { set_error("trexhip_train_eval: target class out of range"); return TREXHIP_E_INVALID; }
+    TH_CHECK_HIP(hipSetDevice(t->ctx->p.device));
+    hipStream_t s = t->ctx->stream;
+    TH_CHECK_HIP(hipMemcpyAsync(t->x_stage, inputs, (size_t)n * 6400 * t->CH * sizeof(float), hipMemcpyHostToDevice, s));
+    TH_CHECK_HIP(hipMemcpyAsync(t->y_stage, targets, (size_t)n * sizeof(int32_t), hipMemcpyHostToDevice, s));
+    return trainer_eval(t, t->x_stage, t->y_stage, n, loss, correct);
 }
 
 int trexhip_trainer_read(trexhip_trainer* h, int32_t tensor, int32_t kind, float* out, size_t count) {

@@ -133,6 +133,12 @@ struct HipVINetwork {
             check(trexhip_train_step(_t, images, labels, n, nullptr, &r.loss, &r.correct));
             return r;
         }
+        // validation batch in eval mode (running statistics, no dropout): the val_loss / val_acc of train() :1171-1206
+        Result evaluate(const float* images, const int32_t* labels, int n) {
+            Result r{};
+            check(trexhip_train_eval(_t, images, labels, n, &r.loss, &r.correct));
+            return r;
+        }
         void set_learning_rate(float lr) { check(trexhip_trainer_set_lr(_t, lr)); }          // ReduceLROnPlateau lives with the caller
         int64_t steps() const { return trexhip_trainer_steps(_t); }
         std::vector<uint8_t> weights() const {                                                // what the reference serialises back (state_dict)
