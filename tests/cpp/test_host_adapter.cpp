@@ -510,6 +510,8 @@ int main(int argc, char** argv) {
             HipVINetwork::Trainer::Result last = first;
             for (int k = 0; k < 5; ++k) last = tr.train_batch(x.data(), y.data(), (int)n);
             CHECK(std::isfinite(first.loss) && last.loss < first.loss && tr.steps() == 6 && last.correct >= 0 && last.correct <= (int)n);
+            auto val = tr.evaluate(x.data(), y.data(), (int)n);                            // eval mode: running statistics, no dropout; nothing changes
+            CHECK(std::isfinite(val.loss) && val.correct >= 0 && val.correct <= (int)n && tr.steps() == 6);
             y[0] = C;                                                                   // label out of range: refused (visual_recognition_torch.py:1112)
             bool threw = false; try { tr.train_batch(x.data(), y.data(), (int)n); } catch (const std::exception&) { threw = true; } CHECK(threw);
             threw = false; try { tr.train_batch(x.data(), y.data(), 65); } catch (const std::exception&) { threw = true; } CHECK(threw);   // n > max_batch
