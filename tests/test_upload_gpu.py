@@ -89,3 +89,29 @@ def test_upload_legs_overlap():
     assert wall < copy_ms + dma_ms - 0.4 * min(copy_ms, dma_ms)        # the smaller leg is (mostly) hidden under the larger one
     assert gbps > 20.0                                                  # PCIe Gen5 x16: 63 GB/s spec; a serial copy -> DMA path stays below ~25
     seg.close()
+
+
+def test_row_pitch_larger_than_the_width():
+    # tiles that are views into wider buffers: stride > width * channels (the upload threads copy / reduce row by row)
+    import ctypes as C
+    n = 3
+    fr, bg = synth.batch("C2", n)
+    H, W = fr.shape[1:]
+    seg = capi.Segmenter(capi.default_params(W, H, max_batch=n))
+    seg.set_background(bg)
+    d = torch.from_numpy(fr).cuda()
+    seg.segment_device(d.data_ptr(), n); want = tables(seg)
+    L = capi.lib()
+    wide = np.full((n, H, W + 40), 7, np.uint8); wide[:, :, :W] = fr
+    ptrs = (C.c_void_p * n)(*[wide[i].ctypes.data for i in range(n)])
+    assert L.trexhip_segment(seg.handle, ptrs, W + 40, n) == 0
+    assert tables(seg) == want
+    for ch in (3, 4):
+        col = np.repeat(fr[..., None], ch, axis=3); col[..., 1] = fr // 2
+        dc = torch.from_numpy(col).cuda()
+        seg.segment_color_device(dc.data_ptr(), n, ch); want_c = tables(seg)
+        widec = np.full((n, H, W + 24, ch), 9, np.uint8); widec[:, :, :W] = col
+        ptrs = (C.c_void_p * n)(*[widec[i].ctypes.data for i in range(n)])
+        assert L.trexhip_segment_color(seg.handle, ptrs, (W + 24) * ch, n, ch, -1) == 0
+        assert tables(seg) == want_c
+    seg.close()
