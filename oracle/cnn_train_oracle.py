@@ -38,14 +38,16 @@ def new_adam_state(state):
     return {"step": 0, "m": {k: np.zeros_like(state[k]) for k in TRAINABLE}, "v": {k: np.zeros_like(state[k]) for k in TRAINABLE}}
 
 
-def forward_backward(state, x_nhwc, targets, masks, threads=None):
-    """-> loss (float), correct (int), grads {name: ndarray}, new running stats {name: ndarray}, logits"""
+def forward_backward(state, x_nhwc, targets, masks, threads=None, dtype=torch.float32):
+    """-> loss (float), correct (int), grads {name: ndarray}, new running stats {name: ndarray}, logits.
+    dtype=torch.float64 gives the reference point for "which of two fp32 results is closer" questions (near-ties in the max-pool
+    arg-max and at the ReLU flip with fp32 summation order; tools/fuzz_train.py)."""
     if threads:
         torch.set_num_threads(threads)
-    t = {k: torch.from_numpy(np.ascontiguousarray(state[k], np.float32)).clone() for k in TRAINABLE + BUFFERS}
+    t = {k: torch.from_numpy(np.ascontiguousarray(state[k], np.float32)).clone().to(dtype) for k in TRAINABLE + BUFFERS}
     for k in TRAINABLE:
         t[k].requires_grad_(True)
-    x = torch.from_numpy(np.ascontiguousarray(x_nhwc, np.float32)).permute(0, 3, 1, 2)
+    x = torch.from_numpy(np.ascontiguousarray(x_nhwc, np.float32)).to(dtype).permute(0, 3, 1, 2)
     y = torch.from_numpy(np.asarray(targets).astype(np.int64))
     scale = 1.0 - P_DROP
     for i in (1, 2, 3):
@@ -59,13 +61,13 @@ def forward_backward(state, x_nhwc, targets, masks, threads=None):
                          training=True, momentum=BN_MOMENTUM, eps=EPS_BN)
         x = F.relu(x)
         x = F.max_pool2d(x, 2)
-        noise = torch.from_numpy(np.asarray(masks[f"d{i}"]).astype(np.float32)).div_(scale)       # [n, C]
+        noise = torch.from_numpy(np.asarray(masks[f"d{i}"]).astype(np.float32)).div_(scale).to(dtype)       # [n, C]
         x = x * noise[:, :, None, None]
     x = x.reshape(x.shape[0], -1)
     x = F.linear(x, t["fc1.weight"], t["fc1.bias"])
     x = F.layer_norm(x, (100,), t["bn4.weight"], t["bn4.bias"], eps=EPS_LN)
     x = F.relu(x)
-    x = x * torch.from_numpy(np.asarray(masks["d4"]).astype(np.float32)).div_(scale)
+    x = x * torch.from_numpy(np.asarray(masks["d4"]).astype(np.float32)).div_(scale).to(dtype)
     logits = F.linear(x, t["fc2.weight"], t["fc2.bias"])
     loss = F.cross_entropy(logits, y)
     loss.backward()
