@@ -157,3 +157,29 @@ def test_three_channel_network(mode):
     op, _ = cnn_oracle.predict(st, crops, threads=8)
     assert np.abs(p - op).max() <= 1e-4
     seg.close()
+
+
+def test_replayed_chain_follows_new_inputs_and_precision_changes():
+    # small batches replay a captured hipGraph of the identify chain (cnn.hip: net_forward): the replay must see what is in the buffers NOW
+    # (crops rewritten in place, the fp16 range flag of THIS batch), and a precision switch must not reuse another mode's chain
+    classes, n = 100, 100
+    st = weights.synthetic_state(classes, 4242)
+    seg = make_net(st, classes)
+    crops = torch.zeros((n, 80, 80), dtype=torch.uint8, device="cuda")
+    probs = torch.zeros((n, classes), dtype=torch.float32, device="cuda")
+    for rep in range(5):
+        c = weights.synthetic_crops(n, 700 + rep)[..., 0]
+        crops.copy_(torch.from_numpy(c).cuda())
+        if rep == 3:
+            seg.set_identity_precision(capi.CNN_BF16X6)
+        seg.identify_device(crops.data_ptr(), n, probs.data_ptr())
+        seg.synchronize()
+        want, _ = cnn_oracle.predict(st, c[..., None], threads=8)
+        assert np.abs(probs.cpu().numpy() - want).max() <= 1e-4, rep
+    # a second output buffer and another batch size: their own chains
+    probs2 = torch.zeros((37, classes), dtype=torch.float32, device="cuda")
+    for rep in range(3):
+        seg.identify_device(crops.data_ptr(), 37, probs2.data_ptr())
+        seg.synchronize()
+        assert np.abs(probs2.cpu().numpy() - want[:37]).max() <= 1e-4
+    seg.close()

@@ -20,6 +20,7 @@
 #include "conv_f32.h"
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -1553,10 +1554,22 @@ struct Net {
     float *act1 = nullptr, *act2 = nullptr, *act3 = nullptr, *fc1 = nullptr, *probs = nullptr, *logits = nullptr;
     uint8_t* crops = nullptr;
     float* h_probs = nullptr;
+    // small batches are launch-bound (one frame's 100 crops: 60 us of convolutions in a 160 us chain of ~12 launches): the chain of one
+    // identify call is captured into a hipGraph per (buffers, n, precision) and replayed
+    struct GraphEntry { const uint8_t* crops; int n; float* probs; float* logits; int mode, geom; hipStream_t stream; hipGraphExec_t exec; uint64_t used; };
+    std::vector<GraphEntry> graphs;
+    bool graphs_ok = true;
+    uint64_t tick = 0;
 };
+
+static void drop_graphs(Net* n) {
+    for (auto& g : n->graphs) (void)hipGraphExecDestroy(g.exec);
+    n->graphs.clear();
+}
 
 static void free_net(Net* n) {
     if (!n) return;
+    drop_graphs(n);
     float* d[] = {n->w1, n->b1, n->w2, n->b2, n->w3, n->b3, n->wf1, n->bf1, n->lng, n->lnb, n->wf2t, n->bf2,
                   n->act1, n->act2, n->act3, n->fc1, n->probs, n->logits};
     for (float* p : d) if (p) (void)hipFree(p);
@@ -1854,6 +1867,7 @@ int net_load(trexhip_ctx* ctx, const void* blob, size_t bytes) {
 
 static int ensure_act(trexhip_ctx* ctx, Net* net, int n) {
     if (n <= net->max_crops) return TREXHIP_OK;
+    drop_graphs(net);                                      // the captured chains point into the buffers that are replaced here
     float** bufs[] = {&net->act1, &net->act2, &net->act3, &net->fc1, &net->probs, &net->logits};
     for (float** b : bufs) if (*b) { (void)hipFree(*b); *b = nullptr; }
     if (net->crops) { (void)hipFree(net->crops); net->crops = nullptr; }
@@ -1872,7 +1886,7 @@ static int ensure_act(trexhip_ctx* ctx, Net* net, int n) {
     return TREXHIP_OK;
 }
 
-int net_forward(trexhip_ctx* ctx, const uint8_t* d_crops, int n, float* d_probs, float* d_logits) {
+static int net_forward_launch(trexhip_ctx* ctx, const uint8_t* d_crops, int n, float* d_probs, float* d_logits) {
     Net* net = static_cast<Net*>(ctx->net);
     hipStream_t s = ctx->stream;
     using G2 = ConvGeom<16, 64, 40, 20, 16>;
@@ -2025,6 +2039,50 @@ int net_forward(trexhip_ctx* ctx, const uint8_t* d_crops, int n, float* d_probs,
 #undef LAUNCH_SPLITC
 #undef LAUNCH_SPLIT2
     TH_CHECK_HIP(hipGetLastError());
+    return TREXHIP_OK;
+}
+
+static constexpr int GRAPH_MAX_CROPS = 6400;      // above this the kernels themselves dominate
+static constexpr size_t GRAPH_CACHE = 8;
+
+int net_forward(trexhip_ctx* ctx, const uint8_t* d_crops, int n, float* d_probs, float* d_logits) {
+    Net* net = static_cast<Net*>(ctx->net);
+    static const bool enabled = [] { const char* e = std::getenv("TREXHIP_GRAPHS"); return !(e && std::atoi(e) == 0); }();
+    // not while profiling (the stage events are host-side bookkeeping), not before the first plain call (function attributes are set there)
+    if (!enabled || !net->graphs_ok || n > GRAPH_MAX_CROPS || ctx->profiling || !ctx->attr_cnn) return net_forward_launch(ctx, d_crops, n, d_probs, d_logits);
+    hipStream_t s = ctx->stream;
+    const int mode = ctx->cnn_mode, geom = ctx->tune_conv_geom;
+    ++net->tick;
+    for (auto& g : net->graphs)
+        if (g.crops == d_crops && g.n == n && g.probs == d_probs && g.logits == d_logits && g.mode == mode && g.geom == geom && g.stream == s) {
+            g.used = net->tick;
+            TH_CHECK_HIP(hipGraphLaunch(g.exec, s));
+            return TREXHIP_OK;
+        }
+    if (hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) != hipSuccess) {
+        (void)hipGetLastError();
+        net->graphs_ok = false;
+        return net_forward_launch(ctx, d_crops, n, d_probs, d_logits);
+    }
+    const int rc = net_forward_launch(ctx, d_crops, n, d_probs, d_logits);
+    hipGraph_t graph = nullptr;
+    const hipError_t e_end = hipStreamEndCapture(s, &graph);
+    hipGraphExec_t exec = nullptr;
+    if (rc != TREXHIP_OK || e_end != hipSuccess || !graph || hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) != hipSuccess) {
+        (void)hipGetLastError();
+        if (graph) (void)hipGraphDestroy(graph);
+        net->graphs_ok = false;                                   // nothing was executed during the capture: run the chain directly, from now on always
+        return net_forward_launch(ctx, d_crops, n, d_probs, d_logits);
+    }
+    (void)hipGraphDestroy(graph);
+    if (net->graphs.size() >= GRAPH_CACHE) {                      // evict the least recently used chain
+        size_t lru = 0;
+        for (size_t i = 1; i < net->graphs.size(); ++i) if (net->graphs[i].used < net->graphs[lru].used) lru = i;
+        (void)hipGraphExecDestroy(net->graphs[lru].exec);
+        net->graphs.erase(net->graphs.begin() + (long)lru);
+    }
+    net->graphs.push_back({d_crops, n, d_probs, d_logits, mode, geom, s, exec, net->tick});
+    TH_CHECK_HIP(hipGraphLaunch(exec, s));
     return TREXHIP_OK;
 }
 
