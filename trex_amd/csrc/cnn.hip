@@ -20,6 +20,7 @@
 #include "conv_f32.h"
 #include <algorithm>
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <vector>
@@ -109,7 +110,9 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 f16x8_c1 __attribute__((ext_vector_type(8)));
 
 __global__ __launch_bounds__(256) void k_conv1_mfma(const uint8_t* __restrict__ crops, const uint4* __restrict__ wtab /*[16][64]*/,
-                                                    const float* __restrict__ bias, float* __restrict__ out, const float inv_scale) {
+                                                    const float* __restrict__ bias, float* __restrict__ out, const float inv_scale,
+                                                    const uint32_t* __restrict__ guard) {
+    if (guard && *guard == 0u) return;                      // guarded re-run of the default chain: nothing to do unless the fp16 range flag is up
     constexpr int S = 80, PH = 84, PITCH = 88;              // halves per padded row (176 B: rows land on distinct bank groups)
     __shared__ __attribute__((aligned(16))) _Float16 img[PH * PITCH];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -182,7 +185,9 @@ __global__ __launch_bounds__(256) void k_conv1_mfma(const uint8_t* __restrict__ 
 // the same for 3-channel crops (meta_encoding rgb8): one fp16 plane per channel in LDS; per shift four MFMAs of K = 32:
 // channel 0 / 1 / 2 with kernel rows 0..3, and a fourth whose k-octets 0..2 hold kernel row 4 of the three channels
 __global__ __launch_bounds__(256) void k_conv1_mfma3(const uint8_t* __restrict__ crops /*[N][80][80][3]*/, const uint4* __restrict__ wtab /*[32][64]*/,
-                                                     const float* __restrict__ bias, float* __restrict__ out, const float inv_scale) {
+                                                     const float* __restrict__ bias, float* __restrict__ out, const float inv_scale,
+                                                     const uint32_t* __restrict__ guard) {
+    if (guard && *guard == 0u) return;
     constexpr int S = 80, PH = 84, PITCH = 88, PLANE = PH * PITCH;
     __shared__ __attribute__((aligned(16))) _Float16 img[3 * PLANE];
     __shared__ __attribute__((aligned(16))) float tr[4][64 * 17];
@@ -1314,6 +1319,8 @@ __global__ __launch_bounds__(256) void k_conv5_wino1(const float* __restrict__ i
     if (__any(!(mxabs < 4368.0f)) && lane == 0) atomicOr(overflow, 1u);
 }
 
+#include "cnn_wpre.h"
+
 static constexpr int FC1_KSPLIT = 10;     // 12800 = 10 x 1280: 500 workgroups at 6400 crops (5: 129 us, 10: 92 us, 20: 102 us + slower head); partial planes summed in k_head
 // ------------------------------------------------------------------------------------------------
 // fc1: out[N][128] = act[N][K] * W[K][128] + b     (K = 12800, 100 real outputs)
@@ -1552,6 +1559,7 @@ struct Net {
     float *w1 = nullptr, *b1 = nullptr, *w2 = nullptr, *b2 = nullptr, *w3 = nullptr, *b3 = nullptr;
     float *wf1 = nullptr, *bf1 = nullptr, *lng = nullptr, *lnb = nullptr, *wf2t = nullptr, *bf2 = nullptr;
     float *act1 = nullptr, *act2 = nullptr, *act3 = nullptr, *fc1 = nullptr, *probs = nullptr, *logits = nullptr;
+    uint8_t *v2 = nullptr, *v3 = nullptr;      // Winograd-domain operand images of conv2 / conv3 (fp16 pieces), written by the producing layer (cnn_wpre.h)
     uint8_t* crops = nullptr;
     float* h_probs = nullptr;
     // small batches are launch-bound (one frame's 100 crops: 60 us of convolutions in a 160 us chain of ~12 launches): the chain of one
@@ -1582,6 +1590,8 @@ static void free_net(Net* n) {
     if (n->w1h) (void)hipFree(n->w1h);
     if (n->wf1h) (void)hipFree(n->wf1h);
     if (n->d_ovf) (void)hipFree(n->d_ovf);
+    if (n->v2) (void)hipFree(n->v2);
+    if (n->v3) (void)hipFree(n->v3);
     if (n->crops) (void)hipFree(n->crops);
     if (n->h_probs) (void)hipHostFree(n->h_probs);
     delete n;
@@ -1870,6 +1880,8 @@ static int ensure_act(trexhip_ctx* ctx, Net* net, int n) {
     drop_graphs(net);                                      // the captured chains point into the buffers that are replaced here
     float** bufs[] = {&net->act1, &net->act2, &net->act3, &net->fc1, &net->probs, &net->logits};
     for (float** b : bufs) if (*b) { (void)hipFree(*b); *b = nullptr; }
+    if (net->v2) { (void)hipFree(net->v2); net->v2 = nullptr; }
+    if (net->v3) { (void)hipFree(net->v3); net->v3 = nullptr; }
     if (net->crops) { (void)hipFree(net->crops); net->crops = nullptr; }
     if (net->h_probs) { (void)hipHostFree(net->h_probs); net->h_probs = nullptr; }
     const size_t N = n;
@@ -1879,6 +1891,8 @@ static int ensure_act(trexhip_ctx* ctx, Net* net, int n) {
     TH_CHECK_HIP(hipMalloc(reinterpret_cast<void**>(&net->fc1), N * 128 * 4 * FC1_KSPLIT));
     TH_CHECK_HIP(hipMalloc(reinterpret_cast<void**>(&net->probs), N * net->classes * 4));
     TH_CHECK_HIP(hipMalloc(reinterpret_cast<void**>(&net->logits), N * net->classes * 4));
+    TH_CHECK_HIP(hipMalloc(reinterpret_cast<void**>(&net->v2), N * 40 * V2_ROWB));
+    TH_CHECK_HIP(hipMalloc(reinterpret_cast<void**>(&net->v3), N * 20 * V3_ROWB));
     TH_CHECK_HIP(hipMalloc(reinterpret_cast<void**>(&net->crops), N * net->W * net->H * net->CH));
     TH_CHECK_HIP(hipHostMalloc(reinterpret_cast<void**>(&net->h_probs), N * net->classes * 4, hipHostMallocDefault));
     net->max_crops = n;
@@ -1909,6 +1923,23 @@ static int net_forward_launch(trexhip_ctx* ctx, const uint8_t* d_crops, int n, f
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (ConvGeomS<16, 64, 40, 8, 4>::LDS_BYTES)));
         TH_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv5_stream<64, 128, 20, 20, 8, true>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (ConvGeomS<64, 128, 20, 20, 8>::LDS_BYTES)));
+#define W2A(D_) W2AB(D_, 7)
+#define W2AB(D_, B_) TH_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv2_wpre<D_, B_>), hipFuncAttributeMaxDynamicSharedMemorySize, W2Geom::LDS_BYTES))
+#define W3A(D_) W3AB(D_, 7)
+#define W3AB(D_, B_) TH_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv5_wpre<D_, B_>), hipFuncAttributeMaxDynamicSharedMemorySize, (WinoGeom<64, 128, 20, 2>::LDS_BYTES)))
+#define W2BA(D_) W2BAS(D_, 5)
+#define W2BAS(D_, S_) TH_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv2_wpre2<D_, S_>), hipFuncAttributeMaxDynamicSharedMemorySize, W2bGeom::LDS_BYTES))
+        W2A(0); W3A(0); W2BA(0);
+#ifdef TREXHIP_DEV_KNOBS
+        W2BA(1); W2BA(2); W2BA(3); W2BA(7); W2BA(15); W2BA(32); W2BAS(0, 0); W2BAS(0, 3); W2BAS(0, 8); W2BAS(64, 5); W2BAS(128, 5); W2BAS(192, 0); W2BAS(128, 0); W2BAS(64, 0);
+        W2A(1); W2A(2); W2A(3); W2A(7); W2A(15); W2A(32); W2A(16); W2AB(0, 3); W2AB(0, 5); W3A(1); W3A(2); W3A(3); W3A(7); W3A(15); W3A(16); W3AB(0, 3); W3AB(0, 5); TH_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv5_wpre<0, 7, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (WinoGeom<64, 128, 20, 2>::LDS_BYTES)));
+#endif
+#undef W2A
+#undef W3A
+#undef W2AB
+#undef W3AB
+#undef W2BA
+#undef W2BAS
 #define W1A(D_) TH_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv5_wino1<64, 40, D_>), hipFuncAttributeMaxDynamicSharedMemorySize, (WinoGeom1<64, 40>::LDS_BYTES)))
         W1A(0);
 #ifdef TREXHIP_DEV_KNOBS
@@ -1929,18 +1960,32 @@ static int net_forward_launch(trexhip_ctx* ctx, const uint8_t* d_crops, int n, f
 #undef WA
 #undef SET_ATTR
 #undef SET_ATTRC
+        if (std::getenv("TREXHIP_DEBUG_OCC")) {      // dev: resident workgroups per CU of the persistent convolutions
+            int nb2 = 0, nb3 = 0;
+            (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb2, reinterpret_cast<const void*>(&k_conv2_wpre2<0, 5>), 256, W2bGeom::LDS_BYTES);
+            (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb3, reinterpret_cast<const void*>(&k_conv5_wpre<0, 7>), 256, (WinoGeom<64, 128, 20, 2>::LDS_BYTES));
+            fprintf(stderr, "[trexhip] workgroups per CU: k_conv2_wpre2 %d (LDS %d), k_conv5_wpre %d\n", nb2, (int)W2bGeom::LDS_BYTES, nb3);
+        }
         ctx->attr_cnn = true;
     }
     stage_begin(ctx, TREXHIP_STAGE_CNN_ALL);
     const int S = net->W;
     const size_t lds1 = ((size_t)net->CH * (S + 4) * (S + 4) + (size_t)net->CH * 25 * 16) * 4;
-    // the matrix-core conv1 reads the crops with 16-byte loads: unaligned crop buffers take the VALU kernel
-    if (net->CH == 1 && !(ctx->tune_conv_geom & 16) && (reinterpret_cast<uintptr_t>(d_crops) & 15) == 0) hipLaunchKernelGGL(k_conv1_mfma, dim3(n), dim3(256), 0, s, d_crops, net->w1h, net->b1, net->act1, net->inv1h);
-    else if (net->CH == 1) hipLaunchKernelGGL((k_conv1<1>), dim3(n), dim3(256), lds1, s, d_crops, net->w1, net->b1, net->act1, S);
-    else if (net->CH == 3 && !(ctx->tune_conv_geom & 16) && (reinterpret_cast<uintptr_t>(d_crops) & 15) == 0) hipLaunchKernelGGL(k_conv1_mfma3, dim3(n), dim3(256), 0, s, d_crops, net->w1h, net->b1, net->act1, net->inv1h);
-    else              hipLaunchKernelGGL((k_conv1<3>), dim3(n), dim3(256), lds1, s, d_crops, net->w1, net->b1, net->act1, S);
     const int mode = ctx->cnn_mode;
+    // the matrix-core conv1 kernels read the crops with 16-byte loads: unaligned crop buffers take the VALU kernel (and the fp32-activation chain)
+    const bool aligned = (reinterpret_cast<uintptr_t>(d_crops) & 15) == 0;
+    // default chain (cnn_wpre.h): the Winograd-domain fp16 operand images V2 / V3 are written by the producing layer.  Any of the older
+    // geometry bits of TREXHIP_CONV_GEOM (bit 11 = nothing else) selects the fp32-activation chain of rounds 1-2 instead.
+    const bool pre = mode == TREXHIP_CNN_FP16X3 && aligned && (ctx->tune_conv_geom & 0xfff) == 0;
     if (mode == TREXHIP_CNN_FP16X3) TH_CHECK_HIP(hipMemsetAsync(net->d_ovf, 0, 16, s));    // [0] fp16 range flag, [1] / [2] pass counters of the persistent conv3 / conv2
+    if (pre) {
+        if (net->CH == 1) hipLaunchKernelGGL((k_conv1_wpre<1>), dim3(n), dim3(256), 0, s, d_crops, net->w1h, net->b1, net->v2, net->inv1h, net->d_ovf);
+        else              hipLaunchKernelGGL((k_conv1_wpre<3>), dim3(n), dim3(256), 0, s, d_crops, net->w1h, net->b1, net->v2, net->inv1h, net->d_ovf);
+    }
+    else if (net->CH == 1 && !(ctx->tune_conv_geom & 16) && aligned) hipLaunchKernelGGL(k_conv1_mfma, dim3(n), dim3(256), 0, s, d_crops, net->w1h, net->b1, net->act1, net->inv1h, (const uint32_t*)nullptr);
+    else if (net->CH == 1) hipLaunchKernelGGL((k_conv1<1>), dim3(n), dim3(256), lds1, s, d_crops, net->w1, net->b1, net->act1, S);
+    else if (net->CH == 3 && !(ctx->tune_conv_geom & 16) && aligned) hipLaunchKernelGGL(k_conv1_mfma3, dim3(n), dim3(256), 0, s, d_crops, net->w1h, net->b1, net->act1, net->inv1h, (const uint32_t*)nullptr);
+    else              hipLaunchKernelGGL((k_conv1<3>), dim3(n), dim3(256), lds1, s, d_crops, net->w1, net->b1, net->act1, S);
 #define LAUNCH_SPLIT2 LAUNCH_SPLIT
     stage_begin(ctx, TREXHIP_STAGE_CONV2);
 #define LAUNCH_SPLIT(CI_, CO_, S_, ROWS_, KIND_, NT_, in_, w_, b_, out_, sc_, guard_) LAUNCH_SPLITC(CI_, CO_, S_, ROWS_, KIND_, NT_, 16, in_, w_, b_, out_, sc_, guard_)
@@ -1950,7 +1995,35 @@ static int net_forward_launch(trexhip_ctx* ctx, const uint8_t* d_crops, int n, f
                                      : n * (ConvGeomB<CI_, CO_, S_, ROWS_, SplitK<KIND_>::NP, CIC_>::BPC)),                                          \
                        dim3(512), (ConvGeomB<CI_, CO_, S_, ROWS_, SplitK<KIND_>::NP, CIC_>::LDS_BYTES), s, in_, w_, b_, out_, sc_, net->d_ovf, guard_, \
                        n * (ConvGeomB<CI_, CO_, S_, ROWS_, SplitK<KIND_>::NP, CIC_>::BPC))
-    if (mode == TREXHIP_CNN_FP32)
+    if (pre && !(ctx->tune_conv_geom & (1 << 22))) {
+        // two workgroups per CU, one M-tile per wave, operand planes fetched by LDS-DMA during the epilogue (bit 22: the one-workgroup form below)
+        const int n_pass = (n * 20 + W2bGeom::RPP - 1) / W2bGeom::RPP;
+#define W2K(D_) W2KS(D_, 5)
+        const int wgs = ((ctx->tune_conv_geom >> 23) & 1) ? ctx->n_cus : 2 * ctx->n_cus;     // dev: bit 23 = one workgroup per CU
+#define W2KS(D_, S_) hipLaunchKernelGGL((k_conv2_wpre2<D_, S_>), dim3(n_pass < wgs ? n_pass : wgs), dim3(256), W2bGeom::LDS_BYTES, s, \
+                           net->v2, net->w2w, net->b2, net->v3, net->inv2w, net->d_ovf, n, net->d_ovf + 2)
+#ifdef TREXHIP_DEV_KNOBS   // ablations: TREXHIP_CONV_GEOM bits 16..21 = 1 no staging, 2 no epilogue, 4 no weight loads, 8 no A reads, 32 no V3 transform
+        switch ((ctx->tune_conv_geom >> 16) & 63) { case 1: W2K(1); break; case 2: W2K(2); break; case 3: W2K(3); break; case 7: W2K(7); break; case 15: W2K(15); break; case 32: W2K(32); break; case 40: W2KS(0, 0); break; case 41: W2KS(0, 3); break; case 42: W2KS(0, 8); break; case 43: W2KS(64, 5); break; case 44: W2KS(128, 5); break; case 45: W2KS(192, 0); break; case 46: W2KS(128, 0); break; case 47: W2KS(64, 0); break; default: W2K(0); }
+#else
+        W2K(0);
+#endif
+#undef W2K
+#undef W2KS
+    }
+    else if (pre) {
+        const int n_pass = (n * 20 + W2Geom::RPP - 1) / W2Geom::RPP;
+#define W2K(D_) W2KB(D_, 7)
+#define W2KB(D_, B_) hipLaunchKernelGGL((k_conv2_wpre<D_, B_>), dim3(n_pass < ctx->n_cus ? n_pass : ctx->n_cus), dim3(256), W2Geom::LDS_BYTES, s, \
+                           net->v2, net->w2w, net->b2, net->v3, net->inv2w, net->d_ovf, n, net->d_ovf + 2)
+#ifdef TREXHIP_DEV_KNOBS
+        switch ((ctx->tune_conv_geom >> 16) & 63) { case 1: W2K(1); break; case 2: W2K(2); break; case 3: W2K(3); break; case 7: W2K(7); break; case 15: W2K(15); break; case 32: W2K(32); break; case 16: W2K(16); break; case 48: W2KB(0, 3); break; case 49: W2KB(0, 5); break; default: W2K(0); }
+#else
+        W2K(0);
+#endif
+#undef W2K
+#undef W2KB
+    }
+    else if (mode == TREXHIP_CNN_FP32)
         hipLaunchKernelGGL((k_conv5<16, 64, 40, 20, 16>), dim3(n * G2::BPC), dim3(512), G2::LDS_BYTES, s, net->act1, net->w2, net->b2, net->act2);
     else if (mode == TREXHIP_CNN_BF16X6) LAUNCH_SPLIT(16, 64, 40, 10, 0, 6, net->act1, net->w2s, net->b2, net->act2, 1.0f, (const uint32_t*)nullptr);
     else if (mode == TREXHIP_CNN_BF16X3) LAUNCH_SPLIT(16, 64, 40, 10, 0, 3, net->act1, net->w2s, net->b2, net->act2, 1.0f, (const uint32_t*)nullptr);
@@ -1982,7 +2055,21 @@ static int net_forward_launch(trexhip_ctx* ctx, const uint8_t* d_crops, int n, f
     else                                 LAUNCH_SPLIT(16, 64, 40, 10, 1, 3, net->act1, net->w2h, net->b2, net->act2, net->inv2h, (const uint32_t*)nullptr);
     stage_end(ctx, TREXHIP_STAGE_CONV2);
     stage_begin(ctx, TREXHIP_STAGE_CONV3);
-    if (mode == TREXHIP_CNN_FP32)
+    if (pre) {
+        using GW = WinoGeom<64, 128, 20, 2>;
+        const int n_pass = (n * GW::TPC + GW::MB - 1) / GW::MB;
+#define W3K(D_) W3KB(D_, 7)
+#define W3KB(D_, B_) hipLaunchKernelGGL((k_conv5_wpre<D_, B_>), dim3(n_pass < ctx->n_cus ? n_pass : ctx->n_cus), dim3(256), GW::LDS_BYTES, s, \
+                           net->v3, net->w3w, net->b3, net->act3, net->inv3w, n, net->d_ovf + 1)
+#ifdef TREXHIP_DEV_KNOBS
+        switch ((ctx->tune_conv_geom >> 24) & 15) { case 1: W3K(1); break; case 2: W3K(2); break; case 3: W3K(3); break; case 7: W3K(7); break; case 15: W3K(15); break; case 8: W3K(16); break; case 9: W3KB(0, 3); break; case 10: W3KB(0, 5); break; case 11: hipLaunchKernelGGL((k_conv5_wpre<0, 7, 1>), dim3(n_pass < ctx->n_cus ? n_pass : ctx->n_cus), dim3(256), GW::LDS_BYTES, s, net->v3, net->w3w, net->b3, net->act3, net->inv3w, n, net->d_ovf + 1); break; default: W3K(0); }
+#else
+        W3K(0);
+#endif
+#undef W3K
+#undef W3KB
+    }
+    else if (mode == TREXHIP_CNN_FP32)
         hipLaunchKernelGGL((k_conv5<64, 128, 20, 20, 32>), dim3(n * G3::BPC), dim3(512), G3::LDS_BYTES, s, net->act2, net->w3, net->b3, net->act3);
     else if (mode == TREXHIP_CNN_BF16X6) LAUNCH_SPLIT(64, 128, 20, 20, 0, 6, net->act2, net->w3s, net->b3, net->act3, 1.0f, (const uint32_t*)nullptr);
     else if (mode == TREXHIP_CNN_BF16X3) LAUNCH_SPLIT(64, 128, 20, 20, 0, 3, net->act2, net->w3s, net->b3, net->act3, 1.0f, (const uint32_t*)nullptr);
@@ -2028,6 +2115,10 @@ static int net_forward_launch(trexhip_ctx* ctx, const uint8_t* d_crops, int n, f
     if (mode == TREXHIP_CNN_FP16X3) {
         // guarded re-run with the bf16 split: every workgroup returns at once unless an activation left the fp16 range
         const uint32_t* g = net->d_ovf;
+        if (pre) {      // the default chain has no fp32 activations: the re-run starts at the crops
+            if (net->CH == 1) hipLaunchKernelGGL(k_conv1_mfma, dim3(n), dim3(256), 0, s, d_crops, net->w1h, net->b1, net->act1, net->inv1h, g);
+            else              hipLaunchKernelGGL(k_conv1_mfma3, dim3(n), dim3(256), 0, s, d_crops, net->w1h, net->b1, net->act1, net->inv1h, g);
+        }
         LAUNCH_SPLIT2(16, 64, 40, 10, 0, 6, net->act1, net->w2s, net->b2, net->act2, 1.0f, g);
         LAUNCH_SPLIT2(64, 128, 20, 20, 0, 6, net->act2, net->w3s, net->b3, net->act3, 1.0f, g);
         hipLaunchKernelGGL(k_fc1, dim3((n + 31) / 32, FC1_KSPLIT), dim3(256), 0, s, net->act3, net->wf1, net->bf1, net->fc1, n, 12800, g);
