@@ -1932,7 +1932,7 @@ static int net_forward_launch(trexhip_ctx* ctx, const uint8_t* d_crops, int n, f
         W2A(0); W3A(0); W2BA(0);
 #ifdef TREXHIP_DEV_KNOBS
         W2BA(1); W2BA(2); W2BA(3); W2BA(7); W2BA(15); W2BA(32); W2BAS(0, 0); W2BAS(0, 3); W2BAS(0, 8); W2BAS(64, 5); W2BAS(128, 5); W2BAS(192, 0); W2BAS(128, 0); W2BAS(64, 0);
-        W2A(1); W2A(2); W2A(3); W2A(7); W2A(15); W2A(32); W2A(16); W2AB(0, 3); W2AB(0, 5); W3A(1); W3A(2); W3A(3); W3A(7); W3A(15); W3A(16); W3AB(0, 3); W3AB(0, 5); TH_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv5_wpre<0, 7, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (WinoGeom<64, 128, 20, 2>::LDS_BYTES)));
+        W2A(1); W2A(2); W2A(3); W2A(7); W2A(15); W2A(32); W2A(16); W2AB(0, 3); W2AB(0, 5); W3A(1); W3A(2); W3A(3); W3A(7); W3A(15); W3A(16); W3AB(0, 3); W3AB(0, 5); W3A(64); W3A(128); TH_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv5_wpre<0, 7, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (WinoGeom<64, 128, 20, 2>::LDS_BYTES)));
 #endif
 #undef W2A
 #undef W3A
@@ -2062,7 +2062,7 @@ static int net_forward_launch(trexhip_ctx* ctx, const uint8_t* d_crops, int n, f
 #define W3KB(D_, B_) hipLaunchKernelGGL((k_conv5_wpre<D_, B_>), dim3(n_pass < ctx->n_cus ? n_pass : ctx->n_cus), dim3(256), GW::LDS_BYTES, s, \
                            net->v3, net->w3w, net->b3, net->act3, net->inv3w, n, net->d_ovf + 1)
 #ifdef TREXHIP_DEV_KNOBS
-        switch ((ctx->tune_conv_geom >> 24) & 15) { case 1: W3K(1); break; case 2: W3K(2); break; case 3: W3K(3); break; case 7: W3K(7); break; case 15: W3K(15); break; case 8: W3K(16); break; case 9: W3KB(0, 3); break; case 10: W3KB(0, 5); break; case 11: hipLaunchKernelGGL((k_conv5_wpre<0, 7, 1>), dim3(n_pass < ctx->n_cus ? n_pass : ctx->n_cus), dim3(256), GW::LDS_BYTES, s, net->v3, net->w3w, net->b3, net->act3, net->inv3w, n, net->d_ovf + 1); break; default: W3K(0); }
+        switch ((ctx->tune_conv_geom >> 24) & 15) { case 1: W3K(1); break; case 2: W3K(2); break; case 3: W3K(3); break; case 7: W3K(7); break; case 15: W3K(15); break; case 8: W3K(16); break; case 9: W3KB(0, 3); break; case 10: W3KB(0, 5); break; case 12: W3K(64); break; case 13: W3K(128); break; case 11: hipLaunchKernelGGL((k_conv5_wpre<0, 7, 1>), dim3(n_pass < ctx->n_cus ? n_pass : ctx->n_cus), dim3(256), GW::LDS_BYTES, s, net->v3, net->w3w, net->b3, net->act3, net->inv3w, n, net->d_ovf + 1); break; default: W3K(0); }
 #else
         W3K(0);
 #endif

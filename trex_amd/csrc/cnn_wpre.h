@@ -717,7 +717,7 @@ __global__ __launch_bounds__(256) void k_conv5_wpre(const uint8_t* __restrict__ 
         const int pl = i / (G::RP / 16), o = i - pl * (G::RP / 16);
         *reinterpret_cast<uint4*>(ldsb + pl * G::PLANE + o * 16) = make_uint4(0, 0, 0, 0);
     }
-    uint4 sreg[13];
+    uint4 sreg[13] = {};
     __amdgpu_buffer_rsrc_t srs = make_rsrc(v3, 0);
     // (the LDS address of a unit is recomputed at its store: see k_conv2_wpre)
 #define W3_UNIT(k_, nrows_)                                                                                                      \
@@ -824,8 +824,8 @@ __global__ __launch_bounds__(256) void k_conv5_wpre(const uint8_t* __restrict__ 
                 }
                 if (!(DBG & 1)) {
                     // ONE batch of loads per chunk: every batch of HBM misses holds back the weight fragments queued behind it once
-                    if (t == 0) { _Pragma("unroll") for (int k = 0; k < 13; ++k) W3_L(k, k, scc, sqmin, snrows); }
-                    if (t >= 16 && t < 29) W3_S(t - 16, t - 16, snrows, nbase);
+                    if (t == 0 && !(DBG & 128)) { _Pragma("unroll") for (int k = 0; k < 13; ++k) W3_L(k, k, scc, sqmin, snrows); }
+                    if (t >= 16 && t < 29 && !(DBG & 64)) W3_S(t - 16, t - 16, snrows, nbase);
                 }
                 const int p = t % 8;
                 const f16x8 b1 = __builtin_bit_cast(f16x8, bq[t % 8][0]);
