@@ -54,3 +54,36 @@ def test_two_rank_launch_on_one_gpu_runs_the_gather_path():
     j = json.loads([l for l in out.stdout.strip().splitlines() if l.startswith("{")][-1])
     assert j["n_gpus"] == 2 and j["scaling"] == "weak" and j["config"]["gather"].startswith("libtrexhip")
     assert abs(j["value"] - 2 * 16 * 2 / (j["ms_per_step"] * 2e-3)) / j["value"] < 1e-6      # whole-job frames / slowest rank's time
+
+
+def test_gpus_flag_spawns_its_own_ranks():
+    # `python bench.py --gpus 2` without a launcher must not report an N = 1 number under n_gpus = 2: it starts the two ranks itself
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "16", "--same-gpu",
+                          "--no-cpu-baseline"], capture_output=True, text=True, timeout=420, cwd=ROOT,
+                         env={k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")})
+    if out.returncode != 0 and ("Duplicate GPU" in out.stderr or "No socket interfaces" in out.stderr):
+        pytest.skip("RCCL cannot run two ranks on one GPU here")
+    assert out.returncode == 0, out.stderr[-3000:]
+    j = json.loads([l for l in out.stdout.strip().splitlines() if l.startswith("{")][-1])
+    assert j["n_gpus"] == 2 and abs(j["value"] - 2 * 16 * 2 / (j["ms_per_step"] * 2e-3)) / j["value"] < 1e-6
+
+
+def test_a_launcher_that_started_the_wrong_number_of_ranks_is_an_error():
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--batch", "4", "--no-cpu-baseline"],
+                         capture_output=True, text=True, timeout=300, cwd=ROOT, env=env)
+    assert out.returncode != 0 and "--gpus 2" in out.stderr
+
+
+def test_secondary_runs_ride_in_the_same_line():
+    # the other configurations / input paths / the N > 1 code path at N = 1 / the training step, each with its own roofline
+    j = run("--no-cpu-baseline", "--secondary-only", "C2,C4_force_dist,train_step")
+    s = j["secondary"]
+    assert set(s) == {"C2", "C4_force_dist", "train_step"}
+    for name, e in s.items():
+        assert "error" not in e, (name, e)
+        assert e["value"] > 0 and "roofline" in e and 0 < e["roofline"]["frac"] < 1.5, (name, e)
+    assert s["C2"]["roofline"]["bound"] == "hbm" and s["train_step"]["roofline"]["peak"] == 157.3
+    # the N > 1 code path with one rank (library communicator, gather) is the same pipeline as the default run of the same shape
+    assert "roofline_kernels" in j and set(j["roofline_kernels"]) == {"conv2", "conv3"}
+    assert j["roofline"]["kernel"] in (j["roofline_kernels"]["conv2"]["kernel"], j["roofline_kernels"]["conv3"]["kernel"])

@@ -209,15 +209,34 @@ def test_library_drawn_masks_and_argument_checks():
         tr.step_device(dx.data_ptr(), dy.data_ptr(), 0)
     with pytest.raises(capi.TrexHipError):
         tr.set_lr(0.0)
-    # a class index out of range in device memory: flagged by the kernel, the synchronising call and later reads are refused
+    # a class index out of range in device memory (the reference asserts it before touching the model, visual_recognition_torch.py:1109-1112):
+    # the device refuses that step AND the steps queued behind it, the next synchronising call reports it, and nothing has changed --
+    # parameters, Adam moments, running statistics, step count
+    before = [read_all(tr, classes, ch, kind) for kind in (0, 2, 3)]
+    steps_before = tr.steps
     x, y = weights.synthetic_train_batch(n, 41, classes, ch)
-    y[3] = classes
+    ybad = y.copy(); ybad[3] = classes
+    dxb, dyb, dyg = torch.from_numpy(x).cuda(), torch.from_numpy(ybad.astype(np.int32)).cuda(), torch.from_numpy(y.astype(np.int32)).cuda()
+    tr.step_device(dxb.data_ptr(), dyb.data_ptr(), n, 0, want_loss=False)        # refused on the device, not yet reported
+    tr.step_device(dxb.data_ptr(), dyg.data_ptr(), n, 0, want_loss=False)        # queued behind it: refused as well
+    with pytest.raises(capi.TrexHipError, match="refused"):
+        tr.step_device(dxb.data_ptr(), dyg.data_ptr(), n, 0, want_loss=True)
+    assert tr.steps == steps_before
+    after = [read_all(tr, classes, ch, kind) for kind in (0, 2, 3)]
+    for b, a in zip(before, after):
+        for name in b:
+            assert np.array_equal(b[name], a[name]), name
+    loss, correct = step(tr, x, y, None)                              # the trainer goes on where it was
+    assert np.isfinite(loss) and tr.steps == steps_before + 1
+    tr.export()
     with pytest.raises(capi.TrexHipError):
-        step(tr, x, y, None)
-    with pytest.raises(capi.TrexHipError):
-        tr.export()
-    with pytest.raises(capi.TrexHipError):
-        tr.step(x, y)                                                 # host entry point: checked before anything is uploaded
+        tr.step(x, ybad)                                              # host entry point: checked before anything is uploaded
+    with pytest.raises(ValueError):
+        tr.step(x[:, :40], y)                                         # wrong image size: refused before the raw pointer is handed over
+    with pytest.raises(ValueError):
+        tr.step(x, y.astype(np.float32))
+    with pytest.raises(ValueError):
+        tr.step(x, y, np.ones(5, np.uint8))
     tr.close()
     with pytest.raises(capi.TrexHipError):
         capi.Trainer(seg, weights.pack_blob(state, classes, ch)[:-4], max_batch=16)

@@ -86,3 +86,9 @@ def test_short_real_run_learns_and_keeps_the_schedule():
     assert hist[-1]["val_loss"] < hist[0]["val_loss"] and hist[-1]["val_acc"] >= hist[0]["val_acc"]
     assert all(np.isfinite(h["loss"]) for h in hist)
     tr.close(); seg.close()
+
+
+def test_float_labels_are_refused_like_the_reference_asserts():
+    # visual_recognition_torch.py:1109-1110 asserts integer class labels per batch; a float array would be cast silently otherwise
+    with pytest.raises(ValueError):
+        train_loop.train(FakeTrainer(), [(np.zeros((4, 80, 80, 1), np.float32), np.zeros(4, np.float32))], [], Recorder(), None, {"epochs": 1})

@@ -63,12 +63,12 @@ def main():
     ap.add_argument("src"); ap.add_argument("dst")
     ap.add_argument("--width", type=int, default=None); ap.add_argument("--height", type=int, default=None)
     ap.add_argument("--channels", type=int, default=None)
+    ap.add_argument("--unsafe-pickle", action="store_true",
+                    help="load with weights_only=False (arbitrary pickle code runs!): only for a checkpoint you wrote yourself; the reference loads with weights_only=True (trex_utils.py:122)")
     a = ap.parse_args()
     import torch
-    try:
-        obj = torch.load(a.src, map_location="cpu", weights_only=True)
-    except Exception:
-        obj = torch.load(a.src, map_location="cpu", weights_only=False)     # checkpoints with a pickled metadata dict
+    # weights_only=True like the reference; no silent fallback -- a crafted file could fail the safe path on purpose to reach the pickle loader
+    obj = torch.load(a.src, map_location="cpu", weights_only=not a.unsafe_pickle)
     blob, classes, w, h, c = convert(obj, a.width, a.height, a.channels)
     with open(a.dst, "wb") as f:
         f.write(blob)

@@ -503,11 +503,25 @@ class Trainer:
                                                C.byref(loss) if want_loss else None, C.byref(correct) if want_loss else None))
         return (loss.value, correct.value) if want_loss else None
 
+    def _check_batch(self, inputs, targets):
+        """the reference asserts image size, channel count and integer class labels per batch (visual_recognition_torch.py:1109-1110); the ABI
+        takes raw pointers, so a wrong shape would be an out-of-bounds read, not an error"""
+        x = np.asarray(inputs)
+        if x.ndim != 4 or tuple(x.shape[1:]) != (80, 80, self.channels):
+            raise ValueError(f"inputs must be (n, 80, 80, {self.channels}), got {tuple(x.shape)}")
+        t = np.asarray(targets)
+        if t.dtype.kind not in "iu":
+            raise ValueError(f"targets must be integer class indices, got dtype {t.dtype}")
+        if t.shape != (x.shape[0],):
+            raise ValueError(f"targets must be ({x.shape[0]},), got {tuple(t.shape)}")
+        return np.ascontiguousarray(x, np.float32), np.ascontiguousarray(t, np.int32)
+
     def step(self, inputs, targets, keep_masks=None):
         """host arrays: inputs float32 (n,80,80,C) in [0,255], targets int (n,), keep_masks uint8 (n*308,) or None -> (loss, correct)"""
-        x = np.ascontiguousarray(inputs, np.float32)
-        y = np.ascontiguousarray(targets, np.int32)
+        x, y = self._check_batch(inputs, targets)
         k = np.ascontiguousarray(keep_masks, np.uint8) if keep_masks is not None else None
+        if k is not None and k.size != x.shape[0] * 308:
+            raise ValueError(f"keep_masks holds {k.size} entries, a batch of {x.shape[0]} needs {x.shape[0]} x 308 (16 + 64 + 128 + 100 per sample)")
         loss, correct = C.c_float(), C.c_int32()
         _check(lib().trexhip_train_step(self._h, x.ctypes.data_as(C.c_void_p), y.ctypes.data_as(C.c_void_p), x.shape[0],
                                         k.ctypes.data_as(C.c_void_p) if k is not None else None, C.byref(loss), C.byref(correct)))
@@ -515,8 +529,7 @@ class Trainer:
 
     def evaluate(self, inputs, targets):
         """model.eval() forward of one validation batch (host arrays) -> (mean cross entropy, correct count); the trainer is unchanged"""
-        x = np.ascontiguousarray(inputs, np.float32)
-        y = np.ascontiguousarray(targets, np.int32)
+        x, y = self._check_batch(inputs, targets)
         loss, correct = C.c_float(), C.c_int32()
         _check(lib().trexhip_train_eval(self._h, x.ctypes.data_as(C.c_void_p), y.ctypes.data_as(C.c_void_p), x.shape[0], C.byref(loss), C.byref(correct)))
         return loss.value, correct.value

@@ -24,6 +24,7 @@
 #include <cmath>
 #include <cstring>
 #include <type_traits>
+#include <string>
 #include <vector>
 
 namespace trexhip {
@@ -118,7 +119,7 @@ __device__ __forceinline__ double sum_partials(const double* __restrict__ partia
 // batch statistics -> mean, invstd (biased variance, like the normalisation uses), running statistics updated with the unbiased one
 __global__ __launch_bounds__(1024) void k_t_bn_finalize(const double* __restrict__ partial, int nblocks, int C, double count, float momentum,
                                                         float* __restrict__ mean, float* __restrict__ invstd, float* __restrict__ run_mean,
-                                                        float* __restrict__ run_var) {
+                                                        float* __restrict__ run_var, const int32_t* __restrict__ refused) {
     __shared__ double sh[8 * 128];
     const double s = sum_partials(partial, nblocks, C, 0, sh);
     const double q = sum_partials(partial, nblocks, C, 1, sh);
@@ -130,6 +131,7 @@ __global__ __launch_bounds__(1024) void k_t_bn_finalize(const double* __restrict
     mean[c] = (float)m;
     invstd[c] = (float)(1.0 / sqrt(var + (double)EPS_BN));
     const double unbiased = count > 1 ? var * count / (count - 1) : var;
+    if (*refused) return;                                  // a refused step leaves the running statistics alone (k_t_check_targets)
     run_mean[c] = (1.f - momentum) * run_mean[c] + momentum * (float)m;
     run_var[c] = (1.f - momentum) * run_var[c] + momentum * (float)unbiased;
 }
@@ -422,10 +424,7 @@ __global__ __launch_bounds__(128) void k_t_head(const float* __restrict__ hpart,
         __syncthreads();
     }
     int target = targets[s];
-    if (target < 0 || target >= classes) {                 // train() asserts this (visual_recognition_torch.py:1112); here: flag it, the step's result is refused
-        if (tid == 0) atomicOr(bad_target, 1);
-        target = 0;
-    }
+    if (target < 0 || target >= classes) target = 0;       // (memory safety only: k_t_check_targets has already refused this step)
     float se = 0.f;
     for (int c = tid; c < classes; c += 128) se += expf(s_dl[c] - gmax);
     const float sum = block_sum128(se, red);
@@ -684,12 +683,31 @@ __global__ __launch_bounds__(256) void k_t_repack_bwd(const float* __restrict__ 
 
 struct AdamSkip { uint32_t lo[6], hi[6]; };
 
+// train() asserts 0 <= target < classes before it touches the model (visual_recognition_torch.py:1109-1112).  Targets handed over in device
+// memory cannot be checked by the host without a synchronisation, so the step checks them first, on the device: refused[0] counts the steps
+// that were refused -- this one if a target is out of range, and every following one until the host has reported the error (sticky) -- and
+// the kernels that change the trainer's state (running statistics, Adam) return when it is set.  refused[1]: the same for an eval batch.
+__global__ __launch_bounds__(256) void k_t_check_targets(const int32_t* __restrict__ targets, int n, int classes, int32_t* __restrict__ refused, int eval) {
+    __shared__ int s_bad;
+    if (threadIdx.x == 0) s_bad = 0;
+    __syncthreads();
+    bool bad = false;
+    for (int i = threadIdx.x; i < n; i += 256) bad |= targets[i] < 0 || targets[i] >= classes;
+    if (bad) s_bad = 1;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        if (eval) { if (s_bad) refused[1] = 1; }
+        else if (s_bad || refused[0]) refused[0] += 1;
+    }
+}
+
 // torch.optim.Adam (_single_tensor_adam, no weight decay / amsgrad): m.lerp_(g, 1 - b1); v = v * b2 + (1 - b2) g g;
 // p += -step_size * m / (sqrt(v) / sqrt(bias_correction2) + eps)
 __global__ __launch_bounds__(256) void k_t_adam(float* __restrict__ P, const float* __restrict__ G, float* __restrict__ M, float* __restrict__ V,
-                                                uint32_t total, AdamSkip skip, float w1, float b2, float omb2, float step_size, float bc2_sqrt, float eps) {
+                                                uint32_t total, AdamSkip skip, float w1, float b2, float omb2, float step_size, float bc2_sqrt, float eps,
+                                                const int32_t* __restrict__ refused) {
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= total) return;
+    if (i >= total || *refused) return;                    // a refused step updates nothing
 #pragma unroll
     for (int k = 0; k < 6; ++k)
         if (i >= skip.lo[k] && i < skip.hi[k]) return;          // running statistics are buffers, not parameters
@@ -823,7 +841,7 @@ static void bn_forward(Trainer* t, hipStream_t s, int layer, const float* z, flo
     const size_t rows = (size_t)n * S * S;
     launch_colstats<C>(s, z, rows, t->red);
     hipLaunchKernelGGL(k_t_bn_finalize, dim3(1), dim3(1024), 0, s, t->red, RED_BLOCKS, C, (double)rows, t->p.bn_momentum, mean, invstd, t->P + t->off[trm],
-                       t->P + t->off[trv]);
+                       t->P + t->off[trv], t->bad_target);
     const size_t total = (size_t)n * (S / 2) * (S / 2) * (C / 4);
     hipLaunchKernelGGL((k_t_bn_pool<C>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, z, mean, invstd, t->P + t->off[tg], t->P + t->off[tb], keep, scale,
                        a, n, S);
@@ -846,11 +864,19 @@ static void bn_backward(Trainer* t, hipStream_t s, int layer, const float* da, f
     hipLaunchKernelGGL(k_t_sum_finalize, dim3(1), dim3(1024), 0, s, t->red, RED_BLOCKS, C, t->G + t->off[tcb]);
 }
 
-// a step that saw a target outside 0..classes-1 has updated the parameters with a wrong gradient: every later synchronising call fails
+// steps with a target outside 0..classes-1 were refused on the device (k_t_check_targets) and have changed nothing: report them at the next
+// synchronising call, take them back out of the step count (Adam's bias correction, the dropout counter) and go on
 static int check_targets(Trainer* t) {
-    int32_t bad = 0;
-    TH_CHECK_HIP(hipMemcpy(&bad, t->bad_target, 4, hipMemcpyDeviceToHost));
-    if (bad) { set_error("training step: a target class index was outside 0..classes-1 (the parameters were updated with it; recreate the trainer)"); return TREXHIP_E_INVALID; }
+    int32_t bad[2] = {0, 0};
+    TH_CHECK_HIP(hipMemcpy(bad, t->bad_target, 8, hipMemcpyDeviceToHost));
+    if (bad[0] || bad[1]) {
+        TH_CHECK_HIP(hipMemset(t->bad_target, 0, 8));
+        if (bad[0]) t->step -= bad[0];
+        set_error(bad[0] ? std::string("training step: a target class index was outside 0..classes-1; that step (and the ") + std::to_string(bad[0] - 1) +
+                               " queued behind it) was refused, parameters, moments and running statistics are unchanged"
+                         : std::string("evaluation batch: a target class index was outside 0..classes-1"));
+        return TREXHIP_E_INVALID;
+    }
     return TREXHIP_OK;
 }
 
@@ -897,6 +923,7 @@ static int trainer_eval(Trainer* t, const float* x, const int32_t* targets, int 
     hipStream_t s = ctx->stream;
     { const int rc = trainer_attrs(t); if (rc) return rc; }
     TH_CHECK_HIP(hipMemsetAsync(t->keep, 1, (size_t)n * 308, s));                 // nothing dropped
+    hipLaunchKernelGGL(k_t_check_targets, dim3(1), dim3(256), 0, s, targets, n, t->classes, t->bad_target, 1);
     trainer_forward(t, s, x, targets, n, t->keep, 1.0f, false);
     hipLaunchKernelGGL(k_t_loss, dim3(1), dim3(64), 0, s, t->loss, t->correct, n, t->out2);
     TH_CHECK_HIP(hipGetLastError());
@@ -923,6 +950,7 @@ static int trainer_step(Trainer* t, const float* x, const int32_t* targets, int 
     float* P = t->P;
     float* G = t->G;
     const size_t* o = t->off;
+    hipLaunchKernelGGL(k_t_check_targets, dim3(1), dim3(256), 0, s, targets, n, t->classes, t->bad_target, 0);
     trainer_forward(t, s, x, targets, n, keep, scale, true);
     const uint8_t *k1 = keep, *k2 = keep + (size_t)n * 16, *k3 = keep + (size_t)n * 80;
     // ---- backward
@@ -963,7 +991,7 @@ static int trainer_step(Trainer* t, const float* x, const int32_t* targets, int 
         const int bufs[6] = {T_RM1, T_RV1, T_RM2, T_RV2, T_RM3, T_RV3};
         for (int k = 0; k < 6; ++k) { skip.lo[k] = (uint32_t)o[bufs[k]]; skip.hi[k] = (uint32_t)(o[bufs[k]] + t->cnt[bufs[k]]); }
         hipLaunchKernelGGL(k_t_adam, dim3((unsigned)((t->total + 255) / 256)), dim3(256), 0, s, P, G, t->M, t->V, (uint32_t)t->total, skip, (float)(1.0 - b1), (float)b2,
-                           (float)(1.0 - b2), (float)((double)t->p.lr / bc1), (float)std::sqrt(bc2), t->p.eps);
+                           (float)(1.0 - b2), (float)((double)t->p.lr / bc1), (float)std::sqrt(bc2), t->p.eps, t->bad_target);
     }
     hipLaunchKernelGGL(k_t_loss, dim3(1), dim3(64), 0, s, t->loss, t->correct, n, t->out2);
     TH_CHECK_HIP(hipGetLastError());
@@ -1032,7 +1060,7 @@ int trexhip_trainer_create(trexhip_ctx* ctx, const void* blob, size_t bytes, con
     TRY(dev_alloc(t, &t->stat, (size_t)3 * 512));
     TRY(dev_alloc(t, &t->hpart, n * 100 * 100)); TRY(dev_alloc(t, &t->xhat, n * 100)); TRY(dev_alloc(t, &t->hd, n * 100));
     TRY(dev_alloc(t, &t->dl, n * classes)); TRY(dev_alloc(t, &t->dy, n * 100)); TRY(dev_alloc(t, &t->dh, n * 100));
-    TRY(dev_alloc(t, &t->loss, n)); TRY(dev_alloc(t, &t->correct, n)); TRY(dev_alloc(t, &t->out2, 2)); TRY(dev_alloc(t, &t->bad_target, 1));
+    TRY(dev_alloc(t, &t->loss, n)); TRY(dev_alloc(t, &t->correct, n)); TRY(dev_alloc(t, &t->out2, 2)); TRY(dev_alloc(t, &t->bad_target, 2));
     TRY(dev_alloc(t, &t->red, (size_t)RED_BLOCKS * 2 * 128)); TRY(dev_alloc(t, &t->keep, n * 308));
     TRY(dev_alloc(t, &t->x_stage, n * 6400 * CH)); TRY(dev_alloc(t, &t->y_stage, n)); TRY(dev_alloc(t, &t->keep_stage, n * 308));
 #undef TRY
@@ -1044,7 +1072,7 @@ int trexhip_trainer_create(trexhip_ctx* ctx, const void* blob, size_t bytes, con
         src += t->cnt[k];
     }
     bool ok = hipMemcpy(t->P, host.data(), at * 4, hipMemcpyHostToDevice) == hipSuccess;
-    ok = ok && hipMemset(t->bad_target, 0, 4) == hipSuccess;
+    ok = ok && hipMemset(t->bad_target, 0, 8) == hipSuccess;
     ok = ok && hipMemset(t->G, 0, at * 4) == hipSuccess && hipMemset(t->M, 0, at * 4) == hipSuccess && hipMemset(t->V, 0, at * 4) == hipSuccess;
     if (!ok) { trainer_free(t); set_error("trexhip_trainer_create: upload failed"); return TREXHIP_E_DEVICE; }
     trexhip_trainer* h = new trexhip_trainer{t};

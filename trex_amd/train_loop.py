@@ -76,6 +76,8 @@ def train(trainer, train_loader, val_loader, callback, scheduler, settings, abor
             y = np.asarray(targets)
             if x.ndim != 4 or y.ndim != 1 or x.shape[0] != y.shape[0]:
                 raise ValueError(f"Expected inputs (N,H,W,C) and targets (N,), got {x.shape} and {y.shape}")          # train() asserts the same, :1104-1112
+            if np.asarray(y).dtype.kind not in "iu":
+                raise ValueError(f"targets must be integer class indices, got {np.asarray(y).dtype}")     # train() asserts integer labels, :1109-1110
             loss, correct = trainer.step(x, y.astype(np.int32))
             acc = correct / float(x.shape[0])
             running_loss += loss
@@ -88,8 +90,10 @@ def train(trainer, train_loader, val_loader, callback, scheduler, settings, abor
             val_loss, correct, total, nb = 0.0, 0, 0, 0
             for inputs, targets in val_loader:
                 x = np.ascontiguousarray(np.asarray(inputs), np.float32)
-                y = np.asarray(targets).astype(np.int32)
-                l, c = trainer.evaluate(x, y)
+                y = np.asarray(targets)
+                if y.dtype.kind not in "iu":
+                    raise ValueError(f"targets must be integer class indices, got {y.dtype}")
+                l, c = trainer.evaluate(x, y.astype(np.int32))
                 val_loss += l
                 correct += c
                 total += x.shape[0]
