@@ -167,10 +167,10 @@ def test_replayed_chain_follows_new_inputs_and_precision_changes():
     seg = make_net(st, classes)
     crops = torch.zeros((n, 80, 80), dtype=torch.uint8, device="cuda")
     probs = torch.zeros((n, classes), dtype=torch.float32, device="cuda")
-    for rep in range(5):
+    for rep in range(8):                  # (a chain is captured at the third call with the same key: calls 1-2 launch directly, 3 captures, 4+ replay)
         c = weights.synthetic_crops(n, 700 + rep)[..., 0]
         crops.copy_(torch.from_numpy(c).cuda())
-        if rep == 3:
+        if rep == 6:
             seg.set_identity_precision(capi.CNN_BF16X6)
         seg.identify_device(crops.data_ptr(), n, probs.data_ptr())
         seg.synchronize()
@@ -178,8 +178,33 @@ def test_replayed_chain_follows_new_inputs_and_precision_changes():
         assert np.abs(probs.cpu().numpy() - want).max() <= 1e-4, rep
     # a second output buffer and another batch size: their own chains
     probs2 = torch.zeros((37, classes), dtype=torch.float32, device="cuda")
-    for rep in range(3):
+    for rep in range(5):
         seg.identify_device(crops.data_ptr(), 37, probs2.data_ptr())
         seg.synchronize()
         assert np.abs(probs2.cpu().numpy() - want[:37]).max() <= 1e-4
+    seg.close()
+
+
+def test_varying_crop_counts_without_synchronising_between_calls():
+    # tracking hands over a different number of crops almost every batch: nothing may be captured for keys seen once or twice, more
+    # distinct keys than the cache holds must evict safely although the evicted chains were launched asynchronously, and every call
+    # must still give its own crops' rows
+    classes = 100
+    st = weights.synthetic_state(classes, 99)
+    seg = make_net(st, classes)
+    allc = weights.synthetic_crops(160, 5)[..., 0]
+    want, _ = cnn_oracle.predict(st, allc[..., None], threads=8)
+    crops = torch.from_numpy(allc).cuda()
+    sizes = [100, 97, 100, 103, 100, 91, 100, 100] + [60 + 3 * k for k in range(12)] * 3 + [100, 100]
+    outs = [torch.zeros((160, classes), dtype=torch.float32, device="cuda") for _ in sizes]
+    for k, n in enumerate(sizes):          # no synchronisation between the calls
+        seg.identify_device(crops.data_ptr(), n, outs[k].data_ptr())
+    seg.synchronize()
+    for k, n in enumerate(sizes):
+        assert np.abs(outs[k][:n].cpu().numpy() - want[:n]).max() <= 1e-4, (k, n)
+    # the same key over and over with one output buffer: captured, replayed, still correct
+    for _ in range(6):
+        seg.identify_device(crops.data_ptr(), 64, outs[0].data_ptr())
+    seg.synchronize()
+    assert np.abs(outs[0][:64].cpu().numpy() - want[:64]).max() <= 1e-4
     seg.close()

@@ -338,3 +338,47 @@ def test_posture_retry_loop_equals_oracle(seed, method, tpt):
     assert retried >= 2 and ok_late >= 1          # the scene really exercises the loop
     assert n_same >= 0.3 * n_cmp, (n_same, n_cmp)  # the synthetic bodies are exactly symmetric: about half of the tails are coin flips between the two tips
     seg.close()
+
+
+def test_retry_loop_with_sub_blobs_of_more_lines_than_twice_the_parents():
+    # The LDS line capacity of a posture launch is estimated from the detect blobs (2 x their lines).  A thresholded line can split into
+    # many more: a comb whose odd rows alternate strong / faint pixels is one line per row at the detect threshold and 30 per odd row at
+    # track_posture_threshold.  The round is then repeated with the kernel's real capacities -- never counted as a failed attempt
+    # (which would move the blob on to threshold + 2 and differ from calculate_posture, Posture.cpp:331-382).
+    H, W = 256, 512
+    bg = np.full((H, W), 200, np.uint8)
+    fr = bg.copy()
+    for j, (y0, x0) in enumerate([(20, 30), (90, 200), (170, 380)]):
+        rows, width = 24 + 4 * j, 60
+        for r in range(rows):
+            fr[y0 + r, x0:x0 + width] = 200 - 60
+            if r % 2 == 1:
+                fr[y0 + r, x0 + 1:x0 + width:2] = 200 - 20          # faint: passes detect (> 15), fails the posture threshold (30)
+    fr[120:150, 40:70] = 200 - 60                                      # an ordinary blob beside them
+    seg = capi.Segmenter(capi.default_params(W, H, max_batch=1, max_blobs=64))
+    seg.set_background(bg)
+    d = torch.from_numpy(fr[None]).cuda()
+    seg.segment_device(d.data_ptr(), 1)
+    r = seg.fetch()[0]
+    n, MP = len(r.blobs), 1024
+    assert n == 4 and int(r.blobs["n_runs"].max()) <= 40
+    outline = torch.zeros((n, MP, 2), dtype=torch.float32, device="cuda"); segs = torch.zeros((n, MP // 2 + 1, 4), dtype=torch.float32, device="cuda")
+    info = torch.zeros((n, 8), dtype=torch.int32, device="cuda")
+    thr = torch.zeros(n, dtype=torch.int32, device="cuda"); its = torch.zeros(n, dtype=torch.int32, device="cuda")
+    seg.posture_auto_device(n, outline.data_ptr(), segs.data_ptr(), info.data_ptr(), method=0, track_posture_threshold=30,
+                            d_threshold_ptr=thr.data_ptr(), d_iterations_ptr=its.data_ptr(), max_points=MP)
+    seg.synchronize()
+    gi = info.cpu().numpy().view(capi.POSTURE_INFO_DTYPE).reshape(-1); go = outline.cpu().numpy()
+    gt, gn = thr.cpu().numpy(), its.cpu().numpy()
+    pp = oracle.posture_params(max_points=MP)
+    for k, b in enumerate(r.blobs):
+        rs = r.runs[b["run_begin"]:b["run_begin"] + b["n_runs"]]; px = r.pixels[b["pix_begin"]:b["pix_begin"] + b["n_pixels"]]
+        oi, oo, osg = oracle.posture_auto(rs, px, bg, 0, 30, pp)
+        assert gn[k] == oi["iterations"] and gt[k] == oi["threshold"], (k, gn[k], gt[k], oi)
+        assert gi[k]["status"] == oi["status"] and gi[k]["n_outline"] == oi["n_outline"], (k, gi[k], oi)
+        assert gi[k]["status"] != 2, k                                  # within the kernel's limits: never a capacity status
+        if oi["n_outline"]:
+            a = go[k, :oi["n_outline"]]
+            dmin = np.abs(a[:, None, :] - oo[None, :, :]).max(2).min(1)
+            assert dmin.max() <= 2e-3 * max(1.0, oi["n_outline"] / 200.0), k
+    seg.close()

@@ -1564,14 +1564,26 @@ struct Net {
     float* h_probs = nullptr;
     // small batches are launch-bound (one frame's 100 crops: 60 us of convolutions in a 160 us chain of ~12 launches): the chain of one
     // identify call is captured into a hipGraph per (buffers, n, precision) and replayed
-    struct GraphEntry { const uint8_t* crops; int n; float* probs; float* logits; int mode, geom; hipStream_t stream; hipGraphExec_t exec; uint64_t used; };
+    // A chain is only captured once the same (buffers, n, precision) key has come THREE times: in tracking the blob count changes from
+    // batch to batch, and capture + instantiate costs far more than the ~100 us of launch overhead a replay saves.
+    struct GraphEntry { const uint8_t* crops; int n; float* probs; float* logits; int mode, geom; hipStream_t stream; hipGraphExec_t exec; uint64_t used;
+                        hipEvent_t last; int seen; };          // exec == nullptr: a candidate key that is still being counted
     std::vector<GraphEntry> graphs;
     bool graphs_ok = true;
     uint64_t tick = 0;
 };
 
+// an exec may still be running on its stream (launches are asynchronous): wait for the event recorded behind its last launch first
+static void destroy_graph_entry(Net::GraphEntry& g) {
+    if (g.exec) {
+        if (g.last) (void)hipEventSynchronize(g.last);
+        (void)hipGraphExecDestroy(g.exec);
+    }
+    if (g.last) (void)hipEventDestroy(g.last);
+    g.exec = nullptr; g.last = nullptr;
+}
 static void drop_graphs(Net* n) {
-    for (auto& g : n->graphs) (void)hipGraphExecDestroy(g.exec);
+    for (auto& g : n->graphs) destroy_graph_entry(g);
     n->graphs.clear();
 }
 
@@ -2135,6 +2147,7 @@ static int net_forward_launch(trexhip_ctx* ctx, const uint8_t* d_crops, int n, f
 
 static constexpr int GRAPH_MAX_CROPS = 6400;      // above this the kernels themselves dominate
 static constexpr size_t GRAPH_CACHE = 8;
+static constexpr int GRAPH_MIN_SEEN = 3;          // calls with the same key before its chain is captured
 
 int net_forward(trexhip_ctx* ctx, const uint8_t* d_crops, int n, float* d_probs, float* d_logits) {
     Net* net = static_cast<Net*>(ctx->net);
@@ -2144,12 +2157,30 @@ int net_forward(trexhip_ctx* ctx, const uint8_t* d_crops, int n, float* d_probs,
     hipStream_t s = ctx->stream;
     const int mode = ctx->cnn_mode, geom = ctx->tune_conv_geom;
     ++net->tick;
+    Net::GraphEntry* cand = nullptr;
     for (auto& g : net->graphs)
         if (g.crops == d_crops && g.n == n && g.probs == d_probs && g.logits == d_logits && g.mode == mode && g.geom == geom && g.stream == s) {
             g.used = net->tick;
-            TH_CHECK_HIP(hipGraphLaunch(g.exec, s));
-            return TREXHIP_OK;
+            if (g.exec) {
+                TH_CHECK_HIP(hipGraphLaunch(g.exec, s));
+                TH_CHECK_HIP(hipEventRecord(g.last, s));
+                return TREXHIP_OK;
+            }
+            cand = &g;
+            break;
         }
+    auto evict_lru = [&]() {
+        size_t lru = 0;
+        for (size_t i = 1; i < net->graphs.size(); ++i) if (net->graphs[i].used < net->graphs[lru].used) lru = i;
+        destroy_graph_entry(net->graphs[lru]);
+        net->graphs.erase(net->graphs.begin() + (long)lru);
+    };
+    if (!cand) {                                                  // a new key: count it, run the chain directly
+        if (net->graphs.size() >= GRAPH_CACHE) evict_lru();
+        net->graphs.push_back({d_crops, n, d_probs, d_logits, mode, geom, s, nullptr, net->tick, nullptr, 1});
+        return net_forward_launch(ctx, d_crops, n, d_probs, d_logits);
+    }
+    if (++cand->seen < GRAPH_MIN_SEEN) return net_forward_launch(ctx, d_crops, n, d_probs, d_logits);
     if (hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) != hipSuccess) {
         (void)hipGetLastError();
         net->graphs_ok = false;
@@ -2159,21 +2190,19 @@ int net_forward(trexhip_ctx* ctx, const uint8_t* d_crops, int n, float* d_probs,
     hipGraph_t graph = nullptr;
     const hipError_t e_end = hipStreamEndCapture(s, &graph);
     hipGraphExec_t exec = nullptr;
-    if (rc != TREXHIP_OK || e_end != hipSuccess || !graph || hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) != hipSuccess) {
+    hipEvent_t ev = nullptr;
+    if (rc != TREXHIP_OK || e_end != hipSuccess || !graph || hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) != hipSuccess ||
+        hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) {
         (void)hipGetLastError();
+        if (exec) (void)hipGraphExecDestroy(exec);
         if (graph) (void)hipGraphDestroy(graph);
         net->graphs_ok = false;                                   // nothing was executed during the capture: run the chain directly, from now on always
         return net_forward_launch(ctx, d_crops, n, d_probs, d_logits);
     }
     (void)hipGraphDestroy(graph);
-    if (net->graphs.size() >= GRAPH_CACHE) {                      // evict the least recently used chain
-        size_t lru = 0;
-        for (size_t i = 1; i < net->graphs.size(); ++i) if (net->graphs[i].used < net->graphs[lru].used) lru = i;
-        (void)hipGraphExecDestroy(net->graphs[lru].exec);
-        net->graphs.erase(net->graphs.begin() + (long)lru);
-    }
-    net->graphs.push_back({d_crops, n, d_probs, d_logits, mode, geom, s, exec, net->tick});
+    cand->exec = exec; cand->last = ev;
     TH_CHECK_HIP(hipGraphLaunch(exec, s));
+    TH_CHECK_HIP(hipEventRecord(ev, s));
     return TREXHIP_OK;
 }
 

@@ -645,19 +645,29 @@ __global__ void k_auto_sel(const int n, const int32_t* thr, const unsigned long 
     sel[b] = (thr[b] >= 0 && best[b] != 0ull) ? (int32_t)(0xffffffffu - (uint32_t)best[b]) : -1;
 }
 __global__ __launch_bounds__(256) void k_auto_step(const int n, const int tpt, const int max_points, const trexhip_blob* __restrict__ detect,
-                                                   int32_t* thr, const int32_t* sel, unsigned long long* best, int32_t* first_n, int32_t* first_thr,
+                                                   int32_t* thr, int32_t* sel, unsigned long long* best, int32_t* first_n, int32_t* first_thr,
                                                    int32_t* used, int32_t* iters, float2* first, float2* outline, trexhip_posture_info* info,
-                                                   uint32_t* active) {
+                                                   uint32_t* active, const trexhip_blob* __restrict__ sub, const int nr_cap, const int rows_cap) {
     const int lane = threadIdx.x & 63, b = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (b >= n) return;
     const int t = thr[b];
     if (t < 0) return;
     const int s = sel[b];
+    if (s == -2) return;                                   // already handled in this round (the round is being repeated with full LDS capacities)
     const uint32_t count = s >= 0 ? (uint32_t)(best[b] >> 32) : 0u;
     trexhip_posture_info last = info[b];
     if (s < 0) { trexhip_posture_info z = {}; z.status = 1; last = z; }
+    if (s >= 0 && last.status == 2 && (nr_cap < P_NR || rows_cap < P_ROWS)) {
+        // the launch's LDS capacities are an ESTIMATE from the parent blobs (a thresholded line can split into more than two); a sub-blob
+        // beyond the estimate but within the kernel's real limits is not a failed attempt: leave the blob as it is and ask for a repeat
+        const int sr = (int)sub[s].n_runs, srows = sub[s].y1 - sub[s].y0 + 1;
+        if ((sr > nr_cap || srows > rows_cap) && sr <= P_NR && srows <= P_ROWS) {
+            if (lane == 0) atomicAdd(active + 1, 1u);
+            return;
+        }
+    }
     __builtin_amdgcn_wave_barrier();
-    if (lane == 0) { iters[b] += 1; best[b] = 0ull; }
+    if (lane == 0) { iters[b] += 1; best[b] = 0ull; sel[b] = -2; }
     if (s >= 0 && last.status == 0) { if (lane == 0) { used[b] = t; thr[b] = -1; } return; }      // a midline at the lowest possible threshold
     float2* mine = outline + (size_t)b * max_points;
     float2* keep = first + (size_t)b * max_points;
@@ -731,34 +741,44 @@ extern "C" int trexhip_posture_auto_device(trexhip_ctx* ctx, const trexhip_postu
         nr_cap = (int)std::min<uint32_t>((mr + 31u) & ~31u, (uint32_t)P_NR);
         rows_cap = (int)std::min<uint32_t>((mrows + 29u) / 32u * 32u + 30u, (uint32_t)P_ROWS);
     }
-    const int wave_lds = posture_wave_lds(MPt, nr_cap, rows_cap);
-    int wpb = 4;
-    while (wpb > 1 && wpb * wave_lds > 150 * 1024) wpb >>= 1;
-    const int lds_bytes = wpb * wave_lds;
-    if (lds_bytes > ctx->attr_posture_bytes) {
-        TH_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_posture), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
-        ctx->attr_posture_bytes = lds_bytes;
-    }
-    const PostureCfg P{pp->outline_resample, pp->outline_smooth_samples, pp->outline_smooth_step, pp->outline_approximate,
-                       pp->outline_curvature_range_ratio, pp->midline_walk_offset, pp->max_points, nr_cap, rows_cap, 0};
+    PostureCfg P{pp->outline_resample, pp->outline_smooth_samples, pp->outline_smooth_step, pp->outline_approximate,
+                 pp->outline_curvature_range_ratio, pp->midline_walk_offset, pp->max_points, nr_cap, rows_cap, 0};
+    int wpb = 1, lds_bytes = 0;
+    auto size_launch = [&]() -> int {
+        const int wave_lds = posture_wave_lds(MPt, P.nr_cap, P.rows_cap);
+        wpb = 4;
+        while (wpb > 1 && wpb * wave_lds > 150 * 1024) wpb >>= 1;
+        lds_bytes = wpb * wave_lds;
+        if (lds_bytes > ctx->attr_posture_bytes) {
+            TH_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_posture), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
+            ctx->attr_posture_bytes = lds_bytes;
+        }
+        return TREXHIP_OK;
+    };
+    if (int rc = size_launch()) return rc;
     for (int round = 0; round < 51; ++round) {                        // thresholds t, t+2, ..., below t+100
         int rc = trexhip_rethreshold_per_blob_device(ctx, 0, thr, method, nullptr, 0);     // negative entries (finished blobs) are skipped
         if (rc) return rc;
         const Pass2& q = ctx->pass2;
-        TH_CHECK_HIP(hipMemsetAsync(active, 0, 4, s));
         hipLaunchKernelGGL(k_auto_pick, dim3((ctx->cfg.pool_blobs + 255u) / 256u), dim3(256), 0, s, q.d_blobs, q.d_totals, ctx->cfg.pool_blobs, n, best);
         hipLaunchKernelGGL(k_auto_sel, g256, dim3(256), 0, s, n, thr, best, sel);
-        stage_begin(ctx, TREXHIP_STAGE_POSTURE);
-        hipLaunchKernelGGL(k_posture, dim3((n + wpb - 1) / wpb), dim3(wpb * 64), lds_bytes, s, P, q.d_info, q.d_blob_frame, q.d_blobs, q.d_runs, n, ctx->last_n,
-                           reinterpret_cast<float2*>(d_outline), reinterpret_cast<float4*>(d_segments), d_info, sel, ctx->d_blobs);
-        stage_end(ctx, TREXHIP_STAGE_POSTURE);
-        hipLaunchKernelGGL(k_auto_step, dim3((n + 3) / 4), dim3(256), 0, s, n, (int)track_posture_threshold, MPt, ctx->d_blobs, thr, sel, best, first_n, first_thr,
-                           used, iters, first, reinterpret_cast<float2*>(d_outline), d_info, active);
-        TH_CHECK_HIP(hipGetLastError());
-        uint32_t still = 0;
-        TH_CHECK_HIP(hipMemcpyAsync(&still, active, 4, hipMemcpyDeviceToHost, s));
-        TH_CHECK_HIP(hipStreamSynchronize(s));
-        if (still == 0) break;
+        uint32_t still[2] = {0, 0};
+        for (int attempt = 0; attempt < 2; ++attempt) {               // attempt 1: only if a sub-blob did not fit the estimated LDS capacities
+            TH_CHECK_HIP(hipMemsetAsync(active, 0, 8, s));
+            stage_begin(ctx, TREXHIP_STAGE_POSTURE);
+            hipLaunchKernelGGL(k_posture, dim3((n + wpb - 1) / wpb), dim3(wpb * 64), lds_bytes, s, P, q.d_info, q.d_blob_frame, q.d_blobs, q.d_runs, n, ctx->last_n,
+                               reinterpret_cast<float2*>(d_outline), reinterpret_cast<float4*>(d_segments), d_info, sel, ctx->d_blobs);
+            stage_end(ctx, TREXHIP_STAGE_POSTURE);
+            hipLaunchKernelGGL(k_auto_step, dim3((n + 3) / 4), dim3(256), 0, s, n, (int)track_posture_threshold, MPt, ctx->d_blobs, thr, sel, best, first_n, first_thr,
+                               used, iters, first, reinterpret_cast<float2*>(d_outline), d_info, active, q.d_blobs, P.nr_cap, P.rows_cap);
+            TH_CHECK_HIP(hipGetLastError());
+            TH_CHECK_HIP(hipMemcpyAsync(still, active, 8, hipMemcpyDeviceToHost, s));
+            TH_CHECK_HIP(hipStreamSynchronize(s));
+            if (still[1] == 0) break;
+            P.nr_cap = P_NR; P.rows_cap = P_ROWS;                      // from here on the kernel's real limits (fewer blobs per CU)
+            if (int rc2 = size_launch()) return rc2;
+        }
+        if (still[0] == 0) break;
     }
     if (d_threshold_used) TH_CHECK_HIP(hipMemcpyAsync(d_threshold_used, used, (size_t)n * 4, hipMemcpyDeviceToDevice, s));
     if (d_iterations) TH_CHECK_HIP(hipMemcpyAsync(d_iterations, iters, (size_t)n * 4, hipMemcpyDeviceToDevice, s));
