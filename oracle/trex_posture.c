@@ -201,7 +201,10 @@ typedef struct oracle_posture_params {
     float outline_resample; int32_t outline_smooth_samples, outline_smooth_step, outline_approximate;
     float outline_curvature_range_ratio, midline_walk_offset; int32_t max_points;
 } oracle_posture_params;
-typedef struct oracle_posture_info { int32_t status, n_outline, n_segments, tail_index, head_index, n_traced; } oracle_posture_info;
+/* peak_best / peak_runner_up: curvature at the chosen tail and the largest curvature anywhere farther than the curvature range from it
+ * (test infrastructure: when the two are within float rounding of each other the tail is a coin flip, and a test can tell a legitimate
+ * tie from a wrong choice) */
+typedef struct oracle_posture_info { int32_t status, n_outline, n_segments, tail_index, head_index, n_traced; float peak_best, peak_runner_up; } oracle_posture_info;
 
 /* status: 0 ok, 1 empty blob/outline, 2 capacity, 3 no curvature peak, 4 too few midline segments */
 int oracle_posture(const oracle_run* runs, int32_t n_runs, int32_t origin_x, int32_t origin_y, const oracle_posture_params* P,
@@ -240,6 +243,14 @@ int oracle_posture(const oracle_run* runs, int32_t n_runs, int32_t origin_x, int
             if (c1 > c0 && c1 >= c2 && c1 > best) { best = c1; tail = i; }
         }
         if (tail < 0) { rc = 3; memcpy(outline_xy, pts, (size_t)n * sizeof(v2)); info->n_outline = n; goto done; }   /* the outline stays available (first_outline fallback, Posture.cpp:361-368) */
+        {
+            float runner = 0.f;
+            for (int i = 0; i < n; ++i) {
+                int dd = i > tail ? i - tail : tail - i; if (n - dd < dd) dd = n - dd;
+                if (dd > r && curv[i] > runner) runner = curv[i];
+            }
+            info->peak_best = best; info->peak_runner_up = runner;
+        }
         int head = -1; float maxd = 0;
         for (int i = 0; i < n; ++i) {
             const float c0 = curv[(i - 1 + n) % n], c1 = curv[i], c2 = curv[(i + 1) % n];

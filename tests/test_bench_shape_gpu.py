@@ -96,3 +96,74 @@ def test_c4_256_frames_two_lanes_three_steps():
 
     pipe.run(steps, frames.data_ptr(), on_batch=on_batch)
     pipe.close()
+
+
+@pytest.mark.parametrize("name,config,B,kw", [
+    ("C5 as benchmarked", "C5", 64, dict(normalize="posture")),
+    ("C4 posture-normalised crops", "C4", 32, dict(normalize="posture")),
+    ("C4 rgb8 encoding", "C4", 32, dict(rgb=True)),
+])
+def test_other_benchmarked_pipelines(name, config, B, kw):
+    """The other workloads bench.py reports (its `secondary` runs) through the same two-lane Pipeline object at the batch sizes it uses:
+    C5 = 4096x4096, 256 individuals, 256 classes, posture -> midline -> posture-normalised crops -> network -> full per-blob record at
+    B = 64; posture-normalised crops and the rgb8 encoding at C4.  Every frame through properties, samples against the CPU restatements."""
+    from oracle import tables as otables
+    W, H, n_ind, _ = synth.CONFIGS[config]
+    classes = 256 if config == "C5" else 100
+    rgb = bool(kw.get("rgb"))
+    posture = kw.get("normalize") == "posture"
+    frames, bg = synth.batch_torch(config, B, "cuda")
+    src = torch.stack([frames, frames, frames, torch.full_like(frames, 255)], dim=-1).contiguous() if rgb else frames
+    st = weights.synthetic_state(classes, 4242, channels=3 if rgb else 1)
+    pipe = Pipeline(W, H, n_ind, B, classes, bg, weights.pack_blob(st, classes, channels=3 if rgb else 1), **kw)
+    assert len(pipe.lanes) == 2
+    bg_host = bg.cpu().numpy()
+    fr0 = frames[0].cpu().numpy()
+    done = []
+
+    def on_batch(step, ln):
+        res = ln.res
+        n = int(res.total_blobs)
+        assert n == n_ind * B
+        info = capi._from_addr(res.frames, res.n_frames, capi.INFO_DTYPE)
+        blobs = capi._from_addr(res.blobs, res.total_blobs, capi.BLOB_DTYPE)
+        runs = capi._from_addr(res.runs, res.total_runs, capi.RUN_DTYPE)
+        assert (info["flags"] == 0).all() and (info["n_blobs"] == n_ind).all()
+        assert _sorted_lines(info, blobs, runs)
+        crops = ln.crops[:n].cpu().numpy()
+        probs = ln.probs[:n].cpu().numpy()
+        assert np.allclose(probs.sum(1), 1.0, atol=1e-5) and (probs >= 0).all()
+        pick = np.linspace(0, n - 1, 24 if step == 0 else 6).astype(int)
+        want, _ = cnn_oracle.predict(st, crops[pick] if rgb else crops[pick][..., None], threads=8)
+        assert np.abs(probs[pick] - want).max() <= 1e-4
+        b0 = int(info[0]["blob_begin"])
+        fb = blobs[b0:b0 + n_ind]
+        fruns = runs[int(info[0]["run_begin"]):int(info[0]["run_begin"]) + int(info[0]["n_runs"])]
+        if posture:
+            mi = ln.p_minfo[:n].cpu().numpy().view(capi.MIDLINE_INFO_DTYPE).reshape(-1)
+            pi = ln.p_info[:n].cpu().numpy().view(capi.POSTURE_INFO_DTYPE).reshape(-1)
+            assert (pi["status"] == 0).mean() > 0.97 and ((mi["status"] == 0) == (pi["status"] == 0)).all()
+            if step == 0:                       # frame 0: posture-normalised crops bit for bit given the device's midline pose
+                for k in range(0, n_ind, max(1, n_ind // 8)):
+                    if mi[b0 + k]["status"] != 0:
+                        continue
+                    tr = oracle.midline_transform(mi[b0 + k]["angle"], mi[b0 + k]["offx"], mi[b0 + k]["offy"], False)
+                    want_c, _ = oracle.crop_normalized(fr0, bg_host, fb[k], fruns, tr6=tr, midline_length=float(mi[b0 + k]["len"]))
+                    assert np.array_equal(crops[b0 + k], want_c), k
+            t = ln.table_host.numpy().view(np.uint32)
+            assert int(t[:, 7].sum()) == n and not t[n:].any()
+            assert np.array_equal(t[:n, 1], blobs["bid"]) and np.array_equal(t[:n, 2], blobs["n_pixels"])
+            assert np.array_equal(t[:n, otables.HDR_EX:otables.HDR_EX + classes].view(np.float32), probs)
+        else:
+            if rgb:                             # raw pixels painted: every channel of a crop sums to its blob's pixel bytes of that channel
+                px = capi._from_addr(res.pixels, res.total_pixels * 3, np.dtype(np.uint8)).reshape(-1, 3)
+                k = b0
+                pb = int(info[0]["pix_begin"]) + int(blobs[k]["pix_begin"])
+                assert np.array_equal(crops[k].reshape(-1, 3).astype(np.int64).sum(0), px[pb:pb + int(blobs[k]["n_pixels"])].astype(np.int64).sum(0))
+            t = ln.table_host.numpy().view(np.uint32)
+            assert int(t[:, 7].sum()) == n and np.array_equal(t[:n, tdist.HDR:].view(np.float32), probs)
+        done.append(step)
+
+    pipe.run(3, src.data_ptr(), on_batch=on_batch)
+    pipe.close()
+    assert sorted(done) == [0, 1, 2]

@@ -127,7 +127,7 @@ def test_c3_posture_and_midline_at_2048():
     assert fr.shape[1:] == (2048, 2048)
     res, outline, segs, info = run_posture(fr, bg)
     assert all(len(r.blobs) == 100 for r in res)
-    n = compare(res, outline, segs, info, oracle.posture_params(max_points=512))
+    n, ties = compare(res, outline, segs, info, oracle.posture_params(max_points=512), max_ties=0.05)     # tie-aware tail rule, see there
     assert n == 200
     assert (info["status"] == 0).mean() > 0.95
     n_ok, total = check_midline(fr, bg, min_ok=0.9)

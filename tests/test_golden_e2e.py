@@ -77,3 +77,61 @@ def test_device_equals_oracle_on_reference_frames():
         tot += len(gold); hits += h
     assert hits >= 0.7 * tot
     seg.close()
+
+
+@pytest.mark.gpu
+def test_device_tables_against_the_golden_wcentroid_and_midline_length_columns():
+    """Two more columns of videos/compare_data_automatic/test_fish*.csv as device-side anchors over ALL 200 frames (1459 rows):
+      X#wcentroid    against the centroid from the EXACT integer sums of the device's sub-blob table (sum x / n_pixels: row a13).  Measured on
+                     these data: the column equals the PLAIN centroid of the thresholded blob (98.7 % within half a pixel = the CSV's integer
+                     rounding, 100 % within one), not Individual::weighted_centroid's grey-weighted one (tracking/Individual.cpp:2414-2440:
+                     weight = 1 - (p - min) / (max - min + 1); with grey or with difference values as p only 18-19 % land within a pixel) --
+                     so it pins the pixel SET of every blob (a shifted, grown or shrunk blob moves its centroid), not the weighting.  The
+                     weighted sums (sum p, sum p x, min, max) stay checked bit for bit against the CPU restatement elsewhere;
+      midline_length Midline::len() of the normalised midline, from trexhip_posture_device (re-threshold table) + trexhip_midline_device: row a7.
+    The CSV holds integers (output_csv_decimals = 0, cm_per_pixel = 1)."""
+    import torch
+    from trex_amd import capi
+    G = Golden()
+    seg = capi.Segmenter(capi.default_params(G.W, G.H, max_batch=1, threshold=9, size_ranges=[(1, 10000)]))
+    MP, R = 512, 25
+    cap = 256
+    outline = torch.zeros((cap, MP, 2), dtype=torch.float32, device="cuda"); segs = torch.zeros((cap, MP // 2 + 1, 4), dtype=torch.float32, device="cuda")
+    info = torch.zeros((cap, 8), dtype=torch.int32, device="cuda")
+    mid = torch.zeros((cap, R, 4), dtype=torch.float32, device="cuda"); minfo = torch.zeros((cap, 8), dtype=torch.int32, device="cuda")
+    rows = x_exact = x_close = 0
+    ratios = []
+    for i in range(len(G.frames)):
+        img, b, gold = G.rebuild(i)
+        seg.set_background(b)
+        d = torch.from_numpy(img).cuda()
+        seg.segment_device(d.data_ptr(), 1)
+        seg.fetch()
+        seg.rethreshold(12, 1, RANGES)
+        sub = seg.fetch(rethreshold=True)[0]
+        n = len(sub.blobs)
+        assert n <= cap
+        seg.posture_device(n, outline.data_ptr(), segs.data_ptr(), info.data_ptr(), table=1, outline_resample=0.5)
+        seg.midline_device(n, MP, info.data_ptr(), segs.data_ptr(), mid.data_ptr(), minfo.data_ptr())
+        seg.synchronize()
+        mi = minfo.cpu().numpy().view(capi.MIDLINE_INFO_DTYPE).reshape(-1)
+        index = {int(bb["bid"]): k for k, bb in enumerate(sub.blobs) if bb["flags"] == 0}
+        for g in gold:
+            k = index.get(int(g[1]))
+            if k is None:
+                continue
+            bb = sub.blobs[k]
+            rows += 1
+            x = float(bb["m10"]) / float(bb["n_pixels"])
+            if np.isfinite(g[3]):
+                x_exact += abs(x - g[3]) <= 0.5 + 1e-6
+                x_close += abs(x - g[3]) <= 1.0
+            if np.isfinite(g[4]) and g[4] > 0 and mi[k]["status"] == 0:
+                ratios.append(float(mi[k]["len"]) / float(g[4]))
+    print("golden rows matched by blob id: %d; X#wcentroid within half a pixel (the column's rounding): %d, within 1 px: %d; midline_length ratio: n %d median %.4f min %.3f max %.3f"
+          % (rows, x_exact, x_close, len(ratios), np.median(ratios), min(ratios), max(ratios)))
+    assert rows >= 1000
+    assert x_close >= 0.995 * rows and x_exact >= 0.95 * rows, (x_exact, x_close, rows)
+    assert len(ratios) >= 0.8 * rows
+    assert 0.99 < np.median(ratios) < 1.03 and min(ratios) > 0.95 and max(ratios) < 1.07, (np.median(ratios), min(ratios), max(ratios))
+    seg.close()

@@ -32,8 +32,14 @@ def run_posture(frames, bg, table=0, thr=None, **kw):
     return out
 
 
-def compare(res, outline, segs, info, pp, min_ok=0.97):
-    n_cmp = n_same = n_close = 0
+TIE_EPS = 5e-3      # two curvature peaks closer than this (relative) are a tie: device and CPU outlines differ by up to 1e-3 px (EFT's cos / sin)
+
+
+def compare(res, outline, segs, info, pp, max_ties=1.0):
+    """Tie-aware tail rule: where the curvature at the CPU restatement's tail exceeds every peak outside its neighbourhood by more than TIE_EPS
+    the device must have chosen the same tail (same rotation of the outline, same head, same segment count); at a tie either tip is a
+    correct answer and only the closed curve is compared.  -> (blobs compared, ties among them)"""
+    n_cmp = n_same = n_close = n_tie = 0
     for r in res:
         for k, b in enumerate(r.blobs):
             bi = int(r.info["blob_begin"]) + k
@@ -70,19 +76,23 @@ def compare(res, outline, segs, info, pp, min_ok=0.97):
                 # against the oracle's own outline (EFT differs by float rounding) the pairing can flip at a near-tie of two
                 # candidate distances; that is rare
                 n_close += np.abs(gs - osg).max() <= 2e-3
-            else:   # near-tie of a curvature peak (float rounding of cos/sin): the outline must still be the same closed curve
+            else:   # another tail: only legitimate at a tie of the curvature peaks; the outline must still be the same closed curve
+                tie = oi["peak_runner_up"] >= (1.0 - TIE_EPS) * oi["peak_best"]
+                assert tie, (bi, "different tail although the peaks are %.6g vs %.6g" % (oi["peak_best"], oi["peak_runner_up"]), gi, oi)
+                n_tie += 1
                 d = np.abs(go[:, None, :] - oo[None, :, :]).max(2).min(1)
                 # float sums over the outline in a different order (lanes + tree vs sequential): the bound grows with the number of points
                 assert d.max() <= 1e-3 * max(1.0, gi["n_outline"] / 200.0)
-    assert n_cmp > 0 and n_same / n_cmp >= min_ok, (n_same, n_cmp)
+    assert n_cmp > 0 and n_same + n_tie == n_cmp and n_tie <= max_ties * n_cmp, (n_same, n_tie, n_cmp)
     assert n_same - n_close <= max(1, 0.05 * n_same), (n_close, n_same)
-    return n_cmp
+    print("posture: %d blobs compared, %d with the same tail, %d ties of the curvature peaks (either tip accepted)" % (n_cmp, n_same, n_tie))
+    return n_cmp, n_tie
 
 
 def test_synthetic_individuals():
     fr, bg = synth.batch("C2", 3)
     res, outline, segs, info = run_posture(fr, bg)
-    n = compare(res, outline, segs, info, oracle.posture_params(max_points=512))
+    n, ties = compare(res, outline, segs, info, oracle.posture_params(max_points=512), max_ties=0.03)
     assert n == 96
     ok = info["status"] == 0
     assert ok.mean() > 0.9
@@ -113,7 +123,7 @@ def test_setting_variants_and_odd_shapes(kw):
     res, outline, segs, info = run_posture(fr[None], bg, **kw)
     # order-1 EFT turns every outline into an exact ellipse whose two tips have EQUAL curvature: the tail is a coin flip
     # decided by float rounding there, so only the closed curve is compared for that variant
-    compare(res, outline, segs, info, oracle.posture_params(max_points=512, **kw), min_ok=0.0 if kw.get("outline_approximate") == 1 else (0.6 if "midline_walk_offset" in kw else 0.8))   # the random discs have near-tied curvature peaks
+    compare(res, outline, segs, info, oracle.posture_params(max_points=512, **kw))     # (the tie rate is printed: discs and order-1 ellipses are mostly ties)
 
 
 def test_rethreshold_table_and_capacity():
