@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define TREXHIP_ABI_VERSION 4
+#define TREXHIP_ABI_VERSION 5
 
 enum {
     TREXHIP_OK = 0,
@@ -196,8 +196,26 @@ int trexhip_synchronize(trexhip_ctx* ctx);
  *   timestamps  host array [n_frames] (relative to the file header's timestamp) or NULL (zeros)
  *   d_out       the bodies back to back, in frame order;  d_offsets [n_frames + 1] byte offsets (d_offsets[n_frames] = total bytes;
  *               when that exceeds `capacity` nothing valid was written: call again with a larger buffer)
- * The file header (pv.cpp:842-990) and LZO compression are not produced. */
+ * Compression and the index table: trexhip_pv_write_frames below (host side); the file header (pv.cpp:842-990) is not produced. */
 int trexhip_pack_frames_v6_device(trexhip_ctx* ctx, const uint64_t* timestamps, uint8_t* d_out, size_t capacity, uint64_t* d_offsets);
+
+/* ---- .pv data section: per-frame LZO1X compression + index table (host side, no GPU needed) -------
+ * trexhip_pv_write_frames = the tail of pv::Frame::serialize (pv.cpp:705-772: a pack of >= 15000 bytes -- every pack when
+ * always_compress, which is what the rgb8 encoding does -- goes through LZO1X-1 and is kept compressed if 8 + compressed < uncompressed)
+ * + pv::File::add_individual (pv.cpp:1488-1496: u8 compression_flag, then either the pack or u32 compressed size, u32 uncompressed size,
+ * compressed bytes; the frame's offset in the file goes to the index table) for the frames of trexhip_pack_frames_v6_device copied to
+ * the host (`bodies` + `offsets`, each starting with its compression_flag 0).
+ *   file_offset  where `out` will sit in the file (the data section starts right behind the header, pv.cpp:1079-1095)
+ *   out          capacity >= sum of the bodies is always enough;  *out_bytes = bytes written
+ *   index_table  [n_frames] u64 file offsets = what pv::Header::update writes as the index table (pv.cpp:1181-1192) and
+ *                Header::read loads (pv.cpp:986-990)
+ * The stream is read back by pv::Frame::read_from's lzo1x_decompress (pv.cpp:316-340).  The compressor is this library's own LZO1X
+ * encoder, not a byte-for-byte lzo1x_1_compress (ProcessedVideo/lzo/minilzo.c): a reader only ever sees the decompressed pack.
+ * Still blocked on the un-vendored commons: the header's strings / cv::Size encoding (DataFormat) and the >= V_7 line type. */
+size_t trexhip_lzo1x_bound(size_t n);            /* pv.cpp:712 OUT_LEN: n + n / 16 + 64 + 3 */
+int trexhip_lzo1x_compress(const uint8_t* in, size_t n, uint8_t* out, size_t capacity, size_t* out_len);
+int trexhip_pv_write_frames(const uint8_t* bodies, const uint64_t* offsets, int32_t n_frames, int32_t always_compress, uint64_t file_offset,
+                            uint8_t* out, size_t capacity, uint64_t* index_table, size_t* out_bytes);
 
 /* ---- track-stage re-threshold -----------------------------------------------------------------
  * Tracker::prefilter's arithmetic (tracking/Tracker.cpp:765-849): for every kept blob of the last segmented

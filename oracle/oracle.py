@@ -483,6 +483,17 @@ def pv_serialize_v6(blobs, runs, pixels, timestamp=0):
     return out
 
 
+def lzo1x_decompress(data, out_len):
+    """the oracle's restatement of the LZO1X decoder (oracle/trex_pv.c) -> bytes, or None for a malformed stream"""
+    src = np.ascontiguousarray(np.frombuffer(bytes(data), np.uint8))
+    dst = np.zeros(max(1, out_len), np.uint8)
+    f = lib().oracle_lzo1x_decompress
+    f.restype = C.c_int64
+    f.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64]
+    n = f(_ptr(src), len(src), _ptr(dst), out_len)
+    return None if n < 0 else dst[:n].copy()
+
+
 def pv_read_v6(buf):
     """pv::Frame::read_from for version V_6: (bytes consumed, timestamp, runs with y, pixels, runs per object, pixels per object)."""
     buf = np.ascontiguousarray(buf, np.uint8)

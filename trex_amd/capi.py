@@ -110,6 +110,7 @@ SYMBOLS = [
     "trexhip_profile_enable", "trexhip_profile_read", "trexhip_profile_reset",
     "trexhip_default_posture_params", "trexhip_posture_device", "trexhip_posture_auto_device", "trexhip_pack_frames_v6_device", "trexhip_crops_device", "trexhip_pixel_channels", "trexhip_device_alloc", "trexhip_device_free", "trexhip_copy_to_host", "trexhip_copy_to_device", "trexhip_crops_transformed_device", "trexhip_crops_posture_device", "trexhip_default_midline_params", "trexhip_midline_device", "trexhip_default_split_params", "trexhip_split_search_device", "trexhip_export_id_table_device", "trexhip_export_id_table_ex_device", "trexhip_load_weights", "trexhip_set_identity_precision", "trexhip_num_classes", "trexhip_identify_device", "trexhip_identify",
     "trexhip_weight_blob_bytes", "trexhip_trainer_create", "trexhip_trainer_destroy", "trexhip_trainer_set_lr", "trexhip_trainer_steps", "trexhip_train_step_device", "trexhip_train_step", "trexhip_train_eval_device", "trexhip_train_eval", "trexhip_trainer_read", "trexhip_trainer_export",
+    "trexhip_lzo1x_bound", "trexhip_lzo1x_compress", "trexhip_pv_write_frames",
 ]
 
 
@@ -164,6 +165,9 @@ def lib():
         L.trexhip_num_classes.argtypes = [C.c_void_p]
         L.trexhip_network_channels.argtypes = [C.c_void_p]
         L.trexhip_pack_frames_v6_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+        L.trexhip_lzo1x_bound.argtypes = [C.c_size_t]; L.trexhip_lzo1x_bound.restype = C.c_size_t
+        L.trexhip_lzo1x_compress.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
+        L.trexhip_pv_write_frames.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_uint64, C.c_void_p, C.c_size_t, C.c_void_p, C.POINTER(C.c_size_t)]
         L.trexhip_comm_unique_id.argtypes = [C.c_void_p]
         L.trexhip_comm_create.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.POINTER(C.c_void_p)]
         L.trexhip_comm_destroy.argtypes = [C.c_void_p]
@@ -582,3 +586,26 @@ class Comm:
         if self._h:
             lib().trexhip_comm_destroy(self._h)
             self._h = C.c_void_p()
+
+
+def lzo1x_compress(data):
+    """this library's LZO1X encoder (host code: no GPU needed) -> compressed bytes; see include/trexhip.h"""
+    src = np.ascontiguousarray(np.frombuffer(bytes(data), np.uint8))
+    cap = int(lib().trexhip_lzo1x_bound(len(src)))
+    out = np.empty(cap, np.uint8)
+    n = C.c_size_t()
+    _check(lib().trexhip_lzo1x_compress(src.ctypes.data_as(C.c_void_p) if len(src) else None, len(src), out.ctypes.data_as(C.c_void_p), cap, C.byref(n)))
+    return out[:n.value].copy()
+
+
+def pv_write_frames(bodies, offsets, always_compress=False, file_offset=0):
+    """.pv data section of the frames trexhip_pack_frames_v6_device packed (host arrays): -> (bytes, index table [n] u64); see include/trexhip.h"""
+    b = np.ascontiguousarray(bodies, np.uint8)
+    o = np.ascontiguousarray(offsets, np.uint64)
+    n = len(o) - 1
+    out = np.empty(int(o[n]) + 16, np.uint8)
+    idx = np.zeros(n, np.uint64)
+    used = C.c_size_t()
+    _check(lib().trexhip_pv_write_frames(b.ctypes.data_as(C.c_void_p), o.ctypes.data_as(C.c_void_p), n, 1 if always_compress else 0, file_offset,
+                                         out.ctypes.data_as(C.c_void_p), len(out), idx.ctypes.data_as(C.c_void_p), C.byref(used)))
+    return out[:used.value].copy(), idx
