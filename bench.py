@@ -125,9 +125,8 @@ def measure(args, env):
 
     def make_pipe(gather):
         comm_ids = None
-        if gather == "library" and use_dist and world > 1:   # rank 0 makes one ncclUniqueId per lane; torch.distributed only hands them out
-            n_lanes = max(2, args.lanes) if args.pipeline else 1
-            box = [[capi.Comm.unique_id() for _ in range(n_lanes)]] if rank == 0 else [None]
+        if gather == "library" and use_dist and world > 1:   # rank 0 makes the ncclUniqueId; torch.distributed only hands it out
+            box = [[capi.Comm.unique_id()]] if rank == 0 else [None]      # one communicator per process, shared by the lanes
             dist.broadcast_object_list(box, src=0)
             comm_ids = box[0]
         # the lanes, their buffers and the step schedule live in trex_amd/pipeline.py (the same object tests/test_bench_shape_gpu.py checks)

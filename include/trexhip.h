@@ -405,6 +405,10 @@ int trexhip_export_id_table_ex_device(trexhip_ctx* ctx, const float* d_probs, in
  *   trexhip_comm_create      every rank, collectively (ncclCommInitRank on the context's device); world = 1 needs no id and no RCCL
  *   trexhip_comm_gather_device  `bytes` from every rank's d_send land at d_recv_rank0 + rank * bytes on rank 0 (world x bytes there;
  *                            ignored on the other ranks).  Enqueued on the context's stream; trexhip_synchronize waits for it.
+ *   trexhip_comm_gather_device_on  the same on the stream of ANOTHER context of the same device: software-pipelined contexts (one per
+ *                            batch in flight) share ONE communicator -- one ncclCommInitRank per process instead of one per context.
+ *                            RCCL orders the operations of a communicator by their issue order, so every rank must issue its gathers in
+ *                            the same sequence (one host thread driving the contexts in a fixed rotation does).
  * RCCL is loaded with dlopen on first use (an instance already in the process is shared). */
 typedef struct trexhip_comm trexhip_comm;
 int trexhip_comm_unique_id(void* id128);
@@ -413,6 +417,7 @@ void trexhip_comm_destroy(trexhip_comm* comm);
 int trexhip_comm_rank(trexhip_comm* comm);
 int trexhip_comm_world(trexhip_comm* comm);
 int trexhip_comm_gather_device(trexhip_comm* comm, const void* d_send, size_t bytes, void* d_recv_rank0);
+int trexhip_comm_gather_device_on(trexhip_comm* comm, trexhip_ctx* stream_ctx, const void* d_send, size_t bytes, void* d_recv_rank0);
 
 /* live HIP-event timing of the dominant kernels on the ctx stream (bench.py roofline):
  * stage ids TREXHIP_STAGE_* ; returns accumulated milliseconds and launch count since reset */

@@ -10,6 +10,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def run(*extra):
+    if "--secondary-only" not in extra:
+        extra = (*extra, "--no-secondary")          # (the secondary runs use their own, full-size shapes: only the test of them pays for that)
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--batch", "16", *extra],
                          capture_output=True, text=True, timeout=600, cwd=ROOT)
     assert out.returncode == 0, out.stderr[-2000:]
@@ -87,3 +89,19 @@ def test_secondary_runs_ride_in_the_same_line():
     # the N > 1 code path with one rank (library communicator, gather) is the same pipeline as the default run of the same shape
     assert "roofline_kernels" in j and set(j["roofline_kernels"]) == {"conv2", "conv3"}
     assert j["roofline"]["kernel"] in (j["roofline_kernels"]["conv2"]["kernel"], j["roofline_kernels"]["conv3"]["kernel"])
+
+
+@pytest.mark.parametrize("n", [2, 4, 8])
+def test_strong_scaling_path_on_one_gpu(n):
+    # the N > 1 strong-scaling launch (one camera's batch split between the ranks) with every rank on GPU 0: one shared communicator per
+    # process, gather of the lanes' tables to rank 0 on the lanes' streams, rank 0's slab copy on its own stream.  Functional only.
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--steps", "3", "--warmup", "1", "--batch", "16", "--scaling", "strong",
+                          "--same-gpu", "--no-cpu-baseline"], capture_output=True, text=True, timeout=900, cwd=ROOT,
+                         env={k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")})
+    if out.returncode != 0 and ("Duplicate GPU" in out.stderr or "No socket interfaces" in out.stderr):
+        pytest.skip("RCCL cannot run several ranks on one GPU here")
+    assert out.returncode == 0, out.stderr[-3000:]
+    j = json.loads([l for l in out.stdout.strip().splitlines() if l.startswith("{")][-1])
+    assert j["n_gpus"] == n and j["scaling"] == "strong" and j["config"]["frames_per_step_per_gpu"] == 16 // n
+    assert j["config"]["gather"].startswith("libtrexhip")
+    assert abs(j["value"] - 16 * 3 / (j["ms_per_step"] * 3e-3)) / j["value"] < 1e-6        # whole-job frames (the batch is split, not multiplied)

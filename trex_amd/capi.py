@@ -104,7 +104,7 @@ class TrainParams(C.Structure):
 
 
 SYMBOLS = [
-    "trexhip_abi_version", "trexhip_network_channels", "trexhip_comm_unique_id", "trexhip_comm_create", "trexhip_comm_destroy", "trexhip_comm_rank", "trexhip_comm_world", "trexhip_comm_gather_device", "trexhip_last_error", "trexhip_default_params", "trexhip_create", "trexhip_destroy",
+    "trexhip_abi_version", "trexhip_network_channels", "trexhip_comm_unique_id", "trexhip_comm_create", "trexhip_comm_destroy", "trexhip_comm_rank", "trexhip_comm_world", "trexhip_comm_gather_device", "trexhip_comm_gather_device_on", "trexhip_last_error", "trexhip_default_params", "trexhip_create", "trexhip_destroy",
     "trexhip_set_stream", "trexhip_set_background", "trexhip_set_background_device", "trexhip_set_background_color", "trexhip_set_background_color_device", "trexhip_generate_average_device", "trexhip_get_background", "trexhip_segment_device",
     "trexhip_segment", "trexhip_segment_color", "trexhip_segment_color_device", "trexhip_rethreshold_device", "trexhip_rethreshold_per_blob_device", "trexhip_fetch_rethreshold", "trexhip_fetch", "trexhip_device_view_get", "trexhip_synchronize",
     "trexhip_profile_enable", "trexhip_profile_read", "trexhip_profile_reset",
@@ -175,6 +175,7 @@ def lib():
         L.trexhip_comm_rank.argtypes = [C.c_void_p]
         L.trexhip_comm_world.argtypes = [C.c_void_p]
         L.trexhip_comm_gather_device.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+        L.trexhip_comm_gather_device_on.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
         L.trexhip_set_identity_precision.argtypes = [C.c_void_p, C.c_int32]
         L.trexhip_identify_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]
         L.trexhip_identify.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]
@@ -579,8 +580,12 @@ class Comm:
         _check(lib().trexhip_comm_unique_id(buf))
         return bytes(buf)
 
-    def gather_device(self, d_send_ptr, nbytes, d_recv_rank0_ptr):
-        _check(lib().trexhip_comm_gather_device(self._h, C.c_void_p(d_send_ptr), nbytes, C.c_void_p(d_recv_rank0_ptr or 0)))
+    def gather_device(self, d_send_ptr, nbytes, d_recv_rank0_ptr, seg=None):
+        """seg: enqueue on that context's stream instead of the communicator's own (contexts of one device sharing the communicator)"""
+        if seg is None:
+            _check(lib().trexhip_comm_gather_device(self._h, C.c_void_p(d_send_ptr), nbytes, C.c_void_p(d_recv_rank0_ptr or 0)))
+        else:
+            _check(lib().trexhip_comm_gather_device_on(self._h, seg.handle, C.c_void_p(d_send_ptr), nbytes, C.c_void_p(d_recv_rank0_ptr or 0)))
 
     def close(self):
         if self._h:

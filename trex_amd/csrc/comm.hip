@@ -105,9 +105,13 @@ int trexhip_comm_rank(trexhip_comm* c) { return c ? c->rank : -1; }
 int trexhip_comm_world(trexhip_comm* c) { return c ? c->world : 0; }
 
 int trexhip_comm_gather_device(trexhip_comm* c, const void* d_send, size_t bytes, void* d_recv_rank0) {
-    if (!c || !d_send) { trexhip::set_error("trexhip_comm_gather_device: null argument"); return TREXHIP_E_INVALID; }
+    return trexhip_comm_gather_device_on(c, c ? c->ctx : nullptr, d_send, bytes, d_recv_rank0);
+}
+
+int trexhip_comm_gather_device_on(trexhip_comm* c, trexhip_ctx* ctx, const void* d_send, size_t bytes, void* d_recv_rank0) {
+    if (!c || !ctx || !d_send) { trexhip::set_error("trexhip_comm_gather_device: null argument"); return TREXHIP_E_INVALID; }
     if (c->rank == 0 && !d_recv_rank0) { trexhip::set_error("trexhip_comm_gather_device: rank 0 needs the receive buffer (world x bytes)"); return TREXHIP_E_INVALID; }
-    trexhip_ctx* ctx = c->ctx;
+    if (ctx->p.device != c->ctx->p.device) { trexhip::set_error("trexhip_comm_gather_device_on: the stream's context is on another device than the communicator"); return TREXHIP_E_INVALID; }
     TH_CHECK_HIP(hipSetDevice(ctx->p.device));
     if (bytes == 0) return TREXHIP_OK;
     if (c->rank == 0 && d_recv_rank0 != d_send)

@@ -29,12 +29,16 @@ class Lane:
         # per-blob record for rank 0's matcher: header + probabilities, with posture also second moments + normalised midline
         self.table = torch.zeros((pl.rows, pl.rowlen), dtype=torch.int32, device=dev)
         self.table_host = torch.empty((pl.world * pl.rows, pl.rowlen), dtype=torch.int32).pin_memory() if pl.rank == 0 else None
-        # N > 1: the library's own communicator (one per context) gathers every rank's table on rank 0 (trexhip_comm_gather_device)
+        # N > 1: the library's own communicator gathers every rank's table on rank 0 (trexhip_comm_gather_device_on).  ONE communicator per
+        # process, created on the first lane's context and used by every lane on its own stream: the lanes are driven by one host thread in
+        # a fixed rotation, so every rank issues its gathers in the same order (what RCCL requires of operations on one communicator)
         self.comm = None
         self.table_all = None
         if pl.use_dist:
             if pl.gather == "library":
-                self.comm = capi.Comm(self.seg, pl.rank, pl.world, pl.next_comm_id())
+                if pl.shared_comm is None:
+                    pl.shared_comm = capi.Comm(self.seg, pl.rank, pl.world, pl.next_comm_id())
+                self.comm = pl.shared_comm
             self.table_all = torch.zeros((pl.world * pl.rows, pl.rowlen), dtype=torch.int32, device=dev) if pl.rank == 0 else None
         if pl.with_posture:
             MP = pl.MP
@@ -44,6 +48,10 @@ class Lane:
             self.p_mid = torch.empty((pl.pool, 25, 4), dtype=torch.float32, device=dev)
             self.p_minfo = torch.empty((pl.pool, 8), dtype=torch.int32, device=dev)
         self.stream = torch.cuda.Stream(device=dev)   # torch-side copies ride on the same stream as the kernels
+        # rank 0's copy of the gathered slab (world x table) to the host has its own stream: behind the gather by an event, off the lane's
+        # kernel stream, so that the lane's next posture / crops never queue behind world x 14 MB of PCIe traffic
+        self.copy_stream = torch.cuda.Stream(device=dev) if (pl.rank == 0 and pl.use_dist) else None
+        self.gathered = torch.cuda.Event() if self.copy_stream is not None else None
         self.seg.set_stream(self.stream.cuda_stream)
         self.hi = torch.cuda.Stream(device=dev, priority=-1) if o["detect_priority"] else None
         self.n = 0
@@ -94,19 +102,26 @@ class Lane:
             else:
                 seg.export_id_table(self.probs.data_ptr(), n, pl.classes, frame_base, self.table.data_ptr(), pl.rows)
             if pl.use_dist and self.comm is not None:   # grouped send / recv on the context's stream, behind the table kernel
-                self.comm.gather_device(self.table.data_ptr(), self.table.numel() * 4, self.table_all.data_ptr() if pl.rank == 0 else 0)
+                self.comm.gather_device(self.table.data_ptr(), self.table.numel() * 4, self.table_all.data_ptr() if pl.rank == 0 else 0, seg=seg)
             elif pl.use_dist:                   # gather="torch": the same exchange through torch.distributed's RCCL communicator
                 import torch.distributed as dist
                 with torch.cuda.stream(self.stream):
                     dist.gather(self.table, list(self.table_all.view(pl.world, pl.rows, pl.rowlen).unbind(0)) if pl.rank == 0 else None, dst=0)
-            with torch.cuda.stream(self.stream):
-                if pl.rank == 0:
-                    self.table_host.copy_(self.table_all if pl.use_dist else self.table, non_blocking=True)
+            if pl.rank == 0 and self.copy_stream is not None:
+                self.gathered.record(self.stream)
+                self.copy_stream.wait_event(self.gathered)
+                with torch.cuda.stream(self.copy_stream):
+                    self.table_host.copy_(self.table_all, non_blocking=True)
+            elif pl.rank == 0:
+                with torch.cuda.stream(self.stream):
+                    self.table_host.copy_(self.table, non_blocking=True)
         else:
             self.done.record(self.stream)
 
     def drain(self):
         self.stream.synchronize()
+        if self.copy_stream is not None:
+            self.copy_stream.synchronize()
 
 
 class Pipeline:
@@ -117,7 +132,7 @@ class Pipeline:
         self.local, self.rank, self.world, self.use_dist = local, rank, world, use_dist
         assert gather in ("library", "torch")
         self.gather = gather                      # who owns the RCCL communicator of the table gather: libtrexhip (default) or torch.distributed
-        self._comm_ids = list(comm_ids or [])     # one ncclUniqueId (128 bytes, made by rank 0) per lane, in lane order
+        self._comm_ids = list(comm_ids or [])     # the ncclUniqueId (128 bytes, made by rank 0) of the process group's one communicator
         self.dev = torch.device("cuda", local)
         self.with_cnn, self.with_posture, self.rgb, self.bgra_in = with_cnn, with_posture or normalize == "posture", rgb, bgra_in or rgb
         self.weight_blob = weight_blob
@@ -128,6 +143,7 @@ class Pipeline:
         self.rows = B * n_ind * 5 // 4             # fixed table rows per rank per step (a gather needs equal sizes)
         self.MP = 256
         self.rowlen = (tdist.HDR_EX + classes + 3 * 25) if self.with_posture else (tdist.HDR + classes)
+        self.shared_comm = None
         self.lanes = [Lane(self) for _ in range(max(2, lanes))] if pipeline else [Lane(self)]
         if len(self.lanes) > 1:
             for k, ln in enumerate(self.lanes):
@@ -138,7 +154,7 @@ class Pipeline:
     def next_comm_id(self):
         if self.world == 1:
             return None
-        assert self._comm_ids, "Pipeline(use_dist=True, world > 1) needs comm_ids: one trexhip_comm_unique_id() of rank 0 per lane"
+        assert self._comm_ids, "Pipeline(use_dist=True, world > 1) needs comm_ids = [trexhip_comm_unique_id() of rank 0]"
         return self._comm_ids.pop(0)
 
     def run(self, k, frames_ptr, on_batch=None):
@@ -181,7 +197,8 @@ class Pipeline:
         return lanes[(k - 1) % L].n
 
     def close(self):
+        if self.shared_comm is not None:
+            self.shared_comm.close()
+            self.shared_comm = None
         for ln in self.lanes:
-            if ln.comm is not None:
-                ln.comm.close()
             ln.seg.close()
