@@ -86,3 +86,30 @@ def test_unimplemented_settings_are_refused_not_ignored(name):
     rc = capi.lib().trexhip_create(C.byref(p), C.byref(h))
     assert rc == -4 and h.value is None                                   # TREXHIP_E_UNSUPPORTED
     assert name.encode() in capi.lib().trexhip_last_error()
+
+
+def test_host_colour_reduce_simd_paths_are_bit_exact():
+    # hostcvt.cpp: the upload threads' BGRA -> gray reduction (cv::cvtColor's 8-bit fixed point, BackgroundSubtraction.cpp:162-180) has
+    # explicit AVX2 / AVX-512 forms; every instruction set the CPU offers must give the scalar formula's bytes, for every length and alignment
+    import ctypes as C
+    import numpy as np
+    from trex_amd import capi
+    L = capi.lib()
+    f = L.trexhip_host_reduce_row_isa
+    f.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    rng = np.random.default_rng(0)
+    ran = set()
+    for n in (1, 15, 16, 17, 31, 33, 100, 1023, 1024, 1025, 4096, 2048 * 8 + 5):
+        src = rng.integers(0, 256, (n, 4), dtype=np.uint8)
+        src[:min(n, 3)] = [[255, 255, 255, 7], [0, 0, 0, 255], [255, 0, 255, 0]][:min(n, 3)]
+        want = ((src[:, 0].astype(np.uint32) * 1868 + src[:, 1].astype(np.uint32) * 9617 + src[:, 2].astype(np.uint32) * 4899 + 8192) >> 14).astype(np.uint8)
+        for off in (0, 5):
+            for isa in (0, 1, 2):
+                buf = np.full(n + 64, 77, np.uint8)
+                a = (-buf.ctypes.data) % 16 + off
+                rc = f(src.ctypes.data, buf.ctypes.data + a, n, isa)
+                if rc != 0:
+                    continue                      # this CPU lacks the instruction set
+                ran.add(isa)
+                assert np.array_equal(buf[a:a + n], want) and (buf[a + n:] == 77).all() and (buf[:a] == 77).all(), (n, isa, off)
+    assert 0 in ran

@@ -14,8 +14,46 @@
 #include <functional>
 #include <mutex>
 #include <thread>
+#include <cstdio>
+#include <pthread.h>
+#include <sched.h>
 
 namespace trexhip {
+
+// CPUs of the NUMA node the calling thread runs on (empty when /sys does not say).  The copy threads are pinned there, one CPU each:
+// the tiles were written by the caller's side of the machine, and a copy thread on the other socket reads 16 MB per frame across the
+// inter-socket link (measured on the two-socket GPU box: the copy leg of a 256-frame upload then takes 80-95 ms instead of 21)
+static std::vector<int> local_node_cpus() {
+    std::vector<int> out;
+    const int cpu = sched_getcpu();
+    if (cpu < 0) return out;
+    for (int node = 0; node < 64; ++node) {
+        char path[96];
+        std::snprintf(path, sizeof(path), "/sys/devices/system/node/node%d/cpulist", node);
+        FILE* f = std::fopen(path, "r");
+        if (!f) break;
+        std::vector<int> cpus;
+        int a = 0, b = 0;
+        bool mine = false;
+        for (;;) {
+            if (std::fscanf(f, "%d", &a) != 1) break;
+            b = a;
+            int ch = std::fgetc(f);
+            if (ch == '-') { if (std::fscanf(f, "%d", &b) != 1) break; ch = std::fgetc(f); }
+            for (int c = a; c <= b; ++c) { cpus.push_back(c); mine |= c == cpu; }
+            if (ch != ',') break;
+        }
+        std::fclose(f);
+        if (mine) { out = cpus; break; }
+    }
+    cpu_set_t allowed;
+    if (!out.empty() && sched_getaffinity(0, sizeof(allowed), &allowed) == 0) {      // never outside what the process may use (cgroup / taskset)
+        std::vector<int> ok;
+        for (int c : out) if (CPU_ISSET(c, &allowed)) ok.push_back(c);
+        out.swap(ok);
+    }
+    return out;
+}
 
 // a few persistent host threads that copy row ranges; one job at a time (the ctx is not re-entrant)
 struct CopyPool {
@@ -28,8 +66,16 @@ struct CopyPool {
     bool stop = false;
 
     explicit CopyPool(int n) {
+        static const bool pin = [] { const char* e = std::getenv("TREXHIP_UPLOAD_PIN"); return !(e && std::atoi(e) == 0); }();
+        const std::vector<int> cpus = pin ? local_node_cpus() : std::vector<int>();
         for (int w = 0; w < n; ++w)
-            workers.emplace_back([this, w, n]() {
+            workers.emplace_back([this, w, n, cpus]() {
+                if ((int)cpus.size() > n + 1) {                       // worker w on its own CPU of the caller's node (the first one is left to the caller)
+                    cpu_set_t set;
+                    CPU_ZERO(&set);
+                    CPU_SET(cpus[(size_t)(w + 1) % cpus.size()], &set);
+                    (void)pthread_setaffinity_np(pthread_self(), sizeof(set), &set);
+                }
                 uint64_t seen = 0;
                 for (;;) {
                     std::function<void(int, int)> j;
@@ -40,7 +86,7 @@ struct CopyPool {
                         seen = generation;
                         j = job;
                     }
-                    j(w + 1, n + 1);                                   // the calling thread is worker 0
+                    j(w, n);                                           // (the calling thread does not copy: it issues the DMAs meanwhile)
                     {
                         std::lock_guard<std::mutex> g(mu);
                         if (--pending == 0) cv_done.notify_one();
@@ -53,13 +99,14 @@ struct CopyPool {
         cv_go.notify_all();
         for (auto& t : workers) t.join();
     }
-    void run(const std::function<void(int, int)>& f) {
+    void start(const std::function<void(int, int)>& f) {
         {
             std::lock_guard<std::mutex> g(mu);
             job = f; pending = (int)workers.size(); ++generation;
         }
         cv_go.notify_all();
-        f(0, (int)workers.size() + 1);
+    }
+    void wait() {
         std::unique_lock<std::mutex> g(mu);
         cv_done.wait(g, [&] { return pending == 0; });
     }
@@ -93,8 +140,8 @@ static int upload_prepare(trexhip_ctx* ctx, size_t frame_bytes) {   // frame_byt
     if (!u.pool) {
         int n = 0;
         if (const char* e = std::getenv("TREXHIP_UPLOAD_THREADS")) n = std::atoi(e);
-        if (n <= 0) { const unsigned hc = std::thread::hardware_concurrency(); n = hc >= 64 ? 16 : (hc >= 32 ? 10 : (hc >= 16 ? 6 : (hc >= 8 ? 4 : (hc >= 4 ? 2 : 1)))); }   // 6 -> 16 threads on the 256-thread box: 4.5 k -> 8 k BGRA frames/s
-        u.pool = new CopyPool(n - 1);
+        if (n <= 0) { const unsigned hc = std::thread::hardware_concurrency(); n = hc >= 128 ? 32 : hc >= 64 ? 16 : (hc >= 32 ? 10 : (hc >= 16 ? 6 : (hc >= 8 ? 4 : (hc >= 4 ? 2 : 1)))); }   // 6 -> 16 threads on the 256-thread box: 4.5 k -> 8 k BGRA frames/s
+        u.pool = new CopyPool(n);
     }
     return TREXHIP_OK;
 }
@@ -119,7 +166,20 @@ int upload_frames(trexhip_ctx* ctx, const uint8_t* const* frames, int n, size_t 
     // the device buffer may still be read by the previous batch
     TH_CHECK_HIP(hipStreamSynchronize(ctx->stream));
     double copy_ms = 0.0;
-    int chunk = 0;
+    // chunk c is filled by the copy threads while the calling thread enqueues the DMA (and the device work) of chunk c - 1: two event
+    // records, the copy, a stream wait and the caller's launches per chunk cost ~0.2 ms of API time, which used to sit between the fills
+    auto issue = [&](int i0, int cnt, int s) -> int {
+        uint8_t* slot = u.ring + (size_t)s * u.slot_bytes;
+        TH_CHECK_HIP(hipEventRecord(u.ev_start[s], u.copy_stream));
+        TH_CHECK_HIP(hipMemcpyAsync(d_dst + (size_t)i0 * frame_bytes, slot, frame_bytes * (size_t)cnt, hipMemcpyHostToDevice, u.copy_stream));
+        TH_CHECK_HIP(hipEventRecord(u.ev_done[s], u.copy_stream));
+        u.busy[s] = true; u.frames_in[s] = cnt;
+        TH_CHECK_HIP(hipStreamWaitEvent(ctx->stream, u.ev_done[s], 0));
+        if (after_chunk) { const int rc2 = after_chunk(i0, cnt); if (rc2) return rc2; }
+        return TREXHIP_OK;
+    };
+    int chunk = 0, prev_i0 = -1, prev_cnt = 0, prev_s = 0;
+    const auto t_all = std::chrono::steady_clock::now();
     for (int i0 = 0; i0 < n; i0 += per, ++chunk) {
         const int cnt = std::min(per, n - i0);
         const int s = chunk % UP_SLOTS;
@@ -130,9 +190,8 @@ int upload_frames(trexhip_ctx* ctx, const uint8_t* const* frames, int n, size_t 
             u.busy[s] = false;
         }
         uint8_t* slot = u.ring + (size_t)s * u.slot_bytes;
-        const auto t0 = std::chrono::steady_clock::now();
         const size_t total_rows = rows * (size_t)cnt;
-        pool->run([=](int w, int nw) {                                // the rows of the whole chunk are dealt to the threads
+        pool->start([=](int w, int nw) {                              // the rows of the whole chunk are dealt to the threads
             const size_t r0 = total_rows * (size_t)w / (size_t)nw, r1 = total_rows * (size_t)(w + 1) / (size_t)nw;
             size_t r = r0;
             while (r < r1) {
@@ -149,14 +208,14 @@ int upload_frames(trexhip_ctx* ctx, const uint8_t* const* frames, int n, size_t 
                 r += run;
             }
         });
-        copy_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
-        TH_CHECK_HIP(hipEventRecord(u.ev_start[s], u.copy_stream));
-        TH_CHECK_HIP(hipMemcpyAsync(d_dst + (size_t)i0 * frame_bytes, slot, frame_bytes * (size_t)cnt, hipMemcpyHostToDevice, u.copy_stream));
-        TH_CHECK_HIP(hipEventRecord(u.ev_done[s], u.copy_stream));
-        u.busy[s] = true; u.frames_in[s] = cnt;
-        TH_CHECK_HIP(hipStreamWaitEvent(ctx->stream, u.ev_done[s], 0));
-        if (after_chunk) { rc = after_chunk(i0, cnt); if (rc) return rc; }
+        int rc1 = TREXHIP_OK;
+        if (prev_i0 >= 0) rc1 = issue(prev_i0, prev_cnt, prev_s);
+        pool->wait();
+        if (rc1) return rc1;
+        prev_i0 = i0; prev_cnt = cnt; prev_s = s;
     }
+    if (prev_i0 >= 0) { rc = issue(prev_i0, prev_cnt, prev_s); if (rc) return rc; }
+    copy_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_all).count();      // the whole host leg of the call
     u.copy_ms += copy_ms; u.copy_n += n;
     return TREXHIP_OK;
 }
