@@ -8,7 +8,7 @@ ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/prof
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-BENCH="python $ROOT/bench.py --no-cpu-baseline"
+BENCH="python $ROOT/bench.py --no-cpu-baseline --no-secondary"
 rm -rf /tmp/p_stats /tmp/p_fetch /tmp/p_write
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_stats -- $BENCH --steps 5 --warmup 2 > "$OUT/${TAG}_stats_run.log" 2>&1
 f=$(find /tmp/p_stats -name '*kernel_stats.csv' | head -1)

@@ -7,7 +7,7 @@ BARGS="$1"; shift
 cd /tmp && export TMPDIR=/tmp
 for set in "$@"; do
   rm -rf /tmp/pc
-  rocprofv3 --pmc $set --kernel-trace --output-format csv -d /tmp/pc -- python $ROOT/bench.py --no-cpu-baseline --no-pipeline --steps 2 --warmup 1 $BARGS > /tmp/pc.log 2>&1
+  rocprofv3 --pmc $set --kernel-trace --output-format csv -d /tmp/pc -- python $ROOT/bench.py --no-cpu-baseline --no-secondary --no-pipeline --steps 2 --warmup 1 $BARGS > /tmp/pc.log 2>&1
   f=$(find /tmp/pc -name '*counter_collection.csv' | head -1)
   python - "$f" "$PAT" <<'PY'
 import csv, sys, collections, re

@@ -467,7 +467,7 @@ struct W2bGeom {
 };
 __device__ __forceinline__ int w2b_rot(const int slot) { return (slot & 1) + ((slot & 6) << 1); }
 
-template <int DBG = 0, int STAGGER = 5>      // DBG (dev builds): 1 no staging, 2 no epilogue, 4 no weight loads, 8 no A reads, 32 no V3 transform; STAGGER: x 1024 cycles
+template <int DBG = 0, int STAGGER = 5, int AD = 1, int BD = 3>      // DBG (dev builds): 1 no staging, 2 no epilogue, 4 no weight loads, 8 no A reads, 32 no V3 transform; STAGGER: x 1024 cycles; AD / BD: taps of lead of the A / weight fragments
 __global__ __launch_bounds__(256, 2) void k_conv2_wpre2(const uint8_t* __restrict__ v2, const uint4* __restrict__ wp /*[5][8][2][2][64] x 16 B*/,
                                                         const float* __restrict__ bias, uint8_t* __restrict__ v3, const float out_scale,
                                                         uint32_t* __restrict__ overflow, const int n_crops, uint32_t* __restrict__ pass_ctr) {
@@ -525,8 +525,7 @@ __global__ __launch_bounds__(256, 2) void k_conv2_wpre2(const uint8_t* __restric
     __syncthreads();
 #define W2_POS(tau_) (((tau_) / 20) == 0 ? ((tau_) % 4 == 3 ? 7 : (tau_) % 4) : 3 + (tau_) % 4)
 #define W2_BOFF(tau_) (((((tau_) % 20) / 4) * 8 + W2_POS(tau_)) * G::BV * 16)
-    constexpr int BD = 3;
-    uint4 bq[4][2];
+    uint4 bq[8][2];
 #pragma unroll
     for (int t = 0; t < BD; ++t) { bq[t][0] = buf_load16(wrs, boff, W2_BOFF(t)); bq[t][1] = buf_load16(wrs, boff, W2_BOFF(t) + 2 * CO * 16); }
     bool ovf = false;
@@ -564,27 +563,29 @@ __global__ __launch_bounds__(256, 2) void k_conv2_wpre2(const uint8_t* __restric
         // the tap loop outranks the other workgroup's epilogue on the shared issue port: MFMA and VALU instructions are arbitrated by
         // priority, then age, and an older wave in its (VALU-dense) epilogue would leave a younger wave's MFMAs only the leftover slots
         if (!(DBG & 64)) __builtin_amdgcn_s_setprio(3);
-        uint4 af[2][2];                                                   // [tap parity][piece]
+        // operand fetches are issued AD taps (A fragments, LDS) and BD taps (weight fragments, L2) ahead.  Measured: (1, 3), (2, 4), (2, 6) and
+        // (3, 7) all take 3.83-3.95 ms per 25600 crops -- the waves' waits (SQ_WAIT_ANY 52 %) are the pass's barriers and its DMA, not these
+        uint4 af[AD + 1][2];                                              // ring over taps: [tap % (AD + 1)][piece]
 #define W2B_AREAD(dst_, tau_)                                                                                                    \
         do {                                                                                                                     \
             const uint8_t* an_ = ldsb + ((tau_) / 20) * G::BUF + aoff[((tau_) % 20) / 4][(tau_) % 4];                            \
             dst_[0] = *reinterpret_cast<const uint4*>(an_);                                                                      \
             dst_[1] = *reinterpret_cast<const uint4*>(an_ + G::PLANE);                                                           \
         } while (0)
-        W2B_AREAD(af[0], 0);
+#pragma unroll
+        for (int t = 0; t < AD; ++t) W2B_AREAD(af[t], t);
 #pragma clang loop unroll(full)
         for (int tau = 0; tau < 40; ++tau) {
             const int tl = tau % 20;
-            const int cur = tau & 1, nxt = cur ^ 1;
-            if (!(DBG & 8) && tau + 1 < 40) W2B_AREAD(af[nxt], tau + 1);
+            if (!(DBG & 8) && tau + AD < 40) W2B_AREAD(af[(tau + AD) % (AD + 1)], tau + AD);
             if (!(DBG & 4)) {
                 const int wt = W2_BOFF((tau + BD) % 40);
-                bq[(tau + BD) % 4][0] = buf_load16(wrs, boff, wt);
-                bq[(tau + BD) % 4][1] = buf_load16(wrs, boff, wt + 2 * CO * 16);
+                bq[(tau + BD) % 8][0] = buf_load16(wrs, boff, wt);
+                bq[(tau + BD) % 8][1] = buf_load16(wrs, boff, wt + 2 * CO * 16);
             }
             const int p = W2_POS(tau);
-            const f16x8 b1 = __builtin_bit_cast(f16x8, bq[tau % 4][0]), b2 = __builtin_bit_cast(f16x8, bq[tau % 4][1]);
-            const f16x8 a1 = __builtin_bit_cast(f16x8, af[cur][0]), a2 = __builtin_bit_cast(f16x8, af[cur][1]);
+            const f16x8 b1 = __builtin_bit_cast(f16x8, bq[tau % 8][0]), b2 = __builtin_bit_cast(f16x8, bq[tau % 8][1]);
+            const f16x8 a1 = __builtin_bit_cast(f16x8, af[tau % (AD + 1)][0]), a2 = __builtin_bit_cast(f16x8, af[tau % (AD + 1)][1]);
             acc[p] = mfma16(a2, b1, tl < 4 ? zero16 : acc[p]);            // kernel row 0 starts the accumulator
             acc[p] = mfma16(a1, b2, acc[p]);
             acc[p] = mfma16(a1, b1, acc[p]);
