@@ -45,7 +45,7 @@ class PostureParams(C.Structure):
 
 class PostureInfo(C.Structure):
     _fields_ = [("status", C.c_int32), ("n_outline", C.c_int32), ("n_segments", C.c_int32), ("tail_index", C.c_int32),
-                ("head_index", C.c_int32), ("n_traced", C.c_int32), ("peak_best", C.c_float), ("peak_runner_up", C.c_float)]
+                ("head_index", C.c_int32), ("n_traced", C.c_int32), ("peak_best", C.c_float), ("peak_runner_up", C.c_float), ("peak_margin", C.c_float)]
 
 
 def posture_params(outline_resample=1.0, outline_smooth_samples=4, outline_smooth_step=1, outline_approximate=3,

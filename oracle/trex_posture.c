@@ -203,8 +203,9 @@ typedef struct oracle_posture_params {
 } oracle_posture_params;
 /* peak_best / peak_runner_up: curvature at the chosen tail and the largest curvature anywhere farther than the curvature range from it
  * (test infrastructure: when the two are within float rounding of each other the tail is a coin flip, and a test can tell a legitimate
- * tie from a wrong choice) */
-typedef struct oracle_posture_info { int32_t status, n_outline, n_segments, tail_index, head_index, n_traced; float peak_best, peak_runner_up; } oracle_posture_info;
+ * tie from a wrong choice); peak_margin: by how much the tail's curvature exceeds the larger of its two neighbours, relative -- the
+ * local-maximum test itself (c[i] > c[i-1] && c[i] >= c[i+1]) is a coin flip on a flat top */
+typedef struct oracle_posture_info { int32_t status, n_outline, n_segments, tail_index, head_index, n_traced; float peak_best, peak_runner_up, peak_margin; } oracle_posture_info;
 
 /* status: 0 ok, 1 empty blob/outline, 2 capacity, 3 no curvature peak, 4 too few midline segments */
 int oracle_posture(const oracle_run* runs, int32_t n_runs, int32_t origin_x, int32_t origin_y, const oracle_posture_params* P,
@@ -250,6 +251,7 @@ int oracle_posture(const oracle_run* runs, int32_t n_runs, int32_t origin_x, int
                 if (dd > r && curv[i] > runner) runner = curv[i];
             }
             info->peak_best = best; info->peak_runner_up = runner;
+            { const float c0 = curv[(tail - 1 + n) % n], c2 = curv[(tail + 1) % n]; info->peak_margin = best > 0.f ? (best - (c0 > c2 ? c0 : c2)) / best : 0.f; }
         }
         int head = -1; float maxd = 0;
         for (int i = 0; i < n; ++i) {
