@@ -462,7 +462,6 @@ struct W2bGeom {
     static constexpr int PBUF_OFF = 2 * BUF, PBUF = RPP * 20 * 64 * 4;
     static constexpr int LDS_BYTES = PBUF_OFF + PBUF;
     static constexpr int BV = 2 * 2 * CO;
-    static constexpr int NDMA = (NR * ROWL + 1023) / 1024;              // DMA instructions per plane (the last one half a wave)
     static_assert(2 * (LDS_BYTES + 64) <= 160 * 1024, "two workgroups per CU");
 };
 __device__ __forceinline__ int w2b_rot(const int slot) { return (slot & 1) + ((slot & 6) << 1); }
@@ -496,23 +495,30 @@ __global__ __launch_bounds__(256, 2) void k_conv2_wpre2(const uint8_t* __restric
         qmin_ = 2 * gp0_ - (y0_ >= 2 ? 2 : 0);                                                                                   \
         nrows_ = 2 * gpl_ + 1 + (yl_ + 2 <= S - 1 ? 2 : 0) - qmin_ + 1;                                                          \
     } while (0)
-    // plane (group = wave >> 1, piece = wave & 1) of a pass, HBM -> LDS; rows past the pass's last row repeat it
-#define W2B_DMA(qmin_, nrows_)                                                                                                   \
+    // rows [lo_, hi_) (even bounds) of plane (group = wave >> 1, piece = wave & 1), HBM -> LDS.  The row slots are a RING: batch row q lives
+    // in slot q % NR + 1, so the 4 halo rows that consecutive passes share stay where they are and only the 6 new rows of a pass are fetched
+    // (the DMA bytes and the HBM reads of the layer fall by 40 %).  Two rows = 2560 contiguous bytes = 2.5 DMA instructions.
+#define W2B_DMA(lo_, hi_)                                                                                                        \
     do {                                                                                                                         \
-        const uint8_t* src_ = v2 + (size_t)(qmin_) * V2_ROWB + (wave & 1) * 2560 + (wave >> 1) * 1280;                           \
-        uint8_t* dst_ = ldsb + (wave >> 1) * G::BUF + (wave & 1) * G::PLANE + G::ROWL;                                           \
-        _Pragma("unroll 1") for (int i_ = 0; i_ < G::NDMA; ++i_) {                                                               \
-            const int o_ = i_ * 1024 + lane * 16;                                                                                \
-            if (o_ < G::NR * G::ROWL) {                                                                                          \
-                int row_ = o_ / G::ROWL;                                                                                         \
-                const int wl_ = (o_ - row_ * G::ROWL) >> 4;                                                                      \
-                const int w_ = (wl_ & ~15) | ((wl_ - w2b_rot(row_ + 1)) & 15);                                                   \
-                row_ = row_ < (nrows_) ? row_ : (nrows_) - 1;                                                                    \
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src_ + (size_t)row_ * V2_ROWB + w_ * 16), \
-                                                 (__attribute__((address_space(3))) void*)(dst_ + i_ * 1024), 16, 0, 0);         \
+        const uint8_t* src_ = v2 + (wave & 1) * 2560 + (wave >> 1) * 1280;                                                       \
+        uint8_t* dst_ = ldsb + (wave >> 1) * G::BUF + (wave & 1) * G::PLANE;                                                     \
+        _Pragma("unroll 1") for (int q_ = (lo_); q_ < (hi_); q_ += 2) {                                                          \
+            const int slot0_ = q_ % G::NR + 1;                                                                                   \
+            _Pragma("unroll") for (int i_ = 0; i_ < 3; ++i_) {                                                                   \
+                const int o_ = i_ * 1024 + lane * 16;                                                                            \
+                if (o_ < 2 * G::ROWL) {                                                                                          \
+                    const int r_ = o_ >= G::ROWL ? 1 : 0;                                                                        \
+                    const int wl_ = (o_ - r_ * G::ROWL) >> 4;                                                                    \
+                    const int w_ = (wl_ & ~15) | ((wl_ - w2b_rot(slot0_ + r_)) & 15);                                            \
+                    int row_ = q_ + r_;                                                                                          \
+                    row_ = row_ < total_rows ? row_ : total_rows - 1;                                                            \
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src_ + (size_t)row_ * V2_ROWB + w_ * 16), \
+                                                     (__attribute__((address_space(3))) void*)(dst_ + slot0_ * G::ROWL + i_ * 1024), 16, 0, 0); \
+                }                                                                                                                \
             }                                                                                                                    \
         }                                                                                                                        \
     } while (0)
+    const int total_rows = n_crops * S;
 
     const __amdgpu_buffer_rsrc_t wrs = make_rsrc(wp, (uint32_t)(40 * G::BV * 16));
     const int boff = (h * CO + n * 32 + j) * 16;
@@ -520,7 +526,8 @@ __global__ __launch_bounds__(256, 2) void k_conv2_wpre2(const uint8_t* __restric
     const float bz = bias[co];
     int qmin, nrows;
     W2B_ROWS(pass, qmin, nrows);
-    if (!(DBG & 1)) W2B_DMA(qmin, nrows);
+    if (!(DBG & 1)) W2B_DMA(qmin, qmin + nrows);
+    int res_hi = qmin + nrows;                                           // rows [this pass's qmin, res_hi) are resident
     if (tid == 0) s_next_pass = ((int)atomicAdd(pass_ctr, 1u) + (int)gridDim.x) * PK;
     __syncthreads();
 #define W2_POS(tau_) (((tau_) / 20) == 0 ? ((tau_) % 4 == 3 ? 7 : (tau_) % 4) : 3 + (tau_) % 4)
@@ -549,7 +556,7 @@ __global__ __launch_bounds__(256, 2) void k_conv2_wpre2(const uint8_t* __restric
 #pragma unroll
             for (int ky = 0; ky < 5; ++ky) {
                 const int iy = y + ky - 2;
-                const int slot = (iy >= 0 && iy < S) ? qo + ky - 2 - qmin + 1 : 0;
+                const int slot = (iy >= 0 && iy < S) ? (qo + ky - 2) % G::NR + 1 : 0;
                 const int rot = w2b_rot(slot);
 #pragma unroll
                 for (int pg = 0; pg < 4; ++pg) {
@@ -589,6 +596,18 @@ __global__ __launch_bounds__(256, 2) void k_conv2_wpre2(const uint8_t* __restric
             acc[p] = mfma16(a2, b1, tl < 4 ? zero16 : acc[p]);            // kernel row 0 starts the accumulator
             acc[p] = mfma16(a1, b2, acc[p]);
             acc[p] = mfma16(a1, b1, acc[p]);
+            // nothing moves across a tap: left alone, the scheduler sinks every operand fetch down to its use (to save registers) and the
+            // wave then waits out the full LDS / L2 latency in front of each MFMA
+            if (!(DBG & 512)) {
+                __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);       // the A fragments of tap + AD ...
+                __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);       // ... and the weight fragments of tap + BD go first,
+#pragma unroll
+                for (int g = 0; g < 3; ++g) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // then the three MFMAs with the address arithmetic in between
+                    __builtin_amdgcn_sched_group_barrier(0x006, 4, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
 #undef W2B_AREAD
         if (!(DBG & 64)) __builtin_amdgcn_s_setprio(0);
@@ -598,10 +617,15 @@ __global__ __launch_bounds__(256, 2) void k_conv2_wpre2(const uint8_t* __restric
         const bool have_next = next_pass < n_pass;
         int qmin_n = qmin, nrows_n = nrows;
         uint32_t ticket = 0;
-        if (draw && tid == 0) ticket = atomicAdd(pass_ctr, 1u);           // the ticket after the next one; its value is needed at the end of the epilogue only
+        // the ticket after the next one; its value is needed at the end of the epilogue only.  Raw instruction: atomicAdd() goes through the
+        // compiler's wave-reduction form, which waits for the returned value (and with it for every weight fragment in flight) on the spot
+        if (draw && tid == 0) asm volatile("global_atomic_add %0, %1, %2, off sc0" : "=v"(ticket) : "v"(pass_ctr), "v"(1u) : "memory");
         if (have_next) {
             W2B_ROWS(next_pass, qmin_n, nrows_n);
-            if (!(DBG & 1)) W2B_DMA(qmin_n, nrows_n);
+            // the next pass of the same ticket: rows below res_hi are already there (its qmin is not below this pass's)
+            const int lo_new = (next_pass == pass + 1 && res_hi > qmin_n && !(DBG & 256)) ? res_hi : qmin_n;
+            if (!(DBG & 1)) W2B_DMA(lo_new, qmin_n + nrows_n);
+            res_hi = qmin_n + nrows_n;
         }
         if (DBG & 2) {
 #pragma unroll
@@ -652,12 +676,22 @@ __global__ __launch_bounds__(256, 2) void k_conv2_wpre2(const uint8_t* __restric
             const int rp = tid / 80, rem = tid - rp * 80, tx = rem >> 4, quad = rem & 15;
             const int gp = pass * G::RPP + rp;                            // = q3: pooled row of the batch
             if (gp < total_pairs) {
-                float4 d[8];
+                // the reads are invisible to the compiler's wait-count pass on purpose: it cannot tell pbuf from the operand planes the
+                // LDS-DMA above is still filling and would drain that DMA (s_waitcnt vmcnt(0)) in front of every one of them
+                typedef float f32x4n __attribute__((ext_vector_type(4)));
+                f32x4n d[8];
+                const uint32_t pa = (uint32_t)(uintptr_t)(pbuf + rp * 20 * 64 + quad * 4);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    int x = 4 * tx - 2 + k;
+                    x = x < 0 ? 0 : (x > 19 ? 19 : x);
+                    asm volatile("ds_read_b128 %0, %1" : "=v"(d[k]) : "v"(pa + (uint32_t)x * 256u));
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(d[0]), "+v"(d[1]), "+v"(d[2]), "+v"(d[3]), "+v"(d[4]), "+v"(d[5]), "+v"(d[6]), "+v"(d[7]));
 #pragma unroll
                 for (int k = 0; k < 8; ++k) {
                     const int x = 4 * tx - 2 + k;
-                    d[k] = make_float4(0.f, 0.f, 0.f, 0.f);
-                    if (x >= 0 && x < 20) d[k] = *reinterpret_cast<const float4*>(pbuf + (rp * 20 + x) * 64 + quad * 4);
+                    if (x < 0 || x >= 20) d[k] = f32x4n{0.f, 0.f, 0.f, 0.f};
                 }
                 float ua[8], ub[8], uc[8], ud[8];
                 wino_bt(d[0].x, d[1].x, d[2].x, d[3].x, d[4].x, d[5].x, d[6].x, d[7].x, ua);
@@ -675,12 +709,10 @@ __global__ __launch_bounds__(256, 2) void k_conv2_wpre2(const uint8_t* __restric
                 }
             }
         }
-        if (draw && tid == 0) s_next_pass = ((int)ticket + (int)gridDim.x) * PK;   // read behind a later pass's first barrier
         if (!have_next) break;
-        if (!(DBG & 128)) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // this wave's DMA has landed (and its V3 stores have reached L2) ...
-            __syncthreads();                                              // ... and behind the barrier everybody's: the next pass's planes are complete
-        }
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(ticket) :: "memory");    // this wave's DMA has landed (its V3 stores have reached L2, its ticket is back) ...
+        if (draw && tid == 0) s_next_pass = ((int)ticket + (int)gridDim.x) * PK;   // read behind a later pass's first barrier
+        __syncthreads();                                                  // ... and behind the barrier everybody's: the next pass's planes are complete
         pass = next_pass; qmin = qmin_n; nrows = nrows_n;
     }
 #undef W2B_ROWS
