@@ -1943,7 +1943,7 @@ static int net_forward_launch(trexhip_ctx* ctx, const uint8_t* d_crops, int n, f
 #define W2BAS(D_, S_) TH_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv2_wpre2<D_, S_>), hipFuncAttributeMaxDynamicSharedMemorySize, W2bGeom::LDS_BYTES))
         W2A(0); W3A(0); W2BA(0);
 #ifdef TREXHIP_DEV_KNOBS
-        W2BA(1); W2BA(2); W2BA(3); W2BA(7); W2BA(15); W2BA(32); W2BAS(0, 0); W2BAS(0, 3); W2BAS(0, 8); W2BAS(64, 5); W2BAS(128, 5); W2BAS(192, 0); W2BAS(128, 0); W2BAS(64, 0); W2BAS(256, 5); W2BAS(512, 5); TH_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv2_wpre2<0, 5, 2, 6>), hipFuncAttributeMaxDynamicSharedMemorySize, W2bGeom::LDS_BYTES)); TH_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv2_wpre2<0, 5, 2, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, W2bGeom::LDS_BYTES)); TH_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv2_wpre2<0, 5, 3, 7>), hipFuncAttributeMaxDynamicSharedMemorySize, W2bGeom::LDS_BYTES));
+        W2BA(1); W2BA(2); W2BA(3); W2BA(7); W2BA(15);
         W2A(1); W2A(2); W2A(3); W2A(7); W2A(15); W2A(32); W2A(16); W2AB(0, 3); W2AB(0, 5); W3A(1); W3A(2); W3A(3); W3A(7); W3A(15); W3A(16); W3AB(0, 3); W3AB(0, 5); W3A(64); W3A(128); TH_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv5_wpre<0, 7, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (WinoGeom<64, 128, 20, 2>::LDS_BYTES)));
 #endif
 #undef W2A
@@ -2011,11 +2011,11 @@ static int net_forward_launch(trexhip_ctx* ctx, const uint8_t* d_crops, int n, f
         // two workgroups per CU, one M-tile per wave, operand planes fetched by LDS-DMA during the epilogue (bit 22: the one-workgroup form below)
         const int n_pass = (n * 20 + W2bGeom::RPP - 1) / W2bGeom::RPP;
 #define W2K(D_) W2KS(D_, 5)
-        const int wgs = ((ctx->tune_conv_geom >> 23) & 1) ? ctx->n_cus : 2 * ctx->n_cus;     // dev: bit 23 = one workgroup per CU
+        const int wgs = 2 * ctx->n_cus;
 #define W2KS(D_, S_) hipLaunchKernelGGL((k_conv2_wpre2<D_, S_>), dim3(n_pass < wgs ? n_pass : wgs), dim3(256), W2bGeom::LDS_BYTES, s, \
                            net->v2, net->w2w, net->b2, net->v3, net->inv2w, net->d_ovf, n, net->d_ovf + 2)
 #ifdef TREXHIP_DEV_KNOBS   // ablations: TREXHIP_CONV_GEOM bits 16..21 = 1 no staging, 2 no epilogue, 4 no weight loads, 8 no A reads, 32 no V3 transform
-        switch ((ctx->tune_conv_geom >> 16) & 63) { case 1: W2K(1); break; case 2: W2K(2); break; case 3: W2K(3); break; case 7: W2K(7); break; case 15: W2K(15); break; case 32: W2K(32); break; case 40: W2KS(0, 0); break; case 41: W2KS(0, 3); break; case 42: W2KS(0, 8); break; case 43: W2KS(64, 5); break; case 44: W2KS(128, 5); break; case 45: W2KS(192, 0); break; case 46: W2KS(128, 0); break; case 47: W2KS(64, 0); break; case 53: W2KS(256, 5); break; case 54: W2KS(512, 5); break; case 50: hipLaunchKernelGGL((k_conv2_wpre2<0, 5, 2, 6>), dim3(n_pass < wgs ? n_pass : wgs), dim3(256), W2bGeom::LDS_BYTES, s, net->v2, net->w2w, net->b2, net->v3, net->inv2w, net->d_ovf, n, net->d_ovf + 2); break; case 51: hipLaunchKernelGGL((k_conv2_wpre2<0, 5, 2, 4>), dim3(n_pass < wgs ? n_pass : wgs), dim3(256), W2bGeom::LDS_BYTES, s, net->v2, net->w2w, net->b2, net->v3, net->inv2w, net->d_ovf, n, net->d_ovf + 2); break; case 52: hipLaunchKernelGGL((k_conv2_wpre2<0, 5, 3, 7>), dim3(n_pass < wgs ? n_pass : wgs), dim3(256), W2bGeom::LDS_BYTES, s, net->v2, net->w2w, net->b2, net->v3, net->inv2w, net->d_ovf, n, net->d_ovf + 2); break; default: W2K(0); }
+        switch ((ctx->tune_conv_geom >> 16) & 63) { case 1: W2K(1); break; case 2: W2K(2); break; case 3: W2K(3); break; case 7: W2K(7); break; case 15: W2K(15); break; default: W2K(0); }
 #else
         W2K(0);
 #endif

@@ -105,8 +105,16 @@ __global__ __launch_bounds__(256) void k_t_colstats(const float* __restrict__ d,
 __device__ __forceinline__ double sum_partials(const double* __restrict__ partial, int nblocks, int C, int pass, double* sh /*[8][128]*/) {
     const int c = threadIdx.x & 127, ln = threadIdx.x >> 7;
     double t = 0;
-    if (c < C)
-        for (int b = ln; b < nblocks; b += 8) t += partial[((size_t)b * 2 + pass) * C + c];
+    if (c < C) {
+        // eight loads in flight, added in block order (one load per add would string 32 L2 round trips together)
+        for (int b0 = ln; b0 < nblocks; b0 += 64) {
+            double v[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] = b0 + 8 * k < nblocks ? partial[((size_t)(b0 + 8 * k) * 2 + pass) * C + c] : 0.0;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) if (b0 + 8 * k < nblocks) t += v[k];
+        }
+    }
     __syncthreads();
     sh[ln * 128 + c] = t;
     __syncthreads();
@@ -536,24 +544,49 @@ __global__ __launch_bounds__(256) void k_t_fc1_dgrad(const float* __restrict__ d
 
 // ------------------------------------------------------------------------------------------------
 // convolution weight gradient on fp32 MFMA: dW[tap][ci][co] = sum over (crop, y, x) a[crop][y+ky-2][x+kx-2][ci] * dz[crop][y][x][co].
-// One 32x32x2 MFMA step contracts over two neighbouring pixels: A = activations (rows = ci, of TP taps when CI < 32), B = dz; both
-// operands come straight from L2 (a lane reads 4 bytes of a 128-byte channel run).  Block = one tap (pair) x one share of the
-// crops (as many shares as fill the 256 CUs once); its 12 waves take every 12th pixel pair, their sums are added in LDS: part[share][tap][ci][co].
+// One 32x32x2 MFMA step contracts over two neighbouring pixels: A = activations at the taps' shifts, B = dz.
+//   * block = one kernel row ky x one slice of CIS input channels x one slice of COS output channels x one share of the work units
+//     (unit = ROWS output rows of one crop).  It stages the unit's dz slice [ROWS * S pixels][COS] and the ROWS activation rows the kernel
+//     row needs ([ROWS][S][CIS], rows outside the crop skipped) in LDS with 16-byte loads -- round 2 fetched every MFMA operand as a
+//     4-byte load straight from L2 and ran at half its MFMA count -- and all 8 waves read their operands from there;
+//   * M space of a kernel row = [5 kx][CIS] rows in MT tiles of 32 (conv3: CIS = 32, tile = kx; conv2: CIS = 16, 80 rows in 3 tiles);
+//     a wave holds MT x (COS / 32) accumulator tiles and takes every 8th pixel pair; one dz fragment serves the MT shifted A fragments;
+//   * the waves' sums are added in wave order through LDS: part[share][tap][ci][co], summed over the shares by k_t_wgrad_reduce --
+//     the same bits every run.
 // ------------------------------------------------------------------------------------------------
-template <int CI, int CO, int S, int TP>
-__global__ __launch_bounds__(768) void k_t_wgrad(const float* __restrict__ a /*[n][S][S][CI]*/, const float* __restrict__ dz /*[n][S][S][CO]*/,
+template <int CI, int CO, int S, int CIS, int COS, int MT, int ROWS>
+struct WgradGeom {
+    static constexpr int NT = COS / 32, NB = S / ROWS, WAVES = 8;
+    static constexpr int NCS = CI / CIS, NOS = CO / COS, TYPES = 5 * NCS * NOS;
+    static constexpr int DZ_FLOATS = ROWS * S * COS, A_FLOATS = ROWS * S * CIS, UNIT_FLOATS = DZ_FLOATS + A_FLOATS;
+    static constexpr int SUM_FLOATS = MT * NT * 16 * 64;
+    static constexpr int LDS_BYTES = (2 * UNIT_FLOATS > SUM_FLOATS ? 2 * UNIT_FLOATS : SUM_FLOATS) * 4;
+    static_assert(S % ROWS == 0 && S % 2 == 0 && CI % CIS == 0 && CO % COS == 0 && COS % 32 == 0 && MT * 32 >= 5 * CIS, "shapes");
+    static_assert(LDS_BYTES <= 160 * 1024 && (DZ_FLOATS * 4) % 1024 == 0 && 1024 % (COS * 4) == 0 && 1024 % (CIS * 4) == 0, "LDS");
+};
+
+// one LDS-DMA instruction: 64 lanes x 16 bytes from the lanes' global addresses to LDS [lds_addr, lds_addr + 1024).  Raw, so that the compiler's
+// wait-count pass does not know of it: it cannot tell the two LDS buffers apart and would drain the DMA in front of every LDS read.
+__device__ __forceinline__ void dma16_raw(const void* gptr, const uint32_t lds_addr) {
+    uint32_t keep;                                                         // M0 is the compiler's: handed back as found
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "s"(lds_addr), "v"(gptr) : "memory");
+}
+
+template <int CI, int CO, int S, int CIS, int COS, int MT, int ROWS>
+__global__ __launch_bounds__(512) void k_t_wgrad(const float* __restrict__ a /*[n][S][S][CI]*/, const float* __restrict__ dz /*[n][S][S][CO]*/,
                                                  float* __restrict__ part, int n) {
-    constexpr int MI = CI * TP, MT = MI / 32, NT = CO / 32, PP = S * S / 2, WAVES = 12;    // 128 accumulator + ~25 other registers: 3 waves per SIMD
-    static_assert(MI % 32 == 0 && CO % 32 == 0, "tile shapes");
-    __shared__ float sum[MT * NT * 16 * 64];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 31, h = lane >> 5;
-    const int share = blockIdx.y, shares = gridDim.y;
-    int ky[MT], kx[MT], ci[MT];
-    bool tv[MT];
+    using G = WgradGeom<CI, CO, S, CIS, COS, MT, ROWS>;
+    constexpr int NT = G::NT, NB = G::NB, WAVES = G::WAVES;
+    extern __shared__ __attribute__((aligned(16))) float wg_lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), j = lane & 31, h = lane >> 5;
+    const int type = blockIdx.x, ky = type / (G::NCS * G::NOS), cs = (type / G::NOS) % G::NCS, os = type % G::NOS;
+    const int share = blockIdx.y, shares = gridDim.y, units = n * NB;
+    int kx[MT], cc[MT];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
-        const int mi = mt * 32 + j, tap = blockIdx.x * TP + mi / CI;
-        ci[mt] = mi % CI; tv[mt] = tap < 25; ky[mt] = tap / 5 - 2; kx[mt] = tap % 5 - 2;
+        const int mi = mt * 32 + j;
+        kx[mt] = mi / CIS; cc[mt] = mi % CIS;                              // rows past the 5th tap stay zero
     }
     f32x16 acc[MT][NT];
 #pragma unroll
@@ -562,27 +595,78 @@ __global__ __launch_bounds__(768) void k_t_wgrad(const float* __restrict__ a /*[
         for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
-    for (int crop = share; crop < n; crop += shares) {
-        const float* ac = a + (size_t)crop * S * S * CI;
-        const float* dc = dz + (size_t)crop * S * S * CO;
-#pragma unroll 4
-        for (int q = wave; q < PP; q += WAVES) {
-            const int p = 2 * q + h, y = p / S, x = p - y * S;
-            float av[MT], bv[NT];
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt) {
-                const int ys = y + ky[mt], xs = x + kx[mt];
-                av[mt] = (tv[mt] && ys >= 0 && ys < S && xs >= 0 && xs < S) ? ac[((size_t)ys * S + xs) * CI + ci[mt]] : 0.f;
-            }
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) bv[nt] = dc[(size_t)p * CO + nt * 32 + j];
+    // a unit travels L2 -> the other LDS buffer by LDS-DMA while the MFMAs of the previous unit run: 1-KB pieces (4 dz pixels, or
+    // 1024 / (4 CIS) activation pixels), dealt out to the 8 waves.  Activation rows outside the crop are fetched from a clamped row
+    // and never read.
+    const uint32_t lds0 = (uint32_t)(uintptr_t)wg_lds;
+#define WG_FETCH(u_, buf_)                                                                                                       \
+    do {                                                                                                                         \
+        const int crop_ = (u_) / NB, y0_ = ((u_) % NB) * ROWS;                                                                   \
+        const uint8_t* src_ = reinterpret_cast<const uint8_t*>(dz + ((size_t)crop_ * S * S + (size_t)y0_ * S) * CO + os * COS);  \
+        const uint32_t dst_ = lds0 + (buf_) * G::UNIT_FLOATS * 4;                                                                \
+        _Pragma("unroll 1") for (int k_ = wave; k_ < G::DZ_FLOATS * 4 / 1024; k_ += WAVES)                                        \
+            dma16_raw(src_ + (size_t)(k_ * (1024 / (COS * 4)) + lane / (COS / 4)) * (CO * 4) + (lane % (COS / 4)) * 16, dst_ + k_ * 1024); \
+        const uint8_t* asrc_ = reinterpret_cast<const uint8_t*>(a + (size_t)crop_ * S * S * CI + cs * CIS);                       \
+        constexpr int PPI_ = 1024 / (CIS * 4);                           /* pixels per piece */                                  \
+        _Pragma("unroll 1") for (int k_ = wave; k_ < (G::A_FLOATS * 4 + 1023) / 1024; k_ += WAVES) {                              \
+            const int px_ = k_ * PPI_ + lane / (CIS / 4);                                                                        \
+            if (px_ < ROWS * S) {                                                                                                \
+                int ys_ = y0_ + px_ / S + ky - 2;                                                                                \
+                ys_ = ys_ < 0 ? 0 : (ys_ >= S ? S - 1 : ys_);                                                                    \
+                dma16_raw(asrc_ + ((size_t)ys_ * S + px_ % S) * (CI * 4) + (lane % (CIS / 4)) * 16, dst_ + G::DZ_FLOATS * 4 + k_ * 1024); \
+            }                                                                                                                    \
+        }                                                                                                                        \
+    } while (0)
+    int u = share;
+    if (u < units) WG_FETCH(u, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    int cur = 0;
+    for (; u < units; u += shares) {
+        const int un = u + shares;
+        if (un < units) WG_FETCH(un, cur ^ 1);                             // that buffer's readers finished before the previous barrier
+        const float* dzl = wg_lds + cur * G::UNIT_FLOATS;
+        const float* al = dzl + G::DZ_FLOATS;
+        // rows of the unit whose activation row y + ky - 2 lies inside the crop (the others add nothing)
+        const int y0 = (u % NB) * ROWS;
+        int r_lo = 2 - ky - y0, r_hi = S + 2 - ky - y0;
+        r_lo = r_lo < 0 ? 0 : r_lo; r_hi = r_hi > ROWS ? ROWS : r_hi;
+        const int nq = (r_hi - r_lo) * (S / 2);
+        // operands of pixel pair q: the dz fragments and the MT shifted activation fragments (both pixels of a pair lie in one row: S is even)
+#define WG_OPS(q_, av_, bv_)                                                                                                     \
+        do {                                                                                                                     \
+            const int r_ = r_lo + (q_) / (S / 2), x_ = 2 * ((q_) % (S / 2)) + h;                                                 \
+            _Pragma("unroll") for (int nt = 0; nt < NT; ++nt) bv_[nt] = dzl[(r_ * S + x_) * COS + nt * 32 + j];                   \
+            _Pragma("unroll") for (int mt = 0; mt < MT; ++mt) {                                                                  \
+                const int xs_ = x_ + kx[mt] - 2;                                                                                 \
+                const float v_ = al[(r_ * S + (xs_ < 0 ? 0 : (xs_ >= S ? S - 1 : xs_))) * CIS + cc[mt]];                          \
+                av_[mt] = (kx[mt] < 5 && xs_ >= 0 && xs_ < S) ? v_ : 0.f;                                                        \
+            }                                                                                                                    \
+        } while (0)
+        float av[MT], bv[NT];
+        if (wave < nq) WG_OPS(wave, av, bv);
+        for (int q = wave; q < nq; q += WAVES) {
+            float avn[MT], bvn[NT];
+            const int qn = q + WAVES < nq ? q + WAVES : q;                 // the next pair's operands are read under this pair's MFMAs
+            WG_OPS(qn, avn, bvn);
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[mt], bv[nt], acc[mt][nt], 0, 0, 0);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) av[mt] = avn[mt];
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) bv[nt] = bvn[nt];
         }
+#undef WG_OPS
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                   // this wave's pieces of the next unit have landed ...
+        __syncthreads();                                                   // ... everyone's, and everyone is done with this unit
+        cur ^= 1;
     }
+#undef WG_FETCH
     // the waves' sums are added in wave order through LDS: one partial per block, the same bits every run
+    __syncthreads();
+    float* sum = wg_lds;
     for (int w = 0; w < WAVES; ++w) {
         if (wave == w) {
 #pragma unroll
@@ -598,11 +682,11 @@ __global__ __launch_bounds__(768) void k_t_wgrad(const float* __restrict__ a /*[
         __syncthreads();
     }
     float* pp = part + (size_t)share * 25 * CI * CO;
-    for (int e = tid; e < MT * NT * 16 * 64; e += WAVES * 64) {
+    for (int e = tid; e < G::SUM_FLOATS; e += WAVES * 64) {
         const int ln = e & 63, r = (e >> 6) & 15, t = e >> 10, nt = t % NT, mt = t / NT;
         const int mi = mt * 32 + 8 * (r / 4) + 4 * (ln >> 5) + (r % 4);     // accumulator r of lane (j, h) is row 8 (r / 4) + 4 h + r % 4
-        const int tap = blockIdx.x * TP + mi / CI, c = mi % CI;
-        if (tap < 25) pp[((size_t)tap * CI + c) * CO + nt * 32 + (ln & 31)] = sum[e];
+        const int k = mi / CIS, c = cs * CIS + mi % CIS;
+        if (k < 5) pp[((size_t)(ky * 5 + k) * CI + c) * CO + os * COS + nt * 32 + (ln & 31)] = sum[e];
     }
 }
 
@@ -614,7 +698,13 @@ __global__ __launch_bounds__(256) void k_t_wgrad_reduce(const float* __restrict_
     const int co = idx % CO, cic = (idx / CO) % CIC, tap = (idx / (CO * CIC)) % 25, cc = idx / (CO * CIC * 25);
     const size_t src = ((size_t)tap * CI + cc * CIC + cic) * CO + co;
     float acc = 0.f;
-    for (int p = 0; p < nparts; ++p) acc += part[(size_t)p * total + src];
+    for (int p0 = 0; p0 < nparts; p0 += 8) {                            // eight loads in flight, added in part order
+        float v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = p0 + k < nparts ? part[(size_t)(p0 + k) * total + src] : 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) if (p0 + k < nparts) acc += v[k];
+    }
     g[idx] = acc;
 }
 
@@ -654,8 +744,15 @@ __global__ __launch_bounds__(256) void k_t_reduce(const float* __restrict__ part
     __shared__ float sh[256];
     const int tid = threadIdx.x, e = tid & 15, ln = tid >> 4, idx = blockIdx.x * 16 + e;
     float acc = 0.f;
-    if (idx < count)
-        for (int p = ln; p < nparts; p += 16) acc += part[(size_t)p * count + idx];
+    if (idx < count) {
+        for (int p0 = ln; p0 < nparts; p0 += 128) {                     // eight loads in flight, added in part order
+            float v[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] = p0 + 16 * k < nparts ? part[(size_t)(p0 + 16 * k) * count + idx] : 0.f;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) if (p0 + 16 * k < nparts) acc += v[k];
+        }
+    }
     sh[ln * 16 + e] = acc;
     __syncthreads();
     if (tid < 16 && idx < count) {
@@ -768,7 +865,9 @@ struct Trainer {
 };
 
 static constexpr int RED_BLOCKS = 256;
-static constexpr int SHARES3 = 10, SHARES2 = 19;     // 25 taps x 10 = 250 and 13 tap pairs x 19 = 247 workgroups: one round on 256 CUs
+using WG3 = WgradGeom<64, 128, 20, 32, 64, 5, 10>;   // conv3: block type = kernel row x 32-channel half x 64-channel half (20 types), unit = 10 rows of a crop
+using WG2 = WgradGeom<16, 64, 40, 16, 64, 3, 5>;     // conv2: block type = kernel row (5 types), unit = 5 rows of a crop
+static constexpr int SHARES3 = 12, SHARES2 = 51;     // 20 x 12 = 240 and 5 x 51 = 255 workgroups: one round on 256 CUs
 
 static size_t tensor_count(int t, int classes, int CH) {
     switch (t) {
@@ -912,6 +1011,8 @@ static int trainer_attrs(Trainer* t) {
     TH_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv5<64, 128, 20, 10, 32, CONV_EPI_RAW, 128>), hipFuncAttributeMaxDynamicSharedMemorySize, G3F::LDS_BYTES));
     TH_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv5<128, 64, 20, 10, 32, CONV_EPI_RAW, 64>), hipFuncAttributeMaxDynamicSharedMemorySize, G3B::LDS_BYTES));
     TH_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv5<64, 32, 40, 10, 16, CONV_EPI_RAW, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, G2B::LDS_BYTES));
+    TH_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_t_wgrad<64, 128, 20, 32, 64, 5, 10>), hipFuncAttributeMaxDynamicSharedMemorySize, WG3::LDS_BYTES));
+    TH_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_t_wgrad<16, 64, 40, 16, 64, 3, 5>), hipFuncAttributeMaxDynamicSharedMemorySize, WG2::LDS_BYTES));
     t->attr = true;
     return TREXHIP_OK;
 }
@@ -964,8 +1065,8 @@ static int trainer_step(Trainer* t, const float* x, const int32_t* targets, int 
     // block 3
     bn_backward<128>(t, s, 2, t->da3, t->z3, n, 20, T_G3, T_BE3, T_C3B, k3, scale);
     {
-        const int shares = n < SHARES3 ? n : SHARES3;
-        hipLaunchKernelGGL((k_t_wgrad<64, 128, 20, 1>), dim3(25, shares), dim3(768), 0, s, t->a2, t->z3, t->part, n);
+        const int shares = n * WG3::NB < SHARES3 ? n * WG3::NB : SHARES3;
+        hipLaunchKernelGGL((k_t_wgrad<64, 128, 20, 32, 64, 5, 10>), dim3(WG3::TYPES, shares), dim3(512), WG3::LDS_BYTES, s, t->a2, t->z3, t->part, n);
         hipLaunchKernelGGL(k_t_wgrad_reduce, dim3((25 * 64 * 128 + 255) / 256), dim3(256), 0, s, t->part, shares, 64, 128, 32, G + o[T_C3W]);
         hipLaunchKernelGGL(k_t_repack_bwd, dim3((25 * 128 * 64 + 255) / 256), dim3(256), 0, s, P + o[T_C3W], 64, 128, 32, 64, 32, t->wb3);
         hipLaunchKernelGGL((k_conv5<128, 64, 20, 10, 32, CONV_EPI_RAW, 64>), dim3(n * G3B::BPC), dim3(512), G3B::LDS_BYTES, s, t->z3, t->wb3, (const float*)nullptr, t->da2);
@@ -973,8 +1074,8 @@ static int trainer_step(Trainer* t, const float* x, const int32_t* targets, int 
     // block 2
     bn_backward<64>(t, s, 1, t->da2, t->z2, n, 40, T_G2, T_BE2, T_C2B, k2, scale);
     {
-        const int shares = n < SHARES2 ? n : SHARES2;
-        hipLaunchKernelGGL((k_t_wgrad<16, 64, 40, 2>), dim3(13, shares), dim3(768), 0, s, t->a1, t->z2, t->part, n);
+        const int shares = n * WG2::NB < SHARES2 ? n * WG2::NB : SHARES2;
+        hipLaunchKernelGGL((k_t_wgrad<16, 64, 40, 16, 64, 3, 5>), dim3(WG2::TYPES, shares), dim3(512), WG2::LDS_BYTES, s, t->a1, t->z2, t->part, n);
         hipLaunchKernelGGL(k_t_wgrad_reduce, dim3((25 * 16 * 64 + 255) / 256), dim3(256), 0, s, t->part, shares, 16, 64, 16, G + o[T_C2W]);
         hipLaunchKernelGGL(k_t_repack_bwd, dim3((25 * 64 * 32 + 255) / 256), dim3(256), 0, s, P + o[T_C2W], 16, 64, 16, 32, 16, t->wb2);
         hipLaunchKernelGGL((k_conv5<64, 32, 40, 10, 16, CONV_EPI_RAW, 16>), dim3(n * G2B::BPC), dim3(512), G2B::LDS_BYTES, s, t->z2, t->wb2, (const float*)nullptr, t->da1);
