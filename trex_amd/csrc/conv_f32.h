@@ -155,4 +155,88 @@ __global__ __launch_bounds__(512) void k_conv5(const float* __restrict__ in /*[N
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// the same convolution for 16 output channels (conv2's data gradient) on v_mfma_f32_16x16x4_f32: 16 pixels x 16 channels per tile, so
+// that no half of a 32-wide tile multiplies padding.  Raw output only.  Lane l of a step: A = pixel l % 16, input channel 4 t + l / 16;
+// B = the same input channel, output channel l % 16; accumulator r = pixel 4 (l / 16) + r, channel l % 16.
+// ------------------------------------------------------------------------------------------------
+typedef float f32x4a __attribute__((ext_vector_type(4)));
+
+template <int CI, int S, int ROWS, int CIC>
+struct ConvGeom16 {
+    static constexpr int PW = S + 4, PH = ROWS + 4;
+    static constexpr int STR = CIC + 1;                               // odd pixel stride
+    static constexpr int RP = PW * STR;
+    static constexpr int PATCH = PH * RP;
+    static constexpr int BT = CIC * 16;
+    static constexpr int NPIX = ROWS * S;
+    static constexpr int MT = NPIX / 16, TPW = (MT + 7) / 8;
+    static constexpr int LDS_BYTES = (PATCH + 2 * BT) * 4;
+    static constexpr int BPC = S / ROWS;
+    static_assert(NPIX % 16 == 0 && S % ROWS == 0 && CIC % 4 == 0 && BT / 4 <= 512, "shapes");
+};
+
+template <int CI, int S, int ROWS, int CIC>
+__global__ __launch_bounds__(512) void k_conv5_n16(const float* __restrict__ in /*[N][S][S][CI]*/, const float* __restrict__ wp /*[CI/CIC][25][CIC][16]*/,
+                                                   float* __restrict__ out /*[N][S][S][16]*/) {
+    using G = ConvGeom16<CI, S, ROWS, CIC>;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* patch = lds;
+    float* Bs = lds + G::PATCH;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i16 = lane & 15, kq = lane >> 4;
+    const int crop = blockIdx.x / G::BPC, row0 = (blockIdx.x % G::BPC) * ROWS;
+    int aoff[G::TPW];
+#pragma unroll
+    for (int m = 0; m < G::TPW; ++m) {
+        int p = (wave + 8 * m) * 16 + i16;
+        p = p < G::NPIX ? p : G::NPIX - 1;
+        aoff[m] = (p / S) * G::RP + (p % S) * G::STR + kq;
+    }
+    f32x4a acc[G::TPW];
+#pragma unroll
+    for (int m = 0; m < G::TPW; ++m) acc[m] = f32x4a{0.f, 0.f, 0.f, 0.f};
+    const float* inc = in + (size_t)crop * S * S * CI;
+    constexpr int Q = CIC / 4, BV = G::BT / 4;
+    for (int cc = 0; cc < CI / CIC; ++cc) {
+        __syncthreads();                                                // previous chunk's readers are done
+        for (int idx = tid; idx < G::PH * G::PW * Q; idx += 512) {
+            const int q = idx % Q, px = idx / Q;
+            const int py = px / G::PW, pxx = px - py * G::PW;
+            const int iy = row0 + py - 2, ix = pxx - 2;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);                 // zero padding ('same')
+            if (iy >= 0 && iy < S && ix >= 0 && ix < S)
+                v = *reinterpret_cast<const float4*>(inc + ((size_t)iy * S + ix) * CI + cc * CIC + q * 4);
+            float* d = patch + py * G::RP + pxx * G::STR + q * 4;
+            d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+        }
+        const float4* wsrc = reinterpret_cast<const float4*>(wp + (size_t)cc * 25 * G::BT);
+        if (tid < BV) reinterpret_cast<float4*>(Bs)[tid] = wsrc[tid];
+        __syncthreads();
+        for (int tap = 0; tap < 25; ++tap) {
+            const int buf = tap & 1;
+            float4 nb = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (tap < 24 && tid < BV) nb = wsrc[(size_t)(tap + 1) * BV + tid];
+            const float* bsrc = Bs + buf * G::BT + kq * 16 + i16;
+            const float* asrc = patch + (tap / 5) * G::RP + (tap % 5) * G::STR;
+#pragma unroll
+            for (int t = 0; t < CIC / 4; ++t) {
+                const float b = bsrc[4 * t * 16];
+#pragma unroll
+                for (int m = 0; m < G::TPW; ++m) acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(asrc[aoff[m] + 4 * t], b, acc[m], 0, 0, 0);
+            }
+            if (tap < 24 && tid < BV) reinterpret_cast<float4*>(Bs + (buf ^ 1) * G::BT)[tid] = nb;
+            __syncthreads();
+        }
+    }
+    float* oc = out + ((size_t)crop * S * S + (size_t)row0 * S) * 16;
+#pragma unroll
+    for (int m = 0; m < G::TPW; ++m) {
+        const int mt = wave + 8 * m;
+        if (mt >= G::MT) continue;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) oc[(size_t)(mt * 16 + 4 * kq + r) * 16 + i16] = acc[m][r];
+    }
+}
+
 }  // namespace trexhip

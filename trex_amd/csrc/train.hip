@@ -914,7 +914,7 @@ static void trainer_free(Trainer* t) {
 using G2F = ConvGeom<16, 64, 40, 20, 16>;
 using G3F = ConvGeom<64, 128, 20, 10, 32>;     // 10-row bands: 2 blocks per crop (a training batch is 64..128 crops, the chip has 256 CUs; 4-row bands measured no faster)
 using G3B = ConvGeom<128, 64, 20, 10, 32>;
-using G2B = ConvGeom<64, 32, 40, 10, 16>;
+using G2B = ConvGeom16<64, 40, 20, 16>;          // conv2's data gradient: 16 output channels on 16x16x4 tiles, two blocks per crop
 
 template <int C>
 static void launch_colstats(hipStream_t s, const float* d, size_t rows, double* red) {
@@ -1010,7 +1010,7 @@ static int trainer_attrs(Trainer* t) {
     TH_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv5<16, 64, 40, 20, 16, CONV_EPI_RAW, 64>), hipFuncAttributeMaxDynamicSharedMemorySize, G2F::LDS_BYTES));
     TH_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv5<64, 128, 20, 10, 32, CONV_EPI_RAW, 128>), hipFuncAttributeMaxDynamicSharedMemorySize, G3F::LDS_BYTES));
     TH_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv5<128, 64, 20, 10, 32, CONV_EPI_RAW, 64>), hipFuncAttributeMaxDynamicSharedMemorySize, G3B::LDS_BYTES));
-    TH_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv5<64, 32, 40, 10, 16, CONV_EPI_RAW, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, G2B::LDS_BYTES));
+    TH_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv5_n16<64, 40, 20, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, G2B::LDS_BYTES));
     TH_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_t_wgrad<64, 128, 20, 32, 64, 5, 10>), hipFuncAttributeMaxDynamicSharedMemorySize, WG3::LDS_BYTES));
     TH_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_t_wgrad<16, 64, 40, 16, 64, 3, 5>), hipFuncAttributeMaxDynamicSharedMemorySize, WG2::LDS_BYTES));
     t->attr = true;
@@ -1077,8 +1077,8 @@ static int trainer_step(Trainer* t, const float* x, const int32_t* targets, int 
         const int shares = n * WG2::NB < SHARES2 ? n * WG2::NB : SHARES2;
         hipLaunchKernelGGL((k_t_wgrad<16, 64, 40, 16, 64, 3, 5>), dim3(WG2::TYPES, shares), dim3(512), WG2::LDS_BYTES, s, t->a1, t->z2, t->part, n);
         hipLaunchKernelGGL(k_t_wgrad_reduce, dim3((25 * 16 * 64 + 255) / 256), dim3(256), 0, s, t->part, shares, 16, 64, 16, G + o[T_C2W]);
-        hipLaunchKernelGGL(k_t_repack_bwd, dim3((25 * 64 * 32 + 255) / 256), dim3(256), 0, s, P + o[T_C2W], 16, 64, 16, 32, 16, t->wb2);
-        hipLaunchKernelGGL((k_conv5<64, 32, 40, 10, 16, CONV_EPI_RAW, 16>), dim3(n * G2B::BPC), dim3(512), G2B::LDS_BYTES, s, t->z2, t->wb2, (const float*)nullptr, t->da1);
+        hipLaunchKernelGGL(k_t_repack_bwd, dim3((25 * 64 * 16 + 255) / 256), dim3(256), 0, s, P + o[T_C2W], 16, 64, 16, 16, 16, t->wb2);
+        hipLaunchKernelGGL((k_conv5_n16<64, 40, 20, 16>), dim3(n * G2B::BPC), dim3(512), G2B::LDS_BYTES, s, t->z2, t->wb2, t->da1);
     }
     // block 1
     bn_backward<16>(t, s, 0, t->da1, t->z1, n, 80, T_G1, T_BE1, T_C1B, k1, scale);
