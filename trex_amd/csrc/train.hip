@@ -471,51 +471,67 @@ __global__ __launch_bounds__(256) void k_t_head_grads(const float* __restrict__ 
                                                       float* __restrict__ g_b1) {
     const int idx = blockIdx.x * 256 + threadIdx.x;
     const int nw = classes * 100;
+    // sums over the samples in order, eight samples' operands in flight (one dependent L2 round trip per sample otherwise)
+#define HG_SUM(expr_a_, expr_b_)                                                                                                 \
+    for (int s0 = 0; s0 < n; s0 += 8) {                                                                                          \
+        float va_[8], vb_[8];                                                                                                    \
+        _Pragma("unroll") for (int k = 0; k < 8; ++k) { const int s = s0 + k < n ? s0 + k : n - 1; va_[k] = (expr_a_); vb_[k] = (expr_b_); } \
+        _Pragma("unroll") for (int k = 0; k < 8; ++k) if (s0 + k < n) acc += va_[k] * vb_[k];                                     \
+    }
     if (idx < nw) {
         const int c = idx / 100, j = idx % 100;
         float acc = 0.f;
-        for (int s = 0; s < n; ++s) acc += dl[(size_t)s * classes + c] * hd[(size_t)s * 100 + j];
+        HG_SUM(dl[(size_t)s * classes + c], hd[(size_t)s * 100 + j])
         g_w2[idx] = acc;
     } else if (idx < nw + classes) {
         const int c = idx - nw;
         float acc = 0.f;
-        for (int s = 0; s < n; ++s) acc += dl[(size_t)s * classes + c];
+        HG_SUM(dl[(size_t)s * classes + c], 1.f)
         g_b2[c] = acc;
     } else if (idx < nw + classes + 300) {
-        const int k = idx - nw - classes, j = k % 100, which = k / 100;
+        const int k3 = idx - nw - classes, j = k3 % 100, which = k3 / 100;
         float acc = 0.f;
-        if (which == 0) { for (int s = 0; s < n; ++s) acc += dy[(size_t)s * 100 + j] * xhat[(size_t)s * 100 + j]; g_lng[j] = acc; }
-        else if (which == 1) { for (int s = 0; s < n; ++s) acc += dy[(size_t)s * 100 + j]; g_lnb[j] = acc; }
-        else { for (int s = 0; s < n; ++s) acc += dh[(size_t)s * 100 + j]; g_b1[j] = acc; }
+        if (which == 0) { HG_SUM(dy[(size_t)s * 100 + j], xhat[(size_t)s * 100 + j]) g_lng[j] = acc; }
+        else if (which == 1) { HG_SUM(dy[(size_t)s * 100 + j], 1.f) g_lnb[j] = acc; }
+        else { HG_SUM(dh[(size_t)s * 100 + j], 1.f) g_b1[j] = acc; }
     }
+#undef HG_SUM
 }
 
-// fc1 weight gradient: dW1c[hw][c][o] = sum_n a3[n][hw][c] * dh[n][o]
+// fc1 weight gradient: dW1c[hw][c][o] = sum_n a3[n][hw][c] * dh[n][o] -- per spatial position a 128 x 100 matrix = A^T D with the batch as
+// the contraction: fp32 MFMA, one 32x32x2 step contracts two samples; block = one position, wave = 32 channels x all outputs (4 tiles,
+// the last one 4 columns wide); samples in order, so the same bits every run
 __global__ __launch_bounds__(256) void k_t_fc1_wgrad(const float* __restrict__ a3, const float* __restrict__ dh, float* __restrict__ gw, int n) {
-    __shared__ float As[64 * 128];
-    __shared__ float Ds[64 * 100];
-    const int tid = threadIdx.x, hw = blockIdx.x;
-    const int c = tid >> 1, o0 = (tid & 1) * 50;
-    float acc[50];
+    const int tid = threadIdx.x, lane = tid & 63, mt = tid >> 6, j = lane & 31, h = lane >> 5, hw = blockIdx.x;
+    f32x16 acc[4];
 #pragma unroll
-    for (int k = 0; k < 50; ++k) acc[k] = 0.f;
-    for (int n0 = 0; n0 < n; n0 += 64) {
-        const int cnt = min(64, n - n0);
-        __syncthreads();
-        for (int idx = tid; idx < 64 * 128; idx += 256) {
-            const int i = idx >> 7, cc = idx & 127;
-            As[idx] = i < cnt ? a3[((size_t)(n0 + i) * 100 + hw) * 128 + cc] : 0.f;
-        }
-        for (int idx = tid; idx < 64 * 100; idx += 256) Ds[idx] = (idx / 100) < cnt ? dh[(size_t)n0 * 100 + idx] : 0.f;
-        __syncthreads();
-        for (int i = 0; i < cnt; ++i) {
-            const float av = As[i * 128 + c];
+    for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
-            for (int k = 0; k < 50; ++k) acc[k] += av * Ds[i * 100 + o0 + k];
-        }
+        for (int r = 0; r < 16; ++r) acc[nt][r] = 0.f;
+    const float* ap = a3 + (size_t)hw * 128 + mt * 32 + j;
+    const bool last_ok = 96 + j < 100;
+#pragma unroll 4
+    for (int s0 = 0; s0 < n; s0 += 2) {
+        const int s = s0 + h;
+        const bool ok = s < n;
+        const float av = ok ? ap[(size_t)s * 12800] : 0.f;
+        float bv[4];
+#pragma unroll
+        for (int nt = 0; nt < 3; ++nt) bv[nt] = ok ? dh[(size_t)s * 100 + nt * 32 + j] : 0.f;
+        bv[3] = (ok && last_ok) ? dh[(size_t)s * 100 + 96 + j] : 0.f;
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv[nt], acc[nt], 0, 0, 0);
     }
 #pragma unroll
-    for (int k = 0; k < 50; ++k) gw[((size_t)hw * 128 + c) * 100 + o0 + k] = acc[k];
+    for (int nt = 0; nt < 4; ++nt) {
+        const int o = nt * 32 + j;
+        if (o >= 100) continue;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int c = mt * 32 + 8 * (r / 4) + 4 * h + (r % 4);         // accumulator r of lane (j, h) is row 8 (r / 4) + 4 h + r % 4
+            gw[((size_t)hw * 128 + c) * 100 + o] = acc[nt][r];
+        }
+    }
 }
 
 // fc1 data gradient: da3[n][hw][c] = sum_o dh[n][o] * W1c[hw][c][o]
