@@ -40,6 +40,9 @@ struct HipBackgroundSubtraction {
         // gray / binary encodings: colour tiles are reduced to gray by the upload threads on their way into the pinned ring (a quarter of
         // the bytes cross PCIe); true = upload the colour tile and reduce on the device (trexhip_params::device_color_reduce)
         bool device_color_reduce = false;
+        // a batch of two or more tiles is handled in two halves on two device contexts: the first half's pv::Frame objects are built and its
+        // promises fulfilled while the second half is copied and segmented.  false = one context (half the device memory)
+        bool split_batch = true;
         // capacities per frame (0 = scaled with the frame size in init()): raw horizontal lines, kept blobs, kept foreground pixels.
         // A frame that exceeds one fails alone (its promise gets the exception); the other frames of the batch are delivered.
         int max_runs = 0, max_blobs = 0, max_pixels = 0;
@@ -56,6 +59,7 @@ struct HipBackgroundSubtraction {
         auto& d = data();
         std::unique_lock g(d.gpu_mutex);
         if (d.ctx) { trexhip_destroy(d.ctx); d.ctx = nullptr; }
+        if (d.ctx2) { trexhip_destroy(d.ctx2); d.ctx2 = nullptr; }
         d.settings = s;
         trexhip_params p;
         trexhip_default_params(&p, (int32_t)width, (int32_t)height);
@@ -78,6 +82,10 @@ struct HipBackgroundSubtraction {
         p.n_ranges = (int32_t)s.detect_size_filter.size();
         for (int i = 0; i < p.n_ranges && i < 8; ++i) { p.ranges[2 * i] = s.detect_size_filter[i].first; p.ranges[2 * i + 1] = s.detect_size_filter[i].second; }
         check(trexhip_create(&p, &d.ctx));
+        // a second context takes the second half of a batch: its tiles are copied and segmented while the first half's tables are turned
+        // into pv::Frame objects and their promises fulfilled (BackgroundSubtraction.cpp:146-342 handles the tiles one after the other and
+        // fulfils each promise as it goes)
+        if (s.max_batch >= 2 && s.split_batch) check(trexhip_create(&p, &d.ctx2));
         d.width = width; d.height = height;
         d.has_background = false;
     }
@@ -88,22 +96,25 @@ struct HipBackgroundSubtraction {
         std::unique_lock g(d.gpu_mutex);
         if (!average) { d.has_background = false; return; }
         if (!d.ctx) throw std::runtime_error("HipBackgroundSubtraction: not initialised");
-        if (average->dims == 1) check(trexhip_set_background(d.ctx, average->data(), (int32_t)average->cols));
-        else if (average->dims == 3 || average->dims == 4) {
-            // a colour average (Background(image, rgb8)): detection thresholds grey differences, so the library reduces the model like
-            // the frames (cv::cvtColor BGR2GRAY, 8-bit fixed point -- or the selected color_channel) and keeps the colour image for
-            // the per-channel difference crops
-            const int cc = d.settings.color_channel;
-            if (((size_t)average->rows * average->cols) % 4 == 0)
-                check(trexhip_set_background_color(d.ctx, average->data(), (int32_t)(average->cols * average->dims), (int32_t)average->dims, cc));
-            else {                                                  // odd pixel counts: gray model only
-                std::vector<uint8_t> gray((size_t)average->rows * average->cols);
-                const uint8_t* p = average->data();
-                for (size_t i = 0; i < gray.size(); ++i, p += average->dims)
-                    gray[i] = cc >= 0 && cc < (int)average->dims ? p[cc] : (uint8_t)((p[0] * 1868u + p[1] * 9617u + p[2] * 4899u + 8192u) >> 14);
-                check(trexhip_set_background(d.ctx, gray.data(), (int32_t)average->cols));
-            }
-        } else throw std::runtime_error("HipBackgroundSubtraction: background must have 1, 3 or 4 channels");
+        for (trexhip_ctx* c : {d.ctx, d.ctx2}) {
+            if (!c) continue;
+            if (average->dims == 1) check(trexhip_set_background(c, average->data(), (int32_t)average->cols));
+            else if (average->dims == 3 || average->dims == 4) {
+                // a colour average (Background(image, rgb8)): detection thresholds grey differences, so the library reduces the model like
+                // the frames (cv::cvtColor BGR2GRAY, 8-bit fixed point -- or the selected color_channel) and keeps the colour image for
+                // the per-channel difference crops
+                const int cc = d.settings.color_channel;
+                if (((size_t)average->rows * average->cols) % 4 == 0)
+                    check(trexhip_set_background_color(c, average->data(), (int32_t)(average->cols * average->dims), (int32_t)average->dims, cc));
+                else {                                                  // odd pixel counts: gray model only
+                    std::vector<uint8_t> gray((size_t)average->rows * average->cols);
+                    const uint8_t* p = average->data();
+                    for (size_t i = 0; i < gray.size(); ++i, p += average->dims)
+                        gray[i] = cc >= 0 && cc < (int)average->dims ? p[cc] : (uint8_t)((p[0] * 1868u + p[1] * 9617u + p[2] * 4899u + 8192u) >> 14);
+                    check(trexhip_set_background(c, gray.data(), (int32_t)average->cols));
+                }
+            } else throw std::runtime_error("HipBackgroundSubtraction: background must have 1, 3 or 4 channels");
+        }
         d.has_background = true;
         g.unlock();
         if (d.has_type) if (auto* m = detect::try_pipeline_manager(d.type)) m->set_paused(false);   // BackgroundSubtraction.cpp:86-99
@@ -127,10 +138,9 @@ struct HipBackgroundSubtraction {
         // the reference takes a shared lock here (BackgroundSubtraction.cpp:130) because its per-call state is thread-local; this backend
         // has ONE device context (staging buffers, pinned result tables), so concurrent apply() calls are serialised
         std::unique_lock guard(d.gpu_mutex);
-        // one device batch per call: all tiles' first images (1 tile == full frame for bg-sub, DetectionTypes.cpp:294-295)
-        size_t i = 0;
+        // one device batch per call: all tiles' first images (1 tile == full frame for bg-sub, DetectionTypes.cpp:294-295) -- in two halves on
+        // two contexts when the batch has at least two tiles
         std::string batch_error;
-        std::vector<const uint8_t*> ptrs;
         int channels = 0;
         bool ok = d.ctx && d.has_background;
         if (!ok) batch_error = "Background image not set";
@@ -140,6 +150,7 @@ struct HipBackgroundSubtraction {
             const auto have = d.context_encoding == cmn::meta_encoding_t::binary ? cmn::meta_encoding_t::gray : d.context_encoding;
             if (want != have) { ok = false; batch_error = "Invalid image mode: meta_encoding changed after init() (re-initialise the backend)"; }   // cf. BackgroundSubtraction.cpp:188
         }
+        size_t n_images = 0;
         if (ok) {
             for (auto& tile : tiled)
                 for (auto& image : tile.images) {
@@ -149,56 +160,86 @@ struct HipBackgroundSubtraction {
                     // the reference asserts the tile size against the average image (BackgroundSubtraction.cpp:195-199); a smaller tile
                     // would make the upload read past the image
                     if (image->cols != d.width || image->rows != d.height) { ok = false; batch_error = "tile image size does not match the size the backend was initialised with"; }
-                    ptrs.push_back(image->data());
+                    ++n_images;
                 }
+            if ((int)n_images > d.settings.max_batch) { ok = false; batch_error = "more tile images than max_batch"; }
         }
-        trexhip_batch_result res{};
-        if (ok && !ptrs.empty()) {
-            if ((int)ptrs.size() > d.settings.max_batch) { ok = false; batch_error = "more tile images than max_batch"; }
-            else if (trexhip_segment_color(d.ctx, ptrs.data(), (int32_t)(d.width * (uint32_t)channels), (int32_t)ptrs.size(),
-                                           channels, d.settings.color_channel) != 0) { ok = false; batch_error = trexhip_last_error(); }
-            else {
-                // TREXHIP_E_CAPACITY is per frame: the tables stay valid for every frame whose frame_info.flags is 0, only the flagged
-                // frames fail (the reference has no capacity limits and handles each tile on its own, BackgroundSubtraction.cpp:146-342)
-                const int rc = trexhip_fetch(d.ctx, &res);
-                if (rc != 0 && rc != TREXHIP_E_CAPACITY) { ok = false; batch_error = trexhip_last_error(); }
+        struct Part {                                                    // a run of tiles handled by one context
+            size_t t0 = 0, t1 = 0;
+            trexhip_ctx* ctx = nullptr;
+            std::vector<const uint8_t*> ptrs;
+            trexhip_batch_result res{};
+            bool ok = true;
+            std::string error;
+        };
+        Part parts[2];
+        const bool two = ok && d.ctx2 && tiled.size() >= 2;
+        {
+            size_t split = tiled.size();
+            if (two) { size_t acc = 0; for (split = 0; split < tiled.size() && 2 * acc < n_images; ++split) acc += tiled[split].images.size(); }
+            parts[0].t0 = 0; parts[0].t1 = split; parts[0].ctx = d.ctx;
+            parts[1].t0 = split; parts[1].t1 = tiled.size(); parts[1].ctx = d.ctx2;
+        }
+        auto segment = [&](Part& p) {
+            p.ok = ok; p.error = batch_error;
+            if (!p.ok) return;
+            for (size_t t = p.t0; t < p.t1; ++t) for (auto& image : tiled[t].images) p.ptrs.push_back(image->data());
+            if (p.ptrs.empty()) return;
+            if (trexhip_segment_color(p.ctx, p.ptrs.data(), (int32_t)(d.width * (uint32_t)channels), (int32_t)p.ptrs.size(), channels, d.settings.color_channel) != 0) {
+                p.ok = false; p.error = trexhip_last_error(); return;
             }
-        }
-        size_t img_index = 0;
-        for (auto&& tile : tiled) {
-            try {
-                if (!ok) throw std::runtime_error(batch_error);
-                tile.data.frame.set_encoding(d.settings.meta_encoding);            // :303
-                for (size_t k = 0; k < tile.images.size(); ++k) {
-                    const trexhip_frame_info& fi = res.frames[img_index + k];
-                    if (fi.flags != 0)
-                        throw std::runtime_error("frame exceeds the backend's capacity (" + std::string((fi.flags & TREXHIP_FRAME_OVERFLOW_RUNS) ? "max_runs" : "max_blobs / max_pixels") +
-                                                 "): raise HipBackgroundSubtraction::Settings::max_runs / max_blobs / max_pixels");
-                }
-                for (size_t k = 0; k < tile.images.size(); ++k) {
-                    const trexhip_frame_info& fi = res.frames[img_index + k];
-                    for (uint32_t b = 0; b < fi.n_blobs; ++b) {
-                        const trexhip_blob& B = res.blobs[fi.blob_begin + b];
-                        if (B.n_runs >= UINT16_MAX) continue;                       // :306-313
-                        auto lines = std::make_unique<std::vector<cmn::HorizontalLine>>();
-                        lines->reserve(B.n_runs);
-                        const trexhip_run* r = res.runs + fi.run_begin + B.run_begin;
-                        for (uint32_t j = 0; j < B.n_runs; ++j) lines->emplace_back(r[j].y, r[j].x0, r[j].x1);
-                        const uint8_t* px = res.pixels + (size_t)(fi.pix_begin + B.pix_begin) * res.pixel_channels;
-                        auto pixels = std::make_unique<cmn::PixelArray_t>(px, px + (size_t)B.n_pixels * res.pixel_channels);   // pv.cpp:512
-                        tile.data.frame.add_object(cmn::blob::Pair(std::move(lines), std::move(pixels), 0));   // :305-314
+            // TREXHIP_E_CAPACITY is per frame: the tables stay valid for every frame whose frame_info.flags is 0, only the flagged
+            // frames fail (the reference has no capacity limits and handles each tile on its own, BackgroundSubtraction.cpp:146-342)
+            const int rc = trexhip_fetch(p.ctx, &p.res);
+            if (rc != 0 && rc != TREXHIP_E_CAPACITY) { p.ok = false; p.error = trexhip_last_error(); }
+        };
+        // tables -> pv::Frame objects -> promises of the part's tiles (callbacks and buffer returns follow on the calling thread, in tile order)
+        auto deliver = [&](Part& p) {
+            size_t img_index = 0;
+            for (size_t t = p.t0; t < p.t1; ++t) {
+                auto& tile = tiled[t];
+                try {
+                    if (!p.ok) throw std::runtime_error(p.error);
+                    tile.data.frame.set_encoding(d.settings.meta_encoding);            // :303
+                    for (size_t k = 0; k < tile.images.size(); ++k) {
+                        const trexhip_frame_info& fi = p.res.frames[img_index + k];
+                        if (fi.flags != 0)
+                            throw std::runtime_error("frame exceeds the backend's capacity (" + std::string((fi.flags & TREXHIP_FRAME_OVERFLOW_RUNS) ? "max_runs" : "max_blobs / max_pixels") +
+                                                     "): raise HipBackgroundSubtraction::Settings::max_runs / max_blobs / max_pixels");
                     }
+                    for (size_t k = 0; k < tile.images.size(); ++k) {
+                        const trexhip_frame_info& fi = p.res.frames[img_index + k];
+                        for (uint32_t b = 0; b < fi.n_blobs; ++b) {
+                            const trexhip_blob& B = p.res.blobs[fi.blob_begin + b];
+                            if (B.n_runs >= UINT16_MAX) continue;                       // :306-313
+                            auto lines = std::make_unique<std::vector<cmn::HorizontalLine>>();
+                            lines->reserve(B.n_runs);
+                            const trexhip_run* r = p.res.runs + fi.run_begin + B.run_begin;
+                            for (uint32_t j = 0; j < B.n_runs; ++j) lines->emplace_back(r[j].y, r[j].x0, r[j].x1);
+                            const uint8_t* px = p.res.pixels + (size_t)(fi.pix_begin + B.pix_begin) * p.res.pixel_channels;
+                            auto pixels = std::make_unique<cmn::PixelArray_t>(px, px + (size_t)B.n_pixels * p.res.pixel_channels);   // pv.cpp:512
+                            tile.data.frame.add_object(cmn::blob::Pair(std::move(lines), std::move(pixels), 0));   // :305-314
+                        }
+                    }
+                    tile.promise->set_value(std::move(tile.data));                      // :319
+                    tile.promise = nullptr;
+                } catch (...) {
+                    if (tile.promise) { tile.promise->set_exception(std::current_exception()); tile.promise = nullptr; }   // :322-325
                 }
-                tile.promise->set_value(std::move(tile.data));                      // :319
-                tile.promise = nullptr;
-            } catch (...) {
-                if (tile.promise) { tile.promise->set_exception(std::current_exception()); tile.promise = nullptr; }   // :322-325
+                img_index += tile.images.size();
             }
-            img_index += tile.images.size();
+        };
+        segment(parts[0]);
+        if (two) {
+            std::thread first([&] { deliver(parts[0]); });                // the first half's consumers are served while the second half is on its way
+            segment(parts[1]);
+            deliver(parts[1]);
+            first.join();
+        } else deliver(parts[0]);
+        for (auto&& tile : tiled) {
             try { if (tile.callback) tile.callback(); } catch (...) {}              // :328-334
             for (auto& image : tile.images) buffers::TileBuffers::get().move_back(std::move(image));   // :336-339
             tile.images.clear();
-            ++i;
         }
         if (!tiled.empty()) {
             const double el = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
@@ -215,6 +256,7 @@ struct HipBackgroundSubtraction {
         }
         std::unique_lock g(d.gpu_mutex);
         if (d.ctx) { trexhip_destroy(d.ctx); d.ctx = nullptr; }
+        if (d.ctx2) { trexhip_destroy(d.ctx2); d.ctx2 = nullptr; }
         d.has_background = false;
     }
     static double fps() { return data().fps(); }
@@ -226,8 +268,13 @@ struct HipBackgroundSubtraction {
         host_copy_ms = dma_ms = 0; frames = 0;
         if (!d.ctx) return;
         int64_t n2 = 0;
-        (void)trexhip_profile_read(d.ctx, TREXHIP_STAGE_UPLOAD_COPY, &host_copy_ms, &frames);
-        (void)trexhip_profile_read(d.ctx, TREXHIP_STAGE_UPLOAD_DMA, &dma_ms, &n2);
+        for (trexhip_ctx* c : {d.ctx, d.ctx2}) {
+            if (!c) continue;
+            double a = 0, b = 0; int64_t fa = 0;
+            (void)trexhip_profile_read(c, TREXHIP_STAGE_UPLOAD_COPY, &a, &fa);
+            (void)trexhip_profile_read(c, TREXHIP_STAGE_UPLOAD_DMA, &b, &n2);
+            host_copy_ms += a; dma_ms += b; frames += fa;
+        }
     }
     static bool is_initializing() { return false; }
 
@@ -258,7 +305,7 @@ struct HipBackgroundSubtraction {
 
 private:
     struct Data {
-        trexhip_ctx* ctx = nullptr;
+        trexhip_ctx *ctx = nullptr, *ctx2 = nullptr;
         uint32_t width = 0, height = 0;
         Settings settings;
         detect::ObjectDetectionType::Class type{};
