@@ -1935,20 +1935,16 @@ static int net_forward_launch(trexhip_ctx* ctx, const uint8_t* d_crops, int n, f
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (ConvGeomS<16, 64, 40, 8, 4>::LDS_BYTES)));
         TH_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv5_stream<64, 128, 20, 20, 8, true>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (ConvGeomS<64, 128, 20, 20, 8>::LDS_BYTES)));
-#define W2A(D_) W2AB(D_, 7)
-#define W2AB(D_, B_) TH_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv2_wpre<D_, B_>), hipFuncAttributeMaxDynamicSharedMemorySize, W2Geom::LDS_BYTES))
 #define W3A(D_) W3AB(D_, 7)
 #define W3AB(D_, B_) TH_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv5_wpre<D_, B_>), hipFuncAttributeMaxDynamicSharedMemorySize, (WinoGeom<64, 128, 20, 2>::LDS_BYTES)))
 #define W2BA(D_) W2BAS(D_, 5)
 #define W2BAS(D_, S_) TH_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv2_wpre2<D_, S_>), hipFuncAttributeMaxDynamicSharedMemorySize, W2bGeom::LDS_BYTES))
-        W2A(0); W3A(0); W2BA(0);
+        W3A(0); W2BA(0);
 #ifdef TREXHIP_DEV_KNOBS
         W2BA(1); W2BA(2); W2BA(3); W2BA(7); W2BA(15);
-        W2A(1); W2A(2); W2A(3); W2A(7); W2A(15); W2A(32); W2A(16); W2AB(0, 3); W2AB(0, 5); W3A(1); W3A(2); W3A(3); W3A(7); W3A(15); W3A(16); W3AB(0, 3); W3AB(0, 5); W3A(64); W3A(128); TH_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv5_wpre<0, 7, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (WinoGeom<64, 128, 20, 2>::LDS_BYTES)));
+        W3A(1); W3A(2); W3A(3); W3A(7); W3A(15); W3A(16); W3AB(0, 3); W3AB(0, 5); W3A(64); W3A(128); TH_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv5_wpre<0, 7, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (WinoGeom<64, 128, 20, 2>::LDS_BYTES)));
 #endif
-#undef W2A
 #undef W3A
-#undef W2AB
 #undef W3AB
 #undef W2BA
 #undef W2BAS
@@ -2007,8 +2003,8 @@ static int net_forward_launch(trexhip_ctx* ctx, const uint8_t* d_crops, int n, f
                                      : n * (ConvGeomB<CI_, CO_, S_, ROWS_, SplitK<KIND_>::NP, CIC_>::BPC)),                                          \
                        dim3(512), (ConvGeomB<CI_, CO_, S_, ROWS_, SplitK<KIND_>::NP, CIC_>::LDS_BYTES), s, in_, w_, b_, out_, sc_, net->d_ovf, guard_, \
                        n * (ConvGeomB<CI_, CO_, S_, ROWS_, SplitK<KIND_>::NP, CIC_>::BPC))
-    if (pre && !(ctx->tune_conv_geom & (1 << 22))) {
-        // two workgroups per CU, one M-tile per wave, operand planes fetched by LDS-DMA during the epilogue (bit 22: the one-workgroup form below)
+    if (pre) {
+        // two workgroups per CU, one M-tile per wave, operand planes fetched by LDS-DMA during the epilogue
         const int n_pass = (n * 20 + W2bGeom::RPP - 1) / W2bGeom::RPP;
 #define W2K(D_) W2KS(D_, 5)
         const int wgs = 2 * ctx->n_cus;
@@ -2021,19 +2017,6 @@ static int net_forward_launch(trexhip_ctx* ctx, const uint8_t* d_crops, int n, f
 #endif
 #undef W2K
 #undef W2KS
-    }
-    else if (pre) {
-        const int n_pass = (n * 20 + W2Geom::RPP - 1) / W2Geom::RPP;
-#define W2K(D_) W2KB(D_, 7)
-#define W2KB(D_, B_) hipLaunchKernelGGL((k_conv2_wpre<D_, B_>), dim3(n_pass < ctx->n_cus ? n_pass : ctx->n_cus), dim3(256), W2Geom::LDS_BYTES, s, \
-                           net->v2, net->w2w, net->b2, net->v3, net->inv2w, net->d_ovf, n, net->d_ovf + 2)
-#ifdef TREXHIP_DEV_KNOBS
-        switch ((ctx->tune_conv_geom >> 16) & 63) { case 1: W2K(1); break; case 2: W2K(2); break; case 3: W2K(3); break; case 7: W2K(7); break; case 15: W2K(15); break; case 32: W2K(32); break; case 16: W2K(16); break; case 48: W2KB(0, 3); break; case 49: W2KB(0, 5); break; default: W2K(0); }
-#else
-        W2K(0);
-#endif
-#undef W2K
-#undef W2KB
     }
     else if (mode == TREXHIP_CNN_FP32)
         hipLaunchKernelGGL((k_conv5<16, 64, 40, 20, 16>), dim3(n * G2::BPC), dim3(512), G2::LDS_BYTES, s, net->act1, net->w2, net->b2, net->act2);

@@ -4,7 +4,7 @@
 // Network: visual_identification_network_torch.py:184-258 (V118_3, eval mode).  Same arithmetic as k_conv5_wino / k_conv5_wino1
 // (F(4,5) Winograd along x, direct along y, fp16 two-piece split of both operands, three piece products, fp32 accumulate):
 //   k_conv1_wpre  u8 crop -> conv1 (matrix cores) -> bias, ReLU, pool -> B^T d along x -> fp16 pieces -> V2
-//   k_conv2_wpre  V2 -> conv2 (40 position GEMMs) -> A^T, bias, ReLU, pool -> B^T d -> fp16 pieces -> V3
+//   k_conv2_wpre2 V2 -> conv2 (40 position GEMMs) -> A^T, bias, ReLU, pool -> B^T d -> fp16 pieces -> V3
 //   k_conv5_wpre  V3 -> conv3 -> A^T, bias, ReLU, pool -> act3 (fp32, NHWC) -> fc1 -> head
 // so the consumers' staging is a plain 16-byte copy HBM -> VGPR -> LDS (no transform, no split, no 4-byte LDS scatter inside the
 // matrix-bound tap loops), and fp32 activations of conv1 / conv2 never travel through HBM.
@@ -163,282 +163,13 @@ __global__ __launch_bounds__(256) void k_conv1_wpre(const uint8_t* __restrict__ 
             uint8_t* d = vc + (size_t)(band * 8 + row) * V2_ROWB + tx * 32 + oct * 16;
 #pragma unroll
             for (int pi = 0; pi < 8; ++pi) {
-                const int p = pi < 3 ? pi : (pi == 3 ? 7 : pi - 1);      // stored order 0,1,2,7 | 3,4,5,6: the position groups of k_conv2_wpre
+                const int p = pi < 3 ? pi : (pi == 3 ? 7 : pi - 1);      // stored order 0,1,2,7 | 3,4,5,6: the position groups of k_conv2_wpre2
                 *reinterpret_cast<uint4*>(d + pi * 320) = o1[p];
                 *reinterpret_cast<uint4*>(d + 2560 + pi * 320) = o2[p];
             }
         }
         __syncthreads();
     }
-    if (__any(ovf) && lane == 0) atomicOr(overflow, 1u);
-}
-
-// ------------------------------------------------------------------------------------------------
-// conv2 (16 -> 64 channels, 40x40) on V2, writing V3.  The tap loop is k_conv5_wino1's: 4 waves = 2 co-tiles x 2 M-groups, two M-tiles
-// per wave, 8 position accumulators per M-tile (all 256 AGPRs), positions staged in two groups of four so that one group's 20 taps run
-// while the other group's rows are copied in.  Differences:
-//   * a pass = 6 consecutive row pairs of the batch = 120 tiles in 128 M-slots (94 %): passes end on whole pooled rows, which the
-//     V3 epilogue needs (a conv3 tile reads 8 neighbouring pooled pixels of one row);
-//   * staging = 10 x (16-byte load, 16-byte LDS store) per thread and group, no arithmetic;
-//   * epilogue: A^T M, bias, ReLU, pool -> the pass's 6 x 20 x 64 activations as fp32 in LDS (row slots of the group buffer just consumed)
-//     -> 240 threads take (row, conv3 tile, channel octet): B^T d, pieces, 16 x 16-byte stores into V3.
-// ------------------------------------------------------------------------------------------------
-struct W2Geom {
-    static constexpr int CO = 64, S = 40, TPR = 10, TPP = 20, RPP = 6;   // row pairs per pass
-    static constexpr int NR = 2 * RPP + 4;                              // input rows a pass reads
-    static constexpr int TSB = 48, PS = TPR * TSB, RP = 4 * PS;         // 1920 B: == 8 (mod 16) 16-byte slots
-    static constexpr int PLANE = (NR + 1) * RP, BUF = 2 * PLANE, LDS_BYTES = 2 * BUF;
-    static constexpr int BV = 2 * 2 * CO;
-    static constexpr int NU = NR * 2 * 80, NIT = NU / 256;              // 16-byte units per group and thread
-    static constexpr int PXP = 64;                                      // floats per pooled pixel in the epilogue buffer
-    static_assert(NU % 256 == 0 && NIT == 10, "geometry");
-    static_assert(RPP * 20 * PXP * 4 == NR * RP, "the epilogue buffer = row slots 1..NR of one plane (the zero row in slot 0 stays)");
-    static_assert(LDS_BYTES + 64 <= 160 * 1024, "LDS");
-};
-
-template <int DBG = 0, int BD = 7>      // DBG (dev builds): 1 no staging, 2 no epilogue, 4 no weight loads, 8 no A reads, 16 staging loads from one hot row, 32 no V3 transform
-__global__ __launch_bounds__(256) void k_conv2_wpre(const uint8_t* __restrict__ v2, const uint4* __restrict__ wp /*[5][8][2][2][64] x 16 B*/,
-                                                    const float* __restrict__ bias, uint8_t* __restrict__ v3, const float out_scale,
-                                                    uint32_t* __restrict__ overflow, const int n_crops, uint32_t* __restrict__ pass_ctr) {
-    using G = W2Geom;
-    constexpr int CO = 64, S = 40, TPW = 2;
-    extern __shared__ __attribute__((aligned(16))) uint8_t ldsb[];
-    __shared__ int s_next_pass;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int j = lane & 31, h = lane >> 5;
-    const int n = wave & 1, mg = wave >> 1;
-    const int total_pairs = n_crops * (S / 2);
-    const int n_pass = (total_pairs + G::RPP - 1) / G::RPP;
-    int pass = blockIdx.x;
-    if (pass >= n_pass) return;
-    for (int i = tid; i < 4 * (G::RP / 16); i += 256) {                  // the zero rows (slot 0 of both pieces of both buffers)
-        const int pl = i / (G::RP / 16), o = i - pl * (G::RP / 16);
-        *reinterpret_cast<uint4*>(ldsb + pl * G::PLANE + o * 16) = make_uint4(0, 0, 0, 0);
-    }
-    // rows qmin .. qmin+nrows-1 (q = crop*S + y) read by the row pairs [6 pass, 6 pass + 6)
-#define W2_ROWS(pass_, qmin_, nrows_)                                                                                            \
-    do {                                                                                                                         \
-        const int gp0_ = (pass_) * G::RPP;                                                                                       \
-        int gpl_ = gp0_ + G::RPP - 1;                                                                                            \
-        gpl_ = gpl_ < total_pairs ? gpl_ : total_pairs - 1;                                                                      \
-        const int y0_ = (2 * gp0_) % S, yl_ = (2 * gpl_) % S + 1;                                                                \
-        qmin_ = 2 * gp0_ - (y0_ >= 2 ? 2 : 0);                                                                                   \
-        nrows_ = 2 * gpl_ + 1 + (yl_ + 2 <= S - 1 ? 2 : 0) - qmin_ + 1;                                                          \
-    } while (0)
-    uint4 sreg[5];
-    __amdgpu_buffer_rsrc_t srs = make_rsrc(v2, 0);
-    // unit k of this thread for position group grp_: 16 bytes of (row, piece, pg, tx, k-octet); rows past the pass's last row repeat it.
-    // The LDS address is recomputed at the store (a few VALU instructions) rather than kept: every register held across the taps is one
-    // the 8-deep weight ring cannot have, and a spilled one comes back through a scratch load that drains the whole VMEM queue
-#define W2_UNIT(k_, nrows_)                                                                                                      \
-        const int u_ = tid + (k_) * 256;                                                                                         \
-        const int rp_ = u_ / 80, w_ = u_ - rp_ * 80;                                                                             \
-        int row_ = rp_ >> 1;                                                                                                     \
-        const int pc_ = rp_ & 1;                                                                                                 \
-        row_ = row_ < (nrows_) ? row_ : (nrows_) - 1;
-#define W2_L(k_, j_, grp_, qmin_, nrows_)                                                                                        \
-    do {                                                                                                                         \
-        W2_UNIT(k_, nrows_)                                                                                                      \
-        srs = make_rsrc(v2 + (size_t)((DBG & 16) ? 0 : (qmin_)) * V2_ROWB, (uint32_t)(G::NR * V2_ROWB));                         \
-        sreg[j_] = buf_load16(srs, row_ * V2_ROWB + pc_ * 2560 + w_ * 16, (grp_) * 1280);                                        \
-    } while (0)
-#define W2_S(k_, j_, nrows_, base_)                                                                                              \
-    do {                                                                                                                         \
-        W2_UNIT(k_, nrows_)                                                                                                      \
-        const int pg_ = w_ / 20, r20_ = w_ - pg_ * 20;                                                                           \
-        *reinterpret_cast<uint4*>((base_) + (row_ + 1) * G::RP + pc_ * G::PLANE + pg_ * G::PS + (r20_ >> 1) * G::TSB + (r20_ & 1) * 16) = sreg[j_]; \
-    } while (0)
-    // the staging slots of the 20 taps of a unit: five loads at taps 0 and 10, their stores one per tap from 5 / 15 on
-#define W2_SLOT(tl_, grp_, qmin_, nrows_, base_)                                                                                 \
-    do {                                                                                                                         \
-        if ((tl_) >= 5 && (tl_) < 10) W2_S((tl_) - 5, (tl_) - 5, nrows_, base_);                                                 \
-        if ((tl_) >= 15 && (tl_) < 20) W2_S((tl_) - 10, (tl_) - 15, nrows_, base_);                                              \
-        if ((tl_) == 0) { _Pragma("unroll") for (int k_ = 0; k_ < 5; ++k_) W2_L(k_, k_, grp_, qmin_, nrows_); }                  \
-        if ((tl_) == 10) { _Pragma("unroll") for (int k_ = 0; k_ < 5; ++k_) W2_L(5 + k_, k_, grp_, qmin_, nrows_); }             \
-    } while (0)
-
-    const __amdgpu_buffer_rsrc_t wrs = make_rsrc(wp, (uint32_t)(40 * G::BV * 16));
-    const int boff = (h * CO + n * 32 + j) * 16;
-    const int co = n * 32 + j;
-    const float bz = bias[co];
-    int qmin, nrows;
-    W2_ROWS(pass, qmin, nrows);
-    if (!(DBG & 1)) {
-#pragma unroll
-        for (int b = 0; b < 2; ++b) {                                    // first pass: position group 0
-#pragma unroll
-            for (int k = 0; k < 5; ++k) W2_L(5 * b + k, k, 0, qmin, nrows);
-#pragma unroll
-            for (int k = 0; k < 5; ++k) W2_S(5 * b + k, k, nrows, ldsb);
-        }
-    }
-    __syncthreads();
-#define W2_POS(tau_) (((tau_) / 20) == 0 ? ((tau_) % 4 == 3 ? 7 : (tau_) % 4) : 3 + (tau_) % 4)
-#define W2_BOFF(tau_) (((((tau_) % 20) / 4) * 8 + W2_POS(tau_)) * G::BV * 16)
-    // weight fragments are loaded BD taps ahead: a B load issued after a staging batch cannot return before that batch has (loads return
-    // in order), so BD taps are what an HBM miss of the staging loads may take before it stalls the matrix pipe
-    uint4 bq[8][2];
-#pragma unroll
-    for (int t = 0; t < BD; ++t) { bq[t][0] = buf_load16(wrs, boff, W2_BOFF(t)); bq[t][1] = buf_load16(wrs, boff, W2_BOFF(t) + 2 * CO * 16); }
-    bool ovf = false;
-    for (;;) {
-        int aoff[TPW][5];
-#pragma unroll
-        for (int m = 0; m < TPW; ++m) {
-            int s = mg * 64 + m * 32 + j;
-            s = s < G::RPP * G::TPP ? s : G::RPP * G::TPP - 1;
-            const int rp = s / G::TPP, r2 = s - rp * G::TPP;
-            int gp = pass * G::RPP + rp;
-            gp = gp < total_pairs ? gp : total_pairs - 1;
-            const int tx = r2 >> 1, qo = 2 * gp + (r2 & 1), y = qo % S;
-#pragma unroll
-            for (int ky = 0; ky < 5; ++ky) {
-                const int iy = y + ky - 2;
-                aoff[m][ky] = ((iy >= 0 && iy < S) ? (qo + ky - 2 - qmin + 1) * G::RP : 0) + tx * G::TSB + h * 16;
-            }
-        }
-        f32x16 acc[TPW][8];
-        const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        if (tid == 0) s_next_pass = (int)atomicAdd(pass_ctr, 1u) + (int)gridDim.x;   // read after the first unit's barrier
-        int next_pass = 0, qmin_n = qmin, nrows_n = nrows;
-        bool have_next = false;
-#pragma unroll
-        for (int g = 0; g < 2; ++g) {
-            if (g == 1) {
-                next_pass = s_next_pass;
-                have_next = next_pass < n_pass;
-                if (have_next) W2_ROWS(next_pass, qmin_n, nrows_n);
-            }
-            const uint8_t* pbase = ldsb + g * G::BUF;                     // group g lives in buffer g
-            uint8_t* nbase = ldsb + (g ^ 1) * G::BUF;
-            const int sqmin = g == 0 ? qmin : qmin_n, snrows = g == 0 ? nrows : nrows_n;   // under group 0: this pass's group 1; under group 1: the next pass's group 0
-            uint4 af[2][TPW][2];
-#pragma unroll
-            for (int m = 0; m < TPW; ++m) {
-                af[0][m][0] = *reinterpret_cast<const uint4*>(pbase + aoff[m][0]);
-                af[0][m][1] = *reinterpret_cast<const uint4*>(pbase + aoff[m][0] + G::PLANE);
-            }
-#pragma clang loop unroll(full)
-            for (int tl = 0; tl < 20; ++tl) {
-                const int tau = g * 20 + tl;
-                const int cur = tl & 1, nxt = cur ^ 1;
-                if (!(DBG & 8) && tl + 1 < 20) {
-                    const uint8_t* an = pbase + ((tl + 1) % 4) * G::PS;
-#pragma unroll
-                    for (int m = 0; m < TPW; ++m) {
-                        af[nxt][m][0] = *reinterpret_cast<const uint4*>(an + aoff[m][(tl + 1) / 4]);
-                        af[nxt][m][1] = *reinterpret_cast<const uint4*>(an + aoff[m][(tl + 1) / 4] + G::PLANE);
-                    }
-                }
-                if (!(DBG & 4)) {
-                    const int wt = W2_BOFF((tau + BD) % 40);
-                    bq[(tau + BD) % 8][0] = buf_load16(wrs, boff, wt);
-                    bq[(tau + BD) % 8][1] = buf_load16(wrs, boff, wt + 2 * CO * 16);
-                }
-                if (!(DBG & 1)) W2_SLOT(tl, g ^ 1, sqmin, snrows, nbase);
-                const int p = W2_POS(tau);
-                const f16x8 b1 = __builtin_bit_cast(f16x8, bq[tau % 8][0]);
-                const f16x8 b2 = __builtin_bit_cast(f16x8, bq[tau % 8][1]);
-                const f16x8 a10 = __builtin_bit_cast(f16x8, af[cur][0][0]), a20 = __builtin_bit_cast(f16x8, af[cur][0][1]);
-                const f16x8 a11 = __builtin_bit_cast(f16x8, af[cur][1][0]), a21 = __builtin_bit_cast(f16x8, af[cur][1][1]);
-                acc[0][p] = mfma16(a20, b1, tl < 4 ? zero16 : acc[0][p]);      // kernel row 0 starts the accumulator
-                acc[1][p] = mfma16(a21, b1, tl < 4 ? zero16 : acc[1][p]);
-                acc[0][p] = mfma16(a10, b2, acc[0][p]);
-                acc[1][p] = mfma16(a11, b2, acc[1][p]);
-                acc[0][p] = mfma16(a10, b1, acc[0][p]);
-                acc[1][p] = mfma16(a11, b1, acc[1][p]);
-                __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
-                __builtin_amdgcn_sched_group_barrier(0x020, 10, 0);
-#pragma unroll
-                for (int gg = 0; gg < 6; ++gg) {
-                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x206, 8, 0);
-                }
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            __syncthreads();
-        }
-        if (DBG & 2) {
-#pragma unroll
-            for (int m = 0; m < TPW; ++m)
-#pragma unroll
-                for (int p = 0; p < 8; ++p) asm volatile("" :: "a"(acc[m][p]));
-        }
-        // epilogue 1: Y = A^T M, pool, bias, ReLU -> fp32 activations of the pass in LDS (buffer 1: group 1 has been consumed, buffer 0
-        // already holds the next pass's group 0)
-        float* pbuf = reinterpret_cast<float*>(ldsb + G::BUF + G::RP);
-#pragma unroll
-        for (int m = 0; m < ((DBG & 2) ? 0 : TPW); ++m) {
-            f32x16 y0, y1, y2, y3;
-            {
-                const f32x16 e1 = acc[m][1] + acc[m][2], o1 = acc[m][1] - acc[m][2];
-                y0 = acc[m][0] + e1; y1 = o1; y2 = e1; y3 = o1 + acc[m][7];
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            {
-                const f32x16 e2 = acc[m][3] + acc[m][4], o2 = acc[m][3] - acc[m][4];
-                y0 += e2; y1 += 2.f * o2; y2 += 4.f * e2; y3 += 8.f * o2;
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            {
-                const f32x16 e3 = acc[m][5] + acc[m][6], o3 = acc[m][5] - acc[m][6];
-                y0 += e3; y1 += 0.5f * o3; y2 += 0.25f * e3; y3 += 0.125f * o3;
-            }
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int rr = 0; rr < 8; ++rr) {
-                const int r = 2 * rr;
-                const int s = mg * 64 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;      // even: rows y, y+1 of one tile column
-                const float v0 = fmaxf(fmaxf(y0[r], y1[r]), fmaxf(y0[r + 1], y1[r + 1]));
-                const float v1 = fmaxf(fmaxf(y2[r], y3[r]), fmaxf(y2[r + 1], y3[r + 1]));
-                if (s < G::RPP * G::TPP) {
-                    const int rp = s / G::TPP, tx = (s - rp * G::TPP) >> 1;
-                    const float a0 = fmaxf(v0 * out_scale + bz, 0.f), a1 = fmaxf(v1 * out_scale + bz, 0.f);
-                    ovf |= !(a0 < 4368.0f) | !(a1 < 4368.0f);
-                    float* o = pbuf + (rp * 20 + 2 * tx) * G::PXP + co;
-                    o[0] = a0;
-                    o[G::PXP] = a1;
-                }
-            }
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        __syncthreads();
-        // epilogue 2: (pooled row, conv3 tile, channel octet) items -> V3
-        if (!(DBG & (2 | 32)) && tid < 240) {
-            const int rp = tid / 40, rem = tid - rp * 40, tx = rem >> 3, oct = rem & 7;
-            const int gp = pass * G::RPP + rp;                            // = q3: pooled row of the batch
-            if (gp < total_pairs) {
-                float4 lo[8], hi[8];
-#pragma unroll
-                for (int k = 0; k < 8; ++k) {
-                    const int x = 4 * tx - 2 + k;
-                    lo[k] = make_float4(0.f, 0.f, 0.f, 0.f); hi[k] = lo[k];
-                    if (x >= 0 && x < 20) {
-                        const float4* s4 = reinterpret_cast<const float4*>(pbuf + (rp * 20 + x) * G::PXP + oct * 8);
-                        lo[k] = s4[0]; hi[k] = s4[1];
-                    }
-                }
-                uint4 o1[8], o2[8];
-                wino_pack8(lo, hi, o1, o2);
-                uint8_t* d = v3 + (size_t)gp * V3_ROWB + (oct >> 1) * 2560 + tx * 32 + (oct & 1) * 16;
-#pragma unroll
-                for (int p = 0; p < 8; ++p) {
-                    *reinterpret_cast<uint4*>(d + p * 160) = o1[p];
-                    *reinterpret_cast<uint4*>(d + 1280 + p * 160) = o2[p];
-                }
-            }
-        }
-        __syncthreads();                                                  // buffer 1 is staged into again from the next pass's first tap on
-        if (!have_next) break;
-        pass = next_pass; qmin = qmin_n; nrows = nrows_n;
-    }
-#undef W2_ROWS
-#undef W2_L
-#undef W2_UNIT
-#undef W2_S
-#undef W2_SLOT
-#undef W2_POS
-#undef W2_BOFF
     if (__any(ovf) && lane == 0) atomicOr(overflow, 1u);
 }
 
@@ -752,7 +483,8 @@ __global__ __launch_bounds__(256) void k_conv5_wpre(const uint8_t* __restrict__ 
     }
     uint4 sreg[13] = {};
     __amdgpu_buffer_rsrc_t srs = make_rsrc(v3, 0);
-    // (the LDS address of a unit is recomputed at its store: see k_conv2_wpre)
+    // (the LDS address of a unit is recomputed at its store: a register held across the 40 taps is one the weight ring cannot have, and a spilled
+    // one comes back through a scratch load that drains the whole VMEM queue)
 #define W3_UNIT(k_, nrows_)                                                                                                      \
         int u_ = tid + (k_) * 256;                                                                                               \
         asm volatile("" : "+v"(u_));             /* not loop-invariant for the compiler: no hoisting, nothing to keep or spill */ \

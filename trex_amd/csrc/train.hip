@@ -510,7 +510,6 @@ __global__ __launch_bounds__(256) void k_t_fc1_wgrad(const float* __restrict__ a
         for (int r = 0; r < 16; ++r) acc[nt][r] = 0.f;
     const float* ap = a3 + (size_t)hw * 128 + mt * 32 + j;
     const bool last_ok = 96 + j < 100;
-#pragma unroll 4
     for (int s0 = 0; s0 < n; s0 += 2) {
         const int s = s0 + h;
         const bool ok = s < n;
