@@ -381,9 +381,10 @@ def measure(args, env):
     return out
 
 
-def train_step_bench(dev, n=128, classes=100, steps=20):
-    """one optimizer step of V118_3 (fp32 forward, backward, Adam) on `n` samples: SURVEY 8(f)3 -- ms per step, algorithmic TFLOP/s against
-    the fp32 matrix peak (157.3)"""
+def train_step_bench(dev, n=128, classes=100, steps=20, precision=0):
+    """one optimizer step of V118_3 (forward, backward, Adam) on `n` samples: SURVEY 8(f)3 -- ms per step, algorithmic TFLOP/s against
+    the fp32 matrix peak (157.3).  precision 0 (the library's default): conv2 / conv3 forward and data gradients in the inference path's
+    fp16 two-piece split arithmetic; 1: exact fp32 MFMA everywhere"""
     import numpy as np
     import torch
     from trex_amd import capi, weights
@@ -392,7 +393,7 @@ def train_step_bench(dev, n=128, classes=100, steps=20):
     p = capi.default_params(64, 64)
     p.max_batch = 1
     seg = capi.Segmenter(p)
-    tr = capi.Trainer(seg, weights.pack_blob(state, classes, 1), max_batch=n, lr=1e-3, seed=3)
+    tr = capi.Trainer(seg, weights.pack_blob(state, classes, 1), max_batch=n, lr=1e-3, seed=3, precision=precision)
     dx, dy = torch.from_numpy(x).to(dev), torch.from_numpy(y.astype(np.int32)).to(dev)
     for _ in range(3):
         tr.step_device(dx.data_ptr(), dy.data_ptr(), n, 0, want_loss=False)
@@ -406,11 +407,18 @@ def train_step_bench(dev, n=128, classes=100, steps=20):
     seg.close()
     # forward 3 convolutions + fc (MAC per sample) x 3 (forward, data gradient, weight gradient; conv1 has no data gradient)
     gflop = 2 * n * (2.56e6 * 2 + 40.96e6 * 3 + 81.92e6 * 3 + 1.28e6 * 3) / 1e9
-    return {"metric": "training step of the identity network (V118_3 fp32: forward, cross entropy, backward, Adam)", "value": n / dt, "unit": "samples/s",
-            "ms_per_step": dt * 1e3, "steps": steps, "config": {"workload": f"{n} samples of 80x80x1, {classes} classes, dropout 0.05, library-drawn masks"},
-            "dtype": "f32",
-            "roofline": {"kernel": "the whole step (k_conv5<RAW> forward / data gradients, k_t_wgrad*, batch-norm / pool / head kernels, k_t_adam)", "bound": "mfma",
+    dtype = ("f32; conv2 / conv3 forward and data gradients: fp16x3-split (2 fp16 pieces per operand = 22 mantissa bits, 3 MFMA products, fp32 accumulate, "
+             "power-of-two scales per staged patch and per layer)") if precision == 0 else "f32 (exact fp32 MFMA)"
+    kern = ("the whole step (k_t_conv5_h2 forward / data gradients on the 16-bit matrix cores, k_t_wgrad* on fp32 MFMA, batch-norm / pool / head kernels, k_t_adam)"
+            if precision == 0 else "the whole step (k_conv5<RAW> forward / data gradients, k_t_wgrad*, batch-norm / pool / head kernels, k_t_adam)")
+    return {"metric": "training step of the identity network (V118_3: forward, cross entropy, backward, Adam)", "value": n / dt, "unit": "samples/s",
+            "ms_per_step": dt * 1e3, "steps": steps, "config": {"workload": f"{n} samples of 80x80x1, {classes} classes, dropout 0.05, library-drawn masks",
+                                                                 "trexhip_train_params.precision": precision},
+            "dtype": dtype,
+            "roofline": {"kernel": kern, "bound": "mfma",
                          "achieved": gflop / dt / 1e3, "peak": 157.3, "unit": "TFLOP/s", "frac": gflop / dt / 1e3 / 157.3, "traffic": None,
+                         "peak_note": "algorithmic flops of the step against the fp32 matrix peak (the yardstick of rounds 2-3); with precision 0 about 40 % of "
+                                      "those flops run on the 16-bit matrix cores (peak 2500), whose three products per term are not counted",
                          "algorithmic_gflop_per_step": gflop}}
 
 
@@ -465,11 +473,12 @@ def secondary(args, env):
             out[name] = e
         except Exception as ex:      # noqa: BLE001
             out[name] = {"error": "%s: %s" % (type(ex).__name__, ex)}
-    if not only or "train_step" in only:
-        try:
-            out["train_step"] = train_step_bench(env["dev"])
-        except Exception as ex:      # noqa: BLE001
-            out["train_step"] = {"error": "%s: %s" % (type(ex).__name__, ex)}
+    for key, prec in (("train_step", 0), ("train_step_fp32", 1)):
+        if not only or key in only:
+            try:
+                out[key] = train_step_bench(env["dev"], precision=prec)
+            except Exception as ex:      # noqa: BLE001
+                out[key] = {"error": "%s: %s" % (type(ex).__name__, ex)}
     return out
 
 

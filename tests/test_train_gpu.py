@@ -49,14 +49,15 @@ def step(tr, x, y, masks, host=False):
     return out
 
 
+@pytest.mark.parametrize("precision", [0, 1])      # 0: conv2 / conv3 forward + data gradients in fp16 two-piece split arithmetic (default), 1: exact fp32 MFMA
 @pytest.mark.parametrize("name", ["a", "b"])
-def test_training_steps_equal_the_reference_module(name):
+def test_training_steps_equal_the_reference_module(name, precision):
     fx = np.load(FIX)
     classes, ch, n, steps, seed = [int(v) for v in fx[f"{name}/meta"]]
     lr = float(fx[f"{name}/lr"][0])
     state = weights.synthetic_state(classes, seed, channels=ch)
     seg = make_seg()
-    tr = capi.Trainer(seg, weights.pack_blob(state, classes, ch), max_batch=n, lr=lr)
+    tr = capi.Trainer(seg, weights.pack_blob(state, classes, ch), max_batch=n, lr=lr, precision=precision)
     for s in range(steps):
         x, y = weights.synthetic_train_batch(n, seed + 100 * s, classes, ch)
         masks = {t: fx[f"{name}/mask{s}/{t}"] for t in ("d1", "d2", "d3", "d4")}
@@ -136,8 +137,9 @@ def test_one_step_at_vinetwork_batch_size_equals_oracle_and_is_deterministic():
     seg.close()
 
 
+@pytest.mark.parametrize("precision", [0, 1])
 @pytest.mark.parametrize("n,classes,ch", [(1, 2, 1), (67, 257, 3), (33, 1024, 1)])
-def test_ragged_batches_and_class_counts_equal_oracle(n, classes, ch):
+def test_ragged_batches_and_class_counts_equal_oracle(n, classes, ch, precision):
     # a last batch of an epoch is whatever is left (DataLoader drop_last=False, visual_recognition_torch.py:1394-1400); a single sample is legal
     # for BatchNorm2d because the statistics run over the pixels as well
     seed, lr = 900 + n, 1e-3
@@ -148,7 +150,7 @@ def test_ragged_batches_and_class_counts_equal_oracle(n, classes, ch):
     adam = tro.new_adam_state(state)
     new, loss_ref, correct_ref, grads = tro.train_step(state, adam, x, y, masks, lr, threads=16)
     seg = make_seg()
-    tr = capi.Trainer(seg, weights.pack_blob(state, classes, ch), max_batch=max(n, 4), lr=lr)
+    tr = capi.Trainer(seg, weights.pack_blob(state, classes, ch), max_batch=max(n, 4), lr=lr, precision=precision)
     loss, correct = step(tr, x, y, masks)
     assert abs(loss - loss_ref) <= 5e-5 * max(1.0, abs(loss_ref)) and correct == correct_ref
     g = read_all(tr, classes, ch, 1)

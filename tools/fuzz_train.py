@@ -20,7 +20,7 @@ for case in range(n_cases):
     seed = int(rng.integers(1, 1 << 30))
     state = weights.synthetic_state(classes, seed, channels=ch)
     adam = tro.new_adam_state(state)
-    tr = capi.Trainer(seg, weights.pack_blob(state, classes, ch), max_batch=n, lr=lr)
+    tr = capi.Trainer(seg, weights.pack_blob(state, classes, ch), max_batch=n, lr=lr, precision=case % 2)   # both arithmetics of the conv2 / conv3 convolutions
     try:
         for s in range(2):
             x, y = weights.synthetic_train_batch(n, seed + s, classes, ch)

@@ -100,7 +100,7 @@ class TrexHipError(RuntimeError):
 # every symbol include/trexhip.h declares (tests check the library exports all of them)
 class TrainParams(C.Structure):
     _fields_ = [("max_batch", C.c_int32), ("lr", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float),
-                ("bn_momentum", C.c_float), ("dropout", C.c_float), ("reserved_", C.c_int32), ("seed", C.c_uint64)]
+                ("bn_momentum", C.c_float), ("dropout", C.c_float), ("precision", C.c_int32), ("seed", C.c_uint64)]
 
 
 SYMBOLS = [
@@ -493,9 +493,9 @@ class Segmenter:
 class Trainer:
     """Training step of the identity network (include/trexhip.h: trexhip_trainer_*, trexhip_train_step_device)."""
 
-    def __init__(self, seg, weight_blob, max_batch, lr=1e-3, beta1=0.9, beta2=0.999, eps=1e-8, bn_momentum=0.1, dropout=0.05, seed=0):
+    def __init__(self, seg, weight_blob, max_batch, lr=1e-3, beta1=0.9, beta2=0.999, eps=1e-8, bn_momentum=0.1, dropout=0.05, seed=0, precision=0):
         self._h = C.c_void_p()
-        p = TrainParams(max_batch=max_batch, lr=lr, beta1=beta1, beta2=beta2, eps=eps, bn_momentum=bn_momentum, dropout=dropout, seed=seed)
+        p = TrainParams(max_batch=max_batch, lr=lr, beta1=beta1, beta2=beta2, eps=eps, bn_momentum=bn_momentum, dropout=dropout, seed=seed, precision=precision)
         buf = (C.c_char * len(weight_blob)).from_buffer_copy(weight_blob)
         _check(lib().trexhip_trainer_create(seg.handle, buf, len(weight_blob), C.byref(p), C.byref(self._h)))
         hdr = np.frombuffer(weight_blob[:32], np.int32)

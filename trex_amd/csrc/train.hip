@@ -558,6 +558,208 @@ __global__ __launch_bounds__(256) void k_t_fc1_dgrad(const float* __restrict__ d
 }
 
 // ------------------------------------------------------------------------------------------------
+// conv2 / conv3 forward and data gradients on the 16-bit matrix cores (precision 0, the default): the inference path's arithmetic --
+// x = h1 + h2 with two fp16 pieces (22 mantissa bits), products h2 g1, h1 g2, h1 g1 on v_mfma_f32_32x32x16_f16, fp32 accumulation --
+// at a fifth of the fp32-MFMA time (k_conv5<RAW>, precision 1).  fp16 cannot hold every fp32 value, so both operands carry a power-of-two
+// scale: the inputs one per workgroup and 16 / 32-channel chunk, from the largest |value| of the patch it stages (largest scaled input in
+// [2^13, 2^14)); the weights one per layer, from the pack kernel (largest scaled weight in [2^7, 2^8)).  Nothing overflows, and what
+// underflows is below 2^-27 of the patch's / the layer's largest entry.  25 shifted GEMMs, patch and weight tile in LDS, one barrier per tap.
+// ------------------------------------------------------------------------------------------------
+typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ float pow2_scale_for(const uint32_t maxbits, const int target_exp) {   // 2^k with max * 2^k in [2^target, 2^(target + 1))
+    if (maxbits == 0u) return 1.f;
+    int e = (int)((maxbits >> 23) & 0xffu) - 127;
+    int k = target_exp - e;
+    k = k < -100 ? -100 : (k > 100 ? 100 : k);
+    return __uint_as_float((uint32_t)(127 + k) << 23);
+}
+__device__ __forceinline__ void split2h_t(const float x, uint32_t& h1, uint32_t& h2) {
+    const _Float16 a = (_Float16)x;
+    const _Float16 b = (_Float16)(x - (float)a);
+    h1 = (uint32_t)__builtin_bit_cast(uint16_t, a); h2 = (uint32_t)__builtin_bit_cast(uint16_t, b);
+}
+
+template <int CI, int CO, int S, int ROWS, int CIC>
+struct ConvGeomH {
+    static constexpr int PW = S + 4, PH = ROWS + 4;
+    static constexpr int PSTRIDE = CIC * 2 + 16;                      // bytes per pixel (data + 16 pad: odd multiple of 16)
+    static constexpr int PATCH = PH * PW * PSTRIDE;                   // bytes per piece
+    static constexpr int BT = 2 * (CIC / 8) * CO * 16;                // bytes per weight tile: 2 pieces x CIC / 8 k-octets x CO x 16 B
+    static constexpr int NPIX = ROWS * S;
+    static constexpr int MT = (NPIX + 31) / 32, NT = CO / 32, WM = 8 / NT, TPW = (MT + WM - 1) / WM;
+    static constexpr int LDS_BYTES = 2 * PATCH + 2 * BT;
+    static constexpr int BPC = S / ROWS;
+    static_assert(CO % 32 == 0 && 8 % NT == 0 && CIC % 16 == 0 && CI % CIC == 0 && LDS_BYTES <= 160 * 1024, "shapes");
+};
+
+template <int CI, int CO, int S, int ROWS, int CIC, int COUT>
+__global__ __launch_bounds__(512) void k_t_conv5_h2(const float* __restrict__ in /*[N][S][S][CI]*/, const uint4* __restrict__ wp /*[CI/CIC][25][2][CIC/8][CO] x 16 B*/,
+                                                    const float* __restrict__ bias /*[COUT] or null*/, float* __restrict__ out /*[N][S][S][COUT]*/,
+                                                    const float* __restrict__ w_scale) {
+    using G = ConvGeomH<CI, CO, S, ROWS, CIC>;
+    constexpr int Q4 = CIC / 4, KO = CIC / 8;
+    extern __shared__ __attribute__((aligned(16))) uint8_t hlds[];
+    uint8_t* patch = hlds;                       // 2 pieces
+    uint8_t* Bs = hlds + 2 * G::PATCH;           // 2 buffers
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int j = lane & 31, h = lane >> 5;
+    const int n = wave % G::NT, mg = wave / G::NT;
+    const int crop = blockIdx.x / G::BPC, row0 = (blockIdx.x % G::BPC) * ROWS;
+    __shared__ float s_red[8];
+    float in_scale = 1.f;                                             // of the chunk staged last
+    int aoff[G::TPW];
+#pragma unroll
+    for (int m = 0; m < G::TPW; ++m) {
+        int p = (mg + G::WM * m) * 32 + j;                             // row-major pixel of the band
+        p = p < G::NPIX ? p : G::NPIX - 1;
+        aoff[m] = ((p / S) * G::PW + p % S) * G::PSTRIDE + h * 16;
+    }
+    f32x16 acc[G::TPW];
+#pragma unroll
+    for (int m = 0; m < G::TPW; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
+    const float* inc = in + (size_t)crop * S * S * CI;
+    constexpr int BV = G::BT / 16, BPT = (BV + 511) / 512;
+    constexpr int NITEM = G::PH * G::PW * Q4, NLD = (NITEM + 511) / 512;  // Q4 float4 per pixel; float4 per thread and chunk
+    for (int cc = 0; cc < CI / CIC; ++cc) {
+        __syncthreads();
+        // the chunk's patch: loaded into registers, its largest |value| found (wave shuffle + 8 LDS words), scaled by the power of two that
+        // puts that value into [2^13, 2^14), split and stored.  A chunk with another scale than the one before rescales the accumulators
+        // (a power of two: exact)
+        float4 v[NLD];
+        float lm = 0.f;
+#pragma unroll
+        for (int u = 0; u < NLD; ++u) {
+            const int idx = tid + u * 512;
+            v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (idx < NITEM) {
+                const int q = idx % Q4, px = idx / Q4;
+                const int py = px / G::PW, pxx = px - py * G::PW;
+                const int iy = row0 + py - 2, ix = pxx - 2;
+                if (iy >= 0 && iy < S && ix >= 0 && ix < S) v[u] = *reinterpret_cast<const float4*>(inc + ((size_t)iy * S + ix) * CI + cc * CIC + q * 4);
+                lm = fmaxf(lm, fmaxf(fmaxf(fabsf(v[u].x), fabsf(v[u].y)), fmaxf(fabsf(v[u].z), fabsf(v[u].w))));
+            }
+        }
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) lm = fmaxf(lm, __shfl_xor(lm, d));
+        if (lane == 0) s_red[wave] = lm;
+        __syncthreads();
+        float bm = s_red[0];
+#pragma unroll
+        for (int w = 1; w < 8; ++w) bm = fmaxf(bm, s_red[w]);
+        const float sc = pow2_scale_for(__float_as_uint(bm), 13);
+        if (cc > 0 && sc != in_scale) {
+            const float f = sc / in_scale;
+#pragma unroll
+            for (int m = 0; m < G::TPW; ++m) acc[m] *= f;
+        }
+        in_scale = sc;
+#pragma unroll
+        for (int u = 0; u < NLD; ++u) {
+            const int idx = tid + u * 512;
+            if (idx < NITEM) {
+                const int q = idx % Q4, px = idx / Q4;
+                uint32_t a1[4], a2[4];
+                split2h_t(v[u].x * sc, a1[0], a2[0]); split2h_t(v[u].y * sc, a1[1], a2[1]);
+                split2h_t(v[u].z * sc, a1[2], a2[2]); split2h_t(v[u].w * sc, a1[3], a2[3]);
+                uint8_t* d = patch + px * G::PSTRIDE + q * 8;
+                *reinterpret_cast<uint2*>(d) = make_uint2(a1[0] | (a1[1] << 16), a1[2] | (a1[3] << 16));
+                *reinterpret_cast<uint2*>(d + G::PATCH) = make_uint2(a2[0] | (a2[1] << 16), a2[2] | (a2[3] << 16));
+            }
+        }
+        const uint4* wsrc = wp + (size_t)cc * 25 * BV;
+        for (int i = tid; i < BV; i += 512) reinterpret_cast<uint4*>(Bs)[i] = wsrc[i];
+        __syncthreads();
+        for (int tap = 0; tap < 25; ++tap) {
+            const int buf = tap & 1;
+            uint4 nb[BPT];
+            if (tap < 24) {
+#pragma unroll
+                for (int u = 0; u < BPT; ++u) { const int i = tid + u * 512; if (i < BV) nb[u] = wsrc[(size_t)(tap + 1) * BV + i]; }
+            }
+            const uint8_t* asrc = patch + ((tap / 5) * G::PW + (tap % 5)) * G::PSTRIDE;
+#pragma unroll
+            for (int ks = 0; ks < CIC / 16; ++ks) {                        // one 16-deep MFMA step per 16 input channels
+                const uint8_t* bsrc = Bs + buf * G::BT + ((2 * ks + h) * CO + n * 32 + j) * 16;
+                const h16x8 b1 = __builtin_bit_cast(h16x8, *reinterpret_cast<const uint4*>(bsrc));
+                const h16x8 b2 = __builtin_bit_cast(h16x8, *reinterpret_cast<const uint4*>(bsrc + KO * CO * 16));
+#pragma unroll
+                for (int m = 0; m < G::TPW; ++m) {
+                    const h16x8 p1 = __builtin_bit_cast(h16x8, *reinterpret_cast<const uint4*>(asrc + aoff[m] + ks * 32));
+                    const h16x8 p2 = __builtin_bit_cast(h16x8, *reinterpret_cast<const uint4*>(asrc + aoff[m] + ks * 32 + G::PATCH));
+                    acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(p2, b1, acc[m], 0, 0, 0);
+                    acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(p1, b2, acc[m], 0, 0, 0);
+                    acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(p1, b1, acc[m], 0, 0, 0);
+                }
+            }
+            if (tap < 24) {
+#pragma unroll
+                for (int u = 0; u < BPT; ++u) { const int i = tid + u * 512; if (i < BV) reinterpret_cast<uint4*>(Bs + (buf ^ 1) * G::BT)[i] = nb[u]; }
+            }
+            __syncthreads();
+        }
+    }
+    const int co = n * 32 + j;
+    if (co >= COUT) return;
+    const float out_scale = 1.0f / (in_scale * *w_scale);             // powers of two: exact
+    const float bz = bias ? bias[co] : 0.f;
+    float* oc = out + ((size_t)crop * S * S + (size_t)row0 * S) * COUT;
+#pragma unroll
+    for (int m = 0; m < G::TPW; ++m) {
+        const int mt = mg + G::WM * m;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int p = mt * 32 + 8 * (r / 4) + 4 * h + (r % 4);        // accumulator r of lane (j, h) is row 8 (r / 4) + 4 h + r % 4
+            if (p < G::NPIX) oc[(size_t)p * COUT + co] = acc[m][r] * out_scale + bz;
+        }
+    }
+}
+
+// weights of one layer -> the B-operand image of k_t_conv5_h2, both directions in one launch: [dir][k / CICK][tap][piece][(k % CICK) / 8][n] x 16 B
+// (8 consecutive k per 16 bytes).  dir 0 = forward: k = ci, n = co, w(ci, tap, co); dir 1 = data gradient: k = co, n = ci (padded to NP1
+// columns), w(ci, 24 - tap, co).  Parameter layout of w: [ci / CICP][tap][ci % CICP][co].  Every block finds the tensor's largest |w| itself
+// (the same value in every block), block 0 writes the scale.
+__global__ __launch_bounds__(1024) void k_t_pack_h2(const float* __restrict__ w, const int CI, const int CO, const int CICP, const int CICK0, const int CICK1,
+                                                    const int NP1, uint4* __restrict__ out0, uint4* __restrict__ out1, float* __restrict__ w_scale) {
+    __shared__ float red[1024];
+    const int total4 = 25 * CI * CO / 4;
+    float m = 0.f;
+#pragma unroll 4
+    for (int i = threadIdx.x; i < total4; i += 1024) {
+        const float4 v = reinterpret_cast<const float4*>(w)[i];
+        m = fmaxf(m, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))));
+    }
+    red[threadIdx.x] = m;
+    __syncthreads();
+    for (int d = 512; d >= 1; d >>= 1) { if ((int)threadIdx.x < d) red[threadIdx.x] = fmaxf(red[threadIdx.x], red[threadIdx.x + d]); __syncthreads(); }
+    const float sc = pow2_scale_for(__float_as_uint(red[0]), 7);
+    if (blockIdx.x == 0 && threadIdx.x == 0) *w_scale = sc;
+    auto wat = [&](int ci, int tap, int co) -> float { return w[(((size_t)(ci / CICP) * 25 + tap) * CICP + ci % CICP) * CO + co]; };
+    const int n0 = (CI / 8) * 25 * CO, n1 = (CO / 8) * 25 * NP1;         // 16-byte units per piece
+    for (int u = blockIdx.x * 1024 + threadIdx.x; u < n0 + n1; u += gridDim.x * 1024) {
+        const bool d1 = u >= n0;
+        const int v = d1 ? u - n0 : u;
+        const int K = d1 ? CO : CI, N = d1 ? NP1 : CO, CK = d1 ? CICK1 : CICK0;
+        const int nn = v % N, ko = (v / N) % (CK / 8), tap = (v / (N * (CK / 8))) % 25, cc = v / (N * (CK / 8) * 25);
+        (void)K;
+        uint32_t h1[8], h2[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int k = cc * CK + ko * 8 + e;
+            float x = 0.f;
+            if (!d1) x = wat(k, tap, nn);
+            else if (nn < CI) x = wat(nn, 24 - tap, k);
+            split2h_t(x * sc, h1[e], h2[e]);
+        }
+        uint4* o = (d1 ? out1 : out0) + ((size_t)(cc * 25 + tap) * 2 * (CK / 8) + ko) * N + nn;
+        o[0] = make_uint4(h1[0] | (h1[1] << 16), h1[2] | (h1[3] << 16), h1[4] | (h1[5] << 16), h1[6] | (h1[7] << 16));
+        o[(size_t)(CK / 8) * N] = make_uint4(h2[0] | (h2[1] << 16), h2[2] | (h2[3] << 16), h2[4] | (h2[5] << 16), h2[6] | (h2[7] << 16));
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // convolution weight gradient on fp32 MFMA: dW[tap][ci][co] = sum over (crop, y, x) a[crop][y+ky-2][x+kx-2][ci] * dz[crop][y][x][co].
 // One 32x32x2 MFMA step contracts over two neighbouring pixels: A = activations at the taps' shifts, B = dz.
 //   * block = one kernel row ky x one slice of CIS input channels x one slice of COS output channels x one share of the work units
@@ -866,6 +1068,9 @@ struct Trainer {
     float *P = nullptr, *G = nullptr, *M = nullptr, *V = nullptr;
     float *z1 = nullptr, *a1 = nullptr, *z2 = nullptr, *a2 = nullptr, *z3 = nullptr, *a3 = nullptr, *da3 = nullptr, *da2 = nullptr, *da1 = nullptr;
     float *wb3 = nullptr, *wb2 = nullptr, *part = nullptr, *stat = nullptr /*3 x (mean, invstd, sums[2]) x 128*/;
+    // precision 0: fp16 two-piece operand images of the conv2 / conv3 weights (forward, data gradient) and their scales
+    uint4 *wh2f = nullptr, *wh2b = nullptr, *wh3f = nullptr, *wh3b = nullptr;
+    float* wh_scale = nullptr;
     float *hpart = nullptr, *xhat = nullptr, *hd = nullptr, *dl = nullptr, *dy = nullptr, *dh = nullptr, *loss = nullptr, *out2 = nullptr;
     int32_t* correct = nullptr;
     int32_t* bad_target = nullptr;       // set by k_t_head when a target is outside 0..classes-1; sticky until read
@@ -929,7 +1134,11 @@ static void trainer_free(Trainer* t) {
 using G2F = ConvGeom<16, 64, 40, 20, 16>;
 using G3F = ConvGeom<64, 128, 20, 10, 32>;     // 10-row bands: 2 blocks per crop (a training batch is 64..128 crops, the chip has 256 CUs; 4-row bands measured no faster)
 using G3B = ConvGeom<128, 64, 20, 10, 32>;
-using G2B = ConvGeom16<64, 40, 20, 16>;          // conv2's data gradient: 16 output channels on 16x16x4 tiles, two blocks per crop
+using G2B = ConvGeom16<64, 40, 20, 16>;
+using H2F = ConvGeomH<16, 64, 40, 20, 16>;       // precision 0 (fp16 two-piece split): conv2 / conv3 forward, conv3 / conv2 data gradient
+using H3F = ConvGeomH<64, 128, 20, 10, 32>;
+using H3B = ConvGeomH<128, 64, 20, 10, 32>;
+using H2B = ConvGeomH<64, 32, 40, 20, 16>;       // 16 output channels in a 32-wide tile          // conv2's data gradient: 16 output channels on 16x16x4 tiles, two blocks per crop
 
 template <int C>
 static void launch_colstats(hipStream_t s, const float* d, size_t rows, double* red) {
@@ -1000,6 +1209,12 @@ static void trainer_forward(Trainer* t, hipStream_t s, const float* x, const int
     const uint8_t *k1 = keep, *k2 = keep + (size_t)n * 16, *k3 = keep + (size_t)n * 80, *k4 = keep + (size_t)n * 208;
     float* P = t->P;
     const size_t* o = t->off;
+    const bool h2 = t->p.precision == 0;
+    if (h2) {
+        // this step's weights as fp16 two-piece operand images (both directions)
+        hipLaunchKernelGGL(k_t_pack_h2, dim3(10), dim3(1024), 0, s, P + o[T_C2W], 16, 64, 16, 16, 16, 32, t->wh2f, t->wh2b, t->wh_scale);
+        hipLaunchKernelGGL(k_t_pack_h2, dim3(50), dim3(1024), 0, s, P + o[T_C3W], 64, 128, 32, 32, 32, 64, t->wh3f, t->wh3b, t->wh_scale + 1);
+    }
     auto block = [&](auto tag, int layer, const float* z, float* a, int S, int tg, int tb, int trm, int trv, const uint8_t* kp) {
         constexpr int C = decltype(tag)::value;
         if (train) { bn_forward<C>(t, s, layer, z, a, n, S, tg, tb, trm, trv, kp, scale); return; }
@@ -1011,9 +1226,11 @@ static void trainer_forward(Trainer* t, hipStream_t s, const float* x, const int
     };
     if (t->CH == 1) launch_layer1<1>(t, s, x, n); else launch_layer1<3>(t, s, x, n);
     block(std::integral_constant<int, 16>{}, 0, t->z1, t->a1, 80, T_G1, T_BE1, T_RM1, T_RV1, k1);
-    hipLaunchKernelGGL((k_conv5<16, 64, 40, 20, 16, CONV_EPI_RAW, 64>), dim3(n * G2F::BPC), dim3(512), G2F::LDS_BYTES, s, t->a1, P + o[T_C2W], P + o[T_C2B], t->z2);
+    if (h2) hipLaunchKernelGGL((k_t_conv5_h2<16, 64, 40, 20, 16, 64>), dim3(n * H2F::BPC), dim3(512), H2F::LDS_BYTES, s, t->a1, t->wh2f, P + o[T_C2B], t->z2, t->wh_scale);
+    else hipLaunchKernelGGL((k_conv5<16, 64, 40, 20, 16, CONV_EPI_RAW, 64>), dim3(n * G2F::BPC), dim3(512), G2F::LDS_BYTES, s, t->a1, P + o[T_C2W], P + o[T_C2B], t->z2);
     block(std::integral_constant<int, 64>{}, 1, t->z2, t->a2, 40, T_G2, T_BE2, T_RM2, T_RV2, k2);
-    hipLaunchKernelGGL((k_conv5<64, 128, 20, 10, 32, CONV_EPI_RAW, 128>), dim3(n * G3F::BPC), dim3(512), G3F::LDS_BYTES, s, t->a2, P + o[T_C3W], P + o[T_C3B], t->z3);
+    if (h2) hipLaunchKernelGGL((k_t_conv5_h2<64, 128, 20, 10, 32, 128>), dim3(n * H3F::BPC), dim3(512), H3F::LDS_BYTES, s, t->a2, t->wh3f, P + o[T_C3B], t->z3, t->wh_scale + 1);
+    else hipLaunchKernelGGL((k_conv5<64, 128, 20, 10, 32, CONV_EPI_RAW, 128>), dim3(n * G3F::BPC), dim3(512), G3F::LDS_BYTES, s, t->a2, P + o[T_C3W], P + o[T_C3B], t->z3);
     block(std::integral_constant<int, 128>{}, 2, t->z3, t->a3, 20, T_G3, T_BE3, T_RM3, T_RV3, k3);
     hipLaunchKernelGGL(k_t_fc1, dim3(100, (n + 63) / 64), dim3(256), 0, s, t->a3, P + o[T_F1W], t->hpart, n);
     hipLaunchKernelGGL(k_t_head, dim3(n), dim3(128), 0, s, t->hpart, n, P + o[T_F1B], P + o[T_LNG], P + o[T_LNB], k4, scale, P + o[T_F2W], P + o[T_F2B], targets,
@@ -1026,6 +1243,10 @@ static int trainer_attrs(Trainer* t) {
     TH_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv5<64, 128, 20, 10, 32, CONV_EPI_RAW, 128>), hipFuncAttributeMaxDynamicSharedMemorySize, G3F::LDS_BYTES));
     TH_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv5<128, 64, 20, 10, 32, CONV_EPI_RAW, 64>), hipFuncAttributeMaxDynamicSharedMemorySize, G3B::LDS_BYTES));
     TH_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv5_n16<64, 40, 20, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, G2B::LDS_BYTES));
+    TH_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_t_conv5_h2<16, 64, 40, 20, 16, 64>), hipFuncAttributeMaxDynamicSharedMemorySize, H2F::LDS_BYTES));
+    TH_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_t_conv5_h2<64, 128, 20, 10, 32, 128>), hipFuncAttributeMaxDynamicSharedMemorySize, H3F::LDS_BYTES));
+    TH_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_t_conv5_h2<128, 64, 20, 10, 32, 64>), hipFuncAttributeMaxDynamicSharedMemorySize, H3B::LDS_BYTES));
+    TH_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_t_conv5_h2<64, 32, 40, 20, 16, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, H2B::LDS_BYTES));
     TH_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_t_wgrad<64, 128, 20, 32, 64, 5, 10>), hipFuncAttributeMaxDynamicSharedMemorySize, WG3::LDS_BYTES));
     TH_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_t_wgrad<16, 64, 40, 16, 64, 3, 5>), hipFuncAttributeMaxDynamicSharedMemorySize, WG2::LDS_BYTES));
     t->attr = true;
@@ -1078,13 +1299,17 @@ static int trainer_step(Trainer* t, const float* x, const int32_t* targets, int 
     hipLaunchKernelGGL(k_t_fc1_wgrad, dim3(100), dim3(256), 0, s, t->a3, t->dh, G + o[T_F1W], n);
     hipLaunchKernelGGL(k_t_fc1_dgrad, dim3(100, (n + 31) / 32), dim3(256), 0, s, t->dh, P + o[T_F1W], t->da3, n);
     // block 3
+    const bool h2 = t->p.precision == 0;
     bn_backward<128>(t, s, 2, t->da3, t->z3, n, 20, T_G3, T_BE3, T_C3B, k3, scale);
     {
         const int shares = n * WG3::NB < SHARES3 ? n * WG3::NB : SHARES3;
         hipLaunchKernelGGL((k_t_wgrad<64, 128, 20, 32, 64, 5, 10>), dim3(WG3::TYPES, shares), dim3(512), WG3::LDS_BYTES, s, t->a2, t->z3, t->part, n);
         hipLaunchKernelGGL(k_t_wgrad_reduce, dim3((25 * 64 * 128 + 255) / 256), dim3(256), 0, s, t->part, shares, 64, 128, 32, G + o[T_C3W]);
-        hipLaunchKernelGGL(k_t_repack_bwd, dim3((25 * 128 * 64 + 255) / 256), dim3(256), 0, s, P + o[T_C3W], 64, 128, 32, 64, 32, t->wb3);
-        hipLaunchKernelGGL((k_conv5<128, 64, 20, 10, 32, CONV_EPI_RAW, 64>), dim3(n * G3B::BPC), dim3(512), G3B::LDS_BYTES, s, t->z3, t->wb3, (const float*)nullptr, t->da2);
+        if (h2) hipLaunchKernelGGL((k_t_conv5_h2<128, 64, 20, 10, 32, 64>), dim3(n * H3B::BPC), dim3(512), H3B::LDS_BYTES, s, t->z3, t->wh3b, (const float*)nullptr, t->da2, t->wh_scale + 1);
+        else {
+            hipLaunchKernelGGL(k_t_repack_bwd, dim3((25 * 128 * 64 + 255) / 256), dim3(256), 0, s, P + o[T_C3W], 64, 128, 32, 64, 32, t->wb3);
+            hipLaunchKernelGGL((k_conv5<128, 64, 20, 10, 32, CONV_EPI_RAW, 64>), dim3(n * G3B::BPC), dim3(512), G3B::LDS_BYTES, s, t->z3, t->wb3, (const float*)nullptr, t->da2);
+        }
     }
     // block 2
     bn_backward<64>(t, s, 1, t->da2, t->z2, n, 40, T_G2, T_BE2, T_C2B, k2, scale);
@@ -1092,8 +1317,11 @@ static int trainer_step(Trainer* t, const float* x, const int32_t* targets, int 
         const int shares = n * WG2::NB < SHARES2 ? n * WG2::NB : SHARES2;
         hipLaunchKernelGGL((k_t_wgrad<16, 64, 40, 16, 64, 3, 5>), dim3(WG2::TYPES, shares), dim3(512), WG2::LDS_BYTES, s, t->a1, t->z2, t->part, n);
         hipLaunchKernelGGL(k_t_wgrad_reduce, dim3((25 * 16 * 64 + 255) / 256), dim3(256), 0, s, t->part, shares, 16, 64, 16, G + o[T_C2W]);
-        hipLaunchKernelGGL(k_t_repack_bwd, dim3((25 * 64 * 16 + 255) / 256), dim3(256), 0, s, P + o[T_C2W], 16, 64, 16, 16, 16, t->wb2);
-        hipLaunchKernelGGL((k_conv5_n16<64, 40, 20, 16>), dim3(n * G2B::BPC), dim3(512), G2B::LDS_BYTES, s, t->z2, t->wb2, t->da1);
+        if (h2) hipLaunchKernelGGL((k_t_conv5_h2<64, 32, 40, 20, 16, 16>), dim3(n * H2B::BPC), dim3(512), H2B::LDS_BYTES, s, t->z2, t->wh2b, (const float*)nullptr, t->da1, t->wh_scale);
+        else {
+            hipLaunchKernelGGL(k_t_repack_bwd, dim3((25 * 64 * 16 + 255) / 256), dim3(256), 0, s, P + o[T_C2W], 16, 64, 16, 16, 16, t->wb2);
+            hipLaunchKernelGGL((k_conv5_n16<64, 40, 20, 16>), dim3(n * G2B::BPC), dim3(512), G2B::LDS_BYTES, s, t->z2, t->wb2, t->da1);
+        }
     }
     // block 1
     bn_backward<16>(t, s, 0, t->da1, t->z1, n, 80, T_G1, T_BE1, T_C1B, k1, scale);
@@ -1171,6 +1399,9 @@ int trexhip_trainer_create(trexhip_ctx* ctx, const void* blob, size_t bytes, con
     TRY(dev_alloc(t, &t->a2, n * 400 * 64)); TRY(dev_alloc(t, &t->z3, n * 400 * 128)); TRY(dev_alloc(t, &t->a3, n * 100 * 128));
     TRY(dev_alloc(t, &t->da3, n * 100 * 128)); TRY(dev_alloc(t, &t->da2, n * 400 * 64)); TRY(dev_alloc(t, &t->da1, n * 1600 * 16));
     TRY(dev_alloc(t, &t->wb3, (size_t)4 * 25 * 32 * 64)); TRY(dev_alloc(t, &t->wb2, (size_t)2 * 25 * 32 * 32));
+    TRY(dev_alloc(t, &t->wh2f, (size_t)2 * 2 * 25 * 64)); TRY(dev_alloc(t, &t->wh2b, (size_t)2 * 8 * 25 * 32));
+    TRY(dev_alloc(t, &t->wh3f, (size_t)2 * 8 * 25 * 128)); TRY(dev_alloc(t, &t->wh3b, (size_t)2 * 16 * 25 * 64));
+    TRY(dev_alloc(t, &t->wh_scale, 2));
     t->part_floats = std::max(std::max((size_t)SHARES3 * 25 * 64 * 128, (size_t)SHARES2 * 25 * 16 * 64), n * 10 * CH * 400);
     TRY(dev_alloc(t, &t->part, t->part_floats));
     TRY(dev_alloc(t, &t->stat, (size_t)3 * 512));

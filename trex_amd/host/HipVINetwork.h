@@ -117,8 +117,11 @@ struct HipVINetwork {
     // early stopping stay with the caller, as they are host logic in the reference too.
     struct Trainer {
         // weights: the same blob as load_weights (the reference starts from the network's current state_dict)
-        Trainer(HipVINetwork& net, const void* blob, size_t bytes, int max_batch, float learning_rate = 0.001f, uint64_t seed = 0) : _net(net) {
+        // exact_fp32: conv2 / conv3 forward and data gradients on the fp32 matrix cores instead of the fp16 two-piece split arithmetic
+        // (trexhip_train_params::precision; same parity bars, 1.6 instead of 1.2 ms per 128-sample step)
+        Trainer(HipVINetwork& net, const void* blob, size_t bytes, int max_batch, float learning_rate = 0.001f, uint64_t seed = 0, bool exact_fp32 = false) : _net(net) {
             trexhip_train_params p{};
+            p.precision = exact_fp32 ? 1 : 0;
             p.max_batch = max_batch; p.lr = learning_rate; p.beta1 = 0.9f; p.beta2 = 0.999f; p.eps = 1e-8f; p.bn_momentum = 0.1f; p.dropout = 0.05f; p.seed = seed;
             check(trexhip_trainer_create(net._ctx, blob, bytes, &p, &_t));
             std::memcpy(&_classes, static_cast<const char*>(blob) + 8, 4);
