@@ -1034,291 +1034,6 @@ __global__ __launch_bounds__((WinoGeom<CI, CO, S, TPW>::NTHR), (TPW == 1 ? 2 : 1
     if (__any(!(mxabs < 4368.0f)) && lane == 0) atomicOr(overflow, 1u);
 }
 
-// ------------------------------------------------------------------------------------------------
-// k_conv5_wino1: the same F(4,5) Winograd convolution for a layer with ONE 16-channel chunk (conv2: 16 -> 64 channels, 40x40).
-// 4 waves = 2 co-tiles x 2 M-groups, 2 M-tiles per wave: a pass = 128 tiles.  With a single chunk there is nothing to double-buffer
-// over, and the transformed rows of a pass do not fit LDS twice with all 8 positions; so the positions are staged in two groups
-// of four ({0,1,2,7} and {3,4,5,6}: the +- pairs of B^T stay together): while the 20 taps of one group run, the other group (of
-// this pass, then of the next pass) is transformed into the second buffer.  All 8 position accumulators stay live; the first
-// tap row starts them from a zero operand.  LDS: [buffer][piece][row slot][position of the group][tx][16 ci + 16 B pad] fp16.
-// ------------------------------------------------------------------------------------------------
-template <int CO, int S>
-struct WinoGeom1 {
-    static constexpr int CI = 16, TPW = 2;
-    static constexpr int TPR = S / 4, TPP = 2 * TPR, TPC = S * TPR;
-    static constexpr int NT = CO / 32, WM = 4 / NT, NTHR = 256;
-    static constexpr int MB = WM * TPW * 32;
-    static constexpr int MAXPAIRS = (MB + TPP - 2) / TPP + 1;
-    static constexpr int NR = 2 * MAXPAIRS + 4;
-    static constexpr int TSB = 48;                                      // bytes per tile: 16 halves + 16 pad (odd number of 16-byte slots)
-    static constexpr int PS = TPR * TSB;
-    static constexpr int RP0 = 4 * PS;
-    static constexpr int RP = RP0 + (((8 - (RP0 / 16) % 16) + 16) % 16) * 16;   // row pitch == 8 (mod 16) slots: rows y, y+1 on disjoint slots
-    static constexpr int PLANE = (NR + 1) * RP;
-    static constexpr int BUF = 2 * PLANE;
-    static constexpr int LDS_BYTES = 2 * BUF;
-    static constexpr int BV = 2 * 2 * CO;
-    static constexpr int NIT = (NR * TPR * 4 + NTHR - 1) / NTHR;
-    static_assert(NT * WM == 4 && NIT == 4, "geometry");
-    static_assert(LDS_BYTES + 64 <= 160 * 1024, "LDS");
-};
-
-template <int CO, int S, int DBG = 0>      // DBG (dev builds): 1 no staging, 2 no epilogue, 4 no weight loads, 8 no A reads
-__global__ __launch_bounds__(256) void k_conv5_wino1(const float* __restrict__ in /*[N][S][S][16]*/, const uint4* __restrict__ wp /*[5][8][2][2][CO] x 16 B*/,
-                                                     const float* __restrict__ bias, float* __restrict__ out, const float out_scale,
-                                                     uint32_t* __restrict__ overflow, const int n_crops, uint32_t* __restrict__ pass_ctr) {
-    using G = WinoGeom1<CO, S>;
-    constexpr int CI = 16, TPW = 2;
-    extern __shared__ __attribute__((aligned(16))) uint8_t ldsb[];
-    __shared__ int s_next_pass;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int j = lane & 31, h = lane >> 5;
-    const int n = wave % G::NT, mg = wave / G::NT;
-    const int total_tiles = n_crops * G::TPC;
-    const int n_pass = (total_tiles + G::MB - 1) / G::MB;
-    int pass = blockIdx.x;
-    if (pass >= n_pass) return;
-    float mxabs = 0.f;
-    for (int i = tid; i < 4 * (G::RP / 16); i += 256) {                  // the zero rows
-        const int pl = i / (G::RP / 16), o = i - pl * (G::RP / 16);
-        *reinterpret_cast<uint4*>(ldsb + pl * G::PLANE + o * 16) = make_uint4(0, 0, 0, 0);
-    }
-    float4 sd[8];                                        // ONE item in flight (registers are the scarce resource of this kernel)
-    float su[2][4];
-    int sdst2[2] = {0, 0}, sflag = 0;              // the store offset of an item is still needed after the next item's load
-    __amdgpu_buffer_rsrc_t srs = make_rsrc(in, 0);
-#define W1_L(item_, qmin_, nrows_)                                                                                              \
-    do {                                                                                                                        \
-        const int idx_ = tid + (item_) * 256;                                                                                   \
-        int s_ = idx_ / (G::TPR * 4);                                                                                           \
-        const int r_ = idx_ - s_ * (G::TPR * 4);                                                                                \
-        const int cq_ = r_ & 3, tx_ = r_ >> 2;                                                                                  \
-        s_ = s_ < (nrows_) ? s_ : (nrows_) - 1;                                                                                 \
-        srs = make_rsrc(in + ((size_t)(qmin_) * S) * CI, (uint32_t)(G::NR * S * CI * 4));                                       \
-        const int soff_ = s_ * (S * CI * 4) + cq_ * 16;                                                                         \
-        sdst2[(item_) & 1] = (s_ + 1) * G::RP + tx_ * G::TSB + cq_ * 8;                                                         \
-        sflag = (tx_ == 0 ? 1 : 0) | (tx_ == G::TPR - 1 ? 2 : 0);                                                               \
-        _Pragma("unroll") for (int k_ = 0; k_ < 8; ++k_) {                                                                      \
-            int ix_ = 4 * tx_ - 2 + k_;                                                                                         \
-            ix_ = ix_ < 0 ? 0 : (ix_ > S - 1 ? S - 1 : ix_);                                                                    \
-            sd[k_] = buf_load16f(srs, soff_ + ix_ * (CI * 4), 0);                                                               \
-        }                                                                                                                       \
-    } while (0)
-    // B^T rows of one position group for one channel: group 0 -> positions 0, 1, 2, 7; group 1 -> 3, 4, 5, 6
-#define W1_T(item_, grp_, which_, comp_)                                                                                        \
-    do {                                                                                                                        \
-        const int sflag_ = sflag;                                                                                               \
-        const float4* sd_ = sd;                                                                                                 \
-        const float d1_ = (sflag_ & 1) ? 0.f : sd_[1].comp_, d6_ = (sflag_ & 2) ? 0.f : sd_[6].comp_;                           \
-        const float d2_ = sd_[2].comp_, d3_ = sd_[3].comp_, d4_ = sd_[4].comp_, d5_ = sd_[5].comp_;                             \
-        if ((grp_) == 0) {                                                                                                      \
-            const float d0_ = (sflag_ & 1) ? 0.f : sd_[0].comp_, d7_ = (sflag_ & 2) ? 0.f : sd_[7].comp_;                       \
-            mxabs = fmaxf(fmaxf(mxabs, fabsf(d2_)), fmaxf(fabsf(d3_), fmaxf(fabsf(d4_), fabsf(d5_))));                          \
-            mxabs = fmaxf(fmaxf(mxabs, fabsf(d0_)), fmaxf(fabsf(d1_), fmaxf(fabsf(d6_), fabsf(d7_))));                          \
-            su[which_][0] = fmaf(5.25f, d2_ - d4_, d6_ - d0_);                                                                  \
-            su[which_][3] = fmaf(5.25f, d3_ - d5_, d7_ - d1_);                                                                  \
-            const float e1_ = fmaf(-4.25f, d4_, d2_ + d6_), o1_ = fmaf(-4.25f, d3_, d1_ + d5_);                                 \
-            su[which_][1] = e1_ + o1_; su[which_][2] = e1_ - o1_;                                                               \
-        } else {                                                                                                                \
-            const float e2_ = fmaf(-1.25f, d4_, fmaf(0.25f, d2_, d6_)), o2_ = fmaf(2.f, d5_, fmaf(-2.5f, d3_, 0.5f * d1_));     \
-            su[which_][0] = e2_ + o2_; su[which_][1] = e2_ - o2_;                                                               \
-            const float e3_ = fmaf(-5.f, d4_, fmaf(4.f, d2_, d6_)), o3_ = fmaf(0.5f, d5_, fmaf(-2.5f, d3_, 2.f * d1_));         \
-            su[which_][2] = e3_ + o3_; su[which_][3] = e3_ - o3_;                                                               \
-        }                                                                                                                       \
-    } while (0)
-#define W1_S(item_, half_, base_)                                                                                               \
-    do {                                                                                                                        \
-        _Pragma("unroll") for (int q_ = 0; q_ < 4; ++q_) {                                                                      \
-            uint32_t a1_, a2_;                                                                                                  \
-            split2h_pair(su[0][q_], su[1][q_], a1_, a2_);                                                                       \
-            uint8_t* dst_ = (base_) + sdst2[(item_) & 1] + q_ * G::PS + (half_) * 4;                                            \
-            *reinterpret_cast<uint32_t*>(dst_) = a1_;                                                                           \
-            *reinterpret_cast<uint32_t*>(dst_ + G::PLANE) = a2_;                                                                \
-        }                                                                                                                       \
-    } while (0)
-    // the four compute slots of an item
-#define W1_C(st_, item_, grp_, base_)                                                                                           \
-    do {                                                                                                                        \
-        if ((st_) == 0) { W1_T(item_, grp_, 0, x); W1_T(item_, grp_, 1, y); }                                                   \
-        if ((st_) == 1) W1_S(item_, 0, base_);                                                                                  \
-        if ((st_) == 2) { W1_T(item_, grp_, 0, z); W1_T(item_, grp_, 1, w); }                                                   \
-        if ((st_) == 3) W1_S(item_, 1, base_);                                                                                  \
-    } while (0)
-    // the staging slots of the 20 taps of a unit, one item at a time: load at taps 0 / 4 / 9 / 14, then transform x, y (+2 taps), store
-    // (+3), transform z, w (+4, before the next item's load in the same slot), store (+5)
-#define W1_SLOT(tl_, grp_, qmin_, nrows_, base_)                                                                                \
-    do {                                                                                                                        \
-        if ((tl_) == 2) W1_C(0, 0, grp_, base_);                                                                                \
-        if ((tl_) == 3) W1_C(1, 0, grp_, base_);                                                                                \
-        if ((tl_) == 4) W1_C(2, 0, grp_, base_);                                                                                \
-        if ((tl_) == 5) W1_C(3, 0, grp_, base_);                                                                                \
-        if ((tl_) == 6) W1_C(0, 1, grp_, base_);                                                                                \
-        if ((tl_) == 7) W1_C(1, 1, grp_, base_);                                                                                \
-        if ((tl_) == 8) W1_C(2, 1, grp_, base_);                                                                                \
-        if ((tl_) == 9) W1_C(3, 1, grp_, base_);                                                                                \
-        if ((tl_) == 11) W1_C(0, 2, grp_, base_);                                                                               \
-        if ((tl_) == 12) W1_C(1, 2, grp_, base_);                                                                               \
-        if ((tl_) == 13) W1_C(2, 2, grp_, base_);                                                                               \
-        if ((tl_) == 14) W1_C(3, 2, grp_, base_);                                                                               \
-        if ((tl_) == 16) W1_C(0, 3, grp_, base_);                                                                               \
-        if ((tl_) == 17) W1_C(1, 3, grp_, base_);                                                                               \
-        if ((tl_) == 18) W1_C(2, 3, grp_, base_);                                                                               \
-        if ((tl_) == 19) W1_C(3, 3, grp_, base_);                                                                               \
-        if ((tl_) == 0) W1_L(0, qmin_, nrows_);                                                                                 \
-        if ((tl_) == 4) W1_L(1, qmin_, nrows_);                                                                                 \
-        if ((tl_) == 9) W1_L(2, qmin_, nrows_);                                                                                 \
-        if ((tl_) == 14) W1_L(3, qmin_, nrows_);                                                                                \
-    } while (0)
-
-    const __amdgpu_buffer_rsrc_t wrs = make_rsrc(wp, (uint32_t)(40 * G::BV * 16));
-    const int boff = (h * CO + n * 32 + j) * 16;
-    const int co = n * 32 + j;
-    const float bz = bias[co];
-    int qmin, nrows;
-    wino_pass_rows<G, S>(pass, total_tiles, qmin, nrows);
-#pragma unroll
-    for (int it = 0; it < ((DBG & 1) ? 0 : G::NIT); ++it) {                                // first pass: position group 0
-        W1_L(it, qmin, nrows);
-#pragma unroll
-        for (int st = 0; st < 4; ++st) W1_C(st, it, 0, ldsb);
-    }
-    __syncthreads();
-    // tap tau of a pass (0..39): group g = tau / 20, kernel row ky = (tau % 20) / 4, position p = {0,1,2,7} | {3,4,5,6} [tau % 4]
-#define W1_POS(tau_) (((tau_) / 20) == 0 ? ((tau_) % 4 == 3 ? 7 : (tau_) % 4) : 3 + (tau_) % 4)
-#define W1_BOFF(tau_) (((((tau_) % 20) / 4) * 8 + W1_POS(tau_)) * G::BV * 16)
-    constexpr int BD = 3;
-    uint4 bq[4][2];
-#pragma unroll
-    for (int t = 0; t < BD; ++t) { bq[t][0] = buf_load16(wrs, boff, W1_BOFF(t)); bq[t][1] = buf_load16(wrs, boff, W1_BOFF(t) + 2 * CO * 16); }
-    for (;;) {
-        int aoff[TPW][5];
-        const int T0 = pass * G::MB + mg * TPW * 32;
-#pragma unroll
-        for (int m = 0; m < TPW; ++m) {
-            int T = T0 + m * 32 + j;
-            if (T > total_tiles - 1) T = total_tiles - 1;
-            const int gp = T / G::TPP, r2 = T - gp * G::TPP;
-            const int tx = r2 >> 1, qo = 2 * gp + (r2 & 1), y = qo % S;
-#pragma unroll
-            for (int ky = 0; ky < 5; ++ky) {
-                const int iy = y + ky - 2;
-                aoff[m][ky] = ((iy >= 0 && iy < S) ? (qo + ky - 2 - qmin + 1) * G::RP : 0) + tx * G::TSB + h * 16;
-            }
-        }
-        f32x16 acc[TPW][8];
-        const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        if (tid == 0) s_next_pass = (int)atomicAdd(pass_ctr, 1u) + (int)gridDim.x;   // read after the first unit's barrier
-        int next_pass = 0, qmin_n = qmin, nrows_n = nrows;
-        bool have_next = false;
-#pragma unroll
-        for (int g = 0; g < 2; ++g) {
-            if (g == 1) {
-                next_pass = s_next_pass;
-                have_next = next_pass < n_pass;
-                if (have_next) wino_pass_rows<G, S>(next_pass, total_tiles, qmin_n, nrows_n);
-            }
-            const uint8_t* pbase = ldsb + g * G::BUF;                     // group g lives in buffer g
-            uint8_t* nbase = ldsb + (g ^ 1) * G::BUF;
-            const int sqmin = g == 0 ? qmin : qmin_n, snrows = g == 0 ? nrows : nrows_n;   // staged under group 0: this pass's group 1; under group 1: the next pass's group 0
-            uint4 af[2][TPW][2];
-#pragma unroll
-            for (int m = 0; m < TPW; ++m) {
-                af[0][m][0] = *reinterpret_cast<const uint4*>(pbase + aoff[m][0]);
-                af[0][m][1] = *reinterpret_cast<const uint4*>(pbase + aoff[m][0] + G::PLANE);
-            }
-#pragma clang loop unroll(full)
-            for (int tl = 0; tl < 20; ++tl) {
-                const int tau = g * 20 + tl;
-                const int cur = tl & 1, nxt = cur ^ 1;
-                if (!(DBG & 8) && tl + 1 < 20) {
-                    const uint8_t* an = pbase + ((tl + 1) % 4) * G::PS;
-#pragma unroll
-                    for (int m = 0; m < TPW; ++m) {
-                        af[nxt][m][0] = *reinterpret_cast<const uint4*>(an + aoff[m][(tl + 1) / 4]);
-                        af[nxt][m][1] = *reinterpret_cast<const uint4*>(an + aoff[m][(tl + 1) / 4] + G::PLANE);
-                    }
-                }
-                if (!(DBG & 4)) {
-                    const int wt = W1_BOFF((tau + BD) % 40);
-                    bq[(tau + BD) % 4][0] = buf_load16(wrs, boff, wt);
-                    bq[(tau + BD) % 4][1] = buf_load16(wrs, boff, wt + 2 * CO * 16);
-                }
-                if (!(DBG & 1)) W1_SLOT(tl, g ^ 1, sqmin, snrows, nbase);
-                const int p = W1_POS(tau);
-                const f16x8 b1 = __builtin_bit_cast(f16x8, bq[tau % 4][0]);
-                const f16x8 b2 = __builtin_bit_cast(f16x8, bq[tau % 4][1]);
-                const f16x8 a10 = __builtin_bit_cast(f16x8, af[cur][0][0]), a20 = __builtin_bit_cast(f16x8, af[cur][0][1]);
-                const f16x8 a11 = __builtin_bit_cast(f16x8, af[cur][1][0]), a21 = __builtin_bit_cast(f16x8, af[cur][1][1]);
-                acc[0][p] = mfma16(a20, b1, tl < 4 ? zero16 : acc[0][p]);      // kernel row 0 starts the accumulator
-                acc[1][p] = mfma16(a21, b1, tl < 4 ? zero16 : acc[1][p]);
-                acc[0][p] = mfma16(a10, b2, acc[0][p]);
-                acc[1][p] = mfma16(a11, b2, acc[1][p]);
-                acc[0][p] = mfma16(a10, b1, acc[0][p]);
-                acc[1][p] = mfma16(a11, b1, acc[1][p]);
-                __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
-                __builtin_amdgcn_sched_group_barrier(0x020, 10, 0);
-#pragma unroll
-                for (int gg = 0; gg < 6; ++gg) {
-                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x206, 8, 0);
-                }
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            __syncthreads();
-        }
-        if (DBG & 2) {
-#pragma unroll
-            for (int m = 0; m < TPW; ++m)
-#pragma unroll
-                for (int p = 0; p < 8; ++p) asm volatile("" :: "a"(acc[m][p]));
-        }
-#pragma unroll
-        for (int m = 0; m < ((DBG & 2) ? 0 : TPW); ++m) {
-            f32x16 y0, y1, y2, y3;
-            {
-                const f32x16 e1 = acc[m][1] + acc[m][2], o1 = acc[m][1] - acc[m][2];
-                y0 = acc[m][0] + e1; y1 = o1; y2 = e1; y3 = o1 + acc[m][7];
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            {
-                const f32x16 e2 = acc[m][3] + acc[m][4], o2 = acc[m][3] - acc[m][4];
-                y0 += e2; y1 += 2.f * o2; y2 += 4.f * e2; y3 += 8.f * o2;
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            {
-                const f32x16 e3 = acc[m][5] + acc[m][6], o3 = acc[m][5] - acc[m][6];
-                y0 += e3; y1 += 0.5f * o3; y2 += 0.25f * e3; y3 += 0.125f * o3;
-            }
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int rr = 0; rr < 8; ++rr) {
-                const int r = 2 * rr;
-                const int i = (r & 3) + 8 * (r >> 2) + 4 * h;
-                const int T = T0 + m * 32 + i;
-                const float v0 = fmaxf(fmaxf(y0[r], y1[r]), fmaxf(y0[r + 1], y1[r + 1]));
-                const float v1 = fmaxf(fmaxf(y2[r], y3[r]), fmaxf(y2[r + 1], y3[r + 1]));
-                if (T < total_tiles) {
-                    const int gp = T / G::TPP, tx = (T - gp * G::TPP) >> 1;
-                    float* o = out + ((size_t)gp * (S / 2) + 2 * tx) * CO + co;
-                    __builtin_nontemporal_store(fmaxf(v0 * out_scale + bz, 0.f), o);
-                    __builtin_nontemporal_store(fmaxf(v1 * out_scale + bz, 0.f), o + CO);
-                }
-            }
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        if (!have_next) break;
-        pass = next_pass; qmin = qmin_n; nrows = nrows_n;
-    }
-#undef W1_L
-#undef W1_T
-#undef W1_S
-#undef W1_C
-#undef W1_SLOT
-#undef W1_POS
-#undef W1_BOFF
-    if (__any(!(mxabs < 4368.0f)) && lane == 0) atomicOr(overflow, 1u);
-}
-
 #include "cnn_wpre.h"
 
 static constexpr int FC1_KSPLIT = 10;     // 12800 = 10 x 1280: 500 workgroups at 6400 crops (5: 129 us, 10: 92 us, 20: 102 us + slower head); partial planes summed in k_head
@@ -1958,20 +1673,8 @@ static int net_forward_launch(trexhip_ctx* ctx, const uint8_t* d_crops, int n, f
 #undef W3AB
 #undef W2BA
 #undef W2BAS
-#define W1A(D_) TH_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv5_wino1<64, 40, D_>), hipFuncAttributeMaxDynamicSharedMemorySize, (WinoGeom1<64, 40>::LDS_BYTES)))
-        W1A(0);
-#ifdef TREXHIP_DEV_KNOBS
-        W1A(1); W1A(2); W1A(3); W1A(7); W1A(15); W1A(4); W1A(8);
-#endif
-#undef W1A
 #define WA(D_) TH_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv5_wino<64, 128, 20, 2, D_>), hipFuncAttributeMaxDynamicSharedMemorySize, (WinoGeom<64, 128, 20, 2>::LDS_BYTES)))
         WA(0);
-#define WA1(D_) TH_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv5_wino<64, 128, 20, 1, D_>), hipFuncAttributeMaxDynamicSharedMemorySize, (WinoGeom<64, 128, 20, 1>::LDS_BYTES)))
-        WA1(0);
-#ifdef TREXHIP_DEV_KNOBS
-        WA1(1); WA1(2); WA1(3); WA1(4); WA1(7); WA1(15);
-#endif
-#undef WA1
 #ifdef TREXHIP_DEV_KNOBS
         WA(1); WA(2); WA(3); WA(4); WA(7); WA(8); WA(15); WA(12); WA(16);
 #endif
@@ -2032,24 +1735,6 @@ static int net_forward_launch(trexhip_ctx* ctx, const uint8_t* d_crops, int n, f
         hipLaunchKernelGGL((k_conv5<16, 64, 40, 20, 16>), dim3(n * G2::BPC), dim3(512), G2::LDS_BYTES, s, net->act1, net->w2, net->b2, net->act2);
     else if (mode == TREXHIP_CNN_BF16X6) LAUNCH_SPLIT(16, 64, 40, 10, 0, 6, net->act1, net->w2s, net->b2, net->act2, 1.0f, (const uint32_t*)nullptr);
     else if (mode == TREXHIP_CNN_BF16X3) LAUNCH_SPLIT(16, 64, 40, 10, 0, 3, net->act1, net->w2s, net->b2, net->act2, 1.0f, (const uint32_t*)nullptr);
-    else if (ctx->tune_conv_geom & 512) {
-        // Winograd F(4,5) along x for conv2 too: correct (same parity tests) but NOT faster than the direct kernel below on this layer
-        // (4.9 vs 4.6 ms per 25600 crops: with 16 input channels and 64 outputs the input transform + fp16 split per staged value and the
-        // output transform per pass are not amortised by enough matrix work), so it stays opt-in (TREXHIP_CONV_GEOM bit 9); the persistent pass counter is d_ovf[2]
-        using GW = WinoGeom1<64, 40>;
-        const int n_pass = (n * GW::TPC + GW::MB - 1) / GW::MB;
-#define W1K(D_) hipLaunchKernelGGL((k_conv5_wino1<64, 40, D_>), dim3(n_pass < ctx->n_cus ? n_pass : ctx->n_cus), dim3(256), GW::LDS_BYTES, s, \
-                           net->act1, net->w2w, net->b2, net->act2, net->inv2w, net->d_ovf, n, net->d_ovf + 2)
-#ifdef TREXHIP_DEV_KNOBS
-        switch ((ctx->tune_conv_geom >> 12) & 15) {
-            case 1: W1K(1); break; case 2: W1K(2); break; case 3: W1K(3); break; case 7: W1K(7); break; case 15: W1K(15); break;
-            case 4: W1K(4); break; case 8: W1K(8); break; default: W1K(0);
-        }
-#else
-        W1K(0);
-#endif
-#undef W1K
-    }
     else if (!(ctx->tune_conv_geom & (4 | 64)))   // 8 output rows per workgroup: 320 pixels = exactly 10 M-tiles, 3 workgroups per CU (1.15 ms; 10 rows: 1.31 ms)
         hipLaunchKernelGGL((k_conv5_stream<16, 64, 40, 8, 4>), dim3(n * (ConvGeomS<16, 64, 40, 8, 4>::BPC)), dim3(256),
                            (ConvGeomS<16, 64, 40, 8, 4>::LDS_BYTES), s, net->act1, net->w2h, net->b2, net->act2, net->inv2h, net->d_ovf, n * (ConvGeomS<16, 64, 40, 8, 4>::BPC), (uint32_t*)nullptr);
@@ -2078,19 +1763,6 @@ static int net_forward_launch(trexhip_ctx* ctx, const uint8_t* d_crops, int n, f
         hipLaunchKernelGGL((k_conv5<64, 128, 20, 20, 32>), dim3(n * G3::BPC), dim3(512), G3::LDS_BYTES, s, net->act2, net->w3, net->b3, net->act3);
     else if (mode == TREXHIP_CNN_BF16X6) LAUNCH_SPLIT(64, 128, 20, 20, 0, 6, net->act2, net->w3s, net->b3, net->act3, 1.0f, (const uint32_t*)nullptr);
     else if (mode == TREXHIP_CNN_BF16X3) LAUNCH_SPLIT(64, 128, 20, 20, 0, 3, net->act2, net->w3s, net->b3, net->act3, 1.0f, (const uint32_t*)nullptr);
-    else if (!(ctx->tune_conv_geom & 256) && (ctx->tune_conv_geom & 1024)) {
-        // one M-tile per wave (128 accumulator registers), two workgroups per CU: TREXHIP_CONV_GEOM bit 10
-        using GW1 = WinoGeom<64, 128, 20, 1>;
-        const int n_pass = (n * GW1::TPC + GW1::MB - 1) / GW1::MB;
-#define WL1(D_) hipLaunchKernelGGL((k_conv5_wino<64, 128, 20, 1, D_>), dim3(n_pass < 2 * ctx->n_cus ? n_pass : 2 * ctx->n_cus), dim3(GW1::NTHR), GW1::LDS_BYTES, s, \
-                           net->act2, net->w3w, net->b3, net->act3, net->inv3w, net->d_ovf, n, net->d_ovf + 1)
-#ifdef TREXHIP_DEV_KNOBS
-        switch ((ctx->tune_conv_geom >> 12) & 15) { case 1: WL1(1); break; case 2: WL1(2); break; case 3: WL1(3); break; case 4: WL1(4); break; case 7: WL1(7); break; case 15: WL1(15); break; default: WL1(0); }
-#else
-        WL1(0);
-#endif
-#undef WL1
-    }
     else if (!(ctx->tune_conv_geom & 256)) {
         // Winograd F(4,5) along x: 0.4x the matrix work of the direct form (TREXHIP_CONV_GEOM bit 8: the direct kernels below)
         using GW = WinoGeom<64, 128, 20, 2>;
