@@ -166,6 +166,36 @@ def test_ragged_batches_and_class_counts_equal_oracle(n, classes, ch, precision)
     seg.close()
 
 
+@pytest.mark.parametrize("precision", [0, 1])
+@pytest.mark.parametrize("s2,s3", [(1e3, 1e-3), (1e-4, 3e2)])
+def test_split_arithmetic_follows_the_operands_ranges(s2, s3, precision):
+    # precision 0 scales every staged patch and each layer's weights by a power of two before splitting them into fp16 pieces.  Convolution
+    # weights (and the running statistics behind them) 1000 times larger / smaller move the operands of conv2 / conv3 across the fp16 range;
+    # the forward pass is continuous in its operands (no arg-max to flip), so the loss must follow the restatement as closely as unscaled
+    classes, ch, n = 10, 1, 40
+    state = dict(weights.synthetic_state(classes, 71, channels=ch))
+    rng = np.random.default_rng(71)
+    for k in ("bn1", "bn2", "bn3"):
+        state[k + ".running_mean"] = rng.uniform(-0.5, 0.5, state[k + ".running_mean"].shape).astype(np.float32)
+        state[k + ".running_var"] = rng.uniform(0.5, 2.0, state[k + ".running_var"].shape).astype(np.float32)
+    for k, sc in (("2", s2), ("3", s3)):
+        state[f"conv{k}.weight"] = (state[f"conv{k}.weight"] * np.float32(sc)).astype(np.float32)
+        state[f"conv{k}.bias"] = (state[f"conv{k}.bias"] * np.float32(sc)).astype(np.float32)
+        state[f"bn{k}.running_mean"] = (state[f"bn{k}.running_mean"] * np.float32(sc)).astype(np.float32)
+        state[f"bn{k}.running_var"] = (state[f"bn{k}.running_var"] * np.float32(sc) ** 2).astype(np.float32)
+    x, y = weights.synthetic_train_batch(n, 72, classes, ch)
+    x = np.round(x)
+    logits = cnn_oracle.forward_logits(state, x.astype(np.uint8), threads=16)
+    z = logits - logits.max(1, keepdims=True)
+    loss_ref = float(np.mean(np.log(np.exp(z.astype(np.float64)).sum(1)) - z[np.arange(n), y]))
+    seg = make_seg()
+    tr = capi.Trainer(seg, weights.pack_blob(state, classes, ch), max_batch=64, lr=1e-3, precision=precision)
+    loss, correct = tr.evaluate(x, y)
+    assert abs(loss - loss_ref) <= 5e-5 * max(1.0, abs(loss_ref)), (loss, loss_ref)
+    assert correct == int((logits.argmax(1) == y).sum())
+    tr.close(); seg.close()
+
+
 def test_eval_mode_loss_equals_the_eval_restatement():
     # validation batches: model.eval() -> running statistics, no dropout; loss = CrossEntropyLoss(logits, targets) (train() :1171-1190)
     classes, ch, n = 100, 1, 77

@@ -18,7 +18,10 @@ for case in range(n_cases):
     ch = int(rng.choice([1, 3]))
     lr = float(rng.choice([1e-4, 1e-3, 1e-2]))
     seed = int(rng.integers(1, 1 << 30))
-    state = weights.synthetic_state(classes, seed, channels=ch)
+    state = dict(weights.synthetic_state(classes, seed, channels=ch))
+    if rng.random() < 0.3:      # convolution weights far from their usual range: the operand scales of the fp16 two-piece arithmetic
+        for k in ("conv2.weight", "conv3.weight"):
+            state[k] = (state[k] * np.float32(10.0 ** rng.uniform(-3, 3))).astype(np.float32)
     adam = tro.new_adam_state(state)
     tr = capi.Trainer(seg, weights.pack_blob(state, classes, ch), max_batch=n, lr=lr, precision=case % 2)   # both arithmetics of the conv2 / conv3 convolutions
     try:
