@@ -407,9 +407,9 @@ def train_step_bench(dev, n=128, classes=100, steps=20, precision=0):
     seg.close()
     # forward 3 convolutions + fc (MAC per sample) x 3 (forward, data gradient, weight gradient; conv1 has no data gradient)
     gflop = 2 * n * (2.56e6 * 2 + 40.96e6 * 3 + 81.92e6 * 3 + 1.28e6 * 3) / 1e9
-    dtype = ("f32; conv2 / conv3 forward and data gradients: fp16x3-split (2 fp16 pieces per operand = 22 mantissa bits, 3 MFMA products, fp32 accumulate, "
+    dtype = ("f32; conv2 / conv3 forward, data and weight gradients: fp16x3-split (2 fp16 pieces per operand = 22 mantissa bits, 3 MFMA products, fp32 accumulate, "
              "power-of-two scales per staged patch and per layer)") if precision == 0 else "f32 (exact fp32 MFMA)"
-    kern = ("the whole step (k_t_conv5_h2 forward / data gradients on the 16-bit matrix cores, k_t_wgrad* on fp32 MFMA, batch-norm / pool / head kernels, k_t_adam)"
+    kern = ("the whole step (k_t_conv5_h2 forward / data gradients and k_t_wgrad_h2 weight gradients on the 16-bit matrix cores, batch-norm / pool / head kernels, k_t_adam)"
             if precision == 0 else "the whole step (k_conv5<RAW> forward / data gradients, k_t_wgrad*, batch-norm / pool / head kernels, k_t_adam)")
     return {"metric": "training step of the identity network (V118_3: forward, cross entropy, backward, Adam)", "value": n / dt, "unit": "samples/s",
             "ms_per_step": dt * 1e3, "steps": steps, "config": {"workload": f"{n} samples of 80x80x1, {classes} classes, dropout 0.05, library-drawn masks",
@@ -417,7 +417,7 @@ def train_step_bench(dev, n=128, classes=100, steps=20, precision=0):
             "dtype": dtype,
             "roofline": {"kernel": kern, "bound": "mfma",
                          "achieved": gflop / dt / 1e3, "peak": 157.3, "unit": "TFLOP/s", "frac": gflop / dt / 1e3 / 157.3, "traffic": None,
-                         "peak_note": "algorithmic flops of the step against the fp32 matrix peak (the yardstick of rounds 2-3); with precision 0 about 40 % of "
+                         "peak_note": "algorithmic flops of the step against the fp32 matrix peak (the yardstick of rounds 2-3); with precision 0 about 95 % of "
                                       "those flops run on the 16-bit matrix cores (peak 2500), whose three products per term are not counted",
                          "algorithmic_gflop_per_step": gflop}}
 

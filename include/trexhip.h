@@ -459,7 +459,7 @@ typedef struct {
     float beta1, beta2, eps;    /* torch.optim.Adam defaults 0.9, 0.999, 1e-8                                                */
     float bn_momentum;          /* nn.BatchNorm2d default 0.1                                                                */
     float dropout;              /* 0.05 for all four dropout layers (visual_identification_network_torch.py:189-208)         */
-    int32_t precision;          /* arithmetic of the conv2 / conv3 forward and data-gradient convolutions: 0 = fp16 two-piece split on the
+    int32_t precision;          /* arithmetic of the conv2 / conv3 forward, data-gradient and weight-gradient convolutions: 0 = fp16 two-piece split on the
                                    16-bit matrix cores (22-bit operands, fp32 accumulate, per-tensor power-of-two scales: the inference
                                    path's arithmetic), 1 = exact fp32 MFMA.  Everything else is fp32 either way                     */
     uint64_t seed;              /* of the library's own dropout masks                                                        */

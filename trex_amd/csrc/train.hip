@@ -907,6 +907,171 @@ __global__ __launch_bounds__(512) void k_t_wgrad(const float* __restrict__ a /*[
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// the same weight gradients in the fp16 two-piece split arithmetic (precision 0): v_mfma_f32_32x32x16_f16 contracts SIXTEEN pixels per step
+// (three products per term), a fifth of the fp32-MFMA time -- the kernel is then bound by staging, so a workgroup stages a unit once for
+// ALL 25 taps:
+//   * block = a slice of CIS input channels x a slice of 64 output channels x a share of the units (unit = ROWS output rows of a crop);
+//     10 waves = 5 kernel rows x 2 output-channel tiles, a wave holds the 5 kx tiles (conv2: 80 rows = 5 kx x 16 channels in 3 tiles) of
+//     its kernel row and walks over ALL pixel segments of the unit: no sum across waves;
+//   * operands: a [ROWS + 4 rows][x + 2 .. halo][CIS] and dz [ROWS][x (padded to 8)][64] as two fp16 planes each, [pixel][channel] as they lie
+//     in memory; the MFMA wants 8 consecutive PIXELS per lane for one channel -- ds_read_b64_tr_b16 delivers exactly that transpose (a
+//     16-lane group reads 4 pixels x 16 channels; lane l supplies pixel l / 4, channels 4 (l % 4) .. and receives channel l of the 4 pixels);
+//     a K step = two 8-pixel segments (lanes 0..31 / 32..63), shifted by kx - 2 along x for the A operand (zero halo columns), rows
+//     outside the crop are zero rows;
+//   * fp16 range: a unit's activations and gradients are scaled by powers of two from their largest |value| (kept while that stays inside
+//     [2^10, 2^15)); a change rescales the accumulators (exact).
+// ------------------------------------------------------------------------------------------------
+typedef __fp16 fh4 __attribute__((__vector_size__(4 * sizeof(__fp16))));
+__device__ __forceinline__ h16x8 tr_frag(const uint8_t* p, const int second_off) {
+    struct { fh4 lo, hi; } v;
+    v.lo = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fh4*)(p));
+    v.hi = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fh4*)(p + second_off));
+    return __builtin_bit_cast(h16x8, v);
+}
+
+template <int CI, int CO, int S, int CIS, int ROWS>
+struct WgradHGeom {
+    static constexpr int COS = 64, NT = 2, MT = (5 * CIS + 31) / 32, WAVES = 10, NTHR = WAVES * 64;
+    static constexpr int SEGS = (S + 7) / 8, DW = SEGS * 8, PW = DW + 4, AR = ROWS + 4;
+    static constexpr int A_BYTES = AR * PW * CIS * 2, DZ_BYTES = ROWS * DW * COS * 2;          // per piece
+    static constexpr int LDS_BYTES = 2 * A_BYTES + 2 * DZ_BYTES;
+    static constexpr int NSEG = ROWS * SEGS;
+    static constexpr int NCS = CI / CIS, NOS = CO / COS, TYPES = NCS * NOS, NB = S / ROWS;
+    static constexpr int NA4 = AR * S * CIS / 4, ND4 = ROWS * S * COS / 4, NLA = (NA4 + NTHR - 1) / NTHR, NLD = (ND4 + NTHR - 1) / NTHR;
+    static_assert(NSEG % 2 == 0 && S % ROWS == 0 && CI % CIS == 0 && CO % COS == 0 && CIS % 16 == 0 && LDS_BYTES % 16 == 0 && LDS_BYTES <= 160 * 1024, "shapes");
+};
+
+template <int CI, int CO, int S, int CIS, int ROWS>
+__global__ __launch_bounds__(640) void k_t_wgrad_h2(const float* __restrict__ a /*[n][S][S][CI]*/, const float* __restrict__ dz /*[n][S][S][CO]*/,
+                                                    float* __restrict__ part, int n) {
+    using G = WgradHGeom<CI, CO, S, CIS, ROWS>;
+    constexpr int COS = G::COS, MT = G::MT, PW = G::PW, DW = G::DW, SEGS = G::SEGS;
+    extern __shared__ __attribute__((aligned(16))) uint8_t wh_lds[];
+    __shared__ float s_red[G::WAVES][2];
+    uint8_t* const ap = wh_lds;                                          // two pieces, A_BYTES apart
+    uint8_t* const dp = wh_lds + 2 * G::A_BYTES;                         // two pieces, DZ_BYTES apart
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int j = lane & 31, h = lane >> 5, g16 = (lane >> 4) & 1, l16 = lane & 15;
+    const int ky = wave % 5, ntw = wave / 5;
+    const int cs = blockIdx.x / G::NOS, os = blockIdx.x % G::NOS;
+    const int share = blockIdx.y, shares = gridDim.y, units = n * G::NB;
+    for (int i = tid; i < G::LDS_BYTES / 16; i += G::NTHR) reinterpret_cast<uint4*>(wh_lds)[i] = make_uint4(0, 0, 0, 0);   // halo and pad columns stay zero
+    // lane constants of the transposing reads: tile i = rows i * 32 + 16 g16 + (l16): kernel column kx = row / CIS, channel = row % CIS
+    int a_lane[MT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+        const int m0 = i * 32 + 16 * g16;
+        int kx = m0 / CIS;
+        kx = kx < 5 ? kx : 4;                                            // rows past the fifth tap are never written out
+        a_lane[i] = (((l16 >> 2) + kx) * CIS + m0 % CIS + 4 * (l16 & 3)) * 2;
+    }
+    const int d_lane = ((l16 >> 2) * COS + ntw * 32 + 16 * g16 + 4 * (l16 & 3)) * 2;
+    f32x16 acc[MT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+    float sa = 1.f, sd = 1.f;                                            // scales of the unit staged last
+    for (int u = share; u < units; u += shares) {
+        const int crop = u / G::NB, y0 = (u % G::NB) * ROWS;
+        const float* asrc = a + (size_t)crop * S * S * CI + cs * CIS;
+        const float* dsrc = dz + ((size_t)crop * S * S + (size_t)y0 * S) * CO + os * COS;
+        float4 va[G::NLA], vd[G::NLD];
+        float ma = 0.f, md = 0.f;
+#pragma unroll
+        for (int k = 0; k < G::NLA; ++k) {
+            const int idx = tid + k * G::NTHR;
+            va[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (idx < G::NA4) {
+                const int c4 = idx % (CIS / 4), x = (idx / (CIS / 4)) % S, ar = idx / (CIS / 4 * S);
+                const int y = y0 - 2 + ar;
+                if (y >= 0 && y < S) va[k] = *reinterpret_cast<const float4*>(asrc + ((size_t)y * S + x) * CI + c4 * 4);
+                ma = fmaxf(ma, fmaxf(fmaxf(fabsf(va[k].x), fabsf(va[k].y)), fmaxf(fabsf(va[k].z), fabsf(va[k].w))));
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < G::NLD; ++k) {
+            const int idx = tid + k * G::NTHR;
+            vd[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (idx < G::ND4) {
+                const int c4 = idx % (COS / 4), px = idx / (COS / 4);
+                vd[k] = *reinterpret_cast<const float4*>(dsrc + (size_t)px * CO + c4 * 4);
+                md = fmaxf(md, fmaxf(fmaxf(fabsf(vd[k].x), fabsf(vd[k].y)), fmaxf(fabsf(vd[k].z), fabsf(vd[k].w))));
+            }
+        }
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) { ma = fmaxf(ma, __shfl_xor(ma, d)); md = fmaxf(md, __shfl_xor(md, d)); }
+        __syncthreads();                                                 // the previous unit's readers are done (and s_red is free)
+        if (lane == 0) { s_red[wave][0] = ma; s_red[wave][1] = md; }
+        __syncthreads();
+        ma = s_red[0][0]; md = s_red[0][1];
+#pragma unroll
+        for (int w = 1; w < G::WAVES; ++w) { ma = fmaxf(ma, s_red[w][0]); md = fmaxf(md, s_red[w][1]); }
+        // keep a scale while the unit's largest value stays inside [2^10, 2^15) with it: few rescalings of the accumulators
+        float na = sa, nd = sd;
+        if (!(ma * sa >= 1024.f && ma * sa < 32768.f) && ma > 0.f) na = pow2_scale_for(__float_as_uint(ma), 13);
+        if (!(md * sd >= 1024.f && md * sd < 32768.f) && md > 0.f) nd = pow2_scale_for(__float_as_uint(md), 13);
+        if (na != sa || nd != sd) {
+            const float f = (na / sa) * (nd / sd);
+#pragma unroll
+            for (int i = 0; i < MT; ++i) acc[i] *= f;
+            sa = na; sd = nd;
+        }
+#pragma unroll
+        for (int k = 0; k < G::NLA; ++k) {
+            const int idx = tid + k * G::NTHR;
+            if (idx < G::NA4) {
+                const int c4 = idx % (CIS / 4), x = (idx / (CIS / 4)) % S, ar = idx / (CIS / 4 * S);
+                uint32_t p1[4], p2[4];
+                split2h_t(va[k].x * sa, p1[0], p2[0]); split2h_t(va[k].y * sa, p1[1], p2[1]);
+                split2h_t(va[k].z * sa, p1[2], p2[2]); split2h_t(va[k].w * sa, p1[3], p2[3]);
+                uint8_t* d = ap + ((ar * PW + x + 2) * CIS + c4 * 4) * 2;
+                *reinterpret_cast<uint2*>(d) = make_uint2(p1[0] | (p1[1] << 16), p1[2] | (p1[3] << 16));
+                *reinterpret_cast<uint2*>(d + G::A_BYTES) = make_uint2(p2[0] | (p2[1] << 16), p2[2] | (p2[3] << 16));
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < G::NLD; ++k) {
+            const int idx = tid + k * G::NTHR;
+            if (idx < G::ND4) {
+                const int c4 = idx % (COS / 4), px = idx / (COS / 4), x = px % S, r = px / S;
+                uint32_t p1[4], p2[4];
+                split2h_t(vd[k].x * sd, p1[0], p2[0]); split2h_t(vd[k].y * sd, p1[1], p2[1]);
+                split2h_t(vd[k].z * sd, p1[2], p2[2]); split2h_t(vd[k].w * sd, p1[3], p2[3]);
+                uint8_t* d = dp + ((r * DW + x) * COS + c4 * 4) * 2;
+                *reinterpret_cast<uint2*>(d) = make_uint2(p1[0] | (p1[1] << 16), p1[2] | (p1[3] << 16));
+                *reinterpret_cast<uint2*>(d + G::DZ_BYTES) = make_uint2(p2[0] | (p2[1] << 16), p2[2] | (p2[3] << 16));
+            }
+        }
+        __syncthreads();
+        for (int p = 0; p < G::NSEG / 2; ++p) {
+            const int sg = 2 * p + h, r = sg / SEGS, x0 = 8 * (sg - r * SEGS);
+            const uint8_t* dseg = dp + (r * DW + x0) * COS * 2 + d_lane;
+            const uint8_t* aseg = ap + ((r + ky) * PW + x0) * CIS * 2;
+            const h16x8 b1 = tr_frag(dseg, 4 * COS * 2), b2 = tr_frag(dseg + G::DZ_BYTES, 4 * COS * 2);
+#pragma unroll
+            for (int i = 0; i < MT; ++i) {
+                const h16x8 a1 = tr_frag(aseg + a_lane[i], 4 * CIS * 2), a2 = tr_frag(aseg + a_lane[i] + G::A_BYTES, 4 * CIS * 2);
+                acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a2, b1, acc[i], 0, 0, 0);
+                acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b2, acc[i], 0, 0, 0);
+                acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b1, acc[i], 0, 0, 0);
+            }
+        }
+    }
+    const float inv = 1.0f / (sa * sd);
+    const int co = os * COS + ntw * 32 + j;
+    float* pp = part + (size_t)share * 25 * CI * CO;
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = i * 32 + 8 * (r / 4) + 4 * h + (r % 4);            // accumulator r of lane (j, h) is row 8 (r / 4) + 4 h + r % 4
+            const int kx = m / CIS, c = cs * CIS + m % CIS;
+            if (kx < 5) pp[((size_t)(ky * 5 + kx) * CI + c) * CO + co] = acc[i][r] * inv;
+        }
+}
+
 // sum of the partials in order -> gradient in the parameter layout [ci / CIC][tap][ci % CIC][co]
 __global__ __launch_bounds__(256) void k_t_wgrad_reduce(const float* __restrict__ part, int nparts, int CI, int CO, int CIC, float* __restrict__ g) {
     const int idx = blockIdx.x * 256 + threadIdx.x;
@@ -1087,6 +1252,9 @@ struct Trainer {
 static constexpr int RED_BLOCKS = 256;
 using WG3 = WgradGeom<64, 128, 20, 32, 64, 5, 10>;   // conv3: block type = kernel row x 32-channel half x 64-channel half (20 types), unit = 10 rows of a crop
 using WG2 = WgradGeom<16, 64, 40, 16, 64, 3, 5>;     // conv2: block type = kernel row (5 types), unit = 5 rows of a crop
+using WH3 = WgradHGeom<64, 128, 20, 32, 10>;        // precision 0: conv3 4 block types x 64 shares, conv2 1 x 256
+using WH2 = WgradHGeom<16, 64, 40, 16, 10>;
+static constexpr int SHARES3H = 64, SHARES2H = 256;
 static constexpr int SHARES3 = 12, SHARES2 = 51;     // 20 x 12 = 240 and 5 x 51 = 255 workgroups: one round on 256 CUs
 
 static size_t tensor_count(int t, int classes, int CH) {
@@ -1249,6 +1417,8 @@ static int trainer_attrs(Trainer* t) {
     TH_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_t_conv5_h2<64, 32, 40, 20, 16, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, H2B::LDS_BYTES));
     TH_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_t_wgrad<64, 128, 20, 32, 64, 5, 10>), hipFuncAttributeMaxDynamicSharedMemorySize, WG3::LDS_BYTES));
     TH_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_t_wgrad<16, 64, 40, 16, 64, 3, 5>), hipFuncAttributeMaxDynamicSharedMemorySize, WG2::LDS_BYTES));
+    TH_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_t_wgrad_h2<64, 128, 20, 32, 10>), hipFuncAttributeMaxDynamicSharedMemorySize, WH3::LDS_BYTES));
+    TH_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_t_wgrad_h2<16, 64, 40, 16, 10>), hipFuncAttributeMaxDynamicSharedMemorySize, WH2::LDS_BYTES));
     t->attr = true;
     return TREXHIP_OK;
 }
@@ -1302,8 +1472,9 @@ static int trainer_step(Trainer* t, const float* x, const int32_t* targets, int 
     const bool h2 = t->p.precision == 0;
     bn_backward<128>(t, s, 2, t->da3, t->z3, n, 20, T_G3, T_BE3, T_C3B, k3, scale);
     {
-        const int shares = n * WG3::NB < SHARES3 ? n * WG3::NB : SHARES3;
-        hipLaunchKernelGGL((k_t_wgrad<64, 128, 20, 32, 64, 5, 10>), dim3(WG3::TYPES, shares), dim3(512), WG3::LDS_BYTES, s, t->a2, t->z3, t->part, n);
+        const int shares = h2 ? (n * WH3::NB < SHARES3H ? n * WH3::NB : SHARES3H) : (n * WG3::NB < SHARES3 ? n * WG3::NB : SHARES3);
+        if (h2) hipLaunchKernelGGL((k_t_wgrad_h2<64, 128, 20, 32, 10>), dim3(WH3::TYPES, shares), dim3(640), WH3::LDS_BYTES, s, t->a2, t->z3, t->part, n);
+        else hipLaunchKernelGGL((k_t_wgrad<64, 128, 20, 32, 64, 5, 10>), dim3(WG3::TYPES, shares), dim3(512), WG3::LDS_BYTES, s, t->a2, t->z3, t->part, n);
         hipLaunchKernelGGL(k_t_wgrad_reduce, dim3((25 * 64 * 128 + 255) / 256), dim3(256), 0, s, t->part, shares, 64, 128, 32, G + o[T_C3W]);
         if (h2) hipLaunchKernelGGL((k_t_conv5_h2<128, 64, 20, 10, 32, 64>), dim3(n * H3B::BPC), dim3(512), H3B::LDS_BYTES, s, t->z3, t->wh3b, (const float*)nullptr, t->da2, t->wh_scale + 1);
         else {
@@ -1314,8 +1485,9 @@ static int trainer_step(Trainer* t, const float* x, const int32_t* targets, int 
     // block 2
     bn_backward<64>(t, s, 1, t->da2, t->z2, n, 40, T_G2, T_BE2, T_C2B, k2, scale);
     {
-        const int shares = n * WG2::NB < SHARES2 ? n * WG2::NB : SHARES2;
-        hipLaunchKernelGGL((k_t_wgrad<16, 64, 40, 16, 64, 3, 5>), dim3(WG2::TYPES, shares), dim3(512), WG2::LDS_BYTES, s, t->a1, t->z2, t->part, n);
+        const int shares = h2 ? (n * WH2::NB < SHARES2H ? n * WH2::NB : SHARES2H) : (n * WG2::NB < SHARES2 ? n * WG2::NB : SHARES2);
+        if (h2) hipLaunchKernelGGL((k_t_wgrad_h2<16, 64, 40, 16, 10>), dim3(WH2::TYPES, shares), dim3(640), WH2::LDS_BYTES, s, t->a1, t->z2, t->part, n);
+        else hipLaunchKernelGGL((k_t_wgrad<16, 64, 40, 16, 64, 3, 5>), dim3(WG2::TYPES, shares), dim3(512), WG2::LDS_BYTES, s, t->a1, t->z2, t->part, n);
         hipLaunchKernelGGL(k_t_wgrad_reduce, dim3((25 * 16 * 64 + 255) / 256), dim3(256), 0, s, t->part, shares, 16, 64, 16, G + o[T_C2W]);
         if (h2) hipLaunchKernelGGL((k_t_conv5_h2<64, 32, 40, 20, 16, 16>), dim3(n * H2B::BPC), dim3(512), H2B::LDS_BYTES, s, t->z2, t->wh2b, (const float*)nullptr, t->da1, t->wh_scale);
         else {
@@ -1402,7 +1574,8 @@ int trexhip_trainer_create(trexhip_ctx* ctx, const void* blob, size_t bytes, con
     TRY(dev_alloc(t, &t->wh2f, (size_t)2 * 2 * 25 * 64)); TRY(dev_alloc(t, &t->wh2b, (size_t)2 * 8 * 25 * 32));
     TRY(dev_alloc(t, &t->wh3f, (size_t)2 * 8 * 25 * 128)); TRY(dev_alloc(t, &t->wh3b, (size_t)2 * 16 * 25 * 64));
     TRY(dev_alloc(t, &t->wh_scale, 2));
-    t->part_floats = std::max(std::max((size_t)SHARES3 * 25 * 64 * 128, (size_t)SHARES2 * 25 * 16 * 64), n * 10 * CH * 400);
+    t->part_floats = std::max(std::max(std::max((size_t)SHARES3 * 25 * 64 * 128, (size_t)SHARES2 * 25 * 16 * 64), std::max((size_t)SHARES3H * 25 * 64 * 128, (size_t)SHARES2H * 25 * 16 * 64)),
+                              n * 10 * CH * 400);
     TRY(dev_alloc(t, &t->part, t->part_floats));
     TRY(dev_alloc(t, &t->stat, (size_t)3 * 512));
     TRY(dev_alloc(t, &t->hpart, n * 100 * 100)); TRY(dev_alloc(t, &t->xhat, n * 100)); TRY(dev_alloc(t, &t->hd, n * 100));
