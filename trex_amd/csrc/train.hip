@@ -671,13 +671,17 @@ __global__ __launch_bounds__(512) void k_t_conv5_h2(const float* __restrict__ in
         }
         const uint4* wsrc = wp + (size_t)cc * 25 * BV;
         for (int i = tid; i < BV; i += 512) reinterpret_cast<uint4*>(Bs)[i] = wsrc[i];
+        // weight tiles travel L2 -> registers -> LDS two taps ahead of their use: a tile fetched at the start of tap t - 1 is stored at the end
+        // of tap t and read in tap t + 1 (one tap ahead, the fetch did not return within a tap's 0.4 us of MFMAs)
+        uint4 n1[BPT], n2[BPT];
+#pragma unroll
+        for (int u = 0; u < BPT; ++u) { const int i = tid + u * 512; n1[u] = make_uint4(0, 0, 0, 0); if (i < BV) n1[u] = wsrc[(size_t)BV + i]; }
         __syncthreads();
         for (int tap = 0; tap < 25; ++tap) {
             const int buf = tap & 1;
-            uint4 nb[BPT];
-            if (tap < 24) {
+            if (tap < 23) {
 #pragma unroll
-                for (int u = 0; u < BPT; ++u) { const int i = tid + u * 512; if (i < BV) nb[u] = wsrc[(size_t)(tap + 1) * BV + i]; }
+                for (int u = 0; u < BPT; ++u) { const int i = tid + u * 512; if (i < BV) n2[u] = wsrc[(size_t)(tap + 2) * BV + i]; }
             }
             const uint8_t* asrc = patch + ((tap / 5) * G::PW + (tap % 5)) * G::PSTRIDE;
 #pragma unroll
@@ -696,9 +700,11 @@ __global__ __launch_bounds__(512) void k_t_conv5_h2(const float* __restrict__ in
             }
             if (tap < 24) {
 #pragma unroll
-                for (int u = 0; u < BPT; ++u) { const int i = tid + u * 512; if (i < BV) reinterpret_cast<uint4*>(Bs + (buf ^ 1) * G::BT)[i] = nb[u]; }
+                for (int u = 0; u < BPT; ++u) { const int i = tid + u * 512; if (i < BV) reinterpret_cast<uint4*>(Bs + (buf ^ 1) * G::BT)[i] = n1[u]; }
             }
             __syncthreads();
+#pragma unroll
+            for (int u = 0; u < BPT; ++u) n1[u] = n2[u];
         }
     }
     const int co = n * 32 + j;
