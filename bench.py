@@ -71,6 +71,50 @@ def build_parser():
     return ap
 
 
+def _cpulist(text):
+    cpus = set()
+    for part in text.strip().split(","):
+        if "-" in part:
+            a, b = part.split("-"); cpus.update(range(int(a), int(b) + 1))
+        elif part:
+            cpus.add(int(part))
+    return cpus
+
+
+def pin_to_gpu_node(local):
+    """pins this process to the CPUs of the NUMA node GPU `local` hangs on (sysfs); falls back to the node of the CPU it is running on"""
+    import ctypes
+    import glob
+    node = -1
+    cands = sorted(glob.glob("/sys/bus/pci/devices/*/numa_node"))
+    gpu_nodes = []
+    for f in cands:
+        d = os.path.dirname(f)
+        try:
+            if open(os.path.join(d, "vendor")).read().strip() != "0x1002" or not open(os.path.join(d, "class")).read().startswith("0x03") \
+                    and not open(os.path.join(d, "class")).read().startswith("0x12"):
+                continue
+            gpu_nodes.append((os.path.basename(d), int(open(f).read().strip())))
+        except OSError:
+            continue
+    if gpu_nodes:
+        node = gpu_nodes[min(local, len(gpu_nodes) - 1)][1]
+    src = "the GPU's node"
+    if node < 0:
+        cpu = ctypes.CDLL(None).sched_getcpu()
+        for f in glob.glob("/sys/devices/system/node/node*/cpulist"):
+            if cpu in _cpulist(open(f).read()):
+                node = int(os.path.basename(os.path.dirname(f))[4:])
+        src = "the node this process was running on"
+    if node < 0:
+        return "not pinned (no NUMA information)"
+    cpus = _cpulist(open(f"/sys/devices/system/node/node{node}/cpulist").read()) & os.sched_getaffinity(0)
+    if not cpus:
+        return "not pinned (node %d has no allowed CPU)" % node
+    os.sched_setaffinity(0, cpus)
+    return "process pinned to NUMA node %d (%s, %d CPUs) while it allocates the tiles and drives the pipeline" % (node, src, len(cpus))
+
+
 def apply_presets(args):
     # the named configurations of BASELINE.json: C2 = bg-sub + CCL only, C3 = + posture (no network), C4 = + identity network,
     # C5 = everything (posture, posture-normalised crops, network, full per-blob record)
@@ -115,6 +159,17 @@ def measure(args, env):
     if bgra_in:     # the same scenes as BGRA tiles (what TRex's TileImage holds)
         frames_c = torch.stack([frames, frames, frames, torch.full_like(frames, 255)], dim=-1).contiguous()
     host_frames = None
+    numa_note = None
+    old_affinity = None
+    if host_in:
+        # two-socket hosts: where the tiles' pages, the pinned ring and the copy threads lie decides the path's speed (5.5 k vs 8.3 k frames/s
+        # measured with the scheduler's choice).  The producer of this benchmark is pinned to the GPU's NUMA node (else the node it runs on)
+        # before it allocates anything; libtrexhip's copy threads follow the caller's node (upload.hip)
+        try:
+            old_affinity = os.sched_getaffinity(0)
+            numa_note = pin_to_gpu_node(local)
+        except Exception as ex:      # noqa: BLE001
+            numa_note = "not pinned (%s)" % ex
     if host_in:     # distinct pageable buffers, one per tile, like TRex's pooled Image::Ptr
         src = frames_c if bgra_in else frames
         host_frames = [np.ascontiguousarray(src[i].cpu().numpy()) for i in range(B)]
@@ -271,7 +326,12 @@ def measure(args, env):
         cms = sum(u[0] for u in up); cn = sum(u[1] for u in up); dms = sum(u[2] for u in up); dn = sum(u[3] for u in up)
         host_reduced = bgra_in and not rgb          # gray pixel arrays: the upload threads reduce BGRA tiles to gray while they copy (hostcvt.cpp)
         pcie_step = float(B * W * H) if host_reduced else bytes_step
-        out["host_input"] = {"tile_bytes_per_step": bytes_step, "tile_GB_per_s": bytes_step * world * args.steps / dt / 1e9,
+        if old_affinity is not None:
+            try:
+                os.sched_setaffinity(0, old_affinity)
+            except OSError:
+                pass
+        out["host_input"] = {"producer_numa": numa_note, "tile_bytes_per_step": bytes_step, "tile_GB_per_s": bytes_step * world * args.steps / dt / 1e9,
                              "pcie_bytes_per_step": pcie_step, "pcie_GB_per_s": pcie_step * world * args.steps / dt / 1e9, "pcie_peak_GB_per_s": 63.0,
                              "frac_of_pcie_peak": pcie_step * world * args.steps / dt / 63e9,
                              "host_copy_ms_per_frame": cms / cn if cn else None, "dma_ms_per_frame": dms / dn if dn else None,
