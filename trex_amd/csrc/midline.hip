@@ -14,14 +14,10 @@ namespace trexhip {
 
 struct MidlineCfg { int resolution; float stiff; int invert, start_with_head, stride; };
 
-// segments per blob worked on in LDS: 48 (48 x 64 lanes x 16 B = 48 KB per workgroup, three workgroups per CU) or, when the launch has no more
-// workgroups than the device has CUs, 144 (144 KB: a workgroup has its CU to itself anyway, and lists of more than 48 segments -- large
-// individuals -- stay out of global memory)
-static constexpr int M_CAP = 48, M_CAP_BIG = 144;
+static constexpr int M_CAP = 48;        // segments per blob worked on in LDS (48 x 64 lanes x 16 B = 48 KB per workgroup)
 __device__ __forceinline__ float vlen(float x, float y) { return sqrtf(x * x + y * y); }
 __device__ __forceinline__ float2 vnorm(float x, float y) { const float L = vlen(x, y); return L > 0 ? make_float2((x / L), (y / L)) : make_float2(0.f, 0.f); }
 
-template <int CAP>
 __global__ __launch_bounds__(64) void k_midline(const MidlineCfg C, const trexhip_posture_info* __restrict__ pinfo, float4* __restrict__ segs,
                                                 int n_blobs, float4* __restrict__ mid, trexhip_midline_info* __restrict__ minfo) {
     const int b = blockIdx.x * 64 + threadIdx.x;
@@ -32,10 +28,10 @@ __global__ __launch_bounds__(64) void k_midline(const MidlineCfg C, const trexhi
     const int n = pi.n_segments;
     if (pi.status != 0 || n <= 2) { I.status = 1; minfo[b] = I; return; }
     // The algorithm below walks the blob's segment list about six times, one lane per blob: done in global memory every access of a wave
-    // touches 64 cache lines.  Lists of at most CAP segments are worked on in the lane's LDS column (one pass in, one pass out).
+    // touches 64 cache lines.  Lists of at most M_CAP segments are worked on in the lane's LDS column (one pass in, one pass out).
     float4* Sg = segs + (size_t)b * C.stride;
-    extern __shared__ __attribute__((aligned(16))) float4 s_seg[];      // CAP x 64
-    const bool in_lds = n <= CAP;
+    __shared__ float4 s_seg[M_CAP * 64];
+    const bool in_lds = n <= M_CAP;
     if (in_lds) for (int i = 0; i < n; ++i) s_seg[i * 64 + threadIdx.x] = Sg[i];
     const int sstride = in_lds ? 64 : 1;
     float4* Sb = in_lds ? s_seg + threadIdx.x : Sg;          // generic pointer: LDS column or the global list
@@ -210,15 +206,8 @@ extern "C" int trexhip_midline_device(trexhip_ctx* ctx, const trexhip_midline_pa
     if (n_blobs == 0) return TREXHIP_OK;
     TH_CHECK_HIP(hipSetDevice(ctx->p.device));
     const MidlineCfg C{mp->midline_resolution, mp->midline_stiff_percentage, mp->midline_invert, mp->midline_start_with_head, max_points / 2 + 1};
-    const int wgs = (n_blobs + 63) / 64;
-    if (wgs <= ctx->n_cus && C.stride > M_CAP) {
-        static bool attr = false;
-        if (!attr) { TH_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_midline<M_CAP_BIG>), hipFuncAttributeMaxDynamicSharedMemorySize, M_CAP_BIG * 64 * 16)); attr = true; }
-        hipLaunchKernelGGL((k_midline<M_CAP_BIG>), dim3(wgs), dim3(64), M_CAP_BIG * 64 * 16, ctx->stream, C, d_posture_info, reinterpret_cast<float4*>(d_segments),
-                           n_blobs, reinterpret_cast<float4*>(d_midline), d_midline_info);
-    } else
-        hipLaunchKernelGGL((k_midline<M_CAP>), dim3(wgs), dim3(64), M_CAP * 64 * 16, ctx->stream, C, d_posture_info, reinterpret_cast<float4*>(d_segments),
-                           n_blobs, reinterpret_cast<float4*>(d_midline), d_midline_info);
+    hipLaunchKernelGGL(k_midline, dim3((n_blobs + 63) / 64), dim3(64), 0, ctx->stream, C, d_posture_info, reinterpret_cast<float4*>(d_segments),
+                       n_blobs, reinterpret_cast<float4*>(d_midline), d_midline_info);
     TH_CHECK_HIP(hipGetLastError());
     return TREXHIP_OK;
 }
