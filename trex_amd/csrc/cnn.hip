@@ -15,7 +15,7 @@
 //               pixels ordered pool-window-major so the 2x2 max-pool is a max over 4 accumulator
 //               registers of one lane; BN folded into weights/bias; epilogue bias+ReLU+pool
 //   k_fc1       [crops x 12800] x [12800 x 128] MFMA GEMM, LDS tiles
-//   k_head_t    LayerNorm + ReLU + fc2 + softmax, one wave per crop (large batches of <= 128 classes: fc2's weights in LDS, workgroups walk over the crops)
+//   k_head      LayerNorm + ReLU + fc2 + softmax, one wave per crop
 #include "internal.h"
 #include "conv_f32.h"
 #include <algorithm>
@@ -1203,22 +1203,15 @@ __device__ __forceinline__ float wave_max(float v) {
     return v;
 }
 
-template <bool WLDS>
-__global__ __launch_bounds__(256) void k_head_t(const float* __restrict__ fc1 /*[N][128]*/, const float* __restrict__ ln_g,
+__global__ __launch_bounds__(256) void k_head(const float* __restrict__ fc1 /*[N][128]*/, const float* __restrict__ ln_g,
                                               const float* __restrict__ ln_b, const float* __restrict__ w2t /*[100][C]*/,
                                               const float* __restrict__ b2, float* __restrict__ probs /*[N][C]*/,
                                               float* __restrict__ logits_out, int n, int C, const uint32_t* __restrict__ guard, int ksplit) {
     if (guard && *guard == 0u) return;
     __shared__ float ys[4][128];
-    extern __shared__ __attribute__((aligned(16))) float w2l[];          // WLDS: fc2's weights [100][C], read once per workgroup
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    if (WLDS) {
-        for (int i = threadIdx.x; i < 100 * C; i += 256) w2l[i] = w2t[i];
-        __syncthreads();
-    }
-    const float* wsrc = WLDS ? w2l : w2t;
-    // WLDS: a workgroup walks over crops (grid-stride), its four waves one crop each per round
-    for (int crop = blockIdx.x * 4 + wave; crop < n; crop += gridDim.x * 4) {
+    const int crop = blockIdx.x * 4 + wave;
+    if (crop >= n) return;
     const float* x = fc1 + (size_t)crop * 128;
     float x0 = x[lane], x1 = lane + 64 < 100 ? x[lane + 64] : 0.f;
     for (int s = 1; s < ksplit; ++s) {                     // fc1 partial planes of the split-K launch, fixed order
@@ -1244,7 +1237,7 @@ __global__ __launch_bounds__(256) void k_head_t(const float* __restrict__ fc1 /*
             const int c = r * 64 + lane;
             if (c < C) {
                 float s = b2[c];
-                for (int k = 0; k < 100; ++k) s = fmaf(ys[wave][k], wsrc[(size_t)k * C + c], s);
+                for (int k = 0; k < 100; ++k) s = fmaf(ys[wave][k], w2t[(size_t)k * C + c], s);
                 lg[r] = s;
                 if (logits_out) logits_out[(size_t)crop * C + c] = s;
             }
@@ -1261,9 +1254,6 @@ __global__ __launch_bounds__(256) void k_head_t(const float* __restrict__ fc1 /*
 #pragma unroll
     for (int r = 0; r < 16; ++r)
         if (r < nrep) { const int c = r * 64 + lane; if (c < C) probs[(size_t)crop * C + c] = lg[r] * inv; }
-    __builtin_amdgcn_wave_barrier();      // the next crop's ys[wave] follows this one's reads
-    if (!WLDS) break;
-    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1787,12 +1777,8 @@ static int net_forward_launch(trexhip_ctx* ctx, const uint8_t* d_crops, int n, f
         hipLaunchKernelGGL(k_fc1_split, dim3((n + 127) / 128, FC1_KSPLIT), dim3(256), 0, s, net->act3, net->wf1h, net->bf1, net->fc1, n, 12800, net->invf1h, net->d_ovf);
     else
         hipLaunchKernelGGL(k_fc1, dim3((n + 31) / 32, FC1_KSPLIT), dim3(256), 0, s, net->act3, net->wf1, net->bf1, net->fc1, n, 12800, (const uint32_t*)nullptr);
-    if (net->classes <= 128 && n >= 4096)       // fc2's weights fit a workgroup's LDS and there are crops enough to amortise loading them
-        hipLaunchKernelGGL((k_head_t<true>), dim3(std::min((n + 3) / 4, 3 * ctx->n_cus)), dim3(256), (size_t)100 * net->classes * 4, s, net->fc1, net->lng, net->lnb,
-                           net->wf2t, net->bf2, d_probs, d_logits, n, net->classes, (const uint32_t*)nullptr, FC1_KSPLIT);
-    else
-        hipLaunchKernelGGL((k_head_t<false>), dim3((n + 3) / 4), dim3(256), 0, s, net->fc1, net->lng, net->lnb, net->wf2t, net->bf2,
-                           d_probs, d_logits, n, net->classes, (const uint32_t*)nullptr, FC1_KSPLIT);
+    hipLaunchKernelGGL(k_head, dim3((n + 3) / 4), dim3(256), 0, s, net->fc1, net->lng, net->lnb, net->wf2t, net->bf2,
+                       d_probs, d_logits, n, net->classes, (const uint32_t*)nullptr, FC1_KSPLIT);
     if (mode == TREXHIP_CNN_FP16X3) {
         // guarded re-run with the bf16 split: every workgroup returns at once unless an activation left the fp16 range
         const uint32_t* g = net->d_ovf;
@@ -1803,7 +1789,7 @@ static int net_forward_launch(trexhip_ctx* ctx, const uint8_t* d_crops, int n, f
         LAUNCH_SPLIT2(16, 64, 40, 10, 0, 6, net->act1, net->w2s, net->b2, net->act2, 1.0f, g);
         LAUNCH_SPLIT2(64, 128, 20, 20, 0, 6, net->act2, net->w3s, net->b3, net->act3, 1.0f, g);
         hipLaunchKernelGGL(k_fc1, dim3((n + 31) / 32, FC1_KSPLIT), dim3(256), 0, s, net->act3, net->wf1, net->bf1, net->fc1, n, 12800, g);
-        hipLaunchKernelGGL((k_head_t<false>), dim3((n + 3) / 4), dim3(256), 0, s, net->fc1, net->lng, net->lnb, net->wf2t, net->bf2,
+        hipLaunchKernelGGL(k_head, dim3((n + 3) / 4), dim3(256), 0, s, net->fc1, net->lng, net->lnb, net->wf2t, net->bf2,
                            d_probs, d_logits, n, net->classes, g, FC1_KSPLIT);
     }
     stage_end(ctx, TREXHIP_STAGE_CNN_ALL);
