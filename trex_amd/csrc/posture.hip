@@ -35,6 +35,7 @@ struct PostureCfg {
     float curvature_range_ratio, midline_walk_offset; int max_points;
     int nr_cap, rows_cap;            // <= P_NR, P_ROWS
     int stop;                        // dev only: return after phase N (TREXHIP_POSTURE_STOP)
+    int walk_group;                  // bits 8 / 16: blobs whose two-pointer walk searches at most 8 / 16 candidates leave the walk to k_posture_walk<8> / <16>
 };
 
 __device__ __forceinline__ float wsum(float v) {
@@ -418,6 +419,17 @@ __global__ __launch_bounds__(256) void k_posture(const PostureCfg P, const trexh
     res.head_index = head == 0x7fffffff ? -1 : ((head - tail) % n + n) % n;
     if (n <= 1) { if (lane == 0) { res.status = 1; out_info[bi] = res; } return; }
     POSTURE_STOP(4);
+    {
+        // the walk keeps 3 .. a few lanes of a wave busy (max_offset candidates per search) and is bound by instruction issue: blobs whose
+        // searches fit a small lane group are finished by k_posture_walk, several blobs per wave (n_segments = -1 marks them)
+        float mo0 = P.midline_walk_offset * (float)n; if (mo0 < 3.0f) mo0 = 3.0f;
+        const int m0 = (int)mo0;      // tag -G / 8 of the smallest launched group that holds the searches
+        const int tag = ((P.walk_group & 8) && m0 <= 8) ? -1 : (((P.walk_group & 16) && m0 <= 16) ? -2 : 0);
+        if (tag) {
+            if (lane == 0) { res.n_segments = tag; res.status = 0; out_info[bi] = res; }
+            return;
+        }
+    }
     // ---- the two-pointer walk (Outline.cpp:790-857): control flow is wave-uniform, the max_offset candidates of each
     // search are evaluated one per lane and reduced to the FIRST minimum (the sequential `len < min_d` rule).  The kernel is bound
     // by instruction issue, so the loop only keeps what the next iteration depends on: the pair of outline indices of every
@@ -547,6 +559,140 @@ __global__ __launch_bounds__(256) void k_posture(const PostureCfg P, const trexh
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// k_posture_walk: the two-pointer walk of k_posture (Outline.cpp:790-857) for the blobs it tagged (n_segments == -G / 8), 64 / G blobs per wave.
+// The walk is a chain of ~40 dependent steps per blob with 3 .. a few candidates per search: one blob per wave leaves the vector unit nearly
+// empty and the phase bound by instruction issue.  Here a group of G lanes owns a blob -- its outline (written by k_posture, tail at point 0)
+// in the group's LDS, the max_offset <= G candidates of a search one per lane -- and a step costs the wave ~100 instructions for 64 / G blobs:
+// the minimum distance over the group is three or four v_min_u32 with a DPP operand (distances are >= +0, their bit patterns order like the
+// values), the FIRST minimum (the sequential `len < min_d` rule) is the lowest set bit of the group's part of a ballot, and the winning point
+// is read back from LDS.  The same float operations in the same order as the in-kernel walk; groups whose blobs take fewer steps idle.
+// ------------------------------------------------------------------------------------------------
+template <int CTRL> __device__ __forceinline__ uint32_t dpp_min_u32(uint32_t v) {
+    const uint32_t o = (uint32_t)__builtin_amdgcn_update_dpp((int)0xffffffffu, (int)v, CTRL, 0xf, 0xf, false);
+    return o < v ? o : v;
+}
+template <int G> __device__ __forceinline__ uint32_t group_min_u32(uint32_t v) {
+    v = dpp_min_u32<0xB1>(v);                              // quad_perm [1,0,3,2]
+    v = dpp_min_u32<0x4E>(v);                              // quad_perm [2,3,0,1]
+    if (G >= 8) v = dpp_min_u32<0x141>(v);                 // row_half_mirror: the other quad of the 8
+    if (G >= 16) v = dpp_min_u32<0x140>(v);                // row_mirror: the other half of the 16
+    return v;
+}
+template <int G>
+__global__ __launch_bounds__(64) void k_posture_walk(const float walk_offset, const int max_points, const int n_blobs, const float2* __restrict__ outline,
+                                                     float4* __restrict__ out_segments, trexhip_posture_info* __restrict__ info) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t wlds[];
+    constexpr int BPW = 64 / G;
+    const int lane = threadIdx.x, g = lane % G, grp = lane / G, gbase = lane - g;
+    const int bi = blockIdx.x * BPW + grp;
+    const int seg_cap = max_points / 2 + 1;
+    const size_t per = (size_t)max_points * 8 + (((size_t)seg_cap * 4 + 7) & ~(size_t)7);
+    float2* pts = reinterpret_cast<float2*>(wlds + (size_t)grp * per);
+    uint32_t* s_pair = reinterpret_cast<uint32_t*>(pts + max_points);
+    int L = 0;                                             // 0: not this kernel's blob (every lane stays, the wave loads the outlines together)
+    if (bi < n_blobs) {
+        const trexhip_posture_info pi = info[bi];
+        if (pi.status == 0 && pi.n_segments == -(G / 8)) L = pi.n_outline;
+    }
+    // ---- the outlines: the whole wave loads one blob's points at a time, the first 128 points of all blobs in flight together
+    {
+        float2 v0[BPW], v1[BPW];
+#pragma unroll
+        for (int b = 0; b < BPW; ++b) {
+            const int Lb = __builtin_amdgcn_readlane(L, b * G);
+            const float2* src = outline + (size_t)(blockIdx.x * BPW + b) * max_points;
+            v0[b] = lane < Lb ? src[lane] : make_float2(0.f, 0.f);
+            v1[b] = lane + 64 < Lb ? src[lane + 64] : make_float2(0.f, 0.f);
+        }
+#pragma unroll
+        for (int b = 0; b < BPW; ++b) {
+            const int Lb = __builtin_amdgcn_readlane(L, b * G);
+            float2* dst = reinterpret_cast<float2*>(wlds + (size_t)b * per);
+            if (lane < Lb) dst[lane] = v0[b];
+            if (lane + 64 < Lb) dst[lane + 64] = v1[b];
+            if (Lb > 128) {
+                const float2* src = outline + (size_t)(blockIdx.x * BPW + b) * max_points;
+                for (int i = 128 + lane; i < Lb; i += 64) dst[i] = src[i];
+            }
+        }
+    }
+    __builtin_amdgcn_wave_barrier();                       // one wave: its LDS operations stay in order
+    int idx_r = 1, idx_l = -1, ns = 0;
+    float mo = walk_offset * (float)L; if (mo < 3.0f) mo = 3.0f;
+    const int max_offset = (int)mo;                        // <= G (k_posture's own test)
+    const uint32_t BIGU = 0x7f7fffffu;                     // FLT_MAX: "no candidate"
+    const bool in_search = g < max_offset;
+    while (idx_r < L + idx_l) {
+        const int il = L + idx_l;
+        const bool cand_r = in_search && idx_r + g < L, cand_l = in_search && il - g > 0;
+        const float2 pl0 = pts[il];
+        const float2 cr = pts[cand_r ? idx_r + g : 0];
+        const float2 cl = pts[cand_l ? il - g : 0];
+        uint32_t lb = BIGU;
+        {
+            const float ddx = cr.x - pl0.x, ddy = cr.y - pl0.y;
+            const uint32_t b = __builtin_bit_cast(uint32_t, sqrtf(ddx * ddx + ddy * ddy));
+            if (cand_r && b < BIGU) lb = b;                // NaN / inf patterns are above FLT_MAX: !(len < FLT_MAX) never wins
+        }
+        const uint32_t m1 = group_min_u32<G>(lb);
+        const uint64_t w1 = __ballot(lb == m1 && lb != BIGU);
+        const uint32_t g1 = (uint32_t)(w1 >> gbase) & ((1u << G) - 1u);
+        float2 pt_r = make_float2(0.f, 0.f);
+        uint32_t used_r = 0xffffu;
+        if (g1) { idx_r += __builtin_ctz(g1); used_r = (uint32_t)idx_r; pt_r = pts[idx_r]; }   // the same in every lane of the group
+        uint32_t lb2 = BIGU;
+        {
+            const float ddx = pt_r.x - cl.x, ddy = pt_r.y - cl.y;
+            const uint32_t b = __builtin_bit_cast(uint32_t, sqrtf(ddx * ddx + ddy * ddy));
+            if (cand_l && b < BIGU) lb2 = b;
+        }
+        const uint32_t m2 = group_min_u32<G>(lb2);
+        const uint64_t w2 = __ballot(lb2 == m2 && lb2 != BIGU);
+        const uint32_t g2 = (uint32_t)(w2 >> gbase) & ((1u << G) - 1u);
+        if (g2) idx_l -= __builtin_ctz(g2);
+        if (g == 0 && ns < seg_cap) s_pair[ns] = used_r | ((uint32_t)(L + idx_l) << 16);
+        ++ns;
+        idx_r++; idx_l--;
+    }
+    if (L == 0) return;
+    __builtin_amdgcn_wave_barrier();
+    float4* so = out_segments + (size_t)bi * seg_cap;
+    const int nseg = ns < seg_cap ? ns : seg_cap;
+    for (int i = g; i < nseg; i += G) {
+        const uint32_t pr = s_pair[i];
+        const float2 pt_r = (pr & 0xffffu) == 0xffffu ? make_float2(0.f, 0.f) : pts[pr & 0xffffu];
+        const float2 pt_l = pts[pr >> 16];
+        const float lx = pt_r.x - pt_l.x, ly = pt_r.y - pt_l.y;
+        const float mx = pt_l.x + lx * 0.5f, my = pt_l.y + ly * 0.5f;
+        so[i] = make_float4(mx, my, sqrtf(lx * lx + ly * ly), sqrtf((mx - pt_l.x) * (mx - pt_l.x) + (my - pt_l.y) * (my - pt_l.y)));
+    }
+    if (g == 0) { info[bi].n_segments = ns; info[bi].status = ns <= 2 ? 4 : 0; }
+}
+
+// which lane groups of k_posture_walk a launch uses (bits 8, 16): groups of 8 take the blobs whose searches fit them (twice the blobs per wave),
+// groups of 16 the rest up to 16 candidates and are not launched when the parameters cannot need them; searches of more than 16 candidates stay
+// inside k_posture, and so does everything when the outlines of a wave's blobs do not fit 64 KB of LDS.  (Groups of 4 -- 16 blobs per wave, 40 KB
+// of LDS at 256 points -- leave one wave per SIMD and measured slower than groups of 8: 62 vs 50 us per 25 600 blobs.)
+static size_t posture_walk_lds(int max_points) { return (size_t)max_points * 8 + ((((size_t)max_points / 2 + 1) * 4 + 7) & ~(size_t)7); }
+static int posture_walk_groups(const trexhip_posture_params* pp) {
+    float mo = pp->midline_walk_offset * (float)pp->max_points; if (mo < 3.0f) mo = 3.0f;
+    const size_t per = posture_walk_lds(pp->max_points);
+    const bool a8 = per * 8 <= 64 * 1024, a16 = per * 4 <= 64 * 1024;
+    return (a8 ? 8 : 0) | (a16 && ((int)mo > 8 || !a8) ? 16 : 0);
+}
+static void launch_posture_walk(hipStream_t s, const trexhip_posture_params* pp, int groups, int n_blobs, float* d_outline, float* d_segments, trexhip_posture_info* d_info) {
+    if (n_blobs <= 0) return;
+    const size_t per = posture_walk_lds(pp->max_points);
+#define PW_LAUNCH(G_) do { const int bpw = 64 / G_; const size_t lds = per * (size_t)bpw; \
+        if (lds > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_posture_walk<G_>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        hipLaunchKernelGGL((k_posture_walk<G_>), dim3((unsigned)((n_blobs + bpw - 1) / bpw)), dim3(64), lds, s, pp->midline_walk_offset, pp->max_points, n_blobs, \
+                           reinterpret_cast<const float2*>(d_outline), reinterpret_cast<float4*>(d_segments), d_info); } while (0)
+    if (groups & 8) PW_LAUNCH(8);
+    if (groups & 16) PW_LAUNCH(16);
+#undef PW_LAUNCH
+}
+
 }  // namespace trexhip
 
 using namespace trexhip;
@@ -602,13 +748,15 @@ extern "C" int trexhip_posture_device(trexhip_ctx* ctx, int32_t table, const tre
         ctx->attr_posture_bytes = lds_bytes;
     }
     PostureCfg P{pp->outline_resample, pp->outline_smooth_samples, pp->outline_smooth_step, pp->outline_approximate,
-                 pp->outline_curvature_range_ratio, pp->midline_walk_offset, pp->max_points, nr_cap, rows_cap, 0};
+                 pp->outline_curvature_range_ratio, pp->midline_walk_offset, pp->max_points, nr_cap, rows_cap, 0, posture_walk_groups(pp)};
 #ifdef TREXHIP_DEV_KNOBS
     if (const char* e = std::getenv("TREXHIP_POSTURE_STOP")) P.stop = std::atoi(e);
+    if (const char* e = std::getenv("TREXHIP_POSTURE_WALK_GROUP")) P.walk_group = std::atoi(e);
 #endif
     stage_begin(ctx, TREXHIP_STAGE_POSTURE);
     hipLaunchKernelGGL(k_posture, dim3((n_blobs + wpb - 1) / wpb), dim3(wpb * 64), lds_bytes, ctx->stream, P, info, bf, bl, ru, n_blobs, ctx->last_n,
                        reinterpret_cast<float2*>(d_outline), reinterpret_cast<float4*>(d_segments), d_info, (const int32_t*)nullptr, (const trexhip_blob*)nullptr);
+    launch_posture_walk(ctx->stream, pp, P.walk_group, n_blobs, d_outline, d_segments, d_info);
     stage_end(ctx, TREXHIP_STAGE_POSTURE);
     TH_CHECK_HIP(hipGetLastError());
     return TREXHIP_OK;
@@ -742,7 +890,10 @@ extern "C" int trexhip_posture_auto_device(trexhip_ctx* ctx, const trexhip_postu
         rows_cap = (int)std::min<uint32_t>((mrows + 29u) / 32u * 32u + 30u, (uint32_t)P_ROWS);
     }
     PostureCfg P{pp->outline_resample, pp->outline_smooth_samples, pp->outline_smooth_step, pp->outline_approximate,
-                 pp->outline_curvature_range_ratio, pp->midline_walk_offset, pp->max_points, nr_cap, rows_cap, 0};
+                 pp->outline_curvature_range_ratio, pp->midline_walk_offset, pp->max_points, nr_cap, rows_cap, 0, posture_walk_groups(pp)};
+#ifdef TREXHIP_DEV_KNOBS
+    if (const char* e = std::getenv("TREXHIP_POSTURE_WALK_GROUP")) P.walk_group = std::atoi(e);
+#endif
     int wpb = 1, lds_bytes = 0;
     auto size_launch = [&]() -> int {
         const int wave_lds = posture_wave_lds(MPt, P.nr_cap, P.rows_cap);
@@ -768,6 +919,7 @@ extern "C" int trexhip_posture_auto_device(trexhip_ctx* ctx, const trexhip_postu
             stage_begin(ctx, TREXHIP_STAGE_POSTURE);
             hipLaunchKernelGGL(k_posture, dim3((n + wpb - 1) / wpb), dim3(wpb * 64), lds_bytes, s, P, q.d_info, q.d_blob_frame, q.d_blobs, q.d_runs, n, ctx->last_n,
                                reinterpret_cast<float2*>(d_outline), reinterpret_cast<float4*>(d_segments), d_info, sel, ctx->d_blobs);
+            launch_posture_walk(s, pp, P.walk_group, n, d_outline, d_segments, d_info);
             stage_end(ctx, TREXHIP_STAGE_POSTURE);
             hipLaunchKernelGGL(k_auto_step, dim3((n + 3) / 4), dim3(256), 0, s, n, (int)track_posture_threshold, MPt, ctx->d_blobs, thr, sel, best, first_n, first_thr,
                                used, iters, first, reinterpret_cast<float2*>(d_outline), d_info, active, q.d_blobs, P.nr_cap, P.rows_cap);
