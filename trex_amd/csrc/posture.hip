@@ -156,28 +156,46 @@ __global__ __launch_bounds__(256) void k_posture(const PostureCfg P, const trexh
         }
         const int E = (int)running;
         if (E <= NPc) {
+            // one lane per SIDE (a lane per (row, direction) would walk up to 60 sides of a horizontal animal's top row while the others idle): the
+            // (row, direction) item that owns side id e is the last one whose first id is <= e -- items write their number at their first id, a
+            // running maximum fills the rest --, and the side is the (e - first id)-th set bit of the item's mask
+            uint16_t* owner = reinterpret_cast<uint16_t*>(jmp1);               // free until the pointer jumping starts
+            for (int e = lane; e < E; e += 64) owner[e] = 0;
+            if (lane == 0) base16[items] = (uint16_t)E;
             __builtin_amdgcn_wave_barrier();
-            for (int it = lane; it < items; it += 64) {
+            for (int it = lane; it < items; it += 64) { const uint16_t b0 = base16[it]; if (base16[it + 1] != b0) owner[b0] = (uint16_t)it; }
+            __builtin_amdgcn_wave_barrier();
+            int carry = 0;
+            for (int e0 = 0; e0 < E; e0 += 64) {
+                const int e = e0 + lane;
+                int it = e < E ? (int)owner[e] : 0;
+#pragma unroll
+                for (int d = 1; d < 64; d <<= 1) { const int t = __shfl_up(it, d); if (lane >= d && t > it) it = t; }
+                if (carry > it) it = carry;
+                carry = __shfl(it, 63);
+                if (e >= E) continue;
                 const int yr = it >> 2, k = it & 3;
-                unsigned long long m = side_mask(yr, k);
-                uint32_t e = base16[it];
+                const unsigned long long m = side_mask(yr, k);
+                int kk = e - (int)base16[it];                                       // the kk-th set bit of m
+                uint32_t w = (uint32_t)m; int xr = 0;
+                { const int c = __popc(w); if (kk >= c) { kk -= c; w = (uint32_t)(m >> 32); xr = 32; } }
+                { const int c = __popc(w & 0xffffu); if (kk >= c) { kk -= c; w >>= 16; xr += 16; } }
+                { const int c = __popc(w & 0xffu); if (kk >= c) { kk -= c; w >>= 8; xr += 8; } }
+                { const int c = __popc(w & 0xfu); if (kk >= c) { kk -= c; w >>= 4; xr += 4; } }
+                { const int c = __popc(w & 0x3u); if (kk >= c) { kk -= c; w >>= 2; xr += 2; } }
+                if (kk >= (int)(w & 1u)) xr += 1;
                 const int ddx = k == 0 ? 1 : (k == 2 ? -1 : 0), ddy = k == 1 ? 1 : (k == 3 ? -1 : 0);
                 const int kl = (k + 3) & 3;
                 const int lx = kl == 0 ? 1 : (kl == 2 ? -1 : 0), ly = kl == 1 ? 1 : (kl == 3 ? -1 : 0);
-                while (m) {
-                    const int xr = __builtin_ctzll(m);
-                    m &= m - 1;
-                    int tx = xr + ddx + lx, ty = yr + ddy + ly, tk = kl;                 // ahead-left: turn left
-                    if (!((unsigned)tx < 64u && ((row64(ty) >> tx) & 1ull))) {
-                        tx = xr + ddx; ty = yr + ddy; tk = k;                            // ahead: straight on
-                        if (!((unsigned)tx < 64u && ((row64(ty) >> tx) & 1ull))) { tx = xr; ty = yr; tk = (k + 1) & 3; }   // turn right
-                    }
-                    const uint32_t tid = (uint32_t)base16[ty * 4 + tk] + (uint32_t)__popcll(side_mask(ty, tk) & ((1ull << tx) - 1ull));
-                    // the side whose successor is the start side (id 0: first top side of the first row) ends the cycle
-                    jmp0[e] = tid == 0u ? e : (tid | (1u << 16));
-                    geo[e] = (uint32_t)xr | ((uint32_t)yr << 6) | ((uint32_t)k << 16);      // x < 64, row < 1024
-                    ++e;
+                int tx = xr + ddx + lx, ty = yr + ddy + ly, tk = kl;                     // ahead-left: turn left
+                if (!((unsigned)tx < 64u && ((row64(ty) >> tx) & 1ull))) {
+                    tx = xr + ddx; ty = yr + ddy; tk = k;                                // ahead: straight on
+                    if (!((unsigned)tx < 64u && ((row64(ty) >> tx) & 1ull))) { tx = xr; ty = yr; tk = (k + 1) & 3; }   // turn right
                 }
+                const uint32_t tid = (uint32_t)base16[ty * 4 + tk] + (uint32_t)__popcll(side_mask(ty, tk) & ((1ull << tx) - 1ull));
+                // the side whose successor is the start side (id 0: first top side of the first row) ends the cycle
+                jmp0[e] = tid == 0u ? (uint32_t)e : (tid | (1u << 16));
+                geo[e] = (uint32_t)xr | ((uint32_t)yr << 6) | ((uint32_t)k << 16);      // x < 64, row < 1024
             }
             __builtin_amdgcn_wave_barrier();
             uint32_t* cur = jmp0; uint32_t* oth = jmp1;
@@ -282,14 +300,20 @@ __global__ __launch_bounds__(256) void k_posture(const PostureCfg P, const trexh
     // ---- smooth_outline (Outline.cpp:330-378): triangular weights over +-range*step ----
     if (P.smooth_samples > 0 && n > P.smooth_samples) {
         const float step_row = (float)P.smooth_samples * (float)P.smooth_step;
-        float w[33]; int nw = 0; float sum = 0.f;
-        for (int i = (int)-step_row; i <= step_row && nw < 33; i += P.smooth_step) { const float val = (step_row - fabsf((float)i)) / step_row; sum += val; w[nw++] = val; }
+        // the normalised weights w[s] / sum once per blob (the curvature array is idle until the outline is final): lane s holds weight s, the sum
+        // runs over them in the reference's order
+        float* s_w = s_curv;
+        int nw = 0; float sum = 0.f, mine = 0.f;
+        for (int i = (int)-step_row; i <= step_row && nw < 33; i += P.smooth_step) { const float val = (step_row - fabsf((float)i)) / step_row; sum += val; if (nw == lane) mine = val; ++nw; }
+        if (lane < nw) s_w[lane] = mine / sum;
+        __builtin_amdgcn_wave_barrier();
         for (int i = lane; i < n; i += 64) {
             float2 pt = make_float2(0.f, 0.f); int s = 0;
-            for (long j = (long)((float)i - step_row); j <= (float)i + step_row; j += P.smooth_step) {
-                long idx = j; while (idx < 0) idx += n; while (idx >= n) idx -= n;
-                const float ww = w[s] / sum; ++s;
-                pt.x += pts[idx].x * ww; pt.y += pts[idx].y * ww;
+            for (int j = (int)((float)i - step_row); (float)j <= (float)i + step_row; j += P.smooth_step) {
+                int idx = j; while (idx < 0) idx += n; while (idx >= n) idx -= n;
+                const float ww = s_w[s < 32 ? s : 32]; ++s;
+                const float2 q = pts[idx];
+                pt.x += q.x * ww; pt.y += q.y * ww;
             }
             other[i] = pt;
         }
@@ -299,7 +323,7 @@ __global__ __launch_bounds__(256) void k_posture(const PostureCfg P, const trexh
     // ---- offset_to_middle: clockwise test ----
     {
         float part = 0.f;
-        for (int i = lane; i < n; i += 64) { const float2 a = pts[i], q = pts[(i + 1) % n]; part += a.x * q.y - q.x * a.y; }
+        for (int i = lane; i < n; i += 64) { const float2 a = pts[i], q = pts[i + 1 == n ? 0 : i + 1]; part += a.x * q.y - q.x * a.y; }
         if (wsum(part) < 0.f) {
             for (int i = lane; i < n; i += 64) other[i] = pts[n - 1 - i];
             __builtin_amdgcn_wave_barrier();
@@ -316,7 +340,7 @@ __global__ __launch_bounds__(256) void k_posture(const PostureCfg P, const trexh
         for (int i0 = 0; i0 < n; i0 += 64) {
             const int i = i0 + lane;
             float dt = 0.f;
-            if (i < n) { const float2 a = pts[i], q = pts[(i + 1) % n]; dt = sqrtf((q.x - a.x) * (q.x - a.x) + (q.y - a.y) * (q.y - a.y)); }
+            if (i < n) { const float2 a = pts[i], q = pts[i + 1 == n ? 0 : i + 1]; dt = sqrtf((q.x - a.x) * (q.x - a.x) + (q.y - a.y) * (q.y - a.y)); }
             float incl = dt;
 #pragma unroll
             for (int d = 1; d < 64; d <<= 1) { const float t = __shfl_up(incl, d); if (lane >= d) incl += t; }
@@ -341,7 +365,7 @@ __global__ __launch_bounds__(256) void k_posture(const PostureCfg P, const trexh
             __builtin_amdgcn_wave_barrier();
             float sa = 0.f, sb = 0.f, sc = 0.f, sd = 0.f;
             for (int i = lane; i < n; i += 64) {
-                const float2 a = pts[i], q = pts[(i + 1) % n];
+                const float2 a = pts[i], q = pts[i + 1 == n ? 0 : i + 1];
                 const float t0 = s_t[i], t1 = (i + 1 < n) ? s_t[i + 1] : T;
                 const float dt = t1 - t0;
                 if (dt <= 0.f) continue;
@@ -371,7 +395,9 @@ __global__ __launch_bounds__(256) void k_posture(const PostureCfg P, const trexh
     // ---- curvature, tail = highest peak, head = farthest peak ----
     int r = (int)(P.curvature_range_ratio * (float)n); if (r < 1) r = 1;
     for (int i = lane; i < n; i += 64) {
-        const float2 p1 = pts[((i - r) % n + n) % n], p2 = pts[i], p3 = pts[(i + r) % n];
+        // (i -+ r) mod n; r < n except for range ratios >= 1
+        const int im = r < n ? (i - r < 0 ? i - r + n : i - r) : ((i - r) % n + n) % n, ip = r < n ? (i + r >= n ? i + r - n : i + r) : (i + r) % n;
+        const float2 p1 = pts[im], p2 = pts[i], p3 = pts[ip];
         const float cr = (p2.x - p1.x) * (p3.y - p2.y) - (p2.y - p1.y) * (p3.x - p2.x);
         const float d12 = (p2.x - p1.x) * (p2.x - p1.x) + (p2.y - p1.y) * (p2.y - p1.y);
         const float d23 = (p3.x - p2.x) * (p3.x - p2.x) + (p3.y - p2.y) * (p3.y - p2.y);
@@ -382,7 +408,7 @@ __global__ __launch_bounds__(256) void k_posture(const PostureCfg P, const trexh
     __builtin_amdgcn_wave_barrier();
     float best = -1.f; int tail = 0x7fffffff;
     for (int i = lane; i < n; i += 64) {
-        const float c0 = s_curv[(i - 1 + n) % n], c1 = s_curv[i], c2 = s_curv[(i + 1) % n];
+        const float c0 = s_curv[i == 0 ? n - 1 : i - 1], c1 = s_curv[i], c2 = s_curv[i + 1 == n ? 0 : i + 1];
         if (c1 > c0 && c1 >= c2 && c1 > best) { best = c1; tail = i; }        // per lane: first index of its maximum
     }
 #pragma unroll
@@ -398,7 +424,7 @@ __global__ __launch_bounds__(256) void k_posture(const PostureCfg P, const trexh
     }
     float maxd = 0.f; int head = 0x7fffffff;
     for (int i = lane; i < n; i += 64) {
-        const float c0 = s_curv[(i - 1 + n) % n], c1 = s_curv[i], c2 = s_curv[(i + 1) % n];
+        const float c0 = s_curv[i == 0 ? n - 1 : i - 1], c1 = s_curv[i], c2 = s_curv[i + 1 == n ? 0 : i + 1];
         if (!(c1 > c0 && c1 >= c2)) continue;
         float dd;
         if (i >= tail) dd = fminf(fabsf((float)(i - tail)), fabsf((float)(i - tail - n)));
@@ -412,7 +438,7 @@ __global__ __launch_bounds__(256) void k_posture(const PostureCfg P, const trexh
     }
     // rotate so that the tail is point 0 (Outline.cpp:707); this is the outline the caller gets
     float2* oo = out_outline + (size_t)bi * P.max_points;
-    for (int i = lane; i < n; i += 64) { const float2 v = pts[(i + tail) % n]; other[i] = v; oo[i] = v; }
+    for (int i = lane; i < n; i += 64) { const float2 v = pts[i + tail >= n ? i + tail - n : i + tail]; other[i] = v; oo[i] = v; }
     __builtin_amdgcn_wave_barrier();
     { float2* t = pts; pts = other; other = t; }
     res.n_outline = n; res.tail_index = 0;
