@@ -355,14 +355,15 @@ __global__ __launch_bounds__(256) void k_posture(const PostureCfg P, const trexh
         for (int h = 1; h <= order; ++h) {
             // cos / sin of the phase at every point once (segment i ends where segment i + 1 starts: same expression, same value),
             // kept in the spare point buffer
-            for (int i = lane; i < n; i += 64) {
+            // (the closing phase 2 pi h T / T rides along as point n: one lane's work instead of every lane's; it goes to the idle curvature array)
+            for (int i = lane; i <= n; i += 64) {
                 float sn, cs;
-                sincosf(2.0f * PI * (float)h * s_t[i] / T, &sn, &cs);
-                other[i] = make_float2(cs, sn);
+                sincosf(2.0f * PI * (float)h * (i < n ? s_t[i] : T) / T, &sn, &cs);
+                if (i < n) other[i] = make_float2(cs, sn);
+                else { s_curv[0] = cs; s_curv[1] = sn; }
             }
-            float snE, csE;
-            sincosf(2.0f * PI * (float)h * T / T, &snE, &csE);
             __builtin_amdgcn_wave_barrier();
+            const float csE = s_curv[0], snE = s_curv[1];
             float sa = 0.f, sb = 0.f, sc = 0.f, sd = 0.f;
             for (int i = lane; i < n; i += 64) {
                 const float2 a = pts[i], q = pts[i + 1 == n ? 0 : i + 1];
