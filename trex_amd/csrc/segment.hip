@@ -1148,6 +1148,27 @@ __global__ __launch_bounds__(1024) void k_ccl_lds(const SegCfg c, const uint32_t
 // ---------------------------------------------------------------------------------------------
 // k_gather: one wave per kept blob
 // ---------------------------------------------------------------------------------------------
+// lane exchanges inside a 32-lane half without an address register (a __shfl_xor keeps its byte address live in a VGPR; the gather kernel had 18
+// of them and a quarter of its occupancy gone): ds_swizzle in bit mode takes the pattern as an immediate.  D = 32 crosses the halves (permute).
+template <int D> __device__ __forceinline__ uint32_t xchg_xor(uint32_t v) {
+    if constexpr (D < 32) return (uint32_t)__builtin_amdgcn_ds_swizzle((int)v, (D << 10) | 0x1f);
+    else return (uint32_t)__shfl_xor((int)v, D);
+}
+// value of lane Q of the own 32-lane half (LPB = 32) / of the wave (LPB = 64)
+template <int LPB, int Q> __device__ __forceinline__ uint32_t bcast_lane(uint32_t v) {
+    if constexpr (LPB == 64) return (uint32_t)__builtin_amdgcn_readlane((int)v, Q);
+    else return (uint32_t)__builtin_amdgcn_ds_swizzle((int)v, (Q << 5));
+}
+// inclusive prefix sum over groups of LPB lanes with DPP row shifts (lanes outside a row read 0) and the row broadcasts of gfx9
+template <int LPB> __device__ __forceinline__ uint32_t group_incl_scan(uint32_t v) {
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, true);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, true);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, true);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, true);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);       // row_bcast:15 into rows 1 and 3
+    if constexpr (LPB == 64) v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);   // row_bcast:31 into rows 2 and 3
+    return v;
+}
 __device__ __forceinline__ uint64_t wave_sum64(uint64_t v) {
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) {
@@ -1159,8 +1180,8 @@ __device__ __forceinline__ uint64_t wave_sum64(uint64_t v) {
 // Eight per-lane values -> eight wave totals with 10 exchanges instead of 48: three transposing butterfly steps halve the number of
 // values a lane carries (a lane keeps one half and hands the other half to its partner), three plain steps finish.  Afterwards every
 // lane holds the total of quantity q(lane) = 4 * bit0 + 2 * bit1 + bit2 of its lane index.
-__device__ __forceinline__ uint64_t shfl_xor64(uint64_t v, int d) {
-    const uint32_t lo = __shfl_xor((uint32_t)v, d), hi = __shfl_xor((uint32_t)(v >> 32), d);
+template <int D> __device__ __forceinline__ uint64_t shfl_xor64(uint64_t v) {
+    const uint32_t lo = xchg_xor<D>((uint32_t)v), hi = xchg_xor<D>((uint32_t)(v >> 32));
     return ((uint64_t)hi << 32) | lo;
 }
 template <int LANES = 64>
@@ -1168,13 +1189,13 @@ __device__ __forceinline__ uint64_t wave_sum8x64(const uint64_t (&v)[8], uint32_
     uint64_t w[4], u[2];
     const bool b0 = lane & 1u, b1 = lane & 2u, b2 = lane & 4u;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) w[j] = (b0 ? v[4 + j] : v[j]) + shfl_xor64(b0 ? v[j] : v[4 + j], 1);
+    for (int j = 0; j < 4; ++j) w[j] = (b0 ? v[4 + j] : v[j]) + shfl_xor64<1>(b0 ? v[j] : v[4 + j]);
 #pragma unroll
-    for (int j = 0; j < 2; ++j) u[j] = (b1 ? w[2 + j] : w[j]) + shfl_xor64(b1 ? w[j] : w[2 + j], 2);
-    uint64_t t = (b2 ? u[1] : u[0]) + shfl_xor64(b2 ? u[0] : u[1], 4);
-    t += shfl_xor64(t, 8);
-    if (LANES > 16) t += shfl_xor64(t, 16);
-    if (LANES > 32) t += shfl_xor64(t, 32);
+    for (int j = 0; j < 2; ++j) u[j] = (b1 ? w[2 + j] : w[j]) + shfl_xor64<2>(b1 ? w[j] : w[2 + j]);
+    uint64_t t = (b2 ? u[1] : u[0]) + shfl_xor64<4>(b2 ? u[0] : u[1]);
+    t += shfl_xor64<8>(t);
+    if (LANES > 16) t += shfl_xor64<16>(t);
+    if (LANES > 32) t += shfl_xor64<32>(t);
     return t;
 }
 template <int LANES = 64>
@@ -1182,13 +1203,13 @@ __device__ __forceinline__ uint32_t wave_min8x32(const uint32_t (&v)[8], uint32_
     uint32_t w[4], u[2];
     const bool b0 = lane & 1u, b1 = lane & 2u, b2 = lane & 4u;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) w[j] = min(b0 ? v[4 + j] : v[j], (uint32_t)__shfl_xor(b0 ? v[j] : v[4 + j], 1));
+    for (int j = 0; j < 4; ++j) w[j] = min(b0 ? v[4 + j] : v[j], xchg_xor<1>(b0 ? v[j] : v[4 + j]));
 #pragma unroll
-    for (int j = 0; j < 2; ++j) u[j] = min(b1 ? w[2 + j] : w[j], (uint32_t)__shfl_xor(b1 ? w[j] : w[2 + j], 2));
-    uint32_t t = min(b2 ? u[1] : u[0], (uint32_t)__shfl_xor(b2 ? u[0] : u[1], 4));
-    t = min(t, (uint32_t)__shfl_xor(t, 8));
-    if (LANES > 16) t = min(t, (uint32_t)__shfl_xor(t, 16));
-    if (LANES > 32) t = min(t, (uint32_t)__shfl_xor(t, 32));
+    for (int j = 0; j < 2; ++j) u[j] = min(b1 ? w[2 + j] : w[j], xchg_xor<2>(b1 ? w[j] : w[2 + j]));
+    uint32_t t = min(b2 ? u[1] : u[0], xchg_xor<4>(b2 ? u[0] : u[1]));
+    t = min(t, xchg_xor<8>(t));
+    if (LANES > 16) t = min(t, xchg_xor<16>(t));
+    if (LANES > 32) t = min(t, xchg_xor<32>(t));
     return t;
 }
 // lane that holds quantity q after the two reductions above
@@ -1242,16 +1263,24 @@ __global__ __launch_bounds__(256) void k_gather(const SegCfg c, const int only_p
         const uint32_t bi = bw + part;
         bool active = bi < total;
         uint32_t f = 0;
-        trexhip_blob B = {};
-        if (active) { f = blob_frame[bi]; B = blobs[bi]; }       // independent of the frame table: run_begin / pix_begin are pooled offsets here
+        // only the three fields the kernel needs travel in registers (the whole records cost 30 registers and a quarter of the occupancy)
+        struct { uint32_t run_begin, n_runs, pix_begin; } B = {0u, 0u, 0u};
+        if (active) {                                            // independent of the frame table: run_begin / pix_begin are pooled offsets here
+            f = blob_frame[bi];
+            const uint2 rn = *reinterpret_cast<const uint2*>(&blobs[bi].run_begin);
+            B.run_begin = rn.x; B.n_runs = rn.y; B.pix_begin = blobs[bi].pix_begin;
+        }
         active = active && f < (uint32_t)c.B && f >= f0 && f < f1;   // else: hole left by a frame that overflowed the pool / another group's frame
-        trexhip_frame_info fi = {};
-        if (active) fi = info[f];                                // off the critical path unless only_pending
-        if (only_pending && fi.reserved[0] != 2u) active = false;
+        struct { uint32_t run_begin, pix_begin; } fi = {0u, 0u};
+        if (active) {                                            // off the critical path unless only_pending
+            const uint2 rp = *reinterpret_cast<const uint2*>(&info[f].run_begin);
+            fi.run_begin = rp.x; fi.pix_begin = rp.y;
+            if (only_pending && info[f].reserved[0] != 2u) active = false;
+        }
         const uint32_t n_runs = active ? B.n_runs : 0u;
-        uint32_t nr_max = n_runs;
-        if (BPW > 1) nr_max = max(nr_max, (uint32_t)__shfl_xor((int)nr_max, 32));
-        if (BPW > 2) nr_max = max(nr_max, (uint32_t)__shfl_xor((int)nr_max, 16));
+        uint32_t nr_max = n_runs;                                 // the same in every lane of a blob: the wave's maximum from one lane per blob
+        if (BPW > 1) nr_max = max((uint32_t)__builtin_amdgcn_readlane((int)n_runs, 0), (uint32_t)__builtin_amdgcn_readlane((int)n_runs, 32));
+        static_assert(BPW <= 2, "k_gather: one or two blobs per wave");
         const trexhip_run* rr = runs + B.run_begin;
         uint8_t* px = pixels + (size_t)B.pix_begin * (enc == 2 ? 3 : 1);
         const uint8_t* img = frames + (size_t)f * c.H * c.W;
@@ -1263,25 +1292,80 @@ __global__ __launch_bounds__(256) void k_gather(const SegCfg c, const int only_p
             trexhip_run q = {};
             uint32_t len = 0;
             if (i < n_runs) { q = rr[i]; len = (uint32_t)(q.x1 - q.x0 + 1); }
-            uint32_t incl = len;
-#pragma unroll
-            for (int d = 1; d < LPB; d <<= 1) { const uint32_t t = __shfl_up(incl, d); if (sub >= (uint32_t)d) incl += t; }
+            const uint32_t incl = group_incl_scan<LPB>(len);
             uint32_t off = po + incl - len;
-            po += __shfl(incl, part_base + LPB - 1);
+            po += bcast_lane<LPB, LPB - 1>(incl);
             if (len) {
                 x0 = min(x0, (uint32_t)q.x0); x1 = max(x1, (uint32_t)q.x1);
                 y0 = min(y0, (uint32_t)q.y);  y1 = max(y1, (uint32_t)q.y);
                 const uint8_t* src = img + (size_t)q.y * c.W;
                 const uint64_t y = q.y;
                 uint64_t rp = 0;                                       // sum of grey values of this run
+                if constexpr (!COLOUR) {
+                    // gray pixel arrays: 8 pixels per step as ONE unaligned 8-byte load (the lanes of a wave read different rows: every load
+                    // instruction costs the texture path a cycle per lane) fetched a step ahead, one 8-byte store, and no per-pixel
+                    // arithmetic: sum p by v_sad_u8, sum p * x = x * sum p + sum k * p_k by v_dot4_u32_u8, min / max on packed 16-bit
+                    // lanes; sum x and sum x^2 of the run in closed form below.  All sums are exact integers: the same values.
+                    const uint32_t W_ = (uint32_t)c.W, xe = (uint32_t)q.x1;
+                    auto load8 = [&](uint32_t xx) -> unsigned long long {
+                        unsigned long long w = 0;
+                        if (xx + 8u <= W_) __builtin_memcpy(&w, src + xx, 8);
+                        else { _Pragma("unroll 1") for (uint32_t k = 0; k < 8u && xx + k <= xe; ++k) w |= (unsigned long long)src[xx + k] << (8 * k); }
+                        return w;
+                    };
+                    uint32_t x = q.x0;
+                    unsigned long long cur = load8(x);
+                    for (;;) {
+                        const uint32_t rem = min(8u, xe + 1u - x);
+                        const bool more = x + 8u <= xe;
+                        unsigned long long nxt = 0;
+                        if (more) nxt = load8(x + 8u);
+                        const unsigned long long vm = rem == 8u ? ~0ull : ((1ull << (8u * rem)) - 1ull);
+                        const unsigned long long w = (c.invert ? ~cur : cur) & vm;
+                        if (rem == 8u) __builtin_memcpy(px + off, &w, 8);
+                        else { _Pragma("unroll 1") for (uint32_t k = 0; k < rem; ++k) px[off + k] = (uint8_t)(w >> (8u * k)); }
+                        const uint32_t wl = (uint32_t)w, wh = (uint32_t)(w >> 32);
+                        const uint32_t sp_ = __builtin_amdgcn_sad_u8(wh, 0u, __builtin_amdgcn_sad_u8(wl, 0u, 0u));
+                        const uint32_t kp = __builtin_amdgcn_udot4(wh, 0x07060504u, __builtin_amdgcn_udot4(wl, 0x03020100u, 0u, false), false);
+                        rp += sp_; spx += (uint64_t)(x * sp_ + kp);                         // x * sp_ < 8192 * 2040
+                        // extrema: the bytes past the run take the value of the run's pixel at x (a valid one)
+                        const unsigned long long wm = w | (((w & 0xffull) * 0x0101010101010101ull) & ~vm);
+                        typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+                        const uint32_t e0 = (uint32_t)wm & 0x00ff00ffu, e1 = ((uint32_t)wm >> 8) & 0x00ff00ffu;
+                        const uint32_t e2 = (uint32_t)(wm >> 32) & 0x00ff00ffu, e3 = ((uint32_t)(wm >> 40)) & 0x00ff00ffu;
+                        const u16x2 a0 = __builtin_bit_cast(u16x2, e0), a1 = __builtin_bit_cast(u16x2, e1), a2 = __builtin_bit_cast(u16x2, e2), a3 = __builtin_bit_cast(u16x2, e3);
+                        const u16x2 mn = __builtin_elementwise_min(__builtin_elementwise_min(a0, a1), __builtin_elementwise_min(a2, a3));
+                        const u16x2 mxv = __builtin_elementwise_max(__builtin_elementwise_max(a0, a1), __builtin_elementwise_max(a2, a3));
+                        pmin = min(pmin, min((uint32_t)mn.x, (uint32_t)mn.y)); pmax = max(pmax, max((uint32_t)mxv.x, (uint32_t)mxv.y));
+                        off += rem;
+                        if (!more) break;
+                        x += 8u; cur = nxt;
+                    }
+                    const uint32_t L32 = len, xa = q.x0;
+                    const uint64_t tri = (uint64_t)((L32 - 1u) * L32 / 2u);                  // 0 + 1 + .. + (L - 1) < 2^25
+                    m10 += (uint64_t)xa * L32 + tri;
+                    m20 += (uint64_t)L32 * (xa * xa) + (uint64_t)xa * (2u * (uint32_t)tri) + tri * (uint64_t)(2u * L32 - 1u) / 3u;   // sum (xa + k)^2
+                } else {
                 // 8 pixels per step: the byte loads of a step are independent, so a run costs len/8 memory round trips, not len;
                 // the sums of one step fit 32 bits (8 * 8191^2 < 2^30) and are widened once per step
                 uint32_t x = q.x0;
                 for (; x <= (uint32_t)q.x1; x += 8) {
                     const uint32_t rem = min(8u, (uint32_t)q.x1 + 1u - x);
                     uint32_t v[8];
+                    bool stored = false;                                 // a full step's grey values go out as one 8-byte store
+                    if (x + 8u <= (uint32_t)c.W) {
+                        // one unaligned 8-byte load instead of eight byte loads (the bytes past the run stay inside the row): the lanes of a
+                        // wave read different rows, every load instruction costs the texture path one cycle per lane, and those cycles -- not
+                        // the latency -- were what the kernel took
+                        unsigned long long w8;
+                        __builtin_memcpy(&w8, src + x, 8);
 #pragma unroll
-                    for (int k = 0; k < 8; ++k) v[k] = (uint32_t)k < rem ? src[x + k] : 0u;
+                        for (int k = 0; k < 8; ++k) v[k] = (uint32_t)k < rem ? (uint32_t)(w8 >> (8 * k)) & 0xffu : 0u;
+                        if (!enc && rem == 8u) { const unsigned long long o8 = c.invert ? ~w8 : w8; __builtin_memcpy(px + off, &o8, 8); stored = true; }
+                    } else {
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) v[k] = (uint32_t)k < rem ? src[x + k] : 0u;
+                    }
                     uint32_t s10 = 0, s20 = 0, sp_ = 0, spx_ = 0;
 #pragma unroll
                     for (int k = 0; k < 8; ++k) {
@@ -1289,7 +1373,7 @@ __global__ __launch_bounds__(256) void k_gather(const SegCfg c, const int only_p
                         uint32_t p = v[k];
                         if (c.invert) p = 255u - p;
                         const uint32_t xx = x + k;
-                        if (!enc) px[off + k] = (uint8_t)p;
+                        if (!enc) { if (!stored) px[off + k] = (uint8_t)p; }
                         else store_colour(px, off + k, cimg + ((size_t)q.y * c.W + xx) * color_ch, enc);
                         s10 += xx; s20 += __umul24(xx, xx);                 // x < 8192, p < 256: 24-bit multiplies run at full rate
                         sp_ += p; spx_ += __umul24(p, xx);
@@ -1297,6 +1381,7 @@ __global__ __launch_bounds__(256) void k_gather(const SegCfg c, const int only_p
                     }
                     m10 += s10; m20 += s20; rp += sp_; spx += spx_;
                     off += rem;
+                }
                 }
                 const uint64_t L = len;
                 const uint64_t sx = (uint64_t)(q.x0 + q.x1) * L / 2;   // sum of x over the run
@@ -1309,9 +1394,9 @@ __global__ __launch_bounds__(256) void k_gather(const SegCfg c, const int only_p
         const uint64_t tot = wave_sum8x64<LPB>(sums, lane);
         const uint32_t ext[8] = {x0, y0, ~x1, ~y1, pmin, ~pmax, 0xffffffffu, 0xffffffffu};
         const uint32_t te = wave_min8x32<LPB>(ext, lane);
-        x0 = __shfl(te, part_base + lane_of_q(0)); y0 = __shfl(te, part_base + lane_of_q(1));
-        x1 = ~__shfl(te, part_base + lane_of_q(2)); y1 = ~__shfl(te, part_base + lane_of_q(3));
-        pmin = __shfl(te, part_base + lane_of_q(4)); pmax = ~__shfl(te, part_base + lane_of_q(5));
+        x0 = bcast_lane<LPB, lane_of_q(0)>(te); y0 = bcast_lane<LPB, lane_of_q(1)>(te);
+        x1 = ~bcast_lane<LPB, lane_of_q(2)>(te); y1 = ~bcast_lane<LPB, lane_of_q(3)>(te);
+        pmin = bcast_lane<LPB, lane_of_q(4)>(te); pmax = ~bcast_lane<LPB, lane_of_q(5)>(te);
         if (!active) continue;
         trexhip_blob* out = blobs + bi;
         if (sub < 8) {
