@@ -3,7 +3,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 os.environ["TREXHIP_CCL_STOP"] = "-1"
 import torch
 from trex_amd import capi, synth
-B = 64
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 W, H, _, _ = synth.CONFIGS["C4"]
 frames, bg = synth.batch_torch("C4", B, "cuda")
 seg = capi.Segmenter(capi.default_params(W, H, max_batch=B, max_blobs=1024, max_pixels=1 << 18, max_runs=32768))

@@ -29,15 +29,25 @@ static constexpr int CTR_STRIDE = TREXHIP_CTR_STRIDE;   // per-frame counters li
 
 __device__ __forceinline__ uint32_t lane_id() { return threadIdx.x & 63; }
 
-__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v) {
-    const uint32_t lane = lane_id();
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        uint32_t t = __shfl_up(v, d);
-        if (lane >= (uint32_t)d) v += t;
-    }
+// inclusive prefix sum over groups of LPB lanes with DPP row shifts (lanes outside a row read 0) and the row broadcasts of gfx9
+template <int LPB> __device__ __forceinline__ uint32_t group_incl_scan(uint32_t v) {
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, true);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, true);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, true);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, true);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);       // row_bcast:15 into rows 1 and 3
+    if constexpr (LPB == 64) v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);   // row_bcast:31 into rows 2 and 3
     return v;
 }
+// inclusive prefix sum inside each row of 16 lanes
+__device__ __forceinline__ uint32_t row_incl_scan(uint32_t v) {
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, true);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, true);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, true);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, true);
+    return v;
+}
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v) { return group_incl_scan<64>(v); }
 
 // exclusive scan over a block of up to 1024 threads; lds must hold >= 16 uint32
 __device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t* lds, uint32_t& total) {
@@ -48,11 +58,9 @@ __device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t* lds, u
     __syncthreads();
     // every wave scans the (<= 16) wave totals itself: lanes 0..nw-1 hold them
     const uint32_t part = lane < nw ? lds[lane] : 0u;
-    uint32_t pi = part;
-#pragma unroll
-    for (int d = 1; d < 16; d <<= 1) { const uint32_t t = __shfl_up(pi, d); if (lane >= (uint32_t)d) pi += t; }
-    total = __shfl(pi, nw - 1);
-    const uint32_t off = __shfl(pi - part, wave);
+    const uint32_t pi = row_incl_scan(part);
+    total = (uint32_t)__builtin_amdgcn_readlane((int)pi, (int)nw - 1);
+    const uint32_t off = (uint32_t)__builtin_amdgcn_readlane((int)(pi - part), __builtin_amdgcn_readfirstlane((int)wave));
     return off + incl - v;
 }
 
@@ -67,11 +75,9 @@ __device__ __forceinline__ void block_excl_scan3(uint32_t a, uint32_t b, uint32_
 #pragma unroll
     for (int q = 0; q < 3; ++q) {
         const uint32_t part = lane < nw ? lds[16 * q + lane] : 0u;
-        uint32_t pi = part;
-#pragma unroll
-        for (int d = 1; d < 16; d <<= 1) { const uint32_t t = __shfl_up(pi, d); if (lane >= (uint32_t)d) pi += t; }
-        tot[q] = __shfl(pi, nw - 1);
-        ex[q] = __shfl(pi - part, wave) + in[q] - v[q];
+        const uint32_t pi = row_incl_scan(part);
+        tot[q] = (uint32_t)__builtin_amdgcn_readlane((int)pi, (int)nw - 1);
+        ex[q] = (uint32_t)__builtin_amdgcn_readlane((int)(pi - part), __builtin_amdgcn_readfirstlane((int)wave)) + in[q] - v[q];
     }
 }
 
@@ -865,8 +871,32 @@ __global__ __launch_bounds__(1024) void k_ccl_lds(const SegCfg c, const uint32_t
 
     CCL_STAMP(0);
     // P1: raster index of every row
+    // (the rows of the first two sweeps -- every row of a frame up to 2048 lines -- keep their count, run offset, raster index and FIRST run in
+    // registers: the offset and the run are fetched while the scan's barriers pass, and P2 starts without a global round trip)
+    const uint32_t* tmp = tmp_runs + (size_t)f * c.T;
     uint32_t n = 0;
-    for (int y0 = 0; y0 < H; y0 += 1024) {
+    uint32_t pk[2] = {0u, 0u}, po[2] = {0u, 0u}, pbase[2] = {0u, 0u}, pt[2] = {0u, 0u};
+    {
+        // both sweeps' loads first (one round trip for the counts and offsets, one for the first runs), then the two scans
+        const int ya = tid, yb = 1024 + tid;
+        const uint32_t va = ya < H ? cnt[ya] : 0u, vb = yb < H ? cnt[yb] : 0u;
+        if (ya < H) po[0] = off[ya];
+        if (yb < H) po[1] = off[yb];
+        if (va) pt[0] = tmp[po[0]];
+        if (vb) pt[1] = tmp[po[1]];
+        pk[0] = va; pk[1] = vb;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            if (j * 1024 >= H) break;
+            const int y = j * 1024 + tid;
+            uint32_t total;
+            const uint32_t ex = block_excl_scan(pk[j], s_misc, total);
+            if (y < H) { rb[y] = n + ex; if (y < CCL_SORT - 1) s_key[y] = n + ex; }
+            pbase[j] = n + ex;
+            n += total;
+        }
+    }
+    for (int y0 = 2048; y0 < H; y0 += 1024) {
         const int y = y0 + tid;
         const uint32_t v = y < H ? cnt[y] : 0;
         uint32_t total;
@@ -891,8 +921,15 @@ __global__ __launch_bounds__(1024) void k_ccl_lds(const SegCfg c, const uint32_t
     CCL_STOP(1);
     CCL_STAMP(1);
     // P2: runs into LDS in raster order
-    const uint32_t* tmp = tmp_runs + (size_t)f * c.T;
-    for (int y = tid; y < H; y += 1024) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const uint32_t k = pk[j], b = pbase[j], o = po[j];
+        const int y = j * 1024 + tid;
+        if (!k) continue;
+        s_run[b] = pt[j]; s_y[b] = (uint16_t)y; s_par[b] = b;
+        for (uint32_t i = 1; i < k; ++i) { s_run[b + i] = tmp[o + i]; s_y[b + i] = (uint16_t)y; s_par[b + i] = b + i; }
+    }
+    for (int y = 2048 + tid; y < H; y += 1024) {
         const uint32_t b = rb_lds ? s_key[y] : rb[y];
         const uint32_t k = (rb_lds ? s_key[y + 1] : rb[y + 1]) - b;
         if (!k) continue;
@@ -1158,16 +1195,6 @@ template <int D> __device__ __forceinline__ uint32_t xchg_xor(uint32_t v) {
 template <int LPB, int Q> __device__ __forceinline__ uint32_t bcast_lane(uint32_t v) {
     if constexpr (LPB == 64) return (uint32_t)__builtin_amdgcn_readlane((int)v, Q);
     else return (uint32_t)__builtin_amdgcn_ds_swizzle((int)v, (Q << 5));
-}
-// inclusive prefix sum over groups of LPB lanes with DPP row shifts (lanes outside a row read 0) and the row broadcasts of gfx9
-template <int LPB> __device__ __forceinline__ uint32_t group_incl_scan(uint32_t v) {
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, true);
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, true);
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, true);
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, true);
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);       // row_bcast:15 into rows 1 and 3
-    if constexpr (LPB == 64) v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);   // row_bcast:31 into rows 2 and 3
-    return v;
 }
 __device__ __forceinline__ uint64_t wave_sum64(uint64_t v) {
 #pragma unroll
