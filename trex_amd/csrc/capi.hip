@@ -73,7 +73,7 @@ static int hmalloc(T** p, size_t count) {
 static int fill_cfg(trexhip_ctx* ctx) {
     const trexhip_params& p = ctx->p;
     SegCfg& c = ctx->cfg;
-    c.W = p.width; c.H = p.height; c.B = p.max_batch; c.R = p.max_runs;
+    c.W = p.width; c.H = p.height; c.B = p.max_batch; c.ctr_frames = p.max_batch; c.R = p.max_runs;
     c.T = p.height * TREXHIP_ROW_SLOT + p.max_runs;
     const int thr = p.threshold < 0 ? -p.threshold : p.threshold;   // abs(threshold), as the reference does
     if (p.threshold_maximum < 255) { c.tmin = thr; c.tmax = p.threshold_maximum; }   // cv::inRange
@@ -182,6 +182,7 @@ int trexhip_create(const trexhip_params* p, trexhip_ctx** out) {
     ctx->stream = ctx->own_stream;
     TRY(dmalloc(&ctx->d_bg, H * W + 16));
     TRY(dmalloc(&ctx->d_ctr, B * TREXHIP_CTR_STRIDE + 4));
+    if (rc == TREXHIP_OK && hipMemset(ctx->d_ctr, 0, sizeof(uint32_t) * (B * TREXHIP_CTR_STRIDE + 4)) != hipSuccess) { set_error("hipMemset of the counters failed"); rc = TREXHIP_E_DEVICE; }   // every pass leaves the counters zero (launch_segment)
     TRY(dmalloc(&ctx->d_row_cnt, B * H));
     TRY(dmalloc(&ctx->d_row_off, B * H));
     TRY(dmalloc(&ctx->d_row_base, B * (H + 1)));

@@ -26,6 +26,7 @@ void set_error(const std::string& msg);
 // wave-uniform constants handed to every segment kernel by value
 struct SegCfg {
     int W, H, B;          // frame size, frames in this launch
+    int ctr_frames;       // frames the per-frame counter array was sized for (max_batch): the pooled totals live behind them
     int R;                // raw run capacity per frame
     int T;                // entries per frame in the tmp run array = H*ROW_SLOT + R
     int tmin;             // smallest difference value that passes the threshold

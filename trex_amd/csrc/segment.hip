@@ -195,6 +195,9 @@ __global__ __launch_bounds__(256) void k_rows(const uint8_t* __restrict__ frames
                                               uint32_t* __restrict__ row_off,
                                               uint32_t* __restrict__ tmp_runs, const uint32_t* __restrict__ bits, const uint32_t f0) {
     const int lane = lane_id();
+    // the pooled totals of the pass (blobs, runs, pixels) start at zero: written here, ahead of the labelling kernel in stream order (the
+    // per-frame counters are handed back zeroed by k_ccl_lds, so a pass needs no memset)
+    if (f0 == 0u && blockIdx.x == 0 && threadIdx.x < 4) frame_ctr[(size_t)c.ctr_frames * CTR_STRIDE + threadIdx.x] = 0u;
     const int W = c.W;
     const int WB = (W + 31) / 32;
     const uint32_t ntask = (uint32_t)c.B * (uint32_t)c.H;
@@ -423,6 +426,9 @@ __global__ __launch_bounds__(256) void k_rows32(const uint8_t* __restrict__ fram
                                                 uint32_t* __restrict__ row_off,
                                                 uint32_t* __restrict__ tmp_runs, const uint32_t f0) {
     const int lane = lane_id();
+    // the pooled totals of the pass (blobs, runs, pixels) start at zero: written here, ahead of the labelling kernel in stream order (the
+    // per-frame counters are handed back zeroed by k_ccl_lds, so a pass needs no memset)
+    if (f0 == 0u && blockIdx.x == 0 && threadIdx.x < 4) frame_ctr[(size_t)c.ctr_frames * CTR_STRIDE + threadIdx.x] = 0u;
     const int W = c.W;
     const uint32_t ntask = (uint32_t)c.B * (uint32_t)c.H;
     const uint32_t nwave = gridDim.x * 4u;
@@ -474,6 +480,9 @@ __global__ __launch_bounds__(256) void k_rows32b(const uint8_t* __restrict__ fra
                                                  uint32_t* __restrict__ row_off,
                                                  uint32_t* __restrict__ tmp_runs, const uint32_t f0) {
     const int lane = lane_id();
+    // the pooled totals of the pass (blobs, runs, pixels) start at zero: written here, ahead of the labelling kernel in stream order (the
+    // per-frame counters are handed back zeroed by k_ccl_lds, so a pass needs no memset)
+    if (f0 == 0u && blockIdx.x == 0 && threadIdx.x < 4) frame_ctr[(size_t)c.ctr_frames * CTR_STRIDE + threadIdx.x] = 0u;
     const int W = c.W;
     const uint32_t groups = (uint32_t)c.B / (uint32_t)K;
     const uint32_t wid = blockIdx.x * 4u + (threadIdx.x >> 6);
@@ -836,7 +845,7 @@ __device__ __forceinline__ void lds_union(uint32_t* par, uint32_t a, uint32_t b)
     }
 }
 
-__global__ __launch_bounds__(1024) void k_ccl_lds(const SegCfg c, const uint32_t* __restrict__ frame_ctr,
+__global__ __launch_bounds__(1024) void k_ccl_lds(const SegCfg c, uint32_t* __restrict__ frame_ctr,
                                                   const uint32_t* __restrict__ row_cnt, const uint32_t* __restrict__ row_off,
                                                   uint32_t* __restrict__ row_base, const uint32_t* __restrict__ tmp_runs,
                                                   trexhip_run* __restrict__ raster, uint32_t* __restrict__ parent,
@@ -870,6 +879,9 @@ __global__ __launch_bounds__(1024) void k_ccl_lds(const SegCfg c, const uint32_t
     const size_t fo = (size_t)f * c.R;
 
     CCL_STAMP(0);
+    // the frame's overflow-area counter: thread 0 reads it and hands it back zeroed for the next pass (every path: a frame left pending for the
+    // global-memory chain did not overflow, and that chain's own check then reads 0)
+    if (tid == 0) { s_misc[60] = frame_ctr[f * CTR_STRIDE]; frame_ctr[f * CTR_STRIDE] = 0u; }
     // P1: raster index of every row
     // (the rows of the first two sweeps -- every row of a frame up to 2048 lines -- keep their count, run offset, raster index and FIRST run in
     // registers: the offset and the run are fetched while the scan's barriers pass, and P2 starts without a global round trip)
@@ -907,7 +919,7 @@ __global__ __launch_bounds__(1024) void k_ccl_lds(const SegCfg c, const uint32_t
     const bool rb_lds = H < CCL_SORT;              // row_base also lives in LDS (s_key is idle until P4)
     trexhip_frame_info fi = {};
     fi.n_raw_runs = n;
-    const bool overflow = n > (uint32_t)c.R || frame_ctr[f * CTR_STRIDE] > (uint32_t)c.R;
+    const bool overflow = n > (uint32_t)c.R || s_misc[60] > (uint32_t)c.R;       // (behind the barriers of the scans above)
     if (overflow || n > (uint32_t)CCL_NMAX) {
         if (tid == 0) {
             rb[H] = n;
@@ -1468,7 +1480,7 @@ int launch_segment(trexhip_ctx* ctx, const uint8_t* d_frames, int n) {
     const int nch = (W + 1023) / 1024;
     if (nch > 8) { set_error("frame width > 8192 is not supported yet"); return TREXHIP_E_UNSUPPORTED; }
     stage_begin(ctx, TREXHIP_STAGE_SEGMENT_ALL);
-    TH_CHECK_HIP(hipMemsetAsync(ctx->d_ctr, 0, sizeof(uint32_t) * ((size_t)ctx->p.max_batch * CTR_STRIDE + 4), s));
+    // (no memset: the rows kernel zeroes the pooled totals, k_ccl_lds hands every frame counter back zeroed; the array starts zeroed at create)
     const unsigned want = (unsigned)(((size_t)H * n + 3) / 4);
     const dim3 grid_rows(want < (unsigned)ctx->tune_rows_blocks ? want : (unsigned)ctx->tune_rows_blocks);
     const bool aligned = (W % 16 == 0) && ((reinterpret_cast<uintptr_t>(d_frames) & 15) == 0) &&
