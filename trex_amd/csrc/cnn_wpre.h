@@ -15,6 +15,19 @@
 
 static constexpr int V2_ROWB = 5120, V3_ROWB = 10240;
 
+// one LDS-DMA instruction: 64 lanes x 16 bytes from the lanes' global addresses (wave-uniform 64-bit base in SGPRs + a 32-bit lane offset: one
+// address register instead of two) to LDS [lds_addr, lds_addr + 1024).  Raw, so that the compiler's wait-count pass does not know of it: it
+// cannot tell the staging buffer from the one being read and would drain the vector-memory queue (the weight fragments in flight included) in
+// front of every LDS read of the tap loop.  M0 is the compiler's: handed back as found.
+__device__ __forceinline__ unsigned long long wave_uniform64(const unsigned long long v) {
+    return ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(v >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v);
+}
+__device__ __forceinline__ void wpre_dma16(const unsigned long long sbase, const uint32_t voff, const uint32_t lds_addr) {
+    uint32_t keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %3\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "s"(lds_addr), "v"(voff), "s"(sbase) : "memory");
+}
+
 // 8 consecutive pixels x 8 channels (lo = channels 0..3, hi = 4..7 of each pixel) -> per position the two fp16 pieces of the 8 channels
 __device__ __forceinline__ void wino_pack8(const float4* __restrict__ lo, const float4* __restrict__ hi, uint4* __restrict__ o1, uint4* __restrict__ o2) {
     uint32_t w1[8][4], w2[8][4];
@@ -459,7 +472,7 @@ __global__ __launch_bounds__(256, 2) void k_conv2_wpre2(const uint8_t* __restric
 // per tap 12 / 11 taps later).  LDS layout unchanged: [buffer][piece][row slot][position][tx][16 ci], a (row, piece) is 1280
 // contiguous bytes both in V3 and in LDS.
 // ------------------------------------------------------------------------------------------------
-template <int DBG = 0, int BD = 7, int PK = 4>      // PK: consecutive passes per workgroup and ticket (their halo rows are then L2 hits)
+template <int DBG = 0, int BD = 7, int PK = 4, int STG = 1, int DT0 = 2>      // PK: consecutive passes per workgroup and ticket (their halo rows are then L2 hits); STG: 1 = staging by LDS-DMA from tap DT0 on, 0 = through registers
 __global__ __launch_bounds__(256) void k_conv5_wpre(const uint8_t* __restrict__ v3, const uint4* __restrict__ wp /*[4][5][8][2][2][128] x 16 B*/,
                                                     const float* __restrict__ bias, float* __restrict__ out, const float out_scale,
                                                     const int n_crops, uint32_t* __restrict__ pass_ctr) {
@@ -470,13 +483,35 @@ __global__ __launch_bounds__(256) void k_conv5_wpre(const uint8_t* __restrict__ 
     static_assert(NIT == 13, "one batch of 13 units");
     extern __shared__ __attribute__((aligned(16))) uint8_t ldsb[];
     __shared__ int s_next_pass;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int j = lane & 31, h = lane >> 5;
     const int n = wave % G::NT, mg = wave / G::NT;
     const int total_tiles = n_crops * G::TPC;
     const int n_pass = (total_tiles + G::MB - 1) / G::MB;
     int pass = blockIdx.x * PK;
     if (pass >= n_pass) return;
+    const uint32_t lds0 = (uint32_t)(uintptr_t)ldsb;
+    // Staging of a chunk by LDS-DMA (no registers, no LDS store instructions -- a 16-byte ds_write costs the whole CU ~30 cycles): the NR padded
+    // rows of a piece plane are one linear LDS range of NR * RP bytes = NI instructions of 1 KB; lane l of instruction ii covers byte
+    // ii * 1024 + 16 l of it = (row, unit) by one division -- units in a row's pad fetch the row's last unit, lanes past the range stay off --
+    // and supplies the offset of its own unit.  Wave w issues the instructions w, w + 4, ...: at most NDW per wave and chunk, one per tap.
+    constexpr int NI = (G::NR * G::RP + 1023) / 1024, NDW = (2 * NI + 3) / 4;
+#define W3_BASE(cc_, qmin_) wave_uniform64(reinterpret_cast<unsigned long long>(v3) + (unsigned long long)(qmin_) * V3_ROWB + (unsigned)((cc_) * 2560))
+#define W3_DMA(k_, sbase_, nrows_, buf_)                                                                                         \
+    do {                                                                                                                         \
+        const int i_ = wave + 4 * (k_);                                                                                          \
+        if (i_ < 2 * NI) {                                                                                                       \
+            const int pc_ = i_ >= NI ? 1 : 0, ii_ = i_ - pc_ * NI;                                                               \
+            const int o_ = ii_ * 1024 + lane * 16;                                                                               \
+            if (o_ < G::NR * G::RP) {                                                                                            \
+                int row_ = o_ / G::RP, w_ = o_ - row_ * G::RP;                                                                   \
+                w_ = w_ < G::RP0 ? w_ : G::RP0 - 16;                                                                             \
+                row_ = row_ < (nrows_) ? row_ : (nrows_) - 1;                                                                    \
+                wpre_dma16(sbase_, (uint32_t)(row_ * V3_ROWB + pc_ * 1280 + w_),                                                 \
+                           lds0 + (uint32_t)((buf_) * G::BUF + pc_ * G::PLANE + G::RP + ii_ * 1024));                            \
+            }                                                                                                                    \
+        }                                                                                                                        \
+    } while (0)
     for (int i = tid; i < 4 * (G::RP / 16); i += G::NTHR) {
         const int pl = i / (G::RP / 16), o = i - pl * (G::RP / 16);
         *reinterpret_cast<uint4*>(ldsb + pl * G::PLANE + o * 16) = make_uint4(0, 0, 0, 0);
@@ -511,10 +546,16 @@ __global__ __launch_bounds__(256) void k_conv5_wpre(const uint8_t* __restrict__ 
     int qmin, nrows;
     wino_pass_rows<G, S>(pass, total_tiles, qmin, nrows);
     if (!(DBG & 1)) {
+        if constexpr (STG) {
 #pragma unroll
-        for (int k = 0; k < 13; ++k) W3_L(k, k, 0, qmin, nrows);
+            for (int k = 0; k < NDW; ++k) W3_DMA(k, W3_BASE(0, qmin), nrows, 0);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        } else {
 #pragma unroll
-        for (int k = 0; k < 13; ++k) W3_S(k, k, nrows, ldsb);
+            for (int k = 0; k < 13; ++k) W3_L(k, k, 0, qmin, nrows);
+#pragma unroll
+            for (int k = 0; k < 13; ++k) W3_S(k, k, nrows, ldsb);
+        }
     }
     __syncthreads();
     uint4 bq[8][2];
@@ -565,6 +606,7 @@ __global__ __launch_bounds__(256) void k_conv5_wpre(const uint8_t* __restrict__ 
             const int scc = last_c ? 0 : cc + 1;
             const int sqmin = last_c ? qmin_n : qmin, snrows = last_c ? nrows_n : nrows;
             const int wc = cc * 40 * G::BV * 16, wn = scc * 40 * G::BV * 16;
+            const unsigned long long sbase = STG ? W3_BASE(scc, sqmin) : 0ull;
             uint4 af[2][TPW][2];
 #pragma unroll
             for (int m = 0; m < TPW; ++m) {
@@ -588,9 +630,13 @@ __global__ __launch_bounds__(256) void k_conv5_wpre(const uint8_t* __restrict__ 
                     bq[(t + BD) % 8][1] = buf_load16(wrs, boff, wt + 2 * CO * 16);
                 }
                 if (!(DBG & 1)) {
-                    // ONE batch of loads per chunk: every batch of HBM misses holds back the weight fragments queued behind it once
-                    if (t == 0 && !(DBG & 128)) { _Pragma("unroll") for (int k = 0; k < 13; ++k) W3_L(k, k, scc, sqmin, snrows); }
-                    if (t >= 16 && t < 29 && !(DBG & 64)) W3_S(t - 16, t - 16, snrows, nbase);
+                    if constexpr (STG) {
+                        if (t >= DT0 && t < DT0 + NDW) W3_DMA(t - DT0, sbase, snrows, bufsel ^ 1);
+                    } else {
+                        // ONE batch of loads per chunk: every batch of HBM misses holds back the weight fragments queued behind it once
+                        if (t == 0 && !(DBG & 128)) { _Pragma("unroll") for (int k = 0; k < 13; ++k) W3_L(k, k, scc, sqmin, snrows); }
+                        if (t >= 16 && t < 29 && !(DBG & 64)) W3_S(t - 16, t - 16, snrows, nbase);
+                    }
                 }
                 const int p = t % 8;
                 const f16x8 b1 = __builtin_bit_cast(f16x8, bq[t % 8][0]);
@@ -613,6 +659,7 @@ __global__ __launch_bounds__(256) void k_conv5_wpre(const uint8_t* __restrict__ 
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
+            if constexpr (STG) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's part of the next chunk has landed
             __syncthreads();
             bufsel ^= 1;
         }
@@ -662,4 +709,6 @@ __global__ __launch_bounds__(256) void k_conv5_wpre(const uint8_t* __restrict__ 
 #undef W3_L
 #undef W3_UNIT
 #undef W3_S
+#undef W3_DMA
+#undef W3_BASE
 }
