@@ -260,6 +260,20 @@ def measure(args, env):
         prof["SEGMENT_ALL"] = ln0.seg.profile_read(capi.STAGE_SEGMENT_ALL)
     for ln in lanes:
         ln.seg.profile_enable(False)
+    # ... and as the pipeline runs it: the lanes' contexts issue alternate detect passes on their own streams, so the labelling / gather of one
+    # batch (latency chains, one workgroup per frame) run under the pixel pass of the next; wall clock over 2 x 10 passes, nothing else on the GPU
+    pipe_detect_s = None
+    if len(lanes) > 1 and not host_in:
+        for ln in lanes[:2]:
+            ln.detect(frames_ptr)
+        torch.cuda.synchronize()
+        tp0 = time.perf_counter()
+        for i in range(20):
+            lanes[i % 2].detect(frames_ptr)
+        torch.cuda.synchronize()
+        pipe_detect_s = (time.perf_counter() - tp0) / 20
+        for ln in lanes[:2]:
+            ln.seg.fetch(copy=False)
 
     def pmc_traffic(kernel_prefix):
         """HBM bytes per launch from the committed PMC passes of this same command (profiles/rNN_pmc_summary.json, newest round;
@@ -317,6 +331,9 @@ def measure(args, env):
                 "whole_detect_pass_frac": (pass_traffic / segall_s / 8e12) if (pass_traffic and segall_s) else None,
                 "whole_detect_pass_frac_algorithmic_bytes": seg_bytes / segall_s / 8e12 if segall_s else None,
                 "whole_detect_pass_traffic": pass_traffic,
+                "pipelined_detect_pass_us": pipe_detect_s * 1e6 if pipe_detect_s else None,
+                "pipelined_detect_pass_frac": (pass_traffic / pipe_detect_s / 8e12) if (pass_traffic and pipe_detect_s) else None,
+                "pipelined_note": "the same three kernels per pass, passes issued alternately by the pipeline's two contexts on their own streams (labelling / gather of one batch under the pixel pass of the next): wall clock per pass over 20 passes with nothing else on the GPU; whole_detect_pass_* is one context alone, serial",
                 "timing": "HIP events on the kernel stream; 5 serial detect passes after the timed region when lanes are pipelined (in-flight the stage shares the GPU with the identity network)",
                 "limiter": "read-only HBM streaming + VALU: the same kernel with the masks replaced by a trivial compare takes 187-200 us (torch's fastest read-only reduction over the same 1.07 GB: 183 us = 5.85 TB/s, tools/read_bw.py); exact masks and run extraction add the rest. A/B on one box (tools/rows_exp.sh): k_rows32 generic 250 us, + compile-time threshold modes 242, background row in registers for 8 frames (k_rows32b) 235, both 220. k_ccl_lds / k_gather are latency chains of one workgroup per frame / half a wave per blob",
                 "frac_of_measured_copy_bw": ((rows_traffic or seg_bytes) / rows_s / 6.29e12) if rows_s else None}
@@ -520,7 +537,7 @@ def secondary(args, env):
             e = {k: r[k] for k in ("metric", "value", "unit", "ms_per_step", "steps", "warmup", "dtype") if k in r}
             e["workload"] = r["config"]["workload"]
             e["input"] = r["config"].get("input")
-            e["roofline"] = {k: r["roofline"].get(k) for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "avg_launch_us", "frac_basis", "whole_detect_pass_us", "whole_detect_pass_frac", "whole_detect_pass_frac_algorithmic_bytes") if k in r["roofline"]}
+            e["roofline"] = {k: r["roofline"].get(k) for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "avg_launch_us", "frac_basis", "whole_detect_pass_us", "whole_detect_pass_frac", "whole_detect_pass_frac_algorithmic_bytes", "pipelined_detect_pass_us", "pipelined_detect_pass_frac") if k in r["roofline"]}
             for k in ("stage_us", "host_input"):
                 if k in r:
                     e[k] = r[k]
