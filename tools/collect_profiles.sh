@@ -19,8 +19,8 @@ for c in FETCH_SIZE WRITE_SIZE; do
     rm -rf $d
     rocprofv3 --pmc $c --kernel-trace --output-format csv -d $d -- $BENCH --steps 3 --warmup 1 > "$OUT/${TAG}_pmc_${c}_run.log" 2>&1
     f=$(find $d -name '*counter_collection.csv' | head -1)
-    # keep the rows of the LAST timed step only (one dispatch per kernel keeps the file small): last 80 trexhip rows
-    { head -1 "$f"; grep 'trexhip::' "$f" | tail -80; } > "$OUT/${TAG}_pmc_${c}.csv"
+    # keep the rows of the LAST timed step only (one dispatch per kernel keeps the file small): last 400 trexhip rows (the bench ends with ~100 detect-pass dispatches of its roofline_detect measurements)
+    { head -1 "$f"; grep 'trexhip::' "$f" | tail -400; } > "$OUT/${TAG}_pmc_${c}.csv"
 done
 python $ROOT/tools/summarize_pmc.py "$OUT/${TAG}_pmc_FETCH_SIZE.csv" "$OUT/${TAG}_pmc_WRITE_SIZE.csv" > "$OUT/${TAG}_pmc_summary.json"
 ls -la "$OUT"
