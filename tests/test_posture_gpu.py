@@ -132,6 +132,23 @@ def test_setting_variants_and_odd_shapes(kw):
     compare(res, outline, segs, info, oracle.posture_params(max_points=512, **kw))     # (the tie rate is printed: discs and order-1 ellipses are mostly ties)
 
 
+@pytest.mark.parametrize("walk_offset", [0.02, 0.04, 0.045, 0.08, 0.085, 0.16, 0.165, 0.2])
+@pytest.mark.parametrize("max_points", [256, 512, 1024])
+def test_midline_walk_across_the_lane_group_boundaries(walk_offset, max_points):
+    """The two-pointer walk runs in k_posture_walk for blobs whose searches hold at most 8 / 16 candidates (max(3, offset * outline points)) and
+    inside k_posture beyond; which of the groups a launch uses also depends on max_points (LDS per wave).  Offsets chosen so that the scene's
+    outlines (about 50 ... 200 points) fall on both sides of both limits; compare() checks the device's segments bit for bit against the CPU walk of
+    the device's own outline and the outline / tail / head against the restatement."""
+    fr, bg = synth.batch("C2", 2)
+    kw = dict(midline_walk_offset=walk_offset, max_points=max_points)
+    res, outline, segs, info = run_posture(fr, bg, **kw)
+    n, _ = compare(res, outline, segs, info, oracle.posture_params(**kw), max_heads=0.1)
+    assert n >= 40
+    ok = info["status"] == 0
+    mo = np.maximum(3, (walk_offset * info["n_outline"][ok]).astype(int))
+    print("searches of <= 8 / 9..16 / > 16 candidates: %d / %d / %d blobs" % ((mo <= 8).sum(), ((mo > 8) & (mo <= 16)).sum(), (mo > 16).sum()))
+
+
 def test_rethreshold_table_and_capacity():
     fr, bg = synth.batch("C2", 1)
     res, outline, segs, info = run_posture(fr, bg, table=1, thr=40)
