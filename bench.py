@@ -39,8 +39,8 @@ def usable_cores():
 def build_parser():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--config", default="C4")
     ap.add_argument("--batch", type=int, default=0, help="frames resident in HBM per step (default 256, C5: 64): large batches amortise the latency-bound labelling / gather stages (one workgroup per frame) over the HBM-bound pixel pass")
     ap.add_argument("--stages", default="all", choices=["all", "segment"])
