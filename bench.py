@@ -541,7 +541,7 @@ def secondary(args, env):
             for k in ("stage_us", "host_input"):
                 if k in r:
                     e[k] = r[k]
-            if name == "C4_input_host_bgra":      # run-to-run spread of the as-deployed path: two more short repetitions
+            if name in ("C4_input_host_bgra", "C4_input_host_gray"):      # run-to-run spread of the host-input paths: two more short repetitions
                 vals = [r["value"]]
                 for _ in range(2):
                     vals.append(measure(a, env)["value"])
