@@ -66,7 +66,7 @@ def build_parser():
     ap.add_argument("--force-all", action="store_true", help="run exactly the stages given on the command line instead of the preset of the named config")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=16.0)
-    ap.add_argument("--no-secondary", action="store_true", help="skip the short secondary runs (C2, C3, C5, host input, fp32, the N > 1 code path at N = 1, training step) whose numbers ride in the same JSON line")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the short secondary runs (C2, C3, C5, host input, fp32, the N > 1 code path at N = 1, training step); their long records go to a '# bench_secondary:' line and gpurun_out/bench_secondary.json, one {value, frac} pair each to `configs` of the final line")
     ap.add_argument("--secondary-only", default="", help="dev: comma-separated subset of the secondary runs")
     return ap
 
@@ -237,10 +237,21 @@ def measure(args, env):
     n_blobs = run(args.steps)
     barrier()
     dt = time.perf_counter() - t0
+    dist_info = None
     if use_dist:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+        # every rank's own clock around the same K steps: the job's time is the slowest rank's (the contract); the spread and rank 0's
+        # extra (it alone receives the tables and copies the slab to its host) are reported beside it
+        mine = torch.zeros(world, device=dev, dtype=torch.float64)
+        mine[rank] = dt
+        dist.all_reduce(mine, op=dist.ReduceOp.SUM)
+        per_rank = [float(x) for x in mine.tolist()]
+        dt = max(per_rank)
+        others = per_rank[1:] or per_rank
+        dist_info = {"ranks_seen": pipe.shared_comm.count_ranks() if pipe.shared_comm is not None else int(sum(1 for x in per_rank if x > 0)),
+                     "ranks_seen_by": "all-reduce of 1 over libtrexhip's communicator" if pipe.shared_comm is not None else "torch.distributed",
+                     "gather_bytes_per_step": (world - 1) * pipe.rows * pipe.rowlen * 4, "table_bytes_per_rank": pipe.rows * pipe.rowlen * 4,
+                     "ms_per_step_min": min(per_rank) / args.steps * 1e3, "ms_per_step_max": max(per_rank) / args.steps * 1e3,
+                     "rank0_extra_ms": (per_rank[0] - sum(others) / len(others)) / args.steps * 1e3}
     prof = {}
     for name in ("ROWS", "SEGMENT_ALL", "CONV2", "CONV3", "CNN_ALL", "CROPS", "POSTURE"):
         ms = cnt = 0
@@ -312,6 +323,8 @@ def measure(args, env):
                              if with_cnn else "detect only (bg-sub+threshold+CCL+filter+gather, tables->host)",
                    "frames_per_step_per_gpu": B, "encoding": args.encoding, "input": ("host " if host_in else "") + ("bgra tiles (cvtColor on the device inside the step)" if bgra_in else "gray frames") + (" in pageable host memory, PCIe inside the step" if host_in else " resident in HBM"), "posture": bool(args.with_posture), "individual_image_normalization": args.normalize, "pipelined_lanes": len(lanes), "blobs_per_step_rank0": n_blobs, "parallelism": f"frame-sharded x{world}" + (" (all ranks on ONE GPU over loopback sockets: functional check only)" if args.same_gpu else ""), **({"gather": gather_by} if use_dist else {})},
     }
+    if dist_info is not None:
+        out["dist"] = dist_info
     rows_traffic = pmc_traffic("trexhip::k_rows")
     pass_traffic = None
     if rows_traffic is not None:
@@ -494,6 +507,8 @@ def train_step_bench(dev, n=128, classes=100, steps=20, precision=0):
             "dtype": dtype,
             "roofline": {"kernel": kern, "bound": "mfma",
                          "achieved": gflop / dt / 1e3, "peak": 157.3, "unit": "TFLOP/s", "frac": gflop / dt / 1e3 / 157.3, "traffic": None,
+                         # against the peak of the instruction that does the work: three fp16 products per term on the 2.5 PFLOP/s cores
+                         "frac_split_peak": (gflop / dt / 1e3 / (2500.0 / 3.0)) if precision == 0 else None,
                          "peak_note": "algorithmic flops of the step against the fp32 matrix peak (the yardstick of rounds 2-3); with precision 0 about 95 % of "
                                       "those flops run on the 16-bit matrix cores (peak 2500), whose three products per term are not counted",
                          "algorithmic_gflop_per_step": gflop}}
@@ -538,7 +553,7 @@ def secondary(args, env):
             e["workload"] = r["config"]["workload"]
             e["input"] = r["config"].get("input")
             e["roofline"] = {k: r["roofline"].get(k) for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "avg_launch_us", "frac_basis", "whole_detect_pass_us", "whole_detect_pass_frac", "whole_detect_pass_frac_algorithmic_bytes", "pipelined_detect_pass_us", "pipelined_detect_pass_frac") if k in r["roofline"]}
-            for k in ("stage_us", "host_input"):
+            for k in ("stage_us", "host_input", "dist"):
                 if k in r:
                     e[k] = r[k]
             if name in ("C4_input_host_bgra", "C4_input_host_gray"):      # run-to-run spread of the host-input paths: two more short repetitions
@@ -578,6 +593,85 @@ def self_spawn(args, argv):
     return subprocess.call(cmd)
 
 
+FINAL_LINE_MAX = 4096       # bytes: the driver keeps the last ~12 KB of stdout; round 3's 22.8 KB line was cut and nothing was parsed
+
+
+def _r(x, n=4):
+    """numbers of the final line: n significant digits are what the measurement carries"""
+    if isinstance(x, float):
+        return float("%.*g" % (n, x))
+    return x
+
+
+def _pick(d, keys, n=4):
+    return {k: _r(d[k], n) for k in keys if d is not None and k in d}
+
+
+def emit_detail(tag, obj):
+    """the long record: one line on stdout BEFORE the final line (prefixed, so that no parser takes it for the result) and a file
+    under gpurun_out/ (merged back by gpurun)"""
+    try:
+        os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+        with open(os.path.join(ROOT, "gpurun_out", tag + ".json"), "w") as f:
+            json.dump(obj, f, indent=1)
+    except OSError:
+        pass
+    print("# %s: %s" % (tag, json.dumps(obj)), flush=True)
+
+
+def compact_line(out, sec):
+    """the final line: the contract's keys, the roofline objects as numbers, cpu_baseline, and one {value, frac} pair per secondary run.
+    Prose (what each kernel is, how each figure is taken) lives in DESIGN.md section 6; the long record is in gpurun_out/bench_detail.json"""
+    o = {k: _r(out[k], 6) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline") if k in out}
+    o["dtype"] = out["dtype"].split(" ")[0]
+    o["data"] = out["data"]
+    c = out["config"]
+    o["config"] = {"workload": c["workload"], **_pick(c, ("frames_per_step_per_gpu", "encoding", "posture", "individual_image_normalization", "pipelined_lanes",
+                                                          "blobs_per_step_rank0", "parallelism", "gather"))}
+    o["config"]["input"] = c["input"][:60]
+    roof_keys = ("bound", "achieved", "peak", "unit", "frac", "traffic", "avg_launch_us", "launches", "mfma_issue_frac")
+    r = out["roofline"]
+    o["roofline"] = {"kernel": r["kernel"].split(" ")[0], **_pick(r, roof_keys)}
+    if "roofline_kernels" in out:
+        o["roofline_kernels"] = {k: {"kernel": v["kernel"].split(" ")[0], **_pick(v, ("achieved", "frac", "traffic", "avg_launch_us"))} for k, v in out["roofline_kernels"].items()}
+    det_keys = ("achieved", "peak", "frac", "traffic", "avg_launch_us", "frac_algorithmic_bytes", "whole_detect_pass_us", "whole_detect_pass_frac",
+                "whole_detect_pass_frac_algorithmic_bytes", "whole_detect_pass_traffic", "pipelined_detect_pass_us", "pipelined_detect_pass_frac")
+    if "roofline_detect" in out:
+        o["roofline_detect"] = {"kernel": out["roofline_detect"]["kernel"].split(" ")[0], "bound": "hbm", "unit": "GB/s", **_pick(out["roofline_detect"], det_keys)}
+    elif r.get("bound") == "hbm":
+        o["roofline"].update(_pick(r, det_keys))
+    if "stage_us" in out:
+        o["stage_us"] = {k: _r(v, 4) for k, v in out["stage_us"].items() if v is not None}
+    if "host_input" in out:
+        o["host_input"] = _pick(out["host_input"], ("pcie_GB_per_s", "frac_of_pcie_peak", "host_copy_ms_per_frame", "dma_ms_per_frame"))
+    if "dist" in out:
+        o["dist"] = {k: _r(v, 4) for k, v in out["dist"].items()}
+    cb = out.get("cpu_baseline")
+    if cb:
+        o["cpu_baseline"] = {**_pick(cb, ("value", "unit", "cores", "kind", "value_1_thread", "detect_frames_per_s", "identify_frames_per_s")), "sample": cb["sample"][:300]}
+    if sec is not None:
+        cfgs = {}
+        for name, e in sec.items():
+            if "error" in e:
+                cfgs[name] = {"error": e["error"][:80]}
+                continue
+            q = {"value": _r(e["value"]), "ms_per_step": _r(e["ms_per_step"])}
+            rr = e.get("roofline") or {}
+            if rr.get("frac") is not None:
+                q["frac"] = _r(rr["frac"], 3)
+            for k in ("whole_detect_pass_us", "whole_detect_pass_frac", "whole_detect_pass_frac_algorithmic_bytes", "frac_split_peak"):
+                if rr.get(k) is not None:
+                    q[k] = _r(rr[k], 3)
+            if "spread" in e:
+                q["spread"] = _r(e["spread"], 2)
+                q["min"], q["max"] = _r(min(e["repetitions"])), _r(max(e["repetitions"]))
+            if "ranks_seen" in (e.get("dist") or {}):
+                q["ranks_seen"] = e["dist"]["ranks_seen"]
+            cfgs[name] = q
+        o["configs"] = cfgs
+    return o
+
+
 def main():
     argv = sys.argv[1:]
     args = build_parser().parse_args(argv)
@@ -609,14 +703,16 @@ def main():
         sys.exit(2)
     env = {"world": world, "rank": rank, "local": local, "use_dist": use_dist, "dev": dev}
     out = measure(args, env)
+    sec = None
     if rank == 0 and world == 1 and not args.no_secondary:
-        out["secondary"] = secondary(args, env)
+        sec = secondary(args, env)
     if dist.is_initialized():
         sys.stdout.flush()
         dist.barrier()                      # every rank is done talking before rank 0 writes its line
         dist.destroy_process_group()
-    # the ONE JSON line is the last thing this process writes: whatever the runtime libraries left in the C stdio buffer (RCCL prints a
-    # version banner there) goes out first
+    # the ONE short JSON line is the last thing this process writes: whatever the runtime libraries left in the C stdio buffer (RCCL prints
+    # a version banner there) goes out first; the long records (every key of the measurement, the secondary runs) go out BEFORE it, on
+    # lines of their own that do not start with "{", and into gpurun_out/ -- the driver keeps only the tail of stdout
     import ctypes
     sys.stdout.flush()
     try:
@@ -624,7 +720,12 @@ def main():
     except Exception:
         pass
     if rank == 0:
-        print(json.dumps(out), flush=True)
+        emit_detail("bench_detail", out)
+        if sec is not None:
+            emit_detail("bench_secondary", sec)
+        line = json.dumps(compact_line(out, sec), separators=(",", ":"))
+        assert len(line) < FINAL_LINE_MAX, "the final line must stay short enough for the driver's stdout tail: %d bytes" % len(line)
+        print(line, flush=True)
 
 
 if __name__ == "__main__":

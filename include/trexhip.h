@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define TREXHIP_ABI_VERSION 5
+#define TREXHIP_ABI_VERSION 6
 
 enum {
     TREXHIP_OK = 0,
@@ -51,7 +51,8 @@ typedef struct trexhip_params {
     int32_t enable_difference;   /* enable_difference           :126                                */
     int32_t absolute_difference; /* detect_threshold_is_absolute core/default_config.cpp:1168       */
     int32_t image_invert;        /* image_invert                :1159                               */
-    int32_t inclusive;           /* 0: diff > thr (cv::threshold, default) ; 1: diff >= thr          */
+    int32_t inclusive;           /* 1 (default): keep diff >= thr -- "disregards any pixel |p| < threshold", core/default_config.cpp:1168,
+                                  * the track-stage rule's wording (:1167), which Tests/test_pixels.cpp:1026-1059 pins as >= ; 0: diff > thr (cv::threshold) */
     int32_t zero_is_background;  /* 1 (default): a masked pixel of grey value 0 is background        */
     /* CPULabeling::run (BackgroundSubtraction.cpp:216) */
     int32_t connectivity;        /* 8 (default) or 4                                                 */
@@ -146,6 +147,21 @@ void trexhip_default_params(trexhip_params* p, int32_t width, int32_t height);
 int trexhip_create(const trexhip_params* p, trexhip_ctx** out);
 /* BackgroundSubtraction::deinit (BackgroundSubtraction.cpp:118-120) */
 void trexhip_destroy(trexhip_ctx* ctx);
+/* The settings the reference re-reads on EVERY apply() (python/BackgroundSubtraction.cpp:137-143: cm_per_pixel, detect_size_filter;
+ * RawProcessing reads its thresholds per call as well): trexhip_get_live_params copies the context's current values,
+ * trexhip_update_params replaces them for every segment call that follows (the kernels take the settings by value at launch: this is a
+ * host-side update, no device work; not to be called while another thread is inside a segment call of the same ctx).  Settings that size
+ * or lay out buffers (frame size, capacities, pixel_encoding, morphology sizes) stay fixed for the life of the context.  More than 8
+ * ranges or image_invert with a colour pixel_encoding are refused like in trexhip_create; the context keeps its previous values then. */
+typedef struct trexhip_live_params {
+    int32_t threshold, threshold_maximum, inclusive;                     /* as in trexhip_params */
+    int32_t enable_difference, absolute_difference, image_invert, zero_is_background;
+    int32_t n_ranges;                                                    /* detect_size_filter, 0 = accept all, at most 8 */
+    double  cm_per_pixel;
+    double  ranges[16];                                                  /* [start,end) pairs in cm^2 */
+} trexhip_live_params;
+int trexhip_get_live_params(trexhip_ctx* ctx, trexhip_live_params* out);
+int trexhip_update_params(trexhip_ctx* ctx, const trexhip_live_params* lp);
 /* use an external hipStream_t (e.g. torch's current stream); NULL = the ctx's own stream */
 int trexhip_set_stream(trexhip_ctx* ctx, void* hip_stream);
 
@@ -418,6 +434,9 @@ int trexhip_comm_rank(trexhip_comm* comm);
 int trexhip_comm_world(trexhip_comm* comm);
 int trexhip_comm_gather_device(trexhip_comm* comm, const void* d_send, size_t bytes, void* d_recv_rank0);
 int trexhip_comm_gather_device_on(trexhip_comm* comm, trexhip_ctx* stream_ctx, const void* d_send, size_t bytes, void* d_recv_rank0);
+/* collective health check: an all-reduce (sum) of 1 over the communicator -> the number of ranks that took part (= world when every
+ * rank of the frame-sharded job is alive and on this communicator); synchronous, on the communicator's context's stream */
+int trexhip_comm_count_ranks(trexhip_comm* comm, int32_t* ranks_seen);
 
 /* live HIP-event timing of the dominant kernels on the ctx stream (bench.py roofline):
  * stage ids TREXHIP_STAGE_* ; returns accumulated milliseconds and launch count since reset */

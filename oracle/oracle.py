@@ -55,7 +55,7 @@ def posture_params(outline_resample=1.0, outline_smooth_samples=4, outline_smoot
 
 
 def make_params(width, height, threshold=15, threshold_maximum=255, enable_difference=1,
-                absolute_difference=1, image_invert=0, inclusive=0, zero_is_background=1,
+                absolute_difference=1, image_invert=0, inclusive=1, zero_is_background=1,
                 connectivity=8, dilation_size=0, use_closing=0, closing_size=3,
                 cm_per_pixel=1.0, size_ranges=()):
     """Defaults = the reference's defaults (SURVEY.md section 5 settings table)."""

@@ -80,7 +80,7 @@ static inline int diff_value(int px, int bg, const oracle_params* p) {
 static inline int passes(int d, const oracle_params* p) {
     if (p->threshold_maximum < 255)                       /* cv::inRange(thr, max): inclusive both ends */
         return d >= abs(p->threshold) && d <= p->threshold_maximum;
-    return p->inclusive ? d >= abs(p->threshold) : d > abs(p->threshold); /* cv::threshold BINARY is strict */
+    return p->inclusive ? d >= abs(p->threshold) : d > abs(p->threshold); /* inclusive: "disregards any pixel |p| < threshold" (core/default_config.cpp:1168); else cv::threshold BINARY, strict */
 }
 
 /* mask = 255 where the pixel survives threshold (+ morphology); grey = (inverted) input value */

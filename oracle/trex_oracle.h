@@ -31,7 +31,7 @@ typedef struct oracle_params {
     int32_t enable_difference;   /* enable_difference (:126)                               */
     int32_t absolute_difference; /* detect_threshold_is_absolute (core/default_config.cpp:1168) */
     int32_t image_invert;        /* image_invert (:157)                                    */
-    int32_t inclusive;           /* 0: diff >  thr (cv::threshold THRESH_BINARY); 1: diff >= thr */
+    int32_t inclusive;           /* 1 (default of make_params): diff >= thr, core/default_config.cpp:1168; 0: diff > thr (cv::threshold THRESH_BINARY) */
     int32_t zero_is_background;  /* 1: output = grey under mask, CCL labels non-zero       */
     int32_t connectivity;        /* 8 (run overlap +-1) or 4                               */
     int32_t dilation_size;       /* core/default_config.cpp:1163 */

@@ -71,7 +71,7 @@ int main(int argc, char** argv) {
     hooks->init();
     oracle_params op; std::memset(&op, 0, sizeof(op));
     op.width = W; op.height = H; op.threshold = 15; op.threshold_maximum = 255; op.enable_difference = 1;
-    op.absolute_difference = 1; op.zero_is_background = 1; op.connectivity = 8; op.closing_size = 3; op.cm_per_pixel = 1.0;
+    op.absolute_difference = 1; op.inclusive = 1; op.zero_is_background = 1; op.connectivity = 8; op.closing_size = 3; op.cm_per_pixel = 1.0;
 
     // --- no background yet: the future must carry an exception (BackgroundSubtraction.cpp:58-73 waits; we refuse) ---
     {
@@ -239,6 +239,54 @@ int main(int argc, char** argv) {
         bool threw = false;
         try { f.get(); } catch (const std::exception&) { threw = true; }
         CHECK(threw);
+    }
+    // --- settings changed between two apply() calls take effect on the second one, as in the reference, which re-reads cm_per_pixel /
+    //     detect_size_filter (BackgroundSubtraction.cpp:137-143) and its thresholds on every call ---
+    {
+        auto& st = HipBackgroundSubtraction::settings();
+        const HipBackgroundSubtraction::Settings keep = st;
+        std::vector<uint8_t> g(W * H, 120);                                   // background is 120 everywhere (set above)
+        for (int x = 2; x < 6; ++x) g[3 * W + x] = 10;                        // 4 px
+        for (int y = 10; y < 13; ++y) for (int x = 2; x < 12; ++x) g[y * W + x] = 10;      // 30 px
+        for (int y = 20; y < 30; ++y) for (int x = 2; x < 22; ++x) g[y * W + x] = 10;      // 200 px
+        for (int x = 40; x < 48; ++x) g[40 * W + x] = 105;                    // 8 px whose difference is exactly detect_threshold = 15
+        auto count = [&](oracle_params o) {
+            TileImage tile; tile.images.push_back(gray_to_bgr(g, W, H, 3, rng, true));
+            SegmentationData d = HipBackgroundSubtraction::apply(std::move(tile)).get();
+            std::vector<uint8_t> bgl(W * H, 120);
+            compare_with_oracle(d.frame, g, bgl, W, H, o);
+            return (int)d.frame.n();
+        };
+        oracle_params o = op;
+        CHECK(count(o) == 4);
+        st.detect_size_filter = {{10.0, 100.0}};                              // [start, end) in cm^2, cm_per_pixel 1: only the 30 px blob
+        o.n_ranges = 1; o.ranges[0] = 10; o.ranges[1] = 100;
+        CHECK(count(o) == 1);
+        st.cm_per_pixel = 0.5;                                                // 30 px -> 7.5 cm^2 (out), 200 px -> 50 cm^2 (in)
+        o.cm_per_pixel = 0.5;
+        CHECK(count(o) == 1);
+        st.detect_size_filter = {{1.5, 10.0}, {40.0, 60.0}};                  // 8 px = 2, 30 px = 7.5, 200 px = 50 cm^2
+        o.n_ranges = 2; o.ranges[0] = 1.5; o.ranges[1] = 10; o.ranges[2] = 40; o.ranges[3] = 60;
+        CHECK(count(o) == 3);
+        st.inclusive = false;                                                 // strict: the difference-15 line goes
+        o.inclusive = 0;
+        CHECK(count(o) == 2);
+        st.inclusive = true; st.detect_threshold = 16;
+        o.inclusive = 1; o.threshold = 16;
+        CHECK(count(o) == 2);
+        st.detect_threshold = 15; st.threshold_maximum = 100;                 // cv::inRange [15, 100]: only the difference-15 line is left
+        o.threshold = 15; o.threshold_maximum = 100;
+        CHECK(count(o) == 1);
+        st.detect_size_filter.assign(9, {1.0, 2.0});                          // more ranges than the device holds: refused loudly, per batch
+        {
+            TileImage tile; tile.images.push_back(gray_to_bgr(g, W, H, 3, rng, true));
+            auto f = HipBackgroundSubtraction::apply(std::move(tile));
+            bool threw = false; std::string what;
+            try { f.get(); } catch (const std::exception& e) { threw = true; what = e.what(); }
+            CHECK(threw && what.find("more than 8 ranges") != std::string::npos);
+        }
+        st = keep;
+        CHECK(count(op) == 4);
     }
     // --- one frame beyond the capacities fails ALONE: the other frames of the batch are delivered ---
     {

@@ -41,7 +41,7 @@ def score(sub_blobs, gold):
     return hits, exact, deltas
 
 
-def run_variant(G, oracle, detect_threshold=9, track_threshold=12, inclusive=0, connectivity=8, frames=None):
+def run_variant(G, oracle, detect_threshold=9, track_threshold=12, inclusive=1, connectivity=8, frames=None):
     tot = hits = exact = 0
     deltas = []
     for i in (range(len(G.frames)) if frames is None else frames):

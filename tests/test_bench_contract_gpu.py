@@ -1,4 +1,4 @@
-"""bench.py prints ONE JSON line with the keys the driver reads; the line is the last thing on stdout."""
+"""bench.py prints ONE short JSON line with the keys the driver reads; the line is the last thing on stdout (long records come before it, prefixed)."""
 import json
 import os
 import subprocess
@@ -16,6 +16,9 @@ def run(*extra):
                          capture_output=True, text=True, timeout=600, cwd=ROOT)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.strip().splitlines() if l.strip()]
+    # the driver keeps the last ~12 KB of stdout: the final line has to fit with room to spare (round 3's 22.8 KB line was cut -> unparsed)
+    assert len(lines[-1]) < 4096, len(lines[-1])
+    run.detail = {l.split(":", 1)[0][2:]: json.loads(l.split(":", 1)[1]) for l in lines[:-1] if l.startswith("# bench_")}
     return json.loads(lines[-1])
 
 
@@ -55,6 +58,8 @@ def test_two_rank_launch_on_one_gpu_runs_the_gather_path():
     assert out.returncode == 0, out.stderr[-3000:]
     j = json.loads([l for l in out.stdout.strip().splitlines() if l.startswith("{")][-1])
     assert j["n_gpus"] == 2 and j["scaling"] == "weak" and j["config"]["gather"].startswith("libtrexhip")
+    assert len(out.stdout.strip().splitlines()[-1]) < 4096
+    assert j["dist"]["ranks_seen"] == 2 and j["dist"]["gather_bytes_per_step"] > 0 and j["dist"]["ms_per_step_min"] <= j["dist"]["ms_per_step_max"]
     assert abs(j["value"] - 2 * 16 * 2 / (j["ms_per_step"] * 2e-3)) / j["value"] < 1e-6      # whole-job frames / slowest rank's time
 
 
@@ -77,18 +82,37 @@ def test_a_launcher_that_started_the_wrong_number_of_ranks_is_an_error():
     assert out.returncode != 0 and "--gpus 2" in out.stderr
 
 
-def test_secondary_runs_ride_in_the_same_line():
-    # the other configurations / input paths / the N > 1 code path at N = 1 / the training step, each with its own roofline
+def test_final_line_is_short_and_the_long_records_come_before_it():
+    # the other configurations / input paths / the N > 1 code path at N = 1 / the training step: one compact entry each in `configs` of the
+    # final line; the full records (with their own rooflines) on a "# bench_secondary:" line before it and in gpurun_out/
     j = run("--no-cpu-baseline", "--secondary-only", "C2,C4_force_dist,train_step")
-    s = j["secondary"]
+    s = j["configs"]
     assert set(s) == {"C2", "C4_force_dist", "train_step"}
     for name, e in s.items():
         assert "error" not in e, (name, e)
-        assert e["value"] > 0 and "roofline" in e and 0 < e["roofline"]["frac"] < 1.5, (name, e)
-    assert s["C2"]["roofline"]["bound"] == "hbm" and s["train_step"]["roofline"]["peak"] == 157.3
+        assert e["value"] > 0 and 0 < e["frac"] < 1.5, (name, e)
+    assert s["C4_force_dist"]["ranks_seen"] == 1
+    assert 0 < s["train_step"]["frac_split_peak"] < 1
+    full = run.detail["bench_secondary"]
+    assert set(full) == set(s) and full["C2"]["roofline"]["bound"] == "hbm" and full["train_step"]["roofline"]["peak"] == 157.3
+    assert json.load(open(os.path.join(ROOT, "gpurun_out", "bench_secondary.json"))).keys() == full.keys()
     # the N > 1 code path with one rank (library communicator, gather) is the same pipeline as the default run of the same shape
     assert "roofline_kernels" in j and set(j["roofline_kernels"]) == {"conv2", "conv3"}
     assert j["roofline"]["kernel"] in (j["roofline_kernels"]["conv2"]["kernel"], j["roofline_kernels"]["conv3"]["kernel"])
+    d = run.detail["bench_detail"]
+    assert d["value"] == pytest.approx(j["value"], rel=1e-4) and "traffic_note" in d["roofline"]
+
+
+def test_full_default_line_fits_the_drivers_tail():
+    # the driver's own command shape (all secondary runs, cpu baseline) at a small batch: the final line stays under 4 KB
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--cpu-seconds", "2"],
+                         capture_output=True, text=True, timeout=1500, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    last = out.stdout.strip().splitlines()[-1]
+    assert len(last) < 4096, len(last)
+    j = json.loads(last)
+    assert "roofline" in j and "cpu_baseline" in j and len(j["configs"]) >= 12
+    assert len(out.stdout[-12000:].strip().splitlines()[-1]) == len(last)
 
 
 @pytest.mark.parametrize("n", [2, 4, 8])
@@ -103,5 +127,5 @@ def test_strong_scaling_path_on_one_gpu(n):
     assert out.returncode == 0, out.stderr[-3000:]
     j = json.loads([l for l in out.stdout.strip().splitlines() if l.startswith("{")][-1])
     assert j["n_gpus"] == n and j["scaling"] == "strong" and j["config"]["frames_per_step_per_gpu"] == 16 // n
-    assert j["config"]["gather"].startswith("libtrexhip")
+    assert j["config"]["gather"].startswith("libtrexhip") and j["dist"]["ranks_seen"] == n
     assert abs(j["value"] - 16 * 3 / (j["ms_per_step"] * 3e-3)) / j["value"] < 1e-6        # whole-job frames (the batch is split, not multiplied)

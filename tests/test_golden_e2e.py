@@ -42,7 +42,7 @@ def test_what_the_golden_data_discriminates():
     tot, hits, exact, _ = run_variant(G, oracle, connectivity=4, frames=sub)
     assert hits < base[1] and exact < base[2]
     # not at all: strictness and value of the detect threshold (anything below the track threshold)
-    for kw in (dict(inclusive=1), dict(detect_threshold=8), dict(detect_threshold=11)):
+    for kw in (dict(inclusive=0), dict(detect_threshold=8), dict(detect_threshold=11)):
         assert run_variant(G, oracle, frames=sub, **kw)[:3] == base
 
 

@@ -100,17 +100,18 @@ def test_threshold_variants_and_zero_pixels():
     bg = np.full((H, W), 100, np.uint8)
     fr = bg.copy()
     fr[3, 3:9] = [85, 84, 0, 116, 115, 130]      # diffs 15,16,100,16,15,30
-    p = oracle.make_params(W, H, threshold=15)
+    p = oracle.make_params(W, H, threshold=15, inclusive=0)
     b, r, px = oracle.segment(fr, bg, p)          # strict >, zero grey is background
     assert [(int(x["x0"]), int(x["x1"])) for x in r] == [(4, 4), (6, 6), (8, 8)]
-    p = oracle.make_params(W, H, threshold=15, inclusive=1)
+    p = oracle.make_params(W, H, threshold=15)    # the default: |p| < threshold is disregarded (core/default_config.cpp:1168), i.e. >=
+    assert p.inclusive == 1
     b, r, px = oracle.segment(fr, bg, p)
     assert [(int(x["x0"]), int(x["x1"])) for x in r] == [(3, 4), (6, 8)]
     p = oracle.make_params(W, H, threshold=15, inclusive=1, zero_is_background=0)
     b, r, px = oracle.segment(fr, bg, p)
     assert [(int(x["x0"]), int(x["x1"])) for x in r] == [(3, 8)]
     assert px.tolist() == [85, 84, 0, 116, 115, 130]
-    p = oracle.make_params(W, H, threshold=15, absolute_difference=0)   # sign: bg - px
+    p = oracle.make_params(W, H, threshold=15, absolute_difference=0, inclusive=0)   # sign: bg - px
     b, r, px = oracle.segment(fr, bg, p)
     assert [(int(x["x0"]), int(x["x1"])) for x in r] == [(4, 4)]
     p = oracle.make_params(W, H, threshold=15, threshold_maximum=29)    # inRange [15,29]

@@ -114,7 +114,7 @@ def test_adversarial_patterns():
 
 
 @pytest.mark.parametrize("kw", [
-    dict(threshold=15, inclusive=1), dict(threshold=0, inclusive=1), dict(threshold=40, absolute_difference=0),
+    dict(threshold=15, inclusive=1), dict(threshold=15, inclusive=0), dict(threshold=0, inclusive=1), dict(threshold=40, absolute_difference=0),
     dict(threshold=20, threshold_maximum=60), dict(threshold=15, zero_is_background=0, inclusive=1),
     dict(threshold=30, image_invert=1), dict(threshold=100, enable_difference=0),
     dict(threshold=15, size_ranges=[(3, 9), (20, 1000)], cm_per_pixel=0.5),
@@ -170,6 +170,67 @@ def test_capacity_overflow_is_reported():
     assert res[1].info["flags"] == 0 and len(res[1].blobs) == 0
     res = run_gpu(fr[None], bg, max_runs=10000, max_blobs=100)
     assert res[0].info["flags"] & 2
+
+
+def test_noise_frame_in_the_last_slot_overflows_gracefully():
+    # the last frame of a full batch carries millions of runs against a small run area: its rows' offsets point far past the end of the
+    # batch's run buffer (only the writes are bounded); the labelling kernel must refuse the frame without reading there, and the
+    # context's overflow counters must be clean for the next pass
+    W, H, n = 2048, 1024, 4
+    rng = np.random.default_rng(5)
+    frs = []
+    for i in range(n - 1):
+        fr, bg = synth.random_scene(np.random.default_rng(77), W, H, density=0.02)
+        frs.append(fr)
+    noise = bg.copy(); noise[:, ::2] = np.where(bg[:, ::2] > 127, 0, 255)          # ~1 M one-pixel runs
+    frs.append(noise)
+    p = capi.default_params(W, H, max_batch=n, max_runs=4096, max_blobs=4096)
+    seg = capi.Segmenter(p)
+    seg.set_background(bg)
+    d = torch.from_numpy(np.stack(frs)).cuda()
+    for rep in range(3):
+        seg.segment_device(d.data_ptr(), n)
+        res = seg.fetch()
+        assert res[n - 1].info["flags"] & 1 and len(res[n - 1].blobs) == 0
+        for r, fr in zip(res[:n - 1], frs[:n - 1]):
+            if r.info["flags"] == 0:
+                assert_frame_equal(r, fr, bg)
+    d2 = torch.from_numpy(np.stack([bg] * n)).cuda()
+    seg.segment_device(d2.data_ptr(), n)
+    assert all(r.info["flags"] == 0 and len(r.blobs) == 0 for r in seg.fetch())
+    seg.close()
+
+
+def test_live_settings_take_effect_on_the_next_call():
+    # the reference re-reads cm_per_pixel / detect_size_filter and the thresholds on every apply() (BackgroundSubtraction.cpp:137-143):
+    # trexhip_update_params changes them on a living context, results equal a context created with those values
+    rng = np.random.default_rng(3)
+    W, H = 512, 64
+    bg = rng.integers(60, 200, (H, W)).astype(np.uint8)
+    fr = np.clip(bg.astype(int) + rng.integers(-70, 70, (H, W)), 0, 255).astype(np.uint8)
+    seg = capi.Segmenter(capi.default_params(W, H, max_batch=1, max_blobs=32768))
+    seg.set_background(bg)
+    d = torch.from_numpy(fr).cuda()
+    seen = []
+    for kw in (dict(), dict(threshold=30), dict(threshold=30, inclusive=0), dict(threshold=20, threshold_maximum=60),
+               dict(threshold=15, threshold_maximum=255, inclusive=1, size_ranges=[(3, 9), (20, 1000)], cm_per_pixel=0.5),
+               dict(size_ranges=[(2, 50)], cm_per_pixel=1.0), dict(absolute_difference=0, size_ranges=[]), dict(absolute_difference=1, image_invert=1)):
+        seg.update_params(**kw)
+        seg.segment_device(d.data_ptr(), 1)
+        r = seg.fetch()[0]
+        lp = seg.params
+        okw = dict(threshold=lp.threshold, threshold_maximum=lp.threshold_maximum, inclusive=lp.inclusive, absolute_difference=lp.absolute_difference,
+                   image_invert=lp.image_invert, cm_per_pixel=lp.cm_per_pixel, size_ranges=[(lp.ranges[2 * i], lp.ranges[2 * i + 1]) for i in range(lp.n_ranges)])
+        assert_frame_equal(r, fr, bg, **okw)
+        seen.append(len(r.blobs))
+    assert len(set(seen)) >= 6, seen
+    with pytest.raises(capi.TrexHipError):
+        seg.update_params(size_ranges=[(1, 2)] * 9)
+    with pytest.raises(capi.TrexHipError):
+        seg.update_params(cm_per_pixel=0.0)
+    seg.segment_device(d.data_ptr(), 1)                 # a refused update leaves the previous values in place
+    assert len(seg.fetch()[0].blobs) == seen[-1]
+    seg.close()
 
 
 def test_errors():

@@ -10,7 +10,7 @@ from e2e_golden import Golden, run_variant
 
 G = Golden()
 variants = [("baseline: detect `>` 9, 8-connectivity, track `>=` 12", {}),
-            ("detect inclusive `>=` 9", dict(inclusive=1)),
+            ("detect strict `>` 9 (the default is the documented `>=`)", dict(inclusive=0)),
             ("4-connectivity", dict(connectivity=4)),
             ("detect_threshold 8", dict(detect_threshold=8)),
             ("detect_threshold 10", dict(detect_threshold=10)),

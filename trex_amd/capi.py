@@ -48,6 +48,12 @@ class Params(C.Structure):
     ]
 
 
+class LiveParams(C.Structure):
+    _fields_ = [("threshold", C.c_int32), ("threshold_maximum", C.c_int32), ("inclusive", C.c_int32),
+                ("enable_difference", C.c_int32), ("absolute_difference", C.c_int32), ("image_invert", C.c_int32), ("zero_is_background", C.c_int32),
+                ("n_ranges", C.c_int32), ("cm_per_pixel", C.c_double), ("ranges", C.c_double * 16)]
+
+
 class PostureParams(C.Structure):
     _fields_ = [("outline_resample", C.c_float), ("outline_smooth_samples", C.c_int32), ("outline_smooth_step", C.c_int32),
                 ("outline_approximate", C.c_int32), ("outline_curvature_range_ratio", C.c_float),
@@ -104,8 +110,8 @@ class TrainParams(C.Structure):
 
 
 SYMBOLS = [
-    "trexhip_abi_version", "trexhip_network_channels", "trexhip_comm_unique_id", "trexhip_comm_create", "trexhip_comm_destroy", "trexhip_comm_rank", "trexhip_comm_world", "trexhip_comm_gather_device", "trexhip_comm_gather_device_on", "trexhip_last_error", "trexhip_default_params", "trexhip_create", "trexhip_destroy",
-    "trexhip_set_stream", "trexhip_set_background", "trexhip_set_background_device", "trexhip_set_background_color", "trexhip_set_background_color_device", "trexhip_generate_average_device", "trexhip_get_background", "trexhip_segment_device",
+    "trexhip_abi_version", "trexhip_network_channels", "trexhip_comm_unique_id", "trexhip_comm_create", "trexhip_comm_destroy", "trexhip_comm_rank", "trexhip_comm_world", "trexhip_comm_gather_device", "trexhip_comm_gather_device_on", "trexhip_comm_count_ranks", "trexhip_last_error", "trexhip_default_params", "trexhip_create", "trexhip_destroy",
+    "trexhip_set_stream", "trexhip_get_live_params", "trexhip_update_params", "trexhip_set_background", "trexhip_set_background_device", "trexhip_set_background_color", "trexhip_set_background_color_device", "trexhip_generate_average_device", "trexhip_get_background", "trexhip_segment_device",
     "trexhip_segment", "trexhip_segment_color", "trexhip_segment_color_device", "trexhip_rethreshold_device", "trexhip_rethreshold_per_blob_device", "trexhip_fetch_rethreshold", "trexhip_fetch", "trexhip_device_view_get", "trexhip_synchronize",
     "trexhip_profile_enable", "trexhip_profile_read", "trexhip_profile_reset",
     "trexhip_default_posture_params", "trexhip_posture_device", "trexhip_posture_auto_device", "trexhip_pack_frames_v6_device", "trexhip_crops_device", "trexhip_pixel_channels", "trexhip_device_alloc", "trexhip_device_free", "trexhip_copy_to_host", "trexhip_copy_to_device", "trexhip_crops_transformed_device", "trexhip_crops_posture_device", "trexhip_default_midline_params", "trexhip_midline_device", "trexhip_default_split_params", "trexhip_split_search_device", "trexhip_export_id_table_device", "trexhip_export_id_table_ex_device", "trexhip_load_weights", "trexhip_set_identity_precision", "trexhip_num_classes", "trexhip_identify_device", "trexhip_identify",
@@ -127,6 +133,8 @@ def lib():
         L.trexhip_destroy.argtypes = [C.c_void_p]
         L.trexhip_destroy.restype = None
         L.trexhip_set_stream.argtypes = [C.c_void_p, C.c_void_p]
+        L.trexhip_get_live_params.argtypes = [C.c_void_p, C.POINTER(LiveParams)]
+        L.trexhip_update_params.argtypes = [C.c_void_p, C.POINTER(LiveParams)]
         L.trexhip_set_background.argtypes = [C.c_void_p, C.c_void_p, C.c_int32]
         L.trexhip_set_background_device.argtypes = [C.c_void_p, C.c_void_p]
         L.trexhip_set_background_color.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32]
@@ -176,6 +184,7 @@ def lib():
         L.trexhip_comm_world.argtypes = [C.c_void_p]
         L.trexhip_comm_gather_device.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
         L.trexhip_comm_gather_device_on.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+        L.trexhip_comm_count_ranks.argtypes = [C.c_void_p, C.POINTER(C.c_int32)]
         L.trexhip_set_identity_precision.argtypes = [C.c_void_p, C.c_int32]
         L.trexhip_identify_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]
         L.trexhip_identify.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]
@@ -270,6 +279,29 @@ class Segmenter:
     @property
     def handle(self):
         return self._h
+
+    def update_params(self, size_ranges=None, **kw):
+        """the settings TRex re-reads on every apply(): threshold, threshold_maximum, inclusive, enable_difference, absolute_difference,
+        image_invert, zero_is_background, cm_per_pixel, size_ranges -- effective from the next segment call (trexhip_update_params)"""
+        lp = LiveParams()
+        _check(lib().trexhip_get_live_params(self._h, C.byref(lp)))
+        for k, v in kw.items():
+            if k not in dict(LiveParams._fields_):
+                raise KeyError(k)
+            setattr(lp, k, v)
+        if size_ranges is not None:
+            if len(size_ranges) > 8:
+                lp.n_ranges = len(size_ranges)       # the library refuses it
+            else:
+                lp.n_ranges = len(size_ranges)
+                for i, (a, b) in enumerate(size_ranges):
+                    lp.ranges[2 * i], lp.ranges[2 * i + 1] = a, b
+        _check(lib().trexhip_update_params(self._h, C.byref(lp)))
+        for k, _ in LiveParams._fields_:
+            if k != "ranges":
+                setattr(self.params, k, getattr(lp, k))
+        for i in range(16):
+            self.params.ranges[i] = lp.ranges[i]
 
     def set_stream(self, hip_stream_ptr):
         _check(lib().trexhip_set_stream(self._h, C.c_void_p(hip_stream_ptr)))
@@ -586,6 +618,12 @@ class Comm:
             _check(lib().trexhip_comm_gather_device(self._h, C.c_void_p(d_send_ptr), nbytes, C.c_void_p(d_recv_rank0_ptr or 0)))
         else:
             _check(lib().trexhip_comm_gather_device_on(self._h, seg.handle, C.c_void_p(d_send_ptr), nbytes, C.c_void_p(d_recv_rank0_ptr or 0)))
+
+    def count_ranks(self):
+        """all-reduce of 1 over the communicator: the number of ranks that took part"""
+        n = C.c_int32()
+        _check(lib().trexhip_comm_count_ranks(self._h, C.byref(n)))
+        return n.value
 
     def close(self):
         if self._h:

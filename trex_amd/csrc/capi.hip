@@ -77,7 +77,7 @@ static int fill_cfg(trexhip_ctx* ctx) {
     c.T = p.height * TREXHIP_ROW_SLOT + p.max_runs;
     const int thr = p.threshold < 0 ? -p.threshold : p.threshold;   // abs(threshold), as the reference does
     if (p.threshold_maximum < 255) { c.tmin = thr; c.tmax = p.threshold_maximum; }   // cv::inRange
-    else { c.tmin = p.inclusive ? thr : thr + 1; c.tmax = 255; }                      // cv::threshold is strict
+    else { c.tmin = p.inclusive ? thr : thr + 1; c.tmax = 255; }                      // inclusive (default): |p| < threshold is disregarded; 0: strict, cv::threshold
     c.enable_diff = p.enable_difference; c.absdiff = p.absolute_difference;
     c.invert = p.image_invert; c.zero_bg = p.zero_is_background;
     c.slack = p.connectivity == 4 ? 0 : 1;
@@ -115,7 +115,11 @@ void trexhip_default_params(trexhip_params* p, int32_t width, int32_t height) {
     p->max_pixels = 1 << 20;
     p->threshold = 15; p->threshold_maximum = 255;
     p->enable_difference = 1; p->absolute_difference = 1;
-    p->image_invert = 0; p->inclusive = 0; p->zero_is_background = 1;
+    p->image_invert = 0; p->zero_is_background = 1;
+    // keep iff |diff| >= detect_threshold: the rule the reference documents for the detect stage (core/default_config.cpp:1168,
+    // docs/parameters_trex.rst:624-629 "disregards any pixel |p| < threshold") in the words of the track-stage rule (:1167), which
+    // Tests/test_pixels.cpp:1026-1059 pins as >=.  0 selects the strict comparison (cv::threshold's THRESH_BINARY).
+    p->inclusive = 1;
     p->connectivity = 8;
     p->dilation_size = 0; p->use_closing = 0; p->closing_size = 3;
     p->n_ranges = 0; p->cm_per_pixel = 1.0;
@@ -271,6 +275,34 @@ int trexhip_copy_to_device(trexhip_ctx* ctx, void* device_dst, const void* host_
     if (bytes) TH_CHECK_HIP(hipMemcpyAsync(device_dst, host_src, bytes, hipMemcpyHostToDevice, ctx->stream));
     TH_CHECK_HIP(hipStreamSynchronize(ctx->stream));
     return TREXHIP_OK;
+}
+
+int trexhip_get_live_params(trexhip_ctx* ctx, trexhip_live_params* out) {
+    if (!ctx || !out) { set_error("trexhip_get_live_params: null argument"); return TREXHIP_E_INVALID; }
+    const trexhip_params& p = ctx->p;
+    std::memset(out, 0, sizeof(*out));
+    out->threshold = p.threshold; out->threshold_maximum = p.threshold_maximum; out->inclusive = p.inclusive;
+    out->enable_difference = p.enable_difference; out->absolute_difference = p.absolute_difference;
+    out->image_invert = p.image_invert; out->zero_is_background = p.zero_is_background;
+    out->n_ranges = p.n_ranges; out->cm_per_pixel = p.cm_per_pixel;
+    for (int i = 0; i < 16; ++i) out->ranges[i] = p.ranges[i];
+    return TREXHIP_OK;
+}
+
+int trexhip_update_params(trexhip_ctx* ctx, const trexhip_live_params* lp) {
+    if (!ctx || !lp) { set_error("trexhip_update_params: null argument"); return TREXHIP_E_INVALID; }
+    if (lp->n_ranges < 0 || lp->n_ranges > 8) { set_error("trexhip_update_params: n_ranges must be 0..8 (detect_size_filter with more than 8 ranges is not supported)"); return TREXHIP_E_INVALID; }
+    if (!(lp->cm_per_pixel > 0.0)) { set_error("trexhip_update_params: cm_per_pixel must be positive"); return TREXHIP_E_INVALID; }
+    if (ctx->p.pixel_encoding != TREXHIP_ENC_GRAY && lp->image_invert) {
+        set_error("trexhip_update_params: image_invert with a colour pixel_encoding is not supported"); return TREXHIP_E_UNSUPPORTED;
+    }
+    trexhip_params& p = ctx->p;
+    p.threshold = lp->threshold; p.threshold_maximum = lp->threshold_maximum; p.inclusive = lp->inclusive;
+    p.enable_difference = lp->enable_difference; p.absolute_difference = lp->absolute_difference;
+    p.image_invert = lp->image_invert; p.zero_is_background = lp->zero_is_background;
+    p.n_ranges = lp->n_ranges; p.cm_per_pixel = lp->cm_per_pixel;
+    for (int i = 0; i < 16; ++i) p.ranges[i] = i < 2 * lp->n_ranges ? lp->ranges[i] : 0.0;
+    return fill_cfg(ctx);
 }
 
 int trexhip_set_stream(trexhip_ctx* ctx, void* hip_stream) {

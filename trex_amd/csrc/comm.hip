@@ -13,7 +13,7 @@ namespace {
 
 typedef struct { char internal[128]; } nccl_unique_id;       // ncclUniqueId, NCCL_UNIQUE_ID_BYTES = 128 (rccl.h:40-43)
 typedef void* nccl_comm;
-enum { NCCL_SUCCESS = 0, NCCL_UINT8 = 1 };                   // ncclSuccess, ncclUint8 (rccl.h ncclResult_t / ncclDataType_t)
+enum { NCCL_SUCCESS = 0, NCCL_UINT8 = 1, NCCL_INT32 = 2, NCCL_SUM = 0 };   // ncclSuccess, ncclUint8, ncclInt32, ncclSum (rccl.h ncclResult_t / ncclDataType_t / ncclRedOp_t)
 
 struct Rccl {
     void* so = nullptr;
@@ -24,6 +24,7 @@ struct Rccl {
     int (*GroupEnd)() = nullptr;
     int (*Send)(const void*, size_t, int, int, nccl_comm, hipStream_t) = nullptr;
     int (*Recv)(void*, size_t, int, int, nccl_comm, hipStream_t) = nullptr;
+    int (*AllReduce)(const void*, void*, size_t, int, int, nccl_comm, hipStream_t) = nullptr;
     const char* (*GetErrorString)(int) = nullptr;
     bool ok = false;
 };
@@ -40,7 +41,7 @@ Rccl& rccl() {
 #define SYM(field, name) r.field = reinterpret_cast<decltype(r.field)>(dlsym(r.so, name))
         SYM(GetUniqueId, "ncclGetUniqueId"); SYM(CommInitRank, "ncclCommInitRank"); SYM(CommDestroy, "ncclCommDestroy");
         SYM(GroupStart, "ncclGroupStart"); SYM(GroupEnd, "ncclGroupEnd"); SYM(Send, "ncclSend"); SYM(Recv, "ncclRecv");
-        SYM(GetErrorString, "ncclGetErrorString");
+        SYM(GetErrorString, "ncclGetErrorString"); SYM(AllReduce, "ncclAllReduce");
 #undef SYM
         r.ok = r.GetUniqueId && r.CommInitRank && r.CommDestroy && r.GroupStart && r.GroupEnd && r.Send && r.Recv;
     });
@@ -129,6 +130,29 @@ int trexhip_comm_gather_device_on(trexhip_comm* c, trexhip_ctx* ctx, const void*
     const int rc2 = r.GroupEnd();
     if (rc != NCCL_SUCCESS) return nccl_fail("ncclSend / ncclRecv", rc);
     if (rc2 != NCCL_SUCCESS) return nccl_fail("ncclGroupEnd", rc2);
+    return TREXHIP_OK;
+}
+
+int trexhip_comm_count_ranks(trexhip_comm* c, int32_t* ranks_seen) {
+    if (!c || !ranks_seen) { trexhip::set_error("trexhip_comm_count_ranks: null argument"); return TREXHIP_E_INVALID; }
+    *ranks_seen = 0;
+    if (c->world == 1) { *ranks_seen = 1; return TREXHIP_OK; }
+    Rccl& r = rccl();
+    if (!r.AllReduce) { trexhip::set_error("trexhip_comm_count_ranks: ncclAllReduce not found in librccl.so"); return TREXHIP_E_UNSUPPORTED; }
+    TH_CHECK_HIP(hipSetDevice(c->ctx->p.device));
+    int32_t* d = nullptr;
+    TH_CHECK_HIP(hipMalloc(&d, sizeof(int32_t)));
+    const int32_t one = 1;
+    hipError_t e = hipMemcpyAsync(d, &one, sizeof(one), hipMemcpyHostToDevice, c->ctx->stream);
+    int rc = NCCL_SUCCESS;
+    if (e == hipSuccess) rc = r.AllReduce(d, d, 1, NCCL_INT32, NCCL_SUM, c->comm, c->ctx->stream);
+    int32_t got = 0;
+    if (e == hipSuccess && rc == NCCL_SUCCESS) e = hipMemcpyAsync(&got, d, sizeof(got), hipMemcpyDeviceToHost, c->ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->ctx->stream);
+    (void)hipFree(d);
+    if (rc != NCCL_SUCCESS) return nccl_fail("ncclAllReduce", rc);
+    TH_CHECK_HIP(e);
+    *ranks_seen = got;
     return TREXHIP_OK;
 }
 

@@ -894,8 +894,10 @@ __global__ __launch_bounds__(1024) void k_ccl_lds(const SegCfg c, uint32_t* __re
         const uint32_t va = ya < H ? cnt[ya] : 0u, vb = yb < H ? cnt[yb] : 0u;
         if (ya < H) po[0] = off[ya];
         if (yb < H) po[1] = off[yb];
-        if (va) pt[0] = tmp[po[0]];
-        if (vb) pt[1] = tmp[po[1]];
+        // (a frame whose run area overflowed carries offsets past its T words -- only the rows kernels' WRITES are bounded; such a frame is
+        // refused below, but this prefetch comes before that test: never read past the area)
+        if (va && po[0] < (uint32_t)c.T) pt[0] = tmp[po[0]];
+        if (vb && po[1] < (uint32_t)c.T) pt[1] = tmp[po[1]];
         pk[0] = va; pk[1] = vb;
 #pragma unroll
         for (int j = 0; j < 2; ++j) {

@@ -21,6 +21,7 @@
 #endif
 #include <algorithm>
 #include <chrono>
+#include <cstring>
 #include <thread>
 #include <shared_mutex>
 #include <string>
@@ -32,6 +33,9 @@ struct HipBackgroundSubtraction {
     struct Settings {                 // the values BackgroundSubtraction::apply / RawProcessing read
         int detect_threshold = 15, threshold_maximum = 255;
         bool detect_threshold_is_absolute = true, enable_difference = true, image_invert = false;
+        // true (default): keep |p| >= detect_threshold -- "disregards any pixel |p| < threshold" (core/default_config.cpp:1168, the wording
+        // of the track-stage rule :1167 that Tests/test_pixels.cpp:1026-1059 pins as >=); false: strict |p| > detect_threshold (cv::threshold)
+        bool inclusive = true;
         int color_channel = -1;       // std::optional<uint8_t> color_channel; <0 = none
         double cm_per_pixel = 1.0;
         std::vector<std::pair<double, double>> detect_size_filter;
@@ -64,9 +68,12 @@ struct HipBackgroundSubtraction {
         trexhip_params p;
         trexhip_default_params(&p, (int32_t)width, (int32_t)height);
         p.device = s.device; p.max_batch = s.max_batch; p.device_color_reduce = s.device_color_reduce;
-        p.threshold = s.detect_threshold; p.threshold_maximum = s.threshold_maximum;
-        p.absolute_difference = s.detect_threshold_is_absolute; p.enable_difference = s.enable_difference;
-        p.image_invert = s.image_invert; p.cm_per_pixel = s.cm_per_pixel;
+        const trexhip_live_params lp = live_of(s);         // (throws on more than 8 size ranges)
+        p.threshold = lp.threshold; p.threshold_maximum = lp.threshold_maximum; p.inclusive = lp.inclusive;
+        p.absolute_difference = lp.absolute_difference; p.enable_difference = lp.enable_difference;
+        p.image_invert = lp.image_invert; p.cm_per_pixel = lp.cm_per_pixel;
+        p.n_ranges = lp.n_ranges;
+        for (int i = 0; i < 16; ++i) p.ranges[i] = lp.ranges[i];
         p.dilation_size = s.dilation_size; p.use_closing = s.use_closing; p.closing_size = s.closing_size;
         p.image_adjust = s.image_adjust; p.blur_difference = s.blur_difference; p.equalize_histogram = s.equalize_histogram;
         p.correct_luminance = s.correct_luminance; p.use_adaptive_threshold = s.use_adaptive_threshold;   // non-default -> trexhip_create refuses
@@ -79,13 +86,13 @@ struct HipBackgroundSubtraction {
         p.pixel_encoding = s.meta_encoding == cmn::meta_encoding_t::rgb8 ? TREXHIP_ENC_RGB8
                          : s.meta_encoding == cmn::meta_encoding_t::r3g3b2 ? TREXHIP_ENC_R3G3B2 : TREXHIP_ENC_GRAY;
         d.context_encoding = s.meta_encoding;
-        p.n_ranges = (int32_t)s.detect_size_filter.size();
-        for (int i = 0; i < p.n_ranges && i < 8; ++i) { p.ranges[2 * i] = s.detect_size_filter[i].first; p.ranges[2 * i + 1] = s.detect_size_filter[i].second; }
         check(trexhip_create(&p, &d.ctx));
+        d.pushed = lp;
         // a second context takes the second half of a batch: its tiles are copied and segmented while the first half's tables are turned
         // into pv::Frame objects and their promises fulfilled (BackgroundSubtraction.cpp:146-342 handles the tiles one after the other and
         // fulfils each promise as it goes)
-        if (s.max_batch >= 2 && s.split_batch) check(trexhip_create(&p, &d.ctx2));
+        // (the second half never holds more than half of the batch's images: its context is sized for that)
+        if (s.max_batch >= 2 && s.split_batch) { p.max_batch = std::max(1, s.max_batch / 2); check(trexhip_create(&p, &d.ctx2)); }
         d.width = width; d.height = height;
         d.has_background = false;
     }
@@ -149,6 +156,17 @@ struct HipBackgroundSubtraction {
             const auto want = d.settings.meta_encoding == cmn::meta_encoding_t::binary ? cmn::meta_encoding_t::gray : d.settings.meta_encoding;
             const auto have = d.context_encoding == cmn::meta_encoding_t::binary ? cmn::meta_encoding_t::gray : d.context_encoding;
             if (want != have) { ok = false; batch_error = "Invalid image mode: meta_encoding changed after init() (re-initialise the backend)"; }   // cf. BackgroundSubtraction.cpp:188
+        }
+        // the reference re-reads cm_per_pixel / detect_size_filter (and RawProcessing its thresholds) on every apply()
+        // (BackgroundSubtraction.cpp:137-143): settings() changed since the last batch are pushed to the contexts before this one
+        if (ok) {
+            try {
+                const trexhip_live_params lp = live_of(d.settings);
+                if (std::memcmp(&lp, &d.pushed, sizeof(lp)) != 0) {
+                    for (trexhip_ctx* c : {d.ctx, d.ctx2}) if (c) check(trexhip_update_params(c, &lp));
+                    d.pushed = lp;
+                }
+            } catch (const std::exception& e) { ok = false; batch_error = e.what(); }
         }
         size_t n_images = 0;
         if (ok) {
@@ -231,10 +249,14 @@ struct HipBackgroundSubtraction {
         };
         segment(parts[0]);
         if (two) {
-            std::thread first([&] { deliver(parts[0]); });                // the first half's consumers are served while the second half is on its way
-            segment(parts[1]);
+            struct Joiner {                                               // an exception below must not destroy a joinable thread
+                std::thread t;
+                ~Joiner() { if (t.joinable()) t.join(); }
+            } first{std::thread([&] { deliver(parts[0]); })};             // the first half's consumers are served while the second half is on its way
+            try {
+                segment(parts[1]);
+            } catch (const std::exception& e) { parts[1].ok = false; parts[1].error = e.what(); }
             deliver(parts[1]);
-            first.join();
         } else deliver(parts[0]);
         for (auto&& tile : tiled) {
             try { if (tile.callback) tile.callback(); } catch (...) {}              // :328-334
@@ -300,14 +322,31 @@ struct HipBackgroundSubtraction {
         detect::register_backend(type, std::move(hooks));
     }
 
-    // the reference re-reads its settings on every apply() (BackgroundSubtraction.cpp:132-143); callers update these in place
+    // the reference re-reads its settings on every apply() (BackgroundSubtraction.cpp:132-143); callers update these in place (not while an
+    // apply() is running).  Live: detect_threshold, threshold_maximum, inclusive, detect_threshold_is_absolute, enable_difference,
+    // image_invert, cm_per_pixel, detect_size_filter (pushed through trexhip_update_params before the next batch) and color_channel (read per
+    // call).  meta_encoding, the capacities, morphology and device need a new init(); a changed meta_encoding fails the batch.
     static Settings& settings() { return data().settings; }
+
+    // the live part of Settings as the ABI takes it
+    static trexhip_live_params live_of(const Settings& s) {
+        if (s.detect_size_filter.size() > 8) throw std::runtime_error("HipBackgroundSubtraction: detect_size_filter with more than 8 ranges is not supported");
+        trexhip_live_params lp;
+        std::memset(&lp, 0, sizeof(lp));
+        lp.threshold = s.detect_threshold; lp.threshold_maximum = s.threshold_maximum; lp.inclusive = s.inclusive ? 1 : 0;
+        lp.enable_difference = s.enable_difference ? 1 : 0; lp.absolute_difference = s.detect_threshold_is_absolute ? 1 : 0;
+        lp.image_invert = s.image_invert ? 1 : 0; lp.zero_is_background = 1;
+        lp.n_ranges = (int32_t)s.detect_size_filter.size(); lp.cm_per_pixel = s.cm_per_pixel;
+        for (int i = 0; i < lp.n_ranges; ++i) { lp.ranges[2 * i] = s.detect_size_filter[i].first; lp.ranges[2 * i + 1] = s.detect_size_filter[i].second; }
+        return lp;
+    }
 
 private:
     struct Data {
         trexhip_ctx *ctx = nullptr, *ctx2 = nullptr;
         uint32_t width = 0, height = 0;
         Settings settings;
+        trexhip_live_params pushed{};             // what the contexts currently hold
         detect::ObjectDetectionType::Class type{};
         bool has_type = false;
         cmn::meta_encoding_t context_encoding = cmn::meta_encoding_t::gray;
