@@ -632,6 +632,7 @@ def compact_line(out, sec):
     roof_keys = ("bound", "achieved", "peak", "unit", "frac", "traffic", "avg_launch_us", "launches", "mfma_issue_frac")
     r = out["roofline"]
     o["roofline"] = {"kernel": r["kernel"].split(" ")[0], **_pick(r, roof_keys)}
+    o["roofline"]["frac"] = o["roofline"]["achieved"] / o["roofline"]["peak"] if o["roofline"]["peak"] else 0.0    # consistent with the rounded `achieved`
     if "roofline_kernels" in out:
         o["roofline_kernels"] = {k: {"kernel": v["kernel"].split(" ")[0], **_pick(v, ("achieved", "frac", "traffic", "avg_launch_us"))} for k, v in out["roofline_kernels"].items()}
     det_keys = ("achieved", "peak", "frac", "traffic", "avg_launch_us", "frac_algorithmic_bytes", "whole_detect_pass_us", "whole_detect_pass_frac",

@@ -38,7 +38,7 @@ def test_default_line_has_the_contract_keys():
     for k in ("value", "unit", "cores", "kind", "sample"):
         assert k in c, k
     assert c["kind"] in ("port", "reference") and c["value"] > 0 and c["cores"] >= 1
-    assert abs(j["value"] - 16 * 2 / (j["ms_per_step"] * 2e-3)) / j["value"] < 1e-6      # value = frames of the timed steps / their time
+    assert abs(j["value"] - 16 * 2 / (j["ms_per_step"] * 2e-3)) / j["value"] < 1e-4      # value = frames of the timed steps / their time
 
 
 def test_detect_only_line_reports_an_hbm_roofline():
@@ -60,7 +60,7 @@ def test_two_rank_launch_on_one_gpu_runs_the_gather_path():
     assert j["n_gpus"] == 2 and j["scaling"] == "weak" and j["config"]["gather"].startswith("libtrexhip")
     assert len(out.stdout.strip().splitlines()[-1]) < 4096
     assert j["dist"]["ranks_seen"] == 2 and j["dist"]["gather_bytes_per_step"] > 0 and j["dist"]["ms_per_step_min"] <= j["dist"]["ms_per_step_max"]
-    assert abs(j["value"] - 2 * 16 * 2 / (j["ms_per_step"] * 2e-3)) / j["value"] < 1e-6      # whole-job frames / slowest rank's time
+    assert abs(j["value"] - 2 * 16 * 2 / (j["ms_per_step"] * 2e-3)) / j["value"] < 1e-4      # whole-job frames / slowest rank's time
 
 
 def test_gpus_flag_spawns_its_own_ranks():
@@ -72,7 +72,7 @@ def test_gpus_flag_spawns_its_own_ranks():
         pytest.skip("RCCL cannot run two ranks on one GPU here")
     assert out.returncode == 0, out.stderr[-3000:]
     j = json.loads([l for l in out.stdout.strip().splitlines() if l.startswith("{")][-1])
-    assert j["n_gpus"] == 2 and abs(j["value"] - 2 * 16 * 2 / (j["ms_per_step"] * 2e-3)) / j["value"] < 1e-6
+    assert j["n_gpus"] == 2 and abs(j["value"] - 2 * 16 * 2 / (j["ms_per_step"] * 2e-3)) / j["value"] < 1e-4
 
 
 def test_a_launcher_that_started_the_wrong_number_of_ranks_is_an_error():
@@ -128,4 +128,4 @@ def test_strong_scaling_path_on_one_gpu(n):
     j = json.loads([l for l in out.stdout.strip().splitlines() if l.startswith("{")][-1])
     assert j["n_gpus"] == n and j["scaling"] == "strong" and j["config"]["frames_per_step_per_gpu"] == 16 // n
     assert j["config"]["gather"].startswith("libtrexhip") and j["dist"]["ranks_seen"] == n
-    assert abs(j["value"] - 16 * 3 / (j["ms_per_step"] * 3e-3)) / j["value"] < 1e-6        # whole-job frames (the batch is split, not multiplied)
+    assert abs(j["value"] - 16 * 3 / (j["ms_per_step"] * 3e-3)) / j["value"] < 1e-4        # whole-job frames (the batch is split, not multiplied)
