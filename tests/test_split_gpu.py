@@ -40,7 +40,7 @@ def device_search(frames, bg, presumed_of, method=1, ranges=(), detect_threshold
 @pytest.mark.parametrize("method,ranges", [(1, [(40, 330)]), (0, []), (1, [(30, 120), (200, 330)])])
 def test_search_equals_oracle(algorithm, method, ranges):
     frames, bgs = [], None
-    for s in range(4):
+    for s in range(8):
         fr, bg, _ = merged_scene(40 + s + 10 * algorithm)
         frames.append(fr); bgs = bg
     frames = np.stack(frames)
