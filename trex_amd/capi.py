@@ -8,7 +8,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libtrexhip.so")
+LIB_PATH = os.environ.get("TREXHIP_LIB_PATH") or os.path.join(_HERE, "libtrexhip.so")      # (the override: dev builds of tools/build_dev.sh)
 _LIB = None
 
 RUN_DTYPE = np.dtype([("x0", "<u2"), ("x1", "<u2"), ("y", "<u2"), ("pad", "<u2")])

@@ -1035,6 +1035,7 @@ __global__ __launch_bounds__((WinoGeom<CI, CO, S, TPW>::NTHR), (TPW == 1 ? 2 : 1
 }
 
 #include "cnn_wpre.h"
+#include "cnn_fused12.h"
 
 static constexpr int FC1_KSPLIT = 10;     // 12800 = 10 x 1280: 500 workgroups at 6400 crops (5: 129 us, 10: 92 us, 20: 102 us + slower head); partial planes summed in k_head
 // ------------------------------------------------------------------------------------------------
@@ -1655,6 +1656,16 @@ static int net_forward_launch(trexhip_ctx* ctx, const uint8_t* d_crops, int n, f
 #define W2BA(D_) W2BAS(D_, 5)
 #define W2BAS(D_, S_) TH_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv2_wpre2<D_, S_>), hipFuncAttributeMaxDynamicSharedMemorySize, W2bGeom::LDS_BYTES))
         W3A(0); W2BA(0);
+#define F12A(D_) TH_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv12_wpre<D_>), hipFuncAttributeMaxDynamicSharedMemorySize, W12Geom::LDS_BYTES))
+        F12A(0);
+#ifdef TREXHIP_DEV_KNOBS
+        F12A(1); F12A(2); F12A(4); F12A(8); F12A(16); F12A(24); F12A(32); F12A(40); F12A(56);
+        TH_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv12_wpre<0, 0x033>), hipFuncAttributeMaxDynamicSharedMemorySize, W12Geom::LDS_BYTES));
+        TH_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv12_wpre<0, 0x333>), hipFuncAttributeMaxDynamicSharedMemorySize, W12Geom::LDS_BYTES));
+        TH_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv12_wpre<0, 0x000>), hipFuncAttributeMaxDynamicSharedMemorySize, W12Geom::LDS_BYTES));
+        TH_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv12_wpre<0, 0x123>), hipFuncAttributeMaxDynamicSharedMemorySize, W12Geom::LDS_BYTES));
+#endif
+#undef F12A
 #ifdef TREXHIP_DEV_KNOBS
         W2BA(1); W2BA(2); W2BA(3); W2BA(7); W2BA(15);
         W3A(1); W3A(2); W3A(3); W3A(7); W3A(15); W3A(16); W3AB(0, 3); W3AB(0, 5); W3A(64); W3A(128); TH_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv5_wpre<0, 7, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (WinoGeom<64, 128, 20, 2>::LDS_BYTES)));
@@ -1689,7 +1700,10 @@ static int net_forward_launch(trexhip_ctx* ctx, const uint8_t* d_crops, int n, f
     // geometry bits of TREXHIP_CONV_GEOM (bit 11 = nothing else) selects the fp32-activation chain of rounds 1-2 instead.
     const bool pre = mode == TREXHIP_CNN_FP16X3 && aligned && (ctx->tune_conv_geom & 0xfff) == 0;
     if (mode == TREXHIP_CNN_FP16X3) TH_CHECK_HIP(hipMemsetAsync(net->d_ovf, 0, 16, s));    // [0] fp16 range flag, [1] / [2] pass counters of the persistent conv3 / conv2
-    if (pre) {
+    // one input channel: conv1 runs INSIDE conv2 (cnn_fused12.h: the V2 image stays in LDS); TREXHIP_CONV_GEOM bit 28 keeps the two kernels
+    const bool fused12 = pre && net->CH == 1 && !(ctx->tune_conv_geom & (1 << 28));
+    if (fused12) { }
+    else if (pre) {
         if (net->CH == 1) hipLaunchKernelGGL((k_conv1_wpre<1>), dim3(n), dim3(256), 0, s, d_crops, net->w1h, net->b1, net->v2, net->inv1h, net->d_ovf);
         else              hipLaunchKernelGGL((k_conv1_wpre<3>), dim3(n), dim3(256), 0, s, d_crops, net->w1h, net->b1, net->v2, net->inv1h, net->d_ovf);
     }
@@ -1706,7 +1720,25 @@ static int net_forward_launch(trexhip_ctx* ctx, const uint8_t* d_crops, int n, f
                                      : n * (ConvGeomB<CI_, CO_, S_, ROWS_, SplitK<KIND_>::NP, CIC_>::BPC)),                                          \
                        dim3(512), (ConvGeomB<CI_, CO_, S_, ROWS_, SplitK<KIND_>::NP, CIC_>::LDS_BYTES), s, in_, w_, b_, out_, sc_, net->d_ovf, guard_, \
                        n * (ConvGeomB<CI_, CO_, S_, ROWS_, SplitK<KIND_>::NP, CIC_>::BPC))
-    if (pre) {
+    if (fused12) {
+        const int n_pass = (n * 20 + W2bGeom::RPP - 1) / W2bGeom::RPP;
+        const int wgs = 2 * ctx->n_cus, want = (n_pass + 7) / 8;          // 8 passes per ticket
+#define F12K(D_) hipLaunchKernelGGL((k_conv12_wpre<D_>), dim3(want < wgs ? want : wgs), dim3(256), W12Geom::LDS_BYTES, s, d_crops, net->w1h, net->b1, net->inv1h, \
+                           net->w2w, net->b2, net->v3, net->inv2w, net->d_ovf, n, net->d_ovf + 2)
+#ifdef TREXHIP_DEV_KNOBS   // ablations: TREXHIP_F12_DBG = 1 no crop loads, 2 no conv1 MFMAs, 4 no P2 transform, 8 no production, 16 no epilogue, 32 no tap loop
+        static const int f12_dbg = std::getenv("TREXHIP_F12_DBG") ? std::atoi(std::getenv("TREXHIP_F12_DBG")) : 0;
+        switch (f12_dbg) { case 1: F12K(1); break; case 2: F12K(2); break; case 4: F12K(4); break; case 8: F12K(8); break; case 16: F12K(16); break; case 24: F12K(24); break; case 32: F12K(32); break; case 40: F12K(40); break; case 56: F12K(56); break;
+            case 100: hipLaunchKernelGGL((k_conv12_wpre<0, 0x033>), dim3(want < wgs ? want : wgs), dim3(256), W12Geom::LDS_BYTES, s, d_crops, net->w1h, net->b1, net->inv1h, net->w2w, net->b2, net->v3, net->inv2w, net->d_ovf, n, net->d_ovf + 2); break;
+            case 101: hipLaunchKernelGGL((k_conv12_wpre<0, 0x333>), dim3(want < wgs ? want : wgs), dim3(256), W12Geom::LDS_BYTES, s, d_crops, net->w1h, net->b1, net->inv1h, net->w2w, net->b2, net->v3, net->inv2w, net->d_ovf, n, net->d_ovf + 2); break;
+            case 102: hipLaunchKernelGGL((k_conv12_wpre<0, 0x000>), dim3(want < wgs ? want : wgs), dim3(256), W12Geom::LDS_BYTES, s, d_crops, net->w1h, net->b1, net->inv1h, net->w2w, net->b2, net->v3, net->inv2w, net->d_ovf, n, net->d_ovf + 2); break;
+            case 103: hipLaunchKernelGGL((k_conv12_wpre<0, 0x123>), dim3(want < wgs ? want : wgs), dim3(256), W12Geom::LDS_BYTES, s, d_crops, net->w1h, net->b1, net->inv1h, net->w2w, net->b2, net->v3, net->inv2w, net->d_ovf, n, net->d_ovf + 2); break;
+            default: F12K(0); }
+#else
+        F12K(0);
+#endif
+#undef F12K
+    }
+    else if (pre) {
         // two workgroups per CU, one M-tile per wave, operand planes fetched by LDS-DMA during the epilogue
         const int n_pass = (n * 20 + W2bGeom::RPP - 1) / W2bGeom::RPP;
 #define W2K(D_) W2KS(D_, 5)
