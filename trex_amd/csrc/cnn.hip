@@ -1722,16 +1722,20 @@ static int net_forward_launch(trexhip_ctx* ctx, const uint8_t* d_crops, int n, f
                        n * (ConvGeomB<CI_, CO_, S_, ROWS_, SplitK<KIND_>::NP, CIC_>::BPC))
     if (fused12) {
         const int n_pass = (n * 20 + W2bGeom::RPP - 1) / W2bGeom::RPP;
-        const int wgs = 2 * ctx->n_cus, want = (n_pass + 7) / 8;          // 8 passes per ticket
+        const int wgs = 2 * ctx->n_cus;
+        // passes per ticket: long tickets save the 4 extra rows of a ticket's first pass, short ones keep every workgroup busy when the batch is small
+        static const int pk_env = std::getenv("TREXHIP_F12_PK") ? std::atoi(std::getenv("TREXHIP_F12_PK")) : 0;
+        const int pk = pk_env > 0 ? pk_env : std::max(1, std::min(16, n_pass / (wgs * 4)));
+        const int want = (n_pass + pk - 1) / pk;
 #define F12K(D_) hipLaunchKernelGGL((k_conv12_wpre<D_>), dim3(want < wgs ? want : wgs), dim3(256), W12Geom::LDS_BYTES, s, d_crops, net->w1h, net->b1, net->inv1h, \
-                           net->w2w, net->b2, net->v3, net->inv2w, net->d_ovf, n, net->d_ovf + 2)
+                           net->w2w, net->b2, net->v3, net->inv2w, net->d_ovf, n, net->d_ovf + 2, pk)
 #ifdef TREXHIP_DEV_KNOBS   // ablations: TREXHIP_F12_DBG = 1 no crop loads, 2 no conv1 MFMAs, 4 no P2 transform, 8 no production, 16 no epilogue, 32 no tap loop
         static const int f12_dbg = std::getenv("TREXHIP_F12_DBG") ? std::atoi(std::getenv("TREXHIP_F12_DBG")) : 0;
         switch (f12_dbg) { case 1: F12K(1); break; case 2: F12K(2); break; case 4: F12K(4); break; case 8: F12K(8); break; case 16: F12K(16); break; case 24: F12K(24); break; case 32: F12K(32); break; case 40: F12K(40); break; case 56: F12K(56); break;
-            case 100: hipLaunchKernelGGL((k_conv12_wpre<0, 0x033>), dim3(want < wgs ? want : wgs), dim3(256), W12Geom::LDS_BYTES, s, d_crops, net->w1h, net->b1, net->inv1h, net->w2w, net->b2, net->v3, net->inv2w, net->d_ovf, n, net->d_ovf + 2); break;
-            case 101: hipLaunchKernelGGL((k_conv12_wpre<0, 0x333>), dim3(want < wgs ? want : wgs), dim3(256), W12Geom::LDS_BYTES, s, d_crops, net->w1h, net->b1, net->inv1h, net->w2w, net->b2, net->v3, net->inv2w, net->d_ovf, n, net->d_ovf + 2); break;
-            case 102: hipLaunchKernelGGL((k_conv12_wpre<0, 0x000>), dim3(want < wgs ? want : wgs), dim3(256), W12Geom::LDS_BYTES, s, d_crops, net->w1h, net->b1, net->inv1h, net->w2w, net->b2, net->v3, net->inv2w, net->d_ovf, n, net->d_ovf + 2); break;
-            case 103: hipLaunchKernelGGL((k_conv12_wpre<0, 0x123>), dim3(want < wgs ? want : wgs), dim3(256), W12Geom::LDS_BYTES, s, d_crops, net->w1h, net->b1, net->inv1h, net->w2w, net->b2, net->v3, net->inv2w, net->d_ovf, n, net->d_ovf + 2); break;
+            case 100: hipLaunchKernelGGL((k_conv12_wpre<0, 0x033>), dim3(want < wgs ? want : wgs), dim3(256), W12Geom::LDS_BYTES, s, d_crops, net->w1h, net->b1, net->inv1h, net->w2w, net->b2, net->v3, net->inv2w, net->d_ovf, n, net->d_ovf + 2, pk); break;
+            case 101: hipLaunchKernelGGL((k_conv12_wpre<0, 0x333>), dim3(want < wgs ? want : wgs), dim3(256), W12Geom::LDS_BYTES, s, d_crops, net->w1h, net->b1, net->inv1h, net->w2w, net->b2, net->v3, net->inv2w, net->d_ovf, n, net->d_ovf + 2, pk); break;
+            case 102: hipLaunchKernelGGL((k_conv12_wpre<0, 0x000>), dim3(want < wgs ? want : wgs), dim3(256), W12Geom::LDS_BYTES, s, d_crops, net->w1h, net->b1, net->inv1h, net->w2w, net->b2, net->v3, net->inv2w, net->d_ovf, n, net->d_ovf + 2, pk); break;
+            case 103: hipLaunchKernelGGL((k_conv12_wpre<0, 0x123>), dim3(want < wgs ? want : wgs), dim3(256), W12Geom::LDS_BYTES, s, d_crops, net->w1h, net->b1, net->inv1h, net->w2w, net->b2, net->v3, net->inv2w, net->d_ovf, n, net->d_ovf + 2, pk); break;
             default: F12K(0); }
 #else
         F12K(0);

@@ -26,12 +26,12 @@ struct W12Geom {
     static_assert(2 * (LDS_BYTES + 64) <= 160 * 1024, "two workgroups per CU");
 };
 
-template <int DBG = 0, int PRIO = 0x030, int STAGGER = 5, int AD = 1, int BD = 3, int PK = 8>      // PRIO: s_setprio of (P2, tap loop, P1) as hex digits      // DBG (dev builds): 1 no crop loads, 2 no conv1 MFMAs, 4 no P2 transform, 8 no production at all, 16 no epilogue, 32 no tap loop
+template <int DBG = 0, int PRIO = 0x030, int STAGGER = 5, int AD = 1, int BD = 3>      // PRIO: s_setprio of (P2, tap loop, P1) as hex digits      // DBG (dev builds): 1 no crop loads, 2 no conv1 MFMAs, 4 no P2 transform, 8 no production at all, 16 no epilogue, 32 no tap loop
 __global__ __launch_bounds__(256, 2) void k_conv12_wpre(const uint8_t* __restrict__ crops /*[N][80][80]*/, const uint4* __restrict__ w1tab /*[16][64]*/,
                                                         const float* __restrict__ bias1, const float inv_scale1,
                                                         const uint4* __restrict__ wp /*[5][8][2][2][64] x 16 B*/, const float* __restrict__ bias,
                                                         uint8_t* __restrict__ v3, const float out_scale, uint32_t* __restrict__ overflow,
-                                                        const int n_crops, uint32_t* __restrict__ pass_ctr) {
+                                                        const int n_crops, uint32_t* __restrict__ pass_ctr, const int PK /* consecutive passes per ticket: the first one produces 10 rows, the others 6 */) {
     using G = W2bGeom;
     using F = W12Geom;
     constexpr int CO = 64, S = 40;
@@ -86,14 +86,15 @@ __global__ __launch_bounds__(256, 2) void k_conv12_wpre(const uint8_t* __restric
             wpre_dma16(crops_u, (uint32_t)((crop * 80 + iyc) * 80 + u * 16), raw_lds + (uint32_t)(wave * 1024));
         }
     };
-    auto produce = [&](const int lo, const int hi, const bool first_from_raw) {
-        for (int c0 = (DBG & 8) ? hi : lo; c0 < hi; c0 += F::CHUNK) {
-            const int nr = hi - c0 < F::CHUNK ? hi - c0 : F::CHUNK;
-            const bool from_raw = first_from_raw && c0 == lo;
-            // the four base fragments of conv1's weights (shift 0: kernel rows 0..3 | row 4, piece hi | lo); the shifted ones are made of them in P1
-            uint4 bf0[4];
+    // Production of the V2 rows [c0, c0 + nr) (nr <= CHUNK) in three phases with a barrier between them:
+    //   p0  their crop rows (from raw when the LDS-DMA prefetch fetched them, else straight from the crop) -> fp16 -> img; also issues the
+    //       loads of conv1's four base weight fragments (shift 0: kernel rows 0..3 | row 4, piece hi | lo), used by p1
+    //   p1  conv1 tiles on the matrix cores -> pooled activations in pbuf
+    //   p2  B^T d, fp16 pieces -> the ring slots (q % NR + 1) of the four operand planes
+    auto p0 = [&](const int c0, const int nr, const bool from_raw, uint4 (&bf0)[4]) {
 #pragma unroll
-            for (int f = 0; f < 4; ++f) bf0[f] = w1tab[f * 64 + lane];
+        for (int f = 0; f < 4; ++f) bf0[f] = w1tab[f * 64 + lane];
+        {
             // P0: crop rows -> img: one 16-byte unit (from raw, or straight from the crop), 16 halves
             for (int it = tid; it < nr * 30; it += 256) {
                 W12_ITEM(it, c0)
@@ -110,7 +111,10 @@ __global__ __launch_bounds__(256, 2) void k_conv12_wpre(const uint8_t* __restric
                     d[e] = pack_h2((_Float16)(float)b0, (_Float16)(float)b1);
                 }
             }
-            __syncthreads();
+        }
+    };
+    auto p1 = [&](const int nr, const uint4 (&bf0)[4]) {
+        {
             // P1: conv1 tiles (8 windows of 4 outputs x 2 image rows; 20 windows per V2 row), wave w takes tiles w, w + 4, ...
             {
                 const int r = lane & 15, q4 = lane >> 4;
@@ -127,7 +131,6 @@ __global__ __launch_bounds__(256, 2) void k_conv12_wpre(const uint8_t* __restric
                     bf[12 + f] = make_uint4(0u, b.x << 16, __builtin_amdgcn_alignbit(b.y, b.x, 16), __builtin_amdgcn_alignbit(b.z, b.y, 16));
                 }
                 const int n_win = nr * 20, n_tiles = (n_win + 7) >> 3;
-                if (PRIO & 0xf) __builtin_amdgcn_s_setprio(PRIO & 0xf);
                 for (int tile = wave; tile < n_tiles; tile += 4) {
                     int wdx = tile * 8 + (r >> 1);
                     wdx = wdx < n_win ? wdx : n_win - 1;
@@ -170,9 +173,10 @@ __global__ __launch_bounds__(256, 2) void k_conv12_wpre(const uint8_t* __restric
                     }
                 }
             }
-            if (PRIO & 0xf) __builtin_amdgcn_s_setprio(0);
-            __syncthreads();
-            if (PRIO >> 8) __builtin_amdgcn_s_setprio(PRIO >> 8);
+        }
+    };
+    auto p2 = [&](const int c0, const int nr) {
+        {
             // P2: (V2 row v, conv2 tile tx, channel quad): 8 pooled pixels x 4 channels -> B^T d -> pieces -> the planes
             if (!(DBG & 4) && tid < nr * 40) {
                 const int v = tid / 40, rem = tid - v * 40, tx = rem >> 2, quad = rem & 3;
@@ -206,7 +210,17 @@ __global__ __launch_bounds__(256, 2) void k_conv12_wpre(const uint8_t* __restric
                     *reinterpret_cast<uint2*>(dst + G::PLANE) = make_uint2(m0, m1);
                 }
             }
-            if (PRIO >> 8) __builtin_amdgcn_s_setprio(0);
+        }
+    };
+    // rows [lo, hi) chunk by chunk; the first chunk's p0 has already run when first_done.  Ends with a barrier: the rows are complete
+    auto produce = [&](const int lo, const int hi, const bool first_done, uint4 (&bf0)[4]) {
+        for (int c0 = (DBG & 8) ? hi : lo; c0 < hi; c0 += F::CHUNK) {
+            const int nr = hi - c0 < F::CHUNK ? hi - c0 : F::CHUNK;
+            if (!(first_done && c0 == lo)) p0(c0, nr, false, bf0);
+            __syncthreads();
+            p1(nr, bf0);
+            __syncthreads();
+            p2(c0, nr);
             __syncthreads();
         }
     };
@@ -218,7 +232,10 @@ __global__ __launch_bounds__(256, 2) void k_conv12_wpre(const uint8_t* __restric
     int qmin, nrows;
     W2B_ROWS(pass, qmin, nrows);
     __syncthreads();
-    produce(qmin, qmin + nrows, false);
+    {
+        uint4 bf0[4];
+        produce(qmin, qmin + nrows, false, bf0);
+    }
     int res_hi = qmin + nrows;                                           // rows [this pass's qmin, res_hi) are resident
     if (tid == 0) s_next_pass = ((int)atomicAdd(pass_ctr, 1u) + (int)gridDim.x) * PK;
     __syncthreads();
@@ -337,7 +354,9 @@ __global__ __launch_bounds__(256, 2) void k_conv12_wpre(const uint8_t* __restric
                 }
             }
         }
-        __syncthreads();
+        __syncthreads();                                                  // the activations are in pbuf
+        uint4 bf0[4];
+        const int hi_new = qmin_n + nrows_n;
         // epilogue 2: (pooled row, conv3 tile, channel quad) items -> V3
         if (!(DBG & 16) && tid < 240) {
             const int rp = tid / 80, rem = tid - rp * 80, tx = rem >> 4, quad = rem & 15;
@@ -367,11 +386,15 @@ __global__ __launch_bounds__(256, 2) void k_conv12_wpre(const uint8_t* __restric
             }
         }
         if (!have_next) break;
-        asm volatile("s_waitcnt vmcnt(0)" : "+v"(ticket) :: "memory");    // this wave's crop rows have landed in raw (and its ticket is back)
-        __syncthreads();                                                  // everybody has read its activations out of pbuf; raw is complete
-        produce(lo_new, qmin_n + nrows_n, true);                          // (ends with a barrier: the next pass's planes are complete)
+        // the first chunk of the next pass's rows starts here: every lane converts the crop-row unit its OWN LDS-DMA fetched (item = thread
+        // index in prefetch and in p0 alike), so no barrier stands between the fetch and the conversion -- only the wave's own counter: the 16
+        // V3 stores of epilogue 2 were issued behind the DMA and may stay in flight
+        asm volatile("s_waitcnt vmcnt(16)" : "+v"(ticket) :: "memory");
+        if (!(DBG & 8)) p0(lo_new, hi_new - lo_new < F::CHUNK ? hi_new - lo_new : F::CHUNK, true, bf0);
+        produce(lo_new, hi_new, true, bf0);                               // (starts with the barrier behind epilogue 2 / p0, ends with one: the planes are complete)
         res_hi = qmin_n + nrows_n;
         if (draw) {
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(ticket) :: "memory");
             if (tid == 0) s_next_pass = ((int)ticket + (int)gridDim.x) * PK;       // read behind a later pass's first barrier
         }
         pass = next_pass; qmin = qmin_n; nrows = nrows_n;
