@@ -201,6 +201,50 @@ def test_noise_frame_in_the_last_slot_overflows_gracefully():
     seg.close()
 
 
+@pytest.mark.parametrize("kind", ["many_small", "one_huge", "mixed", "edge"])
+def test_frames_with_5k_to_8k_lines_are_labelled_in_lds(kind):
+    # k_ccl_lds holds up to 8160 lines of a frame (a 4096 x 4096 frame of 256 individuals has ~7.7 k); more go to the global-memory chain.
+    # Line counts on both sides of the old (5120) and the new limit, with every grouping strategy: many 1-line blobs (as many raw blobs as
+    # lines), one blob of thousands of lines (the whole-frame bitonic sort at 8192 keys), a mix, and counts right at the limit
+    rng = np.random.default_rng(17)
+    W, H = 1024, 2048
+    bg = np.full((H, W), 120, np.uint8)
+    frames = []
+    if kind == "many_small":
+        for n_lines in (5200, 6500, 8100):
+            f = bg.copy()
+            ys = rng.permutation(H // 2)[:n_lines // 8] * 2          # 8 separate 1-line blobs on every other row
+            for y in ys:
+                for j in range(8):
+                    f[y, 10 + 100 * j: 10 + 100 * j + int(rng.integers(1, 60))] = 10
+            frames.append(f)
+    elif kind == "one_huge":
+        for n_rows in (1800, 2040):
+            f = bg.copy()
+            f[4:4 + n_rows, 100:110] = 10                           # a 1800-line column ...
+            for y in range(4, 4 + n_rows): f[y, 300:300 + int(rng.integers(1, 40))] = 10; f[y, 500:520] = 10; f[y, 700:705] = 10
+            f[4:4 + n_rows:7, 110:300] = 10                          # ... that joins some of the combs
+            frames.append(f)
+    elif kind == "mixed":
+        for dens in (0.0025, 0.0033):
+            f, b2 = synth.random_scene(rng, W, H, density=0.02)
+            f = bg.copy(); m = rng.random((H, W)) < dens; f[m] = 5
+            f[100:700, 50:60] = 5
+            frames.append(f)
+    else:
+        for n_lines in (8159, 8160, 8161, 8192):                     # at, and just past, the capacity (the rest take the global chain)
+            f = bg.copy()
+            k = 0
+            for y in range(0, H, 1):
+                for j in range(4):
+                    if k < n_lines: f[y, 8 + 200 * j: 8 + 200 * j + 3 + (y % 5)] = 10; k += 1
+            frames.append(f)
+    res = run_gpu(np.stack(frames), bg, max_runs=20000, max_blobs=16384, max_pixels=1 << 21)
+    for r, fr in zip(res, frames):
+        assert 5000 < r.info["n_raw_runs"] < 9000, r.info["n_raw_runs"]
+        assert_frame_equal(r, fr, bg)
+
+
 def test_live_settings_take_effect_on_the_next_call():
     # the reference re-reads cm_per_pixel / detect_size_filter and the thresholds on every apply() (BackgroundSubtraction.cpp:137-143):
     # trexhip_update_params changes them on a living context, results equal a context created with those values

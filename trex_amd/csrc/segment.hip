@@ -818,12 +818,16 @@ __global__ __launch_bounds__(256) void k_blobs(const SegCfg c, const int only_pe
 // k_ccl_lds: the whole run-level pipeline of one frame inside one workgroup's LDS (1024 threads):
 // row scan -> runs to raster order -> link with the row above (union-find, LDS atomics) -> flatten ->
 // blob numbering / counts -> size filter + offsets -> pooled reservation -> stable grouping of the runs
-// by blob with one bitonic sort of (kept blob index << 13 | raster index).  Frames with more than
-// CCL_NMAX runs are marked pending (info.reserved[0] = 1) and finished by the global-memory chain above.
+// by blob.  Frames with more than CCL_NMAX runs are marked pending (info.reserved[0] = 1) and finished by the global-memory chain above.
+// LDS (20 bytes per run: a 4096 x 4096 frame of 256 individuals carries ~7.7 k runs and fits): s_run, s_par (union-find parent -> root ->
+// raw blob ordinal), s_y, s_seg (u16: the runs grouped by blob) and two general arrays that change their role phase by phase:
+//   s_a  row bases (P1..P3) | runs per raw blob (P5) | runs | first slot of the blob's segment << 16 (P6..) | sort keys (large blobs)
+//   s_b  flatten scratch (P4) | ordinal of a root run (P5a) | pixels per raw blob (P5b) | kept index or ~0 (P6, P7) | segment cursor or ~0
 // ---------------------------------------------------------------------------------------------
-static constexpr int CCL_NMAX = 5120;
-static constexpr int CCL_SORT = 8192;
-static constexpr int CCL_LDS_BYTES = CCL_NMAX * (4 + 4 + 4 + 4 + 4) + CCL_NMAX * 2 + CCL_SORT * 4 + 256;
+static constexpr int CCL_NMAX = 8160;               // runs per frame (16-bit fields: < 65536; the arrays below + 256 B must fit 160 KB)
+static constexpr int CCL_SORT = 8192;               // s_a: row bases of up to 8191 rows; power of two for the bitonic sort
+static constexpr int CCL_LDS_BYTES = CCL_NMAX * (4 + 4 + 4 + 2 + 2) + CCL_SORT * 4 + 256;
+static_assert(CCL_LDS_BYTES <= 160 * 1024, "k_ccl_lds: LDS");
 
 __device__ __forceinline__ uint32_t lds_find(volatile uint32_t* par, uint32_t a) {
     uint32_t p = par[a];
@@ -863,14 +867,14 @@ __global__ __launch_bounds__(1024) void k_ccl_lds(const SegCfg c, uint32_t* __re
 #define CCL_STOP(n) do { } while (0)
 #endif
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
-    uint32_t* s_run = smem;                       // x0 | x1 << 16, raster order
-    uint32_t* s_par = s_run + CCL_NMAX;           // union-find parent -> label
-    uint32_t* s_ord = s_par + CCL_NMAX;           // root run -> raw blob ordinal
-    uint32_t* s_cr = s_ord + CCL_NMAX;            // runs per raw blob
-    uint32_t* s_cp = s_cr + CCL_NMAX;             // pixels per raw blob
-    uint32_t* s_key = s_cp + CCL_NMAX;            // sort keys [CCL_SORT]
-    uint32_t* s_misc = s_key + CCL_SORT;          // [64] scan scratch / broadcasts
+    uint32_t* s_a = smem;                         // [CCL_SORT] (see above)
+    uint32_t* s_run = s_a + CCL_SORT;             // x0 | x1 << 16, raster order
+    uint32_t* s_par = s_run + CCL_NMAX;           // union-find parent -> root run -> raw blob ordinal
+    uint32_t* s_b = s_par + CCL_NMAX;             // (see above)
+    uint32_t* s_misc = s_b + CCL_NMAX;            // [64] scan scratch / broadcasts
     uint16_t* s_y = reinterpret_cast<uint16_t*>(s_misc + 64);
+    uint16_t* s_seg = s_y + CCL_NMAX;             // raster indices of the kept runs, one segment per blob
+    uint32_t* s_key = s_a;                        // P1..P3: raster index of every row's first run
     const int f = blockIdx.x + f0, tid = threadIdx.x;
     const int H = c.H;
     const uint32_t* cnt = row_cnt + (size_t)f * H;
@@ -975,49 +979,58 @@ __global__ __launch_bounds__(1024) void k_ccl_lds(const SegCfg c, uint32_t* __re
     CCL_STOP(3);
     CCL_STAMP(3);
     // P4: flatten
-    for (uint32_t r = tid; r < n; r += 1024) { const uint32_t root = lds_find(s_par, r); s_key[r] = root; }
+    for (uint32_t r = tid; r < n; r += 1024) { const uint32_t root = lds_find(s_par, r); s_b[r] = root; }
     __syncthreads();
-    for (uint32_t r = tid; r < n; r += 1024) s_par[r] = s_key[r];
+    for (uint32_t r = tid; r < n; r += 1024) s_par[r] = s_b[r];
     __syncthreads();
     CCL_STOP(4);
     CCL_STAMP(4);
-    // P5: blob ordinals (raster order of the root run), runs / pixels per blob
+    // P5: blob ordinals (raster order of the root run) -> s_b at the roots; the run-level state of the re-threshold pass (root label, ordinal
+    // of a root) goes to global memory here, then every run's label becomes its blob's ordinal and s_a / s_b count runs / pixels per blob
     uint32_t nraw = 0;
     for (uint32_t b0 = 0; b0 < n; b0 += 1024) {
         const uint32_t r = b0 + tid;
         const uint32_t flag = (r < n && s_par[r] == r) ? 1u : 0u;
         uint32_t total;
         const uint32_t ex = block_excl_scan(flag, s_misc, total);
-        if (flag) s_ord[r] = nraw + ex;
+        if (flag) s_b[r] = nraw + ex;
         nraw += total;
     }
-    for (uint32_t o = tid; o < nraw; o += 1024) { s_cr[o] = 0; s_cp[o] = 0; }
     __syncthreads();
     for (uint32_t r = tid; r < n; r += 1024) {
-        const uint32_t o = s_ord[s_par[r]];
+        const uint32_t lab = s_par[r];
+        const uint32_t o = s_b[lab];
+        parent[fo + r] = lab;
+        if (lab == r) root_ord[fo + r] = o;
+        s_par[r] = o;                                      // (a thread reads and writes its own entry only; s_b stays as it is until the barrier)
+    }
+    __syncthreads();
+    for (uint32_t o = tid; o < nraw; o += 1024) { s_a[o] = 0; s_b[o] = 0; }
+    __syncthreads();
+    for (uint32_t r = tid; r < n; r += 1024) {
+        const uint32_t o = s_par[r];
         const uint32_t q = s_run[r];
-        atomicAdd(s_cr + o, 1u);
-        atomicAdd(s_cp + o, (q >> 16) - (q & 0xffffu) + 1u);
+        atomicAdd(s_a + o, 1u);
+        atomicAdd(s_b + o, (q >> 16) - (q & 0xffffu) + 1u);
     }
     __syncthreads();
     CCL_STOP(5);
     CCL_STAMP(5);
-    // P6: size filter, offsets of the kept blobs
+    // P6: size filter, offsets of the kept blobs.  s_a[o] = runs | first slot of the segment << 16 (both < 8192), s_b[o] = kept index or ~0
     uint32_t kept = 0, kruns = 0, kpx = 0;
-    uint32_t* cur = cur_run + fo;
     uint32_t* pbg = pix_begin + fo;
     int32_t* bmap = blob_map + fo;
     for (uint32_t b0 = 0; b0 < nraw; b0 += 1024) {
         const uint32_t o = b0 + tid;
         uint32_t nr = 0, np = 0, keep = 0;
-        if (o < nraw) { nr = s_cr[o]; np = s_cp[o]; keep = (size_ok(np, c) && nr < 65535u) ? 1u : 0u; }
+        if (o < nraw) { nr = s_a[o]; np = s_b[o]; keep = (size_ok(np, c) && nr < 65535u) ? 1u : 0u; }
         uint32_t ex3[3], tot3[3];
         block_excl_scan3(keep, keep ? nr : 0u, keep ? np : 0u, s_misc, ex3, tot3);
         const uint32_t e0 = ex3[0], e1 = ex3[1], e2 = ex3[2], t0 = tot3[0], t1 = tot3[1], t2 = tot3[2];
         if (o < nraw) {
             bmap[o] = keep ? (int32_t)(kept + e0) : -1;
-            s_cp[o] = keep ? (kept + e0) : 0xffffffffu;            // s_cp now = kept index (pixel counts no longer needed)
-            if (keep) { cur[o] = kruns + e1; pbg[o] = kpx + e2; }
+            s_b[o] = keep ? (kept + e0) : 0xffffffffu;
+            if (keep) { s_a[o] = nr | ((kruns + e1) << 16); pbg[o] = kpx + e2; }
         }
         kept += t0; kruns += t1; kpx += t2;
     }
@@ -1047,31 +1060,27 @@ __global__ __launch_bounds__(1024) void k_ccl_lds(const SegCfg c, uint32_t* __re
     }
     CCL_STOP(6);
     CCL_STAMP(6);
-    // P7: blob records, run-level state for later passes, stable grouping by one sort
+    // P7: blob records, raster-order runs for the re-threshold pass, largest kept blob (decides the grouping strategy, block-uniform)
+    uint32_t mx = 0;
     for (uint32_t o = tid; o < nraw; o += 1024) {
-        const uint32_t k = s_cp[o];
+        const uint32_t k = s_b[o];
         if (k == 0xffffffffu) continue;
+        const uint32_t a = s_a[o];
         trexhip_blob B = {};
-        B.run_begin = cur[o] + rbeg;      // POOLED offsets until k_gather makes them frame-relative
-        B.n_runs = s_cr[o];
-        B.pix_begin = pbg[o] + pb;
+        B.run_begin = (a >> 16) + rbeg;   // POOLED offsets until k_gather makes them frame-relative
+        B.n_runs = a & 0xffffu;
+        B.pix_begin = pbg[o] + pb;        // (written by this thread in P6)
         B.parent = 0xffffffffu;
         blobs[bb + k] = B;
         blob_frame[bb + k] = (uint32_t)f;
+        mx = max(mx, a & 0xffffu);
     }
-    // run-level state for the re-threshold pass
     for (uint32_t r = tid; r < n; r += 1024) {
-        const uint32_t lab = s_par[r];
         trexhip_run q; q.x0 = (uint16_t)(s_run[r] & 0xffffu); q.x1 = (uint16_t)(s_run[r] >> 16); q.y = s_y[r]; q.pad = 0;
         raster[fo + r] = q;
-        parent[fo + r] = lab;
-        if (lab == r) root_ord[fo + r] = s_ord[r];
     }
     CCL_STOP(7);
     CCL_STAMP(7);
-    // largest kept blob decides the grouping strategy (block-uniform)
-    uint32_t mx = 0;
-    for (uint32_t o = tid; o < nraw; o += 1024) if (s_cp[o] != 0xffffffffu) mx = max(mx, s_cr[o]);
     mx = wmax32(mx);
     __syncthreads();
     if ((tid & 63) == 0) s_misc[40 + (tid >> 6)] = mx;
@@ -1079,35 +1088,21 @@ __global__ __launch_bounds__(1024) void k_ccl_lds(const SegCfg c, uint32_t* __re
     mx = 0;
     for (int w = 0; w < 16; ++w) mx = max(mx, s_misc[40 + w]);
     trexhip_run* outr = out_runs + rbeg;
-    if (mx <= 512u && kept <= (uint32_t)(CCL_SORT - CCL_NMAX)) {
-        // (1) scatter raster indices into each blob's segment in arbitrary order (LDS atomics on a per-blob cursor),
-        // (2) one wave per blob ranks its runs by counting smaller raster indices -> sorted order, written straight out
-        uint32_t* s_cursor = s_ord;                               // s_ord is free once the keys are known
+    if (mx <= 512u) {
+        // (1) scatter raster indices into each blob's segment in arbitrary order (LDS atomics on a per-blob cursor: s_b becomes 0 for a
+        //     kept blob, stays ~0 for a dropped one), (2) every segment is sorted by raster index and written straight out
+        for (uint32_t o = tid; o < nraw; o += 1024) if (s_b[o] != 0xffffffffu) s_b[o] = 0u;
         __syncthreads();
-        uint32_t my_k[CCL_NMAX / 1024];                           // each thread keeps its runs' kept index (n <= 5*1024)
-#pragma unroll
-        for (int u = 0; u < CCL_NMAX / 1024; ++u) {
-            const uint32_t r = tid + u * 1024;
-            my_k[u] = r < n ? s_cp[s_ord[s_par[r]]] : 0xffffffffu;
-        }
-        __syncthreads();
-        for (uint32_t o = tid; o < nraw; o += 1024) { const uint32_t k = s_cp[o]; if (k != 0xffffffffu) { s_key[CCL_NMAX + k] = cur[o]; } }
-        __syncthreads();
-        // s_key[CCL_NMAX + k] = segment begin of kept blob k (kept <= CCL_SORT - CCL_NMAX is checked below)
-        for (uint32_t k = tid; k < kept; k += 1024) s_cursor[k] = 0;
-        __syncthreads();
-#pragma unroll
-        for (int u = 0; u < CCL_NMAX / 1024; ++u) {
-            const uint32_t r = tid + u * 1024;
-            const uint32_t k = my_k[u];
-            if (k == 0xffffffffu) continue;
-            const uint32_t slot = atomicAdd(s_cursor + k, 1u);
-            s_key[s_key[CCL_NMAX + k] + slot] = r;               // segment storage: s_key[0 .. kruns)
+        for (uint32_t r = tid; r < n; r += 1024) {
+            const uint32_t o = s_par[r];
+            if (s_b[o] == 0xffffffffu) continue;
+            const uint32_t slot = atomicAdd(s_b + o, 1u);
+            s_seg[(s_a[o] >> 16) + slot] = (uint16_t)r;
         }
         __syncthreads();
         CCL_STAMP(9);
-        // (2) every blob's segment is sorted by raster index: an in-register bitonic network per blob -- two blobs per wave (32
-        //     lanes each) when both have at most 32 lines, one per wave up to 64 lines, rank-by-counting through LDS beyond that
+        // (2) an in-register bitonic network per blob -- two blobs per wave (32 lanes each) when both have at most 32 lines, one per wave
+        //     up to 64 lines, rank-by-counting through LDS beyond that.  The waves walk the RAW ordinals; a dropped blob counts 0 lines
         const uint32_t lane = tid & 63, wave = tid >> 6;
 #define CCL_SORT_STEP(kk_, jj_) { const uint32_t o_ = (uint32_t)__shfl_xor((int)v, jj_); const bool lo_ = ((lane & (jj_)) == 0) == ((lane & (kk_)) == 0); v = lo_ ? min(v, o_) : max(v, o_); }
 #define CCL_SORT32(v)                                                                                                   \
@@ -1120,13 +1115,14 @@ __global__ __launch_bounds__(1024) void k_ccl_lds(const SegCfg c, uint32_t* __re
                 outr[beg + e] = q;
             }
         };
-        for (uint32_t k0 = wave * 2; k0 < kept; k0 += 32) {
-            const uint32_t cA = s_cursor[k0], cB = k0 + 1 < kept ? s_cursor[k0 + 1] : 0u;
+        for (uint32_t k0 = wave * 2; k0 < nraw; k0 += 32) {
+            const uint32_t aA = s_b[k0] != 0xffffffffu ? s_a[k0] : 0u;
+            const uint32_t aB = (k0 + 1 < nraw && s_b[k0 + 1] != 0xffffffffu) ? s_a[k0 + 1] : 0u;
+            const uint32_t cA = aA & 0xffffu, cB = aB & 0xffffu;
             if (cA <= 32u && cB <= 32u) {
-                const uint32_t k = k0 + (lane >> 5), e = lane & 31u;
-                const bool live = k < kept;
-                const uint32_t beg = live ? s_key[CCL_NMAX + k] : 0u, cntk = live ? (lane < 32 ? cA : cB) : 0u;
-                uint32_t v = e < cntk ? s_key[beg + e] : 0xffffffffu;
+                const uint32_t e = lane & 31u;
+                const uint32_t beg = (lane < 32 ? aA : aB) >> 16, cntk = lane < 32 ? cA : cB;
+                uint32_t v = e < cntk ? (uint32_t)s_seg[beg + e] : 0xffffffffu;
                 // lanes 32..63 sort ascending as well: the direction bit of the last stage (lane & 32) is flipped for them
                 CCL_SORT_STEP(2, 1) CCL_SORT_STEP(4, 2) CCL_SORT_STEP(4, 1) CCL_SORT_STEP(8, 4) CCL_SORT_STEP(8, 2) CCL_SORT_STEP(8, 1)
                 CCL_SORT_STEP(16, 8) CCL_SORT_STEP(16, 4) CCL_SORT_STEP(16, 2) CCL_SORT_STEP(16, 1)
@@ -1137,19 +1133,21 @@ __global__ __launch_bounds__(1024) void k_ccl_lds(const SegCfg c, uint32_t* __re
                 { const uint32_t o_ = (uint32_t)__shfl_xor((int)v, 1);  v = (lane & 1) == 0 ? min(v, o_) : max(v, o_); }
                 emit(beg, e, cntk, v);
             } else {
-                for (uint32_t k = k0; k < k0 + 2 && k < kept; ++k) {
-                    const uint32_t beg = s_key[CCL_NMAX + k], cntk = k == k0 ? cA : cB;
+                for (uint32_t k = k0; k < k0 + 2 && k < nraw; ++k) {
+                    const uint32_t a = k == k0 ? aA : aB;
+                    const uint32_t beg = a >> 16, cntk = a & 0xffffu;
+                    if (cntk == 0u) continue;
                     if (cntk <= 64u) {
-                        uint32_t v = lane < cntk ? s_key[beg + lane] : 0xffffffffu;
+                        uint32_t v = lane < cntk ? (uint32_t)s_seg[beg + lane] : 0xffffffffu;
                         CCL_SORT32(v)
                         CCL_SORT_STEP(64, 32) CCL_SORT_STEP(64, 16) CCL_SORT_STEP(64, 8) CCL_SORT_STEP(64, 4) CCL_SORT_STEP(64, 2) CCL_SORT_STEP(64, 1)
                         emit(beg, lane, cntk, v);
                     } else {
                         for (uint32_t e0 = 0; e0 < cntk; e0 += 64) {
                             const uint32_t e = e0 + lane;
-                            const uint32_t mine = e < cntk ? s_key[beg + e] : 0xffffffffu;
+                            const uint32_t mine = e < cntk ? (uint32_t)s_seg[beg + e] : 0xffffffffu;
                             uint32_t rank = 0;
-                            for (uint32_t t = 0; t < cntk; ++t) rank += s_key[beg + t] < mine ? 1u : 0u;
+                            for (uint32_t t = 0; t < cntk; ++t) rank += (uint32_t)s_seg[beg + t] < mine ? 1u : 0u;
                             if (e < cntk) emit(beg, rank, cntk, mine);
                         }
                     }
@@ -1159,29 +1157,35 @@ __global__ __launch_bounds__(1024) void k_ccl_lds(const SegCfg c, uint32_t* __re
 #undef CCL_SORT32
 #undef CCL_SORT_STEP
     } else {
+        // a blob of more than 512 lines: one bitonic sort of (kept blob index << 13 | raster index) over the whole frame, keys in s_a
         uint32_t sn = 64;
         while (sn < n) sn <<= 1;
-        __syncthreads();
-        for (uint32_t r = tid; r < sn; r += 1024) {
+        uint32_t keys[CCL_SORT / 1024];
+#pragma unroll
+        for (int u = 0; u < CCL_SORT / 1024; ++u) {
+            const uint32_t r = tid + u * 1024;
             uint32_t key = 0xffffffffu;
-            if (r < n) { const uint32_t k = s_cp[s_ord[s_par[r]]]; if (k != 0xffffffffu) key = (k << 13) | r; }
-            s_key[r] = key;
+            if (r < n) { const uint32_t k = s_b[s_par[r]]; if (k != 0xffffffffu) key = (k << 13) | r; }
+            keys[u] = key;
         }
+        __syncthreads();                                   // s_a's blob fields are not read any more
+#pragma unroll
+        for (int u = 0; u < CCL_SORT / 1024; ++u) { const uint32_t r = tid + u * 1024; if (r < sn) s_a[r] = keys[u]; }
         __syncthreads();
         for (uint32_t k = 2; k <= sn; k <<= 1)
             for (uint32_t j = k >> 1; j > 0; j >>= 1) {
                 for (uint32_t i = tid; i < sn; i += 1024) {
                     const uint32_t x = i ^ j;
                     if (x > i) {
-                        const uint32_t a = s_key[i], b2 = s_key[x];
+                        const uint32_t a = s_a[i], b2 = s_a[x];
                         const bool up = (i & k) == 0;
-                        if ((a > b2) == up) { s_key[i] = b2; s_key[x] = a; }
+                        if ((a > b2) == up) { s_a[i] = b2; s_a[x] = a; }
                     }
                 }
                 __syncthreads();
             }
         for (uint32_t i = tid; i < kruns; i += 1024) {
-            const uint32_t r = s_key[i] & 8191u;
+            const uint32_t r = s_a[i] & 8191u;
             trexhip_run q; q.x0 = (uint16_t)(s_run[r] & 0xffffu); q.x1 = (uint16_t)(s_run[r] >> 16); q.y = s_y[r]; q.pad = 0;
             outr[i] = q;
         }
