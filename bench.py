@@ -22,6 +22,7 @@ sys.path.insert(0, ROOT)
 
 FLOP_PER_CROP_CONV3 = 2.0 * 400 * 128 * 1600      # 20x20 px, 128 out channels, K = 25*64
 FLOP_PER_CROP_CONV2 = 2.0 * 1600 * 64 * 400       # 40x40 px, 64 out channels, K = 25*16
+FLOP_PER_CROP_CONV1 = 2.0 * 6400 * 16 * 25        # 80x80 px, 16 out channels, K = 25 (one input channel)
 FLOP_PER_CROP_TOTAL = 2.0 * 126.73e6              # 126.73 M MAC per crop at 100 classes
 
 
@@ -145,8 +146,8 @@ def measure(args, env):
     W, H, n_ind, _cid = synth.CONFIGS[args.config]
     B = args.batch or (64 if args.config == "C5" else 256)
     if args.scaling == "strong":
-        assert B % world == 0, "--scaling strong: the batch must divide by the number of GPUs"
-        B //= world
+        from trex_amd import dist as tdist
+        B = tdist.strong_split(B, world)
     classes = 256 if args.config == "C5" else 100
     with_cnn = args.stages == "all"
 
@@ -383,6 +384,9 @@ def measure(args, env):
             k3 = "k_conv5_wpre (conv3 on the V3 operand image: Winograd F(4,5) along x, fp16 two-piece split, 3 MFMA products per transformed product, fp32 accumulate)"
             k2 = "k_conv2_wpre2 (conv2 on the V2 operand image, writes V3: same arithmetic, two workgroups per CU, LDS-DMA staging)"
             r3, r2 = 1.2, 1.28
+            fused12 = not rgb and not (geom & (1 << 28))
+            if fused12:
+                k2 = "k_conv12_wpre (conv1 INSIDE conv2: the V2 operand image is produced into LDS from the u8 crops, never written to HBM; writes V3)"
         elif args.cnn_mode == "fp16x3":
             k3 = "k_conv5_wino<64,128,20,2> (conv3, Winograd F(4,5), in-kernel transform)" if wino3 else "k_conv5_stream<64,128,20,20,8,persistent> (conv3, direct, fp16 MFMA x3)"
             k2, r3, r2 = "k_conv5_stream<16,64,40,8,4> (conv2, direct form, fp16 MFMA x3 per fp32 product)", (1.2 if wino3 else 3.0), 3.0
@@ -401,9 +405,12 @@ def measure(args, env):
         in2 = n_blobs * 40 * 5120 if pre else n_blobs * 40 * 40 * 16 * 4
         out2 = n_blobs * 20 * 10240 if pre else n_blobs * 20 * 20 * 64 * 4
         roof3 = conv_roof(k3, c3_s, FLOP_PER_CROP_CONV3, r3, prof["CONV3"][1], out2 + n_blobs * 10 * 10 * 128 * 4)
-        roof2 = conv_roof(k2, c2_s, FLOP_PER_CROP_CONV2, r2, prof["CONV2"][1], in2 + out2)
+        fused12 = pre and k2.startswith("k_conv12")
+        if fused12:
+            in2 = n_blobs * 6400                      # the u8 crops are all the fused kernel reads
+        roof2 = conv_roof(k2, c2_s, FLOP_PER_CROP_CONV2 + (FLOP_PER_CROP_CONV1 if fused12 else 0.0), r2, prof["CONV2"][1], in2 + out2)
         t3 = pmc_traffic("trexhip::k_conv5_wpre" if pre else ("trexhip::k_conv5_wino<64, 128, 20, 2" if wino3 else "trexhip::k_conv5_stream<64, 128, 20, 20, 8"))
-        t2 = pmc_traffic("trexhip::k_conv2_wpre2" if pre else "trexhip::k_conv5_stream<16, 64, 40, 8, 4")
+        t2 = pmc_traffic(("trexhip::k_conv12_wpre" if fused12 else "trexhip::k_conv2_wpre2") if pre else "trexhip::k_conv5_stream<16, 64, 40, 8, 4")
         if args.cnn_mode == "fp16x3":
             roof3["traffic"], roof2["traffic"] = t3, t2
         # the primary roofline object is the convolution with the larger total duration in this run; both are carried

@@ -28,6 +28,21 @@ def test_shard_plan_covers_every_frame_once():
         assert max(sizes) - min(sizes) <= block
 
 
+@pytest.mark.parametrize("world", [1, 2, 4, 8])
+def test_strong_scaling_split_covers_a_256_frame_block_exactly_once(world):
+    # bench.py --scaling strong --gpus N: one camera's 256-frame block per step, split between the ranks (Pipeline: frame_base of the table rows)
+    per = tdist.strong_split(256, world)
+    for step in range(3):
+        seen = []
+        for rank in range(world):
+            first, n = tdist.step_frames(step, rank, world, per)
+            assert n == per
+            seen.extend(range(first, first + n))
+        assert seen == list(range(step * 256, (step + 1) * 256))        # in rank order, no gap, no overlap: what Tracker::add needs
+    with pytest.raises(ValueError):
+        tdist.strong_split(256, 3)
+
+
 def _frames():
     from trex_amd import synth
     rng = np.random.default_rng(1)

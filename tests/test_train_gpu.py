@@ -273,3 +273,15 @@ def test_library_drawn_masks_and_argument_checks():
     with pytest.raises(capi.TrexHipError):
         capi.Trainer(seg, weights.pack_blob(state, classes, ch)[:-4], max_batch=16)
     seg.close()
+
+
+def test_precision_outside_0_1_is_refused():
+    # trexhip_train_params.precision selects the arithmetic of the big convolutions: anything but 0 / 1 is an error, not a silent choice
+    state = weights.synthetic_state(8, 3)
+    p = capi.default_params(64, 64)
+    p.max_batch = 1
+    seg = capi.Segmenter(p)
+    for bad in (2, -1, 7):
+        with pytest.raises(capi.TrexHipError):
+            capi.Trainer(seg, weights.pack_blob(state, 8, 1), max_batch=4, lr=1e-3, precision=bad)
+    seg.close()

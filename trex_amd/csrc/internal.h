@@ -154,6 +154,7 @@ struct trexhip_ctx {
     int tune_conv_geom = 0;             // dev only: alternative conv tilings (TREXHIP_CONV_GEOM)
     // hipFuncSetAttribute is per device: one process may drive several devices through several contexts
     bool attr_cnn = false, attr_ccl = false, attr_split = false;
+    bool ctr_dirty = false;             // a detect pass was queued but not to its end: the per-frame overflow counters may be non-zero (launch_segment zeroes them first)
     int attr_posture_bytes = 0;
     int pix_ch = 1;                     // bytes per output pixel (pixel_encoding)
     const uint8_t* d_color_src = nullptr; // colour frames of the last segment_color* call ([n][H][W][color_ch])

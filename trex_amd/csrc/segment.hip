@@ -1486,7 +1486,10 @@ int launch_segment(trexhip_ctx* ctx, const uint8_t* d_frames, int n) {
     const int nch = (W + 1023) / 1024;
     if (nch > 8) { set_error("frame width > 8192 is not supported yet"); return TREXHIP_E_UNSUPPORTED; }
     stage_begin(ctx, TREXHIP_STAGE_SEGMENT_ALL);
-    // (no memset: the rows kernel zeroes the pooled totals, k_ccl_lds hands every frame counter back zeroed; the array starts zeroed at create)
+    // (no memset in the normal case: the rows kernel zeroes the pooled totals, k_ccl_lds hands every frame counter back zeroed; the array starts
+    // zeroed at create.  A pass that was left half-queued by an error return below leaves the flag up: the next one starts from clean counters)
+    if (ctx->ctr_dirty) TH_CHECK_HIP(hipMemsetAsync(ctx->d_ctr, 0, sizeof(uint32_t) * ((size_t)ctx->p.max_batch * CTR_STRIDE + 4), s));
+    ctx->ctr_dirty = true;
     const unsigned want = (unsigned)(((size_t)H * n + 3) / 4);
     const dim3 grid_rows(want < (unsigned)ctx->tune_rows_blocks ? want : (unsigned)ctx->tune_rows_blocks);
     const bool aligned = (W % 16 == 0) && ((reinterpret_cast<uintptr_t>(d_frames) & 15) == 0) &&
@@ -1571,6 +1574,7 @@ int launch_segment(trexhip_ctx* ctx, const uint8_t* d_frames, int n) {
     }
     stage_end(ctx, TREXHIP_STAGE_SEGMENT_ALL);
     TH_CHECK_HIP(hipGetLastError());
+    ctx->ctr_dirty = false;              // every frame's labelling kernel is queued behind its rows kernel
     ctx->d_frames = d_frames;
     ctx->last_n = n;
     ctx->fetched = false;

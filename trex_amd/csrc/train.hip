@@ -1555,6 +1555,7 @@ int trexhip_trainer_create(trexhip_ctx* ctx, const void* blob, size_t bytes, con
     if (classes < 1 || classes > 1024) { set_error("trexhip_trainer_create: classes must be 1..1024"); return TREXHIP_E_INVALID; }
     if (bytes != trexhip_weight_blob_bytes(classes, CH)) { set_error("trexhip_trainer_create: blob size does not match its header"); return TREXHIP_E_INVALID; }
     if (p->max_batch < 1 || p->max_batch > 4096) { set_error("trexhip_trainer_create: max_batch must be 1..4096"); return TREXHIP_E_INVALID; }
+    if (p->precision != 0 && p->precision != 1) { set_error("trexhip_trainer_create: precision must be 0 (fp16 two-piece split convolutions) or 1 (exact fp32 MFMA)"); return TREXHIP_E_INVALID; }
     if (!(p->lr > 0.f) || !(p->beta1 >= 0.f && p->beta1 < 1.f) || !(p->beta2 >= 0.f && p->beta2 < 1.f) || !(p->eps > 0.f) ||
         !(p->dropout >= 0.f && p->dropout < 1.f) || !(p->bn_momentum >= 0.f && p->bn_momentum <= 1.f)) {
         set_error("trexhip_trainer_create: lr > 0, 0 <= beta < 1, eps > 0, 0 <= dropout < 1, 0 <= bn_momentum <= 1 are required");

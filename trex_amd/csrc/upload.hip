@@ -70,10 +70,13 @@ struct CopyPool {
         const std::vector<int> cpus = pin ? local_node_cpus() : std::vector<int>();
         for (int w = 0; w < n; ++w)
             workers.emplace_back([this, w, n, cpus]() {
-                if ((int)cpus.size() > n + 1) {                       // worker w on its own CPU of the caller's node (the first one is left to the caller)
+                if (!cpus.empty()) {
+                    // every worker may run on any CPU of the caller's NUMA node (one mask, not one CPU each: the pools of several contexts, lanes
+                    // or ranks on the same node would otherwise all stack on the node's first CPUs and leave the rest idle); TREXHIP_UPLOAD_PIN=0
+                    // leaves the placement to the scheduler
                     cpu_set_t set;
                     CPU_ZERO(&set);
-                    CPU_SET(cpus[(size_t)(w + 1) % cpus.size()], &set);
+                    for (int c : cpus) CPU_SET(c, &set);
                     (void)pthread_setaffinity_np(pthread_self(), sizeof(set), &set);
                 }
                 uint64_t seen = 0;

@@ -27,6 +27,20 @@ def shard_plan(n_frames, world, block):
     return plan
 
 
+def step_frames(step, rank, world, frames_per_rank):
+    """The frames rank `rank` owns in step `step` of the frame-sharded pipeline (trex_amd/pipeline.py, bench.py): every step is one block
+    of world * frames_per_rank consecutive frames, rank r takes the r-th slice of it (weak scaling: frames_per_rank = the batch; strong
+    scaling: the batch divided by the ranks).  Returns (first_frame, n)."""
+    return (step * world + rank) * frames_per_rank, frames_per_rank
+
+
+def strong_split(block_frames, world):
+    """--scaling strong: one camera's block of `block_frames` frames split between the ranks; the block has to divide."""
+    if block_frames % world:
+        raise ValueError("--scaling strong: the batch must divide by the number of GPUs")
+    return block_frames // world
+
+
 def gather_tables_torch(table, dst=0, group=None):
     """CPU-test stand-in of trexhip_comm_gather_device: table [rows, rowlen] from every rank -> [world*rows, rowlen] on rank `dst`
     (None elsewhere), through torch.distributed (gloo)."""

@@ -95,7 +95,7 @@ class Lane:
                 seg.identify_device(self.crops.data_ptr(), n, self.probs.data_ptr())
             self.done.record(self.stream)
             # per-blob identity table -> (gathered over RCCL/xGMI when N > 1) -> rank 0's host, for the sequential matcher
-            frame_base = (step_idx * pl.world + pl.rank) * pl.B
+            frame_base, _ = tdist.step_frames(step_idx, pl.rank, pl.world, pl.B)
             if pl.with_posture:
                 seg.export_id_table_ex(self.probs.data_ptr(), n, pl.classes, frame_base, self.table.data_ptr(), pl.rows,
                                        self.p_mid.data_ptr() if n else 0, self.p_minfo.data_ptr() if n else 0, 25)
