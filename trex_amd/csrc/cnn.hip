@@ -1204,57 +1204,102 @@ __device__ __forceinline__ float wave_max(float v) {
     return v;
 }
 
+// HEAD_CPW crops per wave: the fc2 weight of (input k, class c) is loaded once and serves the wave's crops (four independent sums per lane
+// instead of one chain of 100 dependent loads + multiply-adds); per crop the operations and their order are those of one wave per crop
+static constexpr int HEAD_CPW = 4;
 __global__ __launch_bounds__(256) void k_head(const float* __restrict__ fc1 /*[N][128]*/, const float* __restrict__ ln_g,
                                               const float* __restrict__ ln_b, const float* __restrict__ w2t /*[100][C]*/,
                                               const float* __restrict__ b2, float* __restrict__ probs /*[N][C]*/,
                                               float* __restrict__ logits_out, int n, int C, const uint32_t* __restrict__ guard, int ksplit) {
     if (guard && *guard == 0u) return;
-    __shared__ float ys[4][128];
+    constexpr int Q = HEAD_CPW;
+    __shared__ float ys[4][Q][128];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int crop = blockIdx.x * 4 + wave;
-    if (crop >= n) return;
-    const float* x = fc1 + (size_t)crop * 128;
-    float x0 = x[lane], x1 = lane + 64 < 100 ? x[lane + 64] : 0.f;
-    for (int s = 1; s < ksplit; ++s) {                     // fc1 partial planes of the split-K launch, fixed order
-        const float* xs = x + (size_t)s * n * 128;
-        x0 += xs[lane];
-        if (lane + 64 < 100) x1 += xs[lane + 64];
+    const int crop0 = (blockIdx.x * 4 + wave) * Q;
+    if (crop0 >= n) return;
+    const int nq = n - crop0 < Q ? n - crop0 : Q;            // crops of this wave (wave-uniform)
+    const float g0 = ln_g[lane], be0 = ln_b[lane];
+    const float g1 = lane + 64 < 100 ? ln_g[lane + 64] : 0.f, be1 = lane + 64 < 100 ? ln_b[lane + 64] : 0.f;
+    // the fc1 partial planes of the split-K launch: every load of the wave's crops goes out first (the planes lie n * 512 bytes apart: a chain of
+    // dependent loads would pay one memory latency per plane), the sums follow in the fixed plane order
+    float xa[FC1_KSPLIT][Q], xb[FC1_KSPLIT][Q];
+#pragma unroll
+    for (int s = 0; s < FC1_KSPLIT; ++s)
+#pragma unroll
+        for (int q = 0; q < Q; ++q) {
+            const float* xs = fc1 + (size_t)s * n * 128 + (size_t)(crop0 + (q < nq ? q : 0)) * 128;
+            xa[s][q] = s < ksplit ? xs[lane] : 0.f;
+            xb[s][q] = (s < ksplit && lane + 64 < 100) ? xs[lane + 64] : 0.f;
+        }
+#pragma unroll
+    for (int q = 0; q < Q; ++q) {
+        if (q >= nq) break;
+        float x0 = xa[0][q], x1 = xb[0][q];
+#pragma unroll
+        for (int s = 1; s < FC1_KSPLIT; ++s)
+            if (s < ksplit) { x0 += xa[s][q]; x1 += xb[s][q]; }
+        const float mean = wave_sum(x0 + x1) * (1.f / 100.f);
+        const float d0 = x0 - mean, d1 = lane + 64 < 100 ? x1 - mean : 0.f;
+        const float var = wave_sum(d0 * d0 + d1 * d1) * (1.f / 100.f);     // biased variance (nn.LayerNorm)
+        const float rstd = 1.f / sqrtf(var + 1e-5f);
+        ys[wave][q][lane] = fmaxf(d0 * rstd * g0 + be0, 0.f);
+        if (lane + 64 < 100) ys[wave][q][lane + 64] = fmaxf(d1 * rstd * g1 + be1, 0.f);
     }
-    const float mean = wave_sum(x0 + x1) * (1.f / 100.f);
-    const float d0 = x0 - mean, d1 = lane + 64 < 100 ? x1 - mean : 0.f;
-    const float var = wave_sum(d0 * d0 + d1 * d1) * (1.f / 100.f);     // biased variance (nn.LayerNorm)
-    const float rstd = 1.f / sqrtf(var + 1e-5f);
-    ys[wave][lane] = fmaxf(d0 * rstd * ln_g[lane] + ln_b[lane], 0.f);
-    if (lane + 64 < 100) ys[wave][lane + 64] = fmaxf(d1 * rstd * ln_g[lane + 64] + ln_b[lane + 64], 0.f);
     __builtin_amdgcn_wave_barrier();      // ys[wave] is private to this wave; LDS ops of one wave stay in order
-    // logits: lane = class (stride 64)
-    float mx = -3.4e38f;
+    // logits: lane = class (stride 64), one 64-class slice at a time for all crops of the wave
     const int nrep = (C + 63) / 64;
-    float lg[16];                         // up to 1024 classes (track_max_individuals default)
+    float mx[Q], sum[Q];
+#pragma unroll
+    for (int q = 0; q < Q; ++q) { mx[q] = -3.4e38f; sum[q] = 0.f; }
+    float lg[16][Q];                      // up to 1024 classes (track_max_individuals default)
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-        lg[r] = -3.4e38f;
+#pragma unroll
+        for (int q = 0; q < Q; ++q) lg[r][q] = -3.4e38f;
         if (r < nrep) {
             const int c = r * 64 + lane;
             if (c < C) {
-                float s = b2[c];
-                for (int k = 0; k < 100; ++k) s = fmaf(ys[wave][k], w2t[(size_t)k * C + c], s);
-                lg[r] = s;
-                if (logits_out) logits_out[(size_t)crop * C + c] = s;
+                float s[Q];
+                const float bias = b2[c];
+#pragma unroll
+                for (int q = 0; q < Q; ++q) s[q] = bias;
+                for (int k = 0; k < 100; ++k) {
+                    const float w = w2t[(size_t)k * C + c];
+#pragma unroll
+                    for (int q = 0; q < Q; ++q) s[q] = fmaf(ys[wave][q][k], w, s[q]);
+                }
+#pragma unroll
+                for (int q = 0; q < Q; ++q) {
+                    lg[r][q] = s[q];
+                    if (logits_out && q < nq) logits_out[(size_t)(crop0 + q) * C + c] = s[q];
+                }
             }
-            mx = fmaxf(mx, lg[r]);
+#pragma unroll
+            for (int q = 0; q < Q; ++q) mx[q] = fmaxf(mx[q], lg[r][q]);
         }
     }
-    mx = wave_max(mx);
-    float sum = 0.f;
+#pragma unroll
+    for (int q = 0; q < Q; ++q) mx[q] = wave_max(mx[q]);
 #pragma unroll
     for (int r = 0; r < 16; ++r)
-        if (r < nrep) { const int c = r * 64 + lane; if (c < C) { lg[r] = expf(lg[r] - mx); sum += lg[r]; } }
-    sum = wave_sum(sum);
-    const float inv = 1.f / sum;
+        if (r < nrep) {
+            const int c = r * 64 + lane;
+            if (c < C) {
+#pragma unroll
+                for (int q = 0; q < Q; ++q) { lg[r][q] = expf(lg[r][q] - mx[q]); sum[q] += lg[r][q]; }
+            }
+        }
+#pragma unroll
+    for (int q = 0; q < Q; ++q) sum[q] = 1.f / wave_sum(sum[q]);
 #pragma unroll
     for (int r = 0; r < 16; ++r)
-        if (r < nrep) { const int c = r * 64 + lane; if (c < C) probs[(size_t)crop * C + c] = lg[r] * inv; }
+        if (r < nrep) {
+            const int c = r * 64 + lane;
+            if (c < C) {
+#pragma unroll
+                for (int q = 0; q < Q; ++q) if (q < nq) probs[(size_t)(crop0 + q) * C + c] = lg[r][q] * sum[q];
+            }
+        }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1813,7 +1858,7 @@ static int net_forward_launch(trexhip_ctx* ctx, const uint8_t* d_crops, int n, f
         hipLaunchKernelGGL(k_fc1_split, dim3((n + 127) / 128, FC1_KSPLIT), dim3(256), 0, s, net->act3, net->wf1h, net->bf1, net->fc1, n, 12800, net->invf1h, net->d_ovf);
     else
         hipLaunchKernelGGL(k_fc1, dim3((n + 31) / 32, FC1_KSPLIT), dim3(256), 0, s, net->act3, net->wf1, net->bf1, net->fc1, n, 12800, (const uint32_t*)nullptr);
-    hipLaunchKernelGGL(k_head, dim3((n + 3) / 4), dim3(256), 0, s, net->fc1, net->lng, net->lnb, net->wf2t, net->bf2,
+    hipLaunchKernelGGL(k_head, dim3((n + 4 * HEAD_CPW - 1) / (4 * HEAD_CPW)), dim3(256), 0, s, net->fc1, net->lng, net->lnb, net->wf2t, net->bf2,
                        d_probs, d_logits, n, net->classes, (const uint32_t*)nullptr, FC1_KSPLIT);
     if (mode == TREXHIP_CNN_FP16X3) {
         // guarded re-run with the bf16 split: every workgroup returns at once unless an activation left the fp16 range
@@ -1825,7 +1870,7 @@ static int net_forward_launch(trexhip_ctx* ctx, const uint8_t* d_crops, int n, f
         LAUNCH_SPLIT2(16, 64, 40, 10, 0, 6, net->act1, net->w2s, net->b2, net->act2, 1.0f, g);
         LAUNCH_SPLIT2(64, 128, 20, 20, 0, 6, net->act2, net->w3s, net->b3, net->act3, 1.0f, g);
         hipLaunchKernelGGL(k_fc1, dim3((n + 31) / 32, FC1_KSPLIT), dim3(256), 0, s, net->act3, net->wf1, net->bf1, net->fc1, n, 12800, g);
-        hipLaunchKernelGGL(k_head, dim3((n + 3) / 4), dim3(256), 0, s, net->fc1, net->lng, net->lnb, net->wf2t, net->bf2,
+        hipLaunchKernelGGL(k_head, dim3((n + 4 * HEAD_CPW - 1) / (4 * HEAD_CPW)), dim3(256), 0, s, net->fc1, net->lng, net->lnb, net->wf2t, net->bf2,
                            d_probs, d_logits, n, net->classes, g, FC1_KSPLIT);
     }
     stage_end(ctx, TREXHIP_STAGE_CNN_ALL);
