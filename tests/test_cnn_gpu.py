@@ -208,3 +208,26 @@ def test_varying_crop_counts_without_synchronising_between_calls():
     seg.synchronize()
     assert np.abs(outs[0][:64].cpu().numpy() - want[:64]).max() <= 1e-4
     seg.close()
+
+
+@pytest.mark.parametrize("n", [1, 3, 41, 100, 333, 1000, 2049])
+def test_fused_equals_two_kernel_chain(n, monkeypatch):
+    # conv1 inside conv2 (k_conv12_wpre, the default for 1-channel crops) does the arithmetic of k_conv1_wpre + k_conv2_wpre2 in their
+    # order: the probabilities are bit-identical to the two-kernel chain (TREXHIP_CONV_GEOM bit 28, read when the context is created).
+    # Crop counts around the pass (3 row pairs), ticket (1..16 passes) and chunk boundaries; dense, sparse, empty and saturated crops
+    st = weights.synthetic_state(100, 31)
+    crops = weights.synthetic_crops(n, 77 + n).copy()
+    if n > 2:
+        crops[1] = 0; crops[2] = 255
+    if n > 40:
+        crops[40, 10:30, 5:75] = 0
+    out = {}
+    for name, geom in (("fused", "0"), ("two", str(1 << 28))):
+        monkeypatch.setenv("TREXHIP_CONV_GEOM", geom)
+        seg = make_net(st, 100)
+        seg.set_identity_precision(capi.CNN_FP16X3)
+        out[name] = seg.probabilities(crops)
+        seg.close()
+    assert out["fused"].tobytes() == out["two"].tobytes()
+    want, _ = cnn_oracle.predict(st, crops[:64], threads=4)
+    assert np.abs(out["fused"][:64] - want).max() <= 1e-4
