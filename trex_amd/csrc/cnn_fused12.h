@@ -26,7 +26,7 @@ struct W12Geom {
     static_assert(2 * (LDS_BYTES + 64) <= 160 * 1024, "two workgroups per CU");
 };
 
-template <int DBG = 0, int PRIO = 0x030, int STAGGER = 5, int AD = 1, int BD = 3>      // PRIO: s_setprio of (P2, tap loop, P1) as hex digits      // DBG (dev builds): 1 no crop loads, 2 no conv1 MFMAs, 4 no P2 transform, 8 no production at all, 16 no epilogue, 32 no tap loop
+template <int DBG = 0, int PRIO = 0x030, int STAGGER = 5, int AD = 1, int BD = 3>      // PRIO: s_setprio of (P2, tap loop, P1) as hex digits      // DBG (dev builds): 1 no crop loads, 2 no conv1 MFMAs, 4 no P2 transform, 8 no production at all, 16 no epilogue, 32 no tap loop, 64 half the weight fragments (the second piece = a copy of the first: wrong results, same matrix work)
 __global__ __launch_bounds__(256, 2) void k_conv12_wpre(const uint8_t* __restrict__ crops /*[N][80][80]*/, const uint4* __restrict__ w1tab /*[16][64]*/,
                                                         const float* __restrict__ bias1, const float inv_scale1,
                                                         const uint4* __restrict__ wp /*[5][8][2][2][64] x 16 B*/, const float* __restrict__ bias,
@@ -249,7 +249,7 @@ __global__ __launch_bounds__(256, 2) void k_conv12_wpre(const uint8_t* __restric
     for (;;) {
         uint4 bq[8][2];
 #pragma unroll
-        for (int t = 0; t < BD; ++t) { bq[t][0] = buf_load16(wrs, boff, W2_BOFF(t)); bq[t][1] = buf_load16(wrs, boff, W2_BOFF(t) + 2 * CO * 16); }
+        for (int t = 0; t < BD; ++t) { bq[t][0] = buf_load16(wrs, boff, W2_BOFF(t)); bq[t][1] = (DBG & 64) ? bq[t][0] : buf_load16(wrs, boff, W2_BOFF(t) + 2 * CO * 16); }
         int aoff[5][4];
         {
             int s = mg * 32 + j;
@@ -289,7 +289,7 @@ __global__ __launch_bounds__(256, 2) void k_conv12_wpre(const uint8_t* __restric
             if (tau + BD < 40) {
                 const int wt = W2_BOFF(tau + BD);
                 bq[(tau + BD) % 8][0] = buf_load16(wrs, boff, wt);
-                bq[(tau + BD) % 8][1] = buf_load16(wrs, boff, wt + 2 * CO * 16);
+                bq[(tau + BD) % 8][1] = (DBG & 64) ? bq[(tau + BD) % 8][0] : buf_load16(wrs, boff, wt + 2 * CO * 16);
             }
             const int p = W2_POS(tau);
             const f16x8 b1 = __builtin_bit_cast(f16x8, bq[tau % 8][0]), b2 = __builtin_bit_cast(f16x8, bq[tau % 8][1]);
