@@ -1771,6 +1771,7 @@ static int net_forward_launch(trexhip_ctx* ctx, const uint8_t* d_crops, int n, f
         // passes per ticket: long tickets save the 4 extra rows of a ticket's first pass, short ones keep every workgroup busy when the batch is small
         static const int pk_env = std::getenv("TREXHIP_F12_PK") ? std::atoi(std::getenv("TREXHIP_F12_PK")) : 0;
         const int pk = pk_env > 0 ? pk_env : std::max(1, std::min(16, n_pass / (wgs * 4)));
+        // (a tail of short tickets was measured and dropped: the dynamic tickets already finish together, and every ticket's first pass produces 10 rows instead of 6)
         const int want = (n_pass + pk - 1) / pk;
 #define F12K(D_) hipLaunchKernelGGL((k_conv12_wpre<D_>), dim3(want < wgs ? want : wgs), dim3(256), W12Geom::LDS_BYTES, s, d_crops, net->w1h, net->b1, net->inv1h, \
                            net->w2w, net->b2, net->v3, net->inv2w, net->d_ovf, n, net->d_ovf + 2, pk)
@@ -1820,10 +1821,12 @@ static int net_forward_launch(trexhip_ctx* ctx, const uint8_t* d_crops, int n, f
         using GW = WinoGeom<64, 128, 20, 2>;
         const int n_pass = (n * GW::TPC + GW::MB - 1) / GW::MB;
 #define W3K(D_) W3KB(D_, 7)
-#define W3KB(D_, B_) hipLaunchKernelGGL((k_conv5_wpre<D_, B_>), dim3(n_pass < ctx->n_cus ? n_pass : ctx->n_cus), dim3(256), GW::LDS_BYTES, s, \
-                           net->v3, net->w3w, net->b3, net->act3, net->inv3w, n, net->d_ovf + 1)
+        // tickets of 4 consecutive passes (their halo rows are L2 hits) for the first 7/8 of the passes, single passes behind them
+        const int n_big3 = (int)((long long)n_pass * 7 / 8) / 4, want3 = n_big3 + (n_pass - n_big3 * 4);
+#define W3KB(D_, B_) hipLaunchKernelGGL((k_conv5_wpre<D_, B_>), dim3(want3 < ctx->n_cus ? want3 : ctx->n_cus), dim3(256), GW::LDS_BYTES, s, \
+                           net->v3, net->w3w, net->b3, net->act3, net->inv3w, n, net->d_ovf + 1, n_big3)
 #ifdef TREXHIP_DEV_KNOBS
-        switch ((ctx->tune_conv_geom >> 24) & 15) { case 1: W3K(1); break; case 2: W3K(2); break; case 3: W3K(3); break; case 7: W3K(7); break; case 15: W3K(15); break; case 8: W3K(16); break; case 9: W3KB(0, 3); break; case 10: W3KB(0, 5); break; case 12: W3K(64); break; case 13: W3K(128); break; case 11: hipLaunchKernelGGL((k_conv5_wpre<0, 7, 1>), dim3(n_pass < ctx->n_cus ? n_pass : ctx->n_cus), dim3(256), GW::LDS_BYTES, s, net->v3, net->w3w, net->b3, net->act3, net->inv3w, n, net->d_ovf + 1); break; default: W3K(0); }
+        switch ((ctx->tune_conv_geom >> 24) & 15) { case 1: W3K(1); break; case 2: W3K(2); break; case 3: W3K(3); break; case 7: W3K(7); break; case 15: W3K(15); break; case 8: W3K(16); break; case 9: W3KB(0, 3); break; case 10: W3KB(0, 5); break; case 12: W3K(64); break; case 13: W3K(128); break; case 11: hipLaunchKernelGGL((k_conv5_wpre<0, 7, 1>), dim3(n_pass < ctx->n_cus ? n_pass : ctx->n_cus), dim3(256), GW::LDS_BYTES, s, net->v3, net->w3w, net->b3, net->act3, net->inv3w, n, net->d_ovf + 1, 0); break; default: W3K(0); }
 #else
         W3K(0);
 #endif

@@ -475,7 +475,8 @@ __global__ __launch_bounds__(256, 2) void k_conv2_wpre2(const uint8_t* __restric
 template <int DBG = 0, int BD = 7, int PK = 4, int STG = 1, int DT0 = 2>      // PK: consecutive passes per workgroup and ticket (their halo rows are then L2 hits); STG: 1 = staging by LDS-DMA from tap DT0 on, 0 = through registers
 __global__ __launch_bounds__(256) void k_conv5_wpre(const uint8_t* __restrict__ v3, const uint4* __restrict__ wp /*[4][5][8][2][2][128] x 16 B*/,
                                                     const float* __restrict__ bias, float* __restrict__ out, const float out_scale,
-                                                    const int n_crops, uint32_t* __restrict__ pass_ctr) {
+                                                    const int n_crops, uint32_t* __restrict__ pass_ctr,
+                                                    const int n_big /* tickets of PK passes; the passes behind them go out one by one, so that the workgroups finish together */) {
     constexpr int CI = 64, CO = 128, S = 20, TPW = 2;
     using G = WinoGeom<CI, CO, S, TPW>;
     static_assert(G::NTHR == 256 && G::RP0 == 1280 && G::NCH * 2 * G::RP0 == V3_ROWB, "geometry");
@@ -488,7 +489,9 @@ __global__ __launch_bounds__(256) void k_conv5_wpre(const uint8_t* __restrict__ 
     const int n = wave % G::NT, mg = wave / G::NT;
     const int total_tiles = n_crops * G::TPC;
     const int n_pass = (total_tiles + G::MB - 1) / G::MB;
-    int pass = blockIdx.x * PK;
+    const int big_end = n_big * PK;
+    auto ticket_first = [&](const int t) { return t < n_big ? t * PK : big_end + (t - n_big); };
+    int pass = ticket_first((int)blockIdx.x);
     if (pass >= n_pass) return;
     const uint32_t lds0 = (uint32_t)(uintptr_t)ldsb;
     // Staging of a chunk by LDS-DMA (no registers, no LDS store instructions -- a 16-byte ds_write costs the whole CU ~30 cycles): the NR padded
@@ -588,8 +591,8 @@ __global__ __launch_bounds__(256) void k_conv5_wpre(const uint8_t* __restrict__ 
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[m][p][r] = 0.f;
         int next_pass = pass + 1;
-        const bool draw = pass % PK == PK - 1;                             // the last pass of a ticket draws the next one
-        if (draw && tid == 0) s_next_pass = ((int)atomicAdd(pass_ctr, 1u) + (int)gridDim.x) * PK;   // read by everyone after the first chunk's barrier
+        const bool draw = pass >= big_end || pass % PK == PK - 1;          // the last pass of a ticket draws the next one
+        if (draw && tid == 0) s_next_pass = ticket_first((int)atomicAdd(pass_ctr, 1u) + (int)gridDim.x);   // read by everyone after the first chunk's barrier
         bool have_next = false;
         int qmin_n = qmin, nrows_n = nrows;
         for (int cc = 0; cc < G::NCH; ++cc) {
