@@ -680,6 +680,28 @@ def compact_line(out, sec):
     return o
 
 
+def fit_line(o):
+    """the final line as text, below FINAL_LINE_MAX bytes whatever happened in the secondary runs: optional parts are dropped in a fixed
+    order (never the contract's keys, `roofline` or `cpu_baseline`) until it fits; what was dropped is named in `dropped`"""
+    order = ["host_input", "stage_us", "roofline_kernels", "configs", "roofline_detect", "dist"]
+    dropped = []
+    while True:
+        line = json.dumps(o, separators=(",", ":"))
+        if len(line) < FINAL_LINE_MAX or not order:
+            return line
+        k = order.pop(0)
+        if k == "configs" and "configs" in o:      # first only shorten the entries (errors, extras), then drop the object
+            short = {n: ({"value": e["value"]} if "value" in e else {"error": e.get("error", "")[:24]}) for n, e in o["configs"].items()}
+            if short != o["configs"]:
+                o["configs"] = short
+                order.insert(0, "configs")
+                continue
+        if k in o:
+            del o[k]
+            dropped.append(k)
+            o["dropped"] = dropped
+
+
 def main():
     argv = sys.argv[1:]
     args = build_parser().parse_args(argv)
@@ -731,9 +753,7 @@ def main():
         emit_detail("bench_detail", out)
         if sec is not None:
             emit_detail("bench_secondary", sec)
-        line = json.dumps(compact_line(out, sec), separators=(",", ":"))
-        assert len(line) < FINAL_LINE_MAX, "the final line must stay short enough for the driver's stdout tail: %d bytes" % len(line)
-        print(line, flush=True)
+        print(fit_line(compact_line(out, sec)), flush=True)
 
 
 if __name__ == "__main__":
