@@ -1,4 +1,4 @@
-// cnn.hip -- identity network V118_3 forward + softmax on gfx950 (exact fp32, MFMA for the convs).
+// cnn.hip -- identity network V118_3 forward + softmax on gfx950 (fp32-class arithmetic, MFMA for the convs).
 //
 // Replaces VINetwork::probabilities -> Python predict() -> predict_numpy
 //   Application/src/tracker/ml/VisualIdentification.cpp:440-485
@@ -7,6 +7,8 @@
 //   x = float(u8)  ->  [conv5x5 same -> BN -> ReLU -> maxpool2] x3 -> flatten(NCHW) -> fc1(12800->100)
 //   -> LayerNorm(100) -> ReLU -> fc2(100->classes) -> softmax.
 //
+// Default chain (1-channel crops, fp16 two-piece split): k_conv12_wpre (cnn_fused12.h: conv1 inside conv2) -> V3 -> k_conv5_wpre (cnn_wpre.h)
+// -> k_fc1_split -> k_head.  The kernels of this file are the exact-fp32 / bf16 precision modes, the fallbacks and the head:
 // Kernels (DESIGN.md "Identity network"):
 //   k_conv1     C_in=1: VALU, one block per crop, u8 crop staged in LDS, fused BN+ReLU+pool
 //   k_conv5<>   conv2/conv3 as 25 shifted GEMMs on v_mfma_f32_32x32x2_f32 (exact fp32):
@@ -15,7 +17,7 @@
 //               pixels ordered pool-window-major so the 2x2 max-pool is a max over 4 accumulator
 //               registers of one lane; BN folded into weights/bias; epilogue bias+ReLU+pool
 //   k_fc1       [crops x 12800] x [12800 x 128] MFMA GEMM, LDS tiles
-//   k_head      LayerNorm + ReLU + fc2 + softmax, one wave per crop
+//   k_head      LayerNorm + ReLU + fc2 + softmax, four crops per wave
 #include "internal.h"
 #include "conv_f32.h"
 #include <algorithm>

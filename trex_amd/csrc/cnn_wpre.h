@@ -6,6 +6,8 @@
 //   k_conv1_wpre  u8 crop -> conv1 (matrix cores) -> bias, ReLU, pool -> B^T d along x -> fp16 pieces -> V2
 //   k_conv2_wpre2 V2 -> conv2 (40 position GEMMs) -> A^T, bias, ReLU, pool -> B^T d -> fp16 pieces -> V3
 //   k_conv5_wpre  V3 -> conv3 -> A^T, bias, ReLU, pool -> act3 (fp32, NHWC) -> fc1 -> head
+// (since round 4 the first two run as ONE kernel for 1-channel crops -- cnn_fused12.h: k_conv12_wpre produces V2's rows straight into conv2's LDS row
+// ring; k_conv1_wpre + k_conv2_wpre2 below serve 3-channel crops and TREXHIP_CONV_GEOM bit 28)
 // so the consumers' staging is a plain 16-byte copy HBM -> VGPR -> LDS (no transform, no split, no 4-byte LDS scatter inside the
 // matrix-bound tap loops), and fp32 activations of conv1 / conv2 never travel through HBM.
 //   V2 [q2 = crop*40 + y][piece 2][group 2][pg 4][tx 10][16 ci] halves   (positions of group 0: 0,1,2,7; group 1: 3,4,5,6)  5120 B per row
