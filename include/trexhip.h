@@ -314,7 +314,8 @@ typedef struct trexhip_posture_params {
     /* not implemented, refused with TREXHIP_E_UNSUPPORTED when switched on (never silently ignored):
      *   posture_closing_steps > 0 (Posture.cpp:335, morphological closing inside threshold_get_biggest_blob),
      *   peak_mode = broad (1; Outline.cpp:627-661; 0 = pointy, the default :897),
-     *   posture_direction_smoothing > 0 (the movement-history flip of Midline::post_process needs the tracker's previous frames) */
+     * posture_direction_smoothing is not used by the posture call: the window is the tracker's (Individual::calculate_previous_vector);
+     * with a value > 1 the reference hands the resulting movement direction to Midline::post_process -- trexhip_midline_movement_device */
     int32_t posture_closing_steps, peak_mode, posture_direction_smoothing;
 } trexhip_posture_params;
 typedef struct trexhip_posture_info { int32_t status, n_outline, n_segments, tail_index, head_index, n_traced, reserved[2]; } trexhip_posture_info;
@@ -333,7 +334,7 @@ int trexhip_posture_auto_device(trexhip_ctx* ctx, const trexhip_posture_params* 
                                 int32_t n_blobs, float* d_outline, float* d_segments, trexhip_posture_info* d_info,
                                 int32_t* d_threshold_used, int32_t* d_iterations);
 
-/* Midline::post_process (no movement information, posture_direction_smoothing = 0; Outline.cpp:895-1060) followed by
+/* Midline::post_process (no movement information, posture_direction_smoothing <= 1; Outline.cpp:895-1060) followed by
  * Midline::normalize() (Outline.cpp:1270-1454; call site Individual.cpp:1369-1372) for every blob of a posture call.
  *   d_segments: the segments buffer of trexhip_posture_device (same max_points); post-processed IN PLACE (head part straightened)
  *   d_midline : [n_blobs][midline_resolution] float4 = MidlineSegment{pos.x,pos.y,height,l_length}, head at the origin
@@ -350,6 +351,15 @@ void trexhip_default_midline_params(trexhip_midline_params* p);
 int trexhip_midline_device(trexhip_ctx* ctx, const trexhip_midline_params* mp, int32_t n_blobs, int32_t max_points,
                            const trexhip_posture_info* d_posture_info, float* d_segments, float* d_midline,
                            trexhip_midline_info* d_midline_info);
+/* The same with MovementInformation::direction per blob (posture_direction_smoothing > 1: Individual.cpp:1364-1369 hands
+ * calculate_previous_vector(frame) to post_process): d_movement_direction [n_blobs][2] float (x, y), (0, 0) = no information for that
+ * blob; NULL = trexhip_midline_device.  A midline whose direction (Midline::midline_direction, Outline.cpp:870-887) points against the
+ * movement -- acos(-direction . movement) < acos(direction . movement), :937 -- is turned round; trexhip_midline_info.reserved[0] = 1 for
+ * such a blob (`_inverted_because_previous`): the caller swaps its head and tail index (:959).  The vector itself is tracker state (the
+ * previous frames' velocities): the caller computes it. */
+int trexhip_midline_movement_device(trexhip_ctx* ctx, const trexhip_midline_params* mp, int32_t n_blobs, int32_t max_points,
+                                    const trexhip_posture_info* d_posture_info, float* d_segments, float* d_midline,
+                                    trexhip_midline_info* d_midline_info, const float* d_movement_direction);
 
 /* ---- crops ------------------------------------------------------------------------------------
  * constraints::diff_image (tracking/FilterCache.cpp:265-294): one out_w x out_h uint8 crop per blob of the

@@ -119,6 +119,7 @@ def lib():
                                           C.POINTER(PostureParams), C.c_void_p, C.c_void_p, C.POINTER(PostureInfo), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
         L.oracle_midline_walk.argtypes = [C.c_void_p, C.c_int32, C.c_float, C.c_void_p]
         L.oracle_midline_post_process.argtypes = [C.c_void_p, C.c_int32, C.c_float, C.c_int32, C.c_int32]
+        L.oracle_midline_post_process_mv.argtypes = [C.c_void_p, C.c_int32, C.c_float, C.c_int32, C.c_int32, C.c_float, C.c_float, C.POINTER(C.c_int)]
         L.oracle_midline_normalize.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_float, C.c_void_p, C.c_void_p]
         L.oracle_midline_transform.argtypes = [C.c_float, C.c_float, C.c_float, C.c_int32, C.c_void_p]
         L.oracle_vec_to_r3g3b2.restype = C.c_uint8
@@ -356,16 +357,20 @@ MIDLINE_INFO_DTYPE = np.dtype([("status", "<i4"), ("n", "<i4"), ("len", "<f4"), 
                                ("reserved", "<i4", (2,))])
 
 
-def midline_normalize(segments, resolution=25, stiff=0.15, invert=False, start_with_head=False):
-    """Midline::post_process (no movement information) followed by Midline::normalize() (Individual.cpp:1369-1372).
-    returns (info, processed raw segments [n,4], normalised segments [resolution,4])."""
+def midline_normalize(segments, resolution=25, stiff=0.15, invert=False, start_with_head=False, movement=None):
+    """Midline::post_process followed by Midline::normalize() (Individual.cpp:1369-1372).  movement = MovementInformation::direction (x, y) or
+    None (no movement information).  returns (info, processed raw segments [n,4], normalised segments [resolution,4]); info["reserved"][0] = 1
+    when the midline was turned round because of the movement (`_inverted_because_previous`)."""
     s = np.ascontiguousarray(segments, np.float32).copy()
     info = np.zeros(1, MIDLINE_INFO_DTYPE)
     out = np.zeros((resolution, 4), np.float32)
-    if lib().oracle_midline_post_process(_ptr(s), len(s), stiff, 1 if invert else 0, 1 if start_with_head else 0) != 0:
+    flipped = C.c_int(0)
+    mv = (0.0, 0.0) if movement is None else (float(movement[0]), float(movement[1]))
+    if lib().oracle_midline_post_process_mv(_ptr(s), len(s), stiff, 1 if invert else 0, 1 if start_with_head else 0, mv[0], mv[1], C.byref(flipped)) != 0:
         info["status"] = 1
         return info[0], s, out
     lib().oracle_midline_normalize(_ptr(s), len(s), resolution, stiff, _ptr(out), _ptr(info))
+    info["reserved"][0, 0] = flipped.value
     return info[0], s, out
 
 

@@ -311,9 +311,31 @@ static float midline_calculate_angle(const float* s4, int n, float stiff) {     
     return atan2f(ly, lx);
 }
 
-int oracle_midline_post_process(float* s4, int n, float stiff, int invert, int start_with_head) {      /* :895-1060 */
+/* Midline::midline_direction (Outline.cpp:870-887): mean of the first max(1, size * midline_stiff_percentage) segment steps, normalised.
+ * UNPINNED detail: cmn::max(int, float) is taken to return the float (then narrowed to long_t) */
+static v2 midline_direction(const float* s4, int n, float stiff) {
+    const float sf = (float)n * stiff;
+    const long samples = (long)(sf > 1.f ? sf : 1.f);
+    v2 d = {0, 0};
+    long counted = 0;
+    for (long i = 0; i < samples && i + 1 < (long)n; ++i, ++counted) { d.x += s4[4 * (i + 1)] - s4[4 * i]; d.y += s4[4 * (i + 1) + 1] - s4[4 * i + 1]; }
+    if (counted > 0) { d.x /= (float)counted; d.y /= (float)counted; d = v2norm(d); }
+    return d;
+}
+
+/* post_process with MovementInformation::direction = (mvx, mvy) (Outline.cpp:905-961; (0,0) = no movement information, the case of
+ * posture_direction_smoothing <= 1, Individual.cpp:1366-1368): the midline is turned round when its direction points against the
+ * movement, *flipped = `_inverted_because_previous` (the caller swaps head_index / tail_index, :959) */
+int oracle_midline_post_process_mv(float* s4, int n, float stiff, int invert, int start_with_head, float mvx, float mvy, int* flipped) {      /* :895-1060 */
+    if (flipped) *flipped = 0;
     if (n <= 2) return 1;
-    const int needs_invert = !invert;
+    int needs_invert = !invert;
+    if (mvx != 0.f || mvy != 0.f) {
+        v2 d = midline_direction(s4, n, stiff);
+        if (!needs_invert) { d.x = -d.x; d.y = -d.y; }
+        const float against = (-d.x) * mvx + (-d.y) * mvy, along = d.x * mvx + d.y * mvy;
+        if (acosf(against) < acosf(along)) { needs_invert = !needs_invert; if (flipped) *flipped = 1; }
+    }
     int rev = needs_invert ? !start_with_head : start_with_head;
     if (rev) for (int i = 0; i < n / 2; ++i) for (int k = 0; k < 4; ++k) { float t = s4[4 * i + k]; s4[4 * i + k] = s4[4 * (n - 1 - i) + k]; s4[4 * (n - 1 - i) + k] = t; }
     if (stiff > 0) {
@@ -344,6 +366,9 @@ int oracle_midline_post_process(float* s4, int n, float stiff, int invert, int s
     }
     for (int i = 0; i < n / 2; ++i) for (int k = 0; k < 4; ++k) { float t = s4[4 * i + k]; s4[4 * i + k] = s4[4 * (n - 1 - i) + k]; s4[4 * (n - 1 - i) + k] = t; }   /* :1057 */
     return 0;
+}
+int oracle_midline_post_process(float* s4, int n, float stiff, int invert, int start_with_head) {      /* no movement information */
+    return oracle_midline_post_process_mv(s4, n, stiff, invert, start_with_head, 0.f, 0.f, (int*)0);
 }
 
 int oracle_midline_normalize(const float* s4, int n, int resolution, float stiff, float* out4, oracle_midline_info* info) {   /* :1270-1454 */

@@ -432,6 +432,34 @@ int main(int argc, char** argv) {
             HipPosture::Settings bad = ps; bad.peak_mode_broad = true;
             bool threw = false; try { (void)hp.calculate_posture((int)res.total_blobs, bad); } catch (const std::exception&) { threw = true; }
             CHECK(threw);
+            // posture_direction_smoothing > 1: the movement direction of every blob is handed to Midline::post_process (Individual.cpp:1364-1369).
+            // A vector along the midline's own direction changes nothing, the opposite one turns the normalised midline round (angle + pi,
+            // head and tail index swapped); without the vectors the adapter refuses instead of silently skipping the history flip
+            HipPosture::Settings sm = ps; sm.posture_direction_smoothing = 5;
+            threw = false; try { (void)hp.calculate_posture(0, (int)res.total_blobs, sm); } catch (const std::exception&) { threw = true; }
+            CHECK(threw);
+            auto base = hp.calculate_posture(0, (int)res.total_blobs, ps);
+            std::vector<cmn::Vec2> along(res.total_blobs), against(res.total_blobs);
+            for (size_t b = 0; b < base.size(); ++b) {
+                along[b] = against[b] = cmn::Vec2(0.f, 0.f);
+                if (!base[b].value.midline) continue;
+                const auto& sg = base[b].value.midline->segments();
+                const float dx = sg[1].pos.x - sg[0].pos.x, dy = sg[1].pos.y - sg[0].pos.y, L = std::sqrt(dx * dx + dy * dy);
+                along[b] = cmn::Vec2(dx / L, dy / L); against[b] = cmn::Vec2(-dx / L, -dy / L);
+            }
+            auto ra = hp.calculate_posture(0, (int)res.total_blobs, sm, &along), rb = hp.calculate_posture(0, (int)res.total_blobs, sm, &against);
+            int turned = 0;
+            for (size_t b = 0; b < base.size(); ++b) {
+                if (!base[b].value.normalized_midline) continue;
+                Midline &n0 = *base[b].value.normalized_midline, &na = *ra[b].value.normalized_midline, &nb = *rb[b].value.normalized_midline;
+                CHECK(na.angle() == n0.angle() && na.tail_index() == n0.tail_index() && na.head_index() == n0.head_index());
+                CHECK(nb.tail_index() == n0.head_index() && nb.head_index() == n0.tail_index());
+                float da = std::fabs(nb.angle() - n0.angle()); if (da > 3.14159265f) da = 6.2831853f - da;
+                CHECK(da > 2.5f);                                             // the other end is the head now
+                CHECK(std::fabs(nb.len() - n0.len()) < 0.1f * n0.len());            // (the straightened head part is at the other end now)
+                ++turned;
+            }
+            CHECK(turned == 3);
             r = hp.calculate_posture(0, (int)res.total_blobs, ps);            // leave the single-pass midlines in place for the crops below
         }
         int with_midline = 0;

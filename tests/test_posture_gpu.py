@@ -164,7 +164,17 @@ def test_midline_post_process_and_normalize(kw):
     check_midline(fr, bg, **kw)
 
 
-def check_midline(fr, bg, min_ok=0.8, **kw):
+@pytest.mark.parametrize("kw", [dict(), dict(midline_invert=1), dict(midline_start_with_head=1), dict(midline_stiff_percentage=0.0)])
+def test_midline_movement_history_flip(kw):
+    # posture_direction_smoothing > 1: the reference hands MovementInformation::direction to Midline::post_process, which turns a midline round
+    # when its direction points against the movement (Outline.cpp:905-961).  The vector is tracker state: random unit vectors here, a third
+    # of the blobs without information (0, 0), a few vectors longer than 1 (acos of a value outside [-1, 1] is NaN: no flip then)
+    fr, bg = synth.batch("C2", 2)
+    n_ok, total, flips = check_midline(fr, bg, movement_seed=5, **kw)
+    assert 0.15 * total < flips < 0.6 * total, (flips, total)
+
+
+def check_midline(fr, bg, min_ok=0.8, movement_seed=None, **kw):
     # Midline::post_process + normalize (Outline.cpp:895-1060,1270-1454) on the device's own raw segments vs the CPU restatement
     n, H, W = fr.shape
     seg = capi.Segmenter(capi.default_params(W, H, max_batch=n))
@@ -184,20 +194,35 @@ def check_midline(fr, bg, min_ok=0.8, **kw):
     pinfo = info.cpu().numpy().view(capi.POSTURE_INFO_DTYPE).reshape(-1)
     mid = torch.zeros((total, R, 4), dtype=torch.float32, device="cuda")
     minfo = torch.zeros((total, 8), dtype=torch.int32, device="cuda")
-    seg.midline_device(total, MP, info.data_ptr(), segs.data_ptr(), mid.data_ptr(), minfo.data_ptr(), **kw)
+    move = None
+    if movement_seed is not None:
+        rng = np.random.default_rng(movement_seed)
+        ang = rng.uniform(0, 2 * np.pi, total)
+        move = np.stack([np.cos(ang), np.sin(ang)], 1).astype(np.float32)
+        move[rng.random(total) < 0.33] = 0
+        move[rng.random(total) < 0.05] *= 3.0
+        d_move = torch.from_numpy(move).cuda()
+        seg.midline_device(total, MP, info.data_ptr(), segs.data_ptr(), mid.data_ptr(), minfo.data_ptr(), d_movement_ptr=d_move.data_ptr(), **kw)
+    else:
+        seg.midline_device(total, MP, info.data_ptr(), segs.data_ptr(), mid.data_ptr(), minfo.data_ptr(), **kw)
     seg.synchronize()
     proc = segs.cpu().numpy(); mid = mid.cpu().numpy()
     minfo = minfo.cpu().numpy().view(capi.MIDLINE_INFO_DTYPE).reshape(-1)
-    n_ok = 0
+    n_ok = flips = 0
     for bi in range(total):
         ns = int(pinfo[bi]["n_segments"])
         if pinfo[bi]["status"] != 0:
             assert minfo[bi]["status"] == 1
             continue
         oi, oproc, onorm = oracle.midline_normalize(raw[bi, :ns], resolution=R, stiff=kw.get("midline_stiff_percentage", 0.15),
-                                                    invert=bool(kw.get("midline_invert", 0)), start_with_head=bool(kw.get("midline_start_with_head", 0)))
+                                                    invert=bool(kw.get("midline_invert", 0)), start_with_head=bool(kw.get("midline_start_with_head", 0)),
+                                                    movement=None if move is None else move[bi])
         gi = minfo[bi]
         assert gi["status"] == oi["status"] and gi["n"] == oi["n"], (bi, gi, oi)
+        assert gi["reserved"][0] == oi["reserved"][0], (bi, "movement flip", None if move is None else move[bi])
+        flips += int(gi["reserved"][0])
+        if move is not None and not move[bi].any():
+            assert gi["reserved"][0] == 0
         # post_process is sqrt / divide / multiply / add only: bit-exact
         assert np.array_equal(proc[bi, :ns], oproc), bi
         if oi["status"] != 0:
@@ -209,7 +234,7 @@ def check_midline(fr, bg, min_ok=0.8, **kw):
         assert np.abs(mid[bi] - onorm).max() <= 1e-3
     assert n_ok > min_ok * total
     seg.close()
-    return n_ok, total
+    return (n_ok, total, flips) if movement_seed is not None else (n_ok, total)
 
 
 @pytest.mark.parametrize("legacy", [False, True])
@@ -291,7 +316,7 @@ def test_large_animals_take_fewer_blobs_per_workgroup():
         assert ok == (3 if mp == 4096 else 1)
 
 
-@pytest.mark.parametrize("kw", [dict(posture_closing_steps=1), dict(peak_mode=1), dict(posture_direction_smoothing=2)])
+@pytest.mark.parametrize("kw", [dict(posture_closing_steps=1), dict(peak_mode=1)])
 def test_unimplemented_posture_settings_are_refused(kw):
     fr, bg = synth.batch("C2", 1)
     with pytest.raises(capi.TrexHipError) as e:

@@ -114,7 +114,7 @@ SYMBOLS = [
     "trexhip_set_stream", "trexhip_get_live_params", "trexhip_update_params", "trexhip_set_background", "trexhip_set_background_device", "trexhip_set_background_color", "trexhip_set_background_color_device", "trexhip_generate_average_device", "trexhip_get_background", "trexhip_segment_device",
     "trexhip_segment", "trexhip_segment_color", "trexhip_segment_color_device", "trexhip_rethreshold_device", "trexhip_rethreshold_per_blob_device", "trexhip_fetch_rethreshold", "trexhip_fetch", "trexhip_device_view_get", "trexhip_synchronize",
     "trexhip_profile_enable", "trexhip_profile_read", "trexhip_profile_reset",
-    "trexhip_default_posture_params", "trexhip_posture_device", "trexhip_posture_auto_device", "trexhip_pack_frames_v6_device", "trexhip_crops_device", "trexhip_pixel_channels", "trexhip_device_alloc", "trexhip_device_free", "trexhip_copy_to_host", "trexhip_copy_to_device", "trexhip_crops_transformed_device", "trexhip_crops_posture_device", "trexhip_default_midline_params", "trexhip_midline_device", "trexhip_default_split_params", "trexhip_split_search_device", "trexhip_export_id_table_device", "trexhip_export_id_table_ex_device", "trexhip_load_weights", "trexhip_set_identity_precision", "trexhip_num_classes", "trexhip_identify_device", "trexhip_identify",
+    "trexhip_default_posture_params", "trexhip_posture_device", "trexhip_posture_auto_device", "trexhip_pack_frames_v6_device", "trexhip_crops_device", "trexhip_pixel_channels", "trexhip_device_alloc", "trexhip_device_free", "trexhip_copy_to_host", "trexhip_copy_to_device", "trexhip_crops_transformed_device", "trexhip_crops_posture_device", "trexhip_default_midline_params", "trexhip_midline_device", "trexhip_midline_movement_device", "trexhip_default_split_params", "trexhip_split_search_device", "trexhip_export_id_table_device", "trexhip_export_id_table_ex_device", "trexhip_load_weights", "trexhip_set_identity_precision", "trexhip_num_classes", "trexhip_identify_device", "trexhip_identify",
     "trexhip_weight_blob_bytes", "trexhip_trainer_create", "trexhip_trainer_destroy", "trexhip_trainer_set_lr", "trexhip_trainer_steps", "trexhip_train_step_device", "trexhip_train_step", "trexhip_train_eval_device", "trexhip_train_eval", "trexhip_trainer_read", "trexhip_trainer_export",
     "trexhip_lzo1x_bound", "trexhip_lzo1x_compress", "trexhip_pv_write_frames",
 ]
@@ -157,6 +157,7 @@ def lib():
         L.trexhip_default_midline_params.argtypes = [C.POINTER(MidlineParams)]
         L.trexhip_default_midline_params.restype = None
         L.trexhip_midline_device.argtypes = [C.c_void_p, C.POINTER(MidlineParams), C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.trexhip_midline_movement_device.argtypes = [C.c_void_p, C.POINTER(MidlineParams), C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.trexhip_default_split_params.argtypes = [C.POINTER(SplitParams)]
         L.trexhip_default_split_params.restype = None
         L.trexhip_split_search_device.argtypes = [C.c_void_p, C.POINTER(SplitParams), C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]
@@ -423,14 +424,19 @@ class Segmenter:
         """constraints::diff_image for every blob of the last batch -> uint8 [n_blobs][out_h][out_w] at d_crops_ptr."""
         _check(lib().trexhip_crops_device(self._h, C.c_void_p(d_crops_ptr), n_blobs, out_w, out_h, normalization, difference))
 
-    def midline_device(self, n_blobs, max_points, d_posture_info_ptr, d_segments_ptr, d_midline_ptr, d_midline_info_ptr, **kw):
-        """Midline::post_process + normalize for every blob of a posture call; see include/trexhip.h."""
+    def midline_device(self, n_blobs, max_points, d_posture_info_ptr, d_segments_ptr, d_midline_ptr, d_midline_info_ptr, d_movement_ptr=None, **kw):
+        """Midline::post_process + normalize for every blob of a posture call; d_movement_ptr: [n_blobs][2] float MovementInformation::direction
+        (trexhip_midline_movement_device); see include/trexhip.h."""
         mp = MidlineParams()
         lib().trexhip_default_midline_params(C.byref(mp))
         for k, v in kw.items():
             setattr(mp, k, v)
-        _check(lib().trexhip_midline_device(self._h, C.byref(mp), n_blobs, max_points, C.c_void_p(d_posture_info_ptr), C.c_void_p(d_segments_ptr),
-                                            C.c_void_p(d_midline_ptr), C.c_void_p(d_midline_info_ptr)))
+        if d_movement_ptr is None:
+            _check(lib().trexhip_midline_device(self._h, C.byref(mp), n_blobs, max_points, C.c_void_p(d_posture_info_ptr), C.c_void_p(d_segments_ptr),
+                                                C.c_void_p(d_midline_ptr), C.c_void_p(d_midline_info_ptr)))
+        else:
+            _check(lib().trexhip_midline_movement_device(self._h, C.byref(mp), n_blobs, max_points, C.c_void_p(d_posture_info_ptr), C.c_void_p(d_segments_ptr),
+                                                         C.c_void_p(d_midline_ptr), C.c_void_p(d_midline_info_ptr), C.c_void_p(d_movement_ptr)))
 
     def split_search_device(self, d_presumed_ptr, n_blobs, d_thresholds_ptr, d_info_ptr, method=1, size_ranges=(), **kw):
         """SplitBlob's threshold search for the detect blobs with presumed_nr > 0; see include/trexhip.h."""

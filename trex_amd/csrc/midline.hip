@@ -1,4 +1,4 @@
-// midline.hip -- Midline::post_process (movement information absent: posture_direction_smoothing = 0) and
+// midline.hip -- Midline::post_process (with or without MovementInformation::direction: the movement-history flip of Outline.cpp:905-961) and
 // Midline::normalize() for every blob of a posture call (Outline.cpp:895-1060, 1270-1454; call site
 // Individual.cpp:1369-1372), plus the posture / legacy crop transforms built from the result (Outline.cpp:1237-1255).
 // One lane per blob: the work is a serial walk over <= max_points/2+1 segments and 25 output points.
@@ -19,7 +19,8 @@ __device__ __forceinline__ float vlen(float x, float y) { return sqrtf(x * x + y
 __device__ __forceinline__ float2 vnorm(float x, float y) { const float L = vlen(x, y); return L > 0 ? make_float2((x / L), (y / L)) : make_float2(0.f, 0.f); }
 
 __global__ __launch_bounds__(64) void k_midline(const MidlineCfg C, const trexhip_posture_info* __restrict__ pinfo, float4* __restrict__ segs,
-                                                int n_blobs, float4* __restrict__ mid, trexhip_midline_info* __restrict__ minfo) {
+                                                int n_blobs, float4* __restrict__ mid, trexhip_midline_info* __restrict__ minfo,
+                                                const float2* __restrict__ move_dir /* MovementInformation::direction per blob, or null */) {
     const int b = blockIdx.x * 64 + threadIdx.x;
     if (b >= n_blobs) return;
     trexhip_midline_info I = {};
@@ -36,7 +37,24 @@ __global__ __launch_bounds__(64) void k_midline(const MidlineCfg C, const trexhi
     const int sstride = in_lds ? 64 : 1;
     float4* Sb = in_lds ? s_seg + threadIdx.x : Sg;          // generic pointer: LDS column or the global list
 #define S(i_) Sb[(i_) * sstride]
-    const bool rev = C.invert ? (C.start_with_head != 0) : (C.start_with_head == 0);
+    // the movement-history flip (Outline.cpp:905-961): with movement information, a midline whose direction (mean of its first
+    // max(1, n * stiff) steps, Midline::midline_direction :870-887) points against the movement is turned round
+    bool needs_invert = !C.invert;
+    if (move_dir) {
+        const float2 mv = move_dir[b];
+        if (mv.x != 0.f || mv.y != 0.f) {
+            const float sf = (float)n * C.stiff;
+            const long samples = (long)(sf > 1.f ? sf : 1.f);
+            float dx = 0.f, dy = 0.f;
+            long counted = 0;
+            for (long i = 0; i < samples && i + 1 < (long)n; ++i, ++counted) { const float4 a = S(i), q = S(i + 1); dx += q.x - a.x; dy += q.y - a.y; }
+            if (counted > 0) { dx = dx / (float)counted; dy = dy / (float)counted; const float2 dn = vnorm(dx, dy); dx = dn.x; dy = dn.y; }
+            if (!needs_invert) { dx = -dx; dy = -dy; }
+            const float against = (-dx) * mv.x + (-dy) * mv.y, along = dx * mv.x + dy * mv.y;
+            if (acosf(against) < acosf(along)) { needs_invert = !needs_invert; I.reserved[0] = 1; }      // `_inverted_because_previous`: the caller swaps head / tail index
+        }
+    }
+    const bool rev = needs_invert ? (C.start_with_head == 0) : (C.start_with_head != 0);
 #define PS(i) S(rev ? n - 1 - (i) : (i))
     if (C.stiff > 0) {
         float cf = roundf((float)n * C.stiff) + 1.f; if ((float)n - 1.f < cf) cf = (float)n - 1.f;
@@ -198,6 +216,12 @@ using namespace trexhip;
 extern "C" int trexhip_midline_device(trexhip_ctx* ctx, const trexhip_midline_params* mp, int32_t n_blobs, int32_t max_points,
                                       const trexhip_posture_info* d_posture_info, float* d_segments, float* d_midline,
                                       trexhip_midline_info* d_midline_info) {
+    return trexhip_midline_movement_device(ctx, mp, n_blobs, max_points, d_posture_info, d_segments, d_midline, d_midline_info, nullptr);
+}
+
+extern "C" int trexhip_midline_movement_device(trexhip_ctx* ctx, const trexhip_midline_params* mp, int32_t n_blobs, int32_t max_points,
+                                               const trexhip_posture_info* d_posture_info, float* d_segments, float* d_midline,
+                                               trexhip_midline_info* d_midline_info, const float* d_movement_direction) {
     if (!ctx || !mp || !d_posture_info || !d_segments || !d_midline || !d_midline_info) { set_error("trexhip_midline_device: null argument"); return TREXHIP_E_INVALID; }
     if (mp->midline_resolution < 3 || mp->midline_resolution > 256) { set_error("trexhip_midline_device: midline_resolution must be in 3..256"); return TREXHIP_E_INVALID; }
     if (!(mp->midline_stiff_percentage >= 0.f) || mp->midline_stiff_percentage >= 1.f) { set_error("trexhip_midline_device: midline_stiff_percentage must be in [0,1)"); return TREXHIP_E_INVALID; }
@@ -207,7 +231,7 @@ extern "C" int trexhip_midline_device(trexhip_ctx* ctx, const trexhip_midline_pa
     TH_CHECK_HIP(hipSetDevice(ctx->p.device));
     const MidlineCfg C{mp->midline_resolution, mp->midline_stiff_percentage, mp->midline_invert, mp->midline_start_with_head, max_points / 2 + 1};
     hipLaunchKernelGGL(k_midline, dim3((n_blobs + 63) / 64), dim3(64), 0, ctx->stream, C, d_posture_info, reinterpret_cast<float4*>(d_segments),
-                       n_blobs, reinterpret_cast<float4*>(d_midline), d_midline_info);
+                       n_blobs, reinterpret_cast<float4*>(d_midline), d_midline_info, reinterpret_cast<const float2*>(d_movement_direction));
     TH_CHECK_HIP(hipGetLastError());
     return TREXHIP_OK;
 }

@@ -735,7 +735,7 @@ extern "C" int trexhip_posture_device(trexhip_ctx* ctx, int32_t table, const tre
     // settings whose arithmetic is not built (it lives in the un-vendored commons and nothing in the tree pins it): refuse
     if (pp->posture_closing_steps != 0) { set_error("trexhip_posture_device: posture_closing_steps > 0 is not implemented (closing inside pixel::threshold_get_biggest_blob, Posture.cpp:335)"); return TREXHIP_E_UNSUPPORTED; }
     if (pp->peak_mode != 0) { set_error("trexhip_posture_device: peak_mode = broad is not implemented (needs periodic::find_peaks' peak ranges / integrals, Outline.cpp:627-661); only pointy"); return TREXHIP_E_UNSUPPORTED; }
-    if (pp->posture_direction_smoothing != 0) { set_error("trexhip_posture_device: posture_direction_smoothing > 0 is not implemented (Midline::post_process' movement history is tracker state)"); return TREXHIP_E_UNSUPPORTED; }
+    if (pp->posture_direction_smoothing < 0) { set_error("trexhip_posture_device: posture_direction_smoothing must not be negative"); return TREXHIP_E_INVALID; }   // (> 1: the caller hands the movement direction to trexhip_midline_movement_device)
     if (!ctx->d_frames || ctx->last_n == 0 || !ctx->fetched) { set_error("trexhip_posture_device: segment and fetch a batch first"); return TREXHIP_E_INVALID; }
     if (n_blobs < 0 || (uint32_t)n_blobs > ctx->cfg.pool_blobs) { set_error("trexhip_posture_device: n_blobs outside the blob pool"); return TREXHIP_E_INVALID; }
     if (n_blobs == 0) return TREXHIP_OK;

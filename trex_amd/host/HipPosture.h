@@ -59,17 +59,27 @@ public:
     // posture::calculate_posture(Frame_t, pv::BlobWeakPtr) for every detect blob of the batch, WITH the reference's loop: biggest
     // sub-blob at track_posture_threshold, +2 per failed attempt, first-outline fallback (Posture.cpp:305-399).  One entry per blob,
     // pooled order.  thresholds_used (optional): the threshold whose result each blob got (-1: nothing could be traced).
-    std::vector<Expected> calculate_posture(int n_blobs, const Settings& s, std::vector<int32_t>* thresholds_used = nullptr) {
-        return run(true, 0, n_blobs, s, thresholds_used);
+    // movement (optional, one per blob): MovementInformation::direction = Individual::calculate_previous_vector(frame).direction, which the
+    // reference hands to Midline::post_process when posture_direction_smoothing > 1 (Individual.cpp:1364-1369); (0, 0) = none for that blob.
+    // With posture_direction_smoothing > 1 the vectors are REQUIRED (the history flip would silently be missing otherwise).
+    std::vector<Expected> calculate_posture(int n_blobs, const Settings& s, std::vector<int32_t>* thresholds_used = nullptr,
+                                            const std::vector<cmn::Vec2>* movement = nullptr) {
+        return run(true, 0, n_blobs, s, thresholds_used, movement);
     }
     // one pass over a table as it is: table 0 = the detect blobs, table 1 = the sub-blobs of the caller's last
     // trexhip_rethreshold*_device call.  One entry per blob of that table, pooled order.
-    std::vector<Expected> calculate_posture(int table, int n_blobs, const Settings& s) { return run(false, table, n_blobs, s, nullptr); }
+    std::vector<Expected> calculate_posture(int table, int n_blobs, const Settings& s, const std::vector<cmn::Vec2>* movement = nullptr) {
+        return run(false, table, n_blobs, s, nullptr, movement);
+    }
 
 private:
-    std::vector<Expected> run(bool with_loop, int table, int n_blobs, const Settings& s, std::vector<int32_t>* thresholds_used) {
+    std::vector<Expected> run(bool with_loop, int table, int n_blobs, const Settings& s, std::vector<int32_t>* thresholds_used,
+                              const std::vector<cmn::Vec2>* movement) {
         std::vector<Expected> out((size_t)n_blobs);
         if (n_blobs <= 0) return out;
+        if (s.posture_direction_smoothing > 1 && !movement)
+            throw std::runtime_error("HipPosture: posture_direction_smoothing > 1 needs the movement direction of every blob (Individual::calculate_previous_vector)");
+        if (movement && (int)movement->size() != n_blobs) throw std::runtime_error("HipPosture: one movement vector per blob");
         reserve(n_blobs, s);
         trexhip_posture_params pp; trexhip_default_posture_params(&pp);
         pp.outline_resample = s.outline_resample; pp.outline_smooth_samples = s.outline_smooth_samples;
@@ -101,7 +111,18 @@ private:
         std::vector<trexhip_midline_info> minfo((size_t)n_blobs);
         check(trexhip_synchronize(_ctx));
         check(trexhip_copy_to_host(_ctx, raw.data(), _d_segments, raw.size() * 4));
-        check(trexhip_midline_device(_ctx, &mp, n_blobs, s.max_points, _d_pinfo, _d_segments, _d_midline, _d_minfo));
+        if (movement) {
+            std::vector<float> mv((size_t)n_blobs * 2);
+            for (int b = 0; b < n_blobs; ++b) { mv[2 * (size_t)b] = (*movement)[(size_t)b].x; mv[2 * (size_t)b + 1] = (*movement)[(size_t)b].y; }
+            float* d_mv = nullptr;
+            check(trexhip_device_alloc(_ctx, mv.size() * 4, reinterpret_cast<void**>(&d_mv)));
+            int rc = trexhip_copy_to_device(_ctx, d_mv, mv.data(), mv.size() * 4);
+            if (rc == 0) rc = trexhip_midline_movement_device(_ctx, &mp, n_blobs, s.max_points, _d_pinfo, _d_segments, _d_midline, _d_minfo, d_mv);
+            if (rc == 0) rc = trexhip_synchronize(_ctx);
+            (void)trexhip_device_free(_ctx, d_mv);
+            check(rc);
+        } else
+            check(trexhip_midline_device(_ctx, &mp, n_blobs, s.max_points, _d_pinfo, _d_segments, _d_midline, _d_minfo));
         check(trexhip_synchronize(_ctx));
         check(trexhip_copy_to_host(_ctx, outline.data(), _d_outline, outline.size() * 4));
         check(trexhip_copy_to_host(_ctx, norm.data(), _d_midline, norm.size() * 4));
@@ -141,6 +162,7 @@ private:
                 nm->len() = mi.len; nm->angle() = mi.angle; nm->offset() = cmn::Vec2(mi.offx, mi.offy);
                 nm->is_normalized() = true;
                 nm->tail_index() = pi.tail_index; nm->head_index() = pi.head_index;
+                if (mi.reserved[0]) std::swap(nm->head_index(), nm->tail_index());      // turned round by the movement history (Outline.cpp:957-959)
                 e.value.normalized_midline = std::move(nm);
             }
         }
