@@ -849,6 +849,15 @@ __device__ __forceinline__ void lds_union(uint32_t* par, uint32_t a, uint32_t b)
     }
 }
 
+template <bool COLOUR, int LPB>
+__device__ __forceinline__ void gather_blobs(const SegCfg& c, const int only_pending, const uint8_t* __restrict__ frames,
+                                             const trexhip_frame_info* __restrict__ info, const uint32_t* __restrict__ blob_frame,
+                                             trexhip_blob* __restrict__ blobs, const trexhip_run* __restrict__ runs,
+                                             uint8_t* __restrict__ pixels, const uint32_t f0, const uint32_t f1,
+                                             const uint8_t* __restrict__ color, const int color_ch, const int enc_,
+                                             const uint32_t bw0, const uint32_t bw_step, const uint32_t total,
+                                             const int own_frame, const uint32_t own_run_begin, const uint32_t own_pix_begin);
+
 __global__ __launch_bounds__(1024) void k_ccl_lds(const SegCfg c, uint32_t* __restrict__ frame_ctr,
                                                   const uint32_t* __restrict__ row_cnt, const uint32_t* __restrict__ row_off,
                                                   uint32_t* __restrict__ row_base, const uint32_t* __restrict__ tmp_runs,
@@ -858,7 +867,9 @@ __global__ __launch_bounds__(1024) void k_ccl_lds(const SegCfg c, uint32_t* __re
                                                   uint32_t* __restrict__ totals, trexhip_frame_info* __restrict__ info,
                                                   trexhip_blob* __restrict__ blobs, uint32_t* __restrict__ blob_frame,
                                                   trexhip_run* __restrict__ out_runs, const int dbg_stop,
-                                                  unsigned long long* __restrict__ dbg, const int f0) {
+                                                  unsigned long long* __restrict__ dbg, const int f0,
+                                                  const uint8_t* __restrict__ own_frames /* gray frames: the workgroup also gathers its frame's blobs; else null */,
+                                                  uint8_t* __restrict__ own_pixels) {
 #ifdef TREXHIP_DEV_KNOBS
 #define CCL_STAMP(i) do { if (dbg_stop == -1 && blockIdx.x == 0 && threadIdx.x == 0) dbg[i] = __builtin_readcyclecounter(); } while (0)
 #define CCL_STOP(n) do { if (dbg_stop == (n)) return; } while (0)
@@ -1196,6 +1207,14 @@ __global__ __launch_bounds__(1024) void k_ccl_lds(const SegCfg c, uint32_t* __re
         fi.blob_begin = bb; fi.run_begin = rbeg; fi.pix_begin = pb;
         info[f] = fi;
     }
+    if (own_frames) {
+        // gray pixel arrays: the frame's blobs are gathered right here (pixels, integer moment sums, bounding box, bid) by the 16 waves of this
+        // workgroup, two blobs per wave and step -- the records and lines written above are this workgroup's own (visible behind the barrier),
+        // the frame and its bases are known: no second launch, no look-ups
+        __syncthreads();
+        gather_blobs<false, 32>(c, 0, own_frames, info, blob_frame, blobs, out_runs, own_pixels, 0u, 0xffffffffu, nullptr, 0, 0,
+                                bb + (uint32_t)(tid >> 6) * 2u, 32u, bb + kept, f, rbeg, pb);
+    }
 #undef CCL_STAMP
 #undef CCL_STOP
 }
@@ -1289,35 +1308,34 @@ __device__ __forceinline__ void store_colour(uint8_t* px, uint32_t index, const 
 
 // LPB lanes per blob: 64 (a wave per blob) or 32 (two blobs per wave: most blobs have fewer than 32 lines, and the kernel is a chain of
 // dependent loads -- blob record -> lines -> pixels -- whose throughput is the number of blobs in flight)
+// The waves that call this walk the pooled blobs bw0, bw0 + bw_step, ... below `total` (BPW blobs per wave and step).  own_frame >= 0: the caller
+// is the labelling workgroup of that frame (k_ccl_lds gathers its own blobs: no second launch, no look-up of the frame or of its bases)
 template <bool COLOUR, int LPB>
-__global__ __launch_bounds__(256) void k_gather(const SegCfg c, const int only_pending, const uint8_t* __restrict__ frames,
-                                                const uint32_t* __restrict__ totals,
-                                                const trexhip_frame_info* __restrict__ info,
-                                                const uint32_t* __restrict__ blob_frame,
-                                                trexhip_blob* __restrict__ blobs,
-                                                const trexhip_run* __restrict__ runs,
-                                                uint8_t* __restrict__ pixels, const uint32_t f0, const uint32_t f1,
-                                                const uint8_t* __restrict__ color, const int color_ch, const int enc_) {
+__device__ __forceinline__ void gather_blobs(const SegCfg& c, const int only_pending, const uint8_t* __restrict__ frames,
+                                             const trexhip_frame_info* __restrict__ info, const uint32_t* __restrict__ blob_frame,
+                                             trexhip_blob* __restrict__ blobs, const trexhip_run* __restrict__ runs,
+                                             uint8_t* __restrict__ pixels, const uint32_t f0, const uint32_t f1,
+                                             const uint8_t* __restrict__ color, const int color_ch, const int enc_,
+                                             const uint32_t bw0, const uint32_t bw_step, const uint32_t total,
+                                             const int own_frame, const uint32_t own_run_begin, const uint32_t own_pix_begin) {
     const int enc = COLOUR ? enc_ : 0;                     // the gray instantiation carries no colour addressing at all
     constexpr uint32_t BPW = 64 / LPB;                     // blobs per wave
     const uint32_t lane = lane_id();
     const uint32_t sub = lane & (LPB - 1), part = lane / LPB, part_base = part * LPB;
-    const uint32_t nwaves = gridDim.x * 4;
-    const uint32_t total = min(totals[0], c.pool_blobs);
-    for (uint32_t bw = (blockIdx.x * 4 + (threadIdx.x >> 6)) * BPW; bw < total; bw += nwaves * BPW) {
+    for (uint32_t bw = bw0; bw < total; bw += bw_step) {
         const uint32_t bi = bw + part;
         bool active = bi < total;
         uint32_t f = 0;
         // only the three fields the kernel needs travel in registers (the whole records cost 30 registers and a quarter of the occupancy)
         struct { uint32_t run_begin, n_runs, pix_begin; } B = {0u, 0u, 0u};
         if (active) {                                            // independent of the frame table: run_begin / pix_begin are pooled offsets here
-            f = blob_frame[bi];
+            f = own_frame >= 0 ? (uint32_t)own_frame : blob_frame[bi];
             const uint2 rn = *reinterpret_cast<const uint2*>(&blobs[bi].run_begin);
             B.run_begin = rn.x; B.n_runs = rn.y; B.pix_begin = blobs[bi].pix_begin;
         }
-        active = active && f < (uint32_t)c.B && f >= f0 && f < f1;   // else: hole left by a frame that overflowed the pool / another group's frame
-        struct { uint32_t run_begin, pix_begin; } fi = {0u, 0u};
-        if (active) {                                            // off the critical path unless only_pending
+        active = active && (own_frame >= 0 || (f < (uint32_t)c.B && f >= f0 && f < f1));   // else: hole left by a frame that overflowed the pool / another group's frame
+        struct { uint32_t run_begin, pix_begin; } fi = {own_run_begin, own_pix_begin};
+        if (active && own_frame < 0) {                           // off the critical path unless only_pending
             const uint2 rp = *reinterpret_cast<const uint2*>(&info[f].run_begin);
             fi.run_begin = rp.x; fi.pix_begin = rp.y;
             if (only_pending && info[f].reserved[0] != 2u) active = false;
@@ -1459,6 +1477,20 @@ __global__ __launch_bounds__(256) void k_gather(const SegCfg c, const int only_p
     }
 }
 
+template <bool COLOUR, int LPB>
+__global__ __launch_bounds__(256) void k_gather(const SegCfg c, const int only_pending, const uint8_t* __restrict__ frames,
+                                                const uint32_t* __restrict__ totals,
+                                                const trexhip_frame_info* __restrict__ info,
+                                                const uint32_t* __restrict__ blob_frame,
+                                                trexhip_blob* __restrict__ blobs,
+                                                const trexhip_run* __restrict__ runs,
+                                                uint8_t* __restrict__ pixels, const uint32_t f0, const uint32_t f1,
+                                                const uint8_t* __restrict__ color, const int color_ch, const int enc_) {
+    constexpr uint32_t BPW = 64 / LPB;
+    gather_blobs<COLOUR, LPB>(c, only_pending, frames, info, blob_frame, blobs, runs, pixels, f0, f1, color, color_ch, enc_,
+                              (blockIdx.x * 4 + (threadIdx.x >> 6)) * BPW, gridDim.x * 4 * BPW, min(totals[0], c.pool_blobs), -1, 0u, 0u);
+}
+
 // ---------------------------------------------------------------------------------------------
 // host side launch
 #define LAUNCH_GATHER(grid_, stream_, ...) do { if (ctx->p.pixel_encoding != TREXHIP_ENC_GRAY) hipLaunchKernelGGL((k_gather<true, 64>), grid_, dim3(256), 0, stream_, __VA_ARGS__); \
@@ -1514,6 +1546,10 @@ int launch_segment(trexhip_ctx* ctx, const uint8_t* d_frames, int n) {
         for (int g = 0; g < 9; ++g) TH_CHECK_HIP(hipEventCreateWithFlags(&ctx->ev_grp[g], hipEventDisableTiming));
     }
     const int gs = (n + G - 1) / G;
+    // gray pixel arrays: k_ccl_lds gathers the blobs of the frame it has just labelled (TREXHIP_FUSE_GATHER=0: the separate k_gather launch);
+    // the colour encodings keep k_gather (one wave per blob, colour addressing)
+    static const bool fuse_env = !(std::getenv("TREXHIP_FUSE_GATHER") && std::atoi(std::getenv("TREXHIP_FUSE_GATHER")) == 0);
+    const bool fuse_gather = fuse_env && ctx->p.pixel_encoding == TREXHIP_ENC_GRAY;
     stage_begin(ctx, TREXHIP_STAGE_ROWS);
     for (int g = 0; g < G; ++g) {
         const int f0 = g * gs, f1 = (g + 1) * gs < n ? (g + 1) * gs : n;
@@ -1563,8 +1599,10 @@ int launch_segment(trexhip_ctx* ctx, const uint8_t* d_frames, int n) {
         // and finished by the global-memory chain in finish_segment()
         hipLaunchKernelGGL(k_ccl_lds, dim3(f1 - f0), dim3(1024), CCL_LDS_BYTES, t, c, ctx->d_ctr, ctx->d_row_cnt, ctx->d_row_off, ctx->d_row_base,
                            ctx->d_tmp_runs, ctx->d_raster, ctx->d_parent, ctx->d_root_ord, ctx->d_cur_run, ctx->d_pix_begin, ctx->d_blob_map,
-                           totals, ctx->d_info, ctx->d_blobs, ctx->d_blob_frame, ctx->d_runs, ctx->tune_ccl_stop, reinterpret_cast<unsigned long long*>(ctx->d_cnt_px), f0);
+                           totals, ctx->d_info, ctx->d_blobs, ctx->d_blob_frame, ctx->d_runs, ctx->tune_ccl_stop, reinterpret_cast<unsigned long long*>(ctx->d_cnt_px), f0,
+                           fuse_gather ? d_frames : (const uint8_t*)nullptr, ctx->d_pixels);
         static const int gather_blocks_env = std::getenv("TREXHIP_GATHER_BLOCKS") ? std::atoi(std::getenv("TREXHIP_GATHER_BLOCKS")) : 0;
+        if (!fuse_gather)
         LAUNCH_GATHER(dim3(G > 1 ? 256 : (gather_blocks_env > 0 ? gather_blocks_env : 2048)), t, c, 0, d_frames, totals, ctx->d_info, ctx->d_blob_frame,
                            ctx->d_blobs, ctx->d_runs, ctx->d_pixels, (uint32_t)f0, (uint32_t)f1, ctx->d_color_src, ctx->color_ch, ctx->p.pixel_encoding);
     }
