@@ -180,3 +180,12 @@ def test_library_communicator_two_ranks_on_one_gpu_over_sockets(tmp_path):
     assert np.array_equal(got, np.concatenate(own))
     merged = tdist.merge_tables(got.view(np.uint32))
     assert set(np.unique(merged[:, 0]).tolist()) == set(range(6)) and np.all(np.diff(merged[:, 0].astype(np.int64)) >= 0)
+
+
+def test_count_ranks_of_a_one_rank_communicator():
+    # trexhip_comm_count_ranks: the all-reduce of 1 over the library's communicator (world 1: no RCCL involved) -- bench.py prints it as dist.ranks_seen
+    seg = capi.Segmenter(capi.default_params(64, 64, max_batch=1))
+    comm = capi.Comm(seg, 0, 1)
+    assert comm.count_ranks() == 1
+    comm.close()
+    seg.close()
