@@ -1706,7 +1706,7 @@ static int net_forward_launch(trexhip_ctx* ctx, const uint8_t* d_crops, int n, f
 #define F12A(D_) TH_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv12_wpre<D_>), hipFuncAttributeMaxDynamicSharedMemorySize, W12Geom::LDS_BYTES))
         F12A(0);
 #ifdef TREXHIP_DEV_KNOBS
-        F12A(1); F12A(2); F12A(4); F12A(8); F12A(16); F12A(24); F12A(32); F12A(40); F12A(56); F12A(64);
+        F12A(1); F12A(2); F12A(4); F12A(8); F12A(16); F12A(24); F12A(32); F12A(40); F12A(56); F12A(64); F12A(128);
         TH_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv12_wpre<0, 0x033>), hipFuncAttributeMaxDynamicSharedMemorySize, W12Geom::LDS_BYTES));
         TH_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv12_wpre<0, 0x333>), hipFuncAttributeMaxDynamicSharedMemorySize, W12Geom::LDS_BYTES));
         TH_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv12_wpre<0, 0x000>), hipFuncAttributeMaxDynamicSharedMemorySize, W12Geom::LDS_BYTES));
@@ -1780,6 +1780,7 @@ static int net_forward_launch(trexhip_ctx* ctx, const uint8_t* d_crops, int n, f
 #ifdef TREXHIP_DEV_KNOBS   // ablations: TREXHIP_F12_DBG = 1 no crop loads, 2 no conv1 MFMAs, 4 no P2 transform, 8 no production, 16 no epilogue, 32 no tap loop
         static const int f12_dbg = std::getenv("TREXHIP_F12_DBG") ? std::atoi(std::getenv("TREXHIP_F12_DBG")) : 0;
         switch (f12_dbg) { case 1: F12K(1); break; case 2: F12K(2); break; case 4: F12K(4); break; case 8: F12K(8); break; case 16: F12K(16); break; case 24: F12K(24); break; case 32: F12K(32); break; case 40: F12K(40); break; case 56: F12K(56); break; case 64: F12K(64); break;
+            case 128: hipLaunchKernelGGL((k_conv12_wpre<128>), dim3(want < wgs ? want : wgs), dim3(256), W12Geom::LDS_BYTES, s, d_crops, net->w1h, net->b1, net->inv1h, net->w2w, net->b2, net->v3, net->inv2w, net->d_ovf, n, net->d_ovf + 2, pk, reinterpret_cast<unsigned long long*>(ctx->d_cnt_px)); break;   // phase stamps -> trexhip_debug_read (tools/f12_stamps.py)
             case 100: hipLaunchKernelGGL((k_conv12_wpre<0, 0x033>), dim3(want < wgs ? want : wgs), dim3(256), W12Geom::LDS_BYTES, s, d_crops, net->w1h, net->b1, net->inv1h, net->w2w, net->b2, net->v3, net->inv2w, net->d_ovf, n, net->d_ovf + 2, pk); break;
             case 101: hipLaunchKernelGGL((k_conv12_wpre<0, 0x333>), dim3(want < wgs ? want : wgs), dim3(256), W12Geom::LDS_BYTES, s, d_crops, net->w1h, net->b1, net->inv1h, net->w2w, net->b2, net->v3, net->inv2w, net->d_ovf, n, net->d_ovf + 2, pk); break;
             case 102: hipLaunchKernelGGL((k_conv12_wpre<0, 0x000>), dim3(want < wgs ? want : wgs), dim3(256), W12Geom::LDS_BYTES, s, d_crops, net->w1h, net->b1, net->inv1h, net->w2w, net->b2, net->v3, net->inv2w, net->d_ovf, n, net->d_ovf + 2, pk); break;

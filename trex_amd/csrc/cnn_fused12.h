@@ -26,12 +26,13 @@ struct W12Geom {
     static_assert(2 * (LDS_BYTES + 64) <= 160 * 1024, "two workgroups per CU");
 };
 
-template <int DBG = 0, int PRIO = 0x030, int STAGGER = 5, int AD = 1, int BD = 3>      // PRIO: s_setprio of (P2, tap loop, P1) as hex digits      // DBG (dev builds): 1 no crop loads, 2 no conv1 MFMAs, 4 no P2 transform, 8 no production at all, 16 no epilogue, 32 no tap loop, 64 half the weight fragments (the second piece = a copy of the first: wrong results, same matrix work)
+template <int DBG = 0, int PRIO = 0x030, int STAGGER = 5, int AD = 1, int BD = 3>      // PRIO: s_setprio of (P2, tap loop, P1) as hex digits      // DBG (dev builds): 1 no crop loads, 2 no conv1 MFMAs, 4 no P2 transform, 8 no production at all, 16 no epilogue, 32 no tap loop, 64 half the weight fragments (the second piece = a copy of the first: wrong results, same matrix work), 128 phase stamps
 __global__ __launch_bounds__(256, 2) void k_conv12_wpre(const uint8_t* __restrict__ crops /*[N][80][80]*/, const uint4* __restrict__ w1tab /*[16][64]*/,
                                                         const float* __restrict__ bias1, const float inv_scale1,
                                                         const uint4* __restrict__ wp /*[5][8][2][2][64] x 16 B*/, const float* __restrict__ bias,
                                                         uint8_t* __restrict__ v3, const float out_scale, uint32_t* __restrict__ overflow,
-                                                        const int n_crops, uint32_t* __restrict__ pass_ctr, const int PK /* consecutive passes per ticket: the first one produces 10 rows, the others 6 */) {
+                                                        const int n_crops, uint32_t* __restrict__ pass_ctr, const int PK /* consecutive passes per ticket: the first one produces 10 rows, the others 6 */,
+                                                        unsigned long long* __restrict__ dbg_stamps = nullptr /* DBG & 128: cycles per phase of workgroups 0 and gridDim.x / 2 */) {
     using G = W2bGeom;
     using F = W12Geom;
     constexpr int CO = 64, S = 40;
@@ -53,6 +54,10 @@ __global__ __launch_bounds__(256, 2) void k_conv12_wpre(const uint8_t* __restric
     float* pbuf = reinterpret_cast<float*>(ldsb + G::PBUF_OFF);
     for (int i = tid; i < F::IMG_BYTES / 16; i += 256) reinterpret_cast<uint4*>(img)[i] = make_uint4(0, 0, 0, 0);   // the x padding stays zero
     bool ovf = false;
+    // DBG & 128 (dev builds): thread 0 of two workgroups sums the cycles between the phase boundaries of its passes (tools/f12_stamps.py)
+    unsigned long long st_sum[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, st_last = 0;
+    bool st_on = false;                                                  // switched on behind the prologue
+#define F12_STAMP(i_) do { if ((DBG & 128) && st_on) { const unsigned long long t_ = __builtin_readcyclecounter(); st_sum[i_] += t_ - st_last; st_last = t_; } } while (0)
 #define W2B_ROWS(pass_, qmin_, nrows_)                                                                                           \
     do {                                                                                                                         \
         const int gp0_ = (pass_) * G::RPP;                                                                                       \
@@ -217,11 +222,17 @@ __global__ __launch_bounds__(256, 2) void k_conv12_wpre(const uint8_t* __restric
         for (int c0 = (DBG & 8) ? hi : lo; c0 < hi; c0 += F::CHUNK) {
             const int nr = hi - c0 < F::CHUNK ? hi - c0 : F::CHUNK;
             if (!(first_done && c0 == lo)) p0(c0, nr, false, bf0);
+            F12_STAMP(5);
             __syncthreads();
+            F12_STAMP(6);
             p1(nr, bf0);
+            F12_STAMP(7);
             __syncthreads();
+            F12_STAMP(8);
             p2(c0, nr);
+            F12_STAMP(9);
             __syncthreads();
+            F12_STAMP(10);
         }
     };
 
@@ -246,6 +257,7 @@ __global__ __launch_bounds__(256, 2) void k_conv12_wpre(const uint8_t* __restric
 #pragma unroll 1
         for (int i = 0; i < STAGGER; ++i) __builtin_amdgcn_s_sleep(16);
     }
+    if ((DBG & 128) && dbg_stamps && tid == 0 && (blockIdx.x == 0 || blockIdx.x == gridDim.x / 2)) { st_on = true; st_last = __builtin_readcyclecounter(); }
     for (;;) {
         uint4 bq[8][2];
 #pragma unroll
@@ -308,7 +320,9 @@ __global__ __launch_bounds__(256, 2) void k_conv12_wpre(const uint8_t* __restric
         }
 #undef W2B_AREAD
         __builtin_amdgcn_s_setprio(0);
+        F12_STAMP(0);
         __syncthreads();                                                  // every wave is done with the operand planes
+        F12_STAMP(1);
         const bool draw = pass % PK == PK - 1;                            // the last pass of a ticket moves on to the next ticket
         const int next_pass = draw ? s_next_pass : pass + 1;
         const bool have_next = next_pass < n_pass;
@@ -354,7 +368,9 @@ __global__ __launch_bounds__(256, 2) void k_conv12_wpre(const uint8_t* __restric
                 }
             }
         }
+        F12_STAMP(2);
         __syncthreads();                                                  // the activations are in pbuf
+        F12_STAMP(3);
         uint4 bf0[4];
         const int hi_new = qmin_n + nrows_n;
         // epilogue 2: (pooled row, conv3 tile, channel quad) items -> V3
@@ -385,6 +401,7 @@ __global__ __launch_bounds__(256, 2) void k_conv12_wpre(const uint8_t* __restric
                 }
             }
         }
+        F12_STAMP(4);
         if (!have_next) break;
         // the first chunk of the next pass's rows starts here: every lane converts the crop-row unit its OWN LDS-DMA fetched (item = thread
         // index in prefetch and in p0 alike), so no barrier stands between the fetch and the conversion -- only the wave's own counter: the 16
@@ -398,7 +415,10 @@ __global__ __launch_bounds__(256, 2) void k_conv12_wpre(const uint8_t* __restric
             if (tid == 0) s_next_pass = ((int)ticket + (int)gridDim.x) * PK;       // read behind a later pass's first barrier
         }
         pass = next_pass; qmin = qmin_n; nrows = nrows_n;
+        if ((DBG & 128) && st_on) st_sum[11] += 1;
     }
+    if ((DBG & 128) && st_on) { _Pragma("unroll") for (int i = 0; i < 12; ++i) dbg_stamps[(blockIdx.x ? 12 : 0) + i] = st_sum[i]; }
+#undef F12_STAMP
 #undef W2B_ROWS
 #undef W12_ITEM
 #undef W2_POS
