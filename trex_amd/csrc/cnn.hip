@@ -1862,12 +1862,17 @@ static int net_forward_launch(trexhip_ctx* ctx, const uint8_t* d_crops, int n, f
     else if (ctx->tune_conv_geom & 2)    LAUNCH_SPLIT(64, 128, 20, 10, 1, 3, net->act2, net->w3h, net->b3, net->act3, net->inv3h, (const uint32_t*)nullptr);
     else                                 LAUNCH_SPLIT(64, 128, 20, 20, 1, 3, net->act2, net->w3h, net->b3, net->act3, net->inv3h, (const uint32_t*)nullptr);   // 32-channel chunks (CIC=32) measured slower: 3.7 vs 3.0 ms
     stage_end(ctx, TREXHIP_STAGE_CONV3);
-    if (mode == TREXHIP_CNN_FP16X3 && !(ctx->tune_conv_geom & 32))
-        hipLaunchKernelGGL(k_fc1_split, dim3((n + 127) / 128, FC1_KSPLIT), dim3(256), 0, s, net->act3, net->wf1h, net->bf1, net->fc1, n, 12800, net->invf1h, net->d_ovf);
+    // split-K planes of fc1 (summed in k_head): 10 keeps every CU busy at a few thousand crops; TREXHIP_FC1_KSPLIT overrides (dev)
+    static const int ks_env = std::getenv("TREXHIP_FC1_KSPLIT") ? std::atoi(std::getenv("TREXHIP_FC1_KSPLIT")) : 0;
+    // (25600 crops: 10 planes 344 + 72 us for fc1 + head, 5 planes 319 + 66, 4: 365, 8: 381, 2: 347)
+    const int ks1 = (ks_env > 0 && ks_env <= FC1_KSPLIT && 400 % ks_env == 0) ? ks_env : (n >= 12800 ? 5 : FC1_KSPLIT);
+    const bool split1 = mode == TREXHIP_CNN_FP16X3 && !(ctx->tune_conv_geom & 32);
+    if (split1)
+        hipLaunchKernelGGL(k_fc1_split, dim3((n + 127) / 128, ks1), dim3(256), 0, s, net->act3, net->wf1h, net->bf1, net->fc1, n, 12800, net->invf1h, net->d_ovf);
     else
         hipLaunchKernelGGL(k_fc1, dim3((n + 31) / 32, FC1_KSPLIT), dim3(256), 0, s, net->act3, net->wf1, net->bf1, net->fc1, n, 12800, (const uint32_t*)nullptr);
     hipLaunchKernelGGL(k_head, dim3((n + 4 * HEAD_CPW - 1) / (4 * HEAD_CPW)), dim3(256), 0, s, net->fc1, net->lng, net->lnb, net->wf2t, net->bf2,
-                       d_probs, d_logits, n, net->classes, (const uint32_t*)nullptr, FC1_KSPLIT);
+                       d_probs, d_logits, n, net->classes, (const uint32_t*)nullptr, split1 ? ks1 : FC1_KSPLIT);
     if (mode == TREXHIP_CNN_FP16X3) {
         // guarded re-run with the bf16 split: every workgroup returns at once unless an activation left the fp16 range
         const uint32_t* g = net->d_ovf;
