@@ -210,7 +210,7 @@ def test_varying_crop_counts_without_synchronising_between_calls():
     seg.close()
 
 
-@pytest.mark.parametrize("n", [1, 3, 41, 100, 333, 1000, 2049])
+@pytest.mark.parametrize("n", [1, 3, 41, 100, 333, 1000, 2049, 12800])
 def test_fused_equals_two_kernel_chain(n, monkeypatch):
     # conv1 inside conv2 (k_conv12_wpre, the default for 1-channel crops) does the arithmetic of k_conv1_wpre + k_conv2_wpre2 in their
     # order: the probabilities are bit-identical to the two-kernel chain (TREXHIP_CONV_GEOM bit 28, read when the context is created).
