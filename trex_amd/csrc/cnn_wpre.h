@@ -664,7 +664,10 @@ __global__ __launch_bounds__(256) void k_conv5_wpre(const uint8_t* __restrict__ 
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
-            if constexpr (STG) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's part of the next chunk has landed
+            // this wave's part of the next chunk has landed: loads return in order, so everything older than the 2 x BD weight fragments in flight
+            // (the next chunk's first taps) is complete -- the DMA instructions were issued before them.  (vmcnt(0) would drain those fragments too:
+            // one L2 round trip per chunk)
+            if constexpr (STG) { if constexpr (BD == 7 && !(DBG & 256)) asm volatile("s_waitcnt vmcnt(14)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
             __syncthreads();
             bufsel ^= 1;
         }
