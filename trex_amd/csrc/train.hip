@@ -74,74 +74,94 @@ __global__ __launch_bounds__(320) void k_t_conv1(const float* __restrict__ x, co
 }
 
 // ------------------------------------------------------------------------------------------------
-// per-channel sum and sum of squares of d[rows][C], double accumulation, fixed order: partial[block][2][C]
+// Reductions over the batch (BN statistics, BN backward sums, bias gradients): every block of the producing kernel leaves its column sums
+// as doubles in partial[block][NP][C]; k_t_red_finalize (one workgroup per channel: one L2 round trip, not a chain of them) adds them in
+// a fixed order -- same bits every run -- and does what the sum is for.  (Forming the totals in the producing kernel's last block was
+// tried: the device-scope fences it needs write back / invalidate the L2 per block and cost 25-110 us per launch.)
 // ------------------------------------------------------------------------------------------------
-template <int C>
-__global__ __launch_bounds__(256) void k_t_colstats(const float* __restrict__ d, size_t rows, double* __restrict__ partial) {
-    constexpr int LC = C / 4, RL = 256 / LC;
-    __shared__ double sh[RL * C];
-    const int tid = threadIdx.x, cl = tid % LC, rl = tid / LC;
-    double s[4] = {0, 0, 0, 0}, q[4] = {0, 0, 0, 0};
-    for (size_t r = (size_t)blockIdx.x * RL + rl; r < rows; r += (size_t)gridDim.x * RL) {
-        const float4 v = *reinterpret_cast<const float4*>(d + r * C + cl * 4);
-        s[0] += v.x; s[1] += v.y; s[2] += v.z; s[3] += v.w;
-        q[0] += (double)v.x * v.x; q[1] += (double)v.y * v.y; q[2] += (double)v.z * v.z; q[3] += (double)v.w * v.w;
+enum { FIN_BN_STATS = 0, FIN_BN_BWD = 1, FIN_BIAS = 2 };
+struct FinArgs {
+    double count; float momentum;                         // FIN_BN_STATS
+    float *o0, *o1, *o2, *o3;                             // FIN_BN_STATS: mean, invstd, run_mean, run_var; FIN_BN_BWD: sums[2][C], d_gamma, d_beta; FIN_BIAS: d_bias
+    const int32_t* refused;
+};
+
+template <int MODE>
+__global__ __launch_bounds__(256) void k_t_red_finalize(const double* __restrict__ partial, const int nblocks, const int C, const FinArgs A) {
+    constexpr int NP = MODE == FIN_BIAS ? 1 : 2;
+    __shared__ double sh[NP][4];
+    const int c = blockIdx.x, tid = threadIdx.x;
+    double t[NP];
+#pragma unroll
+    for (int pl = 0; pl < NP; ++pl) t[pl] = 0;
+    for (int b = tid; b < nblocks; b += 256)
+#pragma unroll
+        for (int pl = 0; pl < NP; ++pl) t[pl] += partial[((size_t)b * NP + pl) * C + c];
+#pragma unroll
+    for (int pl = 0; pl < NP; ++pl) {
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) t[pl] += __shfl_xor(t[pl], d);
+        if ((tid & 63) == 0) sh[pl][tid >> 6] = t[pl];
     }
-    for (int pass = 0; pass < 2; ++pass) {
+    __syncthreads();
+    if (tid) return;
+    double tot[NP];
+#pragma unroll
+    for (int pl = 0; pl < NP; ++pl) tot[pl] = ((sh[pl][0] + sh[pl][1]) + sh[pl][2]) + sh[pl][3];
+    if constexpr (MODE == FIN_BN_STATS) {                    // mean, invstd (biased variance, like the normalisation uses); running statistics with the unbiased one
+        const double m = tot[0] / A.count;
+        double var = tot[1] / A.count - m * m;
+        if (var < 0) var = 0;
+        A.o0[c] = (float)m;
+        A.o1[c] = (float)(1.0 / sqrt(var + (double)EPS_BN));
+        const double unbiased = A.count > 1 ? var * A.count / (A.count - 1) : var;
+        if (*A.refused) return;                              // a refused step leaves the running statistics alone (k_t_check_targets)
+        A.o2[c] = (1.f - A.momentum) * A.o2[c] + A.momentum * (float)m;
+        A.o3[c] = (1.f - A.momentum) * A.o3[c] + A.momentum * (float)unbiased;
+    } else if constexpr (MODE == FIN_BN_BWD) {               // sums[0][C] = sum dy (= d beta), sums[1][C] = sum dy x-hat (= d gamma)
+        const float sd = (float)tot[0], sg = (float)tot[1];
+        A.o0[c] = sd; A.o0[C + c] = sg;
+        A.o2[c] = sd; A.o1[c] = sg;
+    } else {
+        A.o0[c] = (float)tot[0];
+    }
+}
+
+// a block's column sums: the RL row-lanes of every channel added in fixed order -> partial[block][plane][C]
+template <int C, int NP>
+__device__ __forceinline__ void block_columns(const double (&acc)[NP][4], double* sh /*[256 / (C / 4) * C]*/, double* partial) {
+    constexpr int LC = C / 4, RL = 256 / LC;
+    const int tid = threadIdx.x, cl = tid % LC, rl = tid / LC;
+#pragma unroll
+    for (int pl = 0; pl < NP; ++pl) {
         __syncthreads();
 #pragma unroll
-        for (int k = 0; k < 4; ++k) sh[rl * C + cl * 4 + k] = pass ? q[k] : s[k];
+        for (int k = 0; k < 4; ++k) sh[rl * C + cl * 4 + k] = acc[pl][k];
         __syncthreads();
         if (tid < C) {
             double t = 0;
             for (int r = 0; r < RL; ++r) t += sh[r * C + tid];
-            partial[((size_t)blockIdx.x * 2 + pass) * C + tid] = t;
-        }
-    }
-}
-
-// sum over the blocks' partials of one pass, fixed order: 8 lanes per channel take every 8th block, then the 8 lane sums are added in
-// order.  Block = 1024 threads (C <= 128); the result is valid in threads < C.
-__device__ __forceinline__ double sum_partials(const double* __restrict__ partial, int nblocks, int C, int pass, double* sh /*[8][128]*/) {
-    const int c = threadIdx.x & 127, ln = threadIdx.x >> 7;
-    double t = 0;
-    if (c < C) {
-        // eight loads in flight, added in block order (one load per add would string 32 L2 round trips together)
-        for (int b0 = ln; b0 < nblocks; b0 += 64) {
-            double v[8];
-#pragma unroll
-            for (int k = 0; k < 8; ++k) v[k] = b0 + 8 * k < nblocks ? partial[((size_t)(b0 + 8 * k) * 2 + pass) * C + c] : 0.0;
-#pragma unroll
-            for (int k = 0; k < 8; ++k) if (b0 + 8 * k < nblocks) t += v[k];
+            partial[((size_t)blockIdx.x * NP + pl) * C + tid] = t;
         }
     }
     __syncthreads();
-    sh[ln * 128 + c] = t;
-    __syncthreads();
-    double r = 0;
-    if (threadIdx.x < C)
-        for (int k = 0; k < 8; ++k) r += sh[k * 128 + threadIdx.x];
-    return r;
 }
 
-// batch statistics -> mean, invstd (biased variance, like the normalisation uses), running statistics updated with the unbiased one
-__global__ __launch_bounds__(1024) void k_t_bn_finalize(const double* __restrict__ partial, int nblocks, int C, double count, float momentum,
-                                                        float* __restrict__ mean, float* __restrict__ invstd, float* __restrict__ run_mean,
-                                                        float* __restrict__ run_var, const int32_t* __restrict__ refused) {
-    __shared__ double sh[8 * 128];
-    const double s = sum_partials(partial, nblocks, C, 0, sh);
-    const double q = sum_partials(partial, nblocks, C, 1, sh);
-    const int c = threadIdx.x;
-    if (c >= C) return;
-    const double m = s / count;
-    double var = q / count - m * m;
-    if (var < 0) var = 0;
-    mean[c] = (float)m;
-    invstd[c] = (float)(1.0 / sqrt(var + (double)EPS_BN));
-    const double unbiased = count > 1 ? var * count / (count - 1) : var;
-    if (*refused) return;                                  // a refused step leaves the running statistics alone (k_t_check_targets)
-    run_mean[c] = (1.f - momentum) * run_mean[c] + momentum * (float)m;
-    run_var[c] = (1.f - momentum) * run_var[c] + momentum * (float)unbiased;
+// ------------------------------------------------------------------------------------------------
+// batch statistics of z[rows][C]: per-channel sum and sum of squares, double accumulation -> partial[block][2][C] (FIN_BN_STATS)
+// ------------------------------------------------------------------------------------------------
+template <int C>
+__global__ __launch_bounds__(256) void k_t_bn_stats(const float* __restrict__ d, size_t rows, double* __restrict__ partial) {
+    constexpr int LC = C / 4, RL = 256 / LC;
+    __shared__ double sh[RL * C];
+    const int tid = threadIdx.x, cl = tid % LC, rl = tid / LC;
+    double a[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
+    for (size_t r = (size_t)blockIdx.x * RL + rl; r < rows; r += (size_t)gridDim.x * RL) {
+        const float4 v = *reinterpret_cast<const float4*>(d + r * C + cl * 4);
+        a[0][0] += v.x; a[0][1] += v.y; a[0][2] += v.z; a[0][3] += v.w;
+        a[1][0] += (double)v.x * v.x; a[1][1] += (double)v.y * v.y; a[1][2] += (double)v.z * v.z; a[1][3] += (double)v.w * v.w;
+    }
+    block_columns<C, 2>(a, sh, partial);
 }
 
 // eval mode: normalise with the running statistics
@@ -150,13 +170,6 @@ __global__ void k_t_bn_from_running(const float* __restrict__ run_mean, const fl
     if (c >= C) return;
     mean[c] = run_mean[c];
     invstd[c] = (float)(1.0 / sqrt((double)run_var[c] + (double)EPS_BN));
-}
-
-// sum over the partials -> a bias gradient (pass 0 of k_t_colstats)
-__global__ __launch_bounds__(1024) void k_t_sum_finalize(const double* __restrict__ partial, int nblocks, int C, float* __restrict__ out) {
-    __shared__ double sh[8 * 128];
-    const double s = sum_partials(partial, nblocks, C, 0, sh);
-    if ((int)threadIdx.x < C) out[threadIdx.x] = (float)s;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -219,7 +232,7 @@ __device__ __forceinline__ float pooled_grad(const float zq[4], float mean, floa
     return (kept && best > 0.f) ? da * scale : 0.f;
 }
 
-// sums of dy and dy * x-hat over (n, y, x) per channel (BN backward), from the pooled gradient: partial[block][2][C]
+// sums of dy and dy * x-hat over (n, y, x) per channel (BN backward), from the pooled gradient: partial[block][2][C] (FIN_BN_BWD)
 template <int C>
 __global__ __launch_bounds__(256) void k_t_pool_bwd_stats(const float* __restrict__ da, const float* __restrict__ z, const float* __restrict__ mean,
                                                           const float* __restrict__ invstd, const float* __restrict__ g, const float* __restrict__ be,
@@ -235,7 +248,7 @@ __global__ __launch_bounds__(256) void k_t_pool_bwd_stats(const float* __restric
         const int c = cl * 4 + k;
         mn[k] = mean[c]; iv[k] = invstd[c]; al[k] = iv[k] * g[c]; bt[k] = be[c] - mn[k] * al[k];
     }
-    double s[4] = {0, 0, 0, 0}, q[4] = {0, 0, 0, 0};
+    double a[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
     for (size_t r = (size_t)blockIdx.x * RL + rl; r < rows; r += (size_t)gridDim.x * RL) {
         const int px = r % H, py = (r / H) % H, crop = r / ((size_t)H * H);
         float4 v[4];
@@ -246,69 +259,62 @@ __global__ __launch_bounds__(256) void k_t_pool_bwd_stats(const float* __restric
             const float zq[4] = {f4get(v[0], k), f4get(v[1], k), f4get(v[2], k), f4get(v[3], k)};
             int arg; float xh;
             const float gy = pooled_grad(zq, mn[k], iv[k], al[k], bt[k], f4get(d, k), keep[(size_t)crop * C + cl * 4 + k] != 0, scale, &arg, &xh);
-            s[k] += gy; q[k] += (double)gy * xh;
+            a[0][k] += gy; a[1][k] += (double)gy * xh;
         }
     }
-    for (int pass = 0; pass < 2; ++pass) {
-        __syncthreads();
-#pragma unroll
-        for (int k = 0; k < 4; ++k) sh[rl * C + cl * 4 + k] = pass ? q[k] : s[k];
-        __syncthreads();
-        if (tid < C) {
-            double t = 0;
-            for (int r = 0; r < RL; ++r) t += sh[r * C + tid];
-            partial[((size_t)blockIdx.x * 2 + pass) * C + tid] = t;
-        }
-    }
+    block_columns<C, 2>(a, sh, partial);
 }
 
-// -> sums[0][C] = sum dy (= d beta), sums[1][C] = sum dy x-hat (= d gamma), and the two gradients
-__global__ __launch_bounds__(1024) void k_t_bn_bwd_finalize(const double* __restrict__ partial, int nblocks, int C, float* __restrict__ sums,
-                                                            float* __restrict__ d_gamma, float* __restrict__ d_beta) {
-    __shared__ double sh[8 * 128];
-    const double s = sum_partials(partial, nblocks, C, 0, sh);
-    const double q = sum_partials(partial, nblocks, C, 1, sh);
-    const int c = threadIdx.x;
-    if (c >= C) return;
-    sums[c] = (float)s; sums[C + c] = (float)q;
-    d_beta[c] = (float)s; d_gamma[c] = (float)q;
-}
-
-// dz = gamma * invstd * (dy - mean(dy) - x-hat * mean(dy x-hat)), written over z (dy is non-zero at the pool's arg-max only)
+// dz = gamma * invstd * (dy - mean(dy) - x-hat * mean(dy x-hat)), written over z (dy is non-zero at the pool's arg-max only); the column sums
+// of what was written are the convolution bias's gradient (rounding noise around 0: the bias feeds a BatchNorm): partial[block][1][C]
+// (FIN_BIAS).  A thread's elements lie a grid-stride apart (a multiple of C / 4: it stays on its four channels)
 template <int C>
 __global__ __launch_bounds__(256) void k_t_bn_bwd(const float* __restrict__ da, float* __restrict__ z, const float* __restrict__ mean,
                                                   const float* __restrict__ invstd, const float* __restrict__ g, const float* __restrict__ be,
-                                                  const uint8_t* __restrict__ keep, float scale, const float* __restrict__ sums, float inv_count, int n, int S) {
+                                                  const uint8_t* __restrict__ keep, float scale, const float* __restrict__ sums, float inv_count, int n, int S,
+                                                  double* __restrict__ partial) {
+    constexpr int LC = C / 4, RL = 256 / LC;
+    __shared__ double sh[RL * C];
     const int H = S / 2;
-    const size_t total = (size_t)n * H * H * (C / 4);
-    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (idx >= total) return;
-    const int c4 = idx % (C / 4);
-    const size_t pos = idx / (C / 4);
-    const int px = pos % H, py = (pos / H) % H, crop = pos / ((size_t)H * H);
-    float4 v[4];
-    load_window<C>(z, S, crop, py, px, c4, v);
-    const float4 d = *reinterpret_cast<const float4*>(da + pos * C + c4 * 4);
-    float4 o[4];
+    const size_t total = (size_t)n * H * H * LC;
+    const int c4 = threadIdx.x % LC;
+    float mn[4], iv[4], al[4], bt[4], m1[4], m2[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const int c = c4 * 4 + k;
-        const float mn = mean[c], iv = invstd[c], gm = g[c], al = iv * gm, bt = be[c] - mn * al;
-        const float zq[4] = {f4get(v[0], k), f4get(v[1], k), f4get(v[2], k), f4get(v[3], k)};
-        int arg; float xh;
-        const float gy = pooled_grad(zq, mn, iv, al, bt, f4get(d, k), keep[(size_t)crop * C + c] != 0, scale, &arg, &xh);
-        const float m1 = sums[c] * inv_count, m2 = sums[C + c] * inv_count;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const float xhat = (zq[q] - mn) * iv;
-            f4set(o[q], k, al * ((q == arg ? gy : 0.f) - m1 - xhat * m2));
-        }
+        mn[k] = mean[c]; iv[k] = invstd[c]; al[k] = iv[k] * g[c]; bt[k] = be[c] - mn[k] * al[k];
+        m1[k] = sums[c] * inv_count; m2[k] = sums[C + c] * inv_count;
     }
-    float* base = z + (((size_t)crop * S + 2 * py) * S + 2 * px) * C + c4 * 4;
-    *reinterpret_cast<float4*>(base) = o[0];
-    *reinterpret_cast<float4*>(base + C) = o[1];
-    *reinterpret_cast<float4*>(base + (size_t)S * C) = o[2];
-    *reinterpret_cast<float4*>(base + (size_t)S * C + C) = o[3];
+    double a[1][4] = {{0, 0, 0, 0}};
+    for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
+        const size_t pos = idx / LC;
+        const int px = pos % H, py = (pos / H) % H, crop = pos / ((size_t)H * H);
+        float4 v[4];
+        load_window<C>(z, S, crop, py, px, c4, v);
+        const float4 d = *reinterpret_cast<const float4*>(da + pos * C + c4 * 4);
+        float4 o[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float zq[4] = {f4get(v[0], k), f4get(v[1], k), f4get(v[2], k), f4get(v[3], k)};
+            int arg; float xh;
+            const float gy = pooled_grad(zq, mn[k], iv[k], al[k], bt[k], f4get(d, k), keep[(size_t)crop * C + c4 * 4 + k] != 0, scale, &arg, &xh);
+            float w = 0.f;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float xhat = (zq[q] - mn[k]) * iv[k];
+                const float dz = al[k] * ((q == arg ? gy : 0.f) - m1[k] - xhat * m2[k]);
+                f4set(o[q], k, dz);
+                w += dz;
+            }
+            a[0][k] += w;
+        }
+        float* base = z + (((size_t)crop * S + 2 * py) * S + 2 * px) * C + c4 * 4;
+        *reinterpret_cast<float4*>(base) = o[0];
+        *reinterpret_cast<float4*>(base + C) = o[1];
+        *reinterpret_cast<float4*>(base + (size_t)S * C) = o[2];
+        *reinterpret_cast<float4*>(base + (size_t)S * C + C) = o[3];
+    }
+    block_columns<C, 1>(a, sh, partial);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1255,7 +1261,7 @@ struct Trainer {
     std::vector<void*> allocs;
 };
 
-static constexpr int RED_BLOCKS = 256;
+static constexpr int RED_BLOCKS = 256, BWD_BLOCKS = 1024;   // grids of the reduction kernels (partials: red[BWD_BLOCKS][2][128])
 using WG3 = WgradGeom<64, 128, 20, 32, 64, 5, 10>;   // conv3: block type = kernel row x 32-channel half x 64-channel half (20 types), unit = 10 rows of a crop
 using WG2 = WgradGeom<16, 64, 40, 16, 64, 3, 5>;     // conv2: block type = kernel row (5 types), unit = 5 rows of a crop
 using WH3 = WgradHGeom<64, 128, 20, 32, 10>;        // precision 0: conv3 4 block types x 64 shares, conv2 1 x 256
@@ -1314,11 +1320,6 @@ using H3F = ConvGeomH<64, 128, 20, 10, 32>;
 using H3B = ConvGeomH<128, 64, 20, 10, 32>;
 using H2B = ConvGeomH<64, 32, 40, 20, 16>;       // 16 output channels in a 32-wide tile          // conv2's data gradient: 16 output channels on 16x16x4 tiles, two blocks per crop
 
-template <int C>
-static void launch_colstats(hipStream_t s, const float* d, size_t rows, double* red) {
-    hipLaunchKernelGGL((k_t_colstats<C>), dim3(RED_BLOCKS), dim3(256), 0, s, d, rows, red);
-}
-
 template <int CH>
 static void launch_layer1(Trainer* t, hipStream_t s, const float* x, int n) {
     hipLaunchKernelGGL((k_t_conv1<CH>), dim3(n * 20), dim3(320), 0, s, x, t->P + t->off[T_C1W], t->P + t->off[T_C1B], t->z1);
@@ -1336,9 +1337,9 @@ static void bn_forward(Trainer* t, hipStream_t s, int layer, const float* z, flo
     float* mean = t->stat + layer * 512;
     float* invstd = mean + 128;
     const size_t rows = (size_t)n * S * S;
-    launch_colstats<C>(s, z, rows, t->red);
-    hipLaunchKernelGGL(k_t_bn_finalize, dim3(1), dim3(1024), 0, s, t->red, RED_BLOCKS, C, (double)rows, t->p.bn_momentum, mean, invstd, t->P + t->off[trm],
-                       t->P + t->off[trv], t->bad_target);
+    hipLaunchKernelGGL((k_t_bn_stats<C>), dim3(RED_BLOCKS), dim3(256), 0, s, z, rows, t->red);
+    hipLaunchKernelGGL((k_t_red_finalize<FIN_BN_STATS>), dim3(C), dim3(256), 0, s, t->red, RED_BLOCKS, C,
+                       FinArgs{(double)rows, t->p.bn_momentum, mean, invstd, t->P + t->off[trm], t->P + t->off[trv], t->bad_target});
     const size_t total = (size_t)n * (S / 2) * (S / 2) * (C / 4);
     hipLaunchKernelGGL((k_t_bn_pool<C>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, z, mean, invstd, t->P + t->off[tg], t->P + t->off[tb], keep, scale,
                        a, n, S);
@@ -1352,13 +1353,15 @@ static void bn_backward(Trainer* t, hipStream_t s, int layer, const float* da, f
     float* sums = mean + 256;
     hipLaunchKernelGGL((k_t_pool_bwd_stats<C>), dim3(RED_BLOCKS), dim3(256), 0, s, da, z, mean, invstd, t->P + t->off[tg], t->P + t->off[tb], keep, scale, n, S,
                        t->red);
-    hipLaunchKernelGGL(k_t_bn_bwd_finalize, dim3(1), dim3(1024), 0, s, t->red, RED_BLOCKS, C, sums, t->G + t->off[tg], t->G + t->off[tb]);
+    hipLaunchKernelGGL((k_t_red_finalize<FIN_BN_BWD>), dim3(C), dim3(256), 0, s, t->red, RED_BLOCKS, C,
+                       FinArgs{0.0, 0.f, sums, t->G + t->off[tg], t->G + t->off[tb], nullptr, nullptr});
     const size_t total = (size_t)n * (S / 2) * (S / 2) * (C / 4);
     const float inv_count = (float)(1.0 / ((double)n * S * S));
-    hipLaunchKernelGGL((k_t_bn_bwd<C>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, da, z, mean, invstd, t->P + t->off[tg], t->P + t->off[tb], keep,
-                       scale, sums, inv_count, n, S);
-    launch_colstats<C>(s, z, (size_t)n * S * S, t->red);
-    hipLaunchKernelGGL(k_t_sum_finalize, dim3(1), dim3(1024), 0, s, t->red, RED_BLOCKS, C, t->G + t->off[tcb]);
+    // whole rounds: every workgroup takes the same number of elements, all of them resident at once
+    const unsigned nb0 = (unsigned)((total + 255) / 256), per = (nb0 + BWD_BLOCKS - 1) / BWD_BLOCKS, nb = (nb0 + per - 1) / per;
+    hipLaunchKernelGGL((k_t_bn_bwd<C>), dim3(nb), dim3(256), 0, s, da, z, mean, invstd, t->P + t->off[tg], t->P + t->off[tb], keep, scale, sums, inv_count, n, S,
+                       t->red);
+    hipLaunchKernelGGL((k_t_red_finalize<FIN_BIAS>), dim3(C), dim3(256), 0, s, t->red, (int)nb, C, FinArgs{0.0, 0.f, t->G + t->off[tcb], nullptr, nullptr, nullptr, nullptr});
 }
 
 // steps with a target outside 0..classes-1 were refused on the device (k_t_check_targets) and have changed nothing: report them at the next
@@ -1588,7 +1591,7 @@ int trexhip_trainer_create(trexhip_ctx* ctx, const void* blob, size_t bytes, con
     TRY(dev_alloc(t, &t->hpart, n * 100 * 100)); TRY(dev_alloc(t, &t->xhat, n * 100)); TRY(dev_alloc(t, &t->hd, n * 100));
     TRY(dev_alloc(t, &t->dl, n * classes)); TRY(dev_alloc(t, &t->dy, n * 100)); TRY(dev_alloc(t, &t->dh, n * 100));
     TRY(dev_alloc(t, &t->loss, n)); TRY(dev_alloc(t, &t->correct, n)); TRY(dev_alloc(t, &t->out2, 2)); TRY(dev_alloc(t, &t->bad_target, 2));
-    TRY(dev_alloc(t, &t->red, (size_t)RED_BLOCKS * 2 * 128)); TRY(dev_alloc(t, &t->keep, n * 308));
+    TRY(dev_alloc(t, &t->red, (size_t)BWD_BLOCKS * 2 * 128)); TRY(dev_alloc(t, &t->keep, n * 308));
     TRY(dev_alloc(t, &t->x_stage, n * 6400 * CH)); TRY(dev_alloc(t, &t->y_stage, n)); TRY(dev_alloc(t, &t->keep_stage, n * 308));
 #undef TRY
     if (rc != TREXHIP_OK) { trainer_free(t); return rc; }
