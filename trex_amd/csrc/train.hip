@@ -1211,13 +1211,13 @@ __global__ __launch_bounds__(256) void k_t_adam(float* __restrict__ P, const flo
     P[i] = P[i] + (-step_size) * (m / denom);
 }
 
-__global__ void k_t_loss(const float* __restrict__ loss, const int32_t* __restrict__ correct, int n, float* __restrict__ out /*[2]*/) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    double s = 0;
+__global__ __launch_bounds__(64) void k_t_loss(const float* __restrict__ loss, const int32_t* __restrict__ correct, int n, float* __restrict__ out /*[2]*/) {
+    double s = 0;                                            // one wave: lane sums in index order, then a fixed butterfly
     int c = 0;
-    for (int i = 0; i < n; ++i) { s += loss[i]; c += correct[i]; }
-    out[0] = (float)(s / n);
-    out[1] = (float)c;
+    for (int i = threadIdx.x; i < n; i += 64) { s += loss[i]; c += correct[i]; }
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { s += __shfl_xor(s, d); c += __shfl_xor(c, d); }
+    if (threadIdx.x == 0) { out[0] = (float)(s / n); out[1] = (float)c; }
 }
 
 // keep masks when the caller injects none: one counter-based hash per (step, layer, sample, channel)
@@ -1257,6 +1257,11 @@ struct Trainer {
     int32_t* y_stage = nullptr;
     uint8_t* keep_stage = nullptr;
     size_t part_floats = 0;
+    float* part1 = nullptr;              // conv1's weight-gradient partials (its kernels run beside the side stream's, which own `part`)
+    // the training step forks: weight packing, the head's / fc1's / the convolutions' weight gradients and the loss sum run on `side`, beside the
+    // chain that the next kernel waits for (data gradients, BN backward); the step joins again in front of Adam
+    hipStream_t side = nullptr;
+    hipEvent_t ev[6] = {};
     bool attr = false;
     std::vector<void*> allocs;
 };
@@ -1308,6 +1313,8 @@ static int dev_alloc(Trainer* t, T** p, size_t count) {
 static void trainer_free(Trainer* t) {
     if (!t) return;
     for (void* q : t->allocs) (void)hipFree(q);
+    for (hipEvent_t e : t->ev) if (e) (void)hipEventDestroy(e);
+    if (t->side) (void)hipStreamDestroy(t->side);
     delete t;
 }
 
@@ -1326,9 +1333,9 @@ static void launch_layer1(Trainer* t, hipStream_t s, const float* x, int n) {
 }
 template <int CH>
 static void launch_wgrad1(Trainer* t, hipStream_t s, const float* x, int n) {
-    hipLaunchKernelGGL((k_t_wgrad1<CH>), dim3(n * 10), dim3(512), 0, s, x, t->z1, t->part);
+    hipLaunchKernelGGL((k_t_wgrad1<CH>), dim3(n * 10), dim3(512), 0, s, x, t->z1, t->part1);
     const int count = CH * 400;
-    hipLaunchKernelGGL(k_t_reduce, dim3((count + 15) / 16), dim3(256), 0, s, t->part, n * 10, count, t->G + t->off[T_C1W]);
+    hipLaunchKernelGGL(k_t_reduce, dim3((count + 15) / 16), dim3(256), 0, s, t->part1, n * 10, count, t->G + t->off[T_C1W]);
 }
 
 template <int C>
@@ -1382,15 +1389,18 @@ static int check_targets(Trainer* t) {
 
 // forward pass up to the per-sample loss / arg-max (and, as a by-product of k_t_head, the gradient at the fc1 output).  train = batch
 // statistics + dropout masks `keep`; eval = running statistics, nothing dropped (model.eval(), visual_recognition_torch.py:1171-1185)
-static void trainer_forward(Trainer* t, hipStream_t s, const float* x, const int32_t* targets, int n, const uint8_t* keep, float scale, bool train) {
+static void trainer_forward(Trainer* t, hipStream_t s, const float* x, const int32_t* targets, int n, const uint8_t* keep, float scale, bool train,
+                            hipStream_t side = nullptr) {
     const uint8_t *k1 = keep, *k2 = keep + (size_t)n * 16, *k3 = keep + (size_t)n * 80, *k4 = keep + (size_t)n * 208;
     float* P = t->P;
     const size_t* o = t->off;
     const bool h2 = t->p.precision == 0;
     if (h2) {
-        // this step's weights as fp16 two-piece operand images (both directions)
-        hipLaunchKernelGGL(k_t_pack_h2, dim3(10), dim3(1024), 0, s, P + o[T_C2W], 16, 64, 16, 16, 16, 32, t->wh2f, t->wh2b, t->wh_scale);
-        hipLaunchKernelGGL(k_t_pack_h2, dim3(50), dim3(1024), 0, s, P + o[T_C3W], 64, 128, 32, 32, 32, 64, t->wh3f, t->wh3b, t->wh_scale + 1);
+        // this step's weights as fp16 two-piece operand images (both directions); conv2 is the first to need them
+        hipStream_t ps = side ? side : s;
+        hipLaunchKernelGGL(k_t_pack_h2, dim3(10), dim3(1024), 0, ps, P + o[T_C2W], 16, 64, 16, 16, 16, 32, t->wh2f, t->wh2b, t->wh_scale);
+        hipLaunchKernelGGL(k_t_pack_h2, dim3(50), dim3(1024), 0, ps, P + o[T_C3W], 64, 128, 32, 32, 32, 64, t->wh3f, t->wh3b, t->wh_scale + 1);
+        if (side) (void)hipEventRecord(t->ev[1], side);
     }
     auto block = [&](auto tag, int layer, const float* z, float* a, int S, int tg, int tb, int trm, int trv, const uint8_t* kp) {
         constexpr int C = decltype(tag)::value;
@@ -1403,6 +1413,7 @@ static void trainer_forward(Trainer* t, hipStream_t s, const float* x, const int
     };
     if (t->CH == 1) launch_layer1<1>(t, s, x, n); else launch_layer1<3>(t, s, x, n);
     block(std::integral_constant<int, 16>{}, 0, t->z1, t->a1, 80, T_G1, T_BE1, T_RM1, T_RV1, k1);
+    if (h2 && side) (void)hipStreamWaitEvent(s == hipStreamLegacy ? nullptr : s, t->ev[1], 0);
     if (h2) hipLaunchKernelGGL((k_t_conv5_h2<16, 64, 40, 20, 16, 64>), dim3(n * H2F::BPC), dim3(512), H2F::LDS_BYTES, s, t->a1, t->wh2f, P + o[T_C2B], t->z2, t->wh_scale);
     else hipLaunchKernelGGL((k_conv5<16, 64, 40, 20, 16, CONV_EPI_RAW, 64>), dim3(n * G2F::BPC), dim3(512), G2F::LDS_BYTES, s, t->a1, P + o[T_C2W], P + o[T_C2B], t->z2);
     block(std::integral_constant<int, 64>{}, 1, t->z2, t->a2, 40, T_G2, T_BE2, T_RM2, T_RV2, k2);
@@ -1467,24 +1478,33 @@ static int trainer_step(Trainer* t, const float* x, const int32_t* targets, int 
     float* G = t->G;
     const size_t* o = t->off;
     hipLaunchKernelGGL(k_t_check_targets, dim3(1), dim3(256), 0, s, targets, n, t->classes, t->bad_target, 0);
-    trainer_forward(t, s, x, targets, n, keep, scale, true);
+    hipStream_t w = t->side;                                                // the weight-gradient side of the step
+    // (events go through the null stream when the caller's stream is the hipStreamLegacy handle: this runtime faults in a wait on an event
+    // recorded on the handle itself; in this library the two name the same stream)
+    hipStream_t es = s == hipStreamLegacy ? nullptr : s;
+    auto fork = [&](int e) { (void)hipEventRecord(t->ev[e], es); (void)hipStreamWaitEvent(w, t->ev[e], 0); };
+    fork(0);                                                                // behind whatever wrote the parameters last
+    trainer_forward(t, s, x, targets, n, keep, scale, true, w);
+    fork(2);
     const uint8_t *k1 = keep, *k2 = keep + (size_t)n * 16, *k3 = keep + (size_t)n * 80;
     // ---- backward
     {
         const int cnt = t->classes * 100 + t->classes + 300;
-        hipLaunchKernelGGL(k_t_head_grads, dim3((cnt + 255) / 256), dim3(256), 0, s, t->dl, t->hd, t->dy, t->xhat, t->dh, n, t->classes, G + o[T_F2W], G + o[T_F2B],
+        hipLaunchKernelGGL(k_t_head_grads, dim3((cnt + 255) / 256), dim3(256), 0, w, t->dl, t->hd, t->dy, t->xhat, t->dh, n, t->classes, G + o[T_F2W], G + o[T_F2B],
                            G + o[T_LNG], G + o[T_LNB], G + o[T_F1B]);
     }
-    hipLaunchKernelGGL(k_t_fc1_wgrad, dim3(100), dim3(256), 0, s, t->a3, t->dh, G + o[T_F1W], n);
+    hipLaunchKernelGGL(k_t_fc1_wgrad, dim3(100), dim3(256), 0, w, t->a3, t->dh, G + o[T_F1W], n);
+    hipLaunchKernelGGL(k_t_loss, dim3(1), dim3(64), 0, w, t->loss, t->correct, n, t->out2);
     hipLaunchKernelGGL(k_t_fc1_dgrad, dim3(100, (n + 31) / 32), dim3(256), 0, s, t->dh, P + o[T_F1W], t->da3, n);
     // block 3
     const bool h2 = t->p.precision == 0;
     bn_backward<128>(t, s, 2, t->da3, t->z3, n, 20, T_G3, T_BE3, T_C3B, k3, scale);
+    fork(3);
     {
         const int shares = h2 ? (n * WH3::NB < SHARES3H ? n * WH3::NB : SHARES3H) : (n * WG3::NB < SHARES3 ? n * WG3::NB : SHARES3);
-        if (h2) hipLaunchKernelGGL((k_t_wgrad_h2<64, 128, 20, 32, 10>), dim3(WH3::TYPES, shares), dim3(640), WH3::LDS_BYTES, s, t->a2, t->z3, t->part, n);
-        else hipLaunchKernelGGL((k_t_wgrad<64, 128, 20, 32, 64, 5, 10>), dim3(WG3::TYPES, shares), dim3(512), WG3::LDS_BYTES, s, t->a2, t->z3, t->part, n);
-        hipLaunchKernelGGL(k_t_wgrad_reduce, dim3((25 * 64 * 128 + 255) / 256), dim3(256), 0, s, t->part, shares, 64, 128, 32, G + o[T_C3W]);
+        if (h2) hipLaunchKernelGGL((k_t_wgrad_h2<64, 128, 20, 32, 10>), dim3(WH3::TYPES, shares), dim3(640), WH3::LDS_BYTES, w, t->a2, t->z3, t->part, n);
+        else hipLaunchKernelGGL((k_t_wgrad<64, 128, 20, 32, 64, 5, 10>), dim3(WG3::TYPES, shares), dim3(512), WG3::LDS_BYTES, w, t->a2, t->z3, t->part, n);
+        hipLaunchKernelGGL(k_t_wgrad_reduce, dim3((25 * 64 * 128 + 255) / 256), dim3(256), 0, w, t->part, shares, 64, 128, 32, G + o[T_C3W]);
         if (h2) hipLaunchKernelGGL((k_t_conv5_h2<128, 64, 20, 10, 32, 64>), dim3(n * H3B::BPC), dim3(512), H3B::LDS_BYTES, s, t->z3, t->wh3b, (const float*)nullptr, t->da2, t->wh_scale + 1);
         else {
             hipLaunchKernelGGL(k_t_repack_bwd, dim3((25 * 128 * 64 + 255) / 256), dim3(256), 0, s, P + o[T_C3W], 64, 128, 32, 64, 32, t->wb3);
@@ -1493,11 +1513,13 @@ static int trainer_step(Trainer* t, const float* x, const int32_t* targets, int 
     }
     // block 2
     bn_backward<64>(t, s, 1, t->da2, t->z2, n, 40, T_G2, T_BE2, T_C2B, k2, scale);
+    fork(4);
     {
         const int shares = h2 ? (n * WH2::NB < SHARES2H ? n * WH2::NB : SHARES2H) : (n * WG2::NB < SHARES2 ? n * WG2::NB : SHARES2);
-        if (h2) hipLaunchKernelGGL((k_t_wgrad_h2<16, 64, 40, 16, 10>), dim3(WH2::TYPES, shares), dim3(640), WH2::LDS_BYTES, s, t->a1, t->z2, t->part, n);
-        else hipLaunchKernelGGL((k_t_wgrad<16, 64, 40, 16, 64, 3, 5>), dim3(WG2::TYPES, shares), dim3(512), WG2::LDS_BYTES, s, t->a1, t->z2, t->part, n);
-        hipLaunchKernelGGL(k_t_wgrad_reduce, dim3((25 * 16 * 64 + 255) / 256), dim3(256), 0, s, t->part, shares, 16, 64, 16, G + o[T_C2W]);
+        if (h2) hipLaunchKernelGGL((k_t_wgrad_h2<16, 64, 40, 16, 10>), dim3(WH2::TYPES, shares), dim3(640), WH2::LDS_BYTES, w, t->a1, t->z2, t->part, n);
+        else hipLaunchKernelGGL((k_t_wgrad<16, 64, 40, 16, 64, 3, 5>), dim3(WG2::TYPES, shares), dim3(512), WG2::LDS_BYTES, w, t->a1, t->z2, t->part, n);
+        hipLaunchKernelGGL(k_t_wgrad_reduce, dim3((25 * 16 * 64 + 255) / 256), dim3(256), 0, w, t->part, shares, 16, 64, 16, G + o[T_C2W]);
+        (void)hipEventRecord(t->ev[5], w);
         if (h2) hipLaunchKernelGGL((k_t_conv5_h2<64, 32, 40, 20, 16, 16>), dim3(n * H2B::BPC), dim3(512), H2B::LDS_BYTES, s, t->z2, t->wh2b, (const float*)nullptr, t->da1, t->wh_scale);
         else {
             hipLaunchKernelGGL(k_t_repack_bwd, dim3((25 * 64 * 16 + 255) / 256), dim3(256), 0, s, P + o[T_C2W], 16, 64, 16, 16, 16, t->wb2);
@@ -1507,6 +1529,7 @@ static int trainer_step(Trainer* t, const float* x, const int32_t* targets, int 
     // block 1
     bn_backward<16>(t, s, 0, t->da1, t->z1, n, 80, T_G1, T_BE1, T_C1B, k1, scale);
     if (t->CH == 1) launch_wgrad1<1>(t, s, x, n); else launch_wgrad1<3>(t, s, x, n);
+    (void)hipStreamWaitEvent(es, t->ev[5], 0);                              // join: every gradient is in G
     // ---- optimizer
     t->step += 1;
     {
@@ -1518,7 +1541,6 @@ static int trainer_step(Trainer* t, const float* x, const int32_t* targets, int 
         hipLaunchKernelGGL(k_t_adam, dim3((unsigned)((t->total + 255) / 256)), dim3(256), 0, s, P, G, t->M, t->V, (uint32_t)t->total, skip, (float)(1.0 - b1), (float)b2,
                            (float)(1.0 - b2), (float)((double)t->p.lr / bc1), (float)std::sqrt(bc2), t->p.eps, t->bad_target);
     }
-    hipLaunchKernelGGL(k_t_loss, dim3(1), dim3(64), 0, s, t->loss, t->correct, n, t->out2);
     TH_CHECK_HIP(hipGetLastError());
     if (h_loss || h_correct) {
         float two[2];
@@ -1586,7 +1608,7 @@ int trexhip_trainer_create(trexhip_ctx* ctx, const void* blob, size_t bytes, con
     TRY(dev_alloc(t, &t->wh_scale, 2));
     t->part_floats = std::max(std::max(std::max((size_t)SHARES3 * 25 * 64 * 128, (size_t)SHARES2 * 25 * 16 * 64), std::max((size_t)SHARES3H * 25 * 64 * 128, (size_t)SHARES2H * 25 * 16 * 64)),
                               n * 10 * CH * 400);
-    TRY(dev_alloc(t, &t->part, t->part_floats));
+    TRY(dev_alloc(t, &t->part, t->part_floats)); TRY(dev_alloc(t, &t->part1, n * 10 * CH * 400));
     TRY(dev_alloc(t, &t->stat, (size_t)3 * 512));
     TRY(dev_alloc(t, &t->hpart, n * 100 * 100)); TRY(dev_alloc(t, &t->xhat, n * 100)); TRY(dev_alloc(t, &t->hd, n * 100));
     TRY(dev_alloc(t, &t->dl, n * classes)); TRY(dev_alloc(t, &t->dy, n * 100)); TRY(dev_alloc(t, &t->dh, n * 100));
@@ -1594,6 +1616,9 @@ int trexhip_trainer_create(trexhip_ctx* ctx, const void* blob, size_t bytes, con
     TRY(dev_alloc(t, &t->red, (size_t)BWD_BLOCKS * 2 * 128)); TRY(dev_alloc(t, &t->keep, n * 308));
     TRY(dev_alloc(t, &t->x_stage, n * 6400 * CH)); TRY(dev_alloc(t, &t->y_stage, n)); TRY(dev_alloc(t, &t->keep_stage, n * 308));
 #undef TRY
+    if (rc == TREXHIP_OK && hipStreamCreateWithFlags(&t->side, hipStreamNonBlocking) != hipSuccess) { set_error("trexhip_trainer_create: no second stream"); rc = TREXHIP_E_DEVICE; }
+    for (hipEvent_t& e : t->ev)
+        if (rc == TREXHIP_OK && hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { set_error("trexhip_trainer_create: no event"); rc = TREXHIP_E_DEVICE; }
     if (rc != TREXHIP_OK) { trainer_free(t); return rc; }
     std::vector<float> host(at, 0.f);
     const float* src = reinterpret_cast<const float*>(static_cast<const char*>(blob) + 32);
