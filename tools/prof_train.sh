@@ -7,10 +7,10 @@ OUT=$ROOT/gpurun_out/prof
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/ptrain
-PYTHONPATH=$ROOT rocprofv3 --kernel-trace --stats -d /tmp/ptrain -o t --output-format csv -- python $ROOT/tools/time_train.py --steps 12 --cpu-steps 0 > /tmp/ptrain.log 2>&1
+PYTHONPATH=$ROOT timeout 120 rocprofv3 --kernel-trace --stats -d /tmp/ptrain -o t --output-format csv -- python $ROOT/tools/time_train.py --steps 12 --cpu-steps 0 > /tmp/ptrain.log 2>&1
 F=$(find /tmp/ptrain -name "*kernel_stats.csv" | head -1)
 [ -n "$F" ] && cp "$F" "$OUT/${TAG}_train_step_kernel_stats.csv"
 cd $ROOT
-for i in 1 2 3; do python tools/time_train.py --steps 50 --cpu-steps 0 2>/dev/null | tail -1; done > "$OUT/${TAG}_train_step_time.txt"
+for i in 1 2 3; do timeout 60 python tools/time_train.py --steps 50 --cpu-steps 0 2>/dev/null | tail -1; done > "$OUT/${TAG}_train_step_time.txt"
 cat "$OUT/${TAG}_train_step_time.txt"
 head -45 "$OUT/${TAG}_train_step_kernel_stats.csv" | cut -c1-60,150-260

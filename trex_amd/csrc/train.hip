@@ -39,7 +39,7 @@ static constexpr float EPS_BN = 1e-5f, EPS_LN = 1e-5f;
 // ------------------------------------------------------------------------------------------------
 template <int CH>
 __global__ __launch_bounds__(320) void k_t_conv1(const float* __restrict__ x, const float* __restrict__ w /*[CH][25][16]*/,
-                                                 const float* __restrict__ b, float* __restrict__ z) {
+                                                 const float* __restrict__ b, float* __restrict__ z, double* __restrict__ stat_partial /*[block][2][16] or null*/) {
     __shared__ float xs[8 * 84 * CH];
     __shared__ __attribute__((aligned(16))) float ws[CH * 25 * 16];
     const int tid = threadIdx.x, crop = blockIdx.x / 20, row0 = (blockIdx.x % 20) * 4;
@@ -68,9 +68,44 @@ __global__ __launch_bounds__(320) void k_t_conv1(const float* __restrict__ x, co
                     acc[4 * q] += v * t.x; acc[4 * q + 1] += v * t.y; acc[4 * q + 2] += v * t.z; acc[4 * q + 3] += v * t.w;
                 }
             }
+#pragma unroll
+    for (int k = 0; k < 16; ++k) acc[k] += b[k];
     float4* o = reinterpret_cast<float4*>(z + (((size_t)crop * 80 + row0 + y) * 80 + xx) * 16);
 #pragma unroll
-    for (int q = 0; q < 4; ++q) o[q] = make_float4(acc[4 * q] + b[4 * q], acc[4 * q + 1] + b[4 * q + 1], acc[4 * q + 2] + b[4 * q + 2], acc[4 * q + 3] + b[4 * q + 3]);
+    for (int q = 0; q < 4; ++q) o[q] = make_float4(acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]);
+    if (!stat_partial) return;                                // (uniform)
+    // the block's column sums and sums of squares for the BN that follows.  Per wave a reduce-scatter butterfly: at distance 32, 16, 8, 4 a lane
+    // keeps half of its channels and hands the other half to its partner, then two plain steps: a lane ends with the sum of channel
+    // 8 b5 + 4 b4 + 2 b3 + b2 (b = bits of its number; 17 exchanges per plane instead of 96).  The five waves are added in order through LDS
+    __shared__ double sred[5][2][16];
+    const int lane = tid & 63, wave = tid >> 6;
+#pragma unroll
+    for (int pl = 0; pl < 2; ++pl) {
+        double v[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) v[k] = pl ? (double)acc[k] * acc[k] : (double)acc[k];
+#define T_RS(N, D)                                                                                       \
+        {                                                                                                \
+            const bool hi = (lane & D) != 0;                                                             \
+            _Pragma("unroll") for (int k = 0; k < N; ++k) {                                              \
+                const double mine = hi ? v[k + N] : v[k], other = hi ? v[k] : v[k + N];                  \
+                v[k] = mine + __shfl_xor(other, D);                                                      \
+            }                                                                                            \
+        }
+        T_RS(8, 32) T_RS(4, 16) T_RS(2, 8) T_RS(1, 4)
+#undef T_RS
+        v[0] += __shfl_xor(v[0], 2);
+        v[0] += __shfl_xor(v[0], 1);
+        if ((lane & 3) == 0) sred[wave][pl][((lane >> 5) & 1) * 8 + ((lane >> 4) & 1) * 4 + ((lane >> 3) & 1) * 2 + ((lane >> 2) & 1)] = v[0];
+    }
+    __syncthreads();
+    if (tid < 32) {
+        const int pl = tid >> 4, c = tid & 15;
+        double t = 0;
+#pragma unroll
+        for (int wv = 0; wv < 5; ++wv) t += sred[wv][pl][c];
+        stat_partial[((size_t)blockIdx.x * 2 + pl) * 16 + c] = t;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -602,7 +637,7 @@ struct ConvGeomH {
 template <int CI, int CO, int S, int ROWS, int CIC, int COUT>
 __global__ __launch_bounds__(512) void k_t_conv5_h2(const float* __restrict__ in /*[N][S][S][CI]*/, const uint4* __restrict__ wp /*[CI/CIC][25][2][CIC/8][CO] x 16 B*/,
                                                     const float* __restrict__ bias /*[COUT] or null*/, float* __restrict__ out /*[N][S][S][COUT]*/,
-                                                    const float* __restrict__ w_scale) {
+                                                    const float* __restrict__ w_scale, double* __restrict__ stat_partial /*[block][2][CO] or null*/) {
     using G = ConvGeomH<CI, CO, S, ROWS, CIC>;
     constexpr int Q4 = CIC / 4, KO = CIC / 8;
     extern __shared__ __attribute__((aligned(16))) uint8_t hlds[];
@@ -714,17 +749,38 @@ __global__ __launch_bounds__(512) void k_t_conv5_h2(const float* __restrict__ in
         }
     }
     const int co = n * 32 + j;
-    if (co >= COUT) return;
+    if (co >= COUT && !(COUT == CO && stat_partial)) return;
     const float out_scale = 1.0f / (in_scale * *w_scale);             // powers of two: exact
     const float bz = bias ? bias[co] : 0.f;
     float* oc = out + ((size_t)crop * S * S + (size_t)row0 * S) * COUT;
+    double sv = 0, sq = 0;                                            // this lane's share of the channel's sum and sum of squares (the BN that follows)
 #pragma unroll
     for (int m = 0; m < G::TPW; ++m) {
         const int mt = mg + G::WM * m;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int p = mt * 32 + 8 * (r / 4) + 4 * h + (r % 4);        // accumulator r of lane (j, h) is row 8 (r / 4) + 4 h + r % 4
-            if (p < G::NPIX) oc[(size_t)p * COUT + co] = acc[m][r] * out_scale + bz;
+            if (p < G::NPIX) {
+                const float v = acc[m][r] * out_scale + bz;
+                oc[(size_t)p * COUT + co] = v;
+                if (COUT == CO) { sv += v; sq += (double)v * v; }
+            }
+        }
+    }
+    if constexpr (COUT == CO) {
+        if (!stat_partial) return;                                    // (uniform)
+        // the 2 WM lanes of a channel through LDS (the patch is dead: the tap loop ended on a barrier), added in a fixed order
+        double* sh = reinterpret_cast<double*>(hlds);
+        const int slot = mg * 2 + h;
+        sh[slot * CO + co] = sv;
+        sh[(2 * G::WM + slot) * CO + co] = sq;
+        __syncthreads();
+        if (tid < 2 * CO) {
+            const int pl = tid / CO, c = tid % CO;
+            double t = 0;
+#pragma unroll
+            for (int k = 0; k < 2 * G::WM; ++k) t += sh[(pl * 2 * G::WM + k) * CO + c];
+            stat_partial[((size_t)blockIdx.x * 2 + pl) * CO + c] = t;
         }
     }
 }
@@ -1328,8 +1384,8 @@ using H3B = ConvGeomH<128, 64, 20, 10, 32>;
 using H2B = ConvGeomH<64, 32, 40, 20, 16>;       // 16 output channels in a 32-wide tile          // conv2's data gradient: 16 output channels on 16x16x4 tiles, two blocks per crop
 
 template <int CH>
-static void launch_layer1(Trainer* t, hipStream_t s, const float* x, int n) {
-    hipLaunchKernelGGL((k_t_conv1<CH>), dim3(n * 20), dim3(320), 0, s, x, t->P + t->off[T_C1W], t->P + t->off[T_C1B], t->z1);
+static void launch_layer1(Trainer* t, hipStream_t s, const float* x, int n, bool train) {
+    hipLaunchKernelGGL((k_t_conv1<CH>), dim3(n * 20), dim3(320), 0, s, x, t->P + t->off[T_C1W], t->P + t->off[T_C1B], t->z1, train ? t->red : nullptr);
 }
 template <int CH>
 static void launch_wgrad1(Trainer* t, hipStream_t s, const float* x, int n) {
@@ -1340,12 +1396,12 @@ static void launch_wgrad1(Trainer* t, hipStream_t s, const float* x, int n) {
 
 template <int C>
 static void bn_forward(Trainer* t, hipStream_t s, int layer, const float* z, float* a, int n, int S, int tg, int tb, int trm, int trv, const uint8_t* keep,
-                       float scale) {
+                       float scale, int have_partials /*workgroups of the convolution that left their column sums in t->red; 0 = none did*/) {
     float* mean = t->stat + layer * 512;
     float* invstd = mean + 128;
     const size_t rows = (size_t)n * S * S;
-    hipLaunchKernelGGL((k_t_bn_stats<C>), dim3(RED_BLOCKS), dim3(256), 0, s, z, rows, t->red);
-    hipLaunchKernelGGL((k_t_red_finalize<FIN_BN_STATS>), dim3(C), dim3(256), 0, s, t->red, RED_BLOCKS, C,
+    if (!have_partials) hipLaunchKernelGGL((k_t_bn_stats<C>), dim3(RED_BLOCKS), dim3(256), 0, s, z, rows, t->red);
+    hipLaunchKernelGGL((k_t_red_finalize<FIN_BN_STATS>), dim3(C), dim3(256), 0, s, t->red, have_partials ? have_partials : RED_BLOCKS, C,
                        FinArgs{(double)rows, t->p.bn_momentum, mean, invstd, t->P + t->off[trm], t->P + t->off[trv], t->bad_target});
     const size_t total = (size_t)n * (S / 2) * (S / 2) * (C / 4);
     hipLaunchKernelGGL((k_t_bn_pool<C>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, z, mean, invstd, t->P + t->off[tg], t->P + t->off[tb], keep, scale,
@@ -1402,24 +1458,24 @@ static void trainer_forward(Trainer* t, hipStream_t s, const float* x, const int
         hipLaunchKernelGGL(k_t_pack_h2, dim3(50), dim3(1024), 0, ps, P + o[T_C3W], 64, 128, 32, 32, 32, 64, t->wh3f, t->wh3b, t->wh_scale + 1);
         if (side) (void)hipEventRecord(t->ev[1], side);
     }
-    auto block = [&](auto tag, int layer, const float* z, float* a, int S, int tg, int tb, int trm, int trv, const uint8_t* kp) {
+    auto block = [&](auto tag, int layer, const float* z, float* a, int S, int tg, int tb, int trm, int trv, const uint8_t* kp, int have_partials) {
         constexpr int C = decltype(tag)::value;
-        if (train) { bn_forward<C>(t, s, layer, z, a, n, S, tg, tb, trm, trv, kp, scale); return; }
+        if (train) { bn_forward<C>(t, s, layer, z, a, n, S, tg, tb, trm, trv, kp, scale, have_partials); return; }
         float* mean = t->stat + layer * 512;
         float* invstd = mean + 128;
         hipLaunchKernelGGL(k_t_bn_from_running, dim3(1), dim3(128), 0, s, P + o[trm], P + o[trv], C, mean, invstd);
         const size_t total = (size_t)n * (S / 2) * (S / 2) * (C / 4);
         hipLaunchKernelGGL((k_t_bn_pool<C>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, z, mean, invstd, P + o[tg], P + o[tb], kp, scale, a, n, S);
     };
-    if (t->CH == 1) launch_layer1<1>(t, s, x, n); else launch_layer1<3>(t, s, x, n);
-    block(std::integral_constant<int, 16>{}, 0, t->z1, t->a1, 80, T_G1, T_BE1, T_RM1, T_RV1, k1);
+    if (t->CH == 1) launch_layer1<1>(t, s, x, n, train); else launch_layer1<3>(t, s, x, n, train);
+    block(std::integral_constant<int, 16>{}, 0, t->z1, t->a1, 80, T_G1, T_BE1, T_RM1, T_RV1, k1, n * 20);
     if (h2 && side) (void)hipStreamWaitEvent(s == hipStreamLegacy ? nullptr : s, t->ev[1], 0);
-    if (h2) hipLaunchKernelGGL((k_t_conv5_h2<16, 64, 40, 20, 16, 64>), dim3(n * H2F::BPC), dim3(512), H2F::LDS_BYTES, s, t->a1, t->wh2f, P + o[T_C2B], t->z2, t->wh_scale);
+    if (h2) hipLaunchKernelGGL((k_t_conv5_h2<16, 64, 40, 20, 16, 64>), dim3(n * H2F::BPC), dim3(512), H2F::LDS_BYTES, s, t->a1, t->wh2f, P + o[T_C2B], t->z2, t->wh_scale, train ? t->red : nullptr);
     else hipLaunchKernelGGL((k_conv5<16, 64, 40, 20, 16, CONV_EPI_RAW, 64>), dim3(n * G2F::BPC), dim3(512), G2F::LDS_BYTES, s, t->a1, P + o[T_C2W], P + o[T_C2B], t->z2);
-    block(std::integral_constant<int, 64>{}, 1, t->z2, t->a2, 40, T_G2, T_BE2, T_RM2, T_RV2, k2);
-    if (h2) hipLaunchKernelGGL((k_t_conv5_h2<64, 128, 20, 10, 32, 128>), dim3(n * H3F::BPC), dim3(512), H3F::LDS_BYTES, s, t->a2, t->wh3f, P + o[T_C3B], t->z3, t->wh_scale + 1);
+    block(std::integral_constant<int, 64>{}, 1, t->z2, t->a2, 40, T_G2, T_BE2, T_RM2, T_RV2, k2, h2 ? n * H2F::BPC : 0);
+    if (h2) hipLaunchKernelGGL((k_t_conv5_h2<64, 128, 20, 10, 32, 128>), dim3(n * H3F::BPC), dim3(512), H3F::LDS_BYTES, s, t->a2, t->wh3f, P + o[T_C3B], t->z3, t->wh_scale + 1, train ? t->red : nullptr);
     else hipLaunchKernelGGL((k_conv5<64, 128, 20, 10, 32, CONV_EPI_RAW, 128>), dim3(n * G3F::BPC), dim3(512), G3F::LDS_BYTES, s, t->a2, P + o[T_C3W], P + o[T_C3B], t->z3);
-    block(std::integral_constant<int, 128>{}, 2, t->z3, t->a3, 20, T_G3, T_BE3, T_RM3, T_RV3, k3);
+    block(std::integral_constant<int, 128>{}, 2, t->z3, t->a3, 20, T_G3, T_BE3, T_RM3, T_RV3, k3, h2 ? n * H3F::BPC : 0);
     hipLaunchKernelGGL(k_t_fc1, dim3(100, (n + 63) / 64), dim3(256), 0, s, t->a3, P + o[T_F1W], t->hpart, n);
     hipLaunchKernelGGL(k_t_head, dim3(n), dim3(128), 0, s, t->hpart, n, P + o[T_F1B], P + o[T_LNG], P + o[T_LNB], k4, scale, P + o[T_F2W], P + o[T_F2B], targets,
                        t->classes, t->xhat, t->hd, t->dl, t->dy, t->dh, t->loss, t->correct, t->bad_target);
@@ -1505,7 +1561,7 @@ static int trainer_step(Trainer* t, const float* x, const int32_t* targets, int 
         if (h2) hipLaunchKernelGGL((k_t_wgrad_h2<64, 128, 20, 32, 10>), dim3(WH3::TYPES, shares), dim3(640), WH3::LDS_BYTES, w, t->a2, t->z3, t->part, n);
         else hipLaunchKernelGGL((k_t_wgrad<64, 128, 20, 32, 64, 5, 10>), dim3(WG3::TYPES, shares), dim3(512), WG3::LDS_BYTES, w, t->a2, t->z3, t->part, n);
         hipLaunchKernelGGL(k_t_wgrad_reduce, dim3((25 * 64 * 128 + 255) / 256), dim3(256), 0, w, t->part, shares, 64, 128, 32, G + o[T_C3W]);
-        if (h2) hipLaunchKernelGGL((k_t_conv5_h2<128, 64, 20, 10, 32, 64>), dim3(n * H3B::BPC), dim3(512), H3B::LDS_BYTES, s, t->z3, t->wh3b, (const float*)nullptr, t->da2, t->wh_scale + 1);
+        if (h2) hipLaunchKernelGGL((k_t_conv5_h2<128, 64, 20, 10, 32, 64>), dim3(n * H3B::BPC), dim3(512), H3B::LDS_BYTES, s, t->z3, t->wh3b, (const float*)nullptr, t->da2, t->wh_scale + 1, (double*)nullptr);
         else {
             hipLaunchKernelGGL(k_t_repack_bwd, dim3((25 * 128 * 64 + 255) / 256), dim3(256), 0, s, P + o[T_C3W], 64, 128, 32, 64, 32, t->wb3);
             hipLaunchKernelGGL((k_conv5<128, 64, 20, 10, 32, CONV_EPI_RAW, 64>), dim3(n * G3B::BPC), dim3(512), G3B::LDS_BYTES, s, t->z3, t->wb3, (const float*)nullptr, t->da2);
@@ -1520,7 +1576,7 @@ static int trainer_step(Trainer* t, const float* x, const int32_t* targets, int 
         else hipLaunchKernelGGL((k_t_wgrad<16, 64, 40, 16, 64, 3, 5>), dim3(WG2::TYPES, shares), dim3(512), WG2::LDS_BYTES, w, t->a1, t->z2, t->part, n);
         hipLaunchKernelGGL(k_t_wgrad_reduce, dim3((25 * 16 * 64 + 255) / 256), dim3(256), 0, w, t->part, shares, 16, 64, 16, G + o[T_C2W]);
         (void)hipEventRecord(t->ev[5], w);
-        if (h2) hipLaunchKernelGGL((k_t_conv5_h2<64, 32, 40, 20, 16, 16>), dim3(n * H2B::BPC), dim3(512), H2B::LDS_BYTES, s, t->z2, t->wh2b, (const float*)nullptr, t->da1, t->wh_scale);
+        if (h2) hipLaunchKernelGGL((k_t_conv5_h2<64, 32, 40, 20, 16, 16>), dim3(n * H2B::BPC), dim3(512), H2B::LDS_BYTES, s, t->z2, t->wh2b, (const float*)nullptr, t->da1, t->wh_scale, (double*)nullptr);
         else {
             hipLaunchKernelGGL(k_t_repack_bwd, dim3((25 * 64 * 16 + 255) / 256), dim3(256), 0, s, P + o[T_C2W], 16, 64, 16, 16, 16, t->wb2);
             hipLaunchKernelGGL((k_conv5_n16<64, 40, 20, 16>), dim3(n * G2B::BPC), dim3(512), G2B::LDS_BYTES, s, t->z2, t->wb2, t->da1);
@@ -1613,7 +1669,8 @@ int trexhip_trainer_create(trexhip_ctx* ctx, const void* blob, size_t bytes, con
     TRY(dev_alloc(t, &t->hpart, n * 100 * 100)); TRY(dev_alloc(t, &t->xhat, n * 100)); TRY(dev_alloc(t, &t->hd, n * 100));
     TRY(dev_alloc(t, &t->dl, n * classes)); TRY(dev_alloc(t, &t->dy, n * 100)); TRY(dev_alloc(t, &t->dh, n * 100));
     TRY(dev_alloc(t, &t->loss, n)); TRY(dev_alloc(t, &t->correct, n)); TRY(dev_alloc(t, &t->out2, 2)); TRY(dev_alloc(t, &t->bad_target, 2));
-    TRY(dev_alloc(t, &t->red, (size_t)BWD_BLOCKS * 2 * 128)); TRY(dev_alloc(t, &t->keep, n * 308));
+    TRY(dev_alloc(t, &t->red, std::max((size_t)BWD_BLOCKS * 2 * 128, n * 640)));   // conv1 leaves 20 n x 2 x 16 partials, conv2 / conv3 2 n x 2 x C
+    TRY(dev_alloc(t, &t->keep, n * 308));
     TRY(dev_alloc(t, &t->x_stage, n * 6400 * CH)); TRY(dev_alloc(t, &t->y_stage, n)); TRY(dev_alloc(t, &t->keep_stage, n * 308));
 #undef TRY
     if (rc == TREXHIP_OK && hipStreamCreateWithFlags(&t->side, hipStreamNonBlocking) != hipSuccess) { set_error("trexhip_trainer_create: no second stream"); rc = TREXHIP_E_DEVICE; }
