@@ -1158,7 +1158,9 @@ __global__ __launch_bounds__(256) void k_t_wgrad_reduce(const float* __restrict_
     g[idx] = acc;
 }
 
-// conv1 weight gradient (VALU): block = 8 rows of one crop -> part[block][c][tap][16]
+// conv1 weight gradient (VALU): block = 8 rows of one crop -> part[block][c][tap][16].  Thread = (2 of the 8 rows, kernel row ky, output channel):
+// per pixel one dz value and one new window value from LDS feed the five kx of the kernel row (a thread per tap read two LDS words per multiply
+// and the kernel ran at the LDS rate); the four row pairs are added in order through LDS
 template <int CH>
 __global__ __launch_bounds__(512) void k_t_wgrad1(const float* __restrict__ x /*[n][80][80][CH]*/, const float* __restrict__ dz /*[n][80][80][16]*/,
                                                   float* __restrict__ part) {
@@ -1170,23 +1172,53 @@ __global__ __launch_bounds__(512) void k_t_wgrad1(const float* __restrict__ x /*
         const int iy = row0 + py - 2, ix = px - 2;
         xs[idx] = (iy >= 0 && iy < 80 && ix >= 0 && ix < 80) ? x[(((size_t)crop * 80 + iy) * 80 + ix) * CH + c] : 0.f;
     }
-    for (int idx = tid; idx < 640 * 16; idx += 512) ds[idx] = dz[((size_t)crop * 80 + row0) * 80 * 16 + idx];
+    {
+        const float4* src = reinterpret_cast<const float4*>(dz + ((size_t)crop * 80 + row0) * 80 * 16);
+        for (int idx = tid; idx < 640 * 4; idx += 512) reinterpret_cast<float4*>(ds)[idx] = src[idx];
+    }
+    __syncthreads();
+    const int co = tid & 15, ky = (tid >> 4) % 5, g = tid / 80;
+    float acc[CH][5];
+#pragma unroll
+    for (int c = 0; c < CH; ++c)
+#pragma unroll
+        for (int k = 0; k < 5; ++k) acc[c][k] = 0.f;
+    if (tid < 320) {
+#pragma unroll 1
+        for (int yy = 0; yy < 2; ++yy) {
+            const int y = g * 2 + yy;
+            const float* xr = xs + (y + ky) * 84 * CH;
+            const float* dr = ds + y * 80 * 16 + co;
+            float win[CH][5];
+#pragma unroll
+            for (int c = 0; c < CH; ++c)
+#pragma unroll
+                for (int k = 1; k < 5; ++k) win[c][k] = xr[(k - 1) * CH + c];
+#pragma unroll 5
+            for (int xx = 0; xx < 80; ++xx) {
+                const float d = dr[xx * 16];
+#pragma unroll
+                for (int c = 0; c < CH; ++c) {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) win[c][k] = win[c][k + 1];
+                    win[c][4] = xr[(xx + 4) * CH + c];
+#pragma unroll
+                    for (int k = 0; k < 5; ++k) acc[c][k] += win[c][k] * d;
+                }
+            }
+        }
+    }
+    __syncthreads();                                                   // ds becomes the row pairs' exchange: [g][c][tap][co]
+    if (tid < 320)
+#pragma unroll
+        for (int c = 0; c < CH; ++c)
+#pragma unroll
+            for (int k = 0; k < 5; ++k) ds[((g * CH + c) * 25 + ky * 5 + k) * 16 + co] = acc[c][k];
     __syncthreads();
     if (tid >= 400) return;
-    const int tap = tid >> 4, co = tid & 15, ky = tap / 5, kx = tap % 5;
-    float acc[CH];
 #pragma unroll
-    for (int c = 0; c < CH; ++c) acc[c] = 0.f;
-#pragma unroll 1
-    for (int y = 0; y < 8; ++y)
-#pragma unroll 4
-        for (int xx = 0; xx < 80; ++xx) {
-            const float d = ds[(y * 80 + xx) * 16 + co];
-#pragma unroll
-            for (int c = 0; c < CH; ++c) acc[c] += xs[((y + ky) * 84 + xx + kx) * CH + c] * d;
-        }
-#pragma unroll
-    for (int c = 0; c < CH; ++c) part[(size_t)blockIdx.x * CH * 400 + c * 400 + tap * 16 + co] = acc[c];
+    for (int c = 0; c < CH; ++c)
+        part[(size_t)blockIdx.x * CH * 400 + c * 400 + tid] = ((ds[c * 400 + tid] + ds[(CH + c) * 400 + tid]) + ds[(2 * CH + c) * 400 + tid]) + ds[(3 * CH + c) * 400 + tid];
 }
 
 // out[i] = sum over the parts, fixed order: 16 lanes per element take every 16th part, then the lane sums are added in order
@@ -1317,7 +1349,9 @@ struct Trainer {
     // the training step forks: weight packing, the head's / fc1's / the convolutions' weight gradients and the loss sum run on `side`, beside the
     // chain that the next kernel waits for (data gradients, BN backward); the step joins again in front of Adam
     hipStream_t side = nullptr;
-    hipEvent_t ev[6] = {};
+    hipEvent_t ev[8] = {};
+    bool masks_on_side = false;          // this step's keep masks are being drawn on `side` (ev[6])
+    double* red_bias = nullptr;          // [3][BWD_BLOCKS][128]: k_t_bn_bwd's column sums, finalized on `side`
     bool attr = false;
     std::vector<void*> allocs;
 };
@@ -1410,7 +1444,7 @@ static void bn_forward(Trainer* t, hipStream_t s, int layer, const float* z, flo
 
 // da (pooled gradient) -> dz written over z; gradients of gamma, beta and of the convolution bias
 template <int C>
-static void bn_backward(Trainer* t, hipStream_t s, int layer, const float* da, float* z, int n, int S, int tg, int tb, int tcb, const uint8_t* keep, float scale) {
+static int bn_backward(Trainer* t, hipStream_t s, int layer, const float* da, float* z, int n, int S, int tg, int tb, int tcb, const uint8_t* keep, float scale) {
     float* mean = t->stat + layer * 512;
     float* invstd = mean + 128;
     float* sums = mean + 256;
@@ -1423,8 +1457,13 @@ static void bn_backward(Trainer* t, hipStream_t s, int layer, const float* da, f
     // whole rounds: every workgroup takes the same number of elements, all of them resident at once
     const unsigned nb0 = (unsigned)((total + 255) / 256), per = (nb0 + BWD_BLOCKS - 1) / BWD_BLOCKS, nb = (nb0 + per - 1) / per;
     hipLaunchKernelGGL((k_t_bn_bwd<C>), dim3(nb), dim3(256), 0, s, da, z, mean, invstd, t->P + t->off[tg], t->P + t->off[tb], keep, scale, sums, inv_count, n, S,
-                       t->red);
-    hipLaunchKernelGGL((k_t_red_finalize<FIN_BIAS>), dim3(C), dim3(256), 0, s, t->red, (int)nb, C, FinArgs{0.0, 0.f, t->G + t->off[tcb], nullptr, nullptr, nullptr, nullptr});
+                       t->red_bias + (size_t)layer * BWD_BLOCKS * 128);
+    return (int)nb;
+}
+// the convolution bias's gradient from k_t_bn_bwd's column sums (nothing but Adam waits for it: the caller puts it on the side stream)
+static void bias_finalize(Trainer* t, hipStream_t w, int layer, int nb, int C, int tcb) {
+    hipLaunchKernelGGL((k_t_red_finalize<FIN_BIAS>), dim3(C), dim3(256), 0, w, t->red_bias + (size_t)layer * BWD_BLOCKS * 128, nb, C,
+                       FinArgs{0.0, 0.f, t->G + t->off[tcb], nullptr, nullptr, nullptr, nullptr});
 }
 
 // steps with a target outside 0..classes-1 were refused on the device (k_t_check_targets) and have changed nothing: report them at the next
@@ -1468,6 +1507,7 @@ static void trainer_forward(Trainer* t, hipStream_t s, const float* x, const int
         hipLaunchKernelGGL((k_t_bn_pool<C>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, z, mean, invstd, P + o[tg], P + o[tb], kp, scale, a, n, S);
     };
     if (t->CH == 1) launch_layer1<1>(t, s, x, n, train); else launch_layer1<3>(t, s, x, n, train);
+    if (side && t->masks_on_side) (void)hipStreamWaitEvent(s == hipStreamLegacy ? nullptr : s, t->ev[6], 0);
     block(std::integral_constant<int, 16>{}, 0, t->z1, t->a1, 80, T_G1, T_BE1, T_RM1, T_RV1, k1, n * 20);
     if (h2 && side) (void)hipStreamWaitEvent(s == hipStreamLegacy ? nullptr : s, t->ev[1], 0);
     if (h2) hipLaunchKernelGGL((k_t_conv5_h2<16, 64, 40, 20, 16, 64>), dim3(n * H2F::BPC), dim3(512), H2F::LDS_BYTES, s, t->a1, t->wh2f, P + o[T_C2B], t->z2, t->wh_scale, train ? t->red : nullptr);
@@ -1525,21 +1565,23 @@ static int trainer_step(Trainer* t, const float* x, const int32_t* targets, int 
     { const int rc = trainer_attrs(t); if (rc) return rc; }
     const float scale = 1.0f / (1.0f - t->p.dropout);
     const uint8_t* keep = d_keep;
-    if (!keep) {
-        const size_t count = (size_t)n * 308;
-        hipLaunchKernelGGL(k_t_masks, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, s, t->keep, count, t->p.seed, (uint64_t)t->step, t->p.dropout);
-        keep = t->keep;
-    }
     float* P = t->P;
     float* G = t->G;
     const size_t* o = t->off;
-    hipLaunchKernelGGL(k_t_check_targets, dim3(1), dim3(256), 0, s, targets, n, t->classes, t->bad_target, 0);
     hipStream_t w = t->side;                                                // the weight-gradient side of the step
     // (events go through the null stream when the caller's stream is the hipStreamLegacy handle: this runtime faults in a wait on an event
     // recorded on the handle itself; in this library the two name the same stream)
     hipStream_t es = s == hipStreamLegacy ? nullptr : s;
     auto fork = [&](int e) { (void)hipEventRecord(t->ev[e], es); (void)hipStreamWaitEvent(w, t->ev[e], 0); };
     fork(0);                                                                // behind whatever wrote the parameters last
+    t->masks_on_side = !keep;
+    if (!keep) {
+        const size_t count = (size_t)n * 308;
+        hipLaunchKernelGGL(k_t_masks, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, w, t->keep, count, t->p.seed, (uint64_t)t->step, t->p.dropout);
+        (void)hipEventRecord(t->ev[6], w);
+        keep = t->keep;
+    }
+    hipLaunchKernelGGL(k_t_check_targets, dim3(1), dim3(256), 0, s, targets, n, t->classes, t->bad_target, 0);
     trainer_forward(t, s, x, targets, n, keep, scale, true, w);
     fork(2);
     const uint8_t *k1 = keep, *k2 = keep + (size_t)n * 16, *k3 = keep + (size_t)n * 80;
@@ -1554,8 +1596,9 @@ static int trainer_step(Trainer* t, const float* x, const int32_t* targets, int 
     hipLaunchKernelGGL(k_t_fc1_dgrad, dim3(100, (n + 31) / 32), dim3(256), 0, s, t->dh, P + o[T_F1W], t->da3, n);
     // block 3
     const bool h2 = t->p.precision == 0;
-    bn_backward<128>(t, s, 2, t->da3, t->z3, n, 20, T_G3, T_BE3, T_C3B, k3, scale);
+    const int nb3 = bn_backward<128>(t, s, 2, t->da3, t->z3, n, 20, T_G3, T_BE3, T_C3B, k3, scale);
     fork(3);
+    bias_finalize(t, w, 2, nb3, 128, T_C3B);
     {
         const int shares = h2 ? (n * WH3::NB < SHARES3H ? n * WH3::NB : SHARES3H) : (n * WG3::NB < SHARES3 ? n * WG3::NB : SHARES3);
         if (h2) hipLaunchKernelGGL((k_t_wgrad_h2<64, 128, 20, 32, 10>), dim3(WH3::TYPES, shares), dim3(640), WH3::LDS_BYTES, w, t->a2, t->z3, t->part, n);
@@ -1568,14 +1611,14 @@ static int trainer_step(Trainer* t, const float* x, const int32_t* targets, int 
         }
     }
     // block 2
-    bn_backward<64>(t, s, 1, t->da2, t->z2, n, 40, T_G2, T_BE2, T_C2B, k2, scale);
+    const int nb2 = bn_backward<64>(t, s, 1, t->da2, t->z2, n, 40, T_G2, T_BE2, T_C2B, k2, scale);
     fork(4);
+    bias_finalize(t, w, 1, nb2, 64, T_C2B);
     {
         const int shares = h2 ? (n * WH2::NB < SHARES2H ? n * WH2::NB : SHARES2H) : (n * WG2::NB < SHARES2 ? n * WG2::NB : SHARES2);
         if (h2) hipLaunchKernelGGL((k_t_wgrad_h2<16, 64, 40, 16, 10>), dim3(WH2::TYPES, shares), dim3(640), WH2::LDS_BYTES, w, t->a1, t->z2, t->part, n);
         else hipLaunchKernelGGL((k_t_wgrad<16, 64, 40, 16, 64, 3, 5>), dim3(WG2::TYPES, shares), dim3(512), WG2::LDS_BYTES, w, t->a1, t->z2, t->part, n);
         hipLaunchKernelGGL(k_t_wgrad_reduce, dim3((25 * 16 * 64 + 255) / 256), dim3(256), 0, w, t->part, shares, 16, 64, 16, G + o[T_C2W]);
-        (void)hipEventRecord(t->ev[5], w);
         if (h2) hipLaunchKernelGGL((k_t_conv5_h2<64, 32, 40, 20, 16, 16>), dim3(n * H2B::BPC), dim3(512), H2B::LDS_BYTES, s, t->z2, t->wh2b, (const float*)nullptr, t->da1, t->wh_scale, (double*)nullptr);
         else {
             hipLaunchKernelGGL(k_t_repack_bwd, dim3((25 * 64 * 16 + 255) / 256), dim3(256), 0, s, P + o[T_C2W], 16, 64, 16, 16, 16, t->wb2);
@@ -1583,7 +1626,10 @@ static int trainer_step(Trainer* t, const float* x, const int32_t* targets, int 
         }
     }
     // block 1
-    bn_backward<16>(t, s, 0, t->da1, t->z1, n, 80, T_G1, T_BE1, T_C1B, k1, scale);
+    const int nb1 = bn_backward<16>(t, s, 0, t->da1, t->z1, n, 80, T_G1, T_BE1, T_C1B, k1, scale);
+    fork(7);
+    bias_finalize(t, w, 0, nb1, 16, T_C1B);
+    (void)hipEventRecord(t->ev[5], w);                                      // the side stream's last piece of this step
     if (t->CH == 1) launch_wgrad1<1>(t, s, x, n); else launch_wgrad1<3>(t, s, x, n);
     (void)hipStreamWaitEvent(es, t->ev[5], 0);                              // join: every gradient is in G
     // ---- optimizer
@@ -1664,7 +1710,7 @@ int trexhip_trainer_create(trexhip_ctx* ctx, const void* blob, size_t bytes, con
     TRY(dev_alloc(t, &t->wh_scale, 2));
     t->part_floats = std::max(std::max(std::max((size_t)SHARES3 * 25 * 64 * 128, (size_t)SHARES2 * 25 * 16 * 64), std::max((size_t)SHARES3H * 25 * 64 * 128, (size_t)SHARES2H * 25 * 16 * 64)),
                               n * 10 * CH * 400);
-    TRY(dev_alloc(t, &t->part, t->part_floats)); TRY(dev_alloc(t, &t->part1, n * 10 * CH * 400));
+    TRY(dev_alloc(t, &t->part, t->part_floats)); TRY(dev_alloc(t, &t->part1, n * 10 * CH * 400)); TRY(dev_alloc(t, &t->red_bias, (size_t)3 * BWD_BLOCKS * 128));
     TRY(dev_alloc(t, &t->stat, (size_t)3 * 512));
     TRY(dev_alloc(t, &t->hpart, n * 100 * 100)); TRY(dev_alloc(t, &t->xhat, n * 100)); TRY(dev_alloc(t, &t->hd, n * 100));
     TRY(dev_alloc(t, &t->dl, n * classes)); TRY(dev_alloc(t, &t->dy, n * 100)); TRY(dev_alloc(t, &t->dh, n * 100));
