@@ -471,7 +471,7 @@ __global__ __launch_bounds__(256) void k_rows32(const uint8_t* __restrict__ fram
 
 // The wide pass with the background row held in registers: a wave takes row y of K consecutive frames (K divides the number of
 // frames of the launch), so the 2 KB background row is loaded once per K frame rows instead of once per frame row -- half the load
-// instructions and half the L2 -> CU traffic of the kernel above.  Wave w: row w / (B / K), frames (w % (B / K)) * K ...
+// instructions and half the L2 -> CU traffic of the kernel above.  Wave w: row w % H, frames (w / H) * K ...
 template <int NCH, int MODE = 0>
 __global__ __launch_bounds__(256) void k_rows32b(const uint8_t* __restrict__ frames,
                                                  const uint8_t* __restrict__ bg, const SegCfg c, const int order, const int K,
@@ -487,7 +487,10 @@ __global__ __launch_bounds__(256) void k_rows32b(const uint8_t* __restrict__ fra
     const uint32_t groups = (uint32_t)c.B / (uint32_t)K;
     const uint32_t wid = blockIdx.x * 4u + (threadIdx.x >> 6);
     if (wid >= groups * (uint32_t)c.H) return;
-    const uint32_t y = wid / groups, fb = f0 + (wid - y * groups) * (uint32_t)K;
+    uint32_t y = wid / groups, fb = f0 + (wid - y * groups) * (uint32_t)K;
+    // rows fastest (the default): neighbouring waves read neighbouring rows of the same frames.  Measured against frame groups fastest
+    // (TREXHIP_ROWS_ORDER bit 0) alternated on three boxes: 215 against 220 us on two of them, 189 against 215 on the third
+    if (!(order & 1)) { const uint32_t gq = wid / (uint32_t)c.H; y = wid - gq * (uint32_t)c.H; fb = f0 + gq * (uint32_t)K; }
     uint4 a[NCH][2], b[NCH][2];
     const uint8_t* bp = bg + (size_t)y * W;
     auto issue = [&](uint32_t f) {
