@@ -478,7 +478,7 @@ def measure(args, env):
     return out
 
 
-def train_step_bench(dev, n=128, classes=100, steps=20, precision=0):
+def train_step_bench(dev, n=128, classes=100, steps=100, precision=0):
     """one optimizer step of V118_3 (forward, backward, Adam) on `n` samples: SURVEY 8(f)3 -- ms per step, algorithmic TFLOP/s against
     the fp32 matrix peak (157.3).  precision 0 (the library's default): conv2 / conv3 forward and data gradients in the inference path's
     fp16 two-piece split arithmetic; 1: exact fp32 MFMA everywhere"""
@@ -492,7 +492,7 @@ def train_step_bench(dev, n=128, classes=100, steps=20, precision=0):
     seg = capi.Segmenter(p)
     tr = capi.Trainer(seg, weights.pack_blob(state, classes, 1), max_batch=n, lr=1e-3, seed=3, precision=precision)
     dx, dy = torch.from_numpy(x).to(dev), torch.from_numpy(y.astype(np.int32)).to(dev)
-    for _ in range(3):
+    for _ in range(10):            # (a 16 ms window right behind the other secondaries read 15 % slower than 100 steps: clocks still settling)
         tr.step_device(dx.data_ptr(), dy.data_ptr(), n, 0, want_loss=False)
     torch.cuda.synchronize()
     t0 = time.perf_counter()

@@ -476,7 +476,9 @@ int trexhip_profile_reset(trexhip_ctx* ctx);
  *                              the reference drew.  loss / correct (host, optional): mean cross entropy and the number of samples
  *                              whose arg-max equals the target; passing either makes the call synchronise.  A target outside
  *                              0..classes-1 (train() asserts it, :1112) is flagged by the device: that call (if it synchronises)
- *                              and every later read / export return TREXHIP_E_INVALID
+ *                              and every later read / export return TREXHIP_E_INVALID.  The step is ordered on the context's
+ *                              stream like every other call; inside, weight packing, mask drawing and the weight gradients run on a
+ *                              second stream owned by the trainer and join the context's stream in front of the parameter update
  *   trexhip_trainer_export     the current weights as a blob for trexhip_load_weights (the reference hands its state_dict back)
  *   trexhip_trainer_read       one tensor in torch's layout; tensor = index in state_dict order (0 conv1.weight ... 23 fc2.bias,
  *                              running statistics included), kind 0 parameter, 1 gradient of the last step, 2 / 3 Adam moments

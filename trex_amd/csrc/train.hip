@@ -353,46 +353,47 @@ __global__ __launch_bounds__(256) void k_t_bn_bwd(const float* __restrict__ da, 
 }
 
 // ------------------------------------------------------------------------------------------------
-// fc1: h[n][100] = a3[n][hw][c] . W1c[hw][c][o], as 100 partial planes (one per hw) summed in fixed order by the head kernel
+// fc1: h[n][100] = a3[n][hw][c] . W1c[hw][c][o], as 100 partial planes (one per hw) summed in fixed order by the head kernel.
+// Block = one position x 64 samples on fp32 MFMA (32x32x2: one step contracts two channels); wave = 32 outputs (the last wave: 4), two sample
+// tiles.  (The VALU form -- 8 x 4 outputs per thread, 12 LDS reads per 32 multiply-adds, one wave per SIMD -- took 30 us.)
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_t_fc1(const float* __restrict__ a3 /*[n][100][128]*/, const float* __restrict__ w /*[100][128][100]*/,
                                                float* __restrict__ hpart /*[100][n][100]*/, int n) {
-    __shared__ float As[64 * 65];
-    __shared__ float Ws[64 * 100];
+    __shared__ float As[64 * 129];                                    // [sample][channel], pitch 129: the 32 rows of a fragment on 32 banks
+    __shared__ __attribute__((aligned(16))) float Ws[128 * 100];      // [channel][output]
     const int tid = threadIdx.x, hw = blockIdx.x, n0 = blockIdx.y * 64;
-    const int ng = tid >> 5, og = tid & 31;
-    float acc[8][4];
-#pragma unroll
-    for (int i = 0; i < 8; ++i)
-#pragma unroll
-        for (int k = 0; k < 4; ++k) acc[i][k] = 0.f;
-    for (int half = 0; half < 2; ++half) {
-        __syncthreads();
-        for (int idx = tid; idx < 64 * 64; idx += 256) {
-            const int i = idx >> 6, c = idx & 63;
-            As[i * 65 + c] = (n0 + i < n) ? a3[((size_t)(n0 + i) * 100 + hw) * 128 + half * 64 + c] : 0.f;
-        }
-        for (int idx = tid; idx < 64 * 100; idx += 256) Ws[idx] = w[((size_t)hw * 128 + half * 64) * 100 + idx];
-        __syncthreads();
-        for (int c = 0; c < 64; ++c) {
-            float wv[4];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) wv[k] = (og + 32 * k < 100) ? Ws[c * 100 + og + 32 * k] : 0.f;
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const float av = As[(ng * 8 + i) * 65 + c];
-#pragma unroll
-                for (int k = 0; k < 4; ++k) acc[i][k] += av * wv[k];
-            }
-        }
+    for (int idx = tid; idx < 64 * 32; idx += 256) {
+        const int i = idx >> 5, q = idx & 31;
+        const float4 v = (n0 + i < n) ? *reinterpret_cast<const float4*>(a3 + ((size_t)(n0 + i) * 100 + hw) * 128 + q * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        float* d = As + i * 129 + q * 4;
+        d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
     }
+    {
+        const float4* src = reinterpret_cast<const float4*>(w + (size_t)hw * 12800);
+        for (int idx = tid; idx < 3200; idx += 256) reinterpret_cast<float4*>(Ws)[idx] = src[idx];
+    }
+    __syncthreads();
+    const int lane = tid & 63, wave = tid >> 6, j = lane & 31, h = lane >> 5;
+    const int o = wave * 32 + j;
+    const bool ov = o < 100;
+    f32x16 acc0, acc1;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const int nn = n0 + ng * 8 + i;
-        if (nn >= n) continue;
+    for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
+    const float* a0 = As + j * 129 + h;
+    const float* a1 = As + (32 + j) * 129 + h;
+    const float* bp = Ws + h * 100 + (ov ? o : 0);
+#pragma unroll 8
+    for (int t = 0; t < 64; ++t) {
+        const float bv = ov ? bp[2 * t * 100] : 0.f;
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[2 * t], bv, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[2 * t], bv, acc1, 0, 0, 0);
+    }
+    if (!ov) return;
 #pragma unroll
-        for (int k = 0; k < 4; ++k)
-            if (og + 32 * k < 100) hpart[((size_t)hw * n + nn) * 100 + og + 32 * k] = acc[i][k];
+    for (int r = 0; r < 16; ++r) {
+        const int i = (r & 3) + 8 * (r >> 2) + 4 * h;                 // accumulator r of lane (j, h) is row 8 (r / 4) + 4 h + r % 4
+        if (n0 + i < n) hpart[((size_t)hw * n + n0 + i) * 100 + o] = acc0[r];
+        if (n0 + 32 + i < n) hpart[((size_t)hw * n + n0 + 32 + i) * 100 + o] = acc1[r];
     }
 }
 
@@ -574,27 +575,28 @@ __global__ __launch_bounds__(256) void k_t_fc1_wgrad(const float* __restrict__ a
     }
 }
 
-// fc1 data gradient: da3[n][hw][c] = sum_o dh[n][o] * W1c[hw][c][o]
+// fc1 data gradient: da3[n][hw][c] = sum_o dh[n][o] * W1c[hw][c][o].  Block = one position x 32 samples on fp32 MFMA (one step contracts two
+// outputs), wave = 32 channels
 __global__ __launch_bounds__(256) void k_t_fc1_dgrad(const float* __restrict__ dh, const float* __restrict__ w, float* __restrict__ da3, int n) {
-    __shared__ float Ws[128 * 101];
-    __shared__ float Ds[32 * 100];
+    __shared__ float Ws[128 * 101];                                   // [channel][output], pitch 101: a fragment's 32 channels on 32 banks
+    __shared__ float Ds[32 * 101];                                    // [sample][output]
     const int tid = threadIdx.x, hw = blockIdx.x, n0 = blockIdx.y * 32;
-    const int c = tid & 127, ng = tid >> 7;
     for (int idx = tid; idx < 128 * 100; idx += 256) Ws[(idx / 100) * 101 + idx % 100] = w[(size_t)hw * 12800 + idx];
-    for (int idx = tid; idx < 32 * 100; idx += 256) Ds[idx] = (n0 + idx / 100) < n ? dh[(size_t)n0 * 100 + idx] : 0.f;
+    for (int idx = tid; idx < 32 * 100; idx += 256) Ds[(idx / 100) * 101 + idx % 100] = (n0 + idx / 100) < n ? dh[(size_t)n0 * 100 + idx] : 0.f;
     __syncthreads();
-    float acc[16];
+    const int lane = tid & 63, wave = tid >> 6, j = lane & 31, h = lane >> 5;
+    const int c = wave * 32 + j;
+    f32x16 acc;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
-    for (int o = 0; o < 100; ++o) {
-        const float wv = Ws[c * 101 + o];
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    const float* ap = Ds + j * 101 + h;
+    const float* bp = Ws + c * 101 + h;
+#pragma unroll 10
+    for (int t = 0; t < 50; ++t) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[2 * t], bp[2 * t], acc, 0, 0, 0);
 #pragma unroll
-        for (int i = 0; i < 16; ++i) acc[i] += Ds[(ng * 16 + i) * 100 + o] * wv;
-    }
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-        const int nn = n0 + ng * 16 + i;
-        if (nn < n) da3[((size_t)nn * 100 + hw) * 128 + c] = acc[i];
+    for (int r = 0; r < 16; ++r) {
+        const int nn = n0 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        if (nn < n) da3[((size_t)nn * 100 + hw) * 128 + c] = acc[r];
     }
 }
 
@@ -604,7 +606,7 @@ __global__ __launch_bounds__(256) void k_t_fc1_dgrad(const float* __restrict__ d
 // at a fifth of the fp32-MFMA time (k_conv5<RAW>, precision 1).  fp16 cannot hold every fp32 value, so both operands carry a power-of-two
 // scale: the inputs one per workgroup and 16 / 32-channel chunk, from the largest |value| of the patch it stages (largest scaled input in
 // [2^13, 2^14)); the weights one per layer, from the pack kernel (largest scaled weight in [2^7, 2^8)).  Nothing overflows, and what
-// underflows is below 2^-27 of the patch's / the layer's largest entry.  25 shifted GEMMs, patch and weight tile in LDS, one barrier per tap.
+// underflows is below 2^-27 of the patch's / the layer's largest entry.  25 shifted GEMMs: patch in LDS, weight fragments L2 -> VGPR, no barrier inside a chunk.
 // ------------------------------------------------------------------------------------------------
 typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
 
@@ -629,7 +631,7 @@ struct ConvGeomH {
     static constexpr int BT = 2 * (CIC / 8) * CO * 16;                // bytes per weight tile: 2 pieces x CIC / 8 k-octets x CO x 16 B
     static constexpr int NPIX = ROWS * S;
     static constexpr int MT = (NPIX + 31) / 32, NT = CO / 32, WM = 8 / NT, TPW = (MT + WM - 1) / WM;
-    static constexpr int LDS_BYTES = 2 * PATCH + 2 * BT;
+    static constexpr int LDS_BYTES = 2 * PATCH;
     static constexpr int BPC = S / ROWS;
     static_assert(CO % 32 == 0 && 8 % NT == 0 && CIC % 16 == 0 && CI % CIC == 0 && LDS_BYTES <= 160 * 1024, "shapes");
 };
@@ -642,7 +644,6 @@ __global__ __launch_bounds__(512) void k_t_conv5_h2(const float* __restrict__ in
     constexpr int Q4 = CIC / 4, KO = CIC / 8;
     extern __shared__ __attribute__((aligned(16))) uint8_t hlds[];
     uint8_t* patch = hlds;                       // 2 pieces
-    uint8_t* Bs = hlds + 2 * G::PATCH;           // 2 buffers
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int j = lane & 31, h = lane >> 5;
     const int n = wave % G::NT, mg = wave / G::NT;
@@ -662,9 +663,18 @@ __global__ __launch_bounds__(512) void k_t_conv5_h2(const float* __restrict__ in
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
     const float* inc = in + (size_t)crop * S * S * CI;
-    constexpr int BV = G::BT / 16, BPT = (BV + 511) / 512;
     constexpr int NITEM = G::PH * G::PW * Q4, NLD = (NITEM + 511) / 512;  // Q4 float4 per pixel; float4 per thread and chunk
+    constexpr int KS = CIC / 16, BV = G::BT / 16;
+    const uint4* wl = wp + (h * CO + n * 32 + j);                      // this lane's fragments: + tap * BV + 2 ks CO (+ KO CO: second piece)
     for (int cc = 0; cc < CI / CIC; ++cc) {
+        const uint4* wsrc = wl + (size_t)cc * 25 * BV;
+        uint4 bq[3][KS][2];
+        auto fetch = [&](uint4 (&d)[KS][2], const int tap) {
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) { d[ks][0] = wsrc[tap * BV + 2 * ks * CO]; d[ks][1] = wsrc[tap * BV + 2 * ks * CO + KO * CO]; }
+        };
+        fetch(bq[0], 0);
+        fetch(bq[1], 1);
         __syncthreads();
         // the chunk's patch: loaded into registers, its largest |value| found (wave shuffle + 8 LDS words), scaled by the power of two that
         // puts that value into [2^13, 2^14), split and stored.  A chunk with another scale than the one before rescales the accumulators
@@ -710,26 +720,17 @@ __global__ __launch_bounds__(512) void k_t_conv5_h2(const float* __restrict__ in
                 *reinterpret_cast<uint2*>(d + G::PATCH) = make_uint2(a2[0] | (a2[1] << 16), a2[2] | (a2[3] << 16));
             }
         }
-        const uint4* wsrc = wp + (size_t)cc * 25 * BV;
-        for (int i = tid; i < BV; i += 512) reinterpret_cast<uint4*>(Bs)[i] = wsrc[i];
-        // weight tiles travel L2 -> registers -> LDS two taps ahead of their use: a tile fetched at the start of tap t - 1 is stored at the end
-        // of tap t and read in tap t + 1 (one tap ahead, the fetch did not return within a tap's 0.4 us of MFMAs)
-        uint4 n1[BPT], n2[BPT];
-#pragma unroll
-        for (int u = 0; u < BPT; ++u) { const int i = tid + u * 512; n1[u] = make_uint4(0, 0, 0, 0); if (i < BV) n1[u] = wsrc[(size_t)BV + i]; }
         __syncthreads();
-        for (int tap = 0; tap < 25; ++tap) {
-            const int buf = tap & 1;
-            if (tap < 23) {
+        // the tap loop runs without barriers: the patch is read-only until the next chunk, and each wave takes its weight fragments L2 -> VGPR
+        // straight from the packed image, two taps ahead (through LDS they cost a barrier per tap: 1.4 us per tap against 0.7 of MFMAs)
 #pragma unroll
-                for (int u = 0; u < BPT; ++u) { const int i = tid + u * 512; if (i < BV) n2[u] = wsrc[(size_t)(tap + 2) * BV + i]; }
-            }
+        for (int tap = 0; tap < 25; ++tap) {
+            if (tap + 2 < 25) fetch(bq[(tap + 2) % 3], tap + 2);
             const uint8_t* asrc = patch + ((tap / 5) * G::PW + (tap % 5)) * G::PSTRIDE;
 #pragma unroll
-            for (int ks = 0; ks < CIC / 16; ++ks) {                        // one 16-deep MFMA step per 16 input channels
-                const uint8_t* bsrc = Bs + buf * G::BT + ((2 * ks + h) * CO + n * 32 + j) * 16;
-                const h16x8 b1 = __builtin_bit_cast(h16x8, *reinterpret_cast<const uint4*>(bsrc));
-                const h16x8 b2 = __builtin_bit_cast(h16x8, *reinterpret_cast<const uint4*>(bsrc + KO * CO * 16));
+            for (int ks = 0; ks < KS; ++ks) {                              // one 16-deep MFMA step per 16 input channels
+                const h16x8 b1 = __builtin_bit_cast(h16x8, bq[tap % 3][ks][0]);
+                const h16x8 b2 = __builtin_bit_cast(h16x8, bq[tap % 3][ks][1]);
 #pragma unroll
                 for (int m = 0; m < G::TPW; ++m) {
                     const h16x8 p1 = __builtin_bit_cast(h16x8, *reinterpret_cast<const uint4*>(asrc + aoff[m] + ks * 32));
@@ -739,15 +740,9 @@ __global__ __launch_bounds__(512) void k_t_conv5_h2(const float* __restrict__ in
                     acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(p1, b1, acc[m], 0, 0, 0);
                 }
             }
-            if (tap < 24) {
-#pragma unroll
-                for (int u = 0; u < BPT; ++u) { const int i = tid + u * 512; if (i < BV) reinterpret_cast<uint4*>(Bs + (buf ^ 1) * G::BT)[i] = n1[u]; }
-            }
-            __syncthreads();
-#pragma unroll
-            for (int u = 0; u < BPT; ++u) n1[u] = n2[u];
         }
     }
+    __syncthreads();                                                      // (the epilogue's statistics reuse the patch)
     const int co = n * 32 + j;
     if (co >= COUT && !(COUT == CO && stat_partial)) return;
     const float out_scale = 1.0f / (in_scale * *w_scale);             // powers of two: exact
