@@ -285,3 +285,33 @@ def test_precision_outside_0_1_is_refused():
         with pytest.raises(capi.TrexHipError):
             capi.Trainer(seg, weights.pack_blob(state, 8, 1), max_batch=4, lr=1e-3, precision=bad)
     seg.close()
+
+
+def test_step_is_the_same_bits_on_every_kind_of_caller_stream():
+    # the step forks onto a second stream and joins again (weight gradients beside the data-gradient chain); its events go through the null
+    # stream for the hipStreamLegacy handle and the fork is skipped for the per-thread handle: the results must not depend on the stream kind
+    classes, ch, n = 10, 1, 24
+    state = weights.synthetic_state(classes, 5, channels=ch)
+    x, y = weights.synthetic_train_batch(n, 6, classes, ch)
+    blob = weights.pack_blob(state, classes, ch)
+    side = torch.cuda.Stream()
+    HIP_STREAM_PER_THREAD = 2
+    results = []
+    for kind, stream in (("own", None), ("legacy", capi.HIP_STREAM_LEGACY), ("torch side stream", side.cuda_stream), ("per-thread", HIP_STREAM_PER_THREAD)):
+        p = capi.default_params(64, 64)
+        p.max_batch = 1
+        seg = capi.Segmenter(p, stream=stream)
+        tr = capi.Trainer(seg, blob, max_batch=n, lr=1e-3, seed=11)
+        dx, dy = torch.from_numpy(x).cuda(), torch.from_numpy(y.astype(np.int32)).cuda()
+        torch.cuda.synchronize()
+        for _ in range(3):                         # library-drawn masks, three steps queued back to back
+            tr.step_device(dx.data_ptr(), dy.data_ptr(), n, 0, want_loss=False)
+        loss, correct = tr.step_device(dx.data_ptr(), dy.data_ptr(), n, 0)
+        seg.synchronize()
+        torch.cuda.synchronize()
+        results.append((kind, loss, correct, read_all(tr, classes, ch, 0), read_all(tr, classes, ch, 1)))
+        tr.close(); seg.close()
+    for kind, loss, correct, p_, g_ in results[1:]:
+        assert loss == results[0][1] and correct == results[0][2], kind
+        for k in NAMES:
+            assert np.array_equal(p_[k], results[0][3][k]) and np.array_equal(g_[k], results[0][4][k]), (kind, k)

@@ -1563,21 +1563,23 @@ static int trainer_step(Trainer* t, const float* x, const int32_t* targets, int 
     float* P = t->P;
     float* G = t->G;
     const size_t* o = t->off;
-    hipStream_t w = t->side;                                                // the weight-gradient side of the step
-    // (events go through the null stream when the caller's stream is the hipStreamLegacy handle: this runtime faults in a wait on an event
-    // recorded on the handle itself; in this library the two name the same stream)
+    // the weight-gradient side of the step.  Events go through the null stream when the caller's stream is the hipStreamLegacy handle (this
+    // runtime faults in a wait on an event recorded on the handle itself; in this library the two name the same stream); the per-thread
+    // handle has no such stand-in: the step then stays on the one stream
+    const bool forked = s != hipStreamPerThread;
+    hipStream_t w = forked ? t->side : s;
     hipStream_t es = s == hipStreamLegacy ? nullptr : s;
-    auto fork = [&](int e) { (void)hipEventRecord(t->ev[e], es); (void)hipStreamWaitEvent(w, t->ev[e], 0); };
+    auto fork = [&](int e) { if (forked) { (void)hipEventRecord(t->ev[e], es); (void)hipStreamWaitEvent(w, t->ev[e], 0); } };
     fork(0);                                                                // behind whatever wrote the parameters last
-    t->masks_on_side = !keep;
+    t->masks_on_side = forked && !keep;
     if (!keep) {
         const size_t count = (size_t)n * 308;
         hipLaunchKernelGGL(k_t_masks, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, w, t->keep, count, t->p.seed, (uint64_t)t->step, t->p.dropout);
-        (void)hipEventRecord(t->ev[6], w);
+        if (forked) (void)hipEventRecord(t->ev[6], w);
         keep = t->keep;
     }
     hipLaunchKernelGGL(k_t_check_targets, dim3(1), dim3(256), 0, s, targets, n, t->classes, t->bad_target, 0);
-    trainer_forward(t, s, x, targets, n, keep, scale, true, w);
+    trainer_forward(t, s, x, targets, n, keep, scale, true, forked ? w : nullptr);
     fork(2);
     const uint8_t *k1 = keep, *k2 = keep + (size_t)n * 16, *k3 = keep + (size_t)n * 80;
     // ---- backward
@@ -1624,9 +1626,9 @@ static int trainer_step(Trainer* t, const float* x, const int32_t* targets, int 
     const int nb1 = bn_backward<16>(t, s, 0, t->da1, t->z1, n, 80, T_G1, T_BE1, T_C1B, k1, scale);
     fork(7);
     bias_finalize(t, w, 0, nb1, 16, T_C1B);
-    (void)hipEventRecord(t->ev[5], w);                                      // the side stream's last piece of this step
+    if (forked) (void)hipEventRecord(t->ev[5], w);                          // the side stream's last piece of this step
     if (t->CH == 1) launch_wgrad1<1>(t, s, x, n); else launch_wgrad1<3>(t, s, x, n);
-    (void)hipStreamWaitEvent(es, t->ev[5], 0);                              // join: every gradient is in G
+    if (forked) (void)hipStreamWaitEvent(es, t->ev[5], 0);                  // join: every gradient is in G
     // ---- optimizer
     t->step += 1;
     {
