@@ -1,5 +1,5 @@
 #!/bin/bash
-# dev: a -DTREXHIP_DEV_KNOBS build of the library next to the product one (trex_amd/libtrexhip_dev.so; chosen with TREXHIP_LIB=dev by the dev
+# dev: a -DTREXHIP_DEV_KNOBS build of the library next to the product one (trex_amd/libtrexhip_dev.so; chosen with TREXHIP_LIB_PATH=$PWD/trex_amd/libtrexhip_dev.so by the dev
 # tools only -- capi.py never loads it by itself).  Only cnn.hip / segment.hip carry knobs; the other objects are shared with the product build.
 cd "$(dirname "$0")/../trex_amd/csrc" || exit 1
 make -s -j8 || exit 1
