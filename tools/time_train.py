@@ -19,12 +19,14 @@ def main():
     ap.add_argument("--channels", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--cpu-steps", type=int, default=2)
+    ap.add_argument("--stream", default="torch", choices=["torch", "own", "side"], help="the context's stream: torch's current one (the legacy null stream), the library's own, a torch side stream")
     a = ap.parse_args()
     state = weights.synthetic_state(a.classes, 1, channels=a.channels)
     x, y = weights.synthetic_train_batch(a.n, 2, a.classes, a.channels)
     p = capi.default_params(64, 64)
     p.max_batch = 1
-    seg = capi.Segmenter(p)
+    side = torch.cuda.Stream() if a.stream == "side" else None
+    seg = capi.Segmenter(p, stream={"torch": "torch", "own": None, "side": side.cuda_stream if side else None}[a.stream])
     tr = capi.Trainer(seg, weights.pack_blob(state, a.classes, a.channels), max_batch=a.n, lr=1e-3, seed=3)
     dx, dy = torch.from_numpy(x).cuda(), torch.from_numpy(y.astype(np.int32)).cuda()
     for _ in range(3):
@@ -33,9 +35,10 @@ def main():
     t0 = time.perf_counter()
     for _ in range(a.steps):
         tr.step_device(dx.data_ptr(), dy.data_ptr(), a.n, 0, want_loss=False)
+    t_enq = (time.perf_counter() - t0) / a.steps          # host time to queue a step (launches + events)
     seg.synchronize()
     dt = (time.perf_counter() - t0) / a.steps
-    out = {"n": a.n, "classes": a.classes, "channels": a.channels, "gpu_ms_per_step": dt * 1e3, "gpu_samples_per_s": a.n / dt,
+    out = {"n": a.n, "classes": a.classes, "channels": a.channels, "gpu_ms_per_step": dt * 1e3, "host_enqueue_ms_per_step": t_enq * 1e3, "gpu_samples_per_s": a.n / dt,
            # forward 3 convs + fc (MAC/sample) x 3 (forward, data gradient, weight gradient; conv1 has no data gradient)
            "algorithmic_gflop_per_step": 2 * a.n * (2.56e6 * a.channels * 2 + 40.96e6 * 3 + 81.92e6 * 3 + 1.28e6 * 3) / 1e9}
     out["gpu_tflops"] = out["algorithmic_gflop_per_step"] / dt / 1e3
