@@ -13,7 +13,7 @@ fails = 0
 ties_dev = ties_cpu = 0
 seg = make_seg()
 for case in range(n_cases):
-    n = int(rng.choice([1, 2, 3, 5, 8, 16, 31, 64, 100]))
+    n = int(rng.choice([1, 2, 3, 5, 8, 16, 31, 64, 100, 129, 257]))
     classes = int(rng.choice([1, 2, 7, 10, 100, 300]))
     ch = int(rng.choice([1, 3]))
     lr = float(rng.choice([1e-4, 1e-3, 1e-2]))
