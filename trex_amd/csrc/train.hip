@@ -1397,9 +1397,10 @@ static int dev_alloc(Trainer* t, T** p, size_t count) {
 
 static void trainer_free(Trainer* t) {
     if (!t) return;
+    if (t->side) (void)hipStreamSynchronize(t->side);                     // (a step joins its side stream before Adam; this is for a half-queued one)
     for (void* q : t->allocs) (void)hipFree(q);
     for (hipEvent_t e : t->ev) if (e) (void)hipEventDestroy(e);
-    if (t->side) (void)hipStreamDestroy(t->side);
+    if (t->side) { (void)hipStreamSynchronize(t->side); (void)hipStreamDestroy(t->side); }
     delete t;
 }
 
