@@ -585,18 +585,16 @@ __global__ __launch_bounds__(256) void k_conv5_wpre(const uint8_t* __restrict__ 
                 aoff[m][ky] = ((iy >= 0 && iy < S) ? (qo + ky - 2 - qmin + 1) * G::RP : 0) + tx * 32 + h * 16;
             }
         }
+        // (not zeroed: the first product of every accumulator -- taps 0..7 of the pass's first chunk -- takes the constant 0 as its C operand;
+        // 256 v_accvgpr_write per pass and wave otherwise)
         f32x16 acc[TPW][8];
-#pragma unroll
-        for (int m = 0; m < TPW; ++m)
-#pragma unroll
-            for (int p = 0; p < 8; ++p)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[m][p][r] = 0.f;
+        const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         int next_pass = pass + 1;
         const bool draw = pass >= big_end || pass % PK == PK - 1;          // the last pass of a ticket draws the next one
         if (draw && tid == 0) s_next_pass = ticket_first((int)atomicAdd(pass_ctr, 1u) + (int)gridDim.x);   // read by everyone after the first chunk's barrier
         bool have_next = false;
         int qmin_n = qmin, nrows_n = nrows;
+#pragma clang loop unroll(full)
         for (int cc = 0; cc < G::NCH; ++cc) {
             const bool last_c = cc == G::NCH - 1;
             if (last_c) {
@@ -650,7 +648,7 @@ __global__ __launch_bounds__(256) void k_conv5_wpre(const uint8_t* __restrict__ 
 #pragma unroll
                 for (int m = 0; m < TPW; ++m) { a1[m] = __builtin_bit_cast(f16x8, af[cur][m][0]); a2[m] = __builtin_bit_cast(f16x8, af[cur][m][1]); }
 #pragma unroll
-                for (int m = 0; m < TPW; ++m) acc[m][p] = mfma16(a2[m], b1, acc[m][p]);
+                for (int m = 0; m < TPW; ++m) acc[m][p] = mfma16(a2[m], b1, (cc == 0 && t < 8) ? zero16 : acc[m][p]);
 #pragma unroll
                 for (int m = 0; m < TPW; ++m) acc[m][p] = mfma16(a1[m], b2, acc[m][p]);
 #pragma unroll
