@@ -589,6 +589,34 @@ __global__ __launch_bounds__(256) void k_conv5_wpre(const uint8_t* __restrict__ 
         // 256 v_accvgpr_write per pass and wave otherwise)
         f32x16 acc[TPW][8];
         const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        // The output transform A^T (4 outputs from the 8 positions) in three position groups; y3 takes position 7 last (it is the last to arrive:
+        // position p is final after tap 32 + p of the last chunk).  Tile 0's first two groups are WRITTEN under taps 34-39 of the last chunk.
+        // What the compiler makes of that: the arithmetic itself sinks back into the guarded store blocks behind the loop, but tile 0's 128
+        // accumulator reads stay under the last taps, and with one wave per SIMD everything behind the last tap is exposed: 4.52 -> 4.32 ms.
+        // (Pinning the arithmetic under the taps as well -- an empty asm on the partial sums -- needs 48-64 more live registers: spills, 7 ms.)
+        f32x16 ya0, ya1, ya2, ya3;
+        auto ep1 = [&](const int m, const int ra, const int rb, f32x16& y0, f32x16& y1, f32x16& y2, f32x16& y3) {
+#pragma unroll
+            for (int r = ra; r < rb; ++r) {
+                const float e1 = acc[m][1][r] + acc[m][2][r], o1 = acc[m][1][r] - acc[m][2][r];
+                y0[r] = acc[m][0][r] + e1; y1[r] = o1; y2[r] = e1; y3[r] = o1;
+            }
+        };
+        auto ep2 = [&](const int m, const int ra, const int rb, f32x16& y0, f32x16& y1, f32x16& y2, f32x16& y3) {
+#pragma unroll
+            for (int r = ra; r < rb; ++r) {
+                const float e2 = acc[m][3][r] + acc[m][4][r], o2 = acc[m][3][r] - acc[m][4][r];
+                y0[r] += e2; y1[r] += 2.f * o2; y2[r] += 4.f * e2; y3[r] += 8.f * o2;
+            }
+        };
+        auto ep3 = [&](const int m, f32x16& y0, f32x16& y1, f32x16& y2, f32x16& y3) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float e3 = acc[m][5][r] + acc[m][6][r], o3 = acc[m][5][r] - acc[m][6][r];
+                y0[r] += e3; y1[r] += 0.5f * o3; y2[r] += 0.25f * e3; y3[r] += 0.125f * o3;
+                y3[r] += acc[m][7][r];
+            }
+        };
         int next_pass = pass + 1;
         const bool draw = pass >= big_end || pass % PK == PK - 1;          // the last pass of a ticket draws the next one
         if (draw && tid == 0) s_next_pass = ticket_first((int)atomicAdd(pass_ctr, 1u) + (int)gridDim.x);   // read by everyone after the first chunk's barrier
@@ -653,6 +681,14 @@ __global__ __launch_bounds__(256) void k_conv5_wpre(const uint8_t* __restrict__ 
                 for (int m = 0; m < TPW; ++m) acc[m][p] = mfma16(a1[m], b2, acc[m][p]);
 #pragma unroll
                 for (int m = 0; m < TPW; ++m) acc[m][p] = mfma16(a1[m], b1, acc[m][p]);
+                if (cc == G::NCH - 1 && !(DBG & 2)) {
+                    if (t == 34) ep1(0, 0, 5, ya0, ya1, ya2, ya3);
+                    if (t == 35) ep1(0, 5, 11, ya0, ya1, ya2, ya3);
+                    if (t == 36) ep1(0, 11, 16, ya0, ya1, ya2, ya3);
+                    if (t == 37) ep2(0, 0, 5, ya0, ya1, ya2, ya3);
+                    if (t == 38) ep2(0, 5, 11, ya0, ya1, ya2, ya3);
+                    if (t == 39) ep2(0, 11, 16, ya0, ya1, ya2, ya3);
+                }
                 __builtin_amdgcn_sched_group_barrier(0x100, 2 * TPW, 0);
                 __builtin_amdgcn_sched_group_barrier(0x020, 10, 0);
 #pragma unroll
@@ -672,20 +708,14 @@ __global__ __launch_bounds__(256) void k_conv5_wpre(const uint8_t* __restrict__ 
 #pragma unroll
         for (int m = 0; m < ((DBG & 2) ? 0 : TPW); ++m) {
             f32x16 y0, y1, y2, y3;
-            {
-                const f32x16 e1 = acc[m][1] + acc[m][2], o1 = acc[m][1] - acc[m][2];
-                y0 = acc[m][0] + e1; y1 = o1; y2 = e1; y3 = o1 + acc[m][7];
+            if (m == 0) { y0 = ya0; y1 = ya1; y2 = ya2; y3 = ya3; }
+            else {
+                ep1(m, 0, 16, y0, y1, y2, y3);
+                __builtin_amdgcn_sched_barrier(0);
+                ep2(m, 0, 16, y0, y1, y2, y3);
+                __builtin_amdgcn_sched_barrier(0);
             }
-            __builtin_amdgcn_sched_barrier(0);
-            {
-                const f32x16 e2 = acc[m][3] + acc[m][4], o2 = acc[m][3] - acc[m][4];
-                y0 += e2; y1 += 2.f * o2; y2 += 4.f * e2; y3 += 8.f * o2;
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            {
-                const f32x16 e3 = acc[m][5] + acc[m][6], o3 = acc[m][5] - acc[m][6];
-                y0 += e3; y1 += 0.5f * o3; y2 += 0.25f * e3; y3 += 0.125f * o3;
-            }
+            ep3(m, y0, y1, y2, y3);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int rr = 0; rr < 8; ++rr) {
