@@ -755,7 +755,11 @@ __device__ __forceinline__ float4 buf_load16f(const __amdgpu_buffer_rsrc_t r, co
 typedef __fp16 h2_t __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void split2h_pair(const float a, const float b, uint32_t& p1, uint32_t& p2) {
     const h2_t h1 = __builtin_amdgcn_cvt_pkrtz(a, b);
-    const float ra = fmaf((float)h1[0], -1.0f, a), rb = fmaf((float)h1[1], -1.0f, b);
+    // residuals a - h1.lo, b - h1.hi in one mixed-precision FMA each (the compiler's own choice is v_cvt_f32_f16 + v_sub_f32: twice the
+    // instructions of a phase that runs at the vector rate); exact either way
+    float ra, rb;
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(ra) : "v"(h1), "v"(a));
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(rb) : "v"(h1), "v"(b));
     const h2_t h2 = __builtin_amdgcn_cvt_pkrtz(ra, rb);
     p1 = __builtin_bit_cast(uint32_t, h1);
     p2 = __builtin_bit_cast(uint32_t, h2);
