@@ -589,21 +589,32 @@ __global__ __launch_bounds__(256) void k_conv5_wpre(const uint8_t* __restrict__ 
         // 256 v_accvgpr_write per pass and wave otherwise)
         f32x16 acc[TPW][8];
         const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        // With one wave per SIMD everything behind the last tap is exposed; what can move under the taps without delaying the MFMAs is the READING
-        // of finished accumulators: position p of the pass is final after tap 32 + p of the last chunk, so tile 0's 128 v_accvgpr_read run 16 per
-        // tap under taps 33..39 (explicit asm: left to the compiler they land wherever the block structure of the epilogue puts them).  Tile 1
-        // has no registers to go to; arithmetic under the taps costs more than it saves.  y3 takes position 7 last.
-        f32x16 raw0[8];                                                    // tile 0's accumulators, read under the last taps (explicitly: see below)
-        auto epi = [&](const f32x16 (&a)[8], f32x16& y0, f32x16& y1, f32x16& y2, f32x16& y3) {
+        // The output transform A^T (4 outputs from the 8 positions) in three position groups; y3 takes position 7 last (it is the last to arrive:
+        // position p is final after tap 32 + p of the last chunk).  Tile 0's first two groups are WRITTEN under taps 34-39 of the last chunk.
+        // What the compiler makes of that: the arithmetic itself sinks back into the guarded store blocks behind the loop, but tile 0's 128
+        // accumulator reads stay under the last taps, and with one wave per SIMD everything behind the last tap is exposed: 4.52 -> 4.32 ms.
+        // (Pinning the arithmetic under the taps as well -- an empty asm on the partial sums -- needs 48-64 more live registers: spills, 7 ms.)
+        f32x16 ya0, ya1, ya2, ya3;
+        auto ep1 = [&](const int m, const int ra, const int rb, f32x16& y0, f32x16& y1, f32x16& y2, f32x16& y3) {
+#pragma unroll
+            for (int r = ra; r < rb; ++r) {
+                const float e1 = acc[m][1][r] + acc[m][2][r], o1 = acc[m][1][r] - acc[m][2][r];
+                y0[r] = acc[m][0][r] + e1; y1[r] = o1; y2[r] = e1; y3[r] = o1;
+            }
+        };
+        auto ep2 = [&](const int m, const int ra, const int rb, f32x16& y0, f32x16& y1, f32x16& y2, f32x16& y3) {
+#pragma unroll
+            for (int r = ra; r < rb; ++r) {
+                const float e2 = acc[m][3][r] + acc[m][4][r], o2 = acc[m][3][r] - acc[m][4][r];
+                y0[r] += e2; y1[r] += 2.f * o2; y2[r] += 4.f * e2; y3[r] += 8.f * o2;
+            }
+        };
+        auto ep3 = [&](const int m, f32x16& y0, f32x16& y1, f32x16& y2, f32x16& y3) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const float e1 = a[1][r] + a[2][r], o1 = a[1][r] - a[2][r];
-                y0[r] = a[0][r] + e1; y1[r] = o1; y2[r] = e1; y3[r] = o1;
-                const float e2 = a[3][r] + a[4][r], o2 = a[3][r] - a[4][r];
-                y0[r] += e2; y1[r] += 2.f * o2; y2[r] += 4.f * e2; y3[r] += 8.f * o2;
-                const float e3 = a[5][r] + a[6][r], o3 = a[5][r] - a[6][r];
+                const float e3 = acc[m][5][r] + acc[m][6][r], o3 = acc[m][5][r] - acc[m][6][r];
                 y0[r] += e3; y1[r] += 0.5f * o3; y2[r] += 0.25f * e3; y3[r] += 0.125f * o3;
-                y3[r] += a[7][r];
+                y3[r] += acc[m][7][r];
             }
         };
         int next_pass = pass + 1;
@@ -670,9 +681,13 @@ __global__ __launch_bounds__(256) void k_conv5_wpre(const uint8_t* __restrict__ 
                 for (int m = 0; m < TPW; ++m) acc[m][p] = mfma16(a1[m], b2, acc[m][p]);
 #pragma unroll
                 for (int m = 0; m < TPW; ++m) acc[m][p] = mfma16(a1[m], b1, acc[m][p]);
-                if (cc == G::NCH - 1 && !(DBG & 2) && t >= 33) {       // position t - 33 of tile 0 was final after the tap before this one
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(raw0[t - 33][r]) : "a"(acc[0][t - 33][r]));
+                if (cc == G::NCH - 1 && !(DBG & 2)) {
+                    if (t == 34) ep1(0, 0, 5, ya0, ya1, ya2, ya3);
+                    if (t == 35) ep1(0, 5, 11, ya0, ya1, ya2, ya3);
+                    if (t == 36) ep1(0, 11, 16, ya0, ya1, ya2, ya3);
+                    if (t == 37) ep2(0, 0, 5, ya0, ya1, ya2, ya3);
+                    if (t == 38) ep2(0, 5, 11, ya0, ya1, ya2, ya3);
+                    if (t == 39) ep2(0, 11, 16, ya0, ya1, ya2, ya3);
                 }
                 __builtin_amdgcn_sched_group_barrier(0x100, 2 * TPW, 0);
                 __builtin_amdgcn_sched_group_barrier(0x020, 10, 0);
@@ -690,17 +705,17 @@ __global__ __launch_bounds__(256) void k_conv5_wpre(const uint8_t* __restrict__ 
             __syncthreads();
             bufsel ^= 1;
         }
-        if (!(DBG & 2)) {
-            // (the MFMA that wrote position 7 was the last one issued, and the hazard recognizer does not look into inline asm: the wait states
-            // a v_accvgpr_read needs behind an 8-pass MFMA are spelled out; the reads under the taps sit six MFMAs behind their writer)
-            asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
-#pragma unroll
-            for (int r = 0; r < 16; ++r) asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(raw0[7][r]) : "a"(acc[0][7][r]));
-        }
 #pragma unroll
         for (int m = 0; m < ((DBG & 2) ? 0 : TPW); ++m) {
             f32x16 y0, y1, y2, y3;
-            if (m == 0) epi(raw0, y0, y1, y2, y3); else epi(acc[1], y0, y1, y2, y3);
+            if (m == 0) { y0 = ya0; y1 = ya1; y2 = ya2; y3 = ya3; }
+            else {
+                ep1(m, 0, 16, y0, y1, y2, y3);
+                __builtin_amdgcn_sched_barrier(0);
+                ep2(m, 0, 16, y0, y1, y2, y3);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            ep3(m, y0, y1, y2, y3);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int rr = 0; rr < 8; ++rr) {
