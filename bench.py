@@ -349,7 +349,7 @@ def measure(args, env):
                 "pipelined_detect_pass_frac": (pass_traffic / pipe_detect_s / 8e12) if (pass_traffic and pipe_detect_s) else None,
                 "pipelined_note": "the same three kernels per pass, passes issued alternately by the pipeline's two contexts on their own streams (labelling / gather of one batch under the pixel pass of the next): wall clock per pass over 20 passes with nothing else on the GPU; whole_detect_pass_* is one context alone, serial",
                 "timing": "HIP events on the kernel stream; 5 serial detect passes after the timed region when lanes are pipelined (in-flight the stage shares the GPU with the identity network)",
-                "limiter": "read-only HBM streaming + VALU: the same kernel with the masks replaced by a trivial compare takes 187-200 us (torch's fastest read-only reduction over the same 1.07 GB: 183 us = 5.85 TB/s, tools/read_bw.py); exact masks and run extraction add the rest. A/B on one box (tools/rows_exp.sh): k_rows32 generic 250 us, + compile-time threshold modes 242, background row in registers for 8 frames (k_rows32b) 235, both 220. k_ccl_lds / k_gather are latency chains of one workgroup per frame / half a wave per blob",
+                "limiter": "read-only HBM streaming + VALU: the same kernel with the masks replaced by a trivial compare takes 187-200 us (a plain grid-stride streaming read of the same 1.07 GB: 167 us = 6.4 TB/s, tools/bw_probe.hip; torch's fastest read-only reduction: 183 us); exact masks and run extraction add the rest. A/B on one box (tools/rows_exp.sh): k_rows32 generic 250 us, + compile-time threshold modes 242, background row in registers for 8 frames (k_rows32b) 235, both 220, rows fastest 215. k_ccl_lds / k_gather are latency chains of one workgroup per frame / half a wave per blob",
                 "frac_of_measured_copy_bw": ((rows_traffic or seg_bytes) / rows_s / 6.29e12) if rows_s else None}
     if host_in:
         bytes_step = float(B * W * H * (4 if bgra_in else 1))
