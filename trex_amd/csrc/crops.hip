@@ -270,7 +270,41 @@ __global__ __launch_bounds__(256) void k_to_gray(const uint8_t* __restrict__ src
     reinterpret_cast<uint32_t*>(dst)[i] = out;
 }
 
+// the same, 16 pixels per thread: CH 16-byte loads, one 16-byte store (4 pixels per thread -- 16 bytes in, 4 out -- moved the 5.4 GB of a
+// 256-frame BGRA batch at 3.9 TB/s)
+template <int CH>
+__global__ __launch_bounds__(256) void k_to_gray16(const uint4* __restrict__ src, uint4* __restrict__ dst, size_t npix16, int color_channel) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= npix16) return;
+    uint32_t w[4 * CH];
+#pragma unroll
+    for (int k = 0; k < CH; ++k) { const uint4 v = src[i * CH + k]; w[4 * k] = v.x; w[4 * k + 1] = v.y; w[4 * k + 2] = v.z; w[4 * k + 3] = v.w; }
+    uint32_t out[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int p = 0; p < 16; ++p) {
+        uint32_t c[4] = {0, 0, 0, 0};
+#pragma unroll
+        for (int k = 0; k < CH; ++k) {
+            const int byte = p * CH + k;
+            c[k] = (w[byte >> 2] >> (8 * (byte & 3))) & 0xffu;
+        }
+        uint32_t g;
+        if (color_channel >= 0) g = c[color_channel & 3];
+        else g = (__umul24(c[0], 1868u) + __umul24(c[1], 9617u) + __umul24(c[2], 4899u) + 8192u) >> 14;
+        out[p >> 2] |= g << (8 * (p & 3));
+    }
+    dst[i] = make_uint4(out[0], out[1], out[2], out[3]);
+}
+
 int launch_to_gray(trexhip_ctx* ctx, const uint8_t* d_color, uint8_t* d_gray, size_t npix, int channels, int color_channel) {
+    if (npix % 16 == 0 && ((reinterpret_cast<uintptr_t>(d_color) | reinterpret_cast<uintptr_t>(d_gray)) & 15) == 0) {
+        const size_t n16 = npix / 16;
+        const dim3 grid16((unsigned)((n16 + 255) / 256));
+        if (channels == 3) hipLaunchKernelGGL((k_to_gray16<3>), grid16, dim3(256), 0, ctx->stream, reinterpret_cast<const uint4*>(d_color), reinterpret_cast<uint4*>(d_gray), n16, color_channel);
+        else               hipLaunchKernelGGL((k_to_gray16<4>), grid16, dim3(256), 0, ctx->stream, reinterpret_cast<const uint4*>(d_color), reinterpret_cast<uint4*>(d_gray), n16, color_channel);
+        TH_CHECK_HIP(hipGetLastError());
+        return TREXHIP_OK;
+    }
     const size_t n4 = npix / 4;
     const dim3 grid((unsigned)((n4 + 255) / 256));
     if (channels == 3) hipLaunchKernelGGL((k_to_gray<3>), grid, dim3(256), 0, ctx->stream, d_color, d_gray, n4, color_channel);
