@@ -40,6 +40,10 @@ class Lane:
                     pl.shared_comm = capi.Comm(self.seg, pl.rank, pl.world, pl.next_comm_id())
                 self.comm = pl.shared_comm
             self.table_all = torch.zeros((pl.world * pl.rows, pl.rowlen), dtype=torch.int32, device=dev) if pl.rank == 0 else None
+            if pl.rank == 0:
+                # rank 0 writes its own table straight into slot 0 of the gathered slab: trexhip_comm_gather_device skips the device copy of
+                # a rank's own share when send and receive pointers coincide (14 MB per step on the lane's kernel stream otherwise)
+                self.table = self.table_all[:pl.rows]
         if pl.with_posture:
             MP = pl.MP
             self.p_outline = torch.empty((pl.pool, MP, 2), dtype=torch.float32, device=dev)
