@@ -377,3 +377,27 @@ def test_two_contexts_from_two_threads():
     for t in ts: t.start()
     for t in ts: t.join()
     assert not errors, errors
+
+
+@pytest.mark.parametrize("channels", [3, 4])
+@pytest.mark.parametrize("shape,shift", [((64, 32), 0), ((36, 10), 0), ((64, 32), 4), ((2048, 8), 0)])
+def test_colour_tiles_on_the_device(channels, shape, shift):
+    # cvtColor on the device (trexhip_segment_color_device): the 16-pixels-per-thread kernel takes frames whose pixel count is a multiple of
+    # 16 at 16-byte aligned addresses, everything else the 4-pixel kernel -- both must give cv::cvtColor's fixed-point grey (oracle.bgr2gray)
+    W, H = shape
+    rng = np.random.default_rng(W * 7 + H + channels + shift)
+    col = rng.integers(0, 256, (2, H, W, channels)).astype(np.uint8)
+    col[:, 2:6, 3:30] //= 8
+    bg = np.full((H, W), 140, np.uint8)
+    gray = oracle.bgr2gray(col)
+    p = capi.default_params(W, H, max_batch=2, max_blobs=4096, threshold=40)
+    seg = capi.Segmenter(p)
+    seg.set_background(bg)
+    buf = torch.zeros(col.size + 64, dtype=torch.uint8, device="cuda")
+    buf[shift:shift + col.size] = torch.from_numpy(col.reshape(-1)).cuda()
+    torch.cuda.synchronize()
+    seg.segment_color_device(buf.data_ptr() + shift, 2, channels)
+    res = seg.fetch()
+    for r, g in zip(res, gray):
+        assert_frame_equal(r, np.ascontiguousarray(g), bg, threshold=40)
+    seg.close()
