@@ -109,42 +109,91 @@ static int smooth_outline(const v2* p, int L, int range, int step, v2* out) {
     return 1;
 }
 
-/* ---- periodic::* restatements (unpinned, see header) ---------------------------------------------- */
+/* ---- periodic::* restatements (unpinned, see header) ----------------------------------------------
+ * periodic::eft / ieft live in the un-vendored commons: what is summed is restated, the ORDER of the float sums and the sin / cos
+ * implementation are not known.  Both are therefore fixed here in a form the device reproduces operation by operation
+ * (trex_amd/csrc/posture.hip, same constants, no FMA contraction on either side), so that device and oracle agree bit for bit:
+ *   - det_sincosf: Cody-Waite reduction by pi/2 in three pieces + the classic degree-7 / degree-8 minimax polynomials on [-pi/4, pi/4]
+ *     (about 1 ulp; glibc's sinf / cosf differ from it in the last bit here and there);
+ *   - arc length: inclusive Hillis-Steele scan over blocks of 64 segments + a running carry (the wave scan of the device);
+ *   - coefficient sums: 64 interleaved partial sums (term i goes to partial i % 64, in order of i), combined by the butterfly
+ *     v[l] += v[l ^ d], d = 32 .. 1.
+ * The centre is NOT part of this: Outline.cpp:502-505 (in tree) sums the points in order, and so do both sides. */
+static void det_sincosf(const float x, float* sn, float* cs) {
+    const float kf = floorf(x * 0.636619772f + 0.5f);
+    const int k = (int)kf;
+    float r = x - kf * 1.5703125f;
+    r = r - kf * 4.837512969970703125e-4f;
+    r = r - kf * 7.54978995489188216e-8f;
+    const float z = r * r;
+    float ps = -1.9515295891e-4f; ps = ps * z + 8.3321608736e-3f; ps = ps * z - 1.6666654611e-1f;
+    const float s0 = r + r * z * ps;
+    float pc = 2.443315711809948e-5f; pc = pc * z - 1.388731625493765e-3f; pc = pc * z + 4.166664568298827e-2f;
+    const float c0 = (1.0f - 0.5f * z) + z * z * pc;
+    switch (k & 3) {
+        case 0: *sn = s0; *cs = c0; break;
+        case 1: *sn = c0; *cs = -s0; break;
+        case 2: *sn = -s0; *cs = -c0; break;
+        default: *sn = -c0; *cs = s0; break;
+    }
+}
+static float butterfly64(float* v) {
+    for (int d = 32; d >= 1; d >>= 1) {
+        float w[64];
+        for (int l = 0; l < 64; ++l) w[l] = v[l] + v[l ^ d];
+        memcpy(v, w, sizeof(w));
+    }
+    return v[0];
+}
 static void eft_ieft(const v2* p, int N, int order, v2 center, v2* out) {
-    float* t = (float*)malloc((size_t)(N + 1) * sizeof(float));
+    float* t = (float*)malloc((size_t)(N + 1) * sizeof(float));          /* t[i + 1] = arc length at the END of segment i */
     t[0] = 0;
-    for (int i = 0; i < N; ++i) {
-        const v2 q = p[(i + 1) % N];
-        const float dx = q.x - p[i].x, dy = q.y - p[i].y;
-        t[i + 1] = t[i] + sqrtf(dx * dx + dy * dy);
+    float run = 0;
+    for (int i0 = 0; i0 < N; i0 += 64) {
+        float incl[64];
+        for (int l = 0; l < 64; ++l) {
+            const int i = i0 + l;
+            incl[l] = 0;
+            if (i < N) { const v2 q = p[(i + 1) % N]; const float dx = q.x - p[i].x, dy = q.y - p[i].y; incl[l] = sqrtf(dx * dx + dy * dy); }
+        }
+        for (int d = 1; d < 64; d <<= 1) {
+            float w[64];
+            for (int l = 0; l < 64; ++l) w[l] = l >= d ? incl[l] + incl[l - d] : incl[l];
+            memcpy(incl, w, sizeof(w));
+        }
+        for (int l = 0; l < 64 && i0 + l < N; ++l) t[i0 + l + 1] = run + incl[l];
+        run = run + incl[63];
     }
     const float T = t[N];
     float a[16], b[16], c[16], d[16];
     const float PI = 3.14159265358979323846f;
+    float* cs = (float*)malloc((size_t)(N + 1) * 2 * sizeof(float));
     for (int n = 1; n <= order; ++n) {
-        float sa = 0, sb = 0, sc = 0, sd = 0;
+        for (int i = 0; i <= N; ++i) det_sincosf(2.0f * PI * (float)n * t[i] / T, &cs[2 * i + 1], &cs[2 * i]);
+        float sa[64] = {0}, sb[64] = {0}, sc[64] = {0}, sd[64] = {0};
         for (int i = 0; i < N; ++i) {
             const v2 q = p[(i + 1) % N];
             const float dx = q.x - p[i].x, dy = q.y - p[i].y;
             const float dt = t[i + 1] - t[i];
             if (dt <= 0) continue;
-            const float ph1 = 2.0f * PI * (float)n * t[i + 1] / T, ph0 = 2.0f * PI * (float)n * t[i] / T;
-            const float dc = cosf(ph1) - cosf(ph0), ds = sinf(ph1) - sinf(ph0);
-            sa += dx / dt * dc; sb += dx / dt * ds; sc += dy / dt * dc; sd += dy / dt * ds;
+            const float dc = cs[2 * (i + 1)] - cs[2 * i], ds = cs[2 * (i + 1) + 1] - cs[2 * i + 1];
+            const int l = i & 63;
+            sa[l] += dx / dt * dc; sb[l] += dx / dt * ds; sc[l] += dy / dt * dc; sd[l] += dy / dt * ds;
         }
         const float k = T / (2.0f * (float)(n * n) * PI * PI);
-        a[n] = k * sa; b[n] = k * sb; c[n] = k * sc; d[n] = k * sd;
+        a[n] = k * butterfly64(sa); b[n] = k * butterfly64(sb); c[n] = k * butterfly64(sc); d[n] = k * butterfly64(sd);
     }
     for (int k = 0; k < N; ++k) {
         const float tt = (float)k / (float)N;
         float x = center.x, y = center.y;
         for (int n = 1; n <= order; ++n) {
-            const float ph = 2.0f * PI * (float)n * tt;
-            const float cs = cosf(ph), sn = sinf(ph);
-            x += a[n] * cs + b[n] * sn; y += c[n] * cs + d[n] * sn;
+            float sn, co;
+            det_sincosf(2.0f * PI * (float)n * tt, &sn, &co);
+            x += a[n] * co + b[n] * sn; y += c[n] * co + d[n] * sn;
         }
         out[k].x = x; out[k].y = y;
     }
+    free(cs);
     free(t);
 }
 

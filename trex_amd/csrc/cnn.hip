@@ -1042,6 +1042,7 @@ __global__ __launch_bounds__((WinoGeom<CI, CO, S, TPW>::NTHR), (TPW == 1 ? 2 : 1
 
 #include "cnn_wpre.h"
 #include "cnn_fused12.h"
+#include "cnn_fused12rs.h"
 
 static constexpr int FC1_KSPLIT = 10;     // 12800 = 10 x 1280: 500 workgroups at 6400 crops (5: 129 us, 10: 92 us, 20: 102 us + slower head); partial planes summed in k_head
 // ------------------------------------------------------------------------------------------------
@@ -1709,12 +1710,19 @@ static int net_forward_launch(trexhip_ctx* ctx, const uint8_t* d_crops, int n, f
         W3A(0); W2BA(0);
 #define F12A(D_) TH_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv12_wpre<D_>), hipFuncAttributeMaxDynamicSharedMemorySize, W12Geom::LDS_BYTES))
         F12A(0);
+#define F12R(D_) TH_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv12_rs<D_>), hipFuncAttributeMaxDynamicSharedMemorySize, W12RGeom::LDS_BYTES))
+        F12R(0);
+#ifdef TREXHIP_DEV_KNOBS
+        F12R(8); F12R(16); F12R(32); F12R(40); F12R(64);
+#endif
+#undef F12R
 #ifdef TREXHIP_DEV_KNOBS
         F12A(1); F12A(2); F12A(4); F12A(8); F12A(16); F12A(24); F12A(32); F12A(40); F12A(56); F12A(64); F12A(128);
-        TH_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv12_wpre<0, 0x033>), hipFuncAttributeMaxDynamicSharedMemorySize, W12Geom::LDS_BYTES));
-        TH_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv12_wpre<0, 0x333>), hipFuncAttributeMaxDynamicSharedMemorySize, W12Geom::LDS_BYTES));
-        TH_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv12_wpre<0, 0x000>), hipFuncAttributeMaxDynamicSharedMemorySize, W12Geom::LDS_BYTES));
-        TH_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv12_wpre<0, 0x123>), hipFuncAttributeMaxDynamicSharedMemorySize, W12Geom::LDS_BYTES));
+        TH_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv12_wpre<128, 0x03>), hipFuncAttributeMaxDynamicSharedMemorySize, W12Geom::LDS_BYTES));
+        TH_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv12_wpre<0, 0x03>), hipFuncAttributeMaxDynamicSharedMemorySize, W12Geom::LDS_BYTES));
+        TH_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv12_wpre<0, 0x10>), hipFuncAttributeMaxDynamicSharedMemorySize, W12Geom::LDS_BYTES));
+        TH_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv12_wpre<0, 0x00>), hipFuncAttributeMaxDynamicSharedMemorySize, W12Geom::LDS_BYTES));
+        TH_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv12_wpre<0, 0x31>), hipFuncAttributeMaxDynamicSharedMemorySize, W12Geom::LDS_BYTES));
 #endif
 #undef F12A
 #ifdef TREXHIP_DEV_KNOBS
@@ -1771,9 +1779,32 @@ static int net_forward_launch(trexhip_ctx* ctx, const uint8_t* d_crops, int n, f
                                      : n * (ConvGeomB<CI_, CO_, S_, ROWS_, SplitK<KIND_>::NP, CIC_>::BPC)),                                          \
                        dim3(512), (ConvGeomB<CI_, CO_, S_, ROWS_, SplitK<KIND_>::NP, CIC_>::LDS_BYTES), s, in_, w_, b_, out_, sc_, net->d_ovf, guard_, \
                        n * (ConvGeomB<CI_, CO_, S_, ROWS_, SplitK<KIND_>::NP, CIC_>::BPC))
-    if (fused12) {
+    if (fused12 && !(ctx->tune_conv_geom & (1 << 29))) {
+        // role-split form (cnn_fused12rs.h): one workgroup of 8 waves per CU, consumer waves (tap loop, output transform) beside producer waves
+        // (V3 transform of the previous pass, V2 rows of the next).  TREXHIP_CONV_GEOM bit 29: the two-workgroups-per-CU kernel of round 4
         const int n_pass = (n * 20 + W2bGeom::RPP - 1) / W2bGeom::RPP;
+        const int wgs = ctx->n_cus;
+        static const int pk_env = std::getenv("TREXHIP_F12_PK") ? std::atoi(std::getenv("TREXHIP_F12_PK")) : 0;
+        const int pk = pk_env > 0 ? pk_env : std::max(1, std::min(32, n_pass / (wgs * 4)));
+        const int want = (n_pass + pk - 1) / pk;
+#define F12RK(D_) hipLaunchKernelGGL((k_conv12_rs<D_>), dim3(want < wgs ? want : wgs), dim3(512), W12RGeom::LDS_BYTES, s, d_crops, net->w1h, net->b1, net->inv1h, \
+                           net->w2w, net->b2, net->v3, net->inv2w, net->d_ovf, n, net->d_ovf + 2, pk)
+#ifdef TREXHIP_DEV_KNOBS
+        static const int f12r_dbg = std::getenv("TREXHIP_F12_DBG") ? std::atoi(std::getenv("TREXHIP_F12_DBG")) : 0;
+        switch (f12r_dbg) { case 8: F12RK(8); break; case 16: F12RK(16); break; case 32: F12RK(32); break; case 40: F12RK(40); break; case 64: F12RK(64); break; default: F12RK(0); }
+#else
+        F12RK(0);
+#endif
+#undef F12RK
+    }
+    else if (fused12) {
+        const int n_pass = (n * 20 + W2bGeom::RPP - 1) / W2bGeom::RPP;
+#ifdef TREXHIP_DEV_KNOBS
+        static const int wgs_env = std::getenv("TREXHIP_F12_WGS") ? std::atoi(std::getenv("TREXHIP_F12_WGS")) : 2;      // dev: workgroups per CU
+        const int wgs = wgs_env * ctx->n_cus;
+#else
         const int wgs = 2 * ctx->n_cus;
+#endif
         // passes per ticket: long tickets save the 4 extra rows of a ticket's first pass, short ones keep every workgroup busy when the batch is small
         static const int pk_env = std::getenv("TREXHIP_F12_PK") ? std::atoi(std::getenv("TREXHIP_F12_PK")) : 0;
         const int pk = pk_env > 0 ? pk_env : std::max(1, std::min(16, n_pass / (wgs * 4)));
@@ -1785,10 +1816,11 @@ static int net_forward_launch(trexhip_ctx* ctx, const uint8_t* d_crops, int n, f
         static const int f12_dbg = std::getenv("TREXHIP_F12_DBG") ? std::atoi(std::getenv("TREXHIP_F12_DBG")) : 0;
         switch (f12_dbg) { case 1: F12K(1); break; case 2: F12K(2); break; case 4: F12K(4); break; case 8: F12K(8); break; case 16: F12K(16); break; case 24: F12K(24); break; case 32: F12K(32); break; case 40: F12K(40); break; case 56: F12K(56); break; case 64: F12K(64); break;
             case 128: hipLaunchKernelGGL((k_conv12_wpre<128>), dim3(want < wgs ? want : wgs), dim3(256), W12Geom::LDS_BYTES, s, d_crops, net->w1h, net->b1, net->inv1h, net->w2w, net->b2, net->v3, net->inv2w, net->d_ovf, n, net->d_ovf + 2, pk, reinterpret_cast<unsigned long long*>(ctx->d_cnt_px)); break;   // phase stamps -> trexhip_debug_read (tools/f12_stamps.py)
-            case 100: hipLaunchKernelGGL((k_conv12_wpre<0, 0x033>), dim3(want < wgs ? want : wgs), dim3(256), W12Geom::LDS_BYTES, s, d_crops, net->w1h, net->b1, net->inv1h, net->w2w, net->b2, net->v3, net->inv2w, net->d_ovf, n, net->d_ovf + 2, pk); break;
-            case 101: hipLaunchKernelGGL((k_conv12_wpre<0, 0x333>), dim3(want < wgs ? want : wgs), dim3(256), W12Geom::LDS_BYTES, s, d_crops, net->w1h, net->b1, net->inv1h, net->w2w, net->b2, net->v3, net->inv2w, net->d_ovf, n, net->d_ovf + 2, pk); break;
-            case 102: hipLaunchKernelGGL((k_conv12_wpre<0, 0x000>), dim3(want < wgs ? want : wgs), dim3(256), W12Geom::LDS_BYTES, s, d_crops, net->w1h, net->b1, net->inv1h, net->w2w, net->b2, net->v3, net->inv2w, net->d_ovf, n, net->d_ovf + 2, pk); break;
-            case 103: hipLaunchKernelGGL((k_conv12_wpre<0, 0x123>), dim3(want < wgs ? want : wgs), dim3(256), W12Geom::LDS_BYTES, s, d_crops, net->w1h, net->b1, net->inv1h, net->w2w, net->b2, net->v3, net->inv2w, net->d_ovf, n, net->d_ovf + 2, pk); break;
+            case 129: hipLaunchKernelGGL((k_conv12_wpre<128, 0x03>), dim3(want < wgs ? want : wgs), dim3(256), W12Geom::LDS_BYTES, s, d_crops, net->w1h, net->b1, net->inv1h, net->w2w, net->b2, net->v3, net->inv2w, net->d_ovf, n, net->d_ovf + 2, pk, reinterpret_cast<unsigned long long*>(ctx->d_cnt_px)); break;   // the same with the priorities of rounds 3-4
+            case 100: hipLaunchKernelGGL((k_conv12_wpre<0, 0x03>), dim3(want < wgs ? want : wgs), dim3(256), W12Geom::LDS_BYTES, s, d_crops, net->w1h, net->b1, net->inv1h, net->w2w, net->b2, net->v3, net->inv2w, net->d_ovf, n, net->d_ovf + 2, pk); break;
+            case 101: hipLaunchKernelGGL((k_conv12_wpre<0, 0x10>), dim3(want < wgs ? want : wgs), dim3(256), W12Geom::LDS_BYTES, s, d_crops, net->w1h, net->b1, net->inv1h, net->w2w, net->b2, net->v3, net->inv2w, net->d_ovf, n, net->d_ovf + 2, pk); break;
+            case 102: hipLaunchKernelGGL((k_conv12_wpre<0, 0x00>), dim3(want < wgs ? want : wgs), dim3(256), W12Geom::LDS_BYTES, s, d_crops, net->w1h, net->b1, net->inv1h, net->w2w, net->b2, net->v3, net->inv2w, net->d_ovf, n, net->d_ovf + 2, pk); break;
+            case 103: hipLaunchKernelGGL((k_conv12_wpre<0, 0x31>), dim3(want < wgs ? want : wgs), dim3(256), W12Geom::LDS_BYTES, s, d_crops, net->w1h, net->b1, net->inv1h, net->w2w, net->b2, net->v3, net->inv2w, net->d_ovf, n, net->d_ovf + 2, pk); break;
             default: F12K(0); }
 #else
         F12K(0);

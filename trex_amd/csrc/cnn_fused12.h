@@ -26,7 +26,7 @@ struct W12Geom {
     static_assert(2 * (LDS_BYTES + 64) <= 160 * 1024, "two workgroups per CU");
 };
 
-template <int DBG = 0, int PRIO = 0x030, int STAGGER = 5, int AD = 1, int BD = 3>      // PRIO: s_setprio of (P2, tap loop, P1) as hex digits      // DBG (dev builds): 1 no crop loads, 2 no conv1 MFMAs, 4 no P2 transform, 8 no production at all, 16 no epilogue, 32 no tap loop, 64 half the weight fragments (the second piece = a copy of the first: wrong results, same matrix work), 128 phase stamps
+template <int DBG = 0, int PRIO = 0x30, int STAGGER = 5, int AD = 1, int BD = 3>      // PRIO: s_setprio of (the vector phases, the tap loop) as hex digits      // DBG (dev builds): 1 no crop loads, 2 no conv1 MFMAs, 4 no P2 transform, 8 no production at all, 16 no epilogue, 32 no tap loop, 64 half the weight fragments (the second piece = a copy of the first: wrong results, same matrix work), 128 phase stamps
 __global__ __launch_bounds__(256, 2) void k_conv12_wpre(const uint8_t* __restrict__ crops /*[N][80][80]*/, const uint4* __restrict__ w1tab /*[16][64]*/,
                                                         const float* __restrict__ bias1, const float inv_scale1,
                                                         const uint4* __restrict__ wp /*[5][8][2][2][64] x 16 B*/, const float* __restrict__ bias,
@@ -46,6 +46,7 @@ __global__ __launch_bounds__(256, 2) void k_conv12_wpre(const uint8_t* __restric
     const int n_pass = (total_pairs + G::RPP - 1) / G::RPP;
     int pass = blockIdx.x * PK;
     if (pass >= n_pass) return;
+    __builtin_amdgcn_s_setprio((PRIO >> 4) & 0xf);
     for (int i = tid; i < 4 * (G::ROWL / 16); i += 256) {                // the zero rows of the four planes
         const int pl = i / (G::ROWL / 16), o = i - pl * (G::ROWL / 16);
         *reinterpret_cast<uint4*>(ldsb + pl * G::PLANE + o * 16) = make_uint4(0, 0, 0, 0);
@@ -284,7 +285,11 @@ __global__ __launch_bounds__(256, 2) void k_conv12_wpre(const uint8_t* __restric
         }
         f32x16 acc[8];
         const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        if ((PRIO >> 4) & 0xf) __builtin_amdgcn_s_setprio((PRIO >> 4) & 0xf);       // the tap loop outranks the other workgroup's epilogue / production
+        // The VECTOR phases outrank the tap loop (round 5, tools/ubench_simd.hip): a wave whose next instruction is an MFMA that waits for its
+        // accumulator holds the SIMD's issue port, and at equal (or higher) priority the other workgroup's wave in its vector phase gets next
+        // to nothing (960 v_fma beside 120 dependent MFMAs: 8486 cycles at priorities 0 / 0 or 3 / 0, 5444 with the vector wave above -- the
+        // MFMA wave loses 1 %).  Rounds 3-4 had it the other way round (tap loop 3, everything else 0): the phases added up instead of overlapping.
+        __builtin_amdgcn_s_setprio(PRIO & 0xf);
         uint4 af[AD + 1][2];
 #define W2B_AREAD(dst_, tau_)                                                                                                    \
         do {                                                                                                                     \
@@ -319,7 +324,7 @@ __global__ __launch_bounds__(256, 2) void k_conv12_wpre(const uint8_t* __restric
             __builtin_amdgcn_sched_barrier(0);
         }
 #undef W2B_AREAD
-        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_s_setprio((PRIO >> 4) & 0xf);
         F12_STAMP(0);
         __syncthreads();                                                  // every wave is done with the operand planes
         F12_STAMP(1);

@@ -1,0 +1,438 @@
+// cnn_fused12rs.h -- conv1 inside conv2 with the work split by ROLE between the waves of one workgroup (round 5).
+// Included by cnn.hip inside namespace trexhip, after cnn_fused12.h (W2bGeom, w2b_rot, wino_bt, split2h_pair, the helpers).
+//
+// What round 5 measured about k_conv12_wpre (profiles/r05_f12_stamps.txt, profiles/r05_ubench_simd.txt, profiles/r05_ubench_blocks.txt):
+//   * a wave issues one instruction per ~5 cycles whatever its kind (256 independent v_add / v_fma: 5.2-5.4 cycles each), and a pass of that kernel
+//     is ~2500 instructions per wave, one dependent chain tap loop -> output transform -> V3 transform -> crop rows -> conv1 -> V2 transform;
+//   * ONE workgroup alone on a CU needs 22.9 k cycles per pass, two per CU 29.5 k each: the kernel's time is the length of that chain, not
+//     the occupancy of any pipe (matrix pipe 0.41, vector issue about 0.5).
+// So the chain is cut in two and the halves run side by side on every SIMD:
+//   consumer waves 0..3   tap loop (conv2's 40 position GEMMs on the matrix cores) -> output transform, pool, bias, ReLU -> pbufE
+//   producer waves 4..7   V3 transform of the PREVIOUS pass (pbufE -> B^T d -> fp16 pieces -> HBM), then the V2 rows of the NEXT pass:
+//                         crop rows -> fp16 (P0), conv1 on the matrix cores + pool (P1), B^T d + pieces -> the LDS row ring (P2)
+// One workgroup of 8 waves per CU (a consumer and a producer wave on each SIMD), 256 registers each; every wave executes the same
+// sequence of s_barrier per round (three: after taps 0-19 | P0, after taps 20-39 | P1, after the output transform | P2), so the roles cannot
+// drift apart.  The arithmetic of every phase is k_conv12_wpre's, instruction for instruction: V3 and the probabilities stay bit-identical to
+// the two-kernel chain (tests/test_cnn_gpu.py::test_fused_equals_two_kernel_chain).
+//
+// LDS: the four operand planes (ring of NR = 10 row slots + the zero row, as before: P2 writes the ring in the stage where no tap reads it),
+// pbufE (consumer -> producer), pbufP (conv1's pooled activations of a chunk), the padded fp16 crop rows of a chunk: 93 KB.
+
+struct W12RGeom {
+    using G = W2bGeom;
+    static constexpr int CHUNK = 6;
+    static constexpr int IMG_PITCH = 88, IMG_ROWS = CHUNK * 6;
+    static constexpr int PBE_OFF = G::PBUF_OFF;                         // the pass's 3 x 20 x 64 pooled activations of conv2 (fp32)
+    static constexpr int PBP_OFF = PBE_OFF + G::PBUF, PBP_BYTES = CHUNK * 40 * 16 * 4;
+    static constexpr int IMG_OFF = PBP_OFF + PBP_BYTES, IMG_BYTES = IMG_ROWS * IMG_PITCH * 2;
+    static constexpr int CTL_OFF = IMG_OFF + IMG_BYTES;                 // the next ticket's first pass
+    static constexpr int LDS_BYTES = CTL_OFF + 16;
+    static_assert(LDS_BYTES <= 160 * 1024 && CTL_OFF % 16 == 0, "one workgroup per CU");
+};
+
+template <int DBG = 0, int BD = 3>
+__global__ __launch_bounds__(512) void k_conv12_rs(const uint8_t* __restrict__ crops /*[N][80][80]*/, const uint4* __restrict__ w1tab /*[16][64]*/,
+                                                   const float* __restrict__ bias1, const float inv_scale1,
+                                                   const uint4* __restrict__ wp /*[5][8][2][2][64] x 16 B*/, const float* __restrict__ bias,
+                                                   uint8_t* __restrict__ v3, const float out_scale, uint32_t* __restrict__ overflow,
+                                                   const int n_crops, uint32_t* __restrict__ pass_ctr, const int PK /* consecutive passes per ticket */) {
+    using G = W2bGeom;
+    using F = W12RGeom;
+    constexpr int CO = 64, S = 40;
+    extern __shared__ __attribute__((aligned(16))) uint8_t ldsb[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool producer = wave >= 4;                                     // wave-uniform
+    const int rt = tid & 255, rw = wave & 3;                             // thread / wave index within the role
+    const int total_pairs = n_crops * (S / 2);
+    const int total_rows = n_crops * S;
+    const int n_pass = (total_pairs + G::RPP - 1) / G::RPP;
+    int pass = blockIdx.x * PK;
+    if (pass >= n_pass) return;
+    volatile int* s_next = reinterpret_cast<volatile int*>(ldsb + F::CTL_OFF);
+    for (int i = tid; i < 4 * (G::ROWL / 16); i += 512) {                // the zero rows of the four planes
+        const int pl = i / (G::ROWL / 16), o = i - pl * (G::ROWL / 16);
+        *reinterpret_cast<uint4*>(ldsb + pl * G::PLANE + o * 16) = make_uint4(0, 0, 0, 0);
+    }
+    _Float16* img = reinterpret_cast<_Float16*>(ldsb + F::IMG_OFF);
+    float* pbe = reinterpret_cast<float*>(ldsb + F::PBE_OFF);
+    float* pbp = reinterpret_cast<float*>(ldsb + F::PBP_OFF);
+    for (int i = tid; i < F::IMG_BYTES / 16; i += 512) reinterpret_cast<uint4*>(img)[i] = make_uint4(0, 0, 0, 0);   // the x padding stays zero
+    if (tid == 0) *s_next = ((int)atomicAdd(pass_ctr, 1u) + (int)gridDim.x) * PK;
+    bool ovf = false;
+    // every wave: LDS writes done, then the workgroup barrier.  Both roles execute the SAME number of these per round.
+#define RS_BAR() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+#define RS_ROWS(pass_, qmin_, nrows_)                                                                                            \
+    do {                                                                                                                         \
+        const int gp0_ = (pass_) * G::RPP;                                                                                       \
+        int gpl_ = gp0_ + G::RPP - 1;                                                                                            \
+        gpl_ = gpl_ < total_pairs ? gpl_ : total_pairs - 1;                                                                      \
+        const int y0_ = (2 * gp0_) % S, yl_ = (2 * gpl_) % S + 1;                                                                \
+        qmin_ = 2 * gp0_ - (y0_ >= 2 ? 2 : 0);                                                                                   \
+        nrows_ = 2 * gpl_ + 1 + (yl_ + 2 <= S - 1 ? 2 : 0) - qmin_ + 1;                                                          \
+    } while (0)
+    // the rows the NEXT pass needs that are not in the ring yet: [lo, hi); the next pass itself (the last pass of a ticket moves on to the
+    // ticket drawn one round earlier).  Computed identically by every wave.
+#define RS_NEXT(pass_, res_hi_, next_, have_, lo_, hi_)                                                                          \
+    do {                                                                                                                         \
+        const bool draw_ = (pass_) % PK == PK - 1;                                                                               \
+        next_ = draw_ ? *s_next : (pass_) + 1;                                                                                   \
+        have_ = next_ < n_pass;                                                                                                  \
+        lo_ = hi_ = 0;                                                                                                           \
+        if (have_) {                                                                                                             \
+            int qn_, nn_;                                                                                                        \
+            RS_ROWS(next_, qn_, nn_);                                                                                            \
+            lo_ = (next_ == (pass_) + 1 && (res_hi_) > qn_) ? (res_hi_) : qn_;                                                   \
+            hi_ = qn_ + nn_;                                                                                                     \
+        }                                                                                                                        \
+    } while (0)
+    __syncthreads();
+
+    int qmin, nrows;
+    RS_ROWS(pass, qmin, nrows);
+    if (producer) {
+        // ------------------------------------------------------------------------------------------------------------------------
+        // PRODUCER: V3 transform of the previous pass, V2 rows of the next one
+        // ------------------------------------------------------------------------------------------------------------------------
+        __builtin_amdgcn_s_setprio(2);
+        // the crop-row unit (16 pixels) item `it` of a chunk that starts at V2 row c0 stands for: item = (V2 row v, crop row k of its six, unit u)
+#define RS_ITEM(it_, c0_)                                                                                                        \
+                const int vk = (it_) / 5, u = (it_) - vk * 5;                                                                    \
+                const int v = vk / 6, k = vk - v * 6;                                                                            \
+                int q = (c0_) + v;                                                                                               \
+                q = q < total_rows ? q : total_rows - 1;                                                                         \
+                const int crop = q / S, y = q - crop * S;                                                                        \
+                const int iy = 2 * y - 2 + k;
+        // P0 in two halves: the loads (issued in front of the V3 transform, whose instructions hide their latency), then the conversion
+        auto p0_load = [&](const int c0, const int nr, uint4& px) {
+            px = make_uint4(0, 0, 0, 0);
+            if (rt < nr * 30) {
+                RS_ITEM(rt, c0)
+                if (!(DBG & 1) && iy >= 0 && iy < 80) px = *reinterpret_cast<const uint4*>(crops + ((size_t)crop * 80 + iy) * 80 + u * 16);
+            }
+        };
+        auto p0_store = [&](const int nr, const uint4 px) {
+            if (rt < nr * 30) {
+                const int vk = rt / 5, u = rt - vk * 5;
+                const uint32_t w4[4] = {px.x, px.y, px.z, px.w};
+                uint32_t* d = reinterpret_cast<uint32_t*>(img + vk * F::IMG_PITCH + 2 + u * 16);       // (4-byte aligned: 2 halves of left padding)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const uint32_t b0 = (w4[e >> 1] >> (16 * (e & 1))) & 0xffu, b1 = (w4[e >> 1] >> (16 * (e & 1) + 8)) & 0xffu;
+                    d[e] = pack_h2((_Float16)(float)b0, (_Float16)(float)b1);
+                }
+            }
+        };
+        // P1: conv1 tiles (8 windows of 4 outputs x 2 image rows; 20 windows per V2 row), role wave w takes tiles w, w + 4, ...  k_conv1_wpre's
+        // tiles and products in its order (two fp16 weight pieces, low pieces first), bias, ReLU, 2x2 max-pool -> pbufP
+        const float bz1 = bias1[lane & 15];
+        // conv1's sixteen weight fragments stay in registers for the whole kernel (a producer wave holds no accumulators): fragment (s, mf, piece) =
+        // the base fragment (mf, piece) moved up by s window slots (16 s bits; the slots it leaves are zero weights, the three it pushes out were zero)
+        uint4 bf[16];
+#pragma unroll
+        for (int f = 0; f < 4; ++f) {
+            const uint4 b = w1tab[f * 64 + lane];
+            bf[f] = b;
+            bf[4 + f] = make_uint4(b.x << 16, __builtin_amdgcn_alignbit(b.y, b.x, 16), __builtin_amdgcn_alignbit(b.z, b.y, 16), __builtin_amdgcn_alignbit(b.w, b.z, 16));
+            bf[8 + f] = make_uint4(0u, b.x, b.y, b.z);
+            bf[12 + f] = make_uint4(0u, b.x << 16, __builtin_amdgcn_alignbit(b.y, b.x, 16), __builtin_amdgcn_alignbit(b.z, b.y, 16));
+        }
+        auto p1 = [&](const int nr) {
+            const int r = lane & 15, q4 = lane >> 4;
+            const int n_win = nr * 20, n_tiles = (n_win + 7) >> 3;
+            for (int tile = rw; tile < n_tiles; tile += 4) {
+                int wdx = tile * 8 + (r >> 1);
+                wdx = wdx < n_win ? wdx : n_win - 1;
+                const int v = wdx / 20, x4 = (wdx - v * 20) * 4;
+                const int row = v * 6 + (r & 1);
+                const _Float16* p1a = img + (row + q4) * F::IMG_PITCH + x4;
+                const _Float16* p2a = img + (row + 4) * F::IMG_PITCH + x4;
+                uint4 a1u, a2u;
+                { const uint2 l2 = *reinterpret_cast<const uint2*>(p1a), h2 = *reinterpret_cast<const uint2*>(p1a + 4); a1u = make_uint4(l2.x, l2.y, h2.x, h2.y); }
+                { const uint2 l2 = *reinterpret_cast<const uint2*>(p2a), h2 = *reinterpret_cast<const uint2*>(p2a + 4); a2u = make_uint4(l2.x, l2.y, h2.x, h2.y); }
+                const f16x8_c1 a1 = __builtin_bit_cast(f16x8_c1, a1u), a2 = __builtin_bit_cast(f16x8_c1, a2u);
+                f32x4 acc[4];
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    f32x4 c = {0.f, 0.f, 0.f, 0.f};
+                    if (DBG & 2) { acc[s] = c; continue; }
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, __builtin_bit_cast(f16x8_c1, bf[s * 4 + 1]), c, 0, 0, 0);   // low pieces first
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_f16(a2, __builtin_bit_cast(f16x8_c1, bf[s * 4 + 3]), c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, __builtin_bit_cast(f16x8_c1, bf[s * 4 + 0]), c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_f16(a2, __builtin_bit_cast(f16x8_c1, bf[s * 4 + 2]), c, 0, 0, 0);
+                    acc[s] = c;
+                }
+                // lane (co = r, q4): accumulator rows 4 q4 .. 4 q4 + 3 = windows 2 q4, 2 q4 + 1 x the two image rows: pooled pixels 2 (window) and
+                // 2 (window) + 1 of the V2 row, channel co.  pbufP [slot of the pooled pixel][16 channels]; slot = the pixel index with its two low
+                // bit pairs swapped (the four q4 groups of a store fill 256 contiguous bytes, P2's lanes read contiguously as well)
+#pragma unroll
+                for (int pos = 0; pos < 2; ++pos) {
+                    const int w = tile * 8 + 2 * q4 + pos;
+                    const float m0 = fmaxf(fmaxf(acc[0][2 * pos], acc[0][2 * pos + 1]), fmaxf(acc[1][2 * pos], acc[1][2 * pos + 1]));
+                    const float m1 = fmaxf(fmaxf(acc[2][2 * pos], acc[2][2 * pos + 1]), fmaxf(acc[3][2 * pos], acc[3][2 * pos + 1]));
+                    const float v0 = fmaxf(m0 * inv_scale1 + bz1, 0.f), v1 = fmaxf(m1 * inv_scale1 + bz1, 0.f);
+                    if (w < n_win) {
+                        ovf |= !(v0 < 4368.0f) | !(v1 < 4368.0f);
+                        const int px = 2 * w;                                    // = v * 40 + x: 20 windows of 2 pooled pixels per row
+                        float* o = pbp + ((px & ~15) | ((px & 3) << 2) | ((px >> 2) & 3)) * 16 + r;
+                        o[0] = v0;
+                        o[64] = v1;                                              // px + 1: bit 0 of the pixel is bit 2 of the slot
+                    }
+                }
+            }
+        };
+        // P2: (V2 row v, conv2 tile tx, channel quad): 8 pooled pixels x 4 channels -> B^T d -> pieces -> the ring slots (q % NR + 1) of the planes
+        auto p2 = [&](const int c0, const int nr) {
+            if (!(DBG & 4) && rt < nr * 40) {
+                const int v = rt / 40, rem = rt - v * 40, tx = rem >> 2, quad = rem & 3;
+                const int q = c0 + v;
+                const int slot = q % G::NR + 1, rot = w2b_rot(slot);
+                float4 d[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const int x = 4 * tx - 2 + k;
+                    d[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (x >= 0 && x < 40) {
+                        const int px = v * 40 + x;
+                        d[k] = *reinterpret_cast<const float4*>(pbp + ((px & ~15) | ((px & 3) << 2) | ((px >> 2) & 3)) * 16 + quad * 4);
+                    }
+                }
+                float ua[8], ub[8], uc[8], ud[8];
+                wino_bt(d[0].x, d[1].x, d[2].x, d[3].x, d[4].x, d[5].x, d[6].x, d[7].x, ua);
+                wino_bt(d[0].y, d[1].y, d[2].y, d[3].y, d[4].y, d[5].y, d[6].y, d[7].y, ub);
+                wino_bt(d[0].z, d[1].z, d[2].z, d[3].z, d[4].z, d[5].z, d[6].z, d[7].z, uc);
+                wino_bt(d[0].w, d[1].w, d[2].w, d[3].w, d[4].w, d[5].w, d[6].w, d[7].w, ud);
+                uint8_t* rowb = ldsb + slot * G::ROWL + (quad & 1) * 8;
+#pragma unroll
+                for (int p = 0; p < 8; ++p) {
+                    const int pi = p < 3 ? p : (p == 7 ? 3 : p + 1);             // stored order 0,1,2,7 | 3,4,5,6: group = pi >> 2, place pi & 3
+                    const int w = (pi & 3) * 20 + tx * 2 + (quad >> 1);
+                    uint8_t* dst = rowb + (pi >> 2) * G::BUF + ((w & ~15) | ((w + rot) & 15)) * 16;
+                    uint32_t l0, l1, m0, m1;
+                    split2h_pair(ua[p], ub[p], l0, m0);
+                    split2h_pair(uc[p], ud[p], l1, m1);
+                    *reinterpret_cast<uint2*>(dst) = make_uint2(l0, l1);
+                    *reinterpret_cast<uint2*>(dst + G::PLANE) = make_uint2(m0, m1);
+                }
+            }
+        };
+        // E2: the V3 transform of pass `ep`: (pooled row, conv3 tile, channel quad) items of pbufE -> B^T d -> pieces -> V3
+        auto e2 = [&](const int ep) {
+            if (!(DBG & 16) && rt < 240) {
+                const int rp = rt / 80, rem = rt - rp * 80, tx = rem >> 4, quad = rem & 15;
+                const int gp = ep * G::RPP + rp;                            // = q3: pooled row of the batch
+                if (gp < total_pairs) {
+                    float4 d[8];
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) {
+                        const int x = 4 * tx - 2 + k;
+                        const int xc = x < 0 ? 0 : (x > 19 ? 19 : x);
+                        d[k] = *reinterpret_cast<const float4*>(pbe + (rp * 20 + xc) * 64 + quad * 4);
+                    }
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) {
+                        const int x = 4 * tx - 2 + k;
+                        if (x < 0 || x >= 20) d[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    }
+                    float ua[8], ub[8], uc[8], ud[8];
+                    wino_bt(d[0].x, d[1].x, d[2].x, d[3].x, d[4].x, d[5].x, d[6].x, d[7].x, ua);
+                    wino_bt(d[0].y, d[1].y, d[2].y, d[3].y, d[4].y, d[5].y, d[6].y, d[7].y, ub);
+                    wino_bt(d[0].z, d[1].z, d[2].z, d[3].z, d[4].z, d[5].z, d[6].z, d[7].z, uc);
+                    wino_bt(d[0].w, d[1].w, d[2].w, d[3].w, d[4].w, d[5].w, d[6].w, d[7].w, ud);
+                    uint8_t* dst = v3 + (size_t)gp * V3_ROWB + (quad >> 2) * 2560 + tx * 32 + (quad & 3) * 8;
+#pragma unroll
+                    for (int p = 0; p < 8; ++p) {
+                        uint32_t l0, l1, m0, m1;
+                        split2h_pair(ua[p], ub[p], l0, m0);
+                        split2h_pair(uc[p], ud[p], l1, m1);
+                        *reinterpret_cast<uint2*>(dst + p * 160) = make_uint2(l0, l1);
+                        *reinterpret_cast<uint2*>(dst + 1280 + p * 160) = make_uint2(m0, m1);
+                    }
+                }
+            }
+        };
+        // prologue: every row of the first pass, chunk by chunk (three barriers each; the consumers wait at them)
+        for (int c0 = qmin; c0 < qmin + nrows; c0 += F::CHUNK) {
+            const int nr = qmin + nrows - c0 < F::CHUNK ? qmin + nrows - c0 : F::CHUNK;
+            uint4 px;
+            p0_load(c0, nr, px);
+            p0_store(nr, px);
+            RS_BAR();
+            p1(nr);
+            RS_BAR();
+            p2(c0, nr);
+            RS_BAR();
+        }
+        int res_hi = qmin + nrows;
+        int prev = -1;
+        for (;;) {
+            int next_pass, lo, hi;
+            bool have_next;
+            RS_NEXT(pass, res_hi, next_pass, have_next, lo, hi);
+            // S1 (beside taps 0-19): the crop rows of the first chunk are requested, the V3 transform of the previous pass runs under their flight
+            const int nr0 = hi - lo < F::CHUNK ? hi - lo : F::CHUNK;
+            uint4 px;
+            if (!(DBG & 8)) p0_load(lo, nr0, px);
+            if (prev >= 0) e2(prev);
+            if (!(DBG & 8)) p0_store(nr0, px);
+            RS_BAR();
+            // S2 (beside taps 20-39): conv1
+            if (!(DBG & 8)) p1(nr0);
+            RS_BAR();
+            // S3 (beside the output transform; nobody reads the ring): the rows go to their slots
+            if (!(DBG & 8)) p2(lo, nr0);
+            RS_BAR();
+            // a ticket's first pass needs 10 rows: the second chunk in three more stages (the consumers wait)
+            for (int c0 = lo + F::CHUNK; c0 < hi; c0 += F::CHUNK) {
+                const int nr = hi - c0 < F::CHUNK ? hi - c0 : F::CHUNK;
+                if (!(DBG & 8)) { p0_load(c0, nr, px); p0_store(nr, px); }
+                RS_BAR();
+                if (!(DBG & 8)) p1(nr);
+                RS_BAR();
+                if (!(DBG & 8)) p2(c0, nr);
+                RS_BAR();
+            }
+            prev = pass;
+            if (!have_next) break;
+            res_hi = hi;
+            pass = next_pass;
+        }
+        e2(prev);                                                         // the last pass's activations (behind its third barrier)
+#undef RS_ITEM
+    } else {
+        // ------------------------------------------------------------------------------------------------------------------------
+        // CONSUMER: conv2's tap loop and output transform
+        // ------------------------------------------------------------------------------------------------------------------------
+        const int j = lane & 31, h = lane >> 5;
+        const int n = rw & 1, mg = rw >> 1;
+        const __amdgpu_buffer_rsrc_t wrs = make_rsrc(wp, (uint32_t)(40 * G::BV * 16));
+        const int boff = (h * CO + n * 32 + j) * 16;
+        const int co = n * 32 + j;
+        const float bz = bias[co];
+        for (int c0 = qmin; c0 < qmin + nrows; c0 += F::CHUNK) { RS_BAR(); RS_BAR(); RS_BAR(); }      // the producers' prologue
+        int res_hi = qmin + nrows;
+#define W2_POS(tau_) (((tau_) / 20) == 0 ? ((tau_) % 4 == 3 ? 7 : (tau_) % 4) : 3 + (tau_) % 4)
+#define W2_BOFF(tau_) (((((tau_) % 20) / 4) * 8 + W2_POS(tau_)) * G::BV * 16)
+        for (;;) {
+            int next_pass, lo, hi;
+            bool have_next;
+            RS_NEXT(pass, res_hi, next_pass, have_next, lo, hi);
+            const bool draw = pass % PK == PK - 1;
+            uint32_t ticket = 0;
+            // the ticket after the next one (raw instruction: atomicAdd() waits for the returned value on the spot); stored behind the second barrier
+            if (draw && tid == 0) asm volatile("global_atomic_add %0, %1, %2, off sc0" : "=v"(ticket) : "v"(pass_ctr), "v"(1u) : "memory");
+            uint4 bq[8][2];
+#pragma unroll
+            for (int t = 0; t < BD; ++t) { bq[t][0] = buf_load16(wrs, boff, W2_BOFF(t)); bq[t][1] = (DBG & 64) ? bq[t][0] : buf_load16(wrs, boff, W2_BOFF(t) + 2 * CO * 16); }
+            int aoff[5][4];
+            {
+                int s = mg * 32 + j;
+                s = s < G::RPP * G::TPP ? s : G::RPP * G::TPP - 1;
+                const int rp = s / G::TPP, r2 = s - rp * G::TPP;
+                int gp = pass * G::RPP + rp;
+                gp = gp < total_pairs ? gp : total_pairs - 1;
+                const int tx = r2 >> 1, qo = 2 * gp + (r2 & 1), y = qo % S;
+#pragma unroll
+                for (int ky = 0; ky < 5; ++ky) {
+                    const int iy = y + ky - 2;
+                    const int slot = (iy >= 0 && iy < S) ? (qo + ky - 2) % G::NR + 1 : 0;
+                    const int rot = w2b_rot(slot);
+#pragma unroll
+                    for (int pg = 0; pg < 4; ++pg) {
+                        const int w = pg * 20 + tx * 2 + h;
+                        aoff[ky][pg] = slot * G::ROWL + ((w & ~15) | ((w + rot) & 15)) * 16;
+                    }
+                }
+            }
+            f32x16 acc[8];
+            const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            __builtin_amdgcn_s_setprio(0);                                // the producer wave on this SIMD outranks the tap loop (cnn_fused12.h)
+            uint4 af[2][2];
+#define RS_AREAD(dst_, tau_)                                                                                                     \
+            do {                                                                                                                 \
+                const uint8_t* an_ = ldsb + ((tau_) / 20) * G::BUF + aoff[((tau_) % 20) / 4][(tau_) % 4];                        \
+                dst_[0] = *reinterpret_cast<const uint4*>(an_);                                                                  \
+                dst_[1] = *reinterpret_cast<const uint4*>(an_ + G::PLANE);                                                       \
+            } while (0)
+#define RS_TAP(tau)                                                                                                              \
+            do {                                                                                                                 \
+                const int tl = (tau) % 20;                                                                                       \
+                if ((tau) + 1 < 40) RS_AREAD(af[((tau) + 1) % 2], (tau) + 1);                                                    \
+                if ((tau) + BD < 40) {                                                                                           \
+                    const int wt = W2_BOFF((tau) + BD);                                                                          \
+                    bq[((tau) + BD) % 8][0] = buf_load16(wrs, boff, wt);                                                         \
+                    bq[((tau) + BD) % 8][1] = (DBG & 64) ? bq[((tau) + BD) % 8][0] : buf_load16(wrs, boff, wt + 2 * CO * 16);    \
+                }                                                                                                                \
+                const int p = W2_POS(tau);                                                                                       \
+                const f16x8 b1 = __builtin_bit_cast(f16x8, bq[(tau) % 8][0]), b2 = __builtin_bit_cast(f16x8, bq[(tau) % 8][1]); \
+                const f16x8 a1 = __builtin_bit_cast(f16x8, af[(tau) % 2][0]), a2 = __builtin_bit_cast(f16x8, af[(tau) % 2][1]); \
+                acc[p] = mfma16(a2, b1, tl < 4 ? zero16 : acc[p]);        /* kernel row 0 starts the accumulator */               \
+                acc[p] = mfma16(a1, b2, acc[p]);                                                                                 \
+                acc[p] = mfma16(a1, b1, acc[p]);                                                                                 \
+                __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);                                                               \
+                __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);                                                               \
+                _Pragma("unroll") for (int g = 0; g < 3; ++g) {                                                                  \
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                                           \
+                    __builtin_amdgcn_sched_group_barrier(0x006, 4, 0);                                                           \
+                }                                                                                                                \
+                __builtin_amdgcn_sched_barrier(0);                                                                               \
+            } while (0)
+            RS_AREAD(af[0], 0);
+#pragma clang loop unroll(full)
+            for (int tau = 0; tau < ((DBG & 32) ? 0 : 20); ++tau) RS_TAP(tau);
+            RS_BAR();                                                     // S1 | S2
+#pragma clang loop unroll(full)
+            for (int tau = 20; tau < ((DBG & 32) ? 0 : 40); ++tau) RS_TAP(tau);
+            if (DBG & 32) { _Pragma("unroll") for (int p = 0; p < 8; ++p) acc[p] = zero16; }
+            if (draw) {
+                asm volatile("s_waitcnt vmcnt(0)" : "+v"(ticket) :: "memory");
+                if (tid == 0) *s_next = ((int)ticket + (int)gridDim.x) * PK;       // read at the start of a later round
+            }
+            RS_BAR();                                                     // S2 | S3: the producers have read pbufE (in S1), it may be written
+            __builtin_amdgcn_s_setprio(2);
+            // output transform: Y = A^T M, pool, bias, ReLU -> the pass's 3 x 20 x 64 activations as fp32 in pbufE
+            if (!(DBG & 16)) {
+                f32x16 y0, y1, y2, y3;
+                {
+                    const f32x16 e1 = acc[1] + acc[2], o1 = acc[1] - acc[2];
+                    y0 = acc[0] + e1; y1 = o1; y2 = e1; y3 = o1 + acc[7];
+                }
+                {
+                    const f32x16 e2 = acc[3] + acc[4], o2 = acc[3] - acc[4];
+                    y0 += e2; y1 += 2.f * o2; y2 += 4.f * e2; y3 += 8.f * o2;
+                }
+                {
+                    const f32x16 e3 = acc[5] + acc[6], o3 = acc[5] - acc[6];
+                    y0 += e3; y1 += 0.5f * o3; y2 += 0.25f * e3; y3 += 0.125f * o3;
+                }
+#pragma unroll
+                for (int rr = 0; rr < 8; ++rr) {
+                    const int r = 2 * rr;
+                    const int s = mg * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;      // even: rows y, y+1 of one tile column
+                    const float v0 = fmaxf(fmaxf(y0[r], y1[r]), fmaxf(y0[r + 1], y1[r + 1]));
+                    const float v1 = fmaxf(fmaxf(y2[r], y3[r]), fmaxf(y2[r + 1], y3[r + 1]));
+                    if (s < G::RPP * G::TPP) {
+                        const int rp = s / G::TPP, tx = (s - rp * G::TPP) >> 1;
+                        const float a0 = fmaxf(v0 * out_scale + bz, 0.f), a1 = fmaxf(v1 * out_scale + bz, 0.f);
+                        ovf |= !(a0 < 4368.0f) | !(a1 < 4368.0f);
+                        float* o = pbe + (rp * 20 + 2 * tx) * 64 + co;
+                        o[0] = a0;
+                        o[64] = a1;
+                    }
+                }
+            }
+            RS_BAR();                                                     // S3 | the next round
+            for (int c0 = lo + F::CHUNK; c0 < hi; c0 += F::CHUNK) { RS_BAR(); RS_BAR(); RS_BAR(); }    // the second chunk of a ticket's first pass
+            if (!have_next) break;
+            res_hi = hi;
+            pass = next_pass;
+        }
+#undef RS_TAP
+#undef RS_AREAD
+#undef W2_POS
+#undef W2_BOFF
+    }
+#undef RS_NEXT
+#undef RS_ROWS
+#undef RS_BAR
+    if (__any(ovf) && lane == 0) atomicOr(overflow, 1u);
+}

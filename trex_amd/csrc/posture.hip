@@ -44,6 +44,26 @@ __device__ __forceinline__ float wsum(float v) {
     return v;
 }
 
+// sin / cos of the EFT phases: the same operations in the same order as oracle/trex_posture.c's det_sincosf (Cody-Waite reduction by pi/2 in three
+// pieces, degree-7 / degree-8 polynomials on [-pi/4, pi/4]; this file is compiled with -ffp-contract=off): bit-identical to the CPU restatement,
+// which the library sincosf (and glibc's on the other side) was not -- the tail / head choice flipped at near-ties of the curvature peaks.
+__device__ __forceinline__ void det_sincosf(const float x, float& sn, float& cs) {
+    const float kf = floorf(x * 0.636619772f + 0.5f);
+    const int k = (int)kf;
+    float r = x - kf * 1.5703125f;
+    r = r - kf * 4.837512969970703125e-4f;
+    r = r - kf * 7.54978995489188216e-8f;
+    const float z = r * r;
+    float ps = -1.9515295891e-4f; ps = ps * z + 8.3321608736e-3f; ps = ps * z - 1.6666654611e-1f;
+    const float s0 = r + r * z * ps;
+    float pc = 2.443315711809948e-5f; pc = pc * z - 1.388731625493765e-3f; pc = pc * z + 4.166664568298827e-2f;
+    const float c0 = (1.0f - 0.5f * z) + z * z * pc;
+    const bool swap = k & 1;
+    const float a = swap ? c0 : s0, b = swap ? s0 : c0;
+    sn = (k & 2) ? -a : a;
+    cs = ((k + 1) & 2) ? -b : b;
+}
+
 __device__ __forceinline__ bool in_blob(const uint32_t* s_runs, const int* s_row, int y0, int y1, int x, int y) {
     if (y < y0 || y > y1) return false;
     for (int i = s_row[y - y0]; i < s_row[y - y0 + 1]; ++i) {
@@ -332,10 +352,12 @@ __global__ __launch_bounds__(256) void k_posture(const PostureCfg P, const trexh
     }
     // ---- EFT (order) -> inverse at n uniform parameters around the centre ----
     if (P.approximate > 0) {
-        float cxp = 0.f, cyp = 0.f;
-        for (int i = lane; i < n; i += 64) { cxp += pts[i].x; cyp += pts[i].y; }
-        const float cx = wsum(cxp) / (float)n, cy = wsum(cyp) / (float)n;
-        // cumulative arc length (wave scan over chunks of 64 segments)
+        // the centre: Outline.cpp:502-505 adds the points IN ORDER, and a float sum is its order -- every lane walks the same sequence (LDS broadcasts)
+        float cx = 0.f, cy = 0.f;
+        for (int i = 0; i < n; ++i) { const float2 a = pts[i]; cx += a.x; cy += a.y; }
+        cx /= (float)n; cy /= (float)n;
+        // cumulative arc length (wave scan over chunks of 64 segments + a running carry; oracle/trex_posture.c restates exactly this order):
+        // s_t[i] = arc length at the END of segment i
         float run = 0.f;
         for (int i0 = 0; i0 < n; i0 += 64) {
             const int i = i0 + lane;
@@ -344,30 +366,30 @@ __global__ __launch_bounds__(256) void k_posture(const PostureCfg P, const trexh
             float incl = dt;
 #pragma unroll
             for (int d = 1; d < 64; d <<= 1) { const float t = __shfl_up(incl, d); if (lane >= d) incl += t; }
-            if (i < n) s_t[i] = run + incl - dt;                 // t at the START of segment i
+            if (i < n) s_t[i] = run + incl;
             run += __shfl(incl, 63);
         }
-        const float T = run;
         __builtin_amdgcn_wave_barrier();
+        const float T = s_t[n - 1];
         const float PI = 3.14159265358979323846f;
         float ca[4][4];                                           // [harmonic 1..3][a b c d]
         const int order = min(P.approximate, 3);
         for (int h = 1; h <= order; ++h) {
-            // cos / sin of the phase at every point once (segment i ends where segment i + 1 starts: same expression, same value),
-            // kept in the spare point buffer
-            // (the closing phase 2 pi h T / T rides along as point n: one lane's work instead of every lane's; it goes to the idle curvature array)
+            // cos / sin of the phase at every segment boundary once (boundary i = the start of segment i = the end of segment i - 1; boundary n closes
+            // the curve: it goes to the idle curvature array), kept in the spare point buffer
             for (int i = lane; i <= n; i += 64) {
                 float sn, cs;
-                sincosf(2.0f * PI * (float)h * (i < n ? s_t[i] : T) / T, &sn, &cs);
+                det_sincosf(2.0f * PI * (float)h * (i > 0 ? s_t[i - 1] : 0.f) / T, sn, cs);
                 if (i < n) other[i] = make_float2(cs, sn);
                 else { s_curv[0] = cs; s_curv[1] = sn; }
             }
             __builtin_amdgcn_wave_barrier();
             const float csE = s_curv[0], snE = s_curv[1];
+            // term i goes to partial sum i % 64 in order of i, the partials are combined by the xor butterfly (wsum): the oracle's order
             float sa = 0.f, sb = 0.f, sc = 0.f, sd = 0.f;
             for (int i = lane; i < n; i += 64) {
                 const float2 a = pts[i], q = pts[i + 1 == n ? 0 : i + 1];
-                const float t0 = s_t[i], t1 = (i + 1 < n) ? s_t[i + 1] : T;
+                const float t0 = i > 0 ? s_t[i - 1] : 0.f, t1 = s_t[i];
                 const float dt = t1 - t0;
                 if (dt <= 0.f) continue;
                 const float2 c0 = other[i], c1 = (i + 1 < n) ? other[i + 1] : make_float2(csE, snE);
@@ -384,7 +406,7 @@ __global__ __launch_bounds__(256) void k_posture(const PostureCfg P, const trexh
             float x = cx, y = cy;
             for (int h = 1; h <= order; ++h) {
                 float sn, cs;
-                sincosf(2.0f * PI * (float)h * tt, &sn, &cs);
+                det_sincosf(2.0f * PI * (float)h * tt, sn, cs);
                 x += ca[h][0] * cs + ca[h][1] * sn; y += ca[h][2] * cs + ca[h][3] * sn;
             }
             other[i] = make_float2(x, y);
