@@ -1713,7 +1713,10 @@ static int net_forward_launch(trexhip_ctx* ctx, const uint8_t* d_crops, int n, f
 #define F12R(D_) TH_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv12_rs<D_>), hipFuncAttributeMaxDynamicSharedMemorySize, W12RGeom::LDS_BYTES))
         F12R(0);
 #ifdef TREXHIP_DEV_KNOBS
-        F12R(8); F12R(16); F12R(32); F12R(40); F12R(64);
+        F12R(8); F12R(16); F12R(32); F12R(40); F12R(64); F12R(128);
+#define F12RV(...) TH_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv12_rs<__VA_ARGS__>), hipFuncAttributeMaxDynamicSharedMemorySize, W12RGeom::LDS_BYTES))
+        F12RV(0, 3, 20, 0x020); F12RV(0, 3, 20, 0x000); F12RV(0, 3, 20, 0x010); F12RV(0, 3, 20, 0x212); F12RV(0, 3, 16, 0x202); F12RV(0, 3, 24, 0x202); F12RV(0, 2, 20, 0x202); F12RV(0, 5, 20, 0x202);
+#undef F12RV
 #endif
 #undef F12R
 #ifdef TREXHIP_DEV_KNOBS
@@ -1779,9 +1782,10 @@ static int net_forward_launch(trexhip_ctx* ctx, const uint8_t* d_crops, int n, f
                                      : n * (ConvGeomB<CI_, CO_, S_, ROWS_, SplitK<KIND_>::NP, CIC_>::BPC)),                                          \
                        dim3(512), (ConvGeomB<CI_, CO_, S_, ROWS_, SplitK<KIND_>::NP, CIC_>::LDS_BYTES), s, in_, w_, b_, out_, sc_, net->d_ovf, guard_, \
                        n * (ConvGeomB<CI_, CO_, S_, ROWS_, SplitK<KIND_>::NP, CIC_>::BPC))
-    if (fused12 && !(ctx->tune_conv_geom & (1 << 29))) {
-        // role-split form (cnn_fused12rs.h): one workgroup of 8 waves per CU, consumer waves (tap loop, output transform) beside producer waves
-        // (V3 transform of the previous pass, V2 rows of the next).  TREXHIP_CONV_GEOM bit 29: the two-workgroups-per-CU kernel of round 4
+    if (fused12 && (ctx->tune_conv_geom & (1 << 29))) {
+        // TREXHIP_CONV_GEOM bit 29: the role-split form (cnn_fused12rs.h): one workgroup of 8 waves per CU, consumer waves (tap loop, output
+        // transform) beside producer waves (V3 transform of the previous pass, V2 rows of the next).  Bit-identical, the same speed as the default
+        // (3.90-3.98 against 3.88-3.91 ms per 25600 crops, profiles/r05_rs_ablation.txt): kept as the base for the next step
         const int n_pass = (n * 20 + W2bGeom::RPP - 1) / W2bGeom::RPP;
         const int wgs = ctx->n_cus;
         static const int pk_env = std::getenv("TREXHIP_F12_PK") ? std::atoi(std::getenv("TREXHIP_F12_PK")) : 0;
@@ -1791,7 +1795,13 @@ static int net_forward_launch(trexhip_ctx* ctx, const uint8_t* d_crops, int n, f
                            net->w2w, net->b2, net->v3, net->inv2w, net->d_ovf, n, net->d_ovf + 2, pk)
 #ifdef TREXHIP_DEV_KNOBS
         static const int f12r_dbg = std::getenv("TREXHIP_F12_DBG") ? std::atoi(std::getenv("TREXHIP_F12_DBG")) : 0;
-        switch (f12r_dbg) { case 8: F12RK(8); break; case 16: F12RK(16); break; case 32: F12RK(32); break; case 40: F12RK(40); break; case 64: F12RK(64); break; default: F12RK(0); }
+        switch (f12r_dbg) { case 8: F12RK(8); break; case 16: F12RK(16); break; case 32: F12RK(32); break; case 40: F12RK(40); break; case 64: F12RK(64); break;
+            case 128: hipLaunchKernelGGL((k_conv12_rs<128>), dim3(want < wgs ? want : wgs), dim3(512), W12RGeom::LDS_BYTES, s, d_crops, net->w1h, net->b1, net->inv1h, net->w2w, net->b2, net->v3, net->inv2w, net->d_ovf, n, net->d_ovf + 2, pk, reinterpret_cast<unsigned long long*>(ctx->d_cnt_px)); break;
+#define F12RKV(...) hipLaunchKernelGGL((k_conv12_rs<__VA_ARGS__>), dim3(want < wgs ? want : wgs), dim3(512), W12RGeom::LDS_BYTES, s, d_crops, net->w1h, net->b1, net->inv1h, net->w2w, net->b2, net->v3, net->inv2w, net->d_ovf, n, net->d_ovf + 2, pk)
+            case 200: F12RKV(0, 3, 20, 0x020); break; case 201: F12RKV(0, 3, 20, 0x000); break; case 202: F12RKV(0, 3, 20, 0x010); break; case 203: F12RKV(0, 3, 20, 0x212); break;
+            case 204: F12RKV(0, 3, 16, 0x202); break; case 205: F12RKV(0, 3, 24, 0x202); break; case 206: F12RKV(0, 2, 20, 0x202); break; case 207: F12RKV(0, 5, 20, 0x202); break;
+#undef F12RKV
+            default: F12RK(0); }
 #else
         F12RK(0);
 #endif

@@ -18,6 +18,12 @@
 // LDS: the four operand planes (ring of NR = 10 row slots + the zero row, as before: P2 writes the ring in the stage where no tap reads it),
 // pbufE (consumer -> producer), pbufP (conv1's pooled activations of a chunk), the padded fp16 crop rows of a chunk: 93 KB.
 
+// max of three / two floats as ONE instruction each (the compiler's fmaxf puts a canonicalising v_max v, v, v in front of operands it does not
+// know to be canonical); exact, so results do not change.  ONLY for operands written by ordinary VALU instructions: an MFMA result read by
+// inline asm is not padded by the hazard recognizer (MI355X guide 5.7) -- round 5 learnt that the hard way
+__device__ __forceinline__ float rs_max3(const float a, const float b, const float c) { float r; asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
+__device__ __forceinline__ float rs_max(const float a, const float b) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+
 struct W12RGeom {
     using G = W2bGeom;
     static constexpr int CHUNK = 6;
@@ -30,12 +36,13 @@ struct W12RGeom {
     static_assert(LDS_BYTES <= 160 * 1024 && CTL_OFF % 16 == 0, "one workgroup per CU");
 };
 
-template <int DBG = 0, int BD = 3>
+template <int DBG = 0, int BD = 3, int TSPLIT = 20, int PRIO = 0x202>      // TSPLIT: taps in front of the first barrier of a round; PRIO: s_setprio of (producer, tap loop, output transform) as hex digits
 __global__ __launch_bounds__(512) void k_conv12_rs(const uint8_t* __restrict__ crops /*[N][80][80]*/, const uint4* __restrict__ w1tab /*[16][64]*/,
                                                    const float* __restrict__ bias1, const float inv_scale1,
                                                    const uint4* __restrict__ wp /*[5][8][2][2][64] x 16 B*/, const float* __restrict__ bias,
                                                    uint8_t* __restrict__ v3, const float out_scale, uint32_t* __restrict__ overflow,
-                                                   const int n_crops, uint32_t* __restrict__ pass_ctr, const int PK /* consecutive passes per ticket */) {
+                                                   const int n_crops, uint32_t* __restrict__ pass_ctr, const int PK /* consecutive passes per ticket */,
+                                                   unsigned long long* __restrict__ dbg_stamps = nullptr /* DBG & 128 (dev): cycles per stage of waves 0 and 4 of workgroup 0 */) {
     using G = W2bGeom;
     using F = W12RGeom;
     constexpr int CO = 64, S = 40;
@@ -58,7 +65,11 @@ __global__ __launch_bounds__(512) void k_conv12_rs(const uint8_t* __restrict__ c
     float* pbp = reinterpret_cast<float*>(ldsb + F::PBP_OFF);
     for (int i = tid; i < F::IMG_BYTES / 16; i += 512) reinterpret_cast<uint4*>(img)[i] = make_uint4(0, 0, 0, 0);   // the x padding stays zero
     if (tid == 0) *s_next = ((int)atomicAdd(pass_ctr, 1u) + (int)gridDim.x) * PK;
-    bool ovf = false;
+    float ovfm = 0.f;                                                    // the largest activation seen (all are >= 0 behind their ReLU): the fp16 range guard
+    // DBG & 128 (dev builds): lane 0 of waves 0 (consumer) and 4 (producer) of workgroup 0 sum the cycles between the stage boundaries
+    unsigned long long st_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_last = 0;
+    const bool st_on = (DBG & 128) && dbg_stamps && blockIdx.x == 0 && (tid == 0 || tid == 256);
+#define RS_STAMP(i_) do { if ((DBG & 128) && st_on) { const unsigned long long t_ = __builtin_readcyclecounter(); st_sum[i_] += t_ - st_last; st_last = t_; } } while (0)
     // every wave: LDS writes done, then the workgroup barrier.  Both roles execute the SAME number of these per round.
 #define RS_BAR() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 #define RS_ROWS(pass_, qmin_, nrows_)                                                                                            \
@@ -93,7 +104,7 @@ __global__ __launch_bounds__(512) void k_conv12_rs(const uint8_t* __restrict__ c
         // ------------------------------------------------------------------------------------------------------------------------
         // PRODUCER: V3 transform of the previous pass, V2 rows of the next one
         // ------------------------------------------------------------------------------------------------------------------------
-        __builtin_amdgcn_s_setprio(2);
+        __builtin_amdgcn_s_setprio((PRIO >> 8) & 3);
         // the crop-row unit (16 pixels) item `it` of a chunk that starts at V2 row c0 stands for: item = (V2 row v, crop row k of its six, unit u)
 #define RS_ITEM(it_, c0_)                                                                                                        \
                 const int vk = (it_) / 5, u = (it_) - vk * 5;                                                                    \
@@ -139,43 +150,59 @@ __global__ __launch_bounds__(512) void k_conv12_rs(const uint8_t* __restrict__ c
         auto p1 = [&](const int nr) {
             const int r = lane & 15, q4 = lane >> 4;
             const int n_win = nr * 20, n_tiles = (n_win + 7) >> 3;
-            for (int tile = rw; tile < n_tiles; tile += 4) {
-                int wdx = tile * 8 + (r >> 1);
-                wdx = wdx < n_win ? wdx : n_win - 1;
-                const int v = wdx / 20, x4 = (wdx - v * 20) * 4;
-                const int row = v * 6 + (r & 1);
-                const _Float16* p1a = img + (row + q4) * F::IMG_PITCH + x4;
-                const _Float16* p2a = img + (row + 4) * F::IMG_PITCH + x4;
-                uint4 a1u, a2u;
-                { const uint2 l2 = *reinterpret_cast<const uint2*>(p1a), h2 = *reinterpret_cast<const uint2*>(p1a + 4); a1u = make_uint4(l2.x, l2.y, h2.x, h2.y); }
-                { const uint2 l2 = *reinterpret_cast<const uint2*>(p2a), h2 = *reinterpret_cast<const uint2*>(p2a + 4); a2u = make_uint4(l2.x, l2.y, h2.x, h2.y); }
-                const f16x8_c1 a1 = __builtin_bit_cast(f16x8_c1, a1u), a2 = __builtin_bit_cast(f16x8_c1, a2u);
-                f32x4 acc[4];
+            // two tiles per step (t0 and t0 + 4): their eight product chains keep the matrix pipe busy while the LDS reads of the step land
+            for (int t0 = rw; t0 < n_tiles; t0 += 8) {
+                f16x8_c1 a1[2], a2[2];
 #pragma unroll
-                for (int s = 0; s < 4; ++s) {
-                    f32x4 c = {0.f, 0.f, 0.f, 0.f};
-                    if (DBG & 2) { acc[s] = c; continue; }
-                    c = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, __builtin_bit_cast(f16x8_c1, bf[s * 4 + 1]), c, 0, 0, 0);   // low pieces first
-                    c = __builtin_amdgcn_mfma_f32_16x16x32_f16(a2, __builtin_bit_cast(f16x8_c1, bf[s * 4 + 3]), c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, __builtin_bit_cast(f16x8_c1, bf[s * 4 + 0]), c, 0, 0, 0);
-                    c = __builtin_amdgcn_mfma_f32_16x16x32_f16(a2, __builtin_bit_cast(f16x8_c1, bf[s * 4 + 2]), c, 0, 0, 0);
-                    acc[s] = c;
+                for (int u = 0; u < 2; ++u) {
+                    const int tile = t0 + 4 * u < n_tiles ? t0 + 4 * u : t0;
+                    int wdx = tile * 8 + (r >> 1);
+                    wdx = wdx < n_win ? wdx : n_win - 1;
+                    const int v = wdx / 20, x4 = (wdx - v * 20) * 4;
+                    const int row = v * 6 + (r & 1);
+                    const _Float16* p1a = img + (row + q4) * F::IMG_PITCH + x4;
+                    const _Float16* p2a = img + (row + 4) * F::IMG_PITCH + x4;
+                    const uint2 l1 = *reinterpret_cast<const uint2*>(p1a), h1 = *reinterpret_cast<const uint2*>(p1a + 4);
+                    const uint2 l2 = *reinterpret_cast<const uint2*>(p2a), h2 = *reinterpret_cast<const uint2*>(p2a + 4);
+                    a1[u] = __builtin_bit_cast(f16x8_c1, make_uint4(l1.x, l1.y, h1.x, h1.y));
+                    a2[u] = __builtin_bit_cast(f16x8_c1, make_uint4(l2.x, l2.y, h2.x, h2.y));
+                }
+                f32x4 acc[2][4];
+#pragma unroll
+                for (int u = 0; u < 2; ++u)
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) acc[u][s] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (!(DBG & 2)) {
+                    // per chain the order of k_conv1_wpre: low pieces first (fragments 1, 3), then the high ones (0, 2)
+#pragma unroll
+                    for (int m = 0; m < 4; ++m)
+#pragma unroll
+                        for (int u = 0; u < 2; ++u)
+#pragma unroll
+                            for (int s = 0; s < 4; ++s)
+                                acc[u][s] = __builtin_amdgcn_mfma_f32_16x16x32_f16((m & 1) ? a2[u] : a1[u], __builtin_bit_cast(f16x8_c1, bf[s * 4 + (m == 0 ? 1 : m == 1 ? 3 : m == 2 ? 0 : 2)]), acc[u][s], 0, 0, 0);
                 }
                 // lane (co = r, q4): accumulator rows 4 q4 .. 4 q4 + 3 = windows 2 q4, 2 q4 + 1 x the two image rows: pooled pixels 2 (window) and
                 // 2 (window) + 1 of the V2 row, channel co.  pbufP [slot of the pooled pixel][16 channels]; slot = the pixel index with its two low
                 // bit pairs swapped (the four q4 groups of a store fill 256 contiguous bytes, P2's lanes read contiguously as well)
 #pragma unroll
-                for (int pos = 0; pos < 2; ++pos) {
-                    const int w = tile * 8 + 2 * q4 + pos;
-                    const float m0 = fmaxf(fmaxf(acc[0][2 * pos], acc[0][2 * pos + 1]), fmaxf(acc[1][2 * pos], acc[1][2 * pos + 1]));
-                    const float m1 = fmaxf(fmaxf(acc[2][2 * pos], acc[2][2 * pos + 1]), fmaxf(acc[3][2 * pos], acc[3][2 * pos + 1]));
-                    const float v0 = fmaxf(m0 * inv_scale1 + bz1, 0.f), v1 = fmaxf(m1 * inv_scale1 + bz1, 0.f);
-                    if (w < n_win) {
-                        ovf |= !(v0 < 4368.0f) | !(v1 < 4368.0f);
-                        const int px = 2 * w;                                    // = v * 40 + x: 20 windows of 2 pooled pixels per row
-                        float* o = pbp + ((px & ~15) | ((px & 3) << 2) | ((px >> 2) & 3)) * 16 + r;
-                        o[0] = v0;
-                        o[64] = v1;                                              // px + 1: bit 0 of the pixel is bit 2 of the slot
+                for (int u = 0; u < 2; ++u) {
+                    const int tile = t0 + 4 * u;
+#pragma unroll
+                    for (int pos = 0; pos < 2; ++pos) {
+                        const int w = tile * 8 + 2 * q4 + pos;
+                        // (fmaxf, not the asm helpers: these operands come straight out of MFMAs, and the hazard recognizer pads MFMA -> VALU reads only
+                        // for instructions it can see -- with v_max3 in inline asm the reads raced the matrix pipe and the range guard fired at random)
+                        const float m0 = fmaxf(fmaxf(acc[u][0][2 * pos], acc[u][0][2 * pos + 1]), fmaxf(acc[u][1][2 * pos], acc[u][1][2 * pos + 1]));
+                        const float m1 = fmaxf(fmaxf(acc[u][2][2 * pos], acc[u][2][2 * pos + 1]), fmaxf(acc[u][3][2 * pos], acc[u][3][2 * pos + 1]));
+                        const float v0 = fmaxf(m0 * inv_scale1 + bz1, 0.f), v1 = fmaxf(m1 * inv_scale1 + bz1, 0.f);
+                        if (tile < n_tiles && w < n_win) {
+                            ovfm = rs_max3(ovfm, v0, v1);
+                            const int px = 2 * w;                                // = v * 40 + x: 20 windows of 2 pooled pixels per row
+                            float* o = pbp + ((px & ~15) | ((px & 3) << 2) | ((px >> 2) & 3)) * 16 + r;
+                            o[0] = v0;
+                            o[64] = v1;                                          // px + 1: bit 0 of the pixel is bit 2 of the slot
+                        }
                     }
                 }
             }
@@ -264,6 +291,7 @@ __global__ __launch_bounds__(512) void k_conv12_rs(const uint8_t* __restrict__ c
         }
         int res_hi = qmin + nrows;
         int prev = -1;
+        if ((DBG & 128) && st_on) st_last = __builtin_readcyclecounter();
         for (;;) {
             int next_pass, lo, hi;
             bool have_next;
@@ -274,13 +302,19 @@ __global__ __launch_bounds__(512) void k_conv12_rs(const uint8_t* __restrict__ c
             if (!(DBG & 8)) p0_load(lo, nr0, px);
             if (prev >= 0) e2(prev);
             if (!(DBG & 8)) p0_store(nr0, px);
+            RS_STAMP(0);
             RS_BAR();
+            RS_STAMP(1);
             // S2 (beside taps 20-39): conv1
             if (!(DBG & 8)) p1(nr0);
+            RS_STAMP(2);
             RS_BAR();
+            RS_STAMP(3);
             // S3 (beside the output transform; nobody reads the ring): the rows go to their slots
             if (!(DBG & 8)) p2(lo, nr0);
+            RS_STAMP(4);
             RS_BAR();
+            RS_STAMP(5);
             // a ticket's first pass needs 10 rows: the second chunk in three more stages (the consumers wait)
             for (int c0 = lo + F::CHUNK; c0 < hi; c0 += F::CHUNK) {
                 const int nr = hi - c0 < F::CHUNK ? hi - c0 : F::CHUNK;
@@ -291,6 +325,8 @@ __global__ __launch_bounds__(512) void k_conv12_rs(const uint8_t* __restrict__ c
                 if (!(DBG & 8)) p2(c0, nr);
                 RS_BAR();
             }
+            RS_STAMP(6);
+            if ((DBG & 128) && st_on) st_sum[7] += 1;
             prev = pass;
             if (!have_next) break;
             res_hi = hi;
@@ -312,6 +348,33 @@ __global__ __launch_bounds__(512) void k_conv12_rs(const uint8_t* __restrict__ c
         int res_hi = qmin + nrows;
 #define W2_POS(tau_) (((tau_) / 20) == 0 ? ((tau_) % 4 == 3 ? 7 : (tau_) % 4) : 3 + (tau_) % 4)
 #define W2_BOFF(tau_) (((((tau_) % 20) / 4) * 8 + W2_POS(tau_)) * G::BV * 16)
+        // the weight fragments of taps 0 .. BD - 1 are the same for every pass: the last taps of a pass fetch them for the next one
+        uint4 bq[8][2];
+#pragma unroll
+        for (int t = 0; t < BD; ++t) { bq[t][0] = buf_load16(wrs, boff, W2_BOFF(t)); bq[t][1] = (DBG & 64) ? bq[t][0] : buf_load16(wrs, boff, W2_BOFF(t) + 2 * CO * 16); }
+        // A-operand byte offsets of this lane's tile for pass `ps_`: per kernel row the row slot (out-of-crop rows -> the zero row), per position of a
+        // group the rotated unit.  Computed for the NEXT pass behind the output transform, off the path to the first tap
+        int aoff[5][4];
+#define RS_AOFF(ps_)                                                                                                             \
+        do {                                                                                                                     \
+            int s_ = mg * 32 + j;                                                                                                \
+            s_ = s_ < G::RPP * G::TPP ? s_ : G::RPP * G::TPP - 1;                                                                \
+            const int rp_ = s_ / G::TPP, r2_ = s_ - rp_ * G::TPP;                                                                \
+            int gp_ = (ps_) * G::RPP + rp_;                                                                                      \
+            gp_ = gp_ < total_pairs ? gp_ : total_pairs - 1;                                                                     \
+            const int tx_ = r2_ >> 1, qo_ = 2 * gp_ + (r2_ & 1), y_ = qo_ % S;                                                   \
+            _Pragma("unroll") for (int ky = 0; ky < 5; ++ky) {                                                                   \
+                const int iy_ = y_ + ky - 2;                                                                                     \
+                const int slot_ = (iy_ >= 0 && iy_ < S) ? (qo_ + ky - 2) % G::NR + 1 : 0;                                        \
+                const int rot_ = w2b_rot(slot_);                                                                                 \
+                _Pragma("unroll") for (int pg = 0; pg < 4; ++pg) {                                                               \
+                    const int w_ = pg * 20 + tx_ * 2 + h;                                                                        \
+                    aoff[ky][pg] = slot_ * G::ROWL + ((w_ & ~15) | ((w_ + rot_) & 15)) * 16;                                     \
+                }                                                                                                                \
+            }                                                                                                                    \
+        } while (0)
+        RS_AOFF(pass);
+        if ((DBG & 128) && st_on) st_last = __builtin_readcyclecounter();
         for (;;) {
             int next_pass, lo, hi;
             bool have_next;
@@ -320,32 +383,9 @@ __global__ __launch_bounds__(512) void k_conv12_rs(const uint8_t* __restrict__ c
             uint32_t ticket = 0;
             // the ticket after the next one (raw instruction: atomicAdd() waits for the returned value on the spot); stored behind the second barrier
             if (draw && tid == 0) asm volatile("global_atomic_add %0, %1, %2, off sc0" : "=v"(ticket) : "v"(pass_ctr), "v"(1u) : "memory");
-            uint4 bq[8][2];
-#pragma unroll
-            for (int t = 0; t < BD; ++t) { bq[t][0] = buf_load16(wrs, boff, W2_BOFF(t)); bq[t][1] = (DBG & 64) ? bq[t][0] : buf_load16(wrs, boff, W2_BOFF(t) + 2 * CO * 16); }
-            int aoff[5][4];
-            {
-                int s = mg * 32 + j;
-                s = s < G::RPP * G::TPP ? s : G::RPP * G::TPP - 1;
-                const int rp = s / G::TPP, r2 = s - rp * G::TPP;
-                int gp = pass * G::RPP + rp;
-                gp = gp < total_pairs ? gp : total_pairs - 1;
-                const int tx = r2 >> 1, qo = 2 * gp + (r2 & 1), y = qo % S;
-#pragma unroll
-                for (int ky = 0; ky < 5; ++ky) {
-                    const int iy = y + ky - 2;
-                    const int slot = (iy >= 0 && iy < S) ? (qo + ky - 2) % G::NR + 1 : 0;
-                    const int rot = w2b_rot(slot);
-#pragma unroll
-                    for (int pg = 0; pg < 4; ++pg) {
-                        const int w = pg * 20 + tx * 2 + h;
-                        aoff[ky][pg] = slot * G::ROWL + ((w & ~15) | ((w + rot) & 15)) * 16;
-                    }
-                }
-            }
             f32x16 acc[8];
             const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-            __builtin_amdgcn_s_setprio(0);                                // the producer wave on this SIMD outranks the tap loop (cnn_fused12.h)
+            __builtin_amdgcn_s_setprio((PRIO >> 4) & 3);
             uint4 af[2][2];
 #define RS_AREAD(dst_, tau_)                                                                                                     \
             do {                                                                                                                 \
@@ -357,8 +397,8 @@ __global__ __launch_bounds__(512) void k_conv12_rs(const uint8_t* __restrict__ c
             do {                                                                                                                 \
                 const int tl = (tau) % 20;                                                                                       \
                 if ((tau) + 1 < 40) RS_AREAD(af[((tau) + 1) % 2], (tau) + 1);                                                    \
-                if ((tau) + BD < 40) {                                                                                           \
-                    const int wt = W2_BOFF((tau) + BD);                                                                          \
+                {                                                                                                                \
+                    const int wt = W2_BOFF(((tau) + BD) % 40);                                                                   \
                     bq[((tau) + BD) % 8][0] = buf_load16(wrs, boff, wt);                                                         \
                     bq[((tau) + BD) % 8][1] = (DBG & 64) ? bq[((tau) + BD) % 8][0] : buf_load16(wrs, boff, wt + 2 * CO * 16);    \
                 }                                                                                                                \
@@ -378,17 +418,21 @@ __global__ __launch_bounds__(512) void k_conv12_rs(const uint8_t* __restrict__ c
             } while (0)
             RS_AREAD(af[0], 0);
 #pragma clang loop unroll(full)
-            for (int tau = 0; tau < ((DBG & 32) ? 0 : 20); ++tau) RS_TAP(tau);
+            for (int tau = 0; tau < ((DBG & 32) ? 0 : TSPLIT); ++tau) RS_TAP(tau);
+            RS_STAMP(0);
             RS_BAR();                                                     // S1 | S2
+            RS_STAMP(1);
 #pragma clang loop unroll(full)
-            for (int tau = 20; tau < ((DBG & 32) ? 0 : 40); ++tau) RS_TAP(tau);
+            for (int tau = TSPLIT; tau < ((DBG & 32) ? 0 : 40); ++tau) RS_TAP(tau);
             if (DBG & 32) { _Pragma("unroll") for (int p = 0; p < 8; ++p) acc[p] = zero16; }
             if (draw) {
                 asm volatile("s_waitcnt vmcnt(0)" : "+v"(ticket) :: "memory");
                 if (tid == 0) *s_next = ((int)ticket + (int)gridDim.x) * PK;       // read at the start of a later round
             }
+            RS_STAMP(2);
             RS_BAR();                                                     // S2 | S3: the producers have read pbufE (in S1), it may be written
-            __builtin_amdgcn_s_setprio(2);
+            RS_STAMP(3);
+            __builtin_amdgcn_s_setprio(PRIO & 3);
             // output transform: Y = A^T M, pool, bias, ReLU -> the pass's 3 x 20 x 64 activations as fp32 in pbufE
             if (!(DBG & 16)) {
                 f32x16 y0, y1, y2, y3;
@@ -408,31 +452,39 @@ __global__ __launch_bounds__(512) void k_conv12_rs(const uint8_t* __restrict__ c
                 for (int rr = 0; rr < 8; ++rr) {
                     const int r = 2 * rr;
                     const int s = mg * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;      // even: rows y, y+1 of one tile column
-                    const float v0 = fmaxf(fmaxf(y0[r], y1[r]), fmaxf(y0[r + 1], y1[r + 1]));
-                    const float v1 = fmaxf(fmaxf(y2[r], y3[r]), fmaxf(y2[r + 1], y3[r + 1]));
+                    const float v0 = rs_max(rs_max3(y0[r], y1[r], y0[r + 1]), y1[r + 1]);
+                    const float v1 = rs_max(rs_max3(y2[r], y3[r], y2[r + 1]), y3[r + 1]);
                     if (s < G::RPP * G::TPP) {
                         const int rp = s / G::TPP, tx = (s - rp * G::TPP) >> 1;
                         const float a0 = fmaxf(v0 * out_scale + bz, 0.f), a1 = fmaxf(v1 * out_scale + bz, 0.f);
-                        ovf |= !(a0 < 4368.0f) | !(a1 < 4368.0f);
+                        ovfm = rs_max3(ovfm, a0, a1);
                         float* o = pbe + (rp * 20 + 2 * tx) * 64 + co;
                         o[0] = a0;
                         o[64] = a1;
                     }
                 }
             }
+            if (have_next) RS_AOFF(next_pass);
+            RS_STAMP(4);
             RS_BAR();                                                     // S3 | the next round
+            RS_STAMP(5);
             for (int c0 = lo + F::CHUNK; c0 < hi; c0 += F::CHUNK) { RS_BAR(); RS_BAR(); RS_BAR(); }    // the second chunk of a ticket's first pass
+            RS_STAMP(6);
+            if ((DBG & 128) && st_on) st_sum[7] += 1;
             if (!have_next) break;
             res_hi = hi;
             pass = next_pass;
         }
 #undef RS_TAP
+#undef RS_AOFF
 #undef RS_AREAD
 #undef W2_POS
 #undef W2_BOFF
     }
+    if ((DBG & 128) && st_on) { _Pragma("unroll") for (int i = 0; i < 8; ++i) dbg_stamps[(tid ? 8 : 0) + i] = st_sum[i]; }
+#undef RS_STAMP
 #undef RS_NEXT
 #undef RS_ROWS
 #undef RS_BAR
-    if (__any(ovf) && lane == 0) atomicOr(overflow, 1u);
+    if (__any(!(ovfm < 4368.0f)) && lane == 0) atomicOr(overflow, 1u);
 }
