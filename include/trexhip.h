@@ -407,6 +407,11 @@ int trexhip_set_identity_precision(trexhip_ctx* ctx, int32_t mode);
  * scaling), probs is [n][classes] float32 softmax rows.  d_logits may be NULL. */
 int trexhip_identify_device(trexhip_ctx* ctx, const uint8_t* d_crops, int32_t n, float* d_probs, float* d_logits);
 int trexhip_identify(trexhip_ctx* ctx, const uint8_t* crops, int32_t n, float* probs);
+/* What the fp16 range guard of the LAST identify call on this context did (waits for the context's stream): *rerun_crops = crops
+ * whose layer stack was re-run by the BF16X6 kernels (0 = none; the whole batch when the flag came from a kernel that does not
+ * know the crop: *whole_batch = 1).  Per crop since round 5: one out-of-range crop no longer re-runs the batch.  No reference
+ * counterpart (the reference's torch network has no range limit); either pointer may be NULL. */
+int trexhip_identify_guard_stats(trexhip_ctx* ctx, uint32_t* rerun_crops, uint32_t* whole_batch);
 
 /* ---- multi-GPU hand-off --------------------------------------------------------------------
  * Fixed-size per-blob identity table of the last batch, written to caller-owned device memory

@@ -222,12 +222,91 @@ def test_fused_equals_two_kernel_chain(n, monkeypatch):
     if n > 40:
         crops[40, 10:30, 5:75] = 0
     out = {}
-    for name, geom in (("fused", "0"), ("two", str(1 << 28))):
+    # ... and so does the role-split form of the fused kernel (k_conv12_rs: consumer / producer waves in one workgroup, bit 29)
+    for name, geom in (("fused", "0"), ("two", str(1 << 28)), ("role-split", str(1 << 29))):
         monkeypatch.setenv("TREXHIP_CONV_GEOM", geom)
         seg = make_net(st, 100)
         seg.set_identity_precision(capi.CNN_FP16X3)
         out[name] = seg.probabilities(crops)
+        assert seg.guard_stats() == (0, False)
         seg.close()
     assert out["fused"].tobytes() == out["two"].tobytes()
+    assert out["role-split"].tobytes() == out["two"].tobytes()
     want, _ = cnn_oracle.predict(st, crops[:64], threads=4)
     assert np.abs(out["fused"][:64] - want).max() <= 1e-4
+
+
+@pytest.mark.parametrize("geom", [0, 1 << 29])
+def test_large_batch_kernels_repeat_bit_for_bit(geom, monkeypatch):
+    """Round 4 found a 1-in-5 schedule hazard (an inline-asm accumulator read that escaped the hazard recognizer) only because one test
+    happened to fail; round 5 found the same class again (v_max3 in inline asm on MFMA results: the range guard fired at random).  So the
+    large-batch kernels run TEN times here: every repetition of the fused chain (both forms) must reproduce the two-kernel chain's
+    probabilities bit for bit, and no repetition may trip the range guard."""
+    st = weights.synthetic_state(100, 31)
+    n = 12800
+    crops = torch.from_numpy(weights.synthetic_crops(n, 77 + n)[..., 0].copy()).cuda()
+    monkeypatch.setenv("TREXHIP_CONV_GEOM", str(1 << 28))
+    seg = make_net(st, 100)
+    seg.set_identity_precision(capi.CNN_FP16X3)
+    ref = torch.zeros((n, 100), dtype=torch.float32, device="cuda")
+    seg.identify_device(crops.data_ptr(), n, ref.data_ptr())
+    seg.synchronize()
+    seg.close()
+    monkeypatch.setenv("TREXHIP_CONV_GEOM", str(geom))
+    seg = make_net(st, 100)
+    seg.set_identity_precision(capi.CNN_FP16X3)
+    out = torch.zeros_like(ref)
+    for rep in range(10):
+        out.zero_()
+        seg.identify_device(crops.data_ptr(), n, out.data_ptr())
+        assert seg.guard_stats() == (0, False), rep
+        assert torch.equal(out, ref), (rep, float((out - ref).abs().max()))
+    seg.close()
+
+
+def _conv1_pooled_max(st, crops):
+    """largest activation behind conv1 + BN + ReLU + pool per crop (float64 on the host): what the fp16 range guard of the default chain looks at"""
+    w = st["conv1.weight"].astype(np.float64)[:, 0]                      # [16][5][5]
+    s = st["bn1.weight"].astype(np.float64) / np.sqrt(st["bn1.running_var"].astype(np.float64) + 1e-5)
+    b = (st["conv1.bias"].astype(np.float64) - st["bn1.running_mean"]) * s + st["bn1.bias"]
+    out = []
+    for c in crops[..., 0].astype(np.float64):
+        p = np.pad(c, 2)
+        win = np.lib.stride_tricks.sliding_window_view(p, (5, 5))       # [80][80][5][5]
+        a = np.einsum("yxij,oij->oyx", win, w) * s[:, None, None] + b[:, None, None]
+        out.append(max(a.max(), 0.0))
+    return np.array(out)
+
+
+@pytest.mark.parametrize("geom", [0, 1 << 29])
+def test_range_guard_is_per_crop(geom, monkeypatch):
+    """One crop whose conv1 activations leave the fp16-piece range (>= 4368) among quiet ones: only that crop (and at most the neighbours that
+    share a pass with it) is re-run by the bf16x6 kernels -- the others keep the bits of a run without it (a whole-batch re-run would move
+    them by ~2e-6) -- and the loud crop's answer is the exact path's."""
+    monkeypatch.setenv("TREXHIP_CONV_GEOM", str(geom))
+    st = {k: v.copy() for k, v in weights.synthetic_state(8, 31).items()}
+    n, loud = 300, 117
+    rng = np.random.default_rng(5)
+    crops = np.zeros((n, 80, 80, 1), np.uint8)
+    crops[:, 20:60, 20:60, 0] = rng.integers(0, 4, (n, 40, 40))          # quiet crops: values 0..3
+    quiet_only = crops.copy()
+    crops[loud, :, :, 0] = rng.integers(0, 256, (80, 80))                 # one loud crop
+    m = 1.0
+    base_q, base_l = _conv1_pooled_max(st, quiet_only[:8]).max(), _conv1_pooled_max(st, crops[loud:loud + 1])[0]
+    m = 3000.0 / max(base_q, 1e-9)                                        # quiet crops peak at 3000, the loud one far above 4368
+    assert base_l * m > 3 * 4368, (base_q, base_l)
+    st["conv1.weight"] *= m; st["conv1.bias"] *= m; st["bn1.running_mean"] *= m
+    st["bn2.running_var"] = st["bn2.running_var"] * m * m                 # bring the scale back down behind conv2
+    ref, _ = cnn_oracle.predict(st, crops[loud - 2:loud + 3], threads=4)
+    seg = make_net(st, 8)
+    seg.set_identity_precision(capi.CNN_FP16X3)
+    a = seg.probabilities(quiet_only)
+    assert seg.guard_stats() == (0, False)
+    b = seg.probabilities(crops)
+    rerun, whole = seg.guard_stats()
+    assert not whole and 1 <= rerun <= 3, (rerun, whole)
+    assert np.all(np.isfinite(b)) and np.abs(b[loud - 2:loud + 3] - ref).max() <= 1e-4
+    far = np.ones(n, bool); far[loud - 1:loud + 2] = False
+    assert a[far].tobytes() == b[far].tobytes()                           # untouched by the re-run
+    assert np.abs(a[~far] - b[~far])[[0, 2]].max() <= 1e-5                # the neighbours: re-run or not, the same answer
+    seg.close()

@@ -114,7 +114,7 @@ SYMBOLS = [
     "trexhip_set_stream", "trexhip_get_live_params", "trexhip_update_params", "trexhip_set_background", "trexhip_set_background_device", "trexhip_set_background_color", "trexhip_set_background_color_device", "trexhip_generate_average_device", "trexhip_get_background", "trexhip_segment_device",
     "trexhip_segment", "trexhip_segment_color", "trexhip_segment_color_device", "trexhip_rethreshold_device", "trexhip_rethreshold_per_blob_device", "trexhip_fetch_rethreshold", "trexhip_fetch", "trexhip_device_view_get", "trexhip_synchronize",
     "trexhip_profile_enable", "trexhip_profile_read", "trexhip_profile_reset",
-    "trexhip_default_posture_params", "trexhip_posture_device", "trexhip_posture_auto_device", "trexhip_pack_frames_v6_device", "trexhip_crops_device", "trexhip_pixel_channels", "trexhip_device_alloc", "trexhip_device_free", "trexhip_copy_to_host", "trexhip_copy_to_device", "trexhip_crops_transformed_device", "trexhip_crops_posture_device", "trexhip_default_midline_params", "trexhip_midline_device", "trexhip_midline_movement_device", "trexhip_default_split_params", "trexhip_split_search_device", "trexhip_export_id_table_device", "trexhip_export_id_table_ex_device", "trexhip_load_weights", "trexhip_set_identity_precision", "trexhip_num_classes", "trexhip_identify_device", "trexhip_identify",
+    "trexhip_default_posture_params", "trexhip_posture_device", "trexhip_posture_auto_device", "trexhip_pack_frames_v6_device", "trexhip_crops_device", "trexhip_pixel_channels", "trexhip_device_alloc", "trexhip_device_free", "trexhip_copy_to_host", "trexhip_copy_to_device", "trexhip_crops_transformed_device", "trexhip_crops_posture_device", "trexhip_default_midline_params", "trexhip_midline_device", "trexhip_midline_movement_device", "trexhip_default_split_params", "trexhip_split_search_device", "trexhip_export_id_table_device", "trexhip_export_id_table_ex_device", "trexhip_load_weights", "trexhip_set_identity_precision", "trexhip_num_classes", "trexhip_identify_device", "trexhip_identify", "trexhip_identify_guard_stats",
     "trexhip_weight_blob_bytes", "trexhip_trainer_create", "trexhip_trainer_destroy", "trexhip_trainer_set_lr", "trexhip_trainer_steps", "trexhip_train_step_device", "trexhip_train_step", "trexhip_train_eval_device", "trexhip_train_eval", "trexhip_trainer_read", "trexhip_trainer_export",
     "trexhip_lzo1x_bound", "trexhip_lzo1x_compress", "trexhip_pv_write_frames",
 ]
@@ -189,6 +189,7 @@ def lib():
         L.trexhip_set_identity_precision.argtypes = [C.c_void_p, C.c_int32]
         L.trexhip_identify_device.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]
         L.trexhip_identify.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]
+        L.trexhip_identify_guard_stats.argtypes = [C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
         L.trexhip_weight_blob_bytes.argtypes = [C.c_int32, C.c_int32]
         L.trexhip_weight_blob_bytes.restype = C.c_size_t
         L.trexhip_trainer_create.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(TrainParams), C.POINTER(C.c_void_p)]
@@ -494,6 +495,12 @@ class Segmenter:
         out = np.empty((n, self.num_classes()), np.float32)
         _check(lib().trexhip_identify(self._h, crops.ctypes.data_as(C.c_void_p), n, out.ctypes.data_as(C.c_void_p)))
         return out
+
+    def guard_stats(self):
+        """(crops re-run by the fp16 range guard in the last identify call, whole batch re-run?)"""
+        a, b = C.c_uint32(0), C.c_uint32(0)
+        _check(lib().trexhip_identify_guard_stats(self._h, C.byref(a), C.byref(b)))
+        return int(a.value), bool(b.value)
 
     def identify_device(self, d_crops_ptr, n, d_probs_ptr, d_logits_ptr=None):
         _check(lib().trexhip_identify_device(self._h, C.c_void_p(d_crops_ptr), n, C.c_void_p(d_probs_ptr),

@@ -111,14 +111,40 @@ __global__ __launch_bounds__(256, 2) void k_conv1(const uint8_t* __restrict__ cr
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 f16x8_c1 __attribute__((ext_vector_type(8)));
 
+// ------------------------------------------------------------------------------------------------
+// fp16 range guard, per crop (round 5).  The default chain raises overflow[0] when an activation leaves the range its fp16 pieces can hold and,
+// where it knows the crop, flags[crop].  k_guard_plan turns the flags into a plan for the bf16 re-run:
+//   plan[0] = number of listed crops, plan[1] = mode (0 nothing to do, 1 the listed crops only, 2 every crop), plan[2 ..] = the list.
+// The re-run kernels take the plan as their guard: item i of a launch is crop plan[2 + i] in list mode.  One out-of-range crop in 25600
+// used to cost a second pass over the whole batch (4x the step); now it costs the launches of the re-run chain and its own crop.
+// ------------------------------------------------------------------------------------------------
+static constexpr int FB_MAX = 1024;           // more flagged crops than this: every crop is re-run
+__device__ __forceinline__ int fb_count(const uint32_t* __restrict__ plan, const int n) { return (plan && plan[1] == 1u) ? (int)plan[0] : n; }
+__device__ __forceinline__ int fb_crop(const uint32_t* __restrict__ plan, const int i) { return (plan && plan[1] == 1u) ? (int)plan[2 + i] : i; }
+__global__ __launch_bounds__(1024) void k_guard_plan(uint32_t* __restrict__ overflow, uint8_t* __restrict__ flags, const int n, uint32_t* __restrict__ plan) {
+    __shared__ uint32_t cnt;
+    if (threadIdx.x == 0) cnt = 0;
+    __syncthreads();
+    if (overflow[0] == 0u) { if (threadIdx.x == 0) { plan[0] = 0; plan[1] = 0; } return; }
+    for (int i = threadIdx.x; i < n; i += 1024)
+        if (flags[i]) {
+            flags[i] = 0;
+            const uint32_t k = atomicAdd(&cnt, 1u);
+            if (k < (uint32_t)FB_MAX) plan[2 + k] = (uint32_t)i;
+        }
+    __syncthreads();
+    if (threadIdx.x == 0) { plan[0] = cnt <= (uint32_t)FB_MAX ? cnt : 0u; plan[1] = (cnt == 0u || cnt > (uint32_t)FB_MAX) ? 2u : 1u; }     // raised by a kernel that does not know the crop: all of them
+}
+
 __global__ __launch_bounds__(256) void k_conv1_mfma(const uint8_t* __restrict__ crops, const uint4* __restrict__ wtab /*[16][64]*/,
                                                     const float* __restrict__ bias, float* __restrict__ out, const float inv_scale,
                                                     const uint32_t* __restrict__ guard) {
-    if (guard && *guard == 0u) return;                      // guarded re-run of the default chain: nothing to do unless the fp16 range flag is up
+    if (guard && guard[1] == 0u) return;                    // guarded re-run of the default chain (guard = the plan of k_guard_plan): nothing to do unless the fp16 range flag is up
+    if ((int)blockIdx.x >= fb_count(guard, (int)gridDim.x)) return;
     constexpr int S = 80, PH = 84, PITCH = 88;              // halves per padded row (176 B: rows land on distinct bank groups)
     __shared__ __attribute__((aligned(16))) _Float16 img[PH * PITCH];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int crop = blockIdx.x;
+    const int crop = fb_crop(guard, (int)blockIdx.x);
     const uint8_t* src = crops + (size_t)crop * S * S;
     // zero the padded image, then 16 pixels per thread: one 16-byte load of the crop row, 16 halves into LDS
     for (int i = tid; i < PH * PITCH * 2 / 16; i += 256) reinterpret_cast<uint4*>(img)[i] = make_uint4(0, 0, 0, 0);
@@ -189,12 +215,13 @@ __global__ __launch_bounds__(256) void k_conv1_mfma(const uint8_t* __restrict__ 
 __global__ __launch_bounds__(256) void k_conv1_mfma3(const uint8_t* __restrict__ crops /*[N][80][80][3]*/, const uint4* __restrict__ wtab /*[32][64]*/,
                                                      const float* __restrict__ bias, float* __restrict__ out, const float inv_scale,
                                                      const uint32_t* __restrict__ guard) {
-    if (guard && *guard == 0u) return;
+    if (guard && guard[1] == 0u) return;
+    if ((int)blockIdx.x >= fb_count(guard, (int)gridDim.x)) return;
     constexpr int S = 80, PH = 84, PITCH = 88, PLANE = PH * PITCH;
     __shared__ __attribute__((aligned(16))) _Float16 img[3 * PLANE];
     __shared__ __attribute__((aligned(16))) float tr[4][64 * 17];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int crop = blockIdx.x;
+    const int crop = fb_crop(guard, (int)blockIdx.x);
     const uint32_t* src = reinterpret_cast<const uint32_t*>(crops + (size_t)crop * S * S * 3);
     for (int i = tid; i < 3 * PLANE * 2 / 16; i += 256) reinterpret_cast<uint4*>(img)[i] = make_uint4(0, 0, 0, 0);
     __syncthreads();
@@ -329,7 +356,7 @@ __global__ __launch_bounds__(512) void k_conv5_split(const float* __restrict__ i
                                                      const float* __restrict__ bias, float* __restrict__ out,
                                                      const float out_scale, uint32_t* __restrict__ overflow,
                                                      const uint32_t* __restrict__ guard, const int n_blocks) {
-    if (guard && *guard == 0u) return;            // re-run pass: only when the fp16 pass flagged an overflow
+    if (guard && guard[1] == 0u) return;          // re-run pass (guard = the plan of k_guard_plan): only when the fp16 pass flagged an overflow
     using K = SplitK<KIND>;
     using frag = typename K::frag;
     using G = ConvGeomB<CI, CO, S, ROWS, K::NP, CIC>;
@@ -342,9 +369,10 @@ __global__ __launch_bounds__(512) void k_conv5_split(const float* __restrict__ i
     const int n = wave % G::NT, mg = wave / G::NT;
     // grid-stride over the (crop, row band) blocks: the guarded re-run is launched with a small grid, so that the usual case (flag
     // clear, every workgroup returns at once) costs a few microseconds instead of the launch of n * BPC empty workgroups
-    for (int blk = blockIdx.x; blk < n_blocks; blk += gridDim.x) {
+    const int n_blocks_eff = (guard && guard[1] == 1u) ? (int)guard[0] * G::BPC : n_blocks;      // list mode: the flagged crops only
+    for (int blk = blockIdx.x; blk < n_blocks_eff; blk += gridDim.x) {
     if (blk != (int)blockIdx.x) __syncthreads();                      // the previous block's readers are done with the LDS buffers
-    const int crop = blk / G::BPC, row0 = (blk % G::BPC) * ROWS;
+    const int crop = fb_crop(guard, blk / G::BPC), row0 = (blk % G::BPC) * ROWS;
     constexpr int WR = S / 2;
 
     int aoff[G::TPW];
@@ -1051,7 +1079,9 @@ static constexpr int FC1_KSPLIT = 10;     // 12800 = 10 x 1280: 500 workgroups a
 __global__ __launch_bounds__(256) void k_fc1(const float* __restrict__ act, const float* __restrict__ w /*[K][128]*/,
                                              const float* __restrict__ bias /*[128]*/, float* __restrict__ out, int n, int K,
                                              const uint32_t* __restrict__ guard) {
-    if (guard && *guard == 0u) return;
+    if (guard && guard[1] == 0u) return;                  // guard = the plan of k_guard_plan; list mode: row i of the GEMM is crop plan[2 + i]
+    const int n_eff = fb_count(guard, n);
+    if ((int)blockIdx.x * 32 >= n_eff) return;
     __shared__ float As[2][32 * 33];
     __shared__ __attribute__((aligned(16))) float Bs[2][32 * 128];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1065,8 +1095,8 @@ __global__ __launch_bounds__(256) void k_fc1(const float* __restrict__ act, cons
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
     float4 na, nb0, nb1, nb2, nb3;
-    const bool arow = m0 + ar < n;
-    const float* asrc = act + (size_t)(m0 + ar) * K + kbeg + aq * 4;
+    const bool arow = m0 + ar < n_eff;
+    const float* asrc = act + (size_t)(arow ? fb_crop(guard, m0 + ar) : 0) * K + kbeg + aq * 4;
     const float4* wsrc = reinterpret_cast<const float4*>(w) + (size_t)kbeg * 32 + tid;
 #define FC1_FETCH(k0)                                                                                  \
     do {                                                                                               \
@@ -1102,7 +1132,7 @@ __global__ __launch_bounds__(256) void k_fc1(const float* __restrict__ act, cons
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int i = (r & 3) + 8 * (r >> 2) + 4 * h;
-        if (m0 + i < n) out[(size_t)(m0 + i) * 128 + co] = acc[r] + bz;
+        if (m0 + i < n_eff) out[(size_t)fb_crop(guard, m0 + i) * 128 + co] = acc[r] + bz;
     }
 }
 
@@ -1115,7 +1145,7 @@ __global__ __launch_bounds__(256) void k_fc1(const float* __restrict__ act, cons
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_fc1_split(const float* __restrict__ act, const uint4* __restrict__ wq /*[K/8][2][128]*/,
                                                    const float* __restrict__ bias, float* __restrict__ out, int n, int K,
-                                                   const float out_scale, uint32_t* __restrict__ overflow) {
+                                                   const float out_scale, uint32_t* __restrict__ overflow, uint8_t* __restrict__ crop_flags) {
     constexpr int RPB = 80;                                     // bytes per staged row (32 halves + 16 pad)
     __shared__ __attribute__((aligned(16))) uint8_t As[2][2][128 * RPB];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1128,7 +1158,7 @@ __global__ __launch_bounds__(256) void k_fc1_split(const float* __restrict__ act
     for (int m = 0; m < 4; ++m)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
-    bool ovf = false;
+    bool ovf4[4] = {false, false, false, false};                // per staged row of this thread (row = crop): the range guard is per crop
     float4 na[4];
     uint4 nb[2][2];
     const uint4* wl = wq + (size_t)(kbeg / 8) * 256 + wave * 32 + j;     // + (ko*2 + piece)*128
@@ -1149,8 +1179,8 @@ __global__ __launch_bounds__(256) void k_fc1_split(const float* __restrict__ act
         _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                                    \
             const int idx = tid + 256 * i, row = idx >> 3, q = idx & 7;                                                    \
             uint32_t a1[4], a2[4];                                                                                         \
-            split2h(na[i].x, a1[0], a2[0], ovf); split2h(na[i].y, a1[1], a2[1], ovf);                                      \
-            split2h(na[i].z, a1[2], a2[2], ovf); split2h(na[i].w, a1[3], a2[3], ovf);                                      \
+            split2h(na[i].x, a1[0], a2[0], ovf4[i]); split2h(na[i].y, a1[1], a2[1], ovf4[i]);                              \
+            split2h(na[i].z, a1[2], a2[2], ovf4[i]); split2h(na[i].w, a1[3], a2[3], ovf4[i]);                              \
             uint8_t* d = As[buf][0] + row * RPB + q * 8;                                                                   \
             *reinterpret_cast<uint2*>(d) = make_uint2(a1[0] | (a1[1] << 16), a1[2] | (a1[3] << 16));                       \
             *reinterpret_cast<uint2*>(d + 128 * RPB) = make_uint2(a2[0] | (a2[1] << 16), a2[2] | (a2[3] << 16));           \
@@ -1185,7 +1215,12 @@ __global__ __launch_bounds__(256) void k_fc1_split(const float* __restrict__ act
     }
 #undef FCS_FETCH
 #undef FCS_STASH
-    if (__any(ovf) && lane == 0) atomicOr(overflow, 1u);
+    if (__any(ovf4[0] | ovf4[1] | ovf4[2] | ovf4[3])) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if (ovf4[i] && crop_flags && m0 + ((tid + 256 * i) >> 3) < n) crop_flags[m0 + ((tid + 256 * i) >> 3)] = 1;
+        if (lane == 0) atomicOr(overflow, 1u);
+    }
     const int co = wave * 32 + j;
     const float bz = blockIdx.y == 0 ? bias[co] : 0.f;
 #pragma unroll
@@ -1218,13 +1253,17 @@ __global__ __launch_bounds__(256) void k_head(const float* __restrict__ fc1 /*[N
                                               const float* __restrict__ ln_b, const float* __restrict__ w2t /*[100][C]*/,
                                               const float* __restrict__ b2, float* __restrict__ probs /*[N][C]*/,
                                               float* __restrict__ logits_out, int n, int C, const uint32_t* __restrict__ guard, int ksplit) {
-    if (guard && *guard == 0u) return;
+    if (guard && guard[1] == 0u) return;                   // guard = the plan of k_guard_plan; list mode: item i is crop plan[2 + i]
+    const int n_items = fb_count(guard, n);
     constexpr int Q = HEAD_CPW;
     __shared__ float ys[4][Q][128];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int crop0 = (blockIdx.x * 4 + wave) * Q;
-    if (crop0 >= n) return;
-    const int nq = n - crop0 < Q ? n - crop0 : Q;            // crops of this wave (wave-uniform)
+    if (crop0 >= n_items) return;
+    const int nq = n_items - crop0 < Q ? n_items - crop0 : Q;            // crops of this wave (wave-uniform)
+    int cidx[Q];
+#pragma unroll
+    for (int q = 0; q < Q; ++q) cidx[q] = fb_crop(guard, crop0 + (q < nq ? q : 0));
     const float g0 = ln_g[lane], be0 = ln_b[lane];
     const float g1 = lane + 64 < 100 ? ln_g[lane + 64] : 0.f, be1 = lane + 64 < 100 ? ln_b[lane + 64] : 0.f;
     // the fc1 partial planes of the split-K launch: every load of the wave's crops goes out first (the planes lie n * 512 bytes apart: a chain of
@@ -1234,7 +1273,7 @@ __global__ __launch_bounds__(256) void k_head(const float* __restrict__ fc1 /*[N
     for (int s = 0; s < FC1_KSPLIT; ++s)
 #pragma unroll
         for (int q = 0; q < Q; ++q) {
-            const float* xs = fc1 + (size_t)s * n * 128 + (size_t)(crop0 + (q < nq ? q : 0)) * 128;
+            const float* xs = fc1 + (size_t)s * n * 128 + (size_t)cidx[q] * 128;
             xa[s][q] = s < ksplit ? xs[lane] : 0.f;
             xb[s][q] = (s < ksplit && lane + 64 < 100) ? xs[lane + 64] : 0.f;
         }
@@ -1278,7 +1317,7 @@ __global__ __launch_bounds__(256) void k_head(const float* __restrict__ fc1 /*[N
 #pragma unroll
                 for (int q = 0; q < Q; ++q) {
                     lg[r][q] = s[q];
-                    if (logits_out && q < nq) logits_out[(size_t)(crop0 + q) * C + c] = s[q];
+                    if (logits_out && q < nq) logits_out[(size_t)cidx[q] * C + c] = s[q];
                 }
             }
 #pragma unroll
@@ -1304,7 +1343,7 @@ __global__ __launch_bounds__(256) void k_head(const float* __restrict__ fc1 /*[N
             const int c = r * 64 + lane;
             if (c < C) {
 #pragma unroll
-                for (int q = 0; q < Q; ++q) if (q < nq) probs[(size_t)(crop0 + q) * C + c] = lg[r][q] * sum[q];
+                for (int q = 0; q < Q; ++q) if (q < nq) probs[(size_t)cidx[q] * C + c] = lg[r][q] * sum[q];
             }
         }
 }
@@ -1323,7 +1362,8 @@ struct Net {
     float invf1h = 1.f;
     uint4* w1h = nullptr;                      // conv1 B fragments (16 fragments x 64 lanes), fp16 pieces of the folded weights
     float inv1h = 1.f;
-    uint32_t* d_ovf = nullptr;
+    uint32_t* d_ovf = nullptr;                 // [0] fp16 range flag, [1] / [2] pass counters of the persistent conv3 / conv2, [4 ..] the re-run plan (k_guard_plan)
+    uint8_t* d_ovfc = nullptr;                 // per-crop range flags [max_crops]
     float *w1 = nullptr, *b1 = nullptr, *w2 = nullptr, *b2 = nullptr, *w3 = nullptr, *b3 = nullptr;
     float *wf1 = nullptr, *bf1 = nullptr, *lng = nullptr, *lnb = nullptr, *wf2t = nullptr, *bf2 = nullptr;
     float *act1 = nullptr, *act2 = nullptr, *act3 = nullptr, *fc1 = nullptr, *probs = nullptr, *logits = nullptr;
@@ -1370,6 +1410,7 @@ static void free_net(Net* n) {
     if (n->w1h) (void)hipFree(n->w1h);
     if (n->wf1h) (void)hipFree(n->wf1h);
     if (n->d_ovf) (void)hipFree(n->d_ovf);
+    if (n->d_ovfc) (void)hipFree(n->d_ovfc);
     if (n->v2) (void)hipFree(n->v2);
     if (n->v3) (void)hipFree(n->v3);
     if (n->crops) (void)hipFree(n->crops);
@@ -1606,7 +1647,8 @@ int net_load(trexhip_ctx* ctx, const void* blob, size_t bytes) {
     TRY(upload_split(&net->w3s, wp, 64, 128));
     TRY(upload_split_f16(&net->w3h, &net->inv3h, wp, 64, 128));
     TRY(upload_wino_f16(&net->w3w, &net->inv3w, wp, 64, 128));
-    if (rc == TREXHIP_OK && hipMalloc(reinterpret_cast<void**>(&net->d_ovf), 16) != hipSuccess) rc = TREXHIP_E_DEVICE;
+    if (rc == TREXHIP_OK && hipMalloc(reinterpret_cast<void**>(&net->d_ovf), 16 + (2 + FB_MAX) * 4) != hipSuccess) rc = TREXHIP_E_DEVICE;
+    if (rc == TREXHIP_OK && hipMemset(net->d_ovf, 0, 16 + (2 + FB_MAX) * 4) != hipSuccess) rc = TREXHIP_E_DEVICE;
     fold_conv(c3w, c3b, g3, be3, m3, v3, 128, 64, 32, wp, bias);
     TRY(upload(&net->w3, wp)); TRY(upload(&net->b3, bias));
     {   // fc1 [100][c*100+h*10+w] -> [(h*10+w)*128 + c][128 (o padded)]
@@ -1664,7 +1706,10 @@ static int ensure_act(trexhip_ctx* ctx, Net* net, int n) {
     if (net->v3) { (void)hipFree(net->v3); net->v3 = nullptr; }
     if (net->crops) { (void)hipFree(net->crops); net->crops = nullptr; }
     if (net->h_probs) { (void)hipHostFree(net->h_probs); net->h_probs = nullptr; }
+    if (net->d_ovfc) { (void)hipFree(net->d_ovfc); net->d_ovfc = nullptr; }
     const size_t N = n;
+    TH_CHECK_HIP(hipMalloc(reinterpret_cast<void**>(&net->d_ovfc), N));
+    TH_CHECK_HIP(hipMemset(net->d_ovfc, 0, N));              // k_guard_plan clears what it reads
     TH_CHECK_HIP(hipMalloc(reinterpret_cast<void**>(&net->act1), N * 40 * 40 * 16 * 4));
     TH_CHECK_HIP(hipMalloc(reinterpret_cast<void**>(&net->act2), N * 20 * 20 * 64 * 4));
     TH_CHECK_HIP(hipMalloc(reinterpret_cast<void**>(&net->act3), N * 10 * 10 * 128 * 4));
@@ -1792,12 +1837,12 @@ static int net_forward_launch(trexhip_ctx* ctx, const uint8_t* d_crops, int n, f
         const int pk = pk_env > 0 ? pk_env : std::max(1, std::min(32, n_pass / (wgs * 4)));
         const int want = (n_pass + pk - 1) / pk;
 #define F12RK(D_) hipLaunchKernelGGL((k_conv12_rs<D_>), dim3(want < wgs ? want : wgs), dim3(512), W12RGeom::LDS_BYTES, s, d_crops, net->w1h, net->b1, net->inv1h, \
-                           net->w2w, net->b2, net->v3, net->inv2w, net->d_ovf, n, net->d_ovf + 2, pk)
+                           net->w2w, net->b2, net->v3, net->inv2w, net->d_ovf, n, net->d_ovf + 2, pk, net->d_ovfc)
 #ifdef TREXHIP_DEV_KNOBS
         static const int f12r_dbg = std::getenv("TREXHIP_F12_DBG") ? std::atoi(std::getenv("TREXHIP_F12_DBG")) : 0;
         switch (f12r_dbg) { case 8: F12RK(8); break; case 16: F12RK(16); break; case 32: F12RK(32); break; case 40: F12RK(40); break; case 64: F12RK(64); break;
-            case 128: hipLaunchKernelGGL((k_conv12_rs<128>), dim3(want < wgs ? want : wgs), dim3(512), W12RGeom::LDS_BYTES, s, d_crops, net->w1h, net->b1, net->inv1h, net->w2w, net->b2, net->v3, net->inv2w, net->d_ovf, n, net->d_ovf + 2, pk, reinterpret_cast<unsigned long long*>(ctx->d_cnt_px)); break;
-#define F12RKV(...) hipLaunchKernelGGL((k_conv12_rs<__VA_ARGS__>), dim3(want < wgs ? want : wgs), dim3(512), W12RGeom::LDS_BYTES, s, d_crops, net->w1h, net->b1, net->inv1h, net->w2w, net->b2, net->v3, net->inv2w, net->d_ovf, n, net->d_ovf + 2, pk)
+            case 128: hipLaunchKernelGGL((k_conv12_rs<128>), dim3(want < wgs ? want : wgs), dim3(512), W12RGeom::LDS_BYTES, s, d_crops, net->w1h, net->b1, net->inv1h, net->w2w, net->b2, net->v3, net->inv2w, net->d_ovf, n, net->d_ovf + 2, pk, net->d_ovfc, reinterpret_cast<unsigned long long*>(ctx->d_cnt_px)); break;
+#define F12RKV(...) hipLaunchKernelGGL((k_conv12_rs<__VA_ARGS__>), dim3(want < wgs ? want : wgs), dim3(512), W12RGeom::LDS_BYTES, s, d_crops, net->w1h, net->b1, net->inv1h, net->w2w, net->b2, net->v3, net->inv2w, net->d_ovf, n, net->d_ovf + 2, pk, net->d_ovfc)
             case 200: F12RKV(0, 3, 20, 0x020); break; case 201: F12RKV(0, 3, 20, 0x000); break; case 202: F12RKV(0, 3, 20, 0x010); break; case 203: F12RKV(0, 3, 20, 0x212); break;
             case 204: F12RKV(0, 3, 16, 0x202); break; case 205: F12RKV(0, 3, 24, 0x202); break; case 206: F12RKV(0, 2, 20, 0x202); break; case 207: F12RKV(0, 5, 20, 0x202); break;
 #undef F12RKV
@@ -1821,16 +1866,16 @@ static int net_forward_launch(trexhip_ctx* ctx, const uint8_t* d_crops, int n, f
         // (a tail of short tickets was measured and dropped: the dynamic tickets already finish together, and every ticket's first pass produces 10 rows instead of 6)
         const int want = (n_pass + pk - 1) / pk;
 #define F12K(D_) hipLaunchKernelGGL((k_conv12_wpre<D_>), dim3(want < wgs ? want : wgs), dim3(256), W12Geom::LDS_BYTES, s, d_crops, net->w1h, net->b1, net->inv1h, \
-                           net->w2w, net->b2, net->v3, net->inv2w, net->d_ovf, n, net->d_ovf + 2, pk)
+                           net->w2w, net->b2, net->v3, net->inv2w, net->d_ovf, n, net->d_ovf + 2, pk, net->d_ovfc)
 #ifdef TREXHIP_DEV_KNOBS   // ablations: TREXHIP_F12_DBG = 1 no crop loads, 2 no conv1 MFMAs, 4 no P2 transform, 8 no production, 16 no epilogue, 32 no tap loop
         static const int f12_dbg = std::getenv("TREXHIP_F12_DBG") ? std::atoi(std::getenv("TREXHIP_F12_DBG")) : 0;
         switch (f12_dbg) { case 1: F12K(1); break; case 2: F12K(2); break; case 4: F12K(4); break; case 8: F12K(8); break; case 16: F12K(16); break; case 24: F12K(24); break; case 32: F12K(32); break; case 40: F12K(40); break; case 56: F12K(56); break; case 64: F12K(64); break;
-            case 128: hipLaunchKernelGGL((k_conv12_wpre<128>), dim3(want < wgs ? want : wgs), dim3(256), W12Geom::LDS_BYTES, s, d_crops, net->w1h, net->b1, net->inv1h, net->w2w, net->b2, net->v3, net->inv2w, net->d_ovf, n, net->d_ovf + 2, pk, reinterpret_cast<unsigned long long*>(ctx->d_cnt_px)); break;   // phase stamps -> trexhip_debug_read (tools/f12_stamps.py)
-            case 129: hipLaunchKernelGGL((k_conv12_wpre<128, 0x03>), dim3(want < wgs ? want : wgs), dim3(256), W12Geom::LDS_BYTES, s, d_crops, net->w1h, net->b1, net->inv1h, net->w2w, net->b2, net->v3, net->inv2w, net->d_ovf, n, net->d_ovf + 2, pk, reinterpret_cast<unsigned long long*>(ctx->d_cnt_px)); break;   // the same with the priorities of rounds 3-4
-            case 100: hipLaunchKernelGGL((k_conv12_wpre<0, 0x03>), dim3(want < wgs ? want : wgs), dim3(256), W12Geom::LDS_BYTES, s, d_crops, net->w1h, net->b1, net->inv1h, net->w2w, net->b2, net->v3, net->inv2w, net->d_ovf, n, net->d_ovf + 2, pk); break;
-            case 101: hipLaunchKernelGGL((k_conv12_wpre<0, 0x10>), dim3(want < wgs ? want : wgs), dim3(256), W12Geom::LDS_BYTES, s, d_crops, net->w1h, net->b1, net->inv1h, net->w2w, net->b2, net->v3, net->inv2w, net->d_ovf, n, net->d_ovf + 2, pk); break;
-            case 102: hipLaunchKernelGGL((k_conv12_wpre<0, 0x00>), dim3(want < wgs ? want : wgs), dim3(256), W12Geom::LDS_BYTES, s, d_crops, net->w1h, net->b1, net->inv1h, net->w2w, net->b2, net->v3, net->inv2w, net->d_ovf, n, net->d_ovf + 2, pk); break;
-            case 103: hipLaunchKernelGGL((k_conv12_wpre<0, 0x31>), dim3(want < wgs ? want : wgs), dim3(256), W12Geom::LDS_BYTES, s, d_crops, net->w1h, net->b1, net->inv1h, net->w2w, net->b2, net->v3, net->inv2w, net->d_ovf, n, net->d_ovf + 2, pk); break;
+            case 128: hipLaunchKernelGGL((k_conv12_wpre<128>), dim3(want < wgs ? want : wgs), dim3(256), W12Geom::LDS_BYTES, s, d_crops, net->w1h, net->b1, net->inv1h, net->w2w, net->b2, net->v3, net->inv2w, net->d_ovf, n, net->d_ovf + 2, pk, net->d_ovfc, reinterpret_cast<unsigned long long*>(ctx->d_cnt_px)); break;   // phase stamps -> trexhip_debug_read (tools/f12_stamps.py)
+            case 129: hipLaunchKernelGGL((k_conv12_wpre<128, 0x03>), dim3(want < wgs ? want : wgs), dim3(256), W12Geom::LDS_BYTES, s, d_crops, net->w1h, net->b1, net->inv1h, net->w2w, net->b2, net->v3, net->inv2w, net->d_ovf, n, net->d_ovf + 2, pk, net->d_ovfc, reinterpret_cast<unsigned long long*>(ctx->d_cnt_px)); break;   // the same with the priorities of rounds 3-4
+            case 100: hipLaunchKernelGGL((k_conv12_wpre<0, 0x03>), dim3(want < wgs ? want : wgs), dim3(256), W12Geom::LDS_BYTES, s, d_crops, net->w1h, net->b1, net->inv1h, net->w2w, net->b2, net->v3, net->inv2w, net->d_ovf, n, net->d_ovf + 2, pk, net->d_ovfc); break;
+            case 101: hipLaunchKernelGGL((k_conv12_wpre<0, 0x10>), dim3(want < wgs ? want : wgs), dim3(256), W12Geom::LDS_BYTES, s, d_crops, net->w1h, net->b1, net->inv1h, net->w2w, net->b2, net->v3, net->inv2w, net->d_ovf, n, net->d_ovf + 2, pk, net->d_ovfc); break;
+            case 102: hipLaunchKernelGGL((k_conv12_wpre<0, 0x00>), dim3(want < wgs ? want : wgs), dim3(256), W12Geom::LDS_BYTES, s, d_crops, net->w1h, net->b1, net->inv1h, net->w2w, net->b2, net->v3, net->inv2w, net->d_ovf, n, net->d_ovf + 2, pk, net->d_ovfc); break;
+            case 103: hipLaunchKernelGGL((k_conv12_wpre<0, 0x31>), dim3(want < wgs ? want : wgs), dim3(256), W12Geom::LDS_BYTES, s, d_crops, net->w1h, net->b1, net->inv1h, net->w2w, net->b2, net->v3, net->inv2w, net->d_ovf, n, net->d_ovf + 2, pk, net->d_ovfc); break;
             default: F12K(0); }
 #else
         F12K(0);
@@ -1911,17 +1956,21 @@ static int net_forward_launch(trexhip_ctx* ctx, const uint8_t* d_crops, int n, f
     // split-K planes of fc1 (summed in k_head): 10 keeps every CU busy at a few thousand crops; TREXHIP_FC1_KSPLIT overrides (dev)
     static const int ks_env = std::getenv("TREXHIP_FC1_KSPLIT") ? std::atoi(std::getenv("TREXHIP_FC1_KSPLIT")) : 0;
     // (25600 crops: 10 planes 344 + 72 us for fc1 + head, 5 planes 319 + 66, 4: 365, 8: 381, 2: 347)
-    const int ks1 = (ks_env > 0 && ks_env <= FC1_KSPLIT && 400 % ks_env == 0) ? ks_env : (n >= 12800 ? 5 : FC1_KSPLIT);
+    // (the number of planes must not depend on n -- 5 planes above 12800 crops gave the same crop bit-different probabilities in batches
+    // of 12799 and 12800; 10 always costs 31 us of a 9 ms step)
+    const int ks1 = (ks_env > 0 && ks_env <= FC1_KSPLIT && 400 % ks_env == 0) ? ks_env : FC1_KSPLIT;
     const bool split1 = mode == TREXHIP_CNN_FP16X3 && !(ctx->tune_conv_geom & 32);
     if (split1)
-        hipLaunchKernelGGL(k_fc1_split, dim3((n + 127) / 128, ks1), dim3(256), 0, s, net->act3, net->wf1h, net->bf1, net->fc1, n, 12800, net->invf1h, net->d_ovf);
+        hipLaunchKernelGGL(k_fc1_split, dim3((n + 127) / 128, ks1), dim3(256), 0, s, net->act3, net->wf1h, net->bf1, net->fc1, n, 12800, net->invf1h, net->d_ovf, net->d_ovfc);
     else
         hipLaunchKernelGGL(k_fc1, dim3((n + 31) / 32, FC1_KSPLIT), dim3(256), 0, s, net->act3, net->wf1, net->bf1, net->fc1, n, 12800, (const uint32_t*)nullptr);
     hipLaunchKernelGGL(k_head, dim3((n + 4 * HEAD_CPW - 1) / (4 * HEAD_CPW)), dim3(256), 0, s, net->fc1, net->lng, net->lnb, net->wf2t, net->bf2,
                        d_probs, d_logits, n, net->classes, (const uint32_t*)nullptr, split1 ? ks1 : FC1_KSPLIT);
     if (mode == TREXHIP_CNN_FP16X3) {
-        // guarded re-run with the bf16 split: every workgroup returns at once unless an activation left the fp16 range
-        const uint32_t* g = net->d_ovf;
+        // guarded re-run with the bf16 split: every workgroup returns at once unless an activation left the fp16 range; k_guard_plan lists the
+        // flagged crops (or orders the whole batch when the flag came from a kernel that does not know the crop) and the re-run follows its plan
+        hipLaunchKernelGGL(k_guard_plan, dim3(1), dim3(1024), 0, s, net->d_ovf, net->d_ovfc, n, net->d_ovf + 4);
+        const uint32_t* g = net->d_ovf + 4;
         if (pre) {      // the default chain has no fp32 activations: the re-run starts at the crops
             if (net->CH == 1) hipLaunchKernelGGL(k_conv1_mfma, dim3(n), dim3(256), 0, s, d_crops, net->w1h, net->b1, net->act1, net->inv1h, g);
             else              hipLaunchKernelGGL(k_conv1_mfma3, dim3(n), dim3(256), 0, s, d_crops, net->w1h, net->b1, net->act1, net->inv1h, g);
@@ -2039,6 +2088,17 @@ int trexhip_identify(trexhip_ctx* ctx, const uint8_t* crops, int32_t n, float* p
     if (rc) return rc;
     TH_CHECK_HIP(hipMemcpyAsync(probs, net->probs, (size_t)n * net->classes * 4, hipMemcpyDeviceToHost, ctx->stream));
     TH_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+    return TREXHIP_OK;
+}
+
+int trexhip_identify_guard_stats(trexhip_ctx* ctx, uint32_t* rerun_crops, uint32_t* whole_batch) {
+    if (!ctx || !ctx->net) { set_error("trexhip_identify_guard_stats: no context / weights not loaded"); return TREXHIP_E_INVALID; }
+    Net* net = static_cast<Net*>(ctx->net);
+    uint32_t plan[2] = {0, 0};
+    TH_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+    if (ctx->cnn_mode == TREXHIP_CNN_FP16X3) TH_CHECK_HIP(hipMemcpy(plan, net->d_ovf + 4, 8, hipMemcpyDeviceToHost));
+    if (rerun_crops) *rerun_crops = plan[1] == 1u ? plan[0] : 0u;
+    if (whole_batch) *whole_batch = plan[1] == 2u ? 1u : 0u;
     return TREXHIP_OK;
 }
 

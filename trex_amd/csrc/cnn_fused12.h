@@ -32,6 +32,7 @@ __global__ __launch_bounds__(256, 2) void k_conv12_wpre(const uint8_t* __restric
                                                         const uint4* __restrict__ wp /*[5][8][2][2][64] x 16 B*/, const float* __restrict__ bias,
                                                         uint8_t* __restrict__ v3, const float out_scale, uint32_t* __restrict__ overflow,
                                                         const int n_crops, uint32_t* __restrict__ pass_ctr, const int PK /* consecutive passes per ticket: the first one produces 10 rows, the others 6 */,
+                                                        uint8_t* __restrict__ crop_flags /* per-crop range flags (may be null) */,
                                                         unsigned long long* __restrict__ dbg_stamps = nullptr /* DBG & 128: cycles per phase of workgroups 0 and gridDim.x / 2 */) {
     using G = W2bGeom;
     using F = W12Geom;
@@ -55,6 +56,14 @@ __global__ __launch_bounds__(256, 2) void k_conv12_wpre(const uint8_t* __restric
     float* pbuf = reinterpret_cast<float*>(ldsb + G::PBUF_OFF);
     for (int i = tid; i < F::IMG_BYTES / 16; i += 256) reinterpret_cast<uint4*>(img)[i] = make_uint4(0, 0, 0, 0);   // the x padding stays zero
     bool ovf = false;
+    // the range guard is per crop: what was raised since the last call belongs to units [u_lo, u_hi] (V2 rows: 40 per crop, pooled rows: 20 per
+    // crop), at most two crops; flagging a neighbour too only means that it is re-run in the wider arithmetic as well
+    auto flag_crops = [&](const int u_lo, const int u_hi, const int per_crop) {
+        if (__any(ovf)) {
+            if (lane == 0) { if (crop_flags) { crop_flags[u_lo / per_crop] = 1; crop_flags[u_hi / per_crop] = 1; } atomicOr(overflow, 1u); }
+            ovf = false;
+        }
+    };
     // DBG & 128 (dev builds): thread 0 of two workgroups sums the cycles between the phase boundaries of its passes (tools/f12_stamps.py)
     unsigned long long st_sum[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, st_last = 0;
     bool st_on = false;                                                  // switched on behind the prologue
@@ -227,6 +236,7 @@ __global__ __launch_bounds__(256, 2) void k_conv12_wpre(const uint8_t* __restric
             __syncthreads();
             F12_STAMP(6);
             p1(nr, bf0);
+            flag_crops(c0 < total_rows ? c0 : total_rows - 1, c0 + nr - 1 < total_rows ? c0 + nr - 1 : total_rows - 1, S);
             F12_STAMP(7);
             __syncthreads();
             F12_STAMP(8);
@@ -373,6 +383,7 @@ __global__ __launch_bounds__(256, 2) void k_conv12_wpre(const uint8_t* __restric
                 }
             }
         }
+        { const int g0 = pass * G::RPP, g1 = g0 + G::RPP - 1; flag_crops(g0, g1 < total_pairs ? g1 : total_pairs - 1, S / 2); }
         F12_STAMP(2);
         __syncthreads();                                                  // the activations are in pbuf
         F12_STAMP(3);

@@ -42,6 +42,7 @@ __global__ __launch_bounds__(512) void k_conv12_rs(const uint8_t* __restrict__ c
                                                    const uint4* __restrict__ wp /*[5][8][2][2][64] x 16 B*/, const float* __restrict__ bias,
                                                    uint8_t* __restrict__ v3, const float out_scale, uint32_t* __restrict__ overflow,
                                                    const int n_crops, uint32_t* __restrict__ pass_ctr, const int PK /* consecutive passes per ticket */,
+                                                   uint8_t* __restrict__ crop_flags /* per-crop range flags (may be null) */,
                                                    unsigned long long* __restrict__ dbg_stamps = nullptr /* DBG & 128 (dev): cycles per stage of waves 0 and 4 of workgroup 0 */) {
     using G = W2bGeom;
     using F = W12RGeom;
@@ -66,6 +67,13 @@ __global__ __launch_bounds__(512) void k_conv12_rs(const uint8_t* __restrict__ c
     for (int i = tid; i < F::IMG_BYTES / 16; i += 512) reinterpret_cast<uint4*>(img)[i] = make_uint4(0, 0, 0, 0);   // the x padding stays zero
     if (tid == 0) *s_next = ((int)atomicAdd(pass_ctr, 1u) + (int)gridDim.x) * PK;
     float ovfm = 0.f;                                                    // the largest activation seen (all are >= 0 behind their ReLU): the fp16 range guard
+    // the range guard is per crop: what was raised since the last call belongs to units [u_lo, u_hi] (V2 rows: 40 per crop, pooled rows: 20 per crop)
+    auto flag_crops = [&](const int u_lo, const int u_hi, const int per_crop) {
+        if (__any(!(ovfm < 4368.0f))) {
+            if (lane == 0) { if (crop_flags) { crop_flags[u_lo / per_crop] = 1; crop_flags[u_hi / per_crop] = 1; } atomicOr(overflow, 1u); }
+            ovfm = 0.f;
+        }
+    };
     // DBG & 128 (dev builds): lane 0 of waves 0 (consumer) and 4 (producer) of workgroup 0 sum the cycles between the stage boundaries
     unsigned long long st_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_last = 0;
     const bool st_on = (DBG & 128) && dbg_stamps && blockIdx.x == 0 && (tid == 0 || tid == 256);
@@ -285,6 +293,7 @@ __global__ __launch_bounds__(512) void k_conv12_rs(const uint8_t* __restrict__ c
             p0_store(nr, px);
             RS_BAR();
             p1(nr);
+            flag_crops(c0, c0 + nr - 1, S);
             RS_BAR();
             p2(c0, nr);
             RS_BAR();
@@ -306,7 +315,7 @@ __global__ __launch_bounds__(512) void k_conv12_rs(const uint8_t* __restrict__ c
             RS_BAR();
             RS_STAMP(1);
             // S2 (beside taps 20-39): conv1
-            if (!(DBG & 8)) p1(nr0);
+            if (!(DBG & 8)) { p1(nr0); if (nr0 > 0) flag_crops(lo, lo + nr0 - 1 < total_rows ? lo + nr0 - 1 : total_rows - 1, S); }
             RS_STAMP(2);
             RS_BAR();
             RS_STAMP(3);
@@ -320,7 +329,7 @@ __global__ __launch_bounds__(512) void k_conv12_rs(const uint8_t* __restrict__ c
                 const int nr = hi - c0 < F::CHUNK ? hi - c0 : F::CHUNK;
                 if (!(DBG & 8)) { p0_load(c0, nr, px); p0_store(nr, px); }
                 RS_BAR();
-                if (!(DBG & 8)) p1(nr);
+                if (!(DBG & 8)) { p1(nr); flag_crops(c0, c0 + nr - 1 < total_rows ? c0 + nr - 1 : total_rows - 1, S); }
                 RS_BAR();
                 if (!(DBG & 8)) p2(c0, nr);
                 RS_BAR();
@@ -464,6 +473,7 @@ __global__ __launch_bounds__(512) void k_conv12_rs(const uint8_t* __restrict__ c
                     }
                 }
             }
+            { const int g0 = pass * G::RPP, g1 = g0 + G::RPP - 1; flag_crops(g0, g1 < total_pairs ? g1 : total_pairs - 1, S / 2); }
             if (have_next) RS_AOFF(next_pass);
             RS_STAMP(4);
             RS_BAR();                                                     // S3 | the next round

@@ -44,7 +44,7 @@ __device__ __forceinline__ float wsum(float v) {
     return v;
 }
 
-// sin / cos of the EFT phases: the same operations in the same order as oracle/trex_posture.c's det_sincosf (Cody-Waite reduction by pi/2 in three
+// sin / cos of the EFT phases: the same operations in the same order as the CPU restatement's det_sincosf (tests' checker) (Cody-Waite reduction by pi/2 in three
 // pieces, degree-7 / degree-8 polynomials on [-pi/4, pi/4]; this file is compiled with -ffp-contract=off): bit-identical to the CPU restatement,
 // which the library sincosf (and glibc's on the other side) was not -- the tail / head choice flipped at near-ties of the curvature peaks.
 __device__ __forceinline__ void det_sincosf(const float x, float& sn, float& cs) {
@@ -356,7 +356,7 @@ __global__ __launch_bounds__(256) void k_posture(const PostureCfg P, const trexh
         float cx = 0.f, cy = 0.f;
         for (int i = 0; i < n; ++i) { const float2 a = pts[i]; cx += a.x; cy += a.y; }
         cx /= (float)n; cy /= (float)n;
-        // cumulative arc length (wave scan over chunks of 64 segments + a running carry; oracle/trex_posture.c restates exactly this order):
+        // cumulative arc length (wave scan over chunks of 64 segments + a running carry; the tests' CPU restatement follows exactly this order):
         // s_t[i] = arc length at the END of segment i
         float run = 0.f;
         for (int i0 = 0; i0 < n; i0 += 64) {
@@ -385,7 +385,7 @@ __global__ __launch_bounds__(256) void k_posture(const PostureCfg P, const trexh
             }
             __builtin_amdgcn_wave_barrier();
             const float csE = s_curv[0], snE = s_curv[1];
-            // term i goes to partial sum i % 64 in order of i, the partials are combined by the xor butterfly (wsum): the oracle's order
+            // term i goes to partial sum i % 64 in order of i, the partials are combined by the xor butterfly (wsum): the order the CPU restatement follows too
             float sa = 0.f, sb = 0.f, sc = 0.f, sd = 0.f;
             for (int i = lane; i < n; i += 64) {
                 const float2 a = pts[i], q = pts[i + 1 == n ? 0 : i + 1];
