@@ -65,6 +65,7 @@ def build_parser():
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                     help="weak: --batch frames per GPU per step (default); strong: --batch frames per step in total, split between the GPUs")
     ap.add_argument("--force-all", action="store_true", help="run exactly the stages given on the command line instead of the preset of the named config")
+    ap.add_argument("--guard-trip", action="store_true", help="secondary row C4_guard_tripped: conv1 of the random-init network is scaled until a handful of the step's crops leave the fp16-piece range, so that the per-crop range guard re-runs them with the bf16x6 kernels inside every timed step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=16.0)
     ap.add_argument("--no-secondary", action="store_true", help="skip the short secondary runs (C2, C3, C5, host input, fp32, the N > 1 code path at N = 1, training step); their long records go to a '# bench_secondary:' line and gpurun_out/bench_secondary.json, one {value, frac} pair each to `configs` of the final line")
@@ -222,6 +223,44 @@ def measure(args, env):
     def run(k):
         return pipe.run(k, frames_ptr)
 
+    guard_info = None
+    if args.guard_trip and with_cnn:
+        # one step for the crops, then conv1 (and what follows it: the BN statistics, so that the later layers keep their scale) is scaled
+        # until between 1 and 64 crops of the step leave the range the fp16 pieces hold (>= 4368 behind conv1's ReLU)
+        n0 = run(1)
+        torch.cuda.synchronize()
+        ln0 = lanes[0]
+
+        def scaled(m):
+            st = {k: v.copy() for k, v in state.items()}
+            st["conv1.weight"] *= m; st["conv1.bias"] *= m; st["bn1.running_mean"] *= m
+            st["bn2.running_var"] = st["bn2.running_var"] * m * m
+            return weights.pack_blob(st, classes, channels=3 if rgb else 1)
+
+        def count(m):
+            ln0.seg.load_weights(scaled(m))
+            ln0.seg.set_identity_precision(3)
+            ln0.seg.identify_device(ln0.crops.data_ptr(), n0, ln0.probs.data_ptr())
+            return ln0.seg.guard_stats()
+
+        lo_m, hi_m = 1.0, None
+        m = 4.0
+        for _ in range(40):
+            c, whole = count(m)
+            if c == 0 and not whole:
+                lo_m = m
+                m = m * 4.0 if hi_m is None else 0.5 * (lo_m + hi_m)
+            elif whole or c > 64:
+                hi_m = m
+                m = 0.5 * (lo_m + hi_m)
+            else:
+                break
+        c, whole = count(m)
+        guard_info = {"conv1_scale": m, "rerun_crops_per_step": c, "whole_batch": whole, "crops_per_step": n0}
+        for ln in lanes:
+            ln.seg.load_weights(scaled(m))
+            ln.seg.set_identity_precision(3)
+
     n_blobs = run(args.warmup) if args.warmup else 0
 
     def barrier():
@@ -236,23 +275,39 @@ def measure(args, env):
     barrier()
     t0 = time.perf_counter()
     n_blobs = run(args.steps)
+    torch.cuda.synchronize()
+    dt_own = time.perf_counter() - t0          # this rank's own K steps, before it waits for the others
     barrier()
     dt = time.perf_counter() - t0
     dist_info = None
     if use_dist:
         # every rank's own clock around the same K steps: the job's time is the slowest rank's (the contract); the spread and rank 0's
         # extra (it alone receives the tables and copies the slab to its host) are reported beside it
-        mine = torch.zeros(world, device=dev, dtype=torch.float64)
+        mine = torch.zeros(2 * world, device=dev, dtype=torch.float64)
         mine[rank] = dt
+        mine[world + rank] = dt_own
         dist.all_reduce(mine, op=dist.ReduceOp.SUM)
-        per_rank = [float(x) for x in mine.tolist()]
-        dt = max(per_rank)
+        both = [float(x) for x in mine.tolist()]
+        dt = max(both[:world])                  # the job's time: the slowest rank's clock around the barriers (the contract)
+        per_rank = both[world:]                 # every rank's own clock, taken BEFORE the closing barrier: the spread and rank 0's extra are real
         others = per_rank[1:] or per_rank
         dist_info = {"ranks_seen": pipe.shared_comm.count_ranks() if pipe.shared_comm is not None else int(sum(1 for x in per_rank if x > 0)),
                      "ranks_seen_by": "all-reduce of 1 over libtrexhip's communicator" if pipe.shared_comm is not None else "torch.distributed",
                      "gather_bytes_per_step": (world - 1) * pipe.rows * pipe.rowlen * 4, "table_bytes_per_rank": pipe.rows * pipe.rowlen * 4,
                      "ms_per_step_min": min(per_rank) / args.steps * 1e3, "ms_per_step_max": max(per_rank) / args.steps * 1e3,
                      "rank0_extra_ms": (per_rank[0] - sum(others) / len(others)) / args.steps * 1e3}
+        if rank == 0 and with_cnn:
+            # what rank 0's matcher would read after the last step: the gathered slab merged into Tracker::add order (tracking/Tracker.cpp:586-587)
+            # must hold every frame of the step's block of world x B frames exactly once (n_ind rows each), ordered by frame
+            from trex_amd import dist as tdist
+            last = lanes[(args.steps - 1) % len(lanes)]
+            merged = tdist.merge_tables(last.table_host.numpy().view(np.uint32))
+            fr = merged[:, 0].astype(np.int64)
+            first = (args.steps - 1) * world * B
+            cnt = np.bincount(fr - first, minlength=world * B) if len(fr) and fr.min() >= first and fr.max() < first + world * B else np.zeros(1)
+            dist_info["merged"] = {"frames": int((cnt > 0).sum()), "frames_expected": world * B, "rows": int(len(merged)),
+                                   "every_frame_once": bool(len(cnt) == world * B and (cnt == n_ind).all()),
+                                   "tracker_order": bool((np.diff(fr) >= 0).all())}
     prof = {}
     for name in ("ROWS", "SEGMENT_ALL", "CONV2", "CONV3", "CNN_ALL", "CROPS", "POSTURE"):
         ms = cnt = 0
@@ -292,14 +347,23 @@ def measure(args, env):
         separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, corrected as MI355X_MICROARCH.md prescribes); only valid for the
         default C4 / 256-frame workload they were collected on, else null.  Counters cannot be read from inside this process."""
         try:
-            if args.config != "C4" or B != 256 or host_in or bgra_in or args.scaling != "weak":
+            if host_in or bgra_in or args.scaling != "weak":
                 return None
             import glob
-            files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_summary.json")))
-            j = json.load(open(files[-1]))
+            if args.config == "C4" and B == 256:
+                files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_summary.json")))
+                j = json.load(open(files[-1]))
+                for k, v in j["kernels"].items():
+                    if k.startswith(kernel_prefix):
+                        return v["hbm_bytes"]
+                return None
+            # the detect kernels of the other configurations at their default batch (profiles/rNN_pmc_detect_configs.json: FETCH / WRITE passes of
+            # `bench.py --config C --stages segment --force-all`); the bytes scale with the frames per launch
+            files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_detect_configs.json")))
+            j = json.load(open(files[-1]))[args.config]
             for k, v in j["kernels"].items():
-                if k.startswith(kernel_prefix):
-                    return v["hbm_bytes"]
+                if ("trexhip::" + k).startswith(kernel_prefix) or k.startswith(kernel_prefix.replace("trexhip::", "")):
+                    return v["hbm_bytes"] * B / j["frames_per_launch"]
         except Exception:
             pass
         return None
@@ -326,6 +390,9 @@ def measure(args, env):
     }
     if dist_info is not None:
         out["dist"] = dist_info
+    if guard_info is not None:
+        guard_info["rerun_crops_last_step"] = lanes[0].seg.guard_stats()[0]
+        out["range_guard"] = guard_info
     rows_traffic = pmc_traffic("trexhip::k_rows")
     pass_traffic = None
     if rows_traffic is not None:
@@ -537,6 +604,14 @@ SECONDARY = [
     ("C4_no_pipeline", {"pipeline": False}, 12, 2),
     ("C4_force_dist", {"force_dist": True}, 12, 3),
     ("C4_detect_only", {"stages": "segment", "force_all": True}, 20, 4),
+    # SURVEY 8(d) / BASELINE.md fix the resident batch of the contract at 64 frames (C5: 16); TRex's own detect_batch_size is a uchar that defaults
+    # to 1 (core/default_config.cpp:1113): the headline's 256 (C5: 64) is what 288 GB of HBM invites, these rows are what the contract and the
+    # reference's default give
+    ("C4_batch64", {"batch": 64}, 40, 6),
+    ("C5_batch16", {"config": "C5", "batch": 16}, 24, 4),
+    ("C4_batch1", {"batch": 1}, 300, 20),
+    # a handful of the step's 25600 crops out of the fp16-piece range: the per-crop range guard re-runs them (bf16x6) inside every step
+    ("C4_guard_tripped", {"guard_trip": True}, 12, 3),
 ]
 
 
@@ -570,7 +645,7 @@ def secondary(args, env):
             e["workload"] = r["config"]["workload"]
             e["input"] = r["config"].get("input")
             e["roofline"] = {k: r["roofline"].get(k) for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "avg_launch_us", "frac_basis", "whole_detect_pass_us", "whole_detect_pass_frac", "whole_detect_pass_frac_algorithmic_bytes", "pipelined_detect_pass_us", "pipelined_detect_pass_frac") if k in r["roofline"]}
-            for k in ("stage_us", "host_input", "dist"):
+            for k in ("stage_us", "host_input", "dist", "range_guard"):
                 if k in r:
                     e[k] = r[k]
             if name in ("C4_input_host_bgra", "C4_input_host_gray"):      # run-to-run spread of the host-input paths: two more short repetitions
@@ -657,7 +732,7 @@ def compact_line(out, sec):
     if "host_input" in out:
         o["host_input"] = _pick(out["host_input"], ("pcie_GB_per_s", "frac_of_pcie_peak", "host_copy_ms_per_frame", "dma_ms_per_frame"))
     if "dist" in out:
-        o["dist"] = {k: _r(v, 4) for k, v in out["dist"].items()}
+        o["dist"] = {k: (_r(v, 4) if not isinstance(v, dict) else v) for k, v in out["dist"].items()}
     cb = out.get("cpu_baseline")
     if cb:
         o["cpu_baseline"] = {**_pick(cb, ("value", "unit", "cores", "kind", "value_1_thread", "detect_frames_per_s", "identify_frames_per_s")), "sample": cb["sample"][:300]}
@@ -669,11 +744,21 @@ def compact_line(out, sec):
                 continue
             q = {"value": _r(e["value"]), "ms_per_step": _r(e["ms_per_step"])}
             rr = e.get("roofline") or {}
-            if rr.get("frac") is not None:
+            if rr.get("bound") == "hbm":
+                # detect-only runs: `frac` = the WHOLE pass (pixel kernel + labelling + gather) by the HBM bytes the counters saw, never the
+                # pixel kernel by algorithmic bytes (which passes 1: the background is re-read from L2, not from HBM); null without a PMC
+                # summary for the configuration
+                q["frac"] = _r(rr.get("whole_detect_pass_frac"), 3) if rr.get("whole_detect_pass_frac") is not None else None
+                if rr.get("frac") is not None and rr.get("frac_basis", "").startswith("measured"):
+                    q["rows_frac"] = _r(rr["frac"], 3)
+                if rr.get("whole_detect_pass_us") is not None:
+                    q["whole_detect_pass_us"] = _r(rr["whole_detect_pass_us"], 3)
+            elif rr.get("frac") is not None:
                 q["frac"] = _r(rr["frac"], 3)
-            for k in ("whole_detect_pass_us", "whole_detect_pass_frac", "whole_detect_pass_frac_algorithmic_bytes", "frac_split_peak"):
-                if rr.get(k) is not None:
-                    q[k] = _r(rr[k], 3)
+            if rr.get("frac_split_peak") is not None:
+                q["frac_split_peak"] = _r(rr["frac_split_peak"], 3)
+            if "range_guard" in e:
+                q["rerun_crops"] = e["range_guard"].get("rerun_crops_last_step")
             if "spread" in e:
                 q["spread"] = _r(e["spread"], 2)
                 q["min"], q["max"] = _r(min(e["repetitions"])), _r(max(e["repetitions"]))

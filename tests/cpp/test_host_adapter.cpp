@@ -320,6 +320,12 @@ int main(int argc, char** argv) {
     // --- full-size BGRA tiles in pageable memory: the host copy into the pinned ring and the DMA overlap (upload.hip) ---
     {
         const int BW = 2048, BH = 2048, NB = 24;
+        {   // detect_batch_size is a uchar: a batch outside 1 .. 255 is refused by name, never truncated
+            HipBackgroundSubtraction::Settings bad; bad.max_batch = 256;
+            bool threw = false; try { HipBackgroundSubtraction::init(bad, 64, 64); } catch (const std::exception& e) { threw = std::string(e.what()).find("detect_batch_size") != std::string::npos; } CHECK(threw);
+            bad.max_batch = 0;
+            threw = false; try { HipBackgroundSubtraction::init(bad, 64, 64); } catch (const std::exception&) { threw = true; } CHECK(threw);
+        }
         HipBackgroundSubtraction::Settings sb; sb.max_batch = NB;
         HipBackgroundSubtraction::init(sb, BW, BH);
         auto bgb = cmn::Image::Make(BH, BW, 1); std::memset(bgb->data(), 120, (size_t)BW * BH);

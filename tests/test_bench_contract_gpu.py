@@ -129,3 +129,24 @@ def test_strong_scaling_path_on_one_gpu(n):
     assert j["n_gpus"] == n and j["scaling"] == "strong" and j["config"]["frames_per_step_per_gpu"] == 16 // n
     assert j["config"]["gather"].startswith("libtrexhip") and j["dist"]["ranks_seen"] == n
     assert abs(j["value"] - 16 * 3 / (j["ms_per_step"] * 3e-3)) / j["value"] < 1e-4        # whole-job frames (the batch is split, not multiplied)
+
+
+def test_eight_rank_weak_launch_on_one_gpu_covers_every_frame_once():
+    # the driver's N = 8 line (weak scaling: B frames per rank and step) with every rank on GPU 0: the gather moves 7 tables to rank 0 per step,
+    # rank 0's merged table holds the step's 8 x B frames exactly once in Tracker::add order, and the N > 1 line is short and complete
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "3", "--warmup", "1", "--batch", "4", "--same-gpu",
+                          "--no-cpu-baseline"], capture_output=True, text=True, timeout=1200, cwd=ROOT,
+                         env={k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")})
+    if out.returncode != 0 and ("Duplicate GPU" in out.stderr or "No socket interfaces" in out.stderr):
+        pytest.skip("RCCL cannot run several ranks on one GPU here")
+    assert out.returncode == 0, out.stderr[-3000:]
+    last = [l for l in out.stdout.strip().splitlines() if l.startswith("{")][-1]
+    assert len(last) < 4096, len(last)
+    j = json.loads(last)
+    assert j["n_gpus"] == 8 and j["scaling"] == "weak" and j["config"]["frames_per_step_per_gpu"] == 4
+    d = j["dist"]
+    assert d["ranks_seen"] == 8 and d["gather_bytes_per_step"] == 7 * d["table_bytes_per_rank"]
+    m = d["merged"]
+    assert m["frames"] == m["frames_expected"] == 8 * 4 and m["every_frame_once"] and m["tracker_order"] and m["rows"] == 8 * 4 * 100
+    assert "roofline" in j and j["roofline"]["bound"] == "mfma"
+    assert abs(j["value"] - 8 * 4 * 3 / (j["ms_per_step"] * 3e-3)) / j["value"] < 1e-4      # whole-job frames / the slowest rank's time

@@ -167,3 +167,36 @@ def test_other_benchmarked_pipelines(name, config, B, kw):
     pipe.run(3, src.data_ptr(), on_batch=on_batch)
     pipe.close()
     assert sorted(done) == [0, 1, 2]
+
+
+def test_c4_pipeline_ten_steps_reproduce_bit_for_bit():
+    """The stress leg of round 5: ten pipelined C4 steps (both lanes, the same resident frames).  Every step's probabilities -- all 25600 rows,
+    ordered by frame -- must equal the first step's bit for bit, and the range guard must stay quiet: a schedule hazard in the large-batch
+    kernels (round 4's accumulator reads, round 5's v_max3 on MFMA results) shows up as a step that differs."""
+    B, classes, n_ind, steps = 256, 100, 100, 10
+    W, H = synth.CONFIGS["C4"][:2]
+    frames, bg = synth.batch_torch("C4", B, "cuda")
+    st = weights.synthetic_state(classes, 4242)
+    pipe = Pipeline(W, H, n_ind, B, classes, bg, weights.pack_blob(st, classes))
+    first = {}
+
+    def on_batch(step, ln):
+        res = ln.res
+        n = int(res.total_blobs)
+        assert n == n_ind * B
+        assert ln.seg.guard_stats() == (0, False), step
+        info = capi._from_addr(res.frames, res.n_frames, capi.INFO_DTYPE)
+        blobs = capi._from_addr(res.blobs, res.total_blobs, capi.BLOB_DTYPE)
+        probs = ln.probs[:n].cpu().numpy()
+        by_frame = np.stack([probs[int(fi["blob_begin"]):int(fi["blob_begin"]) + n_ind] for fi in info])
+        # the blob records too (the labelling workgroup gathers its own frame's blobs behind a fence + barrier: every step must agree)
+        rec = np.stack([np.stack([blobs[name][int(fi["blob_begin"]):int(fi["blob_begin"]) + n_ind].astype(np.int64)
+                                  for name in ("n_pixels", "bid", "m10", "m01", "m11", "sp", "spx", "x0", "y0", "x1", "y1")]) for fi in info])
+        if not first:
+            first["p"], first["b"] = by_frame, rec
+        else:
+            assert by_frame.tobytes() == first["p"].tobytes(), (step, float(np.abs(by_frame - first["p"]).max()))
+            assert np.array_equal(rec, first["b"]), step
+
+    pipe.run(steps, frames.data_ptr(), on_batch=on_batch)
+    pipe.close()

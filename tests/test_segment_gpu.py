@@ -277,6 +277,31 @@ def test_live_settings_take_effect_on_the_next_call():
     seg.close()
 
 
+def test_live_update_between_a_segment_call_and_its_crops_leaves_the_batch_alone():
+    # trexhip_update_params used to rewrite the configuration the downstream calls of the ALREADY segmented batch read: after a live
+    # image_invert change the crops of that batch came out with the new inversion and disagreed with its pixel arrays.  The batch keeps its own.
+    fr, bg = synth.batch("C2", 1)
+    n, H, W = fr.shape
+    seg = capi.Segmenter(capi.default_params(W, H, max_batch=1))
+    seg.set_background(bg)
+    d = torch.from_numpy(fr).cuda()
+    seg.segment_device(d.data_ptr(), 1)
+    r = seg.fetch()[0]
+    nb = len(r.blobs)
+    a = torch.zeros((nb, 80, 80), dtype=torch.uint8, device="cuda"); b = torch.zeros_like(a)
+    seg.crops_device(a.data_ptr(), nb)
+    seg.update_params(image_invert=1)                     # takes effect from the NEXT segment call
+    seg.crops_device(b.data_ptr(), nb)
+    seg.synchronize()
+    assert torch.equal(a, b)
+    want = np.stack([oracle.crop_none(fr[0], bg, bb, r.runs) for bb in r.blobs])
+    assert np.array_equal(a.cpu().numpy(), want)
+    seg.segment_device(d.data_ptr(), 1)                   # ... and from then on it does
+    r2 = seg.fetch()[0]
+    assert_frame_equal(r2, fr[0], bg, image_invert=1)
+    seg.close()
+
+
 def test_errors():
     p = capi.default_params(64, 64)
     seg = capi.Segmenter(p)

@@ -81,6 +81,7 @@ int check_colour_difference(trexhip_ctx* ctx, int difference, const char* who);
 int launch_crops(trexhip_ctx* ctx, uint8_t* d_crops, int n, int OW, int OH, int diff_mode) {
     if (n <= 0) return TREXHIP_OK;
     SegCfg c = ctx->cfg;
+    c.invert = ctx->batch_invert; c.zero_bg = ctx->batch_zero_bg;
     c.B = ctx->last_n;
     stage_begin(ctx, TREXHIP_STAGE_CROPS);
     hipLaunchKernelGGL(k_crops_none, dim3(n), dim3(256), 0, ctx->stream, c, ctx->d_frames, ctx->d_bg, ctx->d_info,
@@ -662,6 +663,7 @@ static int ensure_warp(trexhip_ctx* ctx, int n) {
 // the warp itself, from the per-blob inverse maps in ctx->d_warp
 int launch_crops_warp_maps(trexhip_ctx* ctx, uint8_t* d_crops, int n, int OW, int OH, int diff_mode) {
     SegCfg c = ctx->cfg;
+    c.invert = ctx->batch_invert; c.zero_bg = ctx->batch_zero_bg;
     c.B = ctx->last_n;
     stage_begin(ctx, TREXHIP_STAGE_CROPS);
     hipLaunchKernelGGL(k_crops_warp, dim3(n), dim3(256), 0, ctx->stream, c, ctx->d_frames, ctx->d_bg, ctx->d_info, ctx->d_blob_frame,

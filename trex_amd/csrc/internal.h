@@ -99,6 +99,8 @@ struct trexhip_ctx {
     hipStream_t stream = nullptr;
     bool has_bg = false;
     int last_n = 0;
+    int batch_invert = 0, batch_zero_bg = 0;      // image_invert / zero_is_background the LAST segmented batch was taken with: its crops, re-threshold and
+                                                  // split search keep them although trexhip_update_params may have changed the live settings since
     bool fetched = true;
 
     // device memory (layout: DESIGN.md "Data layout in HBM")

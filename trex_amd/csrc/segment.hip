@@ -1213,7 +1213,10 @@ __global__ __launch_bounds__(1024) void k_ccl_lds(const SegCfg c, uint32_t* __re
     if (own_frames) {
         // gray pixel arrays: the frame's blobs are gathered right here (pixels, integer moment sums, bounding box, bid) by the 16 waves of this
         // workgroup, two blobs per wave and step -- the records and lines written above are this workgroup's own (visible behind the barrier),
-        // the frame and its bases are known: no second launch, no look-ups
+        // the frame and its bases are known: no second launch, no look-ups.  The records and lines were written to GLOBAL memory by other waves of
+        // this workgroup: a workgroup-scope fence in front of the barrier orders those stores before the loads below (the plain
+        // barrier alone relied on the CU's L1 and on the compiler not moving the loads)
+        __threadfence_block();
         __syncthreads();
         gather_blobs<false, 32>(c, 0, own_frames, info, blob_frame, blobs, out_runs, own_pixels, 0u, 0xffffffffu, nullptr, 0, 0,
                                 bb + (uint32_t)(tid >> 6) * 2u, 32u, bb + kept, f, rbeg, pb);
@@ -1516,6 +1519,7 @@ static void launch_rows(int nch, dim3 grid, hipStream_t s, const uint8_t* frames
 int launch_segment(trexhip_ctx* ctx, const uint8_t* d_frames, int n) {
     SegCfg c = ctx->cfg;
     c.B = n;
+    ctx->batch_invert = c.invert; ctx->batch_zero_bg = c.zero_bg;      // the batch's own copy: downstream calls on this batch use it
     hipStream_t s = ctx->stream;
     const int H = c.H, W = c.W;
     const int nch = (W + 1023) / 1024;
@@ -1627,6 +1631,7 @@ int launch_segment(trexhip_ctx* ctx, const uint8_t* d_frames, int n) {
 
 int launch_pending(trexhip_ctx* ctx) {
     SegCfg c = ctx->cfg;
+    c.invert = ctx->batch_invert; c.zero_bg = ctx->batch_zero_bg;
     const int n = ctx->last_n;
     c.B = n;
     hipStream_t s = ctx->stream;
@@ -1772,6 +1777,7 @@ __global__ __launch_bounds__(256) void k_link2(const SegCfg c, const uint32_t* _
 int launch_rethreshold(trexhip_ctx* ctx, int thr, int method, const double* ranges, int n_ranges, const int32_t* d_blob_thr) {
     Pass2& q = ctx->pass2;
     SegCfg c = ctx->cfg;
+    c.invert = ctx->batch_invert; c.zero_bg = ctx->batch_zero_bg;
     const int n = ctx->last_n;
     c.B = n;
     c.n_ranges = n_ranges;

@@ -307,7 +307,7 @@ __global__ __launch_bounds__(64) void k_split_search(const SplitCfg C, const uin
 int launch_split_search(trexhip_ctx* ctx, const trexhip_split_params* sp, int method, const int32_t* d_presumed, int n_blobs, int32_t* d_thr,
                         trexhip_split_info* d_info) {
     SplitCfg C = {};
-    C.W = ctx->cfg.W; C.H = ctx->cfg.H; C.B = ctx->last_n; C.invert = ctx->cfg.invert; C.slack = ctx->cfg.slack; C.method = method;
+    C.W = ctx->cfg.W; C.H = ctx->cfg.H; C.B = ctx->last_n; C.invert = ctx->batch_invert; C.slack = ctx->cfg.slack; C.method = method;
     C.initial_threshold = (sp->calculate_posture ? max(sp->track_threshold, sp->track_posture_threshold) : sp->track_threshold) + 1;   // :512
     C.algorithm = sp->algorithm; C.n_ranges = sp->n_ranges;
     C.sqcm = ctx->cfg.sqcm; C.max_shrink = sp->blob_split_max_shrink; C.global_shrink = sp->blob_split_global_shrink_limit;

@@ -24,6 +24,7 @@
 #include <cstring>
 #include <thread>
 #include <shared_mutex>
+#include <stdexcept>
 #include <string>
 #include "../../include/trexhip.h"
 
@@ -64,6 +65,10 @@ struct HipBackgroundSubtraction {
         std::unique_lock g(d.gpu_mutex);
         if (d.ctx) { trexhip_destroy(d.ctx); d.ctx = nullptr; }
         if (d.ctx2) { trexhip_destroy(d.ctx2); d.ctx2 = nullptr; }
+        // TRex's detect_batch_size is a uchar (core/default_config.cpp:1113, default 1): a batch beyond 255 tiles cannot be asked for by the
+        // reference's settings system, and a Settings object that carries more was filled by hand -- refuse it by name instead of truncating
+        if (s.max_batch < 1 || s.max_batch > 255)
+            throw std::invalid_argument("HipBackgroundSubtraction::init: max_batch = " + std::to_string(s.max_batch) + " is outside detect_batch_size's range (uchar: 1 .. 255)");
         d.settings = s;
         trexhip_params p;
         trexhip_default_params(&p, (int32_t)width, (int32_t)height);
