@@ -27,11 +27,11 @@ for case in range(n_cases):
     if rng.random() < 0.3: kw["midline_walk_offset"] = float(rng.choice([0.01, 0.05, 0.1, 0.2, 0.45]))
     try:
         res, outline, segs, info = run_posture(fr[None], bg, max_points=1024, **kw)
-        n_cmp, n_tie = compare(res, outline, segs, info, oracle.posture_params(max_points=1024, **kw), max_heads=1.0)      # tie-aware tail rule (tests/test_posture_gpu.py); head ambiguities are counted
+        n_cmp, n_tie = compare(res, outline, segs, info, oracle.posture_params(max_points=1024, **kw))      # round 5: exact equality (outline, tail, head, segments)
         total += n_cmp; ties += n_tie
     except AssertionError as e:
         import traceback
         fails += 1
         tb = traceback.extract_tb(e.__traceback__)[-1]
         print("FAIL case", case, kw, "line", tb.lineno, tb.line, str(e)[:200], flush=True)
-print("cases", n_cases, "blobs compared", total, "of them ties of the two largest curvature peaks (either tail accepted)", ties, "same tail / other head", getattr(compare, "heads", 0), "failures", fails)
+print("cases", n_cases, "blobs compared bit for bit (outline, tail, head, midline segments)", total, "failures", fails)

@@ -6,7 +6,7 @@ N = int(sys.argv[1]) if len(sys.argv) > 1 else 25600
 st = weights.synthetic_state(100, 31)
 crops = torch.from_numpy(np.tile(weights.synthetic_crops(256, 3), (N // 256 + 1, 1, 1, 1))[:N]).cuda()
 out = {}
-for name, geom in (("two kernels", 1 << 28), ("fused", (1 << 29) if os.environ.get("TREXHIP_F12_RS") else 0)):
+for name, geom in (("two kernels", 1 << 28), ("fused", (1 << 29) if os.environ.get("TREXHIP_F12_RS") else ((1 << 30) if os.environ.get("TREXHIP_F12_OLD") else 0))):
     os.environ["TREXHIP_CONV_GEOM"] = str(geom)
     seg = capi.Segmenter(capi.default_params(64, 64, max_batch=1)); seg.load_weights(weights.pack_blob(st, 100))
     seg.set_identity_precision(3)

@@ -1827,10 +1827,12 @@ static int net_forward_launch(trexhip_ctx* ctx, const uint8_t* d_crops, int n, f
                                      : n * (ConvGeomB<CI_, CO_, S_, ROWS_, SplitK<KIND_>::NP, CIC_>::BPC)),                                          \
                        dim3(512), (ConvGeomB<CI_, CO_, S_, ROWS_, SplitK<KIND_>::NP, CIC_>::LDS_BYTES), s, in_, w_, b_, out_, sc_, net->d_ovf, guard_, \
                        n * (ConvGeomB<CI_, CO_, S_, ROWS_, SplitK<KIND_>::NP, CIC_>::BPC))
-    if (fused12 && (ctx->tune_conv_geom & (1 << 29))) {
-        // TREXHIP_CONV_GEOM bit 29: the role-split form (cnn_fused12rs.h): one workgroup of 8 waves per CU, consumer waves (tap loop, output
-        // transform) beside producer waves (V3 transform of the previous pass, V2 rows of the next).  Bit-identical, the same speed as the default
-        // (3.90-3.98 against 3.88-3.91 ms per 25600 crops, profiles/r05_rs_ablation.txt): kept as the base for the next step
+    // the role-split form (cnn_fused12rs.h): one workgroup of 8 waves per CU, consumer waves (tap loop, output transform) beside producer waves (V3
+    // transform of the previous pass, V2 rows of the next), the first 15 taps' weight fragments resident in LDS.  Bit-identical to the
+    // two-workgroups-per-CU kernel below and 6 % faster at 25600 crops (3.81 against 4.05 ms on one box); batches that do not give every CU a few
+    // passes keep the older kernel (1000 crops: 0.207 against 0.196 ms).  TREXHIP_CONV_GEOM bit 29 forces the role-split kernel, bit 30 the older one
+    const bool role_split = fused12 && !(ctx->tune_conv_geom & (1 << 30)) && ((ctx->tune_conv_geom & (1 << 29)) || n >= 3200);
+    if (role_split) {
         const int n_pass = (n * 20 + W2bGeom::RPP - 1) / W2bGeom::RPP;
         const int wgs = ctx->n_cus;
         static const int pk_env = std::getenv("TREXHIP_F12_PK") ? std::atoi(std::getenv("TREXHIP_F12_PK")) : 0;

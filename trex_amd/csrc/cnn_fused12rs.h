@@ -22,18 +22,31 @@
 // know to be canonical); exact, so results do not change.  ONLY for operands written by ordinary VALU instructions: an MFMA result read by
 // inline asm is not padded by the hazard recognizer (MI355X guide 5.7) -- round 5 learnt that the hard way
 __device__ __forceinline__ float rs_max3(const float a, const float b, const float c) { float r; asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
+__device__ __forceinline__ float rs_max3z(const float a, const float b) { float r; asm("v_max3_f32 %0, %1, %2, 0" : "=v"(r) : "v"(a), "v"(b)); return r; }      // max(a, b, 0)
 __device__ __forceinline__ float rs_max(const float a, const float b) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
 
 struct W12RGeom {
     using G = W2bGeom;
     static constexpr int CHUNK = 6;
     static constexpr int IMG_PITCH = 88, IMG_ROWS = CHUNK * 6;
-    static constexpr int PBE_OFF = G::PBUF_OFF;                         // the pass's 3 x 20 x 64 pooled activations of conv2 (fp32)
-    static constexpr int PBP_OFF = PBE_OFF + G::PBUF, PBP_BYTES = CHUNK * 40 * 16 * 4;
+    // pbufE: the pass's 3 x 20 x 64 pooled activations of conv2 (fp32), rows padded by two zero pixels on either side: the V3 transform's 8-pixel
+    // windows read their halo as plain loads (no clamps, no selects); pbufP: conv1's pooled activations of a chunk, rows of 40 pixels in a pitch of
+    // 48 (4 zero pixels left and right), 16 channels
+    static constexpr int PEP = 24, PPP = 48;
+    static constexpr int PBE_OFF = G::PBUF_OFF, PBE_BYTES = G::RPP * PEP * 64 * 4;
+    static constexpr int PBP_OFF = PBE_OFF + PBE_BYTES, PBP_BYTES = CHUNK * PPP * 16 * 4;
     static constexpr int IMG_OFF = PBP_OFF + PBP_BYTES, IMG_BYTES = IMG_ROWS * IMG_PITCH * 2;
     static constexpr int CTL_OFF = IMG_OFF + IMG_BYTES;                 // the next ticket's first pass
-    static constexpr int LDS_BYTES = CTL_OFF + 16;
-    static_assert(LDS_BYTES <= 160 * 1024 && CTL_OFF % 16 == 0, "one workgroup per CU");
+    // the weight fragments of NRES of the 40 taps stay in LDS for the whole kernel (4 KB per tap: 2 pieces x 2 k-octets x 64 output channels x
+    // 16 B): the consumer waves' weight stream asks for 84 B/clk of the CU's 64 B/clk vector-memory path, and the producers' V3 stores ride on it too
+    static constexpr int WRES_OFF = CTL_OFF + 16, WTAP = 4096;
+    static constexpr int NRES = (160 * 1024 - WRES_OFF) / WTAP;
+    static constexpr int LDS_BYTES = WRES_OFF + NRES * WTAP;
+    static_assert(LDS_BYTES <= 160 * 1024 && CTL_OFF % 16 == 0 && NRES >= 8 && NRES <= 40, "one workgroup per CU");
+    // the FIRST taps of a pass are the resident ones: they run beside the producers' V3 stores and crop loads (stage 1), the later taps beside
+    // conv1, which touches no vector memory (stage 2) -- spread evenly over the loop the same 15 taps bought 10 % of stage 1, not 40
+    static constexpr bool resident(const int tau) { return tau < NRES; }
+    static constexpr int res_slot(const int tau) { return tau; }
 };
 
 template <int DBG = 0, int BD = 3, int TSPLIT = 20, int PRIO = 0x202>      // TSPLIT: taps in front of the first barrier of a round; PRIO: s_setprio of (producer, tap loop, output transform) as hex digits
@@ -65,6 +78,14 @@ __global__ __launch_bounds__(512) void k_conv12_rs(const uint8_t* __restrict__ c
     float* pbe = reinterpret_cast<float*>(ldsb + F::PBE_OFF);
     float* pbp = reinterpret_cast<float*>(ldsb + F::PBP_OFF);
     for (int i = tid; i < F::IMG_BYTES / 16; i += 512) reinterpret_cast<uint4*>(img)[i] = make_uint4(0, 0, 0, 0);   // the x padding stays zero
+    for (int i = tid; i < (F::PBE_BYTES + F::PBP_BYTES) / 16; i += 512) reinterpret_cast<uint4*>(ldsb + F::PBE_OFF)[i] = make_uint4(0, 0, 0, 0);      // the halo pixels stay zero
+    // resident weight fragments: tap tau -> slot res_slot(tau); a slot holds the tap's [piece][k-octet h][co] x 16 B exactly as the weight image does
+    for (int i = tid; i < 40 * (F::WTAP / 16); i += 512) {
+        const int tau = i / (F::WTAP / 16), u = i - tau * (F::WTAP / 16);
+        const int pos = (tau / 20) == 0 ? (tau % 4 == 3 ? 7 : tau % 4) : 3 + tau % 4;
+        const int slot = F::res_slot(tau);
+        if (F::resident(tau)) reinterpret_cast<uint4*>(ldsb + F::WRES_OFF + slot * F::WTAP)[u] = wp[(size_t)(((tau % 20) / 4) * 8 + pos) * G::BV + u];
+    }
     if (tid == 0) *s_next = ((int)atomicAdd(pass_ctr, 1u) + (int)gridDim.x) * PK;
     float ovfm = 0.f;                                                    // the largest activation seen (all are >= 0 behind their ReLU): the fp16 range guard
     // the range guard is per crop: what was raised since the last call belongs to units [u_lo, u_hi] (V2 rows: 40 per crop, pooled rows: 20 per crop)
@@ -199,14 +220,17 @@ __global__ __launch_bounds__(512) void k_conv12_rs(const uint8_t* __restrict__ c
 #pragma unroll
                     for (int pos = 0; pos < 2; ++pos) {
                         const int w = tile * 8 + 2 * q4 + pos;
-                        // (fmaxf, not the asm helpers: these operands come straight out of MFMAs, and the hazard recognizer pads MFMA -> VALU reads only
-                        // for instructions it can see -- with v_max3 in inline asm the reads raced the matrix pipe and the range guard fired at random)
-                        const float m0 = fmaxf(fmaxf(acc[u][0][2 * pos], acc[u][0][2 * pos + 1]), fmaxf(acc[u][1][2 * pos], acc[u][1][2 * pos + 1]));
-                        const float m1 = fmaxf(fmaxf(acc[u][2][2 * pos], acc[u][2][2 * pos + 1]), fmaxf(acc[u][3][2 * pos], acc[u][3][2 * pos + 1]));
-                        const float v0 = fmaxf(m0 * inv_scale1 + bz1, 0.f), v1 = fmaxf(m1 * inv_scale1 + bz1, 0.f);
+                        // bias + ReLU per element first (v_fma_f32 written by the compiler: it pads the MFMA -> VALU read), then the pool as two
+                        // v_max3: relu(max(x) s + b) = max(relu(x s + b)) exactly (s > 0, rounding is monotone), 6 instructions instead of 9.
+                        // (the asm helpers only ever see VALU results: an MFMA result read by inline asm is not padded by the hazard recognizer)
+                        const float t0 = acc[u][0][2 * pos] * inv_scale1 + bz1, t1 = acc[u][0][2 * pos + 1] * inv_scale1 + bz1;
+                        const float t2 = acc[u][1][2 * pos] * inv_scale1 + bz1, t3 = acc[u][1][2 * pos + 1] * inv_scale1 + bz1;
+                        const float t4 = acc[u][2][2 * pos] * inv_scale1 + bz1, t5 = acc[u][2][2 * pos + 1] * inv_scale1 + bz1;
+                        const float t6 = acc[u][3][2 * pos] * inv_scale1 + bz1, t7 = acc[u][3][2 * pos + 1] * inv_scale1 + bz1;
+                        const float v0 = rs_max3z(rs_max3(t0, t1, t2), t3), v1 = rs_max3z(rs_max3(t4, t5, t6), t7);
                         if (tile < n_tiles && w < n_win) {
                             ovfm = rs_max3(ovfm, v0, v1);
-                            const int px = 2 * w;                                // = v * 40 + x: 20 windows of 2 pooled pixels per row
+                            const int vr = w / 20, px = vr * F::PPP + 4 + 2 * (w - vr * 20);     // row of the chunk, padded pixel index (even)
                             float* o = pbp + ((px & ~15) | ((px & 3) << 2) | ((px >> 2) & 3)) * 16 + r;
                             o[0] = v0;
                             o[64] = v1;                                          // px + 1: bit 0 of the pixel is bit 2 of the slot
@@ -224,12 +248,8 @@ __global__ __launch_bounds__(512) void k_conv12_rs(const uint8_t* __restrict__ c
                 float4 d[8];
 #pragma unroll
                 for (int k = 0; k < 8; ++k) {
-                    const int x = 4 * tx - 2 + k;
-                    d[k] = make_float4(0.f, 0.f, 0.f, 0.f);
-                    if (x >= 0 && x < 40) {
-                        const int px = v * 40 + x;
-                        d[k] = *reinterpret_cast<const float4*>(pbp + ((px & ~15) | ((px & 3) << 2) | ((px >> 2) & 3)) * 16 + quad * 4);
-                    }
+                    const int px = v * F::PPP + 4 * tx + 2 + k;                  // x = 4 tx - 2 + k in the padded row: the halo pixels are zeros
+                    d[k] = *reinterpret_cast<const float4*>(pbp + ((px & ~15) | ((px & 3) << 2) | ((px >> 2) & 3)) * 16 + quad * 4);
                 }
                 float ua[8], ub[8], uc[8], ud[8];
                 wino_bt(d[0].x, d[1].x, d[2].x, d[3].x, d[4].x, d[5].x, d[6].x, d[7].x, ua);
@@ -257,17 +277,9 @@ __global__ __launch_bounds__(512) void k_conv12_rs(const uint8_t* __restrict__ c
                 const int gp = ep * G::RPP + rp;                            // = q3: pooled row of the batch
                 if (gp < total_pairs) {
                     float4 d[8];
+                    const float* src = pbe + (rp * F::PEP + 4 * tx) * 64 + quad * 4;      // x = 4 tx - 2 in the padded row: the halo pixels are zeros
 #pragma unroll
-                    for (int k = 0; k < 8; ++k) {
-                        const int x = 4 * tx - 2 + k;
-                        const int xc = x < 0 ? 0 : (x > 19 ? 19 : x);
-                        d[k] = *reinterpret_cast<const float4*>(pbe + (rp * 20 + xc) * 64 + quad * 4);
-                    }
-#pragma unroll
-                    for (int k = 0; k < 8; ++k) {
-                        const int x = 4 * tx - 2 + k;
-                        if (x < 0 || x >= 20) d[k] = make_float4(0.f, 0.f, 0.f, 0.f);
-                    }
+                    for (int k = 0; k < 8; ++k) d[k] = *reinterpret_cast<const float4*>(src + k * 64);
                     float ua[8], ub[8], uc[8], ud[8];
                     wino_bt(d[0].x, d[1].x, d[2].x, d[3].x, d[4].x, d[5].x, d[6].x, d[7].x, ua);
                     wino_bt(d[0].y, d[1].y, d[2].y, d[3].y, d[4].y, d[5].y, d[6].y, d[7].y, ub);
@@ -359,8 +371,19 @@ __global__ __launch_bounds__(512) void k_conv12_rs(const uint8_t* __restrict__ c
 #define W2_BOFF(tau_) (((((tau_) % 20) / 4) * 8 + W2_POS(tau_)) * G::BV * 16)
         // the weight fragments of taps 0 .. BD - 1 are the same for every pass: the last taps of a pass fetch them for the next one
         uint4 bq[8][2];
+        const uint8_t* wres = ldsb + F::WRES_OFF + boff;
+#define RS_WFETCH(dst_, tau_)                                                                                                    \
+        do {                                                                                                                     \
+            if (F::resident(tau_)) {                                                                                             \
+                dst_[0] = *reinterpret_cast<const uint4*>(wres + F::res_slot(tau_) * F::WTAP);                                   \
+                dst_[1] = *reinterpret_cast<const uint4*>(wres + F::res_slot(tau_) * F::WTAP + 2 * CO * 16);                     \
+            } else {                                                                                                             \
+                dst_[0] = buf_load16(wrs, boff, W2_BOFF(tau_));                                                                  \
+                dst_[1] = (DBG & 64) ? dst_[0] : buf_load16(wrs, boff, W2_BOFF(tau_) + 2 * CO * 16);                             \
+            }                                                                                                                    \
+        } while (0)
 #pragma unroll
-        for (int t = 0; t < BD; ++t) { bq[t][0] = buf_load16(wrs, boff, W2_BOFF(t)); bq[t][1] = (DBG & 64) ? bq[t][0] : buf_load16(wrs, boff, W2_BOFF(t) + 2 * CO * 16); }
+        for (int t = 0; t < BD; ++t) RS_WFETCH(bq[t], t);
         // A-operand byte offsets of this lane's tile for pass `ps_`: per kernel row the row slot (out-of-crop rows -> the zero row), per position of a
         // group the rotated unit.  Computed for the NEXT pass behind the output transform, off the path to the first tap
         int aoff[5][4];
@@ -406,11 +429,7 @@ __global__ __launch_bounds__(512) void k_conv12_rs(const uint8_t* __restrict__ c
             do {                                                                                                                 \
                 const int tl = (tau) % 20;                                                                                       \
                 if ((tau) + 1 < 40) RS_AREAD(af[((tau) + 1) % 2], (tau) + 1);                                                    \
-                {                                                                                                                \
-                    const int wt = W2_BOFF(((tau) + BD) % 40);                                                                   \
-                    bq[((tau) + BD) % 8][0] = buf_load16(wrs, boff, wt);                                                         \
-                    bq[((tau) + BD) % 8][1] = (DBG & 64) ? bq[((tau) + BD) % 8][0] : buf_load16(wrs, boff, wt + 2 * CO * 16);    \
-                }                                                                                                                \
+                RS_WFETCH(bq[((tau) + BD) % 8], ((tau) + BD) % 40);                                                              \
                 const int p = W2_POS(tau);                                                                                       \
                 const f16x8 b1 = __builtin_bit_cast(f16x8, bq[(tau) % 8][0]), b2 = __builtin_bit_cast(f16x8, bq[(tau) % 8][1]); \
                 const f16x8 a1 = __builtin_bit_cast(f16x8, af[(tau) % 2][0]), a2 = __builtin_bit_cast(f16x8, af[(tau) % 2][1]); \
@@ -467,7 +486,7 @@ __global__ __launch_bounds__(512) void k_conv12_rs(const uint8_t* __restrict__ c
                         const int rp = s / G::TPP, tx = (s - rp * G::TPP) >> 1;
                         const float a0 = fmaxf(v0 * out_scale + bz, 0.f), a1 = fmaxf(v1 * out_scale + bz, 0.f);
                         ovfm = rs_max3(ovfm, a0, a1);
-                        float* o = pbe + (rp * 20 + 2 * tx) * 64 + co;
+                        float* o = pbe + (rp * F::PEP + 2 + 2 * tx) * 64 + co;
                         o[0] = a0;
                         o[64] = a1;
                     }
@@ -486,6 +505,7 @@ __global__ __launch_bounds__(512) void k_conv12_rs(const uint8_t* __restrict__ c
             pass = next_pass;
         }
 #undef RS_TAP
+#undef RS_WFETCH
 #undef RS_AOFF
 #undef RS_AREAD
 #undef W2_POS

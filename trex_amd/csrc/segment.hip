@@ -1549,7 +1549,11 @@ int launch_segment(trexhip_ctx* ctx, const uint8_t* d_frames, int n) {
     if (G > 8) G = 8;
     if (G < 1 || n < 2 * G) G = 1;
     if (G > 1 && !ctx->aux_stream) {
-        TH_CHECK_HIP(hipStreamCreateWithFlags(&ctx->aux_stream, hipStreamNonBlocking));
+        // (highest priority: a labelling workgroup needs 16 free wave slots and the whole LDS of a CU at once -- behind the next group's pixel
+        // pass at equal priority it only got a CU when that pass had drained: 398 us for two groups in round 4)
+        int plo = 0, phi = 0;
+        (void)hipDeviceGetStreamPriorityRange(&plo, &phi);
+        TH_CHECK_HIP(hipStreamCreateWithPriority(&ctx->aux_stream, hipStreamNonBlocking, phi));
         for (int g = 0; g < 9; ++g) TH_CHECK_HIP(hipEventCreateWithFlags(&ctx->ev_grp[g], hipEventDisableTiming));
     }
     const int gs = (n + G - 1) / G;
