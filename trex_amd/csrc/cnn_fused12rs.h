@@ -49,7 +49,7 @@ struct W12RGeom {
     static constexpr int res_slot(const int tau) { return tau; }
 };
 
-template <int DBG = 0, int BD = 3, int TSPLIT = 20, int PRIO = 0x202>      // TSPLIT: taps in front of the first barrier of a round; PRIO: s_setprio of (producer, tap loop, output transform) as hex digits
+template <int DBG = 0, int BD = 3, int TSPLIT = 20, int PRIO = 0x202, int PAIR = 0>      // PAIR: two taps at a time, consecutive MFMAs on different accumulators; TSPLIT: taps in front of the first barrier of a round; PRIO: s_setprio of (producer, tap loop, output transform) as hex digits
 __global__ __launch_bounds__(512) void k_conv12_rs(const uint8_t* __restrict__ crops /*[N][80][80]*/, const uint4* __restrict__ w1tab /*[16][64]*/,
                                                    const float* __restrict__ bias1, const float inv_scale1,
                                                    const uint4* __restrict__ wp /*[5][8][2][2][64] x 16 B*/, const float* __restrict__ bias,
@@ -179,11 +179,13 @@ __global__ __launch_bounds__(512) void k_conv12_rs(const uint8_t* __restrict__ c
         auto p1 = [&](const int nr) {
             const int r = lane & 15, q4 = lane >> 4;
             const int n_win = nr * 20, n_tiles = (n_win + 7) >> 3;
-            // two tiles per step (t0 and t0 + 4): their eight product chains keep the matrix pipe busy while the LDS reads of the step land
-            for (int t0 = rw; t0 < n_tiles; t0 += 8) {
-                f16x8_c1 a1[2], a2[2];
+            // all (up to four) tiles of the wave in one step (t0, t0 + 4, t0 + 8, t0 + 12): every LDS read first, then the sixteen product chains, then
+            // the pooling -- the vector part of the stage then runs beside the consumers' taps instead of between two bursts of matrix work
+            constexpr int NT1 = 4;
+            for (int t0 = rw; t0 < n_tiles; t0 += 4 * NT1) {
+                f16x8_c1 a1[NT1], a2[NT1];
 #pragma unroll
-                for (int u = 0; u < 2; ++u) {
+                for (int u = 0; u < NT1; ++u) {
                     const int tile = t0 + 4 * u < n_tiles ? t0 + 4 * u : t0;
                     int wdx = tile * 8 + (r >> 1);
                     wdx = wdx < n_win ? wdx : n_win - 1;
@@ -196,9 +198,9 @@ __global__ __launch_bounds__(512) void k_conv12_rs(const uint8_t* __restrict__ c
                     a1[u] = __builtin_bit_cast(f16x8_c1, make_uint4(l1.x, l1.y, h1.x, h1.y));
                     a2[u] = __builtin_bit_cast(f16x8_c1, make_uint4(l2.x, l2.y, h2.x, h2.y));
                 }
-                f32x4 acc[2][4];
+                f32x4 acc[NT1][4];
 #pragma unroll
-                for (int u = 0; u < 2; ++u)
+                for (int u = 0; u < NT1; ++u)
 #pragma unroll
                     for (int s = 0; s < 4; ++s) acc[u][s] = f32x4{0.f, 0.f, 0.f, 0.f};
                 if (!(DBG & 2)) {
@@ -206,7 +208,7 @@ __global__ __launch_bounds__(512) void k_conv12_rs(const uint8_t* __restrict__ c
 #pragma unroll
                     for (int m = 0; m < 4; ++m)
 #pragma unroll
-                        for (int u = 0; u < 2; ++u)
+                        for (int u = 0; u < NT1; ++u)
 #pragma unroll
                             for (int s = 0; s < 4; ++s)
                                 acc[u][s] = __builtin_amdgcn_mfma_f32_16x16x32_f16((m & 1) ? a2[u] : a1[u], __builtin_bit_cast(f16x8_c1, bf[s * 4 + (m == 0 ? 1 : m == 1 ? 3 : m == 2 ? 0 : 2)]), acc[u][s], 0, 0, 0);
@@ -215,7 +217,7 @@ __global__ __launch_bounds__(512) void k_conv12_rs(const uint8_t* __restrict__ c
                 // 2 (window) + 1 of the V2 row, channel co.  pbufP [slot of the pooled pixel][16 channels]; slot = the pixel index with its two low
                 // bit pairs swapped (the four q4 groups of a store fill 256 contiguous bytes, P2's lanes read contiguously as well)
 #pragma unroll
-                for (int u = 0; u < 2; ++u) {
+                for (int u = 0; u < NT1; ++u) {
                     const int tile = t0 + 4 * u;
 #pragma unroll
                     for (int pos = 0; pos < 2; ++pos) {
@@ -386,7 +388,18 @@ __global__ __launch_bounds__(512) void k_conv12_rs(const uint8_t* __restrict__ c
         for (int t = 0; t < BD; ++t) RS_WFETCH(bq[t], t);
         // A-operand byte offsets of this lane's tile for pass `ps_`: per kernel row the row slot (out-of-crop rows -> the zero row), per position of a
         // group the rotated unit.  Computed for the NEXT pass behind the output transform, off the path to the first tap
-        int aoff[5][4];
+        // A-operand byte offsets of this lane's tile: per kernel row the row slot of the pass (out-of-crop rows -> the zero row) and its rotation --
+        // computed for the NEXT pass behind the output transform -- and per position of a group the rotated unit, put together inside taps 0-19,
+        // one tap ahead of its first use (taps 20-39 use the same twenty offsets for the second position group)
+        int aoff[5][4], srow[5], srot[5];
+        int wh[4], wl[4];
+        {
+            int s_ = mg * 32 + j;
+            s_ = s_ < G::RPP * G::TPP ? s_ : G::RPP * G::TPP - 1;
+            const int r2_ = s_ % G::TPP, tx_ = r2_ >> 1;
+#pragma unroll
+            for (int pg = 0; pg < 4; ++pg) { const int w_ = pg * 20 + tx_ * 2 + h; wh[pg] = (w_ & ~15) * 16; wl[pg] = w_ & 15; }
+        }
 #define RS_AOFF(ps_)                                                                                                             \
         do {                                                                                                                     \
             int s_ = mg * 32 + j;                                                                                                \
@@ -394,17 +407,14 @@ __global__ __launch_bounds__(512) void k_conv12_rs(const uint8_t* __restrict__ c
             const int rp_ = s_ / G::TPP, r2_ = s_ - rp_ * G::TPP;                                                                \
             int gp_ = (ps_) * G::RPP + rp_;                                                                                      \
             gp_ = gp_ < total_pairs ? gp_ : total_pairs - 1;                                                                     \
-            const int tx_ = r2_ >> 1, qo_ = 2 * gp_ + (r2_ & 1), y_ = qo_ % S;                                                   \
+            const int qo_ = 2 * gp_ + (r2_ & 1), y_ = qo_ % S;                                                                   \
             _Pragma("unroll") for (int ky = 0; ky < 5; ++ky) {                                                                   \
                 const int iy_ = y_ + ky - 2;                                                                                     \
                 const int slot_ = (iy_ >= 0 && iy_ < S) ? (qo_ + ky - 2) % G::NR + 1 : 0;                                        \
-                const int rot_ = w2b_rot(slot_);                                                                                 \
-                _Pragma("unroll") for (int pg = 0; pg < 4; ++pg) {                                                               \
-                    const int w_ = pg * 20 + tx_ * 2 + h;                                                                        \
-                    aoff[ky][pg] = slot_ * G::ROWL + ((w_ & ~15) | ((w_ + rot_) & 15)) * 16;                                     \
-                }                                                                                                                \
+                srow[ky] = slot_ * G::ROWL; srot[ky] = w2b_rot(slot_);                                                           \
             }                                                                                                                    \
         } while (0)
+#define RS_AUNIT(tau_) do { if ((tau_) < 20) aoff[(tau_) / 4][(tau_) % 4] = srow[(tau_) / 4] + (wh[(tau_) % 4] | (((wl[(tau_) % 4] + srot[(tau_) / 4]) & 15) << 4)); } while (0)
         RS_AOFF(pass);
         if ((DBG & 128) && st_on) st_last = __builtin_readcyclecounter();
         for (;;) {
@@ -418,7 +428,7 @@ __global__ __launch_bounds__(512) void k_conv12_rs(const uint8_t* __restrict__ c
             f32x16 acc[8];
             const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
             __builtin_amdgcn_s_setprio((PRIO >> 4) & 3);
-            uint4 af[2][2];
+            uint4 af[PAIR ? 4 : 2][2];
 #define RS_AREAD(dst_, tau_)                                                                                                     \
             do {                                                                                                                 \
                 const uint8_t* an_ = ldsb + ((tau_) / 20) * G::BUF + aoff[((tau_) % 20) / 4][(tau_) % 4];                        \
@@ -428,7 +438,7 @@ __global__ __launch_bounds__(512) void k_conv12_rs(const uint8_t* __restrict__ c
 #define RS_TAP(tau)                                                                                                              \
             do {                                                                                                                 \
                 const int tl = (tau) % 20;                                                                                       \
-                if ((tau) + 1 < 40) RS_AREAD(af[((tau) + 1) % 2], (tau) + 1);                                                    \
+                if ((tau) + 1 < 40) { RS_AUNIT((tau) + 1); RS_AREAD(af[((tau) + 1) % 2], (tau) + 1); }                           \
                 RS_WFETCH(bq[((tau) + BD) % 8], ((tau) + BD) % 40);                                                              \
                 const int p = W2_POS(tau);                                                                                       \
                 const f16x8 b1 = __builtin_bit_cast(f16x8, bq[(tau) % 8][0]), b2 = __builtin_bit_cast(f16x8, bq[(tau) % 8][1]); \
@@ -444,14 +454,59 @@ __global__ __launch_bounds__(512) void k_conv12_rs(const uint8_t* __restrict__ c
                 }                                                                                                                \
                 __builtin_amdgcn_sched_barrier(0);                                                                               \
             } while (0)
+            // two taps (tau, tau + 1: two positions of one kernel row) at a time, their three products interleaved: consecutive MFMAs go to different
+            // accumulators.  A wave whose next MFMA waits for its own accumulator holds the SIMD's issue port (profiles/r05_ubench_simd.txt: beside
+            // dependent MFMAs a vector wave of equal priority got 1 % of the port, beside independent ones 84 %) -- and here the producer wave outranks
+            // the tap loop, so every port conflict lands on a dependent chain of the consumer
+#define RS_TAP2(tau)                                                                                                             \
+            do {                                                                                                                 \
+                const int tl = (tau) % 20;                                                                                       \
+                if ((tau) + 2 < 40) {                                                                                            \
+                    RS_AUNIT((tau) + 2); RS_AREAD(af[((tau) + 2) % 4], (tau) + 2);                                               \
+                    RS_AUNIT((tau) + 3); RS_AREAD(af[((tau) + 3) % 4], (tau) + 3);                                               \
+                }                                                                                                                \
+                RS_WFETCH(bq[((tau) + BD) % 8], ((tau) + BD) % 40);                                                              \
+                RS_WFETCH(bq[((tau) + BD + 1) % 8], ((tau) + BD + 1) % 40);                                                      \
+                const int p = W2_POS(tau), q = W2_POS((tau) + 1);                                                                \
+                const f16x8 b1 = __builtin_bit_cast(f16x8, bq[(tau) % 8][0]), b2 = __builtin_bit_cast(f16x8, bq[(tau) % 8][1]); \
+                const f16x8 c1 = __builtin_bit_cast(f16x8, bq[((tau) + 1) % 8][0]), c2 = __builtin_bit_cast(f16x8, bq[((tau) + 1) % 8][1]); \
+                const f16x8 a1 = __builtin_bit_cast(f16x8, af[(tau) % 4][0]), a2 = __builtin_bit_cast(f16x8, af[(tau) % 4][1]); \
+                const f16x8 d1 = __builtin_bit_cast(f16x8, af[((tau) + 1) % 4][0]), d2 = __builtin_bit_cast(f16x8, af[((tau) + 1) % 4][1]); \
+                acc[p] = mfma16(a2, b1, tl < 4 ? zero16 : acc[p]);                                                               \
+                acc[q] = mfma16(d2, c1, tl < 4 ? zero16 : acc[q]);                                                               \
+                acc[p] = mfma16(a1, b2, acc[p]);                                                                                 \
+                acc[q] = mfma16(d1, c2, acc[q]);                                                                                 \
+                acc[p] = mfma16(a1, b1, acc[p]);                                                                                 \
+                acc[q] = mfma16(d1, c1, acc[q]);                                                                                 \
+                __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);        /* the A fragments of the next pair (+ resident weight fragments) */ \
+                __builtin_amdgcn_sched_group_barrier(0x020, 4, 0);        /* weight fragments from L2 */                          \
+                _Pragma("unroll") for (int g = 0; g < 6; ++g) {                                                                  \
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                                           \
+                    __builtin_amdgcn_sched_group_barrier(0x006, 4, 0);                                                           \
+                }                                                                                                                \
+                __builtin_amdgcn_sched_barrier(0);                                                                               \
+            } while (0)
+            RS_AUNIT(0);
             RS_AREAD(af[0], 0);
+            if constexpr (PAIR) { RS_AUNIT(1); RS_AREAD(af[1], 1); }
+            if constexpr (PAIR) {
+                static_assert(!PAIR || (TSPLIT % 2 == 0 && BD % 2 == 0 && BD <= 4), "pairs of taps");
+#pragma clang loop unroll(full)
+                for (int tau = 0; tau < ((DBG & 32) ? 0 : TSPLIT); tau += 2) RS_TAP2(tau);
+            } else {
 #pragma clang loop unroll(full)
             for (int tau = 0; tau < ((DBG & 32) ? 0 : TSPLIT); ++tau) RS_TAP(tau);
+            }
             RS_STAMP(0);
             RS_BAR();                                                     // S1 | S2
             RS_STAMP(1);
+            if constexpr (PAIR) {
+#pragma clang loop unroll(full)
+                for (int tau = TSPLIT; tau < ((DBG & 32) ? 0 : 40); tau += 2) RS_TAP2(tau);
+            } else {
 #pragma clang loop unroll(full)
             for (int tau = TSPLIT; tau < ((DBG & 32) ? 0 : 40); ++tau) RS_TAP(tau);
+            }
             if (DBG & 32) { _Pragma("unroll") for (int p = 0; p < 8; ++p) acc[p] = zero16; }
             if (draw) {
                 asm volatile("s_waitcnt vmcnt(0)" : "+v"(ticket) :: "memory");
@@ -505,8 +560,10 @@ __global__ __launch_bounds__(512) void k_conv12_rs(const uint8_t* __restrict__ c
             pass = next_pass;
         }
 #undef RS_TAP
+#undef RS_TAP2
 #undef RS_WFETCH
 #undef RS_AOFF
+#undef RS_AUNIT
 #undef RS_AREAD
 #undef W2_POS
 #undef W2_BOFF
