@@ -452,8 +452,11 @@ def measure(args, env):
             k2 = "k_conv2_wpre2 (conv2 on the V2 operand image, writes V3: same arithmetic, two workgroups per CU, LDS-DMA staging)"
             r3, r2 = 1.2, 1.28
             fused12 = not rgb and not (geom & (1 << 28))
+            role_split = fused12 and not (geom & (1 << 30)) and ((geom & (1 << 29)) or n_blobs >= 3200)
             if fused12:
                 k2 = "k_conv12_wpre (conv1 INSIDE conv2: the V2 operand image is produced into LDS from the u8 crops, never written to HBM; writes V3)"
+            if role_split:
+                k2 = "k_conv12_rs (conv1 INSIDE conv2, role-split: consumer waves run the tap loop and the output transform, producer waves the V3 transform of the previous pass and the V2 rows of the next; one workgroup of 8 waves per CU; writes V3)"
         elif args.cnn_mode == "fp16x3":
             k3 = "k_conv5_wino<64,128,20,2> (conv3, Winograd F(4,5), in-kernel transform)" if wino3 else "k_conv5_stream<64,128,20,20,8,persistent> (conv3, direct, fp16 MFMA x3)"
             k2, r3, r2 = "k_conv5_stream<16,64,40,8,4> (conv2, direct form, fp16 MFMA x3 per fp32 product)", (1.2 if wino3 else 3.0), 3.0
@@ -477,7 +480,7 @@ def measure(args, env):
             in2 = n_blobs * 6400                      # the u8 crops are all the fused kernel reads
         roof2 = conv_roof(k2, c2_s, FLOP_PER_CROP_CONV2 + (FLOP_PER_CROP_CONV1 if fused12 else 0.0), r2, prof["CONV2"][1], in2 + out2)
         t3 = pmc_traffic("trexhip::k_conv5_wpre" if pre else ("trexhip::k_conv5_wino<64, 128, 20, 2" if wino3 else "trexhip::k_conv5_stream<64, 128, 20, 20, 8"))
-        t2 = pmc_traffic(("trexhip::k_conv12_wpre" if fused12 else "trexhip::k_conv2_wpre2") if pre else "trexhip::k_conv5_stream<16, 64, 40, 8, 4")
+        t2 = pmc_traffic((("trexhip::k_conv12_rs" if k2.startswith("k_conv12_rs") else "trexhip::k_conv12_wpre") if fused12 else "trexhip::k_conv2_wpre2") if pre else "trexhip::k_conv5_stream<16, 64, 40, 8, 4")
         if args.cnn_mode == "fp16x3":
             roof3["traffic"], roof2["traffic"] = t3, t2
         # the primary roofline object is the convolution with the larger total duration in this run; both are carried

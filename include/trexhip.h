@@ -51,8 +51,12 @@ typedef struct trexhip_params {
     int32_t enable_difference;   /* enable_difference           :126                                */
     int32_t absolute_difference; /* detect_threshold_is_absolute core/default_config.cpp:1168       */
     int32_t image_invert;        /* image_invert                :1159                               */
-    int32_t inclusive;           /* 1 (default): keep diff >= thr -- "disregards any pixel |p| < threshold", core/default_config.cpp:1168,
-                                  * the track-stage rule's wording (:1167), which Tests/test_pixels.cpp:1026-1059 pins as >= ; 0: diff > thr (cv::threshold) */
+    int32_t inclusive;           /* 1 (default): keep diff >= thr; 0: diff > thr (a plain cv::threshold).  UNPINNED: the detect-stage comparison
+                                  * happens inside RawProcessing::generate_binary (BackgroundSubtraction.cpp:209), whose source is not in the
+                                  * reference tree.  The default follows the documented wording ("disregards any pixel |p| < threshold",
+                                  * core/default_config.cpp:1168 -- the words of the track-stage rule :1167, which Tests/test_pixels.cpp:1026-1059
+                                  * pins as >=); the reference's golden CSVs cannot tell the two apart.  A maintainer who
+                                  * knows generate_binary to be strict sets 0 here (HipBackgroundSubtraction::Settings::inclusive = false). */
     int32_t zero_is_background;  /* 1 (default): a masked pixel of grey value 0 is background        */
     /* CPULabeling::run (BackgroundSubtraction.cpp:216) */
     int32_t connectivity;        /* 8 (default) or 4                                                 */

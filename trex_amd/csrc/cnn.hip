@@ -1762,6 +1762,7 @@ static int net_forward_launch(trexhip_ctx* ctx, const uint8_t* d_crops, int n, f
 #define F12RV(...) TH_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv12_rs<__VA_ARGS__>), hipFuncAttributeMaxDynamicSharedMemorySize, W12RGeom::LDS_BYTES))
         F12RV(0, 3, 20, 0x020); F12RV(0, 3, 20, 0x000); F12RV(0, 3, 20, 0x010); F12RV(0, 3, 20, 0x212); F12RV(0, 3, 16, 0x202); F12RV(0, 3, 24, 0x202); F12RV(0, 2, 20, 0x202); F12RV(0, 5, 20, 0x202);
         F12RV(0, 4, 20, 0x202, 1); F12RV(0, 2, 20, 0x202, 1); F12RV(0, 4, 20, 0x000, 1); F12RV(0, 4, 20, 0x212, 1); F12RV(128, 4, 20, 0x202, 1);
+        F12RV(0, 3, 20, 0x202, 0, 1); F12RV(0, 3, 20, 0x202, 0, 2); F12RV(0, 3, 18, 0x202, 0, 0); F12RV(0, 3, 22, 0x202, 0, 0); F12RV(0, 3, 22, 0x202, 0, 1);
 #undef F12RV
 #endif
 #undef F12R
@@ -1849,6 +1850,7 @@ static int net_forward_launch(trexhip_ctx* ctx, const uint8_t* d_crops, int n, f
             case 200: F12RKV(0, 3, 20, 0x020); break; case 201: F12RKV(0, 3, 20, 0x000); break; case 202: F12RKV(0, 3, 20, 0x010); break; case 203: F12RKV(0, 3, 20, 0x212); break;
             case 210: F12RKV(0, 4, 20, 0x202, 1); break; case 211: F12RKV(0, 2, 20, 0x202, 1); break; case 212: F12RKV(0, 4, 20, 0x000, 1); break; case 213: F12RKV(0, 4, 20, 0x212, 1); break;
             case 214: hipLaunchKernelGGL((k_conv12_rs<128, 4, 20, 0x202, 1>), dim3(want < wgs ? want : wgs), dim3(512), W12RGeom::LDS_BYTES, s, d_crops, net->w1h, net->b1, net->inv1h, net->w2w, net->b2, net->v3, net->inv2w, net->d_ovf, n, net->d_ovf + 2, pk, net->d_ovfc, reinterpret_cast<unsigned long long*>(ctx->d_cnt_px)); break;
+            case 220: F12RKV(0, 3, 20, 0x202, 0, 1); break; case 221: F12RKV(0, 3, 20, 0x202, 0, 2); break; case 222: F12RKV(0, 3, 18, 0x202, 0, 0); break; case 223: F12RKV(0, 3, 22, 0x202, 0, 0); break; case 224: F12RKV(0, 3, 22, 0x202, 0, 1); break;
             case 204: F12RKV(0, 3, 16, 0x202); break; case 205: F12RKV(0, 3, 24, 0x202); break; case 206: F12RKV(0, 2, 20, 0x202); break; case 207: F12RKV(0, 5, 20, 0x202); break;
 #undef F12RKV
             default: F12RK(0); }

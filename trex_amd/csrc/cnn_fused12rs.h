@@ -45,11 +45,11 @@ struct W12RGeom {
     static_assert(LDS_BYTES <= 160 * 1024 && CTL_OFF % 16 == 0 && NRES >= 8 && NRES <= 40, "one workgroup per CU");
     // the FIRST taps of a pass are the resident ones: they run beside the producers' V3 stores and crop loads (stage 1), the later taps beside
     // conv1, which touches no vector memory (stage 2) -- spread evenly over the loop the same 15 taps bought 10 % of stage 1, not 40
-    static constexpr bool resident(const int tau) { return tau < NRES; }
-    static constexpr int res_slot(const int tau) { return tau; }
+    static constexpr bool resident(const int tau, const int pat = 0) { return pat == 0 ? tau < NRES : (pat == 1 ? (tau < 10 || (tau >= 20 && tau < 25)) : (tau < 7 || (tau >= 20 && tau < 28))); }
+    static constexpr int res_slot(const int tau, const int pat = 0) { return pat == 0 ? tau : (pat == 1 ? (tau < 10 ? tau : tau - 10) : (tau < 7 ? tau : tau - 13)); }
 };
 
-template <int DBG = 0, int BD = 3, int TSPLIT = 20, int PRIO = 0x202, int PAIR = 0>      // PAIR: two taps at a time, consecutive MFMAs on different accumulators; TSPLIT: taps in front of the first barrier of a round; PRIO: s_setprio of (producer, tap loop, output transform) as hex digits
+template <int DBG = 0, int BD = 3, int TSPLIT = 20, int PRIO = 0x202, int PAIR = 0, int RESPAT = 0>      // PAIR: two taps at a time, consecutive MFMAs on different accumulators; TSPLIT: taps in front of the first barrier of a round; PRIO: s_setprio of (producer, tap loop, output transform) as hex digits
 __global__ __launch_bounds__(512) void k_conv12_rs(const uint8_t* __restrict__ crops /*[N][80][80]*/, const uint4* __restrict__ w1tab /*[16][64]*/,
                                                    const float* __restrict__ bias1, const float inv_scale1,
                                                    const uint4* __restrict__ wp /*[5][8][2][2][64] x 16 B*/, const float* __restrict__ bias,
@@ -83,8 +83,8 @@ __global__ __launch_bounds__(512) void k_conv12_rs(const uint8_t* __restrict__ c
     for (int i = tid; i < 40 * (F::WTAP / 16); i += 512) {
         const int tau = i / (F::WTAP / 16), u = i - tau * (F::WTAP / 16);
         const int pos = (tau / 20) == 0 ? (tau % 4 == 3 ? 7 : tau % 4) : 3 + tau % 4;
-        const int slot = F::res_slot(tau);
-        if (F::resident(tau)) reinterpret_cast<uint4*>(ldsb + F::WRES_OFF + slot * F::WTAP)[u] = wp[(size_t)(((tau % 20) / 4) * 8 + pos) * G::BV + u];
+        const int slot = F::res_slot(tau, RESPAT);
+        if (F::resident(tau, RESPAT)) reinterpret_cast<uint4*>(ldsb + F::WRES_OFF + slot * F::WTAP)[u] = wp[(size_t)(((tau % 20) / 4) * 8 + pos) * G::BV + u];
     }
     if (tid == 0) *s_next = ((int)atomicAdd(pass_ctr, 1u) + (int)gridDim.x) * PK;
     float ovfm = 0.f;                                                    // the largest activation seen (all are >= 0 behind their ReLU): the fp16 range guard
@@ -376,9 +376,9 @@ __global__ __launch_bounds__(512) void k_conv12_rs(const uint8_t* __restrict__ c
         const uint8_t* wres = ldsb + F::WRES_OFF + boff;
 #define RS_WFETCH(dst_, tau_)                                                                                                    \
         do {                                                                                                                     \
-            if (F::resident(tau_)) {                                                                                             \
-                dst_[0] = *reinterpret_cast<const uint4*>(wres + F::res_slot(tau_) * F::WTAP);                                   \
-                dst_[1] = *reinterpret_cast<const uint4*>(wres + F::res_slot(tau_) * F::WTAP + 2 * CO * 16);                     \
+            if (F::resident(tau_, RESPAT)) {                                                                                     \
+                dst_[0] = *reinterpret_cast<const uint4*>(wres + F::res_slot(tau_, RESPAT) * F::WTAP);                           \
+                dst_[1] = *reinterpret_cast<const uint4*>(wres + F::res_slot(tau_, RESPAT) * F::WTAP + 2 * CO * 16);             \
             } else {                                                                                                             \
                 dst_[0] = buf_load16(wrs, boff, W2_BOFF(tau_));                                                                  \
                 dst_[1] = (DBG & 64) ? dst_[0] : buf_load16(wrs, boff, W2_BOFF(tau_) + 2 * CO * 16);                             \

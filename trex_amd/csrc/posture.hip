@@ -353,8 +353,17 @@ __global__ __launch_bounds__(256) void k_posture(const PostureCfg P, const trexh
     // ---- EFT (order) -> inverse at n uniform parameters around the centre ----
     if (P.approximate > 0) {
         // the centre: Outline.cpp:502-505 adds the points IN ORDER, and a float sum is its order -- every lane walks the same sequence (LDS broadcasts)
+        // (eight points per iteration: the loads of a block are independent of the running sums, only the adds are the chain)
         float cx = 0.f, cy = 0.f;
-        for (int i = 0; i < n; ++i) { const float2 a = pts[i]; cx += a.x; cy += a.y; }
+        int ic = 0;
+        for (; ic + 8 <= n; ic += 8) {
+            float2 a[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) a[k] = pts[ic + k];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { cx += a[k].x; cy += a[k].y; }
+        }
+        for (; ic < n; ++ic) { const float2 a = pts[ic]; cx += a.x; cy += a.y; }
         cx /= (float)n; cy /= (float)n;
         // cumulative arc length (wave scan over chunks of 64 segments + a running carry; the tests' CPU restatement follows exactly this order):
         // s_t[i] = arc length at the END of segment i
