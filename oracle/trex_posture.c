@@ -168,28 +168,50 @@ static void eft_ieft(const v2* p, int N, int order, v2 center, v2* out) {
     float a[16], b[16], c[16], d[16];
     const float PI = 3.14159265358979323846f;
     float* cs = (float*)malloc((size_t)(N + 1) * 2 * sizeof(float));
-    for (int n = 1; n <= order; ++n) {
-        for (int i = 0; i <= N; ++i) det_sincosf(2.0f * PI * (float)n * t[i] / T, &cs[2 * i + 1], &cs[2 * i]);
-        float sa[64] = {0}, sb[64] = {0}, sc[64] = {0}, sd[64] = {0};
-        for (int i = 0; i < N; ++i) {
-            const v2 q = p[(i + 1) % N];
-            const float dx = q.x - p[i].x, dy = q.y - p[i].y;
-            const float dt = t[i + 1] - t[i];
-            if (dt <= 0) continue;
-            const float dc = cs[2 * (i + 1)] - cs[2 * i], ds = cs[2 * (i + 1) + 1] - cs[2 * i + 1];
-            const int l = i & 63;
-            sa[l] += dx / dt * dc; sb[l] += dx / dt * ds; sc[l] += dy / dt * dc; sd[l] += dy / dt * ds;
+    /* cos / sin of the FIRST harmonic's phase at every boundary; harmonics 2 and 3 by the angle addition formulas, written out in the order the
+     * device uses (c2 = c1 c1 - s1 s1, s2 = 2 (s1 c1), c3 = c2 c1 - s2 s1, s3 = s2 c1 + c2 s1) */
+    for (int i = 0; i <= N; ++i) det_sincosf(2.0f * PI * (float)1 * t[i] / T, &cs[2 * i + 1], &cs[2 * i]);
+    float sa[4][64], sb[4][64], sc[4][64], sd[4][64];
+    memset(sa, 0, sizeof(sa)); memset(sb, 0, sizeof(sb)); memset(sc, 0, sizeof(sc)); memset(sd, 0, sizeof(sd));
+    if (order > 3) order = 3;
+    for (int i = 0; i < N; ++i) {
+        const v2 q = p[(i + 1) % N];
+        const float dx = q.x - p[i].x, dy = q.y - p[i].y;
+        const float dt = t[i + 1] - t[i];
+        if (dt <= 0) continue;
+        const float c0 = cs[2 * i], s0 = cs[2 * i + 1], c1 = cs[2 * (i + 1)], s1 = cs[2 * (i + 1) + 1];
+        const float gx = dx / dt, gy = dy / dt;
+        float c0h = c0, s0h = s0, c1h = c1, s1h = s1;
+        const int l = i & 63;
+        for (int n = 1; n <= order; ++n) {
+            if (n > 1) {
+                float cn, sn;
+                if (n == 2) { cn = c0 * c0 - s0 * s0; sn = 2.0f * (s0 * c0); } else { cn = c0h * c0 - s0h * s0; sn = s0h * c0 + c0h * s0; }
+                c0h = cn; s0h = sn;
+                if (n == 2) { cn = c1 * c1 - s1 * s1; sn = 2.0f * (s1 * c1); } else { cn = c1h * c1 - s1h * s1; sn = s1h * c1 + c1h * s1; }
+                c1h = cn; s1h = sn;
+            }
+            const float dc = c1h - c0h, ds = s1h - s0h;
+            sa[n][l] += gx * dc; sb[n][l] += gx * ds; sc[n][l] += gy * dc; sd[n][l] += gy * ds;
         }
+    }
+    for (int n = 1; n <= order; ++n) {
         const float k = T / (2.0f * (float)(n * n) * PI * PI);
-        a[n] = k * butterfly64(sa); b[n] = k * butterfly64(sb); c[n] = k * butterfly64(sc); d[n] = k * butterfly64(sd);
+        a[n] = k * butterfly64(sa[n]); b[n] = k * butterfly64(sb[n]); c[n] = k * butterfly64(sc[n]); d[n] = k * butterfly64(sd[n]);
     }
     for (int k = 0; k < N; ++k) {
         const float tt = (float)k / (float)N;
         float x = center.x, y = center.y;
+        float s1, c1;
+        det_sincosf(2.0f * PI * (float)1 * tt, &s1, &c1);
+        float ch = c1, sh = s1;
         for (int n = 1; n <= order; ++n) {
-            float sn, co;
-            det_sincosf(2.0f * PI * (float)n * tt, &sn, &co);
-            x += a[n] * co + b[n] * sn; y += c[n] * co + d[n] * sn;
+            if (n > 1) {
+                float cn, sn;
+                if (n == 2) { cn = c1 * c1 - s1 * s1; sn = 2.0f * (s1 * c1); } else { cn = ch * c1 - sh * s1; sn = sh * c1 + ch * s1; }
+                ch = cn; sh = sn;
+            }
+            x += a[n] * ch + b[n] * sh; y += c[n] * ch + d[n] * sh;
         }
         out[k].x = x; out[k].y = y;
     }

@@ -383,40 +383,70 @@ __global__ __launch_bounds__(256) void k_posture(const PostureCfg P, const trexh
         const float PI = 3.14159265358979323846f;
         float ca[4][4];                                           // [harmonic 1..3][a b c d]
         const int order = min(P.approximate, 3);
-        for (int h = 1; h <= order; ++h) {
-            // cos / sin of the phase at every segment boundary once (boundary i = the start of segment i = the end of segment i - 1; boundary n closes
-            // the curve: it goes to the idle curvature array), kept in the spare point buffer
-            for (int i = lane; i <= n; i += 64) {
-                float sn, cs;
-                det_sincosf(2.0f * PI * (float)h * (i > 0 ? s_t[i - 1] : 0.f) / T, sn, cs);
-                if (i < n) other[i] = make_float2(cs, sn);
-                else { s_curv[0] = cs; s_curv[1] = sn; }
-            }
-            __builtin_amdgcn_wave_barrier();
+        // cos / sin of the FIRST harmonic's phase at every segment boundary once (boundary i = the start of segment i = the end of segment i - 1;
+        // boundary n closes the curve: it goes to the idle curvature array), kept in the spare point buffer.  Harmonics 2 and 3 follow by the angle
+        // addition formulas (c2 = c1 c1 - s1 s1, s2 = 2 (s1 c1), c3 = c2 c1 - s2 s1, s3 = s2 c1 + c2 s1): one sin / cos per boundary instead of
+        // three -- the CPU restatement does the same operations in the same order
+        for (int i = lane; i <= n; i += 64) {
+            float sn, cs;
+            det_sincosf(2.0f * PI * (float)1 * (i > 0 ? s_t[i - 1] : 0.f) / T, sn, cs);
+            if (i < n) other[i] = make_float2(cs, sn);
+            else { s_curv[0] = cs; s_curv[1] = sn; }
+        }
+        __builtin_amdgcn_wave_barrier();
+        {
             const float csE = s_curv[0], snE = s_curv[1];
             // term i goes to partial sum i % 64 in order of i, the partials are combined by the xor butterfly (wsum): the order the CPU restatement follows too
-            float sa = 0.f, sb = 0.f, sc = 0.f, sd = 0.f;
+            float sa[4] = {0.f, 0.f, 0.f, 0.f}, sb[4] = {0.f, 0.f, 0.f, 0.f}, sc[4] = {0.f, 0.f, 0.f, 0.f}, sd[4] = {0.f, 0.f, 0.f, 0.f};
             for (int i = lane; i < n; i += 64) {
                 const float2 a = pts[i], q = pts[i + 1 == n ? 0 : i + 1];
                 const float t0 = i > 0 ? s_t[i - 1] : 0.f, t1 = s_t[i];
                 const float dt = t1 - t0;
                 if (dt <= 0.f) continue;
                 const float2 c0 = other[i], c1 = (i + 1 < n) ? other[i + 1] : make_float2(csE, snE);
-                const float dc = c1.x - c0.x, ds = c1.y - c0.y;
                 const float ddx = q.x - a.x, ddy = q.y - a.y;
-                sa += ddx / dt * dc; sb += ddx / dt * ds; sc += ddy / dt * dc; sd += ddy / dt * ds;
+                const float gx = ddx / dt, gy = ddy / dt;
+                float c0h = c0.x, s0h = c0.y, c1h = c1.x, s1h = c1.y;
+#pragma unroll
+                for (int h = 1; h <= 3; ++h) {
+                    if (h <= order) {
+                        if (h > 1) {        // phase (h - 1) theta -> h theta at both boundaries
+                            float cn, sn2;
+                            if (h == 2) { cn = c0.x * c0.x - c0.y * c0.y; sn2 = 2.0f * (c0.y * c0.x); } else { cn = c0h * c0.x - s0h * c0.y; sn2 = s0h * c0.x + c0h * c0.y; }
+                            c0h = cn; s0h = sn2;
+                            if (h == 2) { cn = c1.x * c1.x - c1.y * c1.y; sn2 = 2.0f * (c1.y * c1.x); } else { cn = c1h * c1.x - s1h * c1.y; sn2 = s1h * c1.x + c1h * c1.y; }
+                            c1h = cn; s1h = sn2;
+                        }
+                        const float dc = c1h - c0h, ds = s1h - s0h;
+                        sa[h] += gx * dc; sb[h] += gx * ds; sc[h] += gy * dc; sd[h] += gy * ds;
+                    }
+                }
             }
-            const float k = T / (2.0f * (float)(h * h) * PI * PI);
-            ca[h][0] = k * wsum(sa); ca[h][1] = k * wsum(sb); ca[h][2] = k * wsum(sc); ca[h][3] = k * wsum(sd);
+#pragma unroll
+            for (int h = 1; h <= 3; ++h) {
+                if (h <= order) {
+                    const float k = T / (2.0f * (float)(h * h) * PI * PI);
+                    ca[h][0] = k * wsum(sa[h]); ca[h][1] = k * wsum(sb[h]); ca[h][2] = k * wsum(sc[h]); ca[h][3] = k * wsum(sd[h]);
+                }
+            }
             __builtin_amdgcn_wave_barrier();
         }
         for (int i = lane; i < n; i += 64) {
             const float tt = (float)i / (float)n;
             float x = cx, y = cy;
-            for (int h = 1; h <= order; ++h) {
-                float sn, cs;
-                det_sincosf(2.0f * PI * (float)h * tt, sn, cs);
-                x += ca[h][0] * cs + ca[h][1] * sn; y += ca[h][2] * cs + ca[h][3] * sn;
+            float s1, c1;
+            det_sincosf(2.0f * PI * (float)1 * tt, s1, c1);
+            float ch = c1, sh = s1;
+#pragma unroll
+            for (int h = 1; h <= 3; ++h) {
+                if (h <= order) {
+                    if (h > 1) {
+                        float cn, sn2;
+                        if (h == 2) { cn = c1 * c1 - s1 * s1; sn2 = 2.0f * (s1 * c1); } else { cn = ch * c1 - sh * s1; sn2 = sh * c1 + ch * s1; }
+                        ch = cn; sh = sn2;
+                    }
+                    x += ca[h][0] * ch + ca[h][1] * sh; y += ca[h][2] * ch + ca[h][3] * sh;
+                }
             }
             other[i] = make_float2(x, y);
         }
