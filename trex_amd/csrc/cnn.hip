@@ -1069,9 +1069,13 @@ __global__ __launch_bounds__((WinoGeom<CI, CO, S, TPW>::NTHR), (TPW == 1 ? 2 : 1
 }
 
 #include "cnn_wpre.h"
+#ifndef TREXHIP_V3_OLD
+#include "cnn_conv3p.h"
+#endif
 #include "cnn_fused12.h"
 #include "cnn_fused12rs.h"
 
+static constexpr int W3P_BD = 5;         // k_conv5_wpair: weight fragments 5 taps ahead
 static constexpr int FC1_KSPLIT = 10;     // 12800 = 10 x 1280: 500 workgroups at 6400 crops (5: 129 us, 10: 92 us, 20: 102 us + slower head); partial planes summed in k_head
 // ------------------------------------------------------------------------------------------------
 // fc1: out[N][128] = act[N][K] * W[K][128] + b     (K = 12800, 100 real outputs)
@@ -1752,7 +1756,18 @@ static int net_forward_launch(trexhip_ctx* ctx, const uint8_t* d_crops, int n, f
 #define W3AB(D_, B_) TH_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv5_wpre<D_, B_>), hipFuncAttributeMaxDynamicSharedMemorySize, (WinoGeom<64, 128, 20, 2>::LDS_BYTES)))
 #define W2BA(D_) W2BAS(D_, 5)
 #define W2BAS(D_, S_) TH_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv2_wpre2<D_, S_>), hipFuncAttributeMaxDynamicSharedMemorySize, W2bGeom::LDS_BYTES))
-        W3A(0); W2BA(0);
+#ifdef TREXHIP_V3_OLD
+        W3A(0);
+#endif
+        W2BA(0);
+#ifndef TREXHIP_V3_OLD
+#define W3PA(D_, B_) TH_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv5_wpair<D_, B_>), hipFuncAttributeMaxDynamicSharedMemorySize, (WinoGeom<64, 128, 20, 2>::LDS_BYTES + 1024)))
+        W3PA(0, W3P_BD);
+#ifdef TREXHIP_DEV_KNOBS
+        W3PA(1, W3P_BD); W3PA(4, W3P_BD); W3PA(5, W3P_BD); W3PA(8, W3P_BD); W3PA(13, W3P_BD); W3PA(0, 3); W3PA(0, 5); W3PA(0, 7); TH_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv5_wpair<0, 5, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (WinoGeom<64, 128, 20, 2>::LDS_BYTES + 1024))); TH_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv5_wpair<0, 3, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (WinoGeom<64, 128, 20, 2>::LDS_BYTES + 1024)));
+#endif
+#undef W3PA
+#endif
 #define F12A(D_) TH_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv12_wpre<D_>), hipFuncAttributeMaxDynamicSharedMemorySize, W12Geom::LDS_BYTES))
         F12A(0);
 #define F12R(D_) TH_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv12_rs<D_>), hipFuncAttributeMaxDynamicSharedMemorySize, W12RGeom::LDS_BYTES))
@@ -1777,7 +1792,9 @@ static int net_forward_launch(trexhip_ctx* ctx, const uint8_t* d_crops, int n, f
 #undef F12A
 #ifdef TREXHIP_DEV_KNOBS
         W2BA(1); W2BA(2); W2BA(3); W2BA(7); W2BA(15);
+#ifdef TREXHIP_V3_OLD
         W3A(1); W3A(2); W3A(3); W3A(7); W3A(15); W3A(16); W3AB(0, 3); W3AB(0, 5); W3A(64); W3A(128); TH_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv5_wpre<0, 7, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (WinoGeom<64, 128, 20, 2>::LDS_BYTES)));
+#endif
 #endif
 #undef W3A
 #undef W3AB
@@ -1928,10 +1945,22 @@ static int net_forward_launch(trexhip_ctx* ctx, const uint8_t* d_crops, int n, f
         const int n_big3 = n_pass >= 16 * ctx->n_cus ? (int)((long long)n_pass * 7 / 8) / 4 : 0, want3 = n_big3 + (n_pass - n_big3 * 4);
 #define W3KB(D_, B_) hipLaunchKernelGGL((k_conv5_wpre<D_, B_>), dim3(want3 < ctx->n_cus ? want3 : ctx->n_cus), dim3(256), GW::LDS_BYTES, s, \
                            net->v3, net->w3w, net->b3, net->act3, net->inv3w, n, net->d_ovf + 1, n_big3)
+#ifndef TREXHIP_V3_OLD
+#define W3P(D_, B_) hipLaunchKernelGGL((k_conv5_wpair<D_, B_>), dim3(want3 < ctx->n_cus ? want3 : ctx->n_cus), dim3(256), GW::LDS_BYTES + 1024 /* slack for the last DMA instruction */, s, \
+                           net->v3, net->w3w, net->b3, net->act3, net->inv3w, n, net->d_ovf + 1, n_big3)
+#ifdef TREXHIP_DEV_KNOBS
+        switch ((ctx->tune_conv_geom >> 24) & 15) { case 1: W3P(1, W3P_BD); break; case 2: W3P(4, W3P_BD); break; case 3: W3P(5, W3P_BD); break; case 7: W3P(8, W3P_BD); break; case 15: W3P(13, W3P_BD); break;
+                                                    case 9: W3P(0, 3); break; case 10: W3P(0, 5); break; case 11: W3P(0, 7); break; case 12: hipLaunchKernelGGL((k_conv5_wpair<0, 5, 2>), dim3(want3 < ctx->n_cus ? want3 : ctx->n_cus), dim3(256), GW::LDS_BYTES + 1024, s, net->v3, net->w3w, net->b3, net->act3, net->inv3w, n, net->d_ovf + 1, n_big3); break; case 13: hipLaunchKernelGGL((k_conv5_wpair<0, 3, 2>), dim3(want3 < ctx->n_cus ? want3 : ctx->n_cus), dim3(256), GW::LDS_BYTES + 1024, s, net->v3, net->w3w, net->b3, net->act3, net->inv3w, n, net->d_ovf + 1, n_big3); break; default: W3P(0, W3P_BD); }
+#else
+        W3P(0, W3P_BD);
+#endif
+#undef W3P
+#else
 #ifdef TREXHIP_DEV_KNOBS
         switch ((ctx->tune_conv_geom >> 24) & 15) { case 1: W3K(1); break; case 2: W3K(2); break; case 3: W3K(3); break; case 7: W3K(7); break; case 15: W3K(15); break; case 8: W3K(16); break; case 9: W3KB(0, 3); break; case 10: W3KB(0, 5); break; case 12: W3K(64); break; case 13: W3K(128); break; case 11: hipLaunchKernelGGL((k_conv5_wpre<0, 7, 1>), dim3(n_pass < ctx->n_cus ? n_pass : ctx->n_cus), dim3(256), GW::LDS_BYTES, s, net->v3, net->w3w, net->b3, net->act3, net->inv3w, n, net->d_ovf + 1, 0); break; default: W3K(0); }
 #else
         W3K(0);
+#endif
 #endif
 #undef W3K
 #undef W3KB

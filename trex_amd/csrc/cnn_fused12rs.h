@@ -287,14 +287,14 @@ __global__ __launch_bounds__(512) void k_conv12_rs(const uint8_t* __restrict__ c
                     wino_bt(d[0].y, d[1].y, d[2].y, d[3].y, d[4].y, d[5].y, d[6].y, d[7].y, ub);
                     wino_bt(d[0].z, d[1].z, d[2].z, d[3].z, d[4].z, d[5].z, d[6].z, d[7].z, uc);
                     wino_bt(d[0].w, d[1].w, d[2].w, d[3].w, d[4].w, d[5].w, d[6].w, d[7].w, ud);
-                    uint8_t* dst = v3 + (size_t)gp * V3_ROWB + (quad >> 2) * 2560 + tx * 32 + (quad & 3) * 8;
+                    uint8_t* dst = v3 + (size_t)gp * V3_ROWB + (quad >> 2) * V3_CHUNKB + tx * 32 + (quad & 3) * 8;
 #pragma unroll
                     for (int p = 0; p < 8; ++p) {
                         uint32_t l0, l1, m0, m1;
                         split2h_pair(ua[p], ub[p], l0, m0);
                         split2h_pair(uc[p], ud[p], l1, m1);
-                        *reinterpret_cast<uint2*>(dst + p * 160) = make_uint2(l0, l1);
-                        *reinterpret_cast<uint2*>(dst + 1280 + p * 160) = make_uint2(m0, m1);
+                        *reinterpret_cast<uint2*>(dst + v3_off(p, 0)) = make_uint2(l0, l1);
+                        *reinterpret_cast<uint2*>(dst + v3_off(p, 1)) = make_uint2(m0, m1);
                     }
                 }
             }

@@ -16,6 +16,21 @@
 // host-side guard re-runs the layer stack with the bf16 kernels from the crops.
 
 static constexpr int V2_ROWB = 5120, V3_ROWB = 10240;
+// V3 since round 5 (k_conv5_wpair, cnn_conv3p.h): a row's 10240 bytes are [position pair 4][piece 2][chunk 4][position of the pair 2][tx 5][16 ci],
+// pairs in the order (1,2) (3,4) (5,6) (0,7) -- conv3 walks a pass pair by pair (all 64 input channels of two positions = one 1280-byte plane
+// per row and piece), so that the pairs the output transform combines are final one after the other.  -DTREXHIP_V3_OLD: [chunk][piece][position 8]
+// [tx][16 ci] for k_conv5_wpre.  The producers' stores of position p, chunk c, piece pc, tile tx: v3_off(p, pc) + c * V3_CHUNKB + tx * 32.
+#ifdef TREXHIP_V3_OLD
+static constexpr bool V3_PAIR = false;
+static constexpr int V3_CHUNKB = 2560;
+__host__ __device__ constexpr int v3_off(const int p, const int piece) { return piece * 1280 + p * 160; }
+#else
+static constexpr bool V3_PAIR = true;
+static constexpr int V3_CHUNKB = 320;
+__host__ __device__ constexpr int v3_pair_of(const int p) { return p == 0 || p == 7 ? 3 : (p - 1) / 2; }
+__host__ __device__ constexpr int v3_half_of(const int p) { return p == 0 ? 0 : p == 7 ? 1 : (p - 1) % 2; }
+__host__ __device__ constexpr int v3_off(const int p, const int piece) { return v3_pair_of(p) * 2560 + piece * 1280 + v3_half_of(p) * 160; }
+#endif
 
 // one LDS-DMA instruction: 64 lanes x 16 bytes from the lanes' global addresses (wave-uniform 64-bit base in SGPRs + a 32-bit lane offset: one
 // address register instead of two) to LDS [lds_addr, lds_addr + 1024).  Raw, so that the compiler's wait-count pass does not know of it: it
@@ -444,14 +459,14 @@ __global__ __launch_bounds__(256, 2) void k_conv2_wpre2(const uint8_t* __restric
                 wino_bt(d[0].y, d[1].y, d[2].y, d[3].y, d[4].y, d[5].y, d[6].y, d[7].y, ub);
                 wino_bt(d[0].z, d[1].z, d[2].z, d[3].z, d[4].z, d[5].z, d[6].z, d[7].z, uc);
                 wino_bt(d[0].w, d[1].w, d[2].w, d[3].w, d[4].w, d[5].w, d[6].w, d[7].w, ud);
-                uint8_t* dst = v3 + (size_t)gp * V3_ROWB + (quad >> 2) * 2560 + tx * 32 + (quad & 3) * 8;
+                uint8_t* dst = v3 + (size_t)gp * V3_ROWB + (quad >> 2) * V3_CHUNKB + tx * 32 + (quad & 3) * 8;
 #pragma unroll
                 for (int p = 0; p < 8; ++p) {
                     uint32_t l0, l1, m0, m1;
                     split2h_pair(ua[p], ub[p], l0, m0);
                     split2h_pair(uc[p], ud[p], l1, m1);
-                    *reinterpret_cast<uint2*>(dst + p * 160) = make_uint2(l0, l1);
-                    *reinterpret_cast<uint2*>(dst + 1280 + p * 160) = make_uint2(m0, m1);
+                    *reinterpret_cast<uint2*>(dst + v3_off(p, 0)) = make_uint2(l0, l1);
+                    *reinterpret_cast<uint2*>(dst + v3_off(p, 1)) = make_uint2(m0, m1);
                 }
             }
         }
