@@ -1775,9 +1775,7 @@ static int net_forward_launch(trexhip_ctx* ctx, const uint8_t* d_crops, int n, f
 #ifdef TREXHIP_DEV_KNOBS
         F12R(8); F12R(16); F12R(32); F12R(40); F12R(64); F12R(128);
 #define F12RV(...) TH_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv12_rs<__VA_ARGS__>), hipFuncAttributeMaxDynamicSharedMemorySize, W12RGeom::LDS_BYTES))
-        F12RV(0, 3, 20, 0x020); F12RV(0, 3, 20, 0x000); F12RV(0, 3, 20, 0x010); F12RV(0, 3, 20, 0x212); F12RV(0, 3, 16, 0x202); F12RV(0, 3, 24, 0x202); F12RV(0, 2, 20, 0x202); F12RV(0, 5, 20, 0x202);
-        F12RV(0, 4, 20, 0x202, 1); F12RV(0, 2, 20, 0x202, 1); F12RV(0, 4, 20, 0x000, 1); F12RV(0, 4, 20, 0x212, 1); F12RV(128, 4, 20, 0x202, 1);
-        F12RV(0, 3, 20, 0x202, 0, 1); F12RV(0, 3, 20, 0x202, 0, 2); F12RV(0, 3, 18, 0x202, 0, 0); F12RV(0, 3, 22, 0x202, 0, 0); F12RV(0, 3, 22, 0x202, 0, 1);
+        F12RV(0, 3, 20, 0x202, 0, 0, 0); F12RV(128, 3, 20, 0x202, 0, 0, 0);      // ORD 0: kernel-row-major taps, the whole output transform behind them
 #undef F12RV
 #endif
 #undef F12R
@@ -1864,11 +1862,8 @@ static int net_forward_launch(trexhip_ctx* ctx, const uint8_t* d_crops, int n, f
         switch (f12r_dbg) { case 8: F12RK(8); break; case 16: F12RK(16); break; case 32: F12RK(32); break; case 40: F12RK(40); break; case 64: F12RK(64); break;
             case 128: hipLaunchKernelGGL((k_conv12_rs<128>), dim3(want < wgs ? want : wgs), dim3(512), W12RGeom::LDS_BYTES, s, d_crops, net->w1h, net->b1, net->inv1h, net->w2w, net->b2, net->v3, net->inv2w, net->d_ovf, n, net->d_ovf + 2, pk, net->d_ovfc, reinterpret_cast<unsigned long long*>(ctx->d_cnt_px)); break;
 #define F12RKV(...) hipLaunchKernelGGL((k_conv12_rs<__VA_ARGS__>), dim3(want < wgs ? want : wgs), dim3(512), W12RGeom::LDS_BYTES, s, d_crops, net->w1h, net->b1, net->inv1h, net->w2w, net->b2, net->v3, net->inv2w, net->d_ovf, n, net->d_ovf + 2, pk, net->d_ovfc)
-            case 200: F12RKV(0, 3, 20, 0x020); break; case 201: F12RKV(0, 3, 20, 0x000); break; case 202: F12RKV(0, 3, 20, 0x010); break; case 203: F12RKV(0, 3, 20, 0x212); break;
-            case 210: F12RKV(0, 4, 20, 0x202, 1); break; case 211: F12RKV(0, 2, 20, 0x202, 1); break; case 212: F12RKV(0, 4, 20, 0x000, 1); break; case 213: F12RKV(0, 4, 20, 0x212, 1); break;
-            case 214: hipLaunchKernelGGL((k_conv12_rs<128, 4, 20, 0x202, 1>), dim3(want < wgs ? want : wgs), dim3(512), W12RGeom::LDS_BYTES, s, d_crops, net->w1h, net->b1, net->inv1h, net->w2w, net->b2, net->v3, net->inv2w, net->d_ovf, n, net->d_ovf + 2, pk, net->d_ovfc, reinterpret_cast<unsigned long long*>(ctx->d_cnt_px)); break;
-            case 220: F12RKV(0, 3, 20, 0x202, 0, 1); break; case 221: F12RKV(0, 3, 20, 0x202, 0, 2); break; case 222: F12RKV(0, 3, 18, 0x202, 0, 0); break; case 223: F12RKV(0, 3, 22, 0x202, 0, 0); break; case 224: F12RKV(0, 3, 22, 0x202, 0, 1); break;
-            case 204: F12RKV(0, 3, 16, 0x202); break; case 205: F12RKV(0, 3, 24, 0x202); break; case 206: F12RKV(0, 2, 20, 0x202); break; case 207: F12RKV(0, 5, 20, 0x202); break;
+            case 230: F12RKV(0, 3, 20, 0x202, 0, 0, 0); break;
+            case 231: hipLaunchKernelGGL((k_conv12_rs<128, 3, 20, 0x202, 0, 0, 0>), dim3(want < wgs ? want : wgs), dim3(512), W12RGeom::LDS_BYTES, s, d_crops, net->w1h, net->b1, net->inv1h, net->w2w, net->b2, net->v3, net->inv2w, net->d_ovf, n, net->d_ovf + 2, pk, net->d_ovfc, reinterpret_cast<unsigned long long*>(ctx->d_cnt_px)); break;
 #undef F12RKV
             default: F12RK(0); }
 #else

@@ -25,6 +25,20 @@ __device__ __forceinline__ float rs_max3(const float a, const float b, const flo
 __device__ __forceinline__ float rs_max3z(const float a, const float b) { float r; asm("v_max3_f32 %0, %1, %2, 0" : "=v"(r) : "v"(a), "v"(b)); return r; }      // max(a, b, 0)
 __device__ __forceinline__ float rs_max(const float a, const float b) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
 
+// Order of the 20 taps of a stage (ORD 1, round 5): position PAIR major -- i = tap % 20: pair i / 10, kernel row (i % 10) / 2, position of the pair
+// i % 2 -- with stage 1 = positions (1,2) then (0,7), stage 2 = (3,4) then (5,6): the pairs the output transform A^T combines are final 10 taps
+// before their stage ends, and their part of A^T runs under the taps that follow (the tap loop of stage 2 is bound by the matrix pipe, the
+// output transform behind it by the vector issue of two waves).  Per accumulator the order of the sums is unchanged (kernel row 0..4).
+// ORD 0: kernel row major (i / 4, i % 4), the order of k_conv12_wpre and k_conv2_wpre2.  pg = the position's place in its stored group
+// (group 0 holds positions 0,1,2,7; group 1 holds 3,4,5,6).
+__host__ __device__ constexpr int rs_ky(const int ord, const int tau) { return ord ? ((tau % 20) % 10) / 2 : (tau % 20) / 4; }
+__host__ __device__ constexpr int rs_pg(const int ord, const int tau) {
+    const int i = tau % 20;
+    if (!ord) return i % 4;
+    return tau / 20 == 0 ? (i / 10 == 0 ? 1 + i % 2 : (i % 2 ? 3 : 0)) : 2 * (i / 10) + i % 2;
+}
+__host__ __device__ constexpr int rs_pos(const int ord, const int tau) { return tau / 20 == 0 ? (rs_pg(ord, tau) == 3 ? 7 : rs_pg(ord, tau)) : 3 + rs_pg(ord, tau); }
+
 struct W12RGeom {
     using G = W2bGeom;
     static constexpr int CHUNK = 6;
@@ -49,7 +63,7 @@ struct W12RGeom {
     static constexpr int res_slot(const int tau, const int pat = 0) { return pat == 0 ? tau : (pat == 1 ? (tau < 10 ? tau : tau - 10) : (tau < 7 ? tau : tau - 13)); }
 };
 
-template <int DBG = 0, int BD = 3, int TSPLIT = 20, int PRIO = 0x202, int PAIR = 0, int RESPAT = 0>      // PAIR: two taps at a time, consecutive MFMAs on different accumulators; TSPLIT: taps in front of the first barrier of a round; PRIO: s_setprio of (producer, tap loop, output transform) as hex digits
+template <int DBG = 0, int BD = 3, int TSPLIT = 20, int PRIO = 0x202, int PAIR = 0, int RESPAT = 0, int ORD = 1>      // PAIR: two taps at a time, consecutive MFMAs on different accumulators; TSPLIT: taps in front of the first barrier of a round; PRIO: s_setprio of (producer, tap loop, output transform) as hex digits
 __global__ __launch_bounds__(512) void k_conv12_rs(const uint8_t* __restrict__ crops /*[N][80][80]*/, const uint4* __restrict__ w1tab /*[16][64]*/,
                                                    const float* __restrict__ bias1, const float inv_scale1,
                                                    const uint4* __restrict__ wp /*[5][8][2][2][64] x 16 B*/, const float* __restrict__ bias,
@@ -69,7 +83,10 @@ __global__ __launch_bounds__(512) void k_conv12_rs(const uint8_t* __restrict__ c
     const int n_pass = (total_pairs + G::RPP - 1) / G::RPP;
     int pass = blockIdx.x * PK;
     if (pass >= n_pass) return;
-    volatile int* s_next = reinterpret_cast<volatile int*>(ldsb + F::CTL_OFF);
+    // the next ticket's first pass: written by thread 0, read by every wave behind a barrier (a plain LDS word: through a volatile pointer into
+    // the dynamic array it became a FLAT load with a vmcnt(0) behind it, and everything computed from it vector arithmetic)
+    int* s_next = reinterpret_cast<int*>(ldsb + F::CTL_OFF);
+    int tleft = PK;                                                      // passes left in this ticket, this one included (tickets are PK consecutive passes)
     for (int i = tid; i < 4 * (G::ROWL / 16); i += 512) {                // the zero rows of the four planes
         const int pl = i / (G::ROWL / 16), o = i - pl * (G::ROWL / 16);
         *reinterpret_cast<uint4*>(ldsb + pl * G::PLANE + o * 16) = make_uint4(0, 0, 0, 0);
@@ -82,9 +99,8 @@ __global__ __launch_bounds__(512) void k_conv12_rs(const uint8_t* __restrict__ c
     // resident weight fragments: tap tau -> slot res_slot(tau); a slot holds the tap's [piece][k-octet h][co] x 16 B exactly as the weight image does
     for (int i = tid; i < 40 * (F::WTAP / 16); i += 512) {
         const int tau = i / (F::WTAP / 16), u = i - tau * (F::WTAP / 16);
-        const int pos = (tau / 20) == 0 ? (tau % 4 == 3 ? 7 : tau % 4) : 3 + tau % 4;
         const int slot = F::res_slot(tau, RESPAT);
-        if (F::resident(tau, RESPAT)) reinterpret_cast<uint4*>(ldsb + F::WRES_OFF + slot * F::WTAP)[u] = wp[(size_t)(((tau % 20) / 4) * 8 + pos) * G::BV + u];
+        if (F::resident(tau, RESPAT)) reinterpret_cast<uint4*>(ldsb + F::WRES_OFF + slot * F::WTAP)[u] = wp[(size_t)(rs_ky(ORD, tau) * 8 + rs_pos(ORD, tau)) * G::BV + u];
     }
     if (tid == 0) *s_next = ((int)atomicAdd(pass_ctr, 1u) + (int)gridDim.x) * PK;
     float ovfm = 0.f;                                                    // the largest activation seen (all are >= 0 behind their ReLU): the fp16 range guard
@@ -114,8 +130,8 @@ __global__ __launch_bounds__(512) void k_conv12_rs(const uint8_t* __restrict__ c
     // ticket drawn one round earlier).  Computed identically by every wave.
 #define RS_NEXT(pass_, res_hi_, next_, have_, lo_, hi_)                                                                          \
     do {                                                                                                                         \
-        const bool draw_ = (pass_) % PK == PK - 1;                                                                               \
-        next_ = draw_ ? *s_next : (pass_) + 1;                                                                                   \
+        const bool draw_ = tleft == 1;                                                                                           \
+        next_ = draw_ ? __builtin_amdgcn_readfirstlane(*s_next) : (pass_) + 1;                                                   \
         have_ = next_ < n_pass;                                                                                                  \
         lo_ = hi_ = 0;                                                                                                           \
         if (have_) {                                                                                                             \
@@ -353,6 +369,7 @@ __global__ __launch_bounds__(512) void k_conv12_rs(const uint8_t* __restrict__ c
             prev = pass;
             if (!have_next) break;
             res_hi = hi;
+            tleft = tleft == 1 ? PK : tleft - 1;
             pass = next_pass;
         }
         e2(prev);                                                         // the last pass's activations (behind its third barrier)
@@ -369,8 +386,8 @@ __global__ __launch_bounds__(512) void k_conv12_rs(const uint8_t* __restrict__ c
         const float bz = bias[co];
         for (int c0 = qmin; c0 < qmin + nrows; c0 += F::CHUNK) { RS_BAR(); RS_BAR(); RS_BAR(); }      // the producers' prologue
         int res_hi = qmin + nrows;
-#define W2_POS(tau_) (((tau_) / 20) == 0 ? ((tau_) % 4 == 3 ? 7 : (tau_) % 4) : 3 + (tau_) % 4)
-#define W2_BOFF(tau_) (((((tau_) % 20) / 4) * 8 + W2_POS(tau_)) * G::BV * 16)
+#define W2_POS(tau_) rs_pos(ORD, tau_)
+#define W2_BOFF(tau_) ((rs_ky(ORD, tau_) * 8 + W2_POS(tau_)) * G::BV * 16)
         // the weight fragments of taps 0 .. BD - 1 are the same for every pass: the last taps of a pass fetch them for the next one
         uint4 bq[8][2];
         const uint8_t* wres = ldsb + F::WRES_OFF + boff;
@@ -414,14 +431,14 @@ __global__ __launch_bounds__(512) void k_conv12_rs(const uint8_t* __restrict__ c
                 srow[ky] = slot_ * G::ROWL; srot[ky] = w2b_rot(slot_);                                                           \
             }                                                                                                                    \
         } while (0)
-#define RS_AUNIT(tau_) do { if ((tau_) < 20) aoff[(tau_) / 4][(tau_) % 4] = srow[(tau_) / 4] + (wh[(tau_) % 4] | (((wl[(tau_) % 4] + srot[(tau_) / 4]) & 15) << 4)); } while (0)
+#define RS_AUNIT(tau_) do { if ((tau_) < 20) aoff[rs_ky(ORD, tau_)][rs_pg(ORD, tau_)] = srow[rs_ky(ORD, tau_)] + (wh[rs_pg(ORD, tau_)] | (((wl[rs_pg(ORD, tau_)] + srot[rs_ky(ORD, tau_)]) & 15) << 4)); } while (0)
         RS_AOFF(pass);
         if ((DBG & 128) && st_on) st_last = __builtin_readcyclecounter();
         for (;;) {
             int next_pass, lo, hi;
             bool have_next;
             RS_NEXT(pass, res_hi, next_pass, have_next, lo, hi);
-            const bool draw = pass % PK == PK - 1;
+            const bool draw = tleft == 1;
             uint32_t ticket = 0;
             // the ticket after the next one (raw instruction: atomicAdd() waits for the returned value on the spot); stored behind the second barrier
             if (draw && tid == 0) asm volatile("global_atomic_add %0, %1, %2, off sc0" : "=v"(ticket) : "v"(pass_ctr), "v"(1u) : "memory");
@@ -429,9 +446,38 @@ __global__ __launch_bounds__(512) void k_conv12_rs(const uint8_t* __restrict__ c
             const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
             __builtin_amdgcn_s_setprio((PRIO >> 4) & 3);
             uint4 af[PAIR ? 4 : 2][2];
+            // ORD 1: the part of A^T whose positions are final, two accumulator rows per tap, in place (an empty volatile asm keeps each result at
+            // its tap; the operations and their order are the output transform's: results stay bit-identical).  After it acc[0] = y0, acc[2] = y1,
+            // acc[1] = y2, acc[7] = y3 up to the pair (5,6), which stage 3 adds.
+            auto rs_fold = [&](const int tau) {
+#define RS_PIN(x_) asm volatile("" : "+v"(x_))
+                if (tau >= 11 && tau < 19) {                               // positions 1, 2 (final after tap 9): e1 -> acc[1], o1 -> acc[2]
+#pragma unroll
+                    for (int r = 2 * (tau - 11); r < 2 * (tau - 11) + 2; ++r) {
+                        float e = acc[1][r] + acc[2][r], o = acc[1][r] - acc[2][r];
+                        RS_PIN(e); RS_PIN(o); acc[1][r] = e; acc[2][r] = o;
+                    }
+                }
+                if (tau >= 21 && tau < 29) {                               // positions 0, 7 (final after tap 19): y0 = a0 + e1, y3 = o1 + a7
+#pragma unroll
+                    for (int r = 2 * (tau - 21); r < 2 * (tau - 21) + 2; ++r) {
+                        float a = acc[0][r] + acc[1][r], d = acc[2][r] + acc[7][r];
+                        RS_PIN(a); RS_PIN(d); acc[0][r] = a; acc[7][r] = d;
+                    }
+                }
+                if (tau >= 31 && tau < 39) {                               // positions 3, 4 (final after tap 29)
+#pragma unroll
+                    for (int r = 2 * (tau - 31); r < 2 * (tau - 31) + 2; ++r) {
+                        const float e2 = acc[3][r] + acc[4][r], o2 = acc[3][r] - acc[4][r];
+                        float a = acc[0][r] + e2, b = acc[2][r] + 2.f * o2, c = acc[1][r] + 4.f * e2, d = acc[7][r] + 8.f * o2;
+                        RS_PIN(a); RS_PIN(b); RS_PIN(c); RS_PIN(d); acc[0][r] = a; acc[2][r] = b; acc[1][r] = c; acc[7][r] = d;
+                    }
+                }
+#undef RS_PIN
+            };
 #define RS_AREAD(dst_, tau_)                                                                                                     \
             do {                                                                                                                 \
-                const uint8_t* an_ = ldsb + ((tau_) / 20) * G::BUF + aoff[((tau_) % 20) / 4][(tau_) % 4];                        \
+                const uint8_t* an_ = ldsb + ((tau_) / 20) * G::BUF + aoff[rs_ky(ORD, tau_)][rs_pg(ORD, tau_)];                   \
                 dst_[0] = *reinterpret_cast<const uint4*>(an_);                                                                  \
                 dst_[1] = *reinterpret_cast<const uint4*>(an_ + G::PLANE);                                                       \
             } while (0)
@@ -443,14 +489,15 @@ __global__ __launch_bounds__(512) void k_conv12_rs(const uint8_t* __restrict__ c
                 const int p = W2_POS(tau);                                                                                       \
                 const f16x8 b1 = __builtin_bit_cast(f16x8, bq[(tau) % 8][0]), b2 = __builtin_bit_cast(f16x8, bq[(tau) % 8][1]); \
                 const f16x8 a1 = __builtin_bit_cast(f16x8, af[(tau) % 2][0]), a2 = __builtin_bit_cast(f16x8, af[(tau) % 2][1]); \
-                acc[p] = mfma16(a2, b1, tl < 4 ? zero16 : acc[p]);        /* kernel row 0 starts the accumulator */               \
+                acc[p] = mfma16(a2, b1, rs_ky(ORD, tau) == 0 ? zero16 : acc[p]);      /* kernel row 0 starts the accumulator */   \
                 acc[p] = mfma16(a1, b2, acc[p]);                                                                                 \
                 acc[p] = mfma16(a1, b1, acc[p]);                                                                                 \
+                if constexpr (ORD == 1) { if (!(DBG & 16)) rs_fold(tau); }                                                        \
                 __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);                                                               \
                 __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);                                                               \
                 _Pragma("unroll") for (int g = 0; g < 3; ++g) {                                                                  \
                     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                                           \
-                    __builtin_amdgcn_sched_group_barrier(0x006, 4, 0);                                                           \
+                    __builtin_amdgcn_sched_group_barrier(0x006, ORD ? 6 : 4, 0);                                                 \
                 }                                                                                                                \
                 __builtin_amdgcn_sched_barrier(0);                                                                               \
             } while (0)
@@ -472,8 +519,8 @@ __global__ __launch_bounds__(512) void k_conv12_rs(const uint8_t* __restrict__ c
                 const f16x8 c1 = __builtin_bit_cast(f16x8, bq[((tau) + 1) % 8][0]), c2 = __builtin_bit_cast(f16x8, bq[((tau) + 1) % 8][1]); \
                 const f16x8 a1 = __builtin_bit_cast(f16x8, af[(tau) % 4][0]), a2 = __builtin_bit_cast(f16x8, af[(tau) % 4][1]); \
                 const f16x8 d1 = __builtin_bit_cast(f16x8, af[((tau) + 1) % 4][0]), d2 = __builtin_bit_cast(f16x8, af[((tau) + 1) % 4][1]); \
-                acc[p] = mfma16(a2, b1, tl < 4 ? zero16 : acc[p]);                                                               \
-                acc[q] = mfma16(d2, c1, tl < 4 ? zero16 : acc[q]);                                                               \
+                acc[p] = mfma16(a2, b1, rs_ky(ORD, tau) == 0 ? zero16 : acc[p]);                                                 \
+                acc[q] = mfma16(d2, c1, rs_ky(ORD, (tau) + 1) == 0 ? zero16 : acc[q]);                                           \
                 acc[p] = mfma16(a1, b2, acc[p]);                                                                                 \
                 acc[q] = mfma16(d1, c2, acc[q]);                                                                                 \
                 acc[p] = mfma16(a1, b1, acc[p]);                                                                                 \
@@ -519,13 +566,16 @@ __global__ __launch_bounds__(512) void k_conv12_rs(const uint8_t* __restrict__ c
             // output transform: Y = A^T M, pool, bias, ReLU -> the pass's 3 x 20 x 64 activations as fp32 in pbufE
             if (!(DBG & 16)) {
                 f32x16 y0, y1, y2, y3;
-                {
-                    const f32x16 e1 = acc[1] + acc[2], o1 = acc[1] - acc[2];
-                    y0 = acc[0] + e1; y1 = o1; y2 = e1; y3 = o1 + acc[7];
-                }
-                {
-                    const f32x16 e2 = acc[3] + acc[4], o2 = acc[3] - acc[4];
-                    y0 += e2; y1 += 2.f * o2; y2 += 4.f * e2; y3 += 8.f * o2;
+                if constexpr (ORD == 1) { y0 = acc[0]; y1 = acc[2]; y2 = acc[1]; y3 = acc[7]; }
+                else {
+                    {
+                        const f32x16 e1 = acc[1] + acc[2], o1 = acc[1] - acc[2];
+                        y0 = acc[0] + e1; y1 = o1; y2 = e1; y3 = o1 + acc[7];
+                    }
+                    {
+                        const f32x16 e2 = acc[3] + acc[4], o2 = acc[3] - acc[4];
+                        y0 += e2; y1 += 2.f * o2; y2 += 4.f * e2; y3 += 8.f * o2;
+                    }
                 }
                 {
                     const f32x16 e3 = acc[5] + acc[6], o3 = acc[5] - acc[6];
@@ -557,6 +607,7 @@ __global__ __launch_bounds__(512) void k_conv12_rs(const uint8_t* __restrict__ c
             if ((DBG & 128) && st_on) st_sum[7] += 1;
             if (!have_next) break;
             res_hi = hi;
+            tleft = tleft == 1 ? PK : tleft - 1;
             pass = next_pass;
         }
 #undef RS_TAP
