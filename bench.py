@@ -226,7 +226,7 @@ def measure(args, env):
     guard_info = None
     if args.guard_trip and with_cnn:
         # one step for the crops, then conv1 (and what follows it: the BN statistics, so that the later layers keep their scale) is scaled
-        # until between 1 and 64 crops of the step leave the range the fp16 pieces hold (>= 4368 behind conv1's ReLU)
+        # until between 12 and 24 crops of the step leave the range the fp16 pieces hold (>= 4368 behind conv1's ReLU)
         n0 = run(1)
         torch.cuda.synchronize()
         ln0 = lanes[0]
@@ -247,10 +247,10 @@ def measure(args, env):
         m = 4.0
         for _ in range(40):
             c, whole = count(m)
-            if c == 0 and not whole:
+            if c < 12 and not whole:          # (a band of 12..24 crops, so that runs compare: the cost of a trip grows with the crops re-run)
                 lo_m = m
                 m = m * 4.0 if hi_m is None else 0.5 * (lo_m + hi_m)
-            elif whole or c > 64:
+            elif whole or c > 24:
                 hi_m = m
                 m = 0.5 * (lo_m + hi_m)
             else:

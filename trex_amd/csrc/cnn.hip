@@ -1745,7 +1745,7 @@ static int net_forward_launch(trexhip_ctx* ctx, const uint8_t* d_crops, int n, f
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (ConvGeomB<CI_, CO_, S_, ROWS_, SplitK<KIND_>::NP, CIC_>::LDS_BYTES)))
         SET_ATTR(16, 64, 40, 10, 0, 6); SET_ATTR(16, 64, 40, 10, 0, 3); SET_ATTR(16, 64, 40, 10, 1, 3);
         SET_ATTR(64, 128, 20, 20, 0, 6); SET_ATTR(64, 128, 20, 20, 0, 3); SET_ATTR(64, 128, 20, 20, 1, 3);
-        SET_ATTR(16, 64, 40, 20, 1, 3); SET_ATTR(64, 128, 20, 10, 1, 3);
+        SET_ATTR(16, 64, 40, 20, 1, 3); SET_ATTR(64, 128, 20, 10, 1, 3); SET_ATTR(64, 128, 20, 4, 0, 6);
         TH_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv5_stream<16, 64, 40, 10, 4>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (ConvGeomS<16, 64, 40, 10, 4>::LDS_BYTES)));
         TH_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv5_stream<16, 64, 40, 8, 4>),
@@ -2007,7 +2007,9 @@ static int net_forward_launch(trexhip_ctx* ctx, const uint8_t* d_crops, int n, f
             else              hipLaunchKernelGGL(k_conv1_mfma3, dim3(n), dim3(256), 0, s, d_crops, net->w1h, net->b1, net->act1, net->inv1h, g);
         }
         LAUNCH_SPLIT2(16, 64, 40, 10, 0, 6, net->act1, net->w2s, net->b2, net->act2, 1.0f, g);
-        LAUNCH_SPLIT2(64, 128, 20, 20, 0, 6, net->act2, net->w3s, net->b3, net->act3, 1.0f, g);
+        // (conv3 in bands of 4 rows, five workgroups per crop: a re-run is a handful of crops, and one workgroup walking a whole crop's 2 GFLOP
+        // alone took 0.4 ms of the 0.5 ms a tripped guard cost)
+        LAUNCH_SPLIT2(64, 128, 20, 4, 0, 6, net->act2, net->w3s, net->b3, net->act3, 1.0f, g);
         hipLaunchKernelGGL(k_fc1, dim3((n + 31) / 32, FC1_KSPLIT), dim3(256), 0, s, net->act3, net->wf1, net->bf1, net->fc1, n, 12800, g);
         hipLaunchKernelGGL(k_head, dim3((n + 4 * HEAD_CPW - 1) / (4 * HEAD_CPW)), dim3(256), 0, s, net->fc1, net->lng, net->lnb, net->wf2t, net->bf2,
                            d_probs, d_logits, n, net->classes, g, FC1_KSPLIT);
