@@ -15,6 +15,12 @@
 // drift apart.  The arithmetic of every phase is k_conv12_wpre's, instruction for instruction: V3 and the probabilities stay bit-identical to
 // the two-kernel chain (tests/test_cnn_gpu.py::test_fused_equals_two_kernel_chain).
 //
+// Measured and not kept (round 5, profiles/r05_f12_two_ahead.txt): the producer TWO passes ahead -- V2 transform into registers beside taps 20-39,
+// conv1 beside the output transform, where the matrix pipe idles; contiguous passes per workgroup instead of tickets.  Bit-identical, and taps
+// 20-39 do fall from 3660 to 2580 cycles without conv1's MFMAs beside them, but conv1 + pool is one wave's serial chain of ~350 instructions and
+// 64 MFMAs (~3900 cycles wherever it runs): behind the 1770-cycle output transform it is exposed, the round grows from 10.3 k to 11.7 k cycles
+// (3.63 -> 3.68 ms).  Both roles are single instruction streams of ~8300-8500 cycles per round; the stages only decide how they line up.
+//
 // LDS: the four operand planes (ring of NR = 10 row slots + the zero row, as before: P2 writes the ring in the stage where no tap reads it),
 // pbufE (consumer -> producer), pbufP (conv1's pooled activations of a chunk), the padded fp16 crop rows of a chunk: 93 KB.
 
