@@ -1,13 +1,13 @@
 #!/bin/bash
 # round-5 evidence on the MI355X box: kernel-trace stats + FETCH / WRITE passes of the default bench (tools/collect_profiles.sh), matrix-pipe / wait /
-# LDS / instruction counters of the two convolution kernels of the default chain (k_conv12_rs = conv1 inside conv2, role-split; k_conv5_wpre = conv3),
+# LDS / instruction counters of the two convolution kernels of the default chain (k_conv12_rs = conv1 inside conv2, role-split; k_conv5_wpair = conv3, pair by pair),
 # the detect kernels at C4, the bench line of the driver's command
 #   gpurun --timeout 2400 -- 'bash tools/collect_r05.sh'
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/prof
 mkdir -p "$OUT"
 timeout 1200 bash $ROOT/tools/collect_profiles.sh r05 > "$OUT/r05_collect.log" 2>&1
-bash $ROOT/tools/pmc_kernel.sh "k_conv12_rs|k_conv12_wpre|k_conv5_wpre" "" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE" "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" \
+bash $ROOT/tools/pmc_kernel.sh "k_conv12_rs|k_conv12_wpre|k_conv5_wp" "" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE" "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" \
      "SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS SQ_INSTS_LDS SQ_WAIT_INST_LDS" "SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR" "SQ_INSTS_SALU SQ_INSTS_SMEM" "FETCH_SIZE" "WRITE_SIZE" > "$OUT/r05_pmc_conv.txt" 2>&1
 bash $ROOT/tools/pmc_kernel.sh "k_rows32|k_ccl_lds|k_gather" "--stages segment" "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" "FETCH_SIZE" "WRITE_SIZE" > "$OUT/r05_pmc_detect_kernels.txt" 2>&1
 cd $ROOT
