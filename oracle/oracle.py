@@ -511,3 +511,31 @@ def pv_read_v6(buf):
     used = f(_ptr(buf), len(buf), C.byref(ts), C.byref(n), _ptr(runs), len(runs), _ptr(px), len(px), _ptr(br), _ptr(bp), 65535)
     nb = n.value
     return int(used), int(ts.value), runs[:int(br[:nb].sum())].copy(), px[:int(bp[:nb].sum())].copy(), br[:nb].copy(), bp[:nb].copy()
+
+
+def history_split(n_blobs, n_fish, blob_mappings, paired, streak=None, split_threshold=-1, manual=(), history_split_on=True):
+    """HistorySplit's per-frame decision (tracking/HistorySplit.cpp:52-312, restated in trex_split.c).
+    blob_mappings: {blob: iterable of individuals}, paired: {individual: [(blob, distance), ...]} (walked in the order given).
+    Returns (number[n_blobs], allow_less_than[n_blobs], big[n_blobs], centers: per blob the individuals whose last positions are appended)."""
+    L = lib()
+    L.oracle_history_split.restype = C.c_int32
+    L.oracle_history_split.argtypes = [C.c_int32, C.c_int32] + [C.c_void_p] * 6 + [C.c_int32, C.c_void_p, C.c_int32, C.c_int32] + [C.c_void_p] * 5
+    map_off = np.zeros(n_blobs + 1, np.int32); map_fish = []
+    for b in range(n_blobs):
+        map_off[b] = len(map_fish); map_fish += sorted(set(blob_mappings.get(b, ())))
+    map_off[n_blobs] = len(map_fish)
+    pair_off = np.zeros(n_fish + 1, np.int32); pb = []; pd = []
+    for f in range(n_fish):
+        pair_off[f] = len(pb)
+        for b, d in paired.get(f, ()):
+            pb.append(b); pd.append(d)
+    pair_off[n_fish] = len(pb)
+    map_fish = np.asarray(map_fish + [0], np.int32); pb = np.asarray(pb + [0], np.int32); pd = np.asarray(pd + [0], np.float32)
+    st = np.asarray(streak if streak is not None else [1] * n_fish, np.int32)
+    mn = np.asarray(list(manual) + [0], np.int32)
+    number = np.zeros(n_blobs, np.int32); allow = np.zeros(n_blobs, np.uint8); big = np.zeros(n_blobs, np.uint8)
+    coff = np.zeros(n_blobs + 1, np.int32); cfish = np.zeros(2 * n_fish + 2, np.int32)
+    L.oracle_history_split(n_blobs, n_fish, _ptr(map_off), _ptr(map_fish), _ptr(pair_off), _ptr(pb), _ptr(pd), _ptr(st), int(split_threshold),
+                           _ptr(mn), len(manual), 1 if history_split_on else 0, _ptr(number), _ptr(allow), _ptr(big), _ptr(coff), _ptr(cfish))
+    centers = [list(cfish[coff[b]:coff[b + 1]]) for b in range(n_blobs)]
+    return number, allow, big, centers

@@ -129,6 +129,12 @@ void oracle_split_search(const oracle_run* runs, int32_t n_runs, const uint8_t* 
                          int32_t width, int32_t height, int32_t method, int32_t connectivity, const oracle_split_params* P,
                          int32_t presumed_nr, oracle_split_info* out);
 
+/* HistorySplit's per-frame decision (tracking/HistorySplit.cpp:52-312), see trex_split.c */
+int32_t oracle_history_split(int32_t n_blobs, int32_t n_fish, const int32_t* map_off, const int32_t* map_fish,
+                             const int32_t* pair_off, const int32_t* pair_blob, const float* pair_d,
+                             const int32_t* streak, int32_t split_threshold, const int32_t* manual, int32_t n_manual, int32_t history_split_on,
+                             int32_t* number, uint8_t* allow_less, uint8_t* big, int32_t* center_off, int32_t* center_fish);
+
 #ifdef __cplusplus
 }
 #endif

@@ -201,3 +201,116 @@ void oracle_split_search(const oracle_run* runs, int32_t n_runs, const uint8_t* 
     out->min_pixel = S.min_pixel; out->max_pixel = S.max_pixel;
     out->first_size = S.first_size;
 }
+
+
+/* ------------------------------------------------------------------------------------------------------------------------------
+ * HistorySplit's per-frame decision: which blobs of a frame are split, and into how many.  TEST INFRASTRUCTURE ONLY.
+ *
+ * Follows HistorySplit::HistorySplit, Application/src/tracker/tracking/HistorySplit.cpp:52-312 (apply_manual_matches :8-50), on flat
+ * arrays: blobs are 0 .. n_blobs - 1 (standing for pv::bid), individuals 0 .. n_fish - 1 (Idx_t; a negative entry of a blob's
+ * individuals = the invalid Idx_t a manual split leaves there, skipped like :101-102).
+ *   map_off / map_fish    PPFrame::blob_mappings (PPFrame.h:68): per blob the individuals mapped to it -- a std::set, ascending
+ *   pair_off / pair_blob / pair_d   PPFrame::paired (:69): per individual its (blob, distance) edges, walked in the order given
+ *   streak                frame.cached(fdx)->valid_frame_streak (:139-147), threshold < 0 = track_history_split_threshold invalid
+ * The reference walks two robin_hood maps (blob_mappings at :76, probs_per_fish at :266) in HASH order.  Nothing decided here depends on
+ * that order except (a) the order of `centers`, which only the watershed algorithm reads, and (b) exact ties of two distances for one
+ * blob (:206: the individual assigned first keeps it).  Here: blobs ascending, individuals in the order the clique search meets them.
+ * Output: number[b] / allow_less[b] = expect[b] (0 = not in `expect`), big[b] = in big_blobs; center_off / center_fish = per blob the
+ * individuals whose last_positions :281-291 appends to expect[b].centers, in that order.  Returns the number of big blobs.
+ * ------------------------------------------------------------------------------------------------------------------------------ */
+typedef struct { int fish; float d; } hs_assign;
+int32_t oracle_history_split(int32_t n_blobs, int32_t n_fish, const int32_t* map_off, const int32_t* map_fish,
+                             const int32_t* pair_off, const int32_t* pair_blob, const float* pair_d,
+                             const int32_t* streak, int32_t split_threshold, const int32_t* manual, int32_t n_manual, int32_t history_split_on,
+                             int32_t* number, uint8_t* allow_less, uint8_t* big, int32_t* center_off, int32_t* center_fish) {
+    int32_t n_big = 0;
+    uint8_t* walked = (uint8_t*)calloc((size_t)n_blobs + 1, 1);
+    /* centers as (blob, fish) pairs in the order they are appended; gathered per blob at the end */
+    int32_t* cb = (int32_t*)malloc(sizeof(int32_t) * (size_t)(2 * n_fish + 2)); int32_t* cf = (int32_t*)malloc(sizeof(int32_t) * (size_t)(2 * n_fish + 2)); int32_t nc = 0;
+    for (int b = 0; b < n_blobs; ++b) { number[b] = 0; allow_less[b] = 0; big[b] = 0; }
+    for (int i = 0; i < n_manual; ++i) {                                    /* :18-36 */
+        const int b = manual[i];
+        if (b < 0 || b >= n_blobs) continue;                                /* !bdx.valid() / !frame.has_bdx(bdx) */
+        if (!big[b]) { big[b] = 1; ++n_big; }
+        number[b] = 2; allow_less[b] = 0; walked[b] = 1;
+    }
+    if (history_split_on) {                                                 /* :63-68 */
+        uint8_t* in_b = (uint8_t*)malloc((size_t)n_blobs + 1); uint8_t* in_f = (uint8_t*)malloc((size_t)n_fish + 1);
+        int32_t* qb = (int32_t*)malloc(sizeof(int32_t) * (size_t)(n_blobs + 1)); int32_t* fl = (int32_t*)malloc(sizeof(int32_t) * (size_t)(n_fish + 1));
+        hs_assign* ab = (hs_assign*)malloc(sizeof(hs_assign) * (size_t)(n_blobs + 1));       /* assign_blob */
+        int32_t* cur = (int32_t*)malloc(sizeof(int32_t) * (size_t)(n_fish + 1));             /* first alternative left of probs_per_fish[f] (index into its sorted edges) */
+        int32_t* ord = (int32_t*)malloc(sizeof(int32_t) * (size_t)(pair_off[n_fish] + 1));   /* per individual its edges sorted by (distance, blob): the std::set of :233-236 */
+        int32_t* q = (int32_t*)malloc(sizeof(int32_t) * (size_t)(4 * (pair_off[n_fish] + n_fish) + 16));
+        for (int b0 = 0; b0 < n_blobs; ++b0) {                              /* :76 */
+            if (map_off[b0 + 1] - map_off[b0] <= 1) continue;               /* :79 */
+            if (walked[b0]) continue;                                       /* :82 */
+            memset(in_b, 0, (size_t)n_blobs); memset(in_f, 0, (size_t)n_fish);
+            int qh = 0, qt = 0, nb = 0, nf = 0;
+            qb[qt++] = b0;                                                   /* :91-92: the start blob is NOT inserted into available_bdx / already_walked here */
+            while (qh < qt) {
+                const int c = qb[qh++];
+                for (int k = map_off[c]; k < map_off[c + 1]; ++k) {
+                    const int f = map_fish[k];
+                    if (f < 0) continue;                                    /* :101 */
+                    if (split_threshold >= 0) {                             /* :104-148: the streak is cached per individual, the test is the same every time */
+                        const int len = streak[f] > 0 ? streak[f] : -1;
+                        if (len < 0 || len < split_threshold) continue;
+                    }
+                    for (int e = pair_off[f]; e < pair_off[f + 1]; ++e) {   /* :151-157 */
+                        const int b = pair_blob[e];
+                        if (!in_b[b]) { if (qt <= n_blobs) qb[qt++] = b; in_b[b] = 1; ++nb; walked[b] = 1; }
+                    }
+                    if (!in_f[f]) { in_f[f] = 1; fl[nf++] = f; }            /* :159 */
+                }
+            }
+            if (nf <= nb) continue;                                         /* :172 */
+            for (int b = 0; b < n_blobs; ++b) ab[b].fish = -1;
+            int ch = 0, ct = 0;
+            for (int i = 0; i < nf; ++i) {                                  /* :227-246 */
+                const int f = fl[i], e0 = pair_off[f], e1 = pair_off[f + 1];
+                cur[f] = e0;
+                if (e0 == e1) { cur[f] = -1; continue; }                    /* pairs.empty(): no entry in probs_per_fish */
+                for (int e = e0; e < e1; ++e) ord[e] = e;
+                for (int a = e0 + 1; a < e1; ++a) {                         /* insertion sort by (d, blob) */
+                    const int v = ord[a]; int z = a - 1;
+                    while (z >= e0 && (pair_d[ord[z]] > pair_d[v] || (pair_d[ord[z]] == pair_d[v] && pair_blob[ord[z]] > pair_blob[v]))) { ord[z + 1] = ord[z]; --z; }
+                    ord[z + 1] = v;
+                }
+                int w = e0;                                                 /* a std::set: equal (d, blob) entries collapse */
+                for (int a = e0 + 1; a < e1; ++a) if (pair_d[ord[a]] != pair_d[ord[w]] || pair_blob[ord[a]] != pair_blob[ord[w]]) ord[++w] = ord[a];
+                for (int a = w + 1; a < e1; ++a) ord[a] = -1;
+                q[ct++] = f;
+            }
+            while (ch < ct) {                                               /* :248-257 */
+                const int f = q[ch++];
+                const int e1 = pair_off[f + 1];
+                if (cur[f] < 0 || cur[f] >= e1 || ord[cur[f]] < 0) continue;        /* combinations.empty() */
+                const int e = ord[cur[f]], b = pair_blob[e];                /* check_combinations :190-224 */
+                const float d = pair_d[e];
+                int done = 0;
+                if (ab[b].fish < 0) { ab[b].fish = f; ab[b].d = d; done = 1; }
+                else if (ab[b].fish != f) {
+                    if (!(ab[b].d <= d)) { const int o = ab[b].fish; ab[b].fish = f; ab[b].d = d; q[ct++] = o; done = 1; }
+                }
+                if (!done) { ++cur[f]; q[ct++] = f; }                       /* :221 erase + :256 push again */
+            }
+            for (int i = 0; i < nf; ++i) {                                  /* :266-303 */
+                const int f = fl[i], e0 = pair_off[f], e1 = pair_off[f + 1];
+                if (cur[f] < 0) continue;                                   /* not in probs_per_fish */
+                if (cur[f] < e1 && ord[cur[f]] >= 0) continue;              /* alternatives left (:272) */
+                const int mx = pair_blob[ord[e0]];                          /* assign_fish[fdx] = the closest (:241) */
+                if (ab[mx].fish >= 0) {                                     /* :285-294 */
+                    ++number[mx]; cb[nc] = mx; cf[nc++] = ab[mx].fish; ab[mx].fish = -1;
+                }
+                ++number[mx]; cb[nc] = mx; cf[nc++] = f;                    /* :296-301 */
+                if (!big[mx]) { big[mx] = 1; ++n_big; }
+            }
+        }
+        free(in_b); free(in_f); free(qb); free(fl); free(ab); free(cur); free(ord); free(q);
+    }
+    int32_t o = 0;
+    for (int b = 0; b < n_blobs; ++b) { center_off[b] = o; for (int i = 0; i < nc; ++i) if (cb[i] == b) center_fish[o++] = cf[i]; }
+    center_off[n_blobs] = o;
+    free(walked); free(cb); free(cf);
+    return n_big;
+}

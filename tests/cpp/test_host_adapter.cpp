@@ -12,6 +12,7 @@
 #include "../../trex_amd/host/HipVINetwork.h"
 #include "../../trex_amd/host/HipPosture.h"
 #include "../../trex_amd/host/HipSplitBlob.h"
+#include "../../trex_amd/host/HipHistorySplit.h"
 #include <cmath>
 #include "../../oracle/trex_oracle.h"
 
@@ -555,6 +556,46 @@ int main(int argc, char** argv) {
             for (auto& l : *pr.lines) { n += (size_t)l.x1 - l.x0 + 1; CHECK(l.y <= res.blobs[0].y1 - res.blobs[0].y0 && l.x1 <= res.blobs[0].x1 - res.blobs[0].x0); }
             CHECK(pr.pixels && pr.pixels->size() == n && n <= prev);
             prev = n;
+        }
+        // --- the history split on the same frame (HistorySplit.cpp:52-312 -> PrefilterBlobs::split_big): two individuals were last seen inside the
+        // merged blob, one inside the single one; each blob is the only object its individuals are paired with ---
+        {
+            using HS = HipHistorySplit;
+            auto id_of = [&](const int b) { const trexhip_blob& B = res.blobs[b]; const trexhip_run& r0 = res.runs[res.frames[0].run_begin + B.run_begin];
+                                            return HipSplitBlob::bid(r0.x0, r0.x1, r0.y, B.n_runs); };
+            const HS::bid_t merged = id_of(0), single = id_of(1);
+            HS::Frame F;
+            F.blob_mappings[merged] = {0, 1}; F.blob_mappings[single] = {2};
+            F.paired[0] = {{merged, 3.f}}; F.paired[1] = {{merged, 4.5f}}; F.paired[2] = {{single, 1.f}};
+            F.last_positions[0] = {cmn::Vec2(70, 50)}; F.last_positions[1] = {cmn::Vec2(72, 59)}; F.last_positions[2] = {cmn::Vec2(180, 60)};
+            for (int f = 0; f < 3; ++f) F.valid_frame_streak[f] = 20;
+            F.blob_pos[merged] = cmn::Vec2((float)res.blobs[0].x0, (float)res.blobs[0].y0);
+            F.blob_pos[single] = cmn::Vec2((float)res.blobs[1].x0, (float)res.blobs[1].y0);
+            const HS::Decision D = HS::decide(F, HS::Settings{});
+            CHECK(D.big_blobs.size() == 1 && D.big_blobs[0] == merged);
+            CHECK(D.expect.at(merged).number == 2 && !D.expect.at(merged).allow_less_than && D.expect.at(merged).centers.size() == 2);
+            CHECK(D.expect.at(merged).centers[0][0].x == 70.f - F.blob_pos[merged].x);           // relative to the blob's bounds().pos() (:283-284)
+            // the same decision by the CPU restatement
+            {
+                const int32_t map_off[3] = {0, 2, 3}, map_fish[3] = {0, 1, 2}, pair_off[4] = {0, 1, 2, 3}, pair_blob[3] = {0, 0, 1}, streak[3] = {20, 20, 20};
+                const float pair_d[3] = {3.f, 4.5f, 1.f};
+                int32_t number[2], coff[3], cfish[8]; uint8_t allow[2], big[2];
+                CHECK(oracle_history_split(2, 3, map_off, map_fish, pair_off, pair_blob, pair_d, streak, -1, nullptr, 0, 1, number, allow, big, coff, cfish) == 1);
+                CHECK(number[0] == 2 && number[1] == 0 && big[0] == 1 && big[1] == 0 && cfish[0] == 0 && cfish[1] == 1);
+            }
+            std::map<HS::bid_t, uint32_t> pooled{{merged, 0u}, {single, 1u}};
+            std::vector<HS::Outcome> o;
+            try { o = HS::split_big(sb, D, pooled, res, ss, 1.f); }
+            catch (const std::exception& e) { std::fprintf(stderr, "HipHistorySplit::split_big: %s\n", e.what()); std::exit(1); }
+            CHECK(o.size() == 1 && o[0].blob == merged && o[0].threshold == r[0].threshold && !o[0].kept_whole && !o[0].whole_to_noise);
+            CHECK(o[0].regular.size() == 2 && o[0].regular.size() + o[0].noise.size() == r[0].blobs.size());       // the two largest pieces stay objects (:286-292)
+            size_t n0 = 0, n1 = 0;
+            for (auto& l : *o[0].regular[0].lines) n0 += (size_t)l.x1 - l.x0 + 1;
+            for (auto& l : *o[0].regular[1].lines) n1 += (size_t)l.x1 - l.x0 + 1;
+            CHECK(n0 >= n1 && n1 >= 40 * 0.35);                                  // in_range_of_one(r, 0.35, 1) of the size filter 40 .. 330
+            // with the switch off nothing is split (:63-68)
+            HS::Settings off; off.track_do_history_split = false;
+            CHECK(HS::decide(F, off).big_blobs.empty());
         }
         }
         trexhip_destroy(ctx);
