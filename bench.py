@@ -448,7 +448,7 @@ def measure(args, env):
         if args.cnn_mode == "fp32":
             k3, k2, r3, r2 = "k_conv5<64,128,20,20,32> (conv3, fp32 MFMA)", "k_conv5<16,64,40,20,16> (conv2, fp32 MFMA)", 1.0, 1.0
         elif pre:
-            k3 = "k_conv5_wpre (conv3 on the V3 operand image: Winograd F(4,5) along x, fp16 two-piece split, 3 MFMA products per transformed product, fp32 accumulate)"
+            k3 = "k_conv5_wpair (conv3 on the pair-major V3 operand image: Winograd F(4,5) along x walked position pair by position pair, the output transform under the next pair's taps; fp16 two-piece split, 3 MFMA products per transformed product, fp32 accumulate)"
             k2 = "k_conv2_wpre2 (conv2 on the V2 operand image, writes V3: same arithmetic, two workgroups per CU, LDS-DMA staging)"
             r3, r2 = 1.2, 1.28
             fused12 = not rgb and not (geom & (1 << 28))
@@ -479,7 +479,7 @@ def measure(args, env):
         if fused12:
             in2 = n_blobs * 6400                      # the u8 crops are all the fused kernel reads
         roof2 = conv_roof(k2, c2_s, FLOP_PER_CROP_CONV2 + (FLOP_PER_CROP_CONV1 if fused12 else 0.0), r2, prof["CONV2"][1], in2 + out2)
-        t3 = pmc_traffic("trexhip::k_conv5_wpre" if pre else ("trexhip::k_conv5_wino<64, 128, 20, 2" if wino3 else "trexhip::k_conv5_stream<64, 128, 20, 20, 8"))
+        t3 = pmc_traffic("trexhip::k_conv5_wpair" if pre else ("trexhip::k_conv5_wino<64, 128, 20, 2" if wino3 else "trexhip::k_conv5_stream<64, 128, 20, 20, 8"))
         t2 = pmc_traffic((("trexhip::k_conv12_rs" if k2.startswith("k_conv12_rs") else "trexhip::k_conv12_wpre") if fused12 else "trexhip::k_conv2_wpre2") if pre else "trexhip::k_conv5_stream<16, 64, 40, 8, 4")
         if args.cnn_mode == "fp16x3":
             roof3["traffic"], roof2["traffic"] = t3, t2
