@@ -1147,28 +1147,34 @@ __global__ __launch_bounds__(256) void k_fc1(const float* __restrict__ act, cons
 // [k-octet][piece][co] x 8 halves.  3 MFMA products per product, fp32 accumulate; an activation outside the fp16 range
 // raises the same flag as the convolutions (guarded fp32 re-run).
 // ------------------------------------------------------------------------------------------------
+// MT = tiles of 32 crops per workgroup.  4 (128 crops) for real batches; 1 for SMALL ones (TRex's default detect_batch_size of 1 gives 100 crops per
+// call): ten workgroups walking 40 chunks of (load, split, barrier, 24 MFMAs) each took 54 us of a 234 us step -- a chain no prefetch depth shortens
+// (four chunks in flight: 57 us); with 32 crops per workgroup the chain is a quarter as long per chunk and four times as many workgroups run it.
+// Every output is the same sum in the same order whatever MT is.
+template <int MT = 4>
 __global__ __launch_bounds__(256) void k_fc1_split(const float* __restrict__ act, const uint4* __restrict__ wq /*[K/8][2][128]*/,
                                                    const float* __restrict__ bias, float* __restrict__ out, int n, int K,
                                                    const float out_scale, uint32_t* __restrict__ overflow, uint8_t* __restrict__ crop_flags) {
     constexpr int RPB = 80;                                     // bytes per staged row (32 halves + 16 pad)
-    __shared__ __attribute__((aligned(16))) uint8_t As[2][2][128 * RPB];
+    constexpr int RW = 32 * MT;                                 // crops per workgroup
+    __shared__ __attribute__((aligned(16))) uint8_t As[2][2][RW * RPB];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int j = lane & 31, h = lane >> 5;
-    const int m0 = blockIdx.x * 128;
+    const int m0 = blockIdx.x * RW;
     const int kspan = K / (int)gridDim.y, kbeg = (int)blockIdx.y * kspan;
     out += (size_t)blockIdx.y * n * 128;
-    f32x16 acc[4];
+    f32x16 acc[MT];
 #pragma unroll
-    for (int m = 0; m < 4; ++m)
+    for (int m = 0; m < MT; ++m)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[m][r] = 0.f;
-    bool ovf4[4] = {false, false, false, false};                // per staged row of this thread (row = crop): the range guard is per crop
-    float4 na[4];
+    bool ovf4[MT] = {};                // per staged row of this thread (row = crop): the range guard is per crop
+    float4 na[MT];
     uint4 nb[2][2];
     const uint4* wl = wq + (size_t)(kbeg / 8) * 256 + wave * 32 + j;     // + (ko*2 + piece)*128
 #define FCS_FETCH(kc)                                                                                                      \
     do {                                                                                                                   \
-        _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                                    \
+        _Pragma("unroll") for (int i = 0; i < MT; ++i) {                                                                    \
             const int idx = tid + 256 * i, row = idx >> 3, q = idx & 7;                                                    \
             na[i] = m0 + row < n ? *reinterpret_cast<const float4*>(act + (size_t)(m0 + row) * K + kbeg + (kc) * 32 + q * 4) \
                                  : make_float4(0.f, 0.f, 0.f, 0.f);                                                        \
@@ -1180,14 +1186,14 @@ __global__ __launch_bounds__(256) void k_fc1_split(const float* __restrict__ act
     } while (0)
 #define FCS_STASH(buf)                                                                                                     \
     do {                                                                                                                   \
-        _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                                    \
+        _Pragma("unroll") for (int i = 0; i < MT; ++i) {                                                                    \
             const int idx = tid + 256 * i, row = idx >> 3, q = idx & 7;                                                    \
             uint32_t a1[4], a2[4];                                                                                         \
             split2h(na[i].x, a1[0], a2[0], ovf4[i]); split2h(na[i].y, a1[1], a2[1], ovf4[i]);                              \
             split2h(na[i].z, a1[2], a2[2], ovf4[i]); split2h(na[i].w, a1[3], a2[3], ovf4[i]);                              \
             uint8_t* d = As[buf][0] + row * RPB + q * 8;                                                                   \
             *reinterpret_cast<uint2*>(d) = make_uint2(a1[0] | (a1[1] << 16), a1[2] | (a1[3] << 16));                       \
-            *reinterpret_cast<uint2*>(d + 128 * RPB) = make_uint2(a2[0] | (a2[1] << 16), a2[2] | (a2[3] << 16));           \
+            *reinterpret_cast<uint2*>(d + RW * RPB) = make_uint2(a2[0] | (a2[1] << 16), a2[2] | (a2[3] << 16));           \
         }                                                                                                                  \
     } while (0)
     FCS_FETCH(0);
@@ -1202,10 +1208,10 @@ __global__ __launch_bounds__(256) void k_fc1_split(const float* __restrict__ act
         for (int ks = 0; ks < 2; ++ks) {
             const f16x8 b1 = __builtin_bit_cast(f16x8, cb[ks][0]), b2 = __builtin_bit_cast(f16x8, cb[ks][1]);
 #pragma unroll
-            for (int m = 0; m < 4; ++m) {
+            for (int m = 0; m < MT; ++m) {
                 const uint8_t* a = As[buf][0] + (32 * m + j) * RPB + (2 * ks + h) * 16;
                 const f16x8 p1 = __builtin_bit_cast(f16x8, *reinterpret_cast<const uint4*>(a));
-                const f16x8 p2 = __builtin_bit_cast(f16x8, *reinterpret_cast<const uint4*>(a + 128 * RPB));
+                const f16x8 p2 = __builtin_bit_cast(f16x8, *reinterpret_cast<const uint4*>(a + RW * RPB));
                 acc[m] = mfma16(p2, b1, acc[m]);
                 acc[m] = mfma16(p1, b2, acc[m]);
                 acc[m] = mfma16(p1, b1, acc[m]);
@@ -1219,16 +1225,19 @@ __global__ __launch_bounds__(256) void k_fc1_split(const float* __restrict__ act
     }
 #undef FCS_FETCH
 #undef FCS_STASH
-    if (__any(ovf4[0] | ovf4[1] | ovf4[2] | ovf4[3])) {
+    bool any_ovf = false;
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < MT; ++i) any_ovf |= ovf4[i];
+    if (__any(any_ovf)) {
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
             if (ovf4[i] && crop_flags && m0 + ((tid + 256 * i) >> 3) < n) crop_flags[m0 + ((tid + 256 * i) >> 3)] = 1;
         if (lane == 0) atomicOr(overflow, 1u);
     }
     const int co = wave * 32 + j;
     const float bz = blockIdx.y == 0 ? bias[co] : 0.f;
 #pragma unroll
-    for (int m = 0; m < 4; ++m)
+    for (int m = 0; m < MT; ++m)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int i = 32 * m + (r & 3) + 8 * (r >> 2) + 4 * h;
@@ -1992,7 +2001,10 @@ static int net_forward_launch(trexhip_ctx* ctx, const uint8_t* d_crops, int n, f
     const int ks1 = (ks_env > 0 && ks_env <= FC1_KSPLIT && 400 % ks_env == 0) ? ks_env : FC1_KSPLIT;
     const bool split1 = mode == TREXHIP_CNN_FP16X3 && !(ctx->tune_conv_geom & 32);
     if (split1)
-        hipLaunchKernelGGL(k_fc1_split, dim3((n + 127) / 128, ks1), dim3(256), 0, s, net->act3, net->wf1h, net->bf1, net->fc1, n, 12800, net->invf1h, net->d_ovf, net->d_ovfc);
+        if (n <= 1024)     // small batches: 32 crops per workgroup (same sums in the same order: a crop's row does not depend on the kernel its batch got)
+            hipLaunchKernelGGL(k_fc1_split<1>, dim3((n + 31) / 32, ks1), dim3(256), 0, s, net->act3, net->wf1h, net->bf1, net->fc1, n, 12800, net->invf1h, net->d_ovf, net->d_ovfc);
+        else
+            hipLaunchKernelGGL(k_fc1_split<4>, dim3((n + 127) / 128, ks1), dim3(256), 0, s, net->act3, net->wf1h, net->bf1, net->fc1, n, 12800, net->invf1h, net->d_ovf, net->d_ovfc);
     else
         hipLaunchKernelGGL(k_fc1, dim3((n + 31) / 32, FC1_KSPLIT), dim3(256), 0, s, net->act3, net->wf1, net->bf1, net->fc1, n, 12800, (const uint32_t*)nullptr);
     hipLaunchKernelGGL(k_head, dim3((n + 4 * HEAD_CPW - 1) / (4 * HEAD_CPW)), dim3(256), 0, s, net->fc1, net->lng, net->lnb, net->wf2t, net->bf2,
