@@ -69,7 +69,7 @@ struct W12RGeom {
     static constexpr int res_slot(const int tau, const int pat = 0) { return pat == 0 ? tau : (pat == 1 ? (tau < 10 ? tau : tau - 10) : (tau < 7 ? tau : tau - 13)); }
 };
 
-template <int DBG = 0, int BD = 3, int TSPLIT = 20, int PRIO = 0x202, int PAIR = 0, int RESPAT = 0, int ORD = 1>      // PAIR: two taps at a time, consecutive MFMAs on different accumulators; TSPLIT: taps in front of the first barrier of a round; PRIO: s_setprio of (producer, tap loop, output transform) as hex digits
+template <int DBG = 0, int BD = 3, int TSPLIT = 20, int PRIO = 0x201, int PAIR = 0, int RESPAT = 0, int ORD = 1>      // PRIO 0x201: since the taps run in pair order the producers' V2 transform is the longer half of stage 3 and outranks the output transform (0x202, equal priorities: 3.65 ms, 0x201 / 0x200 / 0x301 / 0x311: 3.58-3.60); PAIR: two taps at a time, consecutive MFMAs on different accumulators; TSPLIT: taps in front of the first barrier of a round; PRIO: s_setprio of (producer, tap loop, output transform) as hex digits
 __global__ __launch_bounds__(512) void k_conv12_rs(const uint8_t* __restrict__ crops /*[N][80][80]*/, const uint4* __restrict__ w1tab /*[16][64]*/,
                                                    const float* __restrict__ bias1, const float inv_scale1,
                                                    const uint4* __restrict__ wp /*[5][8][2][2][64] x 16 B*/, const float* __restrict__ bias,
