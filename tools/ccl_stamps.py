@@ -4,8 +4,10 @@ os.environ["TREXHIP_CCL_STOP"] = "-1"
 import torch
 from trex_amd import capi, synth
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 64
-W, H, _, _ = synth.CONFIGS["C4"]
-frames, bg = synth.batch_torch("C4", B, "cuda")
+CFG = sys.argv[2] if len(sys.argv) > 2 else "C4"
+W, H, _, _ = synth.CONFIGS[CFG]
+frames, bg = synth.batch_torch(CFG, B, "cuda")
+print(f"# {CFG}, {B} frames; cycles of the phases of k_ccl_lds seen by workgroup 0: P1 row scan, P2 runs -> LDS, P3 link, P4 flatten, P5 numbering + counts, P6 filter + reservation, P7 records, P8 grouping")
 seg = capi.Segmenter(capi.default_params(W, H, max_batch=B, max_blobs=1024, max_pixels=1 << 18, max_runs=32768))
 seg.set_background(bg)
 L = capi.lib()

@@ -178,6 +178,8 @@ int trexhip_create(const trexhip_params* p, trexhip_ctx** out) {
     if (const char* e = std::getenv("TREXHIP_CCL_STOP")) ctx->tune_ccl_stop = std::atoi(e);
 #endif
     if (const char* e = std::getenv("TREXHIP_SEG_GROUPS")) ctx->tune_seg_groups = std::atoi(e);
+    if (const char* e = std::getenv("TREXHIP_SEG_SCHEME")) ctx->tune_seg_scheme = std::atoi(e);
+    if (const char* e = std::getenv("TREXHIP_CCL_INST")) ctx->tune_ccl_inst = std::atoi(e);      // which k_ccl_lds instance goes first: same results either way
     if (const char* e = std::getenv("TREXHIP_ROWS_BLOCKS")) { ctx->tune_rows_blocks = std::atoi(e) > 0 ? std::atoi(e) : 8192; ctx->tune_rows_blocks_set = true; }
     const size_t B = p->max_batch, H = p->height, W = p->width, R = p->max_runs, NB = p->max_blobs, P = p->max_pixels;
     int rc = TREXHIP_OK;
@@ -211,6 +213,8 @@ int trexhip_create(const trexhip_params* p, trexhip_ctx** out) {
     }
     TRY(hmalloc(&ctx->h_info, B));
     TRY(hmalloc(&ctx->h_totals, 4));
+    TRY(hmalloc(&ctx->h_ccl_hint, 2));
+    if (rc == TREXHIP_OK) ctx->h_ccl_hint[0] = ctx->h_ccl_hint[1] = 0u;
     TRY(hmalloc(&ctx->h_blobs, B * NB));
     TRY(hmalloc(&ctx->h_runs, B * R));
     TRY(hmalloc(&ctx->h_pixels, B * P * ctx->pix_ch));
@@ -231,7 +235,7 @@ void trexhip_destroy(trexhip_ctx* ctx) {
                    ctx->d_pix_begin, ctx->d_blob_map, ctx->d_info, ctx->d_blobs, ctx->d_blob_frame, ctx->d_runs, ctx->d_pixels, ctx->d_color, ctx->d_bits[0], ctx->d_bits[1], ctx->d_warp, ctx->d_bg_color, ctx->d_len, ctx->d_auto};
     for (void* p : dev) if (p) hipFree(p);
     upload_free(ctx);
-    void* host[] = {ctx->h_info, ctx->h_totals, ctx->h_blobs, ctx->h_runs, ctx->h_pixels, ctx->h_staging, ctx->h_color};
+    void* host[] = {ctx->h_info, ctx->h_totals, ctx->h_blobs, ctx->h_runs, ctx->h_pixels, ctx->h_staging, ctx->h_color, ctx->h_ccl_hint};
     for (void* p : host) if (p) hipHostFree(p);
     stage_free(ctx);
     if (ctx->aux_stream) {

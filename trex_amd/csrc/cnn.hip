@@ -125,7 +125,8 @@ __global__ __launch_bounds__(1024) void k_guard_plan(uint32_t* __restrict__ over
     __shared__ uint32_t cnt;
     if (threadIdx.x == 0) cnt = 0;
     __syncthreads();
-    if (overflow[0] == 0u) { if (threadIdx.x == 0) { plan[0] = 0; plan[1] = 0; } return; }
+    const uint32_t raised = overflow[0];      // bit 0: something left the fp16 range; bit 1: a kernel that cannot name the crop saw it
+    if (raised == 0u) { if (threadIdx.x == 0) { plan[0] = 0; plan[1] = 0; } return; }
     for (int i = threadIdx.x; i < n; i += 1024)
         if (flags[i]) {
             flags[i] = 0;
@@ -133,7 +134,12 @@ __global__ __launch_bounds__(1024) void k_guard_plan(uint32_t* __restrict__ over
             if (k < (uint32_t)FB_MAX) plan[2 + k] = (uint32_t)i;
         }
     __syncthreads();
-    if (threadIdx.x == 0) { plan[0] = cnt <= (uint32_t)FB_MAX ? cnt : 0u; plan[1] = (cnt == 0u || cnt > (uint32_t)FB_MAX) ? 2u : 1u; }     // raised by a kernel that does not know the crop: all of them
+    // an unattributed flag re-runs every crop even when other crops ARE listed: a crop that left the range in k_conv1_wpre / k_conv2_wpre2 (the
+    // 3-channel chain) must not keep its fp16 result because fc1 happened to flag another crop of the batch
+    if (threadIdx.x == 0) {
+        const bool whole = (raised & 2u) || cnt == 0u || cnt > (uint32_t)FB_MAX;
+        plan[0] = whole ? 0u : cnt; plan[1] = whole ? 2u : 1u;
+    }
 }
 
 __global__ __launch_bounds__(256) void k_conv1_mfma(const uint8_t* __restrict__ crops, const uint4* __restrict__ wtab /*[16][64]*/,
@@ -459,7 +465,7 @@ __global__ __launch_bounds__(512) void k_conv5_split(const float* __restrict__ i
             __syncthreads();
         }
     }
-    if (KIND == 1 && __any(ovf) && lane == 0) atomicOr(overflow, 1u);
+    if (KIND == 1 && __any(ovf) && lane == 0) atomicOr(overflow, 3u);      // (bit 1: raised by a kernel that cannot name the crop -- k_guard_plan re-runs every crop)
     const int co = n * 32 + j;
     const float bz = bias[co];
     float* oc = out + (size_t)crop * WR * WR * CO;
@@ -677,7 +683,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_conv5_stream(const float* __rest
     }
 #undef STG_LOAD
 #undef STG_STORE
-    if (__any(ovf) && lane == 0) atomicOr(overflow, 1u);
+    if (__any(ovf) && lane == 0) atomicOr(overflow, 3u);
 }
 
 // B^T of F(4,5), points (0, 1, -1, 2, -2, 1/2, -1/2, inf): 8 consecutive inputs -> 8 positions
@@ -1065,7 +1071,7 @@ __global__ __launch_bounds__((WinoGeom<CI, CO, S, TPW>::NTHR), (TPW == 1 ? 2 : 1
 #undef WS_STEP
     // fp16 range guard: |B^T d| <= 15 max|d| (largest absolute row sum of B^T), so inputs below 65520 / 15 cannot overflow a piece.
     // Larger (or non-finite) inputs raise the flag and the host-side guard re-runs the layer stack with the bf16 kernels.
-    if (__any(!(mxabs < 4368.0f)) && lane == 0) atomicOr(overflow, 1u);
+    if (__any(!(mxabs < 4368.0f)) && lane == 0) atomicOr(overflow, 3u);
 }
 
 #include "cnn_wpre.h"

@@ -439,5 +439,5 @@ __global__ __launch_bounds__(256, 2) void k_conv12_wpre(const uint8_t* __restric
 #undef W12_ITEM
 #undef W2_POS
 #undef W2_BOFF
-    if (__any(ovf) && lane == 0) atomicOr(overflow, 1u);
+    if (__any(ovf) && lane == 0) atomicOr(overflow, 3u);      // (nothing is left here behind the last flag_crops; if it ever is, it is unattributed: every crop)
 }

@@ -630,5 +630,5 @@ __global__ __launch_bounds__(512) void k_conv12_rs(const uint8_t* __restrict__ c
 #undef RS_NEXT
 #undef RS_ROWS
 #undef RS_BAR
-    if (__any(!(ovfm < 4368.0f)) && lane == 0) atomicOr(overflow, 1u);
+    if (__any(!(ovfm < 4368.0f)) && lane == 0) atomicOr(overflow, 3u);      // (nothing is left here behind the last flag_crops; if it ever is, it is unattributed: every crop)
 }

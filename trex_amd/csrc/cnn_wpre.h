@@ -200,7 +200,7 @@ __global__ __launch_bounds__(256) void k_conv1_wpre(const uint8_t* __restrict__ 
         }
         __syncthreads();
     }
-    if (__any(ovf) && lane == 0) atomicOr(overflow, 1u);
+    if (__any(ovf) && lane == 0) atomicOr(overflow, 3u);      // bit 1: this kernel does not know the crop (k_guard_plan: every crop)
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -480,7 +480,7 @@ __global__ __launch_bounds__(256, 2) void k_conv2_wpre2(const uint8_t* __restric
 #undef W2B_DMA
 #undef W2_POS
 #undef W2_BOFF
-    if (__any(ovf) && lane == 0) atomicOr(overflow, 1u);
+    if (__any(ovf) && lane == 0) atomicOr(overflow, 3u);      // bit 1: this kernel does not know the crop (k_guard_plan: every crop)
 }
 
 // ------------------------------------------------------------------------------------------------

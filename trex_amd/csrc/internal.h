@@ -166,8 +166,12 @@ struct trexhip_ctx {
     int n_cus = 256;                    // compute units of the device (persistent kernels size their grids with it)
     int tune_seg_groups = 1;            // >1: pixel pass of frame group g+1 on the caller stream, labelling of g on an auxiliary stream (TREXHIP_SEG_GROUPS); measured SLOWER (cross-stream events cost 30-50 us each: 159 -> 266 us at 2 groups), kept off
     hipStream_t aux_stream = nullptr;   // labelling + gather of a group while the next group's pixel pass runs
-    hipEvent_t ev_grp[9] = {};
+    hipEvent_t ev_grp[10] = {};
+    int tune_seg_scheme = 0;            // TREXHIP_SEG_SCHEME: how the groups use the two streams (launch_segment)
     int tune_ccl_stop = 0;              // dev only: stop k_ccl_lds after phase N (TREXHIP_CCL_STOP)
+    int tune_ccl_inst = 0;              // dev only: the k_ccl_lds instance that goes first (TREXHIP_CCL_INST; 0 = by the hint words)
+    uint32_t* h_ccl_hint = nullptr;     // [2] pinned, written by k_ccl_lds: a frame had more lines than the S / the M instance holds
+    uint32_t ccl_calls = 0;
     trexhip::Stage stages[TREXHIP_STAGE_COUNT];
     trexhip::Uploader up;
 };

@@ -197,7 +197,7 @@ __global__ __launch_bounds__(256) void k_rows(const uint8_t* __restrict__ frames
     const int lane = lane_id();
     // the pooled totals of the pass (blobs, runs, pixels) start at zero: written here, ahead of the labelling kernel in stream order (the
     // per-frame counters are handed back zeroed by k_ccl_lds, so a pass needs no memset)
-    if (f0 == 0u && blockIdx.x == 0 && threadIdx.x < 4) frame_ctr[(size_t)c.ctr_frames * CTR_STRIDE + threadIdx.x] = 0u;
+    if (f0 == 0u && !(order & (1 << 30)) && blockIdx.x == 0 && threadIdx.x < 4) frame_ctr[(size_t)c.ctr_frames * CTR_STRIDE + threadIdx.x] = 0u;
     const int W = c.W;
     const int WB = (W + 31) / 32;
     const uint32_t ntask = (uint32_t)c.B * (uint32_t)c.H;
@@ -428,7 +428,7 @@ __global__ __launch_bounds__(256) void k_rows32(const uint8_t* __restrict__ fram
     const int lane = lane_id();
     // the pooled totals of the pass (blobs, runs, pixels) start at zero: written here, ahead of the labelling kernel in stream order (the
     // per-frame counters are handed back zeroed by k_ccl_lds, so a pass needs no memset)
-    if (f0 == 0u && blockIdx.x == 0 && threadIdx.x < 4) frame_ctr[(size_t)c.ctr_frames * CTR_STRIDE + threadIdx.x] = 0u;
+    if (f0 == 0u && !(order & (1 << 30)) && blockIdx.x == 0 && threadIdx.x < 4) frame_ctr[(size_t)c.ctr_frames * CTR_STRIDE + threadIdx.x] = 0u;
     const int W = c.W;
     const uint32_t ntask = (uint32_t)c.B * (uint32_t)c.H;
     const uint32_t nwave = gridDim.x * 4u;
@@ -482,7 +482,7 @@ __global__ __launch_bounds__(256) void k_rows32b(const uint8_t* __restrict__ fra
     const int lane = lane_id();
     // the pooled totals of the pass (blobs, runs, pixels) start at zero: written here, ahead of the labelling kernel in stream order (the
     // per-frame counters are handed back zeroed by k_ccl_lds, so a pass needs no memset)
-    if (f0 == 0u && blockIdx.x == 0 && threadIdx.x < 4) frame_ctr[(size_t)c.ctr_frames * CTR_STRIDE + threadIdx.x] = 0u;
+    if (f0 == 0u && !(order & (1 << 30)) && blockIdx.x == 0 && threadIdx.x < 4) frame_ctr[(size_t)c.ctr_frames * CTR_STRIDE + threadIdx.x] = 0u;
     const int W = c.W;
     const uint32_t groups = (uint32_t)c.B / (uint32_t)K;
     const uint32_t wid = blockIdx.x * 4u + (threadIdx.x >> 6);
@@ -827,10 +827,21 @@ __global__ __launch_bounds__(256) void k_blobs(const SegCfg c, const int only_pe
 //   s_a  row bases (P1..P3) | runs per raw blob (P5) | runs | first slot of the blob's segment << 16 (P6..) | sort keys (large blobs)
 //   s_b  flatten scratch (P4) | ordinal of a root run (P5a) | pixels per raw blob (P5b) | kept index or ~0 (P6, P7) | segment cursor or ~0
 // ---------------------------------------------------------------------------------------------
-static constexpr int CCL_NMAX = 8160;               // runs per frame (16-bit fields: < 65536; the arrays below + 256 B must fit 160 KB)
-static constexpr int CCL_SORT = 8192;               // s_a: row bases of up to 8191 rows; power of two for the bitonic sort
-static constexpr int CCL_LDS_BYTES = CCL_NMAX * (4 + 4 + 4 + 2 + 2) + CCL_SORT * 4 + 256;
+// Instantiated BY CAPACITY (round 6): a workgroup that holds 8160 lines needs all 160 KB of a CU and 16 waves whatever the frame carries, so one
+// frame occupies one CU.  The smaller instances leave room for several frames per CU (and for the pixel pass of another group beside them):
+//   L  1024 threads, 8160 lines, 160 KB  (a 4096 x 4096 frame of 256 individuals: ~7.7 k lines)
+//   M   512 threads, 3840 lines,  76 KB  (two per CU; a 2048 x 2048 frame of 100 individuals: ~2.5 k lines)
+//   S   256 threads, 2000 lines,  40 KB  (four per CU; 1280 x 720 with 32 blobs: ~0.7 k lines; TRex's one-frame calls)
+// NT threads, NMAX lines, SA words of s_a (row bases of up to SA - 1 rows; power of two >= NMAX for the bitonic sort).  A frame with more lines
+// than the instance holds is left for the L instance (info.reserved[0] = 3: launch_segment queues it behind every smaller one, it returns at
+// once for frames that are done), a frame beyond L for the global-memory chain (reserved[0] = 1) as before.
+static constexpr int CCL_NMAX = 8160;               // runs per frame of the largest instance (16-bit fields: < 65536; the arrays + 256 B must fit 160 KB)
+static constexpr int CCL_SORT = 8192;
+template <int NMAX, int SA> struct CclLds { static constexpr int BYTES = NMAX * (4 + 4 + 4 + 2 + 2) + SA * 4 + 256; };
+static constexpr int CCL_LDS_BYTES = CclLds<CCL_NMAX, CCL_SORT>::BYTES;
 static_assert(CCL_LDS_BYTES <= 160 * 1024, "k_ccl_lds: LDS");
+static constexpr int CCL_M_NMAX = 3840, CCL_M_SA = 4096, CCL_S_NMAX = 2000, CCL_S_SA = 2048;
+static_assert(2 * CclLds<CCL_M_NMAX, CCL_M_SA>::BYTES <= 160 * 1024 && 4 * CclLds<CCL_S_NMAX, CCL_S_SA>::BYTES <= 160 * 1024, "k_ccl_lds: LDS of the small instances");
 
 __device__ __forceinline__ uint32_t lds_find(volatile uint32_t* par, uint32_t a) {
     uint32_t p = par[a];
@@ -861,7 +872,8 @@ __device__ __forceinline__ void gather_blobs(const SegCfg& c, const int only_pen
                                              const uint32_t bw0, const uint32_t bw_step, const uint32_t total,
                                              const int own_frame, const uint32_t own_run_begin, const uint32_t own_pix_begin);
 
-__global__ __launch_bounds__(1024) void k_ccl_lds(const SegCfg c, uint32_t* __restrict__ frame_ctr,
+template <int NT, int NMAX, int SA>
+__global__ __launch_bounds__(NT) void k_ccl_lds(const SegCfg c, uint32_t* __restrict__ frame_ctr,
                                                   const uint32_t* __restrict__ row_cnt, const uint32_t* __restrict__ row_off,
                                                   uint32_t* __restrict__ row_base, const uint32_t* __restrict__ tmp_runs,
                                                   trexhip_run* __restrict__ raster, uint32_t* __restrict__ parent,
@@ -872,7 +884,12 @@ __global__ __launch_bounds__(1024) void k_ccl_lds(const SegCfg c, uint32_t* __re
                                                   trexhip_run* __restrict__ out_runs, const int dbg_stop,
                                                   unsigned long long* __restrict__ dbg, const int f0,
                                                   const uint8_t* __restrict__ own_frames /* gray frames: the workgroup also gathers its frame's blobs; else null */,
-                                                  uint8_t* __restrict__ own_pixels) {
+                                                  uint8_t* __restrict__ own_pixels,
+                                                  const int retry_only /* 1: only the frames a smaller instance left for this one */,
+                                                  uint32_t* __restrict__ hint /* pinned host words: [0] a frame had more lines than S holds, [1] than M holds */) {
+    static_assert(NT % 64 == 0 && NT <= 1024 && (SA & (SA - 1)) == 0 && SA >= NMAX && SA % NT == 0 && NMAX <= CCL_NMAX, "k_ccl_lds: geometry");
+    constexpr int NW = NT / 64;                   // waves
+    constexpr int NSW = NT >= 1024 ? 2 : 4;       // row sweeps whose count / offset / raster index / first run stay in registers
 #ifdef TREXHIP_DEV_KNOBS
 #define CCL_STAMP(i) do { if (dbg_stop == -1 && blockIdx.x == 0 && threadIdx.x == 0) dbg[i] = __builtin_readcyclecounter(); } while (0)
 #define CCL_STOP(n) do { if (dbg_stop == (n)) return; } while (0)
@@ -881,13 +898,13 @@ __global__ __launch_bounds__(1024) void k_ccl_lds(const SegCfg c, uint32_t* __re
 #define CCL_STOP(n) do { } while (0)
 #endif
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
-    uint32_t* s_a = smem;                         // [CCL_SORT] (see above)
-    uint32_t* s_run = s_a + CCL_SORT;             // x0 | x1 << 16, raster order
-    uint32_t* s_par = s_run + CCL_NMAX;           // union-find parent -> root run -> raw blob ordinal
-    uint32_t* s_b = s_par + CCL_NMAX;             // (see above)
-    uint32_t* s_misc = s_b + CCL_NMAX;            // [64] scan scratch / broadcasts
+    uint32_t* s_a = smem;                         // [SA] (see above)
+    uint32_t* s_run = s_a + SA;             // x0 | x1 << 16, raster order
+    uint32_t* s_par = s_run + NMAX;           // union-find parent -> root run -> raw blob ordinal
+    uint32_t* s_b = s_par + NMAX;             // (see above)
+    uint32_t* s_misc = s_b + NMAX;            // [64] scan scratch / broadcasts
     uint16_t* s_y = reinterpret_cast<uint16_t*>(s_misc + 64);
-    uint16_t* s_seg = s_y + CCL_NMAX;             // raster indices of the kept runs, one segment per blob
+    uint16_t* s_seg = s_y + NMAX;             // raster indices of the kept runs, one segment per blob
     uint32_t* s_key = s_a;                        // P1..P3: raster index of every row's first run
     const int f = blockIdx.x + f0, tid = threadIdx.x;
     const int H = c.H;
@@ -897,6 +914,7 @@ __global__ __launch_bounds__(1024) void k_ccl_lds(const SegCfg c, uint32_t* __re
     const size_t fo = (size_t)f * c.R;
 
     CCL_STAMP(0);
+    if (retry_only && info[f].reserved[0] != 3u) return;      // (block-uniform: every thread reads the same word) the frame was finished by a smaller instance
     // the frame's overflow-area counter: thread 0 reads it and hands it back zeroed for the next pass (every path: a frame left pending for the
     // global-memory chain did not overflow, and that chain's own check then reads 0)
     if (tid == 0) { s_misc[60] = frame_ctr[f * CTR_STRIDE]; frame_ctr[f * CTR_STRIDE] = 0u; }
@@ -905,45 +923,52 @@ __global__ __launch_bounds__(1024) void k_ccl_lds(const SegCfg c, uint32_t* __re
     // registers: the offset and the run are fetched while the scan's barriers pass, and P2 starts without a global round trip)
     const uint32_t* tmp = tmp_runs + (size_t)f * c.T;
     uint32_t n = 0;
-    uint32_t pk[2] = {0u, 0u}, po[2] = {0u, 0u}, pbase[2] = {0u, 0u}, pt[2] = {0u, 0u};
+    uint32_t pk[NSW], po[NSW], pbase[NSW], pt[NSW];
     {
-        // both sweeps' loads first (one round trip for the counts and offsets, one for the first runs), then the two scans
-        const int ya = tid, yb = 1024 + tid;
-        const uint32_t va = ya < H ? cnt[ya] : 0u, vb = yb < H ? cnt[yb] : 0u;
-        if (ya < H) po[0] = off[ya];
-        if (yb < H) po[1] = off[yb];
+        // every sweep's loads first (one round trip for the counts and offsets, one for the first runs), then the scans
         // (a frame whose run area overflowed carries offsets past its T words -- only the rows kernels' WRITES are bounded; such a frame is
         // refused below, but this prefetch comes before that test: never read past the area)
-        if (va && po[0] < (uint32_t)c.T) pt[0] = tmp[po[0]];
-        if (vb && po[1] < (uint32_t)c.T) pt[1] = tmp[po[1]];
-        pk[0] = va; pk[1] = vb;
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            if (j * 1024 >= H) break;
-            const int y = j * 1024 + tid;
+        for (int j = 0; j < NSW; ++j) {
+            const int y = j * NT + tid;
+            pk[j] = y < H ? cnt[y] : 0u;
+            po[j] = y < H ? off[y] : 0u;
+            pbase[j] = 0u; pt[j] = 0u;
+        }
+#pragma unroll
+        for (int j = 0; j < NSW; ++j) if (pk[j] && po[j] < (uint32_t)c.T) pt[j] = tmp[po[j]];
+#pragma unroll
+        for (int j = 0; j < NSW; ++j) {
+            if (j * NT >= H) break;
+            const int y = j * NT + tid;
             uint32_t total;
             const uint32_t ex = block_excl_scan(pk[j], s_misc, total);
-            if (y < H) { rb[y] = n + ex; if (y < CCL_SORT - 1) s_key[y] = n + ex; }
+            if (y < H) { rb[y] = n + ex; if (y < SA - 1) s_key[y] = n + ex; }
             pbase[j] = n + ex;
             n += total;
         }
     }
-    for (int y0 = 2048; y0 < H; y0 += 1024) {
+    for (int y0 = NSW * NT; y0 < H; y0 += NT) {
         const int y = y0 + tid;
         const uint32_t v = y < H ? cnt[y] : 0;
         uint32_t total;
         const uint32_t ex = block_excl_scan(v, s_misc, total);
-        if (y < H) { rb[y] = n + ex; if (y < CCL_SORT - 1) s_key[y] = n + ex; }
+        if (y < H) { rb[y] = n + ex; if (y < SA - 1) s_key[y] = n + ex; }
         n += total;
     }
-    const bool rb_lds = H < CCL_SORT;              // row_base also lives in LDS (s_key is idle until P4)
+    const bool rb_lds = H < SA;              // row_base also lives in LDS (s_key is idle until P4)
     trexhip_frame_info fi = {};
     fi.n_raw_runs = n;
     const bool overflow = n > (uint32_t)c.R || s_misc[60] > (uint32_t)c.R;       // (behind the barriers of the scans above)
-    if (overflow || n > (uint32_t)CCL_NMAX) {
+    if (!overflow && hint && tid == 0) {           // (plain stores of a constant into the context's pinned words: the host reads them before its next launch)
+        if (n > (uint32_t)CCL_S_NMAX) hint[0] = 1u;
+        if (n > (uint32_t)CCL_M_NMAX) hint[1] = 1u;
+    }
+    if (overflow || n > (uint32_t)NMAX) {
         if (tid == 0) {
             rb[H] = n;
-            if (overflow) fi.flags = TREXHIP_FRAME_OVERFLOW_RUNS; else fi.reserved[0] = 1u;   // pending: too many runs for LDS
+            if (overflow) fi.flags = TREXHIP_FRAME_OVERFLOW_RUNS;
+            else fi.reserved[0] = n > (uint32_t)CCL_NMAX ? 1u : 3u;   // pending: too many runs for LDS altogether (global-memory chain) / for this instance (L follows)
             info[f] = fi;
         }
         return;
@@ -954,14 +979,14 @@ __global__ __launch_bounds__(1024) void k_ccl_lds(const SegCfg c, uint32_t* __re
     CCL_STAMP(1);
     // P2: runs into LDS in raster order
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
+    for (int j = 0; j < NSW; ++j) {
         const uint32_t k = pk[j], b = pbase[j], o = po[j];
-        const int y = j * 1024 + tid;
+        const int y = j * NT + tid;
         if (!k) continue;
         s_run[b] = pt[j]; s_y[b] = (uint16_t)y; s_par[b] = b;
         for (uint32_t i = 1; i < k; ++i) { s_run[b + i] = tmp[o + i]; s_y[b + i] = (uint16_t)y; s_par[b + i] = b + i; }
     }
-    for (int y = 2048 + tid; y < H; y += 1024) {
+    for (int y = NSW * NT + tid; y < H; y += NT) {
         const uint32_t b = rb_lds ? s_key[y] : rb[y];
         const uint32_t k = (rb_lds ? s_key[y + 1] : rb[y + 1]) - b;
         if (!k) continue;
@@ -973,7 +998,7 @@ __global__ __launch_bounds__(1024) void k_ccl_lds(const SegCfg c, uint32_t* __re
     CCL_STAMP(2);
     // P3: link every run with the touching runs of the row above (thread per run, binary search for the first candidate)
     const int slack = c.slack;
-    for (uint32_t r = tid; r < n; r += 1024) {
+    for (uint32_t r = tid; r < n; r += NT) {
         const int y = s_y[r];
         if (y == 0) continue;
         uint32_t lo = rb_lds ? s_key[y - 1] : rb[y - 1];
@@ -993,16 +1018,16 @@ __global__ __launch_bounds__(1024) void k_ccl_lds(const SegCfg c, uint32_t* __re
     CCL_STOP(3);
     CCL_STAMP(3);
     // P4: flatten
-    for (uint32_t r = tid; r < n; r += 1024) { const uint32_t root = lds_find(s_par, r); s_b[r] = root; }
+    for (uint32_t r = tid; r < n; r += NT) { const uint32_t root = lds_find(s_par, r); s_b[r] = root; }
     __syncthreads();
-    for (uint32_t r = tid; r < n; r += 1024) s_par[r] = s_b[r];
+    for (uint32_t r = tid; r < n; r += NT) s_par[r] = s_b[r];
     __syncthreads();
     CCL_STOP(4);
     CCL_STAMP(4);
     // P5: blob ordinals (raster order of the root run) -> s_b at the roots; the run-level state of the re-threshold pass (root label, ordinal
     // of a root) goes to global memory here, then every run's label becomes its blob's ordinal and s_a / s_b count runs / pixels per blob
     uint32_t nraw = 0;
-    for (uint32_t b0 = 0; b0 < n; b0 += 1024) {
+    for (uint32_t b0 = 0; b0 < n; b0 += NT) {
         const uint32_t r = b0 + tid;
         const uint32_t flag = (r < n && s_par[r] == r) ? 1u : 0u;
         uint32_t total;
@@ -1011,7 +1036,7 @@ __global__ __launch_bounds__(1024) void k_ccl_lds(const SegCfg c, uint32_t* __re
         nraw += total;
     }
     __syncthreads();
-    for (uint32_t r = tid; r < n; r += 1024) {
+    for (uint32_t r = tid; r < n; r += NT) {
         const uint32_t lab = s_par[r];
         const uint32_t o = s_b[lab];
         parent[fo + r] = lab;
@@ -1019,9 +1044,9 @@ __global__ __launch_bounds__(1024) void k_ccl_lds(const SegCfg c, uint32_t* __re
         s_par[r] = o;                                      // (a thread reads and writes its own entry only; s_b stays as it is until the barrier)
     }
     __syncthreads();
-    for (uint32_t o = tid; o < nraw; o += 1024) { s_a[o] = 0; s_b[o] = 0; }
+    for (uint32_t o = tid; o < nraw; o += NT) { s_a[o] = 0; s_b[o] = 0; }
     __syncthreads();
-    for (uint32_t r = tid; r < n; r += 1024) {
+    for (uint32_t r = tid; r < n; r += NT) {
         const uint32_t o = s_par[r];
         const uint32_t q = s_run[r];
         atomicAdd(s_a + o, 1u);
@@ -1034,7 +1059,7 @@ __global__ __launch_bounds__(1024) void k_ccl_lds(const SegCfg c, uint32_t* __re
     uint32_t kept = 0, kruns = 0, kpx = 0;
     uint32_t* pbg = pix_begin + fo;
     int32_t* bmap = blob_map + fo;
-    for (uint32_t b0 = 0; b0 < nraw; b0 += 1024) {
+    for (uint32_t b0 = 0; b0 < nraw; b0 += NT) {
         const uint32_t o = b0 + tid;
         uint32_t nr = 0, np = 0, keep = 0;
         if (o < nraw) { nr = s_a[o]; np = s_b[o]; keep = (size_ok(np, c) && nr < 65535u) ? 1u : 0u; }
@@ -1067,7 +1092,7 @@ __global__ __launch_bounds__(1024) void k_ccl_lds(const SegCfg c, uint32_t* __re
     const uint32_t bb = s_misc[32], rbeg = s_misc[33], pb = s_misc[34];
     fi.n_raw_blobs = nraw;
     if (s_misc[35]) {
-        for (uint32_t k = tid; k < kept; k += 1024)
+        for (uint32_t k = tid; k < kept; k += NT)
             if (bb + k < c.pool_blobs) blob_frame[bb + k] = 0xffffffffu;
         if (tid == 0) { fi.flags |= TREXHIP_FRAME_OVERFLOW_OUTPUT; info[f] = fi; }
         return;
@@ -1076,7 +1101,7 @@ __global__ __launch_bounds__(1024) void k_ccl_lds(const SegCfg c, uint32_t* __re
     CCL_STAMP(6);
     // P7: blob records, raster-order runs for the re-threshold pass, largest kept blob (decides the grouping strategy, block-uniform)
     uint32_t mx = 0;
-    for (uint32_t o = tid; o < nraw; o += 1024) {
+    for (uint32_t o = tid; o < nraw; o += NT) {
         const uint32_t k = s_b[o];
         if (k == 0xffffffffu) continue;
         const uint32_t a = s_a[o];
@@ -1089,7 +1114,7 @@ __global__ __launch_bounds__(1024) void k_ccl_lds(const SegCfg c, uint32_t* __re
         blob_frame[bb + k] = (uint32_t)f;
         mx = max(mx, a & 0xffffu);
     }
-    for (uint32_t r = tid; r < n; r += 1024) {
+    for (uint32_t r = tid; r < n; r += NT) {
         trexhip_run q; q.x0 = (uint16_t)(s_run[r] & 0xffffu); q.x1 = (uint16_t)(s_run[r] >> 16); q.y = s_y[r]; q.pad = 0;
         raster[fo + r] = q;
     }
@@ -1100,14 +1125,14 @@ __global__ __launch_bounds__(1024) void k_ccl_lds(const SegCfg c, uint32_t* __re
     if ((tid & 63) == 0) s_misc[40 + (tid >> 6)] = mx;
     __syncthreads();
     mx = 0;
-    for (int w = 0; w < 16; ++w) mx = max(mx, s_misc[40 + w]);
+    for (int w = 0; w < NW; ++w) mx = max(mx, s_misc[40 + w]);
     trexhip_run* outr = out_runs + rbeg;
     if (mx <= 512u) {
         // (1) scatter raster indices into each blob's segment in arbitrary order (LDS atomics on a per-blob cursor: s_b becomes 0 for a
         //     kept blob, stays ~0 for a dropped one), (2) every segment is sorted by raster index and written straight out
-        for (uint32_t o = tid; o < nraw; o += 1024) if (s_b[o] != 0xffffffffu) s_b[o] = 0u;
+        for (uint32_t o = tid; o < nraw; o += NT) if (s_b[o] != 0xffffffffu) s_b[o] = 0u;
         __syncthreads();
-        for (uint32_t r = tid; r < n; r += 1024) {
+        for (uint32_t r = tid; r < n; r += NT) {
             const uint32_t o = s_par[r];
             if (s_b[o] == 0xffffffffu) continue;
             const uint32_t slot = atomicAdd(s_b + o, 1u);
@@ -1129,7 +1154,7 @@ __global__ __launch_bounds__(1024) void k_ccl_lds(const SegCfg c, uint32_t* __re
                 outr[beg + e] = q;
             }
         };
-        for (uint32_t k0 = wave * 2; k0 < nraw; k0 += 32) {
+        for (uint32_t k0 = wave * 2; k0 < nraw; k0 += 2 * NW) {
             const uint32_t aA = s_b[k0] != 0xffffffffu ? s_a[k0] : 0u;
             const uint32_t aB = (k0 + 1 < nraw && s_b[k0 + 1] != 0xffffffffu) ? s_a[k0 + 1] : 0u;
             const uint32_t cA = aA & 0xffffu, cB = aB & 0xffffu;
@@ -1174,21 +1199,21 @@ __global__ __launch_bounds__(1024) void k_ccl_lds(const SegCfg c, uint32_t* __re
         // a blob of more than 512 lines: one bitonic sort of (kept blob index << 13 | raster index) over the whole frame, keys in s_a
         uint32_t sn = 64;
         while (sn < n) sn <<= 1;
-        uint32_t keys[CCL_SORT / 1024];
+        uint32_t keys[SA / NT];
 #pragma unroll
-        for (int u = 0; u < CCL_SORT / 1024; ++u) {
-            const uint32_t r = tid + u * 1024;
+        for (int u = 0; u < SA / NT; ++u) {
+            const uint32_t r = tid + u * NT;
             uint32_t key = 0xffffffffu;
             if (r < n) { const uint32_t k = s_b[s_par[r]]; if (k != 0xffffffffu) key = (k << 13) | r; }
             keys[u] = key;
         }
         __syncthreads();                                   // s_a's blob fields are not read any more
 #pragma unroll
-        for (int u = 0; u < CCL_SORT / 1024; ++u) { const uint32_t r = tid + u * 1024; if (r < sn) s_a[r] = keys[u]; }
+        for (int u = 0; u < SA / NT; ++u) { const uint32_t r = tid + u * NT; if (r < sn) s_a[r] = keys[u]; }
         __syncthreads();
         for (uint32_t k = 2; k <= sn; k <<= 1)
             for (uint32_t j = k >> 1; j > 0; j >>= 1) {
-                for (uint32_t i = tid; i < sn; i += 1024) {
+                for (uint32_t i = tid; i < sn; i += NT) {
                     const uint32_t x = i ^ j;
                     if (x > i) {
                         const uint32_t a = s_a[i], b2 = s_a[x];
@@ -1198,7 +1223,7 @@ __global__ __launch_bounds__(1024) void k_ccl_lds(const SegCfg c, uint32_t* __re
                 }
                 __syncthreads();
             }
-        for (uint32_t i = tid; i < kruns; i += 1024) {
+        for (uint32_t i = tid; i < kruns; i += NT) {
             const uint32_t r = s_a[i] & 8191u;
             trexhip_run q; q.x0 = (uint16_t)(s_run[r] & 0xffffu); q.x1 = (uint16_t)(s_run[r] >> 16); q.y = s_y[r]; q.pad = 0;
             outr[i] = q;
@@ -1219,7 +1244,7 @@ __global__ __launch_bounds__(1024) void k_ccl_lds(const SegCfg c, uint32_t* __re
         __threadfence_block();
         __syncthreads();
         gather_blobs<false, 32>(c, 0, own_frames, info, blob_frame, blobs, out_runs, own_pixels, 0u, 0xffffffffu, nullptr, 0, 0,
-                                bb + (uint32_t)(tid >> 6) * 2u, 32u, bb + kept, f, rbeg, pb);
+                                bb + (uint32_t)(tid >> 6) * 2u, 2u * NW, bb + kept, f, rbeg, pb);
     }
 #undef CCL_STAMP
 #undef CCL_STOP
@@ -1520,7 +1545,8 @@ int launch_segment(trexhip_ctx* ctx, const uint8_t* d_frames, int n) {
     SegCfg c = ctx->cfg;
     c.B = n;
     ctx->batch_invert = c.invert; ctx->batch_zero_bg = c.zero_bg;      // the batch's own copy: downstream calls on this batch use it
-    hipStream_t s = ctx->stream;
+    hipStream_t s_main = ctx->stream;
+    hipStream_t s = s_main;
     const int H = c.H, W = c.W;
     const int nch = (W + 1023) / 1024;
     if (nch > 8) { set_error("frame width > 8192 is not supported yet"); return TREXHIP_E_UNSUPPORTED; }
@@ -1538,23 +1564,59 @@ int launch_segment(trexhip_ctx* ctx, const uint8_t* d_frames, int n) {
         int rcm = launch_morphology(ctx, d_frames, n, &bits);
         if (rcm) return rcm;
     }
+    using LdsM = CclLds<CCL_M_NMAX, CCL_M_SA>;
+    using LdsS = CclLds<CCL_S_NMAX, CCL_S_SA>;
     if (!ctx->attr_ccl) {
-        TH_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ccl_lds), hipFuncAttributeMaxDynamicSharedMemorySize, CCL_LDS_BYTES));
+        TH_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ccl_lds<1024, CCL_NMAX, CCL_SORT>), hipFuncAttributeMaxDynamicSharedMemorySize, CCL_LDS_BYTES));
+        TH_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ccl_lds<512, CCL_M_NMAX, CCL_M_SA>), hipFuncAttributeMaxDynamicSharedMemorySize, LdsM::BYTES));
+        TH_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ccl_lds<1024, CCL_M_NMAX, CCL_M_SA>), hipFuncAttributeMaxDynamicSharedMemorySize, LdsM::BYTES));
+        TH_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ccl_lds<256, CCL_S_NMAX, CCL_S_SA>), hipFuncAttributeMaxDynamicSharedMemorySize, LdsS::BYTES));
+        TH_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ccl_lds<512, CCL_S_NMAX, CCL_S_SA>), hipFuncAttributeMaxDynamicSharedMemorySize, LdsS::BYTES));
         ctx->attr_ccl = true;
     }
+    // Which instance of k_ccl_lds goes first (see the table above the kernel).  Measured in round 6 (profiles/r06_ccl_by_capacity.txt): with one frame
+    // per CU or fewer the 1024-thread instance is the fastest whatever the frame holds (C2, 256 frames: L 86 us per pass, S 109; C4: L 270, M 302) --
+    // the phases are bound by the threads that walk the lines, not by the barriers; only when a launch brings SEVERAL frames per CU do the small
+    // instances pay (C2, 1024 frames: L 327, S 317).  So: L unless the launch holds at least two frames per CU; then the smallest instance that
+    // held the frames of the earlier calls, told by two pinned words the kernels write (a frame had more lines than S / than M holds).  A wrong
+    // guess costs time, never results: frames the first instance cannot hold are finished by the L instance queued right behind it.  Every 64th
+    // call the words are cleared, so a context whose frames got emptier finds its way back down.
+    // TREXHIP_CCL_INST (dev): 1 S, 2 M, 3 L, 4 M with 1024 threads, 5 S with 512.
+    int inst = ctx->tune_ccl_inst;
+    if (inst <= 0) {
+        inst = 3;
+        if (n >= 2 * ctx->n_cus) {
+            if ((++ctx->ccl_calls & 63) == 0) { ctx->h_ccl_hint[0] = 0u; ctx->h_ccl_hint[1] = 0u; }
+            const uint32_t over_s = __atomic_load_n(&ctx->h_ccl_hint[0], __ATOMIC_RELAXED), over_m = __atomic_load_n(&ctx->h_ccl_hint[1], __ATOMIC_RELAXED);
+            inst = over_m ? 3 : (over_s ? 2 : 1);
+            if (c.R <= CCL_S_NMAX) inst = 1; else if (c.R <= CCL_M_NMAX && inst > 2) inst = 2;     // max_runs itself bounds the lines of a frame
+        }
+    }
     uint32_t* totals = ctx->d_ctr + (size_t)ctx->p.max_batch * CTR_STRIDE;
-    // The batch is cut into groups of frames: the pixel pass of group g+1 (HBM-bound, every CU) runs on the caller's stream
-    // while the labelling + gather of group g (latency-bound, one workgroup per frame) run on an auxiliary stream.
+    // The batch can be cut into groups of frames so that the labelling of one group (latency chains, one workgroup per frame) runs beside the
+    // pixel pass of another (HBM-bound, every CU).  TREXHIP_SEG_GROUPS = G, TREXHIP_SEG_SCHEME:
+    //   0  pixel passes on the caller's stream, labelling of group g on an auxiliary stream behind an event (rounds 4-5: slower, the L instance needs a whole CU)
+    //   1  group g as a whole (pixel pass, labelling) on stream g % 2; the pixel pass of g waits for the pixel pass of g - 1 (one event per group)
+    //   2  the same without events between the groups: the two streams start together, the auxiliary one at the lowest priority
     int G = ctx->tune_seg_groups;
+    const int scheme = ctx->tune_seg_scheme;
     if (G > 8) G = 8;
     if (G < 1 || n < 2 * G) G = 1;
     if (G > 1 && !ctx->aux_stream) {
-        // (highest priority: a labelling workgroup needs 16 free wave slots and the whole LDS of a CU at once -- behind the next group's pixel
-        // pass at equal priority it only got a CU when that pass had drained: 398 us for two groups in round 4)
         int plo = 0, phi = 0;
         (void)hipDeviceGetStreamPriorityRange(&plo, &phi);
-        TH_CHECK_HIP(hipStreamCreateWithPriority(&ctx->aux_stream, hipStreamNonBlocking, phi));
-        for (int g = 0; g < 9; ++g) TH_CHECK_HIP(hipEventCreateWithFlags(&ctx->ev_grp[g], hipEventDisableTiming));
+        TH_CHECK_HIP(hipStreamCreateWithPriority(&ctx->aux_stream, hipStreamNonBlocking, scheme == 0 ? phi : (scheme == 2 ? plo : 0)));
+        // (the events order kernels of this device only: no system-scope fence, i.e. no write-back / invalidate of the caches, when one is recorded)
+        static const unsigned ev_flags = std::getenv("TREXHIP_EVENT_FLAGS") ? (unsigned)std::strtoul(std::getenv("TREXHIP_EVENT_FLAGS"), nullptr, 0) : (hipEventDisableTiming | hipEventDisableSystemFence);
+        for (int g = 0; g < 10; ++g) TH_CHECK_HIP(hipEventCreateWithFlags(&ctx->ev_grp[g], ev_flags));
+    }
+    int order_bits = ctx->tune_rows_order;
+    if (G > 1 && scheme >= 1) {
+        // the pooled totals start at zero BEFORE either stream starts (the pixel pass of frame 0 does it otherwise, in stream order ahead of its labelling)
+        TH_CHECK_HIP(hipMemsetAsync(totals, 0, 16, s));
+        order_bits |= 1 << 30;
+        TH_CHECK_HIP(hipEventRecord(ctx->ev_grp[9], s));
+        TH_CHECK_HIP(hipStreamWaitEvent(ctx->aux_stream, ctx->ev_grp[9], 0));
     }
     const int gs = (n + G - 1) / G;
     // gray pixel arrays: k_ccl_lds gathers the blobs of the frame it has just labelled (TREXHIP_FUSE_GATHER=0: the separate k_gather launch);
@@ -1567,6 +1629,11 @@ int launch_segment(trexhip_ctx* ctx, const uint8_t* d_frames, int n) {
         if (f0 >= f1) break;
         SegCfg cg = c;
         cg.B = f1 - f0;
+        hipStream_t s = s_main;
+        if (G > 1 && scheme >= 1) {
+            s = (g & 1) ? ctx->aux_stream : s_main;
+            if (scheme == 1 && g > 0) TH_CHECK_HIP(hipStreamWaitEvent(s, ctx->ev_grp[g - 1], 0));      // behind the previous group's pixel pass
+        }
         const unsigned wantg = (unsigned)(((size_t)H * cg.B + 3) / 4);
         const int nch32 = (W + 2047) / 2048;
         const bool wide = aligned && !bits && W % 32 == 0 && nch32 <= 4 && W >= 1024 && !(ctx->tune_rows_order & 1024);   // TREXHIP_ROWS_ORDER bit 10: 16 pixels per lane
@@ -1584,8 +1651,8 @@ int launch_segment(trexhip_ctx* ctx, const uint8_t* d_frames, int n) {
             if (!(ctx->tune_rows_order & 4)) { const int want = ctx->tune_rows_k > 0 ? ctx->tune_rows_k : 8; for (int k = want; k >= 2; --k) if (cg.B % k == 0) { K = k; break; } }
             const dim3 grid_b(K ? (unsigned)(((size_t)H * (cg.B / K) + 3) / 4) : 1u);
             // (k_rows32b is instantiated for one 2048-pixel chunk only: hipcc 7.2 crashes in Machine Copy Propagation on the 2-chunk form)
-#define TH_ROWS32(NCH_, MODE_) do { if (K && NCH_ == 1) hipLaunchKernelGGL((k_rows32b<1, MODE_>), grid_b, dim3(256), 0, s, d_frames, ctx->d_bg, cg, ctx->tune_rows_order, K, ctx->d_ctr, ctx->d_row_cnt, ctx->d_row_off, ctx->d_tmp_runs, (uint32_t)f0); \
-                                    else hipLaunchKernelGGL((k_rows32<NCH_, MODE_>), grid_g, dim3(256), 0, s, d_frames, ctx->d_bg, cg, ctx->tune_rows_order, ctx->d_ctr, ctx->d_row_cnt, ctx->d_row_off, ctx->d_tmp_runs, (uint32_t)f0); } while (0)
+#define TH_ROWS32(NCH_, MODE_) do { if (K && NCH_ == 1) hipLaunchKernelGGL((k_rows32b<1, MODE_>), grid_b, dim3(256), 0, s, d_frames, ctx->d_bg, cg, order_bits, K, ctx->d_ctr, ctx->d_row_cnt, ctx->d_row_off, ctx->d_tmp_runs, (uint32_t)f0); \
+                                    else hipLaunchKernelGGL((k_rows32<NCH_, MODE_>), grid_g, dim3(256), 0, s, d_frames, ctx->d_bg, cg, order_bits, ctx->d_ctr, ctx->d_row_cnt, ctx->d_row_off, ctx->d_tmp_runs, (uint32_t)f0); } while (0)
 #define TH_ROWS32_M(NCH_) do { switch (mode) { case 1: TH_ROWS32(NCH_, 1); break; case 2: TH_ROWS32(NCH_, 2); break; case 5: TH_ROWS32(NCH_, 5); break; \
                                                case 6: TH_ROWS32(NCH_, 6); break; default: TH_ROWS32(NCH_, 0); } } while (0)
             switch (nch32) {
@@ -1597,21 +1664,30 @@ int launch_segment(trexhip_ctx* ctx, const uint8_t* d_frames, int n) {
 #undef TH_ROWS32_M
 #undef TH_ROWS32
         } else
-        if (aligned) launch_rows<true>(nch, grid_g, s, d_frames, ctx->d_bg, cg, ctx->tune_rows_order, ctx->d_ctr, ctx->d_row_cnt, ctx->d_row_off, ctx->d_tmp_runs, bits, (uint32_t)f0);
-        else         launch_rows<false>(nch, grid_g, s, d_frames, ctx->d_bg, cg, ctx->tune_rows_order, ctx->d_ctr, ctx->d_row_cnt, ctx->d_row_off, ctx->d_tmp_runs, bits, (uint32_t)f0);
+        if (aligned) launch_rows<true>(nch, grid_g, s, d_frames, ctx->d_bg, cg, order_bits, ctx->d_ctr, ctx->d_row_cnt, ctx->d_row_off, ctx->d_tmp_runs, bits, (uint32_t)f0);
+        else         launch_rows<false>(nch, grid_g, s, d_frames, ctx->d_bg, cg, order_bits, ctx->d_ctr, ctx->d_row_cnt, ctx->d_row_off, ctx->d_tmp_runs, bits, (uint32_t)f0);
         if (g == G - 1) stage_end(ctx, TREXHIP_STAGE_ROWS);
         hipStream_t t = s;
-        if (G > 1) {
+        if (G > 1 && scheme == 0) {
             TH_CHECK_HIP(hipEventRecord(ctx->ev_grp[g], s));
             TH_CHECK_HIP(hipStreamWaitEvent(ctx->aux_stream, ctx->ev_grp[g], 0));
             t = ctx->aux_stream;
-        }
+        } else if (G > 1 && scheme == 1 && g + 1 < G) TH_CHECK_HIP(hipEventRecord(ctx->ev_grp[g], s));
         // run-level CCL of every frame inside one workgroup's LDS; frames with too many runs are left pending
         // and finished by the global-memory chain in finish_segment()
-        hipLaunchKernelGGL(k_ccl_lds, dim3(f1 - f0), dim3(1024), CCL_LDS_BYTES, t, c, ctx->d_ctr, ctx->d_row_cnt, ctx->d_row_off, ctx->d_row_base,
-                           ctx->d_tmp_runs, ctx->d_raster, ctx->d_parent, ctx->d_root_ord, ctx->d_cur_run, ctx->d_pix_begin, ctx->d_blob_map,
-                           totals, ctx->d_info, ctx->d_blobs, ctx->d_blob_frame, ctx->d_runs, ctx->tune_ccl_stop, reinterpret_cast<unsigned long long*>(ctx->d_cnt_px), f0,
-                           fuse_gather ? d_frames : (const uint8_t*)nullptr, ctx->d_pixels);
+#define TH_CCL(NT_, NMAX_, SA_, RETRY_) hipLaunchKernelGGL((k_ccl_lds<NT_, NMAX_, SA_>), dim3(f1 - f0), dim3(NT_), (CclLds<NMAX_, SA_>::BYTES), t, c, ctx->d_ctr, ctx->d_row_cnt, ctx->d_row_off, ctx->d_row_base, \
+                           ctx->d_tmp_runs, ctx->d_raster, ctx->d_parent, ctx->d_root_ord, ctx->d_cur_run, ctx->d_pix_begin, ctx->d_blob_map,                           \
+                           totals, ctx->d_info, ctx->d_blobs, ctx->d_blob_frame, ctx->d_runs, ctx->tune_ccl_stop, reinterpret_cast<unsigned long long*>(ctx->d_cnt_px), f0, \
+                           fuse_gather ? d_frames : (const uint8_t*)nullptr, ctx->d_pixels, RETRY_, ctx->h_ccl_hint)
+        switch (inst) {
+            case 1: TH_CCL(256, CCL_S_NMAX, CCL_S_SA, 0); break;
+            case 2: TH_CCL(512, CCL_M_NMAX, CCL_M_SA, 0); break;
+            case 4: TH_CCL(1024, CCL_M_NMAX, CCL_M_SA, 0); break;
+            case 5: TH_CCL(512, CCL_S_NMAX, CCL_S_SA, 0); break;
+            default: TH_CCL(1024, CCL_NMAX, CCL_SORT, 0); break;
+        }
+        if (inst != 3) TH_CCL(1024, CCL_NMAX, CCL_SORT, 1);      // returns at once for every frame the first instance finished
+#undef TH_CCL
         static const int gather_blocks_env = std::getenv("TREXHIP_GATHER_BLOCKS") ? std::atoi(std::getenv("TREXHIP_GATHER_BLOCKS")) : 0;
         if (!fuse_gather)
         LAUNCH_GATHER(dim3(G > 1 ? 256 : (gather_blocks_env > 0 ? gather_blocks_env : 2048)), t, c, 0, d_frames, totals, ctx->d_info, ctx->d_blob_frame,
@@ -1619,7 +1695,7 @@ int launch_segment(trexhip_ctx* ctx, const uint8_t* d_frames, int n) {
     }
     if (G > 1) {
         TH_CHECK_HIP(hipEventRecord(ctx->ev_grp[8], ctx->aux_stream));
-        TH_CHECK_HIP(hipStreamWaitEvent(s, ctx->ev_grp[8], 0));
+        TH_CHECK_HIP(hipStreamWaitEvent(s_main, ctx->ev_grp[8], 0));
     }
     stage_end(ctx, TREXHIP_STAGE_SEGMENT_ALL);
     TH_CHECK_HIP(hipGetLastError());
