@@ -173,7 +173,7 @@ static void eft_ieft(const v2* p, int N, int order, v2 center, v2* out) {
     for (int i = 0; i <= N; ++i) det_sincosf(2.0f * PI * (float)1 * t[i] / T, &cs[2 * i + 1], &cs[2 * i]);
     float sa[4][64], sb[4][64], sc[4][64], sd[4][64];
     memset(sa, 0, sizeof(sa)); memset(sb, 0, sizeof(sb)); memset(sc, 0, sizeof(sc)); memset(sd, 0, sizeof(sd));
-    if (order > 3) order = 3;
+    /* (order <= 3 here: oracle_posture refuses more, like trexhip_posture_device -- the angle-addition form above is written out for three harmonics) */
     for (int i = 0; i < N; ++i) {
         const v2 q = p[(i + 1) % N];
         const float dx = q.x - p[i].x, dy = q.y - p[i].y;
@@ -216,6 +216,49 @@ static void eft_ieft(const v2* p, int N, int order, v2 center, v2* out) {
         out[k].x = x; out[k].y = y;
     }
     free(cs);
+    free(t);
+}
+
+/* The NAIVE reading of the same formulas (round 6): what somebody who had never seen the device would write down from the
+ * definition of the elliptic Fourier transform -- libm's sinf / cosf of every harmonic's own phase, arc length and coefficient sums
+ * accumulated sequentially in float, any order up to 15 (`outline_approximate` is a uint8_t without an upper bound, core/default_config.cpp:888).
+ * It shares NOTHING with the mirror above but the formulas.  tests/test_posture_oracle.py and tests/test_posture_gpu.py bound the distance
+ * between the two (and so between the device and this one): a future change of the shared operation order cannot drift unseen. */
+static void eft_ieft_naive(const v2* p, int N, int order, v2 center, v2* out) {
+    float* t = (float*)malloc((size_t)(N + 1) * sizeof(float));
+    t[0] = 0;
+    for (int i = 0; i < N; ++i) {
+        const v2 q = p[(i + 1) % N];
+        const float dx = q.x - p[i].x, dy = q.y - p[i].y;
+        t[i + 1] = t[i] + sqrtf(dx * dx + dy * dy);
+    }
+    const float T = t[N];
+    const float PI = 3.14159265358979323846f;
+    if (order > 15) order = 15;
+    float a[16], b[16], c[16], d[16];
+    for (int n = 1; n <= order; ++n) {
+        float sa = 0, sb = 0, sc = 0, sd = 0;
+        for (int i = 0; i < N; ++i) {
+            const v2 q = p[(i + 1) % N];
+            const float dx = q.x - p[i].x, dy = q.y - p[i].y;
+            const float dt = t[i + 1] - t[i];
+            if (dt <= 0) continue;
+            const float p0 = 2.0f * PI * (float)n * t[i] / T, p1 = 2.0f * PI * (float)n * t[i + 1] / T;
+            const float dc = cosf(p1) - cosf(p0), ds = sinf(p1) - sinf(p0);
+            sa += dx / dt * dc; sb += dx / dt * ds; sc += dy / dt * dc; sd += dy / dt * ds;
+        }
+        const float k = T / (2.0f * (float)(n * n) * PI * PI);
+        a[n] = k * sa; b[n] = k * sb; c[n] = k * sc; d[n] = k * sd;
+    }
+    for (int k = 0; k < N; ++k) {
+        const float tt = (float)k / (float)N;
+        float x = center.x, y = center.y;
+        for (int n = 1; n <= order; ++n) {
+            const float ph = 2.0f * PI * (float)n * tt;
+            x += a[n] * cosf(ph) + b[n] * sinf(ph); y += c[n] * cosf(ph) + d[n] * sinf(ph);
+        }
+        out[k].x = x; out[k].y = y;
+    }
     free(t);
 }
 
@@ -278,10 +321,11 @@ typedef struct oracle_posture_params {
  * local-maximum test itself (c[i] > c[i-1] && c[i] >= c[i+1]) is a coin flip on a flat top */
 typedef struct oracle_posture_info { int32_t status, n_outline, n_segments, tail_index, head_index, n_traced; float peak_best, peak_runner_up, peak_margin; } oracle_posture_info;
 
-/* status: 0 ok, 1 empty blob/outline, 2 capacity, 3 no curvature peak, 4 too few midline segments */
-int oracle_posture(const oracle_run* runs, int32_t n_runs, int32_t origin_x, int32_t origin_y, const oracle_posture_params* P,
-                   float* outline_xy, float* segments /* pos.x pos.y height l_length */, oracle_posture_info* info) {
+/* status: 0 ok, 1 empty blob/outline, 2 capacity, 3 no curvature peak, 4 too few midline segments, 5 refused (outline_approximate > 3 in the mirrored form) */
+static int posture_impl(const oracle_run* runs, int32_t n_runs, int32_t origin_x, int32_t origin_y, const oracle_posture_params* P,
+                        float* outline_xy, float* segments /* pos.x pos.y height l_length */, oracle_posture_info* info, const int naive) {
     memset(info, 0, sizeof(*info));
+    if (!naive && P->outline_approximate > 3) { info->status = 5; return 5; }      /* refuse like the device (posture.hip), never cap silently */
     if (n_runs <= 0) { info->status = 1; return 1; }
     const int cap = P->max_points;
     v2* A = (v2*)malloc((size_t)cap * sizeof(v2)); v2* B = (v2*)malloc((size_t)cap * sizeof(v2));
@@ -304,7 +348,8 @@ int oracle_posture(const oracle_run* runs, int32_t n_runs, int32_t origin_x, int
             v2 center = {0, 0};
             for (int i = 0; i < n; ++i) { center.x += pts[i].x; center.y += pts[i].y; }
             center.x /= (float)n; center.y /= (float)n;
-            eft_ieft(pts, n, P->outline_approximate, center, other);
+            if (naive) eft_ieft_naive(pts, n, P->outline_approximate, center, other);
+            else eft_ieft(pts, n, P->outline_approximate, center, other);
             v2* t = pts; pts = other; other = t;
         }
         int r = (int)(P->outline_curvature_range_ratio * (float)n); if (r < 1) r = 1;
@@ -351,6 +396,16 @@ done:
     info->status = rc;
     free(A); free(B); free(curv);
     return rc;
+}
+
+int oracle_posture(const oracle_run* runs, int32_t n_runs, int32_t origin_x, int32_t origin_y, const oracle_posture_params* P,
+                   float* outline_xy, float* segments, oracle_posture_info* info) {
+    return posture_impl(runs, n_runs, origin_x, origin_y, P, outline_xy, segments, info, 0);
+}
+/* the same pipeline with the naive EFT (libm, sequential sums, any order): the independent yardstick */
+int oracle_posture_naive(const oracle_run* runs, int32_t n_runs, int32_t origin_x, int32_t origin_y, const oracle_posture_params* P,
+                         float* outline_xy, float* segments, oracle_posture_info* info) {
+    return posture_impl(runs, n_runs, origin_x, origin_y, P, outline_xy, segments, info, 1);
 }
 
 /* outline tracing alone (tests) */

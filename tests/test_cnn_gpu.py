@@ -310,3 +310,78 @@ def test_range_guard_is_per_crop(geom, monkeypatch):
     assert a[far].tobytes() == b[far].tobytes()                           # untouched by the re-run
     assert np.abs(a[~far] - b[~far])[[0, 2]].max() <= 1e-5                # the neighbours: re-run or not, the same answer
     seg.close()
+
+
+def _stage_maxima(st, crops):
+    """largest activation behind each conv + BN + ReLU + pool stage per crop (float64 on the host): what the range guards of the default chain look at"""
+    import torch.nn.functional as F
+    t = {k: torch.from_numpy(np.ascontiguousarray(v, np.float64)) for k, v in st.items()}
+    out = []
+    with torch.no_grad():
+        x = torch.from_numpy(np.ascontiguousarray(crops)).to(torch.float64).permute(0, 3, 1, 2)
+        for i in (1, 2, 3):
+            x = F.conv2d(x, t[f"conv{i}.weight"], t[f"conv{i}.bias"], padding=2)
+            x = F.batch_norm(x, t[f"bn{i}.running_mean"], t[f"bn{i}.running_var"], t[f"bn{i}.weight"], t[f"bn{i}.bias"], training=False, eps=1e-5)
+            x = F.max_pool2d(F.relu(x), 2)
+            out.append(x.reshape(x.shape[0], -1).max(1).values.numpy())
+    return out
+
+
+def test_unattributed_range_flag_reruns_every_crop(monkeypatch):
+    """in the two-kernel chain (TREXHIP_CONV_GEOM bit 28; also the 3-channel network's chain) conv1 / conv2 raise the fp16 range flag
+    WITHOUT naming the crop, while fc1 names it.  Crop A leaves the range in conv1, crop B only in front of fc1: a plan that listed just B would
+    leave A with its out-of-range fp16 result.  The plan must order every crop, and every row must be the exact path's."""
+    monkeypatch.setenv("TREXHIP_CONV_GEOM", str(1 << 28))
+    st = {k: v.copy() for k, v in weights.synthetic_state(8, 31).items()}
+    n, A, B = 40, 11, 29
+    rng = np.random.default_rng(9)
+    crops = np.zeros((n, 80, 80, 1), np.uint8)
+    crops[:, 20:60, 20:60, 0] = rng.integers(0, 4, (n, 40, 40))           # quiet crops
+    crops[B, 10:70, 10:70, 0] = rng.integers(0, 12, (60, 60))              # B: brighter, still inside conv1's and conv2's range
+    quiet = np.ones(n, bool); quiet[[A, B]] = False
+    crops[A, :, :, 0] = rng.integers(0, 256, (80, 80))                     # A: far outside conv1's range
+    m1 = _stage_maxima(st, crops)[0]
+    m = 3500.0 / m1[B]                                                      # conv1: B peaks at 3500 (< 4368), A far above
+    st["conv1.weight"] *= m; st["conv1.bias"] *= m; st["bn1.running_mean"] *= m
+    st["bn2.running_var"] = st["bn2.running_var"] * m * m
+    s1, s2, s3 = _stage_maxima(st, crops)
+    assert s1[A] > 3 * 4368 and s1[B] < 4368 and s1[quiet].max() < 4368, (s1[A], s1[B], s1[quiet].max())
+    assert s2[B] < 4368 and s2[quiet].max() < 4368, (s2[B], s2[quiet].max())
+    # act3 (fc1's input) scaled so that B alone passes what two fp16 pieces hold; fc1 takes the scale back out
+    assert s3[B] > 1.25 * s3[quiet].max(), (s3[B], s3[quiet].max())
+    M = 80000.0 / s3[B]
+    assert s3[quiet].max() * M < 65000
+    st["bn3.weight"] *= M; st["bn3.bias"] *= M; st["fc1.weight"] = st["fc1.weight"] / M
+    ref, _ = cnn_oracle.predict(st, crops, threads=4)
+    seg = make_net(st, 8)
+    seg.set_identity_precision(capi.CNN_FP16X3)
+    p = seg.probabilities(crops)
+    rerun, whole = seg.guard_stats()
+    assert whole, (rerun, whole)                                            # not the list {B}
+    assert np.all(np.isfinite(p)) and np.abs(p - ref).max() <= 1e-4, np.abs(p - ref).max(1)
+    # ... and B alone among quiet crops IS a list (fc1 names its crop)
+    only_b = crops.copy(); only_b[A] = only_b[0]
+    p2 = seg.probabilities(only_b)
+    rerun, whole = seg.guard_stats()
+    assert not whole and rerun == 1, (rerun, whole)
+    ref2, _ = cnn_oracle.predict(st, only_b, threads=4)
+    assert np.abs(p2 - ref2).max() <= 1e-4
+    seg.close()
+
+
+def test_small_batch_kernels_give_the_rows_of_the_large_batch_kernels():
+    """up to 1024 crops fc1 takes 32 crops per workgroup and the head one crop per wave (k_fc1_split<1>, k_head_small: TRex's default call is 100
+    crops); the same crops inside a larger batch go through k_fc1_split<4> and k_head.  Same sums in the same order: the same bits."""
+    z, st = load_fixture(100)
+    seg = make_net(st, 100)
+    seg.set_identity_precision(capi.CNN_FP16X3)
+    crops = weights.synthetic_crops(1100, 77)
+    big = seg.probabilities(crops)
+    for n in (1, 100, 1000, 1024):
+        small = seg.probabilities(crops[:n])
+        assert small.tobytes() == big[:n].tobytes(), n
+    z256, st256 = load_fixture(256)
+    seg2 = make_net(st256, 256)                                            # four 64-class slices
+    big = seg2.probabilities(crops)
+    assert seg2.probabilities(crops[:100]).tobytes() == big[:100].tobytes()
+    seg.close(); seg2.close()

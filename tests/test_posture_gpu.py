@@ -401,3 +401,46 @@ def test_retry_loop_with_sub_blobs_of_more_lines_than_twice_the_parents():
         if oi["n_outline"]:
             assert np.array_equal(go[k, :oi["n_outline"]], oo[:oi["n_outline"]]), k
     seg.close()
+
+
+def test_device_stays_next_to_the_naive_reading_of_the_eft():
+    """The independent yardstick of a7: compare() above asserts equality with a restatement whose EFT is written in the DEVICE's
+    operation order; this one compares the device with the naive reading of the same formulas (oracle.posture(naive=True): libm sinf / cosf per
+    harmonic, sequential float sums -- nothing shared with posture.hip but the formulas) on 1600 synthetic individuals: the closed curves within
+    2e-3 px, tail and head identical on >= 96 % of the blobs (a curvature near-tie may pick another tip; the curve itself must not move)."""
+    fr, bg = synth.batch("C3", 16)
+    res, outline, segs, info = run_posture(fr, bg)
+    pp = oracle.posture_params(max_points=512)
+    n = same = 0
+    worst = 0.0
+    for r in res:
+        for k, b in enumerate(r.blobs):
+            bi = int(r.info["blob_begin"]) + k
+            rs = r.runs[b["run_begin"]:b["run_begin"] + b["n_runs"]]
+            oi, oo, osg = oracle.posture(rs, (int(b["x0"]), int(b["y0"])), pp, naive=True)
+            gi = info[bi]
+            assert gi["status"] == oi["status"] and gi["n_outline"] == oi["n_outline"], (bi, gi, oi)
+            if oi["status"] != 0:
+                continue
+            n += 1
+            go = outline[bi, :gi["n_outline"]]
+            rot = int(np.argmin(np.abs(oo - go[0]).sum(1)))          # the tail is point 0: another tail is a rotation of the same curve
+            worst = max(worst, float(np.abs(np.roll(oo, -rot, 0) - go).max()))
+            if rot == 0 and gi["head_index"] == oi["head_index"]:
+                same += 1
+                assert gi["n_segments"] == oi["n_segments"]
+                assert np.abs(segs[bi, :gi["n_segments"]] - osg).max() <= 5e-3
+    assert n >= 1500, n
+    assert worst <= 2e-3, worst
+    assert same >= 0.96 * n, (same, n)
+    print("posture vs the naive EFT: %d blobs, %d with the same tail and head, curves within %.2g px" % (n, same, worst))
+
+
+def test_more_than_three_harmonics_are_refused_on_both_sides():
+    fr, bg = synth.batch("C2", 1)
+    with pytest.raises(capi.TrexHipError):
+        run_posture(fr, bg, outline_approximate=4)
+    r0 = oracle.segment(fr[0], bg, oracle.make_params(fr.shape[2], fr.shape[1]))
+    b = r0[0][0]
+    with pytest.raises(ValueError):
+        oracle.posture(r0[1][b["run_begin"]:b["run_begin"] + b["n_runs"]], (int(b["x0"]), int(b["y0"])), oracle.posture_params(max_points=512, outline_approximate=4))

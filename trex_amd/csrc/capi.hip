@@ -380,6 +380,47 @@ int trexhip_synchronize(trexhip_ctx* ctx) {
     return TREXHIP_OK;
 }
 
+
+}  // extern "C"
+namespace trexhip {
+// A batch of a few frames (TRex's default detect_batch_size is ONE frame per call) leaves the device as ONE launch that writes the frame table, the
+// totals and exactly the filled parts of the blob / line / pixel tables into the context's pinned host mirrors, followed by ONE stream synchronize.
+// The DMA path below needs two round trips (frame table and totals first, then three copies whose sizes the totals give): five small copies with
+// 10-17 us of host latency between them -- more than the detect kernels of one frame take (profiles/r06_batch1_timeline.txt).  4-byte words: every
+// table is a multiple of 4 bytes except the pixels, whose tail bytes go out one by one.
+__global__ __launch_bounds__(256) void k_export(const trexhip_frame_info* __restrict__ info, const uint32_t* __restrict__ totals,
+                                                const trexhip_blob* __restrict__ blobs, const trexhip_run* __restrict__ runs, const uint8_t* __restrict__ pixels,
+                                                trexhip_frame_info* __restrict__ h_info, uint32_t* __restrict__ h_totals, trexhip_blob* __restrict__ h_blobs,
+                                                trexhip_run* __restrict__ h_runs, uint8_t* __restrict__ h_pixels, const int n,
+                                                const uint32_t pool_blobs, const uint32_t pool_runs, const uint32_t pool_pixels, const int pix_ch) {
+    const uint32_t tb = min(totals[0], pool_blobs), tr = min(totals[1], pool_runs), tp = min(totals[2], pool_pixels);
+    const size_t gtid = (size_t)blockIdx.x * 256 + threadIdx.x, gstep = (size_t)gridDim.x * 256;
+    auto words = [&](const void* src, void* dst, const size_t nw) {
+        const uint32_t* a = static_cast<const uint32_t*>(src);
+        uint32_t* b = static_cast<uint32_t*>(dst);
+        for (size_t i = gtid; i < nw; i += gstep) b[i] = a[i];
+    };
+    words(info, h_info, (size_t)n * sizeof(trexhip_frame_info) / 4);
+    if (gtid < 4) h_totals[gtid] = totals[gtid];
+    words(blobs, h_blobs, (size_t)tb * sizeof(trexhip_blob) / 4);
+    words(runs, h_runs, (size_t)tr * sizeof(trexhip_run) / 4);
+    const size_t pb = (size_t)tp * pix_ch;
+    words(pixels, h_pixels, pb / 4);
+    if (gtid < (pb & 3)) h_pixels[(pb & ~(size_t)3) + gtid] = pixels[(pb & ~(size_t)3) + gtid];
+}
+static_assert(sizeof(trexhip_frame_info) % 4 == 0 && sizeof(trexhip_blob) % 4 == 0 && sizeof(trexhip_run) % 4 == 0, "k_export copies 4-byte words");
+static constexpr int EXPORT_MAX_FRAMES = 16;
+static int export_small(trexhip_ctx* ctx, int n) {
+    hipLaunchKernelGGL(k_export, dim3(32), dim3(256), 0, ctx->stream, ctx->d_info, ctx->d_ctr + (size_t)ctx->p.max_batch * TREXHIP_CTR_STRIDE, ctx->d_blobs,
+                       ctx->d_runs, ctx->d_pixels, ctx->h_info, ctx->h_totals, ctx->h_blobs, ctx->h_runs, ctx->h_pixels, n,
+                       ctx->cfg.pool_blobs, ctx->cfg.pool_runs, ctx->cfg.pool_pixels, ctx->pix_ch);
+    TH_CHECK_HIP(hipGetLastError());
+    TH_CHECK_HIP(hipStreamSynchronize(ctx->stream));
+    return TREXHIP_OK;
+}
+}  // namespace trexhip
+extern "C" {
+
 int trexhip_fetch(trexhip_ctx* ctx, trexhip_batch_result* out) {
     if (!ctx || !out) { set_error("trexhip_fetch: null argument"); return TREXHIP_E_INVALID; }
     TH_CHECK_HIP(hipSetDevice(ctx->p.device));
@@ -390,26 +431,36 @@ int trexhip_fetch(trexhip_ctx* ctx, trexhip_batch_result* out) {
     out->pixel_channels = (uint32_t)ctx->pix_ch; out->reserved_ = 0;
     if (n == 0) return TREXHIP_OK;
     hipStream_t s = ctx->stream;
-    TH_CHECK_HIP(hipMemcpyAsync(ctx->h_info, ctx->d_info, sizeof(trexhip_frame_info) * n, hipMemcpyDeviceToHost, s));
-    TH_CHECK_HIP(hipMemcpyAsync(ctx->h_totals, ctx->d_ctr + (size_t)ctx->p.max_batch * TREXHIP_CTR_STRIDE, sizeof(uint32_t) * 4, hipMemcpyDeviceToHost, s));
-    TH_CHECK_HIP(hipStreamSynchronize(s));
+    static const bool export_env = !(std::getenv("TREXHIP_EXPORT") && std::atoi(std::getenv("TREXHIP_EXPORT")) == 0);
+    const bool by_kernel = export_env && n <= EXPORT_MAX_FRAMES;      // a few frames: one launch + one synchronize (k_export)
+    if (by_kernel) { int rce = export_small(ctx, n); if (rce) return rce; }
+    else {
+        TH_CHECK_HIP(hipMemcpyAsync(ctx->h_info, ctx->d_info, sizeof(trexhip_frame_info) * n, hipMemcpyDeviceToHost, s));
+        TH_CHECK_HIP(hipMemcpyAsync(ctx->h_totals, ctx->d_ctr + (size_t)ctx->p.max_batch * TREXHIP_CTR_STRIDE, sizeof(uint32_t) * 4, hipMemcpyDeviceToHost, s));
+        TH_CHECK_HIP(hipStreamSynchronize(s));
+    }
     bool pending = false;
     for (int i = 0; i < n; ++i) pending |= ctx->h_info[i].reserved[0] == 1u;
     if (pending) {   // frames with more runs than fit in LDS: finish them with the global-memory chain
         int rc2 = launch_pending(ctx);
         if (rc2) return rc2;
-        TH_CHECK_HIP(hipMemcpyAsync(ctx->h_info, ctx->d_info, sizeof(trexhip_frame_info) * n, hipMemcpyDeviceToHost, s));
-        TH_CHECK_HIP(hipMemcpyAsync(ctx->h_totals, ctx->d_ctr + (size_t)ctx->p.max_batch * TREXHIP_CTR_STRIDE, sizeof(uint32_t) * 4, hipMemcpyDeviceToHost, s));
-        TH_CHECK_HIP(hipStreamSynchronize(s));
+        if (by_kernel) { int rce = export_small(ctx, n); if (rce) return rce; }
+        else {
+            TH_CHECK_HIP(hipMemcpyAsync(ctx->h_info, ctx->d_info, sizeof(trexhip_frame_info) * n, hipMemcpyDeviceToHost, s));
+            TH_CHECK_HIP(hipMemcpyAsync(ctx->h_totals, ctx->d_ctr + (size_t)ctx->p.max_batch * TREXHIP_CTR_STRIDE, sizeof(uint32_t) * 4, hipMemcpyDeviceToHost, s));
+            TH_CHECK_HIP(hipStreamSynchronize(s));
+        }
     }
     // frames that overflowed the pool reserved nothing valid; clamp the copies to the pools
     const uint32_t tb = ctx->h_totals[0] < ctx->cfg.pool_blobs ? ctx->h_totals[0] : ctx->cfg.pool_blobs;
     const uint32_t tr = ctx->h_totals[1] < ctx->cfg.pool_runs ? ctx->h_totals[1] : ctx->cfg.pool_runs;
     const uint32_t tp = ctx->h_totals[2] < ctx->cfg.pool_pixels ? ctx->h_totals[2] : ctx->cfg.pool_pixels;
-    if (tb) TH_CHECK_HIP(hipMemcpyAsync(ctx->h_blobs, ctx->d_blobs, sizeof(trexhip_blob) * tb, hipMemcpyDeviceToHost, s));
-    if (tr) TH_CHECK_HIP(hipMemcpyAsync(ctx->h_runs, ctx->d_runs, sizeof(trexhip_run) * tr, hipMemcpyDeviceToHost, s));
-    if (tp) TH_CHECK_HIP(hipMemcpyAsync(ctx->h_pixels, ctx->d_pixels, (size_t)tp * ctx->pix_ch, hipMemcpyDeviceToHost, s));
-    TH_CHECK_HIP(hipStreamSynchronize(s));
+    if (!by_kernel) {
+        if (tb) TH_CHECK_HIP(hipMemcpyAsync(ctx->h_blobs, ctx->d_blobs, sizeof(trexhip_blob) * tb, hipMemcpyDeviceToHost, s));
+        if (tr) TH_CHECK_HIP(hipMemcpyAsync(ctx->h_runs, ctx->d_runs, sizeof(trexhip_run) * tr, hipMemcpyDeviceToHost, s));
+        if (tp) TH_CHECK_HIP(hipMemcpyAsync(ctx->h_pixels, ctx->d_pixels, (size_t)tp * ctx->pix_ch, hipMemcpyDeviceToHost, s));
+        TH_CHECK_HIP(hipStreamSynchronize(s));
+    }
     out->total_blobs = tb; out->total_runs = tr; out->total_pixels = tp;
     ctx->fetched = true;
     int rc = TREXHIP_OK;

@@ -121,13 +121,20 @@ typedef _Float16 f16x8_c1 __attribute__((ext_vector_type(8)));
 static constexpr int FB_MAX = 1024;           // more flagged crops than this: every crop is re-run
 __device__ __forceinline__ int fb_count(const uint32_t* __restrict__ plan, const int n) { return (plan && plan[1] == 1u) ? (int)plan[0] : n; }
 __device__ __forceinline__ int fb_crop(const uint32_t* __restrict__ plan, const int i) { return (plan && plan[1] == 1u) ? (int)plan[2 + i] : i; }
-__global__ __launch_bounds__(1024) void k_guard_plan(uint32_t* __restrict__ overflow, uint8_t* __restrict__ flags, const int n, uint32_t* __restrict__ plan) {
-    __shared__ uint32_t cnt;
+// (called by every thread of ONE workgroup of NT threads; `cnt` is that workgroup's shared counter.)  The last reader of the range flag and of the
+// persistent convolutions' pass counters hands all three back zeroed for the next forward pass: no memset in front of a pass (round 6)
+template <int NT>
+__device__ __forceinline__ void guard_plan(uint32_t* __restrict__ overflow, uint8_t* __restrict__ flags, const int n, uint32_t* __restrict__ plan, uint32_t& cnt) {
     if (threadIdx.x == 0) cnt = 0;
     __syncthreads();
     const uint32_t raised = overflow[0];      // bit 0: something left the fp16 range; bit 1: a kernel that cannot name the crop saw it
-    if (raised == 0u) { if (threadIdx.x == 0) { plan[0] = 0; plan[1] = 0; } return; }
-    for (int i = threadIdx.x; i < n; i += 1024)
+    if (raised == 0u) {
+        // (flags of an aborted earlier pass would enlarge a later plan: what is there is cleared even when nothing was raised -- ADVICE r5)
+        for (int i = threadIdx.x; i < n; i += NT) if (flags[i]) flags[i] = 0;
+        if (threadIdx.x == 0) { plan[0] = 0; plan[1] = 0; overflow[1] = 0u; overflow[2] = 0u; }
+        return;
+    }
+    for (int i = threadIdx.x; i < n; i += NT)
         if (flags[i]) {
             flags[i] = 0;
             const uint32_t k = atomicAdd(&cnt, 1u);
@@ -139,7 +146,12 @@ __global__ __launch_bounds__(1024) void k_guard_plan(uint32_t* __restrict__ over
     if (threadIdx.x == 0) {
         const bool whole = (raised & 2u) || cnt == 0u || cnt > (uint32_t)FB_MAX;
         plan[0] = whole ? 0u : cnt; plan[1] = whole ? 2u : 1u;
+        overflow[0] = 0u; overflow[1] = 0u; overflow[2] = 0u;
     }
+}
+__global__ __launch_bounds__(1024) void k_guard_plan(uint32_t* __restrict__ overflow, uint8_t* __restrict__ flags, const int n, uint32_t* __restrict__ plan) {
+    __shared__ uint32_t cnt;
+    guard_plan<1024>(overflow, flags, n, plan, cnt);
 }
 
 __global__ __launch_bounds__(256) void k_conv1_mfma(const uint8_t* __restrict__ crops, const uint4* __restrict__ wtab /*[16][64]*/,
@@ -1367,6 +1379,82 @@ __global__ __launch_bounds__(256) void k_head(const float* __restrict__ fc1 /*[N
         }
 }
 
+// k_head for small batches (TRex's default detect_batch_size of 1: 100 crops per call).  k_head gives a wave four crops and walks fc2's 100
+// inputs with one dependent global load per step: 25 us for 100 crops, all of it latency.  Here a wave has ONE crop (100 crops = 25 workgroups
+// instead of 7), the LayerNorm outputs stay in registers and reach the lanes through v_readlane (no LDS), and the 100 weights of a class are
+// fetched 25 at a time ahead of the multiply-adds.  The same operations in the same order per crop -- plane sums, LayerNorm, fc2 with the
+// bias first and k ascending, softmax -- so the probabilities are bit-identical to k_head's (tests/test_cnn_gpu.py).
+__global__ __launch_bounds__(256) void k_head_small(const float* __restrict__ fc1 /*[KSPLIT][N][128]*/, const float* __restrict__ ln_g,
+                                                    const float* __restrict__ ln_b, const float* __restrict__ w2t /*[100][C]*/,
+                                                    const float* __restrict__ b2, float* __restrict__ probs /*[N][C]*/,
+                                                    float* __restrict__ logits_out, int n, int C, int ksplit,
+                                                    uint32_t* __restrict__ overflow, uint8_t* __restrict__ crop_flags, uint32_t* __restrict__ plan) {
+    // the re-run plan of the range guard (k_guard_plan's work: every kernel that can raise the flag lies in front of this one) by workgroup 0: one launch fewer
+    __shared__ uint32_t plan_cnt;
+    if (plan && blockIdx.x == 0) guard_plan<256>(overflow, crop_flags, n, plan, plan_cnt);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int crop = blockIdx.x * 4 + wave;
+    if (crop >= n) return;
+    const bool hi = lane + 64 < 100;
+    float xa[FC1_KSPLIT], xb[FC1_KSPLIT];
+#pragma unroll
+    for (int s = 0; s < FC1_KSPLIT; ++s) {
+        const float* xs = fc1 + (size_t)s * n * 128 + (size_t)crop * 128;
+        xa[s] = s < ksplit ? xs[lane] : 0.f;
+        xb[s] = (s < ksplit && hi) ? xs[lane + 64] : 0.f;
+    }
+    const float g0 = ln_g[lane], be0 = ln_b[lane];
+    const float g1 = hi ? ln_g[lane + 64] : 0.f, be1 = hi ? ln_b[lane + 64] : 0.f;
+    float x0 = xa[0], x1 = xb[0];
+#pragma unroll
+    for (int s = 1; s < FC1_KSPLIT; ++s)
+        if (s < ksplit) { x0 += xa[s]; x1 += xb[s]; }
+    const float mean = wave_sum(x0 + x1) * (1.f / 100.f);
+    const float d0 = x0 - mean, d1 = hi ? x1 - mean : 0.f;
+    const float var = wave_sum(d0 * d0 + d1 * d1) * (1.f / 100.f);
+    const float rstd = 1.f / sqrtf(var + 1e-5f);
+    const float y0 = fmaxf(d0 * rstd * g0 + be0, 0.f);            // input k of fc2 lives in lane k (k < 64) ...
+    const float y1 = hi ? fmaxf(d1 * rstd * g1 + be1, 0.f) : 0.f; // ... or in lane k - 64
+    const int nrep = (C + 63) / 64;
+    float lg[16];
+    float mx = -3.4e38f, sum = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        lg[r] = -3.4e38f;
+        if (r < nrep) {
+            const int c = r * 64 + lane;
+            const int cc = c < C ? c : C - 1;                      // (every lane walks the loop: readlane wants the whole wave; the spare lanes repeat the last class)
+            float s = b2[cc];
+#pragma unroll
+            for (int k0 = 0; k0 < 100; k0 += 25) {
+                float w[25];
+#pragma unroll
+                for (int k = 0; k < 25; ++k) w[k] = w2t[(size_t)(k0 + k) * C + cc];
+#pragma unroll
+                for (int k = 0; k < 25; ++k) {
+                    const int kk = k0 + k;
+                    const float yk = kk < 64 ? __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, y0), kk))
+                                             : __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, y1), kk - 64));
+                    s = fmaf(yk, w[k], s);
+                }
+            }
+            if (c < C) {
+                lg[r] = s;
+                if (logits_out) logits_out[(size_t)crop * C + c] = s;
+            }
+            mx = fmaxf(mx, lg[r]);
+        }
+    }
+    mx = wave_max(mx);
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+        if (r < nrep && r * 64 + lane < C) { lg[r] = expf(lg[r] - mx); sum += lg[r]; }
+    sum = 1.f / wave_sum(sum);
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+        if (r < nrep && r * 64 + lane < C) probs[(size_t)crop * C + r * 64 + lane] = lg[r] * sum;
+}
+
 // ------------------------------------------------------------------------------------------------
 // host: weight blob -> folded / repacked device tensors
 // ------------------------------------------------------------------------------------------------
@@ -1398,6 +1486,8 @@ struct Net {
     std::vector<GraphEntry> graphs;
     bool graphs_ok = true;
     uint64_t tick = 0;
+    bool ovf_clean = true;                     // d_ovf[0..2] are zero, or will be when the queued work has run (see net_forward)
+    int last_mode = -1;                        // precision mode of the last forward pass (trexhip_identify_guard_stats reads the plan only behind an fp16x3 pass)
 };
 
 // an exec may still be running on its stream (launches are asynchronous): wait for the event recorded behind its last launch first
@@ -1728,7 +1818,7 @@ static int ensure_act(trexhip_ctx* ctx, Net* net, int n) {
     if (net->d_ovfc) { (void)hipFree(net->d_ovfc); net->d_ovfc = nullptr; }
     const size_t N = n;
     TH_CHECK_HIP(hipMalloc(reinterpret_cast<void**>(&net->d_ovfc), N));
-    TH_CHECK_HIP(hipMemset(net->d_ovfc, 0, N));              // k_guard_plan clears what it reads
+    TH_CHECK_HIP(hipMemsetAsync(net->d_ovfc, 0, N, ctx->stream));      // on the stream its users run on; the plan kernel clears what it reads
     TH_CHECK_HIP(hipMalloc(reinterpret_cast<void**>(&net->act1), N * 40 * 40 * 16 * 4));
     TH_CHECK_HIP(hipMalloc(reinterpret_cast<void**>(&net->act2), N * 20 * 20 * 64 * 4));
     TH_CHECK_HIP(hipMalloc(reinterpret_cast<void**>(&net->act3), N * 10 * 10 * 128 * 4));
@@ -1838,7 +1928,8 @@ static int net_forward_launch(trexhip_ctx* ctx, const uint8_t* d_crops, int n, f
     // default chain (cnn_wpre.h): the Winograd-domain fp16 operand images V2 / V3 are written by the producing layer.  Any of the older
     // geometry bits of TREXHIP_CONV_GEOM (bit 11 = nothing else) selects the fp32-activation chain of rounds 1-2 instead.
     const bool pre = mode == TREXHIP_CNN_FP16X3 && aligned && (ctx->tune_conv_geom & 0xfff) == 0;
-    if (mode == TREXHIP_CNN_FP16X3) TH_CHECK_HIP(hipMemsetAsync(net->d_ovf, 0, 16, s));    // [0] fp16 range flag, [1] / [2] pass counters of the persistent conv3 / conv2
+    // (d_ovf: [0] fp16 range flag, [1] / [2] pass counters of the persistent conv3 / conv2.  They start at zero: the guard's plan kernel -- the last
+    // reader of all three -- hands them back zeroed; net_forward clears them itself behind a pass that was not queued to its end)
     // one input channel: conv1 runs INSIDE conv2 (cnn_fused12.h: the V2 image stays in LDS); TREXHIP_CONV_GEOM bit 28 keeps the two kernels
     const bool fused12 = pre && net->CH == 1 && !(ctx->tune_conv_geom & (1 << 28));
     if (fused12) { }
@@ -2013,12 +2104,18 @@ static int net_forward_launch(trexhip_ctx* ctx, const uint8_t* d_crops, int n, f
             hipLaunchKernelGGL(k_fc1_split<4>, dim3((n + 127) / 128, ks1), dim3(256), 0, s, net->act3, net->wf1h, net->bf1, net->fc1, n, 12800, net->invf1h, net->d_ovf, net->d_ovfc);
     else
         hipLaunchKernelGGL(k_fc1, dim3((n + 31) / 32, FC1_KSPLIT), dim3(256), 0, s, net->act3, net->wf1, net->bf1, net->fc1, n, 12800, (const uint32_t*)nullptr);
+    const bool small_head = n <= 1024;
+    if (small_head)     // one crop per wave, nothing but latency to save (k_head_small); same bits.  Its first workgroup also makes the range guard's plan
+        hipLaunchKernelGGL(k_head_small, dim3((n + 3) / 4), dim3(256), 0, s, net->fc1, net->lng, net->lnb, net->wf2t, net->bf2,
+                           d_probs, d_logits, n, net->classes, split1 ? ks1 : FC1_KSPLIT,
+                           mode == TREXHIP_CNN_FP16X3 ? net->d_ovf : (uint32_t*)nullptr, net->d_ovfc, mode == TREXHIP_CNN_FP16X3 ? net->d_ovf + 4 : (uint32_t*)nullptr);
+    else
     hipLaunchKernelGGL(k_head, dim3((n + 4 * HEAD_CPW - 1) / (4 * HEAD_CPW)), dim3(256), 0, s, net->fc1, net->lng, net->lnb, net->wf2t, net->bf2,
                        d_probs, d_logits, n, net->classes, (const uint32_t*)nullptr, split1 ? ks1 : FC1_KSPLIT);
     if (mode == TREXHIP_CNN_FP16X3) {
         // guarded re-run with the bf16 split: every workgroup returns at once unless an activation left the fp16 range; k_guard_plan lists the
         // flagged crops (or orders the whole batch when the flag came from a kernel that does not know the crop) and the re-run follows its plan
-        hipLaunchKernelGGL(k_guard_plan, dim3(1), dim3(1024), 0, s, net->d_ovf, net->d_ovfc, n, net->d_ovf + 4);
+        if (!small_head) hipLaunchKernelGGL(k_guard_plan, dim3(1), dim3(1024), 0, s, net->d_ovf, net->d_ovfc, n, net->d_ovf + 4);
         const uint32_t* g = net->d_ovf + 4;
         if (pre) {      // the default chain has no fp32 activations: the re-run starts at the crops
             if (net->CH == 1) hipLaunchKernelGGL(k_conv1_mfma, dim3(n), dim3(256), 0, s, d_crops, net->w1h, net->b1, net->act1, net->inv1h, g);
@@ -2044,7 +2141,20 @@ static constexpr int GRAPH_MAX_CROPS = 6400;      // above this the kernels them
 static constexpr size_t GRAPH_CACHE = 8;
 static constexpr int GRAPH_MIN_SEEN = 3;          // calls with the same key before its chain is captured
 
+static int net_forward_inner(trexhip_ctx* ctx, const uint8_t* d_crops, int n, float* d_probs, float* d_logits);
 int net_forward(trexhip_ctx* ctx, const uint8_t* d_crops, int n, float* d_probs, float* d_logits) {
+    Net* net = static_cast<Net*>(ctx->net);
+    if (ctx->cnn_mode == TREXHIP_CNN_FP16X3) {
+        // the range flag and the pass counters: zero by construction (the plan kernel of the previous pass), cleared here only behind a pass that
+        // failed half-way (outside any capture: a replayed chain never holds this memset)
+        if (!net->ovf_clean) TH_CHECK_HIP(hipMemsetAsync(net->d_ovf, 0, 16, ctx->stream));
+        net->ovf_clean = false;
+    }
+    const int rc = net_forward_inner(ctx, d_crops, n, d_probs, d_logits);
+    if (rc == TREXHIP_OK) { net->last_mode = ctx->cnn_mode; if (ctx->cnn_mode == TREXHIP_CNN_FP16X3) net->ovf_clean = true; }
+    return rc;
+}
+static int net_forward_inner(trexhip_ctx* ctx, const uint8_t* d_crops, int n, float* d_probs, float* d_logits) {
     Net* net = static_cast<Net*>(ctx->net);
     static const bool enabled = [] { const char* e = std::getenv("TREXHIP_GRAPHS"); return !(e && std::atoi(e) == 0); }();
     // not while profiling (the stage events are host-side bookkeeping), not before the first plain call (function attributes are set there)
@@ -2147,7 +2257,9 @@ int trexhip_identify_guard_stats(trexhip_ctx* ctx, uint32_t* rerun_crops, uint32
     Net* net = static_cast<Net*>(ctx->net);
     uint32_t plan[2] = {0, 0};
     TH_CHECK_HIP(hipStreamSynchronize(ctx->stream));
-    if (ctx->cnn_mode == TREXHIP_CNN_FP16X3) TH_CHECK_HIP(hipMemcpy(plan, net->d_ovf + 4, 8, hipMemcpyDeviceToHost));
+    // the plan of the LAST forward pass -- none before the first pass or behind a pass in another precision mode (not ctx->cnn_mode, which
+    // trexhip_set_identity_precision may have changed since)
+    if (net->last_mode == TREXHIP_CNN_FP16X3) TH_CHECK_HIP(hipMemcpy(plan, net->d_ovf + 4, 8, hipMemcpyDeviceToHost));
     if (rerun_crops) *rerun_crops = plan[1] == 1u ? plan[0] : 0u;
     if (whole_batch) *whole_batch = plan[1] == 2u ? 1u : 0u;
     return TREXHIP_OK;

@@ -1621,8 +1621,11 @@ int launch_segment(trexhip_ctx* ctx, const uint8_t* d_frames, int n) {
     const int gs = (n + G - 1) / G;
     // gray pixel arrays: k_ccl_lds gathers the blobs of the frame it has just labelled (TREXHIP_FUSE_GATHER=0: the separate k_gather launch);
     // the colour encodings keep k_gather (one wave per blob, colour addressing)
-    static const bool fuse_env = !(std::getenv("TREXHIP_FUSE_GATHER") && std::atoi(std::getenv("TREXHIP_FUSE_GATHER")) == 0);
-    const bool fuse_gather = fuse_env && ctx->p.pixel_encoding == TREXHIP_ENC_GRAY;
+    // ... when the launch gives (nearly) every CU a frame.  With fewer frames the labelling workgroups are the only ones at work and the gather
+    // is better spread over the idle CUs by its own launch (round 6, profiles/r06_fuse_gather.txt; us per detect pass, fused / separate:
+    // C4 1 frame 47.7 / 39.3, 16 frames 71.0 / 59.7; C5 64 frames 347 / 313, 16 frames 170 / 134; C2 64 frames 44.8 / 45.8; C4 256 frames: fused 5 us ahead)
+    static const int fuse_env = std::getenv("TREXHIP_FUSE_GATHER") ? std::atoi(std::getenv("TREXHIP_FUSE_GATHER")) : -1;
+    const bool fuse_gather = ctx->p.pixel_encoding == TREXHIP_ENC_GRAY && (fuse_env >= 0 ? fuse_env != 0 : 4 * n >= 3 * ctx->n_cus);
     stage_begin(ctx, TREXHIP_STAGE_ROWS);
     for (int g = 0; g < G; ++g) {
         const int f0 = g * gs, f1 = (g + 1) * gs < n ? (g + 1) * gs : n;
@@ -1689,8 +1692,11 @@ int launch_segment(trexhip_ctx* ctx, const uint8_t* d_frames, int n) {
         if (inst != 3) TH_CCL(1024, CCL_NMAX, CCL_SORT, 1);      // returns at once for every frame the first instance finished
 #undef TH_CCL
         static const int gather_blocks_env = std::getenv("TREXHIP_GATHER_BLOCKS") ? std::atoi(std::getenv("TREXHIP_GATHER_BLOCKS")) : 0;
+        // (eight blobs per workgroup; a launch of a few frames does not need 2048 workgroups that look at the total and leave)
+        const unsigned gather_need = (unsigned)(((size_t)(f1 - f0) * ctx->p.max_blobs + 7) / 8);
+        const unsigned gather_grid = gather_blocks_env > 0 ? (unsigned)gather_blocks_env : (gather_need < 16u ? 16u : (gather_need > 2048u ? 2048u : gather_need));
         if (!fuse_gather)
-        LAUNCH_GATHER(dim3(G > 1 ? 256 : (gather_blocks_env > 0 ? gather_blocks_env : 2048)), t, c, 0, d_frames, totals, ctx->d_info, ctx->d_blob_frame,
+        LAUNCH_GATHER(dim3(G > 1 ? 256 : gather_grid), t, c, 0, d_frames, totals, ctx->d_info, ctx->d_blob_frame,
                            ctx->d_blobs, ctx->d_runs, ctx->d_pixels, (uint32_t)f0, (uint32_t)f1, ctx->d_color_src, ctx->color_ch, ctx->p.pixel_encoding);
     }
     if (G > 1) {

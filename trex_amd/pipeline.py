@@ -94,8 +94,11 @@ class Lane:
                     seg.crops_posture_device(self.crops.data_ptr(), n, self.p_minfo.data_ptr())
                 else:
                     seg.crops_device(self.crops.data_ptr(), n, normalization=1 if o["normalize"] == "moments" else 0)
-                if self.after is not None:      # one identity network on the matrix cores at a time; posture / crops above and the
-                    self.stream.wait_event(self.after.done)   # table hand-off below overlap the other lane's network
+                # one identity network on the matrix cores at a time; posture / crops above and the table hand-off below overlap the other
+                # lane's network.  Not for batches of a few frames (TRex's default is ONE frame per call): their network is a chain of small
+                # launches that leaves most of the chip idle, and two lanes' chains side by side are what keeps it busy
+                if self.after is not None and n > 1024:
+                    self.stream.wait_event(self.after.done)
                 seg.identify_device(self.crops.data_ptr(), n, self.probs.data_ptr())
             self.done.record(self.stream)
             # per-blob identity table -> (gathered over RCCL/xGMI when N > 1) -> rank 0's host, for the sequential matcher
