@@ -732,6 +732,8 @@ def compact_line(out, sec):
     roof_keys = ("bound", "achieved", "peak", "unit", "frac", "traffic", "avg_launch_us", "launches", "mfma_issue_frac")
     r = out["roofline"]
     o["roofline"] = {"kernel": r["kernel"].split(" ")[0], **_pick(r, roof_keys)}
+    if o["roofline"].get("traffic") is not None:      # the counters cannot be read from inside this process: the bytes are the committed PMC passes of this same command
+        o["roofline"]["traffic_source"] = "profiles/rNN_pmc_summary.json (separate --pmc passes of this command; not measured in this run)"
     o["roofline"]["frac"] = o["roofline"]["achieved"] / o["roofline"]["peak"] if o["roofline"]["peak"] else 0.0    # consistent with the rounded `achieved`
     if "roofline_kernels" in out:
         o["roofline_kernels"] = {k: {"kernel": v["kernel"].split(" ")[0], **_pick(v, ("achieved", "frac", "traffic", "avg_launch_us"))} for k, v in out["roofline_kernels"].items()}
@@ -773,6 +775,15 @@ def compact_line(out, sec):
                 q["frac_split_peak"] = _r(rr["frac_split_peak"], 3)
             if "range_guard" in e:
                 q["rerun_crops"] = e["range_guard"].get("rerun_crops_last_step")
+            if "host_input" in e:
+                # the two legs of the as-deployed path per step: host threads pageable -> pinned ring (+ BGRA -> gray), DMA ring -> HBM;
+                # they overlap each other and the kernels, so the step is about the larger of the two plus what does not overlap
+                hi_ = e["host_input"]
+                nfr = (e.get("ms_per_step") or 0) and (e["value"] * e["ms_per_step"] / 1e3)      # frames per step
+                if hi_.get("host_copy_ms_per_frame") is not None:
+                    q["copy_ms"] = _r(hi_["host_copy_ms_per_frame"] * nfr, 3)
+                if hi_.get("dma_ms_per_frame") is not None:
+                    q["dma_ms"] = _r(hi_["dma_ms_per_frame"] * nfr, 3)
             if "spread" in e:
                 q["spread"] = _r(e["spread"], 2)
                 q["min"], q["max"] = _r(min(e["repetitions"])), _r(max(e["repetitions"]))
