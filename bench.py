@@ -607,6 +607,10 @@ SECONDARY = [
     # their buffers -- before the timed region).  12 steps where a step is 10 ms: the timed region ends with a drained pipeline, and over 4
     # steps that last, un-overlapped step read as 5 % (C4_force_dist 26.7 k against the 28.1 k of the same code path over 20 steps)
     ("C2", {"config": "C2"}, 30, 4),
+    # 256 frames of 1280 x 720 are 295 MB: a launch that short leaves one labelling workgroup per CU and a pixel pass of 60 us.  The C ABI takes any
+    # max_batch (TRex's own detect_batch_size is a uchar: the adapter stops at 255); at 1024 frames several frames share a CU and k_ccl_lds runs in
+    # its small instance (round 6: 3.6 -> 3.7 TB/s of counter bytes over the whole pass)
+    ("C2_batch1024", {"config": "C2", "batch": 1024}, 16, 4),
     ("C3", {"config": "C3"}, 12, 2),
     ("C5", {"config": "C5"}, 12, 3),
     ("C4_posture_normalised", {"normalize": "posture"}, 12, 3),

@@ -203,7 +203,9 @@ int trexhip_device_alloc(trexhip_ctx* ctx, size_t bytes, void** out_device_ptr);
 int trexhip_device_free(trexhip_ctx* ctx, void* device_ptr);
 int trexhip_copy_to_host(trexhip_ctx* ctx, void* host_dst, const void* device_src, size_t bytes);
 int trexhip_copy_to_device(trexhip_ctx* ctx, void* device_dst, const void* host_src, size_t bytes);
-/* wait for the last segment call and copy its tables to pinned host memory */
+/* wait for the last segment call and copy its tables to pinned host memory.  Batches of up to 16 frames (TRex's default detect_batch_size is 1,
+ * core/default_config.cpp:1113) leave the device as ONE kernel that writes the filled parts of all five tables into the pinned mirrors + one
+ * stream synchronize; larger batches as two rounds of DMA copies (frame table and totals, then the tables at their exact sizes). */
 int trexhip_fetch(trexhip_ctx* ctx, trexhip_batch_result* out);
 int trexhip_device_view_get(trexhip_ctx* ctx, trexhip_device_view* out);
 int trexhip_synchronize(trexhip_ctx* ctx);
@@ -413,7 +415,12 @@ int trexhip_identify_device(trexhip_ctx* ctx, const uint8_t* d_crops, int32_t n,
 int trexhip_identify(trexhip_ctx* ctx, const uint8_t* crops, int32_t n, float* probs);
 /* What the fp16 range guard of the LAST identify call on this context did (waits for the context's stream): *rerun_crops = crops
  * whose layer stack was re-run by the BF16X6 kernels (0 = none; the whole batch when the flag came from a kernel that does not
- * know the crop: *whole_batch = 1).  Per crop since round 5: one out-of-range crop no longer re-runs the batch.  No reference
+ * know the crop: *whole_batch = 1 -- also when other crops WERE named in the same batch).  Per crop since round 5: one out-of-range crop no
+ * longer re-runs the batch.  Two documented exceptions to "a crop's probabilities do not depend on its batch": (1) the fused conv1 + conv2 kernels
+ * attribute an out-of-range value to the crops that share its pass -- the crop itself and at most one neighbour in the batch --, and (2) more than
+ * 1024 named crops re-run the whole batch; a crop that is re-run although it was in range gets the BF16X6 result, which differs from its FP16X3
+ * result by about 2e-6 on the softmax (both inside the 1e-4 bar).  The answer refers to the last identify call even if
+ * trexhip_set_identity_precision was called since; zeros before the first call and behind a call in another precision mode.  No reference
  * counterpart (the reference's torch network has no range limit); either pointer may be NULL. */
 int trexhip_identify_guard_stats(trexhip_ctx* ctx, uint32_t* rerun_crops, uint32_t* whole_batch);
 

@@ -36,7 +36,14 @@ void stage_begin(trexhip_ctx* ctx, int stage) {
     if (s.pending.size() > 1024) stage_fold(s, false);
     EvPair p;
     if (!s.freelist.empty()) { p = s.freelist.back(); s.freelist.pop_back(); }
-    else { hipEventCreate(&p.a); hipEventCreate(&p.b); }
+    else {
+        // timing events only: no system-scope fence when one is recorded (hipEventDisableSystemFence -- "can be used for events that are only being used
+        // to measure timing ... avoiding the cost of cache writeback and invalidation, and the performance impact of those actions on the execution of
+        // following work", hip_runtime_api.h).  A default event between the pixel pass and the labelling kernel wrote back and invalidated the L2 the
+        // labelling kernel was about to read (round 6: the detect pass read 280 us through its own timers and 270 us on the wall clock without them)
+        static const unsigned flags = std::getenv("TREXHIP_TIMER_EVENT_FLAGS") ? (unsigned)std::strtoul(std::getenv("TREXHIP_TIMER_EVENT_FLAGS"), nullptr, 0) : (unsigned)hipEventDisableSystemFence;
+        hipEventCreateWithFlags(&p.a, flags); hipEventCreateWithFlags(&p.b, flags);
+    }
     hipEventRecord(p.a, ctx->stream);
     s.cur = p;
 }

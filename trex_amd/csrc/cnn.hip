@@ -2100,11 +2100,17 @@ static int net_forward_launch(trexhip_ctx* ctx, const uint8_t* d_crops, int n, f
     if (split1)
         if (n <= 1024)     // small batches: 32 crops per workgroup (same sums in the same order: a crop's row does not depend on the kernel its batch got)
             hipLaunchKernelGGL(k_fc1_split<1>, dim3((n + 31) / 32, ks1), dim3(256), 0, s, net->act3, net->wf1h, net->bf1, net->fc1, n, 12800, net->invf1h, net->d_ovf, net->d_ovfc);
-        else
+        else {
+            static const int fc1_mt = std::getenv("TREXHIP_FC1_MT") ? std::atoi(std::getenv("TREXHIP_FC1_MT")) : 4;      // (dev: crops per workgroup / 32; the same sums in the same order)
+            if (fc1_mt == 2) hipLaunchKernelGGL(k_fc1_split<2>, dim3((n + 63) / 64, ks1), dim3(256), 0, s, net->act3, net->wf1h, net->bf1, net->fc1, n, 12800, net->invf1h, net->d_ovf, net->d_ovfc);
+            else if (fc1_mt == 1) hipLaunchKernelGGL(k_fc1_split<1>, dim3((n + 31) / 32, ks1), dim3(256), 0, s, net->act3, net->wf1h, net->bf1, net->fc1, n, 12800, net->invf1h, net->d_ovf, net->d_ovfc);
+            else
             hipLaunchKernelGGL(k_fc1_split<4>, dim3((n + 127) / 128, ks1), dim3(256), 0, s, net->act3, net->wf1h, net->bf1, net->fc1, n, 12800, net->invf1h, net->d_ovf, net->d_ovfc);
+        }
     else
         hipLaunchKernelGGL(k_fc1, dim3((n + 31) / 32, FC1_KSPLIT), dim3(256), 0, s, net->act3, net->wf1, net->bf1, net->fc1, n, 12800, (const uint32_t*)nullptr);
-    const bool small_head = n <= 1024;
+    static const int head_small_max = std::getenv("TREXHIP_HEAD_SMALL_MAX") ? std::atoi(std::getenv("TREXHIP_HEAD_SMALL_MAX")) : 1024;      // (dev: where k_head takes over)
+    const bool small_head = n <= head_small_max;
     if (small_head)     // one crop per wave, nothing but latency to save (k_head_small); same bits.  Its first workgroup also makes the range guard's plan
         hipLaunchKernelGGL(k_head_small, dim3((n + 3) / 4), dim3(256), 0, s, net->fc1, net->lng, net->lnb, net->wf2t, net->bf2,
                            d_probs, d_logits, n, net->classes, split1 ? ks1 : FC1_KSPLIT,

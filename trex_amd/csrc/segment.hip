@@ -35,7 +35,7 @@ template <int LPB> __device__ __forceinline__ uint32_t group_incl_scan(uint32_t 
     v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, true);
     v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, true);
     v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, true);
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);       // row_bcast:15 into rows 1 and 3
+    if constexpr (LPB >= 32) v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);   // row_bcast:15 into rows 1 and 3
     if constexpr (LPB == 64) v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);   // row_bcast:31 into rows 2 and 3
     return v;
 }
@@ -1243,8 +1243,10 @@ __global__ __launch_bounds__(NT) void k_ccl_lds(const SegCfg c, uint32_t* __rest
         // barrier alone relied on the CU's L1 and on the compiler not moving the loads)
         __threadfence_block();
         __syncthreads();
-        gather_blobs<false, 32>(c, 0, own_frames, info, blob_frame, blobs, out_runs, own_pixels, 0u, 0xffffffffu, nullptr, 0, 0,
-                                bb + (uint32_t)(tid >> 6) * 2u, 2u * NW, bb + kept, f, rbeg, pb);
+        // four blobs per wave (16 lanes each): the gather is a chain of dependent loads (record -> lines -> pixels) per blob and step, and a frame of
+        // 100 individuals takes two steps of 64 blobs instead of four of 32 (round 6)
+        gather_blobs<false, 16>(c, 0, own_frames, info, blob_frame, blobs, out_runs, own_pixels, 0u, 0xffffffffu, nullptr, 0, 0,
+                                bb + (uint32_t)(tid >> 6) * 4u, 4u * NW, bb + kept, f, rbeg, pb);
     }
 #undef CCL_STAMP
 #undef CCL_STOP
@@ -1262,7 +1264,8 @@ template <int D> __device__ __forceinline__ uint32_t xchg_xor(uint32_t v) {
 // value of lane Q of the own 32-lane half (LPB = 32) / of the wave (LPB = 64)
 template <int LPB, int Q> __device__ __forceinline__ uint32_t bcast_lane(uint32_t v) {
     if constexpr (LPB == 64) return (uint32_t)__builtin_amdgcn_readlane((int)v, Q);
-    else return (uint32_t)__builtin_amdgcn_ds_swizzle((int)v, (Q << 5));
+    else if constexpr (LPB == 32) return (uint32_t)__builtin_amdgcn_ds_swizzle((int)v, (Q << 5));
+    else return (uint32_t)__builtin_amdgcn_ds_swizzle((int)v, (Q << 5) | 0x10);       // LPB = 16: lane bit 4 (which group of the 32-lane half) is kept
 }
 __device__ __forceinline__ uint64_t wave_sum64(uint64_t v) {
 #pragma unroll
@@ -1374,7 +1377,8 @@ __device__ __forceinline__ void gather_blobs(const SegCfg& c, const int only_pen
         const uint32_t n_runs = active ? B.n_runs : 0u;
         uint32_t nr_max = n_runs;                                 // the same in every lane of a blob: the wave's maximum from one lane per blob
         if (BPW > 1) nr_max = max((uint32_t)__builtin_amdgcn_readlane((int)n_runs, 0), (uint32_t)__builtin_amdgcn_readlane((int)n_runs, 32));
-        static_assert(BPW <= 2, "k_gather: one or two blobs per wave");
+        if (BPW > 2) nr_max = max(nr_max, max((uint32_t)__builtin_amdgcn_readlane((int)n_runs, 16), (uint32_t)__builtin_amdgcn_readlane((int)n_runs, 48)));
+        static_assert(BPW == 1 || BPW == 2 || BPW == 4, "k_gather: one, two or four blobs per wave");
         const trexhip_run* rr = runs + B.run_begin;
         uint8_t* px = pixels + (size_t)B.pix_begin * (enc == 2 ? 3 : 1);
         const uint8_t* img = frames + (size_t)f * c.H * c.W;
@@ -1569,9 +1573,7 @@ int launch_segment(trexhip_ctx* ctx, const uint8_t* d_frames, int n) {
     if (!ctx->attr_ccl) {
         TH_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ccl_lds<1024, CCL_NMAX, CCL_SORT>), hipFuncAttributeMaxDynamicSharedMemorySize, CCL_LDS_BYTES));
         TH_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ccl_lds<512, CCL_M_NMAX, CCL_M_SA>), hipFuncAttributeMaxDynamicSharedMemorySize, LdsM::BYTES));
-        TH_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ccl_lds<1024, CCL_M_NMAX, CCL_M_SA>), hipFuncAttributeMaxDynamicSharedMemorySize, LdsM::BYTES));
         TH_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ccl_lds<256, CCL_S_NMAX, CCL_S_SA>), hipFuncAttributeMaxDynamicSharedMemorySize, LdsS::BYTES));
-        TH_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ccl_lds<512, CCL_S_NMAX, CCL_S_SA>), hipFuncAttributeMaxDynamicSharedMemorySize, LdsS::BYTES));
         ctx->attr_ccl = true;
     }
     // Which instance of k_ccl_lds goes first (see the table above the kernel).  Measured in round 6 (profiles/r06_ccl_by_capacity.txt): with one frame
@@ -1581,7 +1583,7 @@ int launch_segment(trexhip_ctx* ctx, const uint8_t* d_frames, int n) {
     // held the frames of the earlier calls, told by two pinned words the kernels write (a frame had more lines than S / than M holds).  A wrong
     // guess costs time, never results: frames the first instance cannot hold are finished by the L instance queued right behind it.  Every 64th
     // call the words are cleared, so a context whose frames got emptier finds its way back down.
-    // TREXHIP_CCL_INST (dev): 1 S, 2 M, 3 L, 4 M with 1024 threads, 5 S with 512.
+    // TREXHIP_CCL_INST (dev): 1 S, 2 M, 3 L.  (M with 1024 threads and S with 512 were measured too: profiles/r06_ccl_by_capacity.txt, variants 4 and 5.)
     int inst = ctx->tune_ccl_inst;
     if (inst <= 0) {
         inst = 3;
@@ -1685,8 +1687,6 @@ int launch_segment(trexhip_ctx* ctx, const uint8_t* d_frames, int n) {
         switch (inst) {
             case 1: TH_CCL(256, CCL_S_NMAX, CCL_S_SA, 0); break;
             case 2: TH_CCL(512, CCL_M_NMAX, CCL_M_SA, 0); break;
-            case 4: TH_CCL(1024, CCL_M_NMAX, CCL_M_SA, 0); break;
-            case 5: TH_CCL(512, CCL_S_NMAX, CCL_S_SA, 0); break;
             default: TH_CCL(1024, CCL_NMAX, CCL_SORT, 0); break;
         }
         if (inst != 3) TH_CCL(1024, CCL_NMAX, CCL_SORT, 1);      // returns at once for every frame the first instance finished
