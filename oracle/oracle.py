@@ -268,7 +268,7 @@ def rethreshold_frame(frame, bg, params, method, threshold, size_ranges=(), inve
 def posture(runs, origin, pp=None, naive=False):
     """posture::calculate_posture for one blob given its lines: -> (info dict, outline [n,2] f32, segments [m,4] f32
     (pos.x, pos.y, height, l_length)); coordinates relative to `origin` (the blob's bounds().pos()).
-    naive=False: the EFT in the operation order the device reproduces bit for bit (refuses outline_approximate > 3 like the device);
+    naive=False: the EFT in the operation order the device reproduces bit for bit (refuses outline_approximate > 15 like the device);
     naive=True: the independent reading -- libm sinf / cosf per harmonic, sequential float sums, any order up to 15."""
     pp = pp or posture_params()
     runs = np.ascontiguousarray(runs, RUN_DTYPE)
@@ -278,7 +278,7 @@ def posture(runs, origin, pp=None, naive=False):
     fn = lib().oracle_posture_naive if naive else lib().oracle_posture
     rc = fn(_ptr(runs), len(runs), int(origin[0]), int(origin[1]), C.byref(pp), _ptr(out), _ptr(seg), C.byref(info))
     if rc == 5:
-        raise ValueError("oracle.posture: outline_approximate > 3 is refused by the mirrored EFT (as by trexhip_posture_device); naive=True takes any order")
+        raise ValueError("oracle.posture: outline_approximate > 15 is refused by the mirrored EFT (as by trexhip_posture_device)")
     d = {k: getattr(info, k) for k, _ in PostureInfo._fields_}
     return d, out[:info.n_outline].copy(), seg[:info.n_segments].copy()
 

@@ -171,9 +171,10 @@ static void eft_ieft(const v2* p, int N, int order, v2 center, v2* out) {
     /* cos / sin of the FIRST harmonic's phase at every boundary; harmonics 2 and 3 by the angle addition formulas, written out in the order the
      * device uses (c2 = c1 c1 - s1 s1, s2 = 2 (s1 c1), c3 = c2 c1 - s2 s1, s3 = s2 c1 + c2 s1) */
     for (int i = 0; i <= N; ++i) det_sincosf(2.0f * PI * (float)1 * t[i] / T, &cs[2 * i + 1], &cs[2 * i]);
-    float sa[4][64], sb[4][64], sc[4][64], sd[4][64];
+    float sa[16][64], sb[16][64], sc[16][64], sd[16][64];
     memset(sa, 0, sizeof(sa)); memset(sb, 0, sizeof(sb)); memset(sc, 0, sizeof(sc)); memset(sd, 0, sizeof(sd));
-    /* (order <= 3 here: oracle_posture refuses more, like trexhip_posture_device -- the angle-addition form above is written out for three harmonics) */
+    /* (order <= 15 here: oracle_posture refuses more, like trexhip_posture_device.  Harmonic 2 by the doubling form, every further one from its
+     * predecessor by angle addition: the device's general form (more than three harmonics, three per sweep) recomputes exactly this sequence) */
     for (int i = 0; i < N; ++i) {
         const v2 q = p[(i + 1) % N];
         const float dx = q.x - p[i].x, dy = q.y - p[i].y;
@@ -321,11 +322,11 @@ typedef struct oracle_posture_params {
  * local-maximum test itself (c[i] > c[i-1] && c[i] >= c[i+1]) is a coin flip on a flat top */
 typedef struct oracle_posture_info { int32_t status, n_outline, n_segments, tail_index, head_index, n_traced; float peak_best, peak_runner_up, peak_margin; } oracle_posture_info;
 
-/* status: 0 ok, 1 empty blob/outline, 2 capacity, 3 no curvature peak, 4 too few midline segments, 5 refused (outline_approximate > 3 in the mirrored form) */
+/* status: 0 ok, 1 empty blob/outline, 2 capacity, 3 no curvature peak, 4 too few midline segments, 5 refused (outline_approximate > 15 in the mirrored form) */
 static int posture_impl(const oracle_run* runs, int32_t n_runs, int32_t origin_x, int32_t origin_y, const oracle_posture_params* P,
                         float* outline_xy, float* segments /* pos.x pos.y height l_length */, oracle_posture_info* info, const int naive) {
     memset(info, 0, sizeof(*info));
-    if (!naive && P->outline_approximate > 3) { info->status = 5; return 5; }      /* refuse like the device (posture.hip), never cap silently */
+    if (!naive && P->outline_approximate > 15) { info->status = 5; return 5; }     /* refuse like the device (posture.hip), never cap silently */
     if (n_runs <= 0) { info->status = 1; return 1; }
     const int cap = P->max_points;
     v2* A = (v2*)malloc((size_t)cap * sizeof(v2)); v2* B = (v2*)malloc((size_t)cap * sizeof(v2));

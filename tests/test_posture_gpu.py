@@ -434,11 +434,23 @@ def test_device_stays_next_to_the_naive_reading_of_the_eft():
     print("posture vs the naive EFT: %d blobs, %d with the same tail and head, curves within %.2g px" % (n, same, worst))
 
 
-def test_more_than_three_harmonics_are_refused_on_both_sides():
+@pytest.mark.parametrize("order", [4, 5, 9, 15])
+def test_more_than_three_harmonics(order):
+    """outline_approximate above three (a uint8_t without an upper bound in the reference, core/default_config.cpp:888): the device's general form
+    against the mirrored restatement -- equality, as for the default order -- on the synthetic individuals"""
+    fr, bg = synth.batch("C2", 2)
+    res, outline, segs, info = run_posture(fr, bg, outline_approximate=order)
+    n, _ = compare(res, outline, segs, info, oracle.posture_params(max_points=512, outline_approximate=order))
+    assert n >= 50
+
+
+def test_sixteen_harmonics_are_refused_on_both_sides():
     fr, bg = synth.batch("C2", 1)
     with pytest.raises(capi.TrexHipError):
-        run_posture(fr, bg, outline_approximate=4)
+        run_posture(fr, bg, outline_approximate=16)
+    with pytest.raises(capi.TrexHipError):
+        run_posture(fr, bg, outline_approximate=5, max_points=64)       # the coefficients of the general form need 66 floats of the curvature array
     r0 = oracle.segment(fr[0], bg, oracle.make_params(fr.shape[2], fr.shape[1]))
     b = r0[0][0]
     with pytest.raises(ValueError):
-        oracle.posture(r0[1][b["run_begin"]:b["run_begin"] + b["n_runs"]], (int(b["x0"]), int(b["y0"])), oracle.posture_params(max_points=512, outline_approximate=4))
+        oracle.posture(r0[1][b["run_begin"]:b["run_begin"] + b["n_runs"]], (int(b["x0"]), int(b["y0"])), oracle.posture_params(max_points=512, outline_approximate=16))

@@ -237,15 +237,24 @@ def test_mirrored_eft_stays_next_to_the_naive_reading():
     assert same >= 0.96 * n, (same, n)
 
 
-def test_mirrored_eft_refuses_more_than_three_harmonics_and_the_naive_one_takes_them():
+def test_more_harmonics_follow_the_outline_more_closely_and_sixteen_are_refused():
+    """`outline_approximate` is a uint8_t without an upper bound (core/default_config.cpp:888): the mirrored EFT takes up to 15 harmonics like the
+    device and refuses more; mirrored and naive readings stay together at every order."""
     rs, org = next(_synthetic_blobs(1))
     with pytest.raises(ValueError):
-        oracle.posture(rs, org, oracle.posture_params(max_points=512, outline_approximate=4))
-    lo = oracle.posture(rs, org, oracle.posture_params(max_points=512, outline_approximate=3), naive=True)[1]
-    hi = oracle.posture(rs, org, oracle.posture_params(max_points=512, outline_approximate=9), naive=True)[1]
-    raw = oracle.posture(rs, org, oracle.posture_params(max_points=512, outline_approximate=0), naive=True)[1]
-    assert len(lo) == len(hi) == len(raw)
-    # more harmonics follow the smoothed outline more closely (compared as point sets: the tail may sit elsewhere)
-    def dist(a, b):
+        oracle.posture(rs, org, oracle.posture_params(max_points=512, outline_approximate=16))
+    raw = oracle.posture(rs, org, oracle.posture_params(max_points=512, outline_approximate=0))[1]
+
+    def dist(a, b):             # compared as point sets: the tail may sit elsewhere
         return float(np.mean([np.min(np.linalg.norm(b - p, axis=1)) for p in a]))
-    assert dist(hi, raw) < dist(lo, raw)
+    last = None
+    for order in (3, 5, 9, 15):
+        pp = oracle.posture_params(max_points=512, outline_approximate=order)
+        m = oracle.posture(rs, org, pp)[1]
+        nv = oracle.posture(rs, org, pp, naive=True)[1]
+        assert len(m) == len(nv) == len(raw)
+        k = int(np.argmin(np.abs(nv - m[0]).sum(1)))
+        assert np.abs(np.roll(nv, -k, 0) - m).max() <= 2e-3, order
+        d = dist(m, raw)
+        assert last is None or d < last, (order, d, last)
+        last = d

@@ -382,7 +382,7 @@ __global__ __launch_bounds__(256) void k_posture(const PostureCfg P, const trexh
         const float T = s_t[n - 1];
         const float PI = 3.14159265358979323846f;
         float ca[4][4];                                           // [harmonic 1..3][a b c d]
-        const int order = min(P.approximate, 3);
+        const int order = P.approximate;                          // 1 .. 15 (the launch refuses more); up to three harmonics: the unrolled form below
         // cos / sin of the FIRST harmonic's phase at every segment boundary once (boundary i = the start of segment i = the end of segment i - 1;
         // boundary n closes the curve: it goes to the idle curvature array), kept in the spare point buffer.  Harmonics 2 and 3 follow by the angle
         // addition formulas (c2 = c1 c1 - s1 s1, s2 = 2 (s1 c1), c3 = c2 c1 - s2 s1, s3 = s2 c1 + c2 s1): one sin / cos per boundary instead of
@@ -394,7 +394,54 @@ __global__ __launch_bounds__(256) void k_posture(const PostureCfg P, const trexh
             else { s_curv[0] = cs; s_curv[1] = sn; }
         }
         __builtin_amdgcn_wave_barrier();
-        {
+        float* coef = s_curv + 2;                                 // more than three harmonics: [16][4] coefficients in the idle curvature array
+        if (order > 3) {
+            // `outline_approximate` is a uint8_t without an upper bound in the reference (core/default_config.cpp:888).  More than three harmonics
+            // take this general form: the SAME sums per harmonic (term i to partial i % 64, xor butterfly) and the SAME recurrence for the phases
+            // (h = 2 by the doubling form, h >= 3 from harmonic h - 1 by angle addition, always started at harmonic 1), three harmonics per sweep
+            // over the segments -- a sweep recomputes the recurrence up to its first harmonic, which gives the values a single sweep would have had.
+            const float csE = s_curv[0], snE = s_curv[1];
+            for (int hb = 1; hb <= order; hb += 3) {
+                float sa[3] = {0.f, 0.f, 0.f}, sb[3] = {0.f, 0.f, 0.f}, sc[3] = {0.f, 0.f, 0.f}, sd[3] = {0.f, 0.f, 0.f};
+                const int hl = min(order, hb + 2);
+                for (int i = lane; i < n; i += 64) {
+                    const float2 a = pts[i], q = pts[i + 1 == n ? 0 : i + 1];
+                    const float t0 = i > 0 ? s_t[i - 1] : 0.f, t1 = s_t[i];
+                    const float dt = t1 - t0;
+                    if (dt <= 0.f) continue;
+                    const float2 c0 = other[i], c1 = (i + 1 < n) ? other[i + 1] : make_float2(csE, snE);
+                    const float ddx = q.x - a.x, ddy = q.y - a.y;
+                    const float gx = ddx / dt, gy = ddy / dt;
+                    float c0h = c0.x, s0h = c0.y, c1h = c1.x, s1h = c1.y;
+                    for (int h = 1; h <= hl; ++h) {
+                        if (h > 1) {
+                            float cn, sn2;
+                            if (h == 2) { cn = c0.x * c0.x - c0.y * c0.y; sn2 = 2.0f * (c0.y * c0.x); } else { cn = c0h * c0.x - s0h * c0.y; sn2 = s0h * c0.x + c0h * c0.y; }
+                            c0h = cn; s0h = sn2;
+                            if (h == 2) { cn = c1.x * c1.x - c1.y * c1.y; sn2 = 2.0f * (c1.y * c1.x); } else { cn = c1h * c1.x - s1h * c1.y; sn2 = s1h * c1.x + c1h * c1.y; }
+                            c1h = cn; s1h = sn2;
+                        }
+                        if (h >= hb) {
+                            const float dc = c1h - c0h, ds = s1h - s0h;
+                            const float pa = gx * dc, pb = gx * ds, pc = gy * dc, pd = gy * ds;
+                            if (h == hb) { sa[0] += pa; sb[0] += pb; sc[0] += pc; sd[0] += pd; }
+                            else if (h == hb + 1) { sa[1] += pa; sb[1] += pb; sc[1] += pc; sd[1] += pd; }
+                            else { sa[2] += pa; sb[2] += pb; sc[2] += pc; sd[2] += pd; }
+                        }
+                    }
+                }
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    const int h = hb + k;
+                    if (h <= order) {
+                        const float kf = T / (2.0f * (float)(h * h) * PI * PI);
+                        const float va = kf * wsum(sa[k]), vb = kf * wsum(sb[k]), vc = kf * wsum(sc[k]), vd = kf * wsum(sd[k]);
+                        if (lane == 0) { coef[4 * h] = va; coef[4 * h + 1] = vb; coef[4 * h + 2] = vc; coef[4 * h + 3] = vd; }
+                    }
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+        } else {
             const float csE = s_curv[0], snE = s_curv[1];
             // term i goes to partial sum i % 64 in order of i, the partials are combined by the xor butterfly (wsum): the order the CPU restatement follows too
             float sa[4] = {0.f, 0.f, 0.f, 0.f}, sb[4] = {0.f, 0.f, 0.f, 0.f}, sc[4] = {0.f, 0.f, 0.f, 0.f}, sd[4] = {0.f, 0.f, 0.f, 0.f};
@@ -431,6 +478,24 @@ __global__ __launch_bounds__(256) void k_posture(const PostureCfg P, const trexh
             }
             __builtin_amdgcn_wave_barrier();
         }
+        if (order > 3) {
+            for (int i = lane; i < n; i += 64) {
+                const float tt = (float)i / (float)n;
+                float x = cx, y = cy;
+                float s1, c1;
+                det_sincosf(2.0f * PI * (float)1 * tt, s1, c1);
+                float ch = c1, sh = s1;
+                for (int h = 1; h <= order; ++h) {
+                    if (h > 1) {
+                        float cn, sn2;
+                        if (h == 2) { cn = c1 * c1 - s1 * s1; sn2 = 2.0f * (s1 * c1); } else { cn = ch * c1 - sh * s1; sn2 = sh * c1 + ch * s1; }
+                        ch = cn; sh = sn2;
+                    }
+                    x += coef[4 * h] * ch + coef[4 * h + 1] * sh; y += coef[4 * h + 2] * ch + coef[4 * h + 3] * sh;
+                }
+                other[i] = make_float2(x, y);
+            }
+        } else
         for (int i = lane; i < n; i += 64) {
             const float tt = (float)i / (float)n;
             float x = cx, y = cy;
@@ -792,7 +857,11 @@ extern "C" int trexhip_posture_device(trexhip_ctx* ctx, int32_t table, const tre
     if (pp->outline_smooth_samples < 0 || pp->outline_smooth_samples * (pp->outline_smooth_step > 0 ? pp->outline_smooth_step : 1) > 16 || pp->outline_smooth_step < 1) {
         set_error("trexhip_posture_device: outline_smooth_samples*outline_smooth_step must be <= 16"); return TREXHIP_E_UNSUPPORTED;
     }
-    if (pp->outline_approximate > 3) { set_error("trexhip_posture_device: outline_approximate > 3 is not supported"); return TREXHIP_E_UNSUPPORTED; }
+    // (outline_approximate is a uint8_t without an upper bound in the reference, core/default_config.cpp:888: up to 15 harmonics here; beyond three the
+    // general form of k_posture, whose [16][4] coefficients live in the curvature array -- 66 floats)
+    if (pp->outline_approximate > 15 || (pp->outline_approximate > 3 && pp->max_points < 128)) {
+        set_error("trexhip_posture_device: outline_approximate > 15 (or > 3 with max_points < 128) is not supported"); return TREXHIP_E_UNSUPPORTED;
+    }
     // settings whose arithmetic is not built (it lives in the un-vendored commons and nothing in the tree pins it): refuse
     if (pp->posture_closing_steps != 0) { set_error("trexhip_posture_device: posture_closing_steps > 0 is not implemented (closing inside pixel::threshold_get_biggest_blob, Posture.cpp:335)"); return TREXHIP_E_UNSUPPORTED; }
     if (pp->peak_mode != 0) { set_error("trexhip_posture_device: peak_mode = broad is not implemented (needs periodic::find_peaks' peak ranges / integrals, Outline.cpp:627-661); only pointy"); return TREXHIP_E_UNSUPPORTED; }
