@@ -430,3 +430,58 @@ def test_colour_tiles_on_the_device(channels, shape, shift):
     for r, g in zip(res, gray):
         assert_frame_equal(r, np.ascontiguousarray(g), bg, threshold=40)
     seg.close()
+
+
+@pytest.mark.parametrize("bands", [2, 3, 8])
+def test_several_workgroups_per_frame_give_the_same_tables(bands, monkeypatch):
+    """k_ccl_band (round 6): a frame's rows cut into bands labelled by their own workgroups, k_ccl_lds links the seams and goes on.  Forced here
+    (TREXHIP_CCL_BANDS; by itself the library bands only frames of more lines than the M instance holds, when the launch leaves CUs idle): blobs
+    that cross every seam, seams through empty rows, a frame whose band holds more lines than a band workgroup takes (it falls back to the one
+    workgroup per frame), 8- and 4-connectivity -- every table byte for byte the oracle's."""
+    monkeypatch.setenv("TREXHIP_CCL_BANDS", str(bands))
+    rng = np.random.default_rng(100 + bands)
+    W, H = 1024, 2048
+    bg = np.full((H, W), 120, np.uint8)
+    frames = []
+    f = bg.copy()                                                    # tall columns and diagonals through every seam
+    for x in range(20, 1000, 480):
+        f[int(rng.integers(0, 400)):int(rng.integers(1500, H)), x:x + int(rng.integers(1, 9))] = 10
+    for k in range(0, 400):
+        f[300 + k * 2:300 + k * 2 + 3, 40 + k:40 + k + 2] = 10       # a staircase: 8-connected only through its corners in places
+    frames.append(f)
+    f, _ = synth.random_scene(rng, W, H, density=0.018); frames.append(f)        # ~6000 lines: labelled in LDS, banded
+    f, _ = synth.random_scene(rng, W, H, density=0.05); frames.append(f)         # ~16000 lines: the global-memory chain (the band workgroups leave it alone)
+    f = bg.copy(); f[H // 2 - 3:H // 2 + 3, :] = 10; f[::2, 5:9] = 10; frames.append(f)       # a bar on the middle seam, single-line blobs everywhere
+    f = bg.copy()                                                    # ~5000 lines inside ONE band of rows: the band workgroup cannot hold them
+    for y in range(0, 250):
+        for j in range(20):
+            f[y, 10 + 50 * j:10 + 50 * j + 3 + (y % 7)] = 10
+    frames.append(f)
+    frames.append(bg.copy())                                         # an empty frame
+    for kw in (dict(), dict(connectivity=4)):
+        res = run_gpu(np.stack(frames), bg, max_runs=20000, max_blobs=16384, max_pixels=1 << 21, **kw)
+        for r, fr in zip(res, frames):
+            assert_frame_equal(r, fr, bg, **kw)
+    # odd frame heights: the last band is shorter, or there are fewer bands than asked for
+    for (w, h) in ((320, 129), (640, 1000), (4096, 300)):
+        fr, b2 = synth.random_scene(rng, w, h, density=0.08)
+        assert_frame_equal(run_gpu(fr[None], b2)[0], fr, b2)
+
+
+def test_heavy_frames_are_banded_from_the_second_call_on_and_stay_the_same():
+    """the automatic policy: a context whose frames carry more lines than the M instance holds (C5: 4096 x 4096, 256 individuals) bands them from
+    its second call on (the first call's kernels write the hint); the tables of call 1 (one workgroup per frame) and call 2 (banded) are the same"""
+    fr, bg = synth.batch("C5", 2)
+    n, H, W = fr.shape
+    seg = capi.Segmenter(capi.default_params(W, H, max_batch=n, max_blobs=1024, max_pixels=1 << 20, max_runs=32768))
+    seg.set_background(bg)
+    d = torch.from_numpy(fr).cuda()
+    sig = []
+    for _ in range(3):
+        seg.segment_device(d.data_ptr(), n)
+        res = seg.fetch()
+        assert all(r.info["flags"] == 0 and r.info["n_raw_runs"] > 3840 for r in res)
+        sig.append([(r.blobs.tobytes(), r.runs.tobytes(), r.pixels.tobytes()) for r in res])
+    assert sig[0] == sig[1] == sig[2]
+    assert_frame_equal(res[0], fr[0], bg)
+    seg.close()

@@ -186,6 +186,7 @@ int trexhip_create(const trexhip_params* p, trexhip_ctx** out) {
 #endif
     if (const char* e = std::getenv("TREXHIP_SEG_GROUPS")) ctx->tune_seg_groups = std::atoi(e);
     if (const char* e = std::getenv("TREXHIP_SEG_SCHEME")) ctx->tune_seg_scheme = std::atoi(e);
+    if (const char* e = std::getenv("TREXHIP_CCL_BANDS")) ctx->tune_ccl_bands = std::atoi(e);     // same tables whatever the bands
     if (const char* e = std::getenv("TREXHIP_CCL_INST")) ctx->tune_ccl_inst = std::atoi(e);      // which k_ccl_lds instance goes first: same results either way
     if (const char* e = std::getenv("TREXHIP_ROWS_BLOCKS")) { ctx->tune_rows_blocks = std::atoi(e) > 0 ? std::atoi(e) : 8192; ctx->tune_rows_blocks_set = true; }
     const size_t B = p->max_batch, H = p->height, W = p->width, R = p->max_runs, NB = p->max_blobs, P = p->max_pixels;
@@ -196,6 +197,8 @@ int trexhip_create(const trexhip_params* p, trexhip_ctx** out) {
     TRY(dmalloc(&ctx->d_bg, H * W + 16));
     TRY(dmalloc(&ctx->d_ctr, B * TREXHIP_CTR_STRIDE + 4));
     if (rc == TREXHIP_OK && hipMemset(ctx->d_ctr, 0, sizeof(uint32_t) * (B * TREXHIP_CTR_STRIDE + 4)) != hipSuccess) { set_error("hipMemset of the counters failed"); rc = TREXHIP_E_DEVICE; }   // every pass leaves the counters zero (launch_segment)
+    TRY(dmalloc(&ctx->d_band_fail, B));
+    if (rc == TREXHIP_OK && hipMemset(ctx->d_band_fail, 0, sizeof(uint32_t) * B) != hipSuccess) { set_error("hipMemset of the band flags failed"); rc = TREXHIP_E_DEVICE; }
     TRY(dmalloc(&ctx->d_row_cnt, B * H));
     TRY(dmalloc(&ctx->d_row_off, B * H));
     TRY(dmalloc(&ctx->d_row_base, B * (H + 1)));
@@ -237,7 +240,7 @@ void trexhip_destroy(trexhip_ctx* ctx) {
     if (ctx->stream) hipStreamSynchronize(ctx->stream);
     net_free(ctx);
     pass2_free(ctx);
-    void* dev[] = {ctx->d_bg, ctx->d_staging, ctx->d_ctr, ctx->d_row_cnt, ctx->d_row_off, ctx->d_row_base, ctx->d_tmp_runs,
+    void* dev[] = {ctx->d_bg, ctx->d_staging, ctx->d_ctr, ctx->d_band_fail, ctx->d_row_cnt, ctx->d_row_off, ctx->d_row_base, ctx->d_tmp_runs,
                    ctx->d_raster, ctx->d_parent, ctx->d_root_ord, ctx->d_cnt_runs, ctx->d_cnt_px, ctx->d_cur_run,
                    ctx->d_pix_begin, ctx->d_blob_map, ctx->d_info, ctx->d_blobs, ctx->d_blob_frame, ctx->d_runs, ctx->d_pixels, ctx->d_color, ctx->d_bits[0], ctx->d_bits[1], ctx->d_warp, ctx->d_bg_color, ctx->d_len, ctx->d_auto};
     for (void* p : dev) if (p) hipFree(p);

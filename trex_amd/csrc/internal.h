@@ -108,6 +108,7 @@ struct trexhip_ctx {
     uint8_t* d_staging = nullptr;       // frames uploaded by the host-pointer API
     const uint8_t* d_frames = nullptr;  // frames of the last segment call
     uint32_t* d_ctr = nullptr;          // [B*CTR_STRIDE] per-frame overflow counters (128 B apart) + [4] pooled totals
+    uint32_t* d_band_fail = nullptr;    // [B] a band of the frame held more lines than k_ccl_band's workgroup takes (k_ccl_lds reads and clears it)
     uint32_t* d_row_cnt = nullptr;      // [B*H]
     uint32_t* d_row_off = nullptr;      // [B*H]   offset of the row's runs in tmp order
     uint32_t* d_row_base = nullptr;     // [B*(H+1)] exclusive scan of row_cnt = raster index
@@ -169,6 +170,7 @@ struct trexhip_ctx {
     hipEvent_t ev_grp[10] = {};
     int tune_seg_scheme = 0;            // TREXHIP_SEG_SCHEME: how the groups use the two streams (launch_segment)
     int tune_ccl_stop = 0;              // dev only: stop k_ccl_lds after phase N (TREXHIP_CCL_STOP)
+    int tune_ccl_bands = -1;            // dev only: several workgroups per frame (TREXHIP_CCL_BANDS; -1 = by the frames per launch and the hint word, 0 never, n always n bands)
     int tune_ccl_inst = 0;              // dev only: the k_ccl_lds instance that goes first (TREXHIP_CCL_INST; 0 = by the hint words)
     uint32_t* h_ccl_hint = nullptr;     // [2] pinned, written by k_ccl_lds: a frame had more lines than the S / the M instance holds
     uint32_t ccl_calls = 0;

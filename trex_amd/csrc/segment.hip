@@ -872,6 +872,93 @@ __device__ __forceinline__ void gather_blobs(const SegCfg& c, const int only_pen
                                              const uint32_t bw0, const uint32_t bw_step, const uint32_t total,
                                              const int own_frame, const uint32_t own_run_begin, const uint32_t own_pix_begin);
 
+// ---------------------------------------------------------------------------------------------
+// k_ccl_band (round 6): SEVERAL workgroups per frame.  k_ccl_lds gives a frame one workgroup whatever the launch holds, so a launch of few
+// frames (C5: 64 frames of 6.4 k lines on 256 CUs; TRex's default call: ONE frame) leaves most of the chip idle while each workgroup walks
+// its whole frame through the two longest phases, runs into LDS and link.  Here a frame's rows are cut into bands: workgroup (frame, band)
+// loads the band's lines, links them among themselves (never across the band's first row) and writes lines and band-local roots -- as
+// frame-wide raster indices -- to the run-level tables.  k_ccl_lds then takes a frame in `banded` mode: instead of its phases 2 and 3 it
+// loads lines and parents, links the first row of every band with the row above it (the seams: a handful of lines) and goes on with its
+// flatten.  Roots are the smallest raster index of a component either way (lds_union), so every table comes out byte for byte the same.
+// A band with more lines than fit (CCLB_NMAX) raises the frame's word in `band_fail`: k_ccl_lds then labels that frame alone, as before.
+// ---------------------------------------------------------------------------------------------
+static constexpr int CCLB_NT = 512, CCLB_NMAX = 4096, CCLB_ROWS = 2048;
+static constexpr int CCLB_LDS_BYTES = (CCLB_ROWS + 1) * 4 + CCLB_NMAX * (4 + 4 + 2) + 64 * 4 + 16;
+__global__ __launch_bounds__(CCLB_NT) void k_ccl_band(const SegCfg c, const uint32_t* __restrict__ frame_ctr, const uint32_t* __restrict__ row_cnt,
+                                                      const uint32_t* __restrict__ row_off, const uint32_t* __restrict__ tmp_runs,
+                                                      trexhip_run* __restrict__ raster, uint32_t* __restrict__ parent, uint32_t* __restrict__ band_fail,
+                                                      const int n_bands, const int band_rows, const int f0) {
+    constexpr int NT = CCLB_NT;
+    extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+    uint32_t* s_key = smem;                           // [CCLB_ROWS + 1] band-local index of every row's first line
+    uint32_t* s_run = s_key + CCLB_ROWS + 1;
+    uint32_t* s_par = s_run + CCLB_NMAX;
+    uint32_t* s_misc = s_par + CCLB_NMAX;             // [64]
+    uint16_t* s_y = reinterpret_cast<uint16_t*>(s_misc + 64);
+    const int f = (int)blockIdx.x / n_bands + f0, band = (int)blockIdx.x % n_bands, tid = threadIdx.x;
+    const int H = c.H, y0 = band * band_rows, y1 = min(H, y0 + band_rows);
+    if (y0 >= H) return;
+    const uint32_t* cnt = row_cnt + (size_t)f * H;
+    const uint32_t* off = row_off + (size_t)f * H;
+    const uint32_t* tmp = tmp_runs + (size_t)f * c.T;
+    const size_t fo = (size_t)f * c.R;
+    // lines in front of the band (its frame-wide raster base) and in the frame
+    uint32_t sb = 0, sn = 0;
+    for (int y = tid; y < H; y += NT) { const uint32_t v = cnt[y]; sn += v; if (y < y0) sb += v; }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) { sb += (uint32_t)__shfl_xor((int)sb, d); sn += (uint32_t)__shfl_xor((int)sn, d); }
+    if ((tid & 63) == 0) { s_misc[32 + (tid >> 6)] = sb; s_misc[48 + (tid >> 6)] = sn; }
+    __syncthreads();
+    uint32_t base = 0, n = 0;
+#pragma unroll
+    for (int w = 0; w < NT / 64; ++w) { base += s_misc[32 + w]; n += s_misc[48 + w]; }
+    // what k_ccl_lds refuses (overflow of the run area, more lines than LDS holds) it refuses by itself: nothing to prepare, and no table to write into
+    if (n > (uint32_t)c.R || frame_ctr[f * CTR_STRIDE] > (uint32_t)c.R || n > (uint32_t)CCL_NMAX) return;
+    uint32_t nb = 0;
+    for (int ys = y0; ys < y1; ys += NT) {
+        const int y = ys + tid;
+        const uint32_t v = y < y1 ? cnt[y] : 0u;
+        uint32_t total;
+        const uint32_t ex = block_excl_scan(v, s_misc, total);
+        if (y < y1) s_key[y - y0] = nb + ex;
+        nb += total;
+    }
+    if (tid == 0) s_key[y1 - y0] = nb;
+    if (nb > (uint32_t)CCLB_NMAX) { if (tid == 0) atomicOr(band_fail + f, 1u); return; }
+    __syncthreads();
+    for (int y = y0 + tid; y < y1; y += NT) {
+        const uint32_t b = s_key[y - y0], k = s_key[y - y0 + 1] - b;
+        if (!k) continue;
+        const uint32_t o = off[y];
+        for (uint32_t i = 0; i < k; ++i) { s_run[b + i] = tmp[o + i]; s_y[b + i] = (uint16_t)y; s_par[b + i] = b + i; }
+    }
+    __syncthreads();
+    const int slack = c.slack;
+    for (uint32_t r = tid; r < nb; r += NT) {
+        const int y = s_y[r];
+        if (y == y0) continue;                             // the band's first row: its row above belongs to another workgroup (the seam)
+        uint32_t lo = s_key[y - 1 - y0];
+        const uint32_t je = s_key[y - y0];
+        if (lo >= je) continue;
+        const uint32_t cur = s_run[r];
+        const int c0 = cur & 0xffffu, c1 = cur >> 16;
+        uint32_t hi = je;
+        while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if ((int)(s_run[mid] >> 16) + slack >= c0) hi = mid; else lo = mid + 1; }
+        for (uint32_t j = lo; j < je; ++j) {
+            const uint32_t prv = s_run[j];
+            if ((int)(prv & 0xffffu) > c1 + slack) break;
+            lds_union(s_par, j, r);
+        }
+    }
+    __syncthreads();
+    for (uint32_t r = tid; r < nb; r += NT) {
+        const uint32_t root = lds_find(s_par, r);          // (path halving beside it only ever moves parents towards their root)
+        parent[fo + base + r] = base + root;
+        trexhip_run q; q.x0 = (uint16_t)(s_run[r] & 0xffffu); q.x1 = (uint16_t)(s_run[r] >> 16); q.y = s_y[r]; q.pad = 0;
+        raster[fo + base + r] = q;
+    }
+}
+
 template <int NT, int NMAX, int SA>
 __global__ __launch_bounds__(NT) void k_ccl_lds(const SegCfg c, uint32_t* __restrict__ frame_ctr,
                                                   const uint32_t* __restrict__ row_cnt, const uint32_t* __restrict__ row_off,
@@ -886,7 +973,9 @@ __global__ __launch_bounds__(NT) void k_ccl_lds(const SegCfg c, uint32_t* __rest
                                                   const uint8_t* __restrict__ own_frames /* gray frames: the workgroup also gathers its frame's blobs; else null */,
                                                   uint8_t* __restrict__ own_pixels,
                                                   const int retry_only /* 1: only the frames a smaller instance left for this one */,
-                                                  uint32_t* __restrict__ hint /* pinned host words: [0] a frame had more lines than S holds, [1] than M holds */) {
+                                                  uint32_t* __restrict__ hint /* pinned host words: [0] a frame had more lines than S holds, [1] than M holds */,
+                                                  const int band_rows /* > 0: k_ccl_band has prepared the frames in bands of this many rows */,
+                                                  uint32_t* __restrict__ band_fail) {
     static_assert(NT % 64 == 0 && NT <= 1024 && (SA & (SA - 1)) == 0 && SA >= NMAX && SA % NT == 0 && NMAX <= CCL_NMAX, "k_ccl_lds: geometry");
     constexpr int NW = NT / 64;                   // waves
     constexpr int NSW = NT >= 1024 ? 2 : 4;       // row sweeps whose count / offset / raster index / first run stay in registers
@@ -973,10 +1062,38 @@ __global__ __launch_bounds__(NT) void k_ccl_lds(const SegCfg c, uint32_t* __rest
         }
         return;
     }
-    if (tid == 0) { rb[H] = n; if (rb_lds) s_key[H] = n; }
+    if (tid == 0) {
+        rb[H] = n; if (rb_lds) s_key[H] = n;
+        if (band_rows > 0) { s_misc[61] = band_fail[f]; band_fail[f] = 0u; }      // a band of this frame did not fit its workgroup: label the frame here after all
+    }
     __syncthreads();
     CCL_STOP(1);
     CCL_STAMP(1);
+    const int slack = c.slack;
+    if (band_rows > 0 && s_misc[61] == 0u) {
+        // banded (k_ccl_band): lines and band-local roots come from the run-level tables, only the seams are left to link
+        for (uint32_t r = tid; r < n; r += NT) {
+            const uint2 q = *reinterpret_cast<const uint2*>(raster + fo + r);      // x0 | x1 << 16, y | pad << 16
+            s_run[r] = q.x; s_y[r] = (uint16_t)(q.y & 0xffffu); s_par[r] = parent[fo + r];
+        }
+        __syncthreads();
+        for (int yb = band_rows; yb < H; yb += band_rows) {
+            uint32_t lo0 = rb_lds ? s_key[yb - 1] : rb[yb - 1];
+            const uint32_t je = rb_lds ? s_key[yb] : rb[yb], re = rb_lds ? s_key[yb + 1] : rb[yb + 1];
+            if (lo0 >= je) continue;
+            for (uint32_t r = je + tid; r < re; r += NT) {
+                const uint32_t cur = s_run[r];
+                const int c0 = cur & 0xffffu, c1 = cur >> 16;
+                uint32_t lo = lo0, hi = je;
+                while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if ((int)(s_run[mid] >> 16) + slack >= c0) hi = mid; else lo = mid + 1; }
+                for (uint32_t j = lo; j < je; ++j) {
+                    const uint32_t prv = s_run[j];
+                    if ((int)(prv & 0xffffu) > c1 + slack) break;
+                    lds_union(s_par, j, r);
+                }
+            }
+        }
+    } else {
     // P2: runs into LDS in raster order
 #pragma unroll
     for (int j = 0; j < NSW; ++j) {
@@ -997,7 +1114,6 @@ __global__ __launch_bounds__(NT) void k_ccl_lds(const SegCfg c, uint32_t* __rest
     CCL_STOP(2);
     CCL_STAMP(2);
     // P3: link every run with the touching runs of the row above (thread per run, binary search for the first candidate)
-    const int slack = c.slack;
     for (uint32_t r = tid; r < n; r += NT) {
         const int y = s_y[r];
         if (y == 0) continue;
@@ -1013,6 +1129,7 @@ __global__ __launch_bounds__(NT) void k_ccl_lds(const SegCfg c, uint32_t* __rest
             if ((int)(prv & 0xffffu) > c1 + slack) break;
             lds_union(s_par, j, r);
         }
+    }
     }
     __syncthreads();
     CCL_STOP(3);
@@ -1574,6 +1691,7 @@ int launch_segment(trexhip_ctx* ctx, const uint8_t* d_frames, int n) {
         TH_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ccl_lds<1024, CCL_NMAX, CCL_SORT>), hipFuncAttributeMaxDynamicSharedMemorySize, CCL_LDS_BYTES));
         TH_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ccl_lds<512, CCL_M_NMAX, CCL_M_SA>), hipFuncAttributeMaxDynamicSharedMemorySize, LdsM::BYTES));
         TH_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ccl_lds<256, CCL_S_NMAX, CCL_S_SA>), hipFuncAttributeMaxDynamicSharedMemorySize, LdsS::BYTES));
+        TH_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_ccl_band), hipFuncAttributeMaxDynamicSharedMemorySize, CCLB_LDS_BYTES));
         ctx->attr_ccl = true;
     }
     // Which instance of k_ccl_lds goes first (see the table above the kernel).  Measured in round 6 (profiles/r06_ccl_by_capacity.txt): with one frame
@@ -1585,10 +1703,10 @@ int launch_segment(trexhip_ctx* ctx, const uint8_t* d_frames, int n) {
     // call the words are cleared, so a context whose frames got emptier finds its way back down.
     // TREXHIP_CCL_INST (dev): 1 S, 2 M, 3 L.  (M with 1024 threads and S with 512 were measured too: profiles/r06_ccl_by_capacity.txt, variants 4 and 5.)
     int inst = ctx->tune_ccl_inst;
+    if ((++ctx->ccl_calls & 63) == 0) { ctx->h_ccl_hint[0] = 0u; ctx->h_ccl_hint[1] = 0u; }
     if (inst <= 0) {
         inst = 3;
         if (n >= 2 * ctx->n_cus) {
-            if ((++ctx->ccl_calls & 63) == 0) { ctx->h_ccl_hint[0] = 0u; ctx->h_ccl_hint[1] = 0u; }
             const uint32_t over_s = __atomic_load_n(&ctx->h_ccl_hint[0], __ATOMIC_RELAXED), over_m = __atomic_load_n(&ctx->h_ccl_hint[1], __ATOMIC_RELAXED);
             inst = over_m ? 3 : (over_s ? 2 : 1);
             if (c.R <= CCL_S_NMAX) inst = 1; else if (c.R <= CCL_M_NMAX && inst > 2) inst = 2;     // max_runs itself bounds the lines of a frame
@@ -1680,10 +1798,28 @@ int launch_segment(trexhip_ctx* ctx, const uint8_t* d_frames, int n) {
         } else if (G > 1 && scheme == 1 && g + 1 < G) TH_CHECK_HIP(hipEventRecord(ctx->ev_grp[g], s));
         // run-level CCL of every frame inside one workgroup's LDS; frames with too many runs are left pending
         // and finished by the global-memory chain in finish_segment()
+        // several workgroups per frame (k_ccl_band) when the launch leaves CUs idle AND the frames are heavy: bands of at most CCLB_ROWS rows, as many as
+        // there are CUs per frame (at most 8), none of fewer than 64 rows.  The extra launch + the reload cost ~10 us and save phases 2 and 3 of
+        // k_ccl_lds: 29 us for a 4096 x 4096 frame of 6.4 k lines, 10 us for a 2048 x 2048 frame of 2.5 k, 2 us for C2 -- measured (us per pass, one
+        // workgroup per frame / banded): C5 64 frames 325 / 313, 16 frames 133 / 119; C4 one frame 38.9 / 41.9, 64 frames 95 / 100; C2 one frame 23 / 34.
+        // So: only for frames of more lines than the M instance holds (the pinned hint word the kernels of the context's earlier calls wrote).
+        // TREXHIP_CCL_BANDS (dev, read at trexhip_create): 0 never, n >= 2 always n bands.  Same tables either way (tests/test_segment_gpu.py).
+        int n_bands = 1;
+        if (inst == 3) {
+            int want = ctx->tune_ccl_bands >= 0 ? ctx->tune_ccl_bands
+                                                : ((2 * (f1 - f0) <= ctx->n_cus && __atomic_load_n(&ctx->h_ccl_hint[1], __ATOMIC_RELAXED)) ? ctx->n_cus / (f1 - f0) : 0);
+            if (want > 8) want = 8;
+            while (want > 1 && (H + want - 1) / want < 64) --want;
+            if (want >= 2 && (H + want - 1) / want <= CCLB_ROWS) n_bands = want;
+        }
+        const int band_rows = n_bands > 1 ? (H + n_bands - 1) / n_bands : 0;
+        if (n_bands > 1)
+            hipLaunchKernelGGL(k_ccl_band, dim3((f1 - f0) * n_bands), dim3(CCLB_NT), CCLB_LDS_BYTES, t, c, ctx->d_ctr, ctx->d_row_cnt, ctx->d_row_off, ctx->d_tmp_runs,
+                               ctx->d_raster, ctx->d_parent, ctx->d_band_fail, n_bands, band_rows, f0);
 #define TH_CCL(NT_, NMAX_, SA_, RETRY_) hipLaunchKernelGGL((k_ccl_lds<NT_, NMAX_, SA_>), dim3(f1 - f0), dim3(NT_), (CclLds<NMAX_, SA_>::BYTES), t, c, ctx->d_ctr, ctx->d_row_cnt, ctx->d_row_off, ctx->d_row_base, \
                            ctx->d_tmp_runs, ctx->d_raster, ctx->d_parent, ctx->d_root_ord, ctx->d_cur_run, ctx->d_pix_begin, ctx->d_blob_map,                           \
                            totals, ctx->d_info, ctx->d_blobs, ctx->d_blob_frame, ctx->d_runs, ctx->tune_ccl_stop, reinterpret_cast<unsigned long long*>(ctx->d_cnt_px), f0, \
-                           fuse_gather ? d_frames : (const uint8_t*)nullptr, ctx->d_pixels, RETRY_, ctx->h_ccl_hint)
+                           fuse_gather ? d_frames : (const uint8_t*)nullptr, ctx->d_pixels, RETRY_, ctx->h_ccl_hint, (NT_) == 1024 && (NMAX_) == CCL_NMAX && !(RETRY_) ? band_rows : 0, ctx->d_band_fail)
         switch (inst) {
             case 1: TH_CCL(256, CCL_S_NMAX, CCL_S_SA, 0); break;
             case 2: TH_CCL(512, CCL_M_NMAX, CCL_M_SA, 0); break;
