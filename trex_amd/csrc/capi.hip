@@ -177,7 +177,7 @@ int trexhip_create(const trexhip_params* p, trexhip_ctx** out) {
     { int cus = 0; if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, p->device) == hipSuccess && cus > 0) ctx->n_cus = cus; }
     // tuning knobs of the default build only choose between schedules / tilings that give identical results.  The knobs that
     // stop a kernel half-way or skip work (profiling aids) exist only in a -DTREXHIP_DEV_KNOBS build.
-    if (const char* e = std::getenv("TREXHIP_ROWS_ORDER")) ctx->tune_rows_order = std::atoi(e) & (1 | 4 | 1024 | 2048);
+    if (const char* e = std::getenv("TREXHIP_ROWS_ORDER")) ctx->tune_rows_order = std::atoi(e) & (1 | 4 | 8 | 1024 | 2048);
     if (const char* e = std::getenv("TREXHIP_ROWS_K")) ctx->tune_rows_k = std::atoi(e);
     if (const char* e = std::getenv("TREXHIP_CONV_GEOM")) ctx->tune_conv_geom = std::atoi(e);
 #ifdef TREXHIP_DEV_KNOBS

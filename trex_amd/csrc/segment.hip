@@ -498,15 +498,33 @@ __global__ __launch_bounds__(256) void k_rows32b(const uint8_t* __restrict__ fra
 #pragma unroll
         for (int ch = 0; ch < NCH; ++ch) {
             const int x = ch * 2048 + lane * 32;
-            if (x < W) { a[ch][0] = *reinterpret_cast<const uint4*>(fp + x); a[ch][1] = *reinterpret_cast<const uint4*>(fp + x + 16); }
-            else a[ch][0] = a[ch][1] = make_uint4(0, 0, 0, 0);
+            if constexpr (NCH == 1) {
+                if (x < W) { a[ch][0] = *reinterpret_cast<const uint4*>(fp + x); a[ch][1] = *reinterpret_cast<const uint4*>(fp + x + 16); }
+                else a[ch][0] = a[ch][1] = make_uint4(0, 0, 0, 0);
+            } else {
+                // (several chunks: hipcc 7.2 crashes -- Machine Copy Propagation, or Post-RA pseudo expansion -- on the conditional 128-bit assignments
+                // above; a clamped load and a word mask say the same)
+                const int xs = x < W ? x : 0;
+                const uint32_t km = x < W ? 0xffffffffu : 0u;
+                uint4 v0 = *reinterpret_cast<const uint4*>(fp + xs), v1 = *reinterpret_cast<const uint4*>(fp + xs + 16);
+                v0.x &= km; v0.y &= km; v0.z &= km; v0.w &= km; v1.x &= km; v1.y &= km; v1.z &= km; v1.w &= km;
+                a[ch][0] = v0; a[ch][1] = v1;
+            }
         }
     };
 #pragma unroll
     for (int ch = 0; ch < NCH; ++ch) {
         const int x = ch * 2048 + lane * 32;
-        if (x < W) { b[ch][0] = *reinterpret_cast<const uint4*>(bp + x); b[ch][1] = *reinterpret_cast<const uint4*>(bp + x + 16); }
-        else b[ch][0] = b[ch][1] = make_uint4(0, 0, 0, 0);
+        if constexpr (NCH == 1) {
+            if (x < W) { b[ch][0] = *reinterpret_cast<const uint4*>(bp + x); b[ch][1] = *reinterpret_cast<const uint4*>(bp + x + 16); }
+            else b[ch][0] = b[ch][1] = make_uint4(0, 0, 0, 0);
+        } else {
+            const int xs = x < W ? x : 0;
+            const uint32_t km = x < W ? 0xffffffffu : 0u;
+            uint4 v0 = *reinterpret_cast<const uint4*>(bp + xs), v1 = *reinterpret_cast<const uint4*>(bp + xs + 16);
+            v0.x &= km; v0.y &= km; v0.z &= km; v0.w &= km; v1.x &= km; v1.y &= km; v1.z &= km; v1.w &= km;
+            b[ch][0] = v0; b[ch][1] = v1;
+        }
     }
     issue(fb);
     for (int k = 0; k < K; ++k) {
@@ -1773,8 +1791,10 @@ int launch_segment(trexhip_ctx* ctx, const uint8_t* d_frames, int n) {
             int K = 0;
             if (!(ctx->tune_rows_order & 4)) { const int want = ctx->tune_rows_k > 0 ? ctx->tune_rows_k : 8; for (int k = want; k >= 2; --k) if (cg.B % k == 0) { K = k; break; } }
             const dim3 grid_b(K ? (unsigned)(((size_t)H * (cg.B / K) + 3) / 4) : 1u);
-            // (k_rows32b is instantiated for one 2048-pixel chunk only: hipcc 7.2 crashes in Machine Copy Propagation on the 2-chunk form)
+            // (k_rows32b for one and, since round 6, two 2048-pixel chunks: the two-chunk form needed its loads written without conditional 128-bit
+            // assignments, on which hipcc 7.2 crashes; TREXHIP_ROWS_ORDER bit 3 keeps k_rows32 for two chunks)
 #define TH_ROWS32(NCH_, MODE_) do { if (K && NCH_ == 1) hipLaunchKernelGGL((k_rows32b<1, MODE_>), grid_b, dim3(256), 0, s, d_frames, ctx->d_bg, cg, order_bits, K, ctx->d_ctr, ctx->d_row_cnt, ctx->d_row_off, ctx->d_tmp_runs, (uint32_t)f0); \
+                                    else if (K && NCH_ == 2 && !(ctx->tune_rows_order & 8)) hipLaunchKernelGGL((k_rows32b<2, MODE_>), grid_b, dim3(256), 0, s, d_frames, ctx->d_bg, cg, order_bits, K, ctx->d_ctr, ctx->d_row_cnt, ctx->d_row_off, ctx->d_tmp_runs, (uint32_t)f0); \
                                     else hipLaunchKernelGGL((k_rows32<NCH_, MODE_>), grid_g, dim3(256), 0, s, d_frames, ctx->d_bg, cg, order_bits, ctx->d_ctr, ctx->d_row_cnt, ctx->d_row_off, ctx->d_tmp_runs, (uint32_t)f0); } while (0)
 #define TH_ROWS32_M(NCH_) do { switch (mode) { case 1: TH_ROWS32(NCH_, 1); break; case 2: TH_ROWS32(NCH_, 2); break; case 5: TH_ROWS32(NCH_, 5); break; \
                                                case 6: TH_ROWS32(NCH_, 6); break; default: TH_ROWS32(NCH_, 0); } } while (0)
