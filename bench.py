@@ -407,7 +407,7 @@ def measure(args, env):
     rows_traffic = pmc_traffic("trexhip::k_rows")
     pass_traffic = None
     if rows_traffic is not None:
-        others = [pmc_traffic("trexhip::k_ccl_lds"), pmc_traffic("trexhip::k_gather")]
+        others = [pmc_traffic("trexhip::k_ccl_lds"), pmc_traffic("trexhip::k_ccl_band"), pmc_traffic("trexhip::k_gather")]
         pass_traffic = rows_traffic + sum(x for x in others if x)
     # The primary fraction is by the HBM bytes the counters saw (the background is re-read from L2 / MALL, not from HBM); the fraction by
     # the contract's algorithmic bytes (frame + background per pixel) is kept beside it and can pass 1 for that reason.

@@ -861,6 +861,14 @@ static_assert(CCL_LDS_BYTES <= 160 * 1024, "k_ccl_lds: LDS");
 static constexpr int CCL_M_NMAX = 3840, CCL_M_SA = 4096, CCL_S_NMAX = 2000, CCL_S_SA = 2048;
 static_assert(2 * CclLds<CCL_M_NMAX, CCL_M_SA>::BYTES <= 160 * 1024 && 4 * CclLds<CCL_S_NMAX, CCL_S_SA>::BYTES <= 160 * 1024, "k_ccl_lds: LDS of the small instances");
 
+// lane ^ D exchange for the sorting networks of k_ccl_lds: DPP quad permutes for D = 1, 2 (no LDS crossbar trip, no address register), ds_swizzle with an
+// immediate pattern for 4 .. 16, a permute only across the halves
+template <int D> __device__ __forceinline__ uint32_t ccl_xchg(uint32_t v) {
+    if constexpr (D == 1) return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xf, 0xf, true);        // quad_perm [1, 0, 3, 2]
+    else if constexpr (D == 2) return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xf, 0xf, true);   // quad_perm [2, 3, 0, 1]
+    else if constexpr (D < 32) return (uint32_t)__builtin_amdgcn_ds_swizzle((int)v, (D << 10) | 0x1f);
+    else return (uint32_t)__shfl_xor((int)v, D);
+}
 __device__ __forceinline__ uint32_t lds_find(volatile uint32_t* par, uint32_t a) {
     uint32_t p = par[a];
     while (p != a) {
@@ -903,7 +911,7 @@ __device__ __forceinline__ void gather_blobs(const SegCfg& c, const int only_pen
 static constexpr int CCLB_NT = 512, CCLB_NMAX = 4096, CCLB_ROWS = 2048;
 static constexpr int CCLB_LDS_BYTES = (CCLB_ROWS + 1) * 4 + CCLB_NMAX * (4 + 4 + 2) + 64 * 4 + 16;
 __global__ __launch_bounds__(CCLB_NT) void k_ccl_band(const SegCfg c, const uint32_t* __restrict__ frame_ctr, const uint32_t* __restrict__ row_cnt,
-                                                      const uint32_t* __restrict__ row_off, const uint32_t* __restrict__ tmp_runs,
+                                                      const uint32_t* __restrict__ row_off, uint32_t* __restrict__ row_base, const uint32_t* __restrict__ tmp_runs,
                                                       trexhip_run* __restrict__ raster, uint32_t* __restrict__ parent, uint32_t* __restrict__ band_fail,
                                                       const int n_bands, const int band_rows, const int f0) {
     constexpr int NT = CCLB_NT;
@@ -930,18 +938,20 @@ __global__ __launch_bounds__(CCLB_NT) void k_ccl_band(const SegCfg c, const uint
     uint32_t base = 0, n = 0;
 #pragma unroll
     for (int w = 0; w < NT / 64; ++w) { base += s_misc[32 + w]; n += s_misc[48 + w]; }
-    // what k_ccl_lds refuses (overflow of the run area, more lines than LDS holds) it refuses by itself: nothing to prepare, and no table to write into
-    if (n > (uint32_t)c.R || frame_ctr[f * CTR_STRIDE] > (uint32_t)c.R || n > (uint32_t)CCL_NMAX) return;
+    // what k_ccl_lds refuses (overflow of the run area, more lines than LDS holds) it refuses by itself: nothing to prepare, and no table to write into.
+    // Bit 1 of the frame's word tells it that nothing was prepared (it then scans the rows itself and finds the same)
+    if (n > (uint32_t)c.R || frame_ctr[f * CTR_STRIDE] > (uint32_t)c.R || n > (uint32_t)CCL_NMAX) { if (tid == 0) atomicOr(band_fail + f, 2u); return; }
+    uint32_t* rb = row_base + (size_t)f * (H + 1);
     uint32_t nb = 0;
     for (int ys = y0; ys < y1; ys += NT) {
         const int y = ys + tid;
         const uint32_t v = y < y1 ? cnt[y] : 0u;
         uint32_t total;
         const uint32_t ex = block_excl_scan(v, s_misc, total);
-        if (y < y1) s_key[y - y0] = nb + ex;
+        if (y < y1) { s_key[y - y0] = nb + ex; rb[y] = base + nb + ex; }      // the frame-wide raster index of the row: k_ccl_lds takes it from here instead of scanning again
         nb += total;
     }
-    if (tid == 0) s_key[y1 - y0] = nb;
+    if (tid == 0) { s_key[y1 - y0] = nb; if (y1 == H) rb[H] = n; }
     if (nb > (uint32_t)CCLB_NMAX) { if (tid == 0) atomicOr(band_fail + f, 1u); return; }
     __syncthreads();
     for (int y = y0 + tid; y < y1; y += NT) {
@@ -1024,13 +1034,27 @@ __global__ __launch_bounds__(NT) void k_ccl_lds(const SegCfg c, uint32_t* __rest
     if (retry_only && info[f].reserved[0] != 3u) return;      // (block-uniform: every thread reads the same word) the frame was finished by a smaller instance
     // the frame's overflow-area counter: thread 0 reads it and hands it back zeroed for the next pass (every path: a frame left pending for the
     // global-memory chain did not overflow, and that chain's own check then reads 0)
-    if (tid == 0) { s_misc[60] = frame_ctr[f * CTR_STRIDE]; frame_ctr[f * CTR_STRIDE] = 0u; }
+    if (tid == 0) {
+        s_misc[60] = frame_ctr[f * CTR_STRIDE]; frame_ctr[f * CTR_STRIDE] = 0u;
+        // banded (k_ccl_band ran in front): the frame's word is 0 when every band workgroup prepared its rows -- lines, band-local roots AND the rows'
+        // raster indices are in the run-level tables; else (a band held too many lines, or the frame is one this kernel refuses) the frame is labelled here
+        if (band_rows > 0) { s_misc[61] = band_fail[f]; band_fail[f] = 0u; }
+    }
+    const bool rb_lds = H < SA;              // row_base also lives in LDS (s_key is idle until P4)
+    bool banded = false;
+    if (band_rows > 0) { __syncthreads(); banded = s_misc[61] == 0u; }
     // P1: raster index of every row
     // (the rows of the first two sweeps -- every row of a frame up to 2048 lines -- keep their count, run offset, raster index and FIRST run in
     // registers: the offset and the run are fetched while the scan's barriers pass, and P2 starts without a global round trip)
     const uint32_t* tmp = tmp_runs + (size_t)f * c.T;
     uint32_t n = 0;
     uint32_t pk[NSW], po[NSW], pbase[NSW], pt[NSW];
+    if (banded) {
+#pragma unroll
+        for (int j = 0; j < NSW; ++j) { pk[j] = 0u; po[j] = 0u; pbase[j] = 0u; pt[j] = 0u; }
+        n = rb[H];
+        if (rb_lds) for (int y = tid; y < H; y += NT) s_key[y] = rb[y];
+    } else {
     {
         // every sweep's loads first (one round trip for the counts and offsets, one for the first runs), then the scans
         // (a frame whose run area overflowed carries offsets past its T words -- only the rows kernels' WRITES are bounded; such a frame is
@@ -1063,7 +1087,7 @@ __global__ __launch_bounds__(NT) void k_ccl_lds(const SegCfg c, uint32_t* __rest
         if (y < H) { rb[y] = n + ex; if (y < SA - 1) s_key[y] = n + ex; }
         n += total;
     }
-    const bool rb_lds = H < SA;              // row_base also lives in LDS (s_key is idle until P4)
+    }
     trexhip_frame_info fi = {};
     fi.n_raw_runs = n;
     const bool overflow = n > (uint32_t)c.R || s_misc[60] > (uint32_t)c.R;       // (behind the barriers of the scans above)
@@ -1080,15 +1104,12 @@ __global__ __launch_bounds__(NT) void k_ccl_lds(const SegCfg c, uint32_t* __rest
         }
         return;
     }
-    if (tid == 0) {
-        rb[H] = n; if (rb_lds) s_key[H] = n;
-        if (band_rows > 0) { s_misc[61] = band_fail[f]; band_fail[f] = 0u; }      // a band of this frame did not fit its workgroup: label the frame here after all
-    }
+    if (tid == 0) { rb[H] = n; if (rb_lds) s_key[H] = n; }
     __syncthreads();
     CCL_STOP(1);
     CCL_STAMP(1);
     const int slack = c.slack;
-    if (band_rows > 0 && s_misc[61] == 0u) {
+    if (banded) {
         // banded (k_ccl_band): lines and band-local roots come from the run-level tables, only the seams are left to link
         for (uint32_t r = tid; r < n; r += NT) {
             const uint2 q = *reinterpret_cast<const uint2*>(raster + fo + r);      // x0 | x1 << 16, y | pad << 16
@@ -1278,7 +1299,7 @@ __global__ __launch_bounds__(NT) void k_ccl_lds(const SegCfg c, uint32_t* __rest
         // (2) an in-register bitonic network per blob -- two blobs per wave (32 lanes each) when both have at most 32 lines, one per wave
         //     up to 64 lines, rank-by-counting through LDS beyond that.  The waves walk the RAW ordinals; a dropped blob counts 0 lines
         const uint32_t lane = tid & 63, wave = tid >> 6;
-#define CCL_SORT_STEP(kk_, jj_) { const uint32_t o_ = (uint32_t)__shfl_xor((int)v, jj_); const bool lo_ = ((lane & (jj_)) == 0) == ((lane & (kk_)) == 0); v = lo_ ? min(v, o_) : max(v, o_); }
+#define CCL_SORT_STEP(kk_, jj_) { const uint32_t o_ = ccl_xchg<jj_>(v); const bool lo_ = ((lane & (jj_)) == 0) == ((lane & (kk_)) == 0); v = lo_ ? min(v, o_) : max(v, o_); }
 #define CCL_SORT32(v)                                                                                                   \
         CCL_SORT_STEP(2, 1) CCL_SORT_STEP(4, 2) CCL_SORT_STEP(4, 1) CCL_SORT_STEP(8, 4) CCL_SORT_STEP(8, 2) CCL_SORT_STEP(8, 1)    \
         CCL_SORT_STEP(16, 8) CCL_SORT_STEP(16, 4) CCL_SORT_STEP(16, 2) CCL_SORT_STEP(16, 1)                                        \
@@ -1300,11 +1321,11 @@ __global__ __launch_bounds__(NT) void k_ccl_lds(const SegCfg c, uint32_t* __rest
                 // lanes 32..63 sort ascending as well: the direction bit of the last stage (lane & 32) is flipped for them
                 CCL_SORT_STEP(2, 1) CCL_SORT_STEP(4, 2) CCL_SORT_STEP(4, 1) CCL_SORT_STEP(8, 4) CCL_SORT_STEP(8, 2) CCL_SORT_STEP(8, 1)
                 CCL_SORT_STEP(16, 8) CCL_SORT_STEP(16, 4) CCL_SORT_STEP(16, 2) CCL_SORT_STEP(16, 1)
-                { const uint32_t o_ = (uint32_t)__shfl_xor((int)v, 16); v = (lane & 16) == 0 ? min(v, o_) : max(v, o_); }
-                { const uint32_t o_ = (uint32_t)__shfl_xor((int)v, 8);  v = (lane & 8) == 0 ? min(v, o_) : max(v, o_); }
-                { const uint32_t o_ = (uint32_t)__shfl_xor((int)v, 4);  v = (lane & 4) == 0 ? min(v, o_) : max(v, o_); }
-                { const uint32_t o_ = (uint32_t)__shfl_xor((int)v, 2);  v = (lane & 2) == 0 ? min(v, o_) : max(v, o_); }
-                { const uint32_t o_ = (uint32_t)__shfl_xor((int)v, 1);  v = (lane & 1) == 0 ? min(v, o_) : max(v, o_); }
+                { const uint32_t o_ = ccl_xchg<16>(v); v = (lane & 16) == 0 ? min(v, o_) : max(v, o_); }
+                { const uint32_t o_ = ccl_xchg<8>(v);  v = (lane & 8) == 0 ? min(v, o_) : max(v, o_); }
+                { const uint32_t o_ = ccl_xchg<4>(v);  v = (lane & 4) == 0 ? min(v, o_) : max(v, o_); }
+                { const uint32_t o_ = ccl_xchg<2>(v);  v = (lane & 2) == 0 ? min(v, o_) : max(v, o_); }
+                { const uint32_t o_ = ccl_xchg<1>(v);  v = (lane & 1) == 0 ? min(v, o_) : max(v, o_); }
                 emit(beg, e, cntk, v);
             } else {
                 for (uint32_t k = k0; k < k0 + 2 && k < nraw; ++k) {
@@ -1834,7 +1855,7 @@ int launch_segment(trexhip_ctx* ctx, const uint8_t* d_frames, int n) {
         }
         const int band_rows = n_bands > 1 ? (H + n_bands - 1) / n_bands : 0;
         if (n_bands > 1)
-            hipLaunchKernelGGL(k_ccl_band, dim3((f1 - f0) * n_bands), dim3(CCLB_NT), CCLB_LDS_BYTES, t, c, ctx->d_ctr, ctx->d_row_cnt, ctx->d_row_off, ctx->d_tmp_runs,
+            hipLaunchKernelGGL(k_ccl_band, dim3((f1 - f0) * n_bands), dim3(CCLB_NT), CCLB_LDS_BYTES, t, c, ctx->d_ctr, ctx->d_row_cnt, ctx->d_row_off, ctx->d_row_base, ctx->d_tmp_runs,
                                ctx->d_raster, ctx->d_parent, ctx->d_band_fail, n_bands, band_rows, f0);
 #define TH_CCL(NT_, NMAX_, SA_, RETRY_) hipLaunchKernelGGL((k_ccl_lds<NT_, NMAX_, SA_>), dim3(f1 - f0), dim3(NT_), (CclLds<NMAX_, SA_>::BYTES), t, c, ctx->d_ctr, ctx->d_row_cnt, ctx->d_row_off, ctx->d_row_base, \
                            ctx->d_tmp_runs, ctx->d_raster, ctx->d_parent, ctx->d_root_ord, ctx->d_cur_run, ctx->d_pix_begin, ctx->d_blob_map,                           \
