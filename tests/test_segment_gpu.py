@@ -485,3 +485,28 @@ def test_heavy_frames_are_banded_from_the_second_call_on_and_stay_the_same():
     assert sig[0] == sig[1] == sig[2]
     assert_frame_equal(res[0], fr[0], bg)
     seg.close()
+
+
+@pytest.mark.parametrize("W", [2080, 3072, 4096])
+@pytest.mark.parametrize("kw", [dict(), dict(absolute_difference=0), dict(zero_is_background=0), dict(absolute_difference=0, zero_is_background=0),
+                                dict(threshold_maximum=80), dict(image_invert=1, threshold=25)])
+def test_wide_frames_with_the_background_in_registers(W, kw):
+    """k_rows32b<2> (round 6): frames of 2049 .. 4096 pixels per row, several frames per wave with the background row in registers -- every compile-time
+    threshold mode and the generic one, widths that end inside the second chunk, lines across the chunk border at x = 2047 / 2048, batches whose
+    frame count has the divisors 8, 3 and 2 (frames per wave)"""
+    rng = np.random.default_rng(W + len(kw))
+    H = 24
+    bg = rng.integers(60, 200, (H, W)).astype(np.uint8)
+    for n in (8, 3, 2):
+        frames = []
+        for i in range(n):
+            fr = np.clip(bg.astype(int) + rng.integers(-12, 12, (H, W)), 0, 255).astype(np.uint8)
+            m = rng.random((H, W)) < 0.01
+            fr[m] = np.where(rng.random(m.sum()) < 0.5, 0, 255)
+            fr[i % H, 2040:2060] = 0                      # a line across the chunk border
+            fr[(i + 5) % H, W - 9:W] = 255                # ... and one that ends with the row
+            fr[(i + 9) % H, 2047] = 0; fr[(i + 11) % H, 2048] = 0
+            frames.append(fr)
+        res = run_gpu(np.stack(frames), bg, **kw)
+        for r, fr in zip(res, frames):
+            assert_frame_equal(r, fr, bg, **kw)
