@@ -908,7 +908,7 @@ __device__ __forceinline__ void gather_blobs(const SegCfg& c, const int only_pen
 // flatten.  Roots are the smallest raster index of a component either way (lds_union), so every table comes out byte for byte the same.
 // A band with more lines than fit (CCLB_NMAX) raises the frame's word in `band_fail`: k_ccl_lds then labels that frame alone, as before.
 // ---------------------------------------------------------------------------------------------
-static constexpr int CCLB_NT = 512, CCLB_NMAX = 4096, CCLB_ROWS = 2048;
+static constexpr int CCLB_NT = 1024, CCLB_NMAX = 4096, CCLB_ROWS = 2048, CCLB_SW = CCLB_ROWS / CCLB_NT;
 static constexpr int CCLB_LDS_BYTES = (CCLB_ROWS + 1) * 4 + CCLB_NMAX * (4 + 4 + 2) + 64 * 4 + 16;
 __global__ __launch_bounds__(CCLB_NT) void k_ccl_band(const SegCfg c, const uint32_t* __restrict__ frame_ctr, const uint32_t* __restrict__ row_cnt,
                                                       const uint32_t* __restrict__ row_off, uint32_t* __restrict__ row_base, const uint32_t* __restrict__ tmp_runs,
@@ -928,9 +928,22 @@ __global__ __launch_bounds__(CCLB_NT) void k_ccl_band(const SegCfg c, const uint
     const uint32_t* off = row_off + (size_t)f * H;
     const uint32_t* tmp = tmp_runs + (size_t)f * c.T;
     const size_t fo = (size_t)f * c.R;
-    // lines in front of the band (its frame-wide raster base) and in the frame
+    // every load of the prologue goes out first: the band's own rows (count, run offset -- one or two per thread, kept in registers like the first
+    // sweeps of k_ccl_lds), the counts of all rows for the lines in front of the band and in the frame, the frame's overflow counter; then the first
+    // run of each own row.  One round trip + one for the first runs, where a loop per quantity paid one each
+    uint32_t pk[CCLB_SW], po[CCLB_SW], pt[CCLB_SW], pb[CCLB_SW];
+#pragma unroll
+    for (int j = 0; j < CCLB_SW; ++j) {
+        const int y = y0 + j * NT + tid;
+        pk[j] = y < y1 ? cnt[y] : 0u;
+        po[j] = y < y1 ? off[y] : 0u;
+        pt[j] = 0u; pb[j] = 0u;
+    }
+    const uint32_t fctr = frame_ctr[f * CTR_STRIDE];
     uint32_t sb = 0, sn = 0;
     for (int y = tid; y < H; y += NT) { const uint32_t v = cnt[y]; sn += v; if (y < y0) sb += v; }
+#pragma unroll
+    for (int j = 0; j < CCLB_SW; ++j) if (pk[j] && po[j] < (uint32_t)c.T) pt[j] = tmp[po[j]];
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) { sb += (uint32_t)__shfl_xor((int)sb, d); sn += (uint32_t)__shfl_xor((int)sn, d); }
     if ((tid & 63) == 0) { s_misc[32 + (tid >> 6)] = sb; s_misc[48 + (tid >> 6)] = sn; }
@@ -940,25 +953,29 @@ __global__ __launch_bounds__(CCLB_NT) void k_ccl_band(const SegCfg c, const uint
     for (int w = 0; w < NT / 64; ++w) { base += s_misc[32 + w]; n += s_misc[48 + w]; }
     // what k_ccl_lds refuses (overflow of the run area, more lines than LDS holds) it refuses by itself: nothing to prepare, and no table to write into.
     // Bit 1 of the frame's word tells it that nothing was prepared (it then scans the rows itself and finds the same)
-    if (n > (uint32_t)c.R || frame_ctr[f * CTR_STRIDE] > (uint32_t)c.R || n > (uint32_t)CCL_NMAX) { if (tid == 0) atomicOr(band_fail + f, 2u); return; }
+    if (n > (uint32_t)c.R || fctr > (uint32_t)c.R || n > (uint32_t)CCL_NMAX) { if (tid == 0) atomicOr(band_fail + f, 2u); return; }
     uint32_t* rb = row_base + (size_t)f * (H + 1);
     uint32_t nb = 0;
-    for (int ys = y0; ys < y1; ys += NT) {
-        const int y = ys + tid;
-        const uint32_t v = y < y1 ? cnt[y] : 0u;
+#pragma unroll
+    for (int j = 0; j < CCLB_SW; ++j) {
+        if (y0 + j * NT >= y1) break;
+        const int y = y0 + j * NT + tid;
         uint32_t total;
-        const uint32_t ex = block_excl_scan(v, s_misc, total);
+        const uint32_t ex = block_excl_scan(pk[j], s_misc, total);
+        pb[j] = nb + ex;
         if (y < y1) { s_key[y - y0] = nb + ex; rb[y] = base + nb + ex; }      // the frame-wide raster index of the row: k_ccl_lds takes it from here instead of scanning again
         nb += total;
     }
     if (tid == 0) { s_key[y1 - y0] = nb; if (y1 == H) rb[H] = n; }
     if (nb > (uint32_t)CCLB_NMAX) { if (tid == 0) atomicOr(band_fail + f, 1u); return; }
-    __syncthreads();
-    for (int y = y0 + tid; y < y1; y += NT) {
-        const uint32_t b = s_key[y - y0], k = s_key[y - y0 + 1] - b;
+    // the band's lines into LDS
+#pragma unroll
+    for (int j = 0; j < CCLB_SW; ++j) {
+        const uint32_t k = pk[j], b = pb[j], o = po[j];
+        const int y = y0 + j * NT + tid;
         if (!k) continue;
-        const uint32_t o = off[y];
-        for (uint32_t i = 0; i < k; ++i) { s_run[b + i] = tmp[o + i]; s_y[b + i] = (uint16_t)y; s_par[b + i] = b + i; }
+        s_run[b] = pt[j]; s_y[b] = (uint16_t)y; s_par[b] = b;
+        for (uint32_t i = 1; i < k; ++i) { s_run[b + i] = tmp[o + i]; s_y[b + i] = (uint16_t)y; s_par[b + i] = b + i; }
     }
     __syncthreads();
     const int slack = c.slack;
