@@ -1878,7 +1878,7 @@ static int net_forward_launch(trexhip_ctx* ctx, const uint8_t* d_crops, int n, f
 #define F12R(D_) TH_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv12_rs<D_>), hipFuncAttributeMaxDynamicSharedMemorySize, W12RGeom::LDS_BYTES))
         F12R(0);
 #ifdef TREXHIP_DEV_KNOBS
-        F12R(8); F12R(16); F12R(32); F12R(40); F12R(64); F12R(128);
+        F12R(1); F12R(2); F12R(4); F12R(6); F12R(8); F12R(16); F12R(32); F12R(40); F12R(64); F12R(128);
 #define F12RV(...) TH_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv12_rs<__VA_ARGS__>), hipFuncAttributeMaxDynamicSharedMemorySize, W12RGeom::LDS_BYTES))
         F12RV(0, 3, 20, 0x202, 0, 0, 0); F12RV(128, 3, 20, 0x202, 0, 0, 0);      // ORD 0: kernel-row-major taps, the whole output transform behind them
 #undef F12RV
@@ -1965,7 +1965,7 @@ static int net_forward_launch(trexhip_ctx* ctx, const uint8_t* d_crops, int n, f
                            net->w2w, net->b2, net->v3, net->inv2w, net->d_ovf, n, net->d_ovf + 2, pk, net->d_ovfc)
 #ifdef TREXHIP_DEV_KNOBS
         static const int f12r_dbg = std::getenv("TREXHIP_F12_DBG") ? std::atoi(std::getenv("TREXHIP_F12_DBG")) : 0;
-        switch (f12r_dbg) { case 8: F12RK(8); break; case 16: F12RK(16); break; case 32: F12RK(32); break; case 40: F12RK(40); break; case 64: F12RK(64); break;
+        switch (f12r_dbg) { case 1: F12RK(1); break; case 2: F12RK(2); break; case 4: F12RK(4); break; case 6: F12RK(6); break; case 8: F12RK(8); break; case 16: F12RK(16); break; case 32: F12RK(32); break; case 40: F12RK(40); break; case 64: F12RK(64); break;
             case 128: hipLaunchKernelGGL((k_conv12_rs<128>), dim3(want < wgs ? want : wgs), dim3(512), W12RGeom::LDS_BYTES, s, d_crops, net->w1h, net->b1, net->inv1h, net->w2w, net->b2, net->v3, net->inv2w, net->d_ovf, n, net->d_ovf + 2, pk, net->d_ovfc, reinterpret_cast<unsigned long long*>(ctx->d_cnt_px)); break;
 #define F12RKV(...) hipLaunchKernelGGL((k_conv12_rs<__VA_ARGS__>), dim3(want < wgs ? want : wgs), dim3(512), W12RGeom::LDS_BYTES, s, d_crops, net->w1h, net->b1, net->inv1h, net->w2w, net->b2, net->v3, net->inv2w, net->d_ovf, n, net->d_ovf + 2, pk, net->d_ovfc)
             case 230: F12RKV(0, 3, 20, 0x202, 0, 0, 0); break;
